@@ -1,0 +1,132 @@
+/*
+ * xgcm_hip.h -- C ABI of libxgcm_hip.so: MI355X (gfx950) kernels for the xgcm staggered-grid
+ * 1-D stencil hot path (Grid.diff / interp / min / max / cumsum / derivative / integrate).
+ *
+ * Every array argument is a DEVICE pointer to a C-contiguous float64 array described by
+ * (shape[ndim], axis); the caller owns all buffers; kernels never write their inputs; `out`
+ * must not alias an input.  All calls are asynchronous on `stream` (a hipStream_t passed as
+ * void*, NULL = the null stream), re-entrant and thread-safe.  Return value: 0 on success,
+ * a negative xg_status otherwise (message via xg_last_error, thread-local).  Semantic
+ * validation that the reference expresses as Python exceptions (missing boundary condition,
+ * unknown position pair ...) stays in the host layer so messages match the reference.
+ *
+ * "Metric" arguments are optional (NULL = absent) float64 arrays addressed through
+ * per-dimension ELEMENT strides given in the coordinate system of the array they weight
+ * (0 = broadcast along that dim), exactly the broadcasting xarray performs for `da * metric`.
+ *
+ * Reference interfaces replaced (paths relative to the xgcm source tree):
+ *   xg_stencil1d_f64   xgcm/grid_ufunc.py:885-904 (pad-then-apply) + xgcm/padding.py:575-616
+ *                      (_pad_basic) + xgcm/gridops.py:23-215 (diff/interp/min/max bodies)
+ *                      + xgcm/grid.py:804-808,830-832 (metric_weighted) + :1576-1578 (derivative)
+ *   xg_cumsum1d_f64    xgcm/grid.py:1295-1414 (Grid.cumsum per-axis body) and the 8 cumsum
+ *                      grid ufuncs xgcm/gridops.py:221-278
+ *   xg_reduce1d_f64    xgcm/grid.py:1598-1605 (Grid.integrate: (da*weight).sum(dim))
+ *   xg_pad_f64         xgcm/padding.py:765-871 (pad) for user grid-ufuncs of any width
+ *   xg_binary_f64      the xarray broadcasting `*`, `/`, `+`, `-` around the ops
+ *                      (xgcm/grid.py:808,832,1578,1600; get_metric products :614-617)
+ *   xg_vorticity_f64   the chained (diff(v,X) - diff(u,Y)) / area of docs/ufunc_examples.md
+ *                      (one fused pass instead of three apply_ufunc passes, grid.py:798-800 TODO)
+ */
+#ifndef XGCM_HIP_H
+#define XGCM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XG_ABI_VERSION 1
+#define XG_MAX_NDIM 8
+
+typedef enum xg_status {
+  XG_OK = 0,
+  XG_ERR_INVALID = -1,     /* bad argument (shape/axis/widths inconsistent, NULL pointer ...) */
+  XG_ERR_UNSUPPORTED = -2, /* valid request this build cannot serve (ndim > XG_MAX_NDIM ...)  */
+  XG_ERR_HIP = -3          /* HIP runtime error; text in xg_last_error                        */
+} xg_status;
+
+/* raw two-point bodies, xgcm/gridops.py:23-24,76-77,123-126,172-175 */
+typedef enum xg_op { XG_OP_DIFF = 0, XG_OP_INTERP = 1, XG_OP_MIN = 2, XG_OP_MAX = 3 } xg_op;
+
+/* boundary modes, xgcm/padding.py:15-19.  XG_BC_NONE is only legal when no halo cell is read. */
+typedef enum xg_bc { XG_BC_NONE = 0, XG_BC_PERIODIC = 1, XG_BC_FILL = 2, XG_BC_EXTEND = 3 } xg_bc;
+
+typedef enum xg_binop { XG_BIN_MUL = 0, XG_BIN_DIV = 1, XG_BIN_ADD = 2, XG_BIN_SUB = 3 } xg_binop;
+
+/* ---- library / device management ------------------------------------------------------ */
+int xg_version(void);
+/* copies the calling thread's last error text (NUL-terminated) into buf; returns its length */
+int xg_last_error(char* buf, int n);
+int xg_device_count(void);
+int xg_set_device(int device);
+int xg_malloc(void** ptr, uint64_t bytes);
+int xg_free(void* ptr);
+int xg_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void* stream);
+int xg_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void* stream);
+int xg_stream_sync(void* stream);
+/* hipEvent helpers so hosts without a HIP binding can time kernels on `stream` */
+int xg_event_create(void** ev);
+int xg_event_record(void* ev, void* stream);
+int xg_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int xg_event_destroy(void* ev);
+
+/* ---- fused pad + two-point stencil along one axis -------------------------------------- */
+/* out[.., i, ..] = OP(P[i], P[i+1]) / m_out,  P = pad(in * m_in, (pad_lo, pad_hi), bc, fill)
+ * along `axis`;  pad_lo, pad_hi in {0,1};  n_out must equal shape[axis] + pad_lo + pad_hi - 1.
+ * `out` has `shape` with shape[axis] replaced by n_out.  m_in_strides are per-dim strides in
+ * the INPUT coordinate system, m_out_strides in the OUTPUT coordinate system.
+ * The fill halo is NOT multiplied by m_in (the reference pads after the product). */
+int xg_stencil1d_f64(int op, const double* in, double* out, const int64_t* shape, int ndim,
+                     int axis, int64_t n_out, int pad_lo, int pad_hi, int bc, double fill,
+                     const double* m_in, const int64_t* m_in_strides, const double* m_out,
+                     const int64_t* m_out_strides, void* stream);
+
+/* ---- prefix sum along one axis with the reference's trim/pad folded in ------------------ */
+/* c = inclusive cumsum of (in * m_in) along axis (from the high end if `reverse`; NaN counted
+ * as 0 if `skipna`);  t = c[trim_lo : n - trim_hi];  out = pad(t, (pad_lo, pad_hi), bc, fill)
+ * / m_out.  Output length along axis: n - trim_lo - trim_hi + pad_lo + pad_hi.
+ * trim_*, pad_* in {0,1}.  The pad acts on the CUMULATIVE values (xgcm/grid.py:1385-1391). */
+int xg_cumsum1d_f64(const double* in, double* out, const int64_t* shape, int ndim, int axis,
+                    int reverse, int skipna, int trim_lo, int trim_hi, int pad_lo, int pad_hi,
+                    int bc, double fill, const double* m_in, const int64_t* m_in_strides,
+                    const double* m_out, const int64_t* m_out_strides, void* stream);
+
+/* ---- weighted sum along one axis -------------------------------------------------------- */
+/* out = sum_k (in * w)[.., k, ..] with `axis` removed from the output shape; NaN products
+ * count as 0 if `skipna`.  Along a non-last axis the sum runs sequentially k = 0..n-1 per
+ * output cell (bit-identical to numpy); along the last axis it is a lane-strided tree. */
+int xg_reduce1d_f64(const double* in, double* out, const int64_t* shape, int ndim, int axis,
+                    int skipna, const double* w, const int64_t* w_strides, void* stream);
+
+/* ---- generic N-D pad (any widths), axes applied in `order` like the reference's loop ---- */
+/* out shape[d] = shape[d] + lo[d] + hi[d].  order[ndim] lists axes in application order
+ * (NULL = 0..ndim-1); later-applied axes see the halos of earlier ones (numpy.pad chain). */
+int xg_pad_f64(const double* in, double* out, const int64_t* shape, int ndim, const int64_t* lo,
+               const int64_t* hi, const int* bc, const double* fill, const int* order,
+               void* stream);
+
+/* ---- broadcasting elementwise arithmetic ------------------------------------------------ */
+/* out[idx] = a[idx . a_strides] OP b[idx . b_strides] over `shape` (out C-contiguous). */
+int xg_binary_f64(int op, const double* a, const int64_t* a_strides, const double* b,
+                  const int64_t* b_strides, double* out, const int64_t* shape, int ndim,
+                  void* stream);
+
+/* ---- fused relative vorticity on a C-grid ---------------------------------------------- */
+/* out[..,j,i] = ((v[..,j,i] - v[..,j,i-1]) - (u[..,j,i] - u[..,j-1,i])) / area[..,j,i]
+ * for arrays of identical `shape` (.., Y, X), ndim >= 2; the i-1 / j-1 halos follow bc_x/bc_y
+ * (center->left diffs, padding_width (1,0)).  area (nullable) uses broadcast strides. */
+int xg_vorticity_f64(const double* u, const double* v, const double* area,
+                     const int64_t* area_strides, double* out, const int64_t* shape, int ndim,
+                     int bc_x, double fill_x, int bc_y, double fill_y, void* stream);
+
+/* ---- synthetic fields, bit-identical to oracle/refimpl.py:synthetic --------------------- */
+/* out[i] = u * scale + shift,  u = (splitmix64_mix(i + offset + seed*0x9E3779B97F4A7C15) >> 11)
+ * * 2^-53,  i = 0..n-1. */
+int xg_fill_synthetic_f64(double* out, int64_t n, uint64_t seed, uint64_t offset, double scale,
+                          double shift, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XGCM_HIP_H */

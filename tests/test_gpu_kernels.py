@@ -1,0 +1,238 @@
+"""GPU parity tests proper: every C-ABI compute entry point vs the CPU oracle on the same seeded
+inputs.  Bit-exact (np.array_equal, NaN == NaN) wherever the summation order is defined;
+1e-12 relative only for the contiguous-axis scan/reduce (re-associated sums)."""
+
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle import refimpl as R
+
+pytestmark = pytest.mark.gpu
+
+PADS = [(1, 0), (0, 1), (1, 1), (0, 0)]
+BCS = ["periodic", "fill", "extend"]
+OPS = ["diff", "interp", "min", "max"]
+# shapes chosen to hit: vector path (even inner), scalar path (odd inner), 1-D, 4-D, tiny axes
+SHAPES = [(6, 10, 128), (3, 7, 33), (2, 5, 4, 258), (257,), (4, 2), (3, 130), (5, 1, 66)]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from xgcm_amd import device
+
+    return device
+
+
+def _eq(a, b):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.array_equal(a, b, equal_nan=True), f"max abs diff {np.nanmax(np.abs(a - b))}"
+
+
+def _field(shape, seed, nan=False):
+    a = R.synthetic_field(shape, seed)
+    if nan and a.size > 3:
+        a.reshape(-1)[[1, a.size // 2, a.size - 1]] = np.nan
+    return a
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("op", OPS)
+def test_stencil_all_axes_pads_bcs(dev, shape, op):
+    a = _field(shape, 11, nan=op in ("min", "max"))
+    for axis in range(len(shape)):
+        for (lo, hi), bc in itertools.product(PADS, BCS):
+            if shape[axis] + lo + hi - 1 < 1:
+                continue
+            exp = R.stencil1d(op, a, axis, lo, hi, bc, 1.25)
+            got = dev.tohost(dev.stencil1d(op, a, axis, lo, hi, bc, 1.25))
+            _eq(got, exp)
+
+
+def test_stencil_no_halo_needs_no_bc(dev):
+    a = _field((4, 9, 20), 3)
+    for axis in range(3):
+        _eq(dev.tohost(dev.stencil1d("diff", a, axis, 0, 0, None)), R.stencil1d("diff", a, axis, 0, 0, None))
+
+
+def _metric_for(shape, keep_dims, seed):
+    """metric broadcasting over all dims except `keep_dims` (full extent there)."""
+    mshape = [s if d in keep_dims else 1 for d, s in enumerate(shape)]
+    return R.synthetic_metric(mshape, seed)
+
+
+@pytest.mark.parametrize("shape", [(5, 6, 64), (3, 7, 33), (2, 3, 4, 130)])
+@pytest.mark.parametrize("op", ["diff", "interp"])
+def test_stencil_metric_weighted_bitwise(dev, shape, op):
+    """metric_weighted == (x*m_in) -> op -> / m_out bitwise (reference test_metrics_ops.py:59-64)."""
+    nd = len(shape)
+    a = _field(shape, 5)
+    for axis in range(nd):
+        for (lo, hi), bc in itertools.product([(1, 0), (0, 1), (1, 1), (0, 0)], BCS):
+            n_out = shape[axis] + lo + hi - 1
+            if n_out < 1:
+                continue
+            oshape = list(shape)
+            oshape[axis] = n_out
+            # a few broadcast patterns: horizontal 2-D metric, 1-D along axis, full N-D
+            patterns = [set(range(nd)), {axis}, {nd - 1, max(nd - 2, 0)}]
+            for keep in patterns:
+                m_in = _metric_for(shape, keep, 31)
+                m_out = _metric_for(oshape, keep, 32)
+                exp = R.stencil1d(op, a, axis, lo, hi, bc, 0.75, m_in=m_in, m_out=m_out)
+                got = dev.tohost(dev.stencil1d(op, a, axis, lo, hi, bc, 0.75, m_in=m_in, m_out=m_out))
+                _eq(got, exp)
+                # derivative: m_out only
+                exp = R.stencil1d(op, a, axis, lo, hi, bc, 0.75, m_out=m_out)
+                got = dev.tohost(dev.stencil1d(op, a, axis, lo, hi, bc, 0.75, m_out=m_out))
+                _eq(got, exp)
+
+
+@pytest.mark.parametrize("shape", [(6, 10, 128), (3, 7, 33), (2, 5, 4, 66), (300,), (3, 700)])
+def test_cumsum_all(dev, shape):
+    a = _field(shape, 7, nan=True)
+    nd = len(shape)
+    for axis in range(nd):
+        contiguous_axis = axis == nd - 1
+        for reverse, skipna in itertools.product([False, True], [True, False]):
+            for tl, th, pl, ph in [(0, 0, 0, 0), (0, 1, 1, 0), (0, 1, 0, 0), (0, 0, 1, 0), (1, 0, 0, 1), (1, 0, 0, 0),
+                                   (0, 0, 0, 1), (1, 1, 1, 1)]:
+                if shape[axis] - tl - th < 1:
+                    continue
+                for bc in BCS:
+                    exp = R.cumsum1d(a, axis, tl, th, pl, ph, bc, 0.5, reverse, skipna)
+                    got = dev.tohost(dev.cumsum1d(a, axis, tl, th, pl, ph, bc, 0.5, reverse, skipna))
+                    if contiguous_axis and shape[axis] > 1:
+                        assert got.shape == exp.shape
+                        np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-12, equal_nan=True)
+                    else:
+                        _eq(got, exp)
+
+
+def test_cumsum_metric(dev):
+    shape = (4, 9, 6, 34)
+    a = _field(shape, 9)
+    for axis in (1, 2, 3):
+        for reverse in (False, True):
+            tl, th, pl, ph = (0, 1, 1, 0) if not reverse else (1, 0, 0, 1)
+            oshape = list(shape)
+            m_in = _metric_for(shape, {axis}, 41)
+            m_out = _metric_for(oshape, {2, 3}, 42)
+            exp = R.cumsum1d(a, axis, tl, th, pl, ph, "fill", 0.0, reverse, True, m_in, m_out)
+            got = dev.tohost(dev.cumsum1d(a, axis, tl, th, pl, ph, "fill", 0.0, reverse, True, m_in, m_out))
+            if axis == 3:
+                np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
+            else:
+                _eq(got, exp)
+
+
+@pytest.mark.parametrize("shape", [(6, 10, 128), (3, 7, 33), (2, 5, 4, 66), (300,), (75, 6, 10)])
+def test_reduce(dev, shape):
+    a = _field(shape, 13, nan=True)
+    nd = len(shape)
+    for axis in range(nd):
+        for skipna in (True, False):
+            for keep in (None, {axis}, set(range(nd))):
+                w = None if keep is None else _metric_for(shape, keep, 21)
+                exp = R.integrate(a, axis, w, skipna)
+                got = dev.tohost(dev.reduce1d(a, axis, w, skipna))
+                if axis == nd - 1:
+                    np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-13, equal_nan=True)
+                else:
+                    _eq(got, exp)
+
+
+def test_pad_matches_numpy_chain(dev):
+    a = _field((4, 5, 6), 17)
+    cases = [
+        ({2: (1, 1)}, {2: "periodic"}, {}),
+        ({1: (0, 1)}, {1: "extend"}, {}),
+        ({2: (0, 1), 1: (2, 0)}, {2: "periodic", 1: "fill"}, {1: np.nan}),
+        ({1: (2, 0), 2: (0, 1)}, {2: "fill", 1: "periodic"}, {2: 1.5}),
+        ({0: (7, 9), 2: (13, 3)}, {0: "periodic", 2: "extend"}, {}),
+        ({0: (1, 2), 1: (2, 1), 2: (3, 3)}, {0: "fill", 1: "extend", 2: "periodic"}, {0: -2.0}),
+    ]
+    for widths, bc, fill in cases:
+        exp = R.pad_nd(a, widths, bc, fill)
+        got = dev.tohost(dev.pad_nd(a, widths, bc, fill))
+        _eq(got, exp)
+
+
+def test_binary_broadcast(dev):
+    a = _field((3, 4, 6, 10), 19)
+    for op in ("mul", "div", "add", "sub"):
+        for bshape in [(3, 4, 6, 10), (1, 1, 6, 10), (1, 4, 1, 1), (3, 1, 1, 10), (1, 1, 1, 1), (1, 4, 6, 1)]:
+            b = R.synthetic_metric(bshape, 23)
+            _eq(dev.tohost(dev.binary(op, a, b)), R.binary(op, a, b))
+            _eq(dev.tohost(dev.binary(op, b, a)), R.binary(op, b, a))
+    a = _field((5, 7), 2)
+    b = _field((5, 7), 3)
+    _eq(dev.tohost(dev.binary("sub", a, b)), a - b)
+
+
+@pytest.mark.parametrize("shape", [(3, 9, 64), (2, 70, 33), (5, 6), (2, 2, 130, 258)])
+def test_vorticity_fused_equals_unfused_chain(dev, shape):
+    u = _field(shape, 51)
+    v = _field(shape, 52)
+    area2d = R.synthetic_metric((1,) * (len(shape) - 2) + shape[-2:], 53)
+    for bc_x, bc_y in itertools.product(BCS, BCS):
+        exp = R.vorticity(u, v, area2d, bc_x, bc_y, 0.25, -0.5)
+        got = dev.tohost(dev.vorticity(u, v, area2d, bc_x, bc_y, 0.25, -0.5))
+        _eq(got, exp)
+    # unfused chain through the individual kernels gives the same bits
+    dv = dev.stencil1d("diff", v, len(shape) - 1, 1, 0, "fill", 0.0)
+    du = dev.stencil1d("diff", u, len(shape) - 2, 1, 0, "fill", 0.0)
+    chain = dev.binary("div", dev.binary("sub", dv, du), area2d)
+    _eq(dev.tohost(chain), R.vorticity(u, v, area2d, "fill", "fill"))
+
+
+def test_synthetic_bit_identical(dev):
+    for n, seed, off in [(1000, 1, 0), (4097, 4, 123456789), (10, 53, 2**40)]:
+        got = dev.tohost(dev.synthetic((n,), seed, off))
+        _eq(got, R.synthetic(n, seed, off))
+    got = dev.tohost(dev.synthetic((33, 5), 31, 0, 1000.0, 1000.0))
+    _eq(got, R.synthetic_metric((33, 5), 31))
+
+
+def test_c_abi_rejects_bad_arguments(dev):
+    from xgcm_amd import _hip
+
+    a = dev.asdevice(_field((4, 8), 1))
+    with pytest.raises(_hip.XgcmHipError, match="no boundary mode"):
+        dev.stencil1d("diff", a, 1, 1, 0, None)
+    with pytest.raises(_hip.XgcmHipError):
+        dev.cumsum1d(_field((4, 1), 1), 1, 1, 0, 0, 0, "fill")
+
+
+def test_library_device_helpers_roundtrip():
+    """xg_malloc / h2d / kernel / d2h / events without torch: the path a non-torch host would use."""
+    import ctypes as C
+
+    from xgcm_amd import _hip
+
+    lib = _hip.load()
+    assert lib.xg_device_count() >= 1
+    a = R.synthetic_field((16, 128), 2)
+    nbytes = a.nbytes
+    din, dout = C.c_void_p(), C.c_void_p()
+    _hip.check(lib.xg_malloc(C.byref(din), nbytes))
+    _hip.check(lib.xg_malloc(C.byref(dout), nbytes))
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    _hip.check(lib.xg_event_create(C.byref(e0)))
+    _hip.check(lib.xg_event_create(C.byref(e1)))
+    _hip.check(lib.xg_memcpy_h2d(din, a.ctypes.data, nbytes, None))
+    _hip.check(lib.xg_event_record(e0, None))
+    _hip.check(lib.xg_stencil1d_f64(0, din, dout, _hip.i64(a.shape), 2, 1, 128, 1, 0, 1, 0.0, None, None, None, None, None))
+    _hip.check(lib.xg_event_record(e1, None))
+    out = np.empty_like(a)
+    _hip.check(lib.xg_memcpy_d2h(out.ctypes.data, dout, nbytes, None))
+    _hip.check(lib.xg_stream_sync(None))
+    ms = C.c_float()
+    _hip.check(lib.xg_event_elapsed_ms(e0, e1, C.byref(ms)))
+    assert ms.value >= 0
+    _eq(out, R.stencil1d("diff", a, 1, 1, 0, "periodic"))
+    for h in (din, dout):
+        _hip.check(lib.xg_free(h))
+    for e in (e0, e1):
+        _hip.check(lib.xg_event_destroy(e))

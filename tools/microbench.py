@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Kernel-level timing on one GPU (tuning aid, not the judged bench).
+
+    python tools/microbench.py [--shape 75,2400,3600] [--reps 10] [--cases stencil,cumsum,...]
+
+Prints one JSON line per case: median ms, Gcell/s, algorithmic GB/s and fraction of 8 TB/s.
+Tunables are read by the library from the environment once per process (XG_SEG, XG_NT_STORE,
+XG_NT_LOAD), so sweep them by running this script several times.
+"""
+
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+from xgcm_amd import device as D  # noqa: E402
+
+
+def timeit(fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="75,2400,3600")
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--cases", default="copy,stencil,metric,cumsum,reduce,vort")
+    args = ap.parse_args()
+    shape = tuple(int(s) for s in args.shape.split(","))
+    cases = set(args.cases.split(","))
+    nz, ny, nx = shape
+    cells = nz * ny * nx
+    tag = {k: os.environ.get(k) for k in ("XG_SEG", "XG_NT_STORE", "XG_NT_LOAD") if os.environ.get(k)}
+
+    T = D.synthetic(shape, 2)
+    out = []
+
+    def rec(name, ms, best, bytes_per_cell, ncell=cells):
+        gbs = ncell * bytes_per_cell / (ms * 1e-3) / 1e9
+        row = {"case": name, "ms": round(ms, 4), "best_ms": round(best, 4), "gcell_s": round(ncell / ms / 1e6, 3),
+               "GBps": round(gbs, 1), "frac_8TBps": round(gbs / 8000, 4), **tag}
+        print(json.dumps(row), flush=True)
+        out.append(row)
+
+    if "copy" in cases:
+        dst = torch.empty_like(T)
+        ms, b = timeit(lambda: dst.copy_(T), args.reps)
+        rec("torch_copy(ref ceiling)", ms, b, 16)
+        del dst
+    if "stencil" in cases:
+        for op in ("diff", "interp"):
+            ms, b = timeit(lambda: D.stencil1d(op, T, 2, 1, 0, "periodic"), args.reps)
+            rec(f"{op}_X_periodic_c2l", ms, b, 16)
+            ms, b = timeit(lambda: D.stencil1d(op, T, 1, 1, 0, "extend"), args.reps)
+            rec(f"{op}_Y_extend_c2l", ms, b, 16)
+        ms, b = timeit(lambda: D.stencil1d("diff", T, 0, 1, 0, "fill"), args.reps)
+        rec("diff_Z_fill_c2l", ms, b, 16)
+        ms, b = timeit(lambda: D.stencil1d("diff", T, 2, 1, 1, "extend"), args.reps)
+        rec("diff_X_extend_c2outer(scalar path)", ms, b, 16)
+    if "metric" in cases:
+        dx = D.synthetic((1, ny, nx), 31, 0, 1000.0, 1000.0)
+        dz = D.synthetic((nz, 1, 1), 33, 0, 1000.0, 1000.0)
+        ms, b = timeit(lambda: D.stencil1d("diff", T, 2, 1, 0, "periodic", m_out=dx), args.reps)
+        rec("derivative_X(dx 2D)", ms, b, 16 + 8 / nz)
+        ms, b = timeit(lambda: D.stencil1d("diff", T, 1, 1, 0, "extend", m_out=dx), args.reps)
+        rec("derivative_Y(dy 2D)", ms, b, 16 + 8 / nz)
+        ms, b = timeit(lambda: D.stencil1d("diff", T, 0, 1, 0, "fill", m_out=dz), args.reps)
+        rec("derivative_Z(dz 1D)", ms, b, 16)
+        ms, b = timeit(lambda: D.stencil1d("interp", T, 2, 1, 0, "periodic", m_in=dx, m_out=dx), args.reps)
+        rec("interp_X_metric_weighted", ms, b, 16 + 16 / nz)
+    if "cumsum" in cases:
+        ms, b = timeit(lambda: D.cumsum1d(T, 0, 0, 1, 1, 0, "fill"), args.reps)
+        rec("cumsum_Z_c2l_fill", ms, b, 16)
+        ms, b = timeit(lambda: D.cumsum1d(T, 1, 0, 1, 1, 0, "fill"), args.reps)
+        rec("cumsum_Y_c2l_fill", ms, b, 16)
+        ms, b = timeit(lambda: D.cumsum1d(T, 2, 0, 1, 1, 0, "fill"), args.reps)
+        rec("cumsum_X_c2l_fill(block scan)", ms, b, 16)
+    if "reduce" in cases:
+        dz = D.synthetic((nz, 1, 1), 33, 0, 1000.0, 1000.0)
+        ms, b = timeit(lambda: D.reduce1d(T, 0, dz), args.reps)
+        rec("integrate_Z(drF 1D)", ms, b, 8 + 8 / nz)
+        ms, b = timeit(lambda: D.reduce1d(T, 1, None), args.reps)
+        rec("sum_Y", ms, b, 8)
+        ms, b = timeit(lambda: D.reduce1d(T, 2, None), args.reps)
+        rec("sum_X(wave per row)", ms, b, 8)
+    if "vort" in cases:
+        U = D.synthetic(shape, 51)
+        V = D.synthetic(shape, 52)
+        A = D.synthetic((1, ny, nx), 53, 0, 1000.0, 1000.0)
+        ms, b = timeit(lambda: D.vorticity(U, V, A, "fill", "fill"), args.reps)
+        rec("vorticity_fused", ms, b, 24 + 8 / nz)
+
+        def unfused():
+            dv = D.stencil1d("diff", V, 2, 1, 0, "fill")
+            du = D.stencil1d("diff", U, 1, 1, 0, "fill")
+            return D.binary("div", D.binary("sub", dv, du), A)
+
+        ms, b = timeit(unfused, max(3, args.reps // 2))
+        rec("vorticity_unfused(4 kernels; fused-equivalent bytes)", ms, b, 24 + 8 / nz)
+
+
+if __name__ == "__main__":
+    main()

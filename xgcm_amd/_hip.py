@@ -1,0 +1,118 @@
+"""ctypes binding of libxgcm_hip.so (the C ABI declared in include/xgcm_hip.h).
+
+The reference has no native layer; its FFI for this path would be exactly this table.  cffi is
+not available in the target image, so the stdlib `ctypes` is used.  There is deliberately NO
+fallback: if the shared library is missing the import of any compute entry point raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxgcm_hip.so")
+
+# enums of include/xgcm_hip.h
+OP = {"diff": 0, "interp": 1, "min": 2, "max": 3}
+BC = {None: 0, "periodic": 1, "fill": 2, "extend": 3}
+BINOP = {"mul": 0, "div": 1, "add": 2, "sub": 3}
+MAX_NDIM = 8
+
+_i64p = C.POINTER(C.c_int64)
+_intp = C.POINTER(C.c_int)
+_f64p = C.POINTER(C.c_double)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); the complete export list of include/xgcm_hip.h
+SIGNATURES = {
+    "xg_version": (C.c_int, []),
+    "xg_last_error": (C.c_int, [C.c_char_p, C.c_int]),
+    "xg_device_count": (C.c_int, []),
+    "xg_set_device": (C.c_int, [C.c_int]),
+    "xg_malloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
+    "xg_free": (C.c_int, [_vp]),
+    "xg_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "xg_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "xg_stream_sync": (C.c_int, [_vp]),
+    "xg_event_create": (C.c_int, [C.POINTER(_vp)]),
+    "xg_event_record": (C.c_int, [_vp, _vp]),
+    "xg_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "xg_event_destroy": (C.c_int, [_vp]),
+    "xg_stencil1d_f64": (
+        C.c_int,
+        [C.c_int, _vp, _vp, _i64p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double,
+         _vp, _i64p, _vp, _i64p, _vp],
+    ),
+    "xg_cumsum1d_f64": (
+        C.c_int,
+        [_vp, _vp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+         C.c_double, _vp, _i64p, _vp, _i64p, _vp],
+    ),
+    "xg_reduce1d_f64": (C.c_int, [_vp, _vp, _i64p, C.c_int, C.c_int, C.c_int, _vp, _i64p, _vp]),
+    "xg_pad_f64": (C.c_int, [_vp, _vp, _i64p, C.c_int, _i64p, _i64p, _intp, _f64p, _intp, _vp]),
+    "xg_binary_f64": (C.c_int, [C.c_int, _vp, _i64p, _vp, _i64p, _vp, _i64p, C.c_int, _vp]),
+    "xg_vorticity_f64": (
+        C.c_int,
+        [_vp, _vp, _vp, _i64p, _vp, _i64p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, _vp],
+    ),
+    "xg_fill_synthetic_f64": (C.c_int, [_vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_double, C.c_double, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class XgcmHipError(RuntimeError):
+    """A C-ABI call returned a negative status (message from xg_last_error)."""
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and type every export.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "xgcm_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.xg_version() != 1:
+        raise ImportError(f"libxgcm_hip.so ABI version {lib.xg_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().xg_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(status: int) -> None:
+    if status != 0:
+        raise XgcmHipError(f"xgcm_hip status {status}: {last_error()}")
+
+
+def i64(values: Optional[Sequence[int]]):
+    if values is None:
+        return None
+    return (C.c_int64 * len(values))(*[int(v) for v in values])
+
+
+def ints(values: Optional[Sequence[int]]):
+    if values is None:
+        return None
+    return (C.c_int * len(values))(*[int(v) for v in values])
+
+
+def f64s(values: Optional[Sequence[float]]):
+    if values is None:
+        return None
+    return (C.c_double * len(values))(*[float(v) for v in values])

@@ -1,0 +1,1219 @@
+// xgcm_hip.hip -- hand-written CDNA4 (gfx950) kernels + C ABI for the xgcm staggered-grid hot path.
+//
+// Design: every op is HBM-bound (<= 3 flop per 16 B), so the kernels are built
+// around three rules: (1) every cell is read once and written once -- the boundary halo
+// (periodic / fill / extend) is index arithmetic inside the kernel, never a padded copy;
+// (2) lanes always run along the contiguous (last) dimension with 16-byte accesses, whatever
+// the stencil axis is: along a strided axis each lane MARCHES and keeps the previous value in
+// registers; (3) the unit of scheduling is a 64-lane wave-task (outer index, segment, x-tile),
+// with several independent 16-byte loads in flight per lane before the first use.
+// No MFMA, no LDS tiling of the field (nothing is reused), LDS only for cross-wave scan carries.
+//
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off (bitwise parity with numpy forbids
+// FMA contraction of a*m - b*m and reciprocal-based division).
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/xgcm_hip.h"
+
+namespace {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int MAXD = 4;    // coalesced dims on either side of the op axis
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256; // 4 waves; each wave owns one wave-task
+constexpr int WPB = BLOCK / WAVE;
+
+// ------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------
+thread_local char g_err[512] = {0};
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define XG_HIP(call)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(XG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
+                  __FILE__, __LINE__);                                                   \
+  } while (0)
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+// tunables (read once; override with env vars for on-device tuning sessions)
+struct Tune {
+  int seg;       // rows marched per wave-task along a strided stencil axis
+  int nt_store;  // non-temporal stores
+  int nt_load;   // non-temporal loads
+  Tune() {
+    seg = env_int("XG_SEG", 64);
+    nt_store = env_int("XG_NT_STORE", 1);
+    nt_load = env_int("XG_NT_LOAD", 0);
+  }
+};
+const Tune& tune() {
+  static Tune t;
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// geometry: a C-contiguous N-D array seen as (outer..., n, inner...) around the op axis,
+// with adjacent dims coalesced whenever every metric's strides allow it.
+// ------------------------------------------------------------------------------------------
+struct MIdx {  // element strides of one metric in the coalesced coordinate system
+  int64_t outer[MAXD];
+  int64_t axis;
+  int64_t inner[MAXD];
+};
+
+struct Geo {
+  int n_outer, n_inner;
+  int64_t outer_shape[MAXD];
+  int64_t inner_shape[MAXD];
+  int64_t outer;  // prod(outer_shape)
+  int64_t inner;  // prod(inner_shape)
+  int64_t n_in, n_out;
+};
+
+// Build Geo (+ up to two MIdx) from the public (shape, ndim, axis, strides) description.
+// strides arrays may be NULL (metric absent).  Size-1 dims are dropped, mergeable neighbours
+// merged.  Returns 0 or an error.
+int build_geo(const int64_t* shape, int ndim, int axis, int64_t n_out, const int64_t* s1,
+              const int64_t* s2, Geo* g, MIdx* m1, MIdx* m2) {
+  if (ndim < 1 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [1,%d]", ndim, XG_MAX_NDIM);
+  if (axis < 0 || axis >= ndim) return fail(XG_ERR_INVALID, "axis %d out of range for ndim %d", axis, ndim);
+  for (int d = 0; d < ndim; ++d)
+    if (shape[d] < 0) return fail(XG_ERR_INVALID, "negative extent");
+  memset(g, 0, sizeof(*g));
+  if (m1) memset(m1, 0, sizeof(*m1));
+  if (m2) memset(m2, 0, sizeof(*m2));
+  g->n_in = shape[axis];
+  g->n_out = n_out;
+  g->outer = 1;
+  g->inner = 1;
+  if (s1 && m1) m1->axis = s1[axis];
+  if (s2 && m2) m2->axis = s2[axis];
+
+  auto group = [&](int lo, int hi, int64_t* gshape, int64_t* st1, int64_t* st2, int* count,
+                   int64_t* prod) -> int {
+    int n = 0;
+    for (int d = lo; d < hi; ++d) {
+      if (shape[d] == 1) continue;
+      int64_t a = s1 ? s1[d] : 0, b = s2 ? s2[d] : 0;
+      if (n > 0) {
+        // previous (slower) dim merges with this one iff stride_prev == stride_this * extent_this
+        bool ok = (st1[n - 1] == a * shape[d]) && (st2[n - 1] == b * shape[d]);
+        if (ok) {
+          gshape[n - 1] *= shape[d];
+          st1[n - 1] = a;
+          st2[n - 1] = b;
+          continue;
+        }
+      }
+      if (n == MAXD) return fail(XG_ERR_UNSUPPORTED, "more than %d non-coalescable dims on one side of the axis", MAXD);
+      gshape[n] = shape[d];
+      st1[n] = a;
+      st2[n] = b;
+      ++n;
+    }
+    *count = n;
+    *prod = 1;
+    for (int i = 0; i < n; ++i) *prod *= gshape[i];
+    for (int d = lo; d < hi; ++d)
+      if (shape[d] == 0) *prod = 0;
+    return 0;
+  };
+  int64_t o1[MAXD] = {0}, o2[MAXD] = {0}, i1[MAXD] = {0}, i2[MAXD] = {0};
+  int rc = group(0, axis, g->outer_shape, o1, o2, &g->n_outer, &g->outer);
+  if (rc) return rc;
+  rc = group(axis + 1, ndim, g->inner_shape, i1, i2, &g->n_inner, &g->inner);
+  if (rc) return rc;
+  for (int i = 0; i < MAXD; ++i) {
+    if (m1) { m1->outer[i] = o1[i]; m1->inner[i] = i1[i]; }
+    if (m2) { m2->outer[i] = o2[i]; m2->inner[i] = i2[i]; }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+template <int V> struct VecT;
+template <> struct VecT<1> { typedef double type; };
+template <> struct VecT<2> { typedef d2 type; };
+
+template <typename T, bool NT>
+__device__ __forceinline__ T ldg(const double* p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const T*>(p));
+  return *reinterpret_cast<const T*>(p);
+}
+template <typename T, bool NT>
+__device__ __forceinline__ void stg(double* p, T v) {
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
+  else *reinterpret_cast<T*>(p) = v;
+}
+
+// x-difference of a V-wide lane given the value just left of it
+__device__ __forceinline__ d2 dvdx_of(d2 vc, double vl) { d2 o; o.x = vc.x - vl; o.y = vc.y - vc.x; return o; }
+__device__ __forceinline__ double dvdx_of(double vc, double vl) { return vc - vl; }
+
+// two-point bodies; l = a[..., i], r = a[..., i+1] of the padded array (gridops.py:23-24,76-77,123-175)
+template <int OP>
+__device__ __forceinline__ double op2(double l, double r) {
+  if (OP == XG_OP_DIFF) return r - l;
+  if (OP == XG_OP_INTERP) return (l + r) * 0.5;  // == (l + r) / 2.0 bit for bit
+  if (OP == XG_OP_MIN) return (l < r || l != l) ? l : r;  // NaN-propagating like np.min
+  return (l > r || l != l) ? l : r;
+}
+template <int OP> __device__ __forceinline__ d2 op2(d2 l, d2 r) {
+  d2 o; o.x = op2<OP>(l.x, r.x); o.y = op2<OP>(l.y, r.y); return o;
+}
+
+__device__ __forceinline__ double splat1(double f, double*) { return f; }
+__device__ __forceinline__ d2 splat1(double f, d2*) { d2 o; o.x = f; o.y = f; return o; }
+template <typename T> __device__ __forceinline__ T splat(double f) { return splat1(f, (T*)nullptr); }
+
+// offset of flat outer index `o` in a metric (unrolled so Geo/MIdx stay in SGPRs)
+__device__ __forceinline__ int64_t outer_off(const Geo& g, const MIdx& m, int64_t o) {
+  int64_t off = 0;
+#pragma unroll
+  for (int d = MAXD - 1; d >= 0; --d) {
+    if (d < g.n_outer) {
+      int64_t s = g.outer_shape[d];
+      int64_t q = o / s;
+      off += (o - q * s) * m.outer[d];
+      o = q;
+    }
+  }
+  return off;
+}
+__device__ __forceinline__ int64_t inner_off(const Geo& g, const MIdx& m, int64_t x) {
+  int64_t off = 0;
+#pragma unroll
+  for (int d = MAXD - 1; d >= 0; --d) {
+    if (d < g.n_inner) {
+      int64_t s = g.inner_shape[d];
+      int64_t q = x / s;
+      off += (x - q * s) * m.inner[d];
+      x = q;
+    }
+  }
+  return off;
+}
+
+// metric value(s) for a V-wide lane at metric offset `off` (second element `step` further on)
+template <typename T> __device__ __forceinline__ T ldm(const double* m, int64_t off, int64_t step);
+template <> __device__ __forceinline__ double ldm<double>(const double* m, int64_t off, int64_t) { return m[off]; }
+template <> __device__ __forceinline__ d2 ldm<d2>(const double* m, int64_t off, int64_t step) {
+  d2 o; o.x = m[off]; o.y = m[off + step]; return o;
+}
+
+__device__ __forceinline__ u64 wave_id() {
+  // uniform per wave; readfirstlane keeps the task decomposition on the scalar unit
+  u32 w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  return (u64)blockIdx.x * WPB + w;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: stencil along a STRIDED axis.  View (outer, n, inner); lane <-> V consecutive elements of
+// `inner`; wave-task = (o, segment of `seg` output rows, x-tile of 64*V elements).  Each lane
+// marches along the axis holding the previous (metric-weighted) value in registers: exactly
+// one 16-B load and one 16-B store per lane per row (+1 halo row per segment).
+// MET bit0: m_out present, bit1: m_in present.
+// ------------------------------------------------------------------------------------------
+template <int OP, int V, int MET, bool NTL, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_stencil_strided(
+    const double* __restrict__ in, double* __restrict__ out, Geo g, int seg, u32 nseg, u32 ntile,
+    int pad_lo, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
+    const double* __restrict__ m_out, MIdx mo) {
+  typedef typename VecT<V>::type T;
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  constexpr int U = 8;
+
+  const u64 w = wave_id();
+  const u32 tile = (u32)(w % ntile);
+  const u64 r = w / ntile;
+  const u32 sg = (u32)(r % nseg);
+  const int64_t o = (int64_t)(r / nseg);
+  if (o >= g.outer) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t x = ((int64_t)tile * WAVE + lane) * V;
+  if (x >= g.inner) return;
+
+  const int64_t j0 = (int64_t)sg * seg;
+  const int64_t j1 = (j0 + seg < g.n_out) ? j0 + seg : g.n_out;
+  const int64_t inner = g.inner;
+  const double* pin = in + (o * g.n_in) * inner + x;
+  double* pout = out + (o * g.n_out) * inner + x;
+
+  int64_t mi_base = 0, mo_base = 0, mi_step = 0, mo_step = 0;
+  if (HAS_MI) {
+    mi_base = outer_off(g, mi, o) + inner_off(g, mi, x);
+    mi_step = (V == 2) ? inner_off(g, mi, x + 1) - inner_off(g, mi, x) : 0;
+  }
+  if (HAS_MO) {
+    mo_base = outer_off(g, mo, o) + inner_off(g, mo, x);
+    mo_step = (V == 2) ? inner_off(g, mo, x + 1) - inner_off(g, mo, x) : 0;
+  }
+
+  // P(k): value of the padded, metric-weighted input at padded index k (q = k - pad_lo)
+  auto loadq = [&](int64_t q) -> T {
+    T v = ldg<T, NTL>(pin + q * inner);
+    if (HAS_MI) v = v * ldm<T>(m_in, mi_base + q * mi.axis, mi_step);
+    return v;
+  };
+  auto loadP = [&](int64_t k) -> T {
+    int64_t q = k - pad_lo;
+    if (q < 0) {
+      if (bc == XG_BC_FILL) return splat<T>(fill);
+      q = (bc == XG_BC_PERIODIC) ? g.n_in - 1 : 0;
+    } else if (q >= g.n_in) {
+      if (bc == XG_BC_FILL) return splat<T>(fill);
+      q = (bc == XG_BC_PERIODIC) ? 0 : g.n_in - 1;
+    }
+    return loadq(q);
+  };
+  auto emit = [&](int64_t j, T l, T rr) {
+    T res = op2<OP>(l, rr);
+    if (HAS_MO) res = res / ldm<T>(m_out, mo_base + j * mo.axis, mo_step);
+    stg<T, NTS>(pout + j * inner, res);
+  };
+
+  T prev = loadP(j0);
+  int64_t k = j0 + 1;
+  // interior: q = k - pad_lo in [0, n_in) guaranteed for k <= kend
+  const int64_t kend = (j1 < g.n_in - 1 + pad_lo) ? j1 : g.n_in - 1 + pad_lo;
+  for (; k + (U - 1) <= kend; k += U) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ldg<T, NTL>(pin + (k + u - pad_lo) * inner);
+    if (HAS_MI) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = v[u] * ldm<T>(m_in, mi_base + (k + u - pad_lo) * mi.axis, mi_step);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      emit(k + u - 1, prev, v[u]);
+      prev = v[u];
+    }
+  }
+  for (; k <= kend; ++k) {
+    T cur = loadq(k - pad_lo);
+    emit(k - 1, prev, cur);
+    prev = cur;
+  }
+  for (; k <= j1; ++k) {  // at most one step: the high halo
+    T cur = loadP(k);
+    emit(k - 1, prev, cur);
+    prev = cur;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: stencil along the CONTIGUOUS (last) axis.  View (rows, L).  wave-task = (group of R rows,
+// x-tile); lane <-> V consecutive outputs.  V == 2 needs L_in == L_out even (pads (1,0)/(0,1)):
+// one aligned 16-B load + one 8-B neighbour load (same cache lines, L1-served) per lane per row.
+// V == 1 is the general path (any pads, odd lengths, N+1 / N-1 outputs).
+// ------------------------------------------------------------------------------------------
+template <int OP, int V, int MET, bool NTL, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_stencil_contig(
+    const double* __restrict__ in, double* __restrict__ out, Geo g, u32 ntile, int pad_lo,
+    int pad_hi, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
+    const double* __restrict__ m_out, MIdx mo) {
+  typedef typename VecT<V>::type T;
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  constexpr int R = 8;
+
+  const u64 w = wave_id();
+  const u32 tile = (u32)(w % ntile);
+  const int64_t r0 = (int64_t)(w / ntile) * R;
+  if (r0 >= g.outer) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t i0 = ((int64_t)tile * WAVE + lane) * V;
+  const int64_t Li = g.n_in, Lo = g.n_out;
+  if (i0 >= Lo) return;
+  const int nrow = (g.outer - r0 < R) ? (int)(g.outer - r0) : R;
+
+  if (V == 2) {
+    // neighbour index inside the row and whether it is a halo cell
+    int64_t nidx;
+    bool edge;
+    if (pad_lo) { edge = (i0 == 0); nidx = edge ? ((bc == XG_BC_PERIODIC) ? Li - 1 : 0) : i0 - 1; }
+    else { edge = (i0 + 2 == Li); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : Li - 1) : i0 + 2; }
+    const bool fill_edge = edge && (bc == XG_BC_FILL);
+    d2 pr[R];
+    double nb[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (u < nrow) {
+        const double* prow = in + (r0 + u) * Li;
+        pr[u] = ldg<d2, NTL>(prow + i0);
+        nb[u] = prow[nidx];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (u < nrow) {
+        d2 a = pr[u];
+        double n = nb[u];
+        if (HAS_MI) {
+          int64_t mb = outer_off(g, mi, r0 + u);
+          a.x = a.x * m_in[mb + i0 * mi.axis];
+          a.y = a.y * m_in[mb + (i0 + 1) * mi.axis];
+          n = n * m_in[mb + nidx * mi.axis];
+        }
+        if (fill_edge) n = fill;
+        d2 res;
+        if (pad_lo) { res.x = op2<OP>(n, a.x); res.y = op2<OP>(a.x, a.y); }
+        else { res.x = op2<OP>(a.x, a.y); res.y = op2<OP>(a.y, n); }
+        if (HAS_MO) {
+          int64_t mb = outer_off(g, mo, r0 + u);
+          res.x = res.x / m_out[mb + i0 * mo.axis];
+          res.y = res.y / m_out[mb + (i0 + 1) * mo.axis];
+        }
+        stg<d2, NTS>(out + (r0 + u) * Lo + i0, res);
+      }
+    }
+  } else {
+    // general scalar path: out[i] = OP(P(i), P(i+1)), q = k - pad_lo
+    int64_t ql = i0 - pad_lo, qr = i0 + 1 - pad_lo;
+    bool fl = false, fr = false;
+    if (ql < 0) { fl = (bc == XG_BC_FILL); ql = (bc == XG_BC_PERIODIC) ? Li - 1 : 0; }
+    if (qr >= Li) { fr = (bc == XG_BC_FILL); qr = (bc == XG_BC_PERIODIC) ? 0 : Li - 1; }
+    double lv[R], rv[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (u < nrow) {
+        const double* prow = in + (r0 + u) * Li;
+        lv[u] = prow[ql];
+        rv[u] = prow[qr];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      if (u < nrow) {
+        double l = lv[u], rr = rv[u];
+        if (HAS_MI) {
+          int64_t mb = outer_off(g, mi, r0 + u);
+          l = l * m_in[mb + ql * mi.axis];
+          rr = rr * m_in[mb + qr * mi.axis];
+        }
+        if (fl) l = fill;
+        if (fr) rr = fill;
+        double res = op2<OP>(l, rr);
+        if (HAS_MO) res = res / m_out[outer_off(g, mo, r0 + u) + i0 * mo.axis];
+        stg<double, NTS>(out + (r0 + u) * Lo + i0, res);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: cumsum along a STRIDED axis (one lane = one column pair, sequential => bit-exact with
+// numpy.cumsum / nancumsum), trim/pad table folded into the output index, halo cells written
+// from registers at the end of the march.
+// ------------------------------------------------------------------------------------------
+struct ScanArgs {
+  int reverse, skipna, trim_lo, trim_hi, pad_lo, pad_hi, bc;
+  double fill;
+};
+
+__device__ __forceinline__ double nan0(double v) { return (v != v) ? 0.0 : v; }
+__device__ __forceinline__ d2 nan0(d2 v) { d2 o; o.x = nan0(v.x); o.y = nan0(v.y); return o; }
+
+template <int V, int MET, bool NTL, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
+    const double* __restrict__ in, double* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
+    const double* __restrict__ m_in, MIdx mi, const double* __restrict__ m_out, MIdx mo) {
+  typedef typename VecT<V>::type T;
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  constexpr int U = 5;
+
+  const u64 w = wave_id();
+  const u32 tile = (u32)(w % ntile);
+  const int64_t o = (int64_t)(w / ntile);
+  if (o >= g.outer) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t x = ((int64_t)tile * WAVE + lane) * V;
+  if (x >= g.inner) return;
+  const int64_t inner = g.inner, n = g.n_in;
+  const double* pin = in + (o * n) * inner + x;
+  double* pout = out + (o * g.n_out) * inner + x;
+
+  int64_t mi_base = 0, mo_base = 0, mi_step = 0, mo_step = 0;
+  if (HAS_MI) {
+    mi_base = outer_off(g, mi, o) + inner_off(g, mi, x);
+    mi_step = (V == 2) ? inner_off(g, mi, x + 1) - inner_off(g, mi, x) : 0;
+  }
+  if (HAS_MO) {
+    mo_base = outer_off(g, mo, o) + inner_off(g, mo, x);
+    mo_step = (V == 2) ? inner_off(g, mo, x + 1) - inner_off(g, mo, x) : 0;
+  }
+  auto put = [&](int64_t j, T v) {  // j = output index along the axis
+    if (HAS_MO) v = v / ldm<T>(m_out, mo_base + j * mo.axis, mo_step);
+    stg<T, NTS>(pout + j * inner, v);
+  };
+
+  const int64_t first_kept = a.trim_lo, last_kept = n - 1 - a.trim_hi;  // index space
+  const int64_t shift = a.pad_lo - a.trim_lo;
+  T acc = splat<T>(0.0), c_first = splat<T>(0.0), c_last = splat<T>(0.0);
+  bool started = false;
+  auto step = [&](int64_t idx, T v) {
+    if (HAS_MI) v = v * ldm<T>(m_in, mi_base + idx * mi.axis, mi_step);
+    if (a.skipna) v = nan0(v);
+    acc = started ? acc + v : v;
+    started = true;
+    if (idx == first_kept) c_first = acc;
+    if (idx == last_kept) c_last = acc;
+    if (idx >= first_kept && idx <= last_kept) put(idx + shift, acc);
+  };
+  int64_t t = 0;
+  for (; t + U <= n; t += U) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t idx = a.reverse ? n - 1 - (t + u) : t + u;
+      v[u] = ldg<T, NTL>(pin + idx * inner);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(a.reverse ? n - 1 - (t + u) : t + u, v[u]);
+  }
+  for (; t < n; ++t) {
+    int64_t idx = a.reverse ? n - 1 - t : t;
+    step(idx, ldg<T, NTL>(pin + idx * inner));
+  }
+  // halo cells of the padded cumulative result (xgcm/grid.py:1385-1391; numpy.pad semantics)
+  if (a.pad_lo) {
+    T h = (a.bc == XG_BC_FILL) ? splat<T>(a.fill) : (a.bc == XG_BC_PERIODIC ? c_last : c_first);
+    put(0, h);
+  }
+  if (a.pad_hi) {
+    T h = (a.bc == XG_BC_FILL) ? splat<T>(a.fill) : (a.bc == XG_BC_PERIODIC ? c_first : c_last);
+    put(g.n_out - 1, h);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: cumsum along the CONTIGUOUS axis: one workgroup per row, chunks of 256 elements in scan
+// order, wave-level Hillis-Steele scan with cross-lane shuffles, 4 wave totals through LDS,
+// running carry in a register.  Re-associated sum => tolerance parity (not bit-exact).
+// ------------------------------------------------------------------------------------------
+template <int MET>
+__global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
+    const double* __restrict__ in, double* __restrict__ out, Geo g, ScanArgs a,
+    const double* __restrict__ m_in, MIdx mi, const double* __restrict__ m_out, MIdx mo) {
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  __shared__ double wtot[2][WPB];
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t n = g.n_in;
+  const double* prow = in + row * n;
+  double* orow = out + row * g.n_out;
+  int64_t mi_base = 0, mo_base = 0;
+  if (HAS_MI) mi_base = outer_off(g, mi, row);
+  if (HAS_MO) mo_base = outer_off(g, mo, row);
+  const int64_t first_kept = a.trim_lo, last_kept = n - 1 - a.trim_hi;
+  const int64_t shift = a.pad_lo - a.trim_lo;
+  auto put = [&](int64_t j, double v) {
+    if (HAS_MO) v = v / m_out[mo_base + j * mo.axis];
+    orow[j] = v;
+  };
+  double carry = 0.0;
+  int buf = 0;
+  for (int64_t base = 0; base < n; base += BLOCK, buf ^= 1) {
+    const int64_t k = base + tid;
+    const int64_t idx = a.reverse ? n - 1 - k : k;
+    double v = 0.0;
+    if (k < n) {
+      v = prow[idx];
+      if (HAS_MI) v = v * m_in[mi_base + idx * mi.axis];
+      if (a.skipna) v = nan0(v);
+    }
+    double s = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      double t = __shfl_up(s, d, WAVE);
+      if (lane >= d) s += t;
+    }
+    if (lane == WAVE - 1) wtot[buf][wv] = s;
+    __syncthreads();
+    double woff = 0.0, tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < WPB; ++i) {
+      double t = wtot[buf][i];
+      if (i < wv) woff += t;
+      tot += t;
+    }
+    const double c = carry + (woff + s);
+    carry += tot;
+    if (k < n) {
+      if (idx >= first_kept && idx <= last_kept) put(idx + shift, c);
+      if (idx == first_kept) {
+        if (a.pad_lo && a.bc == XG_BC_EXTEND) put(0, c);
+        if (a.pad_hi && a.bc == XG_BC_PERIODIC) put(g.n_out - 1, c);
+      }
+      if (idx == last_kept) {
+        if (a.pad_lo && a.bc == XG_BC_PERIODIC) put(0, c);
+        if (a.pad_hi && a.bc == XG_BC_EXTEND) put(g.n_out - 1, c);
+      }
+    }
+  }
+  if (tid == 0 && a.bc == XG_BC_FILL) {
+    if (a.pad_lo) put(0, a.fill);
+    if (a.pad_hi) put(g.n_out - 1, a.fill);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: weighted sum along a STRIDED axis: one lane per output column pair, sequential in k
+// (bit-exact with numpy's reduction over a non-last axis).
+// ------------------------------------------------------------------------------------------
+template <int V, bool HAS_W, bool NTL>
+__global__ __launch_bounds__(BLOCK) void k_reduce_strided(
+    const double* __restrict__ in, double* __restrict__ out, Geo g, u32 ntile, int skipna,
+    const double* __restrict__ wgt, MIdx mw) {
+  typedef typename VecT<V>::type T;
+  constexpr int U = 5;
+  const u64 w = wave_id();
+  const u32 tile = (u32)(w % ntile);
+  const int64_t o = (int64_t)(w / ntile);
+  if (o >= g.outer) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t x = ((int64_t)tile * WAVE + lane) * V;
+  if (x >= g.inner) return;
+  const int64_t inner = g.inner, n = g.n_in;
+  const double* pin = in + (o * n) * inner + x;
+  int64_t mb = 0, ms = 0;
+  if (HAS_W) {
+    mb = outer_off(g, mw, o) + inner_off(g, mw, x);
+    ms = (V == 2) ? inner_off(g, mw, x + 1) - inner_off(g, mw, x) : 0;
+  }
+  T acc = splat<T>(0.0);
+  bool started = false;
+  auto step = [&](int64_t k, T v) {
+    if (HAS_W) v = v * ldm<T>(wgt, mb + k * mw.axis, ms);
+    if (skipna) v = nan0(v);
+    acc = started ? acc + v : v;
+    started = true;
+  };
+  int64_t k = 0;
+  for (; k + U <= n; k += U) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ldg<T, NTL>(pin + (k + u) * inner);
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(k + u, v[u]);
+  }
+  for (; k < n; ++k) step(k, ldg<T, NTL>(pin + k * inner));
+  *reinterpret_cast<T*>(out + o * inner + x) = acc;
+}
+
+// K4b: weighted sum along the CONTIGUOUS axis: one wave per row, lane-strided partial sums then
+// a shuffle tree (tolerance parity; numpy itself is pairwise here).
+template <bool HAS_W>
+__global__ __launch_bounds__(BLOCK) void k_reduce_contig(const double* __restrict__ in,
+                                                         double* __restrict__ out, Geo g, int skipna,
+                                                         const double* __restrict__ wgt, MIdx mw) {
+  const u64 row = wave_id();
+  if ((int64_t)row >= g.outer) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t n = g.n_in;
+  const double* prow = in + row * n;
+  int64_t mb = 0;
+  if (HAS_W) mb = outer_off(g, mw, row);
+  double acc = 0.0;
+  for (int64_t k = lane; k < n; k += WAVE) {
+    double v = prow[k];
+    if (HAS_W) v = v * wgt[mb + k * mw.axis];
+    if (skipna) v = nan0(v);
+    acc += v;
+  }
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d, WAVE);
+  if (lane == 0) out[row] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// generic N-D pad (user grid ufuncs with arbitrary widths; padding.py:765-871).  Steps are
+// stored in APPLICATION order; the kernel walks them backwards: a fill halo of a later-applied
+// axis wins over anything an earlier axis would have produced (numpy.pad chain semantics).
+// ------------------------------------------------------------------------------------------
+struct PadGeo {
+  int ndim;
+  int64_t total;
+  int64_t out_shape[XG_MAX_NDIM], out_stride[XG_MAX_NDIM];
+  int64_t in_shape[XG_MAX_NDIM], in_stride[XG_MAX_NDIM];
+  int64_t lo[XG_MAX_NDIM];
+  int bc[XG_MAX_NDIM];
+  double fill[XG_MAX_NDIM];
+};
+
+template <typename I>
+__global__ __launch_bounds__(BLOCK) void k_pad(const double* __restrict__ in, double* __restrict__ out, PadGeo p) {
+  const int64_t gid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (gid >= p.total) return;
+  const I idx = (I)gid;
+  int64_t src = 0;
+  bool filled = false;
+  double fv = 0.0;
+#pragma unroll
+  for (int t = XG_MAX_NDIM - 1; t >= 0; --t) {
+    if (t < p.ndim && !filled) {
+      I c = (idx / (I)p.out_stride[t]) % (I)p.out_shape[t];
+      int64_t q = (int64_t)c - p.lo[t];
+      const int64_t n = p.in_shape[t];
+      if (q < 0 || q >= n) {
+        if (p.bc[t] == XG_BC_FILL) { filled = true; fv = p.fill[t]; }
+        else if (p.bc[t] == XG_BC_PERIODIC) { q %= n; if (q < 0) q += n; }
+        else { q = (q < 0) ? 0 : n - 1; }
+      }
+      src += q * p.in_stride[t];
+    }
+  }
+  out[gid] = filled ? fv : in[src];
+}
+
+// ------------------------------------------------------------------------------------------
+// broadcasting binary op (out C-contiguous, a/b addressed through strides; dims pre-coalesced)
+// ------------------------------------------------------------------------------------------
+struct BinGeo {
+  int ndim;
+  int64_t total;  // number of V-wide items
+  int64_t shape[XG_MAX_NDIM];  // shape[ndim-1] counts V-wide items
+  int64_t sa[XG_MAX_NDIM], sb[XG_MAX_NDIM];
+};
+
+template <int BOP> __device__ __forceinline__ double bin2(double a, double b) {
+  if (BOP == XG_BIN_MUL) return a * b;
+  if (BOP == XG_BIN_DIV) return a / b;
+  if (BOP == XG_BIN_ADD) return a + b;
+  return a - b;
+}
+
+template <int BOP, int V, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_binary(const double* __restrict__ a, const double* __restrict__ b,
+                                                  double* __restrict__ out, BinGeo g) {
+  typedef typename VecT<V>::type T;
+  const int64_t gid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (gid >= g.total) return;
+  int64_t r = gid, oa = 0, ob = 0;
+#pragma unroll
+  for (int d = XG_MAX_NDIM - 1; d >= 0; --d) {
+    if (d < g.ndim) {
+      int64_t s = g.shape[d];
+      int64_t q = r / s;
+      int64_t c = r - q * s;
+      if (d == g.ndim - 1) c *= V;
+      oa += c * g.sa[d];
+      ob += c * g.sb[d];
+      r = q;
+    }
+  }
+  const int64_t sa_in = g.sa[g.ndim - 1], sb_in = g.sb[g.ndim - 1];
+  if (V == 2) {
+    d2 av, bv, o;
+    if (sa_in == 1) av = *reinterpret_cast<const d2*>(a + oa); else { av.x = a[oa]; av.y = a[oa + sa_in]; }
+    if (sb_in == 1) bv = *reinterpret_cast<const d2*>(b + ob); else { bv.x = b[ob]; bv.y = b[ob + sb_in]; }
+    o.x = bin2<BOP>(av.x, bv.x);
+    o.y = bin2<BOP>(av.y, bv.y);
+    stg<d2, NTS>(out + gid * 2, o);
+  } else {
+    stg<double, NTS>(out + gid, bin2<BOP>(a[oa], b[ob]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7: fused relative vorticity ((v[j,i]-v[j,i-1]) - (u[j,i]-u[j-1,i])) / area, view (outer,Y,X).
+// Lanes along X (V=2 when nx even), march along Y keeping u[j-1] in registers.
+// ------------------------------------------------------------------------------------------
+template <int V, bool HAS_AREA, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_vorticity(
+    const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ area,
+    double* __restrict__ out, int64_t outer, int64_t ny, int64_t nx, int seg, u32 nseg, u32 ntile,
+    int bc_x, double fill_x, int bc_y, double fill_y, int64_t a_so, int64_t a_sy, int64_t a_sx) {
+  typedef typename VecT<V>::type T;
+  constexpr int U = 4;
+  const u64 w = wave_id();
+  const u32 tile = (u32)(w % ntile);
+  const u64 r = w / ntile;
+  const u32 sg = (u32)(r % nseg);
+  const int64_t o = (int64_t)(r / nseg);
+  if (o >= outer) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t i0 = ((int64_t)tile * WAVE + lane) * V;
+  if (i0 >= nx) return;
+  const int64_t j0 = (int64_t)sg * seg;
+  const int64_t j1 = (j0 + seg < ny) ? j0 + seg : ny;
+  const double* pu = u + o * ny * nx + i0;
+  const double* pv = v + o * ny * nx;
+  double* po = out + o * ny * nx + i0;
+  const bool edge = (i0 == 0);
+  const int64_t nidx = edge ? ((bc_x == XG_BC_PERIODIC) ? nx - 1 : 0) : i0 - 1;
+  const bool fill_edge = edge && (bc_x == XG_BC_FILL);
+
+  T uprev;
+  if (j0 == 0) {
+    if (bc_y == XG_BC_FILL) uprev = splat<T>(fill_y);
+    else uprev = *reinterpret_cast<const T*>(pu + ((bc_y == XG_BC_PERIODIC) ? ny - 1 : 0) * nx);
+  } else {
+    uprev = *reinterpret_cast<const T*>(pu + (j0 - 1) * nx);
+  }
+  auto body = [&](int64_t j, T uc, T vc, double vl) {
+    if (fill_edge) vl = fill_x;
+    T dvdx = dvdx_of(vc, vl), dudy, z;
+    dudy = uc - uprev;
+    z = dvdx - dudy;
+    if (HAS_AREA) z = z / ldm<T>(area, o * a_so + j * a_sy + i0 * a_sx, a_sx);
+    stg<T, NTS>(po + j * nx, z);
+    uprev = uc;
+  };
+  int64_t j = j0;
+  for (; j + U <= j1; j += U) {
+    T uc[U], vc[U];
+    double vl[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      uc[q] = *reinterpret_cast<const T*>(pu + (j + q) * nx);
+      vc[q] = *reinterpret_cast<const T*>(pv + (j + q) * nx + i0);
+      vl[q] = pv[(j + q) * nx + nidx];
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) body(j + q, uc[q], vc[q], vl[q]);
+  }
+  for (; j < j1; ++j)
+    body(j, *reinterpret_cast<const T*>(pu + j * nx), *reinterpret_cast<const T*>(pv + j * nx + i0), pv[j * nx + nidx]);
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic fields (splitmix64 finaliser), bit-identical to oracle/refimpl.py:synthetic
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_fill_synthetic(double* __restrict__ out, int64_t n, u64 seed, u64 offset,
+                                                          double scale, double shift) {
+  const int64_t stride = (int64_t)gridDim.x * BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+    u64 z = (u64)i + offset + seed * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    double uu = (double)(z >> 11) * 0x1.0p-53;
+    out[i] = uu * scale + shift;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int check_grid(u64 nblocks) {
+  if (nblocks == 0 || nblocks > 0x7fffffffull) return fail(XG_ERR_UNSUPPORTED, "launch of %llu blocks exceeds grid limits", nblocks);
+  return 0;
+}
+
+#define XG_LAUNCH_CHECK()                                                              \
+  do {                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                 \
+    if (e_ != hipSuccess) return fail(XG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e_)); \
+  } while (0)
+
+// dispatch on (OP, V, MET, NT) -> template instance
+template <int OP, int V, int MET>
+int launch_stencil_strided(u64 nblocks, hipStream_t st, const double* in, double* out, const Geo& g, int seg,
+                           u32 nseg, u32 ntile, int pad_lo, int bc, double fill, const double* m_in,
+                           const MIdx& mi, const double* m_out, const MIdx& mo) {
+  const bool ntl = tune().nt_load, nts = tune().nt_store;
+#define XG_GO(NTL, NTS)                                                                              \
+  hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, NTL, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, \
+                     out, g, seg, nseg, ntile, pad_lo, bc, fill, m_in, mi, m_out, mo)
+  if (ntl) { if (nts) XG_GO(true, true); else XG_GO(true, false); }
+  else { if (nts) XG_GO(false, true); else XG_GO(false, false); }
+#undef XG_GO
+  XG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int OP, int V, int MET>
+int launch_stencil_contig(u64 nblocks, hipStream_t st, const double* in, double* out, const Geo& g, u32 ntile,
+                          int pad_lo, int pad_hi, int bc, double fill, const double* m_in, const MIdx& mi,
+                          const double* m_out, const MIdx& mo) {
+  const bool ntl = tune().nt_load, nts = tune().nt_store;
+#define XG_GO(NTL, NTS)                                                                             \
+  hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, NTL, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, \
+                     out, g, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo)
+  if (ntl) { if (nts) XG_GO(true, true); else XG_GO(true, false); }
+  else { if (nts) XG_GO(false, true); else XG_GO(false, false); }
+#undef XG_GO
+  XG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int OP, int V>
+int stencil_met(bool contig, int met, u64 nblocks, hipStream_t st, const double* in, double* out, const Geo& g,
+                int seg, u32 nseg, u32 ntile, int pad_lo, int pad_hi, int bc, double fill, const double* m_in,
+                const MIdx& mi, const double* m_out, const MIdx& mo) {
+#define XG_M(M)                                                                                               \
+  return contig ? launch_stencil_contig<OP, V, M>(nblocks, st, in, out, g, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo) \
+                : launch_stencil_strided<OP, V, M>(nblocks, st, in, out, g, seg, nseg, ntile, pad_lo, bc, fill, m_in, mi, m_out, mo)
+  switch (met) {
+    case 0: XG_M(0);
+    case 1: XG_M(1);
+    case 2: XG_M(2);
+    default: XG_M(3);
+  }
+#undef XG_M
+}
+
+template <int OP>
+int stencil_vec(int V, bool contig, int met, u64 nblocks, hipStream_t st, const double* in, double* out,
+                const Geo& g, int seg, u32 nseg, u32 ntile, int pad_lo, int pad_hi, int bc, double fill,
+                const double* m_in, const MIdx& mi, const double* m_out, const MIdx& mo) {
+  if (V == 2) return stencil_met<OP, 2>(contig, met, nblocks, st, in, out, g, seg, nseg, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo);
+  return stencil_met<OP, 1>(contig, met, nblocks, st, in, out, g, seg, nseg, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo);
+}
+
+inline u32 ceil_div_u32(int64_t a, int64_t b) { return (u32)((a + b - 1) / b); }
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int xg_version(void) { return XG_ABI_VERSION; }
+
+int xg_last_error(char* buf, int n) {
+  int len = (int)strlen(g_err);
+  if (buf && n > 0) {
+    int c = len < n - 1 ? len : n - 1;
+    memcpy(buf, g_err, c);
+    buf[c] = 0;
+  }
+  return len;
+}
+
+int xg_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+int xg_set_device(int device) { XG_HIP(hipSetDevice(device)); return 0; }
+int xg_malloc(void** ptr, uint64_t bytes) { XG_HIP(hipMalloc(ptr, bytes)); return 0; }
+int xg_free(void* ptr) { XG_HIP(hipFree(ptr)); return 0; }
+int xg_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void* stream) {
+  XG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return 0;
+}
+int xg_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void* stream) {
+  XG_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+int xg_stream_sync(void* stream) { XG_HIP(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+int xg_event_create(void** ev) { XG_HIP(hipEventCreate((hipEvent_t*)ev)); return 0; }
+int xg_event_record(void* ev, void* stream) { XG_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return 0; }
+int xg_event_elapsed_ms(void* start, void* stop, float* ms) {
+  XG_HIP(hipEventSynchronize((hipEvent_t)stop));
+  XG_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return 0;
+}
+int xg_event_destroy(void* ev) { XG_HIP(hipEventDestroy((hipEvent_t)ev)); return 0; }
+
+int xg_stencil1d_f64(int op, const double* in, double* out, const int64_t* shape, int ndim, int axis,
+                     int64_t n_out, int pad_lo, int pad_hi, int bc, double fill, const double* m_in,
+                     const int64_t* m_in_strides, const double* m_out, const int64_t* m_out_strides,
+                     void* stream) {
+  if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
+  if ((pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "pad widths must be 0 or 1, got (%d,%d)", pad_lo, pad_hi);
+  if (bc < XG_BC_NONE || bc > XG_BC_EXTEND) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
+  if ((m_in && !m_in_strides) || (m_out && !m_out_strides)) return fail(XG_ERR_INVALID, "metric without strides");
+  Geo g; MIdx mi, mo;
+  int rc = build_geo(shape, ndim, axis, n_out, m_in ? m_in_strides : nullptr, m_out ? m_out_strides : nullptr, &g, &mi, &mo);
+  if (rc) return rc;
+  if (n_out != g.n_in + pad_lo + pad_hi - 1) return fail(XG_ERR_INVALID, "n_out %lld != n_in %lld + %d + %d - 1", (long long)n_out, (long long)g.n_in, pad_lo, pad_hi);
+  if ((pad_lo || pad_hi) && bc == XG_BC_NONE) return fail(XG_ERR_INVALID, "halo cells requested but no boundary mode given");
+  if (g.n_in < 1) return fail(XG_ERR_INVALID, "empty stencil axis");
+  if (g.outer == 0 || g.inner == 0 || n_out <= 0) return XG_OK;  // empty output
+  const int met = (m_out ? 1 : 0) | (m_in ? 2 : 0);
+  hipStream_t st = (hipStream_t)stream;
+  const bool al = aligned16(in) && aligned16(out);
+  if (g.inner == 1) {
+    // contiguous axis: rows = outer
+    const int V = (al && (g.n_in % 2 == 0) && (n_out % 2 == 0)) ? 2 : 1;
+    const u32 ntile = ceil_div_u32(n_out, (int64_t)WAVE * V);
+    const u64 ntask = (u64)ntile * (u64)((g.outer + 7) / 8);
+    const u64 nblocks = (ntask + WPB - 1) / WPB;
+    if ((rc = check_grid(nblocks))) return rc;
+#define XG_OPC(O) case O: return stencil_vec<O>(V, true, met, nblocks, st, in, out, g, 0, 1, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo)
+    switch (op) { XG_OPC(XG_OP_DIFF); XG_OPC(XG_OP_INTERP); XG_OPC(XG_OP_MIN); default: XG_OPC(XG_OP_MAX); }
+#undef XG_OPC
+  } else {
+    const int V = (al && (g.inner % 2 == 0)) ? 2 : 1;
+    int seg = tune().seg;
+    if (seg < 1) seg = 1;
+    const u32 nseg = ceil_div_u32(n_out, seg);
+    const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
+    const u64 ntask = (u64)ntile * nseg * (u64)g.outer;
+    const u64 nblocks = (ntask + WPB - 1) / WPB;
+    if ((rc = check_grid(nblocks))) return rc;
+#define XG_OPC(O) case O: return stencil_vec<O>(V, false, met, nblocks, st, in, out, g, seg, nseg, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo)
+    switch (op) { XG_OPC(XG_OP_DIFF); XG_OPC(XG_OP_INTERP); XG_OPC(XG_OP_MIN); default: XG_OPC(XG_OP_MAX); }
+#undef XG_OPC
+  }
+  return XG_OK;
+}
+
+int xg_cumsum1d_f64(const double* in, double* out, const int64_t* shape, int ndim, int axis, int reverse,
+                    int skipna, int trim_lo, int trim_hi, int pad_lo, int pad_hi, int bc, double fill,
+                    const double* m_in, const int64_t* m_in_strides, const double* m_out,
+                    const int64_t* m_out_strides, void* stream) {
+  if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if ((trim_lo | trim_hi | pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "trim/pad widths must be 0 or 1");
+  if (bc < XG_BC_NONE || bc > XG_BC_EXTEND) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
+  if ((pad_lo || pad_hi) && bc == XG_BC_NONE) return fail(XG_ERR_INVALID, "halo cells requested but no boundary mode given");
+  if ((m_in && !m_in_strides) || (m_out && !m_out_strides)) return fail(XG_ERR_INVALID, "metric without strides");
+  if (axis < 0 || axis >= ndim) return fail(XG_ERR_INVALID, "axis out of range");
+  const int64_t n = shape[axis];
+  const int64_t n_out = n - trim_lo - trim_hi + pad_lo + pad_hi;
+  if (n - trim_lo - trim_hi < 1) return fail(XG_ERR_INVALID, "nothing left after trimming (n=%lld)", (long long)n);
+  Geo g; MIdx mi, mo;
+  int rc = build_geo(shape, ndim, axis, n_out, m_in ? m_in_strides : nullptr, m_out ? m_out_strides : nullptr, &g, &mi, &mo);
+  if (rc) return rc;
+  if (g.outer == 0 || g.inner == 0) return XG_OK;
+  ScanArgs a = {reverse ? 1 : 0, skipna ? 1 : 0, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill};
+  const int met = (m_out ? 1 : 0) | (m_in ? 2 : 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (g.inner == 1) {
+    const u64 nblocks = (u64)g.outer;
+    if ((rc = check_grid(nblocks))) return rc;
+#define XG_M(M) hipLaunchKernelGGL((k_cumsum_contig<M>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, a, m_in, mi, m_out, mo)
+    switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
+#undef XG_M
+  } else {
+    const int V = (aligned16(in) && aligned16(out) && (g.inner % 2 == 0)) ? 2 : 1;
+    const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
+    const u64 ntask = (u64)ntile * (u64)g.outer;
+    const u64 nblocks = (ntask + WPB - 1) / WPB;
+    if ((rc = check_grid(nblocks))) return rc;
+    const bool nts = tune().nt_store;
+#define XG_GO(V_, M, NTS) hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, ntile, a, m_in, mi, m_out, mo)
+#define XG_M(V_, M) do { if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
+#define XG_V(V_) switch (met) { case 0: XG_M(V_, 0); break; case 1: XG_M(V_, 1); break; case 2: XG_M(V_, 2); break; default: XG_M(V_, 3); }
+    if (V == 2) { XG_V(2) } else { XG_V(1) }
+#undef XG_V
+#undef XG_M
+#undef XG_GO
+  }
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int xg_reduce1d_f64(const double* in, double* out, const int64_t* shape, int ndim, int axis, int skipna,
+                    const double* w, const int64_t* w_strides, void* stream) {
+  if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (w && !w_strides) return fail(XG_ERR_INVALID, "weight without strides");
+  Geo g; MIdx mw;
+  int rc = build_geo(shape, ndim, axis, 1, w ? w_strides : nullptr, nullptr, &g, &mw, nullptr);
+  if (rc) return rc;
+  if (g.outer == 0 || g.inner == 0) return XG_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (g.n_in == 0) { XG_HIP(hipMemsetAsync(out, 0, sizeof(double) * g.outer * g.inner, st)); return XG_OK; }
+  if (g.inner == 1) {
+    const u64 nblocks = ((u64)g.outer + WPB - 1) / WPB;
+    if ((rc = check_grid(nblocks))) return rc;
+    if (w) hipLaunchKernelGGL((k_reduce_contig<true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+    else hipLaunchKernelGGL((k_reduce_contig<false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+  } else {
+    const int V = (aligned16(in) && aligned16(out) && (g.inner % 2 == 0)) ? 2 : 1;
+    const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
+    const u64 ntask = (u64)ntile * (u64)g.outer;
+    const u64 nblocks = (ntask + WPB - 1) / WPB;
+    if ((rc = check_grid(nblocks))) return rc;
+#define XG_GO(V_, W_) hipLaunchKernelGGL((k_reduce_strided<V_, W_, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, ntile, skipna, w, mw)
+    if (V == 2) { if (w) XG_GO(2, true); else XG_GO(2, false); }
+    else { if (w) XG_GO(1, true); else XG_GO(1, false); }
+#undef XG_GO
+  }
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int xg_pad_f64(const double* in, double* out, const int64_t* shape, int ndim, const int64_t* lo, const int64_t* hi,
+               const int* bc, const double* fill, const int* order, void* stream) {
+  if (!in || !out || !shape || !lo || !hi || !bc) return fail(XG_ERR_INVALID, "NULL argument");
+  if (ndim < 1 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [1,%d]", ndim, XG_MAX_NDIM);
+  PadGeo p;
+  memset(&p, 0, sizeof(p));
+  p.ndim = ndim;
+  int64_t ostride[XG_MAX_NDIM], istride[XG_MAX_NDIM], oshape[XG_MAX_NDIM];
+  bool seen[XG_MAX_NDIM] = {false};
+  int64_t total = 1, itotal = 1;
+  for (int d = ndim - 1; d >= 0; --d) {
+    if (lo[d] < 0 || hi[d] < 0) return fail(XG_ERR_INVALID, "negative pad width");
+    oshape[d] = shape[d] + lo[d] + hi[d];
+    ostride[d] = total;
+    istride[d] = itotal;
+    total *= oshape[d];
+    itotal *= shape[d];
+    if ((lo[d] || hi[d]) && (bc[d] < XG_BC_PERIODIC || bc[d] > XG_BC_EXTEND))
+      return fail(XG_ERR_INVALID, "axis %d is padded but has no boundary mode", d);
+    if ((lo[d] || hi[d]) && shape[d] == 0) return fail(XG_ERR_INVALID, "cannot pad an empty axis");
+  }
+  for (int t = 0; t < ndim; ++t) {
+    int d = order ? order[t] : t;
+    if (d < 0 || d >= ndim || seen[d]) return fail(XG_ERR_INVALID, "order is not a permutation");
+    seen[d] = true;
+    p.out_shape[t] = oshape[d];
+    p.out_stride[t] = ostride[d];
+    p.in_shape[t] = shape[d];
+    p.in_stride[t] = istride[d];
+    p.lo[t] = lo[d];
+    p.bc[t] = bc[d];
+    p.fill[t] = fill ? fill[d] : 0.0;
+  }
+  p.total = total;
+  if (total == 0) return XG_OK;
+  const u64 nblocks = ((u64)total + BLOCK - 1) / BLOCK;
+  int rc;
+  if ((rc = check_grid(nblocks))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (total < 0x7fffffffll) hipLaunchKernelGGL((k_pad<u32>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, p);
+  else hipLaunchKernelGGL((k_pad<u64>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, p);
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int xg_binary_f64(int op, const double* a, const int64_t* a_strides, const double* b, const int64_t* b_strides,
+                  double* out, const int64_t* shape, int ndim, void* stream) {
+  if (!a || !b || !out || (ndim > 0 && (!shape || !a_strides || !b_strides))) return fail(XG_ERR_INVALID, "NULL argument");
+  if (op < XG_BIN_MUL || op > XG_BIN_SUB) return fail(XG_ERR_INVALID, "unknown binary op %d", op);
+  if (ndim < 0 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [0,%d]", ndim, XG_MAX_NDIM);
+  BinGeo g;
+  memset(&g, 0, sizeof(g));
+  // drop size-1 dims, coalesce neighbours compatible for BOTH operands
+  int n = 0;
+  int64_t total = 1;
+  for (int d = 0; d < ndim; ++d) {
+    if (shape[d] < 0) return fail(XG_ERR_INVALID, "negative extent");
+    total *= shape[d];
+    if (shape[d] == 1) continue;
+    if (n > 0 && g.sa[n - 1] == a_strides[d] * shape[d] && g.sb[n - 1] == b_strides[d] * shape[d]) {
+      g.shape[n - 1] *= shape[d];
+      g.sa[n - 1] = a_strides[d];
+      g.sb[n - 1] = b_strides[d];
+    } else {
+      g.shape[n] = shape[d];
+      g.sa[n] = a_strides[d];
+      g.sb[n] = b_strides[d];
+      ++n;
+    }
+  }
+  if (total == 0) return XG_OK;
+  if (n == 0) { g.shape[0] = 1; g.sa[0] = 0; g.sb[0] = 0; n = 1; }
+  g.ndim = n;
+  const int64_t last = g.shape[n - 1];
+  const int64_t sa = g.sa[n - 1], sb = g.sb[n - 1];
+  bool v2 = (last % 2 == 0) && aligned16(out) && (sa == 0 || sa == 1) && (sb == 0 || sb == 1);
+  if (v2 && sa == 1) {
+    if (!aligned16(a)) v2 = false;
+    for (int d = 0; d < n - 1; ++d) if (g.sa[d] % 2) v2 = false;
+  }
+  if (v2 && sb == 1) {
+    if (!aligned16(b)) v2 = false;
+    for (int d = 0; d < n - 1; ++d) if (g.sb[d] % 2) v2 = false;
+  }
+  const int V = v2 ? 2 : 1;
+  g.shape[n - 1] = last / V;
+  g.total = total / V;
+  const u64 nblocks = ((u64)g.total + BLOCK - 1) / BLOCK;
+  int rc;
+  if ((rc = check_grid(nblocks))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const bool nts = tune().nt_store;
+#define XG_GO(O, V_, NTS) hipLaunchKernelGGL((k_binary<O, V_, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, a, b, out, g)
+#define XG_O(O) do { if (V == 2) { if (nts) XG_GO(O, 2, true); else XG_GO(O, 2, false); } else { if (nts) XG_GO(O, 1, true); else XG_GO(O, 1, false); } } while (0)
+  switch (op) { case XG_BIN_MUL: XG_O(XG_BIN_MUL); break; case XG_BIN_DIV: XG_O(XG_BIN_DIV); break; case XG_BIN_ADD: XG_O(XG_BIN_ADD); break; default: XG_O(XG_BIN_SUB); }
+#undef XG_O
+#undef XG_GO
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int xg_vorticity_f64(const double* u, const double* v, const double* area, const int64_t* area_strides, double* out,
+                     const int64_t* shape, int ndim, int bc_x, double fill_x, int bc_y, double fill_y, void* stream) {
+  if (!u || !v || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
+  if (area && !area_strides) return fail(XG_ERR_INVALID, "area without strides");
+  if (bc_x < XG_BC_PERIODIC || bc_x > XG_BC_EXTEND || bc_y < XG_BC_PERIODIC || bc_y > XG_BC_EXTEND)
+    return fail(XG_ERR_INVALID, "vorticity needs a boundary mode on both axes");
+  const int64_t ny = shape[ndim - 2], nx = shape[ndim - 1];
+  int64_t outer = 1;
+  for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
+  if (outer == 0 || ny == 0 || nx == 0) return XG_OK;
+  // area may broadcast over the leading dims only uniformly: accept "all zero" or "contiguous"
+  int64_t a_so = 0, a_sy = 0, a_sx = 0;
+  if (area) {
+    a_sy = area_strides[ndim - 2];
+    a_sx = area_strides[ndim - 1];
+    bool all_zero = true, contig = true;
+    int64_t expect = ny * nx;
+    for (int d = ndim - 3; d >= 0; --d) {
+      if (shape[d] == 1) continue;
+      if (area_strides[d] != 0) all_zero = false;
+      if (area_strides[d] != expect) contig = false;
+      expect *= shape[d];
+    }
+    if (all_zero) a_so = 0;
+    else if (contig && a_sy == nx && a_sx == 1) a_so = ny * nx;
+    else return fail(XG_ERR_UNSUPPORTED, "area must be (Y,X)-shaped or fully materialised");
+  }
+  const int V = (aligned16(u) && aligned16(v) && aligned16(out) && nx % 2 == 0) ? 2 : 1;
+  int seg = tune().seg;
+  if (seg < 1) seg = 1;
+  const u32 nseg = ceil_div_u32(ny, seg);
+  const u32 ntile = ceil_div_u32(nx, (int64_t)WAVE * V);
+  const u64 ntask = (u64)ntile * nseg * (u64)outer;
+  const u64 nblocks = (ntask + WPB - 1) / WPB;
+  int rc;
+  if ((rc = check_grid(nblocks))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const bool nts = tune().nt_store;
+#define XG_GO(V_, A_, NTS) hipLaunchKernelGGL((k_vorticity<V_, A_, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, u, v, area, out, outer, ny, nx, seg, nseg, ntile, bc_x, fill_x, bc_y, fill_y, a_so, a_sy, a_sx)
+#define XG_A(V_, A_) do { if (nts) XG_GO(V_, A_, true); else XG_GO(V_, A_, false); } while (0)
+  if (V == 2) { if (area) XG_A(2, true); else XG_A(2, false); }
+  else { if (area) XG_A(1, true); else XG_A(1, false); }
+#undef XG_A
+#undef XG_GO
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int xg_fill_synthetic_f64(double* out, int64_t n, uint64_t seed, uint64_t offset, double scale, double shift, void* stream) {
+  if (!out && n > 0) return fail(XG_ERR_INVALID, "NULL output");
+  if (n <= 0) return XG_OK;
+  u64 nblocks = ((u64)n + BLOCK - 1) / BLOCK;
+  if (nblocks > 256ull * 32) nblocks = 256ull * 32;  // grid-stride above 8192 blocks
+  hipLaunchKernelGGL(k_fill_synthetic, dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, out, n, (u64)seed, (u64)offset, scale, shift);
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+}  // extern "C"

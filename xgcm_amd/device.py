@@ -1,0 +1,237 @@
+"""Unlabelled-array layer: HBM-resident float64 arrays in, HBM-resident arrays out.
+
+Each function is one C-ABI call (include/xgcm_hip.h).  PyTorch is used only as plumbing: it owns
+the device allocations (`torch.empty`), and its current HIP stream is the stream the kernels are
+enqueued on, so `torch.cuda.Event`, `torch.distributed` and user torch code order correctly
+against them.  No arithmetic is delegated to torch and there is no CPU path: without a GPU or
+without the built library every function raises.
+
+Metric arguments (`m_in`, `m_out`, `w`, `area`) are tensors with the same number of dims as
+the array they weight, each dim either full-size or 1 (broadcast) -- the alignment xarray does
+for `da * metric` (reference xgcm/grid.py:806-808,830-832).
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _hip
+
+__all__ = [
+    "asdevice",
+    "tohost",
+    "is_device_array",
+    "stencil1d",
+    "cumsum1d",
+    "reduce1d",
+    "pad_nd",
+    "binary",
+    "vorticity",
+    "synthetic",
+]
+
+
+def _require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "xgcm_amd needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback."
+        )
+
+
+def is_device_array(x) -> bool:
+    return isinstance(x, torch.Tensor) and x.is_cuda
+
+
+def asdevice(x) -> torch.Tensor:
+    """numpy / host tensor -> contiguous float64 tensor in HBM (PCIe copy); device tensors pass."""
+    _require_gpu()
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64)))
+    if t.dtype != torch.float64:
+        t = t.to(torch.float64)
+    if not t.is_cuda:
+        t = t.cuda()
+    return t.contiguous()
+
+
+def tohost(t) -> np.ndarray:
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _bstrides(m: Optional[torch.Tensor], shape: Sequence[int], what: str):
+    """Per-dim element strides of metric `m` against an array of `shape` (0 = broadcast)."""
+    if m is None:
+        return None
+    if m.dim() != len(shape):
+        raise ValueError(f"{what}: metric has {m.dim()} dims, array has {len(shape)}")
+    st = []
+    for d, (ms, s) in enumerate(zip(m.shape, shape)):
+        if ms == s and s != 1:
+            st.append(m.stride(d))
+        elif ms == 1:
+            st.append(0)
+        else:
+            raise ValueError(f"{what}: metric extent {ms} does not broadcast against {s} on dim {d}")
+    return st
+
+
+def _prep_metric(m) -> Optional[torch.Tensor]:
+    if m is None:
+        return None
+    m = asdevice(m)
+    return m
+
+
+def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str], fill: float = 0.0,
+              m_in=None, m_out=None) -> torch.Tensor:
+    """Fused pad + diff/interp/min/max along `axis` (xg_stencil1d_f64)."""
+    lib = _hip.load()
+    x = asdevice(x)
+    axis = axis % x.dim()
+    shape = list(x.shape)
+    n_out = shape[axis] + pad_lo + pad_hi - 1
+    oshape = list(shape)
+    oshape[axis] = n_out
+    m_in = _prep_metric(m_in)
+    m_out = _prep_metric(m_out)
+    out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    _hip.check(
+        lib.xg_stencil1d_f64(
+            _hip.OP[op], x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, n_out,
+            int(pad_lo), int(pad_hi), _hip.BC[bc], float(fill),
+            _ptr(m_in), _hip.i64(_bstrides(m_in, shape, "m_in")),
+            _ptr(m_out), _hip.i64(_bstrides(m_out, oshape, "m_out")), _stream(),
+        )
+    )
+    return out
+
+
+def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int, bc: Optional[str],
+             fill: float = 0.0, reverse: bool = False, skipna: bool = True, m_in=None, m_out=None) -> torch.Tensor:
+    """Prefix sum along `axis` with the Grid.cumsum trim/pad folded in (xg_cumsum1d_f64)."""
+    lib = _hip.load()
+    x = asdevice(x)
+    axis = axis % x.dim()
+    shape = list(x.shape)
+    oshape = list(shape)
+    oshape[axis] = shape[axis] - trim_lo - trim_hi + pad_lo + pad_hi
+    m_in = _prep_metric(m_in)
+    m_out = _prep_metric(m_out)
+    out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    _hip.check(
+        lib.xg_cumsum1d_f64(
+            x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, int(bool(reverse)), int(bool(skipna)),
+            int(trim_lo), int(trim_hi), int(pad_lo), int(pad_hi), _hip.BC[bc], float(fill),
+            _ptr(m_in), _hip.i64(_bstrides(m_in, shape, "m_in")),
+            _ptr(m_out), _hip.i64(_bstrides(m_out, oshape, "m_out")), _stream(),
+        )
+    )
+    return out
+
+
+def reduce1d(x, axis: int, w=None, skipna: bool = True) -> torch.Tensor:
+    """sum_k (x * w) along `axis`, axis removed (xg_reduce1d_f64)."""
+    lib = _hip.load()
+    x = asdevice(x)
+    axis = axis % x.dim()
+    shape = list(x.shape)
+    oshape = shape[:axis] + shape[axis + 1:]
+    w = _prep_metric(w)
+    out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    _hip.check(
+        lib.xg_reduce1d_f64(
+            x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, int(bool(skipna)),
+            _ptr(w), _hip.i64(_bstrides(w, shape, "w")), _stream(),
+        )
+    )
+    return out
+
+
+def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
+    """Generic pad; dict keys are axis numbers, dict order is the application order (xg_pad_f64)."""
+    lib = _hip.load()
+    x = asdevice(x)
+    nd = x.dim()
+    lo = [0] * nd
+    hi = [0] * nd
+    bcv = [0] * nd
+    fv = [0.0] * nd
+    order = []
+    for ax, (l, h) in widths.items():
+        ax = ax % nd
+        lo[ax], hi[ax] = int(l), int(h)
+        bcv[ax] = _hip.BC[bc.get(ax)]
+        fv[ax] = float(fill.get(ax, 0.0) if fill.get(ax, 0.0) is not None else 0.0)
+        order.append(ax)
+    order += [d for d in range(nd) if d not in order]
+    oshape = [s + l + h for s, l, h in zip(x.shape, lo, hi)]
+    out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    _hip.check(
+        lib.xg_pad_f64(x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), nd, _hip.i64(lo), _hip.i64(hi),
+                       _hip.ints(bcv), _hip.f64s(fv), _hip.ints(order), _stream())
+    )
+    return out
+
+
+def binary(op: str, a, b) -> torch.Tensor:
+    """Broadcasting a OP b for dim-aligned operands (same ndim, extents equal or 1)."""
+    lib = _hip.load()
+    a = asdevice(a)
+    b = asdevice(b)
+    if a.dim() != b.dim():
+        raise ValueError("binary: operands must be dim-aligned (same ndim)")
+    shape = []
+    for sa, sb in zip(a.shape, b.shape):
+        if sa != sb and 1 not in (sa, sb):
+            raise ValueError(f"binary: extents {sa} and {sb} do not broadcast")
+        shape.append(max(sa, sb) if 0 not in (sa, sb) else 0)
+    out = torch.empty(shape, dtype=torch.float64, device=a.device)
+    _hip.check(
+        lib.xg_binary_f64(_hip.BINOP[op], a.data_ptr(), _hip.i64(_bstrides(a, shape, "a")), b.data_ptr(),
+                          _hip.i64(_bstrides(b, shape, "b")), out.data_ptr(), _hip.i64(shape), len(shape), _stream())
+    )
+    return out
+
+
+def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0) -> torch.Tensor:
+    """Fused ((v[j,i]-v[j,i-1]) - (u[j,i]-u[j-1,i])) / area on (..., Y, X) arrays (xg_vorticity_f64)."""
+    lib = _hip.load()
+    u = asdevice(u)
+    v = asdevice(v)
+    if u.shape != v.shape:
+        raise ValueError("vorticity: u and v must have the same shape")
+    shape = list(u.shape)
+    area = _prep_metric(area)
+    out = torch.empty(shape, dtype=torch.float64, device=u.device)
+    _hip.check(
+        lib.xg_vorticity_f64(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
+                             out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
+                             _hip.BC[bc_y], float(fill_y), _stream())
+    )
+    return out
+
+
+def synthetic(shape, seed: int, offset: int = 0, scale: float = 1.0, shift: float = -0.5, out=None) -> torch.Tensor:
+    """Deterministic synthetic field generated in HBM, bit-identical to oracle.refimpl.synthetic."""
+    lib = _hip.load()
+    _require_gpu()
+    if out is None:
+        out = torch.empty(tuple(shape), dtype=torch.float64, device="cuda")
+    _hip.check(lib.xg_fill_synthetic_f64(out.data_ptr(), out.numel(), int(seed), int(offset), float(scale),
+                                         float(shift), _stream()))
+    return out
