@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Grid.interp + Grid.diff on a 3600 x 2400 x 75 float64 MITgcm-like C-grid
+(BASELINE.json configs[1]), periodic X / extend Y, through the public `xgcm_amd.Grid` API.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one resident record (field T(Z,YC,XC), 648e6 cells):
+interp(T,'X'), diff(T,'X') [contiguous axis, periodic] and interp(T,'Y'), diff(T,'Y') [strided
+axis, extend] = 4 kernel launches, 4 x 648e6 output cells.  Inputs are generated in HBM before
+the timed region (synthetic, bit-identical to the oracle's generator); outputs stay in HBM.
+Multi-GPU: every rank owns its own record(s) (the path shards over the outer record axis with no
+data-path collective); RCCL is used for the barriers and the max-time
+reduction only => weak scaling, value = cells of all ranks / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the timed
+region) and `cpu_baseline` (the numpy oracle = the reference's eager call sequence, timed on a
+bounded sample on this box's host cores; N=1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+NZ, NY, NX = 75, 2400, 3600
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_CELL = 16.0  # 1 f64 read + 1 f64 write per output cell
+OPS = [("interp", "X"), ("diff", "X"), ("interp", "Y"), ("diff", "Y")]
+KERNEL_OF_AXIS = {"X": "k_stencil_contig<V=2>", "Y": "k_stencil_strided<V=2>"}
+
+
+def build_grid(nz, device_field):
+    from xgcm_amd import DataArray, Dataset, Grid
+
+    coords = {"XC": ("XC", np.arange(NX) + 0.5), "XG": ("XG", np.arange(NX) * 1.0),
+              "YC": ("YC", np.arange(NY) + 0.5), "YG": ("YG", np.arange(NY) * 1.0),
+              "Z": ("Z", np.arange(nz) * 1.0)}
+    ds = Dataset(coords=coords)
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"},
+                            "Z": {"center": "Z"}},
+                padding={"X": "periodic", "Y": "extend"}, autoparse_metadata=False)
+    T = DataArray(device_field, ("Z", "YC", "XC"), name="T")
+    return grid, T
+
+
+def cpu_baseline(levels=8, budget_s=20.0):
+    """The reference's eager numpy sequence (oracle/refimpl.py) on a `levels`-deep slab of the same
+    workload, single thread = the reference's own execution model (numpy, no dask)."""
+    from oracle import refimpl as R
+
+    a = R.synthetic_field((levels, NY, NX), 2)
+    cells = 0
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        R.stencil1d("interp", a, 2, 1, 0, "periodic")
+        R.stencil1d("diff", a, 2, 1, 0, "periodic")
+        R.stencil1d("interp", a, 1, 1, 0, "extend")
+        R.stencil1d("diff", a, 1, 1, 0, "extend")
+        cells += 4 * a.size
+        passes += 1
+        el = time.perf_counter() - t0
+        if el > budget_s * 0.5 or passes >= 8:
+            break
+    return {"value": round(cells / el / 1e9, 4), "unit": "Gcell/s", "cores": 1, "kind": "port",
+            "sample": f"{passes} pass(es) of the 4 ops on a {levels}x{NY}x{NX} f64 slab (numpy pad copy + sliced op, "
+                      f"single thread = the reference's eager path), {el:.1f} s; host has {os.cpu_count()} cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--levels", type=int, default=NZ, help="Z levels (default = the full 75; smaller only for debugging)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from xgcm_amd import device as D
+
+    nz = args.levels
+    cells_per_op = nz * NY * NX
+    # each rank generates ITS record (seed 2, disjoint index range) directly in HBM
+    field = D.synthetic((nz, NY, NX), 2, offset=rank * cells_per_op)
+    grid, T = build_grid(nz, field)
+
+    def step(events=None):
+        for i, (fn, ax) in enumerate(OPS):
+            getattr(grid, fn)(T, ax)
+            if events is not None:
+                events[i + 1].record()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    # parity spot-check outside the timed region (one level against the oracle, rank 0)
+    parity = None
+    if rank == 0:
+        from oracle import refimpl as R
+
+        a0 = R.synthetic_field((1, NY, NX), 2)
+        g1, T1 = build_grid(1, field[:1].contiguous())
+        parity = bool(
+            np.array_equal(g1.diff(T1, "X").values, R.stencil1d("diff", a0, 2, 1, 0, "periodic"))
+            and np.array_equal(g1.interp(T1, "Y").values, R.stencil1d("interp", a0, 1, 1, 0, "extend"))
+        )
+
+    for _ in range(args.warmup):
+        step()
+    K = args.steps
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(OPS) + 1)] for _ in range(K)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        ev[k][0].record()
+        step(ev[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    from xgcm_amd.sharding import whole_job_throughput
+
+    local_cells = K * len(OPS) * cells_per_op
+    cells_per_s, elapsed = whole_job_throughput(local_cells, elapsed, dist, "cuda")
+
+    # per-launch durations from the HIP events recorded on the launch stream inside the timed region
+    per_op_ms = [float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(K)])) for i in range(len(OPS))]
+    by_kernel = {}
+    for (fn, ax), ms in zip(OPS, per_op_ms):
+        by_kernel.setdefault(KERNEL_OF_AXIS[ax], []).append(ms)
+    dominant = max(by_kernel, key=lambda k: sum(by_kernel[k]))
+    dom_ms = float(np.mean(by_kernel[dominant]))
+    alg_bytes = cells_per_op * BYTES_PER_CELL
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        total_cells = cells_per_s * elapsed
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):  # measured offline with rocprofv3 --pmc (see profiles/README.md)
+            try:
+                traffic = json.load(open(pmc)).get(dominant)
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "stencil-cells/s, Grid.interp+Grid.diff (X periodic, Y extend) on 3600x2400x75 f64",
+            "value": round(total_cells / elapsed / 1e9, 3),
+            "unit": "Gcell/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"configs[1]: Grid.interp+Grid.diff along X (periodic) and Y (extend) on one "
+                                   f"{NX}x{NY}x{nz} f64 C-grid record per GPU, HBM-resident",
+                       "cells_per_step_per_gpu": len(OPS) * cells_per_op, "records_per_gpu": 1,
+                       "sharding": "record axis, no data-path collective"},
+            "achieved_GBps_whole_step": round(total_cells * BYTES_PER_CELL / elapsed / 1e9 / world, 1),
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
+                         "per_op_ms": {f"{fn}_{ax}": round(ms, 4) for (fn, ax), ms in zip(OPS, per_op_ms)}},
+            "parity_spot_check": parity,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""Test double for `xgcm_amd.device`, built on the CPU oracle.
+
+TEST INFRASTRUCTURE ONLY.  The GPU-less `-m "not gpu"` suite uses it (via monkeypatch, see
+tests/conftest.py::backend) to exercise the HOST logic of xgcm_amd -- Grid/Axis dispatch,
+signature matching, kwarg precedence, coordinate re-attachment, error messages -- without
+launching kernels.  The product never imports this module; on a GPU box the same tests run a
+second time against the real HIP library.
+"""
+
+import numpy as np
+
+from . import refimpl as R
+
+
+def asdevice(x):
+    return np.asarray(x, dtype=np.float64, order="C")
+
+
+def tohost(x):
+    return np.asarray(x)
+
+
+def is_device_array(x):
+    return False
+
+
+def stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill=0.0, m_in=None, m_out=None):
+    x = asdevice(x)
+    return R.stencil1d(op, x, axis % x.ndim, pad_lo, pad_hi, bc, fill, m_in, m_out)
+
+
+def cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill=0.0, reverse=False, skipna=True, m_in=None, m_out=None):
+    x = asdevice(x)
+    return R.cumsum1d(x, axis % x.ndim, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, skipna, m_in, m_out)
+
+
+def reduce1d(x, axis, w=None, skipna=True):
+    x = asdevice(x)
+    return R.integrate(x, axis % x.ndim, w, skipna)
+
+
+def pad_nd(x, widths, bc, fill):
+    x = asdevice(x)
+    return R.pad_nd(x, {k % x.ndim: v for k, v in widths.items()}, {k % x.ndim: v for k, v in bc.items()},
+                    {k % x.ndim: (0.0 if v is None else v) for k, v in fill.items()})
+
+
+def binary(op, a, b):
+    return R.binary(op, asdevice(a), asdevice(b))
+
+
+def vorticity(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0):
+    u, v = asdevice(u), asdevice(v)
+    if area is None:
+        area = np.ones((1,) * u.ndim)
+    return R.vorticity(u, v, area, bc_x, bc_y, fill_x, fill_y)
+
+
+def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None):
+    return R.synthetic(int(np.prod(shape)), seed, offset, scale, shift).reshape(tuple(shape))
+
+
+_NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "cumsum1d", "reduce1d", "pad_nd", "binary",
+          "vorticity", "synthetic"]
+
+
+def install(monkeypatch):
+    import xgcm_amd.device as dev
+
+    for n in _NAMES:
+        monkeypatch.setattr(dev, n, globals()[n])

@@ -28,3 +28,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(params=["oracle-double", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request, monkeypatch):
+    """Run a host-logic test twice: on CPU against the oracle-backed device double (no kernels),
+    and on a GPU box against the real HIP library.  `backend` is the residency converter for
+    inputs: identity on CPU, identity on GPU too (numpy in -> numpy out through PCIe)."""
+    if request.param == "oracle-double":
+        from oracle import fake_device
+
+        fake_device.install(monkeypatch)
+    return request.param

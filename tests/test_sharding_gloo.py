@@ -1,0 +1,97 @@
+"""N>1 path on CPU: two `gloo` ranks shard a record axis, run their block through the operator
+stack (oracle-backed device double -- no GPU here), and the sharded outputs + reduced scalars
+must equal the single-process result.  Mirrors what bench.py does with RCCL on the GPU box."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from xgcm_amd.sharding import shard_bounds
+
+
+def test_shard_bounds_cover_exactly():
+    assert [shard_bounds(90, 8, r) for r in range(8)] == [(0, 12), (12, 24), (24, 35), (35, 46), (46, 57), (57, 68),
+                                                           (68, 79), (79, 90)]
+    assert [shard_bounds(360, 8, r)[1] - shard_bounds(360, 8, r)[0] for r in range(8)] == [45] * 8
+    for n in (0, 1, 7, 8, 9, 75):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import fake_device
+        from oracle import refimpl as R
+        import xgcm_amd.device as dev
+
+        class MP:  # minimal monkeypatch stand-in
+            def setattr(self, obj, name, val):
+                setattr(obj, name, val)
+
+        fake_device.install(MP())
+        from xgcm_amd import DataArray, Dataset, Grid
+        from xgcm_amd.sharding import whole_job_throughput
+
+        nt, nz, ny, nx = 5, 6, 8, 16
+        full = R.synthetic_field((nt, nz, ny, nx), 4)
+        lo, hi = shard_bounds(nt, world, rank)
+        ds = Dataset(coords={"XC": ("XC", np.arange(nx) * 1.0), "XG": ("XG", np.arange(nx) - 0.5),
+                             "Z": ("Z", np.arange(nz) * 1.0), "Zl": ("Zl", np.arange(nz) - 0.5)})
+        grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}, "Z": {"center": "Z", "left": "Zl"}},
+                    padding={"X": "periodic", "Z": "fill"}, autoparse_metadata=False)
+        mine = DataArray(full[lo:hi], ("time", "Z", "YC", "XC"))
+        d = grid.diff(mine, "X").values
+        c = grid.cumsum(mine, "Z").values
+        np.save(os.path.join(tmp, f"diff_{rank}.npy"), d)
+        np.save(os.path.join(tmp, f"cumsum_{rank}.npy"), c)
+        # scalar reductions only: checksum (order-independent integer sum) and the timing aggregate
+        chk = torch.tensor([int(np.frombuffer(d.tobytes(), dtype=np.uint64).sum() % (1 << 50))], dtype=torch.int64)
+        dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+        rate, tmax = whole_job_throughput(float(d.size), 1.0 + rank, dist)
+        if rank == 0:
+            np.save(os.path.join(tmp, "scalars.npy"), np.array([float(chk.item()), rate, tmax]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_equals_single_process(tmp_path):
+    from oracle import refimpl as R
+
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    nt, nz, ny, nx = 5, 6, 8, 16
+    full = R.synthetic_field((nt, nz, ny, nx), 4)
+    want_d = R.stencil1d("diff", full, 3, 1, 0, "periodic")
+    want_c = R.grid_cumsum(full, 1, "center", "left", "fill")
+    got_d = np.concatenate([np.load(tmp_path / f"diff_{r}.npy") for r in range(world)], axis=0)
+    got_c = np.concatenate([np.load(tmp_path / f"cumsum_{r}.npy") for r in range(world)], axis=0)
+    assert np.array_equal(got_d, want_d) and np.array_equal(got_c, want_c)
+    chk, rate, tmax = np.load(tmp_path / "scalars.npy")
+    parts = [np.load(tmp_path / f"diff_{r}.npy") for r in range(world)]
+    want_chk = sum(int(np.frombuffer(p.tobytes(), dtype=np.uint64).sum() % (1 << 50)) for p in parts)
+    assert int(chk) == want_chk  # checksum of checksums
+    assert tmax == 2.0 and rate == want_d.size / 2.0  # all units / max-over-ranks time

@@ -51,7 +51,7 @@ def asdevice(x) -> torch.Tensor:
     if isinstance(x, torch.Tensor):
         t = x
     else:
-        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64)))
+        t = torch.from_numpy(np.asarray(x, dtype=np.float64, order="C"))
     if t.dtype != torch.float64:
         t = t.to(torch.float64)
     if not t.is_cuda:

@@ -1,0 +1,439 @@
+"""Minimal labelled arrays (`DataArray`, `Dataset`) for the xarray-in / xarray-out surface.
+
+xarray is not installable in the target image, so the Grid API is exercised through this
+small duck type that implements the subset of `xarray.DataArray` / `xarray.Dataset` the
+reference hot path touches (dims, sizes, coords, rename/transpose/isel, name-based
+broadcasting arithmetic, sum/cumsum).  `.data` is either a host `numpy.ndarray` or a
+HBM-resident `torch.Tensor`; every arithmetic method runs on the GPU through
+`xgcm_amd.device` (never numpy) and returns data of the same residency it was given.
+
+When real xarray objects are passed to `Grid` they are converted with `from_xarray` and the
+results converted back with `to_xarray` (xgcm_amd/grid.py).
+"""
+
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Any, Dict, Hashable, Iterable, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from . import device as _dev
+
+try:  # torch is plumbing for device memory only
+    import torch
+except Exception:  # pragma: no cover
+    torch = None  # type: ignore
+
+
+def _is_tensor(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _shape(x) -> Tuple[int, ...]:
+    return tuple(int(s) for s in x.shape)
+
+
+class DataArray:
+    """N-D array with named dimensions and coordinates (subset of xarray.DataArray)."""
+
+    __slots__ = ("data", "dims", "coords", "name", "attrs")
+
+    def __init__(self, data, dims: Optional[Sequence[str]] = None, coords=None, name: Optional[str] = None,
+                 attrs: Optional[dict] = None):
+        if isinstance(data, DataArray):
+            dims = data.dims if dims is None else dims
+            coords = data.coords if coords is None else coords
+            name = data.name if name is None else name
+            data = data.data
+        if not _is_tensor(data):
+            data = np.asarray(data)
+        if dims is None:
+            dims = tuple(f"dim_{i}" for i in range(data.ndim))
+        if isinstance(dims, str):
+            dims = (dims,)
+        dims = tuple(dims)
+        if len(dims) != len(data.shape):
+            raise ValueError(f"different number of dimensions on data ({len(data.shape)}) and dims {dims}")
+        if len(set(dims)) != len(dims):
+            raise ValueError(f"duplicate dimension names in {dims}")
+        self.data = data
+        self.dims = dims
+        self.name = name
+        self.attrs = dict(attrs) if attrs else {}
+        self.coords: "OrderedDict[str, DataArray]" = OrderedDict()
+        if coords:
+            self._set_coords(coords)
+
+    # ---- construction helpers -----------------------------------------------------------
+    def _set_coords(self, coords: Mapping[str, Any]) -> None:
+        sizes = self.sizes
+        for cname, c in coords.items():
+            if isinstance(c, DataArray):
+                cda = DataArray(c.data, c.dims, name=cname, attrs=c.attrs)
+            elif isinstance(c, tuple) and len(c) >= 2 and isinstance(c[0], (str, list, tuple)):
+                cdims = (c[0],) if isinstance(c[0], str) else tuple(c[0])
+                cda = DataArray(c[1], cdims, name=cname, attrs=c[2] if len(c) > 2 else None)
+            else:
+                cda = DataArray(c, (cname,), name=cname)
+            for d, s in zip(cda.dims, cda.shape):
+                if d not in sizes:
+                    raise ValueError(f"coordinate {cname} has dimension {d} not present on the array dims {self.dims}")
+                if sizes[d] != s:
+                    raise ValueError(
+                        f"conflicting sizes for dimension {d!r}: length {s} on {cname!r} and length {sizes[d]} on the data"
+                    )
+            self.coords[cname] = cda
+
+    def _replace(self, data=None, dims=None, coords=None, name="__keep__") -> "DataArray":
+        out = DataArray.__new__(DataArray)
+        out.data = self.data if data is None else data
+        out.dims = self.dims if dims is None else tuple(dims)
+        out.name = self.name if name == "__keep__" else name
+        out.attrs = dict(self.attrs)
+        out.coords = OrderedDict(self.coords if coords is None else coords)
+        return out
+
+    # ---- basic properties ---------------------------------------------------------------
+    @property
+    def shape(self) -> Tuple[int, ...]:
+        return _shape(self.data)
+
+    @property
+    def ndim(self) -> int:
+        return len(self.dims)
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape)) if self.shape else 1
+
+    @property
+    def sizes(self) -> Dict[str, int]:
+        return dict(zip(self.dims, self.shape))
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def values(self) -> np.ndarray:
+        return _dev.tohost(self.data)
+
+    @property
+    def is_device(self) -> bool:
+        return _is_tensor(self.data) and self.data.is_cuda
+
+    @property
+    def chunks(self):  # never dask-backed
+        return None
+
+    def get_axis_num(self, dim: str) -> int:
+        try:
+            return self.dims.index(dim)
+        except ValueError:
+            raise ValueError(f"{dim!r} not found in array dimensions {self.dims!r}")
+
+    def to_device(self) -> "DataArray":
+        return self._replace(data=_dev.asdevice(self.data))
+
+    def to_host(self) -> "DataArray":
+        return self._replace(data=_dev.tohost(self.data))
+
+    # ---- metadata-only transformations --------------------------------------------------
+    def copy(self, deep: bool = False, data=None) -> "DataArray":
+        if data is not None:
+            if _shape(data) != self.shape:
+                raise ValueError("replacement data must match the shape")
+            return self._replace(data=data if _is_tensor(data) else np.asarray(data))
+        if deep:
+            d = self.data.clone() if _is_tensor(self.data) else self.data.copy()
+            return self._replace(data=d)
+        return self._replace()
+
+    def rename(self, new_name_or_name_dict=None, **names) -> "DataArray":
+        if new_name_or_name_dict is None or isinstance(new_name_or_name_dict, Mapping):
+            mapping = dict(new_name_or_name_dict or {})
+            mapping.update(names)
+            dims = tuple(mapping.get(d, d) for d in self.dims)
+            coords = OrderedDict()
+            for cname, c in self.coords.items():
+                cd = tuple(mapping.get(d, d) for d in c.dims)
+                coords[mapping.get(cname, cname)] = c._replace(dims=cd, name=mapping.get(cname, cname))
+            return self._replace(dims=dims, coords=coords)
+        return self._replace(name=new_name_or_name_dict)
+
+    def transpose(self, *dims: str) -> "DataArray":
+        if not dims:
+            dims = self.dims[::-1]
+        if set(dims) != set(self.dims) or len(dims) != len(self.dims):
+            raise ValueError(f"{dims} must be a permutation of {self.dims}")
+        if tuple(dims) == self.dims:
+            return self._replace()
+        perm = [self.dims.index(d) for d in dims]
+        if _is_tensor(self.data):
+            data = self.data.permute(*perm)
+        else:
+            data = np.transpose(self.data, perm)
+        return self._replace(data=data, dims=dims)
+
+    @property
+    def T(self) -> "DataArray":
+        return self.transpose()
+
+    def isel(self, indexers: Optional[Mapping[str, Any]] = None, **kw) -> "DataArray":
+        idx = dict(indexers or {})
+        idx.update(kw)
+        key = []
+        dims = []
+        for d in self.dims:
+            k = idx.get(d, slice(None))
+            key.append(k)
+            if isinstance(k, slice):
+                dims.append(d)
+            elif not isinstance(k, (int, np.integer)):
+                raise NotImplementedError("isel supports ints and slices only")
+        for d in idx:
+            if d not in self.dims:
+                raise ValueError(f"Dimensions {{{d!r}}} do not exist. Expected one or more of {self.dims}")
+        key = tuple(key)
+        if _is_tensor(self.data) and any(isinstance(k, slice) and k.step not in (None, 1) for k in key):
+            raise NotImplementedError("strided isel on device data")
+        data = self.data[key]
+        coords = OrderedDict()
+        for cname, c in self.coords.items():
+            sub = {d: idx[d] for d in c.dims if d in idx}
+            if all(isinstance(v, slice) for v in sub.values()):
+                coords[cname] = c.isel(sub) if sub else c
+            elif len(c.dims) != len(sub):  # dropped dims of a multi-dim coord
+                coords[cname] = c.isel(sub)
+        return self._replace(data=data, dims=dims, coords=coords)
+
+    def reset_coords(self, names=None, drop: bool = False) -> "DataArray":
+        if not drop:
+            raise NotImplementedError("reset_coords(drop=False)")
+        keep = OrderedDict((k, v) for k, v in self.coords.items() if k in self.dims and v.dims == (k,))
+        return self._replace(coords=keep)
+
+    def drop_vars(self, names, errors: str = "raise") -> "DataArray":
+        if isinstance(names, str):
+            names = [names]
+        names = set(names)
+        return self._replace(coords=OrderedDict((k, v) for k, v in self.coords.items() if k not in names))
+
+    def assign_coords(self, coords: Optional[Mapping[str, Any]] = None, **kw) -> "DataArray":
+        out = self._replace()
+        allc = dict(coords or {})
+        allc.update(kw)
+        out._set_coords(allc)
+        return out
+
+    def to_dataset(self, name: Optional[str] = None) -> "Dataset":
+        return Dataset({name or self.name: self})
+
+    # ---- comparisons --------------------------------------------------------------------
+    def equals(self, other: "DataArray") -> bool:
+        if not isinstance(other, DataArray) or self.dims != other.dims or self.shape != other.shape:
+            return False
+        if not np.array_equal(self.values, other.values, equal_nan=True):
+            return False
+        if set(self.coords) != set(other.coords):
+            return False
+        return all(self.coords[k].dims == other.coords[k].dims
+                   and np.array_equal(self.coords[k].values, other.coords[k].values) for k in self.coords)
+
+    def identical(self, other: "DataArray") -> bool:
+        return self.equals(other) and self.name == other.name
+
+    # ---- arithmetic on the GPU (name-based broadcasting like xarray) ---------------------
+    def _binary(self, other, op: str, reflexive: bool = False) -> "DataArray":
+        if isinstance(other, (int, float, np.integer, np.floating)):
+            o = DataArray(np.full((1,) * self.ndim, float(other)), tuple(f"__s{i}" for i in range(self.ndim)))
+            a, b, dims = self.data, o.data, self.dims
+            coords = OrderedDict(self.coords)
+        elif isinstance(other, DataArray):
+            dims = self.dims + tuple(d for d in other.dims if d not in self.dims)
+            a = _aligned_view(self, dims)
+            b = _aligned_view(other, dims)
+            for d in dims:
+                if d in self.dims and d in other.dims and self.sizes[d] != other.sizes[d]:
+                    raise ValueError(f"cannot broadcast: dimension {d!r} has sizes {self.sizes[d]} and {other.sizes[d]}")
+            coords = OrderedDict(self.coords)
+            for k, v in other.coords.items():
+                coords.setdefault(k, v)
+        else:
+            return NotImplemented
+        if reflexive:
+            a, b = b, a
+        host = not (_is_tensor(self.data) or (isinstance(other, DataArray) and _is_tensor(other.data)))
+        res = _dev.binary(op, a, b)
+        if host:
+            res = _dev.tohost(res)
+        return DataArray(res, dims, coords=coords, name=self.name)
+
+    def __mul__(self, o): return self._binary(o, "mul")
+    def __rmul__(self, o): return self._binary(o, "mul", True)
+    def __truediv__(self, o): return self._binary(o, "div")
+    def __rtruediv__(self, o): return self._binary(o, "div", True)
+    def __add__(self, o): return self._binary(o, "add")
+    def __radd__(self, o): return self._binary(o, "add", True)
+    def __sub__(self, o): return self._binary(o, "sub")
+    def __rsub__(self, o): return self._binary(o, "sub", True)
+
+    def sum(self, dim=None, skipna: Optional[bool] = None, keep_attrs: bool = False, **kwargs) -> "DataArray":
+        """Sum over `dim` (str or list); float default skips NaN like xarray."""
+        if kwargs:
+            raise TypeError(f"sum() got unexpected keyword argument(s): {list(kwargs)}")
+        dims = list(self.dims) if dim is None else ([dim] if isinstance(dim, str) else list(dim))
+        out = self
+        host = not _is_tensor(self.data)
+        data = _dev.asdevice(self.data)
+        cur_dims = list(self.dims)
+        for d in dims:
+            ax = cur_dims.index(d)
+            data = _dev.reduce1d(data, ax, None, True if skipna is None else bool(skipna))
+            cur_dims.pop(ax)
+        coords = OrderedDict((k, v) for k, v in out.coords.items() if all(cd in cur_dims for cd in v.dims))
+        return DataArray(_dev.tohost(data) if host else data, cur_dims, coords=coords, name=self.name,
+                         attrs=self.attrs if keep_attrs else None)
+
+    def cumsum(self, dim: str, skipna: Optional[bool] = None) -> "DataArray":
+        host = not _is_tensor(self.data)
+        ax = self.get_axis_num(dim)
+        res = _dev.cumsum1d(self.data, ax, 0, 0, 0, 0, None, 0.0, False, True if skipna is None else bool(skipna))
+        return self._replace(data=_dev.tohost(res) if host else res)
+
+    def __repr__(self) -> str:
+        where = "HBM" if self.is_device else "host"
+        return f"<xgcm_amd.DataArray {self.name!r} {dict(self.sizes)} [{where}] coords={list(self.coords)}>"
+
+    def __len__(self) -> int:
+        return self.shape[0]
+
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            return self.coords[key]
+        if not isinstance(key, tuple):
+            key = (key,)
+        return self.isel({d: k for d, k in zip(self.dims, key)})
+
+
+def _aligned_view(da: DataArray, dims: Sequence[str]):
+    """View of `da.data` with exactly `dims` (size-1 where da lacks the dim); no copy on device."""
+    present = [d for d in dims if d in da.dims]
+    perm = [da.dims.index(d) for d in present]
+    data = da.data
+    if _is_tensor(data):
+        v = data.permute(*perm) if perm != list(range(len(perm))) else data
+        index = tuple(slice(None) if d in da.dims else None for d in dims)
+        return v[index]
+    v = np.transpose(data, perm) if perm != list(range(len(perm))) else data
+    index = tuple(slice(None) if d in da.dims else np.newaxis for d in dims)
+    return v[index]
+
+
+class Dataset:
+    """Dict of named DataArrays sharing dimensions (subset of xarray.Dataset)."""
+
+    def __init__(self, data_vars: Optional[Mapping[str, Any]] = None, coords: Optional[Mapping[str, Any]] = None,
+                 attrs: Optional[dict] = None):
+        self.data_vars: "OrderedDict[str, DataArray]" = OrderedDict()
+        self.coords: "OrderedDict[str, DataArray]" = OrderedDict()
+        self.attrs = dict(attrs) if attrs else {}
+        self._sizes: Dict[str, int] = {}
+        for k, v in (coords or {}).items():
+            self._add(k, v, True)
+        for k, v in (data_vars or {}).items():
+            self._add(k, v, False)
+
+    def _as_da(self, name, v) -> DataArray:
+        if isinstance(v, DataArray):
+            return v._replace(name=name)
+        if isinstance(v, tuple):
+            dims = (v[0],) if isinstance(v[0], str) else tuple(v[0])
+            return DataArray(v[1], dims, name=name, attrs=v[2] if len(v) > 2 else None)
+        return DataArray(v, (name,), name=name)
+
+    def _add(self, name, v, is_coord: bool) -> None:
+        da = self._as_da(name, v)
+        for d, s in da.sizes.items():
+            if self._sizes.setdefault(d, s) != s:
+                raise ValueError(f"conflicting sizes for dimension {d!r}: length {s} on {name!r} and length {self._sizes[d]}")
+        if is_coord:
+            self.coords[name] = da._replace(coords=OrderedDict())
+        else:
+            for cn, c in da.coords.items():
+                if cn not in self.coords:
+                    self._add(cn, c, True)
+            self.data_vars[name] = da._replace(coords=OrderedDict())
+
+    @property
+    def dims(self) -> Dict[str, int]:
+        return dict(self._sizes)
+
+    sizes = dims
+
+    @property
+    def variables(self) -> Dict[str, DataArray]:
+        out = OrderedDict(self.coords)
+        out.update(self.data_vars)
+        return out
+
+    def __contains__(self, key) -> bool:
+        return key in self.data_vars or key in self.coords
+
+    def __getitem__(self, key: str) -> DataArray:
+        if key in self.data_vars:
+            base = self.data_vars[key]
+        elif key in self.coords:
+            base = self.coords[key]
+        else:
+            raise KeyError(key)
+        coords = OrderedDict((k, c) for k, c in self.coords.items() if all(d in base.dims for d in c.dims))
+        return base._replace(coords=coords, name=key)
+
+    def __setitem__(self, key: str, value) -> None:
+        self._add(key, value, False)
+
+    def __getattr__(self, key: str):
+        if key.startswith("_") or key in ("data_vars", "coords", "attrs"):
+            raise AttributeError(key)
+        try:
+            return self[key]
+        except KeyError:
+            raise AttributeError(key)
+
+    def copy(self) -> "Dataset":
+        out = Dataset(attrs=self.attrs)
+        out.coords = OrderedDict(self.coords)
+        out.data_vars = OrderedDict(self.data_vars)
+        out._sizes = dict(self._sizes)
+        return out
+
+    def __repr__(self) -> str:
+        return f"<xgcm_amd.Dataset dims={self._sizes} data_vars={list(self.data_vars)} coords={list(self.coords)}>"
+
+
+# ---- optional bridges to real xarray ------------------------------------------------------
+def is_xarray(obj) -> bool:
+    mod = type(obj).__module__ or ""
+    return mod.startswith("xarray")
+
+
+def from_xarray(obj):
+    """xarray.DataArray / Dataset -> xgcm_amd labelled object (host data)."""
+    tname = type(obj).__name__
+    if tname == "DataArray":
+        coords = {k: (tuple(v.dims), np.asarray(v.values)) for k, v in obj.coords.items()}
+        return DataArray(np.asarray(obj.values), tuple(obj.dims), coords=coords, name=obj.name, attrs=dict(obj.attrs))
+    if tname == "Dataset":
+        coords = {k: (tuple(v.dims), np.asarray(v.values), dict(v.attrs)) for k, v in obj.coords.items()}
+        dvars = {k: (tuple(v.dims), np.asarray(v.values), dict(v.attrs)) for k, v in obj.data_vars.items()}
+        return Dataset(dvars, coords, attrs=dict(obj.attrs))
+    raise TypeError(type(obj))
+
+
+def to_xarray(da: DataArray):
+    import xarray as xr  # only reached when the caller handed us xarray objects
+
+    coords = {k: (c.dims, c.values) for k, c in da.coords.items()}
+    return xr.DataArray(da.values, dims=da.dims, coords=coords, name=da.name, attrs=da.attrs)
