@@ -306,9 +306,10 @@ def test_integrate_cumint_average_formulas(backend):
             np.testing.assert_allclose(_np(grid.integrate(tr, tuple(axis))), want, rtol=1e-12)
         avg = grid.average(tr, axis)
         np.testing.assert_allclose(_np(avg), want / mfull.sum(axis=nums), rtol=1e-12)
-    # single strided axis is bit-exact (sequential sum)
-    want = R.integrate(tr.values, 3, ds["dz_t"].values)
-    assert np.array_equal(_np(grid.integrate(tr, "Z")), want)
+    # a single STRIDED axis is bit-exact (sequential sum, like numpy); the contiguous axis (Z here) is a tree
+    want = R.integrate(tr.values, 1, ds["dy_t"].values[:, :, None, None])
+    assert np.array_equal(_np(grid.integrate(tr, "Y")), want)
+    np.testing.assert_allclose(_np(grid.integrate(tr, "Z")), R.integrate(tr.values, 3, ds["dz_t"].values), rtol=1e-12)
     # cumint == cumsum(da * metric)
     for ax, mname in (("X", "dx_t"), ("Z", "dz_t")):
         got = grid.cumint(tr, ax, padding="fill")
