@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--shape", default="75,2400,3600")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--cases", default="copy,stencil,metric,cumsum,reduce,vort")
+    ap.add_argument("--const", action="store_true", help="constant-valued field instead of random (DVFS / data-toggle check)")
     args = ap.parse_args()
     shape = tuple(int(s) for s in args.shape.split(","))
     cases = set(args.cases.split(","))
@@ -50,6 +51,9 @@ def main():
     tag = {k: os.environ.get(k) for k in ("XG_SEG", "XG_NT_STORE", "XG_NT_LOAD") if os.environ.get(k)}
 
     T = D.synthetic(shape, 2)
+    if args.const:
+        T = D.synthetic(shape, 2, 0, 0.0, 1.0)
+        tag["data"] = "const"
     out = []
 
     def rec(name, ms, best, bytes_per_cell, ncell=cells):

@@ -1,0 +1,227 @@
+// streambench.hip -- what HBM streaming rate can a read-one/write-one f64 kernel reach on this
+// MI355X, and with which launch shape?  Tuning aid for xgcm_hip.hip (not part of the product).
+//   hipcc -O3 --offload-arch=gfx950 tools/streambench.hip -o gpurun_out/streambench && ./streambench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <bool NT> __device__ __forceinline__ d2 ld(const d2* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ void st(d2* p, d2 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// tile = BLOCK*R vec elements; thread handles t + r*BLOCK within its tile. REMAP: XCD-contiguous chunks.
+template <int R, bool NTL, bool NTS, bool REMAP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_copy(const d2* __restrict__ in, d2* __restrict__ out, size_t nvec, unsigned nblk) {
+  unsigned b = blockIdx.x;
+  if (REMAP) { unsigned per = nblk / 8; if (b < per * 8) b = (b % 8) * per + b / 8; }
+  size_t base = (size_t)b * BLOCK * R + threadIdx.x;
+  d2 v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { size_t i = base + (size_t)r * BLOCK; if (i < nvec) v[r] = ld<NTL>(in + i); }
+#pragma unroll
+  for (int r = 0; r < R; ++r) { size_t i = base + (size_t)r * BLOCK; if (i < nvec) st<NTS>(out + i, v[r]); }
+}
+
+// persistent grid-stride copy
+template <int R, bool NTS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_copy_gs(const d2* __restrict__ in, d2* __restrict__ out, size_t nvec) {
+  size_t stride = (size_t)gridDim.x * BLOCK * R;
+  for (size_t base = (size_t)blockIdx.x * BLOCK * R + threadIdx.x; base < nvec; base += stride) {
+    d2 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { size_t i = base + (size_t)r * BLOCK; if (i < nvec) v[r] = in[i]; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { size_t i = base + (size_t)r * BLOCK; if (i < nvec) st<NTS>(out + i, v[r]); }
+  }
+}
+
+// diff along contiguous rows of length L (periodic), R rows per thread (same shape as k_stencil_contig)
+template <int R, bool NTS>
+__global__ __launch_bounds__(256) void k_diffx(const double* __restrict__ in, double* __restrict__ out, size_t rows, int L, unsigned ntile) {
+  unsigned w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  unsigned tile = w % ntile; size_t r0 = (size_t)(w / ntile) * R;
+  if (r0 >= rows) return;
+  int i0 = (tile * 64 + (threadIdx.x & 63)) * 2;
+  if (i0 >= L) return;
+  int nidx = i0 == 0 ? L - 1 : i0 - 1;
+  d2 pr[R]; double nb[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) if (r0 + u < rows) { const double* p = in + (r0 + u) * L; pr[u] = *(const d2*)(p + i0); nb[u] = p[nidx]; }
+#pragma unroll
+  for (int u = 0; u < R; ++u) if (r0 + u < rows) { d2 o; o.x = pr[u].x - nb[u]; o.y = pr[u].y - pr[u].x; st<NTS>((d2*)(out + (r0 + u) * L + i0), o); }
+}
+
+
+// E1: flat mapping: thread gid -> (row, i0) by division; perfectly linear, no partial waves
+template <bool NTS>
+__global__ __launch_bounds__(256) void k_diffx_flat(const double* __restrict__ in, double* __restrict__ out, size_t nvec, unsigned vpr) {
+  size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= nvec) return;
+  size_t row = gid / vpr; unsigned xv = (unsigned)(gid - row * vpr);
+  unsigned L = vpr * 2, i0 = xv * 2;
+  const double* p = in + row * L;
+  unsigned nidx = i0 == 0 ? L - 1 : i0 - 1;
+  d2 a = *(const d2*)(p + i0); double nb = p[nidx];
+  d2 o; o.x = a.x - nb; o.y = a.y - a.x;
+  st<NTS>((d2*)(out + row * L + i0), o);
+}
+
+// E2/E3: stencil along a strided axis in LINEAR output order: out[j,x] = in[j,x] - in[j-1,x], both
+// loaded (the j-1 row is an L2 / MALL hit).  ntile_pad = tiles per row rounded for XCD alignment.
+template <bool NTS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_diffy_two(const double* __restrict__ in, double* __restrict__ out, size_t nrows, size_t nper,
+                                                      size_t inner, unsigned ntile_pad) {
+  constexpr int WPB = BLOCK / 64;
+  size_t w = (size_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+  unsigned tile = (unsigned)(w % ntile_pad); size_t row = w / ntile_pad;
+  if (row >= nrows) return;
+  size_t x = ((size_t)tile * 64 + (threadIdx.x & 63)) * 2;
+  if (x >= inner) return;
+  size_t j = row % nper;
+  size_t prev = j == 0 ? row : row - 1;
+  d2 a = *(const d2*)(in + row * inner + x);
+  d2 b = *(const d2*)(in + prev * inner + x);
+  d2 o = a - b;
+  st<NTS>((d2*)(out + row * inner + x), o);
+}
+
+// marching reference (same as k_stencil_strided): SEG rows per wave
+template <int SEG, bool NTS>
+__global__ __launch_bounds__(256) void k_diffy_march(const double* __restrict__ in, double* __restrict__ out, size_t outer, size_t n, size_t inner, unsigned ntile) {
+  size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  unsigned nseg = (unsigned)((n + SEG - 1) / SEG);
+  unsigned tile = (unsigned)(w % ntile); size_t r = w / ntile; unsigned sg = (unsigned)(r % nseg); size_t o = r / nseg;
+  if (o >= outer) return;
+  size_t x = ((size_t)tile * 64 + (threadIdx.x & 63)) * 2;
+  if (x >= inner) return;
+  size_t j0 = (size_t)sg * SEG, j1 = j0 + SEG < n ? j0 + SEG : n;
+  const double* p = in + o * n * inner + x; double* q = out + o * n * inner + x;
+  d2 prev = *(const d2*)(p + (j0 == 0 ? 0 : j0 - 1) * inner);
+  size_t j = j0;
+  for (; j + 8 <= j1; j += 8) { d2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *(const d2*)(p + (j + u) * inner);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { st<NTS>((d2*)(q + (j + u) * inner), v[u] - prev); prev = v[u]; } }
+  for (; j < j1; ++j) { d2 v = *(const d2*)(p + j * inner); st<NTS>((d2*)(q + j * inner), v - prev); prev = v; }
+}
+
+
+// XCD-banded variants: block b runs on XCD b%8 (observed); give each XCD a contiguous 1/8 of the
+// linear wave sequence so a row re-read one row later hits the SAME XCD's L2.
+__device__ __forceinline__ bool banded(unsigned nb, size_t& w) {
+  unsigned b = blockIdx.x, pb = (nb + 7) / 8;
+  unsigned lb = (b % 8) * pb + b / 8;
+  if (lb >= nb) return false;
+  w = (size_t)lb * 4 + (threadIdx.x >> 6);
+  return true;
+}
+template <bool BAND>
+__global__ __launch_bounds__(256) void k_diffy_two_b(const double* __restrict__ in, double* __restrict__ out, size_t nrows, unsigned nper,
+                                                      unsigned inner, unsigned ntile, unsigned nb) {
+  size_t w;
+  if (BAND) { if (!banded(nb, w)) return; } else w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  unsigned tile = (unsigned)(w % ntile); size_t row = w / ntile;
+  if (row >= nrows) return;
+  unsigned x = (tile * 64 + (threadIdx.x & 63)) * 2;
+  if (x >= inner) return;
+  unsigned j = (unsigned)(row % nper);
+  size_t prev = j == 0 ? row : row - 1;
+  d2 a = *(const d2*)(in + row * inner + x);
+  d2 b = *(const d2*)(in + prev * inner + x);
+  st<true>((d2*)(out + row * inner + x), a - b);
+}
+template <int SEG, bool BAND>
+__global__ __launch_bounds__(256) void k_diffy_march_b(const double* __restrict__ in, double* __restrict__ out, size_t outer, unsigned n, unsigned inner, unsigned ntile, unsigned nb) {
+  size_t w;
+  if (BAND) { if (!banded(nb, w)) return; } else w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  unsigned nseg = (n + SEG - 1) / SEG;
+  unsigned tile = (unsigned)(w % ntile); size_t r = w / ntile; unsigned sg = (unsigned)(r % nseg); size_t o = r / nseg;
+  if (o >= outer) return;
+  unsigned x = (tile * 64 + (threadIdx.x & 63)) * 2;
+  if (x >= inner) return;
+  unsigned j0 = sg * SEG, j1 = j0 + SEG < n ? j0 + SEG : n;
+  const double* p = in + o * n * inner + x; double* q = out + o * n * inner + x;
+  d2 v[SEG + 1];
+  v[0] = *(const d2*)(p + (size_t)(j0 == 0 ? 0 : j0 - 1) * inner);
+#pragma unroll
+  for (int u = 0; u < SEG; ++u) if (j0 + u < j1) v[u + 1] = *(const d2*)(p + (size_t)(j0 + u) * inner);
+#pragma unroll
+  for (int u = 0; u < SEG; ++u) if (j0 + u < j1) st<true>((d2*)(q + (size_t)(j0 + u) * inner), v[u + 1] - v[u]);
+}
+
+__global__ void k_rand(double* out, size_t n) {
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    unsigned long long z = i + 0x9E3779B97F4A7C15ull * 2;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    out[i] = (double)(z >> 11) * 0x1.0p-53 - 0.5;
+  }
+}
+
+template <typename F> float timeit(F f, int reps = 8) {
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  f(); f(); CK(hipDeviceSynchronize());
+  std::vector<float> t;
+  for (int i = 0; i < reps; ++i) { CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); t.push_back(ms); }
+  std::sort(t.begin(), t.end());
+  return t[t.size() / 2];
+}
+
+int main() {
+  const size_t n = 75ull * 2400 * 3600;  // doubles
+  const size_t nvec = n / 2;
+  double *in, *out;
+  CK(hipMalloc(&in, n * 8)); CK(hipMalloc(&out, n * 8));
+  CK(hipMemset(out, 0, n * 8));
+  if (getenv("SB_CONST")) { CK(hipMemset(in, 1, n * 8)); printf("# input: constant bytes (outputs of diff are ZERO -> inflated rates)\n"); }
+  else { hipLaunchKernelGGL(k_rand, dim3(8192), dim3(256), 0, 0, in, n); CK(hipDeviceSynchronize()); printf("# input: uniform random doubles\n"); }
+  auto report = [&](const char* name, float ms) { printf("%-44s %8.4f ms  %8.1f GB/s  %.3f of 8TB/s\n", name, ms, 2.0 * n * 8 / ms / 1e6, 2.0 * n * 8 / ms / 1e6 / 8000); fflush(stdout); };
+  { float ms = timeit([&] { CK(hipMemcpyAsync(out, in, n * 8, hipMemcpyDeviceToDevice, 0)); }); report("hipMemcpy D2D", ms); }
+#define COPY(R, NTL, NTS, REMAP, BLOCK) { unsigned nblk = (unsigned)((nvec + (size_t)BLOCK * R - 1) / ((size_t)BLOCK * R)); \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_copy<R, NTL, NTS, REMAP, BLOCK>), dim3(nblk), dim3(BLOCK), 0, 0, (const d2*)in, (d2*)out, nvec, nblk); }); \
+    report("copy R=" #R " ntl=" #NTL " nts=" #NTS " remap=" #REMAP " blk=" #BLOCK, ms); }
+  COPY(1, false, false, false, 256) COPY(1, false, true, false, 256) COPY(2, false, true, false, 256) COPY(4, false, true, false, 256)
+  COPY(8, false, true, false, 256) COPY(16, false, true, false, 256) COPY(4, true, true, false, 256) COPY(4, false, true, true, 256)
+  COPY(8, false, true, true, 256) COPY(4, false, true, false, 512) COPY(4, false, true, false, 1024) COPY(8, false, true, false, 64)
+  COPY(8, false, false, false, 256)
+#define GS(R, NTS, BLOCK, NB) { float ms = timeit([&] { hipLaunchKernelGGL((k_copy_gs<R, NTS, BLOCK>), dim3(NB), dim3(BLOCK), 0, 0, (const d2*)in, (d2*)out, nvec); }); \
+    report("grid-stride R=" #R " nts=" #NTS " blk=" #BLOCK " blocks=" #NB, ms); }
+  GS(4, true, 256, 2048) GS(4, true, 256, 4096) GS(8, true, 256, 2048) GS(4, true, 512, 1024) GS(4, true, 1024, 512) GS(4, true, 256, 8192)
+#define DX(R, NTS) { const int L = 3600; size_t rows = n / L; unsigned ntile = (L / 2 + 63) / 64; size_t ntask = (size_t)ntile * ((rows + R - 1) / R); \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_diffx<R, NTS>), dim3((unsigned)((ntask + 3) / 4)), dim3(256), 0, 0, in, out, rows, L, ntile); }); report("diffx R=" #R " nts=" #NTS, ms); }
+  DX(2, true) DX(4, true) DX(8, true) DX(16, true) DX(8, false)
+
+  DX(1, true)
+  { unsigned vpr = 1800; float ms = timeit([&] { hipLaunchKernelGGL((k_diffx_flat<true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, in, out, nvec, vpr); }); report("diffx flat nts", ms); }
+#define DY2(BLOCK, NT, NPER, INNER, NAME) { size_t inner = INNER, nper = NPER, nrows = n / inner; unsigned ntile = (unsigned)((inner / 2 + 63) / 64); unsigned ntp = NT ? NT : ntile; \
+    size_t nw = (size_t)ntp * nrows; constexpr int WPB_ = BLOCK / 64; \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_diffy_two<true, BLOCK>), dim3((unsigned)((nw + WPB_ - 1) / WPB_)), dim3(BLOCK), 0, 0, in, out, nrows, nper, inner, ntp); }); report(NAME, ms); }
+  DY2(256, 0, 2400, 3600, "diffY two-load linear ntile=29 blk256")
+  DY2(256, 32, 2400, 3600, "diffY two-load linear ntile=32(xcd) blk256")
+  DY2(64, 32, 2400, 3600, "diffY two-load linear ntile=32(xcd) blk64")
+  DY2(64, 0, 2400, 3600, "diffY two-load linear ntile=29 blk64")
+  DY2(256, 0, 75, 8640000, "diffZ two-load linear blk256")
+#define DYM(SEG, OUTER, N, INNER, NAME) { size_t inner = INNER, nn = N, outer = OUTER; unsigned ntile = (unsigned)((inner / 2 + 63) / 64); unsigned nseg = (unsigned)((nn + SEG - 1) / SEG); \
+    size_t nw = (size_t)ntile * nseg * outer; \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_diffy_march<SEG, true>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0, 0, in, out, outer, nn, inner, ntile); }); report(NAME, ms); }
+  DYM(2, 75, 2400, 3600, "diffY march SEG=2") DYM(4, 75, 2400, 3600, "diffY march SEG=4") DYM(8, 75, 2400, 3600, "diffY march SEG=8") DYM(16, 75, 2400, 3600, "diffY march SEG=16") DYM(64, 75, 2400, 3600, "diffY march SEG=64")
+  DYM(75, 1, 75, 8640000, "diffZ march SEG=75") DYM(25, 1, 75, 8640000, "diffZ march SEG=25") DYM(15, 1, 75, 8640000, "diffZ march SEG=15")
+
+#define DY2B(BAND, NAME) { unsigned inner = 3600, nper = 2400; size_t nrows = n / inner; unsigned ntile = (inner / 2 + 63) / 64; size_t nw = (size_t)ntile * nrows; unsigned nb = (unsigned)((nw + 3) / 4); \
+    unsigned grid = BAND ? ((nb + 7) / 8) * 8 : nb; \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_diffy_two_b<BAND>), dim3(grid), dim3(256), 0, 0, in, out, nrows, nper, inner, ntile, nb); }); report(NAME, ms); }
+  DY2B(false, "diffY two-load (u32 math) plain") DY2B(true, "diffY two-load XCD-banded")
+#define DYMB(SEG, BAND, NAME) { unsigned inner = 3600, nn = 2400; size_t outer = 75; unsigned ntile = (inner / 2 + 63) / 64; unsigned nseg = (nn + SEG - 1) / SEG; \
+    size_t nw = (size_t)ntile * nseg * outer; unsigned nb = (unsigned)((nw + 3) / 4); unsigned grid = BAND ? ((nb + 7) / 8) * 8 : nb; \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_diffy_march_b<SEG, BAND>), dim3(grid), dim3(256), 0, 0, in, out, outer, nn, inner, ntile, nb); }); report(NAME, ms); }
+  DYMB(1, false, "diffY regmarch SEG=1 plain") DYMB(2, false, "diffY regmarch SEG=2 plain") DYMB(3, false, "diffY regmarch SEG=3 plain") DYMB(4, false, "diffY regmarch SEG=4 plain")
+  DYMB(6, false, "diffY regmarch SEG=6 plain")
+  DYMB(1, true, "diffY regmarch SEG=1 banded") DYMB(2, true, "diffY regmarch SEG=2 banded") DYMB(3, true, "diffY regmarch SEG=3 banded") DYMB(4, true, "diffY regmarch SEG=4 banded")
+  DYMB(8, true, "diffY regmarch SEG=8 banded")
+  return 0;
+}

@@ -63,8 +63,10 @@ struct Tune {
   int seg;       // rows marched per wave-task along a strided stencil axis
   int nt_store;  // non-temporal stores
   int nt_load;   // non-temporal loads
+  int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
   Tune() {
-    seg = env_int("XG_SEG", 64);
+    seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
+    seg = env_int("XG_SEG", 1 << 30);  // long march: whole column by default
     nt_store = env_int("XG_NT_STORE", 1);
     nt_load = env_int("XG_NT_LOAD", 0);
   }
@@ -78,6 +80,30 @@ const Tune& tune() {
 // geometry: a C-contiguous N-D array seen as (outer..., n, inner...) around the op axis,
 // with adjacent dims coalesced whenever every metric's strides allow it.
 // ------------------------------------------------------------------------------------------
+// Exact u32 division by a launch-time constant without a divide instruction (Granlund-Montgomery
+// round-up method): q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(n, m).  On wave-uniform
+// operands the compiler keeps all of it on the scalar unit (s_mul_hi_u32).
+struct FastDiv {
+  u32 d, m, s1, s2;
+};
+inline FastDiv make_fastdiv(u64 d64) {
+  FastDiv f = {1u, 1u, 0u, 0u};
+  if (d64 < 1) d64 = 1;
+  if (d64 > 0xffffffffull) d64 = 0xffffffffull;  // callers check idx32 before relying on it
+  const u32 d = (u32)d64;
+  u32 l = 0;
+  while ((1ull << l) < (u64)d) ++l;
+  f.d = d;
+  f.m = (u32)((((1ull << 32) * ((1ull << l) - (u64)d)) / (u64)d) + 1ull);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 1 ? l - 1 : 0;
+  return f;
+}
+__device__ __forceinline__ u32 fdiv(u32 n, const FastDiv& f) {
+  const u32 t = __umulhi(n, f.m);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
 struct MIdx {  // element strides of one metric in the coalesced coordinate system
   int64_t outer[MAXD];
   int64_t axis;
@@ -91,6 +117,8 @@ struct Geo {
   int64_t outer;  // prod(outer_shape)
   int64_t inner;  // prod(inner_shape)
   int64_t n_in, n_out;
+  int idx32;      // outer, inner, n_in, n_out all < 2^32: u32 index math + FastDiv allowed
+  FastDiv outer_fd[MAXD], inner_fd[MAXD];
 };
 
 // Build Geo (+ up to two MIdx) from the public (shape, ndim, axis, strides) description.
@@ -149,7 +177,11 @@ int build_geo(const int64_t* shape, int ndim, int axis, int64_t n_out, const int
   for (int i = 0; i < MAXD; ++i) {
     if (m1) { m1->outer[i] = o1[i]; m1->inner[i] = i1[i]; }
     if (m2) { m2->outer[i] = o2[i]; m2->inner[i] = i2[i]; }
+    g->outer_fd[i] = make_fastdiv(i < g->n_outer ? (u64)g->outer_shape[i] : 1);
+    g->inner_fd[i] = make_fastdiv(i < g->n_inner ? (u64)g->inner_shape[i] : 1);
   }
+  const int64_t lim = 0xffffffffll;
+  g->idx32 = (g->outer <= lim && g->inner <= lim && g->n_in <= lim && g->n_out <= lim) ? 1 : 0;
   return 0;
 }
 
@@ -217,6 +249,38 @@ __device__ __forceinline__ int64_t inner_off(const Geo& g, const MIdx& m, int64_
     }
   }
   return off;
+}
+
+// u32 variants (valid when g.idx32): no divide instructions
+__device__ __forceinline__ int64_t outer_off32(const Geo& g, const MIdx& m, u32 o) {
+  int64_t off = 0;
+#pragma unroll
+  for (int d = MAXD - 1; d >= 0; --d) {
+    if (d < g.n_outer) {
+      const u32 q = fdiv(o, g.outer_fd[d]);
+      off += (int64_t)(o - q * g.outer_fd[d].d) * m.outer[d];
+      o = q;
+    }
+  }
+  return off;
+}
+__device__ __forceinline__ int64_t inner_off32(const Geo& g, const MIdx& m, u32 x) {
+  int64_t off = 0;
+#pragma unroll
+  for (int d = MAXD - 1; d >= 0; --d) {
+    if (d < g.n_inner) {
+      const u32 q = fdiv(x, g.inner_fd[d]);
+      off += (int64_t)(x - q * g.inner_fd[d].d) * m.inner[d];
+      x = q;
+    }
+  }
+  return off;
+}
+__device__ __forceinline__ int64_t outer_offx(const Geo& g, const MIdx& m, int64_t o) {
+  return g.idx32 ? outer_off32(g, m, (u32)o) : outer_off(g, m, o);
+}
+__device__ __forceinline__ int64_t inner_offx(const Geo& g, const MIdx& m, int64_t x) {
+  return g.idx32 ? inner_off32(g, m, (u32)x) : inner_off(g, m, x);
 }
 
 // metric value(s) for a V-wide lane at metric offset `off` (second element `step` further on)
@@ -328,100 +392,140 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided(
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: stencil along the CONTIGUOUS (last) axis.  View (rows, L).  wave-task = (group of R rows,
-// x-tile); lane <-> V consecutive outputs.  V == 2 needs L_in == L_out even (pads (1,0)/(0,1)):
-// one aligned 16-B load + one 8-B neighbour load (same cache lines, L1-served) per lane per row.
-// V == 1 is the general path (any pads, odd lengths, N+1 / N-1 outputs).
+// Linear-order stencil kernels.  Measured on MI355X (profiles/r01_streambench_*.txt): a kernel
+// whose threads each move ONE 16-byte vector, with thread id == linear memory order, streams at
+// the copy ceiling (~79 % of 8 TB/s); giving a thread several rows/tiles costs 10-25 %.  So the
+// output is walked as a flat list of V-wide items: item -> (row, position) by one 32-bit
+// division (the host splits launches so that item counts stay below 2^31).
+//
+// K1: stencil along the CONTIGUOUS (last) axis, view (rows, L).
+//   V == 2: L_in == L_out even, pads (1,0) or (0,1): one aligned 16-B load + one 8-B neighbour
+//           load that hits the same cache lines (L1-served), one 16-B store.
+//   V == 1: general path (any pads, odd lengths, N+1 / N-1 outputs): two 8-B loads.
 // ------------------------------------------------------------------------------------------
-template <int OP, int V, int MET, bool NTL, bool NTS>
+template <int OP, int V, int MET, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
-    const double* __restrict__ in, double* __restrict__ out, Geo g, u32 ntile, int pad_lo,
-    int pad_hi, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
+    const double* __restrict__ in, double* __restrict__ out, Geo g, int64_t row0, u32 nrows, FastDiv per,
+    int pad_lo, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
     const double* __restrict__ m_out, MIdx mo) {
-  typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
-  constexpr int R = 8;
-
-  const u64 w = wave_id();
-  const u32 tile = (u32)(w % ntile);
-  const int64_t r0 = (int64_t)(w / ntile) * R;
-  if (r0 >= g.outer) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t i0 = ((int64_t)tile * WAVE + lane) * V;
-  const int64_t Li = g.n_in, Lo = g.n_out;
-  if (i0 >= Lo) return;
-  const int nrow = (g.outer - r0 < R) ? (int)(g.outer - r0) : R;
+  const u32 gid = blockIdx.x * BLOCK + threadIdx.x;
+  const u32 r = fdiv(gid, per);  // per.d = V-wide items per output row
+  if (r >= nrows) return;
+  const u32 i0 = (gid - r * per.d) * V;
+  const u32 Li = (u32)g.n_in, Lo = (u32)g.n_out;  // host guarantees row lengths < 2^31
+  const double* prow = in + (row0 * (int64_t)Li + (u64)r * Li);
+  double* orow = out + (row0 * (int64_t)Lo + (u64)r * Lo);
+  int64_t mib = 0, mob = 0;
+  if (HAS_MI) mib = outer_offx(g, mi, row0 + r);
+  if (HAS_MO) mob = outer_offx(g, mo, row0 + r);
 
   if (V == 2) {
-    // neighbour index inside the row and whether it is a halo cell
-    int64_t nidx;
+    u32 nidx;
     bool edge;
     if (pad_lo) { edge = (i0 == 0); nidx = edge ? ((bc == XG_BC_PERIODIC) ? Li - 1 : 0) : i0 - 1; }
     else { edge = (i0 + 2 == Li); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : Li - 1) : i0 + 2; }
-    const bool fill_edge = edge && (bc == XG_BC_FILL);
-    d2 pr[R];
-    double nb[R];
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-      if (u < nrow) {
-        const double* prow = in + (r0 + u) * Li;
-        pr[u] = ldg<d2, NTL>(prow + i0);
-        nb[u] = prow[nidx];
-      }
+    d2 a = *reinterpret_cast<const d2*>(prow + i0);
+    double n = prow[nidx];
+    if (HAS_MI) {
+      a.x = a.x * m_in[mib + (int64_t)i0 * mi.axis];
+      a.y = a.y * m_in[mib + (int64_t)(i0 + 1) * mi.axis];
+      n = n * m_in[mib + (int64_t)nidx * mi.axis];
     }
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-      if (u < nrow) {
-        d2 a = pr[u];
-        double n = nb[u];
-        if (HAS_MI) {
-          int64_t mb = outer_off(g, mi, r0 + u);
-          a.x = a.x * m_in[mb + i0 * mi.axis];
-          a.y = a.y * m_in[mb + (i0 + 1) * mi.axis];
-          n = n * m_in[mb + nidx * mi.axis];
-        }
-        if (fill_edge) n = fill;
-        d2 res;
-        if (pad_lo) { res.x = op2<OP>(n, a.x); res.y = op2<OP>(a.x, a.y); }
-        else { res.x = op2<OP>(a.x, a.y); res.y = op2<OP>(a.y, n); }
-        if (HAS_MO) {
-          int64_t mb = outer_off(g, mo, r0 + u);
-          res.x = res.x / m_out[mb + i0 * mo.axis];
-          res.y = res.y / m_out[mb + (i0 + 1) * mo.axis];
-        }
-        stg<d2, NTS>(out + (r0 + u) * Lo + i0, res);
-      }
+    if (edge && bc == XG_BC_FILL) n = fill;
+    d2 res;
+    if (pad_lo) { res.x = op2<OP>(n, a.x); res.y = op2<OP>(a.x, a.y); }
+    else { res.x = op2<OP>(a.x, a.y); res.y = op2<OP>(a.y, n); }
+    if (HAS_MO) {
+      res.x = res.x / m_out[mob + (int64_t)i0 * mo.axis];
+      res.y = res.y / m_out[mob + (int64_t)(i0 + 1) * mo.axis];
     }
+    stg<d2, NTS>(orow + i0, res);
   } else {
-    // general scalar path: out[i] = OP(P(i), P(i+1)), q = k - pad_lo
-    int64_t ql = i0 - pad_lo, qr = i0 + 1 - pad_lo;
+    int64_t ql = (int64_t)i0 - pad_lo, qr = (int64_t)i0 + 1 - pad_lo;
     bool fl = false, fr = false;
-    if (ql < 0) { fl = (bc == XG_BC_FILL); ql = (bc == XG_BC_PERIODIC) ? Li - 1 : 0; }
-    if (qr >= Li) { fr = (bc == XG_BC_FILL); qr = (bc == XG_BC_PERIODIC) ? 0 : Li - 1; }
-    double lv[R], rv[R];
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-      if (u < nrow) {
-        const double* prow = in + (r0 + u) * Li;
-        lv[u] = prow[ql];
-        rv[u] = prow[qr];
-      }
+    if (ql < 0) { fl = (bc == XG_BC_FILL); ql = (bc == XG_BC_PERIODIC) ? (int64_t)Li - 1 : 0; }
+    if (qr >= (int64_t)Li) { fr = (bc == XG_BC_FILL); qr = (bc == XG_BC_PERIODIC) ? 0 : (int64_t)Li - 1; }
+    double l = prow[ql], rr = prow[qr];
+    if (HAS_MI) {
+      l = l * m_in[mib + ql * mi.axis];
+      rr = rr * m_in[mib + qr * mi.axis];
     }
+    if (fl) l = fill;
+    if (fr) rr = fill;
+    double res = op2<OP>(l, rr);
+    if (HAS_MO) res = res / m_out[mob + (int64_t)i0 * mo.axis];
+    stg<double, NTS>(orow + i0, res);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2S: stencil along a STRIDED axis, the small-row case (few x-tiles per row, e.g. Y of a
+// (Z,Y,X) field).  Measured on MI355X with random data (profiles/r01_streambench_d_*.txt):
+//   * the set of rows in flight must stay compact: each wave register-marches only SEG (= 4)
+//     rows -- SEG+1 independent 16-B loads, then SEG stores -- instead of a long segment;
+//   * the halo row a segment re-reads must come from the SAME XCD's L2: workgroup b runs on XCD
+//     b % 8 (observed dispatch rule, used for speed only), so the linear wave sequence is cut
+//     into 8 contiguous bands, one per XCD ("banding").  Each XCD then streams one compact
+//     address range and its re-reads never cross the fabric.  6.3 TB/s vs 5.1 TB/s without.
+// One wave = one x-tile of one SEG-row segment; the (outer, segment, tile) split and all row
+// bases are wave-uniform (scalar unit, FastDiv).
+// ------------------------------------------------------------------------------------------
+template <int OP, int V, int MET, bool NTS, int SEG>
+__global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
+    const double* __restrict__ in, double* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk,
+    FastDiv ntile, FastDiv nseg, int pad_lo, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
+    const double* __restrict__ m_out, MIdx mo) {
+  typedef typename VecT<V>::type T;
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  // banding: XCD (b % 8) owns logical blocks [xcd * pb, (xcd + 1) * pb)
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
+  const u32 r = fdiv(w, ntile);
+  const u32 tile = w - r * ntile.d;
+  const u32 oo = fdiv(r, nseg);
+  if (oo >= nouter) return;
+  const u32 sg = r - oo * nseg.d;
+  const int64_t o = o0 + oo;
+  const int64_t inner = g.inner;
+  const int64_t x = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
+  if (x >= inner) return;
+  const int64_t j0 = (int64_t)sg * SEG;
+  const int64_t nrow = (g.n_out - j0 < SEG) ? g.n_out - j0 : SEG;  // rows this segment really has
+  const double* pin = in + (o * g.n_in) * inner + x;
+  double* pout = out + (o * g.n_out + j0) * inner + x;
+
+  int64_t mib = 0, mob = 0, mis = 0, mos = 0;
+  if (HAS_MI) {
+    mib = outer_offx(g, mi, o) + inner_offx(g, mi, x);
+    mis = (V == 2) ? inner_offx(g, mi, x + 1) - inner_offx(g, mi, x) : 0;
+  }
+  if (HAS_MO) {
+    mob = outer_offx(g, mo, o) + inner_offx(g, mo, x) + j0 * mo.axis;
+    mos = (V == 2) ? inner_offx(g, mo, x + 1) - inner_offx(g, mo, x) : 0;
+  }
+
+  // padded index k = j0 + u  ->  input row q (wave-uniform), fill flag
+  T v[SEG + 1];
 #pragma unroll
-    for (int u = 0; u < R; ++u) {
-      if (u < nrow) {
-        double l = lv[u], rr = rv[u];
-        if (HAS_MI) {
-          int64_t mb = outer_off(g, mi, r0 + u);
-          l = l * m_in[mb + ql * mi.axis];
-          rr = rr * m_in[mb + qr * mi.axis];
-        }
-        if (fl) l = fill;
-        if (fr) rr = fill;
-        double res = op2<OP>(l, rr);
-        if (HAS_MO) res = res / m_out[outer_off(g, mo, r0 + u) + i0 * mo.axis];
-        stg<double, NTS>(out + (r0 + u) * Lo + i0, res);
-      }
+  for (int u = 0; u <= SEG; ++u) {
+    int64_t k = j0 + ((u <= nrow) ? u : nrow);  // clamp inside the padded range for short tails
+    int64_t q = k - pad_lo;
+    bool f = false;
+    if (q < 0) { f = (bc == XG_BC_FILL); q = (bc == XG_BC_PERIODIC) ? g.n_in - 1 : 0; }
+    else if (q >= g.n_in) { f = (bc == XG_BC_FILL); q = (bc == XG_BC_PERIODIC) ? 0 : g.n_in - 1; }
+    T t = *reinterpret_cast<const T*>(pin + q * inner);
+    if (HAS_MI) t = t * ldm<T>(m_in, mib + q * mi.axis, mis);
+    v[u] = f ? splat<T>(fill) : t;
+  }
+#pragma unroll
+  for (int u = 0; u < SEG; ++u) {
+    if (u < nrow) {
+      T res = op2<OP>(v[u], v[u + 1]);
+      if (HAS_MO) res = res / ldm<T>(m_out, mob + u * mo.axis, mos);
+      stg<T, NTS>(pout + u * inner, res);
     }
   }
 }
@@ -835,58 +939,96 @@ inline int check_grid(u64 nblocks) {
   } while (0)
 
 // dispatch on (OP, V, MET, NT) -> template instance
+struct StencilCall {
+  const double* in; double* out; Geo g; int pad_lo, pad_hi, bc; double fill;
+  const double* m_in; MIdx mi; const double* m_out; MIdx mo; hipStream_t st;
+};
+
+// marching kernel (one HBM read per cell whatever the plane size)
 template <int OP, int V, int MET>
-int launch_stencil_strided(u64 nblocks, hipStream_t st, const double* in, double* out, const Geo& g, int seg,
-                           u32 nseg, u32 ntile, int pad_lo, int bc, double fill, const double* m_in,
-                           const MIdx& mi, const double* m_out, const MIdx& mo) {
-  const bool ntl = tune().nt_load, nts = tune().nt_store;
-#define XG_GO(NTL, NTS)                                                                              \
-  hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, NTL, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, \
-                     out, g, seg, nseg, ntile, pad_lo, bc, fill, m_in, mi, m_out, mo)
-  if (ntl) { if (nts) XG_GO(true, true); else XG_GO(true, false); }
-  else { if (nts) XG_GO(false, true); else XG_GO(false, false); }
-#undef XG_GO
-  XG_LAUNCH_CHECK();
+int launch_march(const StencilCall& c) {
+  int seg = tune().seg < 1 ? 1 : tune().seg;
+  const u32 nseg = (u32)((c.g.n_out + seg - 1) / seg);
+  const u32 ntile = (u32)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
+  const u64 ntask = (u64)ntile * nseg * (u64)c.g.outer;
+  const u64 nblocks = (ntask + WPB - 1) / WPB;
+  if (nblocks == 0 || nblocks > 0x7fffffffull) return fail(XG_ERR_UNSUPPORTED, "launch of %llu blocks exceeds grid limits", nblocks);
+  if (tune().nt_store)
+    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+  else
+    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
   return 0;
 }
 
-template <int OP, int V, int MET>
-int launch_stencil_contig(u64 nblocks, hipStream_t st, const double* in, double* out, const Geo& g, u32 ntile,
-                          int pad_lo, int pad_hi, int bc, double fill, const double* m_in, const MIdx& mi,
-                          const double* m_out, const MIdx& mo) {
-  const bool ntl = tune().nt_load, nts = tune().nt_store;
-#define XG_GO(NTL, NTS)                                                                             \
-  hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, NTL, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, \
-                     out, g, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo)
-  if (ntl) { if (nts) XG_GO(true, true); else XG_GO(true, false); }
-  else { if (nts) XG_GO(false, true); else XG_GO(false, false); }
-#undef XG_GO
-  XG_LAUNCH_CHECK();
-  return 0;
-}
+// linear-order kernels: split the rows into launches of < 2^31 items
+constexpr u64 MAX_ITEMS = 0x7fffff00ull;
 
-template <int OP, int V>
-int stencil_met(bool contig, int met, u64 nblocks, hipStream_t st, const double* in, double* out, const Geo& g,
-                int seg, u32 nseg, u32 ntile, int pad_lo, int pad_hi, int bc, double fill, const double* m_in,
-                const MIdx& mi, const double* m_out, const MIdx& mo) {
-#define XG_M(M)                                                                                               \
-  return contig ? launch_stencil_contig<OP, V, M>(nblocks, st, in, out, g, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo) \
-                : launch_stencil_strided<OP, V, M>(nblocks, st, in, out, g, seg, nseg, ntile, pad_lo, bc, fill, m_in, mi, m_out, mo)
-  switch (met) {
-    case 0: XG_M(0);
-    case 1: XG_M(1);
-    case 2: XG_M(2);
-    default: XG_M(3);
+template <int OP, int V, int MET>
+int launch_contig(const StencilCall& c) {
+  const u64 per = (u64)((c.g.n_out + V - 1) / V);
+  if (per > MAX_ITEMS || c.g.n_in > 0x7fffffffll) return fail(XG_ERR_UNSUPPORTED, "row of %llu items too long", per);
+  const FastDiv fper = make_fastdiv(per);
+  const u64 rows_per = MAX_ITEMS / per;
+  for (int64_t row0 = 0; row0 < c.g.outer; row0 += (int64_t)rows_per) {
+    const u32 nrows = (u32)((c.g.outer - row0 < (int64_t)rows_per) ? c.g.outer - row0 : (int64_t)rows_per);
+    const u32 nblocks = (u32)(((u64)nrows * per + BLOCK - 1) / BLOCK);
+    if (tune().nt_store)
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, true>), dim3(nblocks), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, row0, nrows, fper, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+    else
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, false>), dim3(nblocks), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, row0, nrows, fper, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
   }
-#undef XG_M
+  return 0;
 }
 
+template <int OP, int V, int MET>
+int launch_seg(const StencilCall& c) {
+  constexpr int SEG = 4;
+  const u64 ntile = (u64)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
+  const u64 nseg = (u64)((c.g.n_out + SEG - 1) / SEG);
+  const u64 per_outer = ntile * nseg;  // waves per outer index
+  if (per_outer > MAX_ITEMS) return fail(XG_ERR_UNSUPPORTED, "extent too large for the segment kernel");
+  const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
+  const u64 outer_per = MAX_ITEMS / per_outer;
+  for (int64_t o0 = 0; o0 < c.g.outer; o0 += (int64_t)outer_per) {
+    const u32 nouter = (u32)((c.g.outer - o0 < (int64_t)outer_per) ? c.g.outer - o0 : (int64_t)outer_per);
+    const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
+    const u32 grid = ((nblk + 7) / 8) * 8;
+    if (tune().nt_store)
+      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+    else
+      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+  }
+  return 0;
+}
+
+enum StencilKind { KIND_CONTIG = 0, KIND_LIN = 1, KIND_MARCH = 2 };
+
+template <int OP, int V, int MET>
+int stencil_kind(int kind, const StencilCall& c) {
+  if (kind == KIND_CONTIG) return launch_contig<OP, V, MET>(c);
+  if (kind == KIND_LIN) return launch_seg<OP, V, MET>(c);
+  return launch_march<OP, V, MET>(c);
+}
+template <int OP, int V>
+int stencil_met(int met, int kind, const StencilCall& c) {
+  switch (met) {
+    case 0: return stencil_kind<OP, V, 0>(kind, c);
+    case 1: return stencil_kind<OP, V, 1>(kind, c);
+    case 2: return stencil_kind<OP, V, 2>(kind, c);
+    default: return stencil_kind<OP, V, 3>(kind, c);
+  }
+}
 template <int OP>
-int stencil_vec(int V, bool contig, int met, u64 nblocks, hipStream_t st, const double* in, double* out,
-                const Geo& g, int seg, u32 nseg, u32 ntile, int pad_lo, int pad_hi, int bc, double fill,
-                const double* m_in, const MIdx& mi, const double* m_out, const MIdx& mo) {
-  if (V == 2) return stencil_met<OP, 2>(contig, met, nblocks, st, in, out, g, seg, nseg, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo);
-  return stencil_met<OP, 1>(contig, met, nblocks, st, in, out, g, seg, nseg, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo);
+int stencil_vec(int V, int met, int kind, const StencilCall& c) {
+  return V == 2 ? stencil_met<OP, 2>(met, kind, c) : stencil_met<OP, 1>(met, kind, c);
+}
+int stencil_dispatch(int op, int V, int met, int kind, const StencilCall& c) {
+  switch (op) {
+    case XG_OP_DIFF: return stencil_vec<XG_OP_DIFF>(V, met, kind, c);
+    case XG_OP_INTERP: return stencil_vec<XG_OP_INTERP>(V, met, kind, c);
+    case XG_OP_MIN: return stencil_vec<XG_OP_MIN>(V, met, kind, c);
+    default: return stencil_vec<XG_OP_MAX>(V, met, kind, c);
+  }
 }
 
 inline u32 ceil_div_u32(int64_t a, int64_t b) { return (u32)((a + b - 1) / b); }
@@ -953,31 +1095,23 @@ int xg_stencil1d_f64(int op, const double* in, double* out, const int64_t* shape
   if (g.n_in < 1) return fail(XG_ERR_INVALID, "empty stencil axis");
   if (g.outer == 0 || g.inner == 0 || n_out <= 0) return XG_OK;  // empty output
   const int met = (m_out ? 1 : 0) | (m_in ? 2 : 0);
-  hipStream_t st = (hipStream_t)stream;
   const bool al = aligned16(in) && aligned16(out);
+  StencilCall c = {in, out, g, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo, (hipStream_t)stream};
+  int V, kind;
   if (g.inner == 1) {
-    // contiguous axis: rows = outer
-    const int V = (al && (g.n_in % 2 == 0) && (n_out % 2 == 0)) ? 2 : 1;
-    const u32 ntile = ceil_div_u32(n_out, (int64_t)WAVE * V);
-    const u64 ntask = (u64)ntile * (u64)((g.outer + 7) / 8);
-    const u64 nblocks = (ntask + WPB - 1) / WPB;
-    if ((rc = check_grid(nblocks))) return rc;
-#define XG_OPC(O) case O: return stencil_vec<O>(V, true, met, nblocks, st, in, out, g, 0, 1, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo)
-    switch (op) { XG_OPC(XG_OP_DIFF); XG_OPC(XG_OP_INTERP); XG_OPC(XG_OP_MIN); default: XG_OPC(XG_OP_MAX); }
-#undef XG_OPC
+    kind = KIND_CONTIG;
+    V = (al && (g.n_in % 2 == 0) && (n_out % 2 == 0)) ? 2 : 1;
   } else {
-    const int V = (al && (g.inner % 2 == 0)) ? 2 : 1;
-    int seg = tune().seg;
-    if (seg < 1) seg = 1;
-    const u32 nseg = ceil_div_u32(n_out, seg);
-    const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
-    const u64 ntask = (u64)ntile * nseg * (u64)g.outer;
-    const u64 nblocks = (ntask + WPB - 1) / WPB;
-    if ((rc = check_grid(nblocks))) return rc;
-#define XG_OPC(O) case O: return stencil_vec<O>(V, false, met, nblocks, st, in, out, g, seg, nseg, ntile, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo)
-    switch (op) { XG_OPC(XG_OP_DIFF); XG_OPC(XG_OP_INTERP); XG_OPC(XG_OP_MIN); default: XG_OPC(XG_OP_MAX); }
-#undef XG_OPC
+    V = (al && (g.inner % 2 == 0)) ? 2 : 1;
+    // few x-tiles per row (Y of a (Z,Y,X) field): short banded segments keep the rows in flight
+    // compact.  Many tiles per row (Z: a whole plane per row): all waves in flight already sit
+    // in the same rows, so march the full column and never re-read a halo row.
+    const int64_t ntile = (g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V);
+    kind = (ntile <= (int64_t)tune().seg_max_tiles) ? KIND_LIN : KIND_MARCH;
   }
+  rc = stencil_dispatch(op, V, met, kind, c);
+  if (rc) return rc;
+  XG_LAUNCH_CHECK();
   return XG_OK;
 }
 
