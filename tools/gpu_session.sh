@@ -19,8 +19,6 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/prof_write_$TAG -o
 cd $REPO
 find $OUT/prof_stats_$TAG $OUT/prof_fetch_$TAG $OUT/prof_write_$TAG -type f | head -30
 python tools/summarize_prof.py $OUT $TAG 2>&1 | tee $OUT/prof_summary_$TAG.txt
-echo "== sweeps"
-for seg in 16 32 128 512; do XG_SEG=$seg timeout 120 python tools/microbench.py --reps 7 --cases stencil >> $OUT/mb_sweep_$TAG.jsonl 2>&1; done
-XG_NT_LOAD=1 timeout 120 python tools/microbench.py --reps 7 --cases stencil,cumsum,reduce >> $OUT/mb_sweep_$TAG.jsonl 2>&1
-XG_NT_STORE=0 timeout 120 python tools/microbench.py --reps 7 --cases stencil,cumsum >> $OUT/mb_sweep_$TAG.jsonl 2>&1
-grep -E "diff_X_per|diff_Y|diff_Z|cumsum_Z|integrate_Z" $OUT/mb_sweep_$TAG.jsonl
+echo "== microbench (all kernels, random data)"
+timeout 300 python tools/microbench.py --reps 9 > $OUT/mb_full_$TAG.jsonl 2>&1
+grep -v amdgpu.ids $OUT/mb_full_$TAG.jsonl
