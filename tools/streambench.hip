@@ -154,6 +154,40 @@ __global__ __launch_bounds__(256) void k_diffy_march_b(const double* __restrict_
   for (int u = 0; u < SEG; ++u) if (j0 + u < j1) st<true>((d2*)(q + (size_t)(j0 + u) * inner), v[u + 1] - v[u]);
 }
 
+
+// Z-march with big workgroups kept in lockstep by barriers (DRAM page locality experiment)
+template <int BLK, int U, bool SYNC, bool BAND>
+__global__ __launch_bounds__(BLK) void k_diffz_march(const double* __restrict__ in, double* __restrict__ out, unsigned n, size_t inner, unsigned nblk) {
+  unsigned b = blockIdx.x;
+  if (BAND) { unsigned pb = (nblk + 7) / 8; b = (b % 8) * pb + b / 8; if (b >= nblk) return; }
+  size_t x = ((size_t)b * BLK + threadIdx.x) * 2;
+  bool act = x < inner;
+  const double* p = in + (act ? x : 0); double* q = out + (act ? x : 0);
+  d2 prev = *(const d2*)p;
+  for (unsigned j = 0; j < n; j += U) {
+    d2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (j + u < n) v[u] = *(const d2*)(p + (size_t)(j + u) * inner);
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (j + u < n) { if (act) st<true>((d2*)(q + (size_t)(j + u) * inner), v[u] - prev); prev = v[u]; }
+    if (SYNC) __syncthreads();
+  }
+}
+template <bool BAND>
+__global__ __launch_bounds__(256) void k_diffx_flat_b(const double* __restrict__ in, double* __restrict__ out, size_t nvec, unsigned vpr, unsigned nblk) {
+  unsigned b = blockIdx.x;
+  if (BAND) { unsigned pb = (nblk + 7) / 8; b = (b % 8) * pb + b / 8; if (b >= nblk) return; }
+  size_t gid = (size_t)b * 256 + threadIdx.x;
+  if (gid >= nvec) return;
+  size_t row = gid / vpr; unsigned xv = (unsigned)(gid - row * vpr);
+  unsigned L = vpr * 2, i0 = xv * 2;
+  const double* p = in + row * L;
+  unsigned nidx = i0 == 0 ? L - 1 : i0 - 1;
+  d2 a = *(const d2*)(p + i0); double nb = p[nidx];
+  d2 o; o.x = a.x - nb; o.y = a.y - a.x;
+  st<true>((d2*)(out + row * L + i0), o);
+}
+
 __global__ void k_rand(double* out, size_t n) {
   size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -223,5 +257,15 @@ int main() {
   DYMB(6, false, "diffY regmarch SEG=6 plain")
   DYMB(1, true, "diffY regmarch SEG=1 banded") DYMB(2, true, "diffY regmarch SEG=2 banded") DYMB(3, true, "diffY regmarch SEG=3 banded") DYMB(4, true, "diffY regmarch SEG=4 banded")
   DYMB(8, true, "diffY regmarch SEG=8 banded")
+
+#define DZ(BLK, U, SYNC, BAND, NAME) { size_t inner = 8640000; unsigned nn = 75; unsigned nblk = (unsigned)((inner / 2 + BLK - 1) / BLK); unsigned grid = BAND ? ((nblk + 7) / 8) * 8 : nblk; \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_diffz_march<BLK, U, SYNC, BAND>), dim3(grid), dim3(BLK), 0, 0, in, out, nn, inner, nblk); }); report(NAME, ms); }
+  DZ(256, 8, false, false, "diffZ march blk256 U8") DZ(256, 5, false, false, "diffZ march blk256 U5") DZ(256, 3, false, false, "diffZ march blk256 U3")
+  DZ(256, 8, false, true, "diffZ march blk256 U8 banded") DZ(1024, 8, false, false, "diffZ march blk1024 U8") DZ(1024, 8, true, false, "diffZ march blk1024 U8 sync")
+  DZ(1024, 4, true, false, "diffZ march blk1024 U4 sync") DZ(512, 5, true, false, "diffZ march blk512 U5 sync") DZ(1024, 5, true, true, "diffZ march blk1024 U5 sync banded")
+  DZ(64, 8, false, false, "diffZ march blk64 U8") DZ(256, 15, false, false, "diffZ march blk256 U15")
+  { unsigned vpr = 1800; unsigned nblk = (unsigned)((nvec + 255) / 256); 
+    float ms = timeit([&] { hipLaunchKernelGGL((k_diffx_flat_b<false>), dim3(nblk), dim3(256), 0, 0, in, out, nvec, vpr, nblk); }); report("diffx flat plain", ms);
+    ms = timeit([&] { hipLaunchKernelGGL((k_diffx_flat_b<true>), dim3(((nblk + 7) / 8) * 8), dim3(256), 0, 0, in, out, nvec, vpr, nblk); }); report("diffx flat banded", ms); }
   return 0;
 }

@@ -64,7 +64,9 @@ struct Tune {
   int nt_store;  // non-temporal stores
   int nt_load;   // non-temporal loads
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
+  int zband;          // band-major row order when all metrics are broadcast along the slowest dim
   Tune() {
+    zband = env_int("XG_ZBAND", 1);
     seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
     seg = env_int("XG_SEG", 1 << 30);  // long march: whole column by default
     nt_store = env_int("XG_NT_STORE", 1);
@@ -102,6 +104,34 @@ inline FastDiv make_fastdiv(u64 d64) {
 __device__ __forceinline__ u32 fdiv(u32 n, const FastDiv& f) {
   const u32 t = __umulhi(n, f.m);
   return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
+// "z-banding": when every metric of a launch is broadcast along the slowest outer dim (a 2-D
+// dx(Y,X) weighting a (Z,Y,X) field), rows are visited band by band -- all Z levels of a band of
+// B rows before the next band -- so the band's metric values are fetched once and then served by
+// the XCD's L2 for the other Z-1 levels instead of being re-read from the Infinity Cache per level.
+struct ZBand {
+  u32 on, Z, B, Y;       // Y = rows (or segments) per level, B = rows (segments) per band
+  FastDiv per_band, fB;  // divisors Z*B and B
+};
+inline ZBand make_zband(bool on, u64 Z, u64 Y, u32 B) {
+  ZBand z;
+  memset(&z, 0, sizeof(z));
+  z.per_band = make_fastdiv(1);
+  z.fB = make_fastdiv(1);
+  if (!on || Z < 2 || Z * (u64)B > 0x7fffffffull) return z;
+  z.on = 1; z.Z = (u32)Z; z.B = B; z.Y = (u32)Y;
+  z.per_band = make_fastdiv(Z * B);
+  z.fB = make_fastdiv(B);
+  return z;
+}
+// work index r (band-major) -> (z, y); false if the band's tail row does not exist
+__device__ __forceinline__ bool zband_map(const ZBand& zb, u32 r, u32& z, u32& y) {
+  const u32 b = fdiv(r, zb.per_band);
+  const u32 rem = r - b * zb.per_band.d;
+  z = fdiv(rem, zb.fB);
+  y = b * zb.B + (rem - z * zb.B);
+  return y < zb.Y;
 }
 
 struct MIdx {  // element strides of one metric in the coalesced coordinate system
@@ -405,14 +435,24 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided(
 // ------------------------------------------------------------------------------------------
 template <int OP, int V, int MET, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
-    const double* __restrict__ in, double* __restrict__ out, Geo g, int64_t row0, u32 nrows, FastDiv per,
-    int pad_lo, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
+    const double* __restrict__ in, double* __restrict__ out, Geo g, int64_t row0, u32 nrows, u32 nblk, FastDiv per,
+    ZBand zb, int pad_lo, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
     const double* __restrict__ m_out, MIdx mo) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
-  const u32 gid = blockIdx.x * BLOCK + threadIdx.x;
-  const u32 r = fdiv(gid, per);  // per.d = V-wide items per output row
+  // XCD banding (see K2S): neighbouring workgroups share an L2, so the cache line holding a
+  // workgroup's left neighbour is not fetched a second time by another XCD (-3 % HBM reads)
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 gid = lb * BLOCK + threadIdx.x;
+  u32 r = fdiv(gid, per);  // per.d = V-wide items per output row
   if (r >= nrows) return;
   const u32 i0 = (gid - r * per.d) * V;
+  if (MET != 0 && zb.on) {
+    u32 z, y;
+    if (!zband_map(zb, r, z, y)) return;
+    r = z * zb.Y + y;
+  }
   const u32 Li = (u32)g.n_in, Lo = (u32)g.n_out;  // host guarantees row lengths < 2^31
   const double* prow = in + (row0 * (int64_t)Li + (u64)r * Li);
   double* orow = out + (row0 * (int64_t)Lo + (u64)r * Lo);
@@ -474,8 +514,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
 template <int OP, int V, int MET, bool NTS, int SEG>
 __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
     const double* __restrict__ in, double* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk,
-    FastDiv ntile, FastDiv nseg, int pad_lo, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
-    const double* __restrict__ m_out, MIdx mo) {
+    FastDiv ntile, FastDiv nseg, ZBand zb, int pad_lo, int bc, double fill, const double* __restrict__ m_in,
+    MIdx mi, const double* __restrict__ m_out, MIdx mo) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   // banding: XCD (b % 8) owns logical blocks [xcd * pb, (xcd + 1) * pb)
@@ -485,9 +525,14 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
   const u32 r = fdiv(w, ntile);
   const u32 tile = w - r * ntile.d;
-  const u32 oo = fdiv(r, nseg);
-  if (oo >= nouter) return;
-  const u32 sg = r - oo * nseg.d;
+  u32 oo, sg;
+  if (MET != 0 && zb.on) {  // band-major order over (segment band, outer, segment)
+    if (!zband_map(zb, r, oo, sg)) return;
+  } else {
+    oo = fdiv(r, nseg);
+    if (oo >= nouter) return;
+    sg = r - oo * nseg.d;
+  }
   const int64_t o = o0 + oo;
   const int64_t inner = g.inner;
   const int64_t x = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
@@ -967,13 +1012,25 @@ int launch_contig(const StencilCall& c) {
   if (per > MAX_ITEMS || c.g.n_in > 0x7fffffffll) return fail(XG_ERR_UNSUPPORTED, "row of %llu items too long", per);
   const FastDiv fper = make_fastdiv(per);
   const u64 rows_per = MAX_ITEMS / per;
-  for (int64_t row0 = 0; row0 < c.g.outer; row0 += (int64_t)rows_per) {
-    const u32 nrows = (u32)((c.g.outer - row0 < (int64_t)rows_per) ? c.g.outer - row0 : (int64_t)rows_per);
-    const u32 nblocks = (u32)(((u64)nrows * per + BLOCK - 1) / BLOCK);
+  // z-banding: outer dims (Z, Y) with every metric broadcast along Z, whole problem in one launch
+  const u32 ZB_ROWS = 16;
+  bool zb_ok = MET != 0 && tune().zband && c.g.n_outer == 2 && (!c.m_in || c.mi.outer[0] == 0) &&
+               (!c.m_out || c.mo.outer[0] == 0);
+  u64 work_rows = (u64)c.g.outer;
+  ZBand zb = make_zband(false, 0, 0, 1);
+  if (zb_ok) {
+    const u64 Z = (u64)c.g.outer_shape[0], Y = (u64)c.g.outer_shape[1];
+    const u64 padded = ((Y + ZB_ROWS - 1) / ZB_ROWS) * ZB_ROWS * Z;
+    if (padded <= rows_per) { zb = make_zband(true, Z, Y, ZB_ROWS); if (zb.on) work_rows = padded; }
+  }
+  for (u64 row0 = 0; row0 < work_rows; row0 += rows_per) {
+    const u32 nrows = (u32)((work_rows - row0 < rows_per) ? work_rows - row0 : rows_per);
+    const u32 nblk = (u32)(((u64)nrows * per + BLOCK - 1) / BLOCK);
+    const u32 grid = ((nblk + 7) / 8) * 8;
     if (tune().nt_store)
-      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, true>), dim3(nblocks), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, row0, nrows, fper, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
     else
-      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, false>), dim3(nblocks), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, row0, nrows, fper, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
   }
   return 0;
 }
@@ -987,14 +1044,33 @@ int launch_seg(const StencilCall& c) {
   if (per_outer > MAX_ITEMS) return fail(XG_ERR_UNSUPPORTED, "extent too large for the segment kernel");
   const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
   const u64 outer_per = MAX_ITEMS / per_outer;
+  // z-banding: a single outer dim along which every metric is broadcast, one launch
+  const u32 ZB_SEGS = 4;
+  const bool zb_ok = MET != 0 && tune().zband && c.g.n_outer == 1 && (!c.m_in || c.mi.outer[0] == 0) &&
+                     (!c.m_out || c.mo.outer[0] == 0);
+  if (zb_ok) {
+    const u64 padded_segs = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS;
+    const u64 waves = padded_segs * (u64)c.g.outer * ntile;
+    ZBand zb = make_zband(true, (u64)c.g.outer, nseg, ZB_SEGS);
+    if (zb.on && waves <= MAX_ITEMS) {
+      const u32 nblk = (u32)((waves + WPB - 1) / WPB);
+      const u32 grid = ((nblk + 7) / 8) * 8;
+      if (tune().nt_store)
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      else
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      return 0;
+    }
+  }
+  const ZBand zoff = make_zband(false, 0, 0, 1);
   for (int64_t o0 = 0; o0 < c.g.outer; o0 += (int64_t)outer_per) {
     const u32 nouter = (u32)((c.g.outer - o0 < (int64_t)outer_per) ? c.g.outer - o0 : (int64_t)outer_per);
     const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
     if (tune().nt_store)
-      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
     else
-      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
   }
   return 0;
 }
