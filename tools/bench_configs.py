@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""All BASELINE.json configs (2-5) at full size on ONE MI355X through the public Grid API.
+
+    python tools/bench_configs.py [--reps 7] [--records 8] [--configs 2,3,4,5]
+
+Not the judged bench line (that is bench.py = config 2); this is the per-config evidence table:
+ms, Gcell/s, algorithmic GB/s (bytes/cell of SURVEY.md section 8(d)) and fraction of 8 TB/s.
+Config 4 runs `--records` resident records of the 360 (the per-GPU batch of the sharded run;
+8 records = 5.2 G cells, which also exercises the > 2^32-element index paths); config 5 runs the
+whole 4320x4320x90 field on one GPU.
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from xgcm_amd import DataArray, Dataset, Grid  # noqa: E402
+from xgcm_amd import device as D  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn(); fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def rec(cfg, name, ms, cells, bpc):
+    gbs = cells * bpc / (ms * 1e-3) / 1e9
+    print(json.dumps({"config": cfg, "op": name, "ms": round(ms, 3), "gcell_s": round(cells / ms / 1e6, 2),
+                      "bytes_per_cell": round(bpc, 3), "GBps": round(gbs, 1), "frac_8TBps": round(gbs / 8000, 4)}), flush=True)
+
+
+def mitgcm_grid(nz, ny, nx, nt=None):
+    coords = {"XC": ("XC", np.arange(nx) + 0.5), "XG": ("XG", np.arange(nx) * 1.0),
+              "YC": ("YC", np.arange(ny) + 0.5), "YG": ("YG", np.arange(ny) * 1.0),
+              "Z": ("Z", np.arange(nz) + 0.5), "Zl": ("Zl", np.arange(nz) * 1.0), "Zp1": ("Zp1", np.arange(nz + 1) * 1.0)}
+    dv = {"dxC": DataArray(D.synthetic((ny, nx), 31, 0, 1000.0, 1000.0), ("YC", "XG")),
+          "dyC": DataArray(D.synthetic((ny, nx), 32, 0, 1000.0, 1000.0), ("YG", "XC")),
+          "rAz": DataArray(D.synthetic((ny, nx), 53, 0, 1000.0, 1000.0), ("YG", "XG")),
+          "drF": DataArray(D.synthetic((nz,), 33, 0, 1000.0, 1000.0), ("Z",)),
+          "drC": DataArray(D.synthetic((nz,), 34, 0, 1000.0, 1000.0), ("Zl",))}
+    ds = Dataset(dv, coords)
+    return Grid(ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"},
+                            "Z": {"center": "Z", "left": "Zl", "outer": "Zp1"}},
+                padding={"X": "periodic", "Y": "extend", "Z": "fill"},
+                metrics={("X",): ["dxC"], ("Y",): ["dyC"], ("Z",): ["drF", "drC"], ("X", "Y"): ["rAz"]},
+                autoparse_metadata=False)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--records", type=int, default=8)
+    ap.add_argument("--configs", default="2,3,4,5")
+    a = ap.parse_args()
+    cfgs = set(a.configs.split(","))
+    nz, ny, nx = 75, 2400, 3600
+    cells = nz * ny * nx
+    if cfgs & {"2", "3"}:
+        grid = mitgcm_grid(nz, ny, nx)
+        T = DataArray(D.synthetic((nz, ny, nx), 2), ("Z", "YC", "XC"))
+        if "2" in cfgs:
+            for fn in ("interp", "diff"):
+                rec(2, f"{fn}(T,'X') periodic", timeit(lambda: getattr(grid, fn)(T, "X"), a.reps), cells, 16)
+                rec(2, f"{fn}(T,'Y') extend", timeit(lambda: getattr(grid, fn)(T, "Y"), a.reps), cells, 16)
+        if "3" in cfgs:
+            rec(3, "derivative(T,'X') / dxC(YC,XG)", timeit(lambda: grid.derivative(T, "X"), a.reps), cells, 16 + 8 / nz)
+            rec(3, "derivative(T,'Y') / dyC(YG,XC)", timeit(lambda: grid.derivative(T, "Y"), a.reps), cells, 16 + 8 / nz)
+            rec(3, "derivative(T,'Z') / drC(Zl)", timeit(lambda: grid.derivative(T, "Z"), a.reps), cells, 16)
+            rec(3, "integrate(T,'Z') * drF(Z)", timeit(lambda: grid.integrate(T, "Z"), a.reps), cells, 8 + 8 / nz)
+        del T, grid
+        torch.cuda.empty_cache()
+    if "4" in cfgs:
+        nt = a.records
+        grid = mitgcm_grid(nz, ny, nx)
+        T4 = DataArray(D.synthetic((nt, nz, ny, nx), 4), ("time", "Z", "YC", "XC"))
+        c4 = nt * cells
+        rec(4, f"cumsum(T,'Z') center->left fill, {nt} records ({c4 / 1e9:.2f} Gcell)", timeit(lambda: grid.cumsum(T4, "Z"), a.reps), c4, 16)
+        rec(4, f"cumsum(T,'Z') center->outer fill, {nt} records", timeit(lambda: grid.cumsum(T4, "Z", to="outer"), a.reps), c4, 16)
+        rec(4, f"diff(T,'X') periodic, {nt} records (>2^32 cells)", timeit(lambda: grid.diff(T4, "X"), a.reps), c4, 16)
+        # spot parity on the last record (exercises 64-bit offsets): recompute it alone
+        last = DataArray(T4.data[nt - 1].contiguous(), ("Z", "YC", "XC"))
+        ok = bool(torch.equal(grid.cumsum(T4, "Z").data[nt - 1], grid.cumsum(last, "Z").data)
+                  and torch.equal(grid.diff(T4, "X").data[nt - 1], grid.diff(last, "X").data)
+                  and torch.equal(grid.diff(T4, "Y").data[nt - 1], grid.diff(last, "Y").data))
+        print(json.dumps({"config": 4, "check": "last record of the batch == same record processed alone", "ok": ok}), flush=True)
+        del T4, last, grid
+        torch.cuda.empty_cache()
+    if "5" in cfgs:
+        nz5, n5 = 90, 4320
+        grid = mitgcm_grid(nz5, n5, n5)
+        grid_fill = Grid(grid._ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}},
+                         padding="fill", metrics={("X", "Y"): ["rAz"]}, autoparse_metadata=False)
+        U = DataArray(D.synthetic((nz5, n5, n5), 51), ("Z", "YC", "XG"))
+        V = DataArray(D.synthetic((nz5, n5, n5), 52), ("Z", "YG", "XC"))
+        c5 = nz5 * n5 * n5
+        rec(5, "vorticity fused (diff(v,X)-diff(u,Y))/rAz, fill", timeit(lambda: grid_fill.vorticity(U, V), a.reps), c5, 24 + 8 / nz5)
+
+        def chain():
+            return (grid_fill.diff(V, "X") - grid_fill.diff(U, "Y")) / grid_fill._ds["rAz"].reset_coords(drop=True)
+
+        rec(5, "vorticity unfused operator chain (4 kernels), fused-equivalent bytes", timeit(chain, max(3, a.reps // 2)), c5, 24 + 8 / nz5)
+        ok = bool(torch.equal(grid_fill.vorticity(U, V).data, chain().data))
+        print(json.dumps({"config": 5, "check": "fused == unfused chain bit for bit at full size", "ok": ok}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
