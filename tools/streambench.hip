@@ -188,6 +188,25 @@ __global__ __launch_bounds__(256) void k_diffx_flat_b(const double* __restrict__
   st<true>((d2*)(out + row * L + i0), o);
 }
 
+
+// occupancy-limited Z-march (dynamic LDS just to cap resident workgroups per CU), runtime n/inner
+template <int U, int BLK = 256>
+__global__ __launch_bounds__(BLK) void k_diffz_occ(const double* __restrict__ in, double* __restrict__ out, unsigned n, size_t inner) {
+  extern __shared__ double lds_dummy[];
+  size_t x = ((size_t)blockIdx.x * BLK + threadIdx.x) * 2;
+  if (x >= inner) return;
+  if (n == 0xffffffffu) lds_dummy[threadIdx.x] = 1.0;  // keep the allocation alive
+  const double* p = in + x; double* q = out + x;
+  d2 prev = *(const d2*)p;
+  for (unsigned j = 0; j < n; j += U) {
+    d2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (j + u < n) v[u] = *(const d2*)(p + (size_t)(j + u) * inner);
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (j + u < n) { st<true>((d2*)(q + (size_t)(j + u) * inner), v[u] - prev); prev = v[u]; }
+  }
+}
+
 __global__ void k_rand(double* out, size_t n) {
   size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -267,5 +286,21 @@ int main() {
   { unsigned vpr = 1800; unsigned nblk = (unsigned)((nvec + 255) / 256); 
     float ms = timeit([&] { hipLaunchKernelGGL((k_diffx_flat_b<false>), dim3(nblk), dim3(256), 0, 0, in, out, nvec, vpr, nblk); }); report("diffx flat plain", ms);
     ms = timeit([&] { hipLaunchKernelGGL((k_diffx_flat_b<true>), dim3(((nblk + 7) / 8) * 8), dim3(256), 0, 0, in, out, nvec, vpr, nblk); }); report("diffx flat banded", ms); }
+
+#define DZO(U, LDSKB, NLEV, NAME) { unsigned nn = NLEV; size_t inner = n / nn; inner -= inner % 2; unsigned nblk = (unsigned)((inner / 2 + 255) / 256); \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_diffz_occ<U>), dim3(nblk), dim3(256), LDSKB * 1024, 0, in, out, nn, inner); }); report(NAME, ms); }
+  DZO(8, 0, 75, "diffZ occ: 75 lev, no LDS cap U8") DZO(8, 20, 75, "diffZ occ: 75 lev, 8 blk/CU U8") DZO(8, 40, 75, "diffZ occ: 75 lev, 4 blk/CU U8")
+  DZO(8, 80, 75, "diffZ occ: 75 lev, 2 blk/CU U8") DZO(4, 80, 75, "diffZ occ: 75 lev, 2 blk/CU U4") DZO(8, 160, 75, "diffZ occ: 75 lev, 1 blk/CU U8")
+  DZO(8, 0, 8, "diffZ occ: 8 lev x 81M") DZO(8, 0, 25, "diffZ occ: 25 lev") DZO(8, 0, 300, "diffZ occ: 300 lev x 2.16M") DZO(8, 0, 1200, "diffZ occ: 1200 lev x 0.54M")
+
+  DZO(1, 0, 75, "diffZ occ: 75 lev, U1 full occ") DZO(2, 0, 75, "diffZ occ: 75 lev, U2 full occ") DZO(3, 0, 75, "diffZ occ: 75 lev, U3 full occ")
+  DZO(1, 40, 75, "diffZ occ: 75 lev, U1 4blk/CU") DZO(2, 40, 75, "diffZ occ: 75 lev, U2 4blk/CU") DZO(2, 80, 75, "diffZ occ: 75 lev, U2 2blk/CU") DZO(4, 160, 75, "diffZ occ: 75 lev, U4 1blk/CU")
+  DZO(15, 160, 75, "diffZ occ: 75 lev, U15 1blk/CU") DZO(25, 160, 75, "diffZ occ: 75 lev, U25 1blk/CU")
+
+#define DZB(U, BLK, LDSKB, NAME) { unsigned nn = 75; size_t inner = n / nn; unsigned nblk = (unsigned)((inner / 2 + BLK - 1) / BLK); \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_diffz_occ<U, BLK>), dim3(nblk), dim3(BLK), LDSKB * 1024, 0, in, out, nn, inner); }); report(NAME, ms); }
+  DZB(2, 256, 160, "diffZ 1x256/CU U2") DZB(3, 256, 160, "diffZ 1x256/CU U3") DZB(4, 256, 160, "diffZ 1x256/CU U4") DZB(5, 256, 160, "diffZ 1x256/CU U5") DZB(6, 256, 160, "diffZ 1x256/CU U6")
+  DZB(4, 512, 160, "diffZ 1x512/CU U4") DZB(2, 512, 160, "diffZ 1x512/CU U2") DZB(4, 128, 160, "diffZ 1x128/CU U4") DZB(8, 128, 160, "diffZ 1x128/CU U8") DZB(8, 64, 160, "diffZ 1x64/CU U8")
+  DZB(3, 256, 80, "diffZ 2x256/CU U3") DZB(4, 256, 80, "diffZ 2x256/CU U4") DZB(5, 256, 80, "diffZ 2x256/CU U5") DZB(4, 1024, 160, "diffZ 1x1024/CU U4") DZB(2, 1024, 160, "diffZ 1x1024/CU U2")
   return 0;
 }

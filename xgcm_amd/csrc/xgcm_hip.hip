@@ -65,7 +65,11 @@ struct Tune {
   int nt_load;   // non-temporal loads
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
+  int march_lds_kb;   // optional dynamic LDS request for the column-marching kernels, only to cap residency
+                      // (experiment: +8 % on a bare march in tools/streambench.hip, but -20 % on the real
+                      // kernels whose index/metric math then has too few waves to hide behind) => default 0
   Tune() {
+    march_lds_kb = env_int("XG_MARCH_LDS_KB", 0);
     zband = env_int("XG_ZBAND", 1);
     seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
     seg = env_int("XG_SEG", 1 << 30);  // long march: whole column by default
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided(
     const double* __restrict__ m_out, MIdx mo) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
-  constexpr int U = 8;
+  constexpr int U = 4;
 
   const u64 w = wave_id();
   const u32 tile = (u32)(w % ntile);
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
     const double* __restrict__ m_in, MIdx mi, const double* __restrict__ m_out, MIdx mo) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
-  constexpr int U = 5;
+  constexpr int U = 4;
 
   const u64 w = wave_id();
   const u32 tile = (u32)(w % ntile);
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
     const double* __restrict__ in, double* __restrict__ out, Geo g, u32 ntile, int skipna,
     const double* __restrict__ wgt, MIdx mw) {
   typedef typename VecT<V>::type T;
-  constexpr int U = 5;
+  constexpr int U = 4;
   const u64 w = wave_id();
   const u32 tile = (u32)(w % ntile);
   const int64_t o = (int64_t)(w / ntile);
@@ -899,7 +903,8 @@ template <int V, bool HAS_AREA, bool NTS, int SEG>
 __global__ __launch_bounds__(BLOCK) void k_vorticity(
     const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ area,
     double* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile,
-    FastDiv nseg, int bc_x, double fill_x, int bc_y, double fill_y, int64_t a_so, int64_t a_sy, int64_t a_sx) {
+    FastDiv nseg, ZBand zb, int bc_x, double fill_x, int bc_y, double fill_y, int64_t a_so, int64_t a_sy,
+    int64_t a_sx) {
   typedef typename VecT<V>::type T;
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
@@ -907,9 +912,14 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
   const u32 r = fdiv(w, ntile);
   const u32 tile = w - r * ntile.d;
-  const u32 oo = fdiv(r, nseg);
-  if (oo >= nouter) return;
-  const u32 sg = r - oo * nseg.d;
+  u32 oo, sg;
+  if (HAS_AREA && zb.on) {  // band-major: a (Y,X) area band stays in the XCD's L2 for all levels
+    if (!zband_map(zb, r, oo, sg)) return;
+  } else {
+    oo = fdiv(r, nseg);
+    if (oo >= nouter) return;
+    sg = r - oo * nseg.d;
+  }
   const int64_t o = o0 + oo;
   const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
   if (i0 >= nx) return;
@@ -981,6 +991,13 @@ inline int check_grid(u64 nblocks) {
     if (e_ != hipSuccess) return fail(XG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e_)); \
   } while (0)
 
+inline unsigned march_lds() {
+  int kb = tune().march_lds_kb;
+  if (kb < 0) kb = 0;
+  if (kb > 160) kb = 160;
+  return (unsigned)kb * 1024u;
+}
+
 // dispatch on (OP, V, MET, NT) -> template instance
 struct StencilCall {
   const double* in; double* out; Geo g; int pad_lo, pad_hi, bc; double fill;
@@ -997,9 +1014,9 @@ int launch_march(const StencilCall& c) {
   const u64 nblocks = (ntask + WPB - 1) / WPB;
   if (nblocks == 0 || nblocks > 0x7fffffffull) return fail(XG_ERR_UNSUPPORTED, "launch of %llu blocks exceeds grid limits", nblocks);
   if (tune().nt_store)
-    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
   else
-    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, false>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
   return 0;
 }
 
@@ -1222,7 +1239,7 @@ int xg_cumsum1d_f64(const double* in, double* out, const int64_t* shape, int ndi
     const u64 nblocks = (ntask + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
     const bool nts = tune().nt_store;
-#define XG_GO(V_, M, NTS) hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, ntile, a, m_in, mi, m_out, mo)
+#define XG_GO(V_, M, NTS) hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo)
 #define XG_M(V_, M) do { if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
 #define XG_V(V_) switch (met) { case 0: XG_M(V_, 0); break; case 1: XG_M(V_, 1); break; case 2: XG_M(V_, 2); break; default: XG_M(V_, 3); }
     if (V == 2) { XG_V(2) } else { XG_V(1) }
@@ -1255,7 +1272,7 @@ int xg_reduce1d_f64(const double* in, double* out, const int64_t* shape, int ndi
     const u64 ntask = (u64)ntile * (u64)g.outer;
     const u64 nblocks = (ntask + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
-#define XG_GO(V_, W_) hipLaunchKernelGGL((k_reduce_strided<V_, W_, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, ntile, skipna, w, mw)
+#define XG_GO(V_, W_) hipLaunchKernelGGL((k_reduce_strided<V_, W_, false>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw)
     if (V == 2) { if (w) XG_GO(2, true); else XG_GO(2, false); }
     else { if (w) XG_GO(1, true); else XG_GO(1, false); }
 #undef XG_GO
@@ -1403,11 +1420,22 @@ int xg_vorticity_f64(const double* u, const double* v, const double* area, const
   const u64 outer_per = MAX_ITEMS / per_outer;
   hipStream_t st = (hipStream_t)stream;
   const bool nts = tune().nt_store;
-  for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_per) {
-    const u32 nouter = (u32)((outer - o0 < (int64_t)outer_per) ? outer - o0 : (int64_t)outer_per);
-    const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
+  const u32 ZB_SEGS = 4;
+  ZBand zb = make_zband(false, 0, 0, 1);
+  u64 outer_step = outer_per;
+  if (area && a_so == 0 && tune().zband && outer >= 2) {
+    const u64 padded_segs = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS;
+    if (padded_segs * (u64)outer * ntile <= MAX_ITEMS) {
+      zb = make_zband(true, (u64)outer, nseg, ZB_SEGS);
+      if (zb.on) outer_step = (u64)outer;  // one launch over all levels
+    }
+  }
+  for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_step) {
+    const u32 nouter = (u32)((outer - o0 < (int64_t)outer_step) ? outer - o0 : (int64_t)outer_step);
+    const u64 waves = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * (u64)outer * ntile : (u64)nouter * per_outer;
+    const u32 nblk = (u32)((waves + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GO(V_, A_, NTS) hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, bc_x, fill_x, bc_y, fill_y, a_so, a_sy, a_sx)
+#define XG_GO(V_, A_, NTS) hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, a_so, a_sy, a_sx)
 #define XG_A(V_, A_) do { if (nts) XG_GO(V_, A_, true); else XG_GO(V_, A_, false); } while (0)
     if (V == 2) { if (area) XG_A(2, true); else XG_A(2, false); }
     else { if (area) XG_A(1, true); else XG_A(1, false); }
