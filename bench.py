@@ -101,6 +101,13 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
+    import __graft_entry__ as entry
+
+    if entry._stale():  # clean checkout: the .so is a git-ignored build artefact
+        if rank == 0:
+            entry.build()
+        if dist is not None:
+            dist.barrier(device_ids=[local_rank])
     from xgcm_amd import device as D
 
     nz = args.levels

@@ -62,7 +62,7 @@ def _metric_for(shape, keep_dims, seed):
     return R.synthetic_metric(mshape, seed)
 
 
-@pytest.mark.parametrize("shape", [(5, 6, 64), (3, 7, 33), (2, 3, 4, 130)])
+@pytest.mark.parametrize("shape", [(5, 6, 64), (3, 7, 33), (2, 3, 4, 130), (3, 37, 130), (1, 20, 256)])
 @pytest.mark.parametrize("op", ["diff", "interp"])
 def test_stencil_metric_weighted_bitwise(dev, shape, op):
     """metric_weighted == (x*m_in) -> op -> / m_out bitwise (reference test_metrics_ops.py:59-64)."""
@@ -89,7 +89,7 @@ def test_stencil_metric_weighted_bitwise(dev, shape, op):
                 _eq(got, exp)
 
 
-@pytest.mark.parametrize("shape", [(6, 10, 128), (3, 7, 33), (2, 5, 4, 66), (300,), (3, 700)])
+@pytest.mark.parametrize("shape", [(6, 10, 128), (3, 7, 33), (2, 5, 4, 66), (300,), (3, 700), (2, 2050), (3, 1024), (9, 4100)])
 def test_cumsum_all(dev, shape):
     a = _field(shape, 7, nan=True)
     nd = len(shape)
@@ -108,6 +108,20 @@ def test_cumsum_all(dev, shape):
                         np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-12, equal_nan=True)
                     else:
                         _eq(got, exp)
+
+
+def test_cumsum_long_rows_metric(dev):
+    """wave-per-row scan kernel (even rows >= 256) with metrics, both directions."""
+    shape = (3, 5, 2048)
+    a = _field(shape, 10)
+    m_in = _metric_for(shape, {1, 2}, 43)
+    for reverse in (False, True):
+        tl, th, pl, ph = (0, 1, 1, 0) if not reverse else (1, 0, 0, 1)
+        m_out = _metric_for(shape, {2}, 44)
+        for bc in BCS:
+            exp = R.cumsum1d(a, 2, tl, th, pl, ph, bc, 0.25, reverse, True, m_in, m_out)
+            got = dev.tohost(dev.cumsum1d(a, 2, tl, th, pl, ph, bc, 0.25, reverse, True, m_in, m_out))
+            np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-11)  # values ~1e1, a few cross zero
 
 
 def test_cumsum_metric(dev):

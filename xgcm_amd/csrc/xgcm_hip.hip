@@ -65,11 +65,13 @@ struct Tune {
   int nt_load;   // non-temporal loads
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
+  int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
   int march_lds_kb;   // optional dynamic LDS request for the column-marching kernels, only to cap residency
                       // (experiment: +8 % on a bare march in tools/streambench.hip, but -20 % on the real
                       // kernels whose index/metric math then has too few waves to hide behind) => default 0
   Tune() {
     march_lds_kb = env_int("XG_MARCH_LDS_KB", 0);
+    deep_waves = env_int("XG_DEEP_WAVES", 0);  // measured neutral (4.80 vs 4.88 TB/s on cumsum along Y): off
     zband = env_int("XG_ZBAND", 1);
     seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
     seg = env_int("XG_SEG", 1 << 30);  // long march: whole column by default
@@ -321,6 +323,9 @@ __device__ __forceinline__ int64_t inner_offx(const Geo& g, const MIdx& m, int64
 template <typename T> __device__ __forceinline__ T ldm(const double* m, int64_t off, int64_t step);
 template <> __device__ __forceinline__ double ldm<double>(const double* m, int64_t off, int64_t) { return m[off]; }
 template <> __device__ __forceinline__ d2 ldm<d2>(const double* m, int64_t off, int64_t step) {
+  // metric contiguous along the lanes and 16-B aligned here: one dwordx4 load instead of two dwordx2
+  if (step == 1 && (((reinterpret_cast<uintptr_t>(m) >> 3) + (uintptr_t)off) & 1) == 0)
+    return *reinterpret_cast<const d2*>(m + off);
   d2 o; o.x = m[off]; o.y = m[off + step]; return o;
 }
 
@@ -472,18 +477,14 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     d2 a = *reinterpret_cast<const d2*>(prow + i0);
     double n = prow[nidx];
     if (HAS_MI) {
-      a.x = a.x * m_in[mib + (int64_t)i0 * mi.axis];
-      a.y = a.y * m_in[mib + (int64_t)(i0 + 1) * mi.axis];
+      a = a * ldm<d2>(m_in, mib + (int64_t)i0 * mi.axis, mi.axis);
       n = n * m_in[mib + (int64_t)nidx * mi.axis];
     }
     if (edge && bc == XG_BC_FILL) n = fill;
     d2 res;
     if (pad_lo) { res.x = op2<OP>(n, a.x); res.y = op2<OP>(a.x, a.y); }
     else { res.x = op2<OP>(a.x, a.y); res.y = op2<OP>(a.y, n); }
-    if (HAS_MO) {
-      res.x = res.x / m_out[mob + (int64_t)i0 * mo.axis];
-      res.y = res.y / m_out[mob + (int64_t)(i0 + 1) * mo.axis];
-    }
+    if (HAS_MO) res = res / ldm<d2>(m_out, mob + (int64_t)i0 * mo.axis, mo.axis);
     stg<d2, NTS>(orow + i0, res);
   } else {
     int64_t ql = (int64_t)i0 - pad_lo, qr = (int64_t)i0 + 1 - pad_lo;
@@ -592,13 +593,13 @@ struct ScanArgs {
 __device__ __forceinline__ double nan0(double v) { return (v != v) ? 0.0 : v; }
 __device__ __forceinline__ d2 nan0(d2 v) { d2 o; o.x = nan0(v.x); o.y = nan0(v.y); return o; }
 
-template <int V, int MET, bool NTL, bool NTS>
+template <int V, int MET, bool NTL, bool NTS, int U>
 __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
     const double* __restrict__ in, double* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
     const double* __restrict__ m_in, MIdx mi, const double* __restrict__ m_out, MIdx mo) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
-  constexpr int U = 4;
+  // U independent loads in flight per lane (the scan chain only consumes them)
 
   const u64 w = wave_id();
   const u32 tile = (u32)(w % ntile);
@@ -668,6 +669,11 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
 // K6: cumsum along the CONTIGUOUS axis: one workgroup per row, chunks of 256 elements in scan
 // order, wave-level Hillis-Steele scan with cross-lane shuffles, 4 wave totals through LDS,
 // running carry in a register.  Re-associated sum => tolerance parity (not bit-exact).
+// Tried and rejected (measured, 3600-long rows): a 1024-thread workgroup per row with 16-B loads
+// (2 barrier-separated passes leave too little in flight: 3.2 TB/s) and a barrier-free wave per
+// row owning element PAIRS (its two 8-B stores per lane interleave -> half-filled write
+// sectors: 2.8 TB/s).  This one-element-per-lane form keeps every load/store instruction a
+// contiguous 512 B and runs at 4.5-4.7 TB/s.
 // ------------------------------------------------------------------------------------------
 template <int MET>
 __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
@@ -689,17 +695,24 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
     if (HAS_MO) v = v / m_out[mo_base + j * mo.axis];
     orow[j] = v;
   };
-  double carry = 0.0;
-  int buf = 0;
-  for (int64_t base = 0; base < n; base += BLOCK, buf ^= 1) {
-    const int64_t k = base + tid;
-    const int64_t idx = a.reverse ? n - 1 - k : k;
+  auto fetch = [&](int64_t k) -> double {
     double v = 0.0;
     if (k < n) {
+      const int64_t idx = a.reverse ? n - 1 - k : k;
       v = prow[idx];
       if (HAS_MI) v = v * m_in[mi_base + idx * mi.axis];
       if (a.skipna) v = nan0(v);
     }
+    return v;
+  };
+  double carry = 0.0;
+  int buf = 0;
+  double cur = fetch(tid);
+  for (int64_t base = 0; base < n; base += BLOCK, buf ^= 1) {
+    const int64_t k = base + tid;
+    const int64_t idx = a.reverse ? n - 1 - k : k;
+    const double v = cur;
+    cur = fetch(k + BLOCK);  // next chunk's load is in flight across this chunk's scan + barrier
     double s = v;
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
@@ -739,12 +752,12 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
 // K4: weighted sum along a STRIDED axis: one lane per output column pair, sequential in k
 // (bit-exact with numpy's reduction over a non-last axis).
 // ------------------------------------------------------------------------------------------
-template <int V, bool HAS_W, bool NTL>
+template <int V, bool HAS_W, bool NTL, int U>
 __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
     const double* __restrict__ in, double* __restrict__ out, Geo g, u32 ntile, int skipna,
     const double* __restrict__ wgt, MIdx mw) {
   typedef typename VecT<V>::type T;
-  constexpr int U = 4;
+  // U independent loads in flight per lane
   const u64 w = wave_id();
   const u32 tile = (u32)(w % ntile);
   const int64_t o = (int64_t)(w / ntile);
@@ -1228,10 +1241,12 @@ int xg_cumsum1d_f64(const double* in, double* out, const int64_t* shape, int ndi
   hipStream_t st = (hipStream_t)stream;
   if (g.inner == 1) {
     const u64 nblocks = (u64)g.outer;
-    if ((rc = check_grid(nblocks))) return rc;
+    if ((rc = check_grid(nblocks + 8))) return rc;
+    {
 #define XG_M(M) hipLaunchKernelGGL((k_cumsum_contig<M>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, a, m_in, mi, m_out, mo)
-    switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
+      switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
 #undef XG_M
+    }
   } else {
     const int V = (aligned16(in) && aligned16(out) && (g.inner % 2 == 0)) ? 2 : 1;
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
@@ -1239,7 +1254,11 @@ int xg_cumsum1d_f64(const double* in, double* out, const int64_t* shape, int ndi
     const u64 nblocks = (ntask + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
     const bool nts = tune().nt_store;
-#define XG_GO(V_, M, NTS) hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo)
+    // few columns, long march (cumsum along Y: ~2k waves for the whole chip): occupancy cannot hide
+    // the latency, so keep 16 loads in flight per lane instead of 4
+    const bool deep = ntask < (u64)tune().deep_waves;
+#define XG_GO(V_, M, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); \
+                               else hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); } while (0)
 #define XG_M(V_, M) do { if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
 #define XG_V(V_) switch (met) { case 0: XG_M(V_, 0); break; case 1: XG_M(V_, 1); break; case 2: XG_M(V_, 2); break; default: XG_M(V_, 3); }
     if (V == 2) { XG_V(2) } else { XG_V(1) }
@@ -1272,7 +1291,9 @@ int xg_reduce1d_f64(const double* in, double* out, const int64_t* shape, int ndi
     const u64 ntask = (u64)ntile * (u64)g.outer;
     const u64 nblocks = (ntask + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
-#define XG_GO(V_, W_) hipLaunchKernelGGL((k_reduce_strided<V_, W_, false>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw)
+    const bool deep = ntask < (u64)tune().deep_waves;
+#define XG_GO(V_, W_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, false, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); \
+                           else hipLaunchKernelGGL((k_reduce_strided<V_, W_, false, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); } while (0)
     if (V == 2) { if (w) XG_GO(2, true); else XG_GO(2, false); }
     else { if (w) XG_GO(1, true); else XG_GO(1, false); }
 #undef XG_GO
