@@ -123,3 +123,21 @@ def test_full_size_outputs_match_oracle_on_spot_slabs(env):
         assert np.array_equal(host(dZ.data[z]), R.stencil1d("diff", slab, 1, 1, 0, "periodic", m_out=np.full((NY, NX), 4.0)))
     cols = host(T.data[:, 1200:1204, :])  # (NZ, 4, NX) column block
     assert np.array_equal(host(cZ.data[:, 1200:1204, :]), R.grid_cumsum(cols, 0, "center", "left", "fill"))
+
+
+def test_more_than_2_to_32_cells_in_one_call(env):
+    """5.2 G cells (41 GB) in ONE call: 64-bit addressing and the host-side launch splitting
+    (per-launch item counts stay < 2^31).  The last record must equal the same record alone."""
+    torch, grid, D = env["torch"], env["grid"], env["D"]
+    nt = 8
+    T4 = env["DataArray"](D.synthetic((nt, NZ, NY, NX), 4), ("time", "Z", "YC", "XC"))
+    assert T4.data.numel() > 2 ** 32
+    last = env["DataArray"](T4.data[nt - 1].contiguous(), ("Z", "YC", "XC"))
+    for fn, ax, kw in (("diff", "X", {}), ("interp", "Y", {}), ("diff", "Z", {}), ("cumsum", "Z", {}),
+                       ("derivative", "X", {})):
+        full = getattr(grid, fn)(T4, ax, **kw)
+        one = getattr(grid, fn)(last, ax, **kw)
+        assert full.dims[0] == "time" and _same(torch, full.data[nt - 1], one.data), (fn, ax)
+        del full, one
+    tot = grid.integrate(T4, "Z")
+    assert tot.dims == ("time", "YC", "XC") and _same(torch, tot.data[nt - 1], grid.integrate(last, "Z").data)

@@ -215,8 +215,14 @@ def test_c_abi_rejects_bad_arguments(dev):
     a = dev.asdevice(_field((4, 8), 1))
     with pytest.raises(_hip.XgcmHipError, match="no boundary mode"):
         dev.stencil1d("diff", a, 1, 1, 0, None)
-    with pytest.raises(_hip.XgcmHipError):
-        dev.cumsum1d(_field((4, 1), 1), 1, 1, 0, 0, 0, "fill")
+    # an axis trimmed away completely: constant halo is fine, wrap/extend of nothing is an error (numpy.pad)
+    one = _field((4, 1), 1)
+    _eq(dev.tohost(dev.cumsum1d(one, 1, 0, 1, 1, 0, "fill", 2.5)), R.cumsum1d(one, 1, 0, 1, 1, 0, "fill", 2.5))
+    assert dev.tohost(dev.cumsum1d(one, 1, 1, 0, 0, 0, "fill")).shape == (4, 0)
+    with pytest.raises(ValueError, match="can't extend empty axis"):
+        dev.cumsum1d(one, 1, 0, 1, 1, 0, "extend")
+    with pytest.raises(ValueError, match="can't extend empty axis"):
+        R.cumsum1d(one, 1, 0, 1, 1, 0, "extend")
 
 
 def test_library_device_helpers_roundtrip():
@@ -250,3 +256,28 @@ def test_library_device_helpers_roundtrip():
         _hip.check(lib.xg_free(h))
     for e in (e0, e1):
         _hip.check(lib.xg_event_destroy(e))
+
+
+def test_degenerate_shapes(dev):
+    """empty outer dims, length-1 axes, 0-d results: the edge cases of the shape logic."""
+    import torch
+
+    # length-1 axis: center->left periodic wraps onto itself, extend replicates, fill uses the constant
+    a = _field((3, 1, 4), 1)
+    _eq(dev.tohost(dev.stencil1d("diff", a, 1, 1, 0, "periodic")), np.zeros((3, 1, 4)))
+    _eq(dev.tohost(dev.stencil1d("interp", a, 1, 0, 1, "extend")), a)
+    _eq(dev.tohost(dev.stencil1d("diff", a, 1, 1, 0, "fill", 2.0)), a - 2.0)
+    _eq(dev.tohost(dev.stencil1d("diff", a, 1, 1, 1, "fill", 2.0)), R.stencil1d("diff", a, 1, 1, 1, "fill", 2.0))
+    # empty leading dim: nothing to do, shape bookkeeping still right
+    e = torch.empty((0, 5, 8), dtype=torch.float64, device="cuda")
+    assert tuple(dev.stencil1d("diff", e, 2, 1, 0, "periodic").shape) == (0, 5, 8)
+    assert tuple(dev.stencil1d("diff", e, 1, 1, 1, "fill").shape) == (0, 6, 8)
+    assert tuple(dev.cumsum1d(e, 1, 0, 0, 1, 0, "fill").shape) == (0, 6, 8)
+    assert tuple(dev.reduce1d(e, 1).shape) == (0, 8)
+    # reducing a 1-D array gives a 0-d result
+    v = _field((1000,), 3)
+    got = dev.tohost(dev.reduce1d(v, 0))
+    assert got.shape == () and abs(got - v.sum()) < 1e-12
+    # center->inner on a length-2 axis leaves one cell
+    b = _field((2, 6), 4)
+    _eq(dev.tohost(dev.stencil1d("diff", b, 0, 0, 0, None)), b[1:] - b[:-1])

@@ -81,6 +81,20 @@ def main():
             rec(3, "integrate(T,'Z') * drF(Z)", timeit(lambda: grid.integrate(T, "Z"), a.reps), cells, 8 + 8 / nz)
         del T, grid
         torch.cuda.empty_cache()
+    if "pcie" in cfgs:
+        import time
+
+        from oracle import refimpl as R
+
+        grid = mitgcm_grid(8, ny, nx)
+        host = DataArray(R.synthetic_field((8, ny, nx), 2), ("Z", "YC", "XC"))  # numpy in -> numpy out
+        grid.diff(host, "X")
+        t0 = time.perf_counter()
+        for _ in range(3):
+            grid.diff(host, "X")
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        rec("pcie", "diff(T,'X') with HOST numpy in/out (H2D + kernel + D2H, pageable), 8 levels", ms, 8 * ny * nx, 16)
+        del host, grid
     if "4" in cfgs:
         nt = a.records
         grid = mitgcm_grid(nz, ny, nx)

@@ -110,6 +110,8 @@ def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str]
     m_in = _prep_metric(m_in)
     m_out = _prep_metric(m_out)
     out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    if out.numel() == 0:  # empty outer dims: nothing to launch (a NULL data_ptr is not a valid ABI argument)
+        return out
     _hip.check(
         lib.xg_stencil1d_f64(
             _hip.OP[op], x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, n_out,
@@ -133,6 +135,15 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
     m_in = _prep_metric(m_in)
     m_out = _prep_metric(m_out)
     out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    if out.numel() == 0:
+        return out
+    if shape[axis] - trim_lo - trim_hi == 0:
+        # everything trimmed away: only halo cells remain.  numpy.pad can fill an empty axis with a
+        # constant but refuses to wrap/extend it -- same here.
+        if bc != "fill":
+            raise ValueError(f"can't extend empty axis {axis} using modes other than 'constant' or 'empty'")
+        synthetic(tuple(oshape), 0, 0, 0.0, float(fill), out=out)
+        return out if m_out is None else binary("div", out, m_out)
     _hip.check(
         lib.xg_cumsum1d_f64(
             x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, int(bool(reverse)), int(bool(skipna)),
@@ -153,6 +164,10 @@ def reduce1d(x, axis: int, w=None, skipna: bool = True) -> torch.Tensor:
     oshape = shape[:axis] + shape[axis + 1:]
     w = _prep_metric(w)
     out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    if out.numel() == 0:
+        return out
+    if x.numel() == 0:  # sum over an empty axis is 0
+        return synthetic(tuple(oshape), 0, 0, 0.0, 0.0, out=out)
     _hip.check(
         lib.xg_reduce1d_f64(
             x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, int(bool(skipna)),
@@ -181,6 +196,8 @@ def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
     order += [d for d in range(nd) if d not in order]
     oshape = [s + l + h for s, l, h in zip(x.shape, lo, hi)]
     out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    if out.numel() == 0:
+        return out
     _hip.check(
         lib.xg_pad_f64(x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), nd, _hip.i64(lo), _hip.i64(hi),
                        _hip.ints(bcv), _hip.f64s(fv), _hip.ints(order), _stream())
@@ -201,6 +218,8 @@ def binary(op: str, a, b) -> torch.Tensor:
             raise ValueError(f"binary: extents {sa} and {sb} do not broadcast")
         shape.append(max(sa, sb) if 0 not in (sa, sb) else 0)
     out = torch.empty(shape, dtype=torch.float64, device=a.device)
+    if out.numel() == 0:
+        return out
     _hip.check(
         lib.xg_binary_f64(_hip.BINOP[op], a.data_ptr(), _hip.i64(_bstrides(a, shape, "a")), b.data_ptr(),
                           _hip.i64(_bstrides(b, shape, "b")), out.data_ptr(), _hip.i64(shape), len(shape), _stream())
@@ -218,6 +237,8 @@ def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: flo
     shape = list(u.shape)
     area = _prep_metric(area)
     out = torch.empty(shape, dtype=torch.float64, device=u.device)
+    if out.numel() == 0:
+        return out
     _hip.check(
         lib.xg_vorticity_f64(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
                              out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
@@ -232,6 +253,8 @@ def synthetic(shape, seed: int, offset: int = 0, scale: float = 1.0, shift: floa
     _require_gpu()
     if out is None:
         out = torch.empty(tuple(shape), dtype=torch.float64, device="cuda")
+    if out.numel() == 0:
+        return out
     _hip.check(lib.xg_fill_synthetic_f64(out.data_ptr(), out.numel(), int(seed), int(offset), float(scale),
                                          float(shift), _stream()))
     return out
