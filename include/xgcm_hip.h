@@ -24,6 +24,7 @@
  *   xg_pad_f64         xgcm/padding.py:765-871 (pad) for user grid-ufuncs of any width
  *   xg_binary_f64      the xarray broadcasting `*`, `/`, `+`, `-` around the ops
  *                      (xgcm/grid.py:808,832,1578,1600; get_metric products :614-617)
+ *   xg_stencil2d_f64   Grid.interp/diff/min/max over two axes (xgcm/grid.py:798-828), one pass
  *   xg_vorticity_f64   the chained (diff(v,X) - diff(u,Y)) / area of docs/ufunc_examples.md
  *                      (one fused pass instead of three apply_ufunc passes, grid.py:798-800 TODO)
  */
@@ -119,6 +120,15 @@ int xg_binary_f64(int op, const double* a, const int64_t* a_strides, const doubl
 int xg_vorticity_f64(const double* u, const double* v, const double* area,
                      const int64_t* area_strides, double* out, const int64_t* shape, int ndim,
                      int bc_x, double fill_x, int bc_y, double fill_y, void* stream);
+
+/* ---- the same two-point operator along the last TWO axes in one pass -------------------- */
+/* out = OP_second(pad(OP_first(pad(in)))) for (.., Y, X) arrays, order 0: X then Y, 1: Y then X;
+ * replaces two sequential apply_as_grid_ufunc passes of Grid.interp/diff/min/max(da, [ax1, ax2])
+ * (xgcm/grid.py:798-828; the TODO at :798-800 asks for this fusion).  Length-preserving pads
+ * ((1,0) or (0,1)) on both axes, nx even; bit-identical to two xg_stencil1d_f64 calls. */
+int xg_stencil2d_f64(int op, const double* in, double* out, const int64_t* shape, int ndim, int order,
+                     int padx_lo, int padx_hi, int bc_x, double fill_x, int pady_lo, int pady_hi,
+                     int bc_y, double fill_y, void* stream);
 
 /* ---- synthetic fields, bit-identical to oracle/refimpl.py:synthetic --------------------- */
 /* out[i] = u * scale + shift,  u = (splitmix64_mix(i + offset + seed*0x9E3779B97F4A7C15) >> 11)

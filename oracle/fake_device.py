@@ -56,12 +56,27 @@ def vorticity(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0):
     return R.vorticity(u, v, area, bc_x, bc_y, fill_x, fill_y)
 
 
+def stencil2d_supported(x, padx, pady):
+    x = np.asarray(x)
+    return x.ndim >= 2 and x.shape[-1] % 2 == 0 and sum(padx) == 1 and sum(pady) == 1 and x.shape[-1] > 0 and x.shape[-2] > 0
+
+
+def stencil2d(op, x, order, padx, bc_x, fill_x, pady, bc_y, fill_y):
+    x = asdevice(x)
+    ax_x, ax_y = x.ndim - 1, x.ndim - 2
+    if order == 0:
+        t = R.stencil1d(op, x, ax_x, padx[0], padx[1], bc_x, fill_x)
+        return R.stencil1d(op, t, ax_y, pady[0], pady[1], bc_y, fill_y)
+    t = R.stencil1d(op, x, ax_y, pady[0], pady[1], bc_y, fill_y)
+    return R.stencil1d(op, t, ax_x, padx[0], padx[1], bc_x, fill_x)
+
+
 def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None):
     return R.synthetic(int(np.prod(shape)), seed, offset, scale, shift).reshape(tuple(shape))
 
 
 _NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "cumsum1d", "reduce1d", "pad_nd", "binary",
-          "vorticity", "synthetic"]
+          "vorticity", "stencil2d", "stencil2d_supported", "synthetic"]
 
 
 def install(monkeypatch):

@@ -281,3 +281,25 @@ def test_degenerate_shapes(dev):
     # center->inner on a length-2 axis leaves one cell
     b = _field((2, 6), 4)
     _eq(dev.tohost(dev.stencil1d("diff", b, 0, 0, 0, None)), b[1:] - b[:-1])
+
+
+@pytest.mark.parametrize("shape", [(3, 9, 64), (2, 70, 34), (6, 8), (2, 2, 5, 258), (1, 4, 2)])
+@pytest.mark.parametrize("op", OPS)
+def test_stencil2d_equals_two_sequential_passes(dev, shape, op):
+    """one fused launch == reference order of operations: op along the first axis, then the second."""
+    a = _field(shape, 61, nan=op in ("min", "max"))
+    ax_x, ax_y = len(shape) - 1, len(shape) - 2
+    for order in (0, 1):
+        for padx, pady in itertools.product([(1, 0), (0, 1)], [(1, 0), (0, 1)]):
+            for bc_x, bc_y in itertools.product(BCS, BCS):
+                if order == 0:
+                    t = R.stencil1d(op, a, ax_x, *padx, bc_x, 0.75)
+                    exp = R.stencil1d(op, t, ax_y, *pady, bc_y, -1.5)
+                else:
+                    t = R.stencil1d(op, a, ax_y, *pady, bc_y, -1.5)
+                    exp = R.stencil1d(op, t, ax_x, *padx, bc_x, 0.75)
+                assert dev.stencil2d_supported(dev.asdevice(a), padx, pady)
+                got = dev.tohost(dev.stencil2d(op, a, order, padx, bc_x, 0.75, pady, bc_y, -1.5))
+                _eq(got, exp)
+    assert not dev.stencil2d_supported(dev.asdevice(_field((3, 5, 33), 1)), (1, 0), (1, 0))  # odd nx
+    assert not dev.stencil2d_supported(dev.asdevice(a), (1, 1), (1, 0))  # length-changing pair

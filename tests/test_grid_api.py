@@ -193,6 +193,45 @@ def test_multi_axis_and_per_axis_kwargs(backend):
     assert grid_e.diff(a, "X").equals(res2)
 
 
+def test_two_axes_fused_equals_sequential(backend):
+    """Grid.interp/diff/min/max(da, [ax1, ax2]) on the last two dims runs as ONE launch and must give
+    exactly what the reference's per-axis loop gives (xgcm/grid.py:800-832), coords included."""
+    nz, ny, nx = 3, 10, 16
+    coords = {"XC": ("XC", np.arange(nx) + 0.5), "XG": ("XG", np.arange(nx) * 1.0),
+              "YC": ("YC", np.arange(ny) + 0.5), "YG": ("YG", np.arange(ny) * 1.0), "Z": ("Z", np.arange(nz) * 1.0),
+              "lonG": (("YG", "XG"), R.synthetic_field((ny, nx), 70)), "lonC": (("YC", "XC"), R.synthetic_field((ny, nx), 71))}
+    ds = Dataset({"T": (("Z", "YC", "XC"), R.synthetic_field((nz, ny, nx), 72))}, coords)
+    gcoords = {"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}}
+    from xgcm_amd import device as dev_mod
+
+    calls = []
+    real = dev_mod.stencil2d
+    for padding in ({"X": "periodic", "Y": "extend"}, "fill", {"X": "extend", "Y": "periodic"}):
+        grid = Grid(ds, coords=gcoords, padding=padding, fill_value=None, autoparse_metadata=False)
+        for fn in ("interp", "diff", "min", "max"):
+            f = getattr(grid, fn)
+            for axes in (["X", "Y"], ["Y", "X"]):
+                dev_mod.stencil2d = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+                try:
+                    fused = f(ds["T"], axes, fill_value={"X": 2.0, "Y": -3.0})
+                finally:
+                    dev_mod.stencil2d = real
+                seq = f(f(ds["T"], axes[0], fill_value={"X": 2.0, "Y": -3.0}), axes[1], fill_value={"X": 2.0, "Y": -3.0})
+                assert fused.dims == ("Z", "YG", "XG")
+                assert fused.equals(seq), (padding, fn, axes)
+                assert "lonG" in fused.coords and "lonC" not in fused.coords
+    assert len(calls) == 3 * 4 * 2  # every two-axis call really took the fused path
+    # not the last two dims / metric weighting / odd nx -> sequential path, same answer as before
+    grid = Grid(ds, coords=gcoords, padding="periodic", autoparse_metadata=False)
+    Tt = ds["T"].transpose("YC", "Z", "XC")
+    Tt = DataArray(np.ascontiguousarray(Tt.values), Tt.dims)
+    got = grid.interp(Tt, ["X", "Y"])
+    want = R.stencil1d("interp", R.stencil1d("interp", Tt.values, 2, 1, 0, "periodic"), 0, 1, 0, "periodic")
+    assert got.dims == ("YG", "Z", "XG") and np.array_equal(got.values, want)
+    with pytest.raises(ValueError, match="No boundary condition was specified"):
+        Grid(ds, coords=gcoords, autoparse_metadata=False).interp(ds["T"], ["X", "Y"])
+
+
 def test_vector_component_dict_input(backend):
     ds, coords, _ = cgrid()
     grid = Grid(ds, coords=coords, padding="periodic", autoparse_metadata=False)

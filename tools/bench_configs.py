@@ -67,13 +67,21 @@ def main():
     cfgs = set(a.configs.split(","))
     nz, ny, nx = 75, 2400, 3600
     cells = nz * ny * nx
-    if cfgs & {"2", "3"}:
+    if cfgs & {"2", "3", "f1"}:
         grid = mitgcm_grid(nz, ny, nx)
         T = DataArray(D.synthetic((nz, ny, nx), 2), ("Z", "YC", "XC"))
         if "2" in cfgs:
             for fn in ("interp", "diff"):
                 rec(2, f"{fn}(T,'X') periodic", timeit(lambda: getattr(grid, fn)(T, "X"), a.reps), cells, 16)
                 rec(2, f"{fn}(T,'Y') extend", timeit(lambda: getattr(grid, fn)(T, "Y"), a.reps), cells, 16)
+        if "f1" in cfgs:
+            for fn in ("interp", "diff"):
+                rec("f1", f"{fn}(T,['X','Y']) ONE pass (xg_stencil2d_f64)", timeit(lambda: getattr(grid, fn)(T, ["X", "Y"]), a.reps), cells, 16)
+                rec("f1", f"{fn}(T,'X') then {fn}(.,'Y') two passes (reference order), same 16 B/cell basis",
+                    timeit(lambda: getattr(grid, fn)(getattr(grid, fn)(T, "X"), "Y"), a.reps), cells, 16)
+            same = bool(torch.equal(grid.interp(T, ["X", "Y"]).data, grid.interp(grid.interp(T, "X"), "Y").data)
+                        and torch.equal(grid.diff(T, ["Y", "X"]).data, grid.diff(grid.diff(T, "Y"), "X").data))
+            print(json.dumps({"config": "f1", "check": "fused two-axis == sequential, bit for bit, full size", "ok": same}), flush=True)
         if "3" in cfgs:
             rec(3, "derivative(T,'X') / dxC(YC,XG)", timeit(lambda: grid.derivative(T, "X"), a.reps), cells, 16 + 8 / nz)
             rec(3, "derivative(T,'Y') / dyC(YG,XC)", timeit(lambda: grid.derivative(T, "Y"), a.reps), cells, 16 + 8 / nz)

@@ -57,6 +57,11 @@ SIGNATURES = {
         C.c_int,
         [_vp, _vp, _vp, _i64p, _vp, _i64p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, _vp],
     ),
+    "xg_stencil2d_f64": (
+        C.c_int,
+        [C.c_int, _vp, _vp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+         C.c_int, C.c_double, _vp],
+    ),
     "xg_fill_synthetic_f64": (C.c_int, [_vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_double, C.c_double, _vp]),
 }
 

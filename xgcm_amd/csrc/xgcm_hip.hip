@@ -973,6 +973,93 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
 }
 
 // ------------------------------------------------------------------------------------------
+// K8: the same two-point operator along BOTH of the last two axes in one pass, e.g.
+// Grid.interp(da, ["X", "Y"]) (tracer -> vorticity point).  The reference applies the axes one
+// after the other (xgcm/grid.py:798-800 carries a TODO about fusing them): pad + op along the
+// first, then pad + op along the second = 32 B/cell.  Here one wave loads SEG+1 rows of pairs
+// plus the 8-B X neighbour (as K7), applies the first axis in registers and the second across
+// rows: 16 B/cell, and bit-identical to the sequential form because the order of the
+// floating-point operations is kept (`order` 0: X then Y, 1: Y then X).  The halo of the SECOND
+// axis acts on the intermediate array, as in the reference: a fill halo is the constant itself,
+// periodic/extend halos are the first-axis result of the wrapped/clamped row or column.
+// Length-preserving position pairs only (pads (1,0)/(0,1)), nx even; other cases run sequentially.
+// ------------------------------------------------------------------------------------------
+template <int OP, bool NTS, int SEG>
+__global__ __launch_bounds__(BLOCK) void k_stencil2d(
+    const double* __restrict__ in, double* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny,
+    int64_t nx, FastDiv ntile, FastDiv nseg, int order, int plx, int bcx, double fillx, int ply, int bcy,
+    double filly) {
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
+  const u32 r = fdiv(w, ntile);
+  const u32 tile = w - r * ntile.d;
+  const u32 oo = fdiv(r, nseg);
+  if (oo >= nouter) return;
+  const u32 sg = r - oo * nseg.d;
+  const int64_t o = o0 + oo;
+  const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * 2;
+  if (i0 >= nx) return;
+  const int64_t j0 = (int64_t)sg * SEG;
+  const int64_t nrow = (ny - j0 < SEG) ? ny - j0 : SEG;
+  const double* pin = in + o * ny * nx;
+  double* po = out + (o * ny + j0) * nx + i0;
+
+  int64_t nidx;
+  bool edge;
+  if (plx) { edge = (i0 == 0); nidx = edge ? ((bcx == XG_BC_PERIODIC) ? nx - 1 : 0) : i0 - 1; }
+  else { edge = (i0 + 2 == nx); nidx = edge ? ((bcx == XG_BC_PERIODIC) ? 0 : nx - 1) : i0 + 2; }
+  const bool fill_edge = edge && (bcx == XG_BC_FILL);
+  // X stencil on a pair `a` with the value `n` next to it (left of a.x if plx, right of a.y otherwise)
+  auto opx = [&](d2 a, double n) -> d2 {
+    d2 t;
+    if (plx) { t.x = op2<OP>(n, a.x); t.y = op2<OP>(a.x, a.y); }
+    else { t.x = op2<OP>(a.x, a.y); t.y = op2<OP>(a.y, n); }
+    return t;
+  };
+
+  d2 pr[SEG + 1];
+  double nb[SEG + 1];
+  bool rowfill[SEG + 1];
+#pragma unroll
+  for (int u = 0; u <= SEG; ++u) {
+    int64_t k = j0 + ((u <= nrow) ? u : nrow);
+    int64_t q = k - ply;
+    bool f = false;
+    if (q < 0) { f = (bcy == XG_BC_FILL); q = (bcy == XG_BC_PERIODIC) ? ny - 1 : 0; }
+    else if (q >= ny) { f = (bcy == XG_BC_FILL); q = (bcy == XG_BC_PERIODIC) ? 0 : ny - 1; }
+    rowfill[u] = f;
+    pr[u] = *reinterpret_cast<const d2*>(pin + q * nx + i0);
+    nb[u] = pin[q * nx + nidx];
+  }
+  if (order == 0) {  // X first, then Y on the intermediate
+    d2 tx[SEG + 1];
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) {
+      const d2 t = opx(pr[u], fill_edge ? fillx : nb[u]);
+      tx[u] = rowfill[u] ? splat<d2>(filly) : t;
+    }
+#pragma unroll
+    for (int u = 0; u < SEG; ++u)
+      if (u < nrow) stg<d2, NTS>(po + u * nx, op2<OP>(tx[u], tx[u + 1]));
+  } else {  // Y first, then X on the intermediate
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) {
+      if (rowfill[u]) { pr[u] = splat<d2>(filly); nb[u] = filly; }
+    }
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+      if (u < nrow) {
+        const d2 ty = op2<OP>(pr[u], pr[u + 1]);
+        const double tn = op2<OP>(nb[u], nb[u + 1]);
+        stg<d2, NTS>(po + u * nx, opx(ty, fill_edge ? fillx : tn));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // synthetic fields (splitmix64 finaliser), bit-identical to oracle/refimpl.py:synthetic
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_fill_synthetic(double* __restrict__ out, int64_t n, u64 seed, u64 offset,
@@ -1461,6 +1548,45 @@ int xg_vorticity_f64(const double* u, const double* v, const double* area, const
     if (V == 2) { if (area) XG_A(2, true); else XG_A(2, false); }
     else { if (area) XG_A(1, true); else XG_A(1, false); }
 #undef XG_A
+#undef XG_GO
+  }
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int xg_stencil2d_f64(int op, const double* in, double* out, const int64_t* shape, int ndim, int order,
+                     int padx_lo, int padx_hi, int bc_x, double fill_x, int pady_lo, int pady_hi, int bc_y,
+                     double fill_y, void* stream) {
+  if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
+  if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
+  if (order != 0 && order != 1) return fail(XG_ERR_INVALID, "order must be 0 (X then Y) or 1 (Y then X)");
+  if (padx_lo + padx_hi != 1 || pady_lo + pady_hi != 1 || ((padx_lo | padx_hi | pady_lo | pady_hi) & ~1))
+    return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil needs length-preserving pads (1,0) or (0,1) on both axes");
+  if (bc_x < XG_BC_PERIODIC || bc_x > XG_BC_EXTEND || bc_y < XG_BC_PERIODIC || bc_y > XG_BC_EXTEND)
+    return fail(XG_ERR_INVALID, "fused 2-D stencil needs a boundary mode on both axes");
+  const int64_t ny = shape[ndim - 2], nx = shape[ndim - 1];
+  int64_t outer = 1;
+  for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
+  if (outer == 0 || ny == 0 || nx == 0) return XG_OK;
+  if (nx % 2 || !aligned16(in) || !aligned16(out)) return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil needs an even, 16-byte aligned X extent");
+  constexpr int SEG = 4;
+  const u64 ntile = (u64)((nx + 2 * WAVE - 1) / (2 * WAVE));
+  const u64 nseg = (u64)((ny + SEG - 1) / SEG);
+  const u64 per_outer = ntile * nseg;
+  if (per_outer > MAX_ITEMS) return fail(XG_ERR_UNSUPPORTED, "extent too large for the 2-D stencil kernel");
+  const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
+  const u64 outer_per = MAX_ITEMS / per_outer;
+  hipStream_t st = (hipStream_t)stream;
+  const bool nts = tune().nt_store;
+  for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_per) {
+    const u32 nouter = (u32)((outer - o0 < (int64_t)outer_per) ? outer - o0 : (int64_t)outer_per);
+    const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
+    const u32 grid = ((nblk + 7) / 8) * 8;
+#define XG_GO(O, NTS) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order, padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y)
+#define XG_O(O) do { if (nts) XG_GO(O, true); else XG_GO(O, false); } while (0)
+    switch (op) { case XG_OP_DIFF: XG_O(XG_OP_DIFF); break; case XG_OP_INTERP: XG_O(XG_OP_INTERP); break; case XG_OP_MIN: XG_O(XG_OP_MIN); break; default: XG_O(XG_OP_MAX); }
+#undef XG_O
 #undef XG_GO
   }
   XG_LAUNCH_CHECK();

@@ -30,6 +30,8 @@ __all__ = [
     "pad_nd",
     "binary",
     "vorticity",
+    "stencil2d",
+    "stencil2d_supported",
     "synthetic",
 ]
 
@@ -242,6 +244,28 @@ def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: flo
     _hip.check(
         lib.xg_vorticity_f64(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
                              out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
+                             _hip.BC[bc_y], float(fill_y), _stream())
+    )
+    return out
+
+
+def stencil2d_supported(x, padx, pady) -> bool:
+    """Can xg_stencil2d_f64 serve this call (else run the two axes one after the other)?"""
+    shape = tuple(x.shape)  # numpy (host) or torch (HBM) data
+    return (len(shape) >= 2 and shape[-1] % 2 == 0 and sum(padx) == 1 and sum(pady) == 1
+            and shape[-1] > 0 and shape[-2] > 0)
+
+
+def stencil2d(op: str, x, order: int, padx, bc_x: str, fill_x: float, pady, bc_y: str, fill_y: float) -> torch.Tensor:
+    """OP along the last two axes in one pass (xg_stencil2d_f64); order 0 = X then Y, 1 = Y then X."""
+    lib = _hip.load()
+    x = asdevice(x)
+    out = torch.empty(tuple(x.shape), dtype=torch.float64, device=x.device)
+    if out.numel() == 0:
+        return out
+    _hip.check(
+        lib.xg_stencil2d_f64(_hip.OP[op], x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), x.dim(), int(order),
+                             int(padx[0]), int(padx[1]), _hip.BC[bc_x], float(fill_x), int(pady[0]), int(pady[1]),
                              _hip.BC[bc_y], float(fill_y), _stream())
     )
     return out
