@@ -1,12 +1,19 @@
 // xgcm_hip.hip -- hand-written CDNA4 (gfx950) kernels + C ABI for the xgcm staggered-grid hot path.
 //
-// Design: every op is HBM-bound (<= 3 flop per 16 B), so the kernels are built
-// around three rules: (1) every cell is read once and written once -- the boundary halo
-// (periodic / fill / extend) is index arithmetic inside the kernel, never a padded copy;
-// (2) lanes always run along the contiguous (last) dimension with 16-byte accesses, whatever
-// the stencil axis is: along a strided axis each lane MARCHES and keeps the previous value in
-// registers; (3) the unit of scheduling is a 64-lane wave-task (outer index, segment, x-tile),
-// with several independent 16-byte loads in flight per lane before the first use.
+// Design (see DESIGN.md section 3 for the measurements behind each rule): every op is HBM-bound
+// (<= 3 flop per 16 B), so
+//  (1) every cell is read once and written once: the boundary halo (periodic / fill / extend) is
+//      index arithmetic inside the kernel, never a padded copy; metric multiply / divide ride along;
+//  (2) lanes run along the contiguous (last) dimension with 16-byte accesses whatever the op axis
+//      is, ONE vector per lane, thread id == linear memory order (a copy written this way streams
+//      at 80 % of the 8 TB/s spec; 2-8 tiles per thread or grid-stride loops lose 10-35 %);
+//  (3) the set of rows in flight stays compact: along a strided axis a wave register-marches only
+//      4 rows (whole columns only when a row is a whole plane, i.e. the Z axis);
+//  (4) workgroup b runs on XCD b % 8, each XCD has its own L2: the linear work sequence is cut into
+//      8 contiguous bands, one per XCD, so halo-row re-reads and broadcast metrics hit that XCD's
+//      L2 ("banding", "z-banding") -- speed only, never correctness;
+//  (5) per-item index math is 32-bit with multiply-shift division (FastDiv) and wave-uniform parts
+//      on the scalar unit; launches are split on the host so item counts stay below 2^31.
 // No MFMA, no LDS tiling of the field (nothing is reused), LDS only for cross-wave scan carries.
 //
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off (bitwise parity with numpy forbids
@@ -61,8 +68,7 @@ int env_int(const char* name, int dflt) {
 // tunables (read once; override with env vars for on-device tuning sessions)
 struct Tune {
   int seg;       // rows marched per wave-task along a strided stencil axis
-  int nt_store;  // non-temporal stores
-  int nt_load;   // non-temporal loads
+  int nt_store;  // non-temporal stores (+2-4 %; non-temporal LOADS measured -1 % and are not used)
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
   int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
@@ -76,7 +82,6 @@ struct Tune {
     seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
     seg = env_int("XG_SEG", 1 << 30);  // long march: whole column by default
     nt_store = env_int("XG_NT_STORE", 1);
-    nt_load = env_int("XG_NT_LOAD", 0);
   }
 };
 const Tune& tune() {
