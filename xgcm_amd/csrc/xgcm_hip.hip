@@ -71,12 +71,14 @@ struct Tune {
   int nt_store;  // non-temporal stores (+2-4 %; non-temporal LOADS measured -1 % and are not used)
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
+  int contig_gen;     // pair-wise general path for odd / length-changing rows on the contiguous axis
   int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
   int march_lds_kb;   // optional dynamic LDS request for the column-marching kernels, only to cap residency
                       // (experiment: +8 % on a bare march in tools/streambench.hip, but -20 % on the real
                       // kernels whose index/metric math then has too few waves to hide behind) => default 0
   Tune() {
     march_lds_kb = env_int("XG_MARCH_LDS_KB", 0);
+    contig_gen = env_int("XG_CONTIG_GEN", 1);
     deep_waves = env_int("XG_DEEP_WAVES", 0);  // measured neutral (4.80 vs 4.88 TB/s on cumsum along Y): off
     zband = env_int("XG_ZBAND", 1);
     seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
@@ -506,6 +508,60 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     double res = op2<OP>(l, rr);
     if (HAS_MO) res = res / m_out[mob + (int64_t)i0 * mo.axis];
     stg<double, NTS>(orow + i0, res);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1g: contiguous axis, GENERAL lengths (odd rows, N+1 / N-1 outputs: outer/inner positions).
+// Rows of the output are then not 16-B aligned, but the output ARRAY is: the array is walked as
+// a flat list of element PAIRS (which may straddle two rows), each element is computed like the
+// V == 1 path of K1 (two 8-B loads served by L1) and the pair leaves as one aligned 16-B store.
+// Half the threads, index math and store instructions of the one-element-per-thread form.
+// ------------------------------------------------------------------------------------------
+template <int OP, int MET, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
+    const double* __restrict__ in, double* __restrict__ out, Geo g, int64_t row0, u32 nelem, u32 nblk,
+    FastDiv fLo, int pad_lo, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
+    const double* __restrict__ m_out, MIdx mo) {
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 gid = lb * BLOCK + threadIdx.x;
+  if (gid >= (nelem + 1) / 2) return;
+  const u32 e0 = 2 * gid;
+  const u32 Li = (u32)g.n_in, Lo = (u32)g.n_out;
+  const u32 r0 = fdiv(e0, fLo), i0 = e0 - r0 * Lo;
+  const bool have1 = e0 + 1 < nelem;
+  u32 r1 = r0, i1 = i0 + 1;
+  if (i1 == Lo) { i1 = 0; r1 = r0 + 1; }
+  auto one = [&](u32 r, u32 i) -> double {
+    const double* prow = in + (row0 * (int64_t)Li + (u64)r * Li);
+    int64_t ql = (int64_t)i - pad_lo, qr = (int64_t)i + 1 - pad_lo;
+    bool fl = false, fr = false;
+    if (ql < 0) { fl = (bc == XG_BC_FILL); ql = (bc == XG_BC_PERIODIC) ? (int64_t)Li - 1 : 0; }
+    if (qr >= (int64_t)Li) { fr = (bc == XG_BC_FILL); qr = (bc == XG_BC_PERIODIC) ? 0 : (int64_t)Li - 1; }
+    double l = prow[ql], rr = prow[qr];
+    if (HAS_MI) {
+      const int64_t mib = outer_offx(g, mi, row0 + r);
+      l = l * m_in[mib + ql * mi.axis];
+      rr = rr * m_in[mib + qr * mi.axis];
+    }
+    if (fl) l = fill;
+    if (fr) rr = fill;
+    double res = op2<OP>(l, rr);
+    if (HAS_MO) res = res / m_out[outer_offx(g, mo, row0 + r) + (int64_t)i * mo.axis];
+    return res;
+  };
+  double* po = out + (row0 * (int64_t)Lo + (u64)e0);  // row0 * Lo is even (host) => 16-B aligned
+  const double a = one(r0, i0);
+  if (have1) {
+    d2 res;
+    res.x = a;
+    res.y = one(r1, i1);
+    stg<d2, NTS>(po, res);
+  } else {
+    stg<double, NTS>(po, a);
   }
 }
 
@@ -1128,8 +1184,33 @@ int launch_march(const StencilCall& c) {
 // linear-order kernels: split the rows into launches of < 2^31 items
 constexpr u64 MAX_ITEMS = 0x7fffff00ull;
 
+template <int OP, int MET>
+int launch_contig_gen(const StencilCall& c) {
+  const u64 Lo = (u64)c.g.n_out;
+  u64 rows_per = 0xfffffff0ull / Lo;
+  rows_per -= rows_per & 1;  // even number of rows per launch keeps every launch's first pair aligned
+  if (rows_per < 2) return -1;
+  const FastDiv fLo = make_fastdiv(Lo);
+  for (u64 row0 = 0; row0 < (u64)c.g.outer; row0 += rows_per) {
+    const u64 nrows = ((u64)c.g.outer - row0 < rows_per) ? (u64)c.g.outer - row0 : rows_per;
+    const u32 nelem = (u32)(nrows * Lo);
+    const u32 nblk = (u32)((((u64)nelem + 1) / 2 + BLOCK - 1) / BLOCK);
+    const u32 grid = ((nblk + 7) / 8) * 8;
+    if (tune().nt_store)
+      hipLaunchKernelGGL((k_stencil_contig_gen<OP, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nelem, nblk, fLo, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+    else
+      hipLaunchKernelGGL((k_stencil_contig_gen<OP, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nelem, nblk, fLo, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+  }
+  return 0;
+}
+
 template <int OP, int V, int MET>
 int launch_contig(const StencilCall& c) {
+  if (V == 1 && tune().contig_gen && aligned16(c.out) && c.g.n_in <= 0x7fffffffll && c.g.n_out <= 0x7fffffffll &&
+      c.g.outer * c.g.n_out >= 2) {
+    const int rc = launch_contig_gen<OP, MET>(c);
+    if (rc >= 0) return rc;
+  }
   const u64 per = (u64)((c.g.n_out + V - 1) / V);
   if (per > MAX_ITEMS || c.g.n_in > 0x7fffffffll) return fail(XG_ERR_UNSUPPORTED, "row of %llu items too long", per);
   const FastDiv fper = make_fastdiv(per);
