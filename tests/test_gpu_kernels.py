@@ -303,3 +303,18 @@ def test_stencil2d_equals_two_sequential_passes(dev, shape, op):
                 _eq(got, exp)
     assert not dev.stencil2d_supported(dev.asdevice(_field((3, 5, 33), 1)), (1, 0), (1, 0))  # odd nx
     assert not dev.stencil2d_supported(dev.asdevice(a), (1, 1), (1, 0))  # length-changing pair
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/c_abi_demo.c: the boundary is a real C ABI -- compile with gcc, link the .so, run."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_demo")
+    subprocess.check_call(["gcc", "-O2", os.path.join(root, "examples", "c_abi_demo.c"), "-I" + os.path.join(root, "include"),
+                           "-L" + os.path.join(root, "xgcm_amd"), "-lxgcm_hip", "-Wl,-rpath," + os.path.join(root, "xgcm_amd"),
+                           "-lm", "-o", exe])
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "0 mismatching cells" in res.stdout

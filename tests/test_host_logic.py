@@ -173,6 +173,20 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.xg_version() == 1
 
 
+def test_c_abi_header_compiles_as_c_and_links():
+    """The header is plain C and the demo links against the library without a GPU present."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "demo")
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", os.path.join(ROOT, "examples", "c_abi_demo.c"),
+                               "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "xgcm_amd"), "-lxgcm_hip",
+                               "-Wl,-rpath," + os.path.join(ROOT, "xgcm_amd"), "-lm", "-o", exe])
+        res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert res.returncode == 2 and "no GPU" in res.stderr  # loads, reports the missing device, no crash
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "xgcm_amd")
     for fn in os.listdir(pkg):

@@ -613,9 +613,17 @@ def _valid_mask(da: DataArray) -> DataArray:
     return DataArray(_dev.tohost(mask) if host else mask, da.dims)
 
 
+_SELECT_CACHE: Dict[Tuple[str, Tuple], Any] = {}
+
+
 def _select_grid_ufunc(funcname, signature: _GridUFuncSignature, module, **kwargs):
     """The one GridUFunc of `module` whose name starts with `funcname` and whose signature is
-    equivalent to `signature` (reference grid.py:1779-1824)."""
+    equivalent to `signature` (reference grid.py:1779-1824).  Lookups in the built-in `gridops`
+    namespace (fixed at import) are memoised: the scan costs ~65 us, a kernel on a small array less."""
+    builtin = module is gridops
+    key = (funcname, signature._canonical())
+    if builtin and key in _SELECT_CACHE:
+        return _SELECT_CACHE[key], kwargs
     named = [f for name, f in sorted(vars(module).items()) if isinstance(f, GridUFunc) and name.startswith(funcname)]
     if not named:
         raise NotImplementedError(f"Could not find any pre-defined {funcname} grid ufuncs")
@@ -626,4 +634,6 @@ def _select_grid_ufunc(funcname, signature: _GridUFuncSignature, module, **kwarg
         raise ValueError(
             f"Function {funcname} with signature='{signature}' and kwargs={kwargs.copy()} is an ambiguous selection"
         )
+    if builtin:
+        _SELECT_CACHE[key] = matching[0]
     return matching[0], kwargs
