@@ -260,6 +260,40 @@ def test_coords_reattached_from_grid_and_inputs(backend):
     assert "dx_t" not in res.coords
 
 
+@pytest.mark.parametrize("funcname", ["diff", "interp", "min", "max", "integrate", "average", "cumsum", "cumint", "derivative"])
+def test_keep_coords_all_operators(backend, funcname):
+    """reference test_grid.py:571-611: result coords == its dim coords + every dataset coord that fits."""
+    ds, coords, metrics = cgrid()
+    ds = Dataset(ds.data_vars, {**ds.coords, "yt_bis": ("yt", ds["yt"].values), "xt_bis": ("xt", ds["xt"].values)})
+    grid = Grid(ds, coords=coords, metrics=metrics, padding="periodic", autoparse_metadata=False)
+    func = getattr(grid, funcname)
+    for axis_name in grid.axes:
+        result = func(ds["tracer"], axis_name)
+        fits = [c for c in ds.coords if set(ds[c].dims).issubset(result.dims)]
+        assert set(result.coords) == set(fits), (funcname, axis_name)
+
+
+@pytest.mark.parametrize("funcname", ["interp", "diff", "cumsum"])
+def test_preserve_input_noncore_coords(backend, funcname):
+    """reference test_grid.py:648-756 (GH #496): coords the user changed on NON-core dims survive with their
+    dtype; the shifted core dim's coord comes from the grid; coords on the old core dim disappear."""
+    N = 8
+    ds = Dataset({"v": (("time", "XC"), R.synthetic_field((N, N), 5))},
+                 coords={"XC": ("XC", np.arange(N) + 0.5), "XG": ("XG", np.arange(N) * 1.0),
+                         "time": ("time", np.arange(N) * 600.0), "t_label": ("time", np.arange(N).astype("int64")),
+                         "xc_aux": ("XC", np.arange(N).astype("int64") * 10)})
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", autoparse_metadata=False)
+    new_time = (np.arange(N) * 600 / 3600.0).astype(np.float32)
+    new_t_label = (np.arange(N) + 100).astype(np.float32)
+    v = ds["v"].assign_coords({"time": ("time", new_time), "t_label": ("time", new_t_label),
+                               "xc_aux": ("XC", (np.arange(N) + 500).astype(np.float32))})
+    out = grid.cumsum(v, "X", to="left") if funcname == "cumsum" else getattr(grid, funcname)(v, "X")
+    assert out.coords["time"].dtype == np.float32 and np.array_equal(out.coords["time"].values, new_time)
+    assert out.coords["t_label"].dtype == np.float32 and np.array_equal(out.coords["t_label"].values, new_t_label)
+    assert np.array_equal(out.coords["XG"].values, ds["XG"].values)
+    assert "XC" not in out.dims and "xc_aux" not in out.coords
+
+
 def test_no_coords_dataset(backend):
     """reference test_grid.py:173-186: datasets without dimension coordinates work."""
     ds = Dataset({"c": ("xc", R.synthetic_field((8,), 1)), "g": ("xg", R.synthetic_field((8,), 2))})

@@ -113,6 +113,53 @@ def test_decorator_kwarg_validation():
         u.boundary_width
 
 
+def test_signature_from_type_hints():
+    """reference test/test_grid_ufunc.py:104-213 (TestParseSignatureFromTypeHints)."""
+    from typing import Annotated, Tuple
+
+    import numpy as np
+
+    with pytest.raises(ValueError, match="Must specify axis positions"):
+
+        @as_grid_ufunc()
+        def nothing(): ...
+
+    @as_grid_ufunc()
+    def f1(a: Annotated[np.ndarray, "X:center"]) -> Annotated[np.ndarray, "X:center"]:
+        return a
+
+    assert str(f1.signature) == "(X:center)->(X:center)"
+
+    @as_grid_ufunc()
+    def f2(a: Annotated[np.ndarray, "X:center,Y:center"]) -> Annotated[np.ndarray, "X:center"]:
+        return a
+
+    assert str(f2.signature) == "(X:center,Y:center)->(X:center)"
+
+    @as_grid_ufunc()
+    def f3(a: Annotated[np.ndarray, "X:left"], b: Annotated[np.ndarray, "Y:right"]) -> Annotated[np.ndarray, "X:center"]:
+        return a
+
+    assert str(f3.signature) == "(X:left),(Y:right)->(X:center)"
+
+    @as_grid_ufunc()
+    def f4(a: Annotated[np.ndarray, "X:center"]) -> Tuple[Annotated[np.ndarray, "X:left"], Annotated[np.ndarray, "Y:right"]]:
+        return a, a
+
+    assert str(f4.signature) == "(X:center)->(X:left),(Y:right)"
+
+    @as_grid_ufunc()
+    def f5(a: Annotated[np.ndarray, "X:center"]) -> Annotated[np.ndarray, "X:left,Y:right"]:
+        return a
+
+    assert str(f5.signature) == "(X:center)->(X:left,Y:right)"
+    with pytest.raises(ValueError, match="only one of either type hints or signature kwarg"):
+
+        @as_grid_ufunc(signature="(X:center)->(X:left)")
+        def both(a: Annotated[np.ndarray, "X:center"]) -> Annotated[np.ndarray, "X:left"]:
+            return a
+
+
 def _ds(n=9):
     import numpy as np
 

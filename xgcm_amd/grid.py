@@ -269,12 +269,9 @@ class Grid:
                 continue
             if here != there:
                 shifted.append(name)
-        to = {}
-        for name in shifted:
-            to[name] = self.axes[name]._get_position_name(like)[0]
-        if not shifted:
-            return array
-        return self._1d_grid_ufunc_dispatch("interp", array, shifted, to=to, fill_value=fill_value, padding=padding)
+        # like the reference (grid.py:710-715) the target position is NOT passed on: each axis moves by
+        # its default shift, which is `like`'s position on the usual two-position (center + one edge) axes
+        return self._1d_grid_ufunc_dispatch("interp", array, shifted, fill_value=fill_value, padding=padding)
 
     # ---- the hot path: 1-D operators ---------------------------------------------------------
     def _create_1d_grid_ufunc_signatures(self, da, axis, to) -> List[_GridUFuncSignature]:

@@ -96,6 +96,26 @@ class _GridUFuncSignature:
     def from_string(cls, signature: str) -> "_GridUFuncSignature":
         return cls(*_parse_signature_from_string(signature))
 
+    @classmethod
+    def from_type_hints(cls, hints: Dict[str, Any]) -> "_GridUFuncSignature":
+        """From `typing.get_type_hints(ufunc, include_extras=True)`: every argument / return value
+        annotated as `Annotated[np.ndarray, "X:center,Y:left"]` contributes one signature argument
+        (reference grid_ufunc.py:303-361)."""
+        hints = dict(hints)
+        if "return" in hints:
+            out_anns = [_annotation_of(h) for h in _return_hints(hints.pop("return"))]
+            out_anns = [a for a in out_anns if a is not None]
+            out_names = [tuple(n for n, _ in _PAIR.findall(a)) for a in out_anns]
+            out_pos = [tuple(p for _, p in _PAIR.findall(a)) for a in out_anns]
+        else:
+            out_names, out_pos = [()], [()]
+        in_anns = [a for a in (_annotation_of(h) for h in hints.values()) if a is not None]
+        in_names = [tuple(n for n, _ in _PAIR.findall(a)) for a in in_anns]
+        in_pos = [tuple(p for _, p in _PAIR.findall(a)) for a in in_anns]
+        sig = cls(in_names, in_pos, out_names, out_pos)
+        _parse_signature_from_string(str(sig))  # sanity check, raises "Not a valid grid ufunc signature"
+        return sig
+
     def __str__(self) -> str:
         def side(names, poss):
             return ",".join("(" + ",".join(f"{n}:{p}" for n, p in zip(ns, ps)) + ")" for ns, ps in zip(names, poss))
@@ -117,6 +137,44 @@ class _GridUFuncSignature:
     def equivalent(self, other: "_GridUFuncSignature") -> bool:
         """Equal up to a consistent renaming of the dummy axis names; positions must match exactly."""
         return self._canonical() == other._canonical()
+
+
+def _annotation_of(hint) -> Optional[str]:
+    meta = getattr(hint, "__metadata__", None)
+    return meta[0] if meta else None
+
+
+def _return_hints(hint) -> list:
+    """`Tuple[Annotated[...], Annotated[...]]` -> its members; anything else -> [hint]."""
+    import typing
+
+    if typing.get_origin(hint) is tuple:
+        return list(typing.get_args(hint))
+    return [hint]
+
+
+def _signature_from_str_or_type_hints(ufunc, str_sig) -> "_GridUFuncSignature":
+    """Axis positions come from the `signature` kwarg or from `Annotated` type hints, never both
+    (reference grid_ufunc.py:472-502)."""
+    import typing
+
+    if isinstance(str_sig, _GridUFuncSignature):
+        return str_sig
+    try:
+        hints = typing.get_type_hints(ufunc, include_extras=True)
+    except Exception:  # builtins, partials, objects without introspectable annotations
+        hints = {}
+    annotated = any(_annotation_of(h) is not None for k, h in hints.items() if k != "return") or (
+        "return" in hints and any(_annotation_of(h) is not None for h in _return_hints(hints["return"])))
+    if str_sig:
+        if annotated:
+            raise ValueError(
+                "Must specify axis positions through only one of either type hints or signature kwarg, not both."
+            )
+        return _GridUFuncSignature.from_string(str_sig)
+    if not annotated:
+        raise ValueError("Must specify axis positions through either type hints or signature kwarg")
+    return _GridUFuncSignature.from_type_hints(hints)
 
 
 # ------------------------------------------------------------------------------------------
@@ -243,8 +301,7 @@ class GridUFunc:
             raise ValueError(
                 "Argument 'boundary_width' has been renamed to 'padding_width'. Please use 'padding_width' instead."
             )
-        sig = kwargs.pop("signature")
-        self.signature = sig if isinstance(sig, _GridUFuncSignature) else _GridUFuncSignature.from_string(sig)
+        self.signature = _signature_from_str_or_type_hints(ufunc, kwargs.pop("signature", ""))
         self.padding_width = kwargs.pop("padding_width", None)
         self.padding = kwargs.pop("padding", None)
         self.fill_value = kwargs.pop("fill_value", None)
