@@ -435,6 +435,68 @@ def test_get_metric_conditions(backend):
     grid.set_metrics(("X",), "dx_t", overwrite=True)
 
 
+def test_get_metric_reference_scenarios(backend):
+    """reference test_metrics.py:172-326, scenario by scenario (values via the operators themselves)."""
+    ds, coords, metrics = cgrid()
+    raw = lambda name: ds[name].reset_coords(drop=True)  # noqa: E731
+    # test_get_metric_orig
+    grid = Grid(ds, coords=coords, metrics=metrics, autoparse_metadata=False)
+    for axes, var, want in [("X", "tracer", "dx_t"), (["X", "Y"], "tracer", "area_t"), (("X", "Y"), "tracer", "area_t"),
+                            (["X", "Y", "Z"], "tracer", "volume_t"), (["X"], "u", "dx_e"), (["X", "Y"], "u", "area_e")]:
+        assert np.array_equal(grid.get_metric(ds[var], axes).values, raw(want).values)
+    # 02a: exact axes registered elsewhere -> interpolated (boundary 'extend'), default-shift semantics
+    g = Grid(ds, coords=coords, padding="extend", autoparse_metadata=False)
+    g.set_metrics(("X", "Y"), "area_e")
+    with pytest.warns(UserWarning, match="being interpolated"):
+        got = g.get_metric(ds["v"], ("X", "Y"))
+    assert np.array_equal(got.values, g.interp(ds["area_e"], ("X", "Y")).values)
+    # 02b: the exact-axes metric wins over sub-axis metrics even at matching positions
+    g = Grid(ds, coords=coords, padding="periodic", autoparse_metadata=False)
+    g.set_metrics(("X", "Y"), "area_e")
+    g.set_metrics(("X"), "dx_n")
+    g.set_metrics(("Y"), "dx_n")
+    with pytest.warns(UserWarning, match="being interpolated"):
+        got = g.get_metric(ds["v"], ("X", "Y"))
+    assert np.array_equal(got.values, g.interp(ds["area_e"], ("X", "Y"), padding="extend").values)
+    # 03a / 03b: products of sub-axis metrics
+    g = Grid(ds, coords=coords, autoparse_metadata=False)
+    g.set_metrics(("X"), "dx_n")
+    g.set_metrics(("Y"), "dy_n")
+    assert np.array_equal(g.get_metric(ds["v"], ("X", "Y")).values, ds["dx_n"].values * ds["dy_n"].values)
+    g = Grid(ds, coords=coords, autoparse_metadata=False)
+    g.set_metrics(("X", "Y"), "area_t")
+    g.set_metrics(("Z"), "dz_t")
+    m = g.get_metric(ds["tracer"], ("X", "Y", "Z")).transpose("xt", "yt", "time", "zt")
+    assert np.array_equal(m.values, ds["area_t"].values[:, :, None, None] * ds["dz_t"].values)
+    # 04a / 04b: wrong-position sub-axis metrics are interpolated first, one warning
+    g = Grid(ds, coords=coords, padding="periodic", autoparse_metadata=False)
+    g.set_metrics(("X"), "dx_t")
+    g.set_metrics(("Y"), "dy_n")
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = g.get_metric(ds["v"], ("X", "Y"))
+    assert len([w for w in caught if "being interpolated" in str(w.message)]) == 1
+    want = g.interp(ds["dx_t"], "Y", padding="extend").values * ds["dy_n"].values
+    assert np.array_equal(got.values, want)
+    g = Grid(ds, coords=coords, padding="periodic", autoparse_metadata=False)
+    g.set_metrics(("X"), "dx_t")
+    g.set_metrics(("Y"), "dy_t")
+    with pytest.warns(UserWarning, match="being interpolated"):
+        got = g.get_metric(ds["v"], ("X", "Y"))
+    want = g.interp(ds["dx_t"], "Y", padding="extend").values * g.interp(ds["dy_t"], "Y", padding="extend").values
+    assert np.array_equal(got.values, want)
+    # GH #756: an exact-position combination found late must not emit interpolation warnings
+    for var, zs, dz in (("tracer", ["dz_w", "dz_w_n", "dz_w_e", "dz_t"], "dz_t"), ("wt", ["dz_t", "dz_w"], "dz_w")):
+        g = Grid(ds, coords=coords, metrics={("X", "Y"): ["area_t", "area_n", "area_e", "area_ne"], ("Z",): zs},
+                 autoparse_metadata=False)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            m = g.get_metric(ds[var], ("X", "Y", "Z"))
+        assert [w for w in caught if "being interpolated" in str(w.message)] == []
+        dims = ds[dz].dims
+        assert np.array_equal(m.transpose(*dims).values, ds["area_t"].values[:, :, None, None] * ds[dz].values)
+
+
 # ----------------------------------------------------------------------------------------------
 # cumsum (reference test_grid.py:196-370)
 # ----------------------------------------------------------------------------------------------
