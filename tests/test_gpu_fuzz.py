@@ -1,0 +1,127 @@
+"""Seeded differential fuzzing of the C ABI against the oracle: random ranks, extents (odd, even,
+1), op axes, position pairs, boundary modes and metric broadcast patterns -- the combinations
+that steer the host-side dim coalescing, vector/scalar kernel choice, XCD banding, z-banding and
+launch splitting.  Bit-exact except contiguous-axis scans/reductions (1e-12)."""
+
+import itertools
+
+import numpy as np
+import pytest
+
+from oracle import refimpl as R
+
+pytestmark = pytest.mark.gpu
+
+PADS = [(1, 0), (0, 1), (1, 1), (0, 0)]
+BCS = ["periodic", "fill", "extend"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from xgcm_amd import device
+
+    return device
+
+
+def _shape(rng):
+    nd = int(rng.integers(1, 6))
+    pool = [1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 17, 31, 32, 33, 64, 66, 70, 128, 130, 257]
+    shape = [int(rng.choice(pool)) for _ in range(nd)]
+    while np.prod(shape) > 400_000:
+        shape[int(rng.integers(0, nd))] = int(rng.choice([1, 2, 3, 5]))
+    return tuple(shape)
+
+
+def _metric(rng, shape, seed):
+    """random broadcast pattern: each dim independently full or 1 (at least the values are positive)."""
+    mshape = tuple(s if rng.random() < 0.5 else 1 for s in shape)
+    return R.synthetic_metric(mshape, seed)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_stencil(dev, seed):
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(25):
+        shape = _shape(rng)
+        axis = int(rng.integers(0, len(shape)))
+        op = str(rng.choice(["diff", "interp", "min", "max"]))
+        lo, hi = PADS[int(rng.integers(0, 4))]
+        if shape[axis] + lo + hi - 1 < 1:
+            continue
+        bc = str(rng.choice(BCS))
+        a = R.synthetic_field(shape, 7000 + 31 * seed + case)
+        if op in ("min", "max") and a.size > 4:
+            a.reshape(-1)[rng.integers(0, a.size, 2)] = np.nan
+        oshape = list(shape)
+        oshape[axis] += lo + hi - 1
+        kind = int(rng.integers(0, 4))
+        m_in = _metric(rng, shape, 11 + case) if kind in (2, 3) else None
+        m_out = _metric(rng, oshape, 23 + case) if kind in (1, 3) else None
+        fill = float(rng.choice([0.0, 1.5, -2.25]))
+        exp = R.stencil1d(op, a, axis, lo, hi, bc, fill, m_in, m_out)
+        got = dev.tohost(dev.stencil1d(op, a, axis, lo, hi, bc, fill, m_in, m_out))
+        assert got.shape == exp.shape, (shape, axis, op, lo, hi, bc)
+        assert np.array_equal(got, exp, equal_nan=True), (shape, axis, op, (lo, hi), bc, kind,
+                                                           None if m_in is None else m_in.shape,
+                                                           None if m_out is None else m_out.shape)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_cumsum_reduce(dev, seed):
+    rng = np.random.default_rng(2000 + seed)
+    tables = [(0, 0, 0, 0), (0, 1, 1, 0), (0, 1, 0, 0), (0, 0, 1, 0), (1, 0, 0, 1), (1, 0, 0, 0), (0, 0, 0, 1)]
+    for case in range(20):
+        shape = _shape(rng)
+        axis = int(rng.integers(0, len(shape)))
+        tl, th, pl, ph = tables[int(rng.integers(0, len(tables)))]
+        if shape[axis] - tl - th < 1:
+            continue
+        bc = str(rng.choice(BCS))
+        reverse, skipna = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        a = R.synthetic_field(shape, 9000 + 17 * seed + case)
+        if a.size > 4 and rng.random() < 0.5:
+            a.reshape(-1)[rng.integers(0, a.size, 2)] = np.nan
+        oshape = list(shape)
+        oshape[axis] += pl + ph - tl - th
+        m_in = _metric(rng, shape, 5 + case) if rng.random() < 0.4 else None
+        m_out = _metric(rng, oshape, 6 + case) if rng.random() < 0.4 else None
+        exp = R.cumsum1d(a, axis, tl, th, pl, ph, bc, 0.5, reverse, skipna, m_in, m_out)
+        got = dev.tohost(dev.cumsum1d(a, axis, tl, th, pl, ph, bc, 0.5, reverse, skipna, m_in, m_out))
+        contiguous = axis == len(shape) - 1 or all(s == 1 for s in shape[axis + 1:])
+        if contiguous:
+            np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-9, equal_nan=True)
+        else:
+            assert np.array_equal(got, exp, equal_nan=True), (shape, axis, (tl, th, pl, ph), bc, reverse, skipna)
+        w = _metric(rng, shape, 8 + case) if rng.random() < 0.5 else None
+        exp = R.integrate(a, axis, w, skipna)
+        got = dev.tohost(dev.reduce1d(a, axis, w, skipna))
+        if contiguous:
+            np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-9, equal_nan=True)
+        else:
+            assert np.array_equal(got, exp, equal_nan=True), (shape, axis, "reduce", skipna)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_two_axis_and_vorticity(dev, seed):
+    rng = np.random.default_rng(3000 + seed)
+    for case in range(15):
+        nd = int(rng.integers(2, 5))
+        shape = tuple(int(rng.choice([1, 2, 3, 5])) for _ in range(nd - 2)) + (int(rng.choice([1, 2, 3, 4, 5, 9, 33])),
+                                                                              int(rng.choice([2, 4, 6, 64, 130, 258])))
+        a = R.synthetic_field(shape, 100 + case)
+        b = R.synthetic_field(shape, 200 + case)
+        op = str(rng.choice(["diff", "interp", "min", "max"]))
+        order = int(rng.integers(0, 2))
+        padx, pady = [(1, 0), (0, 1)][int(rng.integers(0, 2))], [(1, 0), (0, 1)][int(rng.integers(0, 2))]
+        bcx, bcy = str(rng.choice(BCS)), str(rng.choice(BCS))
+        ax_x, ax_y = nd - 1, nd - 2
+        if order == 0:
+            exp = R.stencil1d(op, R.stencil1d(op, a, ax_x, *padx, bcx, 0.5), ax_y, *pady, bcy, -1.0)
+        else:
+            exp = R.stencil1d(op, R.stencil1d(op, a, ax_y, *pady, bcy, -1.0), ax_x, *padx, bcx, 0.5)
+        got = dev.tohost(dev.stencil2d(op, a, order, padx, bcx, 0.5, pady, bcy, -1.0))
+        assert np.array_equal(got, exp, equal_nan=True), (shape, op, order, padx, pady, bcx, bcy)
+        area = R.synthetic_metric((1,) * (nd - 2) + shape[-2:], 300 + case) if rng.random() < 0.7 else None
+        exp = R.vorticity(a, b, area if area is not None else np.ones((1,) * nd), bcx, bcy, 0.25, -0.5)
+        got = dev.tohost(dev.vorticity(a, b, area, bcx, bcy, 0.25, -0.5))
+        assert np.array_equal(got, exp), (shape, "vorticity", bcx, bcy, area is not None)
