@@ -3,8 +3,6 @@
 that steer the host-side dim coalescing, vector/scalar kernel choice, XCD banding, z-banding and
 launch splitting.  Bit-exact except contiguous-axis scans/reductions (1e-12)."""
 
-import itertools
-
 import numpy as np
 import pytest
 

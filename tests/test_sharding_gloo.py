@@ -45,7 +45,6 @@ def _worker(rank, world, port, tmp):
     try:
         from oracle import fake_device
         from oracle import refimpl as R
-        import xgcm_amd.device as dev
 
         class MP:  # minimal monkeypatch stand-in
             def setattr(self, obj, name, val):

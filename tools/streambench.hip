@@ -207,6 +207,30 @@ __global__ __launch_bounds__(BLK) void k_diffz_occ(const double* __restrict__ in
   }
 }
 
+
+// Z-march where each lane owns RT x-tiles that are ADJACENT (so a wave touches RT KiB contiguous per
+// level) and keeps U levels in flight: RT*U loads per lane, grouped by DRAM locality.
+template <int RT, int U>
+__global__ __launch_bounds__(256) void k_diffz_rt(const double* __restrict__ in, double* __restrict__ out, unsigned n, size_t inner) {
+  const unsigned wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  size_t x0 = ((size_t)wave * RT * 64 + lane) * 2;  // tile r at x0 + r*128
+  if (x0 >= inner) return;
+  d2 prev[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) prev[r] = (x0 + (size_t)r * 128 < inner) ? *(const d2*)(in + x0 + (size_t)r * 128) : d2{0, 0};
+  for (unsigned j = 0; j < n; j += U) {
+    d2 v[U][RT];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < RT; ++r) if (j + u < n && x0 + (size_t)r * 128 < inner) v[u][r] = *(const d2*)(in + (size_t)(j + u) * inner + x0 + (size_t)r * 128);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < RT; ++r) if (j + u < n && x0 + (size_t)r * 128 < inner) { st<true>((d2*)(out + (size_t)(j + u) * inner + x0 + (size_t)r * 128), v[u][r] - prev[r]); prev[r] = v[u][r]; }
+  }
+}
+
 __global__ void k_rand(double* out, size_t n) {
   size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -302,5 +326,10 @@ int main() {
   DZB(2, 256, 160, "diffZ 1x256/CU U2") DZB(3, 256, 160, "diffZ 1x256/CU U3") DZB(4, 256, 160, "diffZ 1x256/CU U4") DZB(5, 256, 160, "diffZ 1x256/CU U5") DZB(6, 256, 160, "diffZ 1x256/CU U6")
   DZB(4, 512, 160, "diffZ 1x512/CU U4") DZB(2, 512, 160, "diffZ 1x512/CU U2") DZB(4, 128, 160, "diffZ 1x128/CU U4") DZB(8, 128, 160, "diffZ 1x128/CU U8") DZB(8, 64, 160, "diffZ 1x64/CU U8")
   DZB(3, 256, 80, "diffZ 2x256/CU U3") DZB(4, 256, 80, "diffZ 2x256/CU U4") DZB(5, 256, 80, "diffZ 2x256/CU U5") DZB(4, 1024, 160, "diffZ 1x1024/CU U4") DZB(2, 1024, 160, "diffZ 1x1024/CU U2")
+
+#define DZR(RT, U, NAME) { unsigned nn = 75; size_t inner = n / nn; unsigned nw = (unsigned)((inner / 2 + 64 * RT - 1) / (64 * RT)); \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_diffz_rt<RT, U>), dim3((nw + 3) / 4), dim3(256), 0, 0, in, out, nn, inner); }); report(NAME, ms); }
+  DZR(1, 4, "diffZ rt: RT1 U4") DZR(2, 2, "diffZ rt: RT2 U2") DZR(2, 4, "diffZ rt: RT2 U4") DZR(4, 1, "diffZ rt: RT4 U1") DZR(4, 2, "diffZ rt: RT4 U2")
+  DZR(8, 1, "diffZ rt: RT8 U1") DZR(4, 4, "diffZ rt: RT4 U4") DZR(2, 1, "diffZ rt: RT2 U1") DZR(1, 1, "diffZ rt: RT1 U1") DZR(1, 8, "diffZ rt: RT1 U8")
   return 0;
 }

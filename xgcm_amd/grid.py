@@ -25,7 +25,7 @@ import itertools
 import operator
 import warnings
 from collections import OrderedDict
-from typing import Any, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple, Union
+from typing import Any, Dict, Iterable, List, Mapping, Optional, Tuple
 
 import numpy as np
 
@@ -42,7 +42,7 @@ from .grid_ufunc import (
 )
 from .labeled import DataArray, Dataset, _aligned_view, _is_tensor, from_xarray, is_xarray, to_xarray
 from .metrics import iterate_axis_combinations
-from .padding import no_boundary_error, pad
+from .padding import no_boundary_error
 
 
 def _maybe_promote_str_to_list(a):

@@ -21,7 +21,6 @@ from typing import Any, Callable, Dict, List, Mapping, Optional, Sequence, Set, 
 
 import numpy as np
 
-from . import device as _dev
 from .labeled import DataArray, _is_tensor
 from .padding import pad
 

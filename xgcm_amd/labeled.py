@@ -14,7 +14,7 @@ results converted back with `to_xarray` (xgcm_amd/grid.py).
 from __future__ import annotations
 
 from collections import OrderedDict
-from typing import Any, Dict, Hashable, Iterable, Mapping, Optional, Sequence, Tuple, Union
+from typing import Any, Dict, Mapping, Optional, Sequence, Tuple
 
 import numpy as np
 

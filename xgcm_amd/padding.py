@@ -13,7 +13,7 @@ the stencil kernels (xgcm_amd/gridops.py).
 
 from __future__ import annotations
 
-from typing import Dict, Mapping, Optional, Tuple, Union
+from typing import Dict, Mapping, Optional, Tuple
 
 from . import device as _dev
 from .labeled import DataArray, _is_tensor
