@@ -234,6 +234,27 @@ def test_c_abi_header_compiles_as_c_and_links():
         assert res.returncode == 2 and "no GPU" in res.stderr  # loads, reports the missing device, no crash
 
 
+def test_fails_loudly_without_library_or_gpu(monkeypatch):
+    """No silent fallback: a missing .so is an ImportError, a missing GPU a RuntimeError."""
+    import numpy as np
+    import torch
+
+    from xgcm_amd import DataArray, Grid, device
+
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", os.path.join(ROOT, "xgcm_amd", "no_such_library.so"))
+    with pytest.raises(ImportError, match="has not been built"):
+        _hip.load()
+    monkeypatch.undo()
+    if not torch.cuda.is_available():
+        ds = Dataset(coords={"xc": ("xc", np.arange(8.0)), "xg": ("xg", np.arange(8.0))})
+        grid = Grid(ds, coords={"X": {"center": "xc", "left": "xg"}}, padding="periodic", autoparse_metadata=False)
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            grid.diff(DataArray(np.arange(8.0), ("xc",)), "X")
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            device.stencil1d("diff", np.arange(8.0), 0, 1, 0, "periodic")
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "xgcm_amd")
     for fn in os.listdir(pkg):

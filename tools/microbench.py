@@ -104,6 +104,21 @@ def main():
         rec("sum_Y", ms, b, 8)
         ms, b = timeit(lambda: D.reduce1d(T, 2, None), args.reps)
         rec("sum_X(wave per row)", ms, b, 8)
+    if "generic" in cases:
+        ms, b = timeit(lambda: D.pad_nd(T, {2: (1, 1)}, {2: "periodic"}, {}), args.reps)
+        rec("pad_X(1,1)_periodic(generic k_pad)", ms, b, 16)
+        ms, b = timeit(lambda: D.pad_nd(T, {1: (0, 1), 2: (2, 0)}, {1: "extend", 2: "fill"}, {2: 1.5}), args.reps)
+        rec("pad_Y(0,1)+X(2,0)(generic k_pad)", ms, b, 16)
+        B = D.synthetic(shape, 9)
+        ms, b = timeit(lambda: D.binary("mul", T, B), args.reps)
+        rec("binary_mul_full(3 streams)", ms, b, 24)
+        dx = D.synthetic((1, ny, nx), 31, 0, 1000.0, 1000.0)
+        ms, b = timeit(lambda: D.binary("div", T, dx), args.reps)
+        rec("binary_div_bcast2D", ms, b, 16 + 8 / nz)
+        dz = D.synthetic((nz, 1, 1), 33, 0, 1000.0, 1000.0)
+        ms, b = timeit(lambda: D.binary("mul", T, dz), args.reps)
+        rec("binary_mul_bcast1D", ms, b, 16)
+        del B
     if "vort" in cases:
         U = D.synthetic(shape, 51)
         V = D.synthetic(shape, 52)

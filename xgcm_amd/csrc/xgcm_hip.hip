@@ -319,6 +319,17 @@ __device__ __forceinline__ int64_t inner_off32(const Geo& g, const MIdx& m, u32 
   }
   return off;
 }
+// metric offset + lane step along the coalesced inner dims for a V-wide lane starting at inner index x
+// (valid when g.idx32; the single-inner-dim case -- metric varies only along X -- is just a multiply)
+__device__ __forceinline__ void inner_off_step32(const Geo& g, const MIdx& m, u32 x, bool pair, int64_t& off, int64_t& step) {
+  if (g.n_inner == 1) {
+    off = (int64_t)x * m.inner[0];
+    step = m.inner[0];
+    return;
+  }
+  off = inner_off32(g, m, x);
+  step = pair ? inner_off32(g, m, x + 1) - off : 0;
+}
 __device__ __forceinline__ int64_t outer_offx(const Geo& g, const MIdx& m, int64_t o) {
   return g.idx32 ? outer_off32(g, m, (u32)o) : outer_off(g, m, o);
 }
@@ -464,17 +475,24 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
   u32 r = fdiv(gid, per);  // per.d = V-wide items per output row
   if (r >= nrows) return;
   const u32 i0 = (gid - r * per.d) * V;
+  u32 zz = 0, zy = 0;
   if (MET != 0 && zb.on) {
-    u32 z, y;
-    if (!zband_map(zb, r, z, y)) return;
-    r = z * zb.Y + y;
+    if (!zband_map(zb, r, zz, zy)) return;
+    r = zz * zb.Y + zy;
   }
   const u32 Li = (u32)g.n_in, Lo = (u32)g.n_out;  // host guarantees row lengths < 2^31
   const double* prow = in + (row0 * (int64_t)Li + (u64)r * Li);
   double* orow = out + (row0 * (int64_t)Lo + (u64)r * Lo);
+  // metric row offsets: with z-banding (z, y) are already known, else one FastDiv per outer dim
+  // (the host only selects this kernel with metrics when g.idx32 holds)
   int64_t mib = 0, mob = 0;
-  if (HAS_MI) mib = outer_offx(g, mi, row0 + r);
-  if (HAS_MO) mob = outer_offx(g, mo, row0 + r);
+  if (MET != 0 && zb.on) {  // outer dims are exactly (Z, Y)
+    if (HAS_MI) mib = (int64_t)zz * mi.outer[0] + (int64_t)zy * mi.outer[1];
+    if (HAS_MO) mob = (int64_t)zz * mo.outer[0] + (int64_t)zy * mo.outer[1];
+  } else {
+    if (HAS_MI) mib = outer_off32(g, mi, (u32)(row0 + r));
+    if (HAS_MO) mob = outer_off32(g, mo, (u32)(row0 + r));
+  }
 
   if (V == 2) {
     u32 nidx;
@@ -543,14 +561,14 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
     if (qr >= (int64_t)Li) { fr = (bc == XG_BC_FILL); qr = (bc == XG_BC_PERIODIC) ? 0 : (int64_t)Li - 1; }
     double l = prow[ql], rr = prow[qr];
     if (HAS_MI) {
-      const int64_t mib = outer_offx(g, mi, row0 + r);
+      const int64_t mib = outer_off32(g, mi, (u32)(row0 + r));
       l = l * m_in[mib + ql * mi.axis];
       rr = rr * m_in[mib + qr * mi.axis];
     }
     if (fl) l = fill;
     if (fr) rr = fill;
     double res = op2<OP>(l, rr);
-    if (HAS_MO) res = res / m_out[outer_offx(g, mo, row0 + r) + (int64_t)i * mo.axis];
+    if (HAS_MO) res = res / m_out[outer_off32(g, mo, (u32)(row0 + r)) + (int64_t)i * mo.axis];
     return res;
   };
   double* po = out + (row0 * (int64_t)Lo + (u64)e0);  // row0 * Lo is even (host) => 16-B aligned
@@ -608,14 +626,14 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
   const double* pin = in + (o * g.n_in) * inner + x;
   double* pout = out + (o * g.n_out + j0) * inner + x;
 
-  int64_t mib = 0, mob = 0, mis = 0, mos = 0;
+  int64_t mib = 0, mob = 0, mis = 0, mos = 0;  // (host guarantees g.idx32 when metrics are present)
   if (HAS_MI) {
-    mib = outer_offx(g, mi, o) + inner_offx(g, mi, x);
-    mis = (V == 2) ? inner_offx(g, mi, x + 1) - inner_offx(g, mi, x) : 0;
+    inner_off_step32(g, mi, (u32)x, V == 2, mib, mis);
+    mib += outer_off32(g, mi, (u32)o);
   }
   if (HAS_MO) {
-    mob = outer_offx(g, mo, o) + inner_offx(g, mo, x) + j0 * mo.axis;
-    mos = (V == 2) ? inner_offx(g, mo, x + 1) - inner_offx(g, mo, x) : 0;
+    inner_off_step32(g, mo, (u32)x, V == 2, mob, mos);
+    mob += outer_off32(g, mo, (u32)o) + j0 * mo.axis;
   }
 
   // padded index k = j0 + u  ->  input row q (wave-uniform), fill flag
@@ -1386,6 +1404,8 @@ int xg_stencil1d_f64(int op, const double* in, double* out, const int64_t* shape
     const int64_t ntile = (g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V);
     kind = (ntile <= (int64_t)tune().seg_max_tiles) ? KIND_LIN : KIND_MARCH;
   }
+  if (met != 0 && kind != KIND_MARCH && !g.idx32)
+    return fail(XG_ERR_UNSUPPORTED, "metric-weighted stencils need outer/inner extents below 2^32");
   rc = stencil_dispatch(op, V, met, kind, c);
   if (rc) return rc;
   XG_LAUNCH_CHECK();
