@@ -437,9 +437,22 @@ def kats():
     return k
 
 
+def config1(gridops):
+    """BASELINE.json configs[0]: Grid.diff along X on a 128 x 64 periodic C-grid (YC=64, XC=128), f64,
+    center->left: the reference's own ufunc body on the numpy.pad(wrap)-ed synthetic field (seed 1)."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    from oracle.refimpl import synthetic_field
+
+    a = synthetic_field((64, 128), 1)
+    p = np.pad(a, [(0, 0), (1, 0)], "wrap")
+    return {"in": a, "diff_X_center_to_left_periodic": gridops.diff_center_to_left.ufunc(p),
+            "interp_X_center_to_left_periodic": gridops.interp_center_to_left.ufunc(p)}
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     gridops, grid_ufunc, grid, metrics = _import_reference()
+    np.savez_compressed(os.path.join(OUT, "config1.npz"), **config1(gridops))
     with open(os.path.join(OUT, "gridops_table.json"), "w") as f:
         json.dump(dispatch_table(gridops, grid_ufunc), f, indent=1)
     np.savez_compressed(os.path.join(OUT, "gridops_vectors.npz"), **gridops_vectors(gridops, grid_ufunc))

@@ -136,6 +136,21 @@ def test_reference_known_answers(backend, kat):
         np.testing.assert_allclose(got[..., -1], kat["out_last"], atol=kat["atol"])
 
 
+def test_config1_plumbing_against_reference_fixture(backend):
+    """BASELINE.json configs[0]: Grid.diff along X on a 128 x 64 periodic 2-D C-grid, float64 -- the
+    whole stack (Grid -> dispatch -> fused ufunc -> device layer) against the output of the
+    reference's own `diff_center_to_left` body (tests/golden/config1.npz)."""
+    fx = np.load(os.path.join(GOLDEN, "config1.npz"))
+    assert np.array_equal(fx["in"], R.synthetic_field((64, 128), 1))  # the committed input IS the seed-1 field
+    ds = Dataset({"T": (("YC", "XC"), fx["in"])},
+                 coords={"XC": ("XC", np.arange(128) + 0.5), "XG": ("XG", np.arange(128) * 1.0), "YC": ("YC", np.arange(64) * 1.0)})
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", autoparse_metadata=False)
+    d = grid.diff(ds["T"], "X")
+    assert d.dims == ("YC", "XG") and np.array_equal(d.values, fx["diff_X_center_to_left_periodic"])
+    assert np.array_equal(grid.interp(ds["T"], "X").values, fx["interp_X_center_to_left_periodic"])
+    assert np.array_equal(R.stencil1d("diff", fx["in"], 1, 1, 0, "periodic"), fx["diff_X_center_to_left_periodic"])
+
+
 # ----------------------------------------------------------------------------------------------
 # diff / interp / min / max through the Grid: positions x boundaries x axes of an N-D array
 # ----------------------------------------------------------------------------------------------
