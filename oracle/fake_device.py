@@ -12,8 +12,21 @@ import numpy as np
 from . import refimpl as R
 
 
-def asdevice(x):
-    return np.asarray(x, dtype=np.float64, order="C")
+def asdevice(x, dtype=None):
+    a = np.asarray(x)
+    if dtype is None:
+        dtype = np.float32 if a.dtype == np.float32 else np.float64
+    return np.asarray(a, dtype=dtype, order="C")
+
+
+def _common(*arrays):
+    """float32 only if every operand is float32, else float64 (numpy promotion; mirrors device._common)."""
+    present = [np.asarray(a) for a in arrays if a is not None]
+    return np.float32 if present and all(a.dtype == np.float32 for a in present) else np.float64
+
+
+def _cast(dt, *arrays):
+    return [None if a is None else asdevice(a, dt) for a in arrays]
 
 
 def tohost(x):
@@ -25,17 +38,17 @@ def is_device_array(x):
 
 
 def stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill=0.0, m_in=None, m_out=None):
-    x = asdevice(x)
+    x, m_in, m_out = _cast(_common(x, m_in, m_out), x, m_in, m_out)
     return R.stencil1d(op, x, axis % x.ndim, pad_lo, pad_hi, bc, fill, m_in, m_out)
 
 
 def cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill=0.0, reverse=False, skipna=True, m_in=None, m_out=None):
-    x = asdevice(x)
+    x, m_in, m_out = _cast(_common(x, m_in, m_out), x, m_in, m_out)
     return R.cumsum1d(x, axis % x.ndim, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, skipna, m_in, m_out)
 
 
 def reduce1d(x, axis, w=None, skipna=True):
-    x = asdevice(x)
+    x, w = _cast(_common(x, w), x, w)
     return R.integrate(x, axis % x.ndim, w, skipna)
 
 
@@ -46,13 +59,14 @@ def pad_nd(x, widths, bc, fill):
 
 
 def binary(op, a, b):
-    return R.binary(op, asdevice(a), asdevice(b))
+    a, b = _cast(_common(a, b), a, b)
+    return R.binary(op, a, b)
 
 
 def vorticity(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0):
-    u, v = asdevice(u), asdevice(v)
+    u, v, area = _cast(_common(u, v, area), u, v, area)
     if area is None:
-        area = np.ones((1,) * u.ndim)
+        area = np.ones((1,) * u.ndim, dtype=u.dtype)
     return R.vorticity(u, v, area, bc_x, bc_y, fill_x, fill_y)
 
 
@@ -71,8 +85,8 @@ def stencil2d(op, x, order, padx, bc_x, fill_x, pady, bc_y, fill_y):
     return R.stencil1d(op, t, ax_x, padx[0], padx[1], bc_x, fill_x)
 
 
-def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None):
-    return R.synthetic(int(np.prod(shape)), seed, offset, scale, shift).reshape(tuple(shape))
+def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None, dtype=np.float64):
+    return R.synthetic(int(np.prod(shape)), seed, offset, scale, shift).reshape(tuple(shape)).astype(dtype)
 
 
 _NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "cumsum1d", "reduce1d", "pad_nd", "binary",

@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--shape", default="75,2400,3600")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--cases", default="copy,stencil,metric,cumsum,reduce,vort")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--const", action="store_true", help="constant-valued field instead of random (DVFS / data-toggle check)")
     args = ap.parse_args()
     shape = tuple(int(s) for s in args.shape.split(","))
@@ -50,6 +51,12 @@ def main():
     cells = nz * ny * nx
     tag = {k: os.environ.get(k) for k in ("XG_SEG", "XG_NT_STORE", "XG_NT_LOAD") if os.environ.get(k)}
 
+    dt = torch.float32 if args.dtype == "f32" else torch.float64
+    esz = 4 if args.dtype == "f32" else 8
+    if args.dtype == "f32":
+        tag["dtype"] = "f32"
+        _syn = D.synthetic
+        D.synthetic = lambda *a, **k: _syn(*a, **{**k, "dtype": dt})  # every synthetic array of this run in f32
     T = D.synthetic(shape, 2)
     if args.const:
         T = D.synthetic(shape, 2, 0, 0.0, 1.0)
@@ -57,6 +64,7 @@ def main():
     out = []
 
     def rec(name, ms, best, bytes_per_cell, ncell=cells):
+        bytes_per_cell = bytes_per_cell * esz / 8
         gbs = ncell * bytes_per_cell / (ms * 1e-3) / 1e9
         row = {"case": name, "ms": round(ms, 4), "best_ms": round(best, 4), "gcell_s": round(ncell / ms / 1e6, 3),
                "GBps": round(gbs, 1), "frac_8TBps": round(gbs / 8000, 4), **tag}

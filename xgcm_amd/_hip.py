@@ -65,6 +65,16 @@ SIGNATURES = {
     "xg_fill_synthetic_f64": (C.c_int, [_vp, C.c_int64, C.c_uint64, C.c_uint64, C.c_double, C.c_double, _vp]),
 }
 
+# float32 twins of the compute entry points: same argument order, `float` fill values
+# (xg_fill_synthetic_f32 keeps double scale/shift: the value is formed in f64 and rounded once)
+for _name in ["xg_stencil1d", "xg_cumsum1d", "xg_reduce1d", "xg_pad", "xg_binary", "xg_vorticity", "xg_stencil2d",
+              "xg_fill_synthetic"]:
+    _res, _args = SIGNATURES[_name + "_f64"]
+    SIGNATURES[_name + "_f32"] = (_res, list(_args) if _name == "xg_fill_synthetic" else
+                                  [C.c_float if a is C.c_double else (C.POINTER(C.c_float) if a is _f64p else a) for a in _args])
+
+SUFFIX = {"float64": "f64", "float32": "f32"}
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -121,3 +131,11 @@ def f64s(values: Optional[Sequence[float]]):
     if values is None:
         return None
     return (C.c_double * len(values))(*[float(v) for v in values])
+
+
+def reals(values: Optional[Sequence[float]], suffix: str):
+    """array of fill values in the C type of the `_f64` / `_f32` entry point"""
+    if values is None:
+        return None
+    ctype = C.c_double if suffix == "f64" else C.c_float
+    return (ctype * len(values))(*[float(v) for v in values])

@@ -28,9 +28,28 @@
 
 #include "../../include/xgcm_hip.h"
 
+// The file is compiled twice into the same shared library: once with real = double (exports *_f64
+// plus the type-independent helpers) and once with -DXG_F32 (real = float, exports *_f32 only).
+#ifdef XG_F32
+typedef float real;
+#define XG_FN(name) name##_f32
+#else
+typedef double real;
+#define XG_FN(name) name##_f64
+#define XG_PRIMARY 1
+#endif
+
+// thread-local error text shared by both translation units (hidden: not part of the ABI)
+#define XG_ERRBUF_LEN 512
+extern "C" __attribute__((visibility("hidden"))) char* xg_internal_errbuf(void);
+#ifdef XG_PRIMARY
+static thread_local char g_errbuf[XG_ERRBUF_LEN] = {0};
+extern "C" __attribute__((visibility("hidden"))) char* xg_internal_errbuf(void) { return g_errbuf; }
+#endif
+
 namespace {
 
-typedef double d2 __attribute__((ext_vector_type(2)));
+typedef real d2 __attribute__((ext_vector_type(2)));  // the 2-wide lane vector (16 B for f64, 8 B for f32)
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
@@ -42,12 +61,10 @@ constexpr int WPB = BLOCK / WAVE;
 // ------------------------------------------------------------------------------------------
 // error handling
 // ------------------------------------------------------------------------------------------
-thread_local char g_err[512] = {0};
-
 int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  vsnprintf(xg_internal_errbuf(), XG_ERRBUF_LEN, fmt, ap);
   va_end(ap);
   return code;
 }
@@ -232,29 +249,29 @@ int build_geo(const int64_t* shape, int ndim, int axis, int64_t n_out, const int
 // device helpers
 // ------------------------------------------------------------------------------------------
 template <int V> struct VecT;
-template <> struct VecT<1> { typedef double type; };
+template <> struct VecT<1> { typedef real type; };
 template <> struct VecT<2> { typedef d2 type; };
 
 template <typename T, bool NT>
-__device__ __forceinline__ T ldg(const double* p) {
+__device__ __forceinline__ T ldg(const real* p) {
   if (NT) return __builtin_nontemporal_load(reinterpret_cast<const T*>(p));
   return *reinterpret_cast<const T*>(p);
 }
 template <typename T, bool NT>
-__device__ __forceinline__ void stg(double* p, T v) {
+__device__ __forceinline__ void stg(real* p, T v) {
   if (NT) __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
   else *reinterpret_cast<T*>(p) = v;
 }
 
 // x-difference of a V-wide lane given the value just left of it
-__device__ __forceinline__ d2 dvdx_of(d2 vc, double vl) { d2 o; o.x = vc.x - vl; o.y = vc.y - vc.x; return o; }
-__device__ __forceinline__ double dvdx_of(double vc, double vl) { return vc - vl; }
+__device__ __forceinline__ d2 dvdx_of(d2 vc, real vl) { d2 o; o.x = vc.x - vl; o.y = vc.y - vc.x; return o; }
+__device__ __forceinline__ real dvdx_of(real vc, real vl) { return vc - vl; }
 
 // two-point bodies; l = a[..., i], r = a[..., i+1] of the padded array (gridops.py:23-24,76-77,123-175)
 template <int OP>
-__device__ __forceinline__ double op2(double l, double r) {
+__device__ __forceinline__ real op2(real l, real r) {
   if (OP == XG_OP_DIFF) return r - l;
-  if (OP == XG_OP_INTERP) return (l + r) * 0.5;  // == (l + r) / 2.0 bit for bit
+  if (OP == XG_OP_INTERP) return (l + r) * real(0.5);  // == (l + r) / 2.0 bit for bit
   if (OP == XG_OP_MIN) return (l < r || l != l) ? l : r;  // NaN-propagating like np.min
   return (l > r || l != l) ? l : r;
 }
@@ -262,9 +279,9 @@ template <int OP> __device__ __forceinline__ d2 op2(d2 l, d2 r) {
   d2 o; o.x = op2<OP>(l.x, r.x); o.y = op2<OP>(l.y, r.y); return o;
 }
 
-__device__ __forceinline__ double splat1(double f, double*) { return f; }
-__device__ __forceinline__ d2 splat1(double f, d2*) { d2 o; o.x = f; o.y = f; return o; }
-template <typename T> __device__ __forceinline__ T splat(double f) { return splat1(f, (T*)nullptr); }
+__device__ __forceinline__ real splat1(real f, real*) { return f; }
+__device__ __forceinline__ d2 splat1(real f, d2*) { d2 o; o.x = f; o.y = f; return o; }
+template <typename T> __device__ __forceinline__ T splat(real f) { return splat1(f, (T*)nullptr); }
 
 // offset of flat outer index `o` in a metric (unrolled so Geo/MIdx stay in SGPRs)
 __device__ __forceinline__ int64_t outer_off(const Geo& g, const MIdx& m, int64_t o) {
@@ -338,11 +355,11 @@ __device__ __forceinline__ int64_t inner_offx(const Geo& g, const MIdx& m, int64
 }
 
 // metric value(s) for a V-wide lane at metric offset `off` (second element `step` further on)
-template <typename T> __device__ __forceinline__ T ldm(const double* m, int64_t off, int64_t step);
-template <> __device__ __forceinline__ double ldm<double>(const double* m, int64_t off, int64_t) { return m[off]; }
-template <> __device__ __forceinline__ d2 ldm<d2>(const double* m, int64_t off, int64_t step) {
+template <typename T> __device__ __forceinline__ T ldm(const real* m, int64_t off, int64_t step);
+template <> __device__ __forceinline__ real ldm<real>(const real* m, int64_t off, int64_t) { return m[off]; }
+template <> __device__ __forceinline__ d2 ldm<d2>(const real* m, int64_t off, int64_t step) {
   // metric contiguous along the lanes and 16-B aligned here: one dwordx4 load instead of two dwordx2
-  if (step == 1 && (((reinterpret_cast<uintptr_t>(m) >> 3) + (uintptr_t)off) & 1) == 0)
+  if (step == 1 && (((reinterpret_cast<uintptr_t>(m) / sizeof(real)) + (uintptr_t)off) & 1) == 0)
     return *reinterpret_cast<const d2*>(m + off);
   d2 o; o.x = m[off]; o.y = m[off + step]; return o;
 }
@@ -362,9 +379,9 @@ __device__ __forceinline__ u64 wave_id() {
 // ------------------------------------------------------------------------------------------
 template <int OP, int V, int MET, bool NTL, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_strided(
-    const double* __restrict__ in, double* __restrict__ out, Geo g, int seg, u32 nseg, u32 ntile,
-    int pad_lo, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
-    const double* __restrict__ m_out, MIdx mo) {
+    const real* __restrict__ in, real* __restrict__ out, Geo g, int seg, u32 nseg, u32 ntile,
+    int pad_lo, int bc, real fill, const real* __restrict__ m_in, MIdx mi,
+    const real* __restrict__ m_out, MIdx mo) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   constexpr int U = 4;
@@ -382,8 +399,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided(
   const int64_t j0 = (int64_t)sg * seg;
   const int64_t j1 = (j0 + seg < g.n_out) ? j0 + seg : g.n_out;
   const int64_t inner = g.inner;
-  const double* pin = in + (o * g.n_in) * inner + x;
-  double* pout = out + (o * g.n_out) * inner + x;
+  const real* pin = in + (o * g.n_in) * inner + x;
+  real* pout = out + (o * g.n_out) * inner + x;
 
   int64_t mi_base = 0, mo_base = 0, mi_step = 0, mo_step = 0;
   if (HAS_MI) {
@@ -462,9 +479,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided(
 // ------------------------------------------------------------------------------------------
 template <int OP, int V, int MET, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
-    const double* __restrict__ in, double* __restrict__ out, Geo g, int64_t row0, u32 nrows, u32 nblk, FastDiv per,
-    ZBand zb, int pad_lo, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
-    const double* __restrict__ m_out, MIdx mo) {
+    const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t row0, u32 nrows, u32 nblk, FastDiv per,
+    ZBand zb, int pad_lo, int bc, real fill, const real* __restrict__ m_in, MIdx mi,
+    const real* __restrict__ m_out, MIdx mo) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   // XCD banding (see K2S): neighbouring workgroups share an L2, so the cache line holding a
   // workgroup's left neighbour is not fetched a second time by another XCD (-3 % HBM reads)
@@ -481,8 +498,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     r = zz * zb.Y + zy;
   }
   const u32 Li = (u32)g.n_in, Lo = (u32)g.n_out;  // host guarantees row lengths < 2^31
-  const double* prow = in + (row0 * (int64_t)Li + (u64)r * Li);
-  double* orow = out + (row0 * (int64_t)Lo + (u64)r * Lo);
+  const real* prow = in + (row0 * (int64_t)Li + (u64)r * Li);
+  real* orow = out + (row0 * (int64_t)Lo + (u64)r * Lo);
   // metric row offsets: with z-banding (z, y) are already known, else one FastDiv per outer dim
   // (the host only selects this kernel with metrics when g.idx32 holds)
   int64_t mib = 0, mob = 0;
@@ -500,7 +517,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     if (pad_lo) { edge = (i0 == 0); nidx = edge ? ((bc == XG_BC_PERIODIC) ? Li - 1 : 0) : i0 - 1; }
     else { edge = (i0 + 2 == Li); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : Li - 1) : i0 + 2; }
     d2 a = *reinterpret_cast<const d2*>(prow + i0);
-    double n = prow[nidx];
+    real n = prow[nidx];
     if (HAS_MI) {
       a = a * ldm<d2>(m_in, mib + (int64_t)i0 * mi.axis, mi.axis);
       n = n * m_in[mib + (int64_t)nidx * mi.axis];
@@ -516,16 +533,16 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     bool fl = false, fr = false;
     if (ql < 0) { fl = (bc == XG_BC_FILL); ql = (bc == XG_BC_PERIODIC) ? (int64_t)Li - 1 : 0; }
     if (qr >= (int64_t)Li) { fr = (bc == XG_BC_FILL); qr = (bc == XG_BC_PERIODIC) ? 0 : (int64_t)Li - 1; }
-    double l = prow[ql], rr = prow[qr];
+    real l = prow[ql], rr = prow[qr];
     if (HAS_MI) {
       l = l * m_in[mib + ql * mi.axis];
       rr = rr * m_in[mib + qr * mi.axis];
     }
     if (fl) l = fill;
     if (fr) rr = fill;
-    double res = op2<OP>(l, rr);
+    real res = op2<OP>(l, rr);
     if (HAS_MO) res = res / m_out[mob + (int64_t)i0 * mo.axis];
-    stg<double, NTS>(orow + i0, res);
+    stg<real, NTS>(orow + i0, res);
   }
 }
 
@@ -538,9 +555,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
 // ------------------------------------------------------------------------------------------
 template <int OP, int MET, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
-    const double* __restrict__ in, double* __restrict__ out, Geo g, int64_t row0, u32 nelem, u32 nblk,
-    FastDiv fLo, int pad_lo, int bc, double fill, const double* __restrict__ m_in, MIdx mi,
-    const double* __restrict__ m_out, MIdx mo) {
+    const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t row0, u32 nelem, u32 nblk,
+    FastDiv fLo, int pad_lo, int bc, real fill, const real* __restrict__ m_in, MIdx mi,
+    const real* __restrict__ m_out, MIdx mo) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
@@ -553,13 +570,13 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
   const bool have1 = e0 + 1 < nelem;
   u32 r1 = r0, i1 = i0 + 1;
   if (i1 == Lo) { i1 = 0; r1 = r0 + 1; }
-  auto one = [&](u32 r, u32 i) -> double {
-    const double* prow = in + (row0 * (int64_t)Li + (u64)r * Li);
+  auto one = [&](u32 r, u32 i) -> real {
+    const real* prow = in + (row0 * (int64_t)Li + (u64)r * Li);
     int64_t ql = (int64_t)i - pad_lo, qr = (int64_t)i + 1 - pad_lo;
     bool fl = false, fr = false;
     if (ql < 0) { fl = (bc == XG_BC_FILL); ql = (bc == XG_BC_PERIODIC) ? (int64_t)Li - 1 : 0; }
     if (qr >= (int64_t)Li) { fr = (bc == XG_BC_FILL); qr = (bc == XG_BC_PERIODIC) ? 0 : (int64_t)Li - 1; }
-    double l = prow[ql], rr = prow[qr];
+    real l = prow[ql], rr = prow[qr];
     if (HAS_MI) {
       const int64_t mib = outer_off32(g, mi, (u32)(row0 + r));
       l = l * m_in[mib + ql * mi.axis];
@@ -567,19 +584,19 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
     }
     if (fl) l = fill;
     if (fr) rr = fill;
-    double res = op2<OP>(l, rr);
+    real res = op2<OP>(l, rr);
     if (HAS_MO) res = res / m_out[outer_off32(g, mo, (u32)(row0 + r)) + (int64_t)i * mo.axis];
     return res;
   };
-  double* po = out + (row0 * (int64_t)Lo + (u64)e0);  // row0 * Lo is even (host) => 16-B aligned
-  const double a = one(r0, i0);
+  real* po = out + (row0 * (int64_t)Lo + (u64)e0);  // row0 * Lo is even (host) => 16-B aligned
+  const real a = one(r0, i0);
   if (have1) {
     d2 res;
     res.x = a;
     res.y = one(r1, i1);
     stg<d2, NTS>(po, res);
   } else {
-    stg<double, NTS>(po, a);
+    stg<real, NTS>(po, a);
   }
 }
 
@@ -597,9 +614,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
 // ------------------------------------------------------------------------------------------
 template <int OP, int V, int MET, bool NTS, int SEG>
 __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
-    const double* __restrict__ in, double* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk,
-    FastDiv ntile, FastDiv nseg, ZBand zb, int pad_lo, int bc, double fill, const double* __restrict__ m_in,
-    MIdx mi, const double* __restrict__ m_out, MIdx mo) {
+    const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk,
+    FastDiv ntile, FastDiv nseg, ZBand zb, int pad_lo, int bc, real fill, const real* __restrict__ m_in,
+    MIdx mi, const real* __restrict__ m_out, MIdx mo) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   // banding: XCD (b % 8) owns logical blocks [xcd * pb, (xcd + 1) * pb)
@@ -623,8 +640,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
   if (x >= inner) return;
   const int64_t j0 = (int64_t)sg * SEG;
   const int64_t nrow = (g.n_out - j0 < SEG) ? g.n_out - j0 : SEG;  // rows this segment really has
-  const double* pin = in + (o * g.n_in) * inner + x;
-  double* pout = out + (o * g.n_out + j0) * inner + x;
+  const real* pin = in + (o * g.n_in) * inner + x;
+  real* pout = out + (o * g.n_out + j0) * inner + x;
 
   int64_t mib = 0, mob = 0, mis = 0, mos = 0;  // (host guarantees g.idx32 when metrics are present)
   if (HAS_MI) {
@@ -666,16 +683,16 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
 // ------------------------------------------------------------------------------------------
 struct ScanArgs {
   int reverse, skipna, trim_lo, trim_hi, pad_lo, pad_hi, bc;
-  double fill;
+  real fill;
 };
 
-__device__ __forceinline__ double nan0(double v) { return (v != v) ? 0.0 : v; }
+__device__ __forceinline__ real nan0(real v) { return (v != v) ? real(0) : v; }
 __device__ __forceinline__ d2 nan0(d2 v) { d2 o; o.x = nan0(v.x); o.y = nan0(v.y); return o; }
 
 template <int V, int MET, bool NTL, bool NTS, int U>
 __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
-    const double* __restrict__ in, double* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
-    const double* __restrict__ m_in, MIdx mi, const double* __restrict__ m_out, MIdx mo) {
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   // U independent loads in flight per lane (the scan chain only consumes them)
@@ -688,8 +705,8 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
   const int64_t x = ((int64_t)tile * WAVE + lane) * V;
   if (x >= g.inner) return;
   const int64_t inner = g.inner, n = g.n_in;
-  const double* pin = in + (o * n) * inner + x;
-  double* pout = out + (o * g.n_out) * inner + x;
+  const real* pin = in + (o * n) * inner + x;
+  real* pout = out + (o * g.n_out) * inner + x;
 
   int64_t mi_base = 0, mo_base = 0, mi_step = 0, mo_step = 0;
   if (HAS_MI) {
@@ -707,7 +724,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
 
   const int64_t first_kept = a.trim_lo, last_kept = n - 1 - a.trim_hi;  // index space
   const int64_t shift = a.pad_lo - a.trim_lo;
-  T acc = splat<T>(0.0), c_first = splat<T>(0.0), c_last = splat<T>(0.0);
+  T acc = splat<T>(real(0)), c_first = splat<T>(real(0)), c_last = splat<T>(real(0));
   bool started = false;
   auto step = [&](int64_t idx, T v) {
     if (HAS_MI) v = v * ldm<T>(m_in, mi_base + idx * mi.axis, mi_step);
@@ -756,26 +773,26 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
 // ------------------------------------------------------------------------------------------
 template <int MET>
 __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
-    const double* __restrict__ in, double* __restrict__ out, Geo g, ScanArgs a,
-    const double* __restrict__ m_in, MIdx mi, const double* __restrict__ m_out, MIdx mo) {
+    const real* __restrict__ in, real* __restrict__ out, Geo g, ScanArgs a,
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
-  __shared__ double wtot[2][WPB];
+  __shared__ real wtot[2][WPB];
   const int64_t row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int64_t n = g.n_in;
-  const double* prow = in + row * n;
-  double* orow = out + row * g.n_out;
+  const real* prow = in + row * n;
+  real* orow = out + row * g.n_out;
   int64_t mi_base = 0, mo_base = 0;
   if (HAS_MI) mi_base = outer_off(g, mi, row);
   if (HAS_MO) mo_base = outer_off(g, mo, row);
   const int64_t first_kept = a.trim_lo, last_kept = n - 1 - a.trim_hi;
   const int64_t shift = a.pad_lo - a.trim_lo;
-  auto put = [&](int64_t j, double v) {
+  auto put = [&](int64_t j, real v) {
     if (HAS_MO) v = v / m_out[mo_base + j * mo.axis];
     orow[j] = v;
   };
-  auto fetch = [&](int64_t k) -> double {
-    double v = 0.0;
+  auto fetch = [&](int64_t k) -> real {
+    real v = real(0);
     if (k < n) {
       const int64_t idx = a.reverse ? n - 1 - k : k;
       v = prow[idx];
@@ -784,30 +801,30 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
     }
     return v;
   };
-  double carry = 0.0;
+  real carry = real(0);
   int buf = 0;
-  double cur = fetch(tid);
+  real cur = fetch(tid);
   for (int64_t base = 0; base < n; base += BLOCK, buf ^= 1) {
     const int64_t k = base + tid;
     const int64_t idx = a.reverse ? n - 1 - k : k;
-    const double v = cur;
+    const real v = cur;
     cur = fetch(k + BLOCK);  // next chunk's load is in flight across this chunk's scan + barrier
-    double s = v;
+    real s = v;
 #pragma unroll
     for (int d = 1; d < WAVE; d <<= 1) {
-      double t = __shfl_up(s, d, WAVE);
+      real t = __shfl_up(s, d, WAVE);
       if (lane >= d) s += t;
     }
     if (lane == WAVE - 1) wtot[buf][wv] = s;
     __syncthreads();
-    double woff = 0.0, tot = 0.0;
+    real woff = real(0), tot = real(0);
 #pragma unroll
     for (int i = 0; i < WPB; ++i) {
-      double t = wtot[buf][i];
+      real t = wtot[buf][i];
       if (i < wv) woff += t;
       tot += t;
     }
-    const double c = carry + (woff + s);
+    const real c = carry + (woff + s);
     carry += tot;
     if (k < n) {
       if (idx >= first_kept && idx <= last_kept) put(idx + shift, c);
@@ -833,8 +850,8 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
 // ------------------------------------------------------------------------------------------
 template <int V, bool HAS_W, bool NTL, int U>
 __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
-    const double* __restrict__ in, double* __restrict__ out, Geo g, u32 ntile, int skipna,
-    const double* __restrict__ wgt, MIdx mw) {
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, int skipna,
+    const real* __restrict__ wgt, MIdx mw) {
   typedef typename VecT<V>::type T;
   // U independent loads in flight per lane
   const u64 w = wave_id();
@@ -845,13 +862,13 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
   const int64_t x = ((int64_t)tile * WAVE + lane) * V;
   if (x >= g.inner) return;
   const int64_t inner = g.inner, n = g.n_in;
-  const double* pin = in + (o * n) * inner + x;
+  const real* pin = in + (o * n) * inner + x;
   int64_t mb = 0, ms = 0;
   if (HAS_W) {
     mb = outer_off(g, mw, o) + inner_off(g, mw, x);
     ms = (V == 2) ? inner_off(g, mw, x + 1) - inner_off(g, mw, x) : 0;
   }
-  T acc = splat<T>(0.0);
+  T acc = splat<T>(real(0));
   bool started = false;
   auto step = [&](int64_t k, T v) {
     if (HAS_W) v = v * ldm<T>(wgt, mb + k * mw.axis, ms);
@@ -874,19 +891,19 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
 // K4b: weighted sum along the CONTIGUOUS axis: one wave per row, lane-strided partial sums then
 // a shuffle tree (tolerance parity; numpy itself is pairwise here).
 template <bool HAS_W>
-__global__ __launch_bounds__(BLOCK) void k_reduce_contig(const double* __restrict__ in,
-                                                         double* __restrict__ out, Geo g, int skipna,
-                                                         const double* __restrict__ wgt, MIdx mw) {
+__global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict__ in,
+                                                         real* __restrict__ out, Geo g, int skipna,
+                                                         const real* __restrict__ wgt, MIdx mw) {
   const u64 row = wave_id();
   if ((int64_t)row >= g.outer) return;
   const int lane = threadIdx.x & 63;
   const int64_t n = g.n_in;
-  const double* prow = in + row * n;
+  const real* prow = in + row * n;
   int64_t mb = 0;
   if (HAS_W) mb = outer_off(g, mw, row);
-  double acc = 0.0;
+  real acc = real(0);
   for (int64_t k = lane; k < n; k += WAVE) {
-    double v = prow[k];
+    real v = prow[k];
     if (HAS_W) v = v * wgt[mb + k * mw.axis];
     if (skipna) v = nan0(v);
     acc += v;
@@ -908,17 +925,17 @@ struct PadGeo {
   int64_t in_shape[XG_MAX_NDIM], in_stride[XG_MAX_NDIM];
   int64_t lo[XG_MAX_NDIM];
   int bc[XG_MAX_NDIM];
-  double fill[XG_MAX_NDIM];
+  real fill[XG_MAX_NDIM];
 };
 
 template <typename I>
-__global__ __launch_bounds__(BLOCK) void k_pad(const double* __restrict__ in, double* __restrict__ out, PadGeo p) {
+__global__ __launch_bounds__(BLOCK) void k_pad(const real* __restrict__ in, real* __restrict__ out, PadGeo p) {
   const int64_t gid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (gid >= p.total) return;
   const I idx = (I)gid;
   int64_t src = 0;
   bool filled = false;
-  double fv = 0.0;
+  real fv = real(0);
 #pragma unroll
   for (int t = XG_MAX_NDIM - 1; t >= 0; --t) {
     if (t < p.ndim && !filled) {
@@ -946,7 +963,7 @@ struct BinGeo {
   int64_t sa[XG_MAX_NDIM], sb[XG_MAX_NDIM];
 };
 
-template <int BOP> __device__ __forceinline__ double bin2(double a, double b) {
+template <int BOP> __device__ __forceinline__ real bin2(real a, real b) {
   if (BOP == XG_BIN_MUL) return a * b;
   if (BOP == XG_BIN_DIV) return a / b;
   if (BOP == XG_BIN_ADD) return a + b;
@@ -954,8 +971,8 @@ template <int BOP> __device__ __forceinline__ double bin2(double a, double b) {
 }
 
 template <int BOP, int V, bool NTS>
-__global__ __launch_bounds__(BLOCK) void k_binary(const double* __restrict__ a, const double* __restrict__ b,
-                                                  double* __restrict__ out, BinGeo g) {
+__global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, const real* __restrict__ b,
+                                                  real* __restrict__ out, BinGeo g) {
   typedef typename VecT<V>::type T;
   const int64_t gid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
   if (gid >= g.total) return;
@@ -981,7 +998,7 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const double* __restrict__ a, 
     o.y = bin2<BOP>(av.y, bv.y);
     stg<d2, NTS>(out + gid * 2, o);
   } else {
-    stg<double, NTS>(out + gid, bin2<BOP>(a[oa], b[ob]));
+    stg<real, NTS>(out + gid, bin2<BOP>(a[oa], b[ob]));
   }
 }
 
@@ -993,9 +1010,9 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const double* __restrict__ a, 
 // ------------------------------------------------------------------------------------------
 template <int V, bool HAS_AREA, bool NTS, int SEG>
 __global__ __launch_bounds__(BLOCK) void k_vorticity(
-    const double* __restrict__ u, const double* __restrict__ v, const double* __restrict__ area,
-    double* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile,
-    FastDiv nseg, ZBand zb, int bc_x, double fill_x, int bc_y, double fill_y, int64_t a_so, int64_t a_sy,
+    const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ area,
+    real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile,
+    FastDiv nseg, ZBand zb, int bc_x, real fill_x, int bc_y, real fill_y, int64_t a_so, int64_t a_sy,
     int64_t a_sx) {
   typedef typename VecT<V>::type T;
   const u32 pb = (nblk + 7) >> 3;
@@ -1017,15 +1034,15 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
   if (i0 >= nx) return;
   const int64_t j0 = (int64_t)sg * SEG;
   const int64_t nrow = (ny - j0 < SEG) ? ny - j0 : SEG;
-  const double* pu = u + o * ny * nx + i0;
-  const double* pv = v + (o * ny + j0) * nx;
-  double* po = out + (o * ny + j0) * nx + i0;
+  const real* pu = u + o * ny * nx + i0;
+  const real* pv = v + (o * ny + j0) * nx;
+  real* po = out + (o * ny + j0) * nx + i0;
   const bool edge = (i0 == 0);
   const int64_t nidx = edge ? ((bc_x == XG_BC_PERIODIC) ? nx - 1 : 0) : i0 - 1;
   const bool fill_edge = edge && (bc_x == XG_BC_FILL);
 
   T uu[SEG + 1], vv[SEG];
-  double vl[SEG];
+  real vl[SEG];
   {
     int64_t q = j0 - 1;
     bool f = false;
@@ -1043,7 +1060,7 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
 #pragma unroll
   for (int s_ = 0; s_ < SEG; ++s_) {
     if (s_ < nrow) {
-      const double left = fill_edge ? fill_x : vl[s_];
+      const real left = fill_edge ? fill_x : vl[s_];
       T z = dvdx_of(vv[s_], left) - (uu[s_ + 1] - uu[s_]);
       if (HAS_AREA) z = z / ldm<T>(area, o * a_so + (j0 + s_) * a_sy + i0 * a_sx, a_sx);
       stg<T, NTS>(po + s_ * nx, z);
@@ -1065,9 +1082,9 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
 // ------------------------------------------------------------------------------------------
 template <int OP, bool NTS, int SEG>
 __global__ __launch_bounds__(BLOCK) void k_stencil2d(
-    const double* __restrict__ in, double* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny,
-    int64_t nx, FastDiv ntile, FastDiv nseg, int order, int plx, int bcx, double fillx, int ply, int bcy,
-    double filly) {
+    const real* __restrict__ in, real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny,
+    int64_t nx, FastDiv ntile, FastDiv nseg, int order, int plx, int bcx, real fillx, int ply, int bcy,
+    real filly) {
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
   if (lb >= nblk) return;
@@ -1082,8 +1099,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
   if (i0 >= nx) return;
   const int64_t j0 = (int64_t)sg * SEG;
   const int64_t nrow = (ny - j0 < SEG) ? ny - j0 : SEG;
-  const double* pin = in + o * ny * nx;
-  double* po = out + (o * ny + j0) * nx + i0;
+  const real* pin = in + o * ny * nx;
+  real* po = out + (o * ny + j0) * nx + i0;
 
   int64_t nidx;
   bool edge;
@@ -1091,7 +1108,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
   else { edge = (i0 + 2 == nx); nidx = edge ? ((bcx == XG_BC_PERIODIC) ? 0 : nx - 1) : i0 + 2; }
   const bool fill_edge = edge && (bcx == XG_BC_FILL);
   // X stencil on a pair `a` with the value `n` next to it (left of a.x if plx, right of a.y otherwise)
-  auto opx = [&](d2 a, double n) -> d2 {
+  auto opx = [&](d2 a, real n) -> d2 {
     d2 t;
     if (plx) { t.x = op2<OP>(n, a.x); t.y = op2<OP>(a.x, a.y); }
     else { t.x = op2<OP>(a.x, a.y); t.y = op2<OP>(a.y, n); }
@@ -1099,7 +1116,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
   };
 
   d2 pr[SEG + 1];
-  double nb[SEG + 1];
+  real nb[SEG + 1];
   bool rowfill[SEG + 1];
 #pragma unroll
   for (int u = 0; u <= SEG; ++u) {
@@ -1131,7 +1148,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
     for (int u = 0; u < SEG; ++u) {
       if (u < nrow) {
         const d2 ty = op2<OP>(pr[u], pr[u + 1]);
-        const double tn = op2<OP>(nb[u], nb[u + 1]);
+        const real tn = op2<OP>(nb[u], nb[u + 1]);
         stg<d2, NTS>(po + u * nx, opx(ty, fill_edge ? fillx : tn));
       }
     }
@@ -1141,7 +1158,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
 // ------------------------------------------------------------------------------------------
 // synthetic fields (splitmix64 finaliser), bit-identical to oracle/refimpl.py:synthetic
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_fill_synthetic(double* __restrict__ out, int64_t n, u64 seed, u64 offset,
+__global__ __launch_bounds__(BLOCK) void k_fill_synthetic(real* __restrict__ out, int64_t n, u64 seed, u64 offset,
                                                           double scale, double shift) {
   const int64_t stride = (int64_t)gridDim.x * BLOCK;
   for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
@@ -1150,14 +1167,14 @@ __global__ __launch_bounds__(BLOCK) void k_fill_synthetic(double* __restrict__ o
     z ^= z >> 27; z *= 0x94D049BB133111EBull;
     z ^= z >> 31;
     double uu = (double)(z >> 11) * 0x1.0p-53;
-    out[i] = uu * scale + shift;
+    out[i] = (real)(uu * scale + shift);  // formed in f64, rounded once (oracle: synthetic(...).astype(dtype))
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ------------------------------------------------------------------------------------------
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (2 * sizeof(real) - 1)) == 0; }  // "aligned for d2"
 
 inline int check_grid(u64 nblocks) {
   if (nblocks == 0 || nblocks > 0x7fffffffull) return fail(XG_ERR_UNSUPPORTED, "launch of %llu blocks exceeds grid limits", nblocks);
@@ -1179,8 +1196,8 @@ inline unsigned march_lds() {
 
 // dispatch on (OP, V, MET, NT) -> template instance
 struct StencilCall {
-  const double* in; double* out; Geo g; int pad_lo, pad_hi, bc; double fill;
-  const double* m_in; MIdx mi; const double* m_out; MIdx mo; hipStream_t st;
+  const real* in; real* out; Geo g; int pad_lo, pad_hi, bc; real fill;
+  const real* m_in; MIdx mi; const real* m_out; MIdx mo; hipStream_t st;
 };
 
 // marching kernel (one HBM read per cell whatever the plane size)
@@ -1335,9 +1352,11 @@ inline u32 ceil_div_u32(int64_t a, int64_t b) { return (u32)((a + b - 1) / b); }
 // ==========================================================================================
 extern "C" {
 
+#ifdef XG_PRIMARY
 int xg_version(void) { return XG_ABI_VERSION; }
 
 int xg_last_error(char* buf, int n) {
+  const char* g_err = xg_internal_errbuf();
   int len = (int)strlen(g_err);
   if (buf && n > 0) {
     int c = len < n - 1 ? len : n - 1;
@@ -1372,10 +1391,11 @@ int xg_event_elapsed_ms(void* start, void* stop, float* ms) {
   return 0;
 }
 int xg_event_destroy(void* ev) { XG_HIP(hipEventDestroy((hipEvent_t)ev)); return 0; }
+#endif  // XG_PRIMARY
 
-int xg_stencil1d_f64(int op, const double* in, double* out, const int64_t* shape, int ndim, int axis,
-                     int64_t n_out, int pad_lo, int pad_hi, int bc, double fill, const double* m_in,
-                     const int64_t* m_in_strides, const double* m_out, const int64_t* m_out_strides,
+int XG_FN(xg_stencil1d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int axis,
+                     int64_t n_out, int pad_lo, int pad_hi, int bc, real fill, const real* m_in,
+                     const int64_t* m_in_strides, const real* m_out, const int64_t* m_out_strides,
                      void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
@@ -1412,9 +1432,9 @@ int xg_stencil1d_f64(int op, const double* in, double* out, const int64_t* shape
   return XG_OK;
 }
 
-int xg_cumsum1d_f64(const double* in, double* out, const int64_t* shape, int ndim, int axis, int reverse,
-                    int skipna, int trim_lo, int trim_hi, int pad_lo, int pad_hi, int bc, double fill,
-                    const double* m_in, const int64_t* m_in_strides, const double* m_out,
+int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim, int axis, int reverse,
+                    int skipna, int trim_lo, int trim_hi, int pad_lo, int pad_hi, int bc, real fill,
+                    const real* m_in, const int64_t* m_in_strides, const real* m_out,
                     const int64_t* m_out_strides, void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if ((trim_lo | trim_hi | pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "trim/pad widths must be 0 or 1");
@@ -1463,8 +1483,8 @@ int xg_cumsum1d_f64(const double* in, double* out, const int64_t* shape, int ndi
   return XG_OK;
 }
 
-int xg_reduce1d_f64(const double* in, double* out, const int64_t* shape, int ndim, int axis, int skipna,
-                    const double* w, const int64_t* w_strides, void* stream) {
+int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim, int axis, int skipna,
+                    const real* w, const int64_t* w_strides, void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (w && !w_strides) return fail(XG_ERR_INVALID, "weight without strides");
   Geo g; MIdx mw;
@@ -1472,7 +1492,7 @@ int xg_reduce1d_f64(const double* in, double* out, const int64_t* shape, int ndi
   if (rc) return rc;
   if (g.outer == 0 || g.inner == 0) return XG_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (g.n_in == 0) { XG_HIP(hipMemsetAsync(out, 0, sizeof(double) * g.outer * g.inner, st)); return XG_OK; }
+  if (g.n_in == 0) { XG_HIP(hipMemsetAsync(out, 0, sizeof(real) * g.outer * g.inner, st)); return XG_OK; }
   if (g.inner == 1) {
     const u64 nblocks = ((u64)g.outer + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
@@ -1495,8 +1515,8 @@ int xg_reduce1d_f64(const double* in, double* out, const int64_t* shape, int ndi
   return XG_OK;
 }
 
-int xg_pad_f64(const double* in, double* out, const int64_t* shape, int ndim, const int64_t* lo, const int64_t* hi,
-               const int* bc, const double* fill, const int* order, void* stream) {
+int XG_FN(xg_pad)(const real* in, real* out, const int64_t* shape, int ndim, const int64_t* lo, const int64_t* hi,
+               const int* bc, const real* fill, const int* order, void* stream) {
   if (!in || !out || !shape || !lo || !hi || !bc) return fail(XG_ERR_INVALID, "NULL argument");
   if (ndim < 1 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [1,%d]", ndim, XG_MAX_NDIM);
   PadGeo p;
@@ -1526,7 +1546,7 @@ int xg_pad_f64(const double* in, double* out, const int64_t* shape, int ndim, co
     p.in_stride[t] = istride[d];
     p.lo[t] = lo[d];
     p.bc[t] = bc[d];
-    p.fill[t] = fill ? fill[d] : 0.0;
+    p.fill[t] = fill ? fill[d] : real(0);
   }
   p.total = total;
   if (total == 0) return XG_OK;
@@ -1540,8 +1560,8 @@ int xg_pad_f64(const double* in, double* out, const int64_t* shape, int ndim, co
   return XG_OK;
 }
 
-int xg_binary_f64(int op, const double* a, const int64_t* a_strides, const double* b, const int64_t* b_strides,
-                  double* out, const int64_t* shape, int ndim, void* stream) {
+int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real* b, const int64_t* b_strides,
+                  real* out, const int64_t* shape, int ndim, void* stream) {
   if (!a || !b || !out || (ndim > 0 && (!shape || !a_strides || !b_strides))) return fail(XG_ERR_INVALID, "NULL argument");
   if (op < XG_BIN_MUL || op > XG_BIN_SUB) return fail(XG_ERR_INVALID, "unknown binary op %d", op);
   if (ndim < 0 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [0,%d]", ndim, XG_MAX_NDIM);
@@ -1596,8 +1616,8 @@ int xg_binary_f64(int op, const double* a, const int64_t* a_strides, const doubl
   return XG_OK;
 }
 
-int xg_vorticity_f64(const double* u, const double* v, const double* area, const int64_t* area_strides, double* out,
-                     const int64_t* shape, int ndim, int bc_x, double fill_x, int bc_y, double fill_y, void* stream) {
+int XG_FN(xg_vorticity)(const real* u, const real* v, const real* area, const int64_t* area_strides, real* out,
+                     const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y, void* stream) {
   if (!u || !v || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
   if (area && !area_strides) return fail(XG_ERR_INVALID, "area without strides");
@@ -1660,9 +1680,9 @@ int xg_vorticity_f64(const double* u, const double* v, const double* area, const
   return XG_OK;
 }
 
-int xg_stencil2d_f64(int op, const double* in, double* out, const int64_t* shape, int ndim, int order,
-                     int padx_lo, int padx_hi, int bc_x, double fill_x, int pady_lo, int pady_hi, int bc_y,
-                     double fill_y, void* stream) {
+int XG_FN(xg_stencil2d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,
+                     int padx_lo, int padx_hi, int bc_x, real fill_x, int pady_lo, int pady_hi, int bc_y,
+                     real fill_y, void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
   if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
@@ -1699,7 +1719,7 @@ int xg_stencil2d_f64(int op, const double* in, double* out, const int64_t* shape
   return XG_OK;
 }
 
-int xg_fill_synthetic_f64(double* out, int64_t n, uint64_t seed, uint64_t offset, double scale, double shift, void* stream) {
+int XG_FN(xg_fill_synthetic)(real* out, int64_t n, uint64_t seed, uint64_t offset, double scale, double shift, void* stream) {
   if (!out && n > 0) return fail(XG_ERR_INVALID, "NULL output");
   if (n <= 0) return XG_OK;
   u64 nblocks = ((u64)n + BLOCK - 1) / BLOCK;

@@ -47,18 +47,43 @@ def is_device_array(x) -> bool:
     return isinstance(x, torch.Tensor) and x.is_cuda
 
 
-def asdevice(x) -> torch.Tensor:
-    """numpy / host tensor -> contiguous float64 tensor in HBM (PCIe copy); device tensors pass."""
+_FLOATS = (torch.float32, torch.float64)
+
+
+def asdevice(x, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """numpy / host tensor -> contiguous tensor in HBM (PCIe copy); device tensors pass.
+
+    float32 and float64 keep their dtype (the reference computes in the input's dtype); every
+    other dtype is promoted to float64 (documented deviation: the reference keeps integers)."""
     _require_gpu()
     if isinstance(x, torch.Tensor):
         t = x
     else:
-        t = torch.from_numpy(np.asarray(x, dtype=np.float64, order="C"))
-    if t.dtype != torch.float64:
-        t = t.to(torch.float64)
+        a = np.asarray(x)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float64)
+        t = torch.from_numpy(np.asarray(a, order="C"))
+    if dtype is None:
+        dtype = t.dtype if t.dtype in _FLOATS else torch.float64
+    if t.dtype != dtype:
+        t = t.to(dtype)
     if not t.is_cuda:
         t = t.cuda()
     return t.contiguous()
+
+
+def _dtype_of(x) -> torch.dtype:
+    if isinstance(x, torch.Tensor):
+        return x.dtype if x.dtype in _FLOATS else torch.float64
+    return torch.float32 if np.asarray(x).dtype == np.float32 else torch.float64
+
+
+def _common(*arrays):
+    """(dtype, ABI suffix) shared by an array and its metrics: float32 only if ALL are float32
+    (mixed operands promote to float64 like numpy / xarray arithmetic does)."""
+    present = [a for a in arrays if a is not None]
+    dt = torch.float32 if present and all(_dtype_of(a) == torch.float32 for a in present) else torch.float64
+    return dt, ("f32" if dt == torch.float32 else "f64")
 
 
 def tohost(t) -> np.ndarray:
@@ -92,30 +117,28 @@ def _bstrides(m: Optional[torch.Tensor], shape: Sequence[int], what: str):
     return st
 
 
-def _prep_metric(m) -> Optional[torch.Tensor]:
-    if m is None:
-        return None
-    m = asdevice(m)
-    return m
+def _prep_metric(m, dtype) -> Optional[torch.Tensor]:
+    return None if m is None else asdevice(m, dtype)
 
 
 def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str], fill: float = 0.0,
               m_in=None, m_out=None) -> torch.Tensor:
     """Fused pad + diff/interp/min/max along `axis` (xg_stencil1d_f64)."""
     lib = _hip.load()
-    x = asdevice(x)
+    dt, sfx = _common(x, m_in, m_out)
+    x = asdevice(x, dt)
     axis = axis % x.dim()
     shape = list(x.shape)
     n_out = shape[axis] + pad_lo + pad_hi - 1
     oshape = list(shape)
     oshape[axis] = n_out
-    m_in = _prep_metric(m_in)
-    m_out = _prep_metric(m_out)
-    out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    m_in = _prep_metric(m_in, dt)
+    m_out = _prep_metric(m_out, dt)
+    out = torch.empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:  # empty outer dims: nothing to launch (a NULL data_ptr is not a valid ABI argument)
         return out
     _hip.check(
-        lib.xg_stencil1d_f64(
+        getattr(lib, "xg_stencil1d_" + sfx)(
             _hip.OP[op], x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, n_out,
             int(pad_lo), int(pad_hi), _hip.BC[bc], float(fill),
             _ptr(m_in), _hip.i64(_bstrides(m_in, shape, "m_in")),
@@ -129,14 +152,15 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
              fill: float = 0.0, reverse: bool = False, skipna: bool = True, m_in=None, m_out=None) -> torch.Tensor:
     """Prefix sum along `axis` with the Grid.cumsum trim/pad folded in (xg_cumsum1d_f64)."""
     lib = _hip.load()
-    x = asdevice(x)
+    dt, sfx = _common(x, m_in, m_out)
+    x = asdevice(x, dt)
     axis = axis % x.dim()
     shape = list(x.shape)
     oshape = list(shape)
     oshape[axis] = shape[axis] - trim_lo - trim_hi + pad_lo + pad_hi
-    m_in = _prep_metric(m_in)
-    m_out = _prep_metric(m_out)
-    out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    m_in = _prep_metric(m_in, dt)
+    m_out = _prep_metric(m_out, dt)
+    out = torch.empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
         return out
     if shape[axis] - trim_lo - trim_hi == 0:
@@ -147,7 +171,7 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
         synthetic(tuple(oshape), 0, 0, 0.0, float(fill), out=out)
         return out if m_out is None else binary("div", out, m_out)
     _hip.check(
-        lib.xg_cumsum1d_f64(
+        getattr(lib, "xg_cumsum1d_" + sfx)(
             x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, int(bool(reverse)), int(bool(skipna)),
             int(trim_lo), int(trim_hi), int(pad_lo), int(pad_hi), _hip.BC[bc], float(fill),
             _ptr(m_in), _hip.i64(_bstrides(m_in, shape, "m_in")),
@@ -160,18 +184,19 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
 def reduce1d(x, axis: int, w=None, skipna: bool = True) -> torch.Tensor:
     """sum_k (x * w) along `axis`, axis removed (xg_reduce1d_f64)."""
     lib = _hip.load()
-    x = asdevice(x)
+    dt, sfx = _common(x, w)
+    x = asdevice(x, dt)
     axis = axis % x.dim()
     shape = list(x.shape)
     oshape = shape[:axis] + shape[axis + 1:]
-    w = _prep_metric(w)
-    out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    w = _prep_metric(w, dt)
+    out = torch.empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
         return out
     if x.numel() == 0:  # sum over an empty axis is 0
         return synthetic(tuple(oshape), 0, 0, 0.0, 0.0, out=out)
     _hip.check(
-        lib.xg_reduce1d_f64(
+        getattr(lib, "xg_reduce1d_" + sfx)(
             x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, int(bool(skipna)),
             _ptr(w), _hip.i64(_bstrides(w, shape, "w")), _stream(),
         )
@@ -182,7 +207,8 @@ def reduce1d(x, axis: int, w=None, skipna: bool = True) -> torch.Tensor:
 def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
     """Generic pad; dict keys are axis numbers, dict order is the application order (xg_pad_f64)."""
     lib = _hip.load()
-    x = asdevice(x)
+    dt, sfx = _common(x)
+    x = asdevice(x, dt)
     nd = x.dim()
     lo = [0] * nd
     hi = [0] * nd
@@ -197,12 +223,12 @@ def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
         order.append(ax)
     order += [d for d in range(nd) if d not in order]
     oshape = [s + l + h for s, l, h in zip(x.shape, lo, hi)]
-    out = torch.empty(oshape, dtype=torch.float64, device=x.device)
+    out = torch.empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
         return out
     _hip.check(
-        lib.xg_pad_f64(x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), nd, _hip.i64(lo), _hip.i64(hi),
-                       _hip.ints(bcv), _hip.f64s(fv), _hip.ints(order), _stream())
+        getattr(lib, "xg_pad_" + sfx)(x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), nd, _hip.i64(lo),
+                                      _hip.i64(hi), _hip.ints(bcv), _hip.reals(fv, sfx), _hip.ints(order), _stream())
     )
     return out
 
@@ -210,8 +236,9 @@ def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
 def binary(op: str, a, b) -> torch.Tensor:
     """Broadcasting a OP b for dim-aligned operands (same ndim, extents equal or 1)."""
     lib = _hip.load()
-    a = asdevice(a)
-    b = asdevice(b)
+    dt, sfx = _common(a, b)
+    a = asdevice(a, dt)
+    b = asdevice(b, dt)
     if a.dim() != b.dim():
         raise ValueError("binary: operands must be dim-aligned (same ndim)")
     shape = []
@@ -219,11 +246,11 @@ def binary(op: str, a, b) -> torch.Tensor:
         if sa != sb and 1 not in (sa, sb):
             raise ValueError(f"binary: extents {sa} and {sb} do not broadcast")
         shape.append(max(sa, sb) if 0 not in (sa, sb) else 0)
-    out = torch.empty(shape, dtype=torch.float64, device=a.device)
+    out = torch.empty(shape, dtype=dt, device=a.device)
     if out.numel() == 0:
         return out
     _hip.check(
-        lib.xg_binary_f64(_hip.BINOP[op], a.data_ptr(), _hip.i64(_bstrides(a, shape, "a")), b.data_ptr(),
+        getattr(lib, "xg_binary_" + sfx)(_hip.BINOP[op], a.data_ptr(), _hip.i64(_bstrides(a, shape, "a")), b.data_ptr(),
                           _hip.i64(_bstrides(b, shape, "b")), out.data_ptr(), _hip.i64(shape), len(shape), _stream())
     )
     return out
@@ -232,17 +259,18 @@ def binary(op: str, a, b) -> torch.Tensor:
 def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0) -> torch.Tensor:
     """Fused ((v[j,i]-v[j,i-1]) - (u[j,i]-u[j-1,i])) / area on (..., Y, X) arrays (xg_vorticity_f64)."""
     lib = _hip.load()
-    u = asdevice(u)
-    v = asdevice(v)
+    dt, sfx = _common(u, v, area)
+    u = asdevice(u, dt)
+    v = asdevice(v, dt)
     if u.shape != v.shape:
         raise ValueError("vorticity: u and v must have the same shape")
     shape = list(u.shape)
-    area = _prep_metric(area)
-    out = torch.empty(shape, dtype=torch.float64, device=u.device)
+    area = _prep_metric(area, dt)
+    out = torch.empty(shape, dtype=dt, device=u.device)
     if out.numel() == 0:
         return out
     _hip.check(
-        lib.xg_vorticity_f64(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
+        getattr(lib, "xg_vorticity_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
                              out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
                              _hip.BC[bc_y], float(fill_y), _stream())
     )
@@ -259,26 +287,30 @@ def stencil2d_supported(x, padx, pady) -> bool:
 def stencil2d(op: str, x, order: int, padx, bc_x: str, fill_x: float, pady, bc_y: str, fill_y: float) -> torch.Tensor:
     """OP along the last two axes in one pass (xg_stencil2d_f64); order 0 = X then Y, 1 = Y then X."""
     lib = _hip.load()
-    x = asdevice(x)
-    out = torch.empty(tuple(x.shape), dtype=torch.float64, device=x.device)
+    dt, sfx = _common(x)
+    x = asdevice(x, dt)
+    out = torch.empty(tuple(x.shape), dtype=dt, device=x.device)
     if out.numel() == 0:
         return out
     _hip.check(
-        lib.xg_stencil2d_f64(_hip.OP[op], x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), x.dim(), int(order),
+        getattr(lib, "xg_stencil2d_" + sfx)(_hip.OP[op], x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), x.dim(), int(order),
                              int(padx[0]), int(padx[1]), _hip.BC[bc_x], float(fill_x), int(pady[0]), int(pady[1]),
                              _hip.BC[bc_y], float(fill_y), _stream())
     )
     return out
 
 
-def synthetic(shape, seed: int, offset: int = 0, scale: float = 1.0, shift: float = -0.5, out=None) -> torch.Tensor:
-    """Deterministic synthetic field generated in HBM, bit-identical to oracle.refimpl.synthetic."""
+def synthetic(shape, seed: int, offset: int = 0, scale: float = 1.0, shift: float = -0.5, out=None,
+              dtype=torch.float64) -> torch.Tensor:
+    """Deterministic synthetic field generated in HBM, bit-identical to oracle.refimpl.synthetic
+    (float32: the float64 value rounded once, i.e. `synthetic(...).astype(np.float32)`)."""
     lib = _hip.load()
     _require_gpu()
     if out is None:
-        out = torch.empty(tuple(shape), dtype=torch.float64, device="cuda")
+        out = torch.empty(tuple(shape), dtype=dtype, device="cuda")
     if out.numel() == 0:
         return out
-    _hip.check(lib.xg_fill_synthetic_f64(out.data_ptr(), out.numel(), int(seed), int(offset), float(scale),
+    sfx = "f32" if out.dtype == torch.float32 else "f64"
+    _hip.check(getattr(lib, "xg_fill_synthetic_" + sfx)(out.data_ptr(), out.numel(), int(seed), int(offset), float(scale),
                                          float(shift), _stream()))
     return out

@@ -247,7 +247,9 @@ class DataArray:
     # ---- arithmetic on the GPU (name-based broadcasting like xarray) ---------------------
     def _binary(self, other, op: str, reflexive: bool = False) -> "DataArray":
         if isinstance(other, (int, float, np.integer, np.floating)):
-            o = DataArray(np.full((1,) * self.ndim, float(other)), tuple(f"__s{i}" for i in range(self.ndim)))
+            # python / numpy scalars are "weak": a float32 array stays float32 (numpy, xarray)
+            sdt = np.float32 if str(self.dtype).endswith("float32") else np.float64
+            o = DataArray(np.full((1,) * self.ndim, other, dtype=sdt), tuple(f"__s{i}" for i in range(self.ndim)))
             a, b, dims = self.data, o.data, self.dims
             coords = OrderedDict(self.coords)
         elif isinstance(other, DataArray):
