@@ -72,7 +72,8 @@ def vorticity(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0):
 
 def stencil2d_supported(x, padx, pady):
     x = np.asarray(x)
-    return x.ndim >= 2 and x.shape[-1] % 2 == 0 and sum(padx) == 1 and sum(pady) == 1 and x.shape[-1] > 0 and x.shape[-2] > 0
+    lane = 4 if x.dtype == np.float32 else 2
+    return x.ndim >= 2 and x.shape[-1] % lane == 0 and sum(padx) == 1 and sum(pady) == 1 and x.shape[-1] > 0 and x.shape[-2] > 0
 
 
 def stencil2d(op, x, order, padx, bc_x, fill_x, pady, bc_y, fill_y):

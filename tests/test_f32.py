@@ -116,6 +116,9 @@ def test_f32_pad_binary_vorticity_stencil2d_synthetic(dev):
         for bx, by in itertools.product(BCS, BCS):
             _eq(dev.tohost(dev.vorticity(u, v, area, bx, by, 0.25, -0.5)), R.vorticity(u, v, area, bx, by, F(0.25), F(-0.5)))
             for order in (0, 1):
+                if not dev.stencil2d_supported(u, (1, 0), (1, 0)):
+                    assert shape[-1] % 4  # float lanes hold 4 elements: the Grid layer then runs the axes one by one
+                    continue
                 t = R.stencil1d("interp", u, 2 if order == 0 else 1, 1, 0, bx if order == 0 else by, 0.5)
                 exp = R.stencil1d("interp", t, 1 if order == 0 else 2, 1, 0, by if order == 0 else bx, 0.5)
                 _eq(dev.tohost(dev.stencil2d("interp", u, order, (1, 0), bx, 0.5, (1, 0), by, 0.5)), exp)

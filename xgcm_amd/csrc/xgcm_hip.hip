@@ -49,7 +49,9 @@ extern "C" __attribute__((visibility("hidden"))) char* xg_internal_errbuf(void) 
 
 namespace {
 
-typedef real d2 __attribute__((ext_vector_type(2)));  // the 2-wide lane vector (16 B for f64, 8 B for f32)
+constexpr int NV = 16 / (int)sizeof(real);             // elements of a 16-byte lane vector: 2 (f64) / 4 (f32)
+typedef real dv __attribute__((ext_vector_type(NV)));  // THE lane vector: every fast path moves 16 B per lane
+typedef real r2 __attribute__((ext_vector_type(2)));   // element pair of the general contiguous path (K1g)
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
@@ -250,7 +252,7 @@ int build_geo(const int64_t* shape, int ndim, int axis, int64_t n_out, const int
 // ------------------------------------------------------------------------------------------
 template <int V> struct VecT;
 template <> struct VecT<1> { typedef real type; };
-template <> struct VecT<2> { typedef d2 type; };
+template <> struct VecT<NV> { typedef dv type; };
 
 template <typename T, bool NT>
 __device__ __forceinline__ T ldg(const real* p) {
@@ -264,7 +266,13 @@ __device__ __forceinline__ void stg(real* p, T v) {
 }
 
 // x-difference of a V-wide lane given the value just left of it
-__device__ __forceinline__ d2 dvdx_of(d2 vc, real vl) { d2 o; o.x = vc.x - vl; o.y = vc.y - vc.x; return o; }
+__device__ __forceinline__ dv dvdx_of(dv vc, real vl) {
+  dv o;
+  o[0] = vc[0] - vl;
+#pragma unroll
+  for (int k = 1; k < NV; ++k) o[k] = vc[k] - vc[k - 1];
+  return o;
+}
 __device__ __forceinline__ real dvdx_of(real vc, real vl) { return vc - vl; }
 
 // two-point bodies; l = a[..., i], r = a[..., i+1] of the padded array (gridops.py:23-24,76-77,123-175)
@@ -275,12 +283,20 @@ __device__ __forceinline__ real op2(real l, real r) {
   if (OP == XG_OP_MIN) return (l < r || l != l) ? l : r;  // NaN-propagating like np.min
   return (l > r || l != l) ? l : r;
 }
-template <int OP> __device__ __forceinline__ d2 op2(d2 l, d2 r) {
-  d2 o; o.x = op2<OP>(l.x, r.x); o.y = op2<OP>(l.y, r.y); return o;
+template <int OP> __device__ __forceinline__ dv op2(dv l, dv r) {
+  dv o;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) o[k] = op2<OP>(l[k], r[k]);
+  return o;
 }
 
 __device__ __forceinline__ real splat1(real f, real*) { return f; }
-__device__ __forceinline__ d2 splat1(real f, d2*) { d2 o; o.x = f; o.y = f; return o; }
+__device__ __forceinline__ dv splat1(real f, dv*) {
+  dv o;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) o[k] = f;
+  return o;
+}
 template <typename T> __device__ __forceinline__ T splat(real f) { return splat1(f, (T*)nullptr); }
 
 // offset of flat outer index `o` in a metric (unrolled so Geo/MIdx stay in SGPRs)
@@ -357,11 +373,14 @@ __device__ __forceinline__ int64_t inner_offx(const Geo& g, const MIdx& m, int64
 // metric value(s) for a V-wide lane at metric offset `off` (second element `step` further on)
 template <typename T> __device__ __forceinline__ T ldm(const real* m, int64_t off, int64_t step);
 template <> __device__ __forceinline__ real ldm<real>(const real* m, int64_t off, int64_t) { return m[off]; }
-template <> __device__ __forceinline__ d2 ldm<d2>(const real* m, int64_t off, int64_t step) {
-  // metric contiguous along the lanes and 16-B aligned here: one dwordx4 load instead of two dwordx2
-  if (step == 1 && (((reinterpret_cast<uintptr_t>(m) / sizeof(real)) + (uintptr_t)off) & 1) == 0)
-    return *reinterpret_cast<const d2*>(m + off);
-  d2 o; o.x = m[off]; o.y = m[off + step]; return o;
+template <> __device__ __forceinline__ dv ldm<dv>(const real* m, int64_t off, int64_t step) {
+  // metric contiguous along the lanes and 16-B aligned here: one dwordx4 load instead of NV narrow ones
+  if (step == 1 && (((reinterpret_cast<uintptr_t>(m) / sizeof(real)) + (uintptr_t)off) & (NV - 1)) == 0)
+    return *reinterpret_cast<const dv*>(m + off);
+  dv o;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) o[k] = m[off + k * step];
+  return o;
 }
 
 __device__ __forceinline__ u64 wave_id() {
@@ -405,11 +424,11 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided(
   int64_t mi_base = 0, mo_base = 0, mi_step = 0, mo_step = 0;
   if (HAS_MI) {
     mi_base = outer_off(g, mi, o) + inner_off(g, mi, x);
-    mi_step = (V == 2) ? inner_off(g, mi, x + 1) - inner_off(g, mi, x) : 0;
+    mi_step = (V > 1) ? inner_off(g, mi, x + 1) - inner_off(g, mi, x) : 0;
   }
   if (HAS_MO) {
     mo_base = outer_off(g, mo, o) + inner_off(g, mo, x);
-    mo_step = (V == 2) ? inner_off(g, mo, x + 1) - inner_off(g, mo, x) : 0;
+    mo_step = (V > 1) ? inner_off(g, mo, x + 1) - inner_off(g, mo, x) : 0;
   }
 
   // P(k): value of the padded, metric-weighted input at padded index k (q = k - pad_lo)
@@ -511,23 +530,30 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     if (HAS_MO) mob = outer_off32(g, mo, (u32)(row0 + r));
   }
 
-  if (V == 2) {
+  if (V > 1) {
     u32 nidx;
     bool edge;
     if (pad_lo) { edge = (i0 == 0); nidx = edge ? ((bc == XG_BC_PERIODIC) ? Li - 1 : 0) : i0 - 1; }
-    else { edge = (i0 + 2 == Li); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : Li - 1) : i0 + 2; }
-    d2 a = *reinterpret_cast<const d2*>(prow + i0);
+    else { edge = (i0 + NV == Li); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : Li - 1) : i0 + NV; }
+    dv a = *reinterpret_cast<const dv*>(prow + i0);
     real n = prow[nidx];
     if (HAS_MI) {
-      a = a * ldm<d2>(m_in, mib + (int64_t)i0 * mi.axis, mi.axis);
+      a = a * ldm<dv>(m_in, mib + (int64_t)i0 * mi.axis, mi.axis);
       n = n * m_in[mib + (int64_t)nidx * mi.axis];
     }
     if (edge && bc == XG_BC_FILL) n = fill;
-    d2 res;
-    if (pad_lo) { res.x = op2<OP>(n, a.x); res.y = op2<OP>(a.x, a.y); }
-    else { res.x = op2<OP>(a.x, a.y); res.y = op2<OP>(a.y, n); }
-    if (HAS_MO) res = res / ldm<d2>(m_out, mob + (int64_t)i0 * mo.axis, mo.axis);
-    stg<d2, NTS>(orow + i0, res);
+    dv res;
+    if (pad_lo) {
+      res[0] = op2<OP>(n, a[0]);
+#pragma unroll
+      for (int k = 1; k < NV; ++k) res[k] = op2<OP>(a[k - 1], a[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV - 1; ++k) res[k] = op2<OP>(a[k], a[k + 1]);
+      res[NV - 1] = op2<OP>(a[NV - 1], n);
+    }
+    if (HAS_MO) res = res / ldm<dv>(m_out, mob + (int64_t)i0 * mo.axis, mo.axis);
+    stg<dv, NTS>(orow + i0, res);
   } else {
     int64_t ql = (int64_t)i0 - pad_lo, qr = (int64_t)i0 + 1 - pad_lo;
     bool fl = false, fr = false;
@@ -591,10 +617,10 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
   real* po = out + (row0 * (int64_t)Lo + (u64)e0);  // row0 * Lo is even (host) => 16-B aligned
   const real a = one(r0, i0);
   if (have1) {
-    d2 res;
+    r2 res;
     res.x = a;
     res.y = one(r1, i1);
-    stg<d2, NTS>(po, res);
+    stg<r2, NTS>(po, res);
   } else {
     stg<real, NTS>(po, a);
   }
@@ -645,11 +671,11 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
 
   int64_t mib = 0, mob = 0, mis = 0, mos = 0;  // (host guarantees g.idx32 when metrics are present)
   if (HAS_MI) {
-    inner_off_step32(g, mi, (u32)x, V == 2, mib, mis);
+    inner_off_step32(g, mi, (u32)x, V > 1, mib, mis);
     mib += outer_off32(g, mi, (u32)o);
   }
   if (HAS_MO) {
-    inner_off_step32(g, mo, (u32)x, V == 2, mob, mos);
+    inner_off_step32(g, mo, (u32)x, V > 1, mob, mos);
     mob += outer_off32(g, mo, (u32)o) + j0 * mo.axis;
   }
 
@@ -687,7 +713,12 @@ struct ScanArgs {
 };
 
 __device__ __forceinline__ real nan0(real v) { return (v != v) ? real(0) : v; }
-__device__ __forceinline__ d2 nan0(d2 v) { d2 o; o.x = nan0(v.x); o.y = nan0(v.y); return o; }
+__device__ __forceinline__ dv nan0(dv v) {
+  dv o;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) o[k] = nan0(v[k]);
+  return o;
+}
 
 template <int V, int MET, bool NTL, bool NTS, int U>
 __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
@@ -711,11 +742,11 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
   int64_t mi_base = 0, mo_base = 0, mi_step = 0, mo_step = 0;
   if (HAS_MI) {
     mi_base = outer_off(g, mi, o) + inner_off(g, mi, x);
-    mi_step = (V == 2) ? inner_off(g, mi, x + 1) - inner_off(g, mi, x) : 0;
+    mi_step = (V > 1) ? inner_off(g, mi, x + 1) - inner_off(g, mi, x) : 0;
   }
   if (HAS_MO) {
     mo_base = outer_off(g, mo, o) + inner_off(g, mo, x);
-    mo_step = (V == 2) ? inner_off(g, mo, x + 1) - inner_off(g, mo, x) : 0;
+    mo_step = (V > 1) ? inner_off(g, mo, x + 1) - inner_off(g, mo, x) : 0;
   }
   auto put = [&](int64_t j, T v) {  // j = output index along the axis
     if (HAS_MO) v = v / ldm<T>(m_out, mo_base + j * mo.axis, mo_step);
@@ -866,7 +897,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
   int64_t mb = 0, ms = 0;
   if (HAS_W) {
     mb = outer_off(g, mw, o) + inner_off(g, mw, x);
-    ms = (V == 2) ? inner_off(g, mw, x + 1) - inner_off(g, mw, x) : 0;
+    ms = (V > 1) ? inner_off(g, mw, x + 1) - inner_off(g, mw, x) : 0;
   }
   T acc = splat<T>(real(0));
   bool started = false;
@@ -990,13 +1021,21 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, co
     }
   }
   const int64_t sa_in = g.sa[g.ndim - 1], sb_in = g.sb[g.ndim - 1];
-  if (V == 2) {
-    d2 av, bv, o;
-    if (sa_in == 1) av = *reinterpret_cast<const d2*>(a + oa); else { av.x = a[oa]; av.y = a[oa + sa_in]; }
-    if (sb_in == 1) bv = *reinterpret_cast<const d2*>(b + ob); else { bv.x = b[ob]; bv.y = b[ob + sb_in]; }
-    o.x = bin2<BOP>(av.x, bv.x);
-    o.y = bin2<BOP>(av.y, bv.y);
-    stg<d2, NTS>(out + gid * 2, o);
+  if (V > 1) {
+    dv av, bv, o;
+    if (sa_in == 1) av = *reinterpret_cast<const dv*>(a + oa);
+    else {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) av[k] = a[oa + k * sa_in];
+    }
+    if (sb_in == 1) bv = *reinterpret_cast<const dv*>(b + ob);
+    else {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) bv[k] = b[ob + k * sb_in];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) o[k] = bin2<BOP>(av[k], bv[k]);
+    stg<dv, NTS>(out + gid * NV, o);
   } else {
     stg<real, NTS>(out + gid, bin2<BOP>(a[oa], b[ob]));
   }
@@ -1095,7 +1134,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
   if (oo >= nouter) return;
   const u32 sg = r - oo * nseg.d;
   const int64_t o = o0 + oo;
-  const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * 2;
+  const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * NV;
   if (i0 >= nx) return;
   const int64_t j0 = (int64_t)sg * SEG;
   const int64_t nrow = (ny - j0 < SEG) ? ny - j0 : SEG;
@@ -1105,17 +1144,24 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
   int64_t nidx;
   bool edge;
   if (plx) { edge = (i0 == 0); nidx = edge ? ((bcx == XG_BC_PERIODIC) ? nx - 1 : 0) : i0 - 1; }
-  else { edge = (i0 + 2 == nx); nidx = edge ? ((bcx == XG_BC_PERIODIC) ? 0 : nx - 1) : i0 + 2; }
+  else { edge = (i0 + NV == nx); nidx = edge ? ((bcx == XG_BC_PERIODIC) ? 0 : nx - 1) : i0 + NV; }
   const bool fill_edge = edge && (bcx == XG_BC_FILL);
-  // X stencil on a pair `a` with the value `n` next to it (left of a.x if plx, right of a.y otherwise)
-  auto opx = [&](d2 a, real n) -> d2 {
-    d2 t;
-    if (plx) { t.x = op2<OP>(n, a.x); t.y = op2<OP>(a.x, a.y); }
-    else { t.x = op2<OP>(a.x, a.y); t.y = op2<OP>(a.y, n); }
+  // X stencil on a lane vector `a` with the value `n` next to it (left of a[0] if plx, right of a[NV-1] otherwise)
+  auto opx = [&](dv a, real n) -> dv {
+    dv t;
+    if (plx) {
+      t[0] = op2<OP>(n, a[0]);
+#pragma unroll
+      for (int k = 1; k < NV; ++k) t[k] = op2<OP>(a[k - 1], a[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV - 1; ++k) t[k] = op2<OP>(a[k], a[k + 1]);
+      t[NV - 1] = op2<OP>(a[NV - 1], n);
+    }
     return t;
   };
 
-  d2 pr[SEG + 1];
+  dv pr[SEG + 1];
   real nb[SEG + 1];
   bool rowfill[SEG + 1];
 #pragma unroll
@@ -1126,30 +1172,30 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
     if (q < 0) { f = (bcy == XG_BC_FILL); q = (bcy == XG_BC_PERIODIC) ? ny - 1 : 0; }
     else if (q >= ny) { f = (bcy == XG_BC_FILL); q = (bcy == XG_BC_PERIODIC) ? 0 : ny - 1; }
     rowfill[u] = f;
-    pr[u] = *reinterpret_cast<const d2*>(pin + q * nx + i0);
+    pr[u] = *reinterpret_cast<const dv*>(pin + q * nx + i0);
     nb[u] = pin[q * nx + nidx];
   }
   if (order == 0) {  // X first, then Y on the intermediate
-    d2 tx[SEG + 1];
+    dv tx[SEG + 1];
 #pragma unroll
     for (int u = 0; u <= SEG; ++u) {
-      const d2 t = opx(pr[u], fill_edge ? fillx : nb[u]);
-      tx[u] = rowfill[u] ? splat<d2>(filly) : t;
+      const dv t = opx(pr[u], fill_edge ? fillx : nb[u]);
+      tx[u] = rowfill[u] ? splat<dv>(filly) : t;
     }
 #pragma unroll
     for (int u = 0; u < SEG; ++u)
-      if (u < nrow) stg<d2, NTS>(po + u * nx, op2<OP>(tx[u], tx[u + 1]));
+      if (u < nrow) stg<dv, NTS>(po + u * nx, op2<OP>(tx[u], tx[u + 1]));
   } else {  // Y first, then X on the intermediate
 #pragma unroll
     for (int u = 0; u <= SEG; ++u) {
-      if (rowfill[u]) { pr[u] = splat<d2>(filly); nb[u] = filly; }
+      if (rowfill[u]) { pr[u] = splat<dv>(filly); nb[u] = filly; }
     }
 #pragma unroll
     for (int u = 0; u < SEG; ++u) {
       if (u < nrow) {
-        const d2 ty = op2<OP>(pr[u], pr[u + 1]);
+        const dv ty = op2<OP>(pr[u], pr[u + 1]);
         const real tn = op2<OP>(nb[u], nb[u + 1]);
-        stg<d2, NTS>(po + u * nx, opx(ty, fill_edge ? fillx : tn));
+        stg<dv, NTS>(po + u * nx, opx(ty, fill_edge ? fillx : tn));
       }
     }
   }
@@ -1174,7 +1220,8 @@ __global__ __launch_bounds__(BLOCK) void k_fill_synthetic(real* __restrict__ out
 // ------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ------------------------------------------------------------------------------------------
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (2 * sizeof(real) - 1)) == 0; }  // "aligned for d2"
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }  // lane vector
+inline bool aligned_pair(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (2 * sizeof(real) - 1)) == 0; }
 
 inline int check_grid(u64 nblocks) {
   if (nblocks == 0 || nblocks > 0x7fffffffull) return fail(XG_ERR_UNSUPPORTED, "launch of %llu blocks exceeds grid limits", nblocks);
@@ -1241,7 +1288,7 @@ int launch_contig_gen(const StencilCall& c) {
 
 template <int OP, int V, int MET>
 int launch_contig(const StencilCall& c) {
-  if (V == 1 && tune().contig_gen && aligned16(c.out) && c.g.n_in <= 0x7fffffffll && c.g.n_out <= 0x7fffffffll &&
+  if (V == 1 && tune().contig_gen && aligned_pair(c.out) && c.g.n_in <= 0x7fffffffll && c.g.n_out <= 0x7fffffffll &&
       c.g.outer * c.g.n_out >= 2) {
     const int rc = launch_contig_gen<OP, MET>(c);
     if (rc >= 0) return rc;
@@ -1332,7 +1379,7 @@ int stencil_met(int met, int kind, const StencilCall& c) {
 }
 template <int OP>
 int stencil_vec(int V, int met, int kind, const StencilCall& c) {
-  return V == 2 ? stencil_met<OP, 2>(met, kind, c) : stencil_met<OP, 1>(met, kind, c);
+  return V > 1 ? stencil_met<OP, NV>(met, kind, c) : stencil_met<OP, 1>(met, kind, c);
 }
 int stencil_dispatch(int op, int V, int met, int kind, const StencilCall& c) {
   switch (op) {
@@ -1344,6 +1391,14 @@ int stencil_dispatch(int op, int V, int met, int kind, const StencilCall& c) {
 }
 
 inline u32 ceil_div_u32(int64_t a, int64_t b) { return (u32)((a + b - 1) / b); }
+
+// A lane vector of NV elements takes its metric values at a constant step from the first one; that
+// holds when the NV elements share one row of the innermost coalesced dim.  For NV == 2 the step is
+// computed exactly per lane, so only wider vectors (float) need the innermost extent to divide.
+inline bool vec_metric_ok(const Geo& g, bool metrics) {
+  if (!metrics || NV <= 2 || g.n_inner == 0) return true;
+  return g.inner_shape[g.n_inner - 1] % NV == 0;
+}
 
 }  // namespace
 
@@ -1415,9 +1470,9 @@ int XG_FN(xg_stencil1d)(int op, const real* in, real* out, const int64_t* shape,
   int V, kind;
   if (g.inner == 1) {
     kind = KIND_CONTIG;
-    V = (al && (g.n_in % 2 == 0) && (n_out % 2 == 0)) ? 2 : 1;
+    V = (al && (g.n_in % NV == 0) && (n_out % NV == 0)) ? NV : 1;
   } else {
-    V = (al && (g.inner % 2 == 0)) ? 2 : 1;
+    V = (al && (g.inner % NV == 0) && vec_metric_ok(g, met != 0)) ? NV : 1;
     // few x-tiles per row (Y of a (Z,Y,X) field): short banded segments keep the rows in flight
     // compact.  Many tiles per row (Z: a whole plane per row): all waves in flight already sit
     // in the same rows, so march the full column and never re-read a halo row.
@@ -1461,7 +1516,7 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
 #undef XG_M
     }
   } else {
-    const int V = (aligned16(in) && aligned16(out) && (g.inner % 2 == 0)) ? 2 : 1;
+    const int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, met != 0)) ? NV : 1;
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
     const u64 ntask = (u64)ntile * (u64)g.outer;
     const u64 nblocks = (ntask + WPB - 1) / WPB;
@@ -1474,7 +1529,7 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
                                else hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); } while (0)
 #define XG_M(V_, M) do { if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
 #define XG_V(V_) switch (met) { case 0: XG_M(V_, 0); break; case 1: XG_M(V_, 1); break; case 2: XG_M(V_, 2); break; default: XG_M(V_, 3); }
-    if (V == 2) { XG_V(2) } else { XG_V(1) }
+    if (V > 1) { XG_V(NV) } else { XG_V(1) }
 #undef XG_V
 #undef XG_M
 #undef XG_GO
@@ -1499,7 +1554,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     if (w) hipLaunchKernelGGL((k_reduce_contig<true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
     else hipLaunchKernelGGL((k_reduce_contig<false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
   } else {
-    const int V = (aligned16(in) && aligned16(out) && (g.inner % 2 == 0)) ? 2 : 1;
+    const int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, w != nullptr)) ? NV : 1;
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
     const u64 ntask = (u64)ntile * (u64)g.outer;
     const u64 nblocks = (ntask + WPB - 1) / WPB;
@@ -1507,7 +1562,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     const bool deep = ntask < (u64)tune().deep_waves;
 #define XG_GO(V_, W_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, false, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); \
                            else hipLaunchKernelGGL((k_reduce_strided<V_, W_, false, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); } while (0)
-    if (V == 2) { if (w) XG_GO(2, true); else XG_GO(2, false); }
+    if (V > 1) { if (w) XG_GO(NV, true); else XG_GO(NV, false); }
     else { if (w) XG_GO(1, true); else XG_GO(1, false); }
 #undef XG_GO
   }
@@ -1590,16 +1645,16 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
   g.ndim = n;
   const int64_t last = g.shape[n - 1];
   const int64_t sa = g.sa[n - 1], sb = g.sb[n - 1];
-  bool v2 = (last % 2 == 0) && aligned16(out) && (sa == 0 || sa == 1) && (sb == 0 || sb == 1);
+  bool v2 = (last % NV == 0) && aligned16(out) && (sa == 0 || sa == 1) && (sb == 0 || sb == 1);
   if (v2 && sa == 1) {
     if (!aligned16(a)) v2 = false;
-    for (int d = 0; d < n - 1; ++d) if (g.sa[d] % 2) v2 = false;
+    for (int d = 0; d < n - 1; ++d) if (g.sa[d] % NV) v2 = false;
   }
   if (v2 && sb == 1) {
     if (!aligned16(b)) v2 = false;
-    for (int d = 0; d < n - 1; ++d) if (g.sb[d] % 2) v2 = false;
+    for (int d = 0; d < n - 1; ++d) if (g.sb[d] % NV) v2 = false;
   }
-  const int V = v2 ? 2 : 1;
+  const int V = v2 ? NV : 1;
   g.shape[n - 1] = last / V;
   g.total = total / V;
   const u64 nblocks = ((u64)g.total + BLOCK - 1) / BLOCK;
@@ -1608,7 +1663,7 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
   hipStream_t st = (hipStream_t)stream;
   const bool nts = tune().nt_store;
 #define XG_GO(O, V_, NTS) hipLaunchKernelGGL((k_binary<O, V_, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, a, b, out, g)
-#define XG_O(O) do { if (V == 2) { if (nts) XG_GO(O, 2, true); else XG_GO(O, 2, false); } else { if (nts) XG_GO(O, 1, true); else XG_GO(O, 1, false); } } while (0)
+#define XG_O(O) do { if (V > 1) { if (nts) XG_GO(O, NV, true); else XG_GO(O, NV, false); } else { if (nts) XG_GO(O, 1, true); else XG_GO(O, 1, false); } } while (0)
   switch (op) { case XG_BIN_MUL: XG_O(XG_BIN_MUL); break; case XG_BIN_DIV: XG_O(XG_BIN_DIV); break; case XG_BIN_ADD: XG_O(XG_BIN_ADD); break; default: XG_O(XG_BIN_SUB); }
 #undef XG_O
 #undef XG_GO
@@ -1644,7 +1699,7 @@ int XG_FN(xg_vorticity)(const real* u, const real* v, const real* area, const in
     else if (contig && a_sy == nx && a_sx == 1) a_so = ny * nx;
     else return fail(XG_ERR_UNSUPPORTED, "area must be (Y,X)-shaped or fully materialised");
   }
-  const int V = (aligned16(u) && aligned16(v) && aligned16(out) && nx % 2 == 0) ? 2 : 1;
+  const int V = (aligned16(u) && aligned16(v) && aligned16(out) && nx % NV == 0) ? NV : 1;
   constexpr int SEG = 4;
   const u64 ntile = (u64)((nx + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
   const u64 nseg = (u64)((ny + SEG - 1) / SEG);
@@ -1671,7 +1726,7 @@ int XG_FN(xg_vorticity)(const real* u, const real* v, const real* area, const in
     const u32 grid = ((nblk + 7) / 8) * 8;
 #define XG_GO(V_, A_, NTS) hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, a_so, a_sy, a_sx)
 #define XG_A(V_, A_) do { if (nts) XG_GO(V_, A_, true); else XG_GO(V_, A_, false); } while (0)
-    if (V == 2) { if (area) XG_A(2, true); else XG_A(2, false); }
+    if (V > 1) { if (area) XG_A(NV, true); else XG_A(NV, false); }
     else { if (area) XG_A(1, true); else XG_A(1, false); }
 #undef XG_A
 #undef XG_GO
@@ -1695,9 +1750,9 @@ int XG_FN(xg_stencil2d)(int op, const real* in, real* out, const int64_t* shape,
   int64_t outer = 1;
   for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
   if (outer == 0 || ny == 0 || nx == 0) return XG_OK;
-  if (nx % 2 || !aligned16(in) || !aligned16(out)) return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil needs an even, 16-byte aligned X extent");
+  if (nx % NV || !aligned16(in) || !aligned16(out)) return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil needs an X extent that is a multiple of the 16-byte lane vector");
   constexpr int SEG = 4;
-  const u64 ntile = (u64)((nx + 2 * WAVE - 1) / (2 * WAVE));
+  const u64 ntile = (u64)((nx + NV * WAVE - 1) / (NV * WAVE));
   const u64 nseg = (u64)((ny + SEG - 1) / SEG);
   const u64 per_outer = ntile * nseg;
   if (per_outer > MAX_ITEMS) return fail(XG_ERR_UNSUPPORTED, "extent too large for the 2-D stencil kernel");

@@ -280,7 +280,8 @@ def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: flo
 def stencil2d_supported(x, padx, pady) -> bool:
     """Can xg_stencil2d_f64 serve this call (else run the two axes one after the other)?"""
     shape = tuple(x.shape)  # numpy (host) or torch (HBM) data
-    return (len(shape) >= 2 and shape[-1] % 2 == 0 and sum(padx) == 1 and sum(pady) == 1
+    lane = 4 if _dtype_of(x) == torch.float32 else 2  # elements of the 16-byte lane vector
+    return (len(shape) >= 2 and shape[-1] % lane == 0 and sum(padx) == 1 and sum(pady) == 1
             and shape[-1] > 0 and shape[-2] > 0)
 
 
