@@ -36,8 +36,12 @@ def _metric(rng, shape, seed):
     return R.synthetic_metric(mshape, seed)
 
 
+DTYPES = [np.float64, np.float32]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f64", "f32"])
 @pytest.mark.parametrize("seed", range(12))
-def test_fuzz_stencil(dev, seed):
+def test_fuzz_stencil(dev, seed, dtype):
     rng = np.random.default_rng(1000 + seed)
     for case in range(25):
         shape = _shape(rng)
@@ -47,26 +51,28 @@ def test_fuzz_stencil(dev, seed):
         if shape[axis] + lo + hi - 1 < 1:
             continue
         bc = str(rng.choice(BCS))
-        a = R.synthetic_field(shape, 7000 + 31 * seed + case)
+        a = R.synthetic_field(shape, 7000 + 31 * seed + case).astype(dtype)
         if op in ("min", "max") and a.size > 4:
             a.reshape(-1)[rng.integers(0, a.size, 2)] = np.nan
         oshape = list(shape)
         oshape[axis] += lo + hi - 1
         kind = int(rng.integers(0, 4))
-        m_in = _metric(rng, shape, 11 + case) if kind in (2, 3) else None
-        m_out = _metric(rng, oshape, 23 + case) if kind in (1, 3) else None
+        m_in = _metric(rng, shape, 11 + case).astype(dtype) if kind in (2, 3) else None
+        m_out = _metric(rng, oshape, 23 + case).astype(dtype) if kind in (1, 3) else None
         fill = float(rng.choice([0.0, 1.5, -2.25]))
         exp = R.stencil1d(op, a, axis, lo, hi, bc, fill, m_in, m_out)
         got = dev.tohost(dev.stencil1d(op, a, axis, lo, hi, bc, fill, m_in, m_out))
-        assert got.shape == exp.shape, (shape, axis, op, lo, hi, bc)
+        assert got.shape == exp.shape and got.dtype == exp.dtype == dtype, (shape, axis, op, lo, hi, bc)
         assert np.array_equal(got, exp, equal_nan=True), (shape, axis, op, (lo, hi), bc, kind,
                                                            None if m_in is None else m_in.shape,
                                                            None if m_out is None else m_out.shape)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f64", "f32"])
 @pytest.mark.parametrize("seed", range(8))
-def test_fuzz_cumsum_reduce(dev, seed):
+def test_fuzz_cumsum_reduce(dev, seed, dtype):
     rng = np.random.default_rng(2000 + seed)
+    rtol, atol = (1e-12, 1e-9) if dtype == np.float64 else (3e-5, 3e-2)
     tables = [(0, 0, 0, 0), (0, 1, 1, 0), (0, 1, 0, 0), (0, 0, 1, 0), (1, 0, 0, 1), (1, 0, 0, 0), (0, 0, 0, 1)]
     for case in range(20):
         shape = _shape(rng)
@@ -76,38 +82,40 @@ def test_fuzz_cumsum_reduce(dev, seed):
             continue
         bc = str(rng.choice(BCS))
         reverse, skipna = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
-        a = R.synthetic_field(shape, 9000 + 17 * seed + case)
+        a = R.synthetic_field(shape, 9000 + 17 * seed + case).astype(dtype)
         if a.size > 4 and rng.random() < 0.5:
             a.reshape(-1)[rng.integers(0, a.size, 2)] = np.nan
         oshape = list(shape)
         oshape[axis] += pl + ph - tl - th
-        m_in = _metric(rng, shape, 5 + case) if rng.random() < 0.4 else None
-        m_out = _metric(rng, oshape, 6 + case) if rng.random() < 0.4 else None
+        m_in = _metric(rng, shape, 5 + case).astype(dtype) if rng.random() < 0.4 else None
+        m_out = _metric(rng, oshape, 6 + case).astype(dtype) if rng.random() < 0.4 else None
         exp = R.cumsum1d(a, axis, tl, th, pl, ph, bc, 0.5, reverse, skipna, m_in, m_out)
         got = dev.tohost(dev.cumsum1d(a, axis, tl, th, pl, ph, bc, 0.5, reverse, skipna, m_in, m_out))
         contiguous = axis == len(shape) - 1 or all(s == 1 for s in shape[axis + 1:])
+        assert got.dtype == dtype
         if contiguous:
-            np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-9, equal_nan=True)
+            np.testing.assert_allclose(got, exp, rtol=rtol, atol=atol, equal_nan=True)
         else:
             assert np.array_equal(got, exp, equal_nan=True), (shape, axis, (tl, th, pl, ph), bc, reverse, skipna)
-        w = _metric(rng, shape, 8 + case) if rng.random() < 0.5 else None
+        w = _metric(rng, shape, 8 + case).astype(dtype) if rng.random() < 0.5 else None
         exp = R.integrate(a, axis, w, skipna)
         got = dev.tohost(dev.reduce1d(a, axis, w, skipna))
         if contiguous:
-            np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-9, equal_nan=True)
+            np.testing.assert_allclose(got, exp, rtol=rtol, atol=atol * 10, equal_nan=True)
         else:
             assert np.array_equal(got, exp, equal_nan=True), (shape, axis, "reduce", skipna)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f64", "f32"])
 @pytest.mark.parametrize("seed", range(4))
-def test_fuzz_two_axis_and_vorticity(dev, seed):
+def test_fuzz_two_axis_and_vorticity(dev, seed, dtype):
     rng = np.random.default_rng(3000 + seed)
     for case in range(15):
         nd = int(rng.integers(2, 5))
         shape = tuple(int(rng.choice([1, 2, 3, 5])) for _ in range(nd - 2)) + (int(rng.choice([1, 2, 3, 4, 5, 9, 33])),
                                                                               int(rng.choice([2, 4, 6, 64, 130, 258])))
-        a = R.synthetic_field(shape, 100 + case)
-        b = R.synthetic_field(shape, 200 + case)
+        a = R.synthetic_field(shape, 100 + case).astype(dtype)
+        b = R.synthetic_field(shape, 200 + case).astype(dtype)
         op = str(rng.choice(["diff", "interp", "min", "max"]))
         order = int(rng.integers(0, 2))
         padx, pady = [(1, 0), (0, 1)][int(rng.integers(0, 2))], [(1, 0), (0, 1)][int(rng.integers(0, 2))]
@@ -117,9 +125,10 @@ def test_fuzz_two_axis_and_vorticity(dev, seed):
             exp = R.stencil1d(op, R.stencil1d(op, a, ax_x, *padx, bcx, 0.5), ax_y, *pady, bcy, -1.0)
         else:
             exp = R.stencil1d(op, R.stencil1d(op, a, ax_y, *pady, bcy, -1.0), ax_x, *padx, bcx, 0.5)
-        got = dev.tohost(dev.stencil2d(op, a, order, padx, bcx, 0.5, pady, bcy, -1.0))
-        assert np.array_equal(got, exp, equal_nan=True), (shape, op, order, padx, pady, bcx, bcy)
-        area = R.synthetic_metric((1,) * (nd - 2) + shape[-2:], 300 + case) if rng.random() < 0.7 else None
-        exp = R.vorticity(a, b, area if area is not None else np.ones((1,) * nd), bcx, bcy, 0.25, -0.5)
+        if dev.stencil2d_supported(a, padx, pady):
+            got = dev.tohost(dev.stencil2d(op, a, order, padx, bcx, 0.5, pady, bcy, -1.0))
+            assert got.dtype == dtype and np.array_equal(got, exp, equal_nan=True), (shape, op, order, padx, pady, bcx, bcy)
+        area = R.synthetic_metric((1,) * (nd - 2) + shape[-2:], 300 + case).astype(dtype) if rng.random() < 0.7 else None
+        exp = R.vorticity(a, b, area if area is not None else np.ones((1,) * nd, dtype=dtype), bcx, bcy, dtype(0.25), dtype(-0.5))
         got = dev.tohost(dev.vorticity(a, b, area, bcx, bcy, 0.25, -0.5))
         assert np.array_equal(got, exp), (shape, "vorticity", bcx, bcy, area is not None)
