@@ -51,7 +51,6 @@ namespace {
 
 constexpr int NV = 16 / (int)sizeof(real);             // elements of a 16-byte lane vector: 2 (f64) / 4 (f32)
 typedef real dv __attribute__((ext_vector_type(NV)));  // THE lane vector: every fast path moves 16 B per lane
-typedef real r2 __attribute__((ext_vector_type(2)));   // element pair of the general contiguous path (K1g)
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
@@ -575,9 +574,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
 // ------------------------------------------------------------------------------------------
 // K1g: contiguous axis, GENERAL lengths (odd rows, N+1 / N-1 outputs: outer/inner positions).
 // Rows of the output are then not 16-B aligned, but the output ARRAY is: the array is walked as
-// a flat list of element PAIRS (which may straddle two rows), each element is computed like the
-// V == 1 path of K1 (two 8-B loads served by L1) and the pair leaves as one aligned 16-B store.
-// Half the threads, index math and store instructions of the one-element-per-thread form.
+// a flat list of NV-element groups (which may straddle two rows), each element is computed like
+// the V == 1 path of K1 (two narrow loads served by L1) and the group leaves as one aligned
+// 16-B store.  1/NV of the threads, index math and store instructions of the one-element form.
 // ------------------------------------------------------------------------------------------
 template <int OP, int MET, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
@@ -589,13 +588,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
   if (lb >= nblk) return;
   const u32 gid = lb * BLOCK + threadIdx.x;
-  if (gid >= (nelem + 1) / 2) return;
-  const u32 e0 = 2 * gid;
+  if (gid >= (nelem + NV - 1) / NV) return;
+  const u32 e0 = NV * gid;
   const u32 Li = (u32)g.n_in, Lo = (u32)g.n_out;
-  const u32 r0 = fdiv(e0, fLo), i0 = e0 - r0 * Lo;
-  const bool have1 = e0 + 1 < nelem;
-  u32 r1 = r0, i1 = i0 + 1;
-  if (i1 == Lo) { i1 = 0; r1 = r0 + 1; }
   auto one = [&](u32 r, u32 i) -> real {
     const real* prow = in + (row0 * (int64_t)Li + (u64)r * Li);
     int64_t ql = (int64_t)i - pad_lo, qr = (int64_t)i + 1 - pad_lo;
@@ -614,15 +609,41 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
     if (HAS_MO) res = res / m_out[outer_off32(g, mo, (u32)(row0 + r)) + (int64_t)i * mo.axis];
     return res;
   };
-  real* po = out + (row0 * (int64_t)Lo + (u64)e0);  // row0 * Lo is even (host) => 16-B aligned
-  const real a = one(r0, i0);
-  if (have1) {
-    r2 res;
-    res.x = a;
-    res.y = one(r1, i1);
-    stg<r2, NTS>(po, res);
+  u32 r = fdiv(e0, fLo), i = e0 - r * Lo;
+  real* po = out + (row0 * (int64_t)Lo + (u64)e0);  // row0 * Lo is a multiple of NV (host) => 16-B aligned
+  dv res;
+  const int64_t q0 = (int64_t)i - pad_lo;
+  if (i + NV <= Lo && q0 >= 0 && q0 + NV < (int64_t)Li && e0 + NV <= nelem) {
+    // interior group inside one row: the NV outputs share NV + 1 consecutive inputs
+    const real* prow = in + (row0 * (int64_t)Li + (u64)r * Li) + q0;
+    real v[NV + 1];
+#pragma unroll
+    for (int k = 0; k <= NV; ++k) v[k] = prow[k];
+    if (HAS_MI) {
+      const int64_t mib = outer_off32(g, mi, (u32)(row0 + r)) + q0 * mi.axis;
+#pragma unroll
+      for (int k = 0; k <= NV; ++k) v[k] = v[k] * m_in[mib + k * mi.axis];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) res[k] = op2<OP>(v[k], v[k + 1]);
+    if (HAS_MO) {
+      const int64_t mob = outer_off32(g, mo, (u32)(row0 + r)) + (int64_t)i * mo.axis;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) res[k] = res[k] / m_out[mob + k * mo.axis];
+    }
   } else {
-    stg<real, NTS>(po, a);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (e0 + k < nelem) res[k] = one(r, i);
+      if (++i == Lo) { i = 0; ++r; }
+    }
+  }
+  if (e0 + NV <= nelem) {
+    stg<dv, NTS>(po, res);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (e0 + k < nelem) po[k] = res[k];
   }
 }
 
@@ -1221,7 +1242,6 @@ __global__ __launch_bounds__(BLOCK) void k_fill_synthetic(real* __restrict__ out
 // host-side launch helpers
 // ------------------------------------------------------------------------------------------
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }  // lane vector
-inline bool aligned_pair(const void* p) { return (reinterpret_cast<uintptr_t>(p) & (2 * sizeof(real) - 1)) == 0; }
 
 inline int check_grid(u64 nblocks) {
   if (nblocks == 0 || nblocks > 0x7fffffffull) return fail(XG_ERR_UNSUPPORTED, "launch of %llu blocks exceeds grid limits", nblocks);
@@ -1270,13 +1290,13 @@ template <int OP, int MET>
 int launch_contig_gen(const StencilCall& c) {
   const u64 Lo = (u64)c.g.n_out;
   u64 rows_per = 0xfffffff0ull / Lo;
-  rows_per -= rows_per & 1;  // even number of rows per launch keeps every launch's first pair aligned
-  if (rows_per < 2) return -1;
+  rows_per -= rows_per % NV;  // a multiple of NV rows per launch keeps every launch's first group aligned
+  if (rows_per < (u64)NV) return -1;
   const FastDiv fLo = make_fastdiv(Lo);
   for (u64 row0 = 0; row0 < (u64)c.g.outer; row0 += rows_per) {
     const u64 nrows = ((u64)c.g.outer - row0 < rows_per) ? (u64)c.g.outer - row0 : rows_per;
     const u32 nelem = (u32)(nrows * Lo);
-    const u32 nblk = (u32)((((u64)nelem + 1) / 2 + BLOCK - 1) / BLOCK);
+    const u32 nblk = (u32)((((u64)nelem + NV - 1) / NV + BLOCK - 1) / BLOCK);
     const u32 grid = ((nblk + 7) / 8) * 8;
     if (tune().nt_store)
       hipLaunchKernelGGL((k_stencil_contig_gen<OP, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nelem, nblk, fLo, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
@@ -1288,7 +1308,7 @@ int launch_contig_gen(const StencilCall& c) {
 
 template <int OP, int V, int MET>
 int launch_contig(const StencilCall& c) {
-  if (V == 1 && tune().contig_gen && aligned_pair(c.out) && c.g.n_in <= 0x7fffffffll && c.g.n_out <= 0x7fffffffll &&
+  if (V == 1 && tune().contig_gen && aligned16(c.out) && c.g.n_in <= 0x7fffffffll && c.g.n_out <= 0x7fffffffll &&
       c.g.outer * c.g.n_out >= 2) {
     const int rc = launch_contig_gen<OP, MET>(c);
     if (rc >= 0) return rc;
