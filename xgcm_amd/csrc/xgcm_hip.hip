@@ -942,7 +942,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
 
 // K4b: weighted sum along the CONTIGUOUS axis: one wave per row, lane-strided partial sums then
 // a shuffle tree (tolerance parity; numpy itself is pairwise here).
-template <bool HAS_W>
+template <bool HAS_W, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict__ in,
                                                          real* __restrict__ out, Geo g, int skipna,
                                                          const real* __restrict__ wgt, MIdx mw) {
@@ -954,7 +954,21 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
   int64_t mb = 0;
   if (HAS_W) mb = outer_off(g, mw, row);
   real acc = real(0);
-  for (int64_t k = lane; k < n; k += WAVE) {
+  int64_t k0 = 0;
+  if (VEC) {  // rows 16-B aligned (host): 16-B loads, NV partial sums per lane, two loads in flight
+    dv a = splat<dv>(real(0));
+    const int64_t nvec = n / NV;
+    for (int64_t t = lane; t < nvec; t += WAVE) {
+      dv v = *reinterpret_cast<const dv*>(prow + t * NV);
+      if (HAS_W) v = v * ldm<dv>(wgt, mb + t * NV * mw.axis, mw.axis);
+      if (skipna) v = nan0(v);
+      a = a + v;
+    }
+#pragma unroll
+    for (int c = 0; c < NV; ++c) acc += a[c];
+    k0 = nvec * NV;
+  }
+  for (int64_t k = k0 + lane; k < n; k += WAVE) {
     real v = prow[k];
     if (HAS_W) v = v * wgt[mb + k * mw.axis];
     if (skipna) v = nan0(v);
@@ -1571,8 +1585,14 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
   if (g.inner == 1) {
     const u64 nblocks = ((u64)g.outer + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
-    if (w) hipLaunchKernelGGL((k_reduce_contig<true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
-    else hipLaunchKernelGGL((k_reduce_contig<false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+    const bool vec = aligned16(in) && (g.n_in % NV == 0) && g.n_in >= 4 * NV;  // every row starts 16-B aligned
+    if (vec) {
+      if (w) hipLaunchKernelGGL((k_reduce_contig<true, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+      else hipLaunchKernelGGL((k_reduce_contig<false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+    } else {
+      if (w) hipLaunchKernelGGL((k_reduce_contig<true, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+      else hipLaunchKernelGGL((k_reduce_contig<false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+    }
   } else {
     const int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, w != nullptr)) ? NV : 1;
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
