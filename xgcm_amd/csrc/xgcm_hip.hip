@@ -89,6 +89,7 @@ struct Tune {
   int nt_store;  // non-temporal stores (+2-4 %; non-temporal LOADS measured -1 % and are not used)
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
+  int scan_vec;       // aligned-output-group scan for cumsum along the contiguous axis
   int contig_gen;     // pair-wise general path for odd / length-changing rows on the contiguous axis
   int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
   int march_lds_kb;   // optional dynamic LDS request for the column-marching kernels, only to cap residency
@@ -97,6 +98,7 @@ struct Tune {
   Tune() {
     march_lds_kb = env_int("XG_MARCH_LDS_KB", 0);
     contig_gen = env_int("XG_CONTIG_GEN", 1);
+    scan_vec = env_int("XG_SCAN_VEC", 1);
     deep_waves = env_int("XG_DEEP_WAVES", 0);  // measured neutral (4.80 vs 4.88 TB/s on cumsum along Y): off
     zband = env_int("XG_ZBAND", 1);
     seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
@@ -897,6 +899,104 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
 }
 
 // ------------------------------------------------------------------------------------------
+// K6v: cumsum along the CONTIGUOUS axis when output rows are 16-B aligned (n_out % NV == 0, no
+// periodic halo).  Threads own aligned groups of NV consecutive OUTPUTS (one 16-B store each) and
+// fetch the NV inputs behind them with narrow consecutive loads (input = output index - shift, so
+// it may be misaligned: served by L1, the trick that made K1g fast); a thread scans its group,
+// waves scan the group totals with shuffles, wave totals go through LDS, the running carry stays
+// in a register.  Inputs that map outside the output range (at most one, when the trim is on the
+// side the scan starts from) seed the carry.  Re-associated sum => 1e-12 parity like K6.
+// ------------------------------------------------------------------------------------------
+template <int MET, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_cumsum_contig_vec(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 nrows, ScanArgs a,
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  __shared__ real wtot[2][WPB];
+  const u32 pb = (nrows + 7) >> 3;
+  const u32 row = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);  // XCD banding over rows
+  if (row >= nrows) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t n = g.n_in, no = g.n_out;
+  const real* prow = in + (int64_t)row * n;
+  real* orow = out + (int64_t)row * no;
+  int64_t mi_base = 0, mo_base = 0;
+  if (HAS_MI) mi_base = outer_off(g, mi, row);
+  if (HAS_MO) mo_base = outer_off(g, mo, row);
+  const int64_t shift = a.pad_lo - a.trim_lo;
+  auto fetch = [&](int64_t idx) -> real {  // weighted, NaN-cleaned input or 0 outside the row
+    if (idx < 0 || idx >= n) return real(0);
+    real v = prow[idx];
+    if (HAS_MI) v = v * m_in[mi_base + idx * mi.axis];
+    if (a.skipna) v = nan0(v);
+    return v;
+  };
+  // the one input (if any) that precedes everything in scan order but maps outside [0, no)
+  real carry = real(0);
+  if (!a.reverse && shift < 0) carry = fetch(0);
+  if (a.reverse && (n - 1 + shift) >= no) carry = fetch(n - 1);
+  const int64_t groups = no / NV;
+  int buf = 0;
+  auto group_lo = [&](int64_t t) -> int64_t { return a.reverse ? no - NV * (t + 1) : NV * t; };
+  real xn[NV];  // the next pass's inputs are loaded before this pass's scan and barrier
+#pragma unroll
+  for (int k = 0; k < NV; ++k) xn[k] = (tid < groups) ? fetch(group_lo(tid) + k - shift) : real(0);
+  for (int64_t base = 0; base < groups; base += BLOCK, buf ^= 1) {
+    const int64_t t = base + tid;
+    const bool act = t < groups;
+    const int64_t jlo = group_lo(t);
+    real x[NV], l[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) x[k] = xn[k];
+    {
+      const int64_t tn = t + BLOCK;
+      const int64_t jn = group_lo(tn);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) xn[k] = (tn < groups) ? fetch(jn + k - shift) : real(0);
+    }
+    if (!a.reverse) {
+      l[0] = x[0];
+#pragma unroll
+      for (int k = 1; k < NV; ++k) l[k] = l[k - 1] + x[k];
+    } else {
+      l[NV - 1] = x[NV - 1];
+#pragma unroll
+      for (int k = NV - 2; k >= 0; --k) l[k] = l[k + 1] + x[k];
+    }
+    const real mine = a.reverse ? l[0] : l[NV - 1];
+    real s = mine;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      real u = __shfl_up(s, d, WAVE);
+      if (lane >= d) s += u;
+    }
+    real excl = __shfl_up(s, 1, WAVE);
+    if (lane == 0) excl = real(0);
+    if (lane == WAVE - 1) wtot[buf][wv] = s;
+    __syncthreads();
+    real woff = real(0), tot = real(0);
+#pragma unroll
+    for (int i = 0; i < WPB; ++i) {
+      real u = wtot[buf][i];
+      if (i < wv) woff += u;
+      tot += u;
+    }
+    const real before = carry + (woff + excl);
+    carry += tot;
+    if (act) {
+      dv res;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) res[k] = before + l[k];
+      // halo cells (fill / extend only here): j = 0 and j = no - 1 sit next to a kept cell of the same group
+      if (a.pad_lo && jlo == 0) res[0] = (a.bc == XG_BC_FILL) ? (real)a.fill : res[1];
+      if (a.pad_hi && jlo + NV == no) res[NV - 1] = (a.bc == XG_BC_FILL) ? (real)a.fill : res[NV - 2];
+      if (HAS_MO) res = res / ldm<dv>(m_out, mo_base + jlo * mo.axis, mo.axis);
+      stg<dv, NTS>(orow + jlo, res);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K4: weighted sum along a STRIDED axis: one lane per output column pair, sequential in k
 // (bit-exact with numpy's reduction over a non-last axis).
 // ------------------------------------------------------------------------------------------
@@ -1544,7 +1644,15 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
   if (g.inner == 1) {
     const u64 nblocks = (u64)g.outer;
     if ((rc = check_grid(nblocks + 8))) return rc;
-    {
+    const bool periodic_halo = (pad_lo || pad_hi) && bc == XG_BC_PERIODIC;
+    if (tune().scan_vec && !periodic_halo && n_out % NV == 0 && n_out >= 2 * NV && aligned16(out) && nblocks < 0x7ffffff0ull) {
+      const u32 nrows = (u32)nblocks, grid = ((nrows + 7) / 8) * 8;
+      const bool nts = tune().nt_store;
+#define XG_M(M) do { if (nts) hipLaunchKernelGGL((k_cumsum_contig_vec<M, true>), dim3(grid), dim3(BLOCK), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo); \
+                     else hipLaunchKernelGGL((k_cumsum_contig_vec<M, false>), dim3(grid), dim3(BLOCK), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo); } while (0)
+      switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
+#undef XG_M
+    } else {
 #define XG_M(M) hipLaunchKernelGGL((k_cumsum_contig<M>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, a, m_in, mi, m_out, mo)
       switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
 #undef XG_M
