@@ -190,6 +190,7 @@ def main():
 
     # per-launch durations from the HIP events recorded on the launch stream inside the timed region
     per_op_ms = [float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(K)])) for i in range(len(OPS))]
+    step_ms = sorted(ev[k][0].elapsed_time(ev[k][len(OPS)]) for k in range(K))  # device time per step
     by_kernel = {}
     for (fn, ax), ms in zip(OPS, per_op_ms):
         by_kernel.setdefault(KERNEL_OF_AXIS[ax], []).append(ms)
@@ -229,6 +230,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
                          "per_op_ms": {f"{fn}_{ax}": round(ms, 4) for (fn, ax), ms in zip(OPS, per_op_ms)}},
+            "device_ms_per_step": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4),
+                                   "max": round(step_ms[-1], 4)},
             "parity_spot_check": parity,
         }
         if world == 1 and not args.no_cpu_baseline:
