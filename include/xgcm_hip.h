@@ -22,6 +22,8 @@
  *                      grid ufuncs xgcm/gridops.py:221-278
  *   xg_reduce1d_f64    xgcm/grid.py:1598-1605 (Grid.integrate: (da*weight).sum(dim))
  *   xg_pad_f64         xgcm/padding.py:765-871 (pad) for user grid-ufuncs of any width
+ *   xg_gather_f64      xgcm/padding.py:260-572 (_pad_face_connections) and :619-762 (_fold_north_halo,
+ *                      _pad_fold): halos of complex topologies as one gather through a token map
  *   xg_binary_f64      the xarray broadcasting `*`, `/`, `+`, `-` around the ops
  *                      (xgcm/grid.py:808,832,1578,1600; get_metric products :614-617)
  *   xg_stencil2d_f64   Grid.interp/diff/min/max over two axes (xgcm/grid.py:798-828), one pass
@@ -107,6 +109,24 @@ int xg_pad_f64(const double* in, double* out, const int64_t* shape, int ndim, co
                const int64_t* hi, const int* bc, const double* fill, const int* order,
                void* stream);
 
+/* ---- halo gather through a token map (north fold, face connections) --------------------- */
+/* `mapped[d]` marks the dims the padding procedure touches (face dim, the padded axes' dims);
+ * `tokens` holds one int64 per cell of the PADDED mapped dims (row-major, out dim order),
+ * shared by every index of the unmapped dims:
+ *     |t| in [1, 2^62):  source element k = |t| - 1, counted row-major over the mapped dims of
+ *                        `in` (k < P_in) or of `partner` (k - P_in, in partner's own dim order)
+ *     |t| >= 2^62:       fills[|t| - 2^62]
+ *     t < 0:             the value is negated (vector component across a fold / reversed link)
+ * Interior cells (lo[d] <= c[d] < lo[d] + in_shape[d] on every mapped dim) copy the input and
+ * never read the map.  `partner` (nullable) is the other vector component; its dim k
+ * corresponds to out dim partner_perm[k]; unmapped dims must agree in length.
+ * out_shape[d] == in_shape[d] on unmapped dims. */
+int xg_gather_f64(const double* in, const double* partner, double* out, const int64_t* in_shape,
+                  const int64_t* partner_shape, const int64_t* out_shape, int ndim,
+                  const int* mapped, const int* partner_perm, const int64_t* lo,
+                  const int64_t* tokens, int64_t n_tokens, const double* fills, int n_fills,
+                  void* stream);
+
 /* ---- broadcasting elementwise arithmetic ------------------------------------------------ */
 /* out[idx] = a[idx . a_strides] OP b[idx . b_strides] over `shape` (out C-contiguous). */
 int xg_binary_f64(int op, const double* a, const int64_t* a_strides, const double* b,
@@ -154,6 +174,11 @@ int xg_reduce1d_f32(const float* in, float* out, const int64_t* shape, int ndim,
                     int skipna, const float* w, const int64_t* w_strides, void* stream);
 int xg_pad_f32(const float* in, float* out, const int64_t* shape, int ndim, const int64_t* lo,
                const int64_t* hi, const int* bc, const float* fill, const int* order, void* stream);
+int xg_gather_f32(const float* in, const float* partner, float* out, const int64_t* in_shape,
+                  const int64_t* partner_shape, const int64_t* out_shape, int ndim,
+                  const int* mapped, const int* partner_perm, const int64_t* lo,
+                  const int64_t* tokens, int64_t n_tokens, const float* fills, int n_fills,
+                  void* stream);
 int xg_binary_f32(int op, const float* a, const int64_t* a_strides, const float* b,
                   const int64_t* b_strides, float* out, const int64_t* shape, int ndim,
                   void* stream);

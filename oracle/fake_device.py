@@ -58,6 +58,20 @@ def pad_nd(x, widths, bc, fill):
                     {k % x.ndim: (0.0 if v is None else v) for k, v in fill.items()})
 
 
+def upload_tokens(tokens):
+    return np.ascontiguousarray(tokens, dtype=np.int64)
+
+
+def gather(x, partner, tokens, mapped, lo, out_shape, fills, partner_perm=None):
+    from . import topology as T
+
+    if partner is not None:
+        x, partner = _cast(_common(x, partner), x, partner)
+    else:
+        x = asdevice(x)
+    return T.gather_tokens(x, partner, tokens, mapped, lo, out_shape, fills, partner_perm)
+
+
 def binary(op, a, b):
     a, b = _cast(_common(a, b), a, b)
     return R.binary(op, a, b)
@@ -90,7 +104,7 @@ def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None, dtype=np.f
     return R.synthetic(int(np.prod(shape)), seed, offset, scale, shift).reshape(tuple(shape)).astype(dtype)
 
 
-_NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "cumsum1d", "reduce1d", "pad_nd", "binary",
+_NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "cumsum1d", "reduce1d", "pad_nd", "gather", "upload_tokens", "binary",
           "vorticity", "stencil2d", "stencil2d_supported", "synthetic"]
 
 

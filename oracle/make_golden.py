@@ -16,7 +16,9 @@ xarray is re-implemented -- and then import the reference's own modules and exec
     were padded with ``numpy.pad`` (the routine ``DataArray.pad`` forwards to);
   * ``_GridUFuncSignature.from_string / equivalent / __str__`` (xgcm/grid_ufunc.py:147-301);
   * ``_select_grid_ufunc`` (xgcm/grid.py:1779-1824);
-  * ``iterate_axis_combinations`` (xgcm/metrics.py:4-30).
+  * ``iterate_axis_combinations`` (xgcm/metrics.py:4-30);
+  * the north-fold index helpers ``_seam_partner_indices``, ``_resolve_pivot`` and
+    ``_parse_fold_padding`` (xgcm/padding.py:94-177) -> ``fold_reference.json``.
 
 The xarray-level glue (apply_as_grid_ufunc, pad, Grid.cumsum ...) can NOT be executed; for
 it we transcribe the deterministic known-answer tests of the reference's own test-suite
@@ -437,6 +439,43 @@ def kats():
     return k
 
 
+def fold_cases():
+    """Outputs of the reference's own north-fold helpers (pure numpy / dict logic)."""
+    import xgcm.padding as P
+
+    seam = []
+    for position in ("center", "left", "right", "outer", "inner"):
+        for pivot_seam in ("edge", "center"):
+            for length in (3, 4, 5, 8, 9, 12):
+                seam.append({"position": position, "pivot_seam": pivot_seam, "length": length,
+                             "indices": P._seam_partner_indices(position, pivot_seam, length).tolist()})
+    pivots = []
+    for spec in ("center", "T", "t", "corner", "F", "U", "u", "V", {"X": "right", "Y": "center"},
+                 {"X": "left", "Y": "left"}, {"X": "right", "Y": "right"}, {"Y": "outer"}, {"X": "inner"},
+                 {"X": "center"}):
+        pivots.append({"pivot": spec, "fold_axis": "Y", "seam_axis": "X",
+                       "roles": P._resolve_pivot(spec, "Y", "X")})
+    bad_pivot = {"pivot": {"Z": "left"}, "fold_axis": "Y", "seam_axis": "X"}
+    try:
+        P._resolve_pivot(bad_pivot["pivot"], "Y", "X")
+    except Exception as exc:  # noqa: BLE001
+        bad_pivot["raises"] = type(exc).__name__
+        bad_pivot["message"] = str(exc)
+    pivots.append(bad_pivot)
+    parses = []
+    for spec in ({"fold": "corner"}, {"fold": "U", "south": "extend"}, {"fold": {"X": "left"}, "south": "periodic"},
+                 {"fold": "banana"}, {"fold": "corner", "north": 1}, {"fold": {}}, {"fold": {"X": "centre"}},
+                 {"fold": 3}, {"fold": "corner", "south": "wrap"}, {"south": "fill"}):
+        row = {"spec": spec}
+        try:
+            row["parsed"] = P._parse_fold_padding(spec)
+        except Exception as exc:  # noqa: BLE001
+            row["raises"] = type(exc).__name__
+            row["message"] = str(exc)
+        parses.append(row)
+    return {"seam_partner_indices": seam, "resolve_pivot": pivots, "parse_fold_padding": parses}
+
+
 def config1(gridops):
     """BASELINE.json configs[0]: Grid.diff along X on a 128 x 64 periodic C-grid (YC=64, XC=128), f64,
     center->left: the reference's own ufunc body on the numpy.pad(wrap)-ed synthetic field (seed 1)."""
@@ -464,6 +503,8 @@ def main():
         json.dump(metrics_cases(metrics), f, indent=1)
     with open(os.path.join(OUT, "kats.json"), "w") as f:
         json.dump(kats(), f, indent=1)
+    with open(os.path.join(OUT, "fold_reference.json"), "w") as f:
+        json.dump(fold_cases(), f, indent=1)
     print("wrote fixtures to", os.path.normpath(OUT))
 
 

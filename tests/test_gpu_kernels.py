@@ -173,6 +173,41 @@ def test_pad_matches_numpy_chain(dev):
         _eq(got, exp)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_gather_random_token_maps(dev, dtype):
+    """xg_gather vs the numpy decode of the token map (oracle/topology.py::gather_tokens): random
+    sources, signs, fill slots, a partner with permuted dims, mapped dims not trailing."""
+    from oracle import topology as T
+
+    rng = np.random.default_rng(7)
+    cases = [
+        # (in shape, mapped flags, lo, hi, partner shape or None, partner perm)
+        ((3, 4, 5), (False, True, True), (0, 1, 2), (0, 2, 1), None, None),
+        ((2, 6, 3, 4, 5), (False, True, False, True, True), (0, 0, 0, 1, 1), (0, 0, 0, 1, 0), None, None),
+        ((4, 5, 6), (True, True, True), (0, 2, 2), (0, 2, 2), (4, 6, 5), (0, 2, 1)),
+        ((3, 2, 4, 4), (False, True, True, True), (0, 0, 1, 1), (0, 0, 1, 1), (2, 4, 3, 4), (1, 2, 0, 3)),
+        ((7,), (True,), (3,), (4,), None, None),
+    ]
+    for shape, mapped, lo, hi, pshape, perm in cases:
+        x = _field(shape, 91).astype(dtype)
+        partner = None if pshape is None else _field(pshape, 92).astype(dtype)
+        out_shape = [n + (l + h if m else 0) for n, m, l, h in zip(shape, mapped, lo, hi)]
+        p_out = int(np.prod([n for n, m in zip(out_shape, mapped) if m]))
+        p_in = int(np.prod([n for n, m in zip(shape, mapped) if m]))
+        p_partner = 0
+        if partner is not None:
+            p_partner = int(np.prod([pshape[k] for k in range(len(pshape)) if mapped[perm[k]]]))
+        fills = [0.0, -7.25, float("nan")]
+        tok = rng.integers(1, p_in + p_partner + 1, size=p_out).astype(np.int64)
+        isf = rng.random(p_out) < 0.2
+        tok = np.where(isf, T.FILL_BASE + rng.integers(0, len(fills), size=p_out), tok)
+        tok = np.where(rng.random(p_out) < 0.3, -tok, tok)
+        want = T.gather_tokens(x, partner, tok, mapped, lo, out_shape, fills, perm)
+        got = dev.tohost(dev.gather(x, partner, tok, mapped, lo, out_shape, fills, perm))
+        assert got.dtype == dtype
+        _eq(got, want)
+
+
 def test_binary_broadcast(dev):
     a = _field((3, 4, 6, 10), 19)
     for op in ("mul", "div", "add", "sub"):

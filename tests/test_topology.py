@@ -1,0 +1,615 @@
+"""Complex topologies: north fold and face connections.
+
+* the reference's OWN helper outputs (tests/golden/fold_reference.json, written by
+  oracle/make_golden.py from xgcm/padding.py:94-177) pin both the oracle and the product helpers;
+* the known answers of the reference's tests (xgcm/test/test_fold.py, test_faceconnections.py,
+  test_padding.py:341-1205; file:line in each docstring) are restated with numpy and checked against
+  the oracle (oracle/topology.py) AND the product (`xgcm_amd.padding.pad`, Grid operators);
+* seeded sweeps compare product and oracle where the reference's tests use unseeded random data.
+
+Every product test runs twice through the `backend` fixture: on CPU with the oracle-backed device
+double (host logic + numpy decode of the token map) and, marked gpu, through `xg_gather_f64`.
+"""
+
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import refimpl as R
+from oracle import topology as T
+from xgcm_amd import DataArray, Dataset, Grid
+from xgcm_amd import halo_map as H
+from xgcm_amd.padding import _parse_fold_padding, _resolve_pivot, pad
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+with open(os.path.join(GOLDEN, "fold_reference.json")) as f:
+    FOLD_REF = json.load(f)
+
+Nx, Ny = 8, 5
+
+
+# ----------------------------------------------------------------------------------------------
+# reference helper outputs (golden) vs oracle and product
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("row", FOLD_REF["seam_partner_indices"],
+                         ids=lambda r: f"{r['position']}-{r['pivot_seam']}-{r['length']}")
+def test_seam_partner_indices_match_reference(row):
+    want = np.array(row["indices"])
+    np.testing.assert_array_equal(T.seam_partner(row["position"], row["pivot_seam"], row["length"]), want)
+    np.testing.assert_array_equal(H.seam_partner_indices(row["position"], row["pivot_seam"], row["length"]), want)
+
+
+@pytest.mark.parametrize("row", FOLD_REF["resolve_pivot"], ids=lambda r: str(r["pivot"]))
+def test_resolve_pivot_matches_reference(row):
+    if "raises" in row:
+        with pytest.raises(ValueError) as err:
+            _resolve_pivot(row["pivot"], row["fold_axis"], row["seam_axis"])
+        assert str(err.value) == row["message"]
+    else:
+        assert _resolve_pivot(row["pivot"], row["fold_axis"], row["seam_axis"]) == row["roles"]
+
+
+@pytest.mark.parametrize("row", FOLD_REF["parse_fold_padding"], ids=lambda r: str(r["spec"]))
+def test_parse_fold_padding_matches_reference(row):
+    if "raises" in row:
+        with pytest.raises(ValueError) as err:
+            _parse_fold_padding(row["spec"])
+        assert str(err.value) == row["message"]
+    else:
+        assert _parse_fold_padding(row["spec"]) == row["parsed"]
+
+
+# ----------------------------------------------------------------------------------------------
+# fold fixtures (xgcm/test/test_fold.py:24-73)
+# ----------------------------------------------------------------------------------------------
+def _fold_ds():
+    ds = Dataset(coords={"xh": np.arange(Nx), "xl": np.arange(Nx), "yh": np.arange(Ny), "yl": np.arange(Ny)})
+
+    def fld(dy, dx):
+        n = ds.dims[dy] * ds.dims[dx]
+        return DataArray(np.arange(n).reshape(ds.dims[dy], ds.dims[dx]).astype(float), dims=[dy, dx])
+
+    ds["c"] = fld("yh", "xh")
+    ds["u"] = fld("yh", "xl")
+    ds["v"] = fld("yl", "xh")
+    ds["q"] = fld("yl", "xl")
+    return ds
+
+
+def _fold_grid(ds, pivot):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        return Grid(ds, coords={"X": {"center": "xh", "left": "xl"}, "Y": {"center": "yh", "left": "yl"}},
+                    padding={"X": "periodic", "Y": {"fold": pivot}}, autoparse_metadata=False)
+
+
+def test_fold_grid_validation():
+    """test_fold.py:121-246: seam inference, ambiguity, bad pivots, fold + face connections."""
+    ds = _fold_ds()
+    with pytest.warns(UserWarning, match="experimental"):
+        grid = Grid(ds, coords={"X": {"center": "xh", "left": "xl"}, "Y": {"center": "yh", "left": "yl"}},
+                    padding={"X": "periodic", "Y": {"fold": "corner"}}, autoparse_metadata=False)
+    assert grid._folds["Y"]["seam_axis"] == "X"
+    with pytest.raises(ValueError, match="periodic seam axis"):
+        Grid(ds, coords={"X": {"center": "xh"}, "Y": {"center": "yh"}}, padding={"X": "fill", "Y": {"fold": "corner"}},
+             autoparse_metadata=False)
+    ds3 = _fold_ds()
+    ds3["zh"] = ("zh", np.arange(3))
+    coords3 = {"X": {"center": "xh", "left": "xl"}, "Y": {"center": "yh", "left": "yl"}, "Z": {"center": "zh"}}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        g3 = Grid(ds3, coords=coords3, padding={"X": "periodic", "Y": {"fold": "corner"}}, autoparse_metadata=False)
+    assert g3._folds["Y"]["seam_axis"] == "X" and "Z" not in g3._explicitly_periodic_axes
+    with pytest.raises(ValueError, match="ambiguous"):
+        Grid(ds3, coords=coords3, padding={"X": "periodic", "Z": "periodic", "Y": {"fold": "corner"}},
+             autoparse_metadata=False)
+    with pytest.raises(ValueError, match="Unknown fold pivot"):
+        _fold_grid(ds, "banana")
+    with pytest.raises(ValueError, match="Invalid position"):
+        _fold_grid(ds, {"X": "centre", "Y": "center"})
+    with pytest.raises(ValueError, match="Invalid position"):
+        _fold_grid(ds, {"X": "banana"})
+    dsf = Dataset(coords={"face": [0, 1], "xh": np.arange(Nx), "xl": np.arange(Nx), "yh": np.arange(Ny),
+                          "yl": np.arange(Ny)})
+    fc = {"face": {0: {"X": (None, (1, "X", False))}, 1: {"X": ((0, "X", False), None)}}}
+    with pytest.raises(NotImplementedError, match="face_connections"):
+        Grid(dsf, coords={"X": {"center": "xh", "left": "xl"}, "Y": {"center": "yh", "left": "yl"}},
+             padding={"X": "periodic", "Y": {"fold": "corner"}}, face_connections=fc, autoparse_metadata=False)
+
+
+def test_corner_pivot_all_positions(backend):
+    """test_fold.py:285-318 (explicit expected halos, vector sign flip)."""
+    ds = _fold_ds()
+    grid = _fold_grid(ds, "corner")
+    c, u, v, q = (ds[k].values for k in "cuvq")
+    out = pad(ds.c, grid, padding_width={"Y": (0, 1)})
+    np.testing.assert_array_equal(out.values[-1], c[-1][::-1])
+    assert out.dims == ("yh", "xh") and out.shape == (Ny + 1, Nx)
+    out = pad({"X": ds.u}, grid, padding_width={"Y": (0, 1)}, other_component={"Y": ds.v})
+    np.testing.assert_array_equal(out.values[-1], -np.roll(u[-1][::-1], 1))
+    out = pad({"Y": ds.v}, grid, padding_width={"Y": (0, 1)}, other_component={"X": ds.u})
+    np.testing.assert_array_equal(out.values[-1], -v[-2][::-1])
+    out = pad(ds.q, grid, padding_width={"Y": (0, 1)})
+    np.testing.assert_array_equal(out.values[-1], np.roll(q[-2][::-1], 1))
+    np.testing.assert_array_equal(out.values[:-1], q)
+
+
+def test_u_pivot_redundant_row(backend):
+    """test_fold.py:321-337."""
+    ds = _fold_ds()
+    grid = _fold_grid(ds, "U")
+    np.testing.assert_array_equal(pad(ds.c, grid, padding_width={"Y": (0, 1)}).values[-1], ds.c.values[-2][::-1])
+    np.testing.assert_array_equal(pad(ds.v, grid, padding_width={"Y": (0, 1)}).values[-1], ds.v.values[-1][::-1])
+
+
+def test_center_and_edge_mirror_same_pole(backend):
+    """test_fold.py:345-376: centre- and edge-staggered fields fold about one physical pole."""
+    F = lambda x: np.sin(2 * np.pi * x / Nx) + 0.3 * np.cos(6 * np.pi * x / Nx)  # noqa: E731
+    xc, xe = np.arange(Nx) + 0.5, np.arange(Nx).astype(float)
+    ds = Dataset(coords={"xh": np.arange(Nx), "xl": np.arange(Nx), "yh": np.arange(Ny)})
+    ds["c"] = (("yh", "xh"), np.tile(F(xc), (Ny, 1)))
+    ds["u"] = (("yh", "xl"), np.tile(F(xe), (Ny, 1)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        grid = Grid(ds, coords={"X": {"center": "xh", "left": "xl"}, "Y": {"center": "yh"}},
+                    padding={"X": "periodic", "Y": {"fold": "corner"}}, autoparse_metadata=False)
+    np.testing.assert_allclose(pad(ds.c, grid, padding_width={"Y": (0, 1)}).values[-1], F((-xc) % Nx), atol=1e-12)
+    np.testing.assert_allclose(pad(ds.u, grid, padding_width={"Y": (0, 1)}).values[-1], F((-xe) % Nx), atol=1e-12)
+
+
+def test_outer_symmetric_memory(backend):
+    """test_fold.py:379-418: `outer` (N+1) dims with the duplicated periodic endpoint."""
+    F = lambda x, y: np.sin(2 * np.pi * x / Nx) + 0.5 * y  # noqa: E731
+    xq, yq = np.arange(Nx + 1), np.arange(Ny + 1)
+    ds = Dataset(coords={"xh": np.arange(Nx), "xq": xq, "yh": np.arange(Ny), "yq": yq})
+    ds["q"] = (("yq", "xq"), F(xq[None, :], yq[:, None]))
+    ds["v"] = (("yq", "xh"), F((np.arange(Nx) + 0.5)[None, :], yq[:, None]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        grid = Grid(ds, coords={"X": {"center": "xh", "outer": "xq"}, "Y": {"center": "yh", "outer": "yq"}},
+                    padding={"X": "periodic", "Y": {"fold": "corner"}}, autoparse_metadata=False)
+    xc = np.arange(Nx) + 0.5
+    np.testing.assert_allclose(pad(ds.v, grid, padding_width={"Y": (0, 1)}).values[-1], F((-xc) % Nx, Ny - 1), atol=1e-12)
+    np.testing.assert_allclose(pad(ds.q, grid, padding_width={"Y": (0, 1)}).values[-1],
+                               np.array([F((-j) % Nx, Ny - 1) for j in range(Nx + 1)]), atol=1e-12)
+
+
+def test_vector_flips_scalar_does_not(backend):
+    """test_fold.py:424-441."""
+    ds = _fold_ds()
+    grid = _fold_grid(ds, "corner")
+    scal = pad(ds.v, grid, padding_width={"Y": (0, 1)}).values[-1]
+    vec = pad({"Y": ds.v}, grid, padding_width={"Y": (0, 1)}, other_component={"X": ds.u}).values[-1]
+    np.testing.assert_array_equal(vec, -scal)
+
+
+def test_interp_diff_across_seam_known_answer(backend):
+    """test_fold.py:446-506: operators (not just pad) across the seam, scalar and vector."""
+    ds = _fold_ds()
+    v, q = ds.v.values, ds.q.values
+
+    def straddle(field, halo):
+        fp = np.vstack([field, halo[None, :]])
+        return 0.5 * (fp[:-1] + fp[1:]), fp[1:] - fp[:-1]
+
+    grid = _fold_grid(ds, "corner")
+    d = grid.diff(ds.q, "Y")
+    assert d.dims == ("yh", "xl") and np.isfinite(d.values).all()
+    exp_i, exp_d = straddle(v, v[-2][::-1])
+    np.testing.assert_array_equal(grid.interp(ds.v, "Y").values, exp_i)
+    np.testing.assert_array_equal(grid.diff(ds.v, "Y").values, exp_d)
+    exp_i, exp_d = straddle(v, -v[-2][::-1])
+    oc = {"X": ds.u}
+    np.testing.assert_array_equal(grid.interp({"Y": ds.v}, "Y", other_component=oc).values, exp_i)
+    np.testing.assert_array_equal(grid.diff({"Y": ds.v}, "Y", other_component=oc).values, exp_d)
+    exp_i, exp_d = straddle(q, np.roll(q[-2][::-1], 1))
+    np.testing.assert_array_equal(grid.interp(ds.q, "Y").values, exp_i)
+    np.testing.assert_array_equal(grid.diff(ds.q, "Y").values, exp_d)
+    gridU = _fold_grid(ds, "U")
+    exp_i, exp_d = straddle(v, v[-1][::-1])
+    np.testing.assert_array_equal(gridU.interp(ds.v, "Y").values, exp_i)
+    np.testing.assert_array_equal(gridU.diff(ds.v, "Y").values, exp_d)
+    # the seam axis itself stays on the fused kernel path and is an ordinary periodic diff
+    np.testing.assert_array_equal(grid.diff(ds.c, "X").values, ds.c.values - np.roll(ds.c.values, 1, axis=1))
+
+
+def test_fold_south_edge_and_multi_row_and_errors(backend):
+    """test_fold.py:509-581: per-call south override, two halo rows, too-wide halo, inner seam."""
+    ds = _fold_ds()
+    grid = _fold_grid(ds, "corner")
+    c = ds.c.values
+    out = pad(ds.c, grid, padding_width={"Y": (1, 1)}, padding={"Y": "extend"}).values
+    np.testing.assert_array_equal(out[0], c[0])
+    np.testing.assert_array_equal(out[-1], c[-1][::-1])
+    np.testing.assert_array_equal(pad(ds.c, grid, padding_width={"Y": (1, 0)}).values[0], 0.0)
+    out = pad(ds.c, grid, padding_width={"Y": (0, 2)}).values
+    np.testing.assert_array_equal(out[-2], c[-1][::-1])
+    np.testing.assert_array_equal(out[-1], c[-2][::-1])
+    assert pad(ds.c, grid, padding_width={"Y": (0, Ny)}).shape[0] == 2 * Ny
+    with pytest.raises(ValueError, match="exceeds the .* interior row"):
+        pad(ds.c, grid, padding_width={"Y": (0, Ny + 1)})
+    out = pad(ds.c, grid, padding_width={"X": (1, 1), "Y": (0, 1)}).values
+    assert out.shape == (Ny + 1, Nx + 2)
+    base = c[-1][::-1]
+    np.testing.assert_array_equal(out[-1], np.concatenate([[base[-1]], base, [base[0]]]))
+    for pivot in ("center", "V"):  # test_fold.py:249-279
+        dsi = Dataset(coords={"xh": np.arange(Nx), "xi": np.arange(Nx - 1), "yh": np.arange(Ny), "yl": np.arange(Ny)})
+        dsi["f"] = (("yl", "xi"), np.zeros((Ny, Nx - 1)))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", UserWarning)
+            g = Grid(dsi, coords={"X": {"center": "xh", "inner": "xi"}, "Y": {"center": "yh", "left": "yl"}},
+                     padding={"X": "periodic", "Y": {"fold": pivot}}, autoparse_metadata=False)
+        with pytest.raises(NotImplementedError, match="incompatible"):
+            pad(dsi.f, g, padding_width={"Y": (0, 1)})
+
+
+@pytest.mark.parametrize("pivot", ["corner", "center", "U", "V"])
+@pytest.mark.parametrize("name", ["c", "u", "v", "q"])
+@pytest.mark.parametrize("widths", [{"Y": (0, 1)}, {"Y": (1, 2)}, {"X": (2, 1), "Y": (1, 1)}, {"Y": (0, 2), "X": (0, 1)}])
+def test_fold_product_equals_oracle_seeded(backend, pivot, name, widths):
+    """Seeded (time, z, Y, X) fields: product (token map + gather) == oracle (explicit loops)."""
+    dims = {"c": ("yh", "xh"), "u": ("yh", "xl"), "v": ("yl", "xh"), "q": ("yl", "xl")}[name]
+    ds = _fold_ds()
+    a = R.synthetic_field((2, 3, Ny, Nx), 71)
+    da = DataArray(a, dims=("time", "z") + dims)
+    grid = _fold_grid(ds, pivot)
+    pos = {"X": "center" if dims[1] == "xh" else "left", "Y": "center" if dims[0] == "yh" else "left"}
+    for isvector in (False, True):
+        arg = {("X" if name == "u" else "Y"): da} if isvector else da
+        got = pad(arg, grid, padding_width=dict(widths), fill_value={"X": 0.0, "Y": -7.5})
+        want = T.pad_fold(a, {"X": 3, "Y": 2}, pos, "Y", "X", _resolve_pivot(pivot, "Y", "X"), "fill", widths,
+                          {"X": "periodic", "Y": None}, {"X": 0.0, "Y": -7.5}, isvector)
+        np.testing.assert_array_equal(got.values, want)
+        assert got.dims == da.dims
+
+
+# ----------------------------------------------------------------------------------------------
+# face connections
+# ----------------------------------------------------------------------------------------------
+N = 6
+X_TO_X = {"face": {0: {"X": (None, (1, "X", False))}, 1: {"X": ((0, "X", False), None)}}}
+X_TO_Y = {"face": {0: {"X": (None, (1, "Y", False))}, 1: {"Y": ((0, "X", False), None)}}}
+X_TO_Y_REV = {"face": {0: {"X": (None, (1, "Y", True))}, 1: {"Y": (None, (0, "X", True))}}}
+X_TO_X_REV = {"face": {0: {"X": (None, (1, "X", True))}, 1: {"X": (None, (0, "X", True))}}}
+CUBED_SPHERE = {
+    "face": {
+        0: {"X": ((3, "X", False), (1, "X", False)), "Y": ((4, "Y", False), (5, "Y", False))},
+        1: {"X": ((0, "X", False), (2, "X", False)), "Y": ((4, "X", False), (5, "X", True))},
+        2: {"X": ((1, "X", False), (3, "X", False)), "Y": ((4, "Y", True), (5, "Y", True))},
+        3: {"X": ((2, "X", False), (0, "X", False)), "Y": ((4, "X", True), (5, "X", False))},
+        4: {"X": ((3, "Y", True), (1, "Y", False)), "Y": ((2, "Y", True), (0, "Y", False))},
+        5: {"X": ((3, "Y", False), (1, "Y", True)), "Y": ((0, "Y", False), (2, "Y", True))},
+    }
+}
+COORDS = {"X": {"center": "x", "left": "xl"}, "Y": {"center": "y", "left": "yl"}}
+
+
+def _faces_ds(nf=2, n=N, seed=5):
+    """Seeded analogue of test_faceconnections.py:9-37 (u on (face, xl, y), v on (face, x, yl))."""
+    rnd = lambda s: R.synthetic_field((nf, n, n), seed + s) + 0.5  # noqa: E731
+    return Dataset(
+        {"data_c": (["face", "y", "x"], rnd(0)), "u": (["face", "xl", "y"], rnd(1)), "v": (["face", "x", "yl"], rnd(2))},
+        coords={"x": np.arange(n), "xl": np.arange(n) - 0.5, "y": np.arange(n), "yl": np.arange(n) - 0.5,
+                "face": np.arange(nf)},
+    )
+
+
+def test_create_connected_grid_and_errors():
+    """test_faceconnections.py:134-161 + grid.py:334-409 consistency checks."""
+    ds = _faces_ds()
+    grid = Grid(ds, coords=COORDS, face_connections=X_TO_X, autoparse_metadata=False)
+    xaxis = grid.axes["X"]
+    assert xaxis._facedim == "face"
+    assert xaxis._face_connections[0][1][0] == 1 and xaxis._face_connections[0][1][1] is xaxis
+    assert xaxis._face_connections[1][0][0] == 0 and xaxis._face_connections[1][0][1] is xaxis
+    bad = Dataset({"data_c": (["tile", "y", "x"], np.zeros((2, N, N)))}, coords={"x": np.arange(N), "xl": np.arange(N),
+                                                                                   "y": np.arange(N), "yl": np.arange(N)})
+    with pytest.raises(ValueError, match="Face dimension face does not exist in the dataset."):
+        Grid(bad, coords=COORDS, face_connections=X_TO_X, autoparse_metadata=False)
+    with pytest.raises(ValueError, match="Face link mismatch"):
+        Grid(ds, coords=COORDS, autoparse_metadata=False,
+             face_connections={"face": {0: {"X": (None, (1, "X", False))}, 1: {"X": ((0, "X", True), None)}}})
+    with pytest.raises(KeyError, match="Couldn't find a face link"):
+        Grid(ds, coords=COORDS, autoparse_metadata=False, face_connections={"face": {0: {"X": (None, (1, "X", False))}}})
+    Grid(_faces_ds(6), coords=COORDS, face_connections=CUBED_SPHERE, autoparse_metadata=False)  # :406-407
+
+
+def test_diff_interp_connected_grid_x_to_x(backend):
+    """test_faceconnections.py:164-180."""
+    ds = _faces_ds()
+    c = ds.data_c.values
+    grid = Grid(ds, coords=COORDS, face_connections=X_TO_X, padding="fill", autoparse_metadata=False)
+    diff_x = grid.diff(ds.data_c, "X", padding="fill").values
+    interp_x = grid.interp(ds.data_c, "X", padding="fill").values
+    np.testing.assert_array_equal(diff_x[1, :, 0], c[1, :, 0] - c[0, :, -1])
+    np.testing.assert_array_equal(interp_x[1, :, 0], 0.5 * (c[1, :, 0] + c[0, :, -1]))
+    np.testing.assert_array_equal(diff_x[0, :, 0], c[0, :, 0] - 0.0)
+    np.testing.assert_array_equal(interp_x[0, :, 0], 0.5 * (c[0, :, 0] + 0.0))
+    np.testing.assert_array_equal(diff_x[:, :, 1:], c[:, :, 1:] - c[:, :, :-1])
+
+
+def test_diff_interp_connected_grid_x_to_y(backend):
+    """test_faceconnections.py:183-202: a rotated connection."""
+    ds = _faces_ds()
+    c = ds.data_c.values
+    grid = Grid(ds, coords=COORDS, face_connections=X_TO_Y, autoparse_metadata=False)
+    diff_y = grid.diff(ds.data_c, "Y", padding="fill").values
+    interp_y = grid.interp(ds.data_c, "Y", padding="fill").values
+    np.testing.assert_array_equal(diff_y[1, 0, :], c[1, 0, :] - c[0, ::-1, -1])
+    np.testing.assert_array_equal(interp_y[1, 0, :], 0.5 * (c[1, 0, :] + c[0, ::-1, -1]))
+
+
+@pytest.mark.parametrize("padding", ["periodic", "fill"])
+def test_vector_connected_grid_x_to_y(backend, padding):
+    """test_faceconnections.py:205-230: the sign change of the rotated vector component."""
+    ds = _faces_ds()
+    grid = Grid(ds, coords=COORDS, face_connections=X_TO_Y, padding=padding, fill_value=1, autoparse_metadata=False)
+    u = DataArray(np.broadcast_to(np.array([-2.0, -1.0])[:, None, None], (2, N, N)).copy(), dims=("face", "xl", "y"))
+    v = DataArray(np.ones((2, N, N)), dims=("face", "x", "yl"))
+    v_out = grid.interp({"Y": v}, "X", other_component={"X": u})
+    np.testing.assert_array_equal(v_out.values, 1.0)
+
+
+def test_vector_diff_interp_connected_grid_x_to_y(backend):
+    """test_faceconnections.py:233-293 (interp_2d_vector / diff_2d_vector)."""
+    ds = _faces_ds()
+    u, v = ds.u.values, ds.v.values
+    grid = Grid(ds, coords=COORDS, face_connections=X_TO_Y, autoparse_metadata=False)
+    with pytest.warns(DeprecationWarning):
+        vc = grid.interp_2d_vector({"X": ds.u, "Y": ds.v}, to="center", padding="fill", fill_value=100)
+    with pytest.warns(DeprecationWarning):
+        vd = grid.diff_2d_vector({"X": ds.u, "Y": ds.v}, to="center", padding="fill", fill_value=100)
+    ui, ud = vc["X"].values, vd["X"].values
+    np.testing.assert_array_equal(ui[0, 0, :], 0.5 * (u[0, 0, :] + u[0, 1, :]))
+    np.testing.assert_array_equal(ud[0, 0, :], u[0, 1, :] - u[0, 0, :])
+    np.testing.assert_array_equal(ui[0, -1, :], 0.5 * (u[0, -1, :] + v[1, ::-1, 0]))
+    np.testing.assert_array_equal(ud[0, -1, :], -u[0, -1, :] + v[1, ::-1, 0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        with pytest.raises(NotImplementedError):
+            grid.interp_2d_vector({"X": ds.v, "Y": ds.u}, to="left", padding="fill")
+        with pytest.raises(NotImplementedError):
+            grid.interp_2d_vector({"X": ds.v, "Y": ds.u}, padding="fill")
+
+
+def test_diff_interp_cubed_sphere(backend):
+    """test_faceconnections.py:410-428: fully connected, no boundary condition needed."""
+    cs = _faces_ds(6)
+    grid = Grid(cs, coords=COORDS, face_connections=CUBED_SPHERE, autoparse_metadata=False)
+    face = DataArray(np.broadcast_to(np.arange(6.0)[:, None, None], (6, N, N)).copy(), dims=("face", "y", "x"))
+    dx = grid.diff(face, "X").values
+    np.testing.assert_array_equal(dx[:, 0, 0], [-3, 1, 1, 1, 1, 2])
+    np.testing.assert_array_equal(dx[:, -1, 0], [-3, 1, 1, 1, 1, 2])
+    dy = grid.diff(face, "Y").values
+    np.testing.assert_array_equal(dy[:, 0, 0], [-4, -3, -2, -1, 2, 5])
+    np.testing.assert_array_equal(dy[:, 0, -1], [-4, -3, -2, -1, 2, 5])
+    np.testing.assert_array_equal(grid.interp(face, "X").values[:, 0, 0], [1.5, 0.5, 1.5, 2.5, 3.5, 4.0])
+
+
+def test_unconnected_edge_without_boundary_raises(backend):
+    """test_faceconnections.py:431-442."""
+    ds = _faces_ds()
+    grid = Grid(ds, coords=COORDS, face_connections=X_TO_X, autoparse_metadata=False)
+    with pytest.raises(ValueError, match="No boundary condition was specified"):
+        grid.diff(ds.data_c, "X")
+    grid.diff(ds.data_c, "X", padding="fill")
+
+
+def test_cubed_sphere_scalar_pad_connected_halos(backend):
+    """test_faceconnections.py:445-478: every connected halo cell reads the declared neighbour."""
+    cs = _faces_ds(6)
+    grid = Grid(cs, coords=COORDS, face_connections=CUBED_SPHERE, autoparse_metadata=False)
+    face = DataArray(np.broadcast_to(np.arange(6.0)[:, None, None], (6, N, N)).copy(), dims=("face", "y", "x"))
+    padded = pad(face, grid, {"X": (1, 1), "Y": (1, 1)}, padding={"X": "fill", "Y": "fill"}, fill_value=np.nan).values
+    assert padded.shape == (6, N + 2, N + 2)
+    for f in range(6):
+        (left_x, right_x), (down_y, up_y) = CUBED_SPHERE["face"][f]["X"], CUBED_SPHERE["face"][f]["Y"]
+        np.testing.assert_array_equal(padded[f, 1:-1, 0], left_x[0])
+        np.testing.assert_array_equal(padded[f, 1:-1, -1], right_x[0])
+        np.testing.assert_array_equal(padded[f, 0, 1:-1], down_y[0])
+        np.testing.assert_array_equal(padded[f, -1, 1:-1], up_y[0])
+
+
+def test_vector_missing_other_component(backend):
+    """test_faceconnections.py:481-490."""
+    ds = _faces_ds()
+    grid = Grid(ds, coords=COORDS, face_connections=X_TO_Y, autoparse_metadata=False)
+    with pytest.raises(ValueError, match="Padding vector components requires `other_component` input"):
+        grid.diff({"X": ds.u}, "X", other_component=None)
+
+
+# -- test_padding.py:341-615 scalar expectations, restated with numpy ------------------------------
+WIDTHS = [{"X": (1, 1)}, {"X": (1, 2)}, {"X": (0, 1)}, {"X": (1, 1), "Y": (1, 1)}, {"X": (2, 2), "Y": (2, 2)},
+          {"X": (0, 1), "Y": (1, 0)}, {"X": (0, 2), "Y": (1, 0)}]
+
+
+def _cpad(a, y, x, fv):
+    """numpy form of `face.pad(x=..., y=..., mode="constant", constant_values=fv)` on (y, x) faces."""
+    return np.pad(a, [tuple(y), tuple(x)], mode="constant", constant_values=fv)
+
+
+@pytest.mark.parametrize("fv", [np.nan, 0.0])
+@pytest.mark.parametrize("pw", WIDTHS)
+def test_face_connections_scalar_expected_values(backend, pw, fv):
+    """test_padding.py:343-615: right->left / right->right, same axis and swapped axis."""
+    pw = {"X": pw["X"], "Y": pw.get("Y", (0, 0))}
+    (xl, xr), (yl, yr) = pw["X"], pw["Y"]
+    ds = _faces_ds(2, 5)
+    a = ds.data_c.values
+    f0, f1 = a[0], a[1]
+
+    def run(conn, data=ds.data_c):
+        grid = Grid(ds, coords=COORDS, face_connections=conn, autoparse_metadata=False)
+        return pad(data, grid, padding_width=dict(pw), padding="fill", fill_value=fv).values
+
+    # right edge of face 0 -> left edge of face 1, same axis (:343-396)
+    p0, p1 = _cpad(f0, (yl, yr), (xl, 0), fv), _cpad(f1, (yl, yr), (0, xr), fv)
+    want = np.stack([np.concatenate([p0, p1[:, :xr]], axis=1),
+                     np.concatenate([p0[:, p0.shape[1] - xl:], p1], axis=1)])
+    np.testing.assert_array_equal(run(X_TO_X), want)
+    # right edge of face 0 <-> right edge of face 1, reversed (:398-460)
+    p0, p1 = _cpad(f0, (yl, yr), (xl, 0), fv), _cpad(f1, (yl, yr), (xl, 0), fv)
+    add0 = p1[:, p1.shape[1] - xr:][:, ::-1]
+    add1 = p0[:, p0.shape[1] - xr:][:, ::-1]
+    want = np.stack([np.concatenate([p0, add0], axis=1), np.concatenate([p1, add1], axis=1)])
+    np.testing.assert_array_equal(run(X_TO_X_REV), want)
+
+
+@pytest.mark.parametrize("fv", [np.nan, 0.0])
+@pytest.mark.parametrize("pw", WIDTHS)
+def test_face_connections_scalar_swap_axis_expected_values(backend, pw, fv):
+    """test_padding.py:462-615: X edge of face 0 connected to a Y edge of face 1."""
+    pw = {"X": pw["X"], "Y": pw.get("Y", (0, 0))}
+    (xl, xr), (yl, yr) = pw["X"], pw["Y"]
+    ds = _faces_ds(2, 3)
+    a = ds.data_c.values
+    f0, f1 = a[0], a[1]
+
+    def run(conn):
+        grid = Grid(ds, coords=COORDS, face_connections=conn, autoparse_metadata=False)
+        return pad(ds.data_c, grid, padding_width=dict(pw), padding="fill", fill_value=fv).values
+
+    # right-left, swapped (:462-535): faces padded "as the other axis sees them", then rotated
+    p0 = _cpad(f0, (yl, yr), (xl, 0), fv)
+    p1 = _cpad(f1, (0, yr), (xl, xr), fv)
+    p0s = _cpad(f0, (xr, xl), (yl, 0), fv)
+    p1s = _cpad(f1, (0, xr), (yr, yl), fv)
+    add0 = p1s[:xr, :][:, ::-1].T          # rows of face 1 -> columns of face 0, flipped along x
+    add1 = p0s[:, p0s.shape[1] - yl:][::-1, :].T
+    want0 = np.concatenate([p0, add0], axis=1)
+    want1 = np.concatenate([add1, p1], axis=0)
+    got = run(X_TO_Y)
+    np.testing.assert_array_equal(got[0], want0)
+    np.testing.assert_array_equal(got[1], want1)
+    # right-right, swapped and reversed (:537-615)
+    p0 = _cpad(f0, (yl, yr), (xl, 0), fv)
+    p1 = _cpad(f1, (yl, 0), (xl, xr), fv)
+    p0s = _cpad(f0, (xl, xr), (yl, 0), fv)
+    p1s = _cpad(f1, (xl, 0), (yl, yr), fv)
+    add0 = p1s[p1s.shape[0] - xr:, :][::-1, :].T
+    add1 = p0s[:, p0s.shape[1] - yr:][:, ::-1].T
+    got = run(X_TO_Y_REV)
+    np.testing.assert_array_equal(got[0], np.concatenate([p0, add0], axis=1))
+    np.testing.assert_array_equal(got[1], np.concatenate([p1, add1], axis=0))
+
+
+@pytest.mark.parametrize("fv", [np.nan, 0.0])
+@pytest.mark.parametrize("pw", WIDTHS)
+def test_vector_face_connections_right_left_swap_axis_expected_values(backend, pw, fv):
+    """test_padding.py:824-937: vector components across a rotated connection -- the halo of u comes
+    from v (tangential flip, no sign change on face 0, sign change on face 1) and vice versa."""
+    pw = {"X": pw["X"], "Y": pw.get("Y", (0, 0))}
+    (X0, X1), (Y0, Y1) = pw["X"], pw["Y"]
+    ds = _faces_ds(2, 4, seed=41)
+    u, v = ds.u.values, ds.v.values  # (face, xl, y) and (face, x, yl): axis 0 = X dim, axis 1 = Y dim
+    cp = lambda a, x, y: np.pad(a, [tuple(x), tuple(y)], mode="constant", constant_values=fv)  # noqa: E731
+
+    def prepad(a):
+        return (cp(a[0], (X0, 0), (Y0, Y1)), cp(a[1], (X0, X1), (0, Y1)),
+                cp(a[0], (Y0, 0), (X1, X0)), cp(a[1], (Y1, Y0), (0, X1)))
+
+    u0, u1, u0s, u1s = prepad(u)
+    v0, v1, v0s, v1s = prepad(v)
+    u0_add = v1s[:, :X1][::-1, :].T                       # tangential flip, then (y, xl) -> (xl, y)
+    u1_add = (-v0s[v0s.shape[0] - Y0:, :][:, ::-1]).T
+    v0_add = (-u1s[:, :X1][::-1, :]).T
+    v1_add = u0s[u0s.shape[0] - Y0:, :][:, ::-1].T
+    u_want = np.stack([np.concatenate([u0, u0_add], axis=0), np.concatenate([u1_add, u1], axis=1)])
+    v_want = np.stack([np.concatenate([v0, v0_add], axis=0), np.concatenate([v1_add, v1], axis=1)])
+    grid = Grid(ds, coords=COORDS, face_connections=X_TO_Y, autoparse_metadata=False)
+    u_got = pad({"X": ds.u}, grid, padding_width=dict(pw), padding="fill", fill_value=fv, other_component={"Y": ds.v})
+    v_got = pad({"Y": ds.v}, grid, padding_width=dict(pw), padding="fill", fill_value=fv, other_component={"X": ds.u})
+    np.testing.assert_array_equal(u_got.values, u_want)
+    np.testing.assert_array_equal(v_got.values, v_want)
+
+
+# -- seeded sweeps: product vs oracle --------------------------------------------------------------
+def _oracle_faces(ds, name, conn, pw, padding, fill, vector=None):
+    da = ds[name]
+    dims = da.dims
+    pos_dims = {"X": [d for d in ("x", "xl") if d in dims][0], "Y": [d for d in ("y", "yl") if d in dims][0]}
+    pad_axes = [ax for ax in ("X", "Y")]
+    kw = {}
+    if vector is not None:
+        other = ds[vector[1]]
+        kw = dict(partner=other.values, partner_dims=other.dims, vectoraxis=vector[0],
+                  partner_axis_dim={"X": [d for d in ("x", "xl") if d in other.dims][0],
+                                    "Y": [d for d in ("y", "yl") if d in other.dims][0]})
+    return T.pad_face_connections(da.values, dims, "face", pos_dims, conn["face"], pad_axes, pw, padding, fill, **kw)
+
+
+@pytest.mark.parametrize("conn", [X_TO_X, X_TO_Y, X_TO_Y_REV, X_TO_X_REV, CUBED_SPHERE],
+                         ids=["x2x", "x2y", "x2y_rev", "x2x_rev", "cubed_sphere"])
+@pytest.mark.parametrize("pw", [{"X": (1, 1)}, {"X": (0, 1), "Y": (1, 0)}, {"X": (2, 2), "Y": (2, 2)}, {"Y": (1, 2)}])
+@pytest.mark.parametrize("mode", ["fill", "extend", "periodic"])
+def test_face_connections_product_equals_oracle_scalar(backend, conn, pw, mode):
+    nf = 6 if conn is CUBED_SPHERE else 2
+    ds = _faces_ds(nf, 5, seed=11)
+    grid = Grid(ds, coords=COORDS, face_connections=conn, autoparse_metadata=False)
+    fill = {"X": 3.25, "Y": -1.5}
+    got = pad(ds.data_c, grid, padding_width=dict(pw), padding=mode, fill_value=fill)
+    want = _oracle_faces(ds, "data_c", conn, pw, {"X": mode, "Y": mode}, fill)
+    np.testing.assert_array_equal(got.values, want)
+    assert got.dims == ds.data_c.dims
+
+
+@pytest.mark.parametrize("conn", [X_TO_X, X_TO_Y, X_TO_Y_REV, X_TO_X_REV, CUBED_SPHERE],
+                         ids=["x2x", "x2y", "x2y_rev", "x2x_rev", "cubed_sphere"])
+@pytest.mark.parametrize("pw", [{"X": (1, 1)}, {"X": (0, 1), "Y": (1, 0)}, {"X": (2, 2), "Y": (2, 2)}])
+@pytest.mark.parametrize("component", ["u", "v"])
+def test_face_connections_product_equals_oracle_vector(backend, conn, pw, component):
+    """Vector components (dict and bare form): rotation picks the partner, reversal flips signs."""
+    nf = 6 if conn is CUBED_SPHERE else 2
+    ds = _faces_ds(nf, 5, seed=23)
+    grid = Grid(ds, coords=COORDS, face_connections=conn, autoparse_metadata=False)
+    ax, other, oax = ("X", "v", "Y") if component == "u" else ("Y", "u", "X")
+    fill = {"X": 100.0, "Y": 100.0}
+    want = _oracle_faces(ds, component, conn, pw, {"X": "fill", "Y": "fill"}, fill, vector=(ax, other))
+    got = pad({ax: ds[component]}, grid, padding_width=dict(pw), padding="fill", fill_value=fill,
+              other_component={oax: ds[other]})
+    np.testing.assert_array_equal(got.values, want)
+    bare = pad(ds[component], grid, padding_width=dict(pw), padding="fill", fill_value=fill,
+               other_component={oax: ds[other]})   # test_padding.py:939-1003
+    np.testing.assert_array_equal(bare.values, want)
+
+
+def test_bare_vector_pad_ambiguous_axis_raises(backend):
+    """test_padding.py:1005-1037."""
+    ds = _faces_ds()
+    grid = Grid(ds, coords=COORDS, face_connections=X_TO_Y, autoparse_metadata=False)
+    with pytest.raises(ValueError, match="Could not unambiguously infer"):
+        pad(ds.data_c, grid, padding_width={"X": (1, 1)}, padding="fill", other_component={"Y": ds.v})
+
+
+def test_faces_with_leading_and_interleaved_dims(backend):
+    """(time, face, z, y, x): only (face, y, x) are mapped; time and z ride along."""
+    ds = _faces_ds(6, 4, seed=31)
+    grid = Grid(ds, coords=COORDS, face_connections=CUBED_SPHERE, autoparse_metadata=False)
+    a = R.synthetic_field((2, 6, 3, 4, 4), 32)
+    da = DataArray(a, dims=("time", "face", "z", "y", "x"))
+    got = pad(da, grid, padding_width={"X": (1, 1), "Y": (1, 0)}).values
+    for t in range(2):
+        for k in range(3):
+            want = T.pad_face_connections(a[t, :, k], ("face", "y", "x"), "face", {"X": "x", "Y": "y"},
+                                          CUBED_SPHERE["face"], ["X", "Y"], {"X": (1, 1), "Y": (1, 0)},
+                                          {"X": None, "Y": None}, {"X": 0.0, "Y": 0.0})
+            np.testing.assert_array_equal(got[t, :, k], want)
+    d = grid.diff(da, "X")
+    assert d.dims == ("time", "face", "z", "y", "xl")
+    np.testing.assert_array_equal(d.values[:, :, :, :, 1:], a[..., 1:] - a[..., :-1])
+
+
+def test_cumsum_on_connected_grid(backend):
+    """Grid.cumsum pads through `pad` (grid.py:1389-1395): the halo is the neighbour face's data."""
+    ds = _faces_ds()
+    grid = Grid(ds, coords=COORDS, face_connections=X_TO_X, autoparse_metadata=False)
+    c = ds.data_c.values
+    out = grid.cumsum(ds.data_c, "X", to="left", padding="fill").values
+    cs = np.cumsum(c, axis=2)[:, :, :-1]
+    np.testing.assert_allclose(out[:, :, 1:], cs, rtol=1e-12)  # contiguous-axis scan: re-associated sums
+    np.testing.assert_array_equal(out[0, :, 0], 0.0)
+    # the face-1 halo is the LAST column of the (trimmed) face-0 cumsum, as the reference's pad does
+    np.testing.assert_array_equal(out[1, :, 0], out[0, :, -1])

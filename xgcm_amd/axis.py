@@ -3,8 +3,8 @@
 Host-side metadata only (no arithmetic).  Behaviour and error messages follow reference
 xgcm/axis.py:20-257: position validation (:99-123), default shifts / FALLBACK_SHIFTS
 (:11-17,126-146), padding / fill_value defaults (:152-171), `_get_position_name` (:232-251),
-`_get_axis_dim_num` (:253-256).  North-fold padding specs (dict values) are out of scope for
-this backend and are rejected.
+`_get_axis_dim_num` (:253-256).  A north-fold padding spec (dict value, :153-156) is validated
+here and resolved against the seam axis by `Grid._validate_folds`.
 """
 
 from __future__ import annotations
@@ -56,6 +56,8 @@ class Axis:
 
         self._name = name
         self._coords = coords
+        self._facedim = None            # set by Grid._assign_face_connections
+        self._face_connections = None
 
         user_shifts = default_shifts or {}
         shifts: Dict[str, str] = {}
@@ -71,11 +73,10 @@ class Axis:
         self._default_shifts = shifts
 
         if isinstance(padding, Mapping):
-            raise NotImplementedError(
-                "north-fold padding specs are not supported by the MI355X backend (reference padding.py:619-762 "
-                "is outside the accelerated hot path)"
-            )
-        if padding is not None and padding not in VALID_PADDINGS:
+            from .padding import _parse_fold_padding
+
+            padding = _parse_fold_padding(padding)
+        elif padding is not None and padding not in VALID_PADDINGS:
             raise ValueError(
                 f"padding must be one of {list(VALID_PADDINGS)} "
                 f"or a fold spec (e.g. {{'fold': 'corner'}}) or None, but got {padding}"

@@ -1152,6 +1152,99 @@ __global__ __launch_bounds__(BLOCK) void k_pad(const real* __restrict__ in, real
 }
 
 // ------------------------------------------------------------------------------------------
+// halo gather through a token map (complex topologies: north fold, face connections;
+// padding.py:260-572,619-762).  The host turns the reference's padding procedure into ONE
+// int64 token per cell of the padded "mapped" dims (face/Y/X ...), shared by all other dims:
+//   |t| in [1, 2^62):  source element k = |t| - 1; k < P0 -> `in`, else `partner` (k - P0),
+//                      k counted row-major over that source's mapped dims
+//   |t| >= 2^62:       fill value number |t| - 2^62
+//   t < 0:             negated (vector components across a fold / reversed connection)
+// Interior cells never read the map (the padded interior IS the input), so the map costs
+// traffic only on the halo frame.
+// ------------------------------------------------------------------------------------------
+#define XG_TOKEN_FILL_BASE (1ll << 62)
+struct GatherSrc {
+  int n_mapped;
+  int64_t m_extent[XG_MAX_NDIM], m_stride[XG_MAX_NDIM];  // mapped dims in the source's own order
+  int64_t u_stride[XG_MAX_NDIM];                         // per OUT dim; 0 for mapped dims
+  int64_t mapped_size;                                   // prod(m_extent)
+};
+struct GatherGeo {
+  int ndim;
+  int64_t total;
+  int64_t out_shape[XG_MAX_NDIM];
+  int mapped[XG_MAX_NDIM];
+  int64_t lo[XG_MAX_NDIM];        // interior offset per out dim (mapped dims)
+  int64_t in_shape[XG_MAX_NDIM];  // per out dim
+  int64_t in_stride[XG_MAX_NDIM];
+  real fills[XG_MAX_NDIM];
+  int n_fills;
+  GatherSrc src[2];
+};
+
+template <typename I>
+__global__ __launch_bounds__(BLOCK) void k_gather(const real* __restrict__ in, const real* __restrict__ partner,
+                                                  real* __restrict__ out, const int64_t* __restrict__ tokens,
+                                                  GatherGeo g) {
+  const int64_t gid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (gid >= g.total) return;
+  I rem = (I)gid;
+  int64_t c[XG_MAX_NDIM];
+#pragma unroll
+  for (int d = XG_MAX_NDIM - 1; d >= 0; --d) {
+    if (d < g.ndim) {
+      const I n = (I)g.out_shape[d];
+      const I q = rem / n;
+      c[d] = (int64_t)(rem - q * n);
+      rem = q;
+    }
+  }
+  bool interior = true;
+  int64_t off = 0, p = 0;
+#pragma unroll
+  for (int d = 0; d < XG_MAX_NDIM; ++d) {
+    if (d < g.ndim) {
+      if (g.mapped[d]) {
+        const int64_t ci = c[d] - g.lo[d];
+        interior = interior && ci >= 0 && ci < g.in_shape[d];
+        off += ci * g.in_stride[d];
+        p = p * g.out_shape[d] + c[d];
+      } else {
+        off += c[d] * g.in_stride[d];
+      }
+    }
+  }
+  if (interior) { out[gid] = in[off]; return; }
+  const int64_t t = tokens[p];
+  const int64_t a = t < 0 ? -t : t;
+  real v;
+  if (a >= XG_TOKEN_FILL_BASE) {
+    const int64_t f = a - XG_TOKEN_FILL_BASE;
+    v = g.fills[f < g.n_fills ? f : 0];
+  } else {
+    int64_t k = a - 1;
+    const int s = (k >= g.src[0].mapped_size) ? 1 : 0;
+    k -= s ? g.src[0].mapped_size : 0;
+    const GatherSrc& S = g.src[s];
+    int64_t o = 0;
+#pragma unroll
+    for (int d = 0; d < XG_MAX_NDIM; ++d)
+      if (d < g.ndim && !g.mapped[d]) o += c[d] * S.u_stride[d];
+#pragma unroll
+    for (int m = XG_MAX_NDIM - 1; m >= 0; --m) {
+      if (m < S.n_mapped) {
+        const int64_t n = S.m_extent[m];
+        const int64_t q = k / n;
+        o += (k - q * n) * S.m_stride[m];
+        k = q;
+      }
+    }
+    v = s ? partner[o] : in[o];
+  }
+  out[gid] = t < 0 ? -v : v;
+}
+
+// ------------------------------------------------------------------------------------------
 // broadcasting binary op (out C-contiguous, a/b addressed through strides; dims pre-coalesced)
 // ------------------------------------------------------------------------------------------
 struct BinGeo {
@@ -1795,6 +1888,70 @@ int XG_FN(xg_pad)(const real* in, real* out, const int64_t* shape, int ndim, con
   hipStream_t st = (hipStream_t)stream;
   if (total < 0x7fffffffll) hipLaunchKernelGGL((k_pad<u32>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, p);
   else hipLaunchKernelGGL((k_pad<u64>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, p);
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int XG_FN(xg_gather)(const real* in, const real* partner, real* out, const int64_t* in_shape,
+                  const int64_t* partner_shape, const int64_t* out_shape, int ndim, const int* mapped,
+                  const int* partner_perm, const int64_t* lo, const int64_t* tokens, int64_t n_tokens,
+                  const real* fills, int n_fills, void* stream) {
+  if (!in || !out || !in_shape || !out_shape || !mapped || !lo || !tokens) return fail(XG_ERR_INVALID, "NULL argument");
+  if (ndim < 1 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [1,%d]", ndim, XG_MAX_NDIM);
+  if (n_fills < 0 || n_fills > XG_MAX_NDIM || (n_fills > 0 && !fills)) return fail(XG_ERR_INVALID, "bad fill table");
+  if (partner && (!partner_shape || !partner_perm)) return fail(XG_ERR_INVALID, "partner without shape/permutation");
+  GatherGeo g;
+  memset(&g, 0, sizeof(g));
+  g.ndim = ndim;
+  g.n_fills = n_fills;
+  for (int f = 0; f < n_fills; ++f) g.fills[f] = fills[f];
+  int64_t total = 1, pmap = 1, istr = 1;
+  for (int d = ndim - 1; d >= 0; --d) {
+    if (in_shape[d] < 0 || out_shape[d] < 0) return fail(XG_ERR_INVALID, "negative extent");
+    g.out_shape[d] = out_shape[d];
+    g.in_shape[d] = in_shape[d];
+    g.in_stride[d] = istr;
+    istr *= in_shape[d];
+    g.mapped[d] = mapped[d] ? 1 : 0;
+    g.lo[d] = mapped[d] ? lo[d] : 0;
+    total *= out_shape[d];
+    if (mapped[d]) pmap *= out_shape[d];
+    else if (in_shape[d] != out_shape[d]) return fail(XG_ERR_INVALID, "unmapped dim %d changes length", d);
+  }
+  if (pmap != n_tokens) return fail(XG_ERR_INVALID, "token plane has %lld cells, padded mapped dims have %lld", (long long)n_tokens, (long long)pmap);
+  // source 0 = `in` (dims in out order); source 1 = `partner` (its dim k is out dim partner_perm[k])
+  for (int s = 0; s < 2; ++s) {
+    GatherSrc& S = g.src[s];
+    S.mapped_size = 1;
+    if (s == 1 && !partner) { S.mapped_size = 0; continue; }
+    const int64_t* shp = s ? partner_shape : in_shape;
+    int64_t str = 1;
+    int64_t strides[XG_MAX_NDIM];
+    for (int k = ndim - 1; k >= 0; --k) { strides[k] = str; str *= shp[k]; }
+    bool seen[XG_MAX_NDIM] = {false};
+    for (int k = 0; k < ndim; ++k) {
+      const int d = s ? partner_perm[k] : k;
+      if (d < 0 || d >= ndim || seen[d]) return fail(XG_ERR_INVALID, "partner_perm is not a permutation");
+      seen[d] = true;
+      if (mapped[d]) {
+        S.m_extent[S.n_mapped] = shp[k];
+        S.m_stride[S.n_mapped] = strides[k];
+        S.mapped_size *= shp[k];
+        ++S.n_mapped;
+      } else {
+        if (shp[k] != out_shape[d]) return fail(XG_ERR_INVALID, "source %d: unmapped dim %d has another length", s, d);
+        S.u_stride[d] = strides[k];
+      }
+    }
+  }
+  g.total = total;
+  if (total == 0) return XG_OK;
+  const u64 nblocks = ((u64)total + BLOCK - 1) / BLOCK;
+  int rc;
+  if ((rc = check_grid(nblocks))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (total < 0x7fffffffll) hipLaunchKernelGGL((k_gather<u32>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, partner, out, tokens, g);
+  else hipLaunchKernelGGL((k_gather<u64>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, partner, out, tokens, g);
   XG_LAUNCH_CHECK();
   return XG_OK;
 }

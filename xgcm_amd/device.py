@@ -28,6 +28,8 @@ __all__ = [
     "cumsum1d",
     "reduce1d",
     "pad_nd",
+    "gather",
+    "upload_tokens",
     "binary",
     "vorticity",
     "stencil2d",
@@ -229,6 +231,41 @@ def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
     _hip.check(
         getattr(lib, "xg_pad_" + sfx)(x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), nd, _hip.i64(lo),
                                       _hip.i64(hi), _hip.ints(bcv), _hip.reals(fv, sfx), _hip.ints(order), _stream())
+    )
+    return out
+
+
+def upload_tokens(tokens: np.ndarray) -> torch.Tensor:
+    """int64 token plane of a halo map -> HBM (see xg_gather_f64 in include/xgcm_hip.h)."""
+    _require_gpu()
+    return torch.from_numpy(np.ascontiguousarray(tokens, dtype=np.int64)).to("cuda")
+
+
+def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_shape: Sequence[int],
+           fills: Sequence[float], partner_perm: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """Padded array of a complex topology through a token map (xg_gather_f64)."""
+    lib = _hip.load()
+    dt, sfx = _common(x, partner) if partner is not None else _common(x)
+    x = asdevice(x, dt)
+    nd = x.dim()
+    if partner is not None:
+        partner = asdevice(partner, dt)
+        if partner.dim() != nd:
+            raise ValueError("gather: the other vector component must have as many dims as the padded one")
+        if partner_perm is None:
+            partner_perm = list(range(nd))
+    if not isinstance(tokens, torch.Tensor):
+        tokens = upload_tokens(tokens)
+    out = torch.empty([int(v) for v in out_shape], dtype=dt, device=x.device)
+    if out.numel() == 0:
+        return out
+    _hip.check(
+        getattr(lib, "xg_gather_" + sfx)(
+            x.data_ptr(), _ptr(partner), out.data_ptr(), _hip.i64(list(x.shape)),
+            _hip.i64(list(partner.shape)) if partner is not None else None, _hip.i64(list(out_shape)), nd,
+            _hip.ints([1 if m else 0 for m in mapped]), _hip.ints(partner_perm) if partner is not None else None,
+            _hip.i64(list(lo)), tokens.data_ptr(), int(tokens.numel()), _hip.reals(list(fills) or [0.0], sfx),
+            len(fills), _stream())
     )
     return out
 

@@ -14,8 +14,9 @@ Reference call stacks and what replaces them here:
 
 Metadata logic (axis lookup, default shifts, per-axis kwargs, metric search, coordinate
 re-attachment, error types and messages) is restated from the reference so that the parity tests
-read like the reference's own.  Out of scope and rejected loudly: face connections, north folds,
-dask-chunked inputs, metadata autoparsing, `transform`.
+read like the reference's own.  Grids with face connections or a north fold take the generic
+pad-then-apply route (halo gather `xg_gather_f64`, then the un-padded stencil kernel).  Out of scope
+and rejected loudly: dask-chunked inputs, metadata autoparsing, `transform`.
 """
 
 from __future__ import annotations
@@ -42,7 +43,7 @@ from .grid_ufunc import (
 )
 from .labeled import DataArray, Dataset, _aligned_view, _is_tensor, from_xarray, is_xarray, to_xarray
 from .metrics import iterate_axis_combinations
-from .padding import no_boundary_error
+from .padding import _is_fold_padding, no_boundary_error, pad
 
 
 def _maybe_promote_str_to_list(a):
@@ -93,18 +94,18 @@ class Grid:
                 "Could not determine Axis names - please provide them in the coords kwarg "
                 "or provide a dataset from which they can be parsed"
             )
-        if face_connections:
-            raise NotImplementedError(
-                "face_connections (reference padding.py:260-572) are not supported by the MI355X backend"
-            )
-        self._facedim = None
-        self._face_connections = None
-        self._folds: Dict[str, Any] = {}
-
         names = list(coords.keys())
         per_axis_padding = self._map_kwargs_over_axes(padding, axes=names)
         per_axis_shifts = self._map_kwargs_over_axes(default_shifts, axes=names)
         per_axis_fill = self._map_kwargs_over_axes(fill_value, axes=names)
+        # only an axis the user marked periodic can be the seam of a north fold (grid.py:241-249)
+        self._explicitly_periodic_axes = {ax for ax, p in per_axis_padding.items() if p == "periodic"}
+        if face_connections:
+            self._facedim = list(face_connections.keys())[0]
+            self._face_connections = face_connections
+        else:
+            self._facedim = None
+            self._face_connections = None
         self.axes: "OrderedDict[str, Axis]" = OrderedDict()
         for ax in names:
             self.axes[ax] = Axis(
@@ -116,12 +117,109 @@ class Grid:
                 fill_value=per_axis_fill.get(ax, None),
             )
 
+        if face_connections is not None:
+            self._assign_face_connections(face_connections)
+        self._validate_folds()
+
         self._metrics: Dict[frozenset, List[DataArray]] = {}
         self._device_cache: Dict[int, Any] = {}
         self._metric_ids: set = set()
         if metrics is not None:
             for key, value in metrics.items():
                 self.set_metrics(key, value)
+
+    # ---- complex topologies (reference grid.py:334-470) --------------------------------------
+    def _assign_face_connections(self, fc) -> None:
+        """Check that every face link is mirrored by its neighbour and hand each axis its links."""
+        if len(fc) > 1:
+            raise ValueError("Only one face dimension is supported for now. Instead found %r" % repr(fc.keys()))
+        facedim = list(fc.keys())[0]
+        if facedim not in self._ds.dims:
+            raise ValueError(
+                f"Face dimension {facedim} does not exist in the dataset. Found {list(self._ds.dims)} instead"
+            )
+        face_links = fc[facedim]
+        if facedim in self._ds.coords:
+            valid_faces = set(np.asarray(self._ds[facedim].values).tolist())
+        else:
+            valid_faces = set(range(self._ds.dims[facedim]))
+        per_axis: Dict[str, Dict[Any, Tuple]] = {}
+        for fidx, axis_links_of_face in face_links.items():
+            for axis, (link_left, link_right) in axis_links_of_face.items():
+                checked = []
+                # a link seen from its left end must come back from the neighbour's right end,
+                # unless the connection is reversed
+                for link, position in ((link_left, 1), (link_right, 0)):
+                    if link is None:
+                        checked.append(None)
+                        continue
+                    idx, ax, rev = link
+                    back_position = int(not position) if rev else position
+                    try:
+                        neighbor_link = face_links[idx][ax][back_position]
+                    except (KeyError, IndexError):
+                        raise KeyError(
+                            "Couldn't find a face link for face %r"
+                            "in axis %r at position %r" % (idx, ax, back_position)
+                        )
+                    idx_n, ax_n, rev_n = neighbor_link
+                    for name in (ax, ax_n):
+                        if name not in self.axes:
+                            raise KeyError("axis %r is not a valid axis" % name)
+                    for face in (idx, idx_n):
+                        if face not in valid_faces:
+                            raise IndexError("%r is not a valid index for facedimension %r" % (face, facedim))
+                    if (idx_n != fidx) or (ax_n != axis) or (rev_n != rev):
+                        raise ValueError(
+                            "Face link mismatch: neighbor doesn't"
+                            " correctly link back to this face. "
+                            "face: %r, axis: %r, position: %r, "
+                            "rev: %r, link: %r, neighbor_link: %r"
+                            % (fidx, axis, position, rev, link, neighbor_link)
+                        )
+                    checked.append((idx, self.axes[ax], rev))
+                per_axis.setdefault(axis, {})[fidx] = tuple(checked)
+        for axis, links in per_axis.items():
+            self.axes[axis]._facedim = facedim
+            self.axes[axis]._face_connections = links
+
+    def _validate_folds(self) -> None:
+        """Resolve north-fold paddings: the seam is the one explicitly periodic other axis."""
+        self._folds = {}
+        for axname, axis in self.axes.items():
+            spec = axis._padding
+            if not _is_fold_padding(spec):
+                continue
+            candidates = [o for o in self.axes if o != axname and o in self._explicitly_periodic_axes]
+            if not candidates:
+                raise ValueError(
+                    f"A fold padding on axis {axname!r} requires an explicitly "
+                    "periodic seam axis (the zonal wrap), but no other axis was "
+                    "explicitly marked periodic. Set e.g. "
+                    "padding={'X': 'periodic', '" + str(axname) + "': {'fold': ...}}."
+                )
+            if len(candidates) > 1:
+                raise ValueError(
+                    f"A fold padding on axis {axname!r} is ambiguous: more than one "
+                    f"explicitly periodic axis could be the seam ({candidates}). "
+                    "Multiple candidate seam axes are not supported."
+                )
+            self._folds[axname] = {"seam_axis": candidates[0], "pivot": spec["fold"], "south": spec["south"]}
+        if self._folds and self._face_connections is not None:
+            raise NotImplementedError(
+                "Combining a north-fold boundary with face_connections is not "
+                f"supported (fold axes: {sorted(self._folds)}). Use one or the "
+                "other."
+            )
+        if self._folds:
+            warnings.warn(
+                "The north-fold (tripolar) boundary condition is experimental. "
+                "Its API and numerical behavior may change in future releases, "
+                "and it has not yet been validated across the full range of grid "
+                "configurations. Please review results carefully and report any "
+                "issues at https://github.com/xgcm/xgcm/issues.",
+                category=UserWarning,
+            )
 
     # ---- kwarg plumbing (reference grid.py:291-332) -----------------------------------------
     def _map_kwargs_over_axes(self, kwargs, axes: Optional[Iterable[str]] = None) -> Dict[str, Any]:
@@ -410,6 +508,43 @@ class Grid:
         """Maximum of neighboring points on the intermediate grid point."""
         return self._1d_grid_ufunc_dispatch("max", da, axis, **kwargs)
 
+    def _apply_vector_function(self, function, vector, **kwargs):
+        """Each component of a C-grid vector moved to the cell centre with the other one as its
+        `other_component` (reference grid.py:1420-1471; deprecated there, kept for its tests)."""
+        if not (isinstance(vector, dict) and len(vector) == 2):
+            raise ValueError(
+                "Input is expected to be a dictionary with two key/value pairs which map grid axis to the vector component parallel to that axis"
+            )
+        warnings.warn(
+            "`interp_2d_vector` and `diff_2d_vector` will be removed from future releases."
+            "The same functionality will be accessible under the `xgcm.Grid.diff` and `xgcm.Grid.interp` methods, please see those docstrings for details.",
+            category=DeprecationWarning,
+        )
+        to = kwargs.get("to", "center")
+        if to != "center":
+            raise NotImplementedError("Only vector interpolation to cell center is implemented, but got to=%r" % to)
+        for axis_name, component in vector.items():
+            position, _ = self.axes[axis_name]._get_position_name(self._wrap_in(component)[0])
+            if position == "center":
+                raise NotImplementedError(
+                    "Only vector interpolation to cell "
+                    "center is implemented, but vector "
+                    "%s component is defined at center "
+                    "(dims: %r)" % (axis_name, tuple(component.dims))
+                )
+        x_name, y_name = list(vector)
+        x_component = function({x_name: vector[x_name]}, x_name, other_component={y_name: vector[y_name]}, **kwargs)
+        y_component = function({y_name: vector[y_name]}, y_name, other_component={x_name: vector[x_name]}, **kwargs)
+        return {x_name: x_component, y_name: y_component}
+
+    def diff_2d_vector(self, vector, **kwargs):
+        """Difference a 2D vector to the intermediate grid point (complex topologies)."""
+        return self._apply_vector_function(self.diff, vector, **kwargs)
+
+    def interp_2d_vector(self, vector, **kwargs):
+        """Interpolate a 2D vector to the intermediate grid point (complex topologies)."""
+        return self._apply_vector_function(self.interp, vector, **kwargs)
+
     def derivative(self, da, axis, **kwargs):
         """Centered-difference derivative: `diff(da, axis) / get_metric(diff, (axis,))` (grid.py:1576-1578)."""
         return self._1d_grid_ufunc_dispatch("diff", da, axis, _divide_by=(axis,), **kwargs)
@@ -452,10 +587,9 @@ class Grid:
                 ax_to = ax._default_shifts[pos]
             trim_lo, trim_hi, pad_lo, pad_hi = _cumsum_trim_pad(pos, ax_to, rev, ax)
             bc = all_padding[ax.name]
-            if (pad_lo or pad_hi) and bc is None:
+            generic_pad = self._face_connections is not None or ax.name in self._folds
+            if (pad_lo or pad_hi) and bc is None and not generic_pad:
                 raise no_boundary_error(ax.name)
-            if isinstance(bc, Mapping):
-                raise NotImplementedError("north-fold padding is not supported by the MI355X backend")
             fv = all_fill[ax.name]
             new_dim = ax.coords[ax_to]
             out_dims = tuple(new_dim if d == dim else d for d in data.dims)
@@ -468,9 +602,19 @@ class Grid:
             num = data.get_axis_num(dim)
             host = not _is_tensor(data.data)
             # xarray's DataArray.cumsum skips NaN for floats (numpy.nancumsum); see DESIGN.md "unpinned"
-            out = _dev.cumsum1d(data.data, num, trim_lo, trim_hi, pad_lo, pad_hi, bc if (pad_lo or pad_hi) else None,
-                                0.0 if fv is None else float(fv), rev, True, m_in, m_out)
-            res = DataArray(_dev.tohost(out) if host else out, out_dims, name=data.name)
+            if generic_pad:
+                # complex topology: scan without halo, then the reference's own pad (grid.py:1389-1395)
+                out = _dev.cumsum1d(data.data, num, trim_lo, trim_hi, 0, 0, None, 0.0, rev, True, m_in, None)
+                trimmed = DataArray(_dev.tohost(out) if host else out, data.dims, name=data.name)
+                padded = pad(trimmed, self, {ax.name: (pad_lo, pad_hi)}, padding=padding, fill_value=fill_value)
+                res = DataArray(padded.data, out_dims, name=data.name)
+                if weighted:
+                    res = res / self._resident(self.get_metric(res, weighted), res.data)
+            else:
+                out = _dev.cumsum1d(data.data, num, trim_lo, trim_hi, pad_lo, pad_hi,
+                                    bc if (pad_lo or pad_hi) else None, 0.0 if fv is None else float(fv), rev, True,
+                                    m_in, m_out)
+                res = DataArray(_dev.tohost(out) if host else out, out_dims, name=data.name)
             data = _reattach_coords([res], self, {ax.name: (pad_lo, pad_hi)}, {new_dim}, [data])[0]
         return to_xarray(data) if was_xr else data
 

@@ -78,7 +78,9 @@ class HipGridUFunc(GridUFunc):
         if grid is None or len(args) != 1 or axis is None or len(axis) != 1 or len(axis[0]) != 1:
             return False
         if getattr(grid, "_face_connections", None) is not None:
-            return False
+            return False  # halos come from neighbouring faces: generic pad (xg_gather) then apply
+        if axis[0][0] in (getattr(grid, "_folds", None) or {}):
+            return False  # the north edge of this axis folds: generic pad then apply
         extra = set(kwargs) - {"padding", "fill_value", "dask", "map_overlap", "other_component", "pad_before_func",
                                "metric_in", "metric_out"}
         if extra:

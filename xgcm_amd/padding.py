@@ -1,21 +1,32 @@
 """Boundary padding of labelled arrays on the GPU (generic path for user grid ufuncs).
 
-`pad` has the reference's signature and semantics for simple topologies (xgcm/padding.py:765-871
--> `_pad_basic` :575-616): per axis, in `padding_width` order, periodic = numpy 'wrap',
-fill = 'constant', extend = 'edge'; all coordinates are stripped from the result; all-zero
-widths return the input untouched; a padded axis without a boundary condition raises the
-reference's ValueError.  The whole multi-axis pad is ONE kernel launch (xg_pad_f64), not one
-array copy per axis.  Face connections and north folds are out of scope.
+`pad` has the reference's signature and semantics (xgcm/padding.py:765-871):
 
-The built-in diff/interp/min/max/cumsum operators never call this: their halo is fused into
-the stencil kernels (xgcm_amd/gridops.py).
+* simple topologies -> `_pad_basic` (:575-616): per axis, in `padding_width` order, periodic =
+  numpy 'wrap', fill = 'constant', extend = 'edge'; the whole multi-axis pad is ONE kernel
+  launch (xg_pad_f64), not one array copy per axis;
+* a north fold on a padded axis -> `_pad_fold` (:689-762);
+* face connections -> `_pad_face_connections` (:260-572).
+
+The two complex topologies are pure data movement, so their procedure runs once on a plane of
+int64 tokens (xgcm_amd/halo_map.py, host-side index logic, cached on the grid) and the data
+moves in one `xg_gather_f64` launch.  All coordinates are stripped from the result; all-zero
+widths return the input untouched; a padded edge without boundary condition or connection
+raises the reference's ValueError.
+
+The built-in diff/interp/min/max/cumsum operators on simple topologies never call this: their
+halo is fused into the stencil kernels (xgcm_amd/gridops.py).
 """
 
 from __future__ import annotations
 
 from typing import Dict, Mapping, Optional, Tuple
 
+import numpy as np
+
 from . import device as _dev
+from . import halo_map as _hm
+from .halo_map import seam_partner_indices as _seam_partner_indices  # noqa: F401  (reference name)
 from .labeled import DataArray, _is_tensor
 
 _XGCM_BOUNDARY_KWARG_TO_XARRAY_PAD_KWARG = {"periodic": "wrap", "fill": "constant", "extend": "edge"}
@@ -52,13 +63,18 @@ def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding
 
     if padding_width is None or all(tuple(w) == (0, 0) for w in padding_width.values()):
         return data
-    if getattr(grid, "_face_connections", None) is not None:
-        raise NotImplementedError("face connections are not supported by the MI355X backend (padding.py:260-572)")
-
     data = _strip_all_coords(data)
+    if getattr(grid, "_face_connections", None) is not None:
+        return _pad_face_connections(data, grid, padding_width, padding, fill_value, other_component)
+    if getattr(grid, "_folds", None) and any(ax in grid._folds for ax in padding_width):
+        return _pad_fold(data, grid, padding_width, padding, fill_value)
     if isinstance(data, dict):
         [data] = list(data.values())
+    return _pad_basic(data, grid, padding_width, padding, fill_value)
 
+
+def _pad_basic(data: DataArray, grid, padding_width, padding, fill_value) -> DataArray:
+    """numpy.pad chain over the given axes in one launch (reference padding.py:575-616)."""
     widths: Dict[int, Tuple[int, int]] = {}
     bc: Dict[int, Optional[str]] = {}
     fv: Dict[int, float] = {}
@@ -69,8 +85,6 @@ def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding
         mode = padding[ax]
         if mode is None:
             raise no_boundary_error(ax)
-        if isinstance(mode, Mapping):
-            raise NotImplementedError("north-fold padding is not supported by the MI355X backend")
         if mode not in _XGCM_BOUNDARY_KWARG_TO_XARRAY_PAD_KWARG:
             raise KeyError(mode)
         num = data.get_axis_num(dim)
@@ -83,3 +97,310 @@ def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding
     host = not _is_tensor(data.data)
     out = _dev.pad_nd(data.data, widths, bc, fv)
     return DataArray(_dev.tohost(out) if host else out, data.dims, name=data.name)
+
+
+# ------------------------------------------------------------------------------------------
+# fold padding values (reference padding.py:60-180)
+# ------------------------------------------------------------------------------------------
+_PIVOT_ALIASES = {
+    # role "seam" = the zonal (X) axis, role "fold" = the meridional (Y) axis
+    "center": {"seam": "center", "fold": "center"},
+    "t": {"seam": "center", "fold": "center"},
+    "corner": {"seam": "edge", "fold": "edge"},
+    "f": {"seam": "edge", "fold": "edge"},
+    "u": {"seam": "edge", "fold": "center"},
+    "v": {"seam": "center", "fold": "edge"},
+}
+
+
+def _is_fold_padding(padding) -> bool:
+    return isinstance(padding, Mapping) and "fold" in padding
+
+
+def _position_kind(position: str) -> str:
+    return "center" if position == "center" else "edge"
+
+
+def _parse_fold_padding(padding: Mapping) -> Dict:
+    """Validate `{"fold": pivot[, "south": mode]}` -> `{"fold": pivot, "south": mode}`."""
+    if not _is_fold_padding(padding):
+        raise ValueError(f"Not a fold padding value: {padding!r}")
+    extra = set(padding) - {"fold", "south"}
+    if extra:
+        raise ValueError(
+            f"Unknown keys {sorted(extra)} in fold padding {dict(padding)!r}. "
+            "Allowed keys are 'fold' (pivot type) and 'south' (south-edge mode)."
+        )
+    pivot = padding["fold"]
+    names = sorted(_PIVOT_ALIASES)
+    if isinstance(pivot, str):
+        if pivot.lower() not in _PIVOT_ALIASES:
+            raise ValueError(
+                f"Unknown fold pivot {pivot!r}. Use one of {names} or an explicit {{axis: position}} mapping."
+            )
+    elif isinstance(pivot, Mapping):
+        if not pivot:
+            raise ValueError("Explicit fold pivot mapping must not be empty.")
+        bad = {ax: pos for ax, pos in pivot.items() if pos not in _hm.SEAM_POSITION}
+        if bad:
+            raise ValueError(
+                f"Invalid position(s) {bad} in explicit fold pivot {dict(pivot)!r}. "
+                f"Each must be one of {sorted(_hm.SEAM_POSITION)}."
+            )
+    else:
+        raise ValueError(f"Fold pivot must be a name ({names}) or an {{axis: position}} mapping, got {pivot!r}.")
+    south = padding.get("south", "fill")
+    if south not in _XGCM_BOUNDARY_KWARG_TO_XARRAY_PAD_KWARG:
+        raise ValueError(
+            f"Fold 'south' mode must be one of {list(_XGCM_BOUNDARY_KWARG_TO_XARRAY_PAD_KWARG)}, got {south!r}."
+        )
+    return {"fold": pivot, "south": south}
+
+
+def _resolve_pivot(pivot, fold_axis: str, seam_axis: str) -> Dict[str, str]:
+    """pivot spec -> {'seam': center|edge, 'fold': center|edge} (reference padding.py:150-177)."""
+    if isinstance(pivot, str):
+        return dict(_PIVOT_ALIASES[pivot.lower()])
+    roles = {}
+    for axname, position in pivot.items():
+        if axname == fold_axis:
+            roles["fold"] = _position_kind(position)
+        elif axname == seam_axis:
+            roles["seam"] = _position_kind(position)
+        else:
+            raise ValueError(
+                f"Fold pivot axis {axname!r} is neither the fold axis {fold_axis!r} nor the seam axis {seam_axis!r}."
+            )
+    roles.setdefault("seam", "center")
+    roles.setdefault("fold", "center")
+    return roles
+
+
+# ------------------------------------------------------------------------------------------
+# token-map padding: shared plumbing
+# ------------------------------------------------------------------------------------------
+def _axis_dims(grid) -> Dict[str, Tuple[str, ...]]:
+    return {name: tuple(ax.coords.values()) for name, ax in grid.axes.items()}
+
+
+def _gather(data: DataArray, partner: Optional[DataArray], grid, key, build, partner_same_as=None) -> DataArray:
+    """Run (or reuse) the token-plane builder `build()` -> (plane, mapped dims, lo per dim, fills)
+    and move the data through it."""
+    cache = grid.__dict__.setdefault("_halo_maps", {})
+    entry = cache.get(key)
+    if entry is None:
+        plane, lo_of_dim, fills = build()
+        mapped_dims = tuple(d for d in data.dims if d in plane.dims)
+        plane = plane.transpose(mapped_dims)
+        entry = {"tokens": np.ascontiguousarray(plane.a), "sizes": dict(zip(mapped_dims, plane.a.shape)),
+                 "lo": lo_of_dim, "fills": list(fills.values), "device": None}
+        if len(cache) > 64:
+            cache.clear()
+        cache[key] = entry
+    mapped = [d in entry["sizes"] for d in data.dims]
+    out_shape = [entry["sizes"].get(d, n) for d, n in zip(data.dims, data.shape)]
+    lo = [int(entry["lo"].get(d, 0)) for d in data.dims]
+    host = not (_is_tensor(data.data) or (partner is not None and _is_tensor(partner.data)))
+    tokens = entry["tokens"]
+    if not host:
+        if entry["device"] is None:
+            entry["device"] = _dev.upload_tokens(tokens)
+        tokens = entry["device"]
+    perm = None
+    pdata = None
+    if partner is not None:
+        # partner dim k plays the role of out dim perm[k]: unmapped dims by name, mapped dims in order
+        free = [i for i, d in enumerate(data.dims) if mapped[i]]
+        perm = []
+        for d in partner.dims:
+            twin = (partner_same_as or {}).get(d, d)  # the padded array's dim on the same grid axis
+            if twin in data.dims and not mapped[data.dims.index(twin)]:
+                perm.append(data.dims.index(twin))
+            else:
+                perm.append(free.pop(0))
+        pdata = partner.data
+    out = _dev.gather(data.data, pdata, tokens, mapped, lo, out_shape, entry["fills"], perm)
+    return DataArray(_dev.tohost(out) if host else out, data.dims, name=data.name)
+
+
+def _fill_key(fill_value: Mapping) -> Tuple:
+    return tuple((k, None if v is None else (float(v) if float(v) == float(v) else "nan")) for k, v in fill_value.items())
+
+
+# ------------------------------------------------------------------------------------------
+# north fold (reference padding.py:689-762)
+# ------------------------------------------------------------------------------------------
+def _pad_fold(data, grid, padding_width, padding, fill_value) -> DataArray:
+    isvector = isinstance(data, dict)
+    if isvector:
+        # a fold is a 180-degree pivot: the lone component flips sign, no partner is needed
+        _, data = dict(data).popitem()
+    fold_axes = [ax for ax in padding_width if ax in grid._folds and padding_width[ax][1] > 0]
+    if len(fold_axes) > 1:
+        raise NotImplementedError(
+            f"Padding more than one north-fold axis at once is not supported (got fold axes {sorted(fold_axes)})."
+        )
+    basic_width, basic_padding = {}, {}
+    for ax, w in padding_width.items():
+        if ax in grid._folds:
+            per_call = padding[ax]
+            basic_width[ax] = (w[0], 0)
+            basic_padding[ax] = per_call if isinstance(per_call, str) else grid._folds[ax]["south"]
+        else:
+            basic_width[ax] = tuple(w)
+            basic_padding[ax] = padding[ax]
+    if not fold_axes:
+        return _pad_basic(data, grid, basic_width, basic_padding, fill_value)
+
+    fax = fold_axes[0]
+    info = grid._folds[fax]
+    seam_axis = info["seam_axis"]
+    pivot = _resolve_pivot(info["pivot"], fax, seam_axis)
+    fold_position, fold_dim = grid.axes[fax]._get_position_name(data)
+    seam_position, seam_dim = grid.axes[seam_axis]._get_position_name(data)
+    width = int(padding_width[fax][1])
+    dim_of_axis = {fax: fold_dim, seam_axis: seam_dim}
+    for ax, w in basic_width.items():
+        if any(w):
+            dim_of_axis[ax] = grid.axes[ax]._get_position_name(data)[1]
+    mapped_dims = tuple(d for d in data.dims if d in dim_of_axis.values())
+    sizes = tuple(data.sizes[d] for d in mapped_dims)
+
+    def build():
+        fills = _hm.FillTable()
+        plane = _hm.identity_plane(sizes, mapped_dims)
+        plane = _hm.fold_plane(plane, fold_dim, fold_position, seam_dim, seam_position, pivot, width, isvector, fax)
+        plane = _hm.basic_pad(plane, dim_of_axis, basic_width, basic_padding, fill_value, fills, no_boundary_error)
+        lo = {dim_of_axis[ax]: int(w[0]) for ax, w in basic_width.items() if ax in dim_of_axis}
+        return plane, lo, fills
+
+    key = ("fold", data.dims, sizes, fax, tuple((k, tuple(v)) for k, v in padding_width.items()),
+           tuple(sorted(basic_padding.items(), key=str)), _fill_key(fill_value), isvector, repr(info["pivot"]))
+    return _gather(data, None, grid, key, build)
+
+
+# ------------------------------------------------------------------------------------------
+# face connections (reference padding.py:260-572)
+# ------------------------------------------------------------------------------------------
+def _infer_vector_component_axis(grid, da) -> str:
+    """The single axis on which a bare vector component is edge-staggered (padding.py:229-257)."""
+    edge_axes = []
+    for axname, axis in grid.axes.items():
+        try:
+            position, _ = axis._get_position_name(da)
+        except KeyError:
+            continue
+        if position != "center":
+            edge_axes.append(axname)
+    if len(edge_axes) == 1:
+        return edge_axes[0]
+    raise ValueError(
+        "Could not unambiguously infer the axis of the vector component being "
+        f"padded from its staggered position (edge axes found: {edge_axes}). "
+        "Pass the component as a `{axis_name: DataArray}` dict so its "
+        "orientation is explicit, e.g. "
+        "`pad({'Y': v}, ..., other_component={'X': u})`."
+    )
+
+
+def _get_all_connection_axes(connections, facedim):
+    found = []
+    for c in connections[facedim].values():
+        for ax in c:
+            if ax not in found:
+                found.append(ax)
+    return found
+
+
+def _pad_face_connections(da, grid, padding_width, padding, fill_value, other_component=None) -> DataArray:
+    facedim = grid._facedim
+    connections = grid._face_connections
+    if connections is None:
+        raise ValueError("Grid connections cannot be None")
+    if facedim is None:
+        raise ValueError("Face dimension cannot be None")
+
+    vectoraxis = None
+    if isinstance(da, dict):
+        vectoraxis, da = dict(da).popitem()
+    elif other_component is not None:
+        vectoraxis = _infer_vector_component_axis(grid, da)
+    partner = None
+    if vectoraxis is not None:
+        if other_component is None:
+            raise ValueError("Padding vector components requires `other_component` input.")
+        _, partner = dict(other_component).popitem()
+        partner = _strip_all_coords(partner)
+
+    # every axis named by a connection or by the request takes part; the reference iterates them
+    # in set (hash) order, here: grid axis order (only corner cells can depend on the order)
+    wanted = set(_get_all_connection_axes(connections, facedim)) | set(padding_width)
+    pad_axes = [ax for ax in grid.axes if ax in wanted] + [ax for ax in padding_width if ax not in grid.axes]
+    widths = {ax: tuple(int(v) for v in padding_width.get(ax, (0, 0))) for ax in pad_axes}
+    width = max([v for w in widths.values() for v in w] + [0])
+    n_face = da.sizes[facedim]
+    face_links = connections[facedim]
+
+    # edges without connection need a boundary condition; fully connected axes take a neutral
+    # placeholder for the pre-padding that the connection data overwrites (padding.py:338-372)
+    prepad_padding = dict(padding)
+    for ax in pad_axes:
+        if prepad_padding.get(ax) is not None:
+            continue
+        for side, side_name in ((0, "left"), (1, "right")):
+            if widths[ax][side] == 0:
+                continue
+            loose = [i for i in range(n_face) if face_links.get(i, {}).get(ax, (None, None))[side] is None]
+            if loose:
+                raise ValueError(
+                    f"No boundary condition was specified for axis {ax!r}, "
+                    f"but the requested operation needs to pad the {side_name} "
+                    f"edge of face(s) {loose}, which have no face "
+                    f"connection there. Set a boundary condition, e.g. "
+                    f"``padding='fill'`` (or 'extend'/'periodic'), on the Grid "
+                    f"(``Grid(..., padding=...)``) or pass ``padding=`` to the "
+                    f"grid method."
+                )
+        prepad_padding[ax] = "fill"
+    if width == 0:
+        return da
+
+    all_axis_dims = _axis_dims(grid)
+    dims_own = {ax: grid.axes[ax]._get_position_name(da)[1] for ax in pad_axes}
+    mapped_dims = tuple(d for d in da.dims if d == facedim or d in dims_own.values())
+    sizes = tuple(da.sizes[d] for d in mapped_dims)
+    p_in = int(np.prod(sizes, dtype=np.int64))
+    dims_partner = p_mapped = p_sizes = None
+    if partner is not None:
+        dims_partner = {ax: grid.axes[ax]._get_position_name(partner)[1] for ax in pad_axes}
+        p_mapped = tuple(d for d in partner.dims if d == facedim or d in dims_partner.values())
+        p_sizes = tuple(partner.sizes[d] for d in p_mapped)
+    uniform = {ax: (width, width) for ax in pad_axes}
+
+    def build():
+        fills = _hm.FillTable()
+        own = _hm.basic_pad(_hm.identity_plane(sizes, mapped_dims), dims_own, uniform, prepad_padding, fill_value,
+                            fills, no_boundary_error)
+        other = None
+        if partner is not None:
+            other = _hm.basic_pad(_hm.identity_plane(p_sizes, p_mapped, offset=p_in), dims_partner, uniform,
+                                  prepad_padding, fill_value, fills, no_boundary_error)
+        plane = _hm.face_connection_plane(own, other, facedim, face_links, pad_axes, dims_own, dims_partner,
+                                          all_axis_dims, widths, width, vectoraxis)
+        lo = {dims_own[ax]: widths[ax][0] for ax in pad_axes}
+        return plane, lo, fills
+
+    key = ("faces", da.dims, sizes, None if partner is None else (partner.dims, p_sizes), vectoraxis,
+           tuple(widths.items()), tuple(sorted(prepad_padding.items(), key=str)), _fill_key(fill_value))
+    same_as = None
+    if partner is not None:  # unmapped dims of the two components correspond through their grid axis
+        same_as = {}
+        for d in partner.dims:
+            if d in da.dims or d == facedim:
+                continue
+            for cand in all_axis_dims.values():
+                if d in cand:
+                    own = [c for c in cand if c in da.dims]
+                    if own:
+                        same_as[d] = own[0]
+    return _gather(da, partner, grid, key, build, same_as)
