@@ -18,6 +18,8 @@
  *   xg_stencil1d_f64   xgcm/grid_ufunc.py:885-904 (pad-then-apply) + xgcm/padding.py:575-616
  *                      (_pad_basic) + xgcm/gridops.py:23-215 (diff/interp/min/max bodies)
  *                      + xgcm/grid.py:804-808,830-832 (metric_weighted) + :1576-1578 (derivative)
+ *   xg_stencil1d_halo_f64  the same operators on grids with face connections / a north fold
+ *                      (halo values pre-gathered by xg_gather_f64 instead of a padded copy)
  *   xg_cumsum1d_f64    xgcm/grid.py:1295-1414 (Grid.cumsum per-axis body) and the 8 cumsum
  *                      grid ufuncs xgcm/gridops.py:221-278
  *   xg_reduce1d_f64    xgcm/grid.py:1598-1605 (Grid.integrate: (da*weight).sum(dim))
@@ -53,7 +55,8 @@ typedef enum xg_status {
 typedef enum xg_op { XG_OP_DIFF = 0, XG_OP_INTERP = 1, XG_OP_MIN = 2, XG_OP_MAX = 3 } xg_op;
 
 /* boundary modes, xgcm/padding.py:15-19.  XG_BC_NONE is only legal when no halo cell is read. */
-typedef enum xg_bc { XG_BC_NONE = 0, XG_BC_PERIODIC = 1, XG_BC_FILL = 2, XG_BC_EXTEND = 3 } xg_bc;
+/* XG_BC_HALO (internal to xg_stencil1d_halo_*): halo values were gathered beforehand. */
+typedef enum xg_bc { XG_BC_NONE = 0, XG_BC_PERIODIC = 1, XG_BC_FILL = 2, XG_BC_EXTEND = 3, XG_BC_HALO = 4 } xg_bc;
 
 typedef enum xg_binop { XG_BIN_MUL = 0, XG_BIN_DIV = 1, XG_BIN_ADD = 2, XG_BIN_SUB = 3 } xg_binop;
 
@@ -84,6 +87,16 @@ int xg_stencil1d_f64(int op, const double* in, double* out, const int64_t* shape
                      int axis, int64_t n_out, int pad_lo, int pad_hi, int bc, double fill,
                      const double* m_in, const int64_t* m_in_strides, const double* m_out,
                      const int64_t* m_out_strides, void* stream);
+
+/* Same operator on a complex topology (face connections xgcm/padding.py:260-572, north fold
+ * :619-762): the halo cells do not follow from `in` by a wrap / clamp / constant rule, so the
+ * caller gathers them first (xg_gather_f64 over the halo cells only) into `halo`, an array shaped
+ * like `in` with the op axis shortened to pad_lo + pad_hi (low halo first).  The kernels are the
+ * ones of xg_stencil1d_f64; `in` is read once, no padded copy of the field is ever made. */
+int xg_stencil1d_halo_f64(int op, const double* in, const double* halo, double* out,
+                          const int64_t* shape, int ndim, int axis, int64_t n_out, int pad_lo,
+                          int pad_hi, const double* m_out, const int64_t* m_out_strides,
+                          void* stream);
 
 /* ---- prefix sum along one axis with the reference's trim/pad folded in ------------------ */
 /* c = inclusive cumsum of (in * m_in) along axis (from the high end if `reverse`; NaN counted
@@ -166,6 +179,9 @@ int xg_stencil1d_f32(int op, const float* in, float* out, const int64_t* shape, 
                      int64_t n_out, int pad_lo, int pad_hi, int bc, float fill, const float* m_in,
                      const int64_t* m_in_strides, const float* m_out, const int64_t* m_out_strides,
                      void* stream);
+int xg_stencil1d_halo_f32(int op, const float* in, const float* halo, float* out,
+                          const int64_t* shape, int ndim, int axis, int64_t n_out, int pad_lo,
+                          int pad_hi, const float* m_out, const int64_t* m_out_strides, void* stream);
 int xg_cumsum1d_f32(const float* in, float* out, const int64_t* shape, int ndim, int axis,
                     int reverse, int skipna, int trim_lo, int trim_hi, int pad_lo, int pad_hi,
                     int bc, float fill, const float* m_in, const int64_t* m_in_strides,

@@ -58,6 +58,14 @@ def pad_nd(x, widths, bc, fill):
                     {k % x.ndim: (0.0 if v is None else v) for k, v in fill.items()})
 
 
+def stencil1d_halo(op, x, halo, axis, pad_lo, pad_hi, m_out=None):
+    x, halo, m_out = _cast(_common(x, halo, m_out), x, halo, m_out)
+    axis = axis % x.ndim
+    lo = np.take(halo, range(0, pad_lo), axis=axis)
+    hi = np.take(halo, range(pad_lo, pad_lo + pad_hi), axis=axis)
+    return R.stencil1d(op, np.concatenate([lo, x, hi], axis=axis), axis, 0, 0, None, 0.0, None, m_out)
+
+
 def upload_tokens(tokens):
     return np.ascontiguousarray(tokens, dtype=np.int64)
 
@@ -104,7 +112,7 @@ def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None, dtype=np.f
     return R.synthetic(int(np.prod(shape)), seed, offset, scale, shift).reshape(tuple(shape)).astype(dtype)
 
 
-_NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "cumsum1d", "reduce1d", "pad_nd", "gather", "upload_tokens", "binary",
+_NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "stencil1d_halo", "cumsum1d", "reduce1d", "pad_nd", "gather", "upload_tokens", "binary",
           "vorticity", "stencil2d", "stencil2d_supported", "synthetic"]
 
 

@@ -234,8 +234,18 @@ def gather_tokens(x: np.ndarray, partner: Optional[np.ndarray], tokens: np.ndarr
     inv = np.argsort(u_dims + m_dims)
     out = np.transpose(vals, inv)
     # interior cells copy the input (the kernel does not consult the map there)
-    sel = tuple(slice(int(lo[d]), int(lo[d]) + x.shape[d]) if mapped[d] else slice(None) for d in range(nd))
     out = np.ascontiguousarray(out)
-    out[sel] = x
+    sel_out, sel_in = [], []
+    for d in range(nd):
+        if not mapped[d]:
+            sel_out.append(slice(None)); sel_in.append(slice(None))
+            continue
+        a0, a1 = max(int(lo[d]), 0), min(int(lo[d]) + x.shape[d], int(out_shape[d]))
+        if a1 <= a0:
+            sel_out = None  # a halo-only plane: no interior cell at all
+            break
+        sel_out.append(slice(a0, a1)); sel_in.append(slice(a0 - int(lo[d]), a1 - int(lo[d])))
+    if sel_out is not None:
+        out[tuple(sel_out)] = x[tuple(sel_in)]
     assert list(out.shape) == [int(v) for v in out_shape]
     return out

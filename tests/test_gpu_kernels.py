@@ -208,6 +208,32 @@ def test_gather_random_token_maps(dev, dtype):
         _eq(got, want)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", SHAPES + [(2, 40, 2600), (3, 2, 4, 8)])
+def test_stencil_with_pregathered_halo(dev, shape, dtype):
+    """xg_stencil1d_halo: every kernel family (contiguous V/general, short segments, column chunks)
+    must read the low / high halo cell from the halo slab exactly where numpy's concatenate puts it."""
+    a = _field(shape, 77).astype(dtype)
+    for axis in range(len(shape)):
+        for lo, hi in PADS:
+            hshape = list(shape)
+            hshape[axis] = lo + hi
+            halo = _field(hshape, 78).astype(dtype) if lo + hi else np.zeros(hshape, dtype)
+            lo_part = np.take(halo, range(0, lo), axis=axis)
+            hi_part = np.take(halo, range(lo, lo + hi), axis=axis)
+            padded = np.concatenate([lo_part, a, hi_part], axis=axis)
+            if padded.shape[axis] < 2:
+                continue
+            for op in ("diff", "interp"):
+                want = R.stencil1d(op, padded, axis, 0, 0, None)
+                got = dev.tohost(dev.stencil1d_halo(op, a, halo, axis, lo, hi))
+                assert got.dtype == dtype
+                _eq(got, want)
+            # output metric (derivative): divides after the op, halo or not
+            m = (R.synthetic_metric(want.shape, 79)).astype(dtype)
+            _eq(dev.tohost(dev.stencil1d_halo("diff", a, halo, axis, lo, hi, m)), R.stencil1d("diff", padded, axis, 0, 0, None) / m)
+
+
 def test_binary_broadcast(dev):
     a = _field((3, 4, 6, 10), 19)
     for op in ("mul", "div", "add", "sub"):

@@ -613,3 +613,23 @@ def test_cumsum_on_connected_grid(backend):
     np.testing.assert_array_equal(out[0, :, 0], 0.0)
     # the face-1 halo is the LAST column of the (trimmed) face-0 cumsum, as the reference's pad does
     np.testing.assert_array_equal(out[1, :, 0], out[0, :, -1])
+
+
+def test_metrics_on_connected_grid(backend):
+    """derivative (output metric fused with the pre-gathered halo) and metric_weighted (input metric:
+    the reference's multiply -> pad -> op -> divide sequence, grid.py:804-832) on a cubed sphere."""
+    ds = _faces_ds(6, 4, seed=51)
+    dx = R.synthetic_metric((6, 4, 4), 52)
+    dxl = R.synthetic_metric((6, 4, 4), 53)
+    ds["dx"] = (("face", "y", "x"), dx)
+    ds["dxl"] = (("face", "y", "xl"), dxl)
+    grid = Grid(ds, coords=COORDS, face_connections=CUBED_SPHERE, metrics={("X",): ["dx", "dxl"]},
+                autoparse_metadata=False)
+    c = ds.data_c.values
+    want_pad = T.pad_face_connections(c, ("face", "y", "x"), "face", {"X": "x", "Y": "y"}, CUBED_SPHERE["face"],
+                                      ["X", "Y"], {"X": (1, 0)}, {"X": None, "Y": None}, {"X": 0.0, "Y": 0.0})
+    np.testing.assert_array_equal(grid.derivative(ds.data_c, "X").values, (want_pad[..., 1:] - want_pad[..., :-1]) / dxl)
+    wpad = T.pad_face_connections(c * dx, ("face", "y", "x"), "face", {"X": "x", "Y": "y"}, CUBED_SPHERE["face"],
+                                  ["X", "Y"], {"X": (1, 0)}, {"X": None, "Y": None}, {"X": 0.0, "Y": 0.0})
+    got = grid.interp(ds.data_c, "X", metric_weighted="X").values
+    np.testing.assert_array_equal(got, ((wpad[..., :-1] + wpad[..., 1:]) / 2.0) / dxl)

@@ -423,7 +423,7 @@ __device__ __forceinline__ u64 wave_id() {
 template <int OP, int V, int MET, bool NTL, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_strided(
     const real* __restrict__ in, real* __restrict__ out, Geo g, int seg, u32 nseg, u32 ntile,
-    int pad_lo, int bc, real fill, const real* __restrict__ m_in, MIdx mi,
+    int pad_lo, int bc, real fill, const real* __restrict__ halo, const real* __restrict__ m_in, MIdx mi,
     const real* __restrict__ m_out, MIdx mo) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
@@ -463,12 +463,11 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided(
   };
   auto loadP = [&](int64_t k) -> T {
     int64_t q = k - pad_lo;
-    if (q < 0) {
+    if (q < 0 || q >= g.n_in) {
       if (bc == XG_BC_FILL) return splat<T>(fill);
-      q = (bc == XG_BC_PERIODIC) ? g.n_in - 1 : 0;
-    } else if (q >= g.n_in) {
-      if (bc == XG_BC_FILL) return splat<T>(fill);
-      q = (bc == XG_BC_PERIODIC) ? 0 : g.n_in - 1;
+      if (bc == XG_BC_HALO)  // halo values gathered beforehand: layout (outer, pad_lo + pad_hi, inner)
+        return *reinterpret_cast<const T*>(halo + ((o * (g.n_out - g.n_in + 1) + (q < 0 ? 0 : pad_lo)) * inner + x));
+      q = (q < 0) ? ((bc == XG_BC_PERIODIC) ? g.n_in - 1 : 0) : ((bc == XG_BC_PERIODIC) ? 0 : g.n_in - 1);
     }
     return loadq(q);
   };
@@ -523,8 +522,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided(
 template <int OP, int V, int MET, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t row0, u32 nrows, u32 nblk, FastDiv per,
-    ZBand zb, int pad_lo, int bc, real fill, const real* __restrict__ m_in, MIdx mi,
-    const real* __restrict__ m_out, MIdx mo) {
+    ZBand zb, int pad_lo, int bc, real fill, const real* __restrict__ halo, const real* __restrict__ m_in,
+    MIdx mi, const real* __restrict__ m_out, MIdx mo) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   // XCD banding (see K2S): neighbouring workgroups share an L2, so the cache line holding a
   // workgroup's left neighbour is not fetched a second time by another XCD (-3 % HBM reads)
@@ -566,6 +565,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
       n = n * m_in[mib + (int64_t)nidx * mi.axis];
     }
     if (edge && bc == XG_BC_FILL) n = fill;
+    if (edge && bc == XG_BC_HALO) n = halo[(row0 + r) * (int64_t)(Lo - Li + 1)];  // one halo cell per row here
     dv res;
     if (pad_lo) {
       res[0] = op2<OP>(n, a[0]);
@@ -590,6 +590,11 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     }
     if (fl) l = fill;
     if (fr) rr = fill;
+    if (bc == XG_BC_HALO) {
+      const int64_t hb = (row0 + r) * (int64_t)(Lo - Li + 1);
+      if ((int64_t)i0 - pad_lo < 0) l = halo[hb];
+      if ((int64_t)i0 + 1 - pad_lo >= (int64_t)Li) rr = halo[hb + pad_lo];
+    }
     real res = op2<OP>(l, rr);
     if (HAS_MO) res = res / m_out[mob + (int64_t)i0 * mo.axis];
     stg<real, NTS>(orow + i0, res);
@@ -606,8 +611,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
 template <int OP, int MET, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
     const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t row0, u32 nelem, u32 nblk,
-    FastDiv fLo, int pad_lo, int bc, real fill, const real* __restrict__ m_in, MIdx mi,
-    const real* __restrict__ m_out, MIdx mo) {
+    FastDiv fLo, int pad_lo, int bc, real fill, const real* __restrict__ halo, const real* __restrict__ m_in,
+    MIdx mi, const real* __restrict__ m_out, MIdx mo) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
@@ -630,6 +635,11 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
     }
     if (fl) l = fill;
     if (fr) rr = fill;
+    if (bc == XG_BC_HALO) {
+      const int64_t hb = (row0 + r) * (int64_t)(Lo - Li + 1);
+      if ((int64_t)i - pad_lo < 0) l = halo[hb];
+      if ((int64_t)i + 1 - pad_lo >= (int64_t)Li) rr = halo[hb + pad_lo];
+    }
     real res = op2<OP>(l, rr);
     if (HAS_MO) res = res / m_out[outer_off32(g, mo, (u32)(row0 + r)) + (int64_t)i * mo.axis];
     return res;
@@ -688,7 +698,7 @@ template <int OP, int V, int MET, bool NTS, int SEG>
 __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
     const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk,
     FastDiv ntile, FastDiv nseg, ZBand zb, Chunk ck, int pad_lo, int bc, real fill,
-    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+    const real* __restrict__ halo, const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   // banding: XCD (b % 8) owns logical blocks [xcd * pb, (xcd + 1) * pb)
@@ -741,9 +751,17 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
     int64_t k = j0 + ((u <= nrow) ? u : nrow);  // clamp inside the padded range for short tails
     int64_t q = k - pad_lo;
     bool f = false;
-    if (q < 0) { f = (bc == XG_BC_FILL); q = (bc == XG_BC_PERIODIC) ? g.n_in - 1 : 0; }
-    else if (q >= g.n_in) { f = (bc == XG_BC_FILL); q = (bc == XG_BC_PERIODIC) ? 0 : g.n_in - 1; }
-    T t = *reinterpret_cast<const T*>(pin + q * inner);
+    const real* src = pin;
+    if (q < 0 || q >= g.n_in) {
+      f = (bc == XG_BC_FILL);
+      if (bc == XG_BC_HALO) {  // pre-gathered halo rows, layout (outer, pad_lo + pad_hi, inner)
+        src = halo + (o * (g.n_out - g.n_in + 1)) * inner + x;
+        q = (q < 0) ? 0 : pad_lo;
+      } else {
+        q = (q < 0) ? ((bc == XG_BC_PERIODIC) ? g.n_in - 1 : 0) : ((bc == XG_BC_PERIODIC) ? 0 : g.n_in - 1);
+      }
+    }
+    T t = *reinterpret_cast<const T*>(src + q * inner);
     if (HAS_MI) t = t * ldm<T>(m_in, mib + q * mi.axis, mis);
     v[u] = f ? splat<T>(fill) : t;
   }
@@ -1502,7 +1520,7 @@ inline unsigned march_lds() {
 
 // dispatch on (OP, V, MET, NT) -> template instance
 struct StencilCall {
-  const real* in; real* out; Geo g; int pad_lo, pad_hi, bc; real fill;
+  const real* in; real* out; Geo g; int pad_lo, pad_hi, bc; real fill; const real* halo;
   const real* m_in; MIdx mi; const real* m_out; MIdx mo; hipStream_t st;
 };
 
@@ -1516,9 +1534,9 @@ int launch_march(const StencilCall& c) {
   const u64 nblocks = (ntask + WPB - 1) / WPB;
   if (nblocks == 0 || nblocks > 0x7fffffffull) return fail(XG_ERR_UNSUPPORTED, "launch of %llu blocks exceeds grid limits", nblocks);
   if (tune().nt_store)
-    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
   else
-    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, false>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, false>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
   return 0;
 }
 
@@ -1538,9 +1556,9 @@ int launch_contig_gen(const StencilCall& c) {
     const u32 nblk = (u32)((((u64)nelem + NV - 1) / NV + BLOCK - 1) / BLOCK);
     const u32 grid = ((nblk + 7) / 8) * 8;
     if (tune().nt_store)
-      hipLaunchKernelGGL((k_stencil_contig_gen<OP, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nelem, nblk, fLo, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_contig_gen<OP, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nelem, nblk, fLo, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
     else
-      hipLaunchKernelGGL((k_stencil_contig_gen<OP, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nelem, nblk, fLo, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_contig_gen<OP, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nelem, nblk, fLo, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
   }
   return 0;
 }
@@ -1572,9 +1590,9 @@ int launch_contig(const StencilCall& c) {
     const u32 nblk = (u32)(((u64)nrows * per + BLOCK - 1) / BLOCK);
     const u32 grid = ((nblk + 7) / 8) * 8;
     if (tune().nt_store)
-      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
     else
-      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
   }
   return 0;
 }
@@ -1602,9 +1620,9 @@ int launch_seg(const StencilCall& c) {
       const u32 nblk = (u32)((waves + WPB - 1) / WPB);
       const u32 grid = ((nblk + 7) / 8) * 8;
       if (tune().nt_store)
-        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
       else
-        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
       return 0;
     }
   }
@@ -1614,9 +1632,9 @@ int launch_seg(const StencilCall& c) {
     const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
     if (tune().nt_store)
-      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, ck, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, ck, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
     else
-      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, ck, c.pad_lo, c.bc, c.fill, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, ck, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
   }
   return 0;
 }
@@ -1709,14 +1727,16 @@ int xg_event_elapsed_ms(void* start, void* stop, float* ms) {
 int xg_event_destroy(void* ev) { XG_HIP(hipEventDestroy((hipEvent_t)ev)); return 0; }
 #endif  // XG_PRIMARY
 
-int XG_FN(xg_stencil1d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int axis,
-                     int64_t n_out, int pad_lo, int pad_hi, int bc, real fill, const real* m_in,
-                     const int64_t* m_in_strides, const real* m_out, const int64_t* m_out_strides,
-                     void* stream) {
+static int stencil1d_impl(int op, const real* in, const real* halo, real* out, const int64_t* shape, int ndim,
+                          int axis, int64_t n_out, int pad_lo, int pad_hi, int bc, real fill, const real* m_in,
+                          const int64_t* m_in_strides, const real* m_out, const int64_t* m_out_strides,
+                          void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
   if ((pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "pad widths must be 0 or 1, got (%d,%d)", pad_lo, pad_hi);
-  if (bc < XG_BC_NONE || bc > XG_BC_EXTEND) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
+  if (bc < XG_BC_NONE || bc > XG_BC_HALO) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
+  if (bc == XG_BC_HALO && !halo) return fail(XG_ERR_INVALID, "XG_BC_HALO without a halo buffer");
+  if (bc == XG_BC_HALO && m_in) return fail(XG_ERR_UNSUPPORTED, "pre-gathered halos cannot be combined with an input metric");
   if ((m_in && !m_in_strides) || (m_out && !m_out_strides)) return fail(XG_ERR_INVALID, "metric without strides");
   Geo g; MIdx mi, mo;
   int rc = build_geo(shape, ndim, axis, n_out, m_in ? m_in_strides : nullptr, m_out ? m_out_strides : nullptr, &g, &mi, &mo);
@@ -1726,8 +1746,8 @@ int XG_FN(xg_stencil1d)(int op, const real* in, real* out, const int64_t* shape,
   if (g.n_in < 1) return fail(XG_ERR_INVALID, "empty stencil axis");
   if (g.outer == 0 || g.inner == 0 || n_out <= 0) return XG_OK;  // empty output
   const int met = (m_out ? 1 : 0) | (m_in ? 2 : 0);
-  const bool al = aligned16(in) && aligned16(out);
-  StencilCall c = {in, out, g, pad_lo, pad_hi, bc, fill, m_in, mi, m_out, mo, (hipStream_t)stream};
+  const bool al = aligned16(in) && aligned16(out) && (bc != XG_BC_HALO || aligned16(halo));
+  StencilCall c = {in, out, g, pad_lo, pad_hi, bc, fill, halo, m_in, mi, m_out, mo, (hipStream_t)stream};
   int V, kind;
   if (g.inner == 1) {
     kind = KIND_CONTIG;
@@ -1748,6 +1768,24 @@ int XG_FN(xg_stencil1d)(int op, const real* in, real* out, const int64_t* shape,
   if (rc) return rc;
   XG_LAUNCH_CHECK();
   return XG_OK;
+}
+
+int XG_FN(xg_stencil1d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int axis,
+                     int64_t n_out, int pad_lo, int pad_hi, int bc, real fill, const real* m_in,
+                     const int64_t* m_in_strides, const real* m_out, const int64_t* m_out_strides,
+                     void* stream) {
+  if (bc == XG_BC_HALO) return fail(XG_ERR_INVALID, "XG_BC_HALO needs xg_stencil1d_halo");
+  return stencil1d_impl(op, in, nullptr, out, shape, ndim, axis, n_out, pad_lo, pad_hi, bc, fill, m_in, m_in_strides,
+                        m_out, m_out_strides, stream);
+}
+
+int XG_FN(xg_stencil1d_halo)(int op, const real* in, const real* halo, real* out, const int64_t* shape, int ndim,
+                          int axis, int64_t n_out, int pad_lo, int pad_hi, const real* m_out,
+                          const int64_t* m_out_strides, void* stream) {
+  if (!halo && (pad_lo || pad_hi)) return fail(XG_ERR_INVALID, "NULL halo buffer");
+  return stencil1d_impl(op, in, halo, out, shape, ndim, axis, n_out, pad_lo, pad_hi,
+                        (pad_lo || pad_hi) ? XG_BC_HALO : XG_BC_NONE, real(0), nullptr, nullptr, m_out, m_out_strides,
+                        stream);
 }
 
 int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim, int axis, int reverse,

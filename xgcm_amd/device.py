@@ -25,6 +25,7 @@ __all__ = [
     "tohost",
     "is_device_array",
     "stencil1d",
+    "stencil1d_halo",
     "cumsum1d",
     "reduce1d",
     "pad_nd",
@@ -146,6 +147,35 @@ def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str]
             _ptr(m_in), _hip.i64(_bstrides(m_in, shape, "m_in")),
             _ptr(m_out), _hip.i64(_bstrides(m_out, oshape, "m_out")), _stream(),
         )
+    )
+    return out
+
+
+def stencil1d_halo(op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, m_out=None) -> torch.Tensor:
+    """diff / interp / min / max along `axis` with pre-gathered halo cells (xg_stencil1d_halo_f64):
+    `halo` is shaped like `x` with `axis` shortened to pad_lo + pad_hi, low halo first."""
+    lib = _hip.load()
+    dt, sfx = _common(x, halo, m_out)
+    x = asdevice(x, dt)
+    halo = asdevice(halo, dt)
+    axis = axis % x.dim()
+    n = x.shape[axis]
+    expect = list(x.shape)
+    expect[axis] = pad_lo + pad_hi
+    if list(halo.shape) != expect:
+        raise ValueError(f"halo buffer has shape {tuple(halo.shape)}, expected {tuple(expect)}")
+    n_out = n + pad_lo + pad_hi - 1
+    oshape = list(x.shape)
+    oshape[axis] = n_out
+    out = torch.empty(oshape, dtype=dt, device=x.device)
+    if out.numel() == 0:
+        return out
+    m_out = _prep_metric(m_out, dt)
+    _hip.check(
+        getattr(lib, "xg_stencil1d_halo_" + sfx)(
+            _hip.OP[op], x.data_ptr(), halo.data_ptr() if halo.numel() else None, out.data_ptr(),
+            _hip.i64(list(x.shape)), x.dim(), axis, n_out, int(pad_lo), int(pad_hi), _ptr(m_out),
+            _hip.i64(_bstrides(m_out, oshape, "m_out")), _stream())
     )
     return out
 

@@ -435,7 +435,8 @@ class Grid:
                 else:
                     post_divide = dx  # two successive divisions cannot be merged bit-exactly
             arg = {vector_key: array} if vector_key is not None else array
-            if isinstance(ufunc, gridops.HipGridUFunc):
+            unfusable_metric = m_in is not None and gridops.complex_topology(self, ax_name)
+            if isinstance(ufunc, gridops.HipGridUFunc) and not unfusable_metric:
                 array = ufunc(self, arg, axis=[(ax_name,)], other_component=other_component, metric_in=m_in,
                               metric_out=m_out, **remaining)
             else:  # a plain GridUFunc registered in gridops (none of the built-ins): unfused sequence

@@ -23,7 +23,7 @@ from .grid_ufunc import (
     _reattach_coords,
 )
 from .labeled import DataArray, _aligned_view, _is_tensor
-from .padding import no_boundary_error
+from .padding import halo_cells, no_boundary_error
 
 # (from, to) -> padding_width of the two-point stencils (reference gridops.py:27-65)
 _STENCIL_WIDTHS = {
@@ -63,6 +63,12 @@ def _cumsum(data, *args):
     return _same_residency(data, _dev.cumsum1d(data, *args))
 
 
+def complex_topology(grid, ax_name: str) -> bool:
+    """True when halos along `ax_name` do not follow from the array itself: face connections
+    (every axis) or a north fold on this axis (the seam axis of a fold stays an ordinary wrap)."""
+    return getattr(grid, "_face_connections", None) is not None or ax_name in (getattr(grid, "_folds", None) or {})
+
+
 class HipGridUFunc(GridUFunc):
     """A built-in 1-D grid ufunc whose labelled call is a single fused kernel launch."""
 
@@ -77,16 +83,16 @@ class HipGridUFunc(GridUFunc):
     def _fusable(self, grid, args, axis, kwargs) -> bool:
         if grid is None or len(args) != 1 or axis is None or len(axis) != 1 or len(axis[0]) != 1:
             return False
-        if getattr(grid, "_face_connections", None) is not None:
-            return False  # halos come from neighbouring faces: generic pad (xg_gather) then apply
-        if axis[0][0] in (getattr(grid, "_folds", None) or {}):
-            return False  # the north edge of this axis folds: generic pad then apply
         extra = set(kwargs) - {"padding", "fill_value", "dask", "map_overlap", "other_component", "pad_before_func",
                                "metric_in", "metric_out"}
         if extra:
             return False
         if kwargs.get("pad_before_func", self.pad_before_func) != self.pad_before_func:
             return False
+        if complex_topology(grid, axis[0][0]):
+            # halos come from neighbouring faces / the folded row: gathered first, then the same
+            # kernels (xg_stencil1d_halo); scans and input metrics keep the reference's pad-then-apply
+            return self.funcname != "cumsum" and kwargs.get("metric_in") is None
         return True
 
     def __call__(self, grid=None, *args, axis, **kwargs):
@@ -99,7 +105,7 @@ class HipGridUFunc(GridUFunc):
         return self._fused(grid, args[0], axis[0][0], **kwargs)
 
     def _fused(self, grid, arg, ax_name: str, padding="__default__", fill_value="__default__", metric_in=None,
-               metric_out=None, **_ignored):
+               metric_out=None, other_component=None, **_ignored):
         arg = _check_data_input(arg, grid)
         da = _maybe_unpack_vector_component(arg)
         if padding == "__default__":
@@ -123,21 +129,27 @@ class HipGridUFunc(GridUFunc):
         except KeyError:
             raise ValueError(f"Axis position ({ax_name}:{self.to_pos}) does not exist in grid")
 
-        bc = grid._complete_user_kwargs_using_axis_defaults(padding, "padding")[ax_name]
-        fv = grid._complete_user_kwargs_using_axis_defaults(fill_value, "fill_value")[ax_name]
-        fv = 0.0 if fv is None else float(fv)
         (lo, hi) = next(iter(self.padding_width.values())) if self.padding_width else (0, 0)
-        if (lo or hi) and bc is None:
-            raise no_boundary_error(ax_name)
-        if isinstance(bc, Mapping):
-            raise NotImplementedError("north-fold padding is not supported by the MI355X backend")
-        if not (lo or hi):
-            bc = None
-
         num = da.get_axis_num(in_dim)
         out_dims = tuple(out_dim if d == in_dim else d for d in da.dims)
         m_in = None if metric_in is None else _aligned_view(metric_in, da.dims)
         m_out = None if metric_out is None else _aligned_view(metric_out, out_dims)
+        if complex_topology(grid, ax_name) and (lo or hi):
+            # the halo cells alone (a (lo+hi)-wide slab) are gathered through the token map, then
+            # the ordinary kernel reads the field once: no padded copy (reference: pad, then apply)
+            halo = halo_cells(arg, grid, ax_name, (lo, hi), padding=padding, fill_value=fill_value,
+                              other_component=other_component)
+            data = _same_residency(da.data, _dev.stencil1d_halo(self.funcname, da.data, halo.data, num, lo, hi, m_out))
+            res = DataArray(data, out_dims, name=da.name)
+            return _reattach_coords([res], grid, self.padding_width, {out_dim}, [da])[0]
+
+        bc = grid._complete_user_kwargs_using_axis_defaults(padding, "padding")[ax_name]
+        fv = grid._complete_user_kwargs_using_axis_defaults(fill_value, "fill_value")[ax_name]
+        fv = 0.0 if fv is None else float(fv)
+        if (lo or hi) and bc is None:
+            raise no_boundary_error(ax_name)
+        if not (lo or hi):
+            bc = None
         if self.funcname == "cumsum":
             _, _, _, drop_last = _CUMSUM_TABLE[(self.from_pos, self.to_pos)]
             data = _cumsum(da.data, num, 0, 1 if drop_last else 0, lo, hi, bc, fv, False, False, m_in, m_out)

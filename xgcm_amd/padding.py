@@ -52,6 +52,7 @@ def _strip_all_coords(obj):
 def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding=None, fill_value=None,
         other_component=None, **kwargs):
     """Pad `data` along the given grid axes according to the boundary conditions."""
+    halo_only = kwargs.pop("_halo_only", None)  # internal: see `halo_cells`
     if "boundary" in kwargs:
         raise ValueError("Argument 'boundary' has been renamed to 'padding'. Please use 'padding' instead.")
     if "boundary_width" in kwargs:
@@ -65,9 +66,11 @@ def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding
         return data
     data = _strip_all_coords(data)
     if getattr(grid, "_face_connections", None) is not None:
-        return _pad_face_connections(data, grid, padding_width, padding, fill_value, other_component)
+        return _pad_face_connections(data, grid, padding_width, padding, fill_value, other_component, halo_only)
     if getattr(grid, "_folds", None) and any(ax in grid._folds for ax in padding_width):
-        return _pad_fold(data, grid, padding_width, padding, fill_value)
+        return _pad_fold(data, grid, padding_width, padding, fill_value, halo_only)
+    if halo_only is not None:
+        raise ValueError("halo-only padding is meant for complex topologies")
     if isinstance(data, dict):
         [data] = list(data.values())
     return _pad_basic(data, grid, padding_width, padding, fill_value)
@@ -183,15 +186,33 @@ def _axis_dims(grid) -> Dict[str, Tuple[str, ...]]:
     return {name: tuple(ax.coords.values()) for name, ax in grid.axes.items()}
 
 
-def _gather(data: DataArray, partner: Optional[DataArray], grid, key, build, partner_same_as=None) -> DataArray:
+def halo_cells(data, grid, ax_name: str, widths: Tuple[int, int], padding=None, fill_value=None,
+               other_component=None) -> DataArray:
+    """Only the halo cells `pad` would add along `ax_name` on a complex topology: an array shaped
+    like the input with that axis shortened to lo + hi (low halo first).  Feeds
+    xg_stencil1d_halo_f64, which then needs no padded copy of the field."""
+    return pad(data, grid, {ax_name: tuple(widths)}, padding=padding, fill_value=fill_value,
+               other_component=other_component, _halo_only=ax_name)
+
+
+def _gather(data: DataArray, partner: Optional[DataArray], grid, key, build, partner_same_as=None,
+            halo_dim: Optional[str] = None) -> DataArray:
     """Run (or reuse) the token-plane builder `build()` -> (plane, mapped dims, lo per dim, fills)
-    and move the data through it."""
+    and move the data through it.  With `halo_dim` only the halo cells along that dim are produced."""
     cache = grid.__dict__.setdefault("_halo_maps", {})
+    key = key + (halo_dim,)
     entry = cache.get(key)
     if entry is None:
         plane, lo_of_dim, fills = build()
         mapped_dims = tuple(d for d in data.dims if d in plane.dims)
         plane = plane.transpose(mapped_dims)
+        if halo_dim is not None:
+            lo_h = int(lo_of_dim.get(halo_dim, 0))
+            n_in = data.sizes[halo_dim]
+            plane = _hm.Plane.concat([plane.isel(halo_dim, slice(0, lo_h)), plane.isel(halo_dim, slice(lo_h + n_in, None))],
+                                     halo_dim)
+            lo_of_dim = dict(lo_of_dim)
+            lo_of_dim[halo_dim] = plane.size(halo_dim) + n_in + 1  # no cell of this plane is an interior cell
         entry = {"tokens": np.ascontiguousarray(plane.a), "sizes": dict(zip(mapped_dims, plane.a.shape)),
                  "lo": lo_of_dim, "fills": list(fills.values), "device": None}
         if len(cache) > 64:
@@ -230,7 +251,7 @@ def _fill_key(fill_value: Mapping) -> Tuple:
 # ------------------------------------------------------------------------------------------
 # north fold (reference padding.py:689-762)
 # ------------------------------------------------------------------------------------------
-def _pad_fold(data, grid, padding_width, padding, fill_value) -> DataArray:
+def _pad_fold(data, grid, padding_width, padding, fill_value, halo_only=None) -> DataArray:
     isvector = isinstance(data, dict)
     if isvector:
         # a fold is a 180-degree pivot: the lone component flips sign, no partner is needed
@@ -249,10 +270,10 @@ def _pad_fold(data, grid, padding_width, padding, fill_value) -> DataArray:
         else:
             basic_width[ax] = tuple(w)
             basic_padding[ax] = padding[ax]
-    if not fold_axes:
+    if not fold_axes and halo_only is None:
         return _pad_basic(data, grid, basic_width, basic_padding, fill_value)
 
-    fax = fold_axes[0]
+    fax = fold_axes[0] if fold_axes else halo_only
     info = grid._folds[fax]
     seam_axis = info["seam_axis"]
     pivot = _resolve_pivot(info["pivot"], fax, seam_axis)
@@ -269,14 +290,15 @@ def _pad_fold(data, grid, padding_width, padding, fill_value) -> DataArray:
     def build():
         fills = _hm.FillTable()
         plane = _hm.identity_plane(sizes, mapped_dims)
-        plane = _hm.fold_plane(plane, fold_dim, fold_position, seam_dim, seam_position, pivot, width, isvector, fax)
+        if width > 0:
+            plane = _hm.fold_plane(plane, fold_dim, fold_position, seam_dim, seam_position, pivot, width, isvector, fax)
         plane = _hm.basic_pad(plane, dim_of_axis, basic_width, basic_padding, fill_value, fills, no_boundary_error)
         lo = {dim_of_axis[ax]: int(w[0]) for ax, w in basic_width.items() if ax in dim_of_axis}
         return plane, lo, fills
 
     key = ("fold", data.dims, sizes, fax, tuple((k, tuple(v)) for k, v in padding_width.items()),
            tuple(sorted(basic_padding.items(), key=str)), _fill_key(fill_value), isvector, repr(info["pivot"]))
-    return _gather(data, None, grid, key, build)
+    return _gather(data, None, grid, key, build, None, None if halo_only is None else dim_of_axis[halo_only])
 
 
 # ------------------------------------------------------------------------------------------
@@ -312,7 +334,8 @@ def _get_all_connection_axes(connections, facedim):
     return found
 
 
-def _pad_face_connections(da, grid, padding_width, padding, fill_value, other_component=None) -> DataArray:
+def _pad_face_connections(da, grid, padding_width, padding, fill_value, other_component=None,
+                          halo_only=None) -> DataArray:
     facedim = grid._facedim
     connections = grid._face_connections
     if connections is None:
@@ -403,4 +426,4 @@ def _pad_face_connections(da, grid, padding_width, padding, fill_value, other_co
                     own = [c for c in cand if c in da.dims]
                     if own:
                         same_as[d] = own[0]
-    return _gather(da, partner, grid, key, build, same_as)
+    return _gather(da, partner, grid, key, build, same_as, None if halo_only is None else dims_own[halo_only])
