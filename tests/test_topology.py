@@ -633,3 +633,16 @@ def test_metrics_on_connected_grid(backend):
                                   ["X", "Y"], {"X": (1, 0)}, {"X": None, "Y": None}, {"X": 0.0, "Y": 0.0})
     got = grid.interp(ds.data_c, "X", metric_weighted="X").values
     np.testing.assert_array_equal(got, ((wpad[..., :-1] + wpad[..., 1:]) / 2.0) / dxl)
+
+
+def test_two_axes_on_connected_grid_run_one_axis_at_a_time(backend):
+    """`diff(da, ["X", "Y"])` must not take the simple-topology two-axis kernel on a connected grid."""
+    ds = _faces_ds(6, 4, seed=61)
+    grid = Grid(ds, coords=COORDS, face_connections=CUBED_SPHERE, padding="fill", autoparse_metadata=False)
+    both = grid.diff(ds.data_c, ["X", "Y"]).values
+    seq = grid.diff(grid.diff(ds.data_c, "X"), "Y").values
+    np.testing.assert_array_equal(both, seq)
+    plain = Grid(ds, coords=COORDS, padding="fill", autoparse_metadata=False)
+    assert not np.array_equal(both, plain.diff(ds.data_c, ["X", "Y"]).values)
+    with pytest.raises(NotImplementedError, match="chain the operators"):
+        grid.vorticity(ds.u, ds.v)

@@ -460,8 +460,8 @@ class Grid:
         if array.ndim < 2 or getattr(array, "chunks", None) is not None:
             return None
         (sig_a, ax_a), (sig_b, ax_b) = step_a, step_b
-        if ax_a == ax_b:
-            return None
+        if ax_a == ax_b or gridops.complex_topology(self, ax_a) or gridops.complex_topology(self, ax_b):
+            return None  # halos from other faces / the folded row: one axis at a time (xg_stencil1d_halo)
         ufa, _ = _select_grid_ufunc(funcname, sig_a, module=gridops)
         ufb, _ = _select_grid_ufunc(funcname, sig_b, module=gridops)
         if not (isinstance(ufa, gridops.HipGridUFunc) and isinstance(ufb, gridops.HipGridUFunc)):
@@ -687,6 +687,11 @@ class Grid:
         center->left; the reference's own docs motivate fusing it (docs/grid_ufuncs.md:27)."""
         (u, xr1), (v, xr2) = self._wrap_in(u), self._wrap_in(v)
         xa, ya = self.axes[x_axis], self.axes[y_axis]
+        if gridops.complex_topology(self, x_axis) or gridops.complex_topology(self, y_axis):
+            raise NotImplementedError(
+                "fused vorticity is implemented for simple topologies; on grids with face connections or a "
+                "north fold chain the operators: (grid.diff(v, X) - grid.diff(u, Y)) / area"
+            )
         vx_pos, vx_dim = xa._get_position_name(v)
         uy_pos, uy_dim = ya._get_position_name(u)
         if (vx_pos, uy_pos) != ("center", "center") or "left" not in xa.coords or "left" not in ya.coords:
