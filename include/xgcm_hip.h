@@ -26,6 +26,9 @@
  *   xg_pad_f64         xgcm/padding.py:765-871 (pad) for user grid-ufuncs of any width
  *   xg_gather_f64      xgcm/padding.py:260-572 (_pad_face_connections) and :619-762 (_fold_north_halo,
  *                      _pad_fold): halos of complex topologies as one gather through a token map
+ *   xg_transform_linear_f64 / xg_transform_conservative_f64
+ *                      xgcm/transform.py:15-41 (_interp_1d_linear) and :88-142
+ *                      (_interp_1d_conservative), the numba gufuncs behind Grid.transform
  *   xg_binary_f64      the xarray broadcasting `*`, `/`, `+`, `-` around the ops
  *                      (xgcm/grid.py:808,832,1578,1600; get_metric products :614-617)
  *   xg_stencil2d_f64   Grid.interp/diff/min/max over two axes (xgcm/grid.py:798-828), one pass
@@ -140,6 +143,28 @@ int xg_gather_f64(const double* in, const double* partner, double* out, const in
                   const int64_t* tokens, int64_t n_tokens, const double* fills, int n_fills,
                   void* stream);
 
+/* ---- vertical coordinate transform (xgcm/transform.py:15-142) ----------------------------- */
+/* Per column along `axis` of `phi` (shape[ndim], C-contiguous):
+ *   linear:       out[.., i, ..] = numpy.interp(target[i], theta[:], phi[:]) with the reference's
+ *                 pre-steps: optional log of theta/target (`logarithmic`), flip when theta decreases
+ *                 (first vs last non-NaN value; skipped if `bypass_checks`), NaN outside
+ *                 [nanmin(theta), nanmax(theta)] if `mask_edges`.  numpy's search (carried guess,
+ *                 probes, bisection) is reproduced, so NaN / duplicate thetas give numpy's answer.
+ *   conservative: phi (n cells) is spread over the bins [bins[j], bins[j+1]) by the overlap of
+ *                 each cell's theta range (theta has n + 1 vertices along `axis`), contributions
+ *                 added in cell order; bins increasing (the host flips decreasing targets).
+ * `theta` / `target` are addressed through element strides per dim of `shape` (0 = broadcast;
+ * the entry at `axis` is the step between levels).  `out` has `shape` with `axis` -> m levels
+ * (linear) or n_edges - 1 bins (conservative): the new dim stays where the axis was. */
+int xg_transform_linear_f64(const double* phi, const double* theta, const int64_t* theta_strides,
+                            const double* target, const int64_t* target_strides, int64_t m,
+                            double* out, const int64_t* shape, int ndim, int axis, int mask_edges,
+                            int bypass_checks, int logarithmic, void* stream);
+int xg_transform_conservative_f64(const double* phi, const double* theta,
+                                  const int64_t* theta_strides, const double* bins,
+                                  int64_t n_edges, double* out, const int64_t* shape, int ndim,
+                                  int axis, void* stream);
+
 /* ---- broadcasting elementwise arithmetic ------------------------------------------------ */
 /* out[idx] = a[idx . a_strides] OP b[idx . b_strides] over `shape` (out C-contiguous). */
 int xg_binary_f64(int op, const double* a, const int64_t* a_strides, const double* b,
@@ -195,6 +220,14 @@ int xg_gather_f32(const float* in, const float* partner, float* out, const int64
                   const int* mapped, const int* partner_perm, const int64_t* lo,
                   const int64_t* tokens, int64_t n_tokens, const float* fills, int n_fills,
                   void* stream);
+int xg_transform_linear_f32(const float* phi, const float* theta, const int64_t* theta_strides,
+                            const float* target, const int64_t* target_strides, int64_t m,
+                            float* out, const int64_t* shape, int ndim, int axis, int mask_edges,
+                            int bypass_checks, int logarithmic, void* stream);
+int xg_transform_conservative_f32(const float* phi, const float* theta,
+                                  const int64_t* theta_strides, const float* bins, int64_t n_edges,
+                                  float* out, const int64_t* shape, int ndim, int axis,
+                                  void* stream);
 int xg_binary_f32(int op, const float* a, const int64_t* a_strides, const float* b,
                   const int64_t* b_strides, float* out, const int64_t* shape, int ndim,
                   void* stream);

@@ -66,6 +66,25 @@ def stencil1d_halo(op, x, halo, axis, pad_lo, pad_hi, m_out=None):
     return R.stencil1d(op, np.concatenate([lo, x, hi], axis=axis), axis, 0, 0, None, 0.0, None, m_out)
 
 
+def transform_linear(phi, theta, target, axis, mask_edges=True, bypass_checks=False, logarithmic=False):
+    from . import transform as TR
+
+    phi, theta, target = _cast(_common(phi, theta, target), phi, theta, target)
+    axis = axis % phi.ndim
+    mv = lambda a: np.moveaxis(a, axis, -1)  # noqa: E731
+    out = TR.interp_1d_linear(mv(phi), mv(theta), mv(target), mask_edges, bypass_checks, logarithmic)
+    return np.ascontiguousarray(np.moveaxis(out, -1, axis))
+
+
+def transform_conservative(phi, theta, bins, axis):
+    from . import transform as TR
+
+    phi, theta, bins = _cast(_common(phi, theta, bins), phi, theta, bins)
+    axis = axis % phi.ndim
+    out = TR.interp_1d_conservative(np.moveaxis(phi, axis, -1), np.moveaxis(theta, axis, -1), bins)
+    return np.ascontiguousarray(np.moveaxis(out, -1, axis))
+
+
 def upload_tokens(tokens):
     return np.ascontiguousarray(tokens, dtype=np.int64)
 
@@ -112,7 +131,7 @@ def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None, dtype=np.f
     return R.synthetic(int(np.prod(shape)), seed, offset, scale, shift).reshape(tuple(shape)).astype(dtype)
 
 
-_NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "stencil1d_halo", "cumsum1d", "reduce1d", "pad_nd", "gather", "upload_tokens", "binary",
+_NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "stencil1d_halo", "cumsum1d", "reduce1d", "pad_nd", "gather", "upload_tokens", "transform_linear", "transform_conservative", "binary",
           "vorticity", "stencil2d", "stencil2d_supported", "synthetic"]
 
 

@@ -18,7 +18,9 @@ xarray is re-implemented -- and then import the reference's own modules and exec
   * ``_select_grid_ufunc`` (xgcm/grid.py:1779-1824);
   * ``iterate_axis_combinations`` (xgcm/metrics.py:4-30);
   * the north-fold index helpers ``_seam_partner_indices``, ``_resolve_pivot`` and
-    ``_parse_fold_padding`` (xgcm/padding.py:94-177) -> ``fold_reference.json``.
+    ``_parse_fold_padding`` (xgcm/padding.py:94-177) -> ``fold_reference.json``;
+  * the ``cases`` data table of xgcm/test/test_transform.py:40-686 (inputs + expected outputs of
+    the transform tests) -> ``transform_cases.json``.
 
 The xarray-level glue (apply_as_grid_ufunc, pad, Grid.cumsum ...) can NOT be executed; for
 it we transcribe the deterministic known-answer tests of the reference's own test-suite
@@ -476,6 +478,32 @@ def fold_cases():
     return {"seam_partner_indices": seam, "resolve_pivot": pivots, "parse_fold_padding": parses}
 
 
+def transform_cases():
+    """The `cases` table of the reference's transform tests (xgcm/test/test_transform.py:40-686):
+    inputs and expected outputs, evaluated here (its expected values call numpy.interp) and written
+    out as plain data.  Only that dictionary literal is executed; the module itself needs xarray."""
+    path = os.path.join(REF, "xgcm", "test", "test_transform.py")
+    with open(path) as f:
+        lines = f.read().splitlines()
+    start = next(i for i, ln in enumerate(lines) if ln.startswith("cases = {"))
+    stop = next(i for i, ln in enumerate(lines) if ln.startswith("def construct_test_source_data"))
+    ns = {"np": np}
+    exec("\n".join(lines[start:stop]), ns)  # noqa: S102  (reference test DATA, build container only)
+
+    def plain(v):
+        if isinstance(v, np.ndarray):
+            return plain(v.tolist())
+        if isinstance(v, (list, tuple)):
+            return [plain(x) for x in v]
+        if isinstance(v, dict):
+            return {k: plain(x) for k, x in v.items()}
+        if isinstance(v, (np.floating, np.integer)):
+            return v.item()
+        return v
+
+    return {name: plain(case) for name, case in ns["cases"].items()}
+
+
 def config1(gridops):
     """BASELINE.json configs[0]: Grid.diff along X on a 128 x 64 periodic C-grid (YC=64, XC=128), f64,
     center->left: the reference's own ufunc body on the numpy.pad(wrap)-ed synthetic field (seed 1)."""
@@ -505,6 +533,8 @@ def main():
         json.dump(kats(), f, indent=1)
     with open(os.path.join(OUT, "fold_reference.json"), "w") as f:
         json.dump(fold_cases(), f, indent=1)
+    with open(os.path.join(OUT, "transform_cases.json"), "w") as f:
+        json.dump(transform_cases(), f, indent=1)
     print("wrote fixtures to", os.path.normpath(OUT))
 
 

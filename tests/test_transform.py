@@ -1,0 +1,409 @@
+"""Vertical coordinate transform (reference xgcm/transform.py, Grid.transform).
+
+* `tests/golden/transform_cases.json` is the `cases` table of the reference's own test-suite
+  (xgcm/test/test_transform.py:40-686, inputs + expected outputs, written by oracle/make_golden.py);
+  it pins the oracle (oracle/transform.py) and, through `Grid.transform`, the product;
+* the reference's low / mid / high level tests (:849-1424) are mirrored with file:line references;
+* seeded sweeps (NaN-laden, decreasing, duplicated theta; broadcasting; float32) compare the HIP
+  kernels with the oracle: bit-exact for linear and conservative, 1e-12 for method="log" (libm).
+
+Product tests run twice via `backend`: CPU with the oracle-backed device double, GPU through the C ABI.
+"""
+
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import refimpl as R
+from oracle import transform as TR
+from xgcm_amd import DataArray, Dataset, Grid
+from xgcm_amd import transform as X
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+with open(os.path.join(GOLDEN, "transform_cases.json")) as f:
+    CASES = json.load(f)
+
+ALL = list(CASES)
+NOT_CONS_MULTIDIM = [c for c in ALL if not ("conservative" in c and "multidim_target" in c)]
+LINEAR_1D = [c for c in ALL if ("linear" in c or "log" in c) and "multidim_target" not in c]
+CONS_1D = [c for c in ALL if "conservative" in c and "multidim_target" not in c]
+MULTIDIM = ["conservative_depth_dens_nonmono_edge", "linear_depth_dens", "linear_depth_depth", "conservative_depth_temp"]
+
+
+def _arr(v):
+    return np.array(v, dtype=float)
+
+
+def construct(case):
+    """numpy/duck-array form of reference test_transform.py:688-769 `construct_test_source_data`."""
+    case = dict(case)
+
+    def make_da(prefix):
+        name, data = case[prefix + "_data"]
+        cname, cvals = case[prefix + "_coord"]
+        if prefix + "_dims" in case:
+            dims = tuple(case[prefix + "_dims"])
+            coords = {cname: (dims, _arr(cvals))}
+        else:
+            dims = (cname,)
+            coords = {cname: _arr(cvals)}
+        return DataArray(_arr(data), dims=dims, coords=coords, name=name)
+
+    def make_ds(prefix):
+        da = make_da(prefix)
+        ds = Dataset({da.name: da})
+        if prefix + "_additional_data" in case and prefix + "_additional_data_coord" in case:
+            an, av = case[prefix + "_additional_data"]
+            cn, cv = case[prefix + "_additional_data_coord"]
+            ds[an] = DataArray(_arr(av), dims=[cn], coords={cn: _arr(cv)}, name=an)
+        if prefix + "_bounds_coord" in case:
+            bn, bv = case[prefix + "_bounds_coord"]
+            ds[bn] = (bn, _arr(bv))
+        if prefix + "_data_mask_index" in case:
+            vals = ds[da.name].values.copy()
+            for ii in case[prefix + "_data_mask_index"]:
+                vals[tuple(ii) if isinstance(ii, list) else ii] = np.nan
+            ds[da.name] = DataArray(vals, dims=da.dims, coords=dict(da.coords), name=da.name)
+        return ds
+
+    source, expected, target = make_ds("source"), make_ds("expected"), make_da("target")
+    kw = dict(case["transform_kwargs"])
+    if kw.get("target_data") is not None:
+        kw["target_data"] = source[kw["target_data"]].copy()
+    return source, dict(case["grid_kwargs"]), target, kw, expected, case.get("error")
+
+
+def _expected(expected, kw):
+    return expected["data" + kw.get("suffix", "")]
+
+
+def _assert_like_reference(got, want):
+    """xr.testing.assert_allclose of the reference (rtol 1e-5, NaN == NaN, same dims)."""
+    assert tuple(got.dims) == tuple(want.dims)
+    np.testing.assert_allclose(got.values, want.values, rtol=1e-5, atol=1e-8, equal_nan=True)
+    for name, c in want.coords.items():
+        np.testing.assert_allclose(np.asarray(got.coords[name].values, dtype=float), np.asarray(c.values, dtype=float), rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------
+# the oracle against the reference's table (CPU)
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", LINEAR_1D)
+def test_oracle_linear_matches_reference_cases(name):
+    source, gkw, target, kw, expected, _ = construct(CASES[name])
+    theta = kw["target_data"].values if kw.get("target_data") is not None else source[source.data.dims[0]].values
+    out = TR.interp_1d_linear(source.data.values, theta, target.values, mask_edges=kw.get("mask_edges", True),
+                              logarithmic=kw["method"] == "log")
+    np.testing.assert_allclose(out, _expected(expected, kw).values, rtol=1e-5, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", [c for c in CONS_1D if not CASES[c].get("error")])
+def test_oracle_conservative_matches_reference_cases(name):
+    source, gkw, target, kw, expected, _ = construct(CASES[name])
+    bounds_dim = gkw["coords"]["Z"]["outer"]
+    theta = kw["target_data"].values if kw.get("target_data") is not None else source[bounds_dim].values
+    out = TR.interp_1d_conservative(source.data.values, theta, target.values)
+    np.testing.assert_allclose(out, _expected(expected, kw).values, rtol=1e-5, equal_nan=True)
+    np.testing.assert_allclose(np.nansum(out), np.nansum(source.data.values))  # test_transform.py:1043
+
+
+# ----------------------------------------------------------------------------------------------
+# low level (test_transform.py:849-921)
+# ----------------------------------------------------------------------------------------------
+def test_interp_1d_linear(backend):
+    """:849-864: uniformly stratified scalar, analytic answer."""
+    nz, nx = 100, 1000
+    zv = np.linspace(0, 1, nz + 1)
+    z = 0.5 * (zv[:-1] + zv[1:])
+    x = 2 * np.pi * np.linspace(0, 1, nx)
+    theta = z + 0.1 * np.cos(3 * x)[:, None]
+    phi = np.sin(theta) + 0.1 * np.cos(5 * x)[:, None]
+    levels = np.arange(0.2, 0.9, 0.025)
+    got = X.interp_1d_linear(phi, theta, levels, mask_edges=False)
+    np.testing.assert_allclose(got, np.sin(levels) + 0.1 * np.cos(5 * x)[:, None], rtol=1e-4)
+    np.testing.assert_array_equal(got, TR.interp_1d_linear(phi, theta, levels, mask_edges=False))
+
+
+def test_interp_1d_conservative(backend):
+    """:867-898: the column integral is conserved; NaNs in the data are ignored; bad targets raise."""
+    nz = 30
+    dz = 10 + np.linspace(0, 90, nz - 1)
+    z = np.concatenate([[0], np.cumsum(dz)])
+    H = z.max()
+    theta = z / H + 0.2 * np.cos(np.pi * z / H)
+    bins = np.linspace(theta.min() - 0.1, theta.max() + 0.1, 100)
+    dz2, th2 = np.tile(dz, (5, 1)), np.tile(theta, (5, 1))
+    out = X.interp_1d_conservative(dz2, th2, bins)
+    np.testing.assert_allclose(np.nansum(out, axis=-1), np.nansum(dz2, axis=-1))
+    np.testing.assert_array_equal(out, TR.interp_1d_conservative(dz2, th2, bins))
+    phi = np.array([1, 2, np.nan])
+    np.testing.assert_allclose(X.interp_1d_conservative(phi, np.array([30.0, 40, 50, 60]), np.array([30.0, 50])), np.nansum(phi))
+    with pytest.raises(ValueError):
+        X.interp_1d_conservative(dz2, th2, np.array([0.0, -2, 4]))
+
+
+# ----------------------------------------------------------------------------------------------
+# mid level (test_transform.py:923-1046)
+# ----------------------------------------------------------------------------------------------
+def test_mid_level_rejects_plain_arrays(backend):
+    """:923-947."""
+    source, _, target, _, _, _ = construct(CASES["linear_depth_depth"])
+    with pytest.raises(ValueError):
+        X.linear_interpolation(source.data, source["z"], target.values, "z", "z", "z")
+    source, _, target, _, _, _ = construct(CASES["conservative_depth_depth"])
+    with pytest.raises(ValueError):
+        X.conservative_interpolation(source.data, source["z"], target.values, "z", "z", "z")
+
+
+@pytest.mark.parametrize("name", LINEAR_1D)
+def test_mid_level_linear(backend, name):
+    """:950-992."""
+    source, _, target, kw, expected, error = construct(CASES[name])
+    kw.setdefault("suffix", "")
+    method = kw.pop("method")
+    sdim, tdim = source.data.dims[0], target.dims[0]
+    theta = kw.pop("target_data", None)
+    if theta is None:
+        theta = source[sdim]
+    out = X.linear_interpolation(source.data, theta, target, sdim, sdim, tdim, logarithmic=(method == "log"), **kw)
+    _assert_like_reference(out, expected["data" + kw["suffix"]])
+    assert out.name == "data" + kw["suffix"]
+
+
+@pytest.mark.parametrize("name", CONS_1D)
+def test_mid_level_conservative(backend, name):
+    """:995-1046 (the two cases flagged `error` there need the high-level interp and are skipped here)."""
+    source, gkw, target, kw, expected, error = construct(CASES[name])
+    if error:
+        pytest.skip("mid level cannot handle this case in the reference either (xfail there)")
+    kw.setdefault("suffix", "")
+    kw.pop("method")
+    sdim, bdim, tdim = gkw["coords"]["Z"]["center"], gkw["coords"]["Z"]["outer"], target.dims[0]
+    theta = kw.pop("target_data", None)
+    if theta is None:
+        theta = source[bdim]
+    out = X.conservative_interpolation(source.data, theta, target, sdim, bdim, tdim, **kw)
+    _assert_like_reference(out, expected["data" + kw["suffix"]])
+    np.testing.assert_allclose(np.nansum(out.values), np.nansum(source.data.values))
+    assert out.name == "data" + kw["suffix"]
+
+
+# ----------------------------------------------------------------------------------------------
+# high level (test_transform.py:1052-1424)
+# ----------------------------------------------------------------------------------------------
+def _grid(source, gkw, **extra):
+    return Grid(source, **{**gkw, **extra})
+
+
+@pytest.mark.parametrize("name", NOT_CONS_MULTIDIM)
+def test_grid_transform(backend, name):
+    """:1052-1068: every case of the table through Grid.transform."""
+    source, gkw, target, kw, expected, _ = construct(CASES[name])
+    grid = _grid(source, gkw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        out = grid.transform(source.data, "Z", target, **kw)
+    _assert_like_reference(out, _expected(expected, kw))
+
+
+def test_conservative_multidim_target_and_explicit_target_dim(backend):
+    """:1071-1105."""
+    source, gkw, target, kw, _, _ = construct(CASES["conservative_depth_depth_multidim_target"])
+    with pytest.raises(NotImplementedError, match="multi-dimensional targets"):
+        _grid(source, gkw).transform(source.data, "Z", target, **kw)
+    source, gkw, target, kw, expected, _ = construct(CASES["conservative_depth_depth_rename"])
+    (tdim,) = target.dims
+    assert len(tdim) > 1
+    out = _grid(source, gkw).transform(source.data, "Z", target, target_dim=tdim, **kw)
+    _assert_like_reference(out, _expected(expected, kw))
+
+
+def test_conservative_warns_without_cell_bounds(backend):
+    """:1108-1126."""
+    source, gkw, target, kw, _, _ = construct(CASES["conservative_depth_temp"])
+    with pytest.warns(UserWarning, match="The `target data` input is not located on the cell bounds"):
+        _grid(source, gkw).transform(source.data, "Z", target, **kw)
+
+
+@pytest.mark.parametrize("name", MULTIDIM)
+def test_names_errors_and_auto_naming(backend, name):
+    """:1129-1214: unnamed input, periodic axis, dimension naming for ndarray targets."""
+    source, gkw, target, kw, expected, _ = construct(CASES[name])
+    grid = _grid(source, gkw)
+    unnamed = DataArray(source.data.values, dims=source.data.dims, coords=dict(source.data.coords))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        assert grid.transform(unnamed, "Z", target, **kw).name is None
+        with pytest.raises(ValueError, match="non-periodic"):
+            _grid(source, gkw, padding="periodic").transform(source.data, "Z", target, **kw)
+        td = kw.get("target_data")
+        if td is None:
+            want = grid.axes["Z"].coords["center" if kw["method"] == "linear" else "outer"]
+        else:
+            want = td.name
+        out = grid.transform(source.data, "Z", target.values, **kw)
+        assert want in out.coords and want in out.dims
+
+
+def test_noname_target_data_warns(backend):
+    """:1146-1173."""
+    source, gkw, target, kw, _, _ = construct(CASES["linear_depth_dens"])
+    td = kw.pop("target_data")
+    td = DataArray(td.values, dims=td.dims, coords=dict(td.coords))  # no name
+    with pytest.warns(UserWarning, match="TRANSFORMED_DIMENSION"):
+        out = _grid(source, gkw).transform(source.data, "Z", target.values, target_data=td, **kw)
+    assert "TRANSFORMED_DIMENSION" in out.dims
+
+
+@pytest.mark.parametrize("bypass", [True, False])
+def test_bypass_checks(backend, bypass):
+    """:1217-1245."""
+    source, gkw, target, kw, expected, _ = construct(CASES["linear_depth_dens"])
+    td = kw.pop("target_data")
+    out = _grid(source, gkw).transform(source.data, "Z", target, target_data=td, bypass_checks=bypass, **kw)
+    _assert_like_reference(out, expected["data"])
+
+
+@pytest.mark.parametrize("name", MULTIDIM)
+def test_grid_transform_multidim(backend, name):
+    """:1285-1316: the column broadcast against another dim gives the 1-D answer everywhere."""
+    source, gkw, target, kw, expected, _ = construct(CASES[name])
+    na = 8
+    col = source.data
+    big = DataArray(np.repeat(col.values[None], na, axis=0), dims=("a",) + col.dims, coords=dict(col.coords), name="data")
+    ds = Dataset({k: v for k, v in source.variables.items() if k != "data"})
+    ds["data"] = big
+    td = kw.pop("target_data", None)
+    if td is not None:
+        td = DataArray(np.repeat(td.values[None], na, axis=0), dims=("a",) + td.dims, coords=dict(td.coords), name=td.name)
+    grid = _grid(ds, gkw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        out = grid.transform(big, "Z", target, target_data=td, **kw)
+    want = _expected(expected, kw)
+    assert out.dims == ("a",) + tuple(want.dims)
+    np.testing.assert_allclose(out.values, np.broadcast_to(want.values, out.shape), rtol=1e-5, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["linear_depth_depth_nomask_multidim_target", "linear_depth_depth_multidim_target"])
+def test_grid_transform_spatially_varying_target(backend, name):
+    """:1319-1339: a 2-D target (eta_rho, s_rho) for a 1-D column."""
+    source, gkw, target, kw, expected, _ = construct(CASES[name])
+    td = kw.pop("target_data", None)
+    out = _grid(source, gkw).transform(source.data, "Z", target, target_data=td, **kw)
+    _assert_like_reference(out, expected["data"])
+
+
+def test_other_dims_error_and_input_check(backend):
+    """:1342-1368 and :1391-1424."""
+    source, gkw, target, kw, _, _ = construct(CASES["linear_depth_dens"])
+    grid = _grid(source, gkw)
+    td = kw.pop("target_data")
+    a3 = DataArray(np.repeat(source.data.values[None], 3, axis=0), dims=("a",) + source.data.dims, name="data")
+    td_other = DataArray(np.repeat(td.values[None], 3, axis=0), dims=("a_other",) + td.dims, name=td.name)
+    with pytest.raises(ValueError, match="additional dimensions"):
+        grid.transform(a3, "Z", target, target_data=td_other, **kw)
+    with pytest.raises(ValueError, match=r"`da` needs to be a"):
+        grid.transform(source, "Z", target, target_data=td, **kw)
+    with pytest.raises(ValueError, match="needs to be a"):
+        grid.transform(source.data, "Z", Dataset({"dummy": target}), target_data=td, **kw)
+    with pytest.raises(ValueError, match="needs to be a"):
+        grid.transform(source.data, "Z", target, target_data=Dataset({"dummy": td}), **kw)
+    no_outer = Grid(source, coords={"Z": {"center": "depth"}}, autoparse_metadata=False)
+    with pytest.raises(RuntimeError, match="`outer` coordinates"):
+        no_outer.transform(source.data, "Z", target, method="conservative", target_data=td)
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded sweeps: kernels vs oracle on hard columns
+# ----------------------------------------------------------------------------------------------
+def _columns(shape, seed, kind):
+    """theta fields (..., n): increasing / decreasing / with duplicates / NaN head, tail, holes."""
+    rng = np.random.default_rng(seed)
+    base = np.cumsum(rng.random(shape) + 0.05, axis=-1)
+    if kind == "decreasing":
+        base = base[..., ::-1].copy()
+    if kind == "duplicates":
+        base[..., 2] = base[..., 1]
+        base[..., -1] = base[..., -2]
+    if kind == "nan_tail":
+        base[..., -2:] = np.nan
+    if kind == "nan_head":
+        base[..., :2] = np.nan
+    if kind == "nan_holes":
+        base[..., 3] = np.nan
+        base[1:, ..., 0] = np.nan
+    if kind == "nonmonotonic":
+        base = base + 3 * np.sin(base)
+    return base
+
+
+@pytest.mark.parametrize("kind", ["increasing", "decreasing", "duplicates", "nan_tail", "nan_head", "nan_holes", "nonmonotonic"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_linear_kernel_equals_numpy_interp(backend, kind, dtype):
+    shape = (3, 5, 17)
+    theta = _columns(shape, 3, kind).astype(dtype)
+    phi = (R.synthetic_field(shape, 5) * 10).astype(dtype)
+    phi[0, 0, 4] = np.nan
+    levels = np.concatenate([[-1.0, np.nan], np.linspace(0.0, float(np.nanmax(theta)) + 1, 23), [theta[1, 2, 5]]]).astype(dtype)
+    for mask in (False, True):
+        for bypass in (False, True):
+            got = X.interp_1d_linear(phi, theta, levels, mask_edges=mask, bypass_checks=bypass)
+            want = TR.interp_1d_linear(phi, theta, levels, mask_edges=mask, bypass_checks=bypass)
+            assert got.dtype == dtype
+            np.testing.assert_array_equal(got, want)
+    # a target that varies from column to column, theta a single shared profile
+    lv2 = (levels[None, None, 2:] + R.synthetic_field((3, 5, 1), 9)).astype(dtype)
+    got = X.interp_1d_linear(phi, theta[0, 0], lv2, mask_edges=True)
+    np.testing.assert_array_equal(got, TR.interp_1d_linear(phi, theta[0, 0], lv2, mask_edges=True))
+    pos = np.abs(theta) + dtype(0.5)
+    lv = np.abs(levels[2:]) + dtype(0.25)
+    got = X.interp_1d_linear(phi, pos, lv, mask_edges=True, logarithmic=True)
+    np.testing.assert_allclose(got, TR.interp_1d_linear(phi, pos, lv, mask_edges=True, logarithmic=True),
+                               rtol=1e-12 if dtype == np.float64 else 5e-3, atol=0 if dtype == np.float64 else 1e-4,
+                               equal_nan=True)  # float32: 1-ulp log differences, amplified by steep slopes
+
+
+@pytest.mark.parametrize("kind", ["increasing", "decreasing", "duplicates", "nan_tail", "nan_head", "nan_holes", "nonmonotonic"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_conservative_kernel_equals_oracle(backend, kind, dtype):
+    shape = (2, 4, 13)
+    theta = _columns(shape[:-1] + (shape[-1] + 1,), 7, kind).astype(dtype)
+    phi = (R.synthetic_field(shape, 8) * 100).astype(dtype)
+    phi[1, 1, 3] = np.nan
+    bins = np.linspace(-0.5, float(np.nanmax(theta)) + 0.5, 21).astype(dtype)   # 20 bins: 2.5 register tiles
+    got = X.interp_1d_conservative(phi, theta, bins)
+    assert got.dtype == dtype and got.shape == shape[:-1] + (20,)
+    np.testing.assert_array_equal(got, TR.interp_1d_conservative(phi, theta, bins))
+    np.testing.assert_array_equal(X.interp_1d_conservative(phi, theta, bins[::-1].copy()),
+                                  TR.interp_1d_conservative(phi, theta, bins[::-1].copy()))
+
+
+def test_transform_on_a_zyx_field_without_transposes(backend):
+    """(time, Z, Y, X) field, density-like target data: the column axis stays where it is in HBM;
+    the result carries the reference's dim order (time, Y, X, target)."""
+    nt, nz, ny, nx = 2, 9, 4, 6
+    zc = np.arange(nz) + 0.5
+    zo = np.arange(nz + 1) * 1.0
+    ds = Dataset(coords={"Z": zc, "Zp1": zo, "Y": np.arange(ny), "X": np.arange(nx), "time": np.arange(nt)})
+    grid = Grid(ds, coords={"Z": {"center": "Z", "outer": "Zp1"}}, autoparse_metadata=False)
+    phi = R.synthetic_field((nt, nz, ny, nx), 21)
+    dens = np.cumsum(R.synthetic_field((nt, nz, ny, nx), 22) + 0.6, axis=1)
+    da = DataArray(phi, dims=("time", "Z", "Y", "X"), name="salt")
+    sigma = DataArray(dens, dims=("time", "Z", "Y", "X"), name="sigma")
+    levels = np.linspace(0.0, dens.max(), 7)
+    out = grid.transform(da, "Z", levels, target_data=sigma)
+    assert out.dims == ("time", "Y", "X", "sigma") and out.name == "salt_transformed"
+    want = TR.interp_1d_linear(np.moveaxis(phi, 1, -1), np.moveaxis(dens, 1, -1), levels, mask_edges=True)
+    np.testing.assert_array_equal(out.values, want)
+    np.testing.assert_array_equal(out.coords["sigma"].values, levels)
+    dens_o = np.cumsum(R.synthetic_field((nt, nz + 1, ny, nx), 23) + 0.6, axis=1)
+    sig_o = DataArray(dens_o, dims=("time", "Zp1", "Y", "X"), name="sigma")
+    out = grid.transform(da, "Z", levels, target_data=sig_o, method="conservative")
+    assert out.dims == ("time", "Y", "X", "sigma")
+    want = TR.interp_1d_conservative(np.moveaxis(phi, 1, -1), np.moveaxis(dens_o, 1, -1), levels)
+    np.testing.assert_array_equal(out.values, want)
+    np.testing.assert_array_equal(out.coords["sigma"].values, (levels[1:] + levels[:-1]) / 2)

@@ -157,6 +157,40 @@ def main():
         print(json.dumps({"config": "f2", "check": "cubed-sphere diff: interior and connected halos at full size", "ok": ok}), flush=True)
         del Tf, d, t, gridf
         torch.cuda.empty_cache()
+    if "f4" in cfgs:
+        # next-row f4: vertical coordinate transform of a (Z, Y, X) = (75, 2400, 3600) f64 field onto 50
+        # density-like levels / bins; theta is a full 3-D tracer (the expensive, common case)
+        from xgcm_amd import transform as XT
+        nzt, nyt, nxt, mt = 75, 2400, 3600, 50
+        dsz = Dataset({}, {"Z": ("Z", np.arange(nzt) + 0.5), "Zp1": ("Zp1", np.arange(nzt + 1) * 1.0)})
+        gz = Grid(dsz, coords={"Z": {"center": "Z", "outer": "Zp1"}}, autoparse_metadata=False)
+        phi = DataArray(D.synthetic((nzt, nyt, nxt), 71), ("Z", "Y", "X"), name="salt")
+        # monotonic "density": running sum of positive increments along Z (built with the cumsum kernel)
+        inc = D.synthetic((nzt, nyt, nxt), 72, 0, 1.0, 0.55)
+        sigma = DataArray(D.cumsum1d(inc, 0, 0, 0, 0, 0, None, 0.0, False, False), ("Z", "Y", "X"), name="sigma")
+        inc_o = D.synthetic((nzt + 1, nyt, nxt), 73, 0, 1.0, 0.55)
+        sigma_o = DataArray(D.cumsum1d(inc_o, 0, 0, 0, 0, 0, None, 0.0, False, False), ("Zp1", "Y", "X"), name="sigma")
+        levels = np.linspace(1.0, 0.9 * nzt, mt)
+        edges = np.linspace(0.0, 1.6 * (nzt + 1), mt + 1)
+        cols = nyt * nxt
+        rec("f4", f"transform linear: {nzt} levels -> {mt} sigma levels (numpy.interp per column), cells = input cells",
+            timeit(lambda: gz.transform(phi, "Z", levels, target_data=sigma), a.reps), nzt * cols, (2 * nzt + mt) * 8 / nzt)
+        rec("f4", f"transform conservative: {nzt} cells -> {mt} sigma bins, cells = input cells",
+            timeit(lambda: gz.transform(phi, "Z", edges, target_data=sigma_o, method="conservative"), max(3, a.reps // 2)),
+            nzt * cols, (2 * nzt + 1 + mt) * 8 / nzt)
+        out = gz.transform(phi, "Z", levels, target_data=sigma)
+        oc = gz.transform(phi, "Z", edges, target_data=sigma_o, method="conservative")
+        # full-size properties: a target equal to a column's own theta returns the column; integral conserved
+        ident = XT.interp_1d_linear(phi.data.permute(1, 2, 0)[:64].contiguous(), sigma.data.permute(1, 2, 0)[:64].contiguous(),
+                                    sigma.data[:, 7, 11].contiguous(), mask_edges=False)
+        ok_ident = bool(torch.equal(ident[7, 11], phi.data[:, 7, 11]))
+        tot_in = phi.data.sum(0)
+        tot_out = torch.nan_to_num(oc.data, nan=0.0).sum(-1)
+        ok_cons = bool(torch.allclose(tot_in, tot_out, rtol=1e-10, atol=1e-9))
+        print(json.dumps({"config": "f4", "check": "linear identity column; conservative column integrals at full size",
+                          "ok": ok_ident and ok_cons, "dims": list(out.dims)}), flush=True)
+        del phi, inc, sigma, inc_o, sigma_o, out, oc
+        torch.cuda.empty_cache()
     if "5" in cfgs:
         nz5, n5 = 90, 4320
         grid = mitgcm_grid(nz5, n5, n5)

@@ -88,6 +88,7 @@ struct Tune {
   int seg;       // rows marched per wave-task along a strided stencil axis
   int nt_store;  // non-temporal stores (+2-4 %; non-temporal LOADS measured -1 % and are not used)
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
+  int transform_fast;  // streaming path of the linear transform for well-formed columns (0: always the exact search)
   int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
   int scan_vec;       // aligned-output-group scan for cumsum along the contiguous axis
@@ -103,6 +104,7 @@ struct Tune {
     deep_waves = env_int("XG_DEEP_WAVES", 0);  // measured neutral (4.80 vs 4.88 TB/s on cumsum along Y): off
     zband = env_int("XG_ZBAND", 1);
     zchunk = env_int("XG_ZCHUNK", 256);
+    transform_fast = env_int("XG_TRANSFORM_FAST", 1);
     seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
     seg = env_int("XG_SEG", 1 << 30);  // long march: whole column by default
     nt_store = env_int("XG_NT_STORE", 1);
@@ -1263,6 +1265,251 @@ __global__ __launch_bounds__(BLOCK) void k_gather(const real* __restrict__ in, c
 }
 
 // ------------------------------------------------------------------------------------------
+// vertical coordinate transform (next-row f4; reference xgcm/transform.py:15-142, numba gufuncs)
+//
+// One thread = one column (all other dims); lanes run along the innermost dim, so every step of
+// the column loops is a coalesced access when the transform axis is not the contiguous one.
+//
+// K9a linear: numpy.interp(target, theta, phi) per column, restated step for step because the
+//   result on NaN-laden or duplicated theta depends on the search path: the guess carried from one
+//   target level to the next, the +-1 probes, the 8-element window, then bisection
+//   (numpy/_core/src/multiarray/compiled_base.c; numba's np.interp is a port of the same code).
+//   Arithmetic is double whatever the storage type, as in numpy/numba.
+// K9b conservative: the reference's O(n*m) accumulation; per output bin the contributions are
+//   added in source-level order (the order of the reference's outer loop), JT bins per pass held
+//   in registers so that the column is re-read m/JT times instead of m times; a cell that misses
+//   the whole (sorted) tile of bins is rejected with two compares.
+// Measured dead end: staging each column in LDS ([level][lane], 64-lane blocks) made every probe
+//   an LDS hit but left 2 waves per CU -- linear 12.8 -> 18.9 ms, conservative 18.5 -> 61.9 ms on
+//   the 75 x 2400 x 3600 case; the kernels therefore run at full occupancy on global memory.
+// ------------------------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ int64_t interp_search(double key, F xp, int64_t len, int64_t guess) {
+  int64_t imin = 0, imax = len;
+  if (key > xp(len - 1)) return len;
+  else if (key < xp(0)) return -1;
+  if (len <= 4) {
+    int64_t i;
+    for (i = 1; i < len && key >= xp(i); ++i) {}
+    return i - 1;
+  }
+  if (guess > len - 3) guess = len - 3;
+  if (guess < 1) guess = 1;
+  if (key < xp(guess)) {
+    if (key < xp(guess - 1)) {
+      imax = guess - 1;
+      if (guess > 8 && key >= xp(guess - 8)) imin = guess - 8;
+    } else {
+      return guess - 1;
+    }
+  } else {
+    if (key < xp(guess + 1)) return guess;
+    if (key < xp(guess + 2)) return guess + 1;
+    imin = guess + 2;
+    if (guess < len - 8 - 1 && key < xp(guess + 8)) imax = guess + 8;
+  }
+  while (imin < imax) {
+    const int64_t imid = imin + ((imax - imin) >> 1);
+    if (key >= xp(imid)) imin = imid + 1;
+    else imax = imid;
+  }
+  return imin - 1;
+}
+
+// np.log in the storage type: evaluated in double and rounded once (float32: correctly rounded
+// up to double-rounding ties; numpy's own float32 log is a few-ulp SIMD routine, so method="log"
+// is a tolerance comparison in float32, not a bit-exact one)
+__device__ __forceinline__ real xg_log_store(real v) { return (real)log((double)v); }
+
+// one interpolated value from the bracketing pair, numpy's formula and NaN fall-backs
+__device__ __forceinline__ double interp_pair(double xv, double xj, double xj1, double fj, double fj1) {
+  const double slope = (fj1 - fj) / (xj1 - xj);
+  double res = slope * (xv - xj) + fj;
+  if (res != res) {
+    res = slope * (xv - xj1) + fj1;
+    if (res != res && fj == fj1) res = fj;
+  }
+  return res;
+}
+
+template <bool LOG>
+__global__ __launch_bounds__(BLOCK) void k_transform_linear(
+    const real* __restrict__ phi, const real* __restrict__ theta, const real* __restrict__ target,
+    real* __restrict__ out, Geo g, MIdx mt, MIdx mg, int mask_edges, int bypass_checks, int fast_path) {
+  const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= g.outer * g.inner) return;
+  const int64_t inner = g.inner, n = g.n_in, m = g.n_out;
+  const int64_t o = c / inner, x = c - o * inner;
+  const real* pphi = phi + (o * n) * inner + x;
+  const real* pth = theta + outer_off(g, mt, o) + inner_off(g, mt, x);
+  const real* ptg = target + outer_off(g, mg, o) + inner_off(g, mg, x);
+  real* pout = out + (o * m) * inner + x;
+  // theta as the reference sees it: the storage type's log first (np.log in interp_1d_linear)
+  auto TH = [&](int64_t k) -> real { real v = pth[k * mt.axis]; return LOG ? xg_log_store(v) : v; };
+  auto LEV = [&](int64_t i) -> real { real v = ptg[i * mg.axis]; return LOG ? xg_log_store(v) : v; };
+
+  // ---- fast path: a well-formed column (no NaN, monotonic theta) and non-decreasing, NaN-free
+  // targets.  numpy's search then returns max{j: xp[j] <= key} whatever its probing path, so the
+  // column is streamed ONCE level by level (coalesced across lanes) while a per-lane cursor walks
+  // the targets; any violation met on the way sends the lane to the exact path below, which
+  // rewrites every output of the column.
+  bool exact = !fast_path || n < 2;
+  if (!exact) {
+    const real a0 = TH(0), a1 = TH(n - 1);
+    if (a0 != a0 || a1 != a1) exact = true;
+    else {
+      const bool flip = !bypass_checks && (a1 < a0);
+      const real tmin = flip ? a1 : a0, tmax = flip ? a0 : a1;  // == nanmin / nanmax once monotonic
+      if (bypass_checks && a1 < a0) exact = true;               // decreasing but not flipped: numpy's path decides
+      int64_t i = 0;
+      double xk = (double)(flip ? a1 : a0);
+      double fk = (double)pphi[(flip ? n - 1 : 0) * inner];
+      const double lval = fk;
+      real prev_lev = (real)0;
+      bool have_prev = false;
+      auto emit = [&](int64_t ii, real lev, double res) {
+        real r = (real)res;
+        if (mask_edges && (lev < tmin || lev > tmax)) r = (real)NAN;
+        pout[ii * inner] = r;
+      };
+      for (int64_t k = 1; k < n && !exact; ++k) {
+        const int64_t kk = flip ? n - 1 - k : k;
+        const real tv = TH(kk);
+        const double xk1 = (double)tv, fk1 = (double)pphi[kk * inner];
+        if (tv != tv || xk1 < xk) { exact = true; break; }
+        while (i < m) {
+          const real lev = LEV(i);
+          if (lev != lev || (have_prev && lev < prev_lev)) { exact = true; break; }
+          const double xv = (double)lev;
+          if (!(xv < xk1)) break;            // belongs to a later interval (or to the right edge)
+          double res;
+          if (xv < xk) res = lval;           // only possible while k == 1: left of the column
+          else if (xv == xk) res = fk;
+          else res = interp_pair(xv, xk, xk1, fk, fk1);
+          emit(i, lev, res);
+          prev_lev = lev; have_prev = true;
+          ++i;
+        }
+        xk = xk1; fk = fk1;
+      }
+      if (!exact) {
+        // remaining targets are >= xp[n-1]: the last point itself, or right of the column
+        while (i < m) {
+          const real lev = LEV(i);
+          if (lev != lev || (have_prev && lev < prev_lev)) { exact = true; break; }
+          emit(i, lev, fk);                  // key == xp[n-1] -> fp[n-1]; key > xp[n-1] -> rval == fp[n-1]
+          prev_lev = lev; have_prev = true;
+          ++i;
+        }
+      }
+    }
+    if (!exact) return;
+  }
+
+  // ---- exact path: numpy's search, probe for probe
+  bool flip = false;
+  real tmin = real(0), tmax = real(0);
+  bool have = false;
+  if (!bypass_checks || mask_edges) {
+    real first = real(0), last = real(0);
+    for (int64_t k = 0; k < n; ++k) {
+      const real v = TH(k);
+      if (v != v) continue;
+      if (!have) { first = v; tmin = v; tmax = v; have = true; }
+      last = v;
+      tmin = (v < tmin) ? v : tmin;
+      tmax = (v > tmax) ? v : tmax;
+    }
+    if (!bypass_checks && have) flip = last < first;
+  }
+  auto XP = [&](int64_t k) -> double { return (double)TH(flip ? n - 1 - k : k); };
+  auto FP = [&](int64_t k) -> double { return (double)pphi[(flip ? n - 1 - k : k) * inner]; };
+
+  const double lval = FP(0), rval = FP(n - 1);
+  int64_t j = 0;
+  for (int64_t i = 0; i < m; ++i) {
+    const real lev = LEV(i);
+    const double xv = (double)lev;
+    double res;
+    if (xv != xv) {
+      res = xv;
+    } else if (n == 1) {
+      const double x0 = XP(0);
+      res = (xv < x0) ? lval : ((xv > x0) ? rval : FP(0));
+    } else {
+      j = interp_search(xv, XP, n, j);
+      if (j == -1) res = lval;
+      else if (j == n) res = rval;
+      else if (j == n - 1) res = FP(j);
+      else {
+        const double xj = XP(j);
+        if (xj == xv) res = FP(j);
+        else res = interp_pair(xv, xj, XP(j + 1), FP(j), FP(j + 1));
+      }
+    }
+    real r = (real)res;
+    if (mask_edges && have && (lev < tmin || lev > tmax)) r = (real)NAN;
+    pout[i * inner] = r;
+  }
+}
+
+template <int JT>
+__global__ __launch_bounds__(BLOCK) void k_transform_conservative(
+    const real* __restrict__ phi, const real* __restrict__ theta, const real* __restrict__ bins,
+    real* __restrict__ out, Geo g, MIdx mt) {
+  const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= g.outer * g.inner) return;
+  const int64_t inner = g.inner, n = g.n_in, m = g.n_out;
+  const int64_t o = c / inner, x = c - o * inner;
+  const real* pphi = phi + (o * n) * inner + x;
+  const real* pth = theta + outer_off(g, mt, o) + inner_off(g, mt, x);
+  real* pout = out + (o * m) * inner + x;
+  for (int64_t j0 = 0; j0 < m; j0 += JT) {
+    real acc[JT], b1[JT], b2[JT];
+#pragma unroll
+    for (int t = 0; t < JT; ++t) {
+      const int64_t j = (j0 + t < m) ? j0 + t : m - 1;
+      acc[t] = (real)NAN;
+      b1[t] = bins[j];
+      b2[t] = bins[j + 1];
+    }
+    real t1 = pth[0];
+    for (int64_t i = 0; i < n; ++i) {
+      const real t2 = pth[(i + 1) * mt.axis];
+      const real p = pphi[i * inner];
+      const real a1 = t1;
+      t1 = t2;
+      const bool n1 = a1 != a1, n2 = t2 != t2;
+      if (n1 && n2) continue;
+      real lo_, hi_;
+      if (n1) { lo_ = hi_ = t2; }
+      else if (n2) { lo_ = hi_ = a1; }
+      else if (a1 < t2) { lo_ = a1; hi_ = t2; }
+      else { lo_ = t2; hi_ = a1; }
+      if (p != p) continue;
+      if (b1[0] > hi_ || b2[JT - 1] < lo_) continue;  // bins increase: the cell misses this whole tile
+#pragma unroll
+      for (int t = 0; t < JT; ++t) {
+        if (b1[t] > hi_ || b2[t] < lo_) continue;
+        real add;
+        if (hi_ == lo_) {
+          add = p;
+        } else {
+          const real hmin = (b1[t] > lo_) ? b1[t] : lo_;  // python max(theta_min, theta_hat_1)
+          const real hmax = (b2[t] < hi_) ? b2[t] : hi_;  // python min(theta_max, theta_hat_2)
+          const real alpha = (hmax - hmin) / (hi_ - lo_);
+          add = alpha * p;
+        }
+        acc[t] = (acc[t] != acc[t]) ? add : acc[t] + add;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < JT; ++t)
+      if (j0 + t < m) pout[(j0 + t) * inner] = acc[t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // broadcasting binary op (out C-contiguous, a/b addressed through strides; dims pre-coalesced)
 // ------------------------------------------------------------------------------------------
 struct BinGeo {
@@ -1990,6 +2237,45 @@ int XG_FN(xg_gather)(const real* in, const real* partner, real* out, const int64
   hipStream_t st = (hipStream_t)stream;
   if (total < 0x7fffffffll) hipLaunchKernelGGL((k_gather<u32>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, partner, out, tokens, g);
   else hipLaunchKernelGGL((k_gather<u64>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, partner, out, tokens, g);
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int XG_FN(xg_transform_linear)(const real* phi, const real* theta, const int64_t* theta_strides, const real* target,
+                            const int64_t* target_strides, int64_t m, real* out, const int64_t* shape, int ndim,
+                            int axis, int mask_edges, int bypass_checks, int logarithmic, void* stream) {
+  if (!phi || !theta || !target || !out || !shape || !theta_strides || !target_strides)
+    return fail(XG_ERR_INVALID, "NULL argument");
+  if (m < 0) return fail(XG_ERR_INVALID, "negative number of target levels");
+  Geo g; MIdx mt, mg;
+  int rc = build_geo(shape, ndim, axis, m, theta_strides, target_strides, &g, &mt, &mg);
+  if (rc) return rc;
+  if (g.n_in < 1) return fail(XG_ERR_INVALID, "empty transform axis");
+  const int64_t cols = g.outer * g.inner;
+  if (cols == 0 || m == 0) return XG_OK;
+  const u64 nblocks = ((u64)cols + BLOCK - 1) / BLOCK;
+  if ((rc = check_grid(nblocks))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int fast = tune().transform_fast;
+  if (logarithmic) hipLaunchKernelGGL((k_transform_linear<true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
+  else hipLaunchKernelGGL((k_transform_linear<false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int XG_FN(xg_transform_conservative)(const real* phi, const real* theta, const int64_t* theta_strides, const real* bins,
+                                  int64_t n_edges, real* out, const int64_t* shape, int ndim, int axis,
+                                  void* stream) {
+  if (!phi || !theta || !bins || !out || !shape || !theta_strides) return fail(XG_ERR_INVALID, "NULL argument");
+  if (n_edges < 2) return fail(XG_ERR_INVALID, "need at least two bin edges");
+  Geo g; MIdx mt;
+  int rc = build_geo(shape, ndim, axis, n_edges - 1, theta_strides, nullptr, &g, &mt, nullptr);
+  if (rc) return rc;
+  const int64_t cols = g.outer * g.inner;
+  if (cols == 0) return XG_OK;
+  const u64 nblocks = ((u64)cols + BLOCK - 1) / BLOCK;
+  if ((rc = check_grid(nblocks))) return rc;
+  hipLaunchKernelGGL((k_transform_conservative<8>), dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, phi, theta, bins, out, g, mt);
   XG_LAUNCH_CHECK();
   return XG_OK;
 }

@@ -31,6 +31,8 @@ __all__ = [
     "pad_nd",
     "gather",
     "upload_tokens",
+    "transform_linear",
+    "transform_conservative",
     "binary",
     "vorticity",
     "stencil2d",
@@ -296,6 +298,71 @@ def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_sh
             _hip.ints([1 if m else 0 for m in mapped]), _hip.ints(partner_perm) if partner is not None else None,
             _hip.i64(list(lo)), tokens.data_ptr(), int(tokens.numel()), _hip.reals(list(fills) or [0.0], sfx),
             len(fills), _stream())
+    )
+    return out
+
+
+def transform_linear(phi, theta, target, axis: int, mask_edges: bool = True, bypass_checks: bool = False,
+                     logarithmic: bool = False) -> torch.Tensor:
+    """numpy.interp per column along `axis` (xg_transform_linear_f64).  `theta` and `target` are
+    dim-aligned with `phi` (extent 1 = broadcast); along `axis` theta has phi's length, target its
+    own number of levels m.  Returns phi's shape with `axis` -> m."""
+    lib = _hip.load()
+    dt, sfx = _common(phi, theta, target)
+    phi = asdevice(phi, dt)
+    theta = asdevice(theta, dt)
+    target = asdevice(target, dt)
+    axis = axis % phi.dim()
+    shape = list(phi.shape)
+    m = int(target.shape[axis])
+    oshape = list(shape)
+    oshape[axis] = m
+    out = torch.empty(oshape, dtype=dt, device=phi.device)
+    if out.numel() == 0:
+        return out
+    if shape[axis] < 1:
+        raise ValueError("transform needs at least one level along the axis")
+    th_st = _bstrides(theta, shape, "theta")
+    th_st[axis] = theta.stride(axis) if theta.shape[axis] > 1 else 0
+    tg_st = _bstrides(target, oshape, "target")
+    tg_st[axis] = target.stride(axis) if m > 1 else 0
+    _hip.check(
+        getattr(lib, "xg_transform_linear_" + sfx)(
+            phi.data_ptr(), theta.data_ptr(), _hip.i64(th_st), target.data_ptr(), _hip.i64(tg_st), m, out.data_ptr(),
+            _hip.i64(shape), phi.dim(), axis, int(bool(mask_edges)), int(bool(bypass_checks)), int(bool(logarithmic)),
+            _stream())
+    )
+    return out
+
+
+def transform_conservative(phi, theta, bins, axis: int) -> torch.Tensor:
+    """Conservative remap per column (xg_transform_conservative_f64): `theta` is dim-aligned with
+    `phi` and has one more level along `axis` (cell vertices); `bins` is a 1-D increasing array of
+    bin edges.  Returns phi's shape with `axis` -> len(bins) - 1."""
+    lib = _hip.load()
+    dt, sfx = _common(phi, theta, bins)
+    phi = asdevice(phi, dt)
+    theta = asdevice(theta, dt)
+    bins = asdevice(bins, dt)
+    axis = axis % phi.dim()
+    shape = list(phi.shape)
+    if theta.shape[axis] != shape[axis] + 1:
+        raise ValueError(f"theta needs {shape[axis] + 1} vertices along the axis, got {theta.shape[axis]}")
+    if bins.dim() != 1 or bins.numel() < 2:
+        raise ValueError("bins must be a 1-D array of at least two edges")
+    oshape = list(shape)
+    oshape[axis] = int(bins.numel()) - 1
+    out = torch.empty(oshape, dtype=dt, device=phi.device)
+    if out.numel() == 0:
+        return out
+    vshape = list(shape)
+    vshape[axis] = shape[axis] + 1
+    th_st = _bstrides(theta, vshape, "theta")
+    th_st[axis] = theta.stride(axis)
+    _hip.check(
+        getattr(lib, "xg_transform_conservative_" + sfx)(
+            phi.data_ptr(), theta.data_ptr(), _hip.i64(th_st), bins.data_ptr(), int(bins.numel()), out.data_ptr(),
+            _hip.i64(shape), phi.dim(), axis, _stream())
     )
     return out
 

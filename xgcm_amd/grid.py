@@ -714,8 +714,12 @@ class Grid:
         res = _reattach_coords([res], self, None, {out_x, out_y}, [u, v])[0]
         return to_xarray(res) if (xr1 or xr2) else res
 
-    def transform(self, *a, **k):
-        raise NotImplementedError("vertical coordinate transform (reference transform.py) is outside this backend")
+    def transform(self, da, axis, target, **kwargs):
+        """Convert `da` to new 1-D coordinates along `axis` (linear / log / conservative; reference
+        grid.py:1687-1777 -> transform.py:284-514), one HIP kernel launch per call."""
+        from .transform import transform as _transform
+
+        return _transform(self, axis, da, target, **kwargs)
 
 
 # ----------------------------------------------------------------------------------------------

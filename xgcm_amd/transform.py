@@ -1,0 +1,271 @@
+"""1-D coordinate transformation along a grid axis (reference xgcm/transform.py).
+
+Three levels, as in the reference:
+
+* low level -- `interp_1d_linear` / `interp_1d_conservative` on unlabelled arrays with the column
+  axis LAST (reference :44-86, :145-193; there numba gufuncs, here one HIP kernel launch each,
+  `xg_transform_linear_f64` / `xg_transform_conservative_f64`);
+* mid level -- `linear_interpolation` / `conservative_interpolation` on labelled arrays (reference
+  :199-281: `xr.apply_ufunc` with core dims, temporary dim names, output naming);
+* high level -- `transform(grid, axis_name, da, target, ...)` behind `Grid.transform` (:284-514).
+
+Layout: the reference moves the column axis last for the gufunc and gets the new dim last.  Here
+the field is read where it lies (column axis anywhere, lanes along the contiguous dim) and the new
+dim is written where the axis was; the result is then presented with the reference's dim order
+(broadcast dims..., new dim) as a transposed VIEW, not a copy.
+"""
+
+from __future__ import annotations
+
+import warnings
+from collections import OrderedDict
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import device as _dev
+from .labeled import DataArray, _aligned_view, _is_tensor, is_xarray, from_xarray, to_xarray
+
+
+# ------------------------------------------------------------------------------------------
+# low level (unlabelled arrays, column axis last)
+# ------------------------------------------------------------------------------------------
+def _host(*arrays) -> bool:
+    return not any(_is_tensor(a) for a in arrays if a is not None)
+
+
+def _lead_align(a, ndim: int):
+    """view of `a` with leading size-1 dims up to `ndim` dims"""
+    extra = ndim - a.ndim
+    if extra <= 0:
+        return a
+    return a[(None,) * extra] if _is_tensor(a) or isinstance(a, np.ndarray) else np.asarray(a)[(None,) * extra]
+
+
+def interp_1d_linear(phi, theta, target_theta_levels, mask_edges=False, bypass_checks=False, logarithmic=False):
+    """Interpolate `phi` (..., n) to the isosurfaces `target_theta_levels` (m,) of `theta` (..., n)."""
+    host = _host(phi, theta, target_theta_levels)
+    phi, theta, target = (a if _is_tensor(a) else np.asarray(a) for a in (phi, theta, target_theta_levels))
+    nd = max(phi.ndim, theta.ndim, target.ndim)
+    phi, theta, target = _lead_align(phi, nd), _lead_align(theta, nd), _lead_align(target, nd)
+    lead = np.broadcast_shapes(tuple(phi.shape[:-1]), tuple(theta.shape[:-1]), tuple(target.shape[:-1]))
+    if tuple(phi.shape[:-1]) != lead:  # the field itself is broadcast (rare: 1-D data, N-D target)
+        phi = _broadcast_copy(phi, lead + (phi.shape[-1],))
+    out = _dev.transform_linear(phi, theta, target, -1, mask_edges, bypass_checks, logarithmic)
+    return _dev.tohost(out) if host else out
+
+
+def interp_1d_conservative(phi, theta, target_theta_bins):
+    """Accumulate the extensive `phi` (..., n) into the bins `target_theta_bins` (m,) of `theta` (..., n+1)."""
+    host = _host(phi, theta, target_theta_bins)
+    bins = _dev.tohost(target_theta_bins) if _is_tensor(target_theta_bins) else np.asarray(target_theta_bins)
+    phi, theta = (a if _is_tensor(a) else np.asarray(a) for a in (phi, theta))
+    assert phi.shape[-1] == (theta.shape[-1] - 1)
+    assert bins.ndim == 1
+    diff = np.diff(bins)
+    if np.all(diff < 0):
+        flip = True
+        bins = bins[::-1]
+    elif np.all(diff > 0):
+        flip = False
+    else:
+        raise ValueError("Target values are not monotonic")
+    nd = max(phi.ndim, theta.ndim)
+    phi, theta = _lead_align(phi, nd), _lead_align(theta, nd)
+    lead = np.broadcast_shapes(tuple(phi.shape[:-1]), tuple(theta.shape[:-1]))
+    if tuple(phi.shape[:-1]) != lead:
+        phi = _broadcast_copy(phi, lead + (phi.shape[-1],))
+    out = _dev.transform_conservative(phi, theta, np.ascontiguousarray(bins), -1)
+    if flip:
+        # un-flip along the BIN axis (the reference writes out[::-1], equal to this for 1-D input)
+        out = out.flip(-1) if _is_tensor(out) else out[..., ::-1]
+    return _dev.tohost(out) if host else out
+
+
+def _broadcast_copy(a, shape):
+    if _is_tensor(a):
+        return a.expand(*shape).contiguous()
+    return np.ascontiguousarray(np.broadcast_to(a, shape))
+
+
+# ------------------------------------------------------------------------------------------
+# mid level (labelled arrays)
+# ------------------------------------------------------------------------------------------
+def _ordered_union(*dim_lists: Sequence[str]) -> List[str]:
+    seen: List[str] = []
+    for dims in dim_lists:
+        for d in dims:
+            if d not in seen:
+                seen.append(d)
+    return seen
+
+
+def _merge_coords(out_dims: Sequence[str], *sources: Tuple[DataArray, Optional[str]]) -> "OrderedDict":
+    """Coordinates of the inputs that survive `xr.apply_ufunc`: those not touching the input's core
+    (column) dim and living on dims of the result; first input wins."""
+    coords: "OrderedDict" = OrderedDict()
+    for src, core_dim in sources:
+        for name, c in src.coords.items():
+            if core_dim is not None and core_dim in c.dims:
+                continue
+            if name not in coords and all(d in out_dims for d in c.dims):
+                coords[name] = c
+    return coords
+
+
+def _check_labelled(*named):
+    for label, obj in named:
+        if not isinstance(obj, DataArray):
+            raise ValueError(f"`{label}` needs to be a DataArray. Found {type(obj)}")
+
+
+def _column_call(kind: str, phi: DataArray, theta: DataArray, target: DataArray, phi_dim: str, theta_dim: str,
+                 target_dim: str, **kwargs) -> DataArray:
+    """Shared plumbing of the two interpolations: align dims, one kernel launch, reference dim order."""
+    others = _ordered_union([d for d in phi.dims if d != phi_dim], [d for d in theta.dims if d != theta_dim],
+                            [d for d in target.dims if d != target_dim] if kind == "linear" else [])
+    extra = [d for d in others if d not in phi.dims]
+    work_dims = tuple(extra) + tuple(phi.dims)             # the field's own order, column axis where it lies
+    axis = work_dims.index(phi_dim)
+    phi_arr = phi.data
+    if extra:  # the field is broadcast along dims only the target / theta have
+        shape = [theta.sizes[d] if d in theta.dims else target.sizes[d] for d in extra] + list(phi.shape)
+        phi_arr = _broadcast_copy(_lead_align(phi_arr, len(shape)), shape)
+    host = _host(phi_arr, theta.data, target.data)
+    theta_arr = _aligned_view(theta.rename({theta_dim: phi_dim}) if theta_dim != phi_dim else theta, work_dims)
+    if kind == "linear":
+        target_arr = _aligned_view(target.rename({target_dim: phi_dim}), work_dims)
+        out = _dev.transform_linear(phi_arr, theta_arr, target_arr, axis, **kwargs)
+    else:
+        bins = _dev.tohost(target.data) if _is_tensor(target.data) else np.asarray(target.data)
+        diff = np.diff(bins)
+        if np.all(diff < 0):
+            flip, bins = True, bins[::-1]
+        elif np.all(diff > 0):
+            flip = False
+        else:
+            raise ValueError("Target values are not monotonic")
+        out = _dev.transform_conservative(phi_arr, theta_arr, np.ascontiguousarray(bins), axis)
+        if flip:
+            out = out.flip(axis) if _is_tensor(out) else np.flip(out, axis=axis)
+    if host:
+        out = _dev.tohost(out)
+    out_dims_work = tuple(target_dim if d == phi_dim else d for d in work_dims)
+    final = tuple(others) + (target_dim,)
+    res = DataArray(out, out_dims_work)
+    if final != out_dims_work:
+        res = res.transpose(*final)  # a view: the reference's (broadcast dims..., new dim) order
+    return res
+
+
+def _input_handling(kind: str, phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, suffix="", **kwargs):
+    _check_labelled(("phi", phi), ("theta", theta), ("target_theta_levels", target_theta_levels))
+    res = _column_call(kind, phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs)
+    coords = _merge_coords(res.dims, (phi, phi_dim), (theta, theta_dim), (target_theta_levels, None))
+    if kind == "conservative":
+        levels = _dev.tohost(target_theta_levels.data) if _is_tensor(target_theta_levels.data) else np.asarray(
+            target_theta_levels.data)
+        coords.pop(target_dim, None)
+        coords[target_dim] = DataArray((levels[1:] + levels[:-1]) / 2, (target_dim,))
+    res = DataArray(res.data, res.dims, coords=coords, name=(phi.name + suffix) if phi.name else None)
+    return res
+
+
+def linear_interpolation(phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs):
+    """`phi` on the `target_theta_levels` isosurfaces of `theta` (reference transform.py:237-253)."""
+    return _input_handling("linear", phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs)
+
+
+def conservative_interpolation(phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs):
+    """Extensive `phi` binned between `target_theta_levels` (reference transform.py:256-281)."""
+    return _input_handling("conservative", phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs)
+
+
+# ------------------------------------------------------------------------------------------
+# high level
+# ------------------------------------------------------------------------------------------
+def transform(grid, axis_name, da, target, target_data=None, target_dim=None, method="linear", mask_edges=True,
+              bypass_checks=False, suffix="_transformed"):
+    """Convert `da` to new 1-D coordinates along `axis_name` (reference transform.py:284-514)."""
+    axis = grid.axes[axis_name]
+    if axis.padding == "periodic":
+        raise ValueError(
+            "`transform` can only be used on axes that are non-periodic. Set a "
+            "non-periodic boundary (e.g. `padding='fill'`, or leave it unset) "
+            "for this axis on `xgcm.Grid`."
+        )
+    was_xr = any(is_xarray(v) for v in (da, target, target_data))
+    da, target, target_data = (from_xarray(v) if is_xarray(v) else v for v in (da, target, target_data))
+    for var_name, variable, allowed in [("da", da, (DataArray,)), ("target", target, (DataArray, np.ndarray)),
+                                        ("target_data", target_data, (DataArray,))]:
+        if not (isinstance(variable, allowed) or variable is None):
+            raise ValueError(
+                f"`{var_name}` needs to be a {' or '.join(str(a) for a in allowed)}. Found {type(variable)}"
+            )
+
+    def check_other_dims(target_da):
+        da_other = set(da.dims) - set(axis.coords.values())
+        target_other = set(target_da.dims) - set(axis.coords.values())
+        if not target_other.issubset(da_other):
+            raise ValueError(
+                f"Found additional dimensions [{target_other - da_other}]"
+                "in `target_data` not found in `da`. This could mean that the target "
+                "array is not on the same position along other axes."
+                " If the additional dimensions are associated witha staggered axis, "
+                "use grid.interp() to move values to other grid position. "
+                "If additional dimensions are not related to the grid (e.g. climate "
+                "model ensemble members or similar), use xr.broadcast() before using transform."
+            )
+
+    def parse_target(target, target_dim, target_data_dim, target_data):
+        if target_data is None:
+            target_data = grid._ds[target_data_dim]
+        if target_dim is None:
+            if isinstance(target, DataArray):
+                if len(target.dims) == 1:
+                    target_dim = list(target.dims)[0]
+            else:
+                if target_data.name is None:
+                    warnings.warn(
+                        "Input`target_data` has no name, but we need a name for the transformed dimension. The name `TRANSFORMED_DIMENSION` will be used. To avoid this warning, call `.rename` on `target_data` before calling `transform`."
+                    )
+                    target_data = target_data.rename("TRANSFORMED_DIMENSION")
+                target_dim = target_data.name
+        elif isinstance(target, DataArray) and target_dim not in target.dims:
+            raise ValueError(
+                f"The specified `target_dim` {target_dim} is not within the dimensions of the target: [{target.dims}]."
+            )
+        if target_dim is None:
+            raise ValueError("`target` has more than one dimension: `target_dim` must be given explicitly")
+        if not isinstance(target, DataArray):
+            target = DataArray(np.asarray(target), dims=[target_dim], coords={target_dim: np.asarray(target)})
+        check_other_dims(target_data)
+        return target, target_dim, target_data
+
+    _, dim = axis._get_position_name(da)
+    if method in ("linear", "log"):
+        target, target_dim, target_data = parse_target(target, target_dim, dim, target_data)
+        out = linear_interpolation(da, target_data, target, dim, dim, target_dim, suffix=suffix, mask_edges=mask_edges,
+                                   bypass_checks=bypass_checks, logarithmic=(method == "log"))
+    elif method == "conservative":
+        if isinstance(target, DataArray) and len(target.dims) > 1:
+            raise NotImplementedError(
+                "Conservative transformation is not yet supported for multi-dimensional targets."
+            )
+        try:
+            target_data_dim = axis.coords["outer"]
+        except KeyError:
+            raise RuntimeError(
+                "In order to use the method `conservative` the grid object needs to have `outer` coordinates."
+            )
+        target, target_dim, target_data = parse_target(target, target_dim, target_data_dim, target_data)
+        if target_data_dim not in target_data.dims:
+            warnings.warn(
+                "The `target data` input is not located on the cell bounds. This method will continue with linear interpolation with repeated boundary values. For most accurate results provide values on cell bounds.",
+                UserWarning,
+            )
+            target_data = grid.interp(target_data, axis_name, padding="extend")
+        out = conservative_interpolation(da, target_data, target, dim, target_data_dim, target_dim, suffix=suffix)
+    else:
+        raise ValueError(f"unknown transform method {method!r}: use 'linear', 'log' or 'conservative'")
+    return to_xarray(out) if was_xr else out
