@@ -349,12 +349,21 @@ def test_linear_kernel_equals_numpy_interp(backend, kind, dtype):
     phi = (R.synthetic_field(shape, 5) * 10).astype(dtype)
     phi[0, 0, 4] = np.nan
     levels = np.concatenate([[-1.0, np.nan], np.linspace(0.0, float(np.nanmax(theta)) + 1, 23), [theta[1, 2, 5]]]).astype(dtype)
-    for mask in (False, True):
-        for bypass in (False, True):
-            got = X.interp_1d_linear(phi, theta, levels, mask_edges=mask, bypass_checks=bypass)
-            want = TR.interp_1d_linear(phi, theta, levels, mask_edges=mask, bypass_checks=bypass)
-            assert got.dtype == dtype
-            np.testing.assert_array_equal(got, want)
+    # sorted, NaN-free targets (the kernel's streaming path on well-formed columns): values left and right
+    # of every column, repeated levels, levels that coincide with theta entries (first, inner, last)
+    clean = np.sort(np.concatenate([levels[~np.isnan(levels)], [theta[0, 0, 0], theta[2, 4, -1], theta[1, 2, 5]],
+                                    np.nan_to_num(theta[2, 3, 6:9], nan=1.0)])).astype(dtype)
+    for lv in (levels, clean):
+        for mask in (False, True):
+            for bypass in (False, True):
+                got = X.interp_1d_linear(phi, theta, lv, mask_edges=mask, bypass_checks=bypass)
+                want = TR.interp_1d_linear(phi, theta, lv, mask_edges=mask, bypass_checks=bypass)
+                assert got.dtype == dtype
+                np.testing.assert_array_equal(got, want)
+    # every column interpolated onto its own (sorted) theta values: exact hits all the way
+    own = np.sort(np.nan_to_num(theta, nan=0.5), axis=-1)
+    np.testing.assert_array_equal(X.interp_1d_linear(phi, theta, own, mask_edges=True),
+                                  TR.interp_1d_linear(phi, theta, own, mask_edges=True))
     # a target that varies from column to column, theta a single shared profile
     lv2 = (levels[None, None, 2:] + R.synthetic_field((3, 5, 1), 9)).astype(dtype)
     got = X.interp_1d_linear(phi, theta[0, 0], lv2, mask_edges=True)

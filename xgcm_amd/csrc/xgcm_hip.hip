@@ -88,6 +88,7 @@ struct Tune {
   int seg;       // rows marched per wave-task along a strided stencil axis
   int nt_store;  // non-temporal stores (+2-4 %; non-temporal LOADS measured -1 % and are not used)
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
+  int transform_lds_kb;  // LDS budget of the cell-major conservative kernel (0: always the register-tile kernel)
   int transform_fast;  // streaming path of the linear transform for well-formed columns (0: always the exact search)
   int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
@@ -105,6 +106,7 @@ struct Tune {
     zband = env_int("XG_ZBAND", 1);
     zchunk = env_int("XG_ZCHUNK", 256);
     transform_fast = env_int("XG_TRANSFORM_FAST", 1);
+    transform_lds_kb = env_int("XG_TRANSFORM_LDS_KB", 64);
     seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
     seg = env_int("XG_SEG", 1 << 30);  // long march: whole column by default
     nt_store = env_int("XG_NT_STORE", 1);
@@ -1365,43 +1367,50 @@ __global__ __launch_bounds__(BLOCK) void k_transform_linear(
       double xk = (double)(flip ? a1 : a0);
       double fk = (double)pphi[(flip ? n - 1 : 0) * inner];
       const double lval = fk;
-      real prev_lev = (real)0;
-      bool have_prev = false;
-      auto emit = [&](int64_t ii, real lev, double res) {
+      // the cursor's current target level, loaded once per target and validated on load
+      real lev = LEV(0);
+      if (lev != lev) exact = true;
+      auto emit_and_advance = [&](double res) {
         real r = (real)res;
         if (mask_edges && (lev < tmin || lev > tmax)) r = (real)NAN;
-        pout[ii * inner] = r;
+        pout[i * inner] = r;
+        ++i;
+        if (i < m) {
+          const real nxt = LEV(i);
+          if (nxt != nxt || nxt < lev) exact = true;
+          lev = nxt;
+        }
       };
-      for (int64_t k = 1; k < n && !exact; ++k) {
-        const int64_t kk = flip ? n - 1 - k : k;
-        const real tv = TH(kk);
-        const double xk1 = (double)tv, fk1 = (double)pphi[kk * inner];
-        if (tv != tv || xk1 < xk) { exact = true; break; }
-        while (i < m) {
-          const real lev = LEV(i);
-          if (lev != lev || (have_prev && lev < prev_lev)) { exact = true; break; }
-          const double xv = (double)lev;
-          if (!(xv < xk1)) break;            // belongs to a later interval (or to the right edge)
-          double res;
-          if (xv < xk) res = lval;           // only possible while k == 1: left of the column
-          else if (xv == xk) res = fk;
-          else res = interp_pair(xv, xk, xk1, fk, fk1);
-          emit(i, lev, res);
-          prev_lev = lev; have_prev = true;
-          ++i;
+      constexpr int UT = 4;  // levels fetched ahead of use: the column loads do not wait on each other
+      for (int64_t k0 = 1; k0 < n && !exact; k0 += UT) {
+        real tvs[UT], fvs[UT];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+          const int64_t k = (k0 + u < n) ? k0 + u : n - 1;
+          const int64_t kk = flip ? n - 1 - k : k;
+          tvs[u] = TH(kk);
+          fvs[u] = pphi[kk * inner];
         }
-        xk = xk1; fk = fk1;
-      }
-      if (!exact) {
-        // remaining targets are >= xp[n-1]: the last point itself, or right of the column
-        while (i < m) {
-          const real lev = LEV(i);
-          if (lev != lev || (have_prev && lev < prev_lev)) { exact = true; break; }
-          emit(i, lev, fk);                  // key == xp[n-1] -> fp[n-1]; key > xp[n-1] -> rval == fp[n-1]
-          prev_lev = lev; have_prev = true;
-          ++i;
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+          if (k0 + u >= n || exact) break;
+          const real tv = tvs[u];
+          const double xk1 = (double)tv, fk1 = (double)fvs[u];
+          if (tv != tv || xk1 < xk) { exact = true; break; }
+          while (i < m && !exact) {
+            const double xv = (double)lev;
+            if (!(xv < xk1)) break;          // belongs to a later interval (or to the right edge)
+            double res;
+            if (xv < xk) res = lval;         // only possible in the first interval: left of the column
+            else if (xv == xk) res = fk;
+            else res = interp_pair(xv, xk, xk1, fk, fk1);
+            emit_and_advance(res);
+          }
+          xk = xk1; fk = fk1;
         }
       }
+      // remaining targets are >= xp[n-1]: the last point itself (fp[n-1]) or right of it (rval == fp[n-1])
+      while (i < m && !exact) emit_and_advance(fk);
     }
     if (!exact) return;
   }
@@ -1474,9 +1483,93 @@ __global__ __launch_bounds__(BLOCK) void k_transform_conservative(
       b2[t] = bins[j + 1];
     }
     real t1 = pth[0];
-    for (int64_t i = 0; i < n; ++i) {
-      const real t2 = pth[(i + 1) * mt.axis];
-      const real p = pphi[i * inner];
+    constexpr int UT = 4;  // cells fetched ahead of use (the loads of a pass do not depend on each other)
+    for (int64_t i0 = 0; i0 < n; i0 += UT) {
+      real tts[UT], pps[UT];
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int64_t i = (i0 + u < n) ? i0 + u : n - 1;
+        tts[u] = pth[(i + 1) * mt.axis];
+        pps[u] = pphi[i * inner];
+      }
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        if (i0 + u >= n) break;
+        const real t2 = tts[u], p = pps[u];
+        const real a1 = t1;
+        t1 = t2;
+        const bool n1 = a1 != a1, n2 = t2 != t2;
+        if (n1 && n2) continue;
+        real lo_, hi_;
+        if (n1) { lo_ = hi_ = t2; }
+        else if (n2) { lo_ = hi_ = a1; }
+        else if (a1 < t2) { lo_ = a1; hi_ = t2; }
+        else { lo_ = t2; hi_ = a1; }
+        if (p != p) continue;
+        if (b1[0] > hi_ || b2[JT - 1] < lo_) continue;  // bins increase: the cell misses this whole tile
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+          if (b1[t] > hi_ || b2[t] < lo_) continue;
+          real add;
+          if (hi_ == lo_) {
+            add = p;
+          } else {
+            const real hmin = (b1[t] > lo_) ? b1[t] : lo_;  // python max(theta_min, theta_hat_1)
+            const real hmax = (b2[t] < hi_) ? b2[t] : hi_;  // python min(theta_max, theta_hat_2)
+            const real alpha = (hmax - hmin) / (hi_ - lo_);
+            add = alpha * p;
+          }
+          acc[t] = (acc[t] != acc[t]) ? add : acc[t] + add;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < JT; ++t)
+      if (j0 + t < m) pout[(j0 + t) * inner] = acc[t];
+  }
+}
+
+// K9c conservative, accumulators in LDS: cell-major order like the reference's loops.  Each lane
+// owns m accumulator slots ([bin][lane] layout) and a cursor into the sorted bin edges, so a cell
+// only visits the bins it overlaps (1-3 for stratified columns) instead of testing all m; per bin
+// the additions still arrive in cell order => same bits as K9b / the reference.  Column data is
+// streamed once (2n + 1 loads per column, coalesced).
+constexpr int CTB = 128;
+#ifndef XG_CONS_UT
+#define XG_CONS_UT 16
+#endif
+extern __shared__ __align__(16) unsigned char xg_dyn_lds[];
+
+__global__ __launch_bounds__(CTB) void k_transform_conservative_lds(
+    const real* __restrict__ phi, const real* __restrict__ theta, const real* __restrict__ bins,
+    real* __restrict__ out, Geo g, MIdx mt) {
+  const int64_t inner = g.inner, n = g.n_in, m = g.n_out;
+  real* sb = reinterpret_cast<real*>(xg_dyn_lds);          // m + 1 edges, padded to an even count
+  real* acc = sb + ((m + 2) & ~(int64_t)1) + threadIdx.x;  // slot of bin j: acc[j * CTB]
+  for (int64_t j = threadIdx.x; j <= m; j += CTB) sb[j] = bins[j];
+  __syncthreads();
+  const int64_t c = (int64_t)blockIdx.x * CTB + threadIdx.x;
+  if (c >= g.outer * g.inner) return;
+  const int64_t o = c / inner, x = c - o * inner;
+  const real* pphi = phi + (o * n) * inner + x;
+  const real* pth = theta + outer_off(g, mt, o) + inner_off(g, mt, x);
+  real* pout = out + (o * m) * inner + x;
+  for (int64_t j = 0; j < m; ++j) acc[j * CTB] = (real)NAN;
+  int64_t jlo = 0;
+  real t1 = pth[0];
+  constexpr int UT = XG_CONS_UT;
+  for (int64_t i0 = 0; i0 < n; i0 += UT) {
+    real tts[UT], pps[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int64_t i = (i0 + u < n) ? i0 + u : n - 1;
+      tts[u] = pth[(i + 1) * mt.axis];
+      pps[u] = pphi[i * inner];
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      if (i0 + u >= n) break;
+      const real t2 = tts[u], p = pps[u];
       const real a1 = t1;
       t1 = t2;
       const bool n1 = a1 != a1, n2 = t2 != t2;
@@ -1487,26 +1580,28 @@ __global__ __launch_bounds__(BLOCK) void k_transform_conservative(
       else if (a1 < t2) { lo_ = a1; hi_ = t2; }
       else { lo_ = t2; hi_ = a1; }
       if (p != p) continue;
-      if (b1[0] > hi_ || b2[JT - 1] < lo_) continue;  // bins increase: the cell misses this whole tile
-#pragma unroll
-      for (int t = 0; t < JT; ++t) {
-        if (b1[t] > hi_ || b2[t] < lo_) continue;
+      // first bin whose upper edge reaches the cell: min{j: edge[j+1] >= lo}
+      while (jlo > 0 && sb[jlo] >= lo_) --jlo;
+      while (jlo < m && sb[jlo + 1] < lo_) ++jlo;
+      for (int64_t j = jlo; j < m; ++j) {
+        const real e1 = sb[j];
+        if (e1 > hi_) break;               // later bins start above the cell
+        const real e2 = sb[j + 1];
         real add;
         if (hi_ == lo_) {
           add = p;
         } else {
-          const real hmin = (b1[t] > lo_) ? b1[t] : lo_;  // python max(theta_min, theta_hat_1)
-          const real hmax = (b2[t] < hi_) ? b2[t] : hi_;  // python min(theta_max, theta_hat_2)
+          const real hmin = (e1 > lo_) ? e1 : lo_;
+          const real hmax = (e2 < hi_) ? e2 : hi_;
           const real alpha = (hmax - hmin) / (hi_ - lo_);
           add = alpha * p;
         }
-        acc[t] = (acc[t] != acc[t]) ? add : acc[t] + add;
+        const real old = acc[j * CTB];
+        acc[j * CTB] = (old != old) ? add : old + add;
       }
     }
-#pragma unroll
-    for (int t = 0; t < JT; ++t)
-      if (j0 + t < m) pout[(j0 + t) * inner] = acc[t];
   }
+  for (int64_t j = 0; j < m; ++j) pout[j * inner] = acc[j * CTB];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2273,9 +2368,21 @@ int XG_FN(xg_transform_conservative)(const real* phi, const real* theta, const i
   if (rc) return rc;
   const int64_t cols = g.outer * g.inner;
   if (cols == 0) return XG_OK;
-  const u64 nblocks = ((u64)cols + BLOCK - 1) / BLOCK;
-  if ((rc = check_grid(nblocks))) return rc;
-  hipLaunchKernelGGL((k_transform_conservative<8>), dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+  const int64_t m = n_edges - 1;
+  const size_t lds = ((size_t)((m + 2) & ~(int64_t)1) + (size_t)m * CTB) * sizeof(real);
+  if (tune().transform_lds_kb > 0 && lds <= (size_t)tune().transform_lds_kb * 1024u) {
+    const u64 nblocks = ((u64)cols + CTB - 1) / CTB;
+    if ((rc = check_grid(nblocks))) return rc;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_transform_conservative_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(XG_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k_transform_conservative_lds, dim3((u32)nblocks), dim3(CTB), lds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+  } else {
+    const u64 nblocks = ((u64)cols + BLOCK - 1) / BLOCK;
+    if ((rc = check_grid(nblocks))) return rc;
+    hipLaunchKernelGGL((k_transform_conservative<8>), dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+  }
   XG_LAUNCH_CHECK();
   return XG_OK;
 }
