@@ -16,7 +16,7 @@ Metadata logic (axis lookup, default shifts, per-axis kwargs, metric search, coo
 re-attachment, error types and messages) is restated from the reference so that the parity tests
 read like the reference's own.  Grids with face connections or a north fold take the generic
 pad-then-apply route (halo gather `xg_gather_f64`, then the un-padded stencil kernel).  Out of scope
-and rejected loudly: dask-chunked inputs, metadata autoparsing, `transform`.
+and rejected loudly: dask-chunked inputs, metadata autoparsing.
 """
 
 from __future__ import annotations
