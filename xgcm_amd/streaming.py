@@ -1,0 +1,172 @@
+"""Host <-> HBM record streaming (first half: out-of-core inputs).
+
+The reference reaches larger-than-memory datasets through dask: one chunk at a time is loaded,
+processed by numpy and written back (`xgcm/grid.py:786-818`).  The accelerator analogue is a
+pipeline over the record (outermost, e.g. time) axis of a HOST array:
+
+    copy-in stream:   H2D of record block k+1      |  three HIP streams, ordered by events, so the
+    compute stream:   Grid operators on block k    |  PCIe transfers in both directions overlap with
+    copy-out stream:  D2H of the result of k-1     |  the kernels (which take ~2 % of the time)
+
+so a record batch that does not fit the 288 GB of HBM -- or that simply lives on the host -- is
+processed at the PCIe rate instead of (PCIe in) + (kernel) + (PCIe out) + pageable-copy overheads.
+Host memory is page-locked in place (`hipHostRegister` through torch's runtime handle) when
+possible, else staged through pinned buffers.  PyTorch provides streams, events and the caching
+allocator here; the arithmetic is the HIP library's as everywhere else.
+"""
+
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .labeled import DataArray
+
+__all__ = ["record_blocks", "stream_records", "stream_apply"]
+
+
+def record_blocks(n_records: int, block: int) -> List[Tuple[int, int]]:
+    """[start, stop) of consecutive record blocks (the last one may be short)."""
+    if block < 1:
+        raise ValueError("block must be >= 1")
+    return [(s, min(s + block, n_records)) for s in range(0, n_records, block)]
+
+
+class _Pinned:
+    """Page-lock a numpy array in place for the lifetime of the object (fallback: not pinned)."""
+
+    def __init__(self, arr: np.ndarray):
+        self.arr = arr
+        self.tensor = torch.from_numpy(arr)
+        self.registered = False
+        try:
+            rt = torch.cuda.cudart()
+            err = rt.cudaHostRegister(self.tensor.data_ptr(), self.tensor.numel() * self.tensor.element_size(), 0)
+            self.registered = int(err) == 0
+        except Exception:
+            self.registered = False
+
+    def close(self) -> None:
+        if self.registered:
+            try:
+                torch.cuda.cudart().cudaHostUnregister(self.tensor.data_ptr())
+            except Exception:
+                pass
+            self.registered = False
+
+
+def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, block: int = 1,
+                   out: Optional[np.ndarray] = None, register: bool = True) -> np.ndarray:
+    """Apply `fn` (HBM tensor of `block` records -> HBM tensor with the same leading length) to a
+    C-contiguous host array record block by record block, with H2D / compute / D2H overlapped."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("xgcm_amd.streaming needs a GPU (there is no CPU fallback)")
+    src = np.asarray(src)
+    if not src.flags.c_contiguous:
+        raise ValueError("the host array must be C-contiguous (records along the first axis)")
+    n = src.shape[0]
+    blocks = record_blocks(n, block)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    s_cmp = torch.cuda.current_stream(dev)
+    pin_src = _Pinned(src) if register else None
+    src_t = pin_src.tensor if pin_src is not None else torch.from_numpy(src)
+    # page-locking in place failed (or was declined): stage through two pinned buffers per direction
+    stage_in = None
+    if pin_src is None or not pin_src.registered:
+        stage_in = [torch.empty((block,) + src.shape[1:], dtype=src_t.dtype).pin_memory() for _ in range(2)]
+    in_done: List[Optional[torch.cuda.Event]] = [None, None]
+    pin_out: Optional[_Pinned] = None
+    out_t: Optional[torch.Tensor] = None
+    stage_out: Optional[List[torch.Tensor]] = None
+    pending: List[Optional[Tuple[int, int, torch.cuda.Event]]] = [None, None]
+
+    def drain(slot: int) -> None:
+        """finish the D2H that went into staging buffer `slot` and move it to its place in `out`"""
+        if stage_out is None or pending[slot] is None:
+            return
+        a0, b0, ev = pending[slot]
+        ev.synchronize()
+        out_t[a0:b0].copy_(stage_out[slot][: b0 - a0])
+        pending[slot] = None
+
+    try:
+        for k, (a, b) in enumerate(blocks):
+            slot = k % 2
+            with torch.cuda.stream(s_in):
+                if stage_in is not None:
+                    if in_done[slot] is not None:
+                        in_done[slot].synchronize()      # the H2D that last read this staging buffer is done
+                    stage_in[slot][: b - a].copy_(src_t[a:b])
+                    host_block = stage_in[slot][: b - a]
+                else:
+                    host_block = src_t[a:b]
+                x = host_block.to(dev, non_blocking=True)
+                ev_in = torch.cuda.Event()
+                ev_in.record(s_in)
+                in_done[slot] = ev_in
+            s_cmp.wait_event(ev_in)
+            x.record_stream(s_cmp)
+            y = fn(x)
+            if y.shape[0] != b - a:
+                raise ValueError("fn must keep the record axis (first dim) of its block")
+            ev_cmp = torch.cuda.Event()
+            ev_cmp.record(s_cmp)
+            if out_t is None:
+                if out is None:
+                    out = np.empty((n,) + tuple(y.shape[1:]), dtype=np.float32 if y.dtype == torch.float32 else np.float64)
+                if not out.flags.c_contiguous or out.shape[0] != n or tuple(out.shape[1:]) != tuple(y.shape[1:]):
+                    raise ValueError("`out` must be C-contiguous with the result's shape")
+                pin_out = _Pinned(out) if register else None
+                out_t = pin_out.tensor if pin_out is not None else torch.from_numpy(out)
+                if pin_out is None or not pin_out.registered:
+                    stage_out = [torch.empty((block,) + tuple(y.shape[1:]), dtype=y.dtype).pin_memory() for _ in range(2)]
+            drain(slot)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_cmp)
+                y.record_stream(s_out)
+                if stage_out is not None:
+                    stage_out[slot][: b - a].copy_(y, non_blocking=True)
+                else:
+                    out_t[a:b].copy_(y, non_blocking=True)
+                ev_out = torch.cuda.Event()
+                ev_out.record(s_out)
+            pending[slot] = (a, b, ev_out)
+            del x, y
+        drain(0)
+        drain(1)
+        s_out.synchronize()
+        s_in.synchronize()
+    finally:
+        if pin_src is not None:
+            pin_src.close()
+        if pin_out is not None:
+            pin_out.close()
+    return out
+
+
+def stream_apply(fn: Callable[[DataArray], DataArray], da: DataArray, record_dim: Optional[str] = None,
+                 block: int = 1) -> DataArray:
+    """Labelled form: `fn` maps a device-resident block `DataArray` (same dims as `da`, `block`
+    records along the FIRST dim) to a `DataArray`; the host result keeps `fn`'s dims and name."""
+    if record_dim is None:
+        record_dim = da.dims[0]
+    if da.dims[0] != record_dim:
+        raise ValueError(f"the record dim {record_dim!r} must be the first (slowest) dim of the array, got {da.dims}")
+    meta = {}
+
+    def on_block(x: torch.Tensor) -> torch.Tensor:
+        res = fn(DataArray(x, da.dims, name=da.name))
+        if res.dims[0] != record_dim:
+            raise ValueError("fn must keep the record dim first")
+        meta.setdefault("dims", res.dims)
+        meta.setdefault("name", res.name)
+        return res.data if isinstance(res.data, torch.Tensor) else torch.as_tensor(res.data, device=x.device)
+
+    host = np.ascontiguousarray(da.values)
+    out = stream_records(on_block, host, block=block)
+    coords = {k: c for k, c in da.coords.items() if all(d in meta["dims"] for d in c.dims) and
+              all(c.sizes[d] == out.shape[meta["dims"].index(d)] for d in c.dims)}
+    return DataArray(out, meta["dims"], coords=coords, name=meta["name"])
