@@ -32,6 +32,7 @@
  *   xg_binary_f64      the xarray broadcasting `*`, `/`, `+`, `-` around the ops
  *                      (xgcm/grid.py:808,832,1578,1600; get_metric products :614-617)
  *   xg_stencil2d_f64   Grid.interp/diff/min/max over two axes (xgcm/grid.py:798-828), one pass
+ *   xg_divergence_f64  the chained (diff(u,X) + diff(v,Y)) / area of docs/ufunc_examples.md, fused
  *   xg_vorticity_f64   the chained (diff(v,X) - diff(u,Y)) / area of docs/ufunc_examples.md
  *                      (one fused pass instead of three apply_ufunc passes, grid.py:798-800 TODO)
  */
@@ -179,6 +180,14 @@ int xg_vorticity_f64(const double* u, const double* v, const double* area,
                      const int64_t* area_strides, double* out, const int64_t* shape, int ndim,
                      int bc_x, double fill_x, int bc_y, double fill_y, void* stream);
 
+/* ---- fused horizontal divergence (docs/ufunc_examples.md "Divergence") -------------------- */
+/* out[..,j,i] = ((u[..,j,i+1] - u[..,j,i]) + (v[..,j+1,i] - v[..,j,i])) / area: both differences
+ * left -> center (padding_width (0,1)), halos per bc_x / bc_y as in xg_stencil1d; same argument
+ * list as xg_vorticity_f64; bit-identical to (diff(u,X) + diff(v,Y)) / area run operator by operator. */
+int xg_divergence_f64(const double* u, const double* v, const double* area,
+                     const int64_t* area_strides, double* out, const int64_t* shape, int ndim,
+                     int bc_x, double fill_x, int bc_y, double fill_y, void* stream);
+
 /* ---- the same two-point operator along the last TWO axes in one pass -------------------- */
 /* out = OP_second(pad(OP_first(pad(in)))) for (.., Y, X) arrays, order 0: X then Y, 1: Y then X;
  * replaces two sequential apply_as_grid_ufunc passes of Grid.interp/diff/min/max(da, [ax1, ax2])
@@ -232,6 +241,9 @@ int xg_binary_f32(int op, const float* a, const int64_t* a_strides, const float*
                   const int64_t* b_strides, float* out, const int64_t* shape, int ndim,
                   void* stream);
 int xg_vorticity_f32(const float* u, const float* v, const float* area,
+                     const int64_t* area_strides, float* out, const int64_t* shape, int ndim,
+                     int bc_x, float fill_x, int bc_y, float fill_y, void* stream);
+int xg_divergence_f32(const float* u, const float* v, const float* area,
                      const int64_t* area_strides, float* out, const int64_t* shape, int ndim,
                      int bc_x, float fill_x, int bc_y, float fill_y, void* stream);
 int xg_stencil2d_f32(int op, const float* in, float* out, const int64_t* shape, int ndim, int order,

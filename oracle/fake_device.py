@@ -111,6 +111,13 @@ def vorticity(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0):
     return R.vorticity(u, v, area, bc_x, bc_y, fill_x, fill_y)
 
 
+def divergence(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0):
+    u, v, area = _cast(_common(u, v, area), u, v, area)
+    if area is None:
+        area = np.ones((1,) * u.ndim, dtype=u.dtype)
+    return R.divergence(u, v, area, bc_x, bc_y, fill_x, fill_y)
+
+
 def stencil2d_supported(x, padx, pady):
     x = np.asarray(x)
     lane = 4 if x.dtype == np.float32 else 2
@@ -132,7 +139,7 @@ def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None, dtype=np.f
 
 
 _NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "stencil1d_halo", "cumsum1d", "reduce1d", "pad_nd", "gather", "upload_tokens", "transform_linear", "transform_conservative", "binary",
-          "vorticity", "stencil2d", "stencil2d_supported", "synthetic"]
+          "vorticity", "divergence", "stencil2d", "stencil2d_supported", "synthetic"]
 
 
 def install(monkeypatch):

@@ -264,6 +264,14 @@ def vorticity(u, v, area, padding_x, padding_y, fill_x=0.0, fill_y=0.0):
     return (dvdx - dudy) / area
 
 
+def divergence(u, v, area, padding_x, padding_y, fill_x=0.0, fill_y=0.0):
+    """`(diff(u,'X') + diff(v,'Y')) / area` on (..., Y, X) arrays, both diffs left->center, i.e.
+    padding_width (0,1) (docs/ufunc_examples.md "Divergence", with the metric of the result)."""
+    dudx = stencil1d("diff", u, u.ndim - 1, 0, 1, padding_x, fill_x)
+    dvdy = stencil1d("diff", v, v.ndim - 2, 0, 1, padding_y, fill_y)
+    return (dudx + dvdy) / area
+
+
 # --------------------------------------------------------------------------------------
 # synthetic C-grid fields, bit-identical on host and device (SURVEY.md section 8(d))
 # --------------------------------------------------------------------------------------

@@ -132,3 +132,6 @@ def test_fuzz_two_axis_and_vorticity(dev, seed, dtype):
         exp = R.vorticity(a, b, area if area is not None else np.ones((1,) * nd, dtype=dtype), bcx, bcy, dtype(0.25), dtype(-0.5))
         got = dev.tohost(dev.vorticity(a, b, area, bcx, bcy, 0.25, -0.5))
         assert np.array_equal(got, exp), (shape, "vorticity", bcx, bcy, area is not None)
+        exp = R.divergence(a, b, area if area is not None else np.ones((1,) * nd, dtype=dtype), bcx, bcy, dtype(0.25), dtype(-0.5))
+        got = dev.tohost(dev.divergence(a, b, area, bcx, bcy, 0.25, -0.5))
+        assert np.array_equal(got, exp), (shape, "divergence", bcx, bcy, area is not None)

@@ -262,6 +262,25 @@ def test_vorticity_fused_equals_unfused_chain(dev, shape):
     _eq(dev.tohost(chain), R.vorticity(u, v, area2d, "fill", "fill"))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(3, 9, 64), (2, 70, 33), (5, 6), (2, 2, 130, 258), (4, 1, 2), (3, 5, 4)])
+def test_divergence_fused_equals_unfused_chain(dev, shape, dtype):
+    u = _field(shape, 61).astype(dtype)
+    v = _field(shape, 62).astype(dtype)
+    area2d = R.synthetic_metric((1,) * (len(shape) - 2) + shape[-2:], 63).astype(dtype)
+    for bc_x, bc_y in itertools.product(BCS, BCS):
+        exp = R.divergence(u, v, area2d, bc_x, bc_y, dtype(0.25), dtype(-0.5))
+        got = dev.tohost(dev.divergence(u, v, area2d, bc_x, bc_y, 0.25, -0.5))
+        assert got.dtype == dtype
+        _eq(got, exp)
+        _eq(dev.tohost(dev.divergence(u, v, None, bc_x, bc_y, 0.25, -0.5)),
+            R.divergence(u, v, np.ones((1,) * len(shape), dtype=dtype), bc_x, bc_y, dtype(0.25), dtype(-0.5)))
+    du = dev.stencil1d("diff", u, len(shape) - 1, 0, 1, "periodic", 0.0)
+    dv = dev.stencil1d("diff", v, len(shape) - 2, 0, 1, "extend", 0.0)
+    chain = dev.binary("div", dev.binary("add", du, dv), area2d)
+    _eq(dev.tohost(chain), dev.tohost(dev.divergence(u, v, area2d, "periodic", "extend")))
+
+
 def test_synthetic_bit_identical(dev):
     for n, seed, off in [(1000, 1, 0), (4097, 4, 123456789), (10, 53, 2**40)]:
         got = dev.tohost(dev.synthetic((n,), seed, off))

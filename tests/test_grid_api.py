@@ -662,6 +662,33 @@ def test_fused_vorticity_equals_operator_chain(backend):
     assert np.array_equal(_np(zeta), R.vorticity(ds["U"].values, ds["V"].values, ds["rAz"].values[None], "fill", "fill"))
 
 
+def test_fused_divergence_equals_operator_chain(backend):
+    """docs/ufunc_examples.md "Divergence": u (YC, XG), v (YG, XC) -> cell centre, one launch."""
+    nz, ny, nx = 3, 6, 8
+    coords = {"XC": ("XC", np.arange(nx) + 0.5), "XG": ("XG", np.arange(nx) * 1.0),
+              "YC": ("YC", np.arange(ny) + 0.5), "YG": ("YG", np.arange(ny) * 1.0), "Z": ("Z", np.arange(nz) * 1.0)}
+    ds = Dataset({"U": (("Z", "YC", "XG"), R.synthetic_field((nz, ny, nx), 61)),
+                  "V": (("Z", "YG", "XC"), R.synthetic_field((nz, ny, nx), 62)),
+                  "rA": (("YC", "XC"), R.synthetic_metric((ny, nx), 63))}, coords)
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}},
+                metrics={("X", "Y"): ["rA"]}, padding={"X": "periodic", "Y": "fill"}, autoparse_metadata=False)
+    div = grid.divergence(ds["U"], ds["V"])
+    chain = (grid.diff(ds["U"], "X") + grid.diff(ds["V"], "Y")) / ds["rA"].reset_coords(drop=True)
+    assert div.dims == ("Z", "YC", "XC")
+    assert np.array_equal(_np(div), _np(chain))
+    assert np.array_equal(_np(div), R.divergence(ds["U"].values, ds["V"].values, ds["rA"].values[None], "periodic", "fill"))
+    # the user-ufunc form of the docs (pad (0,1) on both axes, then trimmed differences) gives the same bits
+    def divergence(u, v):
+        return (u[..., :-1, 1:] - u[..., :-1, :-1]) + (v[..., 1:, :-1] - v[..., :-1, :-1])
+
+    ref = grid.apply_as_grid_ufunc(divergence, ds["U"], ds["V"], axis=[("Y", "X"), ("Y", "X")],
+                                   signature="(Y:center,X:left),(Y:left,X:center)->(Y:center,X:center)",
+                                   padding_width={"X": (0, 1), "Y": (0, 1)})
+    assert np.array_equal(_np(grid.divergence(ds["U"], ds["V"], metric_weighted=False)), _np(ref))
+    with pytest.raises(NotImplementedError, match="u at"):
+        grid.divergence(ds["V"], ds["U"])
+
+
 def test_grid_constructor_errors(backend):
     ds, coords, metrics = cgrid()
     with pytest.raises(ValueError, match="`periodic` argument has been removed"):

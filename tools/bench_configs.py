@@ -238,6 +238,11 @@ def main():
         rec(5, "vorticity unfused operator chain (4 kernels), fused-equivalent bytes", timeit(chain, max(3, a.reps // 2)), c5, 24 + 8 / nz5)
         ok = bool(torch.equal(grid_fill.vorticity(U, V).data, chain().data))
         print(json.dumps({"config": 5, "check": "fused == unfused chain bit for bit at full size", "ok": ok}), flush=True)
+        grid_div = Grid(grid._ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}},
+                        padding="fill", autoparse_metadata=False)
+        rec(5, "divergence fused diff(u,X)+diff(v,Y) (f1, docs/ufunc_examples.md), fill", timeit(lambda: grid_div.divergence(U, V, metric_weighted=False), a.reps), c5, 24)
+        okd = bool(torch.equal(grid_div.divergence(U, V, metric_weighted=False).data, (grid_div.diff(U, "X") + grid_div.diff(V, "Y")).data))
+        print(json.dumps({"config": 5, "check": "fused divergence == operator chain bit for bit at full size", "ok": okd}), flush=True)
 
 
 if __name__ == "__main__":

@@ -302,6 +302,15 @@ __device__ __forceinline__ dv dvdx_of(dv vc, real vl) {
   return o;
 }
 __device__ __forceinline__ real dvdx_of(real vc, real vl) { return vc - vl; }
+// forward difference of a lane vector whose RIGHT neighbour is `ur`: (u[k+1] - u[k])
+__device__ __forceinline__ dv dudx_fwd(dv uc, real ur) {
+  dv o;
+#pragma unroll
+  for (int k = 0; k < NV - 1; ++k) o[k] = uc[k + 1] - uc[k];
+  o[NV - 1] = ur - uc[NV - 1];
+  return o;
+}
+__device__ __forceinline__ real dudx_fwd(real uc, real ur) { return ur - uc; }
 
 // two-point bodies; l = a[..., i], r = a[..., i+1] of the padded array (gridops.py:23-24,76-77,123-175)
 template <int OP>
@@ -1728,6 +1737,73 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
 }
 
 // ------------------------------------------------------------------------------------------
+// K7b: fused horizontal divergence (delta_x u + delta_y v) / area of docs/ufunc_examples.md
+// ("Divergence": u on (Y:center, X:left), v on (Y:left, X:center), both left -> center, i.e.
+// padding_width (0,1) on both axes).  Mirror image of K7: SEG rows of u with their right
+// neighbour, SEG+1 rows of v (the last one is the upper halo row of the segment).
+// ------------------------------------------------------------------------------------------
+template <int V, bool HAS_AREA, bool NTS, int SEG>
+__global__ __launch_bounds__(BLOCK) void k_divergence(
+    const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ area,
+    real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile,
+    FastDiv nseg, ZBand zb, int bc_x, real fill_x, int bc_y, real fill_y, int64_t a_so, int64_t a_sy,
+    int64_t a_sx) {
+  typedef typename VecT<V>::type T;
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
+  const u32 r = fdiv(w, ntile);
+  const u32 tile = w - r * ntile.d;
+  u32 oo, sg;
+  if (HAS_AREA && zb.on) {
+    if (!zband_map(zb, r, oo, sg)) return;
+  } else {
+    oo = fdiv(r, nseg);
+    if (oo >= nouter) return;
+    sg = r - oo * nseg.d;
+  }
+  const int64_t o = o0 + oo;
+  const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
+  if (i0 >= nx) return;
+  const int64_t j0 = (int64_t)sg * SEG;
+  const int64_t nrow = (ny - j0 < SEG) ? ny - j0 : SEG;
+  const real* pu = u + (o * ny + j0) * nx;
+  const real* pv = v + o * ny * nx + i0;
+  real* po = out + (o * ny + j0) * nx + i0;
+  const bool edge = (i0 + V >= nx);
+  const int64_t ridx = edge ? ((bc_x == XG_BC_PERIODIC) ? 0 : nx - 1) : i0 + V;
+  const bool fill_edge = edge && (bc_x == XG_BC_FILL);
+
+  T uu[SEG], vv[SEG + 1];
+  real ur[SEG];
+#pragma unroll
+  for (int s_ = 0; s_ < SEG; ++s_) {
+    const int64_t jr = (s_ < nrow) ? s_ : nrow - 1;
+    uu[s_] = *reinterpret_cast<const T*>(pu + jr * nx + i0);
+    ur[s_] = pu[jr * nx + ridx];
+    vv[s_] = *reinterpret_cast<const T*>(pv + (j0 + jr) * nx);
+  }
+  {
+    int64_t q = j0 + nrow;  // the row above the segment's last row
+    bool f = false;
+    if (q >= ny) { f = (bc_y == XG_BC_FILL); q = (bc_y == XG_BC_PERIODIC) ? 0 : ny - 1; }
+    T t = *reinterpret_cast<const T*>(pv + q * nx);
+    vv[SEG] = f ? splat<T>(fill_y) : t;
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < SEG; ++s_) {
+    if (s_ < nrow) {
+      const real right = fill_edge ? fill_x : ur[s_];
+      const T up = (s_ + 1 < nrow) ? vv[s_ + 1] : vv[SEG];
+      T z = dudx_fwd(uu[s_], right) + (up - vv[s_]);
+      if (HAS_AREA) z = z / ldm<T>(area, o * a_so + (j0 + s_) * a_sy + i0 * a_sx, a_sx);
+      stg<T, NTS>(po + s_ * nx, z);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K8: the same two-point operator along BOTH of the last two axes in one pass, e.g.
 // Grid.interp(da, ["X", "Y"]) (tracer -> vorticity point).  The reference applies the axes one
 // after the other (xgcm/grid.py:798-800 carries a TODO about fusing them): pad + op along the
@@ -2443,13 +2519,14 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
   return XG_OK;
 }
 
-int XG_FN(xg_vorticity)(const real* u, const real* v, const real* area, const int64_t* area_strides, real* out,
-                     const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y, void* stream) {
+static int curl_div_impl(bool div, const real* u, const real* v, const real* area, const int64_t* area_strides,
+                         real* out, const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y,
+                         void* stream) {
   if (!u || !v || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
   if (area && !area_strides) return fail(XG_ERR_INVALID, "area without strides");
   if (bc_x < XG_BC_PERIODIC || bc_x > XG_BC_EXTEND || bc_y < XG_BC_PERIODIC || bc_y > XG_BC_EXTEND)
-    return fail(XG_ERR_INVALID, "vorticity needs a boundary mode on both axes");
+    return fail(XG_ERR_INVALID, "vorticity / divergence need a boundary mode on both axes");
   const int64_t ny = shape[ndim - 2], nx = shape[ndim - 1];
   int64_t outer = 1;
   for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
@@ -2496,7 +2573,8 @@ int XG_FN(xg_vorticity)(const real* u, const real* v, const real* area, const in
     const u64 waves = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * (u64)outer * ntile : (u64)nouter * per_outer;
     const u32 nblk = (u32)((waves + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GO(V_, A_, NTS) hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, a_so, a_sy, a_sx)
+#define XG_GO(V_, A_, NTS) do { if (div) hipLaunchKernelGGL((k_divergence<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, a_so, a_sy, a_sx); \
+                                else hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, a_so, a_sy, a_sx); } while (0)
 #define XG_A(V_, A_) do { if (nts) XG_GO(V_, A_, true); else XG_GO(V_, A_, false); } while (0)
     if (V > 1) { if (area) XG_A(NV, true); else XG_A(NV, false); }
     else { if (area) XG_A(1, true); else XG_A(1, false); }
@@ -2505,6 +2583,16 @@ int XG_FN(xg_vorticity)(const real* u, const real* v, const real* area, const in
   }
   XG_LAUNCH_CHECK();
   return XG_OK;
+}
+
+int XG_FN(xg_vorticity)(const real* u, const real* v, const real* area, const int64_t* area_strides, real* out,
+                     const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y, void* stream) {
+  return curl_div_impl(false, u, v, area, area_strides, out, shape, ndim, bc_x, fill_x, bc_y, fill_y, stream);
+}
+
+int XG_FN(xg_divergence)(const real* u, const real* v, const real* area, const int64_t* area_strides, real* out,
+                      const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y, void* stream) {
+  return curl_div_impl(true, u, v, area, area_strides, out, shape, ndim, bc_x, fill_x, bc_y, fill_y, stream);
 }
 
 int XG_FN(xg_stencil2d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,

@@ -35,6 +35,7 @@ __all__ = [
     "transform_conservative",
     "binary",
     "vorticity",
+    "divergence",
     "stencil2d",
     "stencil2d_supported",
     "synthetic",
@@ -407,6 +408,27 @@ def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: flo
         getattr(lib, "xg_vorticity_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
                              out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
                              _hip.BC[bc_y], float(fill_y), _stream())
+    )
+    return out
+
+
+def divergence(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0) -> torch.Tensor:
+    """Fused ((u[j,i+1]-u[j,i]) + (v[j+1,i]-v[j,i])) / area on (..., Y, X) arrays (xg_divergence_f64)."""
+    lib = _hip.load()
+    dt, sfx = _common(u, v, area)
+    u = asdevice(u, dt)
+    v = asdevice(v, dt)
+    if u.shape != v.shape:
+        raise ValueError("divergence: u and v must have the same shape")
+    shape = list(u.shape)
+    area = _prep_metric(area, dt)
+    out = torch.empty(shape, dtype=dt, device=u.device)
+    if out.numel() == 0:
+        return out
+    _hip.check(
+        getattr(lib, "xg_divergence_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
+                              out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
+                              _hip.BC[bc_y], float(fill_y), _stream())
     )
     return out
 

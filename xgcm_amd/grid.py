@@ -714,6 +714,47 @@ class Grid:
         res = _reattach_coords([res], self, None, {out_x, out_y}, [u, v])[0]
         return to_xarray(res) if (xr1 or xr2) else res
 
+    def divergence(self, u, v, x_axis: str = "X", y_axis: str = "Y", padding=None, fill_value=None,
+                   metric_weighted: bool = True):
+        """Fused horizontal divergence `(diff(u, X) + diff(v, Y)) / area` in one kernel launch.
+
+        `u` lives on (Y:center, X:left), `v` on (Y:left, X:center); both differences go left -> center
+        (the "Divergence" grid ufunc of the reference's docs/ufunc_examples.md, padding_width (0,1)),
+        so the result sits at the cell centre and -- with `metric_weighted` -- is divided by the
+        (X, Y) metric there.  Bit-identical to the chain of reference operators
+        `(grid.diff(u, X) + grid.diff(v, Y)) / grid.get_metric(div, (X, Y))`; pass transports
+        (u*dy, v*dx) for the finite-volume form."""
+        (u, xr1), (v, xr2) = self._wrap_in(u), self._wrap_in(v)
+        xa, ya = self.axes[x_axis], self.axes[y_axis]
+        if gridops.complex_topology(self, x_axis) or gridops.complex_topology(self, y_axis):
+            raise NotImplementedError(
+                "fused divergence is implemented for simple topologies; on grids with face connections or a "
+                "north fold chain the operators: (grid.diff(u, X) + grid.diff(v, Y)) / area"
+            )
+        ux_pos, ux_dim = xa._get_position_name(u)
+        uy_pos, uy_dim = ya._get_position_name(u)
+        vx_pos, vx_dim = xa._get_position_name(v)
+        vy_pos, vy_dim = ya._get_position_name(v)
+        if (ux_pos, uy_pos, vx_pos, vy_pos) != ("left", "center", "center", "left"):
+            raise NotImplementedError("fused divergence needs u at (Y:center, X:left) and v at (Y:left, X:center)")
+        out_x, out_y = xa.coords["center"], ya.coords["center"]
+        if u.dims[-2:] != (uy_dim, ux_dim) or v.dims[-2:] != (vy_dim, vx_dim) or u.dims[:-2] != v.dims[:-2]:
+            raise NotImplementedError("fused divergence needs u(..., YC, XG) and v(..., YG, XC) with (Y, X) last")
+        bc = self._complete_user_kwargs_using_axis_defaults(padding, "padding")
+        fv = self._complete_user_kwargs_using_axis_defaults(fill_value, "fill_value")
+        for a in (x_axis, y_axis):
+            if bc[a] is None:
+                raise no_boundary_error(a)
+        out_dims = u.dims[:-2] + (out_y, out_x)
+        area = None
+        if metric_weighted:
+            area = _aligned_view(self._resident(self.get_metric(_DimsOnly(out_dims), (x_axis, y_axis)), u.data), out_dims)
+        host = not (_is_tensor(u.data) or _is_tensor(v.data))
+        out = _dev.divergence(u.data, v.data, area, bc[x_axis], bc[y_axis], float(fv[x_axis] or 0.0), float(fv[y_axis] or 0.0))
+        res = DataArray(_dev.tohost(out) if host else out, out_dims)
+        res = _reattach_coords([res], self, None, {out_x, out_y}, [u, v])[0]
+        return to_xarray(res) if (xr1 or xr2) else res
+
     def transform(self, da, axis, target, **kwargs):
         """Convert `da` to new 1-D coordinates along `axis` (linear / log / conservative; reference
         grid.py:1687-1777 -> transform.py:284-514), one HIP kernel launch per call."""
