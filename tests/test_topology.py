@@ -646,3 +646,43 @@ def test_two_axes_on_connected_grid_run_one_axis_at_a_time(backend):
     assert not np.array_equal(both, plain.diff(ds.data_c, ["X", "Y"]).values)
     with pytest.raises(NotImplementedError, match="chain the operators"):
         grid.vorticity(ds.u, ds.v)
+
+
+def test_fold_operator_with_both_halos_and_float32(backend):
+    """center -> outer along the fold axis needs the south halo (basic `south` mode) AND the folded
+    north halo in one halo slab; float32 stays float32."""
+    ds = Dataset(coords={"xh": np.arange(Nx), "yh": np.arange(Ny), "yq": np.arange(Ny + 1)})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        grid = Grid(ds, coords={"X": {"center": "xh"}, "Y": {"center": "yh", "outer": "yq"}},
+                    padding={"X": "periodic", "Y": {"fold": "corner", "south": "extend"}}, autoparse_metadata=False)
+    for dtype in (np.float64, np.float32):
+        a = R.synthetic_field((3, Ny, Nx), 81).astype(dtype)
+        da = DataArray(a, dims=("z", "yh", "xh"))
+        got = grid.interp(da, "Y", to="outer")
+        assert got.dims == ("z", "yq", "xh") and got.values.dtype == dtype
+        padded = np.concatenate([a[:, :1], a, a[:, -1:, ::-1]], axis=1)   # south: extend; north: mirrored top row
+        np.testing.assert_array_equal(got.values, ((padded[:, :-1] + padded[:, 1:]) / dtype(2.0)).astype(dtype))
+
+
+@pytest.mark.gpu
+def test_resident_tensors_on_complex_topologies():
+    """HBM-resident inputs stay resident (token map uploaded once and cached on the grid)."""
+    import torch
+
+    from xgcm_amd import device as dev
+
+    cs = _faces_ds(6, 8, seed=91)
+    grid = Grid(cs, coords=COORDS, face_connections=CUBED_SPHERE, autoparse_metadata=False)
+    a = R.synthetic_field((3, 6, 8, 8), 92)
+    da = DataArray(dev.asdevice(a), dims=("z", "face", "y", "x"))
+    for _ in range(2):  # second call reuses the cached, uploaded map
+        out = grid.diff(da, "Y")
+        assert isinstance(out.data, torch.Tensor) and out.data.is_cuda
+        want = T.pad_face_connections(a, ("z", "face", "y", "x"), "face", {"X": "x", "Y": "y"}, CUBED_SPHERE["face"],
+                                      ["X", "Y"], {"Y": (1, 0)}, {"X": None, "Y": None}, {"X": 0.0, "Y": 0.0})
+        np.testing.assert_array_equal(out.values, want[:, :, 1:] - want[:, :, :-1])
+    padded = pad(da, grid, {"X": (1, 1)})
+    assert isinstance(padded.data, torch.Tensor) and padded.shape == (3, 6, 8, 10)
+    entries = [e for e in grid._halo_maps.values() if e["device"] is not None]
+    assert entries and all(isinstance(e["device"], torch.Tensor) for e in entries)

@@ -416,3 +416,25 @@ def test_transform_on_a_zyx_field_without_transposes(backend):
     want = TR.interp_1d_conservative(np.moveaxis(phi, 1, -1), np.moveaxis(dens_o, 1, -1), levels)
     np.testing.assert_array_equal(out.values, want)
     np.testing.assert_array_equal(out.coords["sigma"].values, (levels[1:] + levels[:-1]) / 2)
+
+
+@pytest.mark.gpu
+def test_transform_resident_tensors():
+    """HBM-resident phi / theta: the result is a resident tensor, a transposed VIEW in the reference's
+    dim order (no copy), identical to the host path."""
+    import torch
+
+    from xgcm_amd import device as dev
+
+    nz, ny, nx = 11, 6, 32
+    ds = Dataset(coords={"Z": np.arange(nz) + 0.5, "Zp1": np.arange(nz + 1) * 1.0})
+    grid = Grid(ds, coords={"Z": {"center": "Z", "outer": "Zp1"}}, autoparse_metadata=False)
+    phi = R.synthetic_field((nz, ny, nx), 31)
+    sig = np.cumsum(R.synthetic_field((nz, ny, nx), 32) + 0.6, axis=0)
+    levels = np.linspace(0.2, sig.max(), 9)
+    host = grid.transform(DataArray(phi, ("Z", "Y", "X"), name="s"), "Z", levels, target_data=DataArray(sig, ("Z", "Y", "X"), name="sigma"))
+    res = grid.transform(DataArray(dev.asdevice(phi), ("Z", "Y", "X"), name="s"), "Z", levels,
+                         target_data=DataArray(dev.asdevice(sig), ("Z", "Y", "X"), name="sigma"))
+    assert isinstance(res.data, torch.Tensor) and res.data.is_cuda and res.dims == ("Y", "X", "sigma")
+    assert not res.data.is_contiguous()  # (sigma, Y, X) in memory, presented as (Y, X, sigma)
+    np.testing.assert_array_equal(res.values, host.values)
