@@ -209,7 +209,9 @@ def gather_tokens(x: np.ndarray, partner: Optional[np.ndarray], tokens: np.ndarr
     m_dims = [d for d in range(nd) if mapped[d]]
     u_dims = [d for d in range(nd) if not mapped[d]]
     # bring unmapped dims first, mapped dims last (both in order), flatten the mapped block
-    xs = np.transpose(x, u_dims + m_dims).reshape([x.shape[d] for d in u_dims] + [-1])
+    if int(np.prod([int(v) for v in out_shape])) == 0:
+        return np.empty([int(v) for v in out_shape], dtype=x.dtype)
+    xs = np.transpose(x, u_dims + m_dims).reshape([x.shape[d] for d in u_dims] + [int(np.prod([x.shape[d] for d in m_dims]))])
     p_in = xs.shape[-1]
     sources = xs
     if partner is not None:
@@ -217,7 +219,7 @@ def gather_tokens(x: np.ndarray, partner: Optional[np.ndarray], tokens: np.ndarr
         perm = list(partner_perm) if partner_perm is not None else list(range(nd))
         pm = [k for k in range(nd) if mapped[perm[k]]]                 # partner's mapped dims, own order
         pu = sorted((k for k in range(nd) if not mapped[perm[k]]), key=lambda k: perm[k])  # in out order
-        ps = np.transpose(partner, pu + pm).reshape([partner.shape[k] for k in pu] + [-1])
+        ps = np.transpose(partner, pu + pm).reshape([partner.shape[k] for k in pu] + [int(np.prod([partner.shape[k] for k in pm]))])
         sources = np.concatenate([xs, ps], axis=-1)
     t = np.asarray(tokens, dtype=np.int64).reshape(-1)
     a = np.abs(t)

@@ -686,3 +686,29 @@ def test_resident_tensors_on_complex_topologies():
     assert isinstance(padded.data, torch.Tensor) and padded.shape == (3, 6, 8, 10)
     entries = [e for e in grid._halo_maps.values() if e["device"] is not None]
     assert entries and all(isinstance(e["device"], torch.Tensor) for e in entries)
+
+
+def test_single_face_connected_to_itself_is_a_periodic_box(backend):
+    """A face whose right edge links to its own left edge: the connection halo equals numpy's wrap."""
+    ds = _faces_ds(1, 5, seed=71)
+    conn = {"face": {0: {"X": ((0, "X", False), (0, "X", False)), "Y": ((0, "Y", False), (0, "Y", False))}}}
+    grid = Grid(ds, coords=COORDS, face_connections=conn, autoparse_metadata=False)
+    a = ds.data_c.values
+    got = pad(ds.data_c, grid, {"X": (2, 1)}).values
+    np.testing.assert_array_equal(got, np.pad(a, [(0, 0), (0, 0), (2, 1)], mode="wrap"))
+    np.testing.assert_array_equal(grid.diff(ds.data_c, "Y").values, a - np.roll(a, 1, axis=1))
+    np.testing.assert_array_equal(grid.interp(ds.data_c, "X", to="left").values, (np.roll(a, 1, axis=2) + a) / 2.0)
+
+
+def test_complex_topology_edge_shapes(backend):
+    """zero-size leading dims and one-cell-wide faces go through the same path"""
+    ds = _faces_ds(2, 1, seed=72)   # 1 x 1 faces
+    grid = Grid(ds, coords=COORDS, face_connections=X_TO_X, padding="fill", autoparse_metadata=False)
+    got = grid.diff(ds.data_c, "X").values
+    a = ds.data_c.values
+    np.testing.assert_array_equal(got[:, 0, 0], [a[0, 0, 0] - 0.0, a[1, 0, 0] - a[0, 0, 0]])
+    ds4 = _faces_ds(2, 4, seed=73)
+    g4 = Grid(ds4, coords=COORDS, face_connections=X_TO_X, padding="fill", autoparse_metadata=False)
+    empty = DataArray(np.zeros((0, 2, 4, 4)), dims=("time", "face", "y", "x"))
+    assert g4.diff(empty, "X").shape == (0, 2, 4, 4)
+    assert pad(empty, g4, {"X": (1, 1)}).shape == (0, 2, 4, 6)

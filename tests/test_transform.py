@@ -438,3 +438,22 @@ def test_transform_resident_tensors():
     assert isinstance(res.data, torch.Tensor) and res.data.is_cuda and res.dims == ("Y", "X", "sigma")
     assert not res.data.is_contiguous()  # (sigma, Y, X) in memory, presented as (Y, X, sigma)
     np.testing.assert_array_equal(res.values, host.values)
+
+
+def test_transform_edge_shapes(backend):
+    """empty batches, single-level columns, a single target level, targets all outside the column"""
+    phi = R.synthetic_field((4, 6), 41)
+    theta = np.cumsum(R.synthetic_field((4, 6), 42) + 0.6, axis=-1)
+    assert X.interp_1d_linear(phi[:0], theta[:0], np.array([0.5, 1.0])).shape == (0, 2)
+    assert X.interp_1d_conservative(phi[:0, :5], theta[:0], np.array([0.0, 1.0, 2.0])).shape == (0, 2)
+    one = X.interp_1d_linear(phi[:, :1], theta[:, :1], np.array([-1.0, float(theta[0, 0]), 99.0]), mask_edges=False)
+    np.testing.assert_array_equal(one, TR.interp_1d_linear(phi[:, :1], theta[:, :1], np.array([-1.0, float(theta[0, 0]), 99.0]), mask_edges=False))
+    for lv in (np.array([1.5]), np.array([-5.0, -4.0]), np.array([1e3, 2e3])):
+        for mask in (False, True):
+            np.testing.assert_array_equal(X.interp_1d_linear(phi, theta, lv, mask_edges=mask),
+                                          TR.interp_1d_linear(phi, theta, lv, mask_edges=mask))
+    np.testing.assert_array_equal(X.interp_1d_conservative(phi[:, :5], theta, np.array([0.0, 100.0])),
+                                  TR.interp_1d_conservative(phi[:, :5], theta, np.array([0.0, 100.0])))
+    # 70 bins: beyond the LDS-accumulator budget of one kernel variant for float64 -> register-tile kernel
+    bins = np.linspace(0.0, 6.0, 131)
+    np.testing.assert_array_equal(X.interp_1d_conservative(phi[:, :5], theta, bins), TR.interp_1d_conservative(phi[:, :5], theta, bins))
