@@ -175,6 +175,10 @@ def main():
         step()
     K = args.steps
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(OPS) + 1)] for _ in range(K)]
+    import gc
+
+    gc.collect()
+    gc.disable()  # an interpreter GC pause (~10 ms, seen once in r01d) is not part of the hot path
     barrier()
     t0 = time.perf_counter()
     for k in range(K):
@@ -182,6 +186,7 @@ def main():
         step(ev[k])
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
 
     from xgcm_amd.sharding import whole_job_throughput
 
