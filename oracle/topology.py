@@ -29,7 +29,7 @@ the checker of `xg_gather_f64` and by the CPU test double oracle/fake_device.py.
 
 from __future__ import annotations
 
-from typing import Dict, Mapping, Optional, Sequence, Tuple
+from typing import Mapping, Optional, Sequence, Tuple
 
 import numpy as np
 

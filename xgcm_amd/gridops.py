@@ -13,7 +13,6 @@ xgcm/gridops.py:27-278 (pinned by tests/golden/gridops_table.json), so `_select_
 
 from __future__ import annotations
 
-from typing import Mapping
 
 from . import device as _dev
 from .grid_ufunc import (

@@ -17,7 +17,7 @@ allocator here; the arithmetic is the HIP library's as everywhere else.
 
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 import torch
