@@ -124,6 +124,21 @@ def test_cumsum_long_rows_metric(dev):
             np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-11)  # values ~1e1, a few cross zero
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_long_strided_march_with_few_columns(dev, dtype):
+    """n >= 256 along a strided axis and few wave-tasks: the scans / reductions switch to one element
+    per lane with 16 loads in flight; results stay bit-identical to the sequential numpy order."""
+    a = _field((3, 300, 128), 88, nan=True).astype(dtype)
+    w = R.synthetic_metric((1, 300, 1), 89).astype(dtype)
+    for rev in (False, True):
+        exp = R.cumsum1d(a, 1, 0, 1, 1, 0, "fill", dtype(0.5), rev, True)
+        _eq(dev.tohost(dev.cumsum1d(a, 1, 0, 1, 1, 0, "fill", 0.5, rev, True)), exp)
+    _eq(dev.tohost(dev.cumsum1d(a, 1, 0, 0, 0, 0, None, 0.0, False, False, w, None)), R.cumsum1d(a, 1, 0, 0, 0, 0, None, 0.0, False, False, w, None))
+    for skipna in (True, False):
+        exp = R.integrate(a, 1, w, skipna)
+        _eq(dev.tohost(dev.reduce1d(a, 1, w, skipna)), exp.astype(dtype) if exp.dtype != dtype else exp)
+
+
 def test_cumsum_metric(dev):
     shape = (4, 9, 6, 34)
     a = _field(shape, 9)

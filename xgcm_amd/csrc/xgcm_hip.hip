@@ -88,6 +88,7 @@ struct Tune {
   int seg;       // rows marched per wave-task along a strided stencil axis
   int nt_store;  // non-temporal stores (+2-4 %; non-temporal LOADS measured -1 % and are not used)
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
+  int scan_narrow_below; // marching scans with fewer wave-tasks than this use one element per lane
   int transform_lds_kb;  // LDS budget of the cell-major conservative kernel (0: always the register-tile kernel)
   int transform_fast;  // streaming path of the linear transform for well-formed columns (0: always the exact search)
   int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
@@ -102,10 +103,11 @@ struct Tune {
     march_lds_kb = env_int("XG_MARCH_LDS_KB", 0);
     contig_gen = env_int("XG_CONTIG_GEN", 1);
     scan_vec = env_int("XG_SCAN_VEC", 1);
-    deep_waves = env_int("XG_DEEP_WAVES", 0);  // measured neutral (4.80 vs 4.88 TB/s on cumsum along Y): off
+    deep_waves = env_int("XG_DEEP_WAVES", 8192);  // neutral on its own, pays together with scan_narrow_below
     zband = env_int("XG_ZBAND", 1);
     zchunk = env_int("XG_ZCHUNK", 256);
     transform_fast = env_int("XG_TRANSFORM_FAST", 1);
+    scan_narrow_below = env_int("XG_SCAN_NARROW_BELOW", 8192);
     transform_lds_kb = env_int("XG_TRANSFORM_LDS_KB", 64);
     seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
     seg = env_int("XG_SEG", 1 << 30);  // long march: whole column by default
@@ -2265,15 +2267,20 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
 #undef XG_M
     }
   } else {
-    const int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, met != 0)) ? NV : 1;
+    int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, met != 0)) ? NV : 1;
+    // few, long columns (cumsum along Y of (Z,Y,X): ~2k wave-tasks for 1024 SIMDs): one element per
+    // lane doubles (f64) / quadruples (f32) the number of independent marches
+    const bool long_march = g.n_in >= 256;
+    if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = 1;
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
     const u64 ntask = (u64)ntile * (u64)g.outer;
     const u64 nblocks = (ntask + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
     const bool nts = tune().nt_store;
     // few columns, long march (cumsum along Y: ~2k waves for the whole chip): occupancy cannot hide
-    // the latency, so keep 16 loads in flight per lane instead of 4
-    const bool deep = ntask < (u64)tune().deep_waves;
+    // the latency, so keep 16 loads in flight per lane instead of 4 (measured with the narrow lanes
+    // above: cumsum along Y f32 48 -> 55 %, sum along Y 59 -> 67 % f32 / 68 -> 71 % f64)
+    const bool deep = long_march && ntask < (u64)tune().deep_waves;
 #define XG_GO(V_, M, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); \
                                else hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); } while (0)
 #define XG_M(V_, M) do { if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
@@ -2309,12 +2316,14 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
       else hipLaunchKernelGGL((k_reduce_contig<false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
     }
   } else {
-    const int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, w != nullptr)) ? NV : 1;
+    int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, w != nullptr)) ? NV : 1;
+    const bool long_march = g.n_in >= 256;
+    if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = 1;
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
     const u64 ntask = (u64)ntile * (u64)g.outer;
     const u64 nblocks = (ntask + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
-    const bool deep = ntask < (u64)tune().deep_waves;
+    const bool deep = long_march && ntask < (u64)tune().deep_waves;
 #define XG_GO(V_, W_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, false, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); \
                            else hipLaunchKernelGGL((k_reduce_strided<V_, W_, false, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); } while (0)
     if (V > 1) { if (w) XG_GO(NV, true); else XG_GO(NV, false); }
