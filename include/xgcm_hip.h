@@ -188,6 +188,21 @@ int xg_divergence_f64(const double* u, const double* v, const double* area,
                      const int64_t* area_strides, double* out, const int64_t* shape, int ndim,
                      int bc_x, double fill_x, int bc_y, double fill_y, void* stream);
 
+/* The two fused operators on a complex topology (face connections, north fold): an axis whose
+ * boundary mode is XG_BC_HALO takes its one-cell halo from a pre-gathered slab (xg_gather_f64 over
+ * the halo cells, vector-component rules included) instead of the array itself:
+ *   vorticity:  halo_x[outer, Y] = v left of column 0,   halo_y[outer, X] = u below row 0
+ *   divergence: halo_x[outer, Y] = u right of the last column, halo_y[outer, X] = v above the last row
+ * (NULL for an axis with an ordinary mode). */
+int xg_vorticity_halo_f64(const double* u, const double* v, const double* halo_x, const double* halo_y,
+                          const double* area, const int64_t* area_strides, double* out,
+                          const int64_t* shape, int ndim, int bc_x, double fill_x, int bc_y,
+                          double fill_y, void* stream);
+int xg_divergence_halo_f64(const double* u, const double* v, const double* halo_x,
+                           const double* halo_y, const double* area, const int64_t* area_strides,
+                           double* out, const int64_t* shape, int ndim, int bc_x, double fill_x,
+                           int bc_y, double fill_y, void* stream);
+
 /* ---- the same two-point operator along the last TWO axes in one pass -------------------- */
 /* out = OP_second(pad(OP_first(pad(in)))) for (.., Y, X) arrays, order 0: X then Y, 1: Y then X;
  * replaces two sequential apply_as_grid_ufunc passes of Grid.interp/diff/min/max(da, [ax1, ax2])
@@ -246,6 +261,14 @@ int xg_vorticity_f32(const float* u, const float* v, const float* area,
 int xg_divergence_f32(const float* u, const float* v, const float* area,
                      const int64_t* area_strides, float* out, const int64_t* shape, int ndim,
                      int bc_x, float fill_x, int bc_y, float fill_y, void* stream);
+int xg_vorticity_halo_f32(const float* u, const float* v, const float* halo_x, const float* halo_y,
+                          const float* area, const int64_t* area_strides, float* out,
+                          const int64_t* shape, int ndim, int bc_x, float fill_x, int bc_y,
+                          float fill_y, void* stream);
+int xg_divergence_halo_f32(const float* u, const float* v, const float* halo_x, const float* halo_y,
+                           const float* area, const int64_t* area_strides, float* out,
+                           const int64_t* shape, int ndim, int bc_x, float fill_x, int bc_y,
+                           float fill_y, void* stream);
 int xg_stencil2d_f32(int op, const float* in, float* out, const int64_t* shape, int ndim, int order,
                      int padx_lo, int padx_hi, int bc_x, float fill_x, int pady_lo, int pady_hi,
                      int bc_y, float fill_y, void* stream);

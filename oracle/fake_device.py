@@ -104,18 +104,38 @@ def binary(op, a, b):
     return R.binary(op, a, b)
 
 
-def vorticity(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0):
+def _with_halo(a, halo, axis, low, bc):
+    """the array with its one-cell halo attached along `axis` (then no boundary mode is needed)"""
+    if bc != "halo":
+        return a, bc, (1, 0) if low else (0, 1)
+    h = np.expand_dims(np.asarray(halo, dtype=a.dtype).reshape([n for i, n in enumerate(a.shape) if i != axis % a.ndim]), axis)
+    return (np.concatenate([h, a], axis=axis) if low else np.concatenate([a, h], axis=axis)), None, (0, 0)
+
+
+def vorticity(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0, halo_x=None, halo_y=None):
     u, v, area = _cast(_common(u, v, area), u, v, area)
     if area is None:
         area = np.ones((1,) * u.ndim, dtype=u.dtype)
-    return R.vorticity(u, v, area, bc_x, bc_y, fill_x, fill_y)
+    if bc_x != "halo" and bc_y != "halo":
+        return R.vorticity(u, v, area, bc_x, bc_y, fill_x, fill_y)
+    vp, bx, px = _with_halo(v, halo_x, -1, True, bc_x)
+    up, by, py = _with_halo(u, halo_y, -2, True, bc_y)
+    dvdx = R.stencil1d("diff", vp, v.ndim - 1, px[0], px[1], bx, fill_x)
+    dudy = R.stencil1d("diff", up, u.ndim - 2, py[0], py[1], by, fill_y)
+    return (dvdx - dudy) / area
 
 
-def divergence(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0):
+def divergence(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0, halo_x=None, halo_y=None):
     u, v, area = _cast(_common(u, v, area), u, v, area)
     if area is None:
         area = np.ones((1,) * u.ndim, dtype=u.dtype)
-    return R.divergence(u, v, area, bc_x, bc_y, fill_x, fill_y)
+    if bc_x != "halo" and bc_y != "halo":
+        return R.divergence(u, v, area, bc_x, bc_y, fill_x, fill_y)
+    up, bx, px = _with_halo(u, halo_x, -1, False, bc_x)
+    vp, by, py = _with_halo(v, halo_y, -2, False, bc_y)
+    dudx = R.stencil1d("diff", up, u.ndim - 1, px[0], px[1], bx, fill_x)
+    dvdy = R.stencil1d("diff", vp, v.ndim - 2, py[0], py[1], by, fill_y)
+    return (dudx + dvdy) / area
 
 
 def stencil2d_supported(x, padx, pady):

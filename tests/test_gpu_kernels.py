@@ -296,6 +296,19 @@ def test_divergence_fused_equals_unfused_chain(dev, shape, dtype):
     _eq(dev.tohost(chain), dev.tohost(dev.divergence(u, v, area2d, "periodic", "extend")))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_vorticity_divergence_area_broadcast_patterns(dev, dtype):
+    """area with only SOME of the leading dims (rAz(face, j, i) for a (time, Z, face, j, i) field, ...)."""
+    shape = (2, 3, 4, 6, 64)
+    u = _field(shape, 71).astype(dtype)
+    v = _field(shape, 72).astype(dtype)
+    for ashape in [(1, 1, 4, 6, 64), (1, 3, 1, 6, 64), (2, 1, 4, 6, 64), (2, 3, 4, 6, 64), (1, 1, 1, 6, 64), (1, 3, 4, 6, 64),
+                   (2, 1, 1, 6, 64), (1, 1, 4, 1, 64), (1, 1, 4, 6, 1)]:
+        area = R.synthetic_metric(ashape, 73).astype(dtype)
+        _eq(dev.tohost(dev.vorticity(u, v, area, "periodic", "extend")), R.vorticity(u, v, area, "periodic", "extend"))
+        _eq(dev.tohost(dev.divergence(u, v, area, "fill", "periodic", 0.5, 0.0)), R.divergence(u, v, area, "fill", "periodic", dtype(0.5), dtype(0.0)))
+
+
 def test_synthetic_bit_identical(dev):
     for n, seed, off in [(1000, 1, 0), (4097, 4, 123456789), (10, 53, 2**40)]:
         got = dev.tohost(dev.synthetic((n,), seed, off))

@@ -644,8 +644,6 @@ def test_two_axes_on_connected_grid_run_one_axis_at_a_time(backend):
     np.testing.assert_array_equal(both, seq)
     plain = Grid(ds, coords=COORDS, padding="fill", autoparse_metadata=False)
     assert not np.array_equal(both, plain.diff(ds.data_c, ["X", "Y"]).values)
-    with pytest.raises(NotImplementedError, match="chain the operators"):
-        grid.vorticity(ds.u, ds.v)
 
 
 def test_fold_operator_with_both_halos_and_float32(backend):
@@ -712,3 +710,43 @@ def test_complex_topology_edge_shapes(backend):
     empty = DataArray(np.zeros((0, 2, 4, 4)), dims=("time", "face", "y", "x"))
     assert g4.diff(empty, "X").shape == (0, 2, 4, 4)
     assert pad(empty, g4, {"X": (1, 1)}).shape == (0, 2, 4, 6)
+
+
+@pytest.mark.parametrize("conn", [X_TO_X, X_TO_Y, X_TO_Y_REV, CUBED_SPHERE], ids=["x2x", "x2y", "x2y_rev", "cubed_sphere"])
+def test_fused_vorticity_and_divergence_on_connected_grids(backend, conn):
+    """One launch (+ two halo gathers) == the chain of vector-aware reference operators, bit for bit."""
+    nf = 6 if conn is CUBED_SPHERE else 2
+    n = 6
+    rnd = lambda s: R.synthetic_field((3, nf, n, n), 100 + s) + 0.5  # noqa: E731
+    ds = Dataset({"rAz": (("face", "yl", "xl"), R.synthetic_metric((nf, n, n), 7)),
+                  "rA": (("face", "y", "x"), R.synthetic_metric((nf, n, n), 8))},
+                 coords={"x": np.arange(n), "xl": np.arange(n) - 0.5, "y": np.arange(n), "yl": np.arange(n) - 0.5,
+                         "face": np.arange(nf)})
+    grid = Grid(ds, coords=COORDS, face_connections=conn, padding="fill", metrics={("X", "Y"): ["rAz", "rA"]},
+                autoparse_metadata=False)
+    u = DataArray(rnd(1), dims=("z", "face", "y", "xl"))
+    v = DataArray(rnd(2), dims=("z", "face", "yl", "x"))
+    zeta = grid.vorticity(u, v, fill_value=2.5)
+    chain = (grid.diff({"Y": v}, "X", other_component={"X": u}, fill_value=2.5)
+             - grid.diff({"X": u}, "Y", other_component={"Y": v}, fill_value=2.5)) / ds["rAz"].reset_coords(drop=True)
+    assert zeta.dims == ("z", "face", "yl", "xl")
+    np.testing.assert_array_equal(zeta.values, chain.values)
+    div = grid.divergence(u, v, fill_value=-1.5)
+    chain = (grid.diff({"X": u}, "X", other_component={"Y": v}, fill_value=-1.5)
+             + grid.diff({"Y": v}, "Y", other_component={"X": u}, fill_value=-1.5)) / ds["rA"].reset_coords(drop=True)
+    assert div.dims == ("z", "face", "y", "x")
+    np.testing.assert_array_equal(div.values, chain.values)
+
+
+def test_fused_vorticity_on_a_fold_grid(backend):
+    """tripolar grid: X periodic (ordinary mode inside the kernel), Y folded (pre-gathered halo)."""
+    ds = _fold_ds()
+    grid = _fold_grid(ds, "corner")
+    u = DataArray(R.synthetic_field((2, Ny, Nx), 111), dims=("z", "yh", "xl"))
+    v = DataArray(R.synthetic_field((2, Ny, Nx), 112), dims=("z", "yl", "xh"))
+    zeta = grid.vorticity(u, v, metric_weighted=False)
+    chain = grid.diff({"Y": v}, "X", other_component={"X": u}) - grid.diff({"X": u}, "Y", other_component={"Y": v})
+    np.testing.assert_array_equal(zeta.values, chain.values)
+    div = grid.divergence(u, v, metric_weighted=False)   # needs the folded NORTH halo of v (sign-flipped mirror row)
+    chain = grid.diff({"X": u}, "X", other_component={"Y": v}) + grid.diff({"Y": v}, "Y", other_component={"X": u})
+    np.testing.assert_array_equal(div.values, chain.values)

@@ -186,7 +186,21 @@ def main():
                   and torch.equal(d[:, 4, :, 0], t[:, 4, :, 0] - t[:, 3, 0, :])  # face 4 left <- face 3 low-Y edge (reversed link)
                   and torch.equal(d[..., 1:], t[..., 1:] - t[..., :-1]))
         print(json.dumps({"config": "f2", "check": "cubed-sphere diff: interior and connected halos at full size", "ok": ok}), flush=True)
-        del Tf, d, t, gridf
+        del Tf, d, t
+        torch.cuda.empty_cache()
+        Uf = DataArray(D.synthetic((nzc, nf, n, n), 62), ("Z", "face", "j", "i_g"))
+        Vf = DataArray(D.synthetic((nzc, nf, n, n), 63), ("Z", "face", "j_g", "i"))
+        rec("f2", "vorticity fused on the cubed sphere (vector halos: rotated / sign-flipped partner component)",
+            timeit(lambda: gridf.vorticity(Uf, Vf, metric_weighted=False), a.reps), cf, 24)
+
+        def chain_f():
+            return (gridf.diff({"Y": Vf}, "X", other_component={"X": Uf}) - gridf.diff({"X": Uf}, "Y", other_component={"Y": Vf}))
+
+        rec("f2", "same through the operator chain (2 halo-fused diffs + subtract), fused-equivalent bytes",
+            timeit(chain_f, max(3, a.reps // 2)), cf, 24)
+        okv = bool(torch.equal(gridf.vorticity(Uf, Vf, metric_weighted=False).data, chain_f().data))
+        print(json.dumps({"config": "f2", "check": "cubed-sphere fused vorticity == operator chain bit for bit at full size", "ok": okv}), flush=True)
+        del Uf, Vf, gridf
         torch.cuda.empty_cache()
     if "f4" in cfgs:
         # next-row f4: vertical coordinate transform of a (Z, Y, X) = (75, 2400, 3600) f64 field onto 50

@@ -1700,12 +1700,34 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, co
 // SEG rows of Y: SEG+1 rows of u (the j-1 halo row is an L2 hit), SEG rows of v plus the 8-byte
 // left neighbour (same cache lines), SEG rows of area.  24 B/cell instead of 56 B unfused.
 // ------------------------------------------------------------------------------------------
+// offset of the (Y, X) plane of `area` that belongs to outer index o: the leading dims of the field
+// that the area does not have broadcast (stride 0), the others advance it (e.g. a field (Z, face, j, i)
+// with rAz(face, j, i)); dims are peeled innermost-first with multiply-shift division on the scalar unit
+struct AreaIdx {
+  int n;
+  FastDiv fd[XG_MAX_NDIM];
+  int64_t stride[XG_MAX_NDIM];
+};
+__device__ __forceinline__ int64_t area_outer_off(const AreaIdx& ai, int64_t o) {
+  int64_t off = 0;
+  u32 rem = (u32)o;
+#pragma unroll
+  for (int d = XG_MAX_NDIM - 1; d >= 0; --d) {
+    if (d < ai.n) {
+      const u32 q = fdiv(rem, ai.fd[d]);
+      off += (int64_t)(rem - q * ai.fd[d].d) * ai.stride[d];
+      rem = q;
+    }
+  }
+  return off;
+}
+
 template <int V, bool HAS_AREA, bool NTS, int SEG>
 __global__ __launch_bounds__(BLOCK) void k_vorticity(
     const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ area,
     real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile,
-    FastDiv nseg, ZBand zb, int bc_x, real fill_x, int bc_y, real fill_y, int64_t a_so, int64_t a_sy,
-    int64_t a_sx) {
+    FastDiv nseg, ZBand zb, int bc_x, real fill_x, int bc_y, real fill_y, AreaIdx ai, int64_t a_sy,
+    int64_t a_sx, const real* __restrict__ halo_x, const real* __restrict__ halo_y) {
   typedef typename VecT<V>::type T;
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
@@ -1722,6 +1744,7 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
     sg = r - oo * nseg.d;
   }
   const int64_t o = o0 + oo;
+  const int64_t a_base = HAS_AREA ? area_outer_off(ai, o) : 0;
   const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
   if (i0 >= nx) return;
   const int64_t j0 = (int64_t)sg * SEG;
@@ -1738,8 +1761,13 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
   {
     int64_t q = j0 - 1;
     bool f = false;
-    if (q < 0) { f = (bc_y == XG_BC_FILL); q = (bc_y == XG_BC_PERIODIC) ? ny - 1 : 0; }
-    T t = *reinterpret_cast<const T*>(pu + q * nx);
+    const real* src = pu + q * nx;
+    if (q < 0) {
+      f = (bc_y == XG_BC_FILL);
+      src = pu + ((bc_y == XG_BC_PERIODIC) ? ny - 1 : 0) * nx;
+      if (bc_y == XG_BC_HALO) src = halo_y + o * nx + i0;  // pre-gathered row below the first one: (outer, 1, X)
+    }
+    T t = *reinterpret_cast<const T*>(src);
     uu[0] = f ? splat<T>(fill_y) : t;
   }
 #pragma unroll
@@ -1747,14 +1775,15 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
     const int64_t jr = (s_ < nrow) ? s_ : nrow - 1;  // clamp inside the array for short tails
     uu[s_ + 1] = *reinterpret_cast<const T*>(pu + (j0 + jr) * nx);
     vv[s_] = *reinterpret_cast<const T*>(pv + jr * nx + i0);
-    vl[s_] = pv[jr * nx + nidx];
+    vl[s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[o * ny + j0 + jr]  // pre-gathered column left of the first: (outer, Y, 1)
+                                          : pv[jr * nx + nidx];
   }
 #pragma unroll
   for (int s_ = 0; s_ < SEG; ++s_) {
     if (s_ < nrow) {
       const real left = fill_edge ? fill_x : vl[s_];
       T z = dvdx_of(vv[s_], left) - (uu[s_ + 1] - uu[s_]);
-      if (HAS_AREA) z = z / ldm<T>(area, o * a_so + (j0 + s_) * a_sy + i0 * a_sx, a_sx);
+      if (HAS_AREA) z = z / ldm<T>(area, a_base + (j0 + s_) * a_sy + i0 * a_sx, a_sx);
       stg<T, NTS>(po + s_ * nx, z);
     }
   }
@@ -1770,8 +1799,8 @@ template <int V, bool HAS_AREA, bool NTS, int SEG>
 __global__ __launch_bounds__(BLOCK) void k_divergence(
     const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ area,
     real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile,
-    FastDiv nseg, ZBand zb, int bc_x, real fill_x, int bc_y, real fill_y, int64_t a_so, int64_t a_sy,
-    int64_t a_sx) {
+    FastDiv nseg, ZBand zb, int bc_x, real fill_x, int bc_y, real fill_y, AreaIdx ai, int64_t a_sy,
+    int64_t a_sx, const real* __restrict__ halo_x, const real* __restrict__ halo_y) {
   typedef typename VecT<V>::type T;
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
@@ -1788,6 +1817,7 @@ __global__ __launch_bounds__(BLOCK) void k_divergence(
     sg = r - oo * nseg.d;
   }
   const int64_t o = o0 + oo;
+  const int64_t a_base = HAS_AREA ? area_outer_off(ai, o) : 0;
   const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
   if (i0 >= nx) return;
   const int64_t j0 = (int64_t)sg * SEG;
@@ -1805,14 +1835,20 @@ __global__ __launch_bounds__(BLOCK) void k_divergence(
   for (int s_ = 0; s_ < SEG; ++s_) {
     const int64_t jr = (s_ < nrow) ? s_ : nrow - 1;
     uu[s_] = *reinterpret_cast<const T*>(pu + jr * nx + i0);
-    ur[s_] = pu[jr * nx + ridx];
+    ur[s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[o * ny + j0 + jr]  // pre-gathered column right of the last: (outer, Y, 1)
+                                          : pu[jr * nx + ridx];
     vv[s_] = *reinterpret_cast<const T*>(pv + (j0 + jr) * nx);
   }
   {
     int64_t q = j0 + nrow;  // the row above the segment's last row
     bool f = false;
-    if (q >= ny) { f = (bc_y == XG_BC_FILL); q = (bc_y == XG_BC_PERIODIC) ? 0 : ny - 1; }
-    T t = *reinterpret_cast<const T*>(pv + q * nx);
+    const real* src = pv + q * nx;
+    if (q >= ny) {
+      f = (bc_y == XG_BC_FILL);
+      src = pv + ((bc_y == XG_BC_PERIODIC) ? 0 : ny - 1) * nx;
+      if (bc_y == XG_BC_HALO) src = halo_y + o * nx + i0;  // pre-gathered row above the last one: (outer, 1, X)
+    }
+    T t = *reinterpret_cast<const T*>(src);
     vv[SEG] = f ? splat<T>(fill_y) : t;
   }
 #pragma unroll
@@ -1821,7 +1857,7 @@ __global__ __launch_bounds__(BLOCK) void k_divergence(
       const real right = fill_edge ? fill_x : ur[s_];
       const T up = (s_ + 1 < nrow) ? vv[s_ + 1] : vv[SEG];
       T z = dudx_fwd(uu[s_], right) + (up - vv[s_]);
-      if (HAS_AREA) z = z / ldm<T>(area, o * a_so + (j0 + s_) * a_sy + i0 * a_sx, a_sx);
+      if (HAS_AREA) z = z / ldm<T>(area, a_base + (j0 + s_) * a_sy + i0 * a_sx, a_sx);
       stg<T, NTS>(po + s_ * nx, z);
     }
   }
@@ -2558,34 +2594,44 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
 
 static int curl_div_impl(bool div, const real* u, const real* v, const real* area, const int64_t* area_strides,
                          real* out, const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y,
-                         void* stream) {
+                         void* stream, const real* halo_x = nullptr, const real* halo_y = nullptr) {
   if (!u || !v || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
   if (area && !area_strides) return fail(XG_ERR_INVALID, "area without strides");
-  if (bc_x < XG_BC_PERIODIC || bc_x > XG_BC_EXTEND || bc_y < XG_BC_PERIODIC || bc_y > XG_BC_EXTEND)
+  if (bc_x < XG_BC_PERIODIC || bc_x > XG_BC_HALO || bc_y < XG_BC_PERIODIC || bc_y > XG_BC_HALO)
     return fail(XG_ERR_INVALID, "vorticity / divergence need a boundary mode on both axes");
+  if ((bc_x == XG_BC_HALO && !halo_x) || (bc_y == XG_BC_HALO && !halo_y))
+    return fail(XG_ERR_INVALID, "XG_BC_HALO without the halo buffer of that axis");
   const int64_t ny = shape[ndim - 2], nx = shape[ndim - 1];
   int64_t outer = 1;
   for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
   if (outer == 0 || ny == 0 || nx == 0) return XG_OK;
-  // area may broadcast over the leading dims only uniformly: accept "all zero" or "contiguous"
-  int64_t a_so = 0, a_sy = 0, a_sx = 0;
+  // area: (Y, X) strides + one stride per leading dim (0 = broadcast); adjacent leading dims are merged
+  int64_t a_sy = 0, a_sx = 0;
+  bool area_bcast_all = true;
+  AreaIdx ai;
+  memset(&ai, 0, sizeof(ai));
+  for (int d = 0; d < XG_MAX_NDIM; ++d) ai.fd[d] = make_fastdiv(1);
   if (area) {
     a_sy = area_strides[ndim - 2];
     a_sx = area_strides[ndim - 1];
-    bool all_zero = true, contig = true;
-    int64_t expect = ny * nx;
-    for (int d = ndim - 3; d >= 0; --d) {
+    for (int d = 0; d < ndim - 2; ++d) {
       if (shape[d] == 1) continue;
-      if (area_strides[d] != 0) all_zero = false;
-      if (area_strides[d] != expect) contig = false;
-      expect *= shape[d];
+      const int64_t st = area_strides[d];
+      if (st != 0) area_bcast_all = false;
+      if (ai.n > 0 && ai.stride[ai.n - 1] == st * shape[d]) {  // merges with the previous (slower) dim
+        ai.fd[ai.n - 1] = make_fastdiv((u64)ai.fd[ai.n - 1].d * (u64)shape[d]);
+        ai.stride[ai.n - 1] = st;
+        continue;
+      }
+      ai.fd[ai.n] = make_fastdiv((u64)shape[d]);
+      ai.stride[ai.n] = st;
+      ++ai.n;
     }
-    if (all_zero) a_so = 0;
-    else if (contig && a_sy == nx && a_sx == 1) a_so = ny * nx;
-    else return fail(XG_ERR_UNSUPPORTED, "area must be (Y,X)-shaped or fully materialised");
+    if (outer > 0xffffffffll) return fail(XG_ERR_UNSUPPORTED, "more than 2^32 (Y,X) planes");
   }
-  const int V = (aligned16(u) && aligned16(v) && aligned16(out) && nx % NV == 0) ? NV : 1;
+  const int V = (aligned16(u) && aligned16(v) && aligned16(out) && nx % NV == 0 &&
+                 (bc_y != XG_BC_HALO || aligned16(halo_y))) ? NV : 1;
   constexpr int SEG = 4;
   const u64 ntile = (u64)((nx + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
   const u64 nseg = (u64)((ny + SEG - 1) / SEG);
@@ -2598,7 +2644,7 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
   const u32 ZB_SEGS = 4;
   ZBand zb = make_zband(false, 0, 0, 1);
   u64 outer_step = outer_per;
-  if (area && a_so == 0 && tune().zband && outer >= 2) {
+  if (area && area_bcast_all && tune().zband && outer >= 2) {
     const u64 padded_segs = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS;
     if (padded_segs * (u64)outer * ntile <= MAX_ITEMS) {
       zb = make_zband(true, (u64)outer, nseg, ZB_SEGS);
@@ -2610,8 +2656,8 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
     const u64 waves = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * (u64)outer * ntile : (u64)nouter * per_outer;
     const u32 nblk = (u32)((waves + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GO(V_, A_, NTS) do { if (div) hipLaunchKernelGGL((k_divergence<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, a_so, a_sy, a_sx); \
-                                else hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, a_so, a_sy, a_sx); } while (0)
+#define XG_GO(V_, A_, NTS) do { if (div) hipLaunchKernelGGL((k_divergence<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y); \
+                                else hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y); } while (0)
 #define XG_A(V_, A_) do { if (nts) XG_GO(V_, A_, true); else XG_GO(V_, A_, false); } while (0)
     if (V > 1) { if (area) XG_A(NV, true); else XG_A(NV, false); }
     else { if (area) XG_A(1, true); else XG_A(1, false); }
@@ -2624,12 +2670,26 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
 
 int XG_FN(xg_vorticity)(const real* u, const real* v, const real* area, const int64_t* area_strides, real* out,
                      const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y, void* stream) {
+  if (bc_x == XG_BC_HALO || bc_y == XG_BC_HALO) return fail(XG_ERR_INVALID, "XG_BC_HALO needs xg_vorticity_halo");
   return curl_div_impl(false, u, v, area, area_strides, out, shape, ndim, bc_x, fill_x, bc_y, fill_y, stream);
 }
 
 int XG_FN(xg_divergence)(const real* u, const real* v, const real* area, const int64_t* area_strides, real* out,
                       const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y, void* stream) {
+  if (bc_x == XG_BC_HALO || bc_y == XG_BC_HALO) return fail(XG_ERR_INVALID, "XG_BC_HALO needs xg_divergence_halo");
   return curl_div_impl(true, u, v, area, area_strides, out, shape, ndim, bc_x, fill_x, bc_y, fill_y, stream);
+}
+
+int XG_FN(xg_vorticity_halo)(const real* u, const real* v, const real* halo_x, const real* halo_y, const real* area,
+                          const int64_t* area_strides, real* out, const int64_t* shape, int ndim, int bc_x,
+                          real fill_x, int bc_y, real fill_y, void* stream) {
+  return curl_div_impl(false, u, v, area, area_strides, out, shape, ndim, bc_x, fill_x, bc_y, fill_y, stream, halo_x, halo_y);
+}
+
+int XG_FN(xg_divergence_halo)(const real* u, const real* v, const real* halo_x, const real* halo_y, const real* area,
+                           const int64_t* area_strides, real* out, const int64_t* shape, int ndim, int bc_x,
+                           real fill_x, int bc_y, real fill_y, void* stream) {
+  return curl_div_impl(true, u, v, area, area_strides, out, shape, ndim, bc_x, fill_x, bc_y, fill_y, stream, halo_x, halo_y);
 }
 
 int XG_FN(xg_stencil2d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,

@@ -391,10 +391,12 @@ def binary(op: str, a, b) -> torch.Tensor:
     return out
 
 
-def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0) -> torch.Tensor:
-    """Fused ((v[j,i]-v[j,i-1]) - (u[j,i]-u[j-1,i])) / area on (..., Y, X) arrays (xg_vorticity_f64)."""
+def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0, halo_x=None,
+              halo_y=None) -> torch.Tensor:
+    """Fused ((v[j,i]-v[j,i-1]) - (u[j,i]-u[j-1,i])) / area on (..., Y, X) arrays (xg_vorticity_f64).
+    A boundary mode "halo" takes that axis' one-cell halo from `halo_x` (..., Y) / `halo_y` (..., X)."""
     lib = _hip.load()
-    dt, sfx = _common(u, v, area)
+    dt, sfx = _common(u, v, area, halo_x, halo_y)
     u = asdevice(u, dt)
     v = asdevice(v, dt)
     if u.shape != v.shape:
@@ -404,6 +406,21 @@ def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: flo
     out = torch.empty(shape, dtype=dt, device=u.device)
     if out.numel() == 0:
         return out
+    if bc_x == "halo" or bc_y == "halo":
+        hx = None if halo_x is None else asdevice(halo_x, dt).reshape(shape[:-2] + [shape[-2]])
+        hy = None if halo_y is None else asdevice(halo_y, dt).reshape(shape[:-2] + [shape[-1]])
+        _hip.check(
+            getattr(lib, "xg_vorticity_halo_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(hx), _ptr(hy), _ptr(area),
+                                          _hip.i64(_bstrides(area, shape, "area")), out.data_ptr(), _hip.i64(shape),
+                                          len(shape), _hip.BC[bc_x], float(fill_x), _hip.BC[bc_y], float(fill_y), _stream())
+        )
+        return out
+    _hip.check(
+        getattr(lib, "xg_vorticity_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
+                             out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
+                             _hip.BC[bc_y], float(fill_y), _stream())
+    )
+    return out
     _hip.check(
         getattr(lib, "xg_vorticity_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
                              out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
@@ -412,10 +429,12 @@ def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: flo
     return out
 
 
-def divergence(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0) -> torch.Tensor:
-    """Fused ((u[j,i+1]-u[j,i]) + (v[j+1,i]-v[j,i])) / area on (..., Y, X) arrays (xg_divergence_f64)."""
+def divergence(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0, halo_x=None,
+               halo_y=None) -> torch.Tensor:
+    """Fused ((u[j,i+1]-u[j,i]) + (v[j+1,i]-v[j,i])) / area on (..., Y, X) arrays (xg_divergence_f64).
+    A boundary mode "halo" takes that axis' one-cell halo from `halo_x` (..., Y) / `halo_y` (..., X)."""
     lib = _hip.load()
-    dt, sfx = _common(u, v, area)
+    dt, sfx = _common(u, v, area, halo_x, halo_y)
     u = asdevice(u, dt)
     v = asdevice(v, dt)
     if u.shape != v.shape:
@@ -425,6 +444,21 @@ def divergence(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: fl
     out = torch.empty(shape, dtype=dt, device=u.device)
     if out.numel() == 0:
         return out
+    if bc_x == "halo" or bc_y == "halo":
+        hx = None if halo_x is None else asdevice(halo_x, dt).reshape(shape[:-2] + [shape[-2]])
+        hy = None if halo_y is None else asdevice(halo_y, dt).reshape(shape[:-2] + [shape[-1]])
+        _hip.check(
+            getattr(lib, "xg_divergence_halo_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(hx), _ptr(hy), _ptr(area),
+                                          _hip.i64(_bstrides(area, shape, "area")), out.data_ptr(), _hip.i64(shape),
+                                          len(shape), _hip.BC[bc_x], float(fill_x), _hip.BC[bc_y], float(fill_y), _stream())
+        )
+        return out
+    _hip.check(
+        getattr(lib, "xg_divergence_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
+                             out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
+                             _hip.BC[bc_y], float(fill_y), _stream())
+    )
+    return out
     _hip.check(
         getattr(lib, "xg_divergence_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
                               out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),

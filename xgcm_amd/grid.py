@@ -43,7 +43,7 @@ from .grid_ufunc import (
 )
 from .labeled import DataArray, Dataset, _aligned_view, _is_tensor, from_xarray, is_xarray, to_xarray
 from .metrics import iterate_axis_combinations
-from .padding import _is_fold_padding, no_boundary_error, pad
+from .padding import _is_fold_padding, halo_cells, no_boundary_error, pad
 
 
 def _maybe_promote_str_to_list(a):
@@ -684,14 +684,13 @@ class Grid:
 
         Equivalent (bit for bit) to the chain of three reference operators
         `(grid.diff(v, X) - grid.diff(u, Y)) / grid.get_metric(zeta, (X, Y))` with both diffs
-        center->left; the reference's own docs motivate fusing it (docs/grid_ufuncs.md:27)."""
+        center->left; the reference's own docs motivate fusing it (docs/grid_ufuncs.md:27).
+        On grids with face connections or a north fold `u`, `v` are the X / Y components of a
+        vector: the chain is then `(grid.diff({Y: v}, X, other_component={X: u}) -
+        grid.diff({X: u}, Y, other_component={Y: v})) / area`, and the two one-cell halos are
+        gathered through the topology's token map before the same single launch."""
         (u, xr1), (v, xr2) = self._wrap_in(u), self._wrap_in(v)
         xa, ya = self.axes[x_axis], self.axes[y_axis]
-        if gridops.complex_topology(self, x_axis) or gridops.complex_topology(self, y_axis):
-            raise NotImplementedError(
-                "fused vorticity is implemented for simple topologies; on grids with face connections or a "
-                "north fold chain the operators: (grid.diff(v, X) - grid.diff(u, Y)) / area"
-            )
         vx_pos, vx_dim = xa._get_position_name(v)
         uy_pos, uy_dim = ya._get_position_name(u)
         if (vx_pos, uy_pos) != ("center", "center") or "left" not in xa.coords or "left" not in ya.coords:
@@ -699,20 +698,39 @@ class Grid:
         out_x, out_y = xa.coords["left"], ya.coords["left"]
         if u.dims[-2:] != (uy_dim, out_x) or v.dims[-2:] != (out_y, vx_dim) or u.dims[:-2] != v.dims[:-2]:
             raise NotImplementedError("fused vorticity needs u(..., YC, XG) and v(..., YG, XC) with (Y, X) last")
-        bc = self._complete_user_kwargs_using_axis_defaults(padding, "padding")
-        fv = self._complete_user_kwargs_using_axis_defaults(fill_value, "fill_value")
-        for a in (x_axis, y_axis):
-            if bc[a] is None:
-                raise no_boundary_error(a)
         out_dims = u.dims[:-2] + (out_y, out_x)
         area = None
         if metric_weighted:
             area = _aligned_view(self._resident(self.get_metric(_DimsOnly(out_dims), (x_axis, y_axis)), u.data), out_dims)
+        bcx, bcy, fx, fy, hx, hy = self._two_component_halos(u, v, x_axis, y_axis, (1, 0), padding, fill_value,
+                                                             x_of="v", y_of="u")
         host = not (_is_tensor(u.data) or _is_tensor(v.data))
-        out = _dev.vorticity(u.data, v.data, area, bc[x_axis], bc[y_axis], float(fv[x_axis] or 0.0), float(fv[y_axis] or 0.0))
+        out = _dev.vorticity(u.data, v.data, area, bcx, bcy, fx, fy, hx, hy)
         res = DataArray(_dev.tohost(out) if host else out, out_dims)
         res = _reattach_coords([res], self, None, {out_x, out_y}, [u, v])[0]
         return to_xarray(res) if (xr1 or xr2) else res
+
+    def _two_component_halos(self, u, v, x_axis, y_axis, widths, padding, fill_value, x_of: str, y_of: str):
+        """Boundary modes, fill values and (on complex topologies) the pre-gathered one-cell halos of the
+        fused two-component operators: along X the halo of component `x_of`, along Y of `y_of`; `u` is
+        the X-component, `v` the Y-component of the vector (rotation / sign rules of `padding.pad`)."""
+        bc = self._complete_user_kwargs_using_axis_defaults(padding, "padding")
+        fv = self._complete_user_kwargs_using_axis_defaults(fill_value, "fill_value")
+        comp = {"u": ({x_axis: u}, {y_axis: v}), "v": ({y_axis: v}, {x_axis: u})}
+        modes, halos = {}, {}
+        for ax, which in ((x_axis, x_of), (y_axis, y_of)):
+            if gridops.complex_topology(self, ax):
+                arg, other = comp[which]
+                halos[ax] = halo_cells(arg, self, ax, widths, padding=padding, fill_value=fill_value,
+                                       other_component=dict(other)).data
+                modes[ax] = "halo"
+            else:
+                if bc[ax] is None:
+                    raise no_boundary_error(ax)
+                halos[ax] = None
+                modes[ax] = bc[ax]
+        return (modes[x_axis], modes[y_axis], float(fv[x_axis] or 0.0), float(fv[y_axis] or 0.0), halos[x_axis],
+                halos[y_axis])
 
     def divergence(self, u, v, x_axis: str = "X", y_axis: str = "Y", padding=None, fill_value=None,
                    metric_weighted: bool = True):
@@ -726,11 +744,6 @@ class Grid:
         (u*dy, v*dx) for the finite-volume form."""
         (u, xr1), (v, xr2) = self._wrap_in(u), self._wrap_in(v)
         xa, ya = self.axes[x_axis], self.axes[y_axis]
-        if gridops.complex_topology(self, x_axis) or gridops.complex_topology(self, y_axis):
-            raise NotImplementedError(
-                "fused divergence is implemented for simple topologies; on grids with face connections or a "
-                "north fold chain the operators: (grid.diff(u, X) + grid.diff(v, Y)) / area"
-            )
         ux_pos, ux_dim = xa._get_position_name(u)
         uy_pos, uy_dim = ya._get_position_name(u)
         vx_pos, vx_dim = xa._get_position_name(v)
@@ -740,17 +753,14 @@ class Grid:
         out_x, out_y = xa.coords["center"], ya.coords["center"]
         if u.dims[-2:] != (uy_dim, ux_dim) or v.dims[-2:] != (vy_dim, vx_dim) or u.dims[:-2] != v.dims[:-2]:
             raise NotImplementedError("fused divergence needs u(..., YC, XG) and v(..., YG, XC) with (Y, X) last")
-        bc = self._complete_user_kwargs_using_axis_defaults(padding, "padding")
-        fv = self._complete_user_kwargs_using_axis_defaults(fill_value, "fill_value")
-        for a in (x_axis, y_axis):
-            if bc[a] is None:
-                raise no_boundary_error(a)
         out_dims = u.dims[:-2] + (out_y, out_x)
         area = None
         if metric_weighted:
             area = _aligned_view(self._resident(self.get_metric(_DimsOnly(out_dims), (x_axis, y_axis)), u.data), out_dims)
+        bcx, bcy, fx, fy, hx, hy = self._two_component_halos(u, v, x_axis, y_axis, (0, 1), padding, fill_value,
+                                                             x_of="u", y_of="v")
         host = not (_is_tensor(u.data) or _is_tensor(v.data))
-        out = _dev.divergence(u.data, v.data, area, bc[x_axis], bc[y_axis], float(fv[x_axis] or 0.0), float(fv[y_axis] or 0.0))
+        out = _dev.divergence(u.data, v.data, area, bcx, bcy, fx, fy, hx, hy)
         res = DataArray(_dev.tohost(out) if host else out, out_dims)
         res = _reattach_coords([res], self, None, {out_x, out_y}, [u, v])[0]
         return to_xarray(res) if (xr1 or xr2) else res
