@@ -284,6 +284,25 @@ CUBED_SPHERE = {
         5: {"X": ((3, "Y", False), (1, "Y", True)), "Y": ((0, "Y", False), (2, "Y", True))},
     }
 }
+# the 13-face "lat-lon-cap" (LLC) topology of MITgcm / ECCOv4 output: faces 0-2 and 3-5 are the two
+# lat-lon strips, 6 the Arctic cap, 7-12 the rotated strips (their X runs along the others' Y)
+LLC = {
+    "face": {
+        0: {"X": ((12, "Y", False), (3, "X", False)), "Y": (None, (1, "Y", False))},
+        1: {"X": ((11, "Y", False), (4, "X", False)), "Y": ((0, "Y", False), (2, "Y", False))},
+        2: {"X": ((10, "Y", False), (5, "X", False)), "Y": ((1, "Y", False), (6, "X", False))},
+        3: {"X": ((0, "X", False), (9, "Y", False)), "Y": (None, (4, "Y", False))},
+        4: {"X": ((1, "X", False), (8, "Y", False)), "Y": ((3, "Y", False), (5, "Y", False))},
+        5: {"X": ((2, "X", False), (7, "Y", False)), "Y": ((4, "Y", False), (6, "Y", False))},
+        6: {"X": ((2, "Y", False), (7, "X", False)), "Y": ((5, "Y", False), (10, "X", False))},
+        7: {"X": ((6, "X", False), (8, "X", False)), "Y": ((5, "X", False), (10, "Y", False))},
+        8: {"X": ((7, "X", False), (9, "X", False)), "Y": ((4, "X", False), (11, "Y", False))},
+        9: {"X": ((8, "X", False), None), "Y": ((3, "X", False), (12, "Y", False))},
+        10: {"X": ((6, "Y", False), (11, "X", False)), "Y": ((7, "Y", False), (2, "X", False))},
+        11: {"X": ((10, "X", False), (12, "X", False)), "Y": ((8, "Y", False), (1, "X", False))},
+        12: {"X": ((11, "X", False), None), "Y": ((9, "Y", False), (0, "X", False))},
+    }
+}
 COORDS = {"X": {"center": "x", "left": "xl"}, "Y": {"center": "y", "left": "yl"}}
 
 
@@ -750,3 +769,28 @@ def test_fused_vorticity_on_a_fold_grid(backend):
     div = grid.divergence(u, v, metric_weighted=False)   # needs the folded NORTH halo of v (sign-flipped mirror row)
     chain = grid.diff({"X": u}, "X", other_component={"Y": v}) + grid.diff({"Y": v}, "Y", other_component={"X": u})
     np.testing.assert_array_equal(div.values, chain.values)
+
+
+def test_llc_13_face_topology(backend):
+    """The LLC topology (13 faces, rotated links, open southern edges): the link checker accepts it,
+    scalar and vector halos equal the oracle, and tracer -> vorticity-point operators run fused."""
+    ds = _faces_ds(13, 5, seed=121)
+    grid = Grid(ds, coords=COORDS, face_connections=LLC, padding="fill", autoparse_metadata=False)
+    fill = {"X": 0.0, "Y": 0.0}
+    for pw in ({"X": (1, 1), "Y": (1, 1)}, {"X": (0, 1)}, {"Y": (2, 0)}):
+        np.testing.assert_array_equal(pad(ds.data_c, grid, dict(pw)).values,
+                                      _oracle_faces(ds, "data_c", LLC, pw, {"X": "fill", "Y": "fill"}, fill))
+        for comp, ax, other, oax in (("u", "X", "v", "Y"), ("v", "Y", "u", "X")):
+            got = pad({ax: ds[comp]}, grid, dict(pw), other_component={oax: ds[other]})
+            np.testing.assert_array_equal(got.values, _oracle_faces(ds, comp, LLC, pw, {"X": "fill", "Y": "fill"}, fill, vector=(ax, other)))
+    c = ds.data_c.values
+    dx = grid.diff(ds.data_c, "X").values
+    np.testing.assert_array_equal(dx[4, :, 0], c[4, :, 0] - c[1, :, -1])         # strip to strip
+    np.testing.assert_array_equal(dx[0, :, 0], c[0, :, 0] - c[12, -1, ::-1])     # rotated: face 12's top row, flipped
+    np.testing.assert_array_equal(grid.diff(ds.data_c, "Y").values[0, 0, :], c[0, 0, :] - 0.0)  # open southern edge: fill
+    # vector operators fused through the halo kernels == chain (u on (face, xl, y) is transposed to (face, y, xl) first)
+    u = DataArray(np.ascontiguousarray(ds.u.values.transpose(0, 2, 1)), dims=("face", "y", "xl"))
+    v = DataArray(np.ascontiguousarray(ds.v.values.transpose(0, 2, 1)), dims=("face", "yl", "x"))
+    zeta = grid.vorticity(u, v, metric_weighted=False)
+    chain = grid.diff({"Y": v}, "X", other_component={"X": u}) - grid.diff({"X": u}, "Y", other_component={"Y": v})
+    np.testing.assert_array_equal(zeta.values, chain.values)

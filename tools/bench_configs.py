@@ -236,6 +236,38 @@ def main():
                           "ok": ok_ident and ok_cons, "dims": list(out.dims)}), flush=True)
         del phi, inc, sigma, inc_o, sigma_o, out, oc
         torch.cuda.empty_cache()
+    if "llc" in cfgs:
+        # f2 at its motivating scale: the 13-face LLC topology (MITgcm / ECCO), LLC1080 x 50 levels and the
+        # real LLC4320 horizontal grid x 3 levels (one-time halo-map construction is reported separately)
+        import time as _time
+
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        from test_topology import LLC  # the connectivity table (data)
+
+        for n, nzl in ((1080, 50), (4320, 3)):
+            dsl = Dataset({}, {"i": ("i", np.arange(n) + 0.5), "i_g": ("i_g", np.arange(n) * 1.0),
+                               "j": ("j", np.arange(n) + 0.5), "j_g": ("j_g", np.arange(n) * 1.0),
+                               "face": ("face", np.arange(13))})
+            gl = Grid(dsl, coords={"X": {"center": "i", "left": "i_g"}, "Y": {"center": "j", "left": "j_g"}},
+                      face_connections=LLC, padding="fill", autoparse_metadata=False)
+            Tl = DataArray(D.synthetic((nzl, 13, n, n), 81), ("k", "face", "j", "i"))
+            cl = nzl * 13 * n * n
+            t0 = _time.perf_counter(); gl.diff(Tl, "X"); torch.cuda.synchronize()
+            print(json.dumps({"config": "llc", "note": f"LLC{n}: first diff incl. token-map construction + upload", "s": round(_time.perf_counter() - t0, 2)}), flush=True)
+            for ax in ("X", "Y"):
+                rec("llc", f"diff(T,'{ax}') on LLC{n} x {nzl} levels (13 faces, f64)", timeit(lambda: gl.diff(Tl, ax), a.reps), cl, 16)
+            del Tl
+            torch.cuda.empty_cache()
+            Ul = DataArray(D.synthetic((nzl, 13, n, n), 82), ("k", "face", "j", "i_g"))
+            Vl = DataArray(D.synthetic((nzl, 13, n, n), 83), ("k", "face", "j_g", "i"))
+            gl.vorticity(Ul, Vl, metric_weighted=False)
+            rec("llc", f"vorticity fused on LLC{n} x {nzl} levels (vector halos)", timeit(lambda: gl.vorticity(Ul, Vl, metric_weighted=False), a.reps), cl, 24)
+            if n == 1080:
+                ch = gl.diff({"Y": Vl}, "X", other_component={"X": Ul}) - gl.diff({"X": Ul}, "Y", other_component={"Y": Vl})
+                print(json.dumps({"config": "llc", "check": "LLC1080 fused vorticity == operator chain bit for bit", "ok": bool(torch.equal(gl.vorticity(Ul, Vl, metric_weighted=False).data, ch.data))}), flush=True)
+                del ch
+            del Ul, Vl, gl
+            torch.cuda.empty_cache()
     if "5" in cfgs:
         nz5, n5 = 90, 4320
         grid = mitgcm_grid(nz5, n5, n5)
