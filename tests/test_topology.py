@@ -794,3 +794,31 @@ def test_llc_13_face_topology(backend):
     zeta = grid.vorticity(u, v, metric_weighted=False)
     chain = grid.diff({"Y": v}, "X", other_component={"X": u}) - grid.diff({"X": u}, "Y", other_component={"Y": v})
     np.testing.assert_array_equal(zeta.values, chain.values)
+
+
+def test_unconnected_axes_of_a_connected_grid_keep_the_fused_kernels(backend):
+    """The vertical of an LLC / cubed-sphere grid has no links: padding it is the ordinary per-axis pad
+    (what `_pad_face_connections` reduces to), so diff / cumsum along Z take the fully fused kernels."""
+    from xgcm_amd import gridops
+
+    ds = _faces_ds(6, 4, seed=131)
+    ds["z"] = ("z", np.arange(5) + 0.5)
+    ds["zl"] = ("zl", np.arange(5) * 1.0)
+    coords = dict(COORDS, Z={"center": "z", "left": "zl"})
+    grid = Grid(ds, coords=coords, face_connections=CUBED_SPHERE, padding={"Z": "extend"}, autoparse_metadata=False)
+    assert gridops.complex_topology(grid, "X") and gridops.complex_topology(grid, "Y")
+    assert not gridops.complex_topology(grid, "Z")
+    a = R.synthetic_field((5, 6, 4, 4), 132)
+    da = DataArray(a, dims=("z", "face", "y", "x"))
+    np.testing.assert_array_equal(grid.diff(da, "Z").values, R.stencil1d("diff", a, 0, 1, 0, "extend"))
+    np.testing.assert_array_equal(grid.cumsum(da, "Z", to="left", padding="fill").values,
+                                  R.cumsum1d(a, 0, 0, 1, 1, 0, "fill", 0.0, False, True))
+    np.testing.assert_array_equal(pad(da, grid, {"Z": (2, 1)}).values, np.pad(a, [(2, 1), (0, 0), (0, 0), (0, 0)], mode="edge"))
+    # a pad that mixes a linked and an unlinked axis still goes through the connection logic
+    both = pad(da, grid, {"Z": (1, 0), "X": (1, 1)}).values
+    want = T.pad_face_connections(np.pad(a, [(1, 0), (0, 0), (0, 0), (0, 0)], mode="edge"), ("z", "face", "y", "x"), "face",
+                                  {"X": "x", "Y": "y"}, CUBED_SPHERE["face"], ["X", "Y"], {"X": (1, 1)},
+                                  {"X": None, "Y": None}, {"X": 0.0, "Y": 0.0})
+    np.testing.assert_array_equal(both, want)
+    with pytest.raises(ValueError, match="No boundary condition was specified for axis 'Z'"):
+        Grid(ds, coords=coords, face_connections=CUBED_SPHERE, autoparse_metadata=False).diff(da, "Z")

@@ -106,6 +106,7 @@ class Grid:
         else:
             self._facedim = None
             self._face_connections = None
+        self._connected_axes: set = set()
         self.axes: "OrderedDict[str, Axis]" = OrderedDict()
         for ax in names:
             self.axes[ax] = Axis(
@@ -182,6 +183,11 @@ class Grid:
         for axis, links in per_axis.items():
             self.axes[axis]._facedim = facedim
             self.axes[axis]._face_connections = links
+        # axes that any link touches, as the linked edge or as the neighbour's axis
+        self._connected_axes = set(per_axis)
+        for links in face_links.values():
+            for pair in links.values():
+                self._connected_axes.update(link[1] for link in pair if link is not None)
 
     def _validate_folds(self) -> None:
         """Resolve north-fold paddings: the seam is the one explicitly periodic other axis."""
@@ -588,7 +594,7 @@ class Grid:
                 ax_to = ax._default_shifts[pos]
             trim_lo, trim_hi, pad_lo, pad_hi = _cumsum_trim_pad(pos, ax_to, rev, ax)
             bc = all_padding[ax.name]
-            generic_pad = self._face_connections is not None or ax.name in self._folds
+            generic_pad = gridops.complex_topology(self, ax.name)
             if (pad_lo or pad_hi) and bc is None and not generic_pad:
                 raise no_boundary_error(ax.name)
             fv = all_fill[ax.name]

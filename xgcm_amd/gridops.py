@@ -63,9 +63,14 @@ def _cumsum(data, *args):
 
 
 def complex_topology(grid, ax_name: str) -> bool:
-    """True when halos along `ax_name` do not follow from the array itself: face connections
-    (every axis) or a north fold on this axis (the seam axis of a fold stays an ordinary wrap)."""
-    return getattr(grid, "_face_connections", None) is not None or ax_name in (getattr(grid, "_folds", None) or {})
+    """True when halos along `ax_name` do not follow from the array itself: an axis that takes part
+    in a face connection (as the linked edge or as the neighbour's axis), or the fold axis of a north
+    fold.  Other axes of such grids (the vertical of an LLC grid, the seam axis of a fold) keep the
+    ordinary wrap / clamp / constant rules -- the reference's `_pad_face_connections` reduces to
+    `_pad_basic` for them -- and therefore the fully fused kernels."""
+    if getattr(grid, "_face_connections", None) is not None and ax_name in getattr(grid, "_connected_axes", ()):
+        return True
+    return ax_name in (getattr(grid, "_folds", None) or {})
 
 
 class HipGridUFunc(GridUFunc):

@@ -65,7 +65,11 @@ def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding
     if padding_width is None or all(tuple(w) == (0, 0) for w in padding_width.values()):
         return data
     data = _strip_all_coords(data)
-    if getattr(grid, "_face_connections", None) is not None:
+    connected = getattr(grid, "_connected_axes", ())
+    if getattr(grid, "_face_connections", None) is not None and (
+            halo_only is not None or any(ax in connected and any(w) for ax, w in padding_width.items())):
+        # (padding only axes that no link touches is the ordinary per-axis pad: `_pad_face_connections`
+        # pre-pads them with `_pad_basic`, overwrites nothing and trims the other axes back to zero width)
         return _pad_face_connections(data, grid, padding_width, padding, fill_value, other_component, halo_only)
     if getattr(grid, "_folds", None) and any(ax in grid._folds for ax in padding_width):
         return _pad_fold(data, grid, padding_width, padding, fill_value, halo_only)
