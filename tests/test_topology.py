@@ -769,6 +769,12 @@ def test_fused_vorticity_on_a_fold_grid(backend):
     div = grid.divergence(u, v, metric_weighted=False)   # needs the folded NORTH halo of v (sign-flipped mirror row)
     chain = grid.diff({"X": u}, "X", other_component={"Y": v}) + grid.diff({"Y": v}, "Y", other_component={"X": u})
     np.testing.assert_array_equal(div.values, chain.values)
+    u32 = DataArray(u.values.astype(np.float32), dims=u.dims)
+    v32 = DataArray(v.values.astype(np.float32), dims=v.dims)
+    z32 = grid.vorticity(u32, v32, metric_weighted=False)
+    c32 = grid.diff({"Y": v32}, "X", other_component={"X": u32}) - grid.diff({"X": u32}, "Y", other_component={"Y": v32})
+    assert z32.values.dtype == np.float32
+    np.testing.assert_array_equal(z32.values, c32.values)
 
 
 def test_llc_13_face_topology(backend):
