@@ -1414,7 +1414,7 @@ __global__ __launch_bounds__(BLOCK) void k_transform_linear(
           lev = nxt;
         }
       };
-      constexpr int UT = 4;  // levels fetched ahead of use: the column loads do not wait on each other
+      constexpr int UT = 8;  // levels fetched ahead of use: the column loads do not wait on each other
       for (int64_t k0 = 1; k0 < n && !exact; k0 += UT) {
         real tvs[UT], fvs[UT];
 #pragma unroll
