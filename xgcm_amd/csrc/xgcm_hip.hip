@@ -89,6 +89,7 @@ struct Tune {
   int nt_store;  // non-temporal stores (+2-4 %; non-temporal LOADS measured -1 % and are not used)
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
   int scan_narrow_below; // marching scans with fewer wave-tasks than this use one element per lane
+  int pad_rows;          // row-wise generic pad (wave-uniform row logic); 0: one thread per cell
   int transform_lds_kb;  // LDS budget of the cell-major conservative kernel (0: always the register-tile kernel)
   int transform_fast;  // streaming path of the linear transform for well-formed columns (0: always the exact search)
   int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
@@ -107,6 +108,7 @@ struct Tune {
     zband = env_int("XG_ZBAND", 1);
     zchunk = env_int("XG_ZCHUNK", 256);
     transform_fast = env_int("XG_TRANSFORM_FAST", 1);
+    pad_rows = env_int("XG_PAD_ROWS", 1);
     scan_narrow_below = env_int("XG_SCAN_NARROW_BELOW", 8192);
     transform_lds_kb = env_int("XG_TRANSFORM_LDS_KB", 64);
     seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
@@ -1205,6 +1207,83 @@ __global__ __launch_bounds__(BLOCK) void k_pad(const real* __restrict__ in, real
   out[gid] = filled ? fv : in[src];
 }
 
+// K_pad rows: the same pad with the index work hoisted to the scalar unit.  A wave owns 64*V consecutive
+// cells of ONE output row (row = every dim but the innermost); the row's coordinates, the fill /
+// wrap / clamp decisions of the outer dims and the source row offset are wave-uniform, a lane only
+// resolves the innermost coordinate.  The walk order of the reference's chain is kept by splitting
+// the outer steps into those applied after the innermost dim (they win) and those applied before.
+// V == NV when the innermost dim is not padded: rows are straight 16-B copies or fills.
+template <int V>
+__global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in, real* __restrict__ out, PadGeo p,
+                                                    u32 nrows, FastDiv ntile) {
+  typedef typename VecT<V>::type T;
+  const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + (threadIdx.x >> 6));
+  const u32 r = fdiv(w, ntile);
+  if (r >= nrows) return;
+  const u32 tile = w - r * ntile.d;
+  const int nd = p.ndim;
+  const int t_in = p.mem_step[nd - 1];  // application step of the innermost memory dim
+  // peel the row index over the outer memory dims (innermost of them first)
+  int64_t coord[XG_MAX_NDIM];
+  u32 rem = r;
+#pragma unroll
+  for (int k = XG_MAX_NDIM - 2; k >= 0; --k) {
+    if (k < nd - 1) {
+      const u32 q = fdiv(rem, p.mem_fd[k]);
+      coord[p.mem_step[k]] = (int64_t)(rem - q * p.mem_fd[k].d);
+      rem = q;
+    }
+  }
+  int64_t src = 0;
+  bool fill_after = false, fill_before = false;
+  real fv_after = real(0), fv_before = real(0);
+#pragma unroll
+  for (int t = XG_MAX_NDIM - 1; t >= 0; --t) {
+    if (t < nd && t != t_in) {
+      const bool later = t > t_in;
+      if ((later && fill_after) || (!later && (fill_after || fill_before))) continue;
+      int64_t q = coord[t] - p.lo[t];
+      const int64_t n = p.in_shape[t];
+      if (q < 0 || q >= n) {
+        if (p.bc[t] == XG_BC_FILL) {
+          if (later) { fill_after = true; fv_after = p.fill[t]; }
+          else { fill_before = true; fv_before = p.fill[t]; }
+        } else if (p.bc[t] == XG_BC_PERIODIC) { q %= n; if (q < 0) q += n; }
+        else { q = (q < 0) ? 0 : n - 1; }
+      }
+      src += q * p.in_stride[t];
+    }
+  }
+  const int64_t Lo = p.out_shape[t_in], Li = p.in_shape[t_in];
+  const int64_t x = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
+  if (x >= Lo) return;
+  real* dst = out + (int64_t)r * Lo + x;
+  if (V > 1) {  // innermost dim not padded: Lo == Li, lo == 0
+    T val;
+    if (fill_after) val = splat<T>(fv_after);
+    else if (fill_before) val = splat<T>(fv_before);
+    else val = *reinterpret_cast<const T*>(in + src + x);
+    *reinterpret_cast<T*>(dst) = val;
+  } else {
+    real val;
+    if (fill_after) {
+      val = fv_after;
+    } else {
+      int64_t q = x - p.lo[t_in];
+      bool f_in = false;
+      if (q < 0 || q >= Li) {
+        if (p.bc[t_in] == XG_BC_FILL) f_in = true;
+        else if (p.bc[t_in] == XG_BC_PERIODIC) { q %= Li; if (q < 0) q += Li; }
+        else q = (q < 0) ? 0 : Li - 1;
+      }
+      if (f_in) val = p.fill[t_in];
+      else if (fill_before) val = fv_before;
+      else val = in[src + q * p.in_stride[t_in]];
+    }
+    *dst = val;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // halo gather through a token map (complex topologies: north fold, face connections;
 // padding.py:260-572,619-762).  The host turns the reference's padding procedure into ONE
@@ -2148,6 +2227,7 @@ int stencil_dispatch(int op, int V, int met, int kind, const StencilCall& c) {
 }
 
 inline u32 ceil_div_u32(int64_t a, int64_t b) { return (u32)((a + b - 1) / b); }
+inline bool in_stride_inner_is_one(const int64_t* istride, int ndim) { return istride[ndim - 1] == 1; }
 
 // A lane vector of NV elements takes its metric values at a constant step from the first one; that
 // holds when the NV elements share one row of the innermost coalesced dim.  For NV == 2 the step is
@@ -2410,10 +2490,28 @@ int XG_FN(xg_pad)(const real* in, real* out, const int64_t* shape, int ndim, con
   }
   p.total = total;
   if (total == 0) return XG_OK;
-  const u64 nblocks = ((u64)total + BLOCK - 1) / BLOCK;
   int rc;
-  if ((rc = check_grid(nblocks))) return rc;
   hipStream_t st = (hipStream_t)stream;
+  // long rows: one wave per (row, 64-cell tile) with the row logic on the scalar unit
+  const int64_t Lrow = oshape[ndim - 1];
+  const int64_t nrows64 = Lrow > 0 ? total / Lrow : 0;
+  const bool inner_padded = lo[ndim - 1] != 0 || hi[ndim - 1] != 0;
+  if (tune().pad_rows && (tune().pad_rows > 1 || !inner_padded) && Lrow >= 64 && nrows64 < 0x7fffffffll && in_stride_inner_is_one(istride, ndim)) {
+    const int V = (!inner_padded && Lrow % NV == 0 && aligned16(in) && aligned16(out)) ? NV : 1;
+    const u64 nt = (u64)((Lrow + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
+    const u64 waves = (u64)nrows64 * nt;
+    if (waves < 0x7fffffffull) {
+      const u64 nb = (waves + WPB - 1) / WPB;
+      if ((rc = check_grid(nb))) return rc;
+      const FastDiv fnt = make_fastdiv(nt);
+      if (V > 1) hipLaunchKernelGGL((k_pad_rows<NV>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
+      else hipLaunchKernelGGL((k_pad_rows<1>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
+      XG_LAUNCH_CHECK();
+      return XG_OK;
+    }
+  }
+  const u64 nblocks = ((u64)total + BLOCK - 1) / BLOCK;
+  if ((rc = check_grid(nblocks))) return rc;
   if (total < 0x7fffffffll) hipLaunchKernelGGL((k_pad<u32>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, p);
   else hipLaunchKernelGGL((k_pad<u64>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, p);
   XG_LAUNCH_CHECK();
