@@ -1213,7 +1213,7 @@ __global__ __launch_bounds__(BLOCK) void k_pad(const real* __restrict__ in, real
 // resolves the innermost coordinate.  The walk order of the reference's chain is kept by splitting
 // the outer steps into those applied after the innermost dim (they win) and those applied before.
 // V == NV when the innermost dim is not padded: rows are straight 16-B copies or fills.
-template <int V>
+template <int V, bool INNER>
 __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in, real* __restrict__ out, PadGeo p,
                                                     u32 nrows, FastDiv ntile) {
   typedef typename VecT<V>::type T;
@@ -1258,12 +1258,32 @@ __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in,
   const int64_t x = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
   if (x >= Lo) return;
   real* dst = out + (int64_t)r * Lo + x;
-  if (V > 1) {  // innermost dim not padded: Lo == Li, lo == 0
+  if (V > 1 && !INNER) {  // innermost dim not padded: Lo == Li, lo == 0
     T val;
     if (fill_after) val = splat<T>(fv_after);
     else if (fill_before) val = splat<T>(fv_before);
     else val = *reinterpret_cast<const T*>(in + src + x);
     *reinterpret_cast<T*>(dst) = val;
+  } else if (V > 1) {  // padded innermost dim, row length a multiple of NV: narrow gathers, one 16-B store
+    dv val;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      real e;
+      if (fill_after) {
+        e = fv_after;
+      } else {
+        int64_t q = x + k - p.lo[t_in];
+        bool f_in = false;
+        if (q < 0 || q >= Li) {
+          if (p.bc[t_in] == XG_BC_FILL) f_in = true;
+          else if (p.bc[t_in] == XG_BC_PERIODIC) { q %= Li; if (q < 0) q += Li; }
+          else q = (q < 0) ? 0 : Li - 1;
+        }
+        e = f_in ? p.fill[t_in] : (fill_before ? fv_before : in[src + q]);
+      }
+      val[k] = e;
+    }
+    *reinterpret_cast<dv*>(dst) = val;
   } else {
     real val;
     if (fill_after) {
@@ -2496,16 +2516,18 @@ int XG_FN(xg_pad)(const real* in, real* out, const int64_t* shape, int ndim, con
   const int64_t Lrow = oshape[ndim - 1];
   const int64_t nrows64 = Lrow > 0 ? total / Lrow : 0;
   const bool inner_padded = lo[ndim - 1] != 0 || hi[ndim - 1] != 0;
-  if (tune().pad_rows && (tune().pad_rows > 1 || !inner_padded) && Lrow >= 64 && nrows64 < 0x7fffffffll && in_stride_inner_is_one(istride, ndim)) {
-    const int V = (!inner_padded && Lrow % NV == 0 && aligned16(in) && aligned16(out)) ? NV : 1;
+  const bool rows_vec = Lrow % NV == 0 && aligned16(out) && (inner_padded || aligned16(in));
+  if (tune().pad_rows && (tune().pad_rows > 1 || rows_vec) && Lrow >= 64 && nrows64 < 0x7fffffffll && in_stride_inner_is_one(istride, ndim)) {
+    const int V = rows_vec ? NV : 1;
     const u64 nt = (u64)((Lrow + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
     const u64 waves = (u64)nrows64 * nt;
     if (waves < 0x7fffffffull) {
       const u64 nb = (waves + WPB - 1) / WPB;
       if ((rc = check_grid(nb))) return rc;
       const FastDiv fnt = make_fastdiv(nt);
-      if (V > 1) hipLaunchKernelGGL((k_pad_rows<NV>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
-      else hipLaunchKernelGGL((k_pad_rows<1>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
+      if (V > 1 && inner_padded) hipLaunchKernelGGL((k_pad_rows<NV, true>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
+      else if (V > 1) hipLaunchKernelGGL((k_pad_rows<NV, false>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
+      else hipLaunchKernelGGL((k_pad_rows<1, true>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
       XG_LAUNCH_CHECK();
       return XG_OK;
     }
