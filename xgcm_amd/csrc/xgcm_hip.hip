@@ -1321,6 +1321,7 @@ struct GatherSrc {
   int64_t m_extent[XG_MAX_NDIM], m_stride[XG_MAX_NDIM];  // mapped dims in the source's own order
   int64_t u_stride[XG_MAX_NDIM];                         // per OUT dim; 0 for mapped dims
   int64_t mapped_size;                                   // prod(m_extent)
+  int trailing;  // the mapped dims are the source's trailing dims: element k sits at offset k of its block
 };
 struct GatherGeo {
   int ndim;
@@ -1335,6 +1336,22 @@ struct GatherGeo {
   GatherSrc src[2];
   FastDiv out_fd[XG_MAX_NDIM];
 };
+
+// offset of element k (row-major over the source's mapped dims) inside the source array
+__device__ __forceinline__ int64_t gather_mapped_off(const GatherSrc& S, int64_t k) {
+  if (S.trailing) return k;
+  int64_t o = 0;
+#pragma unroll
+  for (int m = XG_MAX_NDIM - 1; m >= 0; --m) {
+    if (m < S.n_mapped) {
+      const int64_t n = S.m_extent[m];
+      const int64_t q = k / n;
+      o += (k - q * n) * S.m_stride[m];
+      k = q;
+    }
+  }
+  return o;
+}
 
 template <typename I>
 __global__ __launch_bounds__(BLOCK) void k_gather(const real* __restrict__ in, const real* __restrict__ partner,
@@ -1384,18 +1401,81 @@ __global__ __launch_bounds__(BLOCK) void k_gather(const real* __restrict__ in, c
 #pragma unroll
     for (int d = 0; d < XG_MAX_NDIM; ++d)
       if (d < g.ndim && !g.mapped[d]) o += c[d] * S.u_stride[d];
-#pragma unroll
-    for (int m = XG_MAX_NDIM - 1; m >= 0; --m) {
-      if (m < S.n_mapped) {
-        const int64_t n = S.m_extent[m];
-        const int64_t q = k / n;
-        o += (k - q * n) * S.m_stride[m];
-        k = q;
-      }
-    }
+    o += gather_mapped_off(S, k);
     v = s ? partner[o] : in[o];
   }
   out[gid] = t < 0 ? -v : v;
+}
+
+// k_gather, row-wise: a wave owns 64 aligned 16-B groups of ONE output row; the row's coordinates, its
+// interior test over the outer dims, the interior source offset and the token-row base are
+// wave-uniform.  Interior cells are narrow loads of consecutive inputs; halo cells decode a token
+// (without any division when the mapped dims are the source's trailing dims, the usual
+// (time, depth, face, j, i) layouts).
+__global__ __launch_bounds__(BLOCK) void k_gather_rows(const real* __restrict__ in, const real* __restrict__ partner,
+                                                       real* __restrict__ out, const int64_t* __restrict__ tokens,
+                                                       GatherGeo g, u32 nrows, FastDiv ntile) {
+  const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + (threadIdx.x >> 6));
+  const u32 r = fdiv(w, ntile);
+  if (r >= nrows) return;
+  const u32 tile = w - r * ntile.d;
+  const int nd = g.ndim;
+  u32 rem = r;
+  bool interior = true;   // over the outer dims
+  int64_t off = 0;        // interior source offset of the row
+  int64_t uoff[2] = {0, 0};  // unmapped-dim offset of the row in `in` / `partner`
+  int64_t prow = 0, pmul = 1;  // token index of the row start (outer mapped dims, row-major)
+#pragma unroll
+  for (int d = XG_MAX_NDIM - 2; d >= 0; --d) {
+    if (d < nd - 1) {
+      const u32 q = fdiv(rem, g.out_fd[d]);
+      const int64_t cd = (int64_t)(rem - q * g.out_fd[d].d);
+      rem = q;
+      if (g.mapped[d]) {
+        const int64_t ci = cd - g.lo[d];
+        interior = interior && ci >= 0 && ci < g.in_shape[d];
+        off += ci * g.in_stride[d];
+        prow += cd * pmul;
+        pmul *= g.out_shape[d];
+      } else {
+        off += cd * g.in_stride[d];
+        uoff[0] += cd * g.src[0].u_stride[d];
+        uoff[1] += cd * g.src[1].u_stride[d];
+      }
+    }
+  }
+  const int di = nd - 1;
+  const int64_t Lo = g.out_shape[di], Li = g.in_shape[di];
+  const bool in_mapped = g.mapped[di] != 0;
+  const int64_t lo_in = in_mapped ? g.lo[di] : 0;
+  const int64_t x0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * NV;
+  if (x0 >= Lo) return;
+  dv val;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int64_t x = x0 + k;
+    const int64_t ci = x - lo_in;
+    if (interior && ci >= 0 && ci < Li) {
+      val[k] = in[off + ci];
+    } else {
+      const int64_t t = tokens[in_mapped ? prow * Lo + x : prow];
+      const int64_t a = t < 0 ? -t : t;
+      real v;
+      if (a >= XG_TOKEN_FILL_BASE) {
+        const int64_t f = a - XG_TOKEN_FILL_BASE;
+        v = g.fills[f < g.n_fills ? f : 0];
+      } else {
+        int64_t kk = a - 1;
+        const int s = (kk >= g.src[0].mapped_size) ? 1 : 0;
+        kk -= s ? g.src[0].mapped_size : 0;
+        int64_t o = uoff[s] + gather_mapped_off(g.src[s], kk);
+        if (!in_mapped) o += x * g.src[s].u_stride[di];
+        v = s ? partner[o] : in[o];
+      }
+      val[k] = t < 0 ? -v : v;
+    }
+  }
+  *reinterpret_cast<dv*>(out + (int64_t)r * Lo + x0) = val;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2592,13 +2672,34 @@ int XG_FN(xg_gather)(const real* in, const real* partner, real* out, const int64
         S.u_stride[d] = strides[k];
       }
     }
+    // mapped dims trailing in THIS source's own dim order: no unmapped dim after the first mapped one
+    S.trailing = 1;
+    bool seen_mapped = false;
+    for (int k = 0; k < ndim; ++k) {
+      const int d = s ? partner_perm[k] : k;
+      if (mapped[d]) seen_mapped = true;
+      else if (seen_mapped && shp[k] != 1) S.trailing = 0;
+    }
   }
   g.total = total;
   if (total == 0) return XG_OK;
-  const u64 nblocks = ((u64)total + BLOCK - 1) / BLOCK;
   int rc;
-  if ((rc = check_grid(nblocks))) return rc;
   hipStream_t st = (hipStream_t)stream;
+  const int64_t Lrow = out_shape[ndim - 1];
+  const int64_t nrows64 = Lrow > 0 ? total / Lrow : 0;
+  if (tune().pad_rows && Lrow >= 64 && Lrow % NV == 0 && aligned16(out) && nrows64 < 0x7fffffffll) {
+    const u64 nt = (u64)((Lrow + (int64_t)WAVE * NV - 1) / ((int64_t)WAVE * NV));
+    const u64 waves = (u64)nrows64 * nt;
+    if (waves < 0x7fffffffull) {
+      const u64 nb = (waves + WPB - 1) / WPB;
+      if ((rc = check_grid(nb))) return rc;
+      hipLaunchKernelGGL(k_gather_rows, dim3((u32)nb), dim3(BLOCK), 0, st, in, partner, out, tokens, g, (u32)nrows64, make_fastdiv(nt));
+      XG_LAUNCH_CHECK();
+      return XG_OK;
+    }
+  }
+  const u64 nblocks = ((u64)total + BLOCK - 1) / BLOCK;
+  if ((rc = check_grid(nblocks))) return rc;
   if (total < 0x7fffffffll) hipLaunchKernelGGL((k_gather<u32>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, partner, out, tokens, g);
   else hipLaunchKernelGGL((k_gather<u64>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, partner, out, tokens, g);
   XG_LAUNCH_CHECK();
