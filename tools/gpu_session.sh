@@ -20,5 +20,5 @@ cd $REPO
 find $OUT/prof_stats_$TAG $OUT/prof_fetch_$TAG $OUT/prof_write_$TAG -type f | head -30
 python tools/summarize_prof.py $OUT $TAG 2>&1 | tee $OUT/prof_summary_$TAG.txt
 echo "== microbench (all kernels, random data)"
-timeout 300 python tools/microbench.py --reps 9 > $OUT/mb_full_$TAG.jsonl 2>&1
+timeout 300 python tools/microbench.py --reps 9 --cases copy,stencil,metric,cumsum,reduce,vort,generic > $OUT/mb_full_$TAG.jsonl 2>&1
 grep -v amdgpu.ids $OUT/mb_full_$TAG.jsonl
