@@ -1835,9 +1835,17 @@ template <int BOP> __device__ __forceinline__ real bin2(real a, real b) {
 
 template <int BOP, int V, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, const real* __restrict__ b,
-                                                  real* __restrict__ out, BinGeo g) {
+                                                  real* __restrict__ out, BinGeo g, ZBand zb) {
   typedef typename VecT<V>::type T;
-  const int64_t gid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  int64_t gid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (zb.on) {
+    // (Z, P) items with one operand broadcast along Z (da / dx(Y,X)): band-major order keeps the
+    // band of the small operand in L2 while all Z levels of the band stream by (as in K1 / K2S)
+    u32 z, pin;
+    if (gid >= (int64_t)zb.per_band.d * ((zb.Y + zb.B - 1) / zb.B)) return;
+    if (!zband_map(zb, (u32)gid, z, pin)) return;
+    gid = (int64_t)z * zb.Y + pin;
+  }
   if (gid >= g.total) return;
   int64_t r = gid, oa = 0, ob = 0;
 #pragma unroll
@@ -2799,12 +2807,24 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
   const int V = v2 ? NV : 1;
   g.shape[n - 1] = last / V;
   g.total = total / V;
-  const u64 nblocks = ((u64)g.total + BLOCK - 1) / BLOCK;
+  u64 nitems = (u64)g.total;
+  ZBand zb = make_zband(false, 0, 0, 1);
+  if (tune().zband && n == 2 && (g.sa[0] == 0) != (g.sb[0] == 0) && g.shape[0] >= 2) {
+    // exactly one operand is broadcast along the slow dim and re-read once per level: band it
+    const u64 Z = (u64)g.shape[0], P = (u64)g.shape[1];
+    const u32 B = 16384;  // items per band: 256 KiB of the broadcast operand at 16 B per item
+    const u64 padded = ((P + B - 1) / B) * B * Z;
+    if (P > 2 * (u64)B && padded < 0x7fffffffull) {
+      zb = make_zband(true, Z, P, B);
+      if (zb.on) nitems = padded;
+    }
+  }
+  const u64 nblocks = (nitems + BLOCK - 1) / BLOCK;
   int rc;
   if ((rc = check_grid(nblocks))) return rc;
   hipStream_t st = (hipStream_t)stream;
   const bool nts = tune().nt_store;
-#define XG_GO(O, V_, NTS) hipLaunchKernelGGL((k_binary<O, V_, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, a, b, out, g)
+#define XG_GO(O, V_, NTS) hipLaunchKernelGGL((k_binary<O, V_, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, a, b, out, g, zb)
 #define XG_O(O) do { if (V > 1) { if (nts) XG_GO(O, NV, true); else XG_GO(O, NV, false); } else { if (nts) XG_GO(O, 1, true); else XG_GO(O, 1, false); } } while (0)
   switch (op) { case XG_BIN_MUL: XG_O(XG_BIN_MUL); break; case XG_BIN_DIV: XG_O(XG_BIN_DIV); break; case XG_BIN_ADD: XG_O(XG_BIN_ADD); break; default: XG_O(XG_BIN_SUB); }
 #undef XG_O
