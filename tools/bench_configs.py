@@ -223,6 +223,22 @@ def main():
         rec("f4", f"transform conservative: {nzt} cells -> {mt} sigma bins, cells = input cells",
             timeit(lambda: gz.transform(phi, "Z", edges, target_data=sigma_o, method="conservative"), max(3, a.reps // 2)),
             nzt * cols, (2 * nzt + 1 + mt) * 8 / nzt)
+        # the same with a smooth stratification (neighbouring columns cross a level at nearly the same depth,
+        # as in ocean data): lanes of a wave then emit together instead of at 64 different source levels
+        zz = torch.arange(nzt, dtype=torch.float64, device="cuda")[:, None, None]
+        yy = torch.arange(nyt, dtype=torch.float64, device="cuda")[None, :, None]
+        xx = torch.arange(nxt, dtype=torch.float64, device="cuda")[None, None, :]
+        smooth = 1.05 * (zz + 0.5) + 2.0 * torch.sin(2 * np.pi * xx / nxt) * torch.cos(2 * np.pi * yy / nyt)
+        sigma_s = DataArray(smooth.contiguous(), ("Z", "Y", "X"), name="sigma")
+        rec("f4", "transform linear, smooth stratification (same sizes)",
+            timeit(lambda: gz.transform(phi, "Z", levels, target_data=sigma_s), a.reps), nzt * cols, (2 * nzt + mt) * 8 / nzt)
+        zo = torch.arange(nzt + 1, dtype=torch.float64, device="cuda")[:, None, None]
+        smooth_o = 1.05 * zo + 2.0 * torch.sin(2 * np.pi * xx / nxt) * torch.cos(2 * np.pi * yy / nyt)
+        sigma_so = DataArray(smooth_o.contiguous(), ("Zp1", "Y", "X"), name="sigma")
+        rec("f4", "transform conservative, smooth stratification (same sizes)",
+            timeit(lambda: gz.transform(phi, "Z", edges, target_data=sigma_so, method="conservative"), max(3, a.reps // 2)),
+            nzt * cols, (2 * nzt + 1 + mt) * 8 / nzt)
+        del zz, yy, xx, smooth, smooth_o, sigma_s, sigma_so
         out = gz.transform(phi, "Z", levels, target_data=sigma)
         oc = gz.transform(phi, "Z", edges, target_data=sigma_o, method="conservative")
         # full-size properties: a target equal to a column's own theta returns the column; integral conserved

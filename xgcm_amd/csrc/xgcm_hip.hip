@@ -1767,7 +1767,17 @@ __global__ __launch_bounds__(CTB) void k_transform_conservative_lds(
   const real* pth = theta + outer_off(g, mt, o) + inner_off(g, mt, x);
   real* pout = out + (o * m) * inner + x;
   for (int64_t j = 0; j < m; ++j) acc[j * CTB] = (real)NAN;
-  int64_t jlo = 0;
+  // cursor bin jlo with its two edges and its accumulator held in registers: a stratified column
+  // stays in the same bin for several cells, which then cost no LDS round trip at all
+  int jlo = 0;
+  const int mm = (int)m;
+  real e_lo = sb[0], e_hi = sb[1], a_cur = (real)NAN;
+  auto move_to = [&](int j) {
+    acc[jlo * CTB] = a_cur;
+    jlo = j;
+    e_lo = sb[j]; e_hi = sb[j + 1];
+    a_cur = acc[j * CTB];
+  };
   real t1 = pth[0];
   constexpr int UT = XG_CONS_UT;
   for (int64_t i0 = 0; i0 < n; i0 += UT) {
@@ -1793,26 +1803,36 @@ __global__ __launch_bounds__(CTB) void k_transform_conservative_lds(
       else { lo_ = t2; hi_ = a1; }
       if (p != p) continue;
       // first bin whose upper edge reaches the cell: min{j: edge[j+1] >= lo}
-      while (jlo > 0 && sb[jlo] >= lo_) --jlo;
-      while (jlo < m && sb[jlo + 1] < lo_) ++jlo;
-      for (int64_t j = jlo; j < m; ++j) {
-        const real e1 = sb[j];
-        if (e1 > hi_) break;               // later bins start above the cell
+      if ((jlo > 0 && e_lo >= lo_) || (e_hi < lo_ && jlo < mm - 1)) {
+        int j = jlo;
+        while (j > 0 && sb[j] >= lo_) --j;
+        while (j < mm - 1 && sb[j + 1] < lo_) ++j;
+        move_to(j);
+      }
+      if (e_hi < lo_ || e_lo > hi_) continue;  // the cell lies above the last bin / below this one: no overlap at all
+      auto share = [&](real e1, real e2) -> real {
+        if (hi_ == lo_) return p;
+        const real hmin = (e1 > lo_) ? e1 : lo_;
+        const real hmax = (e2 < hi_) ? e2 : hi_;
+        const real alpha = (hmax - hmin) / (hi_ - lo_);
+        return alpha * p;
+      };
+      {
+        const real add = share(e_lo, e_hi);
+        a_cur = (a_cur != a_cur) ? add : a_cur + add;
+      }
+      real e1 = e_hi;
+      for (int j = jlo + 1; j < mm; ++j) {   // further bins the cell reaches into (through LDS)
+        if (e1 > hi_) break;
         const real e2 = sb[j + 1];
-        real add;
-        if (hi_ == lo_) {
-          add = p;
-        } else {
-          const real hmin = (e1 > lo_) ? e1 : lo_;
-          const real hmax = (e2 < hi_) ? e2 : hi_;
-          const real alpha = (hmax - hmin) / (hi_ - lo_);
-          add = alpha * p;
-        }
+        const real add = share(e1, e2);
         const real old = acc[j * CTB];
         acc[j * CTB] = (old != old) ? add : old + add;
+        e1 = e2;
       }
     }
   }
+  acc[jlo * CTB] = a_cur;
   for (int64_t j = 0; j < m; ++j) pout[j * inner] = acc[j * CTB];
 }
 
