@@ -117,6 +117,8 @@ def main():
         rec("pad_X(1,1)_periodic(generic k_pad)", ms, b, 16)
         ms, b = timeit(lambda: D.pad_nd(T, {1: (0, 1), 2: (2, 0)}, {1: "extend", 2: "fill"}, {2: 1.5}), args.reps)
         rec("pad_Y(0,1)+X(2,0)(generic k_pad)", ms, b, 16)
+        ms, b = timeit(lambda: D.pad_nd(T, {2: (1, 0)}, {2: "periodic"}, {}), args.reps)
+        rec("pad_X(1,0)_periodic: odd row length", ms, b, 16)
         ms, b = timeit(lambda: D.pad_nd(T, {1: (1, 1), 0: (1, 0)}, {1: "extend", 0: "fill"}, {0: 0.0}), args.reps)
         rec("pad_Y(1,1)+Z(1,0) rows untouched along X (k_pad_rows)", ms, b, 16)
         B = D.synthetic(shape, 9)

@@ -1255,52 +1255,47 @@ __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in,
     }
   }
   const int64_t Lo = p.out_shape[t_in], Li = p.in_shape[t_in];
-  const int64_t x = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
-  if (x >= Lo) return;
-  real* dst = out + (int64_t)r * Lo + x;
-  if (V > 1 && !INNER) {  // innermost dim not padded: Lo == Li, lo == 0
+  auto elem = [&](int64_t xx) -> real {  // value of output cell xx of this row
+    if (fill_after) return fv_after;
+    int64_t q = xx - p.lo[t_in];
+    if (q < 0 || q >= Li) {
+      if (p.bc[t_in] == XG_BC_FILL) return p.fill[t_in];
+      if (p.bc[t_in] == XG_BC_PERIODIC) { q %= Li; if (q < 0) q += Li; }
+      else q = (q < 0) ? 0 : Li - 1;
+    }
+    return fill_before ? fv_before : in[src + q];
+  };
+  real* drow = out + (int64_t)r * Lo;
+  if (V > 1 && !INNER) {  // aligned rows, innermost dim not padded: straight vector copies or fills
+    const int64_t x = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
+    if (x >= Lo) return;
     T val;
     if (fill_after) val = splat<T>(fv_after);
     else if (fill_before) val = splat<T>(fv_before);
     else val = *reinterpret_cast<const T*>(in + src + x);
-    *reinterpret_cast<T*>(dst) = val;
-  } else if (V > 1) {  // padded innermost dim, row length a multiple of NV: narrow gathers, one 16-B store
-    dv val;
+    *reinterpret_cast<T*>(drow + x) = val;
+  } else if (V > 1) {
+    // any row length: the row starts `lead` cells before a 16-B boundary of the output; those cells and
+    // the cells after the last whole group go out as scalars (lane 0 of tile 0 / the lane that owns them),
+    // everything in between as NV narrow gathers + one 16-B store
+    const int64_t lead = (NV - (int64_t)(((int64_t)r * Lo) % NV)) % NV;
+    const int lane = threadIdx.x & 63;
+    if (tile == 0 && lane == 0)
+      for (int64_t xx = 0; xx < lead && xx < Lo; ++xx) drow[xx] = elem(xx);
+    const int64_t x = lead + ((int64_t)tile * WAVE + lane) * NV;
+    if (x >= Lo) return;
+    if (x + NV <= Lo) {
+      dv val;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      real e;
-      if (fill_after) {
-        e = fv_after;
-      } else {
-        int64_t q = x + k - p.lo[t_in];
-        bool f_in = false;
-        if (q < 0 || q >= Li) {
-          if (p.bc[t_in] == XG_BC_FILL) f_in = true;
-          else if (p.bc[t_in] == XG_BC_PERIODIC) { q %= Li; if (q < 0) q += Li; }
-          else q = (q < 0) ? 0 : Li - 1;
-        }
-        e = f_in ? p.fill[t_in] : (fill_before ? fv_before : in[src + q]);
-      }
-      val[k] = e;
-    }
-    *reinterpret_cast<dv*>(dst) = val;
-  } else {
-    real val;
-    if (fill_after) {
-      val = fv_after;
+      for (int k = 0; k < NV; ++k) val[k] = elem(x + k);
+      *reinterpret_cast<dv*>(drow + x) = val;
     } else {
-      int64_t q = x - p.lo[t_in];
-      bool f_in = false;
-      if (q < 0 || q >= Li) {
-        if (p.bc[t_in] == XG_BC_FILL) f_in = true;
-        else if (p.bc[t_in] == XG_BC_PERIODIC) { q %= Li; if (q < 0) q += Li; }
-        else q = (q < 0) ? 0 : Li - 1;
-      }
-      if (f_in) val = p.fill[t_in];
-      else if (fill_before) val = fv_before;
-      else val = in[src + q * p.in_stride[t_in]];
+      for (int64_t xx = x; xx < Lo; ++xx) drow[xx] = elem(xx);
     }
-    *dst = val;
+  } else {
+    const int64_t x = (int64_t)tile * WAVE + (threadIdx.x & 63);
+    if (x >= Lo) return;
+    drow[x] = elem(x);
   }
 }
 
@@ -1448,34 +1443,42 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(const real* __restrict__ 
   const int64_t Lo = g.out_shape[di], Li = g.in_shape[di];
   const bool in_mapped = g.mapped[di] != 0;
   const int64_t lo_in = in_mapped ? g.lo[di] : 0;
-  const int64_t x0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * NV;
-  if (x0 >= Lo) return;
-  dv val;
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int64_t x = x0 + k;
+  auto elem = [&](int64_t x) -> real {  // value of output cell x of this row
     const int64_t ci = x - lo_in;
-    if (interior && ci >= 0 && ci < Li) {
-      val[k] = in[off + ci];
+    if (interior && ci >= 0 && ci < Li) return in[off + ci];
+    const int64_t t = tokens[in_mapped ? prow * Lo + x : prow];
+    const int64_t a = t < 0 ? -t : t;
+    real v;
+    if (a >= XG_TOKEN_FILL_BASE) {
+      const int64_t f = a - XG_TOKEN_FILL_BASE;
+      v = g.fills[f < g.n_fills ? f : 0];
     } else {
-      const int64_t t = tokens[in_mapped ? prow * Lo + x : prow];
-      const int64_t a = t < 0 ? -t : t;
-      real v;
-      if (a >= XG_TOKEN_FILL_BASE) {
-        const int64_t f = a - XG_TOKEN_FILL_BASE;
-        v = g.fills[f < g.n_fills ? f : 0];
-      } else {
-        int64_t kk = a - 1;
-        const int s = (kk >= g.src[0].mapped_size) ? 1 : 0;
-        kk -= s ? g.src[0].mapped_size : 0;
-        int64_t o = uoff[s] + gather_mapped_off(g.src[s], kk);
-        if (!in_mapped) o += x * g.src[s].u_stride[di];
-        v = s ? partner[o] : in[o];
-      }
-      val[k] = t < 0 ? -v : v;
+      int64_t kk = a - 1;
+      const int s = (kk >= g.src[0].mapped_size) ? 1 : 0;
+      kk -= s ? g.src[0].mapped_size : 0;
+      int64_t o = uoff[s] + gather_mapped_off(g.src[s], kk);
+      if (!in_mapped) o += x * g.src[s].u_stride[di];
+      v = s ? partner[o] : in[o];
     }
+    return t < 0 ? -v : v;
+  };
+  // the row starts `lead` cells before a 16-B boundary of the output: those and the cells after the
+  // last whole group leave as scalars, the groups in between as one 16-B store each
+  real* drow = out + (int64_t)r * Lo;
+  const int64_t lead = (NV - (int64_t)(((int64_t)r * Lo) % NV)) % NV;
+  const int lane = threadIdx.x & 63;
+  if (tile == 0 && lane == 0)
+    for (int64_t x = 0; x < lead && x < Lo; ++x) drow[x] = elem(x);
+  const int64_t x0 = lead + ((int64_t)tile * WAVE + lane) * NV;
+  if (x0 >= Lo) return;
+  if (x0 + NV <= Lo) {
+    dv val;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) val[k] = elem(x0 + k);
+    *reinterpret_cast<dv*>(drow + x0) = val;
+  } else {
+    for (int64_t x = x0; x < Lo; ++x) drow[x] = elem(x);
   }
-  *reinterpret_cast<dv*>(out + (int64_t)r * Lo + x0) = val;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2624,18 +2627,18 @@ int XG_FN(xg_pad)(const real* in, real* out, const int64_t* shape, int ndim, con
   const int64_t Lrow = oshape[ndim - 1];
   const int64_t nrows64 = Lrow > 0 ? total / Lrow : 0;
   const bool inner_padded = lo[ndim - 1] != 0 || hi[ndim - 1] != 0;
-  const bool rows_vec = Lrow % NV == 0 && aligned16(out) && (inner_padded || aligned16(in));
-  if (tune().pad_rows && (tune().pad_rows > 1 || rows_vec) && Lrow >= 64 && nrows64 < 0x7fffffffll && in_stride_inner_is_one(istride, ndim)) {
-    const int V = rows_vec ? NV : 1;
-    const u64 nt = (u64)((Lrow + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
+  if (tune().pad_rows && Lrow >= 64 && nrows64 < 0x7fffffffll && in_stride_inner_is_one(istride, ndim) && aligned16(out)) {
+    // aligned rows with an untouched innermost dim: vector copies; everything else: per-element gathers,
+    // 16-B stores between the row's first and last 16-B boundary
+    const bool straight = !inner_padded && Lrow % NV == 0 && aligned16(in);
+    const u64 nt = (u64)((Lrow + (NV - 1) + (int64_t)WAVE * NV - 1) / ((int64_t)WAVE * NV));
     const u64 waves = (u64)nrows64 * nt;
     if (waves < 0x7fffffffull) {
       const u64 nb = (waves + WPB - 1) / WPB;
       if ((rc = check_grid(nb))) return rc;
       const FastDiv fnt = make_fastdiv(nt);
-      if (V > 1 && inner_padded) hipLaunchKernelGGL((k_pad_rows<NV, true>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
-      else if (V > 1) hipLaunchKernelGGL((k_pad_rows<NV, false>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
-      else hipLaunchKernelGGL((k_pad_rows<1, true>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
+      if (straight) hipLaunchKernelGGL((k_pad_rows<NV, false>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
+      else hipLaunchKernelGGL((k_pad_rows<NV, true>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
       XG_LAUNCH_CHECK();
       return XG_OK;
     }
@@ -2715,8 +2718,8 @@ int XG_FN(xg_gather)(const real* in, const real* partner, real* out, const int64
   hipStream_t st = (hipStream_t)stream;
   const int64_t Lrow = out_shape[ndim - 1];
   const int64_t nrows64 = Lrow > 0 ? total / Lrow : 0;
-  if (tune().pad_rows && Lrow >= 64 && Lrow % NV == 0 && aligned16(out) && nrows64 < 0x7fffffffll) {
-    const u64 nt = (u64)((Lrow + (int64_t)WAVE * NV - 1) / ((int64_t)WAVE * NV));
+  if (tune().pad_rows && Lrow >= 64 && aligned16(out) && nrows64 < 0x7fffffffll) {
+    const u64 nt = (u64)((Lrow + (NV - 1) + (int64_t)WAVE * NV - 1) / ((int64_t)WAVE * NV));
     const u64 waves = (u64)nrows64 * nt;
     if (waves < 0x7fffffffull) {
       const u64 nb = (waves + WPB - 1) / WPB;
