@@ -705,3 +705,26 @@ def test_grid_constructor_errors(backend):
         g = Grid(ds, coords=coords, fill_value={"X": 1.0}, autoparse_metadata=False)
     assert g.axes["X"].fill_value == 1.0 and g.axes["Y"].fill_value == 0.0
     assert repr(g).split("\n")[0] == "<xgcm.Grid>"
+
+
+def test_integer_inputs_keep_their_dtype_like_numpy(backend):
+    """diff / min / max / cumsum of signed integers return integers (numpy's result), interp returns
+    floats; a non-integral fill value is truncated as numpy.pad does."""
+    grid = five_position_grid(9, padding="fill")
+    a = (np.arange(18).reshape(2, 9) ** 2 % 17 - 5).astype(np.int64)
+    da = DataArray(a, ("t", "X_c"))
+    for fn in ("diff", "min", "max"):
+        got = getattr(grid, fn)(da, "X", to="left", fill_value=2.7)
+        want = R.stencil1d(fn, a, 1, 1, 0, "fill", 2.7)   # numpy on the int array: pad casts 2.7 -> 2
+        assert _np(got).dtype == np.int64 and want.dtype == np.int64
+        np.testing.assert_array_equal(_np(got), want)
+    got = grid.interp(da, "X", to="left", fill_value=2.7)
+    assert _np(got).dtype == np.float64
+    np.testing.assert_array_equal(_np(got), R.stencil1d("interp", a, 1, 1, 0, "fill", 2.7))
+    got = grid.cumsum(da, "X", to="left", padding="fill")
+    assert _np(got).dtype == np.int64
+    np.testing.assert_array_equal(_np(got), np.concatenate([np.zeros((2, 1), np.int64), np.cumsum(a, axis=1)[:, :-1]], axis=1))
+    a32 = a.astype(np.int32)
+    got = grid.diff(DataArray(a32, ("t", "X_c")), "X", to="right", padding="periodic")
+    assert _np(got).dtype == np.int32
+    np.testing.assert_array_equal(_np(got), np.roll(a32, -1, axis=1) - a32)

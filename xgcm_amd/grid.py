@@ -618,10 +618,11 @@ class Grid:
                 if weighted:
                     res = res / self._resident(self.get_metric(res, weighted), res.data)
             else:
+                keep_int = gridops.signed_int_dtype(data.data) if not weighted else None
                 out = _dev.cumsum1d(data.data, num, trim_lo, trim_hi, pad_lo, pad_hi,
-                                    bc if (pad_lo or pad_hi) else None, 0.0 if fv is None else float(fv), rev, True,
-                                    m_in, m_out)
-                res = DataArray(_dev.tohost(out) if host else out, out_dims, name=data.name)
+                                    bc if (pad_lo or pad_hi) else None,
+                                    gridops.int_fill(0.0 if fv is None else float(fv), keep_int), rev, True, m_in, m_out)
+                res = DataArray(gridops.restore_int(_dev.tohost(out) if host else out, keep_int), out_dims, name=data.name)
             data = _reattach_coords([res], self, {ax.name: (pad_lo, pad_hi)}, {new_dim}, [data])[0]
         return to_xarray(data) if was_xr else data
 
