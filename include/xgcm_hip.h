@@ -32,6 +32,7 @@
  *   xg_binary_f64      the xarray broadcasting `*`, `/`, `+`, `-` around the ops
  *                      (xgcm/grid.py:808,832,1578,1600; get_metric products :614-617)
  *   xg_stencil2d_f64   Grid.interp/diff/min/max over two axes (xgcm/grid.py:798-828), one pass
+ *   xg_gradient_f64 / xg_flux_f64  the "Gradient" and "Advection" grid ufuncs of docs/ufunc_examples.md, fused
  *   xg_divergence_f64  the chained (diff(u,X) + diff(v,Y)) / area of docs/ufunc_examples.md, fused
  *   xg_vorticity_f64   the chained (diff(v,X) - diff(u,Y)) / area of docs/ufunc_examples.md
  *                      (one fused pass instead of three apply_ufunc passes, grid.py:798-800 TODO)
@@ -188,6 +189,20 @@ int xg_divergence_f64(const double* u, const double* v, const double* area,
                      const int64_t* area_strides, double* out, const int64_t* shape, int ndim,
                      int bc_x, double fill_x, int bc_y, double fill_y, void* stream);
 
+/* ---- fused gradient and advective flux (docs/ufunc_examples.md "Gradient", "Advection") ------ */
+/* One centre field in, two staggered fields out (both center -> left, padding_width (1,0) on X and Y):
+ *   gradient: out_x = (a[j,i] - a[j,i-1]) / mx,   out_y = (a[j,i] - a[j-1,i]) / my   (mx / my optional metrics
+ *             at the output positions, broadcast strides; NULL = plain differences)
+ *   flux:     out_x = u * (t[j,i-1] + t[j,i]) / 2, out_y = v * (t[j-1,i] + t[j,i]) / 2
+ * bit-identical to the operator chains (diff / derivative, interp then multiply), the field read once. */
+int xg_gradient_f64(const double* a, double* out_x, double* out_y, const int64_t* shape, int ndim,
+                    int bc_x, double fill_x, int bc_y, double fill_y, const double* mx,
+                    const int64_t* mx_strides, const double* my, const int64_t* my_strides,
+                    void* stream);
+int xg_flux_f64(const double* u, const double* v, const double* t, double* out_x, double* out_y,
+                const int64_t* shape, int ndim, int bc_x, double fill_x, int bc_y, double fill_y,
+                void* stream);
+
 /* The two fused operators on a complex topology (face connections, north fold): an axis whose
  * boundary mode is XG_BC_HALO takes its one-cell halo from a pre-gathered slab (xg_gather_f64 over
  * the halo cells, vector-component rules included) instead of the array itself:
@@ -261,6 +276,12 @@ int xg_vorticity_f32(const float* u, const float* v, const float* area,
 int xg_divergence_f32(const float* u, const float* v, const float* area,
                      const int64_t* area_strides, float* out, const int64_t* shape, int ndim,
                      int bc_x, float fill_x, int bc_y, float fill_y, void* stream);
+int xg_gradient_f32(const float* a, float* out_x, float* out_y, const int64_t* shape, int ndim,
+                    int bc_x, float fill_x, int bc_y, float fill_y, const float* mx,
+                    const int64_t* mx_strides, const float* my, const int64_t* my_strides, void* stream);
+int xg_flux_f32(const float* u, const float* v, const float* t, float* out_x, float* out_y,
+                const int64_t* shape, int ndim, int bc_x, float fill_x, int bc_y, float fill_y,
+                void* stream);
 int xg_vorticity_halo_f32(const float* u, const float* v, const float* halo_x, const float* halo_y,
                           const float* area, const int64_t* area_strides, float* out,
                           const int64_t* shape, int ndim, int bc_x, float fill_x, int bc_y,

@@ -138,6 +138,16 @@ def divergence(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0, halo_x=None, halo
     return (dudx + dvdy) / area
 
 
+def gradient(a, bc_x, bc_y, fill_x=0.0, fill_y=0.0, mx=None, my=None):
+    a, mx, my = _cast(_common(a, mx, my), a, mx, my)
+    return R.gradient(a, bc_x, bc_y, fill_x, fill_y, mx, my)
+
+
+def flux(u, v, t, bc_x, bc_y, fill_x=0.0, fill_y=0.0):
+    u, v, t = _cast(_common(u, v, t), u, v, t)
+    return R.flux(u, v, t, bc_x, bc_y, fill_x, fill_y)
+
+
 def stencil2d_supported(x, padx, pady):
     x = np.asarray(x)
     lane = 4 if x.dtype == np.float32 else 2
@@ -159,7 +169,7 @@ def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None, dtype=np.f
 
 
 _NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "stencil1d_halo", "cumsum1d", "reduce1d", "pad_nd", "gather", "upload_tokens", "transform_linear", "transform_conservative", "binary",
-          "vorticity", "divergence", "stencil2d", "stencil2d_supported", "synthetic"]
+          "vorticity", "divergence", "gradient", "flux", "stencil2d", "stencil2d_supported", "synthetic"]
 
 
 def install(monkeypatch):

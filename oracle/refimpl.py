@@ -272,6 +272,22 @@ def divergence(u, v, area, padding_x, padding_y, fill_x=0.0, fill_y=0.0):
     return (dudx + dvdy) / area
 
 
+def gradient(a, padding_x, padding_y, fill_x=0.0, fill_y=0.0, mx=None, my=None):
+    """`(diff(a,'X') / mx, diff(a,'Y') / my)` on a (..., Y, X) array, both center->left
+    (docs/ufunc_examples.md "Gradient"; with metrics: two `Grid.derivative` calls, grid.py:1465-1468)."""
+    gx = stencil1d("diff", a, a.ndim - 1, 1, 0, padding_x, fill_x)
+    gy = stencil1d("diff", a, a.ndim - 2, 1, 0, padding_y, fill_y)
+    return (gx if mx is None else gx / mx), (gy if my is None else gy / my)
+
+
+def flux(u, v, t, padding_x, padding_y, fill_x=0.0, fill_y=0.0):
+    """`(u * interp(t,'X'), v * interp(t,'Y'))` on (..., Y, X) arrays, both interps center->left
+    (docs/ufunc_examples.md "Advection": first-order advective flux of a tracer)."""
+    tx = stencil1d("interp", t, t.ndim - 1, 1, 0, padding_x, fill_x)
+    ty = stencil1d("interp", t, t.ndim - 2, 1, 0, padding_y, fill_y)
+    return u * tx, v * ty
+
+
 # --------------------------------------------------------------------------------------
 # synthetic C-grid fields, bit-identical on host and device (SURVEY.md section 8(d))
 # --------------------------------------------------------------------------------------

@@ -135,3 +135,9 @@ def test_fuzz_two_axis_and_vorticity(dev, seed, dtype):
         exp = R.divergence(a, b, area if area is not None else np.ones((1,) * nd, dtype=dtype), bcx, bcy, dtype(0.25), dtype(-0.5))
         got = dev.tohost(dev.divergence(a, b, area, bcx, bcy, 0.25, -0.5))
         assert np.array_equal(got, exp), (shape, "divergence", bcx, bcy, area is not None)
+        ex, ey = R.gradient(a, bcx, bcy, dtype(0.25), dtype(-0.5), area, None)
+        gx, gy = dev.gradient(a, bcx, bcy, 0.25, -0.5, area, None)
+        assert np.array_equal(dev.tohost(gx), ex, equal_nan=True) and np.array_equal(dev.tohost(gy), ey, equal_nan=True), (shape, "gradient", bcx, bcy)
+        ex, ey = R.flux(a, b, b, bcx, bcy, dtype(0.25), dtype(-0.5))
+        fx, fy = dev.flux(a, b, b, bcx, bcy, 0.25, -0.5)
+        assert np.array_equal(dev.tohost(fx), ex, equal_nan=True) and np.array_equal(dev.tohost(fy), ey, equal_nan=True), (shape, "flux", bcx, bcy)

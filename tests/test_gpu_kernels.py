@@ -278,6 +278,41 @@ def test_vorticity_fused_equals_unfused_chain(dev, shape):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(3, 9, 64), (2, 70, 33), (5, 6), (2, 2, 130, 258), (4, 1, 2), (3, 5, 4), (1, 1), (2, 3, 1)])
+def test_gradient_and_flux_fused_equal_unfused_chains(dev, shape, dtype):
+    a = _field(shape, 60).astype(dtype)
+    u = _field(shape, 61).astype(dtype)
+    v = _field(shape, 62).astype(dtype)
+    mx = R.synthetic_metric((1,) * (len(shape) - 2) + shape[-2:], 63).astype(dtype)
+    my = R.synthetic_metric(shape, 64).astype(dtype)
+    for bc_x, bc_y in itertools.product(("periodic", "fill", "extend"), repeat=2):
+        for m1, m2 in ((None, None), (mx, my), (my, None), (None, mx)):
+            ex, ey = R.gradient(a, bc_x, bc_y, dtype(0.25), dtype(-0.5), m1, m2)
+            gx, gy = dev.gradient(a, bc_x, bc_y, 0.25, -0.5, m1, m2)
+            _eq(dev.tohost(gx), ex)
+            _eq(dev.tohost(gy), ey)
+        ex, ey = R.flux(u, v, a, bc_x, bc_y, dtype(0.25), dtype(-0.5))
+        fx, fy = dev.flux(u, v, a, bc_x, bc_y, 0.25, -0.5)
+        _eq(dev.tohost(fx), ex)
+        _eq(dev.tohost(fy), ey)
+    # the chain through the product's own 1-D kernels gives the same bits
+    gx, gy = dev.gradient(a, "periodic", "extend")
+    _eq(dev.tohost(gx), dev.tohost(dev.stencil1d("diff", a, len(shape) - 1, 1, 0, "periodic")))
+    _eq(dev.tohost(gy), dev.tohost(dev.stencil1d("diff", a, len(shape) - 2, 1, 0, "extend")))
+
+
+def test_gradient_metric_broadcast_patterns(dev):
+    shape = (3, 2, 6, 8)
+    a = _field(shape, 70)
+    for mshape in ((1, 1, 6, 8), (3, 1, 6, 8), (1, 2, 6, 8), (3, 2, 1, 8), (3, 2, 6, 1), (1, 1, 1, 1)):
+        m = R.synthetic_metric(mshape, 71)
+        ex, ey = R.gradient(a, "fill", "periodic", 0.5, 0.0, m, m)
+        gx, gy = dev.gradient(a, "fill", "periodic", 0.5, 0.0, m, m)
+        _eq(dev.tohost(gx), ex)
+        _eq(dev.tohost(gy), ey)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", [(3, 9, 64), (2, 70, 33), (5, 6), (2, 2, 130, 258), (4, 1, 2), (3, 5, 4)])
 def test_divergence_fused_equals_unfused_chain(dev, shape, dtype):
     u = _field(shape, 61).astype(dtype)

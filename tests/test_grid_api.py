@@ -689,6 +689,59 @@ def test_fused_divergence_equals_operator_chain(backend):
         grid.divergence(ds["V"], ds["U"])
 
 
+def test_fused_gradient_and_flux_equal_operator_chains(backend):
+    """docs/ufunc_examples.md "Gradient" and "Advection": one centre field in, two staggered fields out."""
+    nz, ny, nx = 3, 6, 8
+    coords = {"XC": ("XC", np.arange(nx) + 0.5), "XG": ("XG", np.arange(nx) * 1.0),
+              "YC": ("YC", np.arange(ny) + 0.5), "YG": ("YG", np.arange(ny) * 1.0), "Z": ("Z", np.arange(nz) * 1.0)}
+    ds = Dataset({"T": (("Z", "YC", "XC"), R.synthetic_field((nz, ny, nx), 60)),
+                  "U": (("Z", "YC", "XG"), R.synthetic_field((nz, ny, nx), 61)),
+                  "V": (("Z", "YG", "XC"), R.synthetic_field((nz, ny, nx), 62)),
+                  "dxC": (("YC", "XG"), R.synthetic_metric((ny, nx), 63)),
+                  "dyC": (("YG", "XC"), R.synthetic_metric((ny, nx), 64))}, coords)
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}},
+                metrics={("X",): ["dxC"], ("Y",): ["dyC"]}, padding={"X": "periodic", "Y": "extend"},
+                autoparse_metadata=False)
+    gx, gy = grid.gradient(ds["T"])
+    assert gx.dims == ("Z", "YC", "XG") and gy.dims == ("Z", "YG", "XC")
+    assert np.array_equal(_np(gx), _np(grid.diff(ds["T"], "X")))
+    assert np.array_equal(_np(gy), _np(grid.diff(ds["T"], "Y")))
+    gx, gy = grid.gradient(ds["T"], metric_weighted=True, padding={"Y": "fill"}, fill_value={"Y": 2.5})
+    assert np.array_equal(_np(gx), _np(grid.derivative(ds["T"], "X")))
+    assert np.array_equal(_np(gy), _np(grid.derivative(ds["T"], "Y", padding="fill", fill_value=2.5)))
+    ex, ey = R.gradient(ds["T"].values, "periodic", "fill", 0.0, 2.5, ds["dxC"].values[None], ds["dyC"].values[None])
+    assert np.array_equal(_np(gx), ex) and np.array_equal(_np(gy), ey)
+
+    # the user-ufunc form of the docs (pad (1,0) on both axes, trimmed differences) gives the same bits
+    def gradient(a):
+        return a[..., 1:, 1:] - a[..., 1:, :-1], a[..., 1:, 1:] - a[..., :-1, 1:]
+
+    rx, ry = grid.apply_as_grid_ufunc(gradient, ds["T"], axis=[("Y", "X")],
+                                      signature="(Y:center,X:center)->(Y:center,X:left),(Y:left,X:center)",
+                                      padding_width={"X": (1, 0), "Y": (1, 0)})
+    gx, gy = grid.gradient(ds["T"])
+    assert np.array_equal(_np(gx), _np(rx)) and np.array_equal(_np(gy), _np(ry))
+
+    fx, fy = grid.flux(ds["U"], ds["V"], ds["T"])
+    assert fx.dims == ("Z", "YC", "XG") and fy.dims == ("Z", "YG", "XC")
+    assert np.array_equal(_np(fx), _np(ds["U"] * grid.interp(ds["T"], "X")))
+    assert np.array_equal(_np(fy), _np(ds["V"] * grid.interp(ds["T"], "Y")))
+    ex, ey = R.flux(ds["U"].values, ds["V"].values, ds["T"].values, "periodic", "extend")
+    assert np.array_equal(_np(fx), ex) and np.array_equal(_np(fy), ey)
+    # the advect() step of the docs: T - dt * div(flux)
+    adv = ds["T"] - 3.0 * grid.divergence(fx, fy, metric_weighted=False)
+    ref = ds["T"].values - 3.0 * R.divergence(ex, ey, np.ones((1, 1, 1)), "periodic", "extend")
+    assert np.array_equal(_np(adv), ref)
+    # (X, Y)-ordered dims: the two operator calls run instead, same labelled result
+    tt = ds["T"].transpose("Z", "XC", "YC")
+    gx2, gy2 = grid.gradient(tt)
+    assert np.array_equal(_np(gx2.transpose("Z", "YC", "XG")), _np(gx))
+    with pytest.raises(NotImplementedError, match="center"):
+        grid.gradient(ds["U"])
+    with pytest.raises(NotImplementedError, match="tracer"):
+        grid.flux(ds["U"], ds["V"], ds["U"])
+
+
 def test_grid_constructor_errors(backend):
     ds, coords, metrics = cgrid()
     with pytest.raises(ValueError, match="`periodic` argument has been removed"):

@@ -305,6 +305,17 @@ def main():
         rec(5, "divergence fused diff(u,X)+diff(v,Y) (f1, docs/ufunc_examples.md), fill", timeit(lambda: grid_div.divergence(U, V, metric_weighted=False), a.reps), c5, 24)
         okd = bool(torch.equal(grid_div.divergence(U, V, metric_weighted=False).data, (grid_div.diff(U, "X") + grid_div.diff(V, "Y")).data))
         print(json.dumps({"config": 5, "check": "fused divergence == operator chain bit for bit at full size", "ok": okd}), flush=True)
+        T5 = DataArray(D.synthetic((nz5, n5, n5), 53), ("Z", "YC", "XC"))
+        rec(5, "gradient fused (diff(T,X), diff(T,Y)) (f1), fill: 1 read + 2 writes", timeit(lambda: grid_div.gradient(T5), a.reps), c5, 24)
+        rec(5, "gradient as two diff calls, fused-equivalent bytes", timeit(lambda: (grid_div.diff(T5, "X"), grid_div.diff(T5, "Y")), a.reps), c5, 24)
+        gx, gy = grid_div.gradient(T5)
+        okg = bool(torch.equal(gx.data, grid_div.diff(T5, "X").data) and torch.equal(gy.data, grid_div.diff(T5, "Y").data))
+        del gx, gy
+        rec(5, "flux fused (u*interp(T,X), v*interp(T,Y)) (f1), fill: 3 reads + 2 writes", timeit(lambda: grid_div.flux(U, V, T5), a.reps), c5, 40)
+        rec(5, "flux as operator chain (4 kernels), fused-equivalent bytes", timeit(lambda: (U * grid_div.interp(T5, "X"), V * grid_div.interp(T5, "Y")), max(3, a.reps // 2)), c5, 40)
+        fx, fy = grid_div.flux(U, V, T5)
+        okf = bool(torch.equal(fx.data, (U * grid_div.interp(T5, "X")).data) and torch.equal(fy.data, (V * grid_div.interp(T5, "Y")).data))
+        print(json.dumps({"config": 5, "check": "fused gradient / flux == operator chains bit for bit at full size", "ok": okg and okf}), flush=True)
 
 
 if __name__ == "__main__":

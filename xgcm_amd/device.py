@@ -459,12 +459,48 @@ def divergence(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: fl
                              _hip.BC[bc_y], float(fill_y), _stream())
     )
     return out
+
+
+def gradient(a, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0, mx=None, my=None):
+    """Fused (a - a[x-1]) / mx and (a - a[y-1]) / my on a (..., Y, X) array, both center -> left
+    (xg_gradient_f64); `mx` / `my` None = plain differences.  Returns (out_x, out_y)."""
+    lib = _hip.load()
+    dt, sfx = _common(a, mx, my)
+    a = asdevice(a, dt)
+    shape = list(a.shape)
+    mx, my = _prep_metric(mx, dt), _prep_metric(my, dt)
+    out_x = torch.empty(shape, dtype=dt, device=a.device)
+    out_y = torch.empty(shape, dtype=dt, device=a.device)
+    if a.numel() == 0:
+        return out_x, out_y
     _hip.check(
-        getattr(lib, "xg_divergence_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
-                              out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
-                              _hip.BC[bc_y], float(fill_y), _stream())
+        getattr(lib, "xg_gradient_" + sfx)(a.data_ptr(), out_x.data_ptr(), out_y.data_ptr(), _hip.i64(shape), len(shape),
+                                           _hip.BC[bc_x], float(fill_x), _hip.BC[bc_y], float(fill_y), _ptr(mx),
+                                           _hip.i64(_bstrides(mx, shape, "mx")), _ptr(my),
+                                           _hip.i64(_bstrides(my, shape, "my")), _stream())
     )
-    return out
+    return out_x, out_y
+
+
+def flux(u, v, t, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0):
+    """Fused u * (t[x-1] + t) / 2 and v * (t[y-1] + t) / 2 on (..., Y, X) arrays (xg_flux_f64); the
+    boundary modes pad the TRACER.  Returns (flux_x, flux_y)."""
+    lib = _hip.load()
+    dt, sfx = _common(u, v, t)
+    u, v, t = asdevice(u, dt), asdevice(v, dt), asdevice(t, dt)
+    if u.shape != t.shape or v.shape != t.shape:
+        raise ValueError("flux: u, v and t must have the same shape")
+    shape = list(t.shape)
+    out_x = torch.empty(shape, dtype=dt, device=t.device)
+    out_y = torch.empty(shape, dtype=dt, device=t.device)
+    if t.numel() == 0:
+        return out_x, out_y
+    _hip.check(
+        getattr(lib, "xg_flux_" + sfx)(u.data_ptr(), v.data_ptr(), t.data_ptr(), out_x.data_ptr(), out_y.data_ptr(),
+                                       _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x), _hip.BC[bc_y],
+                                       float(fill_y), _stream())
+    )
+    return out_x, out_y
 
 
 def stencil2d_supported(x, padx, pady) -> bool:
