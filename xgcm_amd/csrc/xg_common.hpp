@@ -1,0 +1,479 @@
+// xg_common.hpp -- shared device / host helpers of the xgcm_amd HIP library (included by every xg_*.hip).
+//
+// Design (see DESIGN.md section 3 for the measurements behind each rule): every op is HBM-bound
+// (<= 3 flop per 16 B), so
+//  (1) every cell is read once and written once: the boundary halo (periodic / fill / extend) is
+//      index arithmetic inside the kernel, never a padded copy; metric multiply / divide ride along;
+//  (2) lanes run along the contiguous (last) dimension with 16-byte accesses whatever the op axis
+//      is, ONE vector per lane, thread id == linear memory order (a copy written this way streams
+//      at 80 % of the 8 TB/s spec; 2-8 tiles per thread or grid-stride loops lose 10-35 %);
+//  (3) the set of rows in flight stays compact: along a strided axis a wave register-marches only
+//      4 rows (whole columns only when a row is a whole plane, i.e. the Z axis);
+//  (4) workgroup b runs on XCD b % 8, each XCD has its own L2: the linear work sequence is cut into
+//      8 contiguous bands, one per XCD, so halo-row re-reads and broadcast metrics hit that XCD's
+//      L2 ("banding", "z-banding") -- speed only, never correctness;
+//  (5) per-item index math is 32-bit with multiply-shift division (FastDiv) and wave-uniform parts
+//      on the scalar unit; launches are split on the host so item counts stay below 2^31.
+// No MFMA, no LDS tiling of the field (nothing is reused), LDS only for cross-wave scan carries.
+//
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off (bitwise parity with numpy forbids
+// FMA contraction of a*m - b*m and reciprocal-based division).
+
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/xgcm_hip.h"
+
+// The file is compiled twice into the same shared library: once with real = double (exports *_f64
+// plus the type-independent helpers) and once with -DXG_F32 (real = float, exports *_f32 only).
+#ifdef XG_F32
+typedef float real;
+#define XG_FN(name) name##_f32
+#else
+typedef double real;
+#define XG_FN(name) name##_f64
+#define XG_PRIMARY 1
+#endif
+
+// thread-local error text shared by every translation unit (hidden: not part of the ABI); defined
+// once, in xg_runtime.hip
+#define XG_ERRBUF_LEN 512
+extern "C" __attribute__((visibility("hidden"))) char* xg_internal_errbuf(void);
+
+namespace {
+
+constexpr int NV = 16 / (int)sizeof(real);             // elements of a 16-byte lane vector: 2 (f64) / 4 (f32)
+typedef real dv __attribute__((ext_vector_type(NV)));  // THE lane vector: every fast path moves 16 B per lane
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+constexpr int MAXD = 4;    // coalesced dims on either side of the op axis
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256; // 4 waves; each wave owns one wave-task
+constexpr int WPB = BLOCK / WAVE;
+
+// ------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(xg_internal_errbuf(), XG_ERRBUF_LEN, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define XG_HIP(call)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail(XG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),     \
+                  __FILE__, __LINE__);                                                   \
+  } while (0)
+
+int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+// tunables (read once; override with env vars for on-device tuning sessions)
+struct Tune {
+  int seg;       // rows marched per wave-task along a strided stencil axis
+  int nt_store;  // non-temporal stores (+2-4 %; non-temporal LOADS measured -1 % and are not used)
+  int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
+  int scan_narrow_below; // marching scans with fewer wave-tasks than this use one element per lane
+  int pad_rows;          // row-wise generic pad (wave-uniform row logic); 0: one thread per cell
+  int transform_lds_kb;  // LDS budget of the cell-major conservative kernel (0: always the register-tile kernel)
+  int transform_fast;  // streaming path of the linear transform for well-formed columns (0: always the exact search)
+  int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
+  int zband;          // band-major row order when all metrics are broadcast along the slowest dim
+  int scan_vec;       // aligned-output-group scan for cumsum along the contiguous axis
+  int contig_gen;     // pair-wise general path for odd / length-changing rows on the contiguous axis
+  int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
+  int march_lds_kb;   // optional dynamic LDS request for the column-marching kernels, only to cap residency
+                      // (experiment: +8 % on a bare march in tools/streambench.hip, but -20 % on the real
+                      // kernels whose index/metric math then has too few waves to hide behind) => default 0
+  Tune() {
+    march_lds_kb = env_int("XG_MARCH_LDS_KB", 0);
+    contig_gen = env_int("XG_CONTIG_GEN", 1);
+    scan_vec = env_int("XG_SCAN_VEC", 1);
+    deep_waves = env_int("XG_DEEP_WAVES", 8192);  // neutral on its own, pays together with scan_narrow_below
+    zband = env_int("XG_ZBAND", 1);
+    zchunk = env_int("XG_ZCHUNK", 256);
+    transform_fast = env_int("XG_TRANSFORM_FAST", 1);
+    pad_rows = env_int("XG_PAD_ROWS", 1);
+    scan_narrow_below = env_int("XG_SCAN_NARROW_BELOW", 8192);
+    transform_lds_kb = env_int("XG_TRANSFORM_LDS_KB", 64);
+    seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
+    seg = env_int("XG_SEG", 1 << 30);  // long march: whole column by default
+    nt_store = env_int("XG_NT_STORE", 1);
+  }
+};
+const Tune& tune() {
+  static Tune t;
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------
+// geometry: a C-contiguous N-D array seen as (outer..., n, inner...) around the op axis,
+// with adjacent dims coalesced whenever every metric's strides allow it.
+// ------------------------------------------------------------------------------------------
+// Exact u32 division by a launch-time constant without a divide instruction (Granlund-Montgomery
+// round-up method): q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(n, m).  On wave-uniform
+// operands the compiler keeps all of it on the scalar unit (s_mul_hi_u32).
+struct FastDiv {
+  u32 d, m, s1, s2;
+};
+inline FastDiv make_fastdiv(u64 d64) {
+  FastDiv f = {1u, 1u, 0u, 0u};
+  if (d64 < 1) d64 = 1;
+  if (d64 > 0xffffffffull) d64 = 0xffffffffull;  // callers check idx32 before relying on it
+  const u32 d = (u32)d64;
+  u32 l = 0;
+  while ((1ull << l) < (u64)d) ++l;
+  f.d = d;
+  f.m = (u32)((((1ull << 32) * ((1ull << l) - (u64)d)) / (u64)d) + 1ull);
+  f.s1 = l < 1 ? l : 1;
+  f.s2 = l > 1 ? l - 1 : 0;
+  return f;
+}
+__device__ __forceinline__ u32 fdiv(u32 n, const FastDiv& f) {
+  const u32 t = __umulhi(n, f.m);
+  return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+
+// "z-banding": when every metric of a launch is broadcast along the slowest outer dim (a 2-D
+// dx(Y,X) weighting a (Z,Y,X) field), rows are visited band by band -- all Z levels of a band of
+// B rows before the next band -- so the band's metric values are fetched once and then served by
+// the XCD's L2 for the other Z-1 levels instead of being re-read from the Infinity Cache per level.
+struct ZBand {
+  u32 on, Z, B, Y;       // Y = rows (or segments) per level, B = rows (segments) per band
+  FastDiv per_band, fB;  // divisors Z*B and B
+};
+inline ZBand make_zband(bool on, u64 Z, u64 Y, u32 B) {
+  ZBand z;
+  memset(&z, 0, sizeof(z));
+  z.per_band = make_fastdiv(1);
+  z.fB = make_fastdiv(1);
+  if (!on || Z < 2 || Z * (u64)B > 0x7fffffffull) return z;
+  z.on = 1; z.Z = (u32)Z; z.B = B; z.Y = (u32)Y;
+  z.per_band = make_fastdiv(Z * B);
+  z.fB = make_fastdiv(B);
+  return z;
+}
+// work index r (band-major) -> (z, y); false if the band's tail row does not exist
+__device__ __forceinline__ bool zband_map(const ZBand& zb, u32 r, u32& z, u32& y) {
+  const u32 b = fdiv(r, zb.per_band);
+  const u32 rem = r - b * zb.per_band.d;
+  z = fdiv(rem, zb.fB);
+  y = b * zb.B + (rem - z * zb.B);
+  return y < zb.Y;
+}
+
+// Column chunking for the short-segment kernel when a "row" of the strided axis is a whole plane
+// (Z of a (Z,Y,X) field): the x-tiles of a row are cut into chunks of `ch` tiles and the waves
+// are ordered (outer, chunk, segment, tile in chunk), so the halo row a segment re-reads was
+// loaded `ch` waves earlier by the same XCD (L2 hit) instead of a whole plane earlier (HBM).
+struct Chunk {
+  u32 on, nchunk;
+  FastDiv ch, per_group, fnchunk;  // divisors: tiles per chunk, nseg * ch, chunks per row
+};
+inline Chunk make_chunk(u64 ntile, u64 nseg, u32 ch) {
+  Chunk c;
+  memset(&c, 0, sizeof(c));
+  c.ch = c.per_group = c.fnchunk = make_fastdiv(1);
+  if (ch == 0 || ntile <= ch) return c;
+  c.on = 1;
+  c.nchunk = (u32)((ntile + ch - 1) / ch);
+  c.ch = make_fastdiv(ch);
+  c.per_group = make_fastdiv(nseg * ch);
+  c.fnchunk = make_fastdiv(c.nchunk);
+  return c;
+}
+
+struct MIdx {  // element strides of one metric in the coalesced coordinate system
+  int64_t outer[MAXD];
+  int64_t axis;
+  int64_t inner[MAXD];
+};
+
+struct Geo {
+  int n_outer, n_inner;
+  int64_t outer_shape[MAXD];
+  int64_t inner_shape[MAXD];
+  int64_t outer;  // prod(outer_shape)
+  int64_t inner;  // prod(inner_shape)
+  int64_t n_in, n_out;
+  int idx32;      // outer, inner, n_in, n_out all < 2^32: u32 index math + FastDiv allowed
+  FastDiv outer_fd[MAXD], inner_fd[MAXD];
+};
+
+// Build Geo (+ up to two MIdx) from the public (shape, ndim, axis, strides) description.
+// strides arrays may be NULL (metric absent).  Size-1 dims are dropped, mergeable neighbours
+// merged.  Returns 0 or an error.
+int build_geo(const int64_t* shape, int ndim, int axis, int64_t n_out, const int64_t* s1,
+              const int64_t* s2, Geo* g, MIdx* m1, MIdx* m2) {
+  if (ndim < 1 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [1,%d]", ndim, XG_MAX_NDIM);
+  if (axis < 0 || axis >= ndim) return fail(XG_ERR_INVALID, "axis %d out of range for ndim %d", axis, ndim);
+  for (int d = 0; d < ndim; ++d)
+    if (shape[d] < 0) return fail(XG_ERR_INVALID, "negative extent");
+  memset(g, 0, sizeof(*g));
+  if (m1) memset(m1, 0, sizeof(*m1));
+  if (m2) memset(m2, 0, sizeof(*m2));
+  g->n_in = shape[axis];
+  g->n_out = n_out;
+  g->outer = 1;
+  g->inner = 1;
+  if (s1 && m1) m1->axis = s1[axis];
+  if (s2 && m2) m2->axis = s2[axis];
+
+  auto group = [&](int lo, int hi, int64_t* gshape, int64_t* st1, int64_t* st2, int* count,
+                   int64_t* prod) -> int {
+    int n = 0;
+    for (int d = lo; d < hi; ++d) {
+      if (shape[d] == 1) continue;
+      int64_t a = s1 ? s1[d] : 0, b = s2 ? s2[d] : 0;
+      if (n > 0) {
+        // previous (slower) dim merges with this one iff stride_prev == stride_this * extent_this
+        bool ok = (st1[n - 1] == a * shape[d]) && (st2[n - 1] == b * shape[d]);
+        if (ok) {
+          gshape[n - 1] *= shape[d];
+          st1[n - 1] = a;
+          st2[n - 1] = b;
+          continue;
+        }
+      }
+      if (n == MAXD) return fail(XG_ERR_UNSUPPORTED, "more than %d non-coalescable dims on one side of the axis", MAXD);
+      gshape[n] = shape[d];
+      st1[n] = a;
+      st2[n] = b;
+      ++n;
+    }
+    *count = n;
+    *prod = 1;
+    for (int i = 0; i < n; ++i) *prod *= gshape[i];
+    for (int d = lo; d < hi; ++d)
+      if (shape[d] == 0) *prod = 0;
+    return 0;
+  };
+  int64_t o1[MAXD] = {0}, o2[MAXD] = {0}, i1[MAXD] = {0}, i2[MAXD] = {0};
+  int rc = group(0, axis, g->outer_shape, o1, o2, &g->n_outer, &g->outer);
+  if (rc) return rc;
+  rc = group(axis + 1, ndim, g->inner_shape, i1, i2, &g->n_inner, &g->inner);
+  if (rc) return rc;
+  for (int i = 0; i < MAXD; ++i) {
+    if (m1) { m1->outer[i] = o1[i]; m1->inner[i] = i1[i]; }
+    if (m2) { m2->outer[i] = o2[i]; m2->inner[i] = i2[i]; }
+    g->outer_fd[i] = make_fastdiv(i < g->n_outer ? (u64)g->outer_shape[i] : 1);
+    g->inner_fd[i] = make_fastdiv(i < g->n_inner ? (u64)g->inner_shape[i] : 1);
+  }
+  const int64_t lim = 0xffffffffll;
+  g->idx32 = (g->outer <= lim && g->inner <= lim && g->n_in <= lim && g->n_out <= lim) ? 1 : 0;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+template <int V> struct VecT;
+template <> struct VecT<1> { typedef real type; };
+template <> struct VecT<NV> { typedef dv type; };
+
+template <typename T, bool NT>
+__device__ __forceinline__ T ldg(const real* p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const T*>(p));
+  return *reinterpret_cast<const T*>(p);
+}
+template <typename T, bool NT>
+__device__ __forceinline__ void stg(real* p, T v) {
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
+  else *reinterpret_cast<T*>(p) = v;
+}
+
+// x-difference of a V-wide lane given the value just left of it
+__device__ __forceinline__ dv dvdx_of(dv vc, real vl) {
+  dv o;
+  o[0] = vc[0] - vl;
+#pragma unroll
+  for (int k = 1; k < NV; ++k) o[k] = vc[k] - vc[k - 1];
+  return o;
+}
+__device__ __forceinline__ real dvdx_of(real vc, real vl) { return vc - vl; }
+// two-point interpolation of a lane vector towards its LEFT neighbour `tl`: (t[k-1] + t[k]) / 2
+__device__ __forceinline__ dv interp_left_of(dv tc, real tl) {
+  dv o;
+  o[0] = (tl + tc[0]) * real(0.5);
+#pragma unroll
+  for (int k = 1; k < NV; ++k) o[k] = (tc[k - 1] + tc[k]) * real(0.5);
+  return o;
+}
+__device__ __forceinline__ real interp_left_of(real tc, real tl) { return (tl + tc) * real(0.5); }
+// forward difference of a lane vector whose RIGHT neighbour is `ur`: (u[k+1] - u[k])
+__device__ __forceinline__ dv dudx_fwd(dv uc, real ur) {
+  dv o;
+#pragma unroll
+  for (int k = 0; k < NV - 1; ++k) o[k] = uc[k + 1] - uc[k];
+  o[NV - 1] = ur - uc[NV - 1];
+  return o;
+}
+__device__ __forceinline__ real dudx_fwd(real uc, real ur) { return ur - uc; }
+
+// two-point bodies; l = a[..., i], r = a[..., i+1] of the padded array (gridops.py:23-24,76-77,123-175)
+template <int OP>
+__device__ __forceinline__ real op2(real l, real r) {
+  if (OP == XG_OP_DIFF) return r - l;
+  if (OP == XG_OP_INTERP) return (l + r) * real(0.5);  // == (l + r) / 2.0 bit for bit
+  if (OP == XG_OP_MIN) return (l < r || l != l) ? l : r;  // NaN-propagating like np.min
+  return (l > r || l != l) ? l : r;
+}
+template <int OP> __device__ __forceinline__ dv op2(dv l, dv r) {
+  dv o;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) o[k] = op2<OP>(l[k], r[k]);
+  return o;
+}
+
+__device__ __forceinline__ real splat1(real f, real*) { return f; }
+__device__ __forceinline__ dv splat1(real f, dv*) {
+  dv o;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) o[k] = f;
+  return o;
+}
+template <typename T> __device__ __forceinline__ T splat(real f) { return splat1(f, (T*)nullptr); }
+
+// offset of flat outer index `o` in a metric (unrolled so Geo/MIdx stay in SGPRs)
+__device__ __forceinline__ int64_t outer_off(const Geo& g, const MIdx& m, int64_t o) {
+  int64_t off = 0;
+#pragma unroll
+  for (int d = MAXD - 1; d >= 0; --d) {
+    if (d < g.n_outer) {
+      int64_t s = g.outer_shape[d];
+      int64_t q = o / s;
+      off += (o - q * s) * m.outer[d];
+      o = q;
+    }
+  }
+  return off;
+}
+__device__ __forceinline__ int64_t inner_off(const Geo& g, const MIdx& m, int64_t x) {
+  int64_t off = 0;
+#pragma unroll
+  for (int d = MAXD - 1; d >= 0; --d) {
+    if (d < g.n_inner) {
+      int64_t s = g.inner_shape[d];
+      int64_t q = x / s;
+      off += (x - q * s) * m.inner[d];
+      x = q;
+    }
+  }
+  return off;
+}
+
+// u32 variants (valid when g.idx32): no divide instructions
+__device__ __forceinline__ int64_t outer_off32(const Geo& g, const MIdx& m, u32 o) {
+  int64_t off = 0;
+#pragma unroll
+  for (int d = MAXD - 1; d >= 0; --d) {
+    if (d < g.n_outer) {
+      const u32 q = fdiv(o, g.outer_fd[d]);
+      off += (int64_t)(o - q * g.outer_fd[d].d) * m.outer[d];
+      o = q;
+    }
+  }
+  return off;
+}
+__device__ __forceinline__ int64_t inner_off32(const Geo& g, const MIdx& m, u32 x) {
+  int64_t off = 0;
+#pragma unroll
+  for (int d = MAXD - 1; d >= 0; --d) {
+    if (d < g.n_inner) {
+      const u32 q = fdiv(x, g.inner_fd[d]);
+      off += (int64_t)(x - q * g.inner_fd[d].d) * m.inner[d];
+      x = q;
+    }
+  }
+  return off;
+}
+// metric offset + lane step along the coalesced inner dims for a V-wide lane starting at inner index x
+// (valid when g.idx32; the single-inner-dim case -- metric varies only along X -- is just a multiply)
+__device__ __forceinline__ void inner_off_step32(const Geo& g, const MIdx& m, u32 x, bool pair, int64_t& off, int64_t& step) {
+  if (g.n_inner == 1) {
+    off = (int64_t)x * m.inner[0];
+    step = m.inner[0];
+    return;
+  }
+  off = inner_off32(g, m, x);
+  step = pair ? inner_off32(g, m, x + 1) - off : 0;
+}
+__device__ __forceinline__ int64_t outer_offx(const Geo& g, const MIdx& m, int64_t o) {
+  return g.idx32 ? outer_off32(g, m, (u32)o) : outer_off(g, m, o);
+}
+__device__ __forceinline__ int64_t inner_offx(const Geo& g, const MIdx& m, int64_t x) {
+  return g.idx32 ? inner_off32(g, m, (u32)x) : inner_off(g, m, x);
+}
+
+// metric value(s) for a V-wide lane at metric offset `off` (second element `step` further on)
+template <typename T> __device__ __forceinline__ T ldm(const real* m, int64_t off, int64_t step);
+template <> __device__ __forceinline__ real ldm<real>(const real* m, int64_t off, int64_t) { return m[off]; }
+template <> __device__ __forceinline__ dv ldm<dv>(const real* m, int64_t off, int64_t step) {
+  // metric contiguous along the lanes and 16-B aligned here: one dwordx4 load instead of NV narrow ones
+  if (step == 1 && (((reinterpret_cast<uintptr_t>(m) / sizeof(real)) + (uintptr_t)off) & (NV - 1)) == 0)
+    return *reinterpret_cast<const dv*>(m + off);
+  dv o;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) o[k] = m[off + k * step];
+  return o;
+}
+
+__device__ __forceinline__ u64 wave_id() {
+  // uniform per wave; readfirstlane keeps the task decomposition on the scalar unit
+  u32 w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  return (u64)blockIdx.x * WPB + w;
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ------------------------------------------------------------------------------------------
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }  // lane vector
+
+inline int check_grid(u64 nblocks) {
+  if (nblocks == 0 || nblocks > 0x7fffffffull) return fail(XG_ERR_UNSUPPORTED, "launch of %llu blocks exceeds grid limits", nblocks);
+  return 0;
+}
+
+#define XG_LAUNCH_CHECK()                                                              \
+  do {                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                 \
+    if (e_ != hipSuccess) return fail(XG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e_)); \
+  } while (0)
+
+inline unsigned march_lds() {
+  int kb = tune().march_lds_kb;
+  if (kb < 0) kb = 0;
+  if (kb > 160) kb = 160;
+  return (unsigned)kb * 1024u;
+}
+
+// dispatch on (OP, V, MET, NT) -> template instance
+
+// linear-order kernels: the host splits the work into launches of < 2^31 items
+constexpr u64 MAX_ITEMS = 0x7fffff00ull;
+
+inline u32 ceil_div_u32(int64_t a, int64_t b) { return (u32)((a + b - 1) / b); }
+inline bool in_stride_inner_is_one(const int64_t* istride, int ndim) { return istride[ndim - 1] == 1; }
+
+// A lane vector of NV elements takes its metric values at a constant step from the first one; that
+// holds when the NV elements share one row of the innermost coalesced dim.  For NV == 2 the step is
+// computed exactly per lane, so only wider vectors (float) need the innermost extent to divide.
+inline bool vec_metric_ok(const Geo& g, bool metrics) {
+  if (!metrics || NV <= 2 || g.n_inner == 0) return true;
+  return g.inner_shape[g.n_inner - 1] % NV == 0;
+}
+
+}  // namespace

@@ -1,0 +1,473 @@
+// xg_scan.hip -- prefix sums (K5, K6, K6v) and weighted reductions (K4, K4b) along one axis
+// Part of libxgcm_hip.so; compiled twice (real = double / -DXG_F32), see xg_common.hpp.
+
+#include "xg_common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// K5: cumsum along a STRIDED axis (one lane = one column pair, sequential => bit-exact with
+// numpy.cumsum / nancumsum), trim/pad table folded into the output index, halo cells written
+// from registers at the end of the march.
+// ------------------------------------------------------------------------------------------
+struct ScanArgs {
+  int reverse, skipna, trim_lo, trim_hi, pad_lo, pad_hi, bc;
+  real fill;
+};
+
+__device__ __forceinline__ real nan0(real v) { return (v != v) ? real(0) : v; }
+__device__ __forceinline__ dv nan0(dv v) {
+  dv o;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) o[k] = nan0(v[k]);
+  return o;
+}
+
+template <int V, int MET, bool NTL, bool NTS, int U>
+__global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+  typedef typename VecT<V>::type T;
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  // U independent loads in flight per lane (the scan chain only consumes them)
+
+  const u64 w = wave_id();
+  const u32 tile = (u32)(w % ntile);
+  const int64_t o = (int64_t)(w / ntile);
+  if (o >= g.outer) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t x = ((int64_t)tile * WAVE + lane) * V;
+  if (x >= g.inner) return;
+  const int64_t inner = g.inner, n = g.n_in;
+  const real* pin = in + (o * n) * inner + x;
+  real* pout = out + (o * g.n_out) * inner + x;
+
+  int64_t mi_base = 0, mo_base = 0, mi_step = 0, mo_step = 0;
+  if (HAS_MI) {
+    mi_base = outer_off(g, mi, o) + inner_off(g, mi, x);
+    mi_step = (V > 1) ? inner_off(g, mi, x + 1) - inner_off(g, mi, x) : 0;
+  }
+  if (HAS_MO) {
+    mo_base = outer_off(g, mo, o) + inner_off(g, mo, x);
+    mo_step = (V > 1) ? inner_off(g, mo, x + 1) - inner_off(g, mo, x) : 0;
+  }
+  auto put = [&](int64_t j, T v) {  // j = output index along the axis
+    if (HAS_MO) v = v / ldm<T>(m_out, mo_base + j * mo.axis, mo_step);
+    stg<T, NTS>(pout + j * inner, v);
+  };
+
+  const int64_t first_kept = a.trim_lo, last_kept = n - 1 - a.trim_hi;  // index space
+  const int64_t shift = a.pad_lo - a.trim_lo;
+  T acc = splat<T>(real(0)), c_first = splat<T>(real(0)), c_last = splat<T>(real(0));
+  bool started = false;
+  auto step = [&](int64_t idx, T v) {
+    if (HAS_MI) v = v * ldm<T>(m_in, mi_base + idx * mi.axis, mi_step);
+    if (a.skipna) v = nan0(v);
+    acc = started ? acc + v : v;
+    started = true;
+    if (idx == first_kept) c_first = acc;
+    if (idx == last_kept) c_last = acc;
+    if (idx >= first_kept && idx <= last_kept) put(idx + shift, acc);
+  };
+  int64_t t = 0;
+  for (; t + U <= n; t += U) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t idx = a.reverse ? n - 1 - (t + u) : t + u;
+      v[u] = ldg<T, NTL>(pin + idx * inner);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(a.reverse ? n - 1 - (t + u) : t + u, v[u]);
+  }
+  for (; t < n; ++t) {
+    int64_t idx = a.reverse ? n - 1 - t : t;
+    step(idx, ldg<T, NTL>(pin + idx * inner));
+  }
+  // halo cells of the padded cumulative result (xgcm/grid.py:1385-1391; numpy.pad semantics)
+  if (a.pad_lo) {
+    T h = (a.bc == XG_BC_FILL) ? splat<T>(a.fill) : (a.bc == XG_BC_PERIODIC ? c_last : c_first);
+    put(0, h);
+  }
+  if (a.pad_hi) {
+    T h = (a.bc == XG_BC_FILL) ? splat<T>(a.fill) : (a.bc == XG_BC_PERIODIC ? c_first : c_last);
+    put(g.n_out - 1, h);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: cumsum along the CONTIGUOUS axis: one workgroup per row, chunks of 256 elements in scan
+// order, wave-level Hillis-Steele scan with cross-lane shuffles, 4 wave totals through LDS,
+// running carry in a register.  Re-associated sum => tolerance parity (not bit-exact).
+// Tried and rejected (measured, 3600-long rows): a 1024-thread workgroup per row with 16-B loads
+// (2 barrier-separated passes leave too little in flight: 3.2 TB/s) and a barrier-free wave per
+// row owning element PAIRS (its two 8-B stores per lane interleave -> half-filled write
+// sectors: 2.8 TB/s).  This one-element-per-lane form keeps every load/store instruction a
+// contiguous 512 B and runs at 4.5-4.7 TB/s.
+// ------------------------------------------------------------------------------------------
+template <int MET>
+__global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, ScanArgs a,
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  __shared__ real wtot[2][WPB];
+  const int64_t row = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t n = g.n_in;
+  const real* prow = in + row * n;
+  real* orow = out + row * g.n_out;
+  int64_t mi_base = 0, mo_base = 0;
+  if (HAS_MI) mi_base = outer_off(g, mi, row);
+  if (HAS_MO) mo_base = outer_off(g, mo, row);
+  const int64_t first_kept = a.trim_lo, last_kept = n - 1 - a.trim_hi;
+  const int64_t shift = a.pad_lo - a.trim_lo;
+  auto put = [&](int64_t j, real v) {
+    if (HAS_MO) v = v / m_out[mo_base + j * mo.axis];
+    orow[j] = v;
+  };
+  auto fetch = [&](int64_t k) -> real {
+    real v = real(0);
+    if (k < n) {
+      const int64_t idx = a.reverse ? n - 1 - k : k;
+      v = prow[idx];
+      if (HAS_MI) v = v * m_in[mi_base + idx * mi.axis];
+      if (a.skipna) v = nan0(v);
+    }
+    return v;
+  };
+  real carry = real(0);
+  int buf = 0;
+  real cur = fetch(tid);
+  for (int64_t base = 0; base < n; base += BLOCK, buf ^= 1) {
+    const int64_t k = base + tid;
+    const int64_t idx = a.reverse ? n - 1 - k : k;
+    const real v = cur;
+    cur = fetch(k + BLOCK);  // next chunk's load is in flight across this chunk's scan + barrier
+    real s = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      real t = __shfl_up(s, d, WAVE);
+      if (lane >= d) s += t;
+    }
+    if (lane == WAVE - 1) wtot[buf][wv] = s;
+    __syncthreads();
+    real woff = real(0), tot = real(0);
+#pragma unroll
+    for (int i = 0; i < WPB; ++i) {
+      real t = wtot[buf][i];
+      if (i < wv) woff += t;
+      tot += t;
+    }
+    const real c = carry + (woff + s);
+    carry += tot;
+    if (k < n) {
+      if (idx >= first_kept && idx <= last_kept) put(idx + shift, c);
+      if (idx == first_kept) {
+        if (a.pad_lo && a.bc == XG_BC_EXTEND) put(0, c);
+        if (a.pad_hi && a.bc == XG_BC_PERIODIC) put(g.n_out - 1, c);
+      }
+      if (idx == last_kept) {
+        if (a.pad_lo && a.bc == XG_BC_PERIODIC) put(0, c);
+        if (a.pad_hi && a.bc == XG_BC_EXTEND) put(g.n_out - 1, c);
+      }
+    }
+  }
+  if (tid == 0 && a.bc == XG_BC_FILL) {
+    if (a.pad_lo) put(0, a.fill);
+    if (a.pad_hi) put(g.n_out - 1, a.fill);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6v: cumsum along the CONTIGUOUS axis when output rows are 16-B aligned (n_out % NV == 0, no
+// periodic halo).  Threads own aligned groups of NV consecutive OUTPUTS (one 16-B store each) and
+// fetch the NV inputs behind them with narrow consecutive loads (input = output index - shift, so
+// it may be misaligned: served by L1, the trick that made K1g fast); a thread scans its group,
+// waves scan the group totals with shuffles, wave totals go through LDS, the running carry stays
+// in a register.  Inputs that map outside the output range (at most one, when the trim is on the
+// side the scan starts from) seed the carry.  Re-associated sum => 1e-12 parity like K6.
+// ------------------------------------------------------------------------------------------
+template <int MET, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_cumsum_contig_vec(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 nrows, ScanArgs a,
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  __shared__ real wtot[2][WPB];
+  const u32 pb = (nrows + 7) >> 3;
+  const u32 row = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);  // XCD banding over rows
+  if (row >= nrows) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t n = g.n_in, no = g.n_out;
+  const real* prow = in + (int64_t)row * n;
+  real* orow = out + (int64_t)row * no;
+  int64_t mi_base = 0, mo_base = 0;
+  if (HAS_MI) mi_base = outer_off(g, mi, row);
+  if (HAS_MO) mo_base = outer_off(g, mo, row);
+  const int64_t shift = a.pad_lo - a.trim_lo;
+  auto fetch = [&](int64_t idx) -> real {  // weighted, NaN-cleaned input or 0 outside the row
+    if (idx < 0 || idx >= n) return real(0);
+    real v = prow[idx];
+    if (HAS_MI) v = v * m_in[mi_base + idx * mi.axis];
+    if (a.skipna) v = nan0(v);
+    return v;
+  };
+  // the one input (if any) that precedes everything in scan order but maps outside [0, no)
+  real carry = real(0);
+  if (!a.reverse && shift < 0) carry = fetch(0);
+  if (a.reverse && (n - 1 + shift) >= no) carry = fetch(n - 1);
+  const int64_t groups = no / NV;
+  int buf = 0;
+  auto group_lo = [&](int64_t t) -> int64_t { return a.reverse ? no - NV * (t + 1) : NV * t; };
+  real xn[NV];  // the next pass's inputs are loaded before this pass's scan and barrier
+#pragma unroll
+  for (int k = 0; k < NV; ++k) xn[k] = (tid < groups) ? fetch(group_lo(tid) + k - shift) : real(0);
+  for (int64_t base = 0; base < groups; base += BLOCK, buf ^= 1) {
+    const int64_t t = base + tid;
+    const bool act = t < groups;
+    const int64_t jlo = group_lo(t);
+    real x[NV], l[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) x[k] = xn[k];
+    {
+      const int64_t tn = t + BLOCK;
+      const int64_t jn = group_lo(tn);
+#pragma unroll
+      for (int k = 0; k < NV; ++k) xn[k] = (tn < groups) ? fetch(jn + k - shift) : real(0);
+    }
+    if (!a.reverse) {
+      l[0] = x[0];
+#pragma unroll
+      for (int k = 1; k < NV; ++k) l[k] = l[k - 1] + x[k];
+    } else {
+      l[NV - 1] = x[NV - 1];
+#pragma unroll
+      for (int k = NV - 2; k >= 0; --k) l[k] = l[k + 1] + x[k];
+    }
+    const real mine = a.reverse ? l[0] : l[NV - 1];
+    real s = mine;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      real u = __shfl_up(s, d, WAVE);
+      if (lane >= d) s += u;
+    }
+    real excl = __shfl_up(s, 1, WAVE);
+    if (lane == 0) excl = real(0);
+    if (lane == WAVE - 1) wtot[buf][wv] = s;
+    __syncthreads();
+    real woff = real(0), tot = real(0);
+#pragma unroll
+    for (int i = 0; i < WPB; ++i) {
+      real u = wtot[buf][i];
+      if (i < wv) woff += u;
+      tot += u;
+    }
+    const real before = carry + (woff + excl);
+    carry += tot;
+    if (act) {
+      dv res;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) res[k] = before + l[k];
+      // halo cells (fill / extend only here): j = 0 and j = no - 1 sit next to a kept cell of the same group
+      if (a.pad_lo && jlo == 0) res[0] = (a.bc == XG_BC_FILL) ? (real)a.fill : res[1];
+      if (a.pad_hi && jlo + NV == no) res[NV - 1] = (a.bc == XG_BC_FILL) ? (real)a.fill : res[NV - 2];
+      if (HAS_MO) res = res / ldm<dv>(m_out, mo_base + jlo * mo.axis, mo.axis);
+      stg<dv, NTS>(orow + jlo, res);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: weighted sum along a STRIDED axis: one lane per output column pair, sequential in k
+// (bit-exact with numpy's reduction over a non-last axis).
+// ------------------------------------------------------------------------------------------
+template <int V, bool HAS_W, bool NTL, int U>
+__global__ __launch_bounds__(BLOCK) void k_reduce_strided(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, int skipna,
+    const real* __restrict__ wgt, MIdx mw) {
+  typedef typename VecT<V>::type T;
+  // U independent loads in flight per lane
+  const u64 w = wave_id();
+  const u32 tile = (u32)(w % ntile);
+  const int64_t o = (int64_t)(w / ntile);
+  if (o >= g.outer) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t x = ((int64_t)tile * WAVE + lane) * V;
+  if (x >= g.inner) return;
+  const int64_t inner = g.inner, n = g.n_in;
+  const real* pin = in + (o * n) * inner + x;
+  int64_t mb = 0, ms = 0;
+  if (HAS_W) {
+    mb = outer_off(g, mw, o) + inner_off(g, mw, x);
+    ms = (V > 1) ? inner_off(g, mw, x + 1) - inner_off(g, mw, x) : 0;
+  }
+  T acc = splat<T>(real(0));
+  bool started = false;
+  auto step = [&](int64_t k, T v) {
+    if (HAS_W) v = v * ldm<T>(wgt, mb + k * mw.axis, ms);
+    if (skipna) v = nan0(v);
+    acc = started ? acc + v : v;
+    started = true;
+  };
+  int64_t k = 0;
+  for (; k + U <= n; k += U) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ldg<T, NTL>(pin + (k + u) * inner);
+#pragma unroll
+    for (int u = 0; u < U; ++u) step(k + u, v[u]);
+  }
+  for (; k < n; ++k) step(k, ldg<T, NTL>(pin + k * inner));
+  *reinterpret_cast<T*>(out + o * inner + x) = acc;
+}
+
+// K4b: weighted sum along the CONTIGUOUS axis: one wave per row, lane-strided partial sums then
+// a shuffle tree (tolerance parity; numpy itself is pairwise here).
+template <bool HAS_W, bool VEC>
+__global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict__ in,
+                                                         real* __restrict__ out, Geo g, int skipna,
+                                                         const real* __restrict__ wgt, MIdx mw) {
+  const u64 row = wave_id();
+  if ((int64_t)row >= g.outer) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t n = g.n_in;
+  const real* prow = in + row * n;
+  int64_t mb = 0;
+  if (HAS_W) mb = outer_off(g, mw, row);
+  real acc = real(0);
+  int64_t k0 = 0;
+  if (VEC) {  // rows 16-B aligned (host): 16-B loads, NV partial sums per lane, two loads in flight
+    dv a = splat<dv>(real(0));
+    const int64_t nvec = n / NV;
+    for (int64_t t = lane; t < nvec; t += WAVE) {
+      dv v = *reinterpret_cast<const dv*>(prow + t * NV);
+      if (HAS_W) v = v * ldm<dv>(wgt, mb + t * NV * mw.axis, mw.axis);
+      if (skipna) v = nan0(v);
+      a = a + v;
+    }
+#pragma unroll
+    for (int c = 0; c < NV; ++c) acc += a[c];
+    k0 = nvec * NV;
+  }
+  for (int64_t k = k0 + lane; k < n; k += WAVE) {
+    real v = prow[k];
+    if (HAS_W) v = v * wgt[mb + k * mw.axis];
+    if (skipna) v = nan0(v);
+    acc += v;
+  }
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d, WAVE);
+  if (lane == 0) out[row] = acc;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim, int axis, int reverse,
+                    int skipna, int trim_lo, int trim_hi, int pad_lo, int pad_hi, int bc, real fill,
+                    const real* m_in, const int64_t* m_in_strides, const real* m_out,
+                    const int64_t* m_out_strides, void* stream) {
+  if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if ((trim_lo | trim_hi | pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "trim/pad widths must be 0 or 1");
+  if (bc < XG_BC_NONE || bc > XG_BC_EXTEND) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
+  if ((pad_lo || pad_hi) && bc == XG_BC_NONE) return fail(XG_ERR_INVALID, "halo cells requested but no boundary mode given");
+  if ((m_in && !m_in_strides) || (m_out && !m_out_strides)) return fail(XG_ERR_INVALID, "metric without strides");
+  if (axis < 0 || axis >= ndim) return fail(XG_ERR_INVALID, "axis out of range");
+  const int64_t n = shape[axis];
+  const int64_t n_out = n - trim_lo - trim_hi + pad_lo + pad_hi;
+  if (n - trim_lo - trim_hi < 1) return fail(XG_ERR_INVALID, "nothing left after trimming (n=%lld)", (long long)n);
+  Geo g; MIdx mi, mo;
+  int rc = build_geo(shape, ndim, axis, n_out, m_in ? m_in_strides : nullptr, m_out ? m_out_strides : nullptr, &g, &mi, &mo);
+  if (rc) return rc;
+  if (g.outer == 0 || g.inner == 0) return XG_OK;
+  ScanArgs a = {reverse ? 1 : 0, skipna ? 1 : 0, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill};
+  const int met = (m_out ? 1 : 0) | (m_in ? 2 : 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (g.inner == 1) {
+    const u64 nblocks = (u64)g.outer;
+    if ((rc = check_grid(nblocks + 8))) return rc;
+    const bool periodic_halo = (pad_lo || pad_hi) && bc == XG_BC_PERIODIC;
+    if (tune().scan_vec && !periodic_halo && n_out % NV == 0 && n_out >= 2 * NV && aligned16(out) && nblocks < 0x7ffffff0ull) {
+      const u32 nrows = (u32)nblocks, grid = ((nrows + 7) / 8) * 8;
+      const bool nts = tune().nt_store;
+#define XG_M(M) do { if (nts) hipLaunchKernelGGL((k_cumsum_contig_vec<M, true>), dim3(grid), dim3(BLOCK), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo); \
+                     else hipLaunchKernelGGL((k_cumsum_contig_vec<M, false>), dim3(grid), dim3(BLOCK), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo); } while (0)
+      switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
+#undef XG_M
+    } else {
+#define XG_M(M) hipLaunchKernelGGL((k_cumsum_contig<M>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, a, m_in, mi, m_out, mo)
+      switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
+#undef XG_M
+    }
+  } else {
+    int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, met != 0)) ? NV : 1;
+    // few, long columns (cumsum along Y of (Z,Y,X): ~2k wave-tasks for 1024 SIMDs): one element per
+    // lane doubles (f64) / quadruples (f32) the number of independent marches
+    const bool long_march = g.n_in >= 256;
+    if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = 1;
+    const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
+    const u64 ntask = (u64)ntile * (u64)g.outer;
+    const u64 nblocks = (ntask + WPB - 1) / WPB;
+    if ((rc = check_grid(nblocks))) return rc;
+    const bool nts = tune().nt_store;
+    // few columns, long march (cumsum along Y: ~2k waves for the whole chip): occupancy cannot hide
+    // the latency, so keep 16 loads in flight per lane instead of 4 (measured with the narrow lanes
+    // above: cumsum along Y f32 48 -> 55 %, sum along Y 59 -> 67 % f32 / 68 -> 71 % f64)
+    const bool deep = long_march && ntask < (u64)tune().deep_waves;
+#define XG_GO(V_, M, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); \
+                               else hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); } while (0)
+#define XG_M(V_, M) do { if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
+#define XG_V(V_) switch (met) { case 0: XG_M(V_, 0); break; case 1: XG_M(V_, 1); break; case 2: XG_M(V_, 2); break; default: XG_M(V_, 3); }
+    if (V > 1) { XG_V(NV) } else { XG_V(1) }
+#undef XG_V
+#undef XG_M
+#undef XG_GO
+  }
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim, int axis, int skipna,
+                    const real* w, const int64_t* w_strides, void* stream) {
+  if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (w && !w_strides) return fail(XG_ERR_INVALID, "weight without strides");
+  Geo g; MIdx mw;
+  int rc = build_geo(shape, ndim, axis, 1, w ? w_strides : nullptr, nullptr, &g, &mw, nullptr);
+  if (rc) return rc;
+  if (g.outer == 0 || g.inner == 0) return XG_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (g.n_in == 0) { XG_HIP(hipMemsetAsync(out, 0, sizeof(real) * g.outer * g.inner, st)); return XG_OK; }
+  if (g.inner == 1) {
+    const u64 nblocks = ((u64)g.outer + WPB - 1) / WPB;
+    if ((rc = check_grid(nblocks))) return rc;
+    const bool vec = aligned16(in) && (g.n_in % NV == 0) && g.n_in >= 4 * NV;  // every row starts 16-B aligned
+    if (vec) {
+      if (w) hipLaunchKernelGGL((k_reduce_contig<true, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+      else hipLaunchKernelGGL((k_reduce_contig<false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+    } else {
+      if (w) hipLaunchKernelGGL((k_reduce_contig<true, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+      else hipLaunchKernelGGL((k_reduce_contig<false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+    }
+  } else {
+    int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, w != nullptr)) ? NV : 1;
+    const bool long_march = g.n_in >= 256;
+    if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = 1;
+    const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
+    const u64 ntask = (u64)ntile * (u64)g.outer;
+    const u64 nblocks = (ntask + WPB - 1) / WPB;
+    if ((rc = check_grid(nblocks))) return rc;
+    const bool deep = long_march && ntask < (u64)tune().deep_waves;
+#define XG_GO(V_, W_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, false, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); \
+                           else hipLaunchKernelGGL((k_reduce_strided<V_, W_, false, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); } while (0)
+    if (V > 1) { if (w) XG_GO(NV, true); else XG_GO(NV, false); }
+    else { if (w) XG_GO(1, true); else XG_GO(1, false); }
+#undef XG_GO
+  }
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+}  // extern "C"

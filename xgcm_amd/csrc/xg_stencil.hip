@@ -1,0 +1,721 @@
+// xg_stencil.hip -- two-point stencils (diff / interp / min / max) along one axis (K1, K1g, K2, K2S) and along two axes at once (K8)
+// Part of libxgcm_hip.so; compiled twice (real = double / -DXG_F32), see xg_common.hpp.
+
+#include "xg_common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// K2: stencil along a STRIDED axis.  View (outer, n, inner); lane <-> V consecutive elements of
+// `inner`; wave-task = (o, segment of `seg` output rows, x-tile of 64*V elements).  Each lane
+// marches along the axis holding the previous (metric-weighted) value in registers: exactly
+// one 16-B load and one 16-B store per lane per row (+1 halo row per segment).
+// MET bit0: m_out present, bit1: m_in present.
+// ------------------------------------------------------------------------------------------
+template <int OP, int V, int MET, bool NTL, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_stencil_strided(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, int seg, u32 nseg, u32 ntile,
+    int pad_lo, int bc, real fill, const real* __restrict__ halo, const real* __restrict__ m_in, MIdx mi,
+    const real* __restrict__ m_out, MIdx mo) {
+  typedef typename VecT<V>::type T;
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  constexpr int U = 4;
+
+  const u64 w = wave_id();
+  const u32 tile = (u32)(w % ntile);
+  const u64 r = w / ntile;
+  const u32 sg = (u32)(r % nseg);
+  const int64_t o = (int64_t)(r / nseg);
+  if (o >= g.outer) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t x = ((int64_t)tile * WAVE + lane) * V;
+  if (x >= g.inner) return;
+
+  const int64_t j0 = (int64_t)sg * seg;
+  const int64_t j1 = (j0 + seg < g.n_out) ? j0 + seg : g.n_out;
+  const int64_t inner = g.inner;
+  const real* pin = in + (o * g.n_in) * inner + x;
+  real* pout = out + (o * g.n_out) * inner + x;
+
+  int64_t mi_base = 0, mo_base = 0, mi_step = 0, mo_step = 0;
+  if (HAS_MI) {
+    mi_base = outer_off(g, mi, o) + inner_off(g, mi, x);
+    mi_step = (V > 1) ? inner_off(g, mi, x + 1) - inner_off(g, mi, x) : 0;
+  }
+  if (HAS_MO) {
+    mo_base = outer_off(g, mo, o) + inner_off(g, mo, x);
+    mo_step = (V > 1) ? inner_off(g, mo, x + 1) - inner_off(g, mo, x) : 0;
+  }
+
+  // P(k): value of the padded, metric-weighted input at padded index k (q = k - pad_lo)
+  auto loadq = [&](int64_t q) -> T {
+    T v = ldg<T, NTL>(pin + q * inner);
+    if (HAS_MI) v = v * ldm<T>(m_in, mi_base + q * mi.axis, mi_step);
+    return v;
+  };
+  auto loadP = [&](int64_t k) -> T {
+    int64_t q = k - pad_lo;
+    if (q < 0 || q >= g.n_in) {
+      if (bc == XG_BC_FILL) return splat<T>(fill);
+      if (bc == XG_BC_HALO)  // halo values gathered beforehand: layout (outer, pad_lo + pad_hi, inner)
+        return *reinterpret_cast<const T*>(halo + ((o * (g.n_out - g.n_in + 1) + (q < 0 ? 0 : pad_lo)) * inner + x));
+      q = (q < 0) ? ((bc == XG_BC_PERIODIC) ? g.n_in - 1 : 0) : ((bc == XG_BC_PERIODIC) ? 0 : g.n_in - 1);
+    }
+    return loadq(q);
+  };
+  auto emit = [&](int64_t j, T l, T rr) {
+    T res = op2<OP>(l, rr);
+    if (HAS_MO) res = res / ldm<T>(m_out, mo_base + j * mo.axis, mo_step);
+    stg<T, NTS>(pout + j * inner, res);
+  };
+
+  T prev = loadP(j0);
+  int64_t k = j0 + 1;
+  // interior: q = k - pad_lo in [0, n_in) guaranteed for k <= kend
+  const int64_t kend = (j1 < g.n_in - 1 + pad_lo) ? j1 : g.n_in - 1 + pad_lo;
+  for (; k + (U - 1) <= kend; k += U) {
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = ldg<T, NTL>(pin + (k + u - pad_lo) * inner);
+    if (HAS_MI) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = v[u] * ldm<T>(m_in, mi_base + (k + u - pad_lo) * mi.axis, mi_step);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      emit(k + u - 1, prev, v[u]);
+      prev = v[u];
+    }
+  }
+  for (; k <= kend; ++k) {
+    T cur = loadq(k - pad_lo);
+    emit(k - 1, prev, cur);
+    prev = cur;
+  }
+  for (; k <= j1; ++k) {  // at most one step: the high halo
+    T cur = loadP(k);
+    emit(k - 1, prev, cur);
+    prev = cur;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Linear-order stencil kernels.  Measured on MI355X (profiles/r01_streambench_*.txt): a kernel
+// whose threads each move ONE 16-byte vector, with thread id == linear memory order, streams at
+// the copy ceiling (~79 % of 8 TB/s); giving a thread several rows/tiles costs 10-25 %.  So the
+// output is walked as a flat list of V-wide items: item -> (row, position) by one 32-bit
+// division (the host splits launches so that item counts stay below 2^31).
+//
+// K1: stencil along the CONTIGUOUS (last) axis, view (rows, L).
+//   V == 2: L_in == L_out even, pads (1,0) or (0,1): one aligned 16-B load + one 8-B neighbour
+//           load that hits the same cache lines (L1-served), one 16-B store.
+//   V == 1: general path (any pads, odd lengths, N+1 / N-1 outputs): two 8-B loads.
+// ------------------------------------------------------------------------------------------
+template <int OP, int V, int MET, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_stencil_contig(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t row0, u32 nrows, u32 nblk, FastDiv per,
+    ZBand zb, int pad_lo, int bc, real fill, const real* __restrict__ halo, const real* __restrict__ m_in,
+    MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  // XCD banding (see K2S): neighbouring workgroups share an L2, so the cache line holding a
+  // workgroup's left neighbour is not fetched a second time by another XCD (-3 % HBM reads)
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 gid = lb * BLOCK + threadIdx.x;
+  u32 r = fdiv(gid, per);  // per.d = V-wide items per output row
+  if (r >= nrows) return;
+  const u32 i0 = (gid - r * per.d) * V;
+  u32 zz = 0, zy = 0;
+  if (MET != 0 && zb.on) {
+    if (!zband_map(zb, r, zz, zy)) return;
+    r = zz * zb.Y + zy;
+  }
+  const u32 Li = (u32)g.n_in, Lo = (u32)g.n_out;  // host guarantees row lengths < 2^31
+  const real* prow = in + (row0 * (int64_t)Li + (u64)r * Li);
+  real* orow = out + (row0 * (int64_t)Lo + (u64)r * Lo);
+  // metric row offsets: with z-banding (z, y) are already known, else one FastDiv per outer dim
+  // (the host only selects this kernel with metrics when g.idx32 holds)
+  int64_t mib = 0, mob = 0;
+  if (MET != 0 && zb.on) {  // outer dims are exactly (Z, Y)
+    if (HAS_MI) mib = (int64_t)zz * mi.outer[0] + (int64_t)zy * mi.outer[1];
+    if (HAS_MO) mob = (int64_t)zz * mo.outer[0] + (int64_t)zy * mo.outer[1];
+  } else {
+    if (HAS_MI) mib = outer_off32(g, mi, (u32)(row0 + r));
+    if (HAS_MO) mob = outer_off32(g, mo, (u32)(row0 + r));
+  }
+
+  if (V > 1) {
+    u32 nidx;
+    bool edge;
+    if (pad_lo) { edge = (i0 == 0); nidx = edge ? ((bc == XG_BC_PERIODIC) ? Li - 1 : 0) : i0 - 1; }
+    else { edge = (i0 + NV == Li); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : Li - 1) : i0 + NV; }
+    dv a = *reinterpret_cast<const dv*>(prow + i0);
+    real n = prow[nidx];
+    if (HAS_MI) {
+      a = a * ldm<dv>(m_in, mib + (int64_t)i0 * mi.axis, mi.axis);
+      n = n * m_in[mib + (int64_t)nidx * mi.axis];
+    }
+    if (edge && bc == XG_BC_FILL) n = fill;
+    if (edge && bc == XG_BC_HALO) n = halo[(row0 + r) * (int64_t)(Lo - Li + 1)];  // one halo cell per row here
+    dv res;
+    if (pad_lo) {
+      res[0] = op2<OP>(n, a[0]);
+#pragma unroll
+      for (int k = 1; k < NV; ++k) res[k] = op2<OP>(a[k - 1], a[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV - 1; ++k) res[k] = op2<OP>(a[k], a[k + 1]);
+      res[NV - 1] = op2<OP>(a[NV - 1], n);
+    }
+    if (HAS_MO) res = res / ldm<dv>(m_out, mob + (int64_t)i0 * mo.axis, mo.axis);
+    stg<dv, NTS>(orow + i0, res);
+  } else {
+    int64_t ql = (int64_t)i0 - pad_lo, qr = (int64_t)i0 + 1 - pad_lo;
+    bool fl = false, fr = false;
+    if (ql < 0) { fl = (bc == XG_BC_FILL); ql = (bc == XG_BC_PERIODIC) ? (int64_t)Li - 1 : 0; }
+    if (qr >= (int64_t)Li) { fr = (bc == XG_BC_FILL); qr = (bc == XG_BC_PERIODIC) ? 0 : (int64_t)Li - 1; }
+    real l = prow[ql], rr = prow[qr];
+    if (HAS_MI) {
+      l = l * m_in[mib + ql * mi.axis];
+      rr = rr * m_in[mib + qr * mi.axis];
+    }
+    if (fl) l = fill;
+    if (fr) rr = fill;
+    if (bc == XG_BC_HALO) {
+      const int64_t hb = (row0 + r) * (int64_t)(Lo - Li + 1);
+      if ((int64_t)i0 - pad_lo < 0) l = halo[hb];
+      if ((int64_t)i0 + 1 - pad_lo >= (int64_t)Li) rr = halo[hb + pad_lo];
+    }
+    real res = op2<OP>(l, rr);
+    if (HAS_MO) res = res / m_out[mob + (int64_t)i0 * mo.axis];
+    stg<real, NTS>(orow + i0, res);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1g: contiguous axis, GENERAL lengths (odd rows, N+1 / N-1 outputs: outer/inner positions).
+// Rows of the output are then not 16-B aligned, but the output ARRAY is: the array is walked as
+// a flat list of NV-element groups (which may straddle two rows), each element is computed like
+// the V == 1 path of K1 (two narrow loads served by L1) and the group leaves as one aligned
+// 16-B store.  1/NV of the threads, index math and store instructions of the one-element form.
+// ------------------------------------------------------------------------------------------
+template <int OP, int MET, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t row0, u32 nelem, u32 nblk,
+    FastDiv fLo, int pad_lo, int bc, real fill, const real* __restrict__ halo, const real* __restrict__ m_in,
+    MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 gid = lb * BLOCK + threadIdx.x;
+  if (gid >= (nelem + NV - 1) / NV) return;
+  const u32 e0 = NV * gid;
+  const u32 Li = (u32)g.n_in, Lo = (u32)g.n_out;
+  auto one = [&](u32 r, u32 i) -> real {
+    const real* prow = in + (row0 * (int64_t)Li + (u64)r * Li);
+    int64_t ql = (int64_t)i - pad_lo, qr = (int64_t)i + 1 - pad_lo;
+    bool fl = false, fr = false;
+    if (ql < 0) { fl = (bc == XG_BC_FILL); ql = (bc == XG_BC_PERIODIC) ? (int64_t)Li - 1 : 0; }
+    if (qr >= (int64_t)Li) { fr = (bc == XG_BC_FILL); qr = (bc == XG_BC_PERIODIC) ? 0 : (int64_t)Li - 1; }
+    real l = prow[ql], rr = prow[qr];
+    if (HAS_MI) {
+      const int64_t mib = outer_off32(g, mi, (u32)(row0 + r));
+      l = l * m_in[mib + ql * mi.axis];
+      rr = rr * m_in[mib + qr * mi.axis];
+    }
+    if (fl) l = fill;
+    if (fr) rr = fill;
+    if (bc == XG_BC_HALO) {
+      const int64_t hb = (row0 + r) * (int64_t)(Lo - Li + 1);
+      if ((int64_t)i - pad_lo < 0) l = halo[hb];
+      if ((int64_t)i + 1 - pad_lo >= (int64_t)Li) rr = halo[hb + pad_lo];
+    }
+    real res = op2<OP>(l, rr);
+    if (HAS_MO) res = res / m_out[outer_off32(g, mo, (u32)(row0 + r)) + (int64_t)i * mo.axis];
+    return res;
+  };
+  u32 r = fdiv(e0, fLo), i = e0 - r * Lo;
+  real* po = out + (row0 * (int64_t)Lo + (u64)e0);  // row0 * Lo is a multiple of NV (host) => 16-B aligned
+  dv res;
+  const int64_t q0 = (int64_t)i - pad_lo;
+  if (i + NV <= Lo && q0 >= 0 && q0 + NV < (int64_t)Li && e0 + NV <= nelem) {
+    // interior group inside one row: the NV outputs share NV + 1 consecutive inputs
+    const real* prow = in + (row0 * (int64_t)Li + (u64)r * Li) + q0;
+    real v[NV + 1];
+#pragma unroll
+    for (int k = 0; k <= NV; ++k) v[k] = prow[k];
+    if (HAS_MI) {
+      const int64_t mib = outer_off32(g, mi, (u32)(row0 + r)) + q0 * mi.axis;
+#pragma unroll
+      for (int k = 0; k <= NV; ++k) v[k] = v[k] * m_in[mib + k * mi.axis];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) res[k] = op2<OP>(v[k], v[k + 1]);
+    if (HAS_MO) {
+      const int64_t mob = outer_off32(g, mo, (u32)(row0 + r)) + (int64_t)i * mo.axis;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) res[k] = res[k] / m_out[mob + k * mo.axis];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (e0 + k < nelem) res[k] = one(r, i);
+      if (++i == Lo) { i = 0; ++r; }
+    }
+  }
+  if (e0 + NV <= nelem) {
+    stg<dv, NTS>(po, res);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (e0 + k < nelem) po[k] = res[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2S: stencil along a STRIDED axis, the small-row case (few x-tiles per row, e.g. Y of a
+// (Z,Y,X) field).  Measured on MI355X with random data (profiles/r01_streambench_d_*.txt):
+//   * the set of rows in flight must stay compact: each wave register-marches only SEG (= 4)
+//     rows -- SEG+1 independent 16-B loads, then SEG stores -- instead of a long segment;
+//   * the halo row a segment re-reads must come from the SAME XCD's L2: workgroup b runs on XCD
+//     b % 8 (observed dispatch rule, used for speed only), so the linear wave sequence is cut
+//     into 8 contiguous bands, one per XCD ("banding").  Each XCD then streams one compact
+//     address range and its re-reads never cross the fabric.  6.3 TB/s vs 5.1 TB/s without.
+// One wave = one x-tile of one SEG-row segment; the (outer, segment, tile) split and all row
+// bases are wave-uniform (scalar unit, FastDiv).
+// ------------------------------------------------------------------------------------------
+template <int OP, int V, int MET, bool NTS, int SEG>
+__global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk,
+    FastDiv ntile, FastDiv nseg, ZBand zb, Chunk ck, int pad_lo, int bc, real fill,
+    const real* __restrict__ halo, const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+  typedef typename VecT<V>::type T;
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  // banding: XCD (b % 8) owns logical blocks [xcd * pb, (xcd + 1) * pb)
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
+  u32 oo, sg, tile;
+  if (ck.on) {  // (outer, chunk, segment, tile in chunk)
+    const u32 cg = fdiv(w, ck.per_group);
+    const u32 rem = w - cg * ck.per_group.d;
+    sg = fdiv(rem, ck.ch);
+    oo = fdiv(cg, ck.fnchunk);
+    tile = (cg - oo * ck.fnchunk.d) * ck.ch.d + (rem - sg * ck.ch.d);
+    if (oo >= nouter || tile >= ntile.d) return;
+  } else {
+    const u32 r = fdiv(w, ntile);
+    tile = w - r * ntile.d;
+    if (MET != 0 && zb.on) {  // band-major order over (segment band, outer, segment)
+      if (!zband_map(zb, r, oo, sg)) return;
+    } else {
+      oo = fdiv(r, nseg);
+      if (oo >= nouter) return;
+      sg = r - oo * nseg.d;
+    }
+  }
+  const int64_t o = o0 + oo;
+  const int64_t inner = g.inner;
+  const int64_t x = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
+  if (x >= inner) return;
+  const int64_t j0 = (int64_t)sg * SEG;
+  const int64_t nrow = (g.n_out - j0 < SEG) ? g.n_out - j0 : SEG;  // rows this segment really has
+  const real* pin = in + (o * g.n_in) * inner + x;
+  real* pout = out + (o * g.n_out + j0) * inner + x;
+
+  int64_t mib = 0, mob = 0, mis = 0, mos = 0;  // (host guarantees g.idx32 when metrics are present)
+  if (HAS_MI) {
+    inner_off_step32(g, mi, (u32)x, V > 1, mib, mis);
+    mib += outer_off32(g, mi, (u32)o);
+  }
+  if (HAS_MO) {
+    inner_off_step32(g, mo, (u32)x, V > 1, mob, mos);
+    mob += outer_off32(g, mo, (u32)o) + j0 * mo.axis;
+  }
+
+  // padded index k = j0 + u  ->  input row q (wave-uniform), fill flag
+  T v[SEG + 1];
+#pragma unroll
+  for (int u = 0; u <= SEG; ++u) {
+    int64_t k = j0 + ((u <= nrow) ? u : nrow);  // clamp inside the padded range for short tails
+    int64_t q = k - pad_lo;
+    bool f = false;
+    const real* src = pin;
+    if (q < 0 || q >= g.n_in) {
+      f = (bc == XG_BC_FILL);
+      if (bc == XG_BC_HALO) {  // pre-gathered halo rows, layout (outer, pad_lo + pad_hi, inner)
+        src = halo + (o * (g.n_out - g.n_in + 1)) * inner + x;
+        q = (q < 0) ? 0 : pad_lo;
+      } else {
+        q = (q < 0) ? ((bc == XG_BC_PERIODIC) ? g.n_in - 1 : 0) : ((bc == XG_BC_PERIODIC) ? 0 : g.n_in - 1);
+      }
+    }
+    T t = *reinterpret_cast<const T*>(src + q * inner);
+    if (HAS_MI) t = t * ldm<T>(m_in, mib + q * mi.axis, mis);
+    v[u] = f ? splat<T>(fill) : t;
+  }
+#pragma unroll
+  for (int u = 0; u < SEG; ++u) {
+    if (u < nrow) {
+      T res = op2<OP>(v[u], v[u + 1]);
+      if (HAS_MO) res = res / ldm<T>(m_out, mob + u * mo.axis, mos);
+      stg<T, NTS>(pout + u * inner, res);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K8: the same two-point operator along BOTH of the last two axes in one pass, e.g.
+// Grid.interp(da, ["X", "Y"]) (tracer -> vorticity point).  The reference applies the axes one
+// after the other (xgcm/grid.py:798-800 carries a TODO about fusing them): pad + op along the
+// first, then pad + op along the second = 32 B/cell.  Here one wave loads SEG+1 rows of pairs
+// plus the 8-B X neighbour (as K7), applies the first axis in registers and the second across
+// rows: 16 B/cell, and bit-identical to the sequential form because the order of the
+// floating-point operations is kept (`order` 0: X then Y, 1: Y then X).  The halo of the SECOND
+// axis acts on the intermediate array, as in the reference: a fill halo is the constant itself,
+// periodic/extend halos are the first-axis result of the wrapped/clamped row or column.
+// Length-preserving position pairs only (pads (1,0)/(0,1)), nx even; other cases run sequentially.
+// ------------------------------------------------------------------------------------------
+template <int OP, bool NTS, int SEG>
+__global__ __launch_bounds__(BLOCK) void k_stencil2d(
+    const real* __restrict__ in, real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny,
+    int64_t nx, FastDiv ntile, FastDiv nseg, int order, int plx, int bcx, real fillx, int ply, int bcy,
+    real filly) {
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
+  const u32 r = fdiv(w, ntile);
+  const u32 tile = w - r * ntile.d;
+  const u32 oo = fdiv(r, nseg);
+  if (oo >= nouter) return;
+  const u32 sg = r - oo * nseg.d;
+  const int64_t o = o0 + oo;
+  const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * NV;
+  if (i0 >= nx) return;
+  const int64_t j0 = (int64_t)sg * SEG;
+  const int64_t nrow = (ny - j0 < SEG) ? ny - j0 : SEG;
+  const real* pin = in + o * ny * nx;
+  real* po = out + (o * ny + j0) * nx + i0;
+
+  int64_t nidx;
+  bool edge;
+  if (plx) { edge = (i0 == 0); nidx = edge ? ((bcx == XG_BC_PERIODIC) ? nx - 1 : 0) : i0 - 1; }
+  else { edge = (i0 + NV == nx); nidx = edge ? ((bcx == XG_BC_PERIODIC) ? 0 : nx - 1) : i0 + NV; }
+  const bool fill_edge = edge && (bcx == XG_BC_FILL);
+  // X stencil on a lane vector `a` with the value `n` next to it (left of a[0] if plx, right of a[NV-1] otherwise)
+  auto opx = [&](dv a, real n) -> dv {
+    dv t;
+    if (plx) {
+      t[0] = op2<OP>(n, a[0]);
+#pragma unroll
+      for (int k = 1; k < NV; ++k) t[k] = op2<OP>(a[k - 1], a[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV - 1; ++k) t[k] = op2<OP>(a[k], a[k + 1]);
+      t[NV - 1] = op2<OP>(a[NV - 1], n);
+    }
+    return t;
+  };
+
+  dv pr[SEG + 1];
+  real nb[SEG + 1];
+  bool rowfill[SEG + 1];
+#pragma unroll
+  for (int u = 0; u <= SEG; ++u) {
+    int64_t k = j0 + ((u <= nrow) ? u : nrow);
+    int64_t q = k - ply;
+    bool f = false;
+    if (q < 0) { f = (bcy == XG_BC_FILL); q = (bcy == XG_BC_PERIODIC) ? ny - 1 : 0; }
+    else if (q >= ny) { f = (bcy == XG_BC_FILL); q = (bcy == XG_BC_PERIODIC) ? 0 : ny - 1; }
+    rowfill[u] = f;
+    pr[u] = *reinterpret_cast<const dv*>(pin + q * nx + i0);
+    nb[u] = pin[q * nx + nidx];
+  }
+  if (order == 0) {  // X first, then Y on the intermediate
+    dv tx[SEG + 1];
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) {
+      const dv t = opx(pr[u], fill_edge ? fillx : nb[u]);
+      tx[u] = rowfill[u] ? splat<dv>(filly) : t;
+    }
+#pragma unroll
+    for (int u = 0; u < SEG; ++u)
+      if (u < nrow) stg<dv, NTS>(po + u * nx, op2<OP>(tx[u], tx[u + 1]));
+  } else {  // Y first, then X on the intermediate
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) {
+      if (rowfill[u]) { pr[u] = splat<dv>(filly); nb[u] = filly; }
+    }
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+      if (u < nrow) {
+        const dv ty = op2<OP>(pr[u], pr[u + 1]);
+        const real tn = op2<OP>(nb[u], nb[u + 1]);
+        stg<dv, NTS>(po + u * nx, opx(ty, fill_edge ? fillx : tn));
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+
+struct StencilCall {
+  const real* in; real* out; Geo g; int pad_lo, pad_hi, bc; real fill; const real* halo;
+  const real* m_in; MIdx mi; const real* m_out; MIdx mo; hipStream_t st;
+};
+
+// marching kernel (one HBM read per cell whatever the plane size)
+template <int OP, int V, int MET>
+int launch_march(const StencilCall& c) {
+  int seg = tune().seg < 1 ? 1 : tune().seg;
+  const u32 nseg = (u32)((c.g.n_out + seg - 1) / seg);
+  const u32 ntile = (u32)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
+  const u64 ntask = (u64)ntile * nseg * (u64)c.g.outer;
+  const u64 nblocks = (ntask + WPB - 1) / WPB;
+  if (nblocks == 0 || nblocks > 0x7fffffffull) return fail(XG_ERR_UNSUPPORTED, "launch of %llu blocks exceeds grid limits", nblocks);
+  if (tune().nt_store)
+    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+  else
+    hipLaunchKernelGGL((k_stencil_strided<OP, V, MET, false, false>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), c.st, c.in, c.out, c.g, seg, nseg, ntile, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+  return 0;
+}
+
+template <int OP, int MET>
+int launch_contig_gen(const StencilCall& c) {
+  const u64 Lo = (u64)c.g.n_out;
+  u64 rows_per = 0xfffffff0ull / Lo;
+  rows_per -= rows_per % NV;  // a multiple of NV rows per launch keeps every launch's first group aligned
+  if (rows_per < (u64)NV) return -1;
+  const FastDiv fLo = make_fastdiv(Lo);
+  for (u64 row0 = 0; row0 < (u64)c.g.outer; row0 += rows_per) {
+    const u64 nrows = ((u64)c.g.outer - row0 < rows_per) ? (u64)c.g.outer - row0 : rows_per;
+    const u32 nelem = (u32)(nrows * Lo);
+    const u32 nblk = (u32)((((u64)nelem + NV - 1) / NV + BLOCK - 1) / BLOCK);
+    const u32 grid = ((nblk + 7) / 8) * 8;
+    if (tune().nt_store)
+      hipLaunchKernelGGL((k_stencil_contig_gen<OP, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nelem, nblk, fLo, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+    else
+      hipLaunchKernelGGL((k_stencil_contig_gen<OP, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nelem, nblk, fLo, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+  }
+  return 0;
+}
+
+template <int OP, int V, int MET>
+int launch_contig(const StencilCall& c) {
+  if (V == 1 && tune().contig_gen && aligned16(c.out) && c.g.n_in <= 0x7fffffffll && c.g.n_out <= 0x7fffffffll &&
+      c.g.outer * c.g.n_out >= 2) {
+    const int rc = launch_contig_gen<OP, MET>(c);
+    if (rc >= 0) return rc;
+  }
+  const u64 per = (u64)((c.g.n_out + V - 1) / V);
+  if (per > MAX_ITEMS || c.g.n_in > 0x7fffffffll) return fail(XG_ERR_UNSUPPORTED, "row of %llu items too long", per);
+  const FastDiv fper = make_fastdiv(per);
+  const u64 rows_per = MAX_ITEMS / per;
+  // z-banding: outer dims (Z, Y) with every metric broadcast along Z, whole problem in one launch
+  const u32 ZB_ROWS = 16;
+  bool zb_ok = MET != 0 && tune().zband && c.g.n_outer == 2 && (!c.m_in || c.mi.outer[0] == 0) &&
+               (!c.m_out || c.mo.outer[0] == 0);
+  u64 work_rows = (u64)c.g.outer;
+  ZBand zb = make_zband(false, 0, 0, 1);
+  if (zb_ok) {
+    const u64 Z = (u64)c.g.outer_shape[0], Y = (u64)c.g.outer_shape[1];
+    const u64 padded = ((Y + ZB_ROWS - 1) / ZB_ROWS) * ZB_ROWS * Z;
+    if (padded <= rows_per) { zb = make_zband(true, Z, Y, ZB_ROWS); if (zb.on) work_rows = padded; }
+  }
+  for (u64 row0 = 0; row0 < work_rows; row0 += rows_per) {
+    const u32 nrows = (u32)((work_rows - row0 < rows_per) ? work_rows - row0 : rows_per);
+    const u32 nblk = (u32)(((u64)nrows * per + BLOCK - 1) / BLOCK);
+    const u32 grid = ((nblk + 7) / 8) * 8;
+    if (tune().nt_store)
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+    else
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+  }
+  return 0;
+}
+
+template <int OP, int V, int MET>
+int launch_seg(const StencilCall& c) {
+  constexpr int SEG = 4;
+  const u64 ntile = (u64)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
+  const u64 nseg = (u64)((c.g.n_out + SEG - 1) / SEG);
+  const Chunk noch = make_chunk(0, 1, 0);
+  const Chunk ck = make_chunk(ntile, nseg, ntile > (u64)tune().seg_max_tiles ? (u32)tune().zchunk : 0u);
+  const u64 per_outer = ck.on ? (u64)ck.nchunk * ck.ch.d * nseg : ntile * nseg;  // waves per outer index
+  if (per_outer > MAX_ITEMS) return launch_march<OP, V, MET>(c);  // (never the case below 2^31 cells per outer index)
+  const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
+  const u64 outer_per = MAX_ITEMS / per_outer;
+  // z-banding: a single outer dim along which every metric is broadcast, one launch
+  const u32 ZB_SEGS = 4;
+  const bool zb_ok = !ck.on && MET != 0 && tune().zband && c.g.n_outer == 1 && (!c.m_in || c.mi.outer[0] == 0) &&
+                     (!c.m_out || c.mo.outer[0] == 0);
+  if (zb_ok) {
+    const u64 padded_segs = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS;
+    const u64 waves = padded_segs * (u64)c.g.outer * ntile;
+    ZBand zb = make_zband(true, (u64)c.g.outer, nseg, ZB_SEGS);
+    if (zb.on && waves <= MAX_ITEMS) {
+      const u32 nblk = (u32)((waves + WPB - 1) / WPB);
+      const u32 grid = ((nblk + 7) / 8) * 8;
+      if (tune().nt_store)
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+      else
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+      return 0;
+    }
+  }
+  const ZBand zoff = make_zband(false, 0, 0, 1);
+  for (int64_t o0 = 0; o0 < c.g.outer; o0 += (int64_t)outer_per) {
+    const u32 nouter = (u32)((c.g.outer - o0 < (int64_t)outer_per) ? c.g.outer - o0 : (int64_t)outer_per);
+    const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
+    const u32 grid = ((nblk + 7) / 8) * 8;
+    if (tune().nt_store)
+      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, ck, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+    else
+      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, ck, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+  }
+  return 0;
+}
+
+enum StencilKind { KIND_CONTIG = 0, KIND_LIN = 1, KIND_MARCH = 2 };
+
+template <int OP, int V, int MET>
+int stencil_kind(int kind, const StencilCall& c) {
+  if (kind == KIND_CONTIG) return launch_contig<OP, V, MET>(c);
+  if (kind == KIND_LIN) return launch_seg<OP, V, MET>(c);
+  return launch_march<OP, V, MET>(c);
+}
+template <int OP, int V>
+int stencil_met(int met, int kind, const StencilCall& c) {
+  switch (met) {
+    case 0: return stencil_kind<OP, V, 0>(kind, c);
+    case 1: return stencil_kind<OP, V, 1>(kind, c);
+    case 2: return stencil_kind<OP, V, 2>(kind, c);
+    default: return stencil_kind<OP, V, 3>(kind, c);
+  }
+}
+template <int OP>
+int stencil_vec(int V, int met, int kind, const StencilCall& c) {
+  return V > 1 ? stencil_met<OP, NV>(met, kind, c) : stencil_met<OP, 1>(met, kind, c);
+}
+int stencil_dispatch(int op, int V, int met, int kind, const StencilCall& c) {
+  switch (op) {
+    case XG_OP_DIFF: return stencil_vec<XG_OP_DIFF>(V, met, kind, c);
+    case XG_OP_INTERP: return stencil_vec<XG_OP_INTERP>(V, met, kind, c);
+    case XG_OP_MIN: return stencil_vec<XG_OP_MIN>(V, met, kind, c);
+    default: return stencil_vec<XG_OP_MAX>(V, met, kind, c);
+  }
+}
+
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+static int stencil1d_impl(int op, const real* in, const real* halo, real* out, const int64_t* shape, int ndim,
+                          int axis, int64_t n_out, int pad_lo, int pad_hi, int bc, real fill, const real* m_in,
+                          const int64_t* m_in_strides, const real* m_out, const int64_t* m_out_strides,
+                          void* stream) {
+  if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
+  if ((pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "pad widths must be 0 or 1, got (%d,%d)", pad_lo, pad_hi);
+  if (bc < XG_BC_NONE || bc > XG_BC_HALO) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
+  if (bc == XG_BC_HALO && !halo) return fail(XG_ERR_INVALID, "XG_BC_HALO without a halo buffer");
+  if (bc == XG_BC_HALO && m_in) return fail(XG_ERR_UNSUPPORTED, "pre-gathered halos cannot be combined with an input metric");
+  if ((m_in && !m_in_strides) || (m_out && !m_out_strides)) return fail(XG_ERR_INVALID, "metric without strides");
+  Geo g; MIdx mi, mo;
+  int rc = build_geo(shape, ndim, axis, n_out, m_in ? m_in_strides : nullptr, m_out ? m_out_strides : nullptr, &g, &mi, &mo);
+  if (rc) return rc;
+  if (n_out != g.n_in + pad_lo + pad_hi - 1) return fail(XG_ERR_INVALID, "n_out %lld != n_in %lld + %d + %d - 1", (long long)n_out, (long long)g.n_in, pad_lo, pad_hi);
+  if ((pad_lo || pad_hi) && bc == XG_BC_NONE) return fail(XG_ERR_INVALID, "halo cells requested but no boundary mode given");
+  if (g.n_in < 1) return fail(XG_ERR_INVALID, "empty stencil axis");
+  if (g.outer == 0 || g.inner == 0 || n_out <= 0) return XG_OK;  // empty output
+  const int met = (m_out ? 1 : 0) | (m_in ? 2 : 0);
+  const bool al = aligned16(in) && aligned16(out) && (bc != XG_BC_HALO || aligned16(halo));
+  StencilCall c = {in, out, g, pad_lo, pad_hi, bc, fill, halo, m_in, mi, m_out, mo, (hipStream_t)stream};
+  int V, kind;
+  if (g.inner == 1) {
+    kind = KIND_CONTIG;
+    V = (al && (g.n_in % NV == 0) && (n_out % NV == 0)) ? NV : 1;
+  } else {
+    V = (al && (g.inner % NV == 0) && vec_metric_ok(g, met != 0)) ? NV : 1;
+    // few x-tiles per row (Y of a (Z,Y,X) field): short banded segments keep the rows in flight
+    // compact.  Many tiles per row (Z: a whole plane per row): the same kernel over column chunks
+    // of `zchunk` tiles (measured 5.2 -> 6.0 TB/s against marching the full column, which is
+    // kept for XG_ZCHUNK=0 and for extents beyond the u32 index range).
+    const int64_t ntile = (g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V);
+    const bool chunked = tune().zchunk > 0 && (met == 0 || g.idx32);
+    kind = (ntile <= (int64_t)tune().seg_max_tiles || chunked) ? KIND_LIN : KIND_MARCH;
+  }
+  if (met != 0 && kind != KIND_MARCH && !g.idx32)
+    return fail(XG_ERR_UNSUPPORTED, "metric-weighted stencils need outer/inner extents below 2^32");
+  rc = stencil_dispatch(op, V, met, kind, c);
+  if (rc) return rc;
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int XG_FN(xg_stencil1d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int axis,
+                     int64_t n_out, int pad_lo, int pad_hi, int bc, real fill, const real* m_in,
+                     const int64_t* m_in_strides, const real* m_out, const int64_t* m_out_strides,
+                     void* stream) {
+  if (bc == XG_BC_HALO) return fail(XG_ERR_INVALID, "XG_BC_HALO needs xg_stencil1d_halo");
+  return stencil1d_impl(op, in, nullptr, out, shape, ndim, axis, n_out, pad_lo, pad_hi, bc, fill, m_in, m_in_strides,
+                        m_out, m_out_strides, stream);
+}
+
+int XG_FN(xg_stencil1d_halo)(int op, const real* in, const real* halo, real* out, const int64_t* shape, int ndim,
+                          int axis, int64_t n_out, int pad_lo, int pad_hi, const real* m_out,
+                          const int64_t* m_out_strides, void* stream) {
+  if (!halo && (pad_lo || pad_hi)) return fail(XG_ERR_INVALID, "NULL halo buffer");
+  return stencil1d_impl(op, in, halo, out, shape, ndim, axis, n_out, pad_lo, pad_hi,
+                        (pad_lo || pad_hi) ? XG_BC_HALO : XG_BC_NONE, real(0), nullptr, nullptr, m_out, m_out_strides,
+                        stream);
+}
+
+int XG_FN(xg_stencil2d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,
+                     int padx_lo, int padx_hi, int bc_x, real fill_x, int pady_lo, int pady_hi, int bc_y,
+                     real fill_y, void* stream) {
+  if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
+  if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
+  if (order != 0 && order != 1) return fail(XG_ERR_INVALID, "order must be 0 (X then Y) or 1 (Y then X)");
+  if (padx_lo + padx_hi != 1 || pady_lo + pady_hi != 1 || ((padx_lo | padx_hi | pady_lo | pady_hi) & ~1))
+    return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil needs length-preserving pads (1,0) or (0,1) on both axes");
+  if (bc_x < XG_BC_PERIODIC || bc_x > XG_BC_EXTEND || bc_y < XG_BC_PERIODIC || bc_y > XG_BC_EXTEND)
+    return fail(XG_ERR_INVALID, "fused 2-D stencil needs a boundary mode on both axes");
+  const int64_t ny = shape[ndim - 2], nx = shape[ndim - 1];
+  int64_t outer = 1;
+  for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
+  if (outer == 0 || ny == 0 || nx == 0) return XG_OK;
+  if (nx % NV || !aligned16(in) || !aligned16(out)) return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil needs an X extent that is a multiple of the 16-byte lane vector");
+  constexpr int SEG = 4;
+  const u64 ntile = (u64)((nx + NV * WAVE - 1) / (NV * WAVE));
+  const u64 nseg = (u64)((ny + SEG - 1) / SEG);
+  const u64 per_outer = ntile * nseg;
+  if (per_outer > MAX_ITEMS) return fail(XG_ERR_UNSUPPORTED, "extent too large for the 2-D stencil kernel");
+  const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
+  const u64 outer_per = MAX_ITEMS / per_outer;
+  hipStream_t st = (hipStream_t)stream;
+  const bool nts = tune().nt_store;
+  for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_per) {
+    const u32 nouter = (u32)((outer - o0 < (int64_t)outer_per) ? outer - o0 : (int64_t)outer_per);
+    const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
+    const u32 grid = ((nblk + 7) / 8) * 8;
+#define XG_GO(O, NTS) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order, padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y)
+#define XG_O(O) do { if (nts) XG_GO(O, true); else XG_GO(O, false); } while (0)
+    switch (op) { case XG_OP_DIFF: XG_O(XG_OP_DIFF); break; case XG_OP_INTERP: XG_O(XG_OP_INTERP); break; case XG_OP_MIN: XG_O(XG_OP_MIN); break; default: XG_O(XG_OP_MAX); }
+#undef XG_O
+#undef XG_GO
+  }
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,424 @@
+// xg_transform.hip -- vertical coordinate transform: linear / log interpolation and conservative remapping (K9a, K9b)
+// Part of libxgcm_hip.so; compiled twice (real = double / -DXG_F32), see xg_common.hpp.
+
+#include "xg_common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// vertical coordinate transform (next-row f4; reference xgcm/transform.py:15-142, numba gufuncs)
+//
+// One thread = one column (all other dims); lanes run along the innermost dim, so every step of
+// the column loops is a coalesced access when the transform axis is not the contiguous one.
+//
+// K9a linear: numpy.interp(target, theta, phi) per column, restated step for step because the
+//   result on NaN-laden or duplicated theta depends on the search path: the guess carried from one
+//   target level to the next, the +-1 probes, the 8-element window, then bisection
+//   (numpy/_core/src/multiarray/compiled_base.c; numba's np.interp is a port of the same code).
+//   Arithmetic is double whatever the storage type, as in numpy/numba.
+// K9b conservative: the reference's O(n*m) accumulation; per output bin the contributions are
+//   added in source-level order (the order of the reference's outer loop), JT bins per pass held
+//   in registers so that the column is re-read m/JT times instead of m times; a cell that misses
+//   the whole (sorted) tile of bins is rejected with two compares.
+// Measured dead end: staging each column in LDS ([level][lane], 64-lane blocks) made every probe
+//   an LDS hit but left 2 waves per CU -- linear 12.8 -> 18.9 ms, conservative 18.5 -> 61.9 ms on
+//   the 75 x 2400 x 3600 case; the kernels therefore run at full occupancy on global memory.
+// ------------------------------------------------------------------------------------------
+template <typename F>
+__device__ __forceinline__ int64_t interp_search(double key, F xp, int64_t len, int64_t guess) {
+  int64_t imin = 0, imax = len;
+  if (key > xp(len - 1)) return len;
+  else if (key < xp(0)) return -1;
+  if (len <= 4) {
+    int64_t i;
+    for (i = 1; i < len && key >= xp(i); ++i) {}
+    return i - 1;
+  }
+  if (guess > len - 3) guess = len - 3;
+  if (guess < 1) guess = 1;
+  if (key < xp(guess)) {
+    if (key < xp(guess - 1)) {
+      imax = guess - 1;
+      if (guess > 8 && key >= xp(guess - 8)) imin = guess - 8;
+    } else {
+      return guess - 1;
+    }
+  } else {
+    if (key < xp(guess + 1)) return guess;
+    if (key < xp(guess + 2)) return guess + 1;
+    imin = guess + 2;
+    if (guess < len - 8 - 1 && key < xp(guess + 8)) imax = guess + 8;
+  }
+  while (imin < imax) {
+    const int64_t imid = imin + ((imax - imin) >> 1);
+    if (key >= xp(imid)) imin = imid + 1;
+    else imax = imid;
+  }
+  return imin - 1;
+}
+
+// np.log in the storage type: evaluated in double and rounded once (float32: correctly rounded
+// up to double-rounding ties; numpy's own float32 log is a few-ulp SIMD routine, so method="log"
+// is a tolerance comparison in float32, not a bit-exact one)
+__device__ __forceinline__ real xg_log_store(real v) { return (real)log((double)v); }
+
+// one interpolated value from the bracketing pair, numpy's formula and NaN fall-backs
+__device__ __forceinline__ double interp_pair(double xv, double xj, double xj1, double fj, double fj1) {
+  const double slope = (fj1 - fj) / (xj1 - xj);
+  double res = slope * (xv - xj) + fj;
+  if (res != res) {
+    res = slope * (xv - xj1) + fj1;
+    if (res != res && fj == fj1) res = fj;
+  }
+  return res;
+}
+
+template <bool LOG>
+__global__ __launch_bounds__(BLOCK) void k_transform_linear(
+    const real* __restrict__ phi, const real* __restrict__ theta, const real* __restrict__ target,
+    real* __restrict__ out, Geo g, MIdx mt, MIdx mg, int mask_edges, int bypass_checks, int fast_path) {
+  const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= g.outer * g.inner) return;
+  const int64_t inner = g.inner, n = g.n_in, m = g.n_out;
+  const int64_t o = c / inner, x = c - o * inner;
+  const real* pphi = phi + (o * n) * inner + x;
+  const real* pth = theta + outer_off(g, mt, o) + inner_off(g, mt, x);
+  const real* ptg = target + outer_off(g, mg, o) + inner_off(g, mg, x);
+  real* pout = out + (o * m) * inner + x;
+  // theta as the reference sees it: the storage type's log first (np.log in interp_1d_linear)
+  auto TH = [&](int64_t k) -> real { real v = pth[k * mt.axis]; return LOG ? xg_log_store(v) : v; };
+  auto LEV = [&](int64_t i) -> real { real v = ptg[i * mg.axis]; return LOG ? xg_log_store(v) : v; };
+
+  // ---- fast path: a well-formed column (no NaN, monotonic theta) and non-decreasing, NaN-free
+  // targets.  numpy's search then returns max{j: xp[j] <= key} whatever its probing path, so the
+  // column is streamed ONCE level by level (coalesced across lanes) while a per-lane cursor walks
+  // the targets; any violation met on the way sends the lane to the exact path below, which
+  // rewrites every output of the column.
+  bool exact = !fast_path || n < 2;
+  if (!exact) {
+    const real a0 = TH(0), a1 = TH(n - 1);
+    if (a0 != a0 || a1 != a1) exact = true;
+    else {
+      const bool flip = !bypass_checks && (a1 < a0);
+      const real tmin = flip ? a1 : a0, tmax = flip ? a0 : a1;  // == nanmin / nanmax once monotonic
+      if (bypass_checks && a1 < a0) exact = true;               // decreasing but not flipped: numpy's path decides
+      int64_t i = 0;
+      double xk = (double)(flip ? a1 : a0);
+      double fk = (double)pphi[(flip ? n - 1 : 0) * inner];
+      const double lval = fk;
+      // the cursor's current target level, loaded once per target and validated on load
+      real lev = LEV(0);
+      if (lev != lev) exact = true;
+      auto emit_and_advance = [&](double res) {
+        real r = (real)res;
+        if (mask_edges && (lev < tmin || lev > tmax)) r = (real)NAN;
+        pout[i * inner] = r;
+        ++i;
+        if (i < m) {
+          const real nxt = LEV(i);
+          if (nxt != nxt || nxt < lev) exact = true;
+          lev = nxt;
+        }
+      };
+      constexpr int UT = 8;  // levels fetched ahead of use: the column loads do not wait on each other
+      for (int64_t k0 = 1; k0 < n && !exact; k0 += UT) {
+        real tvs[UT], fvs[UT];
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+          const int64_t k = (k0 + u < n) ? k0 + u : n - 1;
+          const int64_t kk = flip ? n - 1 - k : k;
+          tvs[u] = TH(kk);
+          fvs[u] = pphi[kk * inner];
+        }
+#pragma unroll
+        for (int u = 0; u < UT; ++u) {
+          if (k0 + u >= n || exact) break;
+          const real tv = tvs[u];
+          const double xk1 = (double)tv, fk1 = (double)fvs[u];
+          if (tv != tv || xk1 < xk) { exact = true; break; }
+          while (i < m && !exact) {
+            const double xv = (double)lev;
+            if (!(xv < xk1)) break;          // belongs to a later interval (or to the right edge)
+            double res;
+            if (xv < xk) res = lval;         // only possible in the first interval: left of the column
+            else if (xv == xk) res = fk;
+            else res = interp_pair(xv, xk, xk1, fk, fk1);
+            emit_and_advance(res);
+          }
+          xk = xk1; fk = fk1;
+        }
+      }
+      // remaining targets are >= xp[n-1]: the last point itself (fp[n-1]) or right of it (rval == fp[n-1])
+      while (i < m && !exact) emit_and_advance(fk);
+    }
+    if (!exact) return;
+  }
+
+  // ---- exact path: numpy's search, probe for probe
+  bool flip = false;
+  real tmin = real(0), tmax = real(0);
+  bool have = false;
+  if (!bypass_checks || mask_edges) {
+    real first = real(0), last = real(0);
+    for (int64_t k = 0; k < n; ++k) {
+      const real v = TH(k);
+      if (v != v) continue;
+      if (!have) { first = v; tmin = v; tmax = v; have = true; }
+      last = v;
+      tmin = (v < tmin) ? v : tmin;
+      tmax = (v > tmax) ? v : tmax;
+    }
+    if (!bypass_checks && have) flip = last < first;
+  }
+  auto XP = [&](int64_t k) -> double { return (double)TH(flip ? n - 1 - k : k); };
+  auto FP = [&](int64_t k) -> double { return (double)pphi[(flip ? n - 1 - k : k) * inner]; };
+
+  const double lval = FP(0), rval = FP(n - 1);
+  int64_t j = 0;
+  for (int64_t i = 0; i < m; ++i) {
+    const real lev = LEV(i);
+    const double xv = (double)lev;
+    double res;
+    if (xv != xv) {
+      res = xv;
+    } else if (n == 1) {
+      const double x0 = XP(0);
+      res = (xv < x0) ? lval : ((xv > x0) ? rval : FP(0));
+    } else {
+      j = interp_search(xv, XP, n, j);
+      if (j == -1) res = lval;
+      else if (j == n) res = rval;
+      else if (j == n - 1) res = FP(j);
+      else {
+        const double xj = XP(j);
+        if (xj == xv) res = FP(j);
+        else res = interp_pair(xv, xj, XP(j + 1), FP(j), FP(j + 1));
+      }
+    }
+    real r = (real)res;
+    if (mask_edges && have && (lev < tmin || lev > tmax)) r = (real)NAN;
+    pout[i * inner] = r;
+  }
+}
+
+template <int JT>
+__global__ __launch_bounds__(BLOCK) void k_transform_conservative(
+    const real* __restrict__ phi, const real* __restrict__ theta, const real* __restrict__ bins,
+    real* __restrict__ out, Geo g, MIdx mt) {
+  const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (c >= g.outer * g.inner) return;
+  const int64_t inner = g.inner, n = g.n_in, m = g.n_out;
+  const int64_t o = c / inner, x = c - o * inner;
+  const real* pphi = phi + (o * n) * inner + x;
+  const real* pth = theta + outer_off(g, mt, o) + inner_off(g, mt, x);
+  real* pout = out + (o * m) * inner + x;
+  for (int64_t j0 = 0; j0 < m; j0 += JT) {
+    real acc[JT], b1[JT], b2[JT];
+#pragma unroll
+    for (int t = 0; t < JT; ++t) {
+      const int64_t j = (j0 + t < m) ? j0 + t : m - 1;
+      acc[t] = (real)NAN;
+      b1[t] = bins[j];
+      b2[t] = bins[j + 1];
+    }
+    real t1 = pth[0];
+    constexpr int UT = 4;  // cells fetched ahead of use (the loads of a pass do not depend on each other)
+    for (int64_t i0 = 0; i0 < n; i0 += UT) {
+      real tts[UT], pps[UT];
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int64_t i = (i0 + u < n) ? i0 + u : n - 1;
+        tts[u] = pth[(i + 1) * mt.axis];
+        pps[u] = pphi[i * inner];
+      }
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        if (i0 + u >= n) break;
+        const real t2 = tts[u], p = pps[u];
+        const real a1 = t1;
+        t1 = t2;
+        const bool n1 = a1 != a1, n2 = t2 != t2;
+        if (n1 && n2) continue;
+        real lo_, hi_;
+        if (n1) { lo_ = hi_ = t2; }
+        else if (n2) { lo_ = hi_ = a1; }
+        else if (a1 < t2) { lo_ = a1; hi_ = t2; }
+        else { lo_ = t2; hi_ = a1; }
+        if (p != p) continue;
+        if (b1[0] > hi_ || b2[JT - 1] < lo_) continue;  // bins increase: the cell misses this whole tile
+#pragma unroll
+        for (int t = 0; t < JT; ++t) {
+          if (b1[t] > hi_ || b2[t] < lo_) continue;
+          real add;
+          if (hi_ == lo_) {
+            add = p;
+          } else {
+            const real hmin = (b1[t] > lo_) ? b1[t] : lo_;  // python max(theta_min, theta_hat_1)
+            const real hmax = (b2[t] < hi_) ? b2[t] : hi_;  // python min(theta_max, theta_hat_2)
+            const real alpha = (hmax - hmin) / (hi_ - lo_);
+            add = alpha * p;
+          }
+          acc[t] = (acc[t] != acc[t]) ? add : acc[t] + add;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < JT; ++t)
+      if (j0 + t < m) pout[(j0 + t) * inner] = acc[t];
+  }
+}
+
+// K9c conservative, accumulators in LDS: cell-major order like the reference's loops.  Each lane
+// owns m accumulator slots ([bin][lane] layout) and a cursor into the sorted bin edges, so a cell
+// only visits the bins it overlaps (1-3 for stratified columns) instead of testing all m; per bin
+// the additions still arrive in cell order => same bits as K9b / the reference.  Column data is
+// streamed once (2n + 1 loads per column, coalesced).
+constexpr int CTB = 128;
+#ifndef XG_CONS_UT
+#define XG_CONS_UT 16
+#endif
+extern __shared__ __align__(16) unsigned char xg_dyn_lds[];
+
+__global__ __launch_bounds__(CTB) void k_transform_conservative_lds(
+    const real* __restrict__ phi, const real* __restrict__ theta, const real* __restrict__ bins,
+    real* __restrict__ out, Geo g, MIdx mt) {
+  const int64_t inner = g.inner, n = g.n_in, m = g.n_out;
+  real* sb = reinterpret_cast<real*>(xg_dyn_lds);          // m + 1 edges, padded to an even count
+  real* acc = sb + ((m + 2) & ~(int64_t)1) + threadIdx.x;  // slot of bin j: acc[j * CTB]
+  for (int64_t j = threadIdx.x; j <= m; j += CTB) sb[j] = bins[j];
+  __syncthreads();
+  const int64_t c = (int64_t)blockIdx.x * CTB + threadIdx.x;
+  if (c >= g.outer * g.inner) return;
+  const int64_t o = c / inner, x = c - o * inner;
+  const real* pphi = phi + (o * n) * inner + x;
+  const real* pth = theta + outer_off(g, mt, o) + inner_off(g, mt, x);
+  real* pout = out + (o * m) * inner + x;
+  for (int64_t j = 0; j < m; ++j) acc[j * CTB] = (real)NAN;
+  // cursor bin jlo with its two edges and its accumulator held in registers: a stratified column
+  // stays in the same bin for several cells, which then cost no LDS round trip at all
+  int jlo = 0;
+  const int mm = (int)m;
+  real e_lo = sb[0], e_hi = sb[1], a_cur = (real)NAN;
+  auto move_to = [&](int j) {
+    acc[jlo * CTB] = a_cur;
+    jlo = j;
+    e_lo = sb[j]; e_hi = sb[j + 1];
+    a_cur = acc[j * CTB];
+  };
+  real t1 = pth[0];
+  constexpr int UT = XG_CONS_UT;
+  for (int64_t i0 = 0; i0 < n; i0 += UT) {
+    real tts[UT], pps[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int64_t i = (i0 + u < n) ? i0 + u : n - 1;
+      tts[u] = pth[(i + 1) * mt.axis];
+      pps[u] = pphi[i * inner];
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      if (i0 + u >= n) break;
+      const real t2 = tts[u], p = pps[u];
+      const real a1 = t1;
+      t1 = t2;
+      const bool n1 = a1 != a1, n2 = t2 != t2;
+      if (n1 && n2) continue;
+      real lo_, hi_;
+      if (n1) { lo_ = hi_ = t2; }
+      else if (n2) { lo_ = hi_ = a1; }
+      else if (a1 < t2) { lo_ = a1; hi_ = t2; }
+      else { lo_ = t2; hi_ = a1; }
+      if (p != p) continue;
+      // first bin whose upper edge reaches the cell: min{j: edge[j+1] >= lo}
+      if ((jlo > 0 && e_lo >= lo_) || (e_hi < lo_ && jlo < mm - 1)) {
+        int j = jlo;
+        while (j > 0 && sb[j] >= lo_) --j;
+        while (j < mm - 1 && sb[j + 1] < lo_) ++j;
+        move_to(j);
+      }
+      if (e_hi < lo_ || e_lo > hi_) continue;  // the cell lies above the last bin / below this one: no overlap at all
+      auto share = [&](real e1, real e2) -> real {
+        if (hi_ == lo_) return p;
+        const real hmin = (e1 > lo_) ? e1 : lo_;
+        const real hmax = (e2 < hi_) ? e2 : hi_;
+        const real alpha = (hmax - hmin) / (hi_ - lo_);
+        return alpha * p;
+      };
+      {
+        const real add = share(e_lo, e_hi);
+        a_cur = (a_cur != a_cur) ? add : a_cur + add;
+      }
+      real e1 = e_hi;
+      for (int j = jlo + 1; j < mm; ++j) {   // further bins the cell reaches into (through LDS)
+        if (e1 > hi_) break;
+        const real e2 = sb[j + 1];
+        const real add = share(e1, e2);
+        const real old = acc[j * CTB];
+        acc[j * CTB] = (old != old) ? add : old + add;
+        e1 = e2;
+      }
+    }
+  }
+  acc[jlo * CTB] = a_cur;
+  for (int64_t j = 0; j < m; ++j) pout[j * inner] = acc[j * CTB];
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int XG_FN(xg_transform_linear)(const real* phi, const real* theta, const int64_t* theta_strides, const real* target,
+                            const int64_t* target_strides, int64_t m, real* out, const int64_t* shape, int ndim,
+                            int axis, int mask_edges, int bypass_checks, int logarithmic, void* stream) {
+  if (!phi || !theta || !target || !out || !shape || !theta_strides || !target_strides)
+    return fail(XG_ERR_INVALID, "NULL argument");
+  if (m < 0) return fail(XG_ERR_INVALID, "negative number of target levels");
+  Geo g; MIdx mt, mg;
+  int rc = build_geo(shape, ndim, axis, m, theta_strides, target_strides, &g, &mt, &mg);
+  if (rc) return rc;
+  if (g.n_in < 1) return fail(XG_ERR_INVALID, "empty transform axis");
+  const int64_t cols = g.outer * g.inner;
+  if (cols == 0 || m == 0) return XG_OK;
+  const u64 nblocks = ((u64)cols + BLOCK - 1) / BLOCK;
+  if ((rc = check_grid(nblocks))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int fast = tune().transform_fast;
+  if (logarithmic) hipLaunchKernelGGL((k_transform_linear<true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
+  else hipLaunchKernelGGL((k_transform_linear<false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int XG_FN(xg_transform_conservative)(const real* phi, const real* theta, const int64_t* theta_strides, const real* bins,
+                                  int64_t n_edges, real* out, const int64_t* shape, int ndim, int axis,
+                                  void* stream) {
+  if (!phi || !theta || !bins || !out || !shape || !theta_strides) return fail(XG_ERR_INVALID, "NULL argument");
+  if (n_edges < 2) return fail(XG_ERR_INVALID, "need at least two bin edges");
+  Geo g; MIdx mt;
+  int rc = build_geo(shape, ndim, axis, n_edges - 1, theta_strides, nullptr, &g, &mt, nullptr);
+  if (rc) return rc;
+  const int64_t cols = g.outer * g.inner;
+  if (cols == 0) return XG_OK;
+  const int64_t m = n_edges - 1;
+  const size_t lds = ((size_t)((m + 2) & ~(int64_t)1) + (size_t)m * CTB) * sizeof(real);
+  if (tune().transform_lds_kb > 0 && lds <= (size_t)tune().transform_lds_kb * 1024u) {
+    const u64 nblocks = ((u64)cols + CTB - 1) / CTB;
+    if ((rc = check_grid(nblocks))) return rc;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void*)k_transform_conservative_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(XG_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", lds, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(k_transform_conservative_lds, dim3((u32)nblocks), dim3(CTB), lds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+  } else {
+    const u64 nblocks = ((u64)cols + BLOCK - 1) / BLOCK;
+    if ((rc = check_grid(nblocks))) return rc;
+    hipLaunchKernelGGL((k_transform_conservative<8>), dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+  }
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+}  // extern "C"

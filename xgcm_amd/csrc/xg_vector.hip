@@ -1,0 +1,571 @@
+// xg_vector.hip -- fused two-component operators (vorticity K7, divergence K7b, gradient / flux K7c) and the broadcasting binary op
+// Part of libxgcm_hip.so; compiled twice (real = double / -DXG_F32), see xg_common.hpp.
+
+#include "xg_common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// broadcasting binary op (out C-contiguous, a/b addressed through strides; dims pre-coalesced)
+// ------------------------------------------------------------------------------------------
+struct BinGeo {
+  int ndim;
+  int64_t total;  // number of V-wide items
+  int64_t shape[XG_MAX_NDIM];  // shape[ndim-1] counts V-wide items
+  int64_t sa[XG_MAX_NDIM], sb[XG_MAX_NDIM];
+};
+
+template <int BOP> __device__ __forceinline__ real bin2(real a, real b) {
+  if (BOP == XG_BIN_MUL) return a * b;
+  if (BOP == XG_BIN_DIV) return a / b;
+  if (BOP == XG_BIN_ADD) return a + b;
+  return a - b;
+}
+
+template <int BOP, int V, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, const real* __restrict__ b,
+                                                  real* __restrict__ out, BinGeo g, ZBand zb) {
+  typedef typename VecT<V>::type T;
+  int64_t gid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (zb.on) {
+    // (Z, P) items with one operand broadcast along Z (da / dx(Y,X)): band-major order keeps the
+    // band of the small operand in L2 while all Z levels of the band stream by (as in K1 / K2S)
+    u32 z, pin;
+    if (gid >= (int64_t)zb.per_band.d * ((zb.Y + zb.B - 1) / zb.B)) return;
+    if (!zband_map(zb, (u32)gid, z, pin)) return;
+    gid = (int64_t)z * zb.Y + pin;
+  }
+  if (gid >= g.total) return;
+  int64_t r = gid, oa = 0, ob = 0;
+#pragma unroll
+  for (int d = XG_MAX_NDIM - 1; d >= 0; --d) {
+    if (d < g.ndim) {
+      int64_t s = g.shape[d];
+      int64_t q = r / s;
+      int64_t c = r - q * s;
+      if (d == g.ndim - 1) c *= V;
+      oa += c * g.sa[d];
+      ob += c * g.sb[d];
+      r = q;
+    }
+  }
+  const int64_t sa_in = g.sa[g.ndim - 1], sb_in = g.sb[g.ndim - 1];
+  if (V > 1) {
+    dv av, bv, o;
+    if (sa_in == 1) av = *reinterpret_cast<const dv*>(a + oa);
+    else {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) av[k] = a[oa + k * sa_in];
+    }
+    if (sb_in == 1) bv = *reinterpret_cast<const dv*>(b + ob);
+    else {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) bv[k] = b[ob + k * sb_in];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) o[k] = bin2<BOP>(av[k], bv[k]);
+    stg<dv, NTS>(out + gid * NV, o);
+  } else {
+    stg<real, NTS>(out + gid, bin2<BOP>(a[oa], b[ob]));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7: fused relative vorticity ((v[j,i]-v[j,i-1]) - (u[j,i]-u[j-1,i])) / area, view (outer,Y,X).
+// Same shape as K2S: lanes along X (V=2 when nx even), XCD-banded waves, each wave register-marches
+// SEG rows of Y: SEG+1 rows of u (the j-1 halo row is an L2 hit), SEG rows of v plus the 8-byte
+// left neighbour (same cache lines), SEG rows of area.  24 B/cell instead of 56 B unfused.
+// ------------------------------------------------------------------------------------------
+// offset of the (Y, X) plane of `area` that belongs to outer index o: the leading dims of the field
+// that the area does not have broadcast (stride 0), the others advance it (e.g. a field (Z, face, j, i)
+// with rAz(face, j, i)); dims are peeled innermost-first with multiply-shift division on the scalar unit
+struct AreaIdx {
+  int n;
+  FastDiv fd[XG_MAX_NDIM];
+  int64_t stride[XG_MAX_NDIM];
+};
+__device__ __forceinline__ int64_t area_outer_off(const AreaIdx& ai, int64_t o) {
+  int64_t off = 0;
+  u32 rem = (u32)o;
+#pragma unroll
+  for (int d = XG_MAX_NDIM - 1; d >= 0; --d) {
+    if (d < ai.n) {
+      const u32 q = fdiv(rem, ai.fd[d]);
+      off += (int64_t)(rem - q * ai.fd[d].d) * ai.stride[d];
+      rem = q;
+    }
+  }
+  return off;
+}
+
+template <int V, bool HAS_AREA, bool NTS, int SEG>
+__global__ __launch_bounds__(BLOCK) void k_vorticity(
+    const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ area,
+    real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile,
+    FastDiv nseg, ZBand zb, int bc_x, real fill_x, int bc_y, real fill_y, AreaIdx ai, int64_t a_sy,
+    int64_t a_sx, const real* __restrict__ halo_x, const real* __restrict__ halo_y) {
+  typedef typename VecT<V>::type T;
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
+  const u32 r = fdiv(w, ntile);
+  const u32 tile = w - r * ntile.d;
+  u32 oo, sg;
+  if (HAS_AREA && zb.on) {  // band-major: a (Y,X) area band stays in the XCD's L2 for all levels
+    if (!zband_map(zb, r, oo, sg)) return;
+  } else {
+    oo = fdiv(r, nseg);
+    if (oo >= nouter) return;
+    sg = r - oo * nseg.d;
+  }
+  const int64_t o = o0 + oo;
+  const int64_t a_base = HAS_AREA ? area_outer_off(ai, o) : 0;
+  const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
+  if (i0 >= nx) return;
+  const int64_t j0 = (int64_t)sg * SEG;
+  const int64_t nrow = (ny - j0 < SEG) ? ny - j0 : SEG;
+  const real* pu = u + o * ny * nx + i0;
+  const real* pv = v + (o * ny + j0) * nx;
+  real* po = out + (o * ny + j0) * nx + i0;
+  const bool edge = (i0 == 0);
+  const int64_t nidx = edge ? ((bc_x == XG_BC_PERIODIC) ? nx - 1 : 0) : i0 - 1;
+  const bool fill_edge = edge && (bc_x == XG_BC_FILL);
+
+  T uu[SEG + 1], vv[SEG];
+  real vl[SEG];
+  {
+    int64_t q = j0 - 1;
+    bool f = false;
+    const real* src = pu + q * nx;
+    if (q < 0) {
+      f = (bc_y == XG_BC_FILL);
+      src = pu + ((bc_y == XG_BC_PERIODIC) ? ny - 1 : 0) * nx;
+      if (bc_y == XG_BC_HALO) src = halo_y + o * nx + i0;  // pre-gathered row below the first one: (outer, 1, X)
+    }
+    T t = *reinterpret_cast<const T*>(src);
+    uu[0] = f ? splat<T>(fill_y) : t;
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < SEG; ++s_) {
+    const int64_t jr = (s_ < nrow) ? s_ : nrow - 1;  // clamp inside the array for short tails
+    uu[s_ + 1] = *reinterpret_cast<const T*>(pu + (j0 + jr) * nx);
+    vv[s_] = *reinterpret_cast<const T*>(pv + jr * nx + i0);
+    vl[s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[o * ny + j0 + jr]  // pre-gathered column left of the first: (outer, Y, 1)
+                                          : pv[jr * nx + nidx];
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < SEG; ++s_) {
+    if (s_ < nrow) {
+      const real left = fill_edge ? fill_x : vl[s_];
+      T z = dvdx_of(vv[s_], left) - (uu[s_ + 1] - uu[s_]);
+      if (HAS_AREA) z = z / ldm<T>(area, a_base + (j0 + s_) * a_sy + i0 * a_sx, a_sx);
+      stg<T, NTS>(po + s_ * nx, z);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7b: fused horizontal divergence (delta_x u + delta_y v) / area of docs/ufunc_examples.md
+// ("Divergence": u on (Y:center, X:left), v on (Y:left, X:center), both left -> center, i.e.
+// padding_width (0,1) on both axes).  Mirror image of K7: SEG rows of u with their right
+// neighbour, SEG+1 rows of v (the last one is the upper halo row of the segment).
+// ------------------------------------------------------------------------------------------
+template <int V, bool HAS_AREA, bool NTS, int SEG>
+__global__ __launch_bounds__(BLOCK) void k_divergence(
+    const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ area,
+    real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile,
+    FastDiv nseg, ZBand zb, int bc_x, real fill_x, int bc_y, real fill_y, AreaIdx ai, int64_t a_sy,
+    int64_t a_sx, const real* __restrict__ halo_x, const real* __restrict__ halo_y) {
+  typedef typename VecT<V>::type T;
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
+  const u32 r = fdiv(w, ntile);
+  const u32 tile = w - r * ntile.d;
+  u32 oo, sg;
+  if (HAS_AREA && zb.on) {
+    if (!zband_map(zb, r, oo, sg)) return;
+  } else {
+    oo = fdiv(r, nseg);
+    if (oo >= nouter) return;
+    sg = r - oo * nseg.d;
+  }
+  const int64_t o = o0 + oo;
+  const int64_t a_base = HAS_AREA ? area_outer_off(ai, o) : 0;
+  const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
+  if (i0 >= nx) return;
+  const int64_t j0 = (int64_t)sg * SEG;
+  const int64_t nrow = (ny - j0 < SEG) ? ny - j0 : SEG;
+  const real* pu = u + (o * ny + j0) * nx;
+  const real* pv = v + o * ny * nx + i0;
+  real* po = out + (o * ny + j0) * nx + i0;
+  const bool edge = (i0 + V >= nx);
+  const int64_t ridx = edge ? ((bc_x == XG_BC_PERIODIC) ? 0 : nx - 1) : i0 + V;
+  const bool fill_edge = edge && (bc_x == XG_BC_FILL);
+
+  T uu[SEG], vv[SEG + 1];
+  real ur[SEG];
+#pragma unroll
+  for (int s_ = 0; s_ < SEG; ++s_) {
+    const int64_t jr = (s_ < nrow) ? s_ : nrow - 1;
+    uu[s_] = *reinterpret_cast<const T*>(pu + jr * nx + i0);
+    ur[s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[o * ny + j0 + jr]  // pre-gathered column right of the last: (outer, Y, 1)
+                                          : pu[jr * nx + ridx];
+    vv[s_] = *reinterpret_cast<const T*>(pv + (j0 + jr) * nx);
+  }
+  {
+    int64_t q = j0 + nrow;  // the row above the segment's last row
+    bool f = false;
+    const real* src = pv + q * nx;
+    if (q >= ny) {
+      f = (bc_y == XG_BC_FILL);
+      src = pv + ((bc_y == XG_BC_PERIODIC) ? 0 : ny - 1) * nx;
+      if (bc_y == XG_BC_HALO) src = halo_y + o * nx + i0;  // pre-gathered row above the last one: (outer, 1, X)
+    }
+    T t = *reinterpret_cast<const T*>(src);
+    vv[SEG] = f ? splat<T>(fill_y) : t;
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < SEG; ++s_) {
+    if (s_ < nrow) {
+      const real right = fill_edge ? fill_x : ur[s_];
+      const T up = (s_ + 1 < nrow) ? vv[s_ + 1] : vv[SEG];
+      T z = dudx_fwd(uu[s_], right) + (up - vv[s_]);
+      if (HAS_AREA) z = z / ldm<T>(area, a_base + (j0 + s_) * a_sy + i0 * a_sx, a_sx);
+      stg<T, NTS>(po + s_ * nx, z);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7c: the two remaining fused grid ufuncs of docs/ufunc_examples.md, one field in, TWO fields out:
+//   gradient: gx = (a - a[x-1]) / mx,  gy = (a - a[y-1]) / my      ("Gradient": center -> left on X, Y)
+//   flux:     fx = u * interp(T, X),   fy = v * interp(T, Y)       ("Advection": center -> left on X, Y)
+// Load pattern of K7/K8 (SEG+1 rows of the centre field + the 8-B left neighbour); the field is read
+// once for both outputs: 24 B/cell instead of 32 (gradient), 40 instead of 80 (flux chain).
+// ------------------------------------------------------------------------------------------
+template <int V, int MODE, bool NTS, int SEG>   // MODE 0: gradient (optional metrics), 1: flux
+__global__ __launch_bounds__(BLOCK) void k_pair2d(
+    const real* __restrict__ a, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ out_x,
+    real* __restrict__ out_y, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile, FastDiv nseg,
+    int bc_x, real fill_x, int bc_y, real fill_y, const real* __restrict__ mx, AreaIdx aix, int64_t mx_sy,
+    int64_t mx_sx, const real* __restrict__ my, AreaIdx aiy, int64_t my_sy, int64_t my_sx) {
+  typedef typename VecT<V>::type T;
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
+  const u32 r = fdiv(w, ntile);
+  const u32 tile = w - r * ntile.d;
+  const u32 oo = fdiv(r, nseg);
+  if (oo >= nouter) return;
+  const u32 sg = r - oo * nseg.d;
+  const int64_t o = o0 + oo;
+  const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
+  if (i0 >= nx) return;
+  const int64_t j0 = (int64_t)sg * SEG;
+  const int64_t nrow = (ny - j0 < SEG) ? ny - j0 : SEG;
+  const int64_t base = o * ny * nx;
+  const real* pa = a + base + i0;
+  const bool edge = (i0 == 0);
+  const int64_t nidx = edge ? ((bc_x == XG_BC_PERIODIC) ? nx - 1 : 0) : i0 - 1;
+  const bool fill_edge = edge && (bc_x == XG_BC_FILL);
+  T aa[SEG + 1];
+  real al[SEG];
+  {
+    int64_t q = j0 - 1;
+    bool f = false;
+    if (q < 0) { f = (bc_y == XG_BC_FILL); q = (bc_y == XG_BC_PERIODIC) ? ny - 1 : 0; }
+    const T t = *reinterpret_cast<const T*>(pa + q * nx);
+    aa[0] = f ? splat<T>(fill_y) : t;
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < SEG; ++s_) {
+    const int64_t jr = j0 + ((s_ < nrow) ? s_ : nrow - 1);
+    aa[s_ + 1] = *reinterpret_cast<const T*>(pa + jr * nx);
+    al[s_] = a[base + jr * nx + nidx];
+  }
+  const int64_t mxb = (MODE == 0 && mx) ? area_outer_off(aix, o) : 0;
+  const int64_t myb = (MODE == 0 && my) ? area_outer_off(aiy, o) : 0;
+#pragma unroll
+  for (int s_ = 0; s_ < SEG; ++s_) {
+    if (s_ < nrow) {
+      const int64_t j = j0 + s_;
+      const real left = fill_edge ? fill_x : al[s_];
+      T rx, ry;
+      if (MODE == 0) {
+        rx = dvdx_of(aa[s_ + 1], left);
+        ry = aa[s_ + 1] - aa[s_];
+        if (mx) rx = rx / ldm<T>(mx, mxb + j * mx_sy + i0 * mx_sx, mx_sx);
+        if (my) ry = ry / ldm<T>(my, myb + j * my_sy + i0 * my_sx, my_sx);
+      } else {
+        const T uu = *reinterpret_cast<const T*>(u + base + j * nx + i0);
+        const T vv = *reinterpret_cast<const T*>(v + base + j * nx + i0);
+        rx = uu * interp_left_of(aa[s_ + 1], left);
+        ry = vv * op2<XG_OP_INTERP>(aa[s_], aa[s_ + 1]);
+      }
+      stg<T, NTS>(out_x + base + j * nx + i0, rx);
+      stg<T, NTS>(out_y + base + j * nx + i0, ry);
+    }
+  }
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real* b, const int64_t* b_strides,
+                  real* out, const int64_t* shape, int ndim, void* stream) {
+  if (!a || !b || !out || (ndim > 0 && (!shape || !a_strides || !b_strides))) return fail(XG_ERR_INVALID, "NULL argument");
+  if (op < XG_BIN_MUL || op > XG_BIN_SUB) return fail(XG_ERR_INVALID, "unknown binary op %d", op);
+  if (ndim < 0 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [0,%d]", ndim, XG_MAX_NDIM);
+  BinGeo g;
+  memset(&g, 0, sizeof(g));
+  // drop size-1 dims, coalesce neighbours compatible for BOTH operands
+  int n = 0;
+  int64_t total = 1;
+  for (int d = 0; d < ndim; ++d) {
+    if (shape[d] < 0) return fail(XG_ERR_INVALID, "negative extent");
+    total *= shape[d];
+    if (shape[d] == 1) continue;
+    if (n > 0 && g.sa[n - 1] == a_strides[d] * shape[d] && g.sb[n - 1] == b_strides[d] * shape[d]) {
+      g.shape[n - 1] *= shape[d];
+      g.sa[n - 1] = a_strides[d];
+      g.sb[n - 1] = b_strides[d];
+    } else {
+      g.shape[n] = shape[d];
+      g.sa[n] = a_strides[d];
+      g.sb[n] = b_strides[d];
+      ++n;
+    }
+  }
+  if (total == 0) return XG_OK;
+  if (n == 0) { g.shape[0] = 1; g.sa[0] = 0; g.sb[0] = 0; n = 1; }
+  g.ndim = n;
+  const int64_t last = g.shape[n - 1];
+  const int64_t sa = g.sa[n - 1], sb = g.sb[n - 1];
+  bool v2 = (last % NV == 0) && aligned16(out) && (sa == 0 || sa == 1) && (sb == 0 || sb == 1);
+  if (v2 && sa == 1) {
+    if (!aligned16(a)) v2 = false;
+    for (int d = 0; d < n - 1; ++d) if (g.sa[d] % NV) v2 = false;
+  }
+  if (v2 && sb == 1) {
+    if (!aligned16(b)) v2 = false;
+    for (int d = 0; d < n - 1; ++d) if (g.sb[d] % NV) v2 = false;
+  }
+  const int V = v2 ? NV : 1;
+  g.shape[n - 1] = last / V;
+  g.total = total / V;
+  u64 nitems = (u64)g.total;
+  ZBand zb = make_zband(false, 0, 0, 1);
+  if (tune().zband && n == 2 && (g.sa[0] == 0) != (g.sb[0] == 0) && g.shape[0] >= 2) {
+    // exactly one operand is broadcast along the slow dim and re-read once per level: band it
+    const u64 Z = (u64)g.shape[0], P = (u64)g.shape[1];
+    const u32 B = 16384;  // items per band: 256 KiB of the broadcast operand at 16 B per item
+    const u64 padded = ((P + B - 1) / B) * B * Z;
+    if (P > 2 * (u64)B && padded < 0x7fffffffull) {
+      zb = make_zband(true, Z, P, B);
+      if (zb.on) nitems = padded;
+    }
+  }
+  const u64 nblocks = (nitems + BLOCK - 1) / BLOCK;
+  int rc;
+  if ((rc = check_grid(nblocks))) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const bool nts = tune().nt_store;
+#define XG_GO(O, V_, NTS) hipLaunchKernelGGL((k_binary<O, V_, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, a, b, out, g, zb)
+#define XG_O(O) do { if (V > 1) { if (nts) XG_GO(O, NV, true); else XG_GO(O, NV, false); } else { if (nts) XG_GO(O, 1, true); else XG_GO(O, 1, false); } } while (0)
+  switch (op) { case XG_BIN_MUL: XG_O(XG_BIN_MUL); break; case XG_BIN_DIV: XG_O(XG_BIN_DIV); break; case XG_BIN_ADD: XG_O(XG_BIN_ADD); break; default: XG_O(XG_BIN_SUB); }
+#undef XG_O
+#undef XG_GO
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+static int curl_div_impl(bool div, const real* u, const real* v, const real* area, const int64_t* area_strides,
+                         real* out, const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y,
+                         void* stream, const real* halo_x = nullptr, const real* halo_y = nullptr) {
+  if (!u || !v || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
+  if (area && !area_strides) return fail(XG_ERR_INVALID, "area without strides");
+  if (bc_x < XG_BC_PERIODIC || bc_x > XG_BC_HALO || bc_y < XG_BC_PERIODIC || bc_y > XG_BC_HALO)
+    return fail(XG_ERR_INVALID, "vorticity / divergence need a boundary mode on both axes");
+  if ((bc_x == XG_BC_HALO && !halo_x) || (bc_y == XG_BC_HALO && !halo_y))
+    return fail(XG_ERR_INVALID, "XG_BC_HALO without the halo buffer of that axis");
+  const int64_t ny = shape[ndim - 2], nx = shape[ndim - 1];
+  int64_t outer = 1;
+  for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
+  if (outer == 0 || ny == 0 || nx == 0) return XG_OK;
+  // area: (Y, X) strides + one stride per leading dim (0 = broadcast); adjacent leading dims are merged
+  int64_t a_sy = 0, a_sx = 0;
+  bool area_bcast_all = true;
+  AreaIdx ai;
+  memset(&ai, 0, sizeof(ai));
+  for (int d = 0; d < XG_MAX_NDIM; ++d) ai.fd[d] = make_fastdiv(1);
+  if (area) {
+    a_sy = area_strides[ndim - 2];
+    a_sx = area_strides[ndim - 1];
+    for (int d = 0; d < ndim - 2; ++d) {
+      if (shape[d] == 1) continue;
+      const int64_t st = area_strides[d];
+      if (st != 0) area_bcast_all = false;
+      if (ai.n > 0 && ai.stride[ai.n - 1] == st * shape[d]) {  // merges with the previous (slower) dim
+        ai.fd[ai.n - 1] = make_fastdiv((u64)ai.fd[ai.n - 1].d * (u64)shape[d]);
+        ai.stride[ai.n - 1] = st;
+        continue;
+      }
+      ai.fd[ai.n] = make_fastdiv((u64)shape[d]);
+      ai.stride[ai.n] = st;
+      ++ai.n;
+    }
+    if (outer > 0xffffffffll) return fail(XG_ERR_UNSUPPORTED, "more than 2^32 (Y,X) planes");
+  }
+  const int V = (aligned16(u) && aligned16(v) && aligned16(out) && nx % NV == 0 &&
+                 (bc_y != XG_BC_HALO || aligned16(halo_y))) ? NV : 1;
+  constexpr int SEG = 4;
+  const u64 ntile = (u64)((nx + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
+  const u64 nseg = (u64)((ny + SEG - 1) / SEG);
+  const u64 per_outer = ntile * nseg;
+  if (per_outer > MAX_ITEMS) return fail(XG_ERR_UNSUPPORTED, "extent too large for the vorticity kernel");
+  const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
+  const u64 outer_per = MAX_ITEMS / per_outer;
+  hipStream_t st = (hipStream_t)stream;
+  const bool nts = tune().nt_store;
+  const u32 ZB_SEGS = 4;
+  ZBand zb = make_zband(false, 0, 0, 1);
+  u64 outer_step = outer_per;
+  if (area && area_bcast_all && tune().zband && outer >= 2) {
+    const u64 padded_segs = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS;
+    if (padded_segs * (u64)outer * ntile <= MAX_ITEMS) {
+      zb = make_zband(true, (u64)outer, nseg, ZB_SEGS);
+      if (zb.on) outer_step = (u64)outer;  // one launch over all levels
+    }
+  }
+  for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_step) {
+    const u32 nouter = (u32)((outer - o0 < (int64_t)outer_step) ? outer - o0 : (int64_t)outer_step);
+    const u64 waves = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * (u64)outer * ntile : (u64)nouter * per_outer;
+    const u32 nblk = (u32)((waves + WPB - 1) / WPB);
+    const u32 grid = ((nblk + 7) / 8) * 8;
+#define XG_GO(V_, A_, NTS) do { if (div) hipLaunchKernelGGL((k_divergence<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y); \
+                                else hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y); } while (0)
+#define XG_A(V_, A_) do { if (nts) XG_GO(V_, A_, true); else XG_GO(V_, A_, false); } while (0)
+    if (V > 1) { if (area) XG_A(NV, true); else XG_A(NV, false); }
+    else { if (area) XG_A(1, true); else XG_A(1, false); }
+#undef XG_A
+#undef XG_GO
+  }
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int XG_FN(xg_vorticity)(const real* u, const real* v, const real* area, const int64_t* area_strides, real* out,
+                     const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y, void* stream) {
+  if (bc_x == XG_BC_HALO || bc_y == XG_BC_HALO) return fail(XG_ERR_INVALID, "XG_BC_HALO needs xg_vorticity_halo");
+  return curl_div_impl(false, u, v, area, area_strides, out, shape, ndim, bc_x, fill_x, bc_y, fill_y, stream);
+}
+
+int XG_FN(xg_divergence)(const real* u, const real* v, const real* area, const int64_t* area_strides, real* out,
+                      const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y, void* stream) {
+  if (bc_x == XG_BC_HALO || bc_y == XG_BC_HALO) return fail(XG_ERR_INVALID, "XG_BC_HALO needs xg_divergence_halo");
+  return curl_div_impl(true, u, v, area, area_strides, out, shape, ndim, bc_x, fill_x, bc_y, fill_y, stream);
+}
+
+int XG_FN(xg_vorticity_halo)(const real* u, const real* v, const real* halo_x, const real* halo_y, const real* area,
+                          const int64_t* area_strides, real* out, const int64_t* shape, int ndim, int bc_x,
+                          real fill_x, int bc_y, real fill_y, void* stream) {
+  return curl_div_impl(false, u, v, area, area_strides, out, shape, ndim, bc_x, fill_x, bc_y, fill_y, stream, halo_x, halo_y);
+}
+
+int XG_FN(xg_divergence_halo)(const real* u, const real* v, const real* halo_x, const real* halo_y, const real* area,
+                           const int64_t* area_strides, real* out, const int64_t* shape, int ndim, int bc_x,
+                           real fill_x, int bc_y, real fill_y, void* stream) {
+  return curl_div_impl(true, u, v, area, area_strides, out, shape, ndim, bc_x, fill_x, bc_y, fill_y, stream, halo_x, halo_y);
+}
+
+static int area_index(const real* m, const int64_t* strides, const int64_t* shape, int ndim, AreaIdx* ai, int64_t* sy,
+                      int64_t* sx) {
+  memset(ai, 0, sizeof(*ai));
+  for (int d = 0; d < XG_MAX_NDIM; ++d) ai->fd[d] = make_fastdiv(1);
+  *sy = *sx = 0;
+  if (!m) return 0;
+  if (!strides) return fail(XG_ERR_INVALID, "metric without strides");
+  *sy = strides[ndim - 2];
+  *sx = strides[ndim - 1];
+  for (int d = 0; d < ndim - 2; ++d) {
+    if (shape[d] == 1) continue;
+    const int64_t st = strides[d];
+    if (ai->n > 0 && ai->stride[ai->n - 1] == st * shape[d]) {
+      ai->fd[ai->n - 1] = make_fastdiv((u64)ai->fd[ai->n - 1].d * (u64)shape[d]);
+      ai->stride[ai->n - 1] = st;
+      continue;
+    }
+    ai->fd[ai->n] = make_fastdiv((u64)shape[d]);
+    ai->stride[ai->n] = st;
+    ++ai->n;
+  }
+  return 0;
+}
+
+static int pair2d_impl(int mode, const real* a, const real* u, const real* v, real* out_x, real* out_y,
+                       const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y, const real* mx,
+                       const int64_t* mx_strides, const real* my, const int64_t* my_strides, void* stream) {
+  if (!a || !out_x || !out_y || !shape || (mode == 1 && (!u || !v))) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
+  if (bc_x < XG_BC_PERIODIC || bc_x > XG_BC_EXTEND || bc_y < XG_BC_PERIODIC || bc_y > XG_BC_EXTEND)
+    return fail(XG_ERR_INVALID, "gradient / flux need a boundary mode on both axes");
+  const int64_t ny = shape[ndim - 2], nx = shape[ndim - 1];
+  int64_t outer = 1;
+  for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
+  if (outer == 0 || ny == 0 || nx == 0) return XG_OK;
+  if (outer > 0xffffffffll) return fail(XG_ERR_UNSUPPORTED, "more than 2^32 (Y,X) planes");
+  AreaIdx aix, aiy;
+  int64_t mx_sy, mx_sx, my_sy, my_sx;
+  int rc;
+  if ((rc = area_index(mx, mx_strides, shape, ndim, &aix, &mx_sy, &mx_sx))) return rc;
+  if ((rc = area_index(my, my_strides, shape, ndim, &aiy, &my_sy, &my_sx))) return rc;
+  bool al = aligned16(a) && aligned16(out_x) && aligned16(out_y) && nx % NV == 0;
+  if (mode == 1) al = al && aligned16(u) && aligned16(v);
+  const int V = al ? NV : 1;
+  constexpr int SEG = 4;
+  const u64 ntile = (u64)((nx + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
+  const u64 nseg = (u64)((ny + SEG - 1) / SEG);
+  const u64 per_outer = ntile * nseg;
+  if (per_outer > MAX_ITEMS) return fail(XG_ERR_UNSUPPORTED, "extent too large for the fused two-output kernel");
+  const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
+  const u64 outer_per = MAX_ITEMS / per_outer;
+  hipStream_t st = (hipStream_t)stream;
+  const bool nts = tune().nt_store;
+  for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_per) {
+    const u32 nouter = (u32)((outer - o0 < (int64_t)outer_per) ? outer - o0 : (int64_t)outer_per);
+    const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
+    const u32 grid = ((nblk + 7) / 8) * 8;
+#define XG_GO(V_, M_, NTS) hipLaunchKernelGGL((k_pair2d<V_, M_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, a, u, v, out_x, out_y, o0, nouter, nblk, ny, nx, fnt, fns, bc_x, fill_x, bc_y, fill_y, mx, aix, mx_sy, mx_sx, my, aiy, my_sy, my_sx)
+#define XG_M(V_, M_) do { if (nts) XG_GO(V_, M_, true); else XG_GO(V_, M_, false); } while (0)
+    if (V > 1) { if (mode) XG_M(NV, 1); else XG_M(NV, 0); }
+    else { if (mode) XG_M(1, 1); else XG_M(1, 0); }
+#undef XG_M
+#undef XG_GO
+  }
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int XG_FN(xg_gradient)(const real* a, real* out_x, real* out_y, const int64_t* shape, int ndim, int bc_x, real fill_x,
+                    int bc_y, real fill_y, const real* mx, const int64_t* mx_strides, const real* my,
+                    const int64_t* my_strides, void* stream) {
+  return pair2d_impl(0, a, nullptr, nullptr, out_x, out_y, shape, ndim, bc_x, fill_x, bc_y, fill_y, mx, mx_strides, my,
+                     my_strides, stream);
+}
+
+int XG_FN(xg_flux)(const real* u, const real* v, const real* t, real* out_x, real* out_y, const int64_t* shape, int ndim,
+                int bc_x, real fill_x, int bc_y, real fill_y, void* stream) {
+  return pair2d_impl(1, t, u, v, out_x, out_y, shape, ndim, bc_x, fill_x, bc_y, fill_y, nullptr, nullptr, nullptr, nullptr,
+                     stream);
+}
+
+}  // extern "C"

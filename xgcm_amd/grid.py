@@ -441,8 +441,14 @@ class Grid:
                 else:
                     post_divide = dx  # two successive divisions cannot be merged bit-exactly
             arg = {vector_key: array} if vector_key is not None else array
-            unfusable_metric = m_in is not None and gridops.complex_topology(self, ax_name)
-            if isinstance(ufunc, gridops.HipGridUFunc) and not unfusable_metric:
+            if isinstance(ufunc, gridops.HipGridUFunc):
+                if m_in is not None and gridops.complex_topology(self, ax_name):
+                    # halos come from other faces / the folded row and must be halos of the PRODUCT (the
+                    # reference multiplies first, grid.py:804-808): one product pass, then the halo-fused
+                    # kernel with the output metric -- 2 passes instead of product, padded copy, op, divide
+                    array = array * m_in
+                    arg = {vector_key: array} if vector_key is not None else array
+                    m_in = None
                 array = ufunc(self, arg, axis=[(ax_name,)], other_component=other_component, metric_in=m_in,
                               metric_out=m_out, **remaining)
             else:  # a plain GridUFunc registered in gridops (none of the built-ins): unfused sequence
