@@ -203,6 +203,17 @@ int xg_flux_f64(const double* u, const double* v, const double* t, double* out_x
                 const int64_t* shape, int ndim, int bc_x, double fill_x, int bc_y, double fill_y,
                 void* stream);
 
+/* gradient / flux on a complex topology: an axis whose mode is XG_BC_HALO takes the one-cell halo of
+ * the centre field from a pre-gathered slab, halo_x (..., Y) = the column left of i = 0, halo_y
+ * (..., X) = the row below j = 0 (xg_gather_f64 over the halo-only plane), like xg_vorticity_halo_f64. */
+int xg_gradient_halo_f64(const double* a, const double* halo_x, const double* halo_y, double* out_x,
+                         double* out_y, const int64_t* shape, int ndim, int bc_x, double fill_x,
+                         int bc_y, double fill_y, const double* mx, const int64_t* mx_strides,
+                         const double* my, const int64_t* my_strides, void* stream);
+int xg_flux_halo_f64(const double* u, const double* v, const double* t, const double* halo_x,
+                     const double* halo_y, double* out_x, double* out_y, const int64_t* shape,
+                     int ndim, int bc_x, double fill_x, int bc_y, double fill_y, void* stream);
+
 /* The two fused operators on a complex topology (face connections, north fold): an axis whose
  * boundary mode is XG_BC_HALO takes its one-cell halo from a pre-gathered slab (xg_gather_f64 over
  * the halo cells, vector-component rules included) instead of the array itself:
@@ -282,6 +293,13 @@ int xg_gradient_f32(const float* a, float* out_x, float* out_y, const int64_t* s
 int xg_flux_f32(const float* u, const float* v, const float* t, float* out_x, float* out_y,
                 const int64_t* shape, int ndim, int bc_x, float fill_x, int bc_y, float fill_y,
                 void* stream);
+int xg_gradient_halo_f32(const float* a, const float* halo_x, const float* halo_y, float* out_x,
+                         float* out_y, const int64_t* shape, int ndim, int bc_x, float fill_x, int bc_y,
+                         float fill_y, const float* mx, const int64_t* mx_strides, const float* my,
+                         const int64_t* my_strides, void* stream);
+int xg_flux_halo_f32(const float* u, const float* v, const float* t, const float* halo_x,
+                     const float* halo_y, float* out_x, float* out_y, const int64_t* shape, int ndim,
+                     int bc_x, float fill_x, int bc_y, float fill_y, void* stream);
 int xg_vorticity_halo_f32(const float* u, const float* v, const float* halo_x, const float* halo_y,
                           const float* area, const int64_t* area_strides, float* out,
                           const int64_t* shape, int ndim, int bc_x, float fill_x, int bc_y,

@@ -138,14 +138,25 @@ def divergence(u, v, area, bc_x, bc_y, fill_x=0.0, fill_y=0.0, halo_x=None, halo
     return (dudx + dvdy) / area
 
 
-def gradient(a, bc_x, bc_y, fill_x=0.0, fill_y=0.0, mx=None, my=None):
-    a, mx, my = _cast(_common(a, mx, my), a, mx, my)
-    return R.gradient(a, bc_x, bc_y, fill_x, fill_y, mx, my)
+def gradient(a, bc_x, bc_y, fill_x=0.0, fill_y=0.0, mx=None, my=None, halo_x=None, halo_y=None):
+    a, mx, my = _cast(_common(a, mx, my, halo_x, halo_y), a, mx, my)
+    if bc_x != "halo" and bc_y != "halo":
+        return R.gradient(a, bc_x, bc_y, fill_x, fill_y, mx, my)
+    ax, bx, px = _with_halo(a, halo_x, -1, True, bc_x)
+    ay, by, py = _with_halo(a, halo_y, -2, True, bc_y)
+    gx = R.stencil1d("diff", ax, a.ndim - 1, px[0], px[1], bx, fill_x)
+    gy = R.stencil1d("diff", ay, a.ndim - 2, py[0], py[1], by, fill_y)
+    return (gx if mx is None else gx / mx), (gy if my is None else gy / my)
 
 
-def flux(u, v, t, bc_x, bc_y, fill_x=0.0, fill_y=0.0):
-    u, v, t = _cast(_common(u, v, t), u, v, t)
-    return R.flux(u, v, t, bc_x, bc_y, fill_x, fill_y)
+def flux(u, v, t, bc_x, bc_y, fill_x=0.0, fill_y=0.0, halo_x=None, halo_y=None):
+    u, v, t = _cast(_common(u, v, t, halo_x, halo_y), u, v, t)
+    if bc_x != "halo" and bc_y != "halo":
+        return R.flux(u, v, t, bc_x, bc_y, fill_x, fill_y)
+    tx, bx, px = _with_halo(t, halo_x, -1, True, bc_x)
+    ty, by, py = _with_halo(t, halo_y, -2, True, bc_y)
+    return (u * R.stencil1d("interp", tx, t.ndim - 1, px[0], px[1], bx, fill_x),
+            v * R.stencil1d("interp", ty, t.ndim - 2, py[0], py[1], by, fill_y))
 
 
 def stencil2d_supported(x, padx, pady):

@@ -301,6 +301,36 @@ def test_gradient_and_flux_fused_equal_unfused_chains(dev, shape, dtype):
     _eq(dev.tohost(gy), dev.tohost(dev.stencil1d("diff", a, len(shape) - 2, 1, 0, "extend")))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(3, 9, 64), (2, 70, 33), (5, 6), (2, 2, 130, 258), (3, 5, 4)])
+def test_gradient_and_flux_with_pregathered_halos(dev, shape, dtype):
+    """xg_gradient_halo / xg_flux_halo: the column left of i = 0 and the row below j = 0 come from halo
+    slabs (what complex topologies gather); either axis may keep an ordinary mode."""
+    a = _field(shape, 80).astype(dtype)
+    u = _field(shape, 81).astype(dtype)
+    v = _field(shape, 82).astype(dtype)
+    hx = _field(shape[:-1], 83).astype(dtype)              # (..., Y)
+    hy = _field(shape[:-2] + shape[-1:], 84).astype(dtype)  # (..., X)
+    m = R.synthetic_metric(shape, 85).astype(dtype)
+    ax = np.concatenate([hx[..., None], a], axis=-1)
+    ay = np.concatenate([np.expand_dims(hy, -2), a], axis=-2)
+    nd = len(shape)
+    for bc_x, bc_y in (("halo", "halo"), ("halo", "extend"), ("periodic", "halo"), ("fill", "halo")):
+        ex = R.stencil1d("diff", ax, nd - 1, 0, 0, None) if bc_x == "halo" else R.stencil1d("diff", a, nd - 1, 1, 0, bc_x, dtype(0.25))
+        ey = R.stencil1d("diff", ay, nd - 2, 0, 0, None) if bc_y == "halo" else R.stencil1d("diff", a, nd - 2, 1, 0, bc_y, dtype(-0.5))
+        gx, gy = dev.gradient(a, bc_x, bc_y, 0.25, -0.5, None, None, hx if bc_x == "halo" else None, hy if bc_y == "halo" else None)
+        _eq(dev.tohost(gx), ex)
+        _eq(dev.tohost(gy), ey)
+        gx, gy = dev.gradient(a, bc_x, bc_y, 0.25, -0.5, m, m, hx if bc_x == "halo" else None, hy if bc_y == "halo" else None)
+        _eq(dev.tohost(gx), ex / m)
+        _eq(dev.tohost(gy), ey / m)
+        ix = R.stencil1d("interp", ax, nd - 1, 0, 0, None) if bc_x == "halo" else R.stencil1d("interp", a, nd - 1, 1, 0, bc_x, dtype(0.25))
+        iy = R.stencil1d("interp", ay, nd - 2, 0, 0, None) if bc_y == "halo" else R.stencil1d("interp", a, nd - 2, 1, 0, bc_y, dtype(-0.5))
+        fx, fy = dev.flux(u, v, a, bc_x, bc_y, 0.25, -0.5, hx if bc_x == "halo" else None, hy if bc_y == "halo" else None)
+        _eq(dev.tohost(fx), u * ix)
+        _eq(dev.tohost(fy), v * iy)
+
+
 def test_gradient_metric_broadcast_patterns(dev):
     shape = (3, 2, 6, 8)
     a = _field(shape, 70)

@@ -757,6 +757,47 @@ def test_fused_vorticity_and_divergence_on_connected_grids(backend, conn):
     np.testing.assert_array_equal(div.values, chain.values)
 
 
+@pytest.mark.parametrize("conn", [X_TO_X, X_TO_Y, X_TO_Y_REV, CUBED_SPHERE], ids=["x2x", "x2y", "x2y_rev", "cubed_sphere"])
+def test_fused_gradient_and_flux_on_connected_grids(backend, conn):
+    """One launch (+ two scalar halo gathers) == the two reference operator calls, bit for bit."""
+    nf = 6 if conn is CUBED_SPHERE else 2
+    n = 6
+    rnd = lambda s: R.synthetic_field((3, nf, n, n), 200 + s) + 0.5  # noqa: E731
+    ds = Dataset({"dxl": (("face", "y", "xl"), R.synthetic_metric((nf, n, n), 17)),
+                  "dyl": (("face", "yl", "x"), R.synthetic_metric((nf, n, n), 18))},
+                 coords={"x": np.arange(n), "xl": np.arange(n) - 0.5, "y": np.arange(n), "yl": np.arange(n) - 0.5,
+                         "face": np.arange(nf)})
+    grid = Grid(ds, coords=COORDS, face_connections=conn, padding="fill", metrics={("X",): ["dxl"], ("Y",): ["dyl"]},
+                autoparse_metadata=False)
+    t = DataArray(rnd(0), dims=("z", "face", "y", "x"))
+    u = DataArray(rnd(1), dims=("z", "face", "y", "xl"))
+    v = DataArray(rnd(2), dims=("z", "face", "yl", "x"))
+    for mw, op in ((False, grid.diff), (True, grid.derivative)):
+        gx, gy = grid.gradient(t, fill_value=2.5, metric_weighted=mw)
+        assert gx.dims == ("z", "face", "y", "xl") and gy.dims == ("z", "face", "yl", "x")
+        np.testing.assert_array_equal(gx.values, op(t, "X", fill_value=2.5).values)
+        np.testing.assert_array_equal(gy.values, op(t, "Y", fill_value=2.5).values)
+    fx, fy = grid.flux(u, v, t, fill_value=-1.5)
+    np.testing.assert_array_equal(fx.values, (u * grid.interp(t, "X", fill_value=-1.5)).values)
+    np.testing.assert_array_equal(fy.values, (v * grid.interp(t, "Y", fill_value=-1.5)).values)
+    t32 = DataArray(t.values.astype(np.float32), dims=t.dims)
+    g32 = grid.gradient(t32)
+    assert g32[0].dtype == np.float32
+    np.testing.assert_array_equal(g32[0].values, grid.diff(t32, "X").values)
+    np.testing.assert_array_equal(g32[1].values, grid.diff(t32, "Y").values)
+
+
+def test_fused_gradient_on_a_fold_grid(backend):
+    """tripolar grid: X periodic inside the kernel; the Y halo is the ordinary south mode (center -> left reads
+    row j-1 only), so the fold is not touched -- but the axis still takes the halo route."""
+    ds = _fold_ds()
+    grid = _fold_grid(ds, "corner")
+    t = DataArray(R.synthetic_field((2, Ny, Nx), 113), dims=("z", "yh", "xh"))
+    gx, gy = grid.gradient(t)
+    np.testing.assert_array_equal(gx.values, grid.diff(t, "X").values)
+    np.testing.assert_array_equal(gy.values, grid.diff(t, "Y").values)
+
+
 def test_fused_vorticity_on_a_fold_grid(backend):
     """tripolar grid: X periodic (ordinary mode inside the kernel), Y folded (pre-gathered halo)."""
     ds = _fold_ds()

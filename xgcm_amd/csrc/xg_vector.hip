@@ -251,7 +251,8 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
     const real* __restrict__ a, const real* __restrict__ u, const real* __restrict__ v, real* __restrict__ out_x,
     real* __restrict__ out_y, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile, FastDiv nseg,
     int bc_x, real fill_x, int bc_y, real fill_y, const real* __restrict__ mx, AreaIdx aix, int64_t mx_sy,
-    int64_t mx_sx, const real* __restrict__ my, AreaIdx aiy, int64_t my_sy, int64_t my_sx) {
+    int64_t mx_sx, const real* __restrict__ my, AreaIdx aiy, int64_t my_sy, int64_t my_sx,
+    const real* __restrict__ halo_x, const real* __restrict__ halo_y) {
   typedef typename VecT<V>::type T;
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
@@ -277,15 +278,21 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
   {
     int64_t q = j0 - 1;
     bool f = false;
-    if (q < 0) { f = (bc_y == XG_BC_FILL); q = (bc_y == XG_BC_PERIODIC) ? ny - 1 : 0; }
-    const T t = *reinterpret_cast<const T*>(pa + q * nx);
+    const real* src = pa + q * nx;
+    if (q < 0) {
+      f = (bc_y == XG_BC_FILL);
+      src = pa + ((bc_y == XG_BC_PERIODIC) ? ny - 1 : 0) * nx;
+      if (bc_y == XG_BC_HALO) src = halo_y + o * nx + i0;  // pre-gathered row below the first one: (outer, 1, X)
+    }
+    const T t = *reinterpret_cast<const T*>(src);
     aa[0] = f ? splat<T>(fill_y) : t;
   }
 #pragma unroll
   for (int s_ = 0; s_ < SEG; ++s_) {
     const int64_t jr = j0 + ((s_ < nrow) ? s_ : nrow - 1);
     aa[s_ + 1] = *reinterpret_cast<const T*>(pa + jr * nx);
-    al[s_] = a[base + jr * nx + nidx];
+    al[s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[o * ny + jr]  // pre-gathered column left of the first: (outer, Y, 1)
+                                          : a[base + jr * nx + nidx];
   }
   const int64_t mxb = (MODE == 0 && mx) ? area_outer_off(aix, o) : 0;
   const int64_t myb = (MODE == 0 && my) ? area_outer_off(aiy, o) : 0;
@@ -513,10 +520,13 @@ static int area_index(const real* m, const int64_t* strides, const int64_t* shap
 
 static int pair2d_impl(int mode, const real* a, const real* u, const real* v, real* out_x, real* out_y,
                        const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y, const real* mx,
-                       const int64_t* mx_strides, const real* my, const int64_t* my_strides, void* stream) {
+                       const int64_t* mx_strides, const real* my, const int64_t* my_strides, void* stream,
+                       const real* halo_x = nullptr, const real* halo_y = nullptr) {
   if (!a || !out_x || !out_y || !shape || (mode == 1 && (!u || !v))) return fail(XG_ERR_INVALID, "NULL array argument");
+  if ((bc_x == XG_BC_HALO && !halo_x) || (bc_y == XG_BC_HALO && !halo_y)) return fail(XG_ERR_INVALID, "halo mode without a halo array");
+  const int bc_max = (halo_x || halo_y) ? XG_BC_HALO : XG_BC_EXTEND;
   if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
-  if (bc_x < XG_BC_PERIODIC || bc_x > XG_BC_EXTEND || bc_y < XG_BC_PERIODIC || bc_y > XG_BC_EXTEND)
+  if (bc_x < XG_BC_PERIODIC || bc_x > bc_max || bc_y < XG_BC_PERIODIC || bc_y > bc_max)
     return fail(XG_ERR_INVALID, "gradient / flux need a boundary mode on both axes");
   const int64_t ny = shape[ndim - 2], nx = shape[ndim - 1];
   int64_t outer = 1;
@@ -530,6 +540,7 @@ static int pair2d_impl(int mode, const real* a, const real* u, const real* v, re
   if ((rc = area_index(my, my_strides, shape, ndim, &aiy, &my_sy, &my_sx))) return rc;
   bool al = aligned16(a) && aligned16(out_x) && aligned16(out_y) && nx % NV == 0;
   if (mode == 1) al = al && aligned16(u) && aligned16(v);
+  if (bc_y == XG_BC_HALO) al = al && aligned16(halo_y);
   const int V = al ? NV : 1;
   constexpr int SEG = 4;
   const u64 ntile = (u64)((nx + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
@@ -544,7 +555,7 @@ static int pair2d_impl(int mode, const real* a, const real* u, const real* v, re
     const u32 nouter = (u32)((outer - o0 < (int64_t)outer_per) ? outer - o0 : (int64_t)outer_per);
     const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GO(V_, M_, NTS) hipLaunchKernelGGL((k_pair2d<V_, M_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, a, u, v, out_x, out_y, o0, nouter, nblk, ny, nx, fnt, fns, bc_x, fill_x, bc_y, fill_y, mx, aix, mx_sy, mx_sx, my, aiy, my_sy, my_sx)
+#define XG_GO(V_, M_, NTS) hipLaunchKernelGGL((k_pair2d<V_, M_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, a, u, v, out_x, out_y, o0, nouter, nblk, ny, nx, fnt, fns, bc_x, fill_x, bc_y, fill_y, mx, aix, mx_sy, mx_sx, my, aiy, my_sy, my_sx, halo_x, halo_y)
 #define XG_M(V_, M_) do { if (nts) XG_GO(V_, M_, true); else XG_GO(V_, M_, false); } while (0)
     if (V > 1) { if (mode) XG_M(NV, 1); else XG_M(NV, 0); }
     else { if (mode) XG_M(1, 1); else XG_M(1, 0); }
@@ -566,6 +577,20 @@ int XG_FN(xg_flux)(const real* u, const real* v, const real* t, real* out_x, rea
                 int bc_x, real fill_x, int bc_y, real fill_y, void* stream) {
   return pair2d_impl(1, t, u, v, out_x, out_y, shape, ndim, bc_x, fill_x, bc_y, fill_y, nullptr, nullptr, nullptr, nullptr,
                      stream);
+}
+
+int XG_FN(xg_gradient_halo)(const real* a, const real* halo_x, const real* halo_y, real* out_x, real* out_y,
+                         const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y, const real* mx,
+                         const int64_t* mx_strides, const real* my, const int64_t* my_strides, void* stream) {
+  return pair2d_impl(0, a, nullptr, nullptr, out_x, out_y, shape, ndim, bc_x, fill_x, bc_y, fill_y, mx, mx_strides, my,
+                     my_strides, stream, halo_x, halo_y);
+}
+
+int XG_FN(xg_flux_halo)(const real* u, const real* v, const real* t, const real* halo_x, const real* halo_y, real* out_x,
+                     real* out_y, const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y,
+                     void* stream) {
+  return pair2d_impl(1, t, u, v, out_x, out_y, shape, ndim, bc_x, fill_x, bc_y, fill_y, nullptr, nullptr, nullptr, nullptr,
+                     stream, halo_x, halo_y);
 }
 
 }  // extern "C"

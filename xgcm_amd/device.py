@@ -461,11 +461,19 @@ def divergence(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: fl
     return out
 
 
-def gradient(a, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0, mx=None, my=None):
+def _pair_halos(halo_x, halo_y, shape, dt):
+    hx = None if halo_x is None else asdevice(halo_x, dt).reshape(shape[:-2] + [shape[-2]])
+    hy = None if halo_y is None else asdevice(halo_y, dt).reshape(shape[:-2] + [shape[-1]])
+    return hx, hy
+
+
+def gradient(a, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0, mx=None, my=None, halo_x=None,
+             halo_y=None):
     """Fused (a - a[x-1]) / mx and (a - a[y-1]) / my on a (..., Y, X) array, both center -> left
-    (xg_gradient_f64); `mx` / `my` None = plain differences.  Returns (out_x, out_y)."""
+    (xg_gradient_f64); `mx` / `my` None = plain differences.  A boundary mode "halo" takes that axis'
+    one-cell halo of `a` from `halo_x` (..., Y) / `halo_y` (..., X).  Returns (out_x, out_y)."""
     lib = _hip.load()
-    dt, sfx = _common(a, mx, my)
+    dt, sfx = _common(a, mx, my, halo_x, halo_y)
     a = asdevice(a, dt)
     shape = list(a.shape)
     mx, my = _prep_metric(mx, dt), _prep_metric(my, dt)
@@ -473,20 +481,22 @@ def gradient(a, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0, 
     out_y = torch.empty(shape, dtype=dt, device=a.device)
     if a.numel() == 0:
         return out_x, out_y
-    _hip.check(
-        getattr(lib, "xg_gradient_" + sfx)(a.data_ptr(), out_x.data_ptr(), out_y.data_ptr(), _hip.i64(shape), len(shape),
-                                           _hip.BC[bc_x], float(fill_x), _hip.BC[bc_y], float(fill_y), _ptr(mx),
-                                           _hip.i64(_bstrides(mx, shape, "mx")), _ptr(my),
-                                           _hip.i64(_bstrides(my, shape, "my")), _stream())
-    )
+    tail = (_hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x), _hip.BC[bc_y], float(fill_y), _ptr(mx),
+            _hip.i64(_bstrides(mx, shape, "mx")), _ptr(my), _hip.i64(_bstrides(my, shape, "my")), _stream())
+    if bc_x == "halo" or bc_y == "halo":
+        hx, hy = _pair_halos(halo_x, halo_y, shape, dt)
+        _hip.check(getattr(lib, "xg_gradient_halo_" + sfx)(a.data_ptr(), _ptr(hx), _ptr(hy), out_x.data_ptr(),
+                                                          out_y.data_ptr(), *tail))
+    else:
+        _hip.check(getattr(lib, "xg_gradient_" + sfx)(a.data_ptr(), out_x.data_ptr(), out_y.data_ptr(), *tail))
     return out_x, out_y
 
 
-def flux(u, v, t, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0):
+def flux(u, v, t, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0, halo_x=None, halo_y=None):
     """Fused u * (t[x-1] + t) / 2 and v * (t[y-1] + t) / 2 on (..., Y, X) arrays (xg_flux_f64); the
-    boundary modes pad the TRACER.  Returns (flux_x, flux_y)."""
+    boundary modes (or the pre-gathered "halo" slabs) pad the TRACER.  Returns (flux_x, flux_y)."""
     lib = _hip.load()
-    dt, sfx = _common(u, v, t)
+    dt, sfx = _common(u, v, t, halo_x, halo_y)
     u, v, t = asdevice(u, dt), asdevice(v, dt), asdevice(t, dt)
     if u.shape != t.shape or v.shape != t.shape:
         raise ValueError("flux: u, v and t must have the same shape")
@@ -495,11 +505,13 @@ def flux(u, v, t, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0
     out_y = torch.empty(shape, dtype=dt, device=t.device)
     if t.numel() == 0:
         return out_x, out_y
-    _hip.check(
-        getattr(lib, "xg_flux_" + sfx)(u.data_ptr(), v.data_ptr(), t.data_ptr(), out_x.data_ptr(), out_y.data_ptr(),
-                                       _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x), _hip.BC[bc_y],
-                                       float(fill_y), _stream())
-    )
+    tail = (out_x.data_ptr(), out_y.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
+            _hip.BC[bc_y], float(fill_y), _stream())
+    if bc_x == "halo" or bc_y == "halo":
+        hx, hy = _pair_halos(halo_x, halo_y, shape, dt)
+        _hip.check(getattr(lib, "xg_flux_halo_" + sfx)(u.data_ptr(), v.data_ptr(), t.data_ptr(), _ptr(hx), _ptr(hy), *tail))
+    else:
+        _hip.check(getattr(lib, "xg_flux_" + sfx)(u.data_ptr(), v.data_ptr(), t.data_ptr(), *tail))
     return out_x, out_y
 
 

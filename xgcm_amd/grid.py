@@ -723,6 +723,24 @@ class Grid:
         res = _reattach_coords([res], self, None, {out_x, out_y}, [u, v])[0]
         return to_xarray(res) if (xr1 or xr2) else res
 
+    def _scalar_halos(self, a, x_axis, y_axis, widths, padding, fill_value):
+        """Boundary modes, fill values and (on complex topologies) the pre-gathered one-cell halos of a
+        scalar field along both axes, for the fused one-in / two-out operators."""
+        bc = self._complete_user_kwargs_using_axis_defaults(padding, "padding")
+        fv = self._complete_user_kwargs_using_axis_defaults(fill_value, "fill_value")
+        modes, halos = {}, {}
+        for ax in (x_axis, y_axis):
+            if gridops.complex_topology(self, ax):
+                halos[ax] = halo_cells(a, self, ax, widths, padding=padding, fill_value=fill_value).data
+                modes[ax] = "halo"
+            else:
+                if bc[ax] is None:
+                    raise no_boundary_error(ax)
+                halos[ax] = None
+                modes[ax] = bc[ax]
+        return (modes[x_axis], modes[y_axis], float(fv[x_axis] or 0.0), float(fv[y_axis] or 0.0), halos[x_axis],
+                halos[y_axis])
+
     def _two_component_halos(self, u, v, x_axis, y_axis, widths, padding, fill_value, x_of: str, y_of: str):
         """Boundary modes, fill values and (on complex topologies) the pre-gathered one-cell halos of the
         fused two-component operators: along X the halo of component `x_of`, along Y of `y_of`; `u` is
@@ -784,7 +802,8 @@ class Grid:
         `metric_weighted` `(derivative(a, X), derivative(a, Y))` -- in ONE kernel launch that reads the
         field once (the "Gradient" grid ufunc of the reference's docs/ufunc_examples.md, center -> left,
         padding_width (1, 0) on both axes).  Bit-identical to the two operator calls; on a complex
-        topology (face connections / fold) those two calls are what runs."""
+        topology (face connections / fold) the two one-cell halos of the field are gathered through the
+        token map first, then the same single launch runs."""
         a, was_xr = self._wrap_in(a)
         xa, ya = self.axes[x_axis], self.axes[y_axis]
         x_pos, x_dim = xa._get_position_name(a)
@@ -792,16 +811,11 @@ class Grid:
         if (x_pos, y_pos) != ("center", "center") or "left" not in xa.coords or "left" not in ya.coords:
             raise NotImplementedError("fused gradient needs a field at (Y:center, X:center) and left points on both axes")
         op = self.derivative if metric_weighted else self.diff
-        if (a.dims[-2:] != (y_dim, x_dim) or gridops.complex_topology(self, x_axis)
-                or gridops.complex_topology(self, y_axis)):
+        if a.dims[-2:] != (y_dim, x_dim):
             kw = dict(padding=padding, fill_value=fill_value)
             res = op(a, x_axis, **kw), op(a, y_axis, **kw)
             return tuple(to_xarray(r) for r in res) if was_xr else res
-        bc = self._complete_user_kwargs_using_axis_defaults(padding, "padding")
-        fv = self._complete_user_kwargs_using_axis_defaults(fill_value, "fill_value")
-        for ax in (x_axis, y_axis):
-            if bc[ax] is None:
-                raise no_boundary_error(ax)
+        bcx, bcy, fx, fy, hx, hy = self._scalar_halos(a, x_axis, y_axis, (1, 0), padding, fill_value)
         dims_x = a.dims[:-1] + (xa.coords["left"],)
         dims_y = a.dims[:-2] + (ya.coords["left"], x_dim)
         mx = my = None
@@ -809,7 +823,7 @@ class Grid:
             mx = _aligned_view(self._resident(self.get_metric(_DimsOnly(dims_x), (x_axis,)), a.data), dims_x)
             my = _aligned_view(self._resident(self.get_metric(_DimsOnly(dims_y), (y_axis,)), a.data), dims_y)
         host = not _is_tensor(a.data)
-        gx, gy = _dev.gradient(a.data, bc[x_axis], bc[y_axis], float(fv[x_axis] or 0.0), float(fv[y_axis] or 0.0), mx, my)
+        gx, gy = _dev.gradient(a.data, bcx, bcy, fx, fy, mx, my, hx, hy)
         rx = DataArray(_dev.tohost(gx) if host else gx, dims_x, name=a.name)
         ry = DataArray(_dev.tohost(gy) if host else gy, dims_y, name=a.name)
         rx = _reattach_coords([rx], self, None, {xa.coords["left"]}, [a])[0]
@@ -820,7 +834,7 @@ class Grid:
         """Fused first-order advective flux of a cell-centre tracer: `(u * interp(T, X), v * interp(T, Y))`
         in one launch (the "Advection" flux of docs/ufunc_examples.md; u at (Y:center, X:left), v at
         (Y:left, X:center)).  Bit-identical to the chain of reference operators; `padding` /
-        `fill_value` pad the tracer.  Complex topologies run the chain itself."""
+        `fill_value` pad the tracer (on complex topologies: its pre-gathered halos)."""
         (u, xr1), (v, xr2), (t, xr3) = self._wrap_in(u), self._wrap_in(v), self._wrap_in(tracer)
         xa, ya = self.axes[x_axis], self.axes[y_axis]
         tx_pos, tx_dim = xa._get_position_name(t)
@@ -830,19 +844,13 @@ class Grid:
         dims_x = t.dims[:-2] + (ty_dim, xa.coords["left"])
         dims_y = t.dims[:-2] + (ya.coords["left"], tx_dim)
         was_xr = xr1 or xr2 or xr3
-        if (t.dims[-2:] != (ty_dim, tx_dim) or u.dims != dims_x or v.dims != dims_y
-                or gridops.complex_topology(self, x_axis) or gridops.complex_topology(self, y_axis)):
+        if t.dims[-2:] != (ty_dim, tx_dim) or u.dims != dims_x or v.dims != dims_y:
             kw = dict(padding=padding, fill_value=fill_value)
             res = u * self.interp(t, x_axis, **kw), v * self.interp(t, y_axis, **kw)
             return tuple(to_xarray(r) for r in res) if was_xr else res
-        bc = self._complete_user_kwargs_using_axis_defaults(padding, "padding")
-        fv = self._complete_user_kwargs_using_axis_defaults(fill_value, "fill_value")
-        for ax in (x_axis, y_axis):
-            if bc[ax] is None:
-                raise no_boundary_error(ax)
+        bcx, bcy, fvx, fvy, hx, hy = self._scalar_halos(t, x_axis, y_axis, (1, 0), padding, fill_value)
         host = not (_is_tensor(u.data) or _is_tensor(v.data) or _is_tensor(t.data))
-        fx, fy = _dev.flux(u.data, v.data, t.data, bc[x_axis], bc[y_axis], float(fv[x_axis] or 0.0),
-                           float(fv[y_axis] or 0.0))
+        fx, fy = _dev.flux(u.data, v.data, t.data, bcx, bcy, fvx, fvy, hx, hy)
         rx = DataArray(_dev.tohost(fx) if host else fx, dims_x)
         ry = DataArray(_dev.tohost(fy) if host else fy, dims_y)
         rx = _reattach_coords([rx], self, None, {xa.coords["left"]}, [u, t])[0]
