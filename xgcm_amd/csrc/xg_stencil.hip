@@ -516,7 +516,7 @@ int launch_contig(const StencilCall& c) {
   const FastDiv fper = make_fastdiv(per);
   const u64 rows_per = MAX_ITEMS / per;
   // z-banding: outer dims (Z, Y) with every metric broadcast along Z, whole problem in one launch
-  const u32 ZB_ROWS = 16;
+  const u32 ZB_ROWS = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16);
   bool zb_ok = MET != 0 && tune().zband && c.g.n_outer == 2 && (!c.m_in || c.mi.outer[0] == 0) &&
                (!c.m_out || c.mo.outer[0] == 0);
   u64 work_rows = (u64)c.g.outer;
