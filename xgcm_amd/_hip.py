@@ -170,12 +170,6 @@ def ints(values: Optional[Sequence[int]]):
     return (C.c_int * len(values))(*[int(v) for v in values])
 
 
-def f64s(values: Optional[Sequence[float]]):
-    if values is None:
-        return None
-    return (C.c_double * len(values))(*[float(v) for v in values])
-
-
 def reals(values: Optional[Sequence[float]], suffix: str):
     """array of fill values in the C type of the `_f64` / `_f32` entry point"""
     if values is None:
