@@ -781,3 +781,25 @@ def test_integer_inputs_keep_their_dtype_like_numpy(backend):
     got = grid.diff(DataArray(a32, ("t", "X_c")), "X", to="right", padding="periodic")
     assert _np(got).dtype == np.int32
     np.testing.assert_array_equal(_np(got), np.roll(a32, -1, axis=1) - a32)
+
+
+def test_sharded_core_axis_single_rank_equals_grid_methods(backend):
+    """xgcm_amd.sharding.stencil_along_sharded_axis with one rank (no exchange): the halo-mode kernel fed
+    with locally made boundary planes gives the bits of the ordinary in-kernel boundary modes."""
+    from xgcm_amd.sharding import stencil_along_sharded_axis
+
+    nz, ny, nx = 6, 5, 8
+    ds = Dataset({"T": (("Z", "YC", "XC"), R.synthetic_field((nz, ny, nx), 21))},
+                 {"Z": ("Z", np.arange(nz) * 1.0), "Zl": ("Zl", np.arange(nz) - 0.5), "XC": ("XC", np.arange(nx) + 0.5),
+                  "XG": ("XG", np.arange(nx) * 1.0)})
+    for bc in ("periodic", "fill", "extend"):
+        grid = Grid(ds, coords={"Z": {"center": "Z", "left": "Zl"}, "X": {"center": "XC", "left": "XG"}}, padding=bc,
+                    fill_value=2.5, autoparse_metadata=False)
+        for fn in ("diff", "interp", "min"):
+            for ax in ("Z", "X"):
+                got = stencil_along_sharded_axis(grid, fn, ds["T"], ax)
+                want = getattr(grid, fn)(ds["T"], ax)
+                assert got.dims == want.dims and np.array_equal(_np(got), _np(want)), (bc, fn, ax)
+    with pytest.raises(NotImplementedError, match="length-preserving"):
+        g5 = five_position_grid(9, "fill")
+        stencil_along_sharded_axis(g5, "diff", DataArray(np.arange(9.0), ("X_c",)), "X", to="outer")

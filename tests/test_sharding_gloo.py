@@ -94,3 +94,66 @@ def test_two_rank_gloo_sharded_equals_single_process(tmp_path):
     want_chk = sum(int(np.frombuffer(p.tobytes(), dtype=np.uint64).sum() % (1 << 50)) for p in parts)
     assert int(chk) == want_chk  # checksum of checksums
     assert tmax == 2.0 and rate == want_d.size / 2.0  # all units / max-over-ranks time
+
+
+# ---- sharding ALONG the operator's axis: neighbour planes exchanged point to point ---------------
+def _core_axis_worker(rank, world, port, tmp):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import fake_device
+        from oracle import refimpl as R
+
+        class MP:
+            def setattr(self, obj, name, val):
+                setattr(obj, name, val)
+
+        fake_device.install(MP())
+        from xgcm_amd import DataArray, Dataset, Grid
+        from xgcm_amd.sharding import stencil_along_sharded_axis
+
+        nz, ny, nx = 7, 5, 8
+        full = R.synthetic_field((nz, ny, nx), 9)
+        lo, hi = shard_bounds(nz, world, rank)
+        ds = Dataset(coords={"Z": ("Z", np.arange(nz) * 1.0), "Zl": ("Zl", np.arange(nz) - 0.5),
+                             "Zr": ("Zr", np.arange(nz) + 0.5)})
+        for bc in ("periodic", "fill", "extend"):
+            grid = Grid(ds, coords={"Z": {"center": "Z", "left": "Zl", "right": "Zr"}}, padding={"Z": bc},
+                        fill_value={"Z": 1.5}, autoparse_metadata=False)
+            mine = DataArray(full[lo:hi], ("Z", "YC", "XC"))
+            for fn in ("diff", "interp", "max"):
+                for to in ("left", "right"):
+                    res = stencil_along_sharded_axis(grid, fn, mine, "Z", dist=dist, to=to)
+                    assert res.dims == ("Zl" if to == "left" else "Zr", "YC", "XC")
+                    np.save(os.path.join(tmp, f"{bc}_{fn}_{to}_{rank}.npy"), res.values)
+            back = stencil_along_sharded_axis(grid, "interp", DataArray(full[lo:hi], ("Zl", "YC", "XC")), "Z", dist=dist)
+            np.save(os.path.join(tmp, f"{bc}_back_{rank}.npy"), back.values)
+        with pytest.raises(NotImplementedError, match="sharded axis"):
+            stencil_along_sharded_axis(grid, "cumsum", mine, "Z", dist=dist)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_ranks_sharded_along_the_core_axis_exchange_one_plane(tmp_path, world):
+    """diff / interp / max along Z of a field split over Z: each rank gets one plane from its neighbour
+    (ring closed for `periodic`, ends made locally for `fill` / `extend`); concatenated blocks ==
+    the single-process operator, bit for bit."""
+    from oracle import refimpl as R
+
+    mp.spawn(_core_axis_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    nz, ny, nx = 7, 5, 8
+    full = R.synthetic_field((nz, ny, nx), 9)
+    for bc in ("periodic", "fill", "extend"):
+        for fn in ("diff", "interp", "max"):
+            for to, pad in (("left", (1, 0)), ("right", (0, 1))):
+                got = np.concatenate([np.load(tmp_path / f"{bc}_{fn}_{to}_{r}.npy") for r in range(world)], axis=0)
+                assert np.array_equal(got, R.stencil1d(fn, full, 0, pad[0], pad[1], bc, 1.5)), (bc, fn, to)
+        got = np.concatenate([np.load(tmp_path / f"{bc}_back_{r}.npy") for r in range(world)], axis=0)
+        assert np.array_equal(got, R.stencil1d("interp", full, 0, 0, 1, bc, 1.5))  # left -> center
