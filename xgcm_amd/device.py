@@ -36,6 +36,8 @@ __all__ = [
     "binary",
     "vorticity",
     "divergence",
+    "gradient",
+    "flux",
     "stencil2d",
     "stencil2d_supported",
     "synthetic",
@@ -75,6 +77,10 @@ def asdevice(x, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         t = t.to(dtype)
     if not t.is_cuda:
         t = t.cuda()
+    elif t.device.index != torch.cuda.current_device():
+        # kernels are enqueued on the CURRENT device's stream (one process per GPU is the model)
+        raise RuntimeError(f"array lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device() for that GPU first")
     return t.contiguous()
 
 
