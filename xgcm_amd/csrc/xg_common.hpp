@@ -93,6 +93,7 @@ struct Tune {
   int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
   int zb_rows;        // rows of the contiguous-axis kernel per band
+  int scan_block;     // workgroup size of the contiguous-axis scan (128 / 256 / 512 / 1024)
   int scan_vec;       // aligned-output-group scan for cumsum along the contiguous axis
   int contig_gen;     // pair-wise general path for odd / length-changing rows on the contiguous axis
   int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
@@ -106,6 +107,7 @@ struct Tune {
     deep_waves = env_int("XG_DEEP_WAVES", 8192);  // neutral on its own, pays together with scan_narrow_below
     zband = env_int("XG_ZBAND", 1);
     zb_rows = env_int("XG_ZB_ROWS", 16);
+    scan_block = env_int("XG_SCAN_BLOCK", 256);
     zchunk = env_int("XG_ZCHUNK", 256);
     transform_fast = env_int("XG_TRANSFORM_FAST", 1);
     pad_rows = env_int("XG_PAD_ROWS", 1);

@@ -187,27 +187,28 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
 // in a register.  Inputs that map outside the output range (at most one, when the trim is on the
 // side the scan starts from) seed the carry.  Re-associated sum => 1e-12 parity like K6.
 // ------------------------------------------------------------------------------------------
-template <int MET, bool NTS>
-__global__ __launch_bounds__(BLOCK) void k_cumsum_contig_vec(
+template <int MET, bool NTS, int BS>
+__global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 nrows, ScanArgs a,
     const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
-  __shared__ real wtot[2][WPB];
+  constexpr int NW = BS / WAVE;
+  __shared__ real wtot[2][NW];
   const u32 pb = (nrows + 7) >> 3;
   const u32 row = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);  // XCD banding over rows
   if (row >= nrows) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t n = g.n_in, no = g.n_out;
+  const int n = (int)g.n_in, no = (int)g.n_out;  // the host selects this kernel for rows below 2^31 cells only
   const real* prow = in + (int64_t)row * n;
   real* orow = out + (int64_t)row * no;
   int64_t mi_base = 0, mo_base = 0;
   if (HAS_MI) mi_base = outer_off(g, mi, row);
   if (HAS_MO) mo_base = outer_off(g, mo, row);
-  const int64_t shift = a.pad_lo - a.trim_lo;
-  auto fetch = [&](int64_t idx) -> real {  // weighted, NaN-cleaned input or 0 outside the row
+  const int shift = a.pad_lo - a.trim_lo;
+  auto fetch = [&](int idx) -> real {  // weighted, NaN-cleaned input or 0 outside the row
     if (idx < 0 || idx >= n) return real(0);
     real v = prow[idx];
-    if (HAS_MI) v = v * m_in[mi_base + idx * mi.axis];
+    if (HAS_MI) v = v * m_in[mi_base + (int64_t)idx * mi.axis];
     if (a.skipna) v = nan0(v);
     return v;
   };
@@ -215,25 +216,52 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig_vec(
   real carry = real(0);
   if (!a.reverse && shift < 0) carry = fetch(0);
   if (a.reverse && (n - 1 + shift) >= no) carry = fetch(n - 1);
-  const int64_t groups = no / NV;
+  const int groups = no / NV;
   int buf = 0;
-  auto group_lo = [&](int64_t t) -> int64_t { return a.reverse ? no - NV * (t + 1) : NV * t; };
-  real xn[NV];  // the next pass's inputs are loaded before this pass's scan and barrier
+  auto group_lo = [&](int t) -> int { return a.reverse ? no - NV * (t + 1) : NV * t; };
+  // inputs of output group t.  All but the first / last group of a row lie inside the row: no per-element
+  // bounds checks there (they were half of the loop's VALU work); one 16-B load when input and output groups
+  // coincide (shift == 0) and rows keep the alignment, else NV narrow loads served by L1.
+  const bool vec_in = (shift == 0) && (n % NV == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
+  auto load_group = [&](int t, real (&x)[NV]) {
+    if (t >= groups) {
 #pragma unroll
-  for (int k = 0; k < NV; ++k) xn[k] = (tid < groups) ? fetch(group_lo(tid) + k - shift) : real(0);
-  for (int64_t base = 0; base < groups; base += BLOCK, buf ^= 1) {
-    const int64_t t = base + tid;
+      for (int k = 0; k < NV; ++k) x[k] = real(0);
+      return;
+    }
+    const int i0 = group_lo(t) - shift;
+    if (i0 >= 0 && i0 + NV <= n) {
+      if (vec_in) {
+        const dv v = *reinterpret_cast<const dv*>(prow + i0);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) x[k] = v[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) x[k] = prow[i0 + k];
+      }
+      if (HAS_MI) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) x[k] = x[k] * m_in[mi_base + (int64_t)(i0 + k) * mi.axis];
+      }
+      if (a.skipna) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) x[k] = nan0(x[k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) x[k] = fetch(i0 + k);
+    }
+  };
+  real xn[NV];  // the next pass's inputs are loaded before this pass's scan and barrier
+  load_group(tid, xn);
+  for (int base = 0; base < groups; base += BS, buf ^= 1) {
+    const int t = base + tid;
     const bool act = t < groups;
-    const int64_t jlo = group_lo(t);
+    const int jlo = group_lo(t);
     real x[NV], l[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) x[k] = xn[k];
-    {
-      const int64_t tn = t + BLOCK;
-      const int64_t jn = group_lo(tn);
-#pragma unroll
-      for (int k = 0; k < NV; ++k) xn[k] = (tn < groups) ? fetch(jn + k - shift) : real(0);
-    }
+    load_group(t + BS, xn);
     if (!a.reverse) {
       l[0] = x[0];
 #pragma unroll
@@ -256,7 +284,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig_vec(
     __syncthreads();
     real woff = real(0), tot = real(0);
 #pragma unroll
-    for (int i = 0; i < WPB; ++i) {
+    for (int i = 0; i < NW; ++i) {
       real u = wtot[buf][i];
       if (i < wv) woff += u;
       tot += u;
@@ -270,7 +298,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig_vec(
       // halo cells (fill / extend only here): j = 0 and j = no - 1 sit next to a kept cell of the same group
       if (a.pad_lo && jlo == 0) res[0] = (a.bc == XG_BC_FILL) ? (real)a.fill : res[1];
       if (a.pad_hi && jlo + NV == no) res[NV - 1] = (a.bc == XG_BC_FILL) ? (real)a.fill : res[NV - 2];
-      if (HAS_MO) res = res / ldm<dv>(m_out, mo_base + jlo * mo.axis, mo.axis);
+      if (HAS_MO) res = res / ldm<dv>(m_out, mo_base + (int64_t)jlo * mo.axis, mo.axis);
       stg<dv, NTS>(orow + jlo, res);
     }
   }
@@ -390,12 +418,17 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
     const u64 nblocks = (u64)g.outer;
     if ((rc = check_grid(nblocks + 8))) return rc;
     const bool periodic_halo = (pad_lo || pad_hi) && bc == XG_BC_PERIODIC;
-    if (tune().scan_vec && !periodic_halo && n_out % NV == 0 && n_out >= 2 * NV && aligned16(out) && nblocks < 0x7ffffff0ull) {
+    if (tune().scan_vec && !periodic_halo && n_out % NV == 0 && n_out >= 2 * NV && aligned16(out) && nblocks < 0x7ffffff0ull &&
+        g.n_in < 0x7fff0000ll && n_out < 0x7fff0000ll) {
       const u32 nrows = (u32)nblocks, grid = ((nrows + 7) / 8) * 8;
       const bool nts = tune().nt_store;
-#define XG_M(M) do { if (nts) hipLaunchKernelGGL((k_cumsum_contig_vec<M, true>), dim3(grid), dim3(BLOCK), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo); \
-                     else hipLaunchKernelGGL((k_cumsum_contig_vec<M, false>), dim3(grid), dim3(BLOCK), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo); } while (0)
+      const int bs = tune().scan_block;
+#define XG_L(M, NTS_, BS_) hipLaunchKernelGGL((k_cumsum_contig_vec<M, NTS_, BS_>), dim3(grid), dim3(BS_), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo)
+#define XG_B(M, NTS_) do { if (bs == 512) XG_L(M, NTS_, 512); else if (bs == 1024) XG_L(M, NTS_, 1024); else if (bs == 128) XG_L(M, NTS_, 128); else if (bs == 64) XG_L(M, NTS_, 64); else XG_L(M, NTS_, 256); } while (0)
+#define XG_M(M) do { if (nts) XG_B(M, true); else XG_B(M, false); } while (0)
       switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
+#undef XG_B
+#undef XG_L
 #undef XG_M
     } else {
 #define XG_M(M) hipLaunchKernelGGL((k_cumsum_contig<M>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, a, m_in, mi, m_out, mo)
