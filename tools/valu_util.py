@@ -16,7 +16,7 @@ ap.add_argument("--simds", type=int, default=1024)
 a = ap.parse_args()
 con = sqlite3.connect(a.db)
 q = ("select kernel_name, counter_name, avg(value), count(*) from counters_collection where dispatch_id in "
-     "(select dispatch_id from counters_collection where counter_name='SQ_WAVES' and value > 100000) "
+     "(select dispatch_id from counters_collection where counter_name='SQ_WAVES' and value > 20000) "
      "group by kernel_name, counter_name")
 vals = {}
 for name, ctr, v, n in con.execute(q):
