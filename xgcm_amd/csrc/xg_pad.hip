@@ -145,8 +145,17 @@ __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in,
     if (x >= Lo) return;
     if (x + NV <= Lo) {
       dv val;
+      const int64_t q0 = x - p.lo[t_in];
+      if (!fill_after && !fill_before && q0 >= 0 && q0 + NV <= Li) {
+        // the group's sources lie inside the row (all but the groups touching a halo): no per-element
+        // wrap / clamp / fill logic, NV consecutive narrow loads served by L1
+        const real* s = in + src + q0;
 #pragma unroll
-      for (int k = 0; k < NV; ++k) val[k] = elem(x + k);
+        for (int k = 0; k < NV; ++k) val[k] = s[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) val[k] = elem(x + k);
+      }
       *reinterpret_cast<dv*>(drow + x) = val;
     } else {
       for (int64_t xx = x; xx < Lo; ++xx) drow[xx] = elem(xx);
