@@ -803,3 +803,11 @@ def test_sharded_core_axis_single_rank_equals_grid_methods(backend):
     with pytest.raises(NotImplementedError, match="length-preserving"):
         g5 = five_position_grid(9, "fill")
         stencil_along_sharded_axis(g5, "diff", DataArray(np.arange(9.0), ("X_c",)), "X", to="outer")
+    from xgcm_amd.sharding import cumsum_along_sharded_axis
+
+    grid = Grid(ds, coords={"Z": {"center": "Z", "left": "Zl"}, "X": {"center": "XC", "left": "XG"}}, padding="extend",
+                autoparse_metadata=False)
+    for ax in ("Z", "X"):  # one rank: exactly Grid.cumsum
+        got = cumsum_along_sharded_axis(grid, ds["T"], ax)
+        want = grid.cumsum(ds["T"], ax)
+        assert got.dims == want.dims and np.array_equal(_np(got), _np(want))

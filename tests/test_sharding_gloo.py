@@ -115,7 +115,7 @@ def _core_axis_worker(rank, world, port, tmp):
 
         fake_device.install(MP())
         from xgcm_amd import DataArray, Dataset, Grid
-        from xgcm_amd.sharding import stencil_along_sharded_axis
+        from xgcm_amd.sharding import cumsum_along_sharded_axis, stencil_along_sharded_axis
 
         nz, ny, nx = 7, 5, 8
         full = R.synthetic_field((nz, ny, nx), 9)
@@ -133,8 +133,17 @@ def _core_axis_worker(rank, world, port, tmp):
                     np.save(os.path.join(tmp, f"{bc}_{fn}_{to}_{rank}.npy"), res.values)
             back = stencil_along_sharded_axis(grid, "interp", DataArray(full[lo:hi], ("Zl", "YC", "XC")), "Z", dist=dist)
             np.save(os.path.join(tmp, f"{bc}_back_{rank}.npy"), back.values)
-        with pytest.raises(NotImplementedError, match="sharded axis"):
+            if bc != "periodic":
+                for to in ("left", "right"):
+                    c = cumsum_along_sharded_axis(grid, mine, "Z", dist=dist, to=to)
+                    assert c.dims == ("Zl" if to == "left" else "Zr", "YC", "XC")
+                    np.save(os.path.join(tmp, f"{bc}_cumsum_{to}_{rank}.npy"), c.values)
+        with pytest.raises(NotImplementedError, match="cumsum_along_sharded_axis"):
             stencil_along_sharded_axis(grid, "cumsum", mine, "Z", dist=dist)
+        pgrid = Grid(ds, coords={"Z": {"center": "Z", "left": "Zl", "right": "Zr"}}, padding={"Z": "periodic"},
+                     autoparse_metadata=False)
+        with pytest.raises(NotImplementedError, match="periodic halo"):
+            cumsum_along_sharded_axis(pgrid, mine, "Z", dist=dist, to="left")
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -157,3 +166,7 @@ def test_gloo_ranks_sharded_along_the_core_axis_exchange_one_plane(tmp_path, wor
                 assert np.array_equal(got, R.stencil1d(fn, full, 0, pad[0], pad[1], bc, 1.5)), (bc, fn, to)
         got = np.concatenate([np.load(tmp_path / f"{bc}_back_{r}.npy") for r in range(world)], axis=0)
         assert np.array_equal(got, R.stencil1d("interp", full, 0, 0, 1, bc, 1.5))  # left -> center
+        if bc != "periodic":  # scans: block totals all-gathered, carry added in rank order (re-associated sum)
+            for to in ("left", "right"):
+                got = np.concatenate([np.load(tmp_path / f"{bc}_cumsum_{to}_{r}.npy") for r in range(world)], axis=0)
+                np.testing.assert_allclose(got, R.grid_cumsum(full, 0, "center", to, bc, 1.5), rtol=1e-12, atol=1e-13)
