@@ -8,12 +8,15 @@
 //      is, ONE vector per lane, thread id == linear memory order (a copy written this way streams
 //      at 80 % of the 8 TB/s spec; 2-8 tiles per thread or grid-stride loops lose 10-35 %);
 //  (3) the set of rows in flight stays compact: along a strided axis a wave register-marches only
-//      4 rows (whole columns only when a row is a whole plane, i.e. the Z axis);
+//      4 rows, whole-plane rows (the Z axis) are cut into column chunks; only the scans and reductions,
+//      whose sums are sequential by contract, march whole columns;
 //  (4) workgroup b runs on XCD b % 8, each XCD has its own L2: the linear work sequence is cut into
 //      8 contiguous bands, one per XCD, so halo-row re-reads and broadcast metrics hit that XCD's
 //      L2 ("banding", "z-banding") -- speed only, never correctness;
 //  (5) per-item index math is 32-bit with multiply-shift division (FastDiv) and wave-uniform parts
-//      on the scalar unit; launches are split on the host so item counts stay below 2^31.
+//      on the scalar unit; launches are split on the host so item counts stay below 2^31;
+//  (6) the instruction stream is budgeted like bandwidth: ~800 SIMD cycles of HBM time per wave-item,
+//      4 cycles per wave64 VALU instruction -- inner loops carry no per-element bounds checks.
 // No MFMA, no LDS tiling of the field (nothing is reused), LDS only for cross-wave scan carries.
 //
 // Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off (bitwise parity with numpy forbids
