@@ -27,72 +27,246 @@ _NUMPY_MODE = {"periodic": "wrap", "fill": "constant", "extend": "edge"}
 
 
 class Plane:
-    """A tiny named-dims int64 array: just what the padding procedures need."""
+    """A named-dims int64 token array that is evaluated LAZILY.
 
-    __slots__ = ("a", "dims")
+    The padding procedures below build the padded plane by slicing, flipping, renaming and concatenating
+    (as the reference does with data).  Doing that on materialised arrays costs O(plane) memory traffic per
+    step -- 2 GB and seconds for the 13 x 4320 x 4320 LLC grid -- although a built-in operator only needs the
+    one-cell halo slab of the result.  So every step returns a small recipe instead: `eval(sel)` produces the
+    tokens of an outer-product selection (one index array per dim) by pushing the selection down the recipe,
+    and the cost of a halo map is proportional to the halo.  `.a` evaluates everything (full pads)."""
 
-    def __init__(self, a: np.ndarray, dims: Sequence[str]):
-        self.a = a
+    __slots__ = ("dims", "shape", "_full")
+
+    def __init__(self, dims: Sequence[str], shape: Sequence[int]):
         self.dims = tuple(dims)
-        assert a.ndim == len(self.dims)
+        self.shape = tuple(int(n) for n in shape)
+        self._full = None
+        assert len(self.dims) == len(self.shape)
 
+    # -- evaluation ------------------------------------------------------------------------
+    def eval(self, sel: Sequence[np.ndarray]) -> np.ndarray:  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    @property
+    def a(self) -> np.ndarray:
+        if self._full is None:
+            self._full = self.eval([np.arange(n, dtype=np.int64) for n in self.shape])
+        return self._full
+
+    # -- the operations the padding procedures use -----------------------------------------
     def num(self, dim: str) -> int:
         return self.dims.index(dim)
 
     def size(self, dim: str) -> int:
-        return self.a.shape[self.num(dim)]
+        return self.shape[self.num(dim)]
+
+    def _identity_maps(self):
+        return [(k, np.arange(n, dtype=np.int64), None, 0) for k, n in enumerate(self.shape)]
+
+    def _view(self, dims, maps, fixed=None, negate=False) -> "Plane":
+        return _View(self, dims, maps, fixed or {}, -1 if negate else 1)
 
     def isel(self, dim: str, index) -> "Plane":
         """slice or integer-array selection along `dim` (the dim is kept)."""
-        key = [slice(None)] * self.a.ndim
-        key[self.num(dim)] = index
-        return Plane(self.a[tuple(key)], self.dims)
+        k = self.num(dim)
+        maps = self._identity_maps()
+        maps[k] = (k, np.arange(self.shape[k], dtype=np.int64)[index], None, 0)
+        return self._view(self.dims, maps)
 
     def take_face(self, facedim: str, i: int) -> "Plane":
         n = self.num(facedim)
-        return Plane(np.take(self.a, i, axis=n), self.dims[:n] + self.dims[n + 1:])
+        maps = [m for k, m in enumerate(self._identity_maps()) if k != n]
+        return self._view(self.dims[:n] + self.dims[n + 1:], maps, fixed={n: int(i)})
 
     def flip(self, dim: str) -> "Plane":
-        return Plane(np.flip(self.a, axis=self.num(dim)), self.dims)
+        return self.isel(dim, slice(None, None, -1))
 
     def negate(self) -> "Plane":
-        return Plane(-self.a, self.dims)
+        return self._view(self.dims, self._identity_maps(), negate=True)
 
     def rename(self, mapping: Mapping[str, str]) -> "Plane":
-        return Plane(self.a, tuple(mapping.get(d, d) for d in self.dims))
+        return self._view(tuple(mapping.get(d, d) for d in self.dims), self._identity_maps())
 
     def swap_names(self, a: str, b: str) -> "Plane":
         """`a` becomes `b`; an existing `b` becomes `a` (higher-dimensional slices)."""
-        return Plane(self.a, tuple(b if d == a else (a if d == b else d) for d in self.dims))
+        return self._view(tuple(b if d == a else (a if d == b else d) for d in self.dims), self._identity_maps())
 
     def transpose(self, order: Sequence[str]) -> "Plane":
-        return Plane(np.transpose(self.a, [self.num(d) for d in order]), tuple(order))
+        order = tuple(order)
+        if order == self.dims:
+            return self
+        ident = self._identity_maps()
+        return self._view(order, [ident[self.num(d)] for d in order])
 
     def pad(self, dim: str, lo: int, hi: int, mode: str, fill_token: int = 0) -> "Plane":
+        """numpy.pad along one dim: wrap / edge / constant (`fill_token`)."""
         if lo == 0 and hi == 0:
             return self
-        widths = [(0, 0)] * self.a.ndim
-        widths[self.num(dim)] = (lo, hi)
+        k = self.num(dim)
+        n = self.shape[k]
+        idx = np.pad(np.arange(n, dtype=np.int64), (lo, hi), mode="constant" if mode == "fill" else _NUMPY_MODE[mode])
+        fill = None
         if mode == "fill":
-            return Plane(np.pad(self.a, widths, mode="constant", constant_values=fill_token), self.dims)
-        return Plane(np.pad(self.a, widths, mode=_NUMPY_MODE[mode]), self.dims)
+            fill = np.zeros(n + lo + hi, dtype=np.int64)
+            fill[:lo] = fill_token
+            fill[n + lo:] = fill_token
+        maps = self._identity_maps()
+        maps[k] = (k, idx, fill, 1)
+        return self._view(self.dims, maps)
 
     @staticmethod
     def concat(parts: List["Plane"], dim: str) -> "Plane":
         order = parts[0].dims
-        arrs = [p.transpose(order).a for p in parts]
-        return Plane(np.concatenate(arrs, axis=order.index(dim)), order)
+        return _Concat([p.transpose(order) for p in parts], order.index(dim))
 
     @staticmethod
     def stack(parts: List["Plane"], dim: str, position: int) -> "Plane":
         order = parts[0].dims
-        arrs = [p.transpose(order).a for p in parts]
-        return Plane(np.stack(arrs, axis=position), order[:position] + (dim,) + order[position:])
+        return _Stack([p.transpose(order) for p in parts], dim, position)
+
+
+class _Base(Plane):
+    """tokens 1 + offset + row-major index: the array itself (or, with an offset, the other component)."""
+
+    __slots__ = ("offset", "strides")
+
+    def __init__(self, sizes, dims, offset=0):
+        super().__init__(dims, sizes)
+        self.offset = int(offset)
+        st, acc = [], 1
+        for n in reversed(self.shape):
+            st.append(acc)
+            acc *= n
+        self.strides = tuple(reversed(st))
+
+    def eval(self, sel):
+        out = np.full((1,) * len(self.shape), 1 + self.offset, dtype=np.int64)
+        for k, s in enumerate(sel):
+            shp = [1] * len(self.shape)
+            shp[k] = len(s)
+            out = out + (np.asarray(s, dtype=np.int64) * self.strides[k]).reshape(shp)
+        return out
+
+
+class _View(Plane):
+    """Per-dim index maps (+ fill overrides, + sign) on top of another plane.  `maps[k]` describes dim k of
+    the view: (inner dim, index array into it, fill tokens or None, order in which the fill was applied);
+    `fixed` pins the remaining inner dims to one index.  Views of views are composed at construction."""
+
+    __slots__ = ("inner", "maps", "fixed", "sign")
+
+    def __init__(self, inner: Plane, dims, maps, fixed, sign):
+        if isinstance(inner, _View):  # compose: at most one view layer above any concat / stack / base
+            base_prio = max([m[3] for m in inner.maps] + [0])
+            by_inner_dim = {}
+            for k_in, m in enumerate(inner.maps):
+                by_inner_dim[k_in] = m
+            new_maps = []
+            for (k_in, idx, fill, prio) in maps:
+                pos, idx_in, fill_in, prio_in = by_inner_dim[k_in]
+                safe = np.where(fill != 0, 0, idx) if fill is not None else idx
+                nidx = idx_in[safe]
+                nfill, nprio = None, prio_in
+                if fill_in is not None:
+                    nfill = fill_in[safe] * sign
+                if fill is not None:
+                    nfill = fill.copy() if nfill is None else np.where(fill != 0, fill, nfill)
+                    nprio = base_prio + prio
+                new_maps.append((pos, nidx, nfill, nprio))
+            new_fixed = dict(inner.fixed)
+            for k_in, v in fixed.items():  # an inner VIEW dim pinned: pin what it points at
+                pos, idx_in, fill_in, _ = by_inner_dim[k_in]
+                if fill_in is not None and fill_in[v] != 0:
+                    raise NotImplementedError("pinning a dim at a fill cell")
+                new_fixed[pos] = int(idx_in[v])
+            maps, fixed, sign, inner = new_maps, new_fixed, sign * inner.sign, inner.inner
+        super().__init__(dims, [len(m[1]) for m in maps])
+        self.inner, self.maps, self.fixed, self.sign = inner, list(maps), dict(fixed), int(sign)
+
+    def eval(self, sel):
+        nd_in = len(self.inner.shape)
+        inner_sel = [None] * nd_in
+        for (pos, idx, fill, _), s in zip(self.maps, sel):
+            j = idx[s]
+            if fill is not None:
+                j = np.where(fill[s] != 0, 0, j)
+            inner_sel[pos] = j
+        for pos, v in self.fixed.items():
+            inner_sel[pos] = np.array([v], dtype=np.int64)
+        res = self.inner.eval(inner_sel)
+        order = [m[0] for m in self.maps] + sorted(self.fixed)
+        res = np.transpose(res, order).reshape([len(s) for s in sel])
+        if self.sign < 0:
+            res = -res
+        elif not res.flags.writeable or any(m[2] is not None for m in self.maps):
+            res = np.array(res)
+        for k in sorted(range(len(self.maps)), key=lambda k: self.maps[k][3]):  # later fills win
+            fill = self.maps[k][2]
+            if fill is None:
+                continue
+            f = fill[sel[k]]
+            hit = np.nonzero(f)[0]
+            if hit.size:
+                key = [slice(None)] * res.ndim
+                key[k] = hit
+                shp = [1] * res.ndim
+                shp[k] = hit.size
+                res[tuple(key)] = f[hit].reshape(shp)
+        return res
+
+
+class _Concat(Plane):
+    __slots__ = ("parts", "axis", "bounds")
+
+    def __init__(self, parts: List[Plane], axis: int):
+        shape = list(parts[0].shape)
+        shape[axis] = sum(p.shape[axis] for p in parts)
+        super().__init__(parts[0].dims, shape)
+        self.parts, self.axis = list(parts), int(axis)
+        self.bounds = np.cumsum([0] + [p.shape[axis] for p in parts])
+
+    def eval(self, sel):
+        s = np.asarray(sel[self.axis], dtype=np.int64)
+        out = np.empty([len(x) for x in sel], dtype=np.int64)
+        for p, b0, b1 in zip(self.parts, self.bounds[:-1], self.bounds[1:]):
+            hit = np.nonzero((s >= b0) & (s < b1))[0]
+            if not hit.size:
+                continue
+            sub = list(sel)
+            sub[self.axis] = s[hit] - b0
+            key = [slice(None)] * out.ndim
+            key[self.axis] = hit
+            out[tuple(key)] = p.eval(sub)
+        return out
+
+
+class _Stack(Plane):
+    __slots__ = ("parts", "position")
+
+    def __init__(self, parts: List[Plane], dim: str, position: int):
+        order = parts[0].dims
+        super().__init__(order[:position] + (dim,) + order[position:],
+                         parts[0].shape[:position] + (len(parts),) + parts[0].shape[position:])
+        self.parts, self.position = list(parts), int(position)
+
+    def eval(self, sel):
+        faces = np.asarray(sel[self.position], dtype=np.int64)
+        sub = [x for k, x in enumerate(sel) if k != self.position]
+        out = np.empty([len(x) for x in sel], dtype=np.int64)
+        cache = {}
+        for j, f in enumerate(faces):
+            f = int(f)
+            if f not in cache:
+                cache[f] = self.parts[f].eval(sub)
+            key = [slice(None)] * out.ndim
+            key[self.position] = j
+            out[tuple(key)] = cache[f]
+        return out
 
 
 def identity_plane(sizes: Sequence[int], dims: Sequence[str], offset: int = 0) -> Plane:
-    n = int(np.prod(sizes, dtype=np.int64)) if len(sizes) else 1
-    return Plane((np.arange(n, dtype=np.int64) + (1 + offset)).reshape(tuple(sizes)), dims)
+    return _Base(tuple(int(n) for n in sizes), dims, offset)
 
 
 class FillTable:
