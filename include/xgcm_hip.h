@@ -116,7 +116,10 @@ int xg_cumsum1d_f64(const double* in, double* out, const int64_t* shape, int ndi
 /* ---- weighted sum along one axis -------------------------------------------------------- */
 /* out = sum_k (in * w)[.., k, ..] with `axis` removed from the output shape; NaN products
  * count as 0 if `skipna`.  Along a non-last axis the sum runs sequentially k = 0..n-1 per
- * output cell (bit-identical to numpy); along the last axis it is a lane-strided tree. */
+ * output cell (bit-identical to numpy); along the last axis it is a lane-strided tree.
+ * `skipna` also selects the two denominators of a weighted mean (xarray's
+ * `da.weighted(w).mean`, xgcm/grid.py:1681-1685) in the same single pass: 2 = sum of the weights of
+ * the valid (non-NaN) cells of `in`, 3 = sum of the weights of all cells. */
 int xg_reduce1d_f64(const double* in, double* out, const int64_t* shape, int ndim, int axis,
                     int skipna, const double* w, const int64_t* w_strides, void* stream);
 

@@ -170,6 +170,16 @@ def test_reduce(dev, shape):
                     np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-13, equal_nan=True)
                 else:
                     _eq(got, exp)
+        # the two denominators of a weighted mean: weights of the valid cells / of all cells, same pass
+        w = _metric_for(shape, set(range(nd)), 22)
+        for mode, ones in (("valid", (~np.isnan(a)).astype(a.dtype)), ("all", np.ones_like(a))):
+            for ww in (w, None):
+                exp = R.integrate(ones, axis, ww, False)
+                got = dev.tohost(dev.reduce1d(a, axis, ww, mode))
+                if axis == nd - 1:
+                    np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-13)
+                else:
+                    _eq(got, exp)
 
 
 def test_pad_matches_numpy_chain(dev):

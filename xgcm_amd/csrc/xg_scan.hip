@@ -23,6 +23,17 @@ __device__ __forceinline__ dv nan0(dv v) {
   return o;
 }
 
+// reduction input modes beyond plain / NaN-skipping sums (xg_reduce1d `skipna` argument):
+// 2: every valid (non-NaN) cell counts as 1, NaN cells as 0 -> sum of the weights of the valid cells,
+// 3: every cell counts as 1 -> sum of the weights (the two denominators of a weighted mean)
+__device__ __forceinline__ real as_count(real v, int mode) { return (mode == 3 || v == v) ? real(1) : real(0); }
+__device__ __forceinline__ dv as_count(dv v, int mode) {
+  dv o;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) o[k] = as_count(v[k], mode);
+  return o;
+}
+
 template <int V, int MET, bool NTL, bool NTS, int U>
 __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
@@ -331,6 +342,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
   T acc = splat<T>(real(0));
   bool started = false;
   auto step = [&](int64_t k, T v) {
+    if (skipna >= 2) v = as_count(v, skipna);
     if (HAS_W) v = v * ldm<T>(wgt, mb + k * mw.axis, ms);
     if (skipna) v = nan0(v);
     acc = started ? acc + v : v;
@@ -368,6 +380,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
     const int64_t nvec = n / NV;
     for (int64_t t = lane; t < nvec; t += WAVE) {
       dv v = *reinterpret_cast<const dv*>(prow + t * NV);
+      if (skipna >= 2) v = as_count(v, skipna);
       if (HAS_W) v = v * ldm<dv>(wgt, mb + t * NV * mw.axis, mw.axis);
       if (skipna) v = nan0(v);
       a = a + v;
@@ -378,6 +391,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
   }
   for (int64_t k = k0 + lane; k < n; k += WAVE) {
     real v = prow[k];
+    if (skipna >= 2) v = as_count(v, skipna);
     if (HAS_W) v = v * wgt[mb + k * mw.axis];
     if (skipna) v = nan0(v);
     acc += v;
@@ -467,6 +481,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
                     const real* w, const int64_t* w_strides, void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (w && !w_strides) return fail(XG_ERR_INVALID, "weight without strides");
+  if (skipna < 0 || skipna > 3) return fail(XG_ERR_INVALID, "skipna / count mode %d not in [0,3]", skipna);
   Geo g; MIdx mw;
   int rc = build_geo(shape, ndim, axis, 1, w ? w_strides : nullptr, nullptr, &g, &mw, nullptr);
   if (rc) return rc;

@@ -222,8 +222,12 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
     return out
 
 
-def reduce1d(x, axis: int, w=None, skipna: bool = True) -> torch.Tensor:
-    """sum_k (x * w) along `axis`, axis removed (xg_reduce1d_f64)."""
+_REDUCE_MODE = {"valid": 2, "all": 3}
+
+
+def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
+    """sum_k (x * w) along `axis`, axis removed (xg_reduce1d_f64).  `skipna` True / False, or the count modes
+    "valid" (sum of the weights of the non-NaN cells of x) / "all" (sum of the weights)."""
     lib = _hip.load()
     dt, sfx = _common(x, w)
     x = asdevice(x, dt)
@@ -238,7 +242,7 @@ def reduce1d(x, axis: int, w=None, skipna: bool = True) -> torch.Tensor:
         return synthetic(tuple(oshape), 0, 0, 0.0, 0.0, out=out)
     _hip.check(
         getattr(lib, "xg_reduce1d_" + sfx)(
-            x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, int(bool(skipna)),
+            x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, _REDUCE_MODE.get(skipna, int(bool(skipna))),
             _ptr(w), _hip.i64(_bstrides(w, shape, "w")), _stream(),
         )
     )

@@ -644,18 +644,23 @@ class Grid:
         extra = [d for d in weight.dims if d not in da.dims]
         if extra:  # weight adds dims: fall back to the explicit product (broadcast result)
             return (da * weight).sum(dims, skipna=skipna, keep_attrs=keep_attrs)
+        out = self._weighted_reduce(da, weight, dims, True if skipna is None else bool(skipna), keep_attrs)
+        return to_xarray(out) if was_xr else out
+
+    def _weighted_reduce(self, da, weight, dims, mode, keep_attrs=False):
+        """sum over `dims` of da * weight in one `xg_reduce1d` launch per dim (the weight rides in the first);
+        `mode`: skipna True / False, or "valid" / "all" = the weights of the valid / of all cells of `da`."""
         host = not _is_tensor(da.data)
         cur_dims = list(da.dims)
         data = da.data
         w = _aligned_view(weight, da.dims)
         for i, d in enumerate(dims):
             num = cur_dims.index(d)
-            data = _dev.reduce1d(data, num, w if i == 0 else None, True if skipna is None else bool(skipna))
+            data = _dev.reduce1d(data, num, w if i == 0 else None, mode if i == 0 else (mode if isinstance(mode, bool) else False))
             cur_dims.pop(num)
         coords = OrderedDict((k, c) for k, c in da.coords.items() if all(cd in cur_dims for cd in c.dims))
-        out = DataArray(_dev.tohost(data) if host else data, cur_dims, coords=coords, name=da.name,
-                        attrs=da.attrs if keep_attrs else None)
-        return to_xarray(out) if was_xr else out
+        return DataArray(_dev.tohost(data) if host else data, cur_dims, coords=coords, name=da.name,
+                         attrs=da.attrs if keep_attrs else None)
 
     def cumint(self, da, axis, **kwargs):
         """Cumulative integral `cumsum(da * metric, axis)` (grid.py:1607-1660)."""
@@ -674,13 +679,15 @@ class Grid:
         weight = self._resident(self.get_metric(da, axis), da.data)
         dims = self._get_dims_from_axis(da, axis)
         skip = True if skipna is None else bool(skipna)
-        num = (da * weight).sum(dims, skipna=skip)
-        if skip:
-            valid = _valid_mask(da)
-            den = (valid * weight).sum(dims, skipna=False)
-        else:
-            ones = da._replace(data=_ones_like(da.data), coords=OrderedDict())
+        if [d for d in weight.dims if d not in da.dims]:  # weight adds dims: explicit broadcast products
+            num = (da * weight).sum(dims, skipna=skip)
+            ones = _valid_mask(da) if skip else da._replace(data=_ones_like(da.data), coords=OrderedDict())
             den = (ones * weight).sum(dims, skipna=False)
+        else:
+            # two passes over `da`, 8 B/cell each: sum(da * w) and sum(w over the valid cells) -- the weighting
+            # and the validity test ride inside the reduction kernel (reference: product, mask and sum arrays)
+            num = self._weighted_reduce(da, weight, dims, skip)
+            den = self._weighted_reduce(da, weight, dims, "valid" if skip else "all")
         out = num / den
         return to_xarray(out) if was_xr else out
 
