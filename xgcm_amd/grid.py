@@ -570,6 +570,7 @@ class Grid:
             raise ValueError(
                 "The 'keep_coords' argument has been removed. Coordinates compatible with the output are now always preserved."
             )
+        pre_weight = kwargs.pop("_pre_weight", None)  # cumint: `da * metric` folded into the first scan's load
         if kwargs:
             raise TypeError(f"cumsum() got unexpected keyword argument(s): {list(kwargs)}")
         da, was_xr = self._wrap_in(da)
@@ -608,6 +609,12 @@ class Grid:
             out_dims = tuple(new_dim if d == dim else d for d in data.dims)
             weighted = metric_weighted.get(ax.name) if isinstance(metric_weighted, dict) else None
             m_in = m_out = None
+            if pre_weight is not None:
+                if weighted or generic_pad:  # two input factors / pad-after route: explicit product first
+                    data = data * pre_weight
+                else:
+                    m_in = _aligned_view(pre_weight, data.dims)
+                pre_weight = None
             if weighted:
                 m_in = _aligned_view(self._resident(self.get_metric(data, weighted), data.data), data.dims)
                 m_out = _aligned_view(
@@ -624,7 +631,7 @@ class Grid:
                 if weighted:
                     res = res / self._resident(self.get_metric(res, weighted), res.data)
             else:
-                keep_int = gridops.signed_int_dtype(data.data) if not weighted else None
+                keep_int = gridops.signed_int_dtype(data.data) if (not weighted and m_in is None) else None
                 out = _dev.cumsum1d(data.data, num, trim_lo, trim_hi, pad_lo, pad_hi,
                                     bc if (pad_lo or pad_hi) else None,
                                     gridops.int_fill(0.0 if fv is None else float(fv), keep_int), rev, True, m_in, m_out)
@@ -666,7 +673,10 @@ class Grid:
         """Cumulative integral `cumsum(da * metric, axis)` (grid.py:1607-1660)."""
         da, was_xr = self._wrap_in(da)
         weight = self._resident(self.get_metric(da, axis), da.data)
-        res = self.cumsum(da * weight, axis, **kwargs)
+        if [d for d in weight.dims if d not in da.dims] or gridops.signed_int_dtype(da.data) is not None:
+            res = self.cumsum(da * weight, axis, **kwargs)  # the product has more dims than `da` / integer data
+        else:
+            res = self.cumsum(da, axis, _pre_weight=weight, **kwargs)  # same products, formed inside the scan
         return to_xarray(res) if was_xr else res
 
     def average(self, da, axis, **kwargs):
