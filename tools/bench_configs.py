@@ -24,14 +24,23 @@ from xgcm_amd import device as D  # noqa: E402
 
 
 def timeit(fn, reps):
-    fn(); fn()
+    """median device time of `fn` over `reps` back-to-back launches (events on the launch stream), after a
+    warm-up of at least 0.15 s so that the first op of a config is not timed on ramping clocks"""
+    import time
+
+    t0 = time.perf_counter()
+    fn()
     torch.cuda.synchronize()
-    ts = []
-    for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); e1.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    ts.sort()
+    while time.perf_counter() - t0 < 0.15:
+        fn()
+        torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
     return ts[len(ts) // 2]
 
 
