@@ -173,7 +173,8 @@ def main():
 
     # untimed priming (allocator pool, code-object load, clock ramp) so that small --warmup values do
     # not leak one-off start-up stalls into the timed region; then the W warmup steps as contracted
-    for _ in range(5):
+    prime = int(os.environ.get("XG_BENCH_PRIME", "5"))
+    for _ in range(prime):
         step()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
