@@ -538,9 +538,15 @@ int launch_contig(const StencilCall& c) {
   return 0;
 }
 
+// rows of the strided axis per wave-task.  One row (+ its halo row, an L2 hit thanks to the banded order) is the
+// most robust choice: measured through the raw ABI on a cool and on a warm MI355X (tools/abi_ab.py), Y stencils
+// 78.9 / 78.0 % with SEG = 1, 79.7 / 76.2 % with 2, 78.7 / 73.9 % with 4; Z (column chunks) 79.1 / 77.0 %, 77.7 / 73.9 %,
+// 76.1 / 70.5 % -- the fewer rows a thread carries, the less it loses when the device is warm.
+constexpr int STENCIL_SEG = 1;
+
 template <int OP, int V, int MET>
 int launch_seg(const StencilCall& c) {
-  constexpr int SEG = 4;
+  constexpr int SEG = STENCIL_SEG;
   const u64 ntile = (u64)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
   const u64 nseg = (u64)((c.g.n_out + SEG - 1) / SEG);
   const Chunk noch = make_chunk(0, 1, 0);
@@ -549,8 +555,8 @@ int launch_seg(const StencilCall& c) {
   if (per_outer > MAX_ITEMS) return launch_march<OP, V, MET>(c);  // (never the case below 2^31 cells per outer index)
   const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
   const u64 outer_per = MAX_ITEMS / per_outer;
-  // z-banding: a single outer dim along which every metric is broadcast, one launch
-  const u32 ZB_SEGS = 4;
+  // z-banding: a single outer dim along which every metric is broadcast, one launch (bands of 16 rows)
+  const u32 ZB_SEGS = 16 / SEG;
   const bool zb_ok = !ck.on && MET != 0 && tune().zband && c.g.n_outer == 1 && (!c.m_in || c.mi.outer[0] == 0) &&
                      (!c.m_out || c.mo.outer[0] == 0);
   if (zb_ok) {
