@@ -12,7 +12,8 @@ import os
 from typing import Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxgcm_hip.so")
+# XG_HIP_LIB points at another build of the same ABI (A/B measurements of kernel variants on one GPU)
+LIB_PATH = os.environ.get("XG_HIP_LIB") or os.path.join(_HERE, "libxgcm_hip.so")
 
 # enums of include/xgcm_hip.h
 OP = {"diff": 0, "interp": 1, "min": 2, "max": 3}

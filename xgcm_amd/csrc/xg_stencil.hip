@@ -3,6 +3,10 @@
 
 #include "xg_common.hpp"
 
+#ifndef XG_FUSED_SEG
+#define XG_FUSED_SEG 2  // rows per wave-task of the two-axis kernel (K8); 2 and 4 measure alike, 1 loses 4 points
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -701,7 +705,7 @@ int XG_FN(xg_stencil2d)(int op, const real* in, real* out, const int64_t* shape,
   for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
   if (outer == 0 || ny == 0 || nx == 0) return XG_OK;
   if (nx % NV || !aligned16(in) || !aligned16(out)) return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil needs an X extent that is a multiple of the 16-byte lane vector");
-  constexpr int SEG = 4;
+  constexpr int SEG = XG_FUSED_SEG;
   const u64 ntile = (u64)((nx + NV * WAVE - 1) / (NV * WAVE));
   const u64 nseg = (u64)((ny + SEG - 1) / SEG);
   const u64 per_outer = ntile * nseg;

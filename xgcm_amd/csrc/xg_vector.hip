@@ -3,6 +3,13 @@
 
 #include "xg_common.hpp"
 
+// rows of Y per wave-task of the fused two-component kernels (see STENCIL_SEG in xg_stencil.hip): A/B on one GPU
+// (XG_HIP_LIB), 4320 x 4320 x 90: vorticity 70.0 / 71.7 / 71.3 % with 4 / 2 / 1 rows, gradient 73.9 / 75.7 / 75.6 %,
+// flux 71.4 / 74.3 / 74.5 %; the two-axis kernel K8 78.3 / 78.6 / 75.1 %  =>  2
+#ifndef XG_FUSED_SEG
+#define XG_FUSED_SEG 2
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -434,7 +441,7 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
   }
   const int V = (aligned16(u) && aligned16(v) && aligned16(out) && nx % NV == 0 &&
                  (bc_y != XG_BC_HALO || aligned16(halo_y))) ? NV : 1;
-  constexpr int SEG = 4;
+  constexpr int SEG = XG_FUSED_SEG;
   const u64 ntile = (u64)((nx + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
   const u64 nseg = (u64)((ny + SEG - 1) / SEG);
   const u64 per_outer = ntile * nseg;
@@ -443,7 +450,7 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
   const u64 outer_per = MAX_ITEMS / per_outer;
   hipStream_t st = (hipStream_t)stream;
   const bool nts = tune().nt_store;
-  const u32 ZB_SEGS = 4;
+  const u32 ZB_SEGS = 16 / SEG;
   ZBand zb = make_zband(false, 0, 0, 1);
   u64 outer_step = outer_per;
   if (area && area_bcast_all && tune().zband && outer >= 2) {
@@ -542,7 +549,7 @@ static int pair2d_impl(int mode, const real* a, const real* u, const real* v, re
   if (mode == 1) al = al && aligned16(u) && aligned16(v);
   if (bc_y == XG_BC_HALO) al = al && aligned16(halo_y);
   const int V = al ? NV : 1;
-  constexpr int SEG = 4;
+  constexpr int SEG = XG_FUSED_SEG;
   const u64 ntile = (u64)((nx + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
   const u64 nseg = (u64)((ny + SEG - 1) / SEG);
   const u64 per_outer = ntile * nseg;
