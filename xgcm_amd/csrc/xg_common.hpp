@@ -7,9 +7,10 @@
 //  (2) lanes run along the contiguous (last) dimension with 16-byte accesses whatever the op axis
 //      is, ONE vector per lane, thread id == linear memory order (a copy written this way streams
 //      at 80 % of the 8 TB/s spec; 2-8 tiles per thread or grid-stride loops lose 10-35 %);
-//  (3) the set of rows in flight stays compact: along a strided axis a wave register-marches only
-//      4 rows, whole-plane rows (the Z axis) are cut into column chunks; only the scans and reductions,
-//      whose sums are sequential by contract, march whole columns;
+//  (3) the set of rows in flight stays compact: along a strided axis a wave owns ONE row (two in the fused
+//      two-component kernels) and re-reads the halo row from its XCD's L2; whole-plane rows (the Z axis) are
+//      cut into column chunks; only the scans and reductions, whose sums are sequential by contract, march
+//      whole columns;
 //  (4) workgroup b runs on XCD b % 8, each XCD has its own L2: the linear work sequence is cut into
 //      8 contiguous bands, one per XCD, so halo-row re-reads and broadcast metrics hit that XCD's
 //      L2 ("banding", "z-banding") -- speed only, never correctness;
