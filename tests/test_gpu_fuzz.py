@@ -108,6 +108,38 @@ def test_fuzz_cumsum_reduce(dev, seed, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f64", "f32"])
 @pytest.mark.parametrize("seed", range(4))
+def test_fuzz_row_scan_any_length(dev, seed, dtype):
+    """The vectorised contiguous-axis scan on rows of ANY length: rows that start before a 16-byte boundary
+    (lead cells), end after one (tail cells), halo cells inside / next to / outside the aligned groups,
+    both directions, every trim / pad combination of the ABI."""
+    rng = np.random.default_rng(4000 + seed)
+    rtol, atol = (1e-11, 1e-11) if dtype == np.float64 else (3e-4, 3e-4)
+    lens = [4, 5, 6, 7, 8, 9, 11, 12, 13, 15, 16, 17, 63, 65, 127, 129, 130, 131, 257, 259, 513, 1025, 1030, 2049]
+    tables = [(0, 0, 0, 0), (0, 1, 1, 0), (0, 1, 0, 0), (0, 0, 1, 0), (1, 0, 0, 1), (1, 0, 0, 0), (0, 0, 0, 1), (0, 0, 1, 1), (1, 1, 1, 1)]
+    for case in range(150):
+        nd = int(rng.integers(1, 4))
+        shape = tuple(int(rng.integers(1, 7)) for _ in range(nd - 1)) + (int(rng.choice(lens)),)
+        tl, th, pl, ph = tables[int(rng.integers(0, len(tables)))]
+        if shape[-1] - tl - th < 1:
+            continue
+        a = (rng.random(shape) - 0.5).astype(dtype)
+        if rng.random() < 0.3:
+            a[rng.random(shape) < 0.1] = np.nan
+        reverse, skipna = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        bc = str(rng.choice(["fill", "extend", "periodic"], p=[0.45, 0.45, 0.1])) if (pl or ph) else None
+        oshape = list(shape)
+        oshape[-1] += pl + ph - tl - th
+        m_in = (rng.random(shape) + 0.5).astype(dtype) if rng.random() < 0.3 else None
+        m_out = (rng.random(oshape) + 0.5).astype(dtype) if rng.random() < 0.3 else None
+        exp = R.cumsum1d(a, nd - 1, tl, th, pl, ph, bc, dtype(0.75), reverse, skipna, m_in, m_out)
+        got = dev.tohost(dev.cumsum1d(a, nd - 1, tl, th, pl, ph, bc, 0.75, reverse, skipna, m_in, m_out))
+        assert got.dtype == dtype and got.shape == exp.shape
+        np.testing.assert_allclose(got, exp, rtol=rtol, atol=atol, equal_nan=True,
+                                   err_msg=str((shape, (tl, th, pl, ph), bc, reverse, skipna)))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f64", "f32"])
+@pytest.mark.parametrize("seed", range(4))
 def test_fuzz_two_axis_and_vorticity(dev, seed, dtype):
     rng = np.random.default_rng(3000 + seed)
     for case in range(15):

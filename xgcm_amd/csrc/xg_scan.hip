@@ -124,24 +124,24 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
   __shared__ real wtot[2][WPB];
   const int64_t row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int64_t n = g.n_in;
+  const int n = (int)g.n_in, no = (int)g.n_out;  // the host sends rows of 2^31 cells or more elsewhere
   const real* prow = in + row * n;
-  real* orow = out + row * g.n_out;
+  real* orow = out + row * no;
   int64_t mi_base = 0, mo_base = 0;
   if (HAS_MI) mi_base = outer_off(g, mi, row);
   if (HAS_MO) mo_base = outer_off(g, mo, row);
-  const int64_t first_kept = a.trim_lo, last_kept = n - 1 - a.trim_hi;
-  const int64_t shift = a.pad_lo - a.trim_lo;
-  auto put = [&](int64_t j, real v) {
-    if (HAS_MO) v = v / m_out[mo_base + j * mo.axis];
+  const int first_kept = a.trim_lo, last_kept = n - 1 - a.trim_hi;
+  const int shift = a.pad_lo - a.trim_lo;
+  auto put = [&](int j, real v) {
+    if (HAS_MO) v = v / m_out[mo_base + (int64_t)j * mo.axis];
     orow[j] = v;
   };
-  auto fetch = [&](int64_t k) -> real {
+  auto fetch = [&](int k) -> real {  // k-th input in scan order (32-bit in-row indices: the loop is VALU-bound)
     real v = real(0);
     if (k < n) {
-      const int64_t idx = a.reverse ? n - 1 - k : k;
+      const int idx = a.reverse ? n - 1 - k : k;
       v = prow[idx];
-      if (HAS_MI) v = v * m_in[mi_base + idx * mi.axis];
+      if (HAS_MI) v = v * m_in[mi_base + (int64_t)idx * mi.axis];
       if (a.skipna) v = nan0(v);
     }
     return v;
@@ -149,9 +149,9 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
   real carry = real(0);
   int buf = 0;
   real cur = fetch(tid);
-  for (int64_t base = 0; base < n; base += BLOCK, buf ^= 1) {
-    const int64_t k = base + tid;
-    const int64_t idx = a.reverse ? n - 1 - k : k;
+  for (int base = 0; base < n; base += BLOCK, buf ^= 1) {
+    const int k = base + tid;
+    const int idx = a.reverse ? n - 1 - k : k;
     const real v = cur;
     cur = fetch(k + BLOCK);  // next chunk's load is in flight across this chunk's scan + barrier
     real s = v;
@@ -175,28 +175,31 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
       if (idx >= first_kept && idx <= last_kept) put(idx + shift, c);
       if (idx == first_kept) {
         if (a.pad_lo && a.bc == XG_BC_EXTEND) put(0, c);
-        if (a.pad_hi && a.bc == XG_BC_PERIODIC) put(g.n_out - 1, c);
+        if (a.pad_hi && a.bc == XG_BC_PERIODIC) put(no - 1, c);
       }
       if (idx == last_kept) {
         if (a.pad_lo && a.bc == XG_BC_PERIODIC) put(0, c);
-        if (a.pad_hi && a.bc == XG_BC_EXTEND) put(g.n_out - 1, c);
+        if (a.pad_hi && a.bc == XG_BC_EXTEND) put(no - 1, c);
       }
     }
   }
   if (tid == 0 && a.bc == XG_BC_FILL) {
     if (a.pad_lo) put(0, a.fill);
-    if (a.pad_hi) put(g.n_out - 1, a.fill);
+    if (a.pad_hi) put(no - 1, a.fill);
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// K6v: cumsum along the CONTIGUOUS axis when output rows are 16-B aligned (n_out % NV == 0, no
-// periodic halo).  Threads own aligned groups of NV consecutive OUTPUTS (one 16-B store each) and
-// fetch the NV inputs behind them with narrow consecutive loads (input = output index - shift, so
-// it may be misaligned: served by L1, the trick that made K1g fast); a thread scans its group,
-// waves scan the group totals with shuffles, wave totals go through LDS, the running carry stays
-// in a register.  Inputs that map outside the output range (at most one, when the trim is on the
-// side the scan starts from) seed the carry.  Re-associated sum => 1e-12 parity like K6.
+// K6v: cumsum along the CONTIGUOUS axis, any row length (no periodic halo).  The output ARRAY is 16-B
+// aligned, a row of it need not be (N + 1 outputs of center -> outer): the row starts `lead` cells before
+// a 16-B boundary and ends `tail` cells after one.  Threads own the aligned groups of NV consecutive
+// OUTPUTS in between (one 16-B store each) and fetch the NV inputs behind them with narrow consecutive
+// loads (input = output index - shift, so it may be misaligned: served by L1, the trick that made K1g
+// fast; one 16-B load when the groups coincide); a thread scans its group, waves scan the group totals
+// with shuffles, wave totals go through LDS, the running carry stays in a register.  The <= NV-1 lead
+// and tail cells are summed by every thread (they seed / follow the carry) and stored by thread 0.
+// Inputs that map outside the output range (at most one, when the trim is on the side the scan starts
+// from) seed the carry.  Re-associated sum => 1e-12 parity like K6.
 // ------------------------------------------------------------------------------------------
 template <int MET, bool NTS, int BS>
 __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
@@ -216,6 +219,9 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
   if (HAS_MI) mi_base = outer_off(g, mi, row);
   if (HAS_MO) mo_base = outer_off(g, mo, row);
   const int shift = a.pad_lo - a.trim_lo;
+  const int lead = (int)((NV - (int)(((u64)row * (u64)no) % NV)) % NV);  // cells before the row's first 16-B boundary
+  const int groups = (no - lead) / NV;
+  const int gend = lead + groups * NV;                                   // first tail cell
   auto fetch = [&](int idx) -> real {  // weighted, NaN-cleaned input or 0 outside the row
     if (idx < 0 || idx >= n) return real(0);
     real v = prow[idx];
@@ -223,17 +229,53 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
     if (a.skipna) v = nan0(v);
     return v;
   };
+  auto put1 = [&](int j, real v) {  // scalar store of output cell j
+    if (HAS_MO) v = v / m_out[mo_base + (int64_t)j * mo.axis];
+    orow[j] = v;
+  };
+  // halo cells of the padded cumulative result (fill / extend only): j = 0 and j = no - 1; an `extend` halo
+  // repeats its inner neighbour (j = 1 resp. no - 2), which may live in another part of the row
+  const bool lo_halo = a.pad_lo != 0, hi_halo = a.pad_hi != 0, fillmode = (a.bc == XG_BC_FILL);
+  // sequential part in scan order over output cells [j0, j1] (either direction), all threads alike, thread 0
+  // stores; returns the carry after it
+  auto scalars = [&](real carry, int jfirst, int count) -> real {
+    real prev = real(0);
+    bool have_prev = false;
+    for (int q = 0; q < count; ++q) {
+      const int j = a.reverse ? jfirst - q : jfirst + q;
+      carry += fetch(j - shift);
+      real val = carry;
+      const bool is_lo = lo_halo && j == 0, is_hi = hi_halo && j == no - 1;
+      if (tid == 0) {
+        if (is_lo || is_hi) {
+          if (fillmode) put1(j, (real)a.fill);
+          else if (have_prev && ((is_lo && a.reverse) || (is_hi && !a.reverse))) put1(j, prev);  // neighbour came just before
+          // otherwise the neighbour comes next (stored below) or sits in a group (its owner stores the halo)
+        } else {
+          put1(j, val);
+          // the neighbour of a halo cell that was passed one step earlier in scan order
+          if (!fillmode && lo_halo && j == 1 && !a.reverse && lead >= 2) put1(0, val);
+          if (!fillmode && hi_halo && j == no - 2 && a.reverse && no - gend >= 2) put1(no - 1, val);
+        }
+      }
+      prev = val;
+      have_prev = true;
+    }
+    return carry;
+  };
   // the one input (if any) that precedes everything in scan order but maps outside [0, no)
   real carry = real(0);
   if (!a.reverse && shift < 0) carry = fetch(0);
   if (a.reverse && (n - 1 + shift) >= no) carry = fetch(n - 1);
-  const int groups = no / NV;
+  // cells before the groups in scan order
+  if (!a.reverse) carry = scalars(carry, 0, lead);
+  else carry = scalars(carry, no - 1, no - gend);
   int buf = 0;
-  auto group_lo = [&](int t) -> int { return a.reverse ? no - NV * (t + 1) : NV * t; };
+  auto group_lo = [&](int t) -> int { return a.reverse ? lead + NV * (groups - 1 - t) : lead + NV * t; };
   // inputs of output group t.  All but the first / last group of a row lie inside the row: no per-element
   // bounds checks there (they were half of the loop's VALU work); one 16-B load when input and output groups
-  // coincide (shift == 0) and rows keep the alignment, else NV narrow loads served by L1.
-  const bool vec_in = (shift == 0) && (n % NV == 0) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
+  // coincide (no shift, equal row lengths) and the arrays keep the alignment, else NV narrow loads served by L1.
+  const bool vec_in = (shift == 0) && (n == no) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
   auto load_group = [&](int t, real (&x)[NV]) {
     if (t >= groups) {
 #pragma unroll
@@ -306,13 +348,19 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
       dv res;
 #pragma unroll
       for (int k = 0; k < NV; ++k) res[k] = before + l[k];
-      // halo cells (fill / extend only here): j = 0 and j = no - 1 sit next to a kept cell of the same group
-      if (a.pad_lo && jlo == 0) res[0] = (a.bc == XG_BC_FILL) ? (real)a.fill : res[1];
-      if (a.pad_hi && jlo + NV == no) res[NV - 1] = (a.bc == XG_BC_FILL) ? (real)a.fill : res[NV - 2];
+      // halo cells inside this group sit next to a kept cell of the same group
+      if (lo_halo && jlo == 0) res[0] = fillmode ? (real)a.fill : res[1];
+      if (hi_halo && jlo + NV == no) res[NV - 1] = fillmode ? (real)a.fill : res[NV - 2];
+      // an `extend` halo cell just outside this group (lead == 1 / one tail cell) repeats this group's edge cell
+      if (!fillmode && lo_halo && jlo == 1) put1(0, res[0]);
+      if (!fillmode && hi_halo && jlo + NV == no - 1) put1(no - 1, res[NV - 1]);
       if (HAS_MO) res = res / ldm<dv>(m_out, mo_base + (int64_t)jlo * mo.axis, mo.axis);
       stg<dv, NTS>(orow + jlo, res);
     }
   }
+  // cells after the groups in scan order
+  if (!a.reverse) scalars(carry, gend, no - gend);
+  else scalars(carry, lead - 1, lead);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -432,7 +480,7 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
     const u64 nblocks = (u64)g.outer;
     if ((rc = check_grid(nblocks + 8))) return rc;
     const bool periodic_halo = (pad_lo || pad_hi) && bc == XG_BC_PERIODIC;
-    if (tune().scan_vec && !periodic_halo && n_out % NV == 0 && n_out >= 2 * NV && aligned16(out) && nblocks < 0x7ffffff0ull &&
+    if (tune().scan_vec && !periodic_halo && n_out >= 3 * NV && aligned16(out) && nblocks < 0x7ffffff0ull &&
         g.n_in < 0x7fff0000ll && n_out < 0x7fff0000ll) {
       const u32 nrows = (u32)nblocks, grid = ((nrows + 7) / 8) * 8;
       const bool nts = tune().nt_store;
@@ -445,6 +493,7 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
 #undef XG_L
 #undef XG_M
     } else {
+      if (g.n_in >= 0x7fff0000ll || n_out >= 0x7fff0000ll) return fail(XG_ERR_UNSUPPORTED, "rows of 2^31 cells or more along the contiguous scan axis");
 #define XG_M(M) hipLaunchKernelGGL((k_cumsum_contig<M>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, a, m_in, mi, m_out, mo)
       switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
 #undef XG_M
