@@ -422,20 +422,30 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
   int64_t mb = 0;
   if (HAS_W) mb = outer_off(g, mw, row);
   real acc = real(0);
-  int64_t k0 = 0;
-  if (VEC) {  // rows 16-B aligned (host): 16-B loads, NV partial sums per lane, two loads in flight
+  int64_t k0 = 0, lead = 0;
+  if (VEC) {  // array 16-B aligned (host): 16-B loads between the row's first and last 16-B boundary, NV partial
+              // sums per lane, two loads in flight; the <= NV-1 cells before / after go through the scalar loops
+    lead = (NV - (int64_t)((row * (u64)n) % NV)) % NV;
     dv a = splat<dv>(real(0));
-    const int64_t nvec = n / NV;
+    const int64_t nvec = (n - lead) / NV;
     for (int64_t t = lane; t < nvec; t += WAVE) {
-      dv v = *reinterpret_cast<const dv*>(prow + t * NV);
+      const int64_t k = lead + t * NV;
+      dv v = *reinterpret_cast<const dv*>(prow + k);
       if (skipna >= 2) v = as_count(v, skipna);
-      if (HAS_W) v = v * ldm<dv>(wgt, mb + t * NV * mw.axis, mw.axis);
+      if (HAS_W) v = v * ldm<dv>(wgt, mb + k * mw.axis, mw.axis);
       if (skipna) v = nan0(v);
       a = a + v;
     }
 #pragma unroll
     for (int c = 0; c < NV; ++c) acc += a[c];
-    k0 = nvec * NV;
+    k0 = lead + nvec * NV;
+    if (lane < lead) {  // the row's first cells, before its first 16-B boundary
+      real v = prow[lane];
+      if (skipna >= 2) v = as_count(v, skipna);
+      if (HAS_W) v = v * wgt[mb + lane * mw.axis];
+      if (skipna) v = nan0(v);
+      acc += v;
+    }
   }
   for (int64_t k = k0 + lane; k < n; k += WAVE) {
     real v = prow[k];
@@ -540,7 +550,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
   if (g.inner == 1) {
     const u64 nblocks = ((u64)g.outer + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
-    const bool vec = aligned16(in) && (g.n_in % NV == 0) && g.n_in >= 4 * NV;  // every row starts 16-B aligned
+    const bool vec = aligned16(in) && g.n_in >= 4 * NV;  // rows of any length: lead / tail cells go through scalar loads
     if (vec) {
       if (w) hipLaunchKernelGGL((k_reduce_contig<true, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
       else hipLaunchKernelGGL((k_reduce_contig<false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
