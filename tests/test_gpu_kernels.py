@@ -341,6 +341,40 @@ def test_gradient_and_flux_with_pregathered_halos(dev, shape, dtype):
         _eq(dev.tohost(fy), v * iy)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("shape", [(3, 7, 9), (2, 5, 131), (5, 3, 2, 67), (1, 4, 1025), (4, 9), (6, 33), (2, 3, 4, 5, 7)])
+def test_strided_axis_with_misaligned_rows(dev, shape, dtype):
+    """K2g: odd inner extents (rows of the strided axis not 16-B aligned, e.g. `outer` X positions): every op,
+    every pad / boundary mode, every strided axis, with and without a pre-gathered halo -- bit for bit."""
+    a = _field(shape, 91, nan=True).astype(dtype)
+    nd = len(shape)
+    for axis in range(nd - 1):
+        for op in ("diff", "interp", "min", "max"):
+            for lo, hi in ((1, 0), (0, 1), (1, 1), (0, 0)):
+                if shape[axis] + lo + hi - 1 < 1:
+                    continue
+                for bc in (("periodic", "fill", "extend") if lo + hi else (None,)):
+                    _eq(dev.tohost(dev.stencil1d(op, a, axis, lo, hi, bc, -1.5)), R.stencil1d(op, a, axis, lo, hi, bc, dtype(-1.5)))
+                if lo + hi:
+                    hshape = list(shape)
+                    hshape[axis] = lo + hi
+                    halo = _field(hshape, 92).astype(dtype)
+                    padded = np.concatenate([np.take(halo, range(0, lo), axis=axis), a, np.take(halo, range(lo, lo + hi), axis=axis)], axis=axis)
+                    _eq(dev.tohost(dev.stencil1d_halo(op, a, halo, axis, lo, hi)), R.stencil1d(op, padded, axis, 0, 0, None))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_strided_axis_misaligned_whole_plane_rows(dev, dtype):
+    """K2g in its column-chunk order: rows of the strided axis are whole planes with an odd number of cells
+    (601 x 901 = 541 501 > 2048 tiles), incl. the groups that straddle two levels and the partial last group."""
+    shape = (5, 601, 901)
+    a = _field(shape, 93).astype(dtype)
+    for op, (lo, hi), bc in (("diff", (1, 0), "fill"), ("interp", (0, 1), "periodic"), ("max", (1, 1), "extend"), ("diff", (0, 0), None)):
+        _eq(dev.tohost(dev.stencil1d(op, a, 0, lo, hi, bc, 0.5)), R.stencil1d(op, a, 0, lo, hi, bc, dtype(0.5)))
+    halo = _field((1,) + shape[1:], 94).astype(dtype)
+    _eq(dev.tohost(dev.stencil1d_halo("diff", a, halo, 0, 1, 0)), R.stencil1d("diff", np.concatenate([halo, a]), 0, 0, 0, None))
+
+
 def test_gradient_metric_broadcast_patterns(dev):
     shape = (3, 2, 6, 8)
     a = _field(shape, 70)

@@ -98,6 +98,7 @@ struct Tune {
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
   int zb_rows;        // rows of the contiguous-axis kernel per band
   int scan_block;     // workgroup size of the contiguous-axis scan (128 / 256 / 512 / 1024)
+  int strided_gen;    // flat NV-group kernel for misaligned rows of a strided stencil axis
   int scan_vec;       // aligned-output-group scan for cumsum along the contiguous axis
   int contig_gen;     // pair-wise general path for odd / length-changing rows on the contiguous axis
   int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
@@ -112,6 +113,7 @@ struct Tune {
     zband = env_int("XG_ZBAND", 1);
     zb_rows = env_int("XG_ZB_ROWS", 16);
     scan_block = env_int("XG_SCAN_BLOCK", 256);
+    strided_gen = env_int("XG_STRIDED_GEN", 1);
     zchunk = env_int("XG_ZCHUNK", 256);
     transform_fast = env_int("XG_TRANSFORM_FAST", 1);
     pad_rows = env_int("XG_PAD_ROWS", 1);

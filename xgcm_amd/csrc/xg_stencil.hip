@@ -372,6 +372,108 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
 }
 
 // ------------------------------------------------------------------------------------------
+// K2g: strided axis, rows NOT vector-aligned (odd inner extent: fields on `outer` positions, N + 1 points
+// along X).  The view is (outer, n, inner); the output ARRAY is 16-B aligned even if its rows are not: a row
+// starts `lead` cells before a 16-B boundary, and from there on it is cut into NV-element groups that leave
+// as aligned 16-B stores.  The last group of a row runs over into the next row's lead cells, so every cell
+// has exactly one owner.  Work order and XCD banding are those of K2S with one row per wave-task (column
+// chunks for whole-plane rows), so the second source row of a task is an L2 hit; the row's coordinates and
+// its halo / fill decisions are wave-uniform.  Inputs are narrow consecutive loads (their alignment differs
+// from the output's).  No metrics here (they keep the scalar-lane path).
+// ------------------------------------------------------------------------------------------
+template <int OP, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_stencil_strided_gen(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk, FastDiv ntile,
+    FastDiv nseg, Chunk ck, int pad_lo, int bc, real fill, const real* __restrict__ halo) {
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
+  u32 oo, jj, tile;
+  if (ck.on) {  // (outer, chunk, row, tile in chunk)
+    const u32 cg = fdiv(w, ck.per_group);
+    const u32 rem = w - cg * ck.per_group.d;
+    jj = fdiv(rem, ck.ch);
+    oo = fdiv(cg, ck.fnchunk);
+    tile = (cg - oo * ck.fnchunk.d) * ck.ch.d + (rem - jj * ck.ch.d);
+    if (oo >= nouter || tile >= ntile.d) return;
+  } else {
+    const u32 r = fdiv(w, ntile);
+    tile = w - r * ntile.d;
+    oo = fdiv(r, nseg);
+    if (oo >= nouter) return;
+    jj = r - oo * nseg.d;
+  }
+  const int64_t inner = g.inner, n_in = g.n_in, n_out = g.n_out;
+  const int nhalo = (int)(n_out - n_in + 1);  // pad_lo + pad_hi
+  // the two source rows of output row (o, j): base pointers and fill flags
+  auto sources = [&](int64_t o, int64_t j, const real* (&src)[2], bool (&fl)[2]) {
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+      int64_t q = j + side - pad_lo;
+      fl[side] = false;
+      const real* base = in + o * n_in * inner;
+      if (q < 0 || q >= n_in) {
+        fl[side] = (bc == XG_BC_FILL);
+        if (bc == XG_BC_HALO) {  // pre-gathered halo rows, layout (outer, pad_lo + pad_hi, inner)
+          base = halo + o * nhalo * inner;
+          q = (q < 0) ? 0 : pad_lo;
+        } else {
+          q = (q < 0) ? ((bc == XG_BC_PERIODIC) ? n_in - 1 : 0) : ((bc == XG_BC_PERIODIC) ? 0 : n_in - 1);
+        }
+      }
+      src[side] = base + q * inner;
+    }
+  };
+  const int64_t o = o0 + oo, j = jj;
+  const int64_t rowstart = (o * n_out + j) * inner;             // flat index of the row's first cell
+  const int64_t lead = (NV - rowstart % NV) % NV;               // those cells belong to the previous row's last group
+  const int64_t x = lead + ((int64_t)tile * WAVE + (threadIdx.x & 63)) * NV;
+  if (x >= inner) return;
+  const real* src[2];
+  bool fl[2];
+  sources(o, j, src, fl);
+  dv res;
+  if (x + NV <= inner) {  // the group lies inside the row: consecutive narrow loads, no per-element logic
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const real l = src[0][x + e], r = src[1][x + e];
+      res[e] = op2<OP>(fl[0] ? fill : l, fl[1] ? fill : r);
+    }
+    stg<dv, NTS>(out + rowstart + x, res);
+    return;
+  }
+  // the row's last group runs over into the next row (or past the end of the array)
+  int64_t o2 = o, j2 = j + 1;
+  if (j2 == n_out) { j2 = 0; ++o2; }
+  const bool more = o2 < g.outer;
+  const real* src2[2] = {src[0], src[1]};
+  bool fl2[2] = {false, false};
+  if (more) sources(o2, j2, src2, fl2);
+  real vals[NV];
+#pragma unroll
+  for (int e = 0; e < NV; ++e) {
+    const int64_t xe = x + e;
+    real v = real(0);
+    if (xe < inner) {
+      const real l = src[0][xe], r = src[1][xe];
+      v = op2<OP>(fl[0] ? fill : l, fl[1] ? fill : r);
+    } else if (more) {
+      const real l = src2[0][xe - inner], r = src2[1][xe - inner];
+      v = op2<OP>(fl2[0] ? fill : l, fl2[1] ? fill : r);
+    }
+    vals[e] = v;
+  }
+  if (more) {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) res[e] = vals[e];
+    stg<dv, NTS>(out + rowstart + x, res);
+  } else {
+    for (int e = 0; x + e < inner; ++e) out[rowstart + x + e] = vals[e];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K8: the same two-point operator along BOTH of the last two axes in one pass, e.g.
 // Grid.interp(da, ["X", "Y"]) (tracer -> vorticity point).  The reference applies the axes one
 // after the other (xgcm/grid.py:798-800 carries a TODO about fusing them): pad + op along the
@@ -590,6 +692,39 @@ int launch_seg(const StencilCall& c) {
   return 0;
 }
 
+// flat NV-group walk for misaligned rows of a strided axis (no metrics); returns 1 when it does not apply
+template <int OP>
+int launch_strided_gen(const StencilCall& c) {
+  const Geo& g = c.g;
+  if (!g.idx32) return 1;
+  const u64 gmax = (u64)((g.inner + NV - 1) / NV);     // groups a row can hold
+  const u64 ntile = (gmax + WAVE - 1) / WAVE;
+  const u64 nrow = (u64)g.n_out;
+  const Chunk ck = make_chunk(ntile, nrow, ntile > (u64)tune().seg_max_tiles ? (u32)tune().zchunk : 0u);
+  const u64 per_outer = ck.on ? (u64)ck.nchunk * ck.ch.d * nrow : ntile * nrow;  // waves per outer index
+  if (per_outer > MAX_ITEMS) return 1;
+  const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nrow);
+  const u64 outer_per = MAX_ITEMS / per_outer;
+  for (int64_t o0 = 0; o0 < g.outer; o0 += (int64_t)outer_per) {
+    const u32 nouter = (u32)((g.outer - o0 < (int64_t)outer_per) ? g.outer - o0 : (int64_t)outer_per);
+    const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
+    const u32 grid = ((nblk + 7) / 8) * 8;
+    if (tune().nt_store)
+      hipLaunchKernelGGL((k_stencil_strided_gen<OP, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, g, o0, nouter, nblk, fnt, fns, ck, c.pad_lo, c.bc, c.fill, c.halo);
+    else
+      hipLaunchKernelGGL((k_stencil_strided_gen<OP, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, g, o0, nouter, nblk, fnt, fns, ck, c.pad_lo, c.bc, c.fill, c.halo);
+  }
+  return 0;
+}
+int strided_gen_dispatch(int op, const StencilCall& c) {
+  switch (op) {
+    case XG_OP_DIFF: return launch_strided_gen<XG_OP_DIFF>(c);
+    case XG_OP_INTERP: return launch_strided_gen<XG_OP_INTERP>(c);
+    case XG_OP_MIN: return launch_strided_gen<XG_OP_MIN>(c);
+    default: return launch_strided_gen<XG_OP_MAX>(c);
+  }
+}
+
 enum StencilKind { KIND_CONTIG = 0, KIND_LIN = 1, KIND_MARCH = 2 };
 
 template <int OP, int V, int MET>
@@ -665,6 +800,12 @@ static int stencil1d_impl(int op, const real* in, const real* halo, real* out, c
   }
   if (met != 0 && kind != KIND_MARCH && !g.idx32)
     return fail(XG_ERR_UNSUPPORTED, "metric-weighted stencils need outer/inner extents below 2^32");
+  if (g.inner > 1 && V == 1 && met == 0 && al && tune().strided_gen && g.inner >= 2 * NV) {
+    // rows of the strided axis are not 16-B aligned (odd inner extent): flat NV-group walk instead of 8-B lanes
+    rc = strided_gen_dispatch(op, c);
+    if (rc == 0) { XG_LAUNCH_CHECK(); return XG_OK; }
+    if (rc != 1) return rc;  // 1: not applicable here, take the scalar-lane path
+  }
   rc = stencil_dispatch(op, V, met, kind, c);
   if (rc) return rc;
   XG_LAUNCH_CHECK();
