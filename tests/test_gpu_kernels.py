@@ -361,6 +361,16 @@ def test_strided_axis_with_misaligned_rows(dev, shape, dtype):
                     halo = _field(hshape, 92).astype(dtype)
                     padded = np.concatenate([np.take(halo, range(0, lo), axis=axis), a, np.take(halo, range(lo, lo + hi), axis=axis)], axis=axis)
                     _eq(dev.tohost(dev.stencil1d_halo(op, a, halo, axis, lo, hi)), R.stencil1d(op, padded, axis, 0, 0, None))
+        # metrics ride along (input metric at the source rows, output metric at the output row), any broadcast pattern
+        oshape = list(shape)
+        for keep in (set(range(nd)), {axis, nd - 1}, {nd - 1}, {axis}):
+            m_in = _metric_for(shape, keep, 95).astype(dtype)
+            for (lo, hi), bc in (((1, 0), "periodic"), ((0, 1), "fill"), ((1, 1), "extend")):
+                oshape[axis] = shape[axis] + lo + hi - 1
+                m_out = _metric_for(tuple(oshape), keep, 96).astype(dtype)
+                for mi_, mo_ in ((m_in, m_out), (None, m_out), (m_in, None)):
+                    _eq(dev.tohost(dev.stencil1d("interp", a, axis, lo, hi, bc, 0.25, mi_, mo_)),
+                        R.stencil1d("interp", a, axis, lo, hi, bc, dtype(0.25), mi_, mo_))
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])

@@ -379,12 +379,14 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
 // has exactly one owner.  Work order and XCD banding are those of K2S with one row per wave-task (column
 // chunks for whole-plane rows), so the second source row of a task is an L2 hit; the row's coordinates and
 // its halo / fill decisions are wave-uniform.  Inputs are narrow consecutive loads (their alignment differs
-// from the output's).  No metrics here (they keep the scalar-lane path).
+// from the output's); metrics are addressed per element through their strides.
 // ------------------------------------------------------------------------------------------
-template <int OP, bool NTS>
+template <int OP, int MET, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_strided_gen(
     const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk, FastDiv ntile,
-    FastDiv nseg, Chunk ck, int pad_lo, int bc, real fill, const real* __restrict__ halo) {
+    FastDiv nseg, Chunk ck, int pad_lo, int bc, real fill, const real* __restrict__ halo,
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
   if (lb >= nblk) return;
@@ -406,40 +408,56 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_gen(
   }
   const int64_t inner = g.inner, n_in = g.n_in, n_out = g.n_out;
   const int nhalo = (int)(n_out - n_in + 1);  // pad_lo + pad_hi
-  // the two source rows of output row (o, j): base pointers and fill flags
-  auto sources = [&](int64_t o, int64_t j, const real* (&src)[2], bool (&fl)[2]) {
+  // one output row (o, j): its two source rows (base pointers, fill flags, input-metric row offsets) and
+  // the output-metric row offset -- all wave-uniform
+  struct Row { const real* src[2]; bool fl[2]; bool wm[2]; int64_t mib[2]; int64_t mob; };
+  auto resolve = [&](int64_t o, int64_t j) -> Row {
+    Row rw;
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
       int64_t q = j + side - pad_lo;
-      fl[side] = false;
+      rw.fl[side] = false;
+      rw.wm[side] = HAS_MI;
       const real* base = in + o * n_in * inner;
       if (q < 0 || q >= n_in) {
-        fl[side] = (bc == XG_BC_FILL);
-        if (bc == XG_BC_HALO) {  // pre-gathered halo rows, layout (outer, pad_lo + pad_hi, inner)
+        rw.fl[side] = (bc == XG_BC_FILL);
+        if (bc == XG_BC_HALO) {  // pre-gathered halo rows, layout (outer, pad_lo + pad_hi, inner); never weighted
           base = halo + o * nhalo * inner;
           q = (q < 0) ? 0 : pad_lo;
+          rw.wm[side] = false;
         } else {
           q = (q < 0) ? ((bc == XG_BC_PERIODIC) ? n_in - 1 : 0) : ((bc == XG_BC_PERIODIC) ? 0 : n_in - 1);
         }
       }
-      src[side] = base + q * inner;
+      rw.src[side] = base + q * inner;
+      rw.mib[side] = HAS_MI ? outer_off32(g, mi, (u32)o) + q * mi.axis : 0;
     }
+    rw.mob = HAS_MO ? outer_off32(g, mo, (u32)o) + j * mo.axis : 0;
+    return rw;
+  };
+  // one output cell at inner index xi of a resolved row (one inner dim -- the usual case -- needs no division)
+  const bool single_inner = g.n_inner == 1;
+  auto cell = [&](const Row& rw, int64_t xi) -> real {
+    real l = rw.src[0][xi], r = rw.src[1][xi];
+    if (HAS_MI) {
+      const int64_t io = single_inner ? xi * mi.inner[0] : inner_off32(g, mi, (u32)xi);
+      if (rw.wm[0]) l = l * m_in[rw.mib[0] + io];
+      if (rw.wm[1]) r = r * m_in[rw.mib[1] + io];
+    }
+    real v = op2<OP>(rw.fl[0] ? fill : l, rw.fl[1] ? fill : r);
+    if (HAS_MO) v = v / m_out[rw.mob + (single_inner ? xi * mo.inner[0] : inner_off32(g, mo, (u32)xi))];
+    return v;
   };
   const int64_t o = o0 + oo, j = jj;
   const int64_t rowstart = (o * n_out + j) * inner;             // flat index of the row's first cell
   const int64_t lead = (NV - rowstart % NV) % NV;               // those cells belong to the previous row's last group
   const int64_t x = lead + ((int64_t)tile * WAVE + (threadIdx.x & 63)) * NV;
   if (x >= inner) return;
-  const real* src[2];
-  bool fl[2];
-  sources(o, j, src, fl);
+  const Row rw = resolve(o, j);
   dv res;
   if (x + NV <= inner) {  // the group lies inside the row: consecutive narrow loads, no per-element logic
 #pragma unroll
-    for (int e = 0; e < NV; ++e) {
-      const real l = src[0][x + e], r = src[1][x + e];
-      res[e] = op2<OP>(fl[0] ? fill : l, fl[1] ? fill : r);
-    }
+    for (int e = 0; e < NV; ++e) res[e] = cell(rw, x + e);
     stg<dv, NTS>(out + rowstart + x, res);
     return;
   }
@@ -447,21 +465,14 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_gen(
   int64_t o2 = o, j2 = j + 1;
   if (j2 == n_out) { j2 = 0; ++o2; }
   const bool more = o2 < g.outer;
-  const real* src2[2] = {src[0], src[1]};
-  bool fl2[2] = {false, false};
-  if (more) sources(o2, j2, src2, fl2);
+  const Row rw2 = more ? resolve(o2, j2) : rw;
   real vals[NV];
 #pragma unroll
   for (int e = 0; e < NV; ++e) {
     const int64_t xe = x + e;
     real v = real(0);
-    if (xe < inner) {
-      const real l = src[0][xe], r = src[1][xe];
-      v = op2<OP>(fl[0] ? fill : l, fl[1] ? fill : r);
-    } else if (more) {
-      const real l = src2[0][xe - inner], r = src2[1][xe - inner];
-      v = op2<OP>(fl2[0] ? fill : l, fl2[1] ? fill : r);
-    }
+    if (xe < inner) v = cell(rw, xe);
+    else if (more) v = cell(rw2, xe - inner);
     vals[e] = v;
   }
   if (more) {
@@ -693,7 +704,7 @@ int launch_seg(const StencilCall& c) {
 }
 
 // flat NV-group walk for misaligned rows of a strided axis (no metrics); returns 1 when it does not apply
-template <int OP>
+template <int OP, int MET>
 int launch_strided_gen(const StencilCall& c) {
   const Geo& g = c.g;
   if (!g.idx32) return 1;
@@ -710,18 +721,27 @@ int launch_strided_gen(const StencilCall& c) {
     const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
     if (tune().nt_store)
-      hipLaunchKernelGGL((k_stencil_strided_gen<OP, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, g, o0, nouter, nblk, fnt, fns, ck, c.pad_lo, c.bc, c.fill, c.halo);
+      hipLaunchKernelGGL((k_stencil_strided_gen<OP, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, g, o0, nouter, nblk, fnt, fns, ck, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
     else
-      hipLaunchKernelGGL((k_stencil_strided_gen<OP, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, g, o0, nouter, nblk, fnt, fns, ck, c.pad_lo, c.bc, c.fill, c.halo);
+      hipLaunchKernelGGL((k_stencil_strided_gen<OP, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, g, o0, nouter, nblk, fnt, fns, ck, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
   }
   return 0;
 }
-int strided_gen_dispatch(int op, const StencilCall& c) {
+template <int OP>
+int strided_gen_met(int met, const StencilCall& c) {
+  switch (met) {
+    case 0: return launch_strided_gen<OP, 0>(c);
+    case 1: return launch_strided_gen<OP, 1>(c);
+    case 2: return launch_strided_gen<OP, 2>(c);
+    default: return launch_strided_gen<OP, 3>(c);
+  }
+}
+int strided_gen_dispatch(int op, int met, const StencilCall& c) {
   switch (op) {
-    case XG_OP_DIFF: return launch_strided_gen<XG_OP_DIFF>(c);
-    case XG_OP_INTERP: return launch_strided_gen<XG_OP_INTERP>(c);
-    case XG_OP_MIN: return launch_strided_gen<XG_OP_MIN>(c);
-    default: return launch_strided_gen<XG_OP_MAX>(c);
+    case XG_OP_DIFF: return strided_gen_met<XG_OP_DIFF>(met, c);
+    case XG_OP_INTERP: return strided_gen_met<XG_OP_INTERP>(met, c);
+    case XG_OP_MIN: return strided_gen_met<XG_OP_MIN>(met, c);
+    default: return strided_gen_met<XG_OP_MAX>(met, c);
   }
 }
 
@@ -800,9 +820,9 @@ static int stencil1d_impl(int op, const real* in, const real* halo, real* out, c
   }
   if (met != 0 && kind != KIND_MARCH && !g.idx32)
     return fail(XG_ERR_UNSUPPORTED, "metric-weighted stencils need outer/inner extents below 2^32");
-  if (g.inner > 1 && V == 1 && met == 0 && al && tune().strided_gen && g.inner >= 2 * NV) {
+  if (g.inner > 1 && V == 1 && al && tune().strided_gen && g.inner >= 2 * NV) {
     // rows of the strided axis are not 16-B aligned (odd inner extent): flat NV-group walk instead of 8-B lanes
-    rc = strided_gen_dispatch(op, c);
+    rc = strided_gen_dispatch(op, met, c);
     if (rc == 0) { XG_LAUNCH_CHECK(); return XG_OK; }
     if (rc != 1) return rc;  // 1: not applicable here, take the scalar-lane path
   }
