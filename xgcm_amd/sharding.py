@@ -138,7 +138,6 @@ def stencil_along_sharded_axis(grid, funcname: str, da, axis: str, dist=None, to
     from . import device as _dev
     from . import gridops
     from .grid import _select_grid_ufunc
-    from .grid_ufunc import _maybe_unpack_vector_component  # noqa: F401  (scalars only here)
     from .labeled import DataArray
 
     if funcname not in ("diff", "interp", "min", "max"):
