@@ -249,6 +249,23 @@ template <typename F> float timeit(F f, int reps = 8) {
   return t[t.size() / 2];
 }
 
+
+// read-only / write-only ceilings: one 16-B vector per thread, linear order
+template <bool NTL>
+__global__ __launch_bounds__(256) void k_readonly(const d2* __restrict__ in, double* __restrict__ sink, size_t nvec) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  d2 v = ld<NTL>(in + i);
+  if (v.x == 1.2345e300 && v.y == -1.0) sink[0] = v.x;  // never true: keeps the load alive
+}
+template <bool NTS>
+__global__ __launch_bounds__(256) void k_writeonly(d2* __restrict__ out, size_t nvec) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec) return;
+  d2 v; v.x = (double)i; v.y = 0.5;
+  st<NTS>(out + i, v);
+}
+
 int main() {
   const size_t n = 75ull * 2400 * 3600;  // doubles
   const size_t nvec = n / 2;
@@ -262,6 +279,16 @@ int main() {
 #define COPY(R, NTL, NTS, REMAP, BLOCK) { unsigned nblk = (unsigned)((nvec + (size_t)BLOCK * R - 1) / ((size_t)BLOCK * R)); \
     float ms = timeit([&] { hipLaunchKernelGGL((k_copy<R, NTL, NTS, REMAP, BLOCK>), dim3(nblk), dim3(BLOCK), 0, 0, (const d2*)in, (d2*)out, nvec, nblk); }); \
     report("copy R=" #R " ntl=" #NTL " nts=" #NTS " remap=" #REMAP " blk=" #BLOCK, ms); }
+  if (getenv("SB_EXTRA")) {  // block-size sweep of the one-vector-per-thread copy, read-only and write-only ceilings
+    COPY(1, false, true, false, 64) COPY(1, false, true, false, 128) COPY(1, false, true, false, 512) COPY(1, false, true, false, 1024)
+    COPY(1, false, true, true, 256) COPY(1, true, true, false, 256)
+    auto report1 = [&](const char* name, float ms) { printf("%-44s %8.4f ms  %8.1f GB/s  %.3f of 8TB/s (one-way bytes)\n", name, ms, 1.0 * n * 8 / ms / 1e6, 1.0 * n * 8 / ms / 1e6 / 8000); fflush(stdout); };
+    { float ms = timeit([&] { hipLaunchKernelGGL((k_readonly<false>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (const d2*)in, out, nvec); }); report1("read-only 16 B/thread", ms); }
+    { float ms = timeit([&] { hipLaunchKernelGGL((k_readonly<true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (const d2*)in, out, nvec); }); report1("read-only 16 B/thread, nt loads", ms); }
+    { float ms = timeit([&] { hipLaunchKernelGGL((k_writeonly<false>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (d2*)out, nvec); }); report1("write-only 16 B/thread", ms); }
+    { float ms = timeit([&] { hipLaunchKernelGGL((k_writeonly<true>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, 0, (d2*)out, nvec); }); report1("write-only 16 B/thread, nt stores", ms); }
+    return 0;
+  }
   COPY(1, false, false, false, 256) COPY(1, false, true, false, 256) COPY(2, false, true, false, 256) COPY(4, false, true, false, 256)
   COPY(8, false, true, false, 256) COPY(16, false, true, false, 256) COPY(4, true, true, false, 256) COPY(4, false, true, true, 256)
   COPY(8, false, true, true, 256) COPY(4, false, true, false, 512) COPY(4, false, true, false, 1024) COPY(8, false, true, false, 64)

@@ -88,7 +88,8 @@ int env_int(const char* name, int dflt) {
 // tunables (read once; override with env vars for on-device tuning sessions)
 struct Tune {
   int seg;       // rows marched per wave-task along a strided stencil axis
-  int nt_store;  // non-temporal stores (+2-4 %; non-temporal LOADS measured -1 % and are not used)
+  int nt_store;  // non-temporal stores (+2-4 %)
+  int nt_load;   // non-temporal loads of streamed-once inputs (reductions, scans, the contiguous stencil's row)
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
   int scan_narrow_below; // marching scans with fewer wave-tasks than this use one element per lane
   int pad_rows;          // row-wise generic pad (wave-uniform row logic); 0: one thread per cell
@@ -122,6 +123,7 @@ struct Tune {
     seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
     seg = env_int("XG_SEG", 1 << 30);  // long march: whole column by default
     nt_store = env_int("XG_NT_STORE", 1);
+    nt_load = env_int("XG_NT_LOAD", 1);  // +3-8 points on the marching scans / reductions, neutral elsewhere
   }
 };
 const Tune& tune() {

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
 template <bool HAS_W, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict__ in,
                                                          real* __restrict__ out, Geo g, int skipna,
-                                                         const real* __restrict__ wgt, MIdx mw) {
+                                                         const real* __restrict__ wgt, MIdx mw, int ntl) {
   const u64 row = wave_id();
   if ((int64_t)row >= g.outer) return;
   const int lane = threadIdx.x & 63;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
     const int64_t nvec = (n - lead) / NV;
     for (int64_t t = lane; t < nvec; t += WAVE) {
       const int64_t k = lead + t * NV;
-      dv v = *reinterpret_cast<const dv*>(prow + k);
+      dv v = ntl ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + k)) : *reinterpret_cast<const dv*>(prow + k);
       if (skipna >= 2) v = as_count(v, skipna);
       if (HAS_W) v = v * ldm<dv>(wgt, mb + k * mw.axis, mw.axis);
       if (skipna) v = nan0(v);
@@ -523,14 +523,16 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
     // the latency, so keep 16 loads in flight per lane instead of 4 (measured with the narrow lanes
     // above: cumsum along Y f32 48 -> 55 %, sum along Y 59 -> 67 % f32 / 68 -> 71 % f64)
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
-#define XG_GO(V_, M, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); \
-                               else hipLaunchKernelGGL((k_cumsum_strided<V_, M, false, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); } while (0)
+#define XG_GL(V_, M, NTL_, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); \
+                               else hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); } while (0)
+#define XG_GO(V_, M, NTS) do { if (tune().nt_load) XG_GL(V_, M, true, NTS); else XG_GL(V_, M, false, NTS); } while (0)
 #define XG_M(V_, M) do { if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
 #define XG_V(V_) switch (met) { case 0: XG_M(V_, 0); break; case 1: XG_M(V_, 1); break; case 2: XG_M(V_, 2); break; default: XG_M(V_, 3); }
     if (V > 1) { XG_V(NV) } else { XG_V(1) }
 #undef XG_V
 #undef XG_M
 #undef XG_GO
+#undef XG_GL
   }
   XG_LAUNCH_CHECK();
   return XG_OK;
@@ -552,11 +554,11 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     if ((rc = check_grid(nblocks))) return rc;
     const bool vec = aligned16(in) && g.n_in >= 4 * NV;  // rows of any length: lead / tail cells go through scalar loads
     if (vec) {
-      if (w) hipLaunchKernelGGL((k_reduce_contig<true, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
-      else hipLaunchKernelGGL((k_reduce_contig<false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+      if (w) hipLaunchKernelGGL((k_reduce_contig<true, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load);
+      else hipLaunchKernelGGL((k_reduce_contig<false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load);
     } else {
-      if (w) hipLaunchKernelGGL((k_reduce_contig<true, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
-      else hipLaunchKernelGGL((k_reduce_contig<false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw);
+      if (w) hipLaunchKernelGGL((k_reduce_contig<true, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load);
+      else hipLaunchKernelGGL((k_reduce_contig<false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load);
     }
   } else {
     int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, w != nullptr)) ? NV : 1;
@@ -567,8 +569,9 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     const u64 nblocks = (ntask + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
-#define XG_GO(V_, W_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, false, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); \
-                           else hipLaunchKernelGGL((k_reduce_strided<V_, W_, false, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); } while (0)
+#define XG_GL(V_, W_, NTL_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); \
+                           else hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); } while (0)
+#define XG_GO(V_, W_) do { if (tune().nt_load) XG_GL(V_, W_, true); else XG_GL(V_, W_, false); } while (0)
     if (V > 1) { if (w) XG_GO(NV, true); else XG_GO(NV, false); }
     else { if (w) XG_GO(1, true); else XG_GO(1, false); }
 #undef XG_GO

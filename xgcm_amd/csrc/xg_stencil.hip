@@ -119,7 +119,7 @@ template <int OP, int V, int MET, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t row0, u32 nrows, u32 nblk, FastDiv per,
     ZBand zb, int pad_lo, int bc, real fill, const real* __restrict__ halo, const real* __restrict__ m_in,
-    MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+    MIdx mi, const real* __restrict__ m_out, MIdx mo, int ntl) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   // XCD banding (see K2S): neighbouring workgroups share an L2, so the cache line holding a
   // workgroup's left neighbour is not fetched a second time by another XCD (-3 % HBM reads)
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     bool edge;
     if (pad_lo) { edge = (i0 == 0); nidx = edge ? ((bc == XG_BC_PERIODIC) ? Li - 1 : 0) : i0 - 1; }
     else { edge = (i0 + NV == Li); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : Li - 1) : i0 + NV; }
-    dv a = *reinterpret_cast<const dv*>(prow + i0);
+    dv a = ntl ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + i0)) : *reinterpret_cast<const dv*>(prow + i0);
     real n = prow[nidx];
     if (HAS_MI) {
       a = a * ldm<dv>(m_in, mib + (int64_t)i0 * mi.axis, mi.axis);
@@ -648,9 +648,9 @@ int launch_contig(const StencilCall& c) {
     const u32 nblk = (u32)(((u64)nrows * per + BLOCK - 1) / BLOCK);
     const u32 grid = ((nblk + 7) / 8) * 8;
     if (tune().nt_store)
-      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, tune().nt_load);
     else
-      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, tune().nt_load);
   }
   return 0;
 }
