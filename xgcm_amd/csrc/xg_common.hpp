@@ -100,6 +100,7 @@ struct Tune {
   int zb_rows;        // rows of the contiguous-axis kernel per band
   int scan_block;     // workgroup size of the contiguous-axis scan (128 / 256 / 512 / 1024)
   int strided_gen;    // flat NV-group kernel for misaligned rows of a strided stencil axis
+  int march_band;     // XCD-banded wave order in the column-marching scans / reductions
   int scan_vec;       // aligned-output-group scan for cumsum along the contiguous axis
   int contig_gen;     // pair-wise general path for odd / length-changing rows on the contiguous axis
   int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
@@ -115,6 +116,7 @@ struct Tune {
     zb_rows = env_int("XG_ZB_ROWS", 16);
     scan_block = env_int("XG_SCAN_BLOCK", 256);
     strided_gen = env_int("XG_STRIDED_GEN", 1);
+    march_band = env_int("XG_MARCH_BAND", 1);  // config 4 (8 records, cumsum along Z) 14.8 -> 13.1 ms
     zchunk = env_int("XG_ZCHUNK", 256);
     transform_fast = env_int("XG_TRANSFORM_FAST", 1);
     pad_rows = env_int("XG_PAD_ROWS", 1);
@@ -443,6 +445,14 @@ template <> __device__ __forceinline__ dv ldm<dv>(const real* m, int64_t off, in
   return o;
 }
 
+// the same with the workgroups of a launch cut into 8 contiguous bands, one per XCD (grid size = multiple of 8;
+// wave ids beyond the work are rejected by the caller's range check)
+__device__ __forceinline__ u64 banded_wave_id() {
+  const u32 pb = (gridDim.x + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  u32 w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  return (u64)lb * WPB + w;
+}
 __device__ __forceinline__ u64 wave_id() {
   // uniform per wave; readfirstlane keeps the task decomposition on the scalar unit
   u32 w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -37,12 +37,12 @@ __device__ __forceinline__ dv as_count(dv v, int mode) {
 template <int V, int MET, bool NTL, bool NTS, int U>
 __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
-    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, int band) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   // U independent loads in flight per lane (the scan chain only consumes them)
 
-  const u64 w = wave_id();
+  const u64 w = band ? banded_wave_id() : wave_id();
   const u32 tile = (u32)(w % ntile);
   const int64_t o = (int64_t)(w / ntile);
   if (o >= g.outer) return;
@@ -370,10 +370,10 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
 template <int V, bool HAS_W, bool NTL, int U>
 __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, int skipna,
-    const real* __restrict__ wgt, MIdx mw) {
+    const real* __restrict__ wgt, MIdx mw, int band) {
   typedef typename VecT<V>::type T;
   // U independent loads in flight per lane
-  const u64 w = wave_id();
+  const u64 w = band ? banded_wave_id() : wave_id();
   const u32 tile = (u32)(w % ntile);
   const int64_t o = (int64_t)(w / ntile);
   if (o >= g.outer) return;
@@ -516,15 +516,15 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
     if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = 1;
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
     const u64 ntask = (u64)ntile * (u64)g.outer;
-    const u64 nblocks = (ntask + WPB - 1) / WPB;
+    const u64 nblocks = tune().march_band ? (((ntask + WPB - 1) / WPB + 7) / 8) * 8 : (ntask + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
     const bool nts = tune().nt_store;
     // few columns, long march (cumsum along Y: ~2k waves for the whole chip): occupancy cannot hide
     // the latency, so keep 16 loads in flight per lane instead of 4 (measured with the narrow lanes
     // above: cumsum along Y f32 48 -> 55 %, sum along Y 59 -> 67 % f32 / 68 -> 71 % f64)
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
-#define XG_GL(V_, M, NTL_, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); \
-                               else hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo); } while (0)
+#define XG_GL(V_, M, NTL_, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band); \
+                               else hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band); } while (0)
 #define XG_GO(V_, M, NTS) do { if (tune().nt_load) XG_GL(V_, M, true, NTS); else XG_GL(V_, M, false, NTS); } while (0)
 #define XG_M(V_, M) do { if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
 #define XG_V(V_) switch (met) { case 0: XG_M(V_, 0); break; case 1: XG_M(V_, 1); break; case 2: XG_M(V_, 2); break; default: XG_M(V_, 3); }
@@ -566,11 +566,11 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = 1;
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
     const u64 ntask = (u64)ntile * (u64)g.outer;
-    const u64 nblocks = (ntask + WPB - 1) / WPB;
+    const u64 nblocks = tune().march_band ? (((ntask + WPB - 1) / WPB + 7) / 8) * 8 : (ntask + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
-#define XG_GL(V_, W_, NTL_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); \
-                           else hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw); } while (0)
+#define XG_GL(V_, W_, NTL_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, tune().march_band); \
+                           else hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, tune().march_band); } while (0)
 #define XG_GO(V_, W_) do { if (tune().nt_load) XG_GL(V_, W_, true); else XG_GL(V_, W_, false); } while (0)
     if (V > 1) { if (w) XG_GO(NV, true); else XG_GO(NV, false); }
     else { if (w) XG_GO(1, true); else XG_GO(1, false); }
