@@ -105,7 +105,7 @@ def main():
         ms, b = timeit(lambda: D.cumsum1d(T, 2, 0, 1, 1, 0, "fill"), args.reps)
         rec("cumsum_X_c2l_fill(block scan)", ms, b, 16)
         ms, b = timeit(lambda: D.cumsum1d(T, 2, 0, 0, 1, 0, "fill"), args.reps)
-        rec("cumsum_X_c2outer_fill(odd rows: scalar scan)", ms, b, 16)
+        rec("cumsum_X_c2outer_fill(odd rows)", ms, b, 16)
     if "reduce" in cases:
         dz = D.synthetic((nz, 1, 1), 33, 0, 1000.0, 1000.0)
         ms, b = timeit(lambda: D.reduce1d(T, 0, dz), args.reps)
