@@ -93,7 +93,14 @@ def cpu_baseline(levels=8, budget_s=20.0):
     out = {"value": round(cells / el / 1e9, 4), "unit": "Gcell/s", "cores": 1, "kind": "port",
            "sample": f"{passes} pass(es) of the 4 ops on a {levels}x{NY}x{NX} f64 slab (numpy pad copy + sliced op, "
                      f"single thread = the reference's eager path), {el:.1f} s; host has {os.cpu_count()} cores"}
-    nthreads = min(32, os.cpu_count() or 1)
+    # every host core (the dask threaded scheduler's default), bounded only by host memory: a task holds its
+    # level, the padded copy, the sliced views' result and the output (~6 levels of 69 MB)
+    nthreads = os.cpu_count() or 1
+    try:
+        avail = next(int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable"))
+        nthreads = max(1, min(nthreads, int(0.5 * avail // (6 * NY * NX * 8))))
+    except Exception:
+        pass
     big = R.synthetic_field((nthreads, NY, NX), 2)
     chunks = [big[i:i + 1] for i in range(nthreads)]
     t0 = time.perf_counter()
@@ -104,10 +111,12 @@ def cpu_baseline(levels=8, budget_s=20.0):
             tcells += sum(pool.map(_cpu_pass, chunks))
             rounds += 1
             el = time.perf_counter() - t0
-            if el > budget_s * 0.4 or rounds >= 8:
+            if el > budget_s * 0.4 or rounds >= 4:
                 break
     out["threaded"] = {"value": round(tcells / el / 1e9, 4), "unit": "Gcell/s", "cores": nthreads,
-                       "sample": f"{rounds} round(s), one 1x{NY}x{NX} level per task on {nthreads} threads, {el:.1f} s"}
+                       "host_cores": os.cpu_count(), "numpy": np.__version__,
+                       "sample": f"{rounds} round(s), one 1x{NY}x{NX} level per task on {nthreads} threads "
+                                 f"(all {os.cpu_count()} host cores unless host memory bounds it), {el:.1f} s"}
     return out
 
 
@@ -120,22 +129,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("XG_BENCH_FORCE_DIST"):  # the env var exercises the RCCL path on one GPU
-        import torch.distributed as dist
+    from xgcm_amd import sharding as S
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    # `--gpus N` means N ranks whoever started us: under torchrun we ARE one of them (WORLD_SIZE must agree),
+    # started by hand we re-execute under torch.distributed.run; fewer visible GPUs than ranks is an error
+    S.ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
+    ranks = S.init_ranks(args.gpus, backend="nccl")
+    world, rank, local_rank, dist = ranks.world, ranks.rank, ranks.local_rank, ranks.dist
 
     import __graft_entry__ as entry
 
@@ -194,10 +196,10 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
 
-    from xgcm_amd.sharding import whole_job_throughput
-
     local_cells = K * len(OPS) * cells_per_op
-    cells_per_s, elapsed = whole_job_throughput(local_cells, elapsed, dist, "cuda")
+    per_rank_ms_per_step = [round(v / K * 1e3, 4) for v in ranks.gather_floats(elapsed)]
+    cells_per_s, elapsed = S.whole_job_throughput(local_cells, elapsed, dist, "cuda")
+    n_ranks = dist.get_world_size() if dist is not None else 1  # the rank count RCCL itself reports
 
     # per-launch durations from the HIP events recorded on the launch stream inside the timed region
     per_op_ms = [float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(K)])) for i in range(len(OPS))]
@@ -223,7 +225,7 @@ def main():
             "metric": "stencil-cells/s, Grid.interp+Grid.diff (X periodic, Y extend) on 3600x2400x75 f64",
             "value": round(total_cells / elapsed / 1e9, 3),
             "unit": "Gcell/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": K,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / K * 1e3, 4),
@@ -241,6 +243,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
                          "per_op_ms": {f"{fn}_{ax}": round(ms, 4) for (fn, ax), ms in zip(OPS, per_op_ms)}},
+            "ranks": {"world_size": n_ranks, "backend": "nccl (RCCL)" if dist is not None else "single process",
+                      "per_rank_ms_per_step": per_rank_ms_per_step},
             "device_ms_per_step": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4),
                                    "max": round(step_ms[-1], 4)},
         }
@@ -248,8 +252,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline()
             line["parity_spot_check"] = spot_check(spot)
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,79 @@
+"""The N-rank path on the GPU box (which has ONE GPU): the launcher and the sharded config-4 / config-5 drivers
+through the real HIP library -- one rank over RCCL (`XG_BENCH_FORCE_DIST=1`), two gloo ranks computing on the
+same GPU, and the refusal to start more RCCL ranks than there are GPUs."""
+
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONFIGS = os.path.join(ROOT, "tools", "bench_configs.py")
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "XG_DIST_BACKEND", "XG_SHARE_GPU"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable] + args, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    return p, [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
+SHAPE = (9, 66, 256)
+ARGS = ["--configs", "4,5", "--records", "7", "--batch-records", "2", "--shape", ",".join(map(str, SHAPE)), "--reps", "3"]
+
+
+def test_two_ranks_on_the_real_library_equal_one_rank_and_the_oracle():
+    from oracle import refimpl as R
+
+    p1, one = _run([CONFIGS, "--gpus", "1"] + ARGS)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    p2, two = _run([CONFIGS, "--gpus", "2"] + ARGS, {"XG_DIST_BACKEND": "gloo", "XG_SHARE_GPU": "1"})
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    ops1 = [ln for ln in one if "op" in ln]
+    ops2 = [ln for ln in two if "op" in ln]
+    assert len(ops1) == len(ops2) == 4
+    for a, b in zip(ops1, ops2):
+        assert a["op"] == b["op"] and a["n_gpus"] == 1 and b["n_gpus"] == 2
+        assert a["checksum_u64"] == b["checksum_u64"] and a["cells"] == b["cells"]
+    assert ops2[0]["records_per_rank"] == [4, 3] and ops2[2]["levels_per_rank"] == [5, 4]
+    assert all(ln["ok"] for ln in one + two if "check" in ln)
+    # against the oracle: cumsum of the same synthetic records, vorticity of the same synthetic fields
+    nz, ny, nx = SHAPE
+    T = R.synthetic_field((7, nz, ny, nx), 4)
+    for to, line in zip(("left", "outer"), ops1[:2]):
+        want = R.grid_cumsum(T, 1, "center", to, "fill")
+        assert line["checksum_u64"] == f"{int(np.ascontiguousarray(want).view(np.uint64).sum(dtype=np.uint64)):016x}"
+    U = R.synthetic(nz * ny * nx, 51).reshape(nz, ny, nx)
+    V = R.synthetic(nz * ny * nx, 52).reshape(nz, ny, nx)
+    area = R.synthetic(ny * nx, 53, 0, 1000.0, 1000.0).reshape(ny, nx)
+    want = (R.stencil1d("diff", V, 2, 1, 0, "fill") - R.stencil1d("diff", U, 1, 1, 0, "fill")) / area
+    chk = f"{int(np.ascontiguousarray(want).view(np.uint64).sum(dtype=np.uint64)):016x}"
+    assert ops1[2]["checksum_u64"] == chk and ops1[3]["checksum_u64"] == chk
+
+
+def test_bench_through_rccl_with_one_rank():
+    p, lines = _run([BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--levels", "4", "--no-cpu-baseline"],
+                    {"XG_BENCH_FORCE_DIST": "1"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "torch.distributed.run" in p.stderr
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 1
+    assert lines[0]["ranks"]["world_size"] == 1 and "nccl" in lines[0]["ranks"]["backend"]
+    assert len(lines[0]["ranks"]["per_rank_ms_per_step"]) == 1
+
+
+def test_more_ranks_than_gpus_is_an_error():
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    for script, extra in ((BENCH, ["--steps", "1", "--warmup", "0"]), (CONFIGS, ARGS)):
+        p, lines = _run([script, "--gpus", str(n)] + extra)
+        assert p.returncode != 0 and not lines
+        assert "GPU(s) are visible" in p.stderr

@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
-"""All BASELINE.json configs (2-5) at full size on ONE MI355X through the public Grid API.
+"""All BASELINE.json configs (2-5) at full size through the public Grid API, on 1..N MI355X.
 
-    python tools/bench_configs.py [--reps 7] [--records 8] [--configs 2,3,4,5]
+    python tools/bench_configs.py [--gpus N] [--reps 7] [--records 360] [--configs 2,3,4,5]
 
 Not the judged bench line (that is bench.py = config 2); this is the per-config evidence table:
 ms, Gcell/s, algorithmic GB/s (bytes/cell of SURVEY.md section 8(d)) and fraction of 8 TB/s.
-Config 4 runs `--records` resident records of the 360 (the per-GPU batch of the sharded run;
-8 records = 5.2 G cells, which also exercises the > 2^32-element index paths); config 5 runs the
-whole 4320x4320x90 field on one GPU.
+
+Configs 4 and 5 are the SHARDED runs of BASELINE.json; `--gpus N` starts N
+ranks (re-executing itself under torch.distributed.run when no launcher did, exactly like bench.py):
+  4   cumsum(T,'Z') center->left and center->outer over `--records` records of 3600x2400x75 f64 (360 =
+      1.866 TB), the record axis split over the ranks by `sharding.shard_bounds` (360 -> 45 per GPU on 8),
+      each rank walking its block in HBM-resident batches sized from its free HBM;
+  5   fused and unfused vorticity (diff(V,'X') - diff(U,'Y')) / rAz, `fill`, on 4320x4320x90 split along Z
+      (90 -> 12,12,11,11,11,11,11,11 on 8 GPUs), rAz replicated.
+No data-path collective: RCCL carries barriers, the max-over-ranks time and a checksum of checksums.
+Single-GPU extras: 4x (> 2^32-cell batch checks), 5x (divergence / gradient / flux), f1, f2, f4, llc, pcie, stream.
 """
 import argparse
 import json
@@ -16,11 +23,14 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+import time  # noqa: E402
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from xgcm_amd import DataArray, Dataset, Grid  # noqa: E402
 from xgcm_amd import device as D  # noqa: E402
+from xgcm_amd import sharding as S  # noqa: E402
 
 
 def timeit(fn, reps):
@@ -67,13 +77,203 @@ def mitgcm_grid(nz, ny, nx, nt=None):
                 autoparse_metadata=False)
 
 
+# ------------------------------------------------------------------------------------------------------
+# Sharded configs (4, 5): N ranks, one per GPU, the record / level axis split by sharding.shard_bounds
+# ------------------------------------------------------------------------------------------------------
+class SpanClock:
+    """device time of the spans between start() and stop(): HIP events on the launch stream on a GPU,
+    perf_counter on the CPU test double"""
+
+    def __init__(self):
+        self.gpu = torch.cuda.is_available()
+        self.pairs, self.host_s = [], 0.0
+
+    def start(self):
+        if self.gpu:
+            self._e0 = torch.cuda.Event(enable_timing=True)
+            self._e0.record()
+        else:
+            self._t0 = time.perf_counter()
+
+    def stop(self):
+        if self.gpu:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.pairs.append((self._e0, e1))
+        else:
+            self.host_s += time.perf_counter() - self._t0
+
+    def ms(self):
+        if self.gpu:
+            torch.cuda.synchronize()
+            return float(sum(a.elapsed_time(b) for a, b in self.pairs))
+        return self.host_s * 1e3
+
+
+def bits_checksum(x) -> int:
+    """sum modulo 2^64 of the 64-bit patterns of a float64 array: order-independent, so the sum over the
+    shards of any split equals the single-process value (checksum of checksums)"""
+    if isinstance(x, torch.Tensor):
+        return int(x.contiguous().view(torch.int64).sum().item()) & 0xFFFFFFFFFFFFFFFF
+    return int(np.ascontiguousarray(x, dtype=np.float64).view(np.uint64).sum(dtype=np.uint64))
+
+
+def _shard_line(ranks, cfg, op, wall_s, dev_ms, local_cells, bpc, chk, extra):
+    """reduce the per-rank figures and let rank 0 print one JSON line"""
+    per_rank_ms = ranks.gather_floats(dev_ms)
+    per_rank_cells = ranks.gather_floats(float(local_cells))
+    wall = ranks.max(wall_s)
+    total = sum(per_rank_cells)
+    chk = ranks.sum_u64(chk)
+    line = {"config": cfg, "op": op, "n_gpus": ranks.world, "backend": ranks.backend or "single process",
+            "cells": int(total), "wall_ms_between_barriers": round(wall * 1e3, 3),
+            "gcell_s": round(total / wall / 1e9, 2) if wall > 0 else None, "bytes_per_cell": round(bpc, 3),
+            "GBps_all_gpus": round(total * bpc / wall / 1e9, 1) if wall > 0 else None,
+            "frac_8TBps_per_gpu": round(total * bpc / wall / 1e9 / 8000 / ranks.world, 4) if wall > 0 else None,
+            "per_rank_device_ms": [round(v, 3) for v in per_rank_ms],
+            "per_rank_cells": [int(v) for v in per_rank_cells], "checksum_u64": f"{chk:016x}"}
+    line.update(extra)
+    if ranks.rank == 0:
+        print(json.dumps(line), flush=True)
+    return line
+
+
+def run_config4(ranks, n_records=360, shape=(75, 2400, 3600), per_batch=None, ops=("left", "outer")):
+    """cumsum(T,'Z') over `n_records` records sharded over the record axis; every rank walks its block in
+    HBM-resident batches (inputs generated in HBM before the timed span, outputs checksummed after it)."""
+    nz, ny, nx = shape
+    cells = nz * ny * nx
+    grid = mitgcm_grid(nz, ny, nx)
+    lo, hi = S.shard_bounds(n_records, ranks.world, ranks.rank)
+    # resident per record: the input, the output ((nz + 1) levels for center->outer) and the int64 view the
+    # checksum reads in place => 2 records + one level; the caching allocator keeps the previous batch's blocks
+    bytes_per_record = 8 * (2 * cells + ny * nx)
+    per = per_batch or S.records_per_batch(hi - lo, bytes_per_record, headroom=0.8)
+    per = max(1, int(ranks.min(per)))
+    batches = S.record_batches(n_records, ranks.world, ranks.rank, per)
+    rounds = int(ranks.max(len(batches)))
+    dims = ("time", "Z", "YC", "XC")
+    lines = []
+    if batches:  # untimed warm-up on one record: code objects, allocator pool, clocks
+        w = DataArray(D.synthetic((1, nz, ny, nx), 4, offset=lo * cells), dims)
+        for _ in range(3):
+            grid.cumsum(w, "Z")
+            grid.cumsum(w, "Z", to="outer")
+        del w
+    for to in ops:
+        kw = {} if to == "left" else {"to": to}
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()  # the two ops' outputs differ in size: do not keep the other op's blocks cached
+        clock, wall, chk, local_cells = SpanClock(), 0.0, 0, 0
+        for b in range(rounds):
+            T4 = out = None
+            if b < len(batches):
+                s, e = batches[b]
+                T4 = DataArray(D.synthetic((e - s, nz, ny, nx), 4, offset=s * cells), dims)
+            ranks.barrier()
+            t0 = time.perf_counter()
+            if T4 is not None:
+                clock.start()
+                out = grid.cumsum(T4, "Z", **kw)
+                clock.stop()
+            ranks.barrier()
+            wall += time.perf_counter() - t0
+            if T4 is not None:
+                chk = (chk + bits_checksum(out.data)) & 0xFFFFFFFFFFFFFFFF
+                local_cells += (e - s) * cells
+            del T4, out
+        lines.append(_shard_line(
+            ranks, 4, f"cumsum(T,'Z') center->{to} fill, {n_records} records of {nx}x{ny}x{nz} f64 over the record axis",
+            wall, clock.ms(), local_cells, 16, chk,
+            {"records": n_records, "records_per_rank": [S.shard_bounds(n_records, ranks.world, r)[1] - S.shard_bounds(n_records, ranks.world, r)[0] for r in range(ranks.world)],
+             "records_per_resident_batch": per, "batch_rounds": rounds}))
+    return lines
+
+
+def config5_grid(ny, nx):
+    coords = {"XC": ("XC", np.arange(nx) + 0.5), "XG": ("XG", np.arange(nx) * 1.0),
+              "YC": ("YC", np.arange(ny) + 0.5), "YG": ("YG", np.arange(ny) * 1.0)}
+    ds = Dataset({"rAz": DataArray(D.synthetic((ny, nx), 53, 0, 1000.0, 1000.0), ("YG", "XG"))}, coords)
+    return Grid(ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}},
+                padding="fill", metrics={("X", "Y"): ["rAz"]}, autoparse_metadata=False)
+
+
+def run_config5(ranks, shape=(90, 4320, 4320), reps=7):
+    """(diff(V,'X') - diff(U,'Y')) / rAz with `fill` on a field split along Z (whole levels per rank, rAz
+    replicated): the fused kernel and the reference's operator chain, each `reps` passes between two barriers."""
+    nz, ny, nx = shape
+    lo, hi = S.shard_bounds(nz, ranks.world, ranks.rank)
+    grid = config5_grid(ny, nx)
+    nl = hi - lo
+    plane = ny * nx
+    U = DataArray(D.synthetic((nl, ny, nx), 51, offset=lo * plane), ("Z", "YC", "XG")) if nl else None
+    V = DataArray(D.synthetic((nl, ny, nx), 52, offset=lo * plane), ("Z", "YG", "XC")) if nl else None
+    area = grid._ds["rAz"].reset_coords(drop=True)
+
+    def fused():
+        return grid.vorticity(U, V)
+
+    def chain():
+        return (grid.diff(V, "X") - grid.diff(U, "Y")) / area
+
+    lines = []
+    levels = [S.shard_bounds(nz, ranks.world, r)[1] - S.shard_bounds(nz, ranks.world, r)[0] for r in range(ranks.world)]
+    for name, fn, n in (("vorticity fused (diff(v,X)-diff(u,Y))/rAz, fill", fused, reps),
+                        ("vorticity unfused operator chain (4 kernels), fused-equivalent bytes", chain, max(3, reps // 2))):
+        out = None
+        if nl:
+            t0 = time.perf_counter()
+            out = fn()
+            while torch.cuda.is_available() and time.perf_counter() - t0 < 0.15:  # warm clocks
+                torch.cuda.synchronize()
+                out = fn()
+        clock = SpanClock()
+        ranks.barrier()
+        t0 = time.perf_counter()
+        if nl:
+            for _ in range(n):
+                clock.start()
+                out = fn()
+                clock.stop()
+        ranks.barrier()
+        wall = (time.perf_counter() - t0) / n
+        chk = bits_checksum(out.data) if nl else 0
+        lines.append(_shard_line(ranks, 5, f"{name}; {nx}x{ny}x{nz} f64 split along Z", wall, clock.ms() / n, nl * plane,
+                                 24 + 8 / nz, chk, {"levels_per_rank": levels, "passes": n}))
+        del out
+    if nl:
+        same = bool(np.array_equal(D.tohost(fused().data[:1]), D.tohost(chain().data[:1])))
+        allsame = ranks.min(1.0 if same else 0.0) == 1.0
+        if ranks.rank == 0:
+            print(json.dumps({"config": 5, "check": "fused == unfused chain bit for bit (first level of every rank)", "ok": allsame}), flush=True)
+    return lines
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=7)
-    ap.add_argument("--records", type=int, default=8)
+    ap.add_argument("--records", type=int, default=360, help="config 4: records in the whole job (360 = BASELINE)")
+    ap.add_argument("--batch-records", type=int, default=0, help="config 4: records per resident batch (0: from free HBM)")
+    ap.add_argument("--xrecords", type=int, default=8, help="config 4x: records in the single resident batch")
     ap.add_argument("--configs", default="2,3,4,5")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU); only configs 4 and 5 shard")
+    ap.add_argument("--shape", default="", help="Z,Y,X override for configs 4 and 5 (tests; default = BASELINE sizes)")
     a = ap.parse_args()
     cfgs = set(a.configs.split(","))
+    S.ensure_ranks(a.gpus, os.path.abspath(__file__), sys.argv[1:])
+    ranks = S.init_ranks(a.gpus)
+    if ranks.world > 1 and cfgs - {"4", "5"}:
+        raise SystemExit("only configs 4 and 5 are sharded runs; run the other configs with --gpus 1")
+    shp = tuple(int(v) for v in a.shape.split(",")) if a.shape else None
+    if ranks.world > 1 or (cfgs and cfgs <= {"4", "5"}):
+        try:
+            if "4" in cfgs:
+                run_config4(ranks, a.records, shape=shp or (75, 2400, 3600), per_batch=a.batch_records or None)
+            if "5" in cfgs:
+                run_config5(ranks, shape=shp or (90, 4320, 4320), reps=a.reps)
+        finally:
+            ranks.close()
+        return
     nz, ny, nx = 75, 2400, 3600
     cells = nz * ny * nx
     if cfgs & {"2", "3", "f1"}:
@@ -143,19 +343,21 @@ def main():
         print(json.dumps({"config": "stream", "check": "last record == host - roll(host, 1) (periodic diff)", "ok": ok}), flush=True)
         del host, out, grid_s
     if "4" in cfgs:
-        nt = a.records
+        run_config4(ranks, a.records, per_batch=a.batch_records or None)
+    if "4x" in cfgs:
+        nt = a.xrecords
         grid = mitgcm_grid(nz, ny, nx)
         T4 = DataArray(D.synthetic((nt, nz, ny, nx), 4), ("time", "Z", "YC", "XC"))
         c4 = nt * cells
-        rec(4, f"cumsum(T,'Z') center->left fill, {nt} records ({c4 / 1e9:.2f} Gcell)", timeit(lambda: grid.cumsum(T4, "Z"), a.reps), c4, 16)
-        rec(4, f"cumsum(T,'Z') center->outer fill, {nt} records", timeit(lambda: grid.cumsum(T4, "Z", to="outer"), a.reps), c4, 16)
-        rec(4, f"diff(T,'X') periodic, {nt} records (>2^32 cells)", timeit(lambda: grid.diff(T4, "X"), a.reps), c4, 16)
+        rec("4x", f"cumsum(T,'Z') center->left fill, {nt} records ({c4 / 1e9:.2f} Gcell)", timeit(lambda: grid.cumsum(T4, "Z"), a.reps), c4, 16)
+        rec("4x", f"cumsum(T,'Z') center->outer fill, {nt} records", timeit(lambda: grid.cumsum(T4, "Z", to="outer"), a.reps), c4, 16)
+        rec("4x", f"diff(T,'X') periodic, {nt} records (>2^32 cells)", timeit(lambda: grid.diff(T4, "X"), a.reps), c4, 16)
         # spot parity on the last record (exercises 64-bit offsets): recompute it alone
         last = DataArray(T4.data[nt - 1].contiguous(), ("Z", "YC", "XC"))
         ok = bool(torch.equal(grid.cumsum(T4, "Z").data[nt - 1], grid.cumsum(last, "Z").data)
                   and torch.equal(grid.diff(T4, "X").data[nt - 1], grid.diff(last, "X").data)
                   and torch.equal(grid.diff(T4, "Y").data[nt - 1], grid.diff(last, "Y").data))
-        print(json.dumps({"config": 4, "check": "last record of the batch == same record processed alone", "ok": ok}), flush=True)
+        print(json.dumps({"config": "4x", "check": "last record of the batch == same record processed alone", "ok": ok}), flush=True)
         del T4, last, grid
         torch.cuda.empty_cache()
     if "f2" in cfgs:
@@ -293,6 +495,8 @@ def main():
             del Ul, Vl, gl
             torch.cuda.empty_cache()
     if "5" in cfgs:
+        run_config5(ranks, reps=a.reps)
+    if "5x" in cfgs:
         nz5, n5 = 90, 4320
         grid = mitgcm_grid(nz5, n5, n5)
         grid_fill = Grid(grid._ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}},
@@ -324,6 +528,7 @@ def main():
         fx, fy = grid_div.flux(U, V, T5)
         okf = bool(torch.equal(fx.data, (U * grid_div.interp(T5, "X")).data) and torch.equal(fy.data, (V * grid_div.interp(T5, "Y")).data))
         print(json.dumps({"config": 5, "check": "fused gradient / flux == operator chains bit for bit at full size", "ok": okg and okf}), flush=True)
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -10,7 +10,7 @@ scalars: the max-over-ranks time and order-independent checksums.
 
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 
 def shard_bounds(n_units: int, world: int, rank: int) -> Tuple[int, int]:
@@ -49,6 +49,211 @@ def whole_job_throughput(local_units: float, local_seconds: float, dist=None, de
     total = reduce_sum(local_units, dist, device)
     tmax = reduce_max(local_seconds, dist, device)
     return total / tmax, tmax
+
+
+# ----------------------------------------------------------------------------------------------
+# Rank launcher: `script --gpus N` must mean N ranks whoever started it.  Under a launcher
+# (torchrun / `python -m torch.distributed.run`, which exports WORLD_SIZE / RANK / LOCAL_RANK) the
+# process is ONE of the N ranks; started by hand with `--gpus N` it re-executes itself under
+# torch.distributed.run with N ranks on 127.0.0.1.  Fewer visible GPUs than ranks is an error, a
+# WORLD_SIZE that disagrees with `--gpus` is an error: no run ever reports a rank count it did not use.
+# ----------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _backend_from_env(default_gpu: str = "nccl") -> str:
+    import os
+
+    import torch
+
+    return os.environ.get("XG_DIST_BACKEND") or (default_gpu if torch.cuda.is_available() else "gloo")
+
+
+def _visible_gpus() -> int:
+    import torch
+
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def ensure_ranks(n_gpus: int, script: str, argv: Sequence[str]) -> None:
+    """Make sure `n_gpus` ranks exist.  Returns in a process that IS one of the ranks (or the only one);
+    otherwise replaces this process by `python -m torch.distributed.run --nproc-per-node n_gpus script argv`
+    and exits with its status.  Call before anything touches the GPU."""
+    import os
+    import subprocess
+    import sys
+
+    n_gpus = int(n_gpus)
+    if n_gpus < 1:
+        raise SystemExit(f"--gpus {n_gpus}: need at least one rank")
+    if "WORLD_SIZE" in os.environ:  # already under a launcher: it decides the rank count, we only verify
+        world = int(os.environ["WORLD_SIZE"])
+        if world != n_gpus:
+            raise SystemExit(f"--gpus {n_gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to "
+                             "report a rank count that was not used")
+        return
+    backend = _backend_from_env()
+    shared = os.environ.get("XG_SHARE_GPU") == "1"  # tests: several gloo ranks computing on one GPU
+    if backend == "nccl" or not shared:
+        vis = _visible_gpus()
+        if backend == "nccl" and vis < n_gpus:
+            raise SystemExit(f"--gpus {n_gpus} but only {vis} GPU(s) are visible; one process per GPU, "
+                             "no oversubscription")
+    if n_gpus == 1 and not os.environ.get("XG_BENCH_FORCE_DIST"):
+        return
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script] + list(argv)
+    print("[launcher] " + " ".join(cmd), file=sys.stderr, flush=True)
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Ranks:
+    """The process group as this rank sees it: RCCL ("nccl") on the GPU box, gloo in CPU tests.  Only
+    barriers and scalar reductions go through it -- the record-axis split has no data-path collective."""
+
+    def __init__(self, rank: int, world: int, local_rank: int, backend: Optional[str], dist):
+        self.rank, self.world, self.local_rank, self.backend, self.dist = rank, world, local_rank, backend, dist
+
+    @property
+    def scalar_device(self) -> str:
+        return "cuda" if self.backend == "nccl" else "cpu"
+
+    def barrier(self) -> None:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if self.dist is not None:
+            if self.backend == "nccl":
+                self.dist.barrier(device_ids=[self.local_rank])
+            else:
+                self.dist.barrier()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+
+    def gather_floats(self, value: float):
+        """[value of rank 0, value of rank 1, ...] on every rank."""
+        if self.dist is None:
+            return [float(value)]
+        import torch
+
+        t = torch.tensor([float(value)], dtype=torch.float64, device=self.scalar_device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def sum_int(self, value: int) -> int:
+        """order-independent checksum of checksums (int64 wrap-around sum)"""
+        if self.dist is None:
+            return int(value)
+        import torch
+
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self.scalar_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
+
+    def sum_u64(self, value: int) -> int:
+        """sum modulo 2^64 over the ranks (checksum of checksums); sent as two 32-bit halves so that no
+        backend's integer overflow behaviour matters"""
+        value = int(value) & 0xFFFFFFFFFFFFFFFF
+        if self.dist is None:
+            return value
+        import torch
+
+        t = torch.tensor([value & 0xFFFFFFFF, value >> 32], dtype=torch.int64, device=self.scalar_device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        lo, hi = int(t[0].item()), int(t[1].item())
+        return (lo + (hi << 32)) & 0xFFFFFFFFFFFFFFFF
+
+    def max(self, value: float) -> float:
+        return reduce_max(value, self.dist, self.scalar_device)
+
+    def min(self, value: float) -> float:
+        return -reduce_max(-float(value), self.dist, self.scalar_device)
+
+    def sum(self, value: float) -> float:
+        return reduce_sum(value, self.dist, self.scalar_device)
+
+    def close(self) -> None:
+        if self.dist is not None and self.dist.is_initialized():
+            self.dist.destroy_process_group()
+
+
+def init_ranks(n_gpus: int, backend: Optional[str] = None) -> Ranks:
+    """Join the process group the launcher prepared (call after `ensure_ranks`).  One process per GPU: rank r
+    of a node computes on cuda:LOCAL_RANK.  The world size RCCL / gloo reports must equal `n_gpus`."""
+    import os
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != int(n_gpus):
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}")
+    backend = backend or _backend_from_env()
+    shared = os.environ.get("XG_SHARE_GPU") == "1" and backend != "nccl"
+    if torch.cuda.is_available():
+        vis = torch.cuda.device_count()
+        if shared:
+            torch.cuda.set_device(local_rank % vis)
+        else:
+            if local_rank >= vis:
+                raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {vis} GPU(s) visible")
+            torch.cuda.set_device(local_rank)
+    elif backend == "nccl":
+        raise SystemExit("backend nccl (RCCL) needs a GPU")
+    if "WORLD_SIZE" not in os.environ:
+        return Ranks(0, 1, 0, None, None)
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    if dist.get_world_size() != int(n_gpus):
+        raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {n_gpus} asked")
+    return Ranks(rank, world, local_rank, backend, dist)
+
+
+# ----------------------------------------------------------------------------------------------
+# Resident batches: a rank's records rarely fit HBM together with their outputs (config 4: 45 records of
+# 5.18 GB in, the same out, per GPU), so it walks its block [lo, hi) of the record axis in batches that do.
+# ----------------------------------------------------------------------------------------------
+def records_per_batch(n_local: int, bytes_per_record: int, free_bytes: Optional[int] = None,
+                      headroom: float = 0.85, cap: Optional[int] = None) -> int:
+    """How many records (inputs + outputs + temporaries = `bytes_per_record` each) stay resident at once:
+    `headroom` x free HBM / bytes_per_record, at least 1, at most `cap` and the rank's own count."""
+    if n_local <= 0:
+        return 0
+    if free_bytes is None:
+        import torch
+
+        free_bytes = torch.cuda.mem_get_info()[0] if torch.cuda.is_available() else 8 << 30
+    n = int(headroom * float(free_bytes) // max(1, int(bytes_per_record)))
+    n = max(1, min(n, n_local))
+    return min(n, int(cap)) if cap else n
+
+
+def record_batches(n_records: int, world: int, rank: int, per_batch: int):
+    """[(start, stop), ...] covering this rank's block of the record axis in resident batches."""
+    lo, hi = shard_bounds(n_records, world, rank)
+    if per_batch < 1:
+        return []
+    return [(s, min(s + per_batch, hi)) for s in range(lo, hi, per_batch)]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -204,9 +409,10 @@ def cumsum_along_sharded_axis(grid, da, axis: str, dist=None, to=None, padding=N
         planes = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(planes, t.contiguous())
         if rank > 0:
-            carry = DataArray(planes[0] if not host else planes[0].numpy(), tuple(d for d in da.dims if d != dim))
+            plane = (lambda p: _dev.tohost(p)) if host else (lambda p: p)  # reduce1d returns HBM tensors on a GPU box
+            carry = DataArray(plane(planes[0]), tuple(d for d in da.dims if d != dim))
             for r in range(1, rank):                              # rank order: ((t0 + t1) + t2) ...
-                carry = carry + DataArray(planes[r] if not host else planes[r].numpy(), carry.dims)
+                carry = carry + DataArray(plane(planes[r]), carry.dims)
             res = DataArray(local if not host else _dev.tohost(local), out_dims) + carry
             return DataArray(res.transpose(*out_dims).data, out_dims, name=da.name)
     return DataArray(_dev.tohost(local) if host else local, out_dims, name=da.name)
