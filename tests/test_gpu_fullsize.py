@@ -14,7 +14,11 @@ from oracle import refimpl as R
 
 pytestmark = pytest.mark.gpu
 
-NZ, NY, NX = 75, 2400, 3600
+import os
+
+# BASELINE.json's sizes; XG_FULLSIZE_SHAPE="z,y,x,n5" shrinks them only to dry-run the test LOGIC on the CPU double
+NZ, NY, NX = (int(v) for v in os.environ.get("XG_FULLSIZE_SHAPE", "75,2400,3600,4320").split(",")[:3])
+N5 = int(os.environ.get("XG_FULLSIZE_SHAPE", "75,2400,3600,4320").split(",")[3])
 
 
 @pytest.fixture(scope="module")
@@ -141,3 +145,126 @@ def test_more_than_2_to_32_cells_in_one_call(env):
         del full, one
     tot = grid.integrate(T4, "Z")
     assert tot.dims == ("time", "YC", "XC") and _same(torch, tot.data[nt - 1], grid.integrate(last, "Z").data)
+
+
+# ----------------------------------------------------------------------------------------------
+# Config 3 / 4 / 5 at full size with RANDOM metrics against oracle slabs: the
+# z-banded 2-D-metric paths re-order rows, so a wrong (z, y) -> metric offset must not be able to hide
+# behind a constant metric.  Reference contract: xgcm/test/test_metrics_ops.py:59-64,134-216 (bitwise).
+# ----------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def env3(env):
+    D, DataArray = env["D"], env["DataArray"]
+    coords = {"XC": ("XC", np.arange(NX) + 0.5), "XG": ("XG", np.arange(NX) * 1.0),
+              "YC": ("YC", np.arange(NY) + 0.5), "YG": ("YG", np.arange(NY) * 1.0),
+              "Z": ("Z", np.arange(NZ) + 0.5), "Zl": ("Zl", np.arange(NZ) * 1.0)}
+    met = lambda shape, seed: D.synthetic(shape, seed, 0, 1000.0, 1000.0)  # noqa: E731  1000 * (1 + u) > 0
+    dv = {"dxC": DataArray(met((NY, NX), 31), ("YC", "XG")), "dyC": DataArray(met((NY, NX), 32), ("YG", "XC")),
+          "dxT": DataArray(met((NY, NX), 35), ("YC", "XC")), "dyT": DataArray(met((NY, NX), 36), ("YC", "XC")),
+          "drF": DataArray(met((NZ,), 33), ("Z",)), "drC": DataArray(met((NZ,), 34), ("Zl",))}
+    grid = env["Grid"](env["Dataset"](dv, coords),
+                       coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"},
+                               "Z": {"center": "Z", "left": "Zl"}},
+                       padding={"X": "periodic", "Y": "extend", "Z": "fill"},
+                       metrics={("X",): ["dxC", "dxT"], ("Y",): ["dyC", "dyT"], ("Z",): ["drF", "drC"]},
+                       autoparse_metadata=False)
+    T = DataArray(D.synthetic((NZ, NY, NX), 2), ("Z", "YC", "XC"))
+    host = {k: R.synthetic_metric((NY, NX), s) for k, s in (("dxC", 31), ("dyC", 32), ("dxT", 35), ("dyT", 36))}
+    host["drF"], host["drC"] = R.synthetic_metric((NZ,), 33), R.synthetic_metric((NZ,), 34)
+    return {"grid": grid, "T": T, "m": host}
+
+
+LEVELS = (0, NZ // 2, NZ - 1)
+
+
+def _h(t):
+    return t.cpu().numpy() if hasattr(t, "cpu") else np.asarray(t)
+
+
+def test_config3_derivative_with_random_2d_metrics_full_size(env3):
+    """derivative(T,'X') / dxC(YC,XG) and derivative(T,'Y') / dyC(YG,XC): whole levels 0 / 37 / 74 bit for bit"""
+    grid, T, m = env3["grid"], env3["T"], env3["m"]
+    dX, dY = grid.derivative(T, "X"), grid.derivative(T, "Y")
+    assert dX.dims == ("Z", "YC", "XG") and dY.dims == ("Z", "YG", "XC")
+    for z in LEVELS:
+        slab = _h(T.data[z])
+        assert np.array_equal(_h(dX.data[z]), R.stencil1d("diff", slab, 1, 1, 0, "periodic", m_out=m["dxC"])), z
+        assert np.array_equal(_h(dY.data[z]), R.stencil1d("diff", slab, 0, 1, 0, "extend", m_out=m["dyC"])), z
+
+
+def test_config3_metric_weighted_interp_full_size(env3):
+    """interp(T, ax, metric_weighted=ax): (T * m_in) padded, interpolated, / m_out -- two broadcast 2-D metrics"""
+    grid, T, m = env3["grid"], env3["T"], env3["m"]
+    iX = grid.interp(T, "X", metric_weighted="X")
+    iY = grid.interp(T, "Y", metric_weighted="Y")
+    for z in LEVELS:
+        slab = _h(T.data[z])
+        assert np.array_equal(_h(iX.data[z]), R.stencil1d("interp", slab, 1, 1, 0, "periodic", m_in=m["dxT"], m_out=m["dxC"])), z
+        assert np.array_equal(_h(iY.data[z]), R.stencil1d("interp", slab, 0, 1, 0, "extend", m_in=m["dyT"], m_out=m["dyC"])), z
+
+
+def test_config3_vertical_derivative_and_integrals_full_size(env3, env):
+    """derivative(T,'Z') / drC(Zl) (1-D), integrate(T,'Z') * drF(Z) (1-D) and the integral of a field on the
+    w-levels weighted by a 3-D drC(Zl,YC,XC): column blocks at the first, a middle and the last rows"""
+    grid, T, m = env3["grid"], env3["T"], env3["m"]
+    D, DataArray = env["D"], env["DataArray"]
+    dZ, iZ = grid.derivative(T, "Z"), grid.integrate(T, "Z")
+    assert dZ.dims == ("Zl", "YC", "XC") and iZ.dims == ("YC", "XC")
+    blocks = (slice(0, 3), slice(NY // 2 - 1, NY // 2 + 2), slice(NY - 3, NY))
+    for b in blocks:
+        cols = _h(T.data[:, b, :])
+        assert np.array_equal(_h(dZ.data[:, b, :]), R.stencil1d("diff", cols, 0, 1, 0, "fill", 0.0, m_out=m["drC"][:, None, None]))
+        assert np.array_equal(_h(iZ.data[b, :]), R.integrate(cols, 0, m["drF"][:, None, None]))
+    # 3-D cell thickness (partial cells): a grid whose Z metric at the w-levels is a full (Zl, YC, XC) array
+    drC3 = DataArray(D.synthetic((NZ, NY, NX), 37, 0, 1000.0, 1000.0), ("Zl", "YC", "XC"))
+    g3 = env["Grid"](env["Dataset"]({"drC3": drC3}, {"Z": ("Z", np.arange(NZ) + 0.5), "Zl": ("Zl", np.arange(NZ) * 1.0)}),
+                     coords={"Z": {"center": "Z", "left": "Zl"}}, padding="fill", metrics={("Z",): ["drC3"]},
+                     autoparse_metadata=False)
+    W = DataArray(T.data, ("Zl", "YC", "XC"))
+    i3 = g3.integrate(W, "Z")
+    c3 = g3.cumint(W, "Z")  # to the centres; fill halo
+    for b in blocks:
+        cols, w = _h(T.data[:, b, :]), _h(drC3.data[:, b, :])
+        assert np.array_equal(_h(i3.data[b, :]), R.integrate(cols, 0, w))
+        assert np.array_equal(_h(c3.data[:, b, :]), R.grid_cumsum(cols, 0, "left", "center", "fill", m_in=w))
+
+
+def test_config4_cumsum_center_to_outer_full_size(env3):
+    """cumsum(T,'Z') center->left and center->outer (fill) against oracle column blocks (config 4's two ops)"""
+    T = env3["T"]
+    g = env3["grid"]
+    from xgcm_amd import Dataset, Grid
+
+    grid = Grid(Dataset(coords={"Z": ("Z", np.arange(NZ) + 0.5), "Zl": ("Zl", np.arange(NZ) * 1.0), "Zp1": ("Zp1", np.arange(NZ + 1) * 1.0)}),
+                coords={"Z": {"center": "Z", "left": "Zl", "outer": "Zp1"}}, padding="fill", autoparse_metadata=False)
+    cl, co = grid.cumsum(T, "Z"), grid.cumsum(T, "Z", to="outer")
+    assert cl.dims == ("Zl", "YC", "XC") and co.dims == ("Zp1", "YC", "XC") and co.shape[0] == NZ + 1
+    for b in (slice(0, 2), slice(NY // 2, NY // 2 + 4), slice(NY - 2, NY)):
+        cols = _h(T.data[:, b, :])
+        assert np.array_equal(_h(cl.data[:, b, :]), R.grid_cumsum(cols, 0, "center", "left", "fill"))
+        assert np.array_equal(_h(co.data[:, b, :]), R.grid_cumsum(cols, 0, "center", "outer", "fill"))
+    assert g is not None
+
+
+def test_config5_vorticity_fill_with_random_area_full_size(env):
+    """(diff(V,'X') - diff(U,'Y')) / rAz on 4320 x 4320 x 90 with `fill` and a RANDOM rAz(YG,XG): whole levels
+    0 / 45 / 89 (row 0 and column 0 carry the fill halo) against the oracle chain, fused and unfused"""
+    torch, D, DataArray = env["torch"], env["D"], env["DataArray"]
+    nz, n = (90, N5) if N5 == 4320 else (6, N5)
+    coords = {"XC": ("XC", np.arange(n) + 0.5), "XG": ("XG", np.arange(n) * 1.0),
+              "YC": ("YC", np.arange(n) + 0.5), "YG": ("YG", np.arange(n) * 1.0)}
+    ds = env["Dataset"]({"rAz": DataArray(D.synthetic((n, n), 53, 0, 1000.0, 1000.0), ("YG", "XG"))}, coords)
+    grid = env["Grid"](ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}},
+                       padding="fill", metrics={("X", "Y"): ["rAz"]}, autoparse_metadata=False)
+    U = DataArray(D.synthetic((nz, n, n), 51), ("Z", "YC", "XG"))
+    V = DataArray(D.synthetic((nz, n, n), 52), ("Z", "YG", "XC"))
+    zeta = grid.vorticity(U, V)
+    assert zeta.dims == ("Z", "YG", "XG")
+    area = R.synthetic_metric((n, n), 53)
+    for z in (0, nz // 2, nz - 1):
+        want = R.vorticity(_h(U.data[z]), _h(V.data[z]), area, "fill", "fill")
+        got = _h(zeta.data[z])
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[:, 0], want[:, 0])  # the fill halo row / column
+        assert np.array_equal(got, want), z
+    chain = (grid.diff(V, "X") - grid.diff(U, "Y")) / ds["rAz"].reset_coords(drop=True)
+    assert np.array_equal(_h(zeta.data), _h(chain.data)) if not hasattr(zeta.data, "is_cuda") else bool(torch.equal(zeta.data, chain.data))

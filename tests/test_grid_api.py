@@ -247,6 +247,47 @@ def test_two_axes_fused_equals_sequential(backend):
         Grid(ds, coords=gcoords, autoparse_metadata=False).interp(ds["T"], ["X", "Y"])
 
 
+def test_two_axes_integer_input_takes_the_sequential_path(backend):
+    """signed-integer data through `diff(da, [X, Y])` must give the dtype and values of the two
+    single-axis calls (the reference pads the INTEGER array: numpy.pad truncates a fractional fill value)."""
+    ny, nx = 6, 8
+    coords = {"XC": ("XC", np.arange(nx) + 0.5), "XG": ("XG", np.arange(nx) * 1.0),
+              "YC": ("YC", np.arange(ny) + 0.5), "YG": ("YG", np.arange(ny) * 1.0)}
+    a = np.arange(ny * nx, dtype=np.int64).reshape(ny, nx) * 3 % 17
+    ds = Dataset({"n": (("YC", "XC"), a)}, coords)
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}},
+                padding="fill", autoparse_metadata=False)
+    fv = {"X": 1.0, "Y": 2.7}
+    for fn in ("diff", "min", "max"):
+        f = getattr(grid, fn)
+        both = f(ds["n"], ["X", "Y"], fill_value=fv)
+        seq = f(f(ds["n"], "X", fill_value=fv), "Y", fill_value=fv)
+        assert both.values.dtype == seq.values.dtype == np.int64, fn
+        assert np.array_equal(both.values, seq.values), fn
+        px = np.pad(a, ((0, 0), (1, 0)), constant_values=1)
+        want_x = {"diff": px[:, 1:] - px[:, :-1], "min": np.minimum(px[:, 1:], px[:, :-1]), "max": np.maximum(px[:, 1:], px[:, :-1])}[fn]
+        py = np.pad(want_x, ((1, 0), (0, 0)), constant_values=2.7)  # numpy casts 2.7 -> 2 for an integer array
+        want = {"diff": py[1:] - py[:-1], "min": np.minimum(py[1:], py[:-1]), "max": np.maximum(py[1:], py[:-1])}[fn]
+        assert np.array_equal(both.values, want), fn
+
+
+def test_integrate_with_a_weight_that_adds_dims(backend):
+    """the broadcast fall-back of `integrate` (metric with a dim the data lacks) returns the same
+    container type as the fused branch and skips NaN by default like xarray's float `sum`."""
+    nz, ny = 4, 5
+    coords = {"Z": ("Z", np.arange(nz) + 0.5), "Zl": ("Zl", np.arange(nz) * 1.0), "Y": ("Y", np.arange(ny) * 1.0)}
+    dz = R.synthetic_metric((nz, ny), 5)
+    ds = Dataset({"dz": (("Z", "Y"), dz)}, coords)
+    grid = Grid(ds, coords={"Z": {"center": "Z", "left": "Zl"}}, padding="fill", metrics={("Z",): ["dz"]},
+                autoparse_metadata=False)
+    col = R.synthetic_field((nz,), 6)
+    col[1] = np.nan
+    out = grid.integrate(DataArray(col, ("Z",)), "Z")
+    assert isinstance(out, DataArray) and out.dims == ("Y",)
+    want = np.nansum(col[:, None] * dz, axis=0)
+    assert np.allclose(out.values, want, rtol=1e-14, atol=0)
+
+
 def test_vector_component_dict_input(backend):
     ds, coords, _ = cgrid()
     grid = Grid(ds, coords=coords, padding="periodic", autoparse_metadata=False)

@@ -401,6 +401,12 @@ def binary(op: str, a, b) -> torch.Tensor:
     return out
 
 
+def _pair_halos(halo_x, halo_y, shape, dt):
+    hx = None if halo_x is None else asdevice(halo_x, dt).reshape(shape[:-2] + [shape[-2]])
+    hy = None if halo_y is None else asdevice(halo_y, dt).reshape(shape[:-2] + [shape[-1]])
+    return hx, hy
+
+
 def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0, halo_x=None,
               halo_y=None) -> torch.Tensor:
     """Fused ((v[j,i]-v[j,i-1]) - (u[j,i]-u[j-1,i])) / area on (..., Y, X) arrays (xg_vorticity_f64).
@@ -417,20 +423,13 @@ def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: flo
     if out.numel() == 0:
         return out
     if bc_x == "halo" or bc_y == "halo":
-        hx = None if halo_x is None else asdevice(halo_x, dt).reshape(shape[:-2] + [shape[-2]])
-        hy = None if halo_y is None else asdevice(halo_y, dt).reshape(shape[:-2] + [shape[-1]])
+        hx, hy = _pair_halos(halo_x, halo_y, shape, dt)
         _hip.check(
             getattr(lib, "xg_vorticity_halo_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(hx), _ptr(hy), _ptr(area),
                                           _hip.i64(_bstrides(area, shape, "area")), out.data_ptr(), _hip.i64(shape),
                                           len(shape), _hip.BC[bc_x], float(fill_x), _hip.BC[bc_y], float(fill_y), _stream())
         )
         return out
-    _hip.check(
-        getattr(lib, "xg_vorticity_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
-                             out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
-                             _hip.BC[bc_y], float(fill_y), _stream())
-    )
-    return out
     _hip.check(
         getattr(lib, "xg_vorticity_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(area), _hip.i64(_bstrides(area, shape, "area")),
                              out.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
@@ -455,8 +454,7 @@ def divergence(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: fl
     if out.numel() == 0:
         return out
     if bc_x == "halo" or bc_y == "halo":
-        hx = None if halo_x is None else asdevice(halo_x, dt).reshape(shape[:-2] + [shape[-2]])
-        hy = None if halo_y is None else asdevice(halo_y, dt).reshape(shape[:-2] + [shape[-1]])
+        hx, hy = _pair_halos(halo_x, halo_y, shape, dt)
         _hip.check(
             getattr(lib, "xg_divergence_halo_" + sfx)(u.data_ptr(), v.data_ptr(), _ptr(hx), _ptr(hy), _ptr(area),
                                           _hip.i64(_bstrides(area, shape, "area")), out.data_ptr(), _hip.i64(shape),
@@ -469,12 +467,6 @@ def divergence(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: fl
                              _hip.BC[bc_y], float(fill_y), _stream())
     )
     return out
-
-
-def _pair_halos(halo_x, halo_y, shape, dt):
-    hx = None if halo_x is None else asdevice(halo_x, dt).reshape(shape[:-2] + [shape[-2]])
-    hy = None if halo_y is None else asdevice(halo_y, dt).reshape(shape[:-2] + [shape[-1]])
-    return hx, hy
 
 
 def gradient(a, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0, mx=None, my=None, halo_x=None,
@@ -529,6 +521,8 @@ def stencil2d_supported(x, padx, pady) -> bool:
     """Can xg_stencil2d_f64 serve this call (else run the two axes one after the other)?"""
     shape = tuple(x.shape)  # numpy (host) or torch (HBM) data
     lane = 4 if _dtype_of(x) == torch.float32 else 2  # elements of the 16-byte lane vector
+    if isinstance(x, torch.Tensor) and x.is_cuda and (x.data_ptr() % 16 or not x.is_contiguous()):
+        return False  # a contiguous view at an odd element offset: the two 1-D launches handle it (8-byte lanes)
     return (len(shape) >= 2 and shape[-1] % lane == 0 and sum(padx) == 1 and sum(pady) == 1
             and shape[-1] > 0 and shape[-2] > 0)
 

@@ -471,6 +471,8 @@ class Grid:
             return None
         if array.ndim < 2 or getattr(array, "chunks", None) is not None:
             return None
+        if gridops.signed_int_dtype(array.data) is not None:
+            return None  # integers: the per-axis path truncates the fill value and casts back like numpy.pad
         (sig_a, ax_a), (sig_b, ax_b) = step_a, step_b
         if ax_a == ax_b or gridops.complex_topology(self, ax_a) or gridops.complex_topology(self, ax_b):
             return None  # halos from other faces / the folded row: one axis at a time (xg_stencil1d_halo)
@@ -649,9 +651,11 @@ class Grid:
         weight = self._resident(self.get_metric(da, axis), da.data)
         dims = self._get_dims_from_axis(da, axis)
         extra = [d for d in weight.dims if d not in da.dims]
+        skip = True if skipna is None else bool(skipna)
         if extra:  # weight adds dims: fall back to the explicit product (broadcast result)
-            return (da * weight).sum(dims, skipna=skipna, keep_attrs=keep_attrs)
-        out = self._weighted_reduce(da, weight, dims, True if skipna is None else bool(skipna), keep_attrs)
+            out = (da * weight).sum(dims, skipna=skip, keep_attrs=keep_attrs)
+        else:
+            out = self._weighted_reduce(da, weight, dims, skip, keep_attrs)
         return to_xarray(out) if was_xr else out
 
     def _weighted_reduce(self, da, weight, dims, mode, keep_attrs=False):
