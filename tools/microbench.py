@@ -49,7 +49,7 @@ def main():
     cases = set(args.cases.split(","))
     nz, ny, nx = shape
     cells = nz * ny * nx
-    tag = {k: os.environ.get(k) for k in ("XG_SEG", "XG_NT_STORE", "XG_NT_LOAD") if os.environ.get(k)}
+    tag = {k: v for k, v in sorted(os.environ.items()) if k.startswith("XG_") and k != "XG_HIP_LIB"}  # tunables of this run
 
     dt = torch.float32 if args.dtype == "f32" else torch.float64
     esz = 4 if args.dtype == "f32" else 8
@@ -97,6 +97,19 @@ def main():
         rec("derivative_Z(dz 1D)", ms, b, 16)
         ms, b = timeit(lambda: D.stencil1d("interp", T, 2, 1, 0, "periodic", m_in=dx, m_out=dx), args.reps)
         rec("interp_X_metric_weighted", ms, b, 16 + 16 / nz)
+        ms, b = timeit(lambda: D.stencil1d("interp", T, 1, 1, 0, "extend", m_in=dx, m_out=dx), args.reps)
+        rec("interp_Y_metric_weighted", ms, b, 16 + 16 / nz)
+    if "scanY" in cases:  # the long march with few columns, alone (tunable sweeps)
+        ms, b = timeit(lambda: D.cumsum1d(T, 1, 0, 1, 1, 0, "fill"), args.reps)
+        rec("cumsum_Y_c2l_fill", ms, b, 16)
+        ms, b = timeit(lambda: D.reduce1d(T, 1, None), args.reps)
+        rec("sum_Y", ms, b, 8)
+    if "scanZ" in cases:
+        ms, b = timeit(lambda: D.cumsum1d(T, 0, 0, 1, 1, 0, "fill"), args.reps)
+        rec("cumsum_Z_c2l_fill", ms, b, 16)
+        dz = D.synthetic((nz, 1, 1), 33, 0, 1000.0, 1000.0)
+        ms, b = timeit(lambda: D.reduce1d(T, 0, dz), args.reps)
+        rec("integrate_Z(drF 1D)", ms, b, 8 + 8 / nz)
     if "cumsum" in cases:
         ms, b = timeit(lambda: D.cumsum1d(T, 0, 0, 1, 1, 0, "fill"), args.reps)
         rec("cumsum_Z_c2l_fill", ms, b, 16)

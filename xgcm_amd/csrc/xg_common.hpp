@@ -104,11 +104,21 @@ struct Tune {
   int scan_vec;       // aligned-output-group scan for cumsum along the contiguous axis
   int contig_gen;     // pair-wise general path for odd / length-changing rows on the contiguous axis
   int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
+  int contig_rw;      // rows per wave-task of the row-wave contiguous-axis metric kernel K1r (0: flat K1)
+  int met_seg;        // rows per wave-task of the strided-axis kernel K2S when metrics ride along (1 / 2 / 4)
+  int scan_pipe;      // software-pipelined loads in the marching scans / reductions (0: batches of U)
+  int scan_u;         // loads in flight per lane of a long march (8 / 16 / 24 / 32)
+  int scan_pace;      // experiment: workgroup barrier per window in the pipelined marching scan
   int march_lds_kb;   // optional dynamic LDS request for the column-marching kernels, only to cap residency
                       // (experiment: +8 % on a bare march in tools/streambench.hip, but -20 % on the real
                       // kernels whose index/metric math then has too few waves to hide behind) => default 0
   Tune() {
     march_lds_kb = env_int("XG_MARCH_LDS_KB", 0);
+    contig_rw = env_int("XG_CONTIG_RW", 2);
+    met_seg = env_int("XG_MET_SEG", 2);
+    scan_pipe = env_int("XG_SCAN_PIPE", 1);
+    scan_u = env_int("XG_SCAN_U", 16);
+    scan_pace = env_int("XG_SCAN_PACE", 0) ? 1 : 0;
     contig_gen = env_int("XG_CONTIG_GEN", 1);
     scan_vec = env_int("XG_SCAN_VEC", 1);
     deep_waves = env_int("XG_DEEP_WAVES", 8192);  // neutral on its own, pays together with scan_narrow_below

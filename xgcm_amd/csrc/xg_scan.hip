@@ -34,7 +34,10 @@ __device__ __forceinline__ dv as_count(dv v, int mode) {
   return o;
 }
 
-template <int V, int MET, bool NTL, bool NTS, int U>
+// PIPE: the U loads of a lane form a rolling window -- every consumed row is replaced by the load of the row U
+// steps ahead, so U - 1 loads stay in flight through the whole march instead of draining at every batch of U
+// (few, long columns: cumsum along Y of (Z,Y,X) has ~4 waves per SIMD, occupancy cannot hide the drain).
+template <int V, int MET, bool NTL, bool NTS, int U, bool PIPE = false>
 __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
     const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, int band) {
@@ -42,7 +45,8 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   // U independent loads in flight per lane (the scan chain only consumes them)
 
-  const u64 w = band ? banded_wave_id() : wave_id();
+  const u64 w = (band & 1) ? banded_wave_id() : wave_id();
+  const bool pace = (band & 2) != 0;  // experiment: the 4 waves of a workgroup (adjacent x-tiles) re-align every window
   const u32 tile = (u32)(w % ntile);
   const int64_t o = (int64_t)(w / ntile);
   if (o >= g.outer) return;
@@ -81,6 +85,30 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
     if (idx >= first_kept && idx <= last_kept) put(idx + shift, acc);
   };
   int64_t t = 0;
+  if (PIPE) {
+    auto row = [&](int64_t k) -> int64_t { return a.reverse ? n - 1 - k : k; };  // k-th row in scan order
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < n) v[u] = ldg<T, NTL>(pin + row(u) * inner);
+    for (; t + 2 * U <= n; t += U) {  // steady state: consume row t + u, refill its slot with row t + U + u
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const T x = v[u];
+        v[u] = ldg<T, NTL>(pin + row(t + U + u) * inner);
+        step(row(t + u), x);
+      }
+      if (pace) __builtin_amdgcn_s_barrier();
+    }
+    for (; t < n; t += U) {  // the last one or two windows: refills and consumes guarded (wave-uniform tests)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const T x = v[u];
+        if (t + U + u < n) v[u] = ldg<T, NTL>(pin + row(t + U + u) * inner);
+        if (t + u < n) step(row(t + u), x);
+      }
+    }
+  } else {
   for (; t + U <= n; t += U) {
     T v[U];
 #pragma unroll
@@ -94,6 +122,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
   for (; t < n; ++t) {
     int64_t idx = a.reverse ? n - 1 - t : t;
     step(idx, ldg<T, NTL>(pin + idx * inner));
+  }
   }
   // halo cells of the padded cumulative result (xgcm/grid.py:1385-1391; numpy.pad semantics)
   if (a.pad_lo) {
@@ -367,7 +396,7 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
 // K4: weighted sum along a STRIDED axis: one lane per output column pair, sequential in k
 // (bit-exact with numpy's reduction over a non-last axis).
 // ------------------------------------------------------------------------------------------
-template <int V, bool HAS_W, bool NTL, int U>
+template <int V, bool HAS_W, bool NTL, int U, bool PIPE = false>
 __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, int skipna,
     const real* __restrict__ wgt, MIdx mw, int band) {
@@ -397,6 +426,28 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
     started = true;
   };
   int64_t k = 0;
+  if (PIPE) {  // rolling window of U loads (see k_cumsum_strided)
+    T v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (u < n) v[u] = ldg<T, NTL>(pin + (int64_t)u * inner);
+    for (; k + 2 * U <= n; k += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const T x = v[u];
+        v[u] = ldg<T, NTL>(pin + (k + U + u) * inner);
+        step(k + u, x);
+      }
+    }
+    for (; k < n; k += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const T x = v[u];
+        if (k + U + u < n) v[u] = ldg<T, NTL>(pin + (k + U + u) * inner);
+        if (k + u < n) step(k + u, x);
+      }
+    }
+  } else {
   for (; k + U <= n; k += U) {
     T v[U];
 #pragma unroll
@@ -405,6 +456,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
     for (int u = 0; u < U; ++u) step(k + u, v[u]);
   }
   for (; k < n; ++k) step(k, ldg<T, NTL>(pin + k * inner));
+  }
   *reinterpret_cast<T*>(out + o * inner + x) = acc;
 }
 
@@ -523,16 +575,22 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
     // the latency, so keep 16 loads in flight per lane instead of 4 (measured with the narrow lanes
     // above: cumsum along Y f32 48 -> 55 %, sum along Y 59 -> 67 % f32 / 68 -> 71 % f64)
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
-#define XG_GL(V_, M, NTL_, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band); \
-                               else hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band); } while (0)
+    // rolling-window variants exist for the default non-temporal loads + stores only; `pipe`: window length
+    const int su = tune().scan_u;
+    const int pipe = (tune().scan_pipe && nts && tune().nt_load) ? (deep ? (su >= 32 ? 32 : su >= 24 ? 24 : su >= 16 ? 16 : 8) : (tune().scan_pipe >= 2 ? 8 : 0)) : 0;
+#define XG_PL(V_, M, U_) hipLaunchKernelGGL((k_cumsum_strided<V_, M, true, true, U_, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band | (tune().scan_pace << 1))
+#define XG_GL(V_, M, NTL_, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band | (tune().scan_pace << 1)); \
+                               else hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band | (tune().scan_pace << 1)); } while (0)
 #define XG_GO(V_, M, NTS) do { if (tune().nt_load) XG_GL(V_, M, true, NTS); else XG_GL(V_, M, false, NTS); } while (0)
-#define XG_M(V_, M) do { if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
+#define XG_M(V_, M) do { if (pipe == 32) XG_PL(V_, M, 32); else if (pipe == 24) XG_PL(V_, M, 24); else if (pipe == 16) XG_PL(V_, M, 16); else if (pipe == 8) XG_PL(V_, M, 8); \
+                         else if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
 #define XG_V(V_) switch (met) { case 0: XG_M(V_, 0); break; case 1: XG_M(V_, 1); break; case 2: XG_M(V_, 2); break; default: XG_M(V_, 3); }
     if (V > 1) { XG_V(NV) } else { XG_V(1) }
 #undef XG_V
 #undef XG_M
 #undef XG_GO
 #undef XG_GL
+#undef XG_PL
   }
   XG_LAUNCH_CHECK();
   return XG_OK;
@@ -571,10 +629,15 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
 #define XG_GL(V_, W_, NTL_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, tune().march_band); \
                            else hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, tune().march_band); } while (0)
-#define XG_GO(V_, W_) do { if (tune().nt_load) XG_GL(V_, W_, true); else XG_GL(V_, W_, false); } while (0)
+    const int su = tune().scan_u;
+    const int pipe = (tune().scan_pipe && tune().nt_load) ? (deep ? (su >= 32 ? 32 : su >= 24 ? 24 : su >= 16 ? 16 : 8) : (tune().scan_pipe >= 2 ? 8 : 0)) : 0;
+#define XG_PL(V_, W_, U_) hipLaunchKernelGGL((k_reduce_strided<V_, W_, true, U_, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, tune().march_band)
+#define XG_GO(V_, W_) do { if (pipe == 32) XG_PL(V_, W_, 32); else if (pipe == 24) XG_PL(V_, W_, 24); else if (pipe == 16) XG_PL(V_, W_, 16); else if (pipe == 8) XG_PL(V_, W_, 8); \
+                           else if (tune().nt_load) XG_GL(V_, W_, true); else XG_GL(V_, W_, false); } while (0)
     if (V > 1) { if (w) XG_GO(NV, true); else XG_GO(NV, false); }
     else { if (w) XG_GO(1, true); else XG_GO(1, false); }
 #undef XG_GO
+#undef XG_PL
   }
   XG_LAUNCH_CHECK();
   return XG_OK;

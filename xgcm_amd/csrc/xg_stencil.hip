@@ -198,6 +198,101 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
 }
 
 // ------------------------------------------------------------------------------------------
+// K1r: contiguous axis WITH metrics (derivative / metric_weighted along X), wave-task = (R consecutive
+// rows, x-tile of 64 lane vectors).  Why a second form of K1: a flat one-vector-per-thread kernel keeps
+// (waves) x (one 1-KB load) in flight, so whatever a wave computes between its load and its store adds to
+// the memory latency it has to hide.  K1 with a divisor spends ~100 VALU instructions per lane vector,
+// 2/3 of them per-lane row decoding (rows of 1800 vectors do not align with waves, so the row index, the
+// z-band map and every row offset are vector work).  Here the row group and tile of a wave are uniform:
+// the decode and all row bases live on the scalar unit, a lane computes one 32-bit offset, and the loads
+// of all R rows (field, neighbour, metrics) are issued before the first operation -- R KB in flight per
+// wave instead of one.  Rows are 16-B aligned (L % NV == 0); `mal`: every metric row is too, and
+// contiguous along X (host-proven) => one 16-B metric load per lane vector, no per-lane alignment test.
+// Outer dims are (Z, Y) or (Y); with broadcast metrics the row groups are visited band-major (z-banding).
+// ------------------------------------------------------------------------------------------
+template <int OP, int MET, bool NTS, int R>
+__global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
+    const real* __restrict__ in, real* __restrict__ out, u32 L, u32 Z, u32 Y, u32 nblk, FastDiv ntile, FastDiv fYG,
+    ZBand zb, int pad_lo, int bc, real fill, const real* __restrict__ halo, const real* __restrict__ m_in,
+    int64_t mi_z, int64_t mi_y, int64_t mi_x, const real* __restrict__ m_out, int64_t mo_z, int64_t mo_y,
+    int64_t mo_x, int mal, int ntl) {
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
+  const u32 grp = fdiv(w, ntile);
+  const u32 tile = w - grp * ntile.d;
+  u32 z, yg;
+  if (zb.on) {
+    if (!zband_map(zb, grp, z, yg)) return;
+  } else {
+    z = fdiv(grp, fYG);
+    yg = grp - z * fYG.d;
+    if (z >= Z) return;
+  }
+  const u32 y0 = yg * R;
+  const u32 i0 = (tile * WAVE + (threadIdx.x & 63)) * NV;
+  if (i0 >= L) return;
+  u32 nidx;
+  bool edge;
+  if (pad_lo) { edge = (i0 == 0); nidx = edge ? ((bc == XG_BC_PERIODIC) ? L - 1 : 0) : i0 - 1; }
+  else { edge = (i0 + NV == L); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : L - 1) : i0 + NV; }
+
+  dv a[R], wi[R], wo[R];
+  real n[R], wn[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const u32 y = (y0 + u < Y) ? y0 + u : Y - 1;  // a short last group repeats its last row (not stored)
+    const u64 row = (u64)z * Y + y;
+    const real* prow = in + row * L;
+    a[u] = ntl ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + i0)) : *reinterpret_cast<const dv*>(prow + i0);
+    n[u] = prow[nidx];
+    if (HAS_MI) {
+      const real* mrow = m_in + ((int64_t)z * mi_z + (int64_t)y * mi_y);
+      if (mal) wi[u] = *reinterpret_cast<const dv*>(mrow + i0);
+      else {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) wi[u][k] = mrow[(int64_t)(i0 + k) * mi_x];
+      }
+      wn[u] = mrow[(int64_t)nidx * mi_x];
+    }
+    if (HAS_MO) {
+      const real* mrow = m_out + ((int64_t)z * mo_z + (int64_t)y * mo_y);
+      if (mal) wo[u] = *reinterpret_cast<const dv*>(mrow + i0);
+      else {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) wo[u][k] = mrow[(int64_t)(i0 + k) * mo_x];
+      }
+    }
+    if (edge && bc == XG_BC_HALO) n[u] = halo[row];  // one halo cell per row (never weighted: no m_in with halos)
+  }
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    if (y0 + u >= Y) break;
+    dv av = a[u];
+    real nv = n[u];
+    if (HAS_MI) {
+      av = av * wi[u];
+      if (!(edge && bc == XG_BC_HALO)) nv = nv * wn[u];
+    }
+    if (edge && bc == XG_BC_FILL) nv = fill;
+    dv res;
+    if (pad_lo) {
+      res[0] = op2<OP>(nv, av[0]);
+#pragma unroll
+      for (int k = 1; k < NV; ++k) res[k] = op2<OP>(av[k - 1], av[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV - 1; ++k) res[k] = op2<OP>(av[k], av[k + 1]);
+      res[NV - 1] = op2<OP>(av[NV - 1], nv);
+    }
+    if (HAS_MO) res = res / wo[u];
+    stg<dv, NTS>(out + ((u64)z * Y + (y0 + u)) * L + i0, res);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K1g: contiguous axis, GENERAL lengths (odd rows, N+1 / N-1 outputs: outer/inner positions).
 // Rows of the output are then not 16-B aligned, but the output ARRAY is: the array is walked as
 // a flat list of NV-element groups (which may straddle two rows), each element is computed like
@@ -294,9 +389,16 @@ template <int OP, int V, int MET, bool NTS, int SEG>
 __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
     const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk,
     FastDiv ntile, FastDiv nseg, ZBand zb, Chunk ck, int pad_lo, int bc, real fill,
-    const real* __restrict__ halo, const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+    const real* __restrict__ halo, const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo,
+    int mal) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  // `mal` (host-proven): every metric is contiguous along the lanes and each of its rows 16-B aligned, so a
+  // lane vector's metric is ONE 16-B load with no per-lane alignment test
+  auto ldmv = [&](const real* m, int64_t off, int64_t step) -> T {
+    if (V > 1 && mal) return *reinterpret_cast<const T*>(m + off);
+    return ldm<T>(m, off, step);
+  };
   // banding: XCD (b % 8) owns logical blocks [xcd * pb, (xcd + 1) * pb)
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
@@ -358,14 +460,19 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
       }
     }
     T t = *reinterpret_cast<const T*>(src + q * inner);
-    if (HAS_MI) t = t * ldm<T>(m_in, mib + q * mi.axis, mis);
+    if (HAS_MI) t = t * ldmv(m_in, mib + q * mi.axis, mis);
     v[u] = f ? splat<T>(fill) : t;
+  }
+  T dm[SEG];  // divisors: loaded with the field rows, before the first operation
+  if (HAS_MO) {
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) dm[u] = ldmv(m_out, mob + ((u < nrow) ? u : 0) * mo.axis, mos);
   }
 #pragma unroll
   for (int u = 0; u < SEG; ++u) {
     if (u < nrow) {
       T res = op2<OP>(v[u], v[u + 1]);
-      if (HAS_MO) res = res / ldm<T>(m_out, mob + u * mo.axis, mos);
+      if (HAS_MO) res = res / dm[u];
       stg<T, NTS>(pout + u * inner, res);
     }
   }
@@ -621,8 +728,49 @@ int launch_contig_gen(const StencilCall& c) {
   return 0;
 }
 
+// K1r launch: metrics present, aligned rows, outer dims (Z, Y) or (Y); returns 1 when it does not apply
+template <int OP, int MET>
+int launch_contig_rw(const StencilCall& c) {
+  const Geo& g = c.g;
+  const int R = tune().contig_rw;
+  if (MET == 0 || R <= 0 || g.n_outer > 2 || g.n_outer < 1 || !g.idx32) return 1;
+  if (g.n_in != g.n_out || g.n_in % NV || g.n_in >= (1ll << 28)) return 1;
+  const u64 Z = g.n_outer == 2 ? (u64)g.outer_shape[0] : 1, Y = (u64)g.outer_shape[g.n_outer - 1];
+  const int yd = g.n_outer - 1;  // index of the Y dim in the metric's outer strides
+  const int64_t mi_z = (c.m_in && g.n_outer == 2) ? c.mi.outer[0] : 0, mi_y = c.m_in ? c.mi.outer[yd] : 0, mi_x = c.m_in ? c.mi.axis : 0;
+  const int64_t mo_z = (c.m_out && g.n_outer == 2) ? c.mo.outer[0] : 0, mo_y = c.m_out ? c.mo.outer[yd] : 0, mo_x = c.m_out ? c.mo.axis : 0;
+  auto vec_ok = [](const real* m, int64_t sz, int64_t sy, int64_t sx) { return !m || (aligned16(m) && sx == 1 && sz % NV == 0 && sy % NV == 0); };
+  const int mal = vec_ok(c.m_in, mi_z, mi_y, mi_x) && vec_ok(c.m_out, mo_z, mo_y, mo_x);
+  const u32 RR = R >= 4 ? 4u : (R >= 2 ? 2u : 1u);
+  const u64 YG = (Y + RR - 1) / RR;
+  const u64 ntile = ((u64)g.n_in / NV + WAVE - 1) / WAVE;
+  // z-banding: all metrics broadcast along Z; bands of zb_rows rows = zb_rows / R row groups
+  const u32 band = (u32)((tune().zb_rows > 0 ? tune().zb_rows : 16) + RR - 1) / RR;
+  ZBand zb = make_zband(false, 0, 0, 1);
+  u64 groups = Z * YG;
+  if (tune().zband && Z >= 2 && mi_z == 0 && mo_z == 0) {
+    const u64 padded = ((YG + band - 1) / band) * band * Z;
+    zb = make_zband(true, Z, YG, band);
+    if (zb.on) groups = padded;
+  }
+  const u64 waves = groups * ntile;
+  if (waves > MAX_ITEMS) return 1;
+  const u32 nblk = (u32)((waves + WPB - 1) / WPB);
+  const u32 grid = ((nblk + 7) / 8) * 8;
+  const FastDiv fnt = make_fastdiv(ntile), fYG = make_fastdiv(YG);
+#define XG_RW(NTS_, R_) hipLaunchKernelGGL((k_stencil_contig_rw<OP, MET, NTS_, R_>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, (u32)g.n_in, (u32)Z, (u32)Y, nblk, fnt, fYG, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, mi_z, mi_y, mi_x, c.m_out, mo_z, mo_y, mo_x, mal, tune().nt_load)
+  if (tune().nt_store) { if (RR == 4) XG_RW(true, 4); else if (RR == 2) XG_RW(true, 2); else XG_RW(true, 1); }
+  else { if (RR == 4) XG_RW(false, 4); else if (RR == 2) XG_RW(false, 2); else XG_RW(false, 1); }
+#undef XG_RW
+  return 0;
+}
+
 template <int OP, int V, int MET>
 int launch_contig(const StencilCall& c) {
+  if (V == NV && MET != 0) {
+    const int rc = launch_contig_rw<OP, MET>(c);
+    if (rc != 1) return rc;
+  }
   if (V == 1 && tune().contig_gen && aligned16(c.out) && c.g.n_in <= 0x7fffffffll && c.g.n_out <= 0x7fffffffll &&
       c.g.outer * c.g.n_out >= 2) {
     const int rc = launch_contig_gen<OP, MET>(c);
@@ -660,10 +808,20 @@ int launch_contig(const StencilCall& c) {
 // 78.9 / 78.0 % with SEG = 1, 79.7 / 76.2 % with 2, 78.7 / 73.9 % with 4; Z (column chunks) 79.1 / 77.0 %, 77.7 / 73.9 %,
 // 76.1 / 70.5 % -- the fewer rows a thread carries, the less it loses when the device is warm.
 constexpr int STENCIL_SEG = 1;
+// With metrics the balance shifts: the division / products sit between a wave's loads and its store, and a
+// wave that carries 2 rows (3 field loads, 2 divisor loads in flight at once) hides that arithmetic behind twice
+// the bytes -- r01 measured derivative along Y at 74 % with four rows per task against 68 % with one.
 
-template <int OP, int V, int MET>
-int launch_seg(const StencilCall& c) {
-  constexpr int SEG = STENCIL_SEG;
+inline bool metric_vec_ok(const Geo& g, const real* m, const MIdx& mm) {
+  if (!m) return true;
+  if (!aligned16(m) || g.n_inner != 1 || mm.inner[0] != 1 || mm.axis % NV) return false;
+  for (int d = 0; d < g.n_outer; ++d)
+    if (mm.outer[d] % NV) return false;
+  return true;
+}
+
+template <int OP, int V, int MET, int SEG>
+int launch_seg_n(const StencilCall& c) {
   const u64 ntile = (u64)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
   const u64 nseg = (u64)((c.g.n_out + SEG - 1) / SEG);
   const Chunk noch = make_chunk(0, 1, 0);
@@ -672,6 +830,7 @@ int launch_seg(const StencilCall& c) {
   if (per_outer > MAX_ITEMS) return launch_march<OP, V, MET>(c);  // (never the case below 2^31 cells per outer index)
   const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
   const u64 outer_per = MAX_ITEMS / per_outer;
+  const int mal = (V > 1 && MET != 0 && metric_vec_ok(c.g, c.m_in, c.mi) && metric_vec_ok(c.g, c.m_out, c.mo)) ? 1 : 0;
   // z-banding: a single outer dim along which every metric is broadcast, one launch (bands of 16 rows)
   const u32 ZB_SEGS = 16 / SEG;
   const bool zb_ok = !ck.on && MET != 0 && tune().zband && c.g.n_outer == 1 && (!c.m_in || c.mi.outer[0] == 0) &&
@@ -684,9 +843,9 @@ int launch_seg(const StencilCall& c) {
       const u32 nblk = (u32)((waves + WPB - 1) / WPB);
       const u32 grid = ((nblk + 7) / 8) * 8;
       if (tune().nt_store)
-        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
       else
-        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
       return 0;
     }
   }
@@ -696,11 +855,21 @@ int launch_seg(const StencilCall& c) {
     const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
     if (tune().nt_store)
-      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, ck, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, ck, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
     else
-      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, ck, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo);
+      hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fns, zoff, ck, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
   }
   return 0;
+}
+
+template <int OP, int V, int MET>
+int launch_seg(const StencilCall& c) {
+  if (MET != 0 && V > 1) {
+    const int ms = tune().met_seg;
+    if (ms >= 4) return launch_seg_n<OP, V, MET, 4>(c);
+    if (ms >= 2) return launch_seg_n<OP, V, MET, 2>(c);
+  }
+  return launch_seg_n<OP, V, MET, STENCIL_SEG>(c);
 }
 
 // flat NV-group walk for misaligned rows of a strided axis (no metrics); returns 1 when it does not apply
