@@ -69,6 +69,11 @@ typedef enum xg_binop { XG_BIN_MUL = 0, XG_BIN_DIV = 1, XG_BIN_ADD = 2, XG_BIN_S
 int xg_version(void);
 /* copies the calling thread's last error text (NUL-terminated) into buf; returns its length */
 int xg_last_error(char* buf, int n);
+/* Launch-shape tunables (rows per wave-task, band heights, window lengths ...; names in INTEGRATION.md): each
+ * starts from the environment variable XG_<NAME> or its measured default; set / read one at run time.  They
+ * change speed only, never results.  Not synchronised: set them while no call is in flight. */
+int xg_set_tunable(const char* name, int value);
+int xg_get_tunable(const char* name, int* value);
 int xg_device_count(void);
 int xg_set_device(int device);
 int xg_malloc(void** ptr, uint64_t bytes);

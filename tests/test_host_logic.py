@@ -262,3 +262,16 @@ def test_product_never_imports_the_oracle():
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("oracle.refimpl.synthetic", "").replace("oracle/refimpl.py", ""), fn
     assert xgcm_amd.__all__
+
+
+def test_tunables_set_and_get_without_a_gpu():
+    """xg_set_tunable / xg_get_tunable: known names round-trip, unknown names are an error (no GPU needed)."""
+    d = _hip.get_tunable("zb_rows")
+    try:
+        _hip.set_tunable("zb_rows", 32)
+        assert _hip.get_tunable("zb_rows") == 32
+    finally:
+        _hip.set_tunable("zb_rows", d)
+    assert _hip.get_tunable("contig_rw") >= 0
+    with pytest.raises(_hip.XgcmHipError, match="unknown tunable"):
+        _hip.set_tunable("no_such_knob", 1)

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of launch-shape tunables on one GPU, inside ONE process (xg_set_tunable).
+
+    python tools/ab_tunables.py --cases dX,dY,iXmw --variants "contig_rw=0,met_seg=1;contig_rw=2,met_seg=2" [--rounds 6]
+
+A device drifts by several percent while it warms up, so variants timed one process after the other cannot be
+compared; here every round times every variant once (order rotated per round) and the table reports the median
+over the rounds.  Cases: the full-size 75 x 2400 x 3600 f64 operators of tools/microbench.py.  Tuning aid only."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+from xgcm_amd import _hip  # noqa: E402
+from xgcm_amd import device as D  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", default="dX,dY,dZ,iXmw,iYmw")
+    ap.add_argument("--variants", required=True, help="';'-separated variants, each 'name=value,name=value'")
+    ap.add_argument("--rounds", type=int, default=6)
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--shape", default="75,2400,3600")
+    a = ap.parse_args()
+    nz, ny, nx = (int(v) for v in a.shape.split(","))
+    cells = nz * ny * nx
+    T = D.synthetic((nz, ny, nx), 2)
+    dx = D.synthetic((1, ny, nx), 31, 0, 1000.0, 1000.0)
+    dx2 = D.synthetic((1, ny, nx), 32, 0, 1000.0, 1000.0)
+    dz = D.synthetic((nz, 1, 1), 33, 0, 1000.0, 1000.0)
+    U = V = None
+    CASES = {
+        "diffX": (lambda: D.stencil1d("diff", T, 2, 1, 0, "periodic"), 16),
+        "diffY": (lambda: D.stencil1d("diff", T, 1, 1, 0, "extend"), 16),
+        "dX": (lambda: D.stencil1d("diff", T, 2, 1, 0, "periodic", m_out=dx), 16 + 8 / nz),
+        "dY": (lambda: D.stencil1d("diff", T, 1, 1, 0, "extend", m_out=dx), 16 + 8 / nz),
+        "dZ": (lambda: D.stencil1d("diff", T, 0, 1, 0, "fill", m_out=dz), 16),
+        "iXmw": (lambda: D.stencil1d("interp", T, 2, 1, 0, "periodic", m_in=dx2, m_out=dx), 16 + 16 / nz),
+        "iYmw": (lambda: D.stencil1d("interp", T, 1, 1, 0, "extend", m_in=dx2, m_out=dx), 16 + 16 / nz),
+        "divT": (lambda: D.binary("div", T, dx), 16 + 8 / nz),
+        "cumY": (lambda: D.cumsum1d(T, 1, 0, 1, 1, 0, "fill"), 16),
+        "cumZ": (lambda: D.cumsum1d(T, 0, 0, 1, 1, 0, "fill"), 16),
+        "cumX": (lambda: D.cumsum1d(T, 2, 0, 1, 1, 0, "fill"), 16),
+        "sumY": (lambda: D.reduce1d(T, 1, None), 8),
+        "sumZ": (lambda: D.reduce1d(T, 0, dz), 8 + 8 / nz),
+        "vort": (lambda: D.vorticity(U, V, dx, "fill", "fill"), 24 + 8 / nz),
+    }
+    cases = a.cases.split(",")
+    if "vort" in cases:
+        U, V = D.synthetic((nz, ny, nx), 51), D.synthetic((nz, ny, nx), 52)
+    variants = []
+    for spec in a.variants.split(";"):
+        kv = dict((k.strip(), int(v)) for k, v in (item.split("=") for item in spec.split(",") if item.strip()))
+        variants.append(kv)
+    defaults = {k: _hip.get_tunable(k) for kv in variants for k in kv}
+    times = {(vi, c): [] for vi in range(len(variants)) for c in cases}
+    for c in cases:  # warm-up: code objects, allocator, clocks
+        for _ in range(3):
+            CASES[c][0]()
+    torch.cuda.synchronize()
+    for rnd in range(a.rounds):
+        order = list(range(len(variants)))
+        order = order[rnd % len(order):] + order[:rnd % len(order)]
+        for vi in order:
+            for k, v in defaults.items():
+                _hip.set_tunable(k, v)
+            for k, v in variants[vi].items():
+                _hip.set_tunable(k, v)
+            for c in cases:
+                fn = CASES[c][0]
+                fn()
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.reps + 1)]
+                ev[0].record()
+                for i in range(a.reps):
+                    fn()
+                    ev[i + 1].record()
+                torch.cuda.synchronize()
+                ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(a.reps))
+                times[(vi, c)].append(ts[len(ts) // 2])
+    for vi, kv in enumerate(variants):
+        for c in cases:
+            ts = sorted(times[(vi, c)])
+            ms = ts[len(ts) // 2]
+            gbs = cells * CASES[c][1] / (ms * 1e-3) / 1e9
+            print(json.dumps({"case": c, "variant": ",".join(f"{k}={v}" for k, v in kv.items()), "median_ms": round(ms, 4),
+                              "min_ms": round(ts[0], 4), "max_ms": round(ts[-1], 4), "GBps": round(gbs, 1),
+                              "frac_8TBps": round(gbs / 8000, 4), "rounds": a.rounds}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -30,6 +30,8 @@ _vp = C.c_void_p
 SIGNATURES = {
     "xg_version": (C.c_int, []),
     "xg_last_error": (C.c_int, [C.c_char_p, C.c_int]),
+    "xg_set_tunable": (C.c_int, [C.c_char_p, C.c_int]),
+    "xg_get_tunable": (C.c_int, [C.c_char_p, _intp]),
     "xg_device_count": (C.c_int, []),
     "xg_set_device": (C.c_int, [C.c_int]),
     "xg_malloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
@@ -146,6 +148,17 @@ def load() -> C.CDLL:
         raise ImportError(f"libxgcm_hip.so ABI version {lib.xg_version()} != 1")
     _lib = lib
     return lib
+
+
+def set_tunable(name: str, value: int) -> None:
+    """launch-shape tunable of the library (speed only, never results); see INTEGRATION.md"""
+    check(load().xg_set_tunable(name.encode(), int(value)))
+
+
+def get_tunable(name: str) -> int:
+    v = C.c_int(0)
+    check(load().xg_get_tunable(name.encode(), C.byref(v)))
+    return int(v.value)
 
 
 def last_error() -> str:

@@ -85,7 +85,10 @@ int env_int(const char* name, int dflt) {
   return (s && *s) ? atoi(s) : dflt;
 }
 
-// tunables (read once; override with env vars for on-device tuning sessions)
+// tunables: ONE table for the whole library (defined in xg_runtime.hip), initialised from XG_* environment
+// variables at first use and changeable afterwards through xg_set_tunable() -- A/B measurements interleave
+// variants inside one process that way (a device drifts by several percent while it warms up, so variants
+// timed one process after the other cannot be compared)
 struct Tune {
   int seg;       // rows marched per wave-task along a strided stencil axis
   int nt_store;  // non-temporal stores (+2-4 %)
@@ -97,7 +100,7 @@ struct Tune {
   int transform_fast;  // streaming path of the linear transform for well-formed columns (0: always the exact search)
   int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
-  int zb_rows;        // rows of the contiguous-axis kernel per band
+  int zb_rows;        // rows per band
   int scan_block;     // workgroup size of the contiguous-axis scan (128 / 256 / 512 / 1024)
   int strided_gen;    // flat NV-group kernel for misaligned rows of a strided stencil axis
   int march_band;     // XCD-banded wave order in the column-marching scans / reductions
@@ -105,43 +108,18 @@ struct Tune {
   int contig_gen;     // pair-wise general path for odd / length-changing rows on the contiguous axis
   int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
   int contig_rw;      // rows per wave-task of the row-wave contiguous-axis metric kernel K1r (0: flat K1)
+  int rw_zshare;      // K1r: the rows of a wave-task are one row of consecutive LEVELS sharing the metric vector
   int met_seg;        // rows per wave-task of the strided-axis kernel K2S when metrics ride along (1 / 2 / 4)
-  int scan_pipe;      // software-pipelined loads in the marching scans / reductions (0: batches of U)
+  int scan_pipe;      // rolling-window loads in the marching scans / reductions (0: batches of U; 2: short marches too)
   int scan_u;         // loads in flight per lane of a long march (8 / 16 / 24 / 32)
   int scan_pace;      // experiment: workgroup barrier per window in the pipelined marching scan
+  int dbg;            // experiments only (never set in production): see the kernels that read it
   int march_lds_kb;   // optional dynamic LDS request for the column-marching kernels, only to cap residency
                       // (experiment: +8 % on a bare march in tools/streambench.hip, but -20 % on the real
                       // kernels whose index/metric math then has too few waves to hide behind) => default 0
-  Tune() {
-    march_lds_kb = env_int("XG_MARCH_LDS_KB", 0);
-    contig_rw = env_int("XG_CONTIG_RW", 2);
-    met_seg = env_int("XG_MET_SEG", 2);
-    scan_pipe = env_int("XG_SCAN_PIPE", 1);
-    scan_u = env_int("XG_SCAN_U", 16);
-    scan_pace = env_int("XG_SCAN_PACE", 0) ? 1 : 0;
-    contig_gen = env_int("XG_CONTIG_GEN", 1);
-    scan_vec = env_int("XG_SCAN_VEC", 1);
-    deep_waves = env_int("XG_DEEP_WAVES", 8192);  // neutral on its own, pays together with scan_narrow_below
-    zband = env_int("XG_ZBAND", 1);
-    zb_rows = env_int("XG_ZB_ROWS", 16);
-    scan_block = env_int("XG_SCAN_BLOCK", 256);
-    strided_gen = env_int("XG_STRIDED_GEN", 1);
-    march_band = env_int("XG_MARCH_BAND", 1);  // config 4 (8 records, cumsum along Z) 14.8 -> 13.1 ms
-    zchunk = env_int("XG_ZCHUNK", 256);
-    transform_fast = env_int("XG_TRANSFORM_FAST", 1);
-    pad_rows = env_int("XG_PAD_ROWS", 1);
-    scan_narrow_below = env_int("XG_SCAN_NARROW_BELOW", 8192);
-    transform_lds_kb = env_int("XG_TRANSFORM_LDS_KB", 64);
-    seg_max_tiles = env_int("XG_SEG_MAX_TILES", 2048);
-    seg = env_int("XG_SEG", 1 << 30);  // long march: whole column by default
-    nt_store = env_int("XG_NT_STORE", 1);
-    nt_load = env_int("XG_NT_LOAD", 1);  // +3-8 points on the marching scans / reductions, neutral elsewhere
-  }
 };
-const Tune& tune() {
-  static Tune t;
-  return t;
-}
+extern "C" __attribute__((visibility("hidden"))) Tune* xg_internal_tune(void);
+inline const Tune& tune() { return *xg_internal_tune(); }
 
 // ------------------------------------------------------------------------------------------
 // geometry: a C-contiguous N-D array seen as (outer..., n, inner...) around the op axis,

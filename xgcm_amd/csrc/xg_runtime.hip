@@ -6,6 +6,55 @@
 #ifdef XG_PRIMARY
 static thread_local char g_errbuf[XG_ERRBUF_LEN] = {0};
 extern "C" __attribute__((visibility("hidden"))) char* xg_internal_errbuf(void) { return g_errbuf; }
+
+// the tunables table: name (env var XG_<NAME>, upper case), member, default
+namespace {
+struct TuneEntry { const char* name; int Tune::*field; int dflt; };
+const TuneEntry TUNABLES[] = {
+    {"seg", &Tune::seg, 1 << 30},  // long march: whole column by default
+    {"nt_store", &Tune::nt_store, 1},
+    {"nt_load", &Tune::nt_load, 1},  // +3-8 points on the marching scans / reductions, neutral elsewhere
+    {"seg_max_tiles", &Tune::seg_max_tiles, 2048},
+    {"scan_narrow_below", &Tune::scan_narrow_below, 8192},
+    {"pad_rows", &Tune::pad_rows, 1},
+    {"transform_lds_kb", &Tune::transform_lds_kb, 64},
+    {"transform_fast", &Tune::transform_fast, 1},
+    {"zchunk", &Tune::zchunk, 256},
+    {"zband", &Tune::zband, 1},
+    {"zb_rows", &Tune::zb_rows, 16},
+    {"scan_block", &Tune::scan_block, 256},
+    {"strided_gen", &Tune::strided_gen, 1},
+    {"march_band", &Tune::march_band, 1},  // config 4 (8 records, cumsum along Z) 14.8 -> 13.1 ms
+    {"scan_vec", &Tune::scan_vec, 1},
+    {"contig_gen", &Tune::contig_gen, 1},
+    {"deep_waves", &Tune::deep_waves, 8192},  // neutral on its own, pays together with scan_narrow_below
+    {"contig_rw", &Tune::contig_rw, 2},
+    {"rw_zshare", &Tune::rw_zshare, 0},
+    {"met_seg", &Tune::met_seg, 2},
+    {"scan_pipe", &Tune::scan_pipe, 1},
+    {"scan_u", &Tune::scan_u, 16},
+    {"scan_pace", &Tune::scan_pace, 0},
+    {"dbg", &Tune::dbg, 0},
+    {"march_lds_kb", &Tune::march_lds_kb, 0},
+};
+constexpr int N_TUNABLES = (int)(sizeof(TUNABLES) / sizeof(TUNABLES[0]));
+Tune make_tune() {
+  Tune t;
+  memset(&t, 0, sizeof(t));
+  for (int i = 0; i < N_TUNABLES; ++i) {
+    char env[64] = "XG_";
+    size_t k = 3;
+    for (const char* c = TUNABLES[i].name; *c && k + 1 < sizeof(env); ++c) env[k++] = (char)((*c >= 'a' && *c <= 'z') ? *c - 32 : *c);
+    env[k] = 0;
+    t.*(TUNABLES[i].field) = env_int(env, TUNABLES[i].dflt);
+  }
+  return t;
+}
+}  // namespace
+extern "C" __attribute__((visibility("hidden"))) Tune* xg_internal_tune(void) {
+  static Tune t = make_tune();
+  return &t;
+}
 #endif
 
 namespace {
@@ -40,6 +89,25 @@ int xg_last_error(char* buf, int n) {
     buf[c] = 0;
   }
   return len;
+}
+
+int xg_set_tunable(const char* name, int value) {
+  if (!name) return fail(XG_ERR_INVALID, "NULL tunable name");
+  for (int i = 0; i < N_TUNABLES; ++i)
+    if (strcmp(name, TUNABLES[i].name) == 0) {
+      xg_internal_tune()->*(TUNABLES[i].field) = value;
+      return XG_OK;
+    }
+  return fail(XG_ERR_INVALID, "unknown tunable '%s'", name);
+}
+int xg_get_tunable(const char* name, int* value) {
+  if (!name || !value) return fail(XG_ERR_INVALID, "NULL argument");
+  for (int i = 0; i < N_TUNABLES; ++i)
+    if (strcmp(name, TUNABLES[i].name) == 0) {
+      *value = xg_internal_tune()->*(TUNABLES[i].field);
+      return XG_OK;
+    }
+  return fail(XG_ERR_INVALID, "unknown tunable '%s'", name);
 }
 
 int xg_device_count(void) {

@@ -210,28 +210,41 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
 // contiguous along X (host-proven) => one 16-B metric load per lane vector, no per-lane alignment test.
 // Outer dims are (Z, Y) or (Y); with broadcast metrics the row groups are visited band-major (z-banding).
 // ------------------------------------------------------------------------------------------
-template <int OP, int MET, bool NTS, int R>
+// ZS ("z-share", needs z-banding): the R rows of a wave are the SAME row y of R consecutive levels, so one
+// metric vector (and one neighbour metric) serves all R rows -- metric loads, although L2 hits, compete with
+// the field loads for the CU's outstanding-request capacity.
+template <int OP, int MET, int R, bool ZS>
 __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
     const real* __restrict__ in, real* __restrict__ out, u32 L, u32 Z, u32 Y, u32 nblk, FastDiv ntile, FastDiv fYG,
     ZBand zb, int pad_lo, int bc, real fill, const real* __restrict__ halo, const real* __restrict__ m_in,
     int64_t mi_z, int64_t mi_y, int64_t mi_x, const real* __restrict__ m_out, int64_t mo_z, int64_t mo_y,
-    int64_t mo_x, int mal, int ntl) {
+    int64_t mo_x, int mal, int ntl, int dbg) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  constexpr int RM = ZS ? 1 : R;  // metric vectors a wave loads
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
   if (lb >= nblk) return;
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
   const u32 grp = fdiv(w, ntile);
   const u32 tile = w - grp * ntile.d;
-  u32 z, yg;
-  if (zb.on) {
+  u32 z0, y0;  // first row of the wave: rows (z0, y0 + u) or, z-shared, (z0 + u, y0)
+  if (ZS) {    // band-major over (band of B rows, level group, row in band)
+    u32 zg, y;
+    if (!zband_map(zb, grp, zg, y)) return;
+    z0 = zg * R;
+    y0 = y;
+  } else if (zb.on) {
+    u32 z, yg;
     if (!zband_map(zb, grp, z, yg)) return;
+    z0 = z;
+    y0 = yg * R;
   } else {
-    z = fdiv(grp, fYG);
-    yg = grp - z * fYG.d;
+    const u32 z = fdiv(grp, fYG);
     if (z >= Z) return;
+    z0 = z;
+    y0 = (grp - z * fYG.d) * R;
   }
-  const u32 y0 = yg * R;
+  const u32 nvalid = ZS ? ((Z - z0 < (u32)R) ? Z - z0 : (u32)R) : ((Y - y0 < (u32)R) ? Y - y0 : (u32)R);
   const u32 i0 = (tile * WAVE + (threadIdx.x & 63)) * NV;
   if (i0 >= L) return;
   u32 nidx;
@@ -239,17 +252,24 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
   if (pad_lo) { edge = (i0 == 0); nidx = edge ? ((bc == XG_BC_PERIODIC) ? L - 1 : 0) : i0 - 1; }
   else { edge = (i0 + NV == L); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : L - 1) : i0 + NV; }
 
-  dv a[R], wi[R], wo[R];
-  real n[R], wn[R];
+  dv a[R], wi[RM], wo[RM];
+  real n[R], wn[RM];
+  u64 rows[R];
 #pragma unroll
   for (int u = 0; u < R; ++u) {
-    const u32 y = (y0 + u < Y) ? y0 + u : Y - 1;  // a short last group repeats its last row (not stored)
-    const u64 row = (u64)z * Y + y;
-    const real* prow = in + row * L;
+    const u32 uu = ((u32)u < nvalid) ? (u32)u : nvalid - 1;  // a short last group repeats its last row (not stored)
+    rows[u] = ZS ? (u64)(z0 + uu) * Y + y0 : (u64)z0 * Y + (y0 + uu);
+    const real* prow = in + rows[u] * L;
     a[u] = ntl ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + i0)) : *reinterpret_cast<const dv*>(prow + i0);
     n[u] = prow[nidx];
+    if (edge && bc == XG_BC_HALO) n[u] = halo[rows[u]];  // one halo cell per row (never weighted: no m_in with halos)
+  }
+#pragma unroll
+  for (int u = 0; u < RM; ++u) {
+    const u32 uu = ((u32)u < nvalid) ? (u32)u : nvalid - 1;
+    const int64_t zz = ZS ? 0 : (int64_t)z0, yy = ZS ? (int64_t)y0 : (int64_t)(y0 + uu);
     if (HAS_MI) {
-      const real* mrow = m_in + ((int64_t)z * mi_z + (int64_t)y * mi_y);
+      const real* mrow = m_in + (zz * mi_z + yy * mi_y);
       if (mal) wi[u] = *reinterpret_cast<const dv*>(mrow + i0);
       else {
 #pragma unroll
@@ -258,23 +278,25 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
       wn[u] = mrow[(int64_t)nidx * mi_x];
     }
     if (HAS_MO) {
-      const real* mrow = m_out + ((int64_t)z * mo_z + (int64_t)y * mo_y);
-      if (mal) wo[u] = *reinterpret_cast<const dv*>(mrow + i0);
+      const real* mrow = m_out + (zz * mo_z + yy * mo_y);
+      if (dbg & 1) wo[u] = splat<dv>(real(1.5));  // experiment: no divisor load
+      else if (mal) wo[u] = *reinterpret_cast<const dv*>(mrow + i0);
       else {
 #pragma unroll
         for (int k = 0; k < NV; ++k) wo[u][k] = mrow[(int64_t)(i0 + k) * mo_x];
       }
     }
-    if (edge && bc == XG_BC_HALO) n[u] = halo[row];  // one halo cell per row (never weighted: no m_in with halos)
   }
 #pragma unroll
   for (int u = 0; u < R; ++u) {
-    if (y0 + u >= Y) break;
+    if ((u32)u >= nvalid) break;
+    constexpr int um_mask = ZS ? 0 : ~0;
+    const int um = u & um_mask;
     dv av = a[u];
     real nv = n[u];
     if (HAS_MI) {
-      av = av * wi[u];
-      if (!(edge && bc == XG_BC_HALO)) nv = nv * wn[u];
+      av = av * wi[um];
+      if (!(edge && bc == XG_BC_HALO)) nv = nv * wn[um];
     }
     if (edge && bc == XG_BC_FILL) nv = fill;
     dv res;
@@ -287,8 +309,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
       for (int k = 0; k < NV - 1; ++k) res[k] = op2<OP>(av[k], av[k + 1]);
       res[NV - 1] = op2<OP>(av[NV - 1], nv);
     }
-    if (HAS_MO) res = res / wo[u];
-    stg<dv, NTS>(out + ((u64)z * Y + (y0 + u)) * L + i0, res);
+    if (HAS_MO) res = (dbg & 2) ? res * wo[um] : res / wo[um];  // (dbg & 2: experiment, a product in place of the division)
+    stg<dv, true>(out + rows[u] * L + i0, res);
   }
 }
 
@@ -733,7 +755,7 @@ template <int OP, int MET>
 int launch_contig_rw(const StencilCall& c) {
   const Geo& g = c.g;
   const int R = tune().contig_rw;
-  if (MET == 0 || R <= 0 || g.n_outer > 2 || g.n_outer < 1 || !g.idx32) return 1;
+  if (MET == 0 || R <= 0 || !tune().nt_store || g.n_outer > 2 || g.n_outer < 1 || !g.idx32) return 1;
   if (g.n_in != g.n_out || g.n_in % NV || g.n_in >= (1ll << 28)) return 1;
   const u64 Z = g.n_outer == 2 ? (u64)g.outer_shape[0] : 1, Y = (u64)g.outer_shape[g.n_outer - 1];
   const int yd = g.n_outer - 1;  // index of the Y dim in the metric's outer strides
@@ -742,25 +764,30 @@ int launch_contig_rw(const StencilCall& c) {
   auto vec_ok = [](const real* m, int64_t sz, int64_t sy, int64_t sx) { return !m || (aligned16(m) && sx == 1 && sz % NV == 0 && sy % NV == 0); };
   const int mal = vec_ok(c.m_in, mi_z, mi_y, mi_x) && vec_ok(c.m_out, mo_z, mo_y, mo_x);
   const u32 RR = R >= 4 ? 4u : (R >= 2 ? 2u : 1u);
-  const u64 YG = (Y + RR - 1) / RR;
+  const bool bcast_z = tune().zband && Z >= 2 && mi_z == 0 && mo_z == 0;  // z-banding: all metrics broadcast along Z
+  const bool zs = bcast_z && RR > 1 && tune().rw_zshare;
   const u64 ntile = ((u64)g.n_in / NV + WAVE - 1) / WAVE;
-  // z-banding: all metrics broadcast along Z; bands of zb_rows rows = zb_rows / R row groups
-  const u32 band = (u32)((tune().zb_rows > 0 ? tune().zb_rows : 16) + RR - 1) / RR;
+  const u32 brows = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16);
   ZBand zb = make_zband(false, 0, 0, 1);
-  u64 groups = Z * YG;
-  if (tune().zband && Z >= 2 && mi_z == 0 && mo_z == 0) {
-    const u64 padded = ((YG + band - 1) / band) * band * Z;
+  u64 YG = (Y + RR - 1) / RR, groups = Z * YG;
+  if (zs) {  // band-major over (band of `brows` rows, level group, row)
+    const u64 ZG = (Z + RR - 1) / RR;
+    zb = make_zband(true, ZG, Y, brows);
+    if (!zb.on) return 1;
+    groups = ((Y + brows - 1) / brows) * brows * ZG;
+  } else if (bcast_z) {
+    const u32 band = (brows + RR - 1) / RR;  // row groups per band
     zb = make_zband(true, Z, YG, band);
-    if (zb.on) groups = padded;
+    if (zb.on) groups = ((YG + band - 1) / band) * band * Z;
   }
   const u64 waves = groups * ntile;
   if (waves > MAX_ITEMS) return 1;
   const u32 nblk = (u32)((waves + WPB - 1) / WPB);
   const u32 grid = ((nblk + 7) / 8) * 8;
   const FastDiv fnt = make_fastdiv(ntile), fYG = make_fastdiv(YG);
-#define XG_RW(NTS_, R_) hipLaunchKernelGGL((k_stencil_contig_rw<OP, MET, NTS_, R_>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, (u32)g.n_in, (u32)Z, (u32)Y, nblk, fnt, fYG, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, mi_z, mi_y, mi_x, c.m_out, mo_z, mo_y, mo_x, mal, tune().nt_load)
-  if (tune().nt_store) { if (RR == 4) XG_RW(true, 4); else if (RR == 2) XG_RW(true, 2); else XG_RW(true, 1); }
-  else { if (RR == 4) XG_RW(false, 4); else if (RR == 2) XG_RW(false, 2); else XG_RW(false, 1); }
+#define XG_RW(R_, ZS_) hipLaunchKernelGGL((k_stencil_contig_rw<OP, MET, R_, ZS_>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, (u32)g.n_in, (u32)Z, (u32)Y, nblk, fnt, fYG, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, mi_z, mi_y, mi_x, c.m_out, mo_z, mo_y, mo_x, mal, tune().nt_load, tune().dbg)
+  if (zs) { if (RR == 4) XG_RW(4, true); else XG_RW(2, true); }
+  else { if (RR == 4) XG_RW(4, false); else if (RR == 2) XG_RW(2, false); else XG_RW(1, false); }
 #undef XG_RW
   return 0;
 }
@@ -832,7 +859,8 @@ int launch_seg_n(const StencilCall& c) {
   const u64 outer_per = MAX_ITEMS / per_outer;
   const int mal = (V > 1 && MET != 0 && metric_vec_ok(c.g, c.m_in, c.mi) && metric_vec_ok(c.g, c.m_out, c.mo)) ? 1 : 0;
   // z-banding: a single outer dim along which every metric is broadcast, one launch (bands of 16 rows)
-  const u32 ZB_SEGS = 16 / SEG;
+  const u32 zbr = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16);
+  const u32 ZB_SEGS = (zbr + SEG - 1) / SEG;
   const bool zb_ok = !ck.on && MET != 0 && tune().zband && c.g.n_outer == 1 && (!c.m_in || c.mi.outer[0] == 0) &&
                      (!c.m_out || c.mo.outer[0] == 0);
   if (zb_ok) {
