@@ -407,7 +407,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
 // One wave = one x-tile of one SEG-row segment; the (outer, segment, tile) split and all row
 // bases are wave-uniform (scalar unit, FastDiv).
 // ------------------------------------------------------------------------------------------
-template <int OP, int V, int MET, bool NTS, int SEG>
+// ZK > 1 ("z-share", z-banded launches only): the wave carries the same rows of ZK consecutive outer levels;
+// the metric rows, broadcast along that dim, are loaded once for all of them (see K1r).
+template <int OP, int V, int MET, bool NTS, int SEG, int ZK = 1>
 __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
     const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk,
     FastDiv ntile, FastDiv nseg, ZBand zb, Chunk ck, int pad_lo, int bc, real fill,
@@ -437,8 +439,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
   } else {
     const u32 r = fdiv(w, ntile);
     tile = w - r * ntile.d;
-    if (MET != 0 && zb.on) {  // band-major order over (segment band, outer, segment)
+    if (MET != 0 && zb.on) {  // band-major order over (segment band, outer [group], segment)
       if (!zband_map(zb, r, oo, sg)) return;
+      oo *= ZK;
     } else {
       oo = fdiv(r, nseg);
       if (oo >= nouter) return;
@@ -446,13 +449,12 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
     }
   }
   const int64_t o = o0 + oo;
+  const int nk = (ZK > 1 && (int64_t)nouter - (int64_t)oo < ZK) ? (int)(nouter - oo) : ZK;  // levels this wave really has
   const int64_t inner = g.inner;
   const int64_t x = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
   if (x >= inner) return;
   const int64_t j0 = (int64_t)sg * SEG;
   const int64_t nrow = (g.n_out - j0 < SEG) ? g.n_out - j0 : SEG;  // rows this segment really has
-  const real* pin = in + (o * g.n_in) * inner + x;
-  real* pout = out + (o * g.n_out + j0) * inner + x;
 
   int64_t mib = 0, mob = 0, mis = 0, mos = 0;  // (host guarantees g.idx32 when metrics are present)
   if (HAS_MI) {
@@ -465,25 +467,38 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
   }
 
   // padded index k = j0 + u  ->  input row q (wave-uniform), fill flag
-  T v[SEG + 1];
+  T v[ZK][SEG + 1];
+  T wm[SEG + 1];  // input-metric rows, shared by the ZK levels
+  bool ff[SEG + 1], hh[SEG + 1];
+  int64_t qq[SEG + 1];
 #pragma unroll
   for (int u = 0; u <= SEG; ++u) {
     int64_t k = j0 + ((u <= nrow) ? u : nrow);  // clamp inside the padded range for short tails
     int64_t q = k - pad_lo;
-    bool f = false;
-    const real* src = pin;
+    ff[u] = false;
+    hh[u] = false;
     if (q < 0 || q >= g.n_in) {
-      f = (bc == XG_BC_FILL);
+      ff[u] = (bc == XG_BC_FILL);
       if (bc == XG_BC_HALO) {  // pre-gathered halo rows, layout (outer, pad_lo + pad_hi, inner)
-        src = halo + (o * (g.n_out - g.n_in + 1)) * inner + x;
+        hh[u] = true;
         q = (q < 0) ? 0 : pad_lo;
       } else {
         q = (q < 0) ? ((bc == XG_BC_PERIODIC) ? g.n_in - 1 : 0) : ((bc == XG_BC_PERIODIC) ? 0 : g.n_in - 1);
       }
     }
-    T t = *reinterpret_cast<const T*>(src + q * inner);
-    if (HAS_MI) t = t * ldmv(m_in, mib + q * mi.axis, mis);
-    v[u] = f ? splat<T>(fill) : t;
+    qq[u] = q;
+  }
+#pragma unroll
+  for (int kz = 0; kz < ZK; ++kz) {
+    const int64_t ok = o + ((kz < nk) ? kz : nk - 1);  // a short last group repeats its last level (not stored)
+    const real* pin = in + (ok * g.n_in) * inner + x;
+    const real* phalo = halo + (ok * (g.n_out - g.n_in + 1)) * inner + x;
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) v[kz][u] = *reinterpret_cast<const T*>((hh[u] ? phalo : pin) + qq[u] * inner);
+  }
+  if (HAS_MI) {
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) wm[u] = ldmv(m_in, mib + qq[u] * mi.axis, mis);
   }
   T dm[SEG];  // divisors: loaded with the field rows, before the first operation
   if (HAS_MO) {
@@ -491,11 +506,23 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
     for (int u = 0; u < SEG; ++u) dm[u] = ldmv(m_out, mob + ((u < nrow) ? u : 0) * mo.axis, mos);
   }
 #pragma unroll
-  for (int u = 0; u < SEG; ++u) {
-    if (u < nrow) {
-      T res = op2<OP>(v[u], v[u + 1]);
-      if (HAS_MO) res = res / dm[u];
-      stg<T, NTS>(pout + u * inner, res);
+  for (int kz = 0; kz < ZK; ++kz) {
+    if (kz >= nk) break;
+    real* pout = out + ((o + kz) * g.n_out + j0) * inner + x;
+    T p[SEG + 1];
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) {
+      T t = v[kz][u];
+      if (HAS_MI) t = t * wm[u];
+      p[u] = ff[u] ? splat<T>(fill) : t;
+    }
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+      if (u < nrow) {
+        T res = op2<OP>(p[u], p[u + 1]);
+        if (HAS_MO) res = res / dm[u];
+        stg<T, NTS>(pout + u * inner, res);
+      }
     }
   }
 }
@@ -754,8 +781,8 @@ int launch_contig_gen(const StencilCall& c) {
 template <int OP, int MET>
 int launch_contig_rw(const StencilCall& c) {
   const Geo& g = c.g;
-  const int R = tune().contig_rw;
-  if (MET == 0 || R <= 0 || !tune().nt_store || g.n_outer > 2 || g.n_outer < 1 || !g.idx32) return 1;
+  const int R = (MET & 2) ? tune().contig_rw_mi : tune().contig_rw;
+  if (MET == 0 || R <= 0 || tune().contig_rw <= 0 || !tune().nt_store || g.n_outer > 2 || g.n_outer < 1 || !g.idx32) return 1;
   if (g.n_in != g.n_out || g.n_in % NV || g.n_in >= (1ll << 28)) return 1;
   const u64 Z = g.n_outer == 2 ? (u64)g.outer_shape[0] : 1, Y = (u64)g.outer_shape[g.n_outer - 1];
   const int yd = g.n_outer - 1;  // index of the Y dim in the metric's outer strides
@@ -763,9 +790,10 @@ int launch_contig_rw(const StencilCall& c) {
   const int64_t mo_z = (c.m_out && g.n_outer == 2) ? c.mo.outer[0] : 0, mo_y = c.m_out ? c.mo.outer[yd] : 0, mo_x = c.m_out ? c.mo.axis : 0;
   auto vec_ok = [](const real* m, int64_t sz, int64_t sy, int64_t sx) { return !m || (aligned16(m) && sx == 1 && sz % NV == 0 && sy % NV == 0); };
   const int mal = vec_ok(c.m_in, mi_z, mi_y, mi_x) && vec_ok(c.m_out, mo_z, mo_y, mo_x);
-  const u32 RR = R >= 4 ? 4u : (R >= 2 ? 2u : 1u);
+  u32 RR = R >= 8 ? 8u : (R >= 4 ? 4u : (R >= 2 ? 2u : 1u));
   const bool bcast_z = tune().zband && Z >= 2 && mi_z == 0 && mo_z == 0;  // z-banding: all metrics broadcast along Z
   const bool zs = bcast_z && RR > 1 && tune().rw_zshare;
+  if (RR == 8 && !zs) RR = 4;
   const u64 ntile = ((u64)g.n_in / NV + WAVE - 1) / WAVE;
   const u32 brows = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16);
   ZBand zb = make_zband(false, 0, 0, 1);
@@ -786,7 +814,7 @@ int launch_contig_rw(const StencilCall& c) {
   const u32 grid = ((nblk + 7) / 8) * 8;
   const FastDiv fnt = make_fastdiv(ntile), fYG = make_fastdiv(YG);
 #define XG_RW(R_, ZS_) hipLaunchKernelGGL((k_stencil_contig_rw<OP, MET, R_, ZS_>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, (u32)g.n_in, (u32)Z, (u32)Y, nblk, fnt, fYG, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, mi_z, mi_y, mi_x, c.m_out, mo_z, mo_y, mo_x, mal, tune().nt_load, tune().dbg)
-  if (zs) { if (RR == 4) XG_RW(4, true); else XG_RW(2, true); }
+  if (zs) { if (RR == 8) XG_RW(8, true); else if (RR == 4) XG_RW(4, true); else XG_RW(2, true); }
   else { if (RR == 4) XG_RW(4, false); else if (RR == 2) XG_RW(2, false); else XG_RW(1, false); }
 #undef XG_RW
   return 0;
@@ -794,7 +822,7 @@ int launch_contig_rw(const StencilCall& c) {
 
 template <int OP, int V, int MET>
 int launch_contig(const StencilCall& c) {
-  if (V == NV && MET != 0) {
+  if constexpr (V == NV && MET != 0) {
     const int rc = launch_contig_rw<OP, MET>(c);
     if (rc != 1) return rc;
   }
@@ -847,7 +875,7 @@ inline bool metric_vec_ok(const Geo& g, const real* m, const MIdx& mm) {
   return true;
 }
 
-template <int OP, int V, int MET, int SEG>
+template <int OP, int V, int MET, int SEG, int ZK = 1>
 int launch_seg_n(const StencilCall& c) {
   const u64 ntile = (u64)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
   const u64 nseg = (u64)((c.g.n_out + SEG - 1) / SEG);
@@ -863,20 +891,23 @@ int launch_seg_n(const StencilCall& c) {
   const u32 ZB_SEGS = (zbr + SEG - 1) / SEG;
   const bool zb_ok = !ck.on && MET != 0 && tune().zband && c.g.n_outer == 1 && (!c.m_in || c.mi.outer[0] == 0) &&
                      (!c.m_out || c.mo.outer[0] == 0);
+  if (ZK > 1 && !tune().nt_store) return launch_seg_n<OP, V, MET, SEG, 1>(c);  // z-shared tasks exist with non-temporal stores only
   if (zb_ok) {
     const u64 padded_segs = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS;
-    const u64 waves = padded_segs * (u64)c.g.outer * ntile;
-    ZBand zb = make_zband(true, (u64)c.g.outer, nseg, ZB_SEGS);
+    const u64 zgroups = ((u64)c.g.outer + ZK - 1) / ZK;  // ZK levels per wave share the metric rows
+    const u64 waves = padded_segs * zgroups * ntile;
+    ZBand zb = make_zband(true, zgroups, nseg, ZB_SEGS);
     if (zb.on && waves <= MAX_ITEMS) {
       const u32 nblk = (u32)((waves + WPB - 1) / WPB);
       const u32 grid = ((nblk + 7) / 8) * 8;
       if (tune().nt_store)
-        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG, ZK>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
       else
         hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
       return 0;
     }
   }
+  if (ZK > 1) return launch_seg_n<OP, V, MET, SEG, 1>(c);  // not z-banded: no shared metric rows
   const ZBand zoff = make_zband(false, 0, 0, 1);
   for (int64_t o0 = 0; o0 < c.g.outer; o0 += (int64_t)outer_per) {
     const u32 nouter = (u32)((c.g.outer - o0 < (int64_t)outer_per) ? c.g.outer - o0 : (int64_t)outer_per);
@@ -892,8 +923,19 @@ int launch_seg_n(const StencilCall& c) {
 
 template <int OP, int V, int MET>
 int launch_seg(const StencilCall& c) {
-  if (MET != 0 && V > 1) {
-    const int ms = tune().met_seg;
+  if constexpr (MET != 0 && V > 1) {
+    const int ms = tune().met_seg, zk = tune().nt_store ? tune().met_zk : 1;
+    if (zk >= 8 && ms >= 2) return launch_seg_n<OP, V, MET, 2, 8>(c);
+    if (zk >= 4) {
+      if (ms >= 4) return launch_seg_n<OP, V, MET, 4, 4>(c);
+      if (ms >= 2) return launch_seg_n<OP, V, MET, 2, 4>(c);
+      return launch_seg_n<OP, V, MET, 1, 4>(c);
+    }
+    if (zk >= 2) {
+      if (ms >= 4) return launch_seg_n<OP, V, MET, 4, 2>(c);
+      if (ms >= 2) return launch_seg_n<OP, V, MET, 2, 2>(c);
+      return launch_seg_n<OP, V, MET, 1, 2>(c);
+    }
     if (ms >= 4) return launch_seg_n<OP, V, MET, 4>(c);
     if (ms >= 2) return launch_seg_n<OP, V, MET, 2>(c);
   }
