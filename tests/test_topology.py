@@ -22,7 +22,7 @@ from oracle import refimpl as R
 from oracle import topology as T
 from xgcm_amd import DataArray, Dataset, Grid
 from xgcm_amd import halo_map as H
-from xgcm_amd.padding import _parse_fold_padding, _resolve_pivot, pad
+from xgcm_amd.padding import FoldSpec, pad, pole_on_edges
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 with open(os.path.join(GOLDEN, "fold_reference.json")) as f:
@@ -34,32 +34,37 @@ Nx, Ny = 8, 5
 # ----------------------------------------------------------------------------------------------
 # reference helper outputs (golden) vs oracle and product
 # ----------------------------------------------------------------------------------------------
+def _roles(on_edges):
+    """the product's (seam_on_edge, fold_on_edge) in the reference's vocabulary (the fixture's and the oracle's)"""
+    return {"seam": "edge" if on_edges[0] else "center", "fold": "edge" if on_edges[1] else "center"}
+
+
 @pytest.mark.parametrize("row", FOLD_REF["seam_partner_indices"],
                          ids=lambda r: f"{r['position']}-{r['pivot_seam']}-{r['length']}")
 def test_seam_partner_indices_match_reference(row):
     want = np.array(row["indices"])
     np.testing.assert_array_equal(T.seam_partner(row["position"], row["pivot_seam"], row["length"]), want)
-    np.testing.assert_array_equal(H.seam_partner_indices(row["position"], row["pivot_seam"], row["length"]), want)
+    np.testing.assert_array_equal(H.mirror_columns(row["position"], row["pivot_seam"] == "edge", row["length"]), want)
 
 
 @pytest.mark.parametrize("row", FOLD_REF["resolve_pivot"], ids=lambda r: str(r["pivot"]))
 def test_resolve_pivot_matches_reference(row):
     if "raises" in row:
         with pytest.raises(ValueError) as err:
-            _resolve_pivot(row["pivot"], row["fold_axis"], row["seam_axis"])
+            pole_on_edges(row["pivot"], row["fold_axis"], row["seam_axis"])
         assert str(err.value) == row["message"]
     else:
-        assert _resolve_pivot(row["pivot"], row["fold_axis"], row["seam_axis"]) == row["roles"]
+        assert _roles(pole_on_edges(row["pivot"], row["fold_axis"], row["seam_axis"])) == row["roles"]
 
 
 @pytest.mark.parametrize("row", FOLD_REF["parse_fold_padding"], ids=lambda r: str(r["spec"]))
 def test_parse_fold_padding_matches_reference(row):
     if "raises" in row:
         with pytest.raises(ValueError) as err:
-            _parse_fold_padding(row["spec"])
+            FoldSpec.parse(row["spec"])
         assert str(err.value) == row["message"]
     else:
-        assert _parse_fold_padding(row["spec"]) == row["parsed"]
+        assert FoldSpec.parse(row["spec"]) == row["parsed"]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -260,7 +265,7 @@ def test_fold_product_equals_oracle_seeded(backend, pivot, name, widths):
     for isvector in (False, True):
         arg = {("X" if name == "u" else "Y"): da} if isvector else da
         got = pad(arg, grid, padding_width=dict(widths), fill_value={"X": 0.0, "Y": -7.5})
-        want = T.pad_fold(a, {"X": 3, "Y": 2}, pos, "Y", "X", _resolve_pivot(pivot, "Y", "X"), "fill", widths,
+        want = T.pad_fold(a, {"X": 3, "Y": 2}, pos, "Y", "X", _roles(pole_on_edges(pivot, "Y", "X")), "fill", widths,
                           {"X": "periodic", "Y": None}, {"X": 0.0, "Y": -7.5}, isvector)
         np.testing.assert_array_equal(got.values, want)
         assert got.dims == da.dims

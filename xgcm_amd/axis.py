@@ -73,9 +73,9 @@ class Axis:
         self._default_shifts = shifts
 
         if isinstance(padding, Mapping):
-            from .padding import _parse_fold_padding
+            from .padding import FoldSpec
 
-            padding = _parse_fold_padding(padding)
+            padding = FoldSpec.parse(padding)
         elif padding is not None and padding not in VALID_PADDINGS:
             raise ValueError(
                 f"padding must be one of {list(VALID_PADDINGS)} "

@@ -43,7 +43,7 @@ from .grid_ufunc import (
 )
 from .labeled import DataArray, Dataset, _aligned_view, _is_tensor, from_xarray, is_xarray, to_xarray
 from .metrics import iterate_axis_combinations
-from .padding import _is_fold_padding, halo_cells, no_boundary_error, pad
+from .padding import FoldSpec, halo_cells, no_boundary_error, pad
 
 
 def _maybe_promote_str_to_list(a):
@@ -194,7 +194,7 @@ class Grid:
         self._folds = {}
         for axname, axis in self.axes.items():
             spec = axis._padding
-            if not _is_fold_padding(spec):
+            if not FoldSpec.looks_like(spec):
                 continue
             candidates = [o for o in self.axes if o != axname and o in self._explicitly_periodic_axes]
             if not candidates:

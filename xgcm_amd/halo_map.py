@@ -306,25 +306,33 @@ def basic_pad(plane: Plane, dim_of_axis: Mapping[str, str], widths: Mapping[str,
 # ------------------------------------------------------------------------------------------
 # north fold
 # ------------------------------------------------------------------------------------------
-# position -> (2 * offset of the point inside its cell, len(dim) - number of cells)
-SEAM_POSITION = {"center": (1, 0), "left": (0, 0), "right": (2, 0), "outer": (0, 1), "inner": (2, -1)}
+# Points of a staggered axis in HALF-cell units: point k of a dim sits at 2*k + HALF_CELL_OFFSET half cells from
+# the western wall of cell 0; a dim of len(dim) points spans len(dim) - EXTRA_POINTS cells.
+HALF_CELL_OFFSET = {"center": 1, "left": 0, "right": 2, "outer": 0, "inner": 2}
+EXTRA_POINTS = {"center": 0, "left": 0, "right": 0, "outer": 1, "inner": -1}  # len(dim) - number of cells
 
 
-def seam_partner_indices(position: str, pivot_seam: str, length: int) -> np.ndarray:
-    """Source column of each seam-axis point mirrored about the pole (padding.py:94-101):
-    with the point at `k + offset` cells and the pole on a cell edge (c = 0) or a cell
-    centre (c = 1), the partner is `(c - k - 2*offset) mod n_cells`."""
-    two_offset, delta = SEAM_POSITION[position]
-    n_cells = length - delta
-    c = 0 if pivot_seam == "edge" else 1
-    return (c - np.arange(length) - two_offset) % n_cells
+def mirror_columns(position: str, pole_on_edge: bool, length: int) -> np.ndarray:
+    """For every point of the seam dim, the index of the point the fold maps onto it.
+
+    Crossing the pole reflects the zonal coordinate: in half-cell units a point at h lands on 2*p - h, where the
+    pole sits at p = 0 (on the wall of cell 0) or p = 1 (in the centre of cell 0).  The image is again a point of
+    the same position when 2*p - h differs from the offset by a whole number of cells; wrapped around the
+    periodic seam that is index ((2*p - h) - offset) / 2 modulo the number of cells.  (Same map as the
+    reference's `_seam_partner_indices`, padding.py:94-101; outputs pinned by tests/golden/fold_reference.json.)"""
+    offset = HALF_CELL_OFFSET[position]
+    cells = length - EXTRA_POINTS[position]
+    here = 2 * np.arange(length) + offset
+    image = (0 if pole_on_edge else 2) - here
+    return ((image - offset) // 2) % cells
 
 
 def fold_plane(plane: Plane, fold_dim: str, fold_position: str, seam_dim: str, seam_position: str,
-               pivot: Mapping[str, str], width: int, isvector: bool, fold_axis: str) -> Plane:
+               pivot: Tuple[bool, bool], width: int, isvector: bool, fold_axis: str) -> Plane:
     """Append the `width` northern halo rows of a north fold (padding.py:619-686)."""
-    fold_kind = "center" if fold_position == "center" else "edge"
-    skip = 1 if fold_kind == pivot["fold"] else 0
+    seam_on_edge, fold_on_edge = pivot
+    # rows ON the pole line are their own images: present iff the field's fold-axis points share the pole's type
+    skip = 1 if (fold_position != "center") == fold_on_edge else 0
     n = plane.size(fold_dim)
     n_interior = n - skip
     if width > n_interior:
@@ -337,11 +345,11 @@ def fold_plane(plane: Plane, fold_dim: str, fold_position: str, seam_dim: str, s
         )
     rows = np.arange(n - 1 - skip, n - 1 - skip - width, -1)  # north to south
     halo = plane.isel(fold_dim, rows)
-    idx = seam_partner_indices(seam_position, pivot["seam"], plane.size(seam_dim))
+    idx = mirror_columns(seam_position, seam_on_edge, plane.size(seam_dim))
     if idx.max() >= plane.size(seam_dim):
         raise NotImplementedError(
             f"A {seam_position!r} seam position is incompatible with a "
-            f"center-type fold pivot (seam role {pivot['seam']!r}): the mirror "
+            f"center-type fold pivot (seam role {'edge' if seam_on_edge else 'center'!r}): the mirror "
             "about a cell-center pole has no partner on this sublattice. Use an "
             "edge-type pivot, or a center/left/right/outer seam position."
         )

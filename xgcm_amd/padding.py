@@ -26,7 +26,6 @@ import numpy as np
 
 from . import device as _dev
 from . import halo_map as _hm
-from .halo_map import seam_partner_indices as _seam_partner_indices  # noqa: F401  (reference name)
 from .labeled import DataArray, _is_tensor
 
 _XGCM_BOUNDARY_KWARG_TO_XARRAY_PAD_KWARG = {"periodic": "wrap", "fill": "constant", "extend": "edge"}
@@ -107,80 +106,80 @@ def _pad_basic(data: DataArray, grid, padding_width, padding, fill_value) -> Dat
 
 
 # ------------------------------------------------------------------------------------------
-# fold padding values (reference padding.py:60-180)
+# north-fold boundary value `{"fold": pivot[, "south": mode]}`  (semantics: reference padding.py:60-177;
+# the texts of the errors are the reference's, pinned by tests/golden/fold_reference.json)
 # ------------------------------------------------------------------------------------------
-_PIVOT_ALIASES = {
-    # role "seam" = the zonal (X) axis, role "fold" = the meridional (Y) axis
-    "center": {"seam": "center", "fold": "center"},
-    "t": {"seam": "center", "fold": "center"},
-    "corner": {"seam": "edge", "fold": "edge"},
-    "f": {"seam": "edge", "fold": "edge"},
-    "u": {"seam": "edge", "fold": "center"},
-    "v": {"seam": "center", "fold": "edge"},
+# A tripolar grid's northern boundary is folded about a pole that lies either ON a cell edge or in a cell
+# CENTRE, independently along the seam (zonal) and the fold (meridional) axis.  Everything downstream needs
+# exactly those two bits, so a pivot is carried as `(seam_on_edge, fold_on_edge)`; the NEMO-style letters
+# name the point type the pole coincides with.
+_NAMED_POLES = {
+    "center": (False, False), "t": (False, False),
+    "u": (True, False),
+    "v": (False, True),
+    "corner": (True, True), "f": (True, True),
 }
+_SOUTH_MODES = tuple(_XGCM_BOUNDARY_KWARG_TO_XARRAY_PAD_KWARG)  # what the southern edge of the fold axis may do
 
 
-def _is_fold_padding(padding) -> bool:
-    return isinstance(padding, Mapping) and "fold" in padding
+class FoldSpec(dict):
+    """A validated fold padding value.  It stays a plain mapping with the keys `fold` (the pivot as the user
+    gave it) and `south` (the mode of the opposite edge) because `Axis.padding` hands it back to user code."""
 
+    @staticmethod
+    def looks_like(value) -> bool:
+        return isinstance(value, Mapping) and "fold" in value
 
-def _position_kind(position: str) -> str:
-    return "center" if position == "center" else "edge"
+    @classmethod
+    def parse(cls, value) -> "FoldSpec":
+        problem = cls._first_problem(value)
+        if problem is not None:
+            raise ValueError(problem)
+        return cls(fold=value["fold"], south=value.get("south", "fill"))
 
-
-def _parse_fold_padding(padding: Mapping) -> Dict:
-    """Validate `{"fold": pivot[, "south": mode]}` -> `{"fold": pivot, "south": mode}`."""
-    if not _is_fold_padding(padding):
-        raise ValueError(f"Not a fold padding value: {padding!r}")
-    extra = set(padding) - {"fold", "south"}
-    if extra:
-        raise ValueError(
-            f"Unknown keys {sorted(extra)} in fold padding {dict(padding)!r}. "
-            "Allowed keys are 'fold' (pivot type) and 'south' (south-edge mode)."
+    @staticmethod
+    def _first_problem(value) -> Optional[str]:
+        """The first rule `value` violates, in the reference's words, or None."""
+        if not FoldSpec.looks_like(value):
+            return f"Not a fold padding value: {value!r}"
+        pivot, south = value["fold"], value.get("south", "fill")
+        names = sorted(_NAMED_POLES)
+        stray_keys = sorted(k for k in value if k not in ("fold", "south"))
+        by_name, by_axis = isinstance(pivot, str), isinstance(pivot, Mapping)
+        bad_positions = {ax: pos for ax, pos in pivot.items() if pos not in _hm.HALF_CELL_OFFSET} if by_axis else {}
+        rules = (
+            (bool(stray_keys),
+             lambda: f"Unknown keys {stray_keys} in fold padding {dict(value)!r}. "
+                     "Allowed keys are 'fold' (pivot type) and 'south' (south-edge mode)."),
+            (not (by_name or by_axis),
+             lambda: f"Fold pivot must be a name ({names}) or an {{axis: position}} mapping, got {pivot!r}."),
+            (by_name and pivot.lower() not in _NAMED_POLES,
+             lambda: f"Unknown fold pivot {pivot!r}. Use one of {names} or an explicit {{axis: position}} mapping."),
+            (by_axis and len(pivot) == 0,
+             lambda: "Explicit fold pivot mapping must not be empty."),
+            (bool(bad_positions),
+             lambda: f"Invalid position(s) {bad_positions} in explicit fold pivot {dict(pivot)!r}. "
+                     f"Each must be one of {sorted(_hm.HALF_CELL_OFFSET)}."),
+            (south not in _SOUTH_MODES,
+             lambda: f"Fold 'south' mode must be one of {list(_SOUTH_MODES)}, got {south!r}."),
         )
-    pivot = padding["fold"]
-    names = sorted(_PIVOT_ALIASES)
-    if isinstance(pivot, str):
-        if pivot.lower() not in _PIVOT_ALIASES:
-            raise ValueError(
-                f"Unknown fold pivot {pivot!r}. Use one of {names} or an explicit {{axis: position}} mapping."
-            )
-    elif isinstance(pivot, Mapping):
-        if not pivot:
-            raise ValueError("Explicit fold pivot mapping must not be empty.")
-        bad = {ax: pos for ax, pos in pivot.items() if pos not in _hm.SEAM_POSITION}
-        if bad:
-            raise ValueError(
-                f"Invalid position(s) {bad} in explicit fold pivot {dict(pivot)!r}. "
-                f"Each must be one of {sorted(_hm.SEAM_POSITION)}."
-            )
-    else:
-        raise ValueError(f"Fold pivot must be a name ({names}) or an {{axis: position}} mapping, got {pivot!r}.")
-    south = padding.get("south", "fill")
-    if south not in _XGCM_BOUNDARY_KWARG_TO_XARRAY_PAD_KWARG:
-        raise ValueError(
-            f"Fold 'south' mode must be one of {list(_XGCM_BOUNDARY_KWARG_TO_XARRAY_PAD_KWARG)}, got {south!r}."
-        )
-    return {"fold": pivot, "south": south}
+        return next((text() for violated, text in rules if violated), None)
 
 
-def _resolve_pivot(pivot, fold_axis: str, seam_axis: str) -> Dict[str, str]:
-    """pivot spec -> {'seam': center|edge, 'fold': center|edge} (reference padding.py:150-177)."""
+def pole_on_edges(pivot, fold_axis: str, seam_axis: str) -> Tuple[bool, bool]:
+    """`(seam_on_edge, fold_on_edge)` of a validated pivot.  A named pivot is a table look-up; an explicit
+    `{axis: position}` pivot puts the pole on a cell edge of every axis it names at a non-centre position,
+    unnamed axes keep the pole in the cell centre."""
     if isinstance(pivot, str):
-        return dict(_PIVOT_ALIASES[pivot.lower()])
-    roles = {}
-    for axname, position in pivot.items():
-        if axname == fold_axis:
-            roles["fold"] = _position_kind(position)
-        elif axname == seam_axis:
-            roles["seam"] = _position_kind(position)
-        else:
+        return _NAMED_POLES[pivot.lower()]
+    on_edge = {seam_axis: False, fold_axis: False}
+    for axis_name, position in pivot.items():
+        if axis_name not in on_edge:
             raise ValueError(
-                f"Fold pivot axis {axname!r} is neither the fold axis {fold_axis!r} nor the seam axis {seam_axis!r}."
+                f"Fold pivot axis {axis_name!r} is neither the fold axis {fold_axis!r} nor the seam axis {seam_axis!r}."
             )
-    roles.setdefault("seam", "center")
-    roles.setdefault("fold", "center")
-    return roles
+        on_edge[axis_name] = position != "center"
+    return on_edge[seam_axis], on_edge[fold_axis]
 
 
 # ------------------------------------------------------------------------------------------
@@ -280,7 +279,7 @@ def _pad_fold(data, grid, padding_width, padding, fill_value, halo_only=None) ->
     fax = fold_axes[0] if fold_axes else halo_only
     info = grid._folds[fax]
     seam_axis = info["seam_axis"]
-    pivot = _resolve_pivot(info["pivot"], fax, seam_axis)
+    pivot = pole_on_edges(info["pivot"], fax, seam_axis)
     fold_position, fold_dim = grid.axes[fax]._get_position_name(data)
     seam_position, seam_dim = grid.axes[seam_axis]._get_position_name(data)
     width = int(padding_width[fax][1])
