@@ -1,0 +1,115 @@
+"""The xarray-in / xarray-out surface the north star says "stays intact" (missing #4): objects of a
+package named `xarray` go in, `xarray.DataArray`s come out with dims / coords / name / attrs as the reference
+attaches them (xgcm/grid_ufunc.py:1262-1320 `_reattach_coords`; xgcm/test/test_grid.py:571-756).  xarray itself
+is not installable here, so `tests/xarray_standin.py` provides the duck type the bridge recognises."""
+
+import numpy as np
+import pytest
+
+from oracle import refimpl as R
+from xgcm_amd import Grid, apply_as_grid_ufunc
+from xgcm_amd import labeled as L
+
+
+@pytest.fixture
+def xr(monkeypatch, backend):
+    import xarray_standin
+
+    return xarray_standin.install(monkeypatch)
+
+
+def _dataset(xr, N=8):
+    coords = {"XC": np.arange(N) + 0.5, "XG": np.arange(N) * 1.0, "time": np.arange(N) * 600.0,
+              "t_label": ("time", np.arange(N).astype("int64")), "xc_aux": ("XC", np.arange(N).astype("int64") * 10),
+              "lon_g": ("XG", np.arange(N) * 2.0, {"units": "degrees_east"})}
+    v = xr.DataArray(R.synthetic_field((N, N), 3), dims=["time", "XC"], name="v", attrs={"units": "m s-1"})
+    return xr.Dataset({"v": v, "dx": (("XC",), R.synthetic_metric((N,), 4))}, coords, attrs={"title": "toy"})
+
+
+def test_bridge_recognises_the_package_by_name(xr):
+    ds = _dataset(xr)
+    assert L.is_xarray(ds) and L.is_xarray(ds["v"]) and not L.is_xarray(np.zeros(3))
+    inner = L.from_xarray(ds)
+    assert isinstance(inner, L.Dataset) and set(inner.data_vars) == {"v", "dx"} and inner.attrs == {"title": "toy"}
+    assert inner.coords["lon_g"].attrs == {"units": "degrees_east"} and inner["v"].dims == ("time", "XC")
+    back = L.to_xarray(L.from_xarray(ds["v"]))
+    assert type(back).__name__ == "DataArray" and L.is_xarray(back)
+    assert back.dims == ("time", "XC") and back.name == "v" and back.attrs == {"units": "m s-1"}
+    np.testing.assert_array_equal(back.values, ds["v"].values)
+
+
+@pytest.mark.parametrize("funcname", ["diff", "interp", "min", "max", "cumsum", "derivative", "cumint"])
+def test_xarray_in_xarray_out_with_reattached_coords(xr, funcname):
+    """mirror of test_grid.py:588-612 (`test_keep_coords`) on the bridge: result coords = its dims' coordinates
+    + every grid coordinate living on those dims; values = the oracle's"""
+    ds = _dataset(xr)
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", metrics={("X",): ["dx"]},
+                autoparse_metadata=False)
+    out = getattr(grid, funcname)(ds["v"], "X")
+    assert L.is_xarray(out) and type(out).__name__ == "DataArray"
+    assert out.dims == ("time", "XG") and out.name == "v"
+    assert set(out.coords) == {"time", "XG", "t_label", "lon_g"}  # xc_aux lives on the old core dim: gone
+    np.testing.assert_array_equal(out.coords["XG"].values, ds["XG"].values)
+    a = ds["v"].values
+    want = {"diff": lambda: R.stencil1d("diff", a, 1, 1, 0, "periodic"),
+            "interp": lambda: R.stencil1d("interp", a, 1, 1, 0, "periodic"),
+            "min": lambda: R.stencil1d("min", a, 1, 1, 0, "periodic"),
+            "max": lambda: R.stencil1d("max", a, 1, 1, 0, "periodic"),
+            "cumsum": lambda: R.grid_cumsum(a, 1, "center", "left", "periodic"),
+            "cumint": lambda: R.grid_cumsum(a, 1, "center", "left", "periodic", m_in=ds["dx"].values[None, :]),
+            "derivative": None}[funcname]
+    if want is not None:
+        np.testing.assert_array_equal(out.values, want())
+
+
+def test_user_coords_on_noncore_dims_survive(xr):
+    """test_grid.py:647-703 (GH #496): coords the user recast on the INPUT win over the grid's stale copies on
+    non-core dims; the shifted core dim's coordinate comes from the grid; coords on the old core dim vanish"""
+    ds = _dataset(xr)
+    N = 8
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", autoparse_metadata=False)
+    new_time = (np.arange(N) * 600 / 3600.0).astype(np.float32)
+    new_label = (np.arange(N) + 100).astype(np.float32)
+    v = xr.DataArray(ds["v"].values, dims=["time", "XC"], name="v",
+                     coords={"time": new_time, "t_label": ("time", new_label),
+                             "xc_aux": ("XC", (np.arange(N) + 500).astype(np.float32)), "XC": ds["XC"].values})
+    for out in (grid.interp(v, "X"), grid.diff(v, "X"), grid.cumsum(v, "X", to="left")):
+        assert L.is_xarray(out)
+        assert out.coords["time"].dtype == np.float32
+        np.testing.assert_array_equal(out.coords["time"].values, new_time)
+        assert out.coords["t_label"].dtype == np.float32
+        np.testing.assert_array_equal(out.coords["t_label"].values, new_label)
+        np.testing.assert_array_equal(out.coords["XG"].values, ds["XG"].values)
+        assert "XC" not in out.dims and "xc_aux" not in out.coords
+
+
+def test_integrate_average_and_user_grid_ufunc_return_xarray(xr):
+    ds = _dataset(xr)
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", metrics={("X",): ["dx"]},
+                autoparse_metadata=False)
+    tot = grid.integrate(ds["v"], "X")
+    assert L.is_xarray(tot) and tot.dims == ("time",) and set(tot.coords) == {"time", "t_label"}
+    np.testing.assert_allclose(tot.values, (ds["v"].values * ds["dx"].values).sum(-1), rtol=1e-12)
+    assert L.is_xarray(grid.average(ds["v"], "X"))
+    out = apply_as_grid_ufunc(lambda a: a[..., 1:] - a[..., :-1], ds["v"], axis=[("X",)], grid=grid,
+                              signature="(X:center)->(X:left)", padding_width={"X": (1, 0)})
+    assert L.is_xarray(out) and out.dims == ("time", "XG")
+    np.testing.assert_array_equal(out.values, R.stencil1d("diff", ds["v"].values, 1, 1, 0, "periodic"))
+
+
+def test_chunked_input_is_refused_with_the_documented_message(xr):
+    """a dask-backed DataArray (`.chunks` set) must not be computed silently (reference path: grid.py:786-818)"""
+    ds = _dataset(xr)
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", autoparse_metadata=False)
+    chunked = ds["v"].chunk({"time": 4})
+    assert chunked.chunks is not None
+    for call in (lambda: grid.diff(chunked, "X"), lambda: grid.cumsum(chunked, "X"), lambda: grid.integrate(chunked, "X")):
+        with pytest.raises(NotImplementedError, match="dask-chunked inputs are not supported"):
+            call()
+    # the same for this package's own labelled arrays that carry `.chunks`
+    class ChunkedLabelled(L.DataArray):
+        chunks = ((4, 4), (8,))
+
+    inner = L.from_xarray(ds["v"])
+    with pytest.raises(NotImplementedError, match="stream_records"):
+        grid.diff(ChunkedLabelled(inner.data, inner.dims), "X")

@@ -41,7 +41,7 @@ from .grid_ufunc import (
     _reattach_coords,
     apply_as_grid_ufunc,
 )
-from .labeled import DataArray, Dataset, _aligned_view, _is_tensor, from_xarray, is_xarray, to_xarray
+from .labeled import CHUNKED_INPUT_MESSAGE, DataArray, Dataset, _aligned_view, _is_tensor, from_xarray, is_xarray, to_xarray
 from .metrics import iterate_axis_combinations
 from .padding import FoldSpec, halo_cells, no_boundary_error, pad
 
@@ -405,7 +405,7 @@ class Grid:
         data = _check_data_input(data, self)
         first = _maybe_unpack_vector_component(data)
         if getattr(first, "chunks", None) is not None:
-            raise NotImplementedError("dask-chunked inputs are not supported by the MI355X backend")
+            raise NotImplementedError(CHUNKED_INPUT_MESSAGE)
         to = self._map_kwargs_over_axes(to)
         if isinstance(metric_weighted, str):
             metric_weighted = (metric_weighted,)

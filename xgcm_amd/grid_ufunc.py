@@ -21,7 +21,7 @@ from typing import Any, Callable, Dict, List, Mapping, Optional, Sequence, Set, 
 
 import numpy as np
 
-from .labeled import DataArray, _is_tensor
+from .labeled import DataArray, _is_tensor, from_xarray, is_xarray, to_xarray
 from .padding import pad
 
 _PAIR = re.compile(r"(\w+):(center|left|right|inner|outer)")
@@ -423,6 +423,22 @@ def apply_as_grid_ufunc(func: Callable, *args, axis=None, grid=None, signature: 
         )
     if grid is None:
         raise ValueError("Must provide a grid object to describe the Axes")
+
+    # xarray objects in -> xarray objects out (the reference's surface); everything in between is labelled
+    # arrays of this package
+    def _unwrap(a):
+        if isinstance(a, dict):
+            return {k: _unwrap(v) for k, v in a.items()}
+        return from_xarray(a) if is_xarray(a) else a
+
+    was_xr = any(is_xarray(v) for a in args for v in (a.values() if isinstance(a, dict) else (a,)))
+    if was_xr:
+        res = apply_as_grid_ufunc(func, *[_unwrap(a) for a in args], axis=axis, grid=grid, signature=signature,
+                                  padding_width=padding_width, padding=padding, fill_value=fill_value, dask=dask,
+                                  map_overlap=map_overlap, pad_before_func=pad_before_func,
+                                  other_component=_unwrap(other_component) if other_component is not None else None,
+                                  **kwargs)
+        return tuple(to_xarray(r) for r in res) if isinstance(res, tuple) else to_xarray(res)
 
     args = _promote_to_sequence_and_check(list(args), grid)
     other_component = _promote_to_sequence_and_check(other_component, grid)

@@ -421,9 +421,18 @@ def is_xarray(obj) -> bool:
     return mod.startswith("xarray")
 
 
+CHUNKED_INPUT_MESSAGE = (
+    "dask-chunked inputs are not supported by the MI355X backend: compute the array first, or hand its blocks "
+    "to xgcm_amd.streaming.stream_records (record blocks streamed through HBM)"
+)
+
+
 def from_xarray(obj):
-    """xarray.DataArray / Dataset -> xgcm_amd labelled object (host data)."""
+    """xarray.DataArray / Dataset -> xgcm_amd labelled object (host data).  A dask-backed DataArray is refused
+    instead of being computed behind the caller's back (reference: `dask="parallelized"`, grid.py:786-818)."""
     tname = type(obj).__name__
+    if tname == "DataArray" and getattr(obj, "chunks", None) is not None:
+        raise NotImplementedError(CHUNKED_INPUT_MESSAGE)
     if tname == "DataArray":
         coords = {k: (tuple(v.dims), np.asarray(v.values)) for k, v in obj.coords.items()}
         return DataArray(np.asarray(obj.values), tuple(obj.dims), coords=coords, name=obj.name, attrs=dict(obj.attrs))
