@@ -17,14 +17,14 @@ allocator here; the arithmetic is the HIP library's as everywhere else.
 
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, Iterable, Iterator, List, Optional, Tuple
 
 import numpy as np
 import torch
 
 from .labeled import DataArray
 
-__all__ = ["record_blocks", "stream_records", "stream_apply"]
+__all__ = ["record_blocks", "stream_records", "stream_apply", "stream_blocks", "iter_stream"]
 
 
 def record_blocks(n_records: int, block: int) -> List[Tuple[int, int]]:
@@ -145,6 +145,122 @@ def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, 
         if pin_out is not None:
             pin_out.close()
     return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# Chunk-iterator input: the shape a dask / zarr / netCDF reader hands data over in.  The reference walks the
+# chunks of a dask array with `apply_ufunc(dask="parallelized")` (xgcm/grid.py:786-818); here ANY iterable of
+# host record blocks -- a generator that memory-maps one file per block, `dask_array.blocks`, a zarr array
+# sliced along time -- is pulled one block ahead of the GPU: while block k is computed, block k+1 is read
+# (page faults of a memory map included), staged into page-locked memory and copied in, and the result of
+# block k-1 is copied out.  Blocks may differ in length along the record axis (ragged last chunk).
+# ------------------------------------------------------------------------------------------------------
+class _Stage:
+    """two rotating page-locked host buffers that grow to the largest block seen"""
+
+    def __init__(self):
+        self.buf: List[Optional[torch.Tensor]] = [None, None]
+
+    def get(self, slot: int, shape, dtype) -> torch.Tensor:
+        n = int(np.prod(shape))
+        b = self.buf[slot]
+        if b is None or b.dtype != dtype or b.numel() < n:
+            self.buf[slot] = b = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+        return b[:n].view(tuple(shape))
+
+
+def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, copy: bool = True) -> Iterator[np.ndarray]:
+    """Yield `fn(block)` for every host block of `blocks`, in order, as host arrays.
+
+    `blocks`: any iterable of array-likes (float32 / float64, records along the first axis; anything
+    `numpy.asarray` accepts, e.g. `numpy.memmap`).  `fn`: HBM tensor -> HBM tensor (e.g. a closure over
+    `Grid` operators).  H2D of block k+1, `fn` on block k and D2H of block k-1 overlap on three HIP streams.
+    `copy=False` yields views of the staging buffers that are valid only until the next `next()`."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("xgcm_amd.streaming needs a GPU (there is no CPU fallback)")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    s_cmp = torch.cuda.current_stream(dev)
+    st_in, st_out = _Stage(), _Stage()
+    in_free: List[Optional[torch.cuda.Event]] = [None, None]   # H2D that last read staging slot i
+    out_ready: List[Optional[Tuple[torch.Tensor, torch.cuda.Event]]] = [None, None]
+
+    def upload(k: int, block) -> Tuple[torch.Tensor, torch.cuda.Event]:
+        a = np.asarray(block)
+        if a.dtype not in (np.float32, np.float64):
+            a = a.astype(np.float64)
+        slot = k % 2
+        if in_free[slot] is not None:
+            in_free[slot].synchronize()
+        host = st_in.get(slot, a.shape, torch.float32 if a.dtype == np.float32 else torch.float64)
+        np.copyto(host.numpy(), a)  # the READ of the block (disk / page cache -> pinned memory), any strides
+        with torch.cuda.stream(s_in):
+            x = host.to(dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(s_in)
+        in_free[slot] = ev
+        return x, ev
+
+    def finish(slot: int) -> np.ndarray:
+        host, ev = out_ready[slot]
+        ev.synchronize()
+        out_ready[slot] = None
+        return np.array(host.numpy(), copy=True) if copy else host.numpy()
+
+    it = iter(blocks)
+    nxt = next(it, None)
+    ahead = upload(0, nxt) if nxt is not None else None
+    k = 0
+    while ahead is not None:
+        x, ev_in = ahead
+        nxt = next(it, None)                       # read + stage + enqueue the NEXT block before computing this one
+        ahead = upload(k + 1, nxt) if nxt is not None else None
+        s_cmp.wait_event(ev_in)
+        x.record_stream(s_cmp)
+        y = fn(x)
+        if not isinstance(y, torch.Tensor):
+            raise TypeError("fn must return an HBM tensor")
+        ev_cmp = torch.cuda.Event()
+        ev_cmp.record(s_cmp)
+        slot = k % 2
+        if out_ready[slot] is not None:            # result of block k-2 still parked there: hand it over first
+            yield finish(slot)
+        host_out = st_out.get(slot, tuple(y.shape), y.dtype)
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(ev_cmp)
+            y.record_stream(s_out)
+            host_out.copy_(y, non_blocking=True)
+            ev_out = torch.cuda.Event()
+            ev_out.record(s_out)
+        out_ready[slot] = (host_out, ev_out)
+        del x, y
+        k += 1
+        other = k % 2
+        if out_ready[other] is not None and ahead is None:  # tail: nothing left to overlap with
+            yield finish(other)
+    for slot in ((k % 2), ((k + 1) % 2)):
+        if out_ready[slot] is not None:
+            yield finish(slot)
+    s_in.synchronize()
+    s_out.synchronize()
+
+
+def stream_blocks(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable,
+                  sink: Optional[Callable[[int, np.ndarray], None]] = None) -> Optional[np.ndarray]:
+    """Run `iter_stream` to completion.  With `sink(k, result_block)` every result is handed over as it arrives
+    (write it to a file, a zarr store ...) and None is returned; without it the results are concatenated along
+    the record axis and returned."""
+    parts = []
+    for k, res in enumerate(iter_stream(fn, blocks, copy=sink is None)):
+        if sink is not None:
+            sink(k, res)
+        else:
+            parts.append(res)
+    if sink is not None:
+        return None
+    if not parts:
+        return np.empty((0,))
+    return np.concatenate(parts, axis=0)
 
 
 def stream_apply(fn: Callable[[DataArray], DataArray], da: DataArray, record_dim: Optional[str] = None,
