@@ -795,7 +795,7 @@ int launch_contig_rw(const StencilCall& c) {
   const bool zs = bcast_z && RR > 1 && tune().rw_zshare;
   if (RR == 8 && !zs) RR = 4;
   const u64 ntile = ((u64)g.n_in / NV + WAVE - 1) / WAVE;
-  const u32 brows = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16);
+  const u32 brows = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16) * ((c.m_in && c.m_out) ? 1u : 2u);  // see launch_seg_n
   ZBand zb = make_zband(false, 0, 0, 1);
   u64 YG = (Y + RR - 1) / RR, groups = Z * YG;
   if (zs) {  // band-major over (band of `brows` rows, level group, row)
@@ -887,7 +887,9 @@ int launch_seg_n(const StencilCall& c) {
   const u64 outer_per = MAX_ITEMS / per_outer;
   const int mal = (V > 1 && MET != 0 && metric_vec_ok(c.g, c.m_in, c.mi) && metric_vec_ok(c.g, c.m_out, c.mo)) ? 1 : 0;
   // z-banding: a single outer dim along which every metric is broadcast, one launch (bands of 16 rows)
-  const u32 zbr = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16);
+  // band height: `zb_rows` rows when two metrics share the XCD's L2, twice that for one -- a band boundary costs one
+  // halo-row re-read from HBM per level (PMC: +6 % reads at 16 rows), a band must stay L2-resident for all levels
+  const u32 zbr = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16) * ((c.m_in && c.m_out) ? 1u : 2u);
   const u32 ZB_SEGS = (zbr + SEG - 1) / SEG;
   const bool zb_ok = !ck.on && MET != 0 && tune().zband && c.g.n_outer == 1 && (!c.m_in || c.mi.outer[0] == 0) &&
                      (!c.m_out || c.mo.outer[0] == 0);

@@ -487,7 +487,7 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
   const u64 outer_per = MAX_ITEMS / per_outer;
   hipStream_t st = (hipStream_t)stream;
   const bool nts = tune().nt_store;
-  const u32 zbr = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16);
+  const u32 zbr = 2u * (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16);  // one metric (the area): double-height bands, see launch_seg_n
   const u32 ZB_SEGS = (zbr + SEG - 1) / SEG;
   ZBand zb = make_zband(false, 0, 0, 1);
   u64 outer_step = outer_per;
