@@ -391,6 +391,33 @@ def test_conservative_kernel_equals_oracle(backend, kind, dtype):
                                   TR.interp_1d_conservative(phi, theta, bins[::-1].copy()))
 
 
+@pytest.mark.parametrize("kind", ["increasing", "decreasing", "nonmonotonic", "nan_holes", "thick"])
+@pytest.mark.parametrize("nbins", [17, 40, 64, 65])
+def test_conservative_many_bins_and_window_slides(backend, kind, nbins):
+    """the sliding accumulator window of the conservative kernel (16 bins per lane in LDS): columns whose sweep
+    runs forward, backward and back and forth over up to 64 bins, cells thicker than the window (read-modify-
+    write beyond it), bins nothing ever reaches (NaN), more columns than one workgroup; 65 bins -> other kernel"""
+    ncol, n = 300, 23
+    if kind == "thick":
+        rng = np.random.default_rng(11)
+        theta = np.cumsum(rng.random((ncol, n + 1)) * 0.02, axis=-1)
+        theta[:, 7:] += 3.0 + rng.random((ncol, 1))        # one cell spans most of the bins
+        theta[::3, 15:] -= 2.5                              # and some columns come back down through them
+    else:
+        theta = _columns((ncol, n + 1), 13, kind)
+    phi = R.synthetic_field((ncol, n), 14) * 100
+    phi[5, 3] = np.nan
+    top = float(np.nanmax(theta))
+    bins = np.linspace(-0.3, top * 1.1 + 0.3, nbins + 1)
+    bins[1:-1] += (R.synthetic_field((nbins - 1,), 15)) * (bins[1] - bins[0]) * 0.8   # uneven, still increasing
+    bins[3] = theta[2, 4] if not np.isnan(theta[2, 4]) else bins[3]                   # an edge that coincides with a vertex
+    bins = np.sort(bins)
+    got = X.interp_1d_conservative(phi, theta, bins)
+    want = TR.interp_1d_conservative(phi, theta, bins)
+    assert got.shape == (ncol, nbins)
+    np.testing.assert_array_equal(got, want)
+
+
 def test_transform_on_a_zyx_field_without_transposes(backend):
     """(time, Z, Y, X) field, density-like target data: the column axis stays where it is in HBM;
     the result carries the reference's dim order (time, Y, X, target)."""

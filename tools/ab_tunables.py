@@ -51,6 +51,31 @@ def main():
         "vort": (lambda: D.vorticity(U, V, dx, "fill", "fill"), 24 + 8 / nz),
     }
     cases = a.cases.split(",")
+    if any(c.startswith("t") and c[1:4] in ("lin", "con") for c in cases):
+        # vertical transform of the field onto 50 levels / bins (tools/bench_configs.py --configs f4): theta =
+        # running sum of positive random increments ("rw") or a smooth stratification ("sm")
+        mt = 50
+        inc = D.synthetic((nz, ny, nx), 72, 0, 1.0, 0.55)
+        th_rw = D.cumsum1d(inc, 0, 0, 0, 0, 0, None, 0.0, False, False)
+        inc_o = D.synthetic((nz + 1, ny, nx), 73, 0, 1.0, 0.55)
+        tho_rw = D.cumsum1d(inc_o, 0, 0, 0, 0, 0, None, 0.0, False, False)
+        del inc, inc_o
+        import numpy as np
+        zz = torch.arange(nz + 1, dtype=torch.float64, device="cuda")[:, None, None]
+        yy = torch.arange(ny, dtype=torch.float64, device="cuda")[None, :, None]
+        xx = torch.arange(nx, dtype=torch.float64, device="cuda")[None, None, :]
+        wave2 = 2.0 * torch.sin(2 * np.pi * xx / nx) * torch.cos(2 * np.pi * yy / ny)
+        th_sm = (1.05 * (zz[:nz] + 0.5) + wave2).contiguous()
+        tho_sm = (1.05 * zz + wave2).contiguous()
+        del zz, yy, xx, wave2
+        levels = torch.linspace(1.0, 0.9 * nz, mt, dtype=torch.float64, device="cuda").reshape(mt, 1, 1)
+        edges = torch.linspace(0.0, 1.6 * (nz + 1), mt + 1, dtype=torch.float64, device="cuda")
+        CASES.update({
+            "tlin_rw": (lambda: D.transform_linear(T, th_rw, levels, 0), (2 * nz + mt) * 8 / nz),
+            "tlin_sm": (lambda: D.transform_linear(T, th_sm, levels, 0), (2 * nz + mt) * 8 / nz),
+            "tcon_rw": (lambda: D.transform_conservative(T, tho_rw, edges, 0), (2 * nz + 1 + mt) * 8 / nz),
+            "tcon_sm": (lambda: D.transform_conservative(T, tho_sm, edges, 0), (2 * nz + 1 + mt) * 8 / nz),
+        })
     if "vort" in cases:
         U, V = D.synthetic((nz, ny, nx), 51), D.synthetic((nz, ny, nx), 52)
     variants = []

@@ -97,6 +97,7 @@ struct Tune {
   int scan_narrow_below; // marching scans with fewer wave-tasks than this use one element per lane
   int pad_rows;          // row-wise generic pad (wave-uniform row logic); 0: one thread per cell
   int transform_lds_kb;  // LDS budget of the cell-major conservative kernel (0: always the register-tile kernel)
+  int transform_win;   // conservative transform: sliding window of accumulators in LDS (K9d) for up to 64 bins
   int transform_fast;  // streaming path of the linear transform for well-formed columns (0: always the exact search)
   int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim

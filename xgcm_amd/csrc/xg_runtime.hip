@@ -18,6 +18,7 @@ const TuneEntry TUNABLES[] = {
     {"scan_narrow_below", &Tune::scan_narrow_below, 8192},
     {"pad_rows", &Tune::pad_rows, 1},
     {"transform_lds_kb", &Tune::transform_lds_kb, 64},
+    {"transform_win", &Tune::transform_win, 1},
     {"transform_fast", &Tune::transform_fast, 1},
     {"zchunk", &Tune::zchunk, 256},
     {"zband", &Tune::zband, 1},

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(BLOCK) void k_transform_linear(
   // column is streamed ONCE level by level (coalesced across lanes) while a per-lane cursor walks
   // the targets; any violation met on the way sends the lane to the exact path below, which
   // rewrites every output of the column.
-  bool exact = !fast_path || n < 2;
+  bool exact = !(fast_path & 1) || n < 2;
   if (!exact) {
     const real a0 = TH(0), a1 = TH(n - 1);
     if (a0 != a0 || a1 != a1) exact = true;
@@ -136,13 +136,26 @@ __global__ __launch_bounds__(BLOCK) void k_transform_linear(
           const real tv = tvs[u];
           const double xk1 = (double)tv, fk1 = (double)fvs[u];
           if (tv != tv || xk1 < xk) { exact = true; break; }
+          // numpy forms the slope per TARGET, but it depends on the interval only: computed here once per level
+          // with every lane active, the IEEE division leaves the divergent emission loop below (the lanes of a
+          // wave emit at different levels, so that loop's body runs for the union of the lanes: ~2.5 x per level
+          // on random columns) -- same operands, same rounding, same bits
+          const bool per_target = (fast_path & 2) != 0;  // experiment (tunable dbg & 4): the division inside the loop
+          const double slope = per_target ? 0.0 : (fk1 - fk) / (xk1 - xk);
           while (i < m && !exact) {
             const double xv = (double)lev;
             if (!(xv < xk1)) break;          // belongs to a later interval (or to the right edge)
             double res;
             if (xv < xk) res = lval;         // only possible in the first interval: left of the column
             else if (xv == xk) res = fk;
-            else res = interp_pair(xv, xk, xk1, fk, fk1);
+            else if (per_target) res = interp_pair(xv, xk, xk1, fk, fk1);
+            else {
+              res = slope * (xv - xk) + fk;
+              if (res != res) {              // numpy's NaN fall-backs (interp_pair)
+                res = slope * (xv - xk1) + fk1;
+                if (res != res && fk == fk1) res = fk;
+              }
+            }
             emit_and_advance(res);
           }
           xk = xk1; fk = fk1;
@@ -363,6 +376,130 @@ __global__ __launch_bounds__(CTB) void k_transform_conservative_lds(
   for (int64_t j = 0; j < m; ++j) pout[j * inner] = acc[j * CTB];
 }
 
+
+// K9d conservative, a SLIDING WINDOW of accumulators in LDS.  K9c is bound by latency, not by bandwidth: m
+// accumulators per lane (50 x 8 B x 128 lanes = 51 KB per workgroup) leave 6 waves on a CU, far too few to
+// hide the dependent chain of a cell (edge look-ups, an IEEE division per overlapped bin, the LDS
+// read-modify-write).  A column sweeps its bins in order -- exactly for monotonic theta, nearly for real
+// stratification -- so each lane keeps only CWIN consecutive bins [wb, wb + CWIN) in LDS (slot = bin mod
+// CWIN, 32 KB per 256 lanes => 16+ waves per CU); a bin the window leaves is written to `out`, a bin it
+// (re-)enters is read back from `out` if it ever received a contribution (one bit per bin, m <= 64) and is
+// NaN otherwise, a bin beyond the window (a cell thicker than CWIN bins) is read-modify-written in `out`
+// directly.  Wherever an accumulator lives, its additions arrive in cell order: same bits as K9b / K9c /
+// the reference.  Bins that never received anything get their NaN in a final pass.
+constexpr int CWIN = 16;
+constexpr int CWB = 256;
+
+__global__ __launch_bounds__(CWB) void k_transform_conservative_win(
+    const real* __restrict__ phi, const real* __restrict__ theta, const real* __restrict__ bins,
+    real* __restrict__ out, Geo g, MIdx mt) {
+  const int64_t inner = g.inner, n = g.n_in;
+  const int m = (int)g.n_out;  // <= 64 (host)
+  real* sb = reinterpret_cast<real*>(xg_dyn_lds);       // m + 1 edges, padded to an even count
+  real* ring = sb + ((m + 2) & ~1) + threadIdx.x;       // slot s of this lane: ring[s * CWB]
+  for (int j = threadIdx.x; j <= m; j += CWB) sb[j] = bins[j];
+  __syncthreads();
+  const int64_t c = (int64_t)blockIdx.x * CWB + threadIdx.x;
+  if (c >= g.outer * g.inner) return;
+  const int64_t o = c / inner, x = c - o * inner;
+  const real* pphi = phi + (o * n) * inner + x;
+  const real* pth = theta + outer_off(g, mt, o) + inner_off(g, mt, x);
+  real* pout = out + (o * (int64_t)m) * inner + x;
+#pragma unroll
+  for (int s_ = 0; s_ < CWIN; ++s_) ring[s_ * CWB] = (real)NAN;
+  u64 touched = 0;  // bins that hold a value, in the window or already in `out`
+  int wb = 0;       // the window covers bins [wb, wb + CWIN)
+  auto was_touched = [&](int j) -> bool { return (touched >> j) & 1ull; };
+  // a value this lane stored earlier: read past the L1 (the store went through to L2)
+  auto reload = [&](int j) -> real { return __hip_atomic_load(pout + (int64_t)j * inner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto slide_to = [&](int j0) {
+    while (wb < j0) {  // forward: bin wb leaves, bin wb + CWIN enters the slot it frees
+      if (was_touched(wb)) pout[(int64_t)wb * inner] = ring[(wb & (CWIN - 1)) * CWB];
+      const int in = wb + CWIN;
+      if (in < m) ring[(in & (CWIN - 1)) * CWB] = was_touched(in) ? reload(in) : (real)NAN;
+      ++wb;
+    }
+    while (wb > j0) {  // backward (non-monotonic columns): bin wb - 1 enters, bin wb - 1 + CWIN leaves
+      --wb;
+      const int outb = wb + CWIN;
+      if (outb < m && was_touched(outb)) pout[(int64_t)outb * inner] = ring[(outb & (CWIN - 1)) * CWB];
+      ring[(wb & (CWIN - 1)) * CWB] = was_touched(wb) ? reload(wb) : (real)NAN;
+    }
+  };
+  auto accumulate = [&](int j, real add) {
+    if (j < wb + CWIN) {
+      real* slot = ring + (j & (CWIN - 1)) * CWB;
+      const real old = *slot;
+      *slot = (old != old) ? add : old + add;
+    } else {  // the cell reaches beyond the window
+      const real old = was_touched(j) ? reload(j) : (real)NAN;
+      pout[(int64_t)j * inner] = (old != old) ? add : old + add;
+    }
+    touched |= 1ull << j;
+  };
+  int jlo = 0;  // cursor: first bin whose upper edge reaches the current cell
+  real e_lo = sb[0], e_hi = sb[1];
+  real t1 = pth[0];
+  constexpr int UT = 8;
+  for (int64_t i0 = 0; i0 < n; i0 += UT) {
+    real tts[UT], pps[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int64_t i = (i0 + u < n) ? i0 + u : n - 1;
+      tts[u] = pth[(i + 1) * mt.axis];
+      pps[u] = pphi[i * inner];
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      if (i0 + u >= n) break;
+      const real t2 = tts[u], p = pps[u];
+      const real a1 = t1;
+      t1 = t2;
+      const bool n1 = a1 != a1, n2 = t2 != t2;
+      if (n1 && n2) continue;
+      real lo_, hi_;
+      if (n1) { lo_ = hi_ = t2; }
+      else if (n2) { lo_ = hi_ = a1; }
+      else if (a1 < t2) { lo_ = a1; hi_ = t2; }
+      else { lo_ = t2; hi_ = a1; }
+      if (p != p) continue;
+      // first bin whose upper edge reaches the cell: min{j: edge[j+1] >= lo}
+      if ((jlo > 0 && e_lo >= lo_) || (e_hi < lo_ && jlo < m - 1)) {
+        int j = jlo;
+        while (j > 0 && sb[j] >= lo_) --j;
+        while (j < m - 1 && sb[j + 1] < lo_) ++j;
+        jlo = j;
+        e_lo = sb[j];
+        e_hi = sb[j + 1];
+      }
+      if (e_hi < lo_ || e_lo > hi_) continue;  // the cell lies above the last bin / below this one: no overlap at all
+      if (jlo != wb) slide_to(jlo);
+      real e1 = e_lo, e2 = e_hi;
+      for (int j = jlo;;) {
+        real add;
+        if (hi_ == lo_) add = p;
+        else {
+          const real hmin = (e1 > lo_) ? e1 : lo_;  // python max(theta_min, theta_hat_1)
+          const real hmax = (e2 < hi_) ? e2 : hi_;  // python min(theta_max, theta_hat_2)
+          const real alpha = (hmax - hmin) / (hi_ - lo_);
+          add = alpha * p;
+        }
+        accumulate(j, add);
+        if (++j >= m) break;
+        e1 = e2;
+        if (e1 > hi_) break;  // bin j starts above the cell
+        e2 = sb[j + 1];
+      }
+    }
+  }
+  for (int s_ = 0; s_ < CWIN; ++s_) {
+    const int b = wb + s_;
+    if (b < m && was_touched(b)) pout[(int64_t)b * inner] = ring[(b & (CWIN - 1)) * CWB];
+  }
+  for (int j = 0; j < m; ++j)
+    if (!was_touched(j)) pout[(int64_t)j * inner] = (real)NAN;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -385,7 +522,7 @@ int XG_FN(xg_transform_linear)(const real* phi, const real* theta, const int64_t
   const u64 nblocks = ((u64)cols + BLOCK - 1) / BLOCK;
   if ((rc = check_grid(nblocks))) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const int fast = tune().transform_fast;
+  const int fast = (tune().transform_fast ? 1 : 0) | ((tune().dbg & 4) ? 2 : 0);
   if (logarithmic) hipLaunchKernelGGL((k_transform_linear<true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
   else hipLaunchKernelGGL((k_transform_linear<false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
   XG_LAUNCH_CHECK();
@@ -403,6 +540,14 @@ int XG_FN(xg_transform_conservative)(const real* phi, const real* theta, const i
   const int64_t cols = g.outer * g.inner;
   if (cols == 0) return XG_OK;
   const int64_t m = n_edges - 1;
+  if (tune().transform_win && m <= 64) {  // sliding accumulator window (K9d)
+    const size_t wlds = ((size_t)((m + 2) & ~(int64_t)1) + (size_t)CWIN * CWB) * sizeof(real);
+    const u64 nblocks = ((u64)cols + CWB - 1) / CWB;
+    if ((rc = check_grid(nblocks))) return rc;
+    hipLaunchKernelGGL(k_transform_conservative_win, dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+    XG_LAUNCH_CHECK();
+    return XG_OK;
+  }
   const size_t lds = ((size_t)((m + 2) & ~(int64_t)1) + (size_t)m * CTB) * sizeof(real);
   if (tune().transform_lds_kb > 0 && lds <= (size_t)tune().transform_lds_kb * 1024u) {
     const u64 nblocks = ((u64)cols + CTB - 1) / CTB;
