@@ -36,7 +36,7 @@ const TuneEntry TUNABLES[] = {
     {"contig_rw_mi", &Tune::contig_rw_mi, 8},
     {"met_seg", &Tune::met_seg, 2},
     {"scan_pipe", &Tune::scan_pipe, 1},
-    {"scan_u", &Tune::scan_u, 16},
+    {"scan_u", &Tune::scan_u, 32},
     {"scan_pace", &Tune::scan_pace, 0},
     {"dbg", &Tune::dbg, 0},
     {"march_lds_kb", &Tune::march_lds_kb, 0},
