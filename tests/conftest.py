@@ -17,6 +17,8 @@ def pytest_configure(config):
 
         if entry._stale():
             entry.build()
+        if entry._host_stale():
+            entry.build_host()
     except Exception as exc:  # pragma: no cover
         print(f"[conftest] could not build libxgcm_hip.so: {exc}", file=sys.stderr)
 
@@ -49,3 +51,13 @@ def backend(request, monkeypatch):
 
         fake_device.install(monkeypatch)
     return request.param
+
+
+@pytest.fixture
+def host_abi(monkeypatch):
+    """The `Grid` stack over the HOST build of the C ABI (libxgcm_host.so: same symbols, host pointers, its own
+    loops) -- BASELINE config 1, "plumbing, no GPU".  Not a product path: xgcm_amd never loads that library."""
+    import host_abi_device
+
+    host_abi_device.install(monkeypatch)
+    return host_abi_device

@@ -1,0 +1,419 @@
+// xg_host.cpp -- HOST build of the C ABI of include/xgcm_hip.h: the same `extern "C"` symbols over HOST pointers,
+// compiled with g++ into libxgcm_host.so ("CPU build of the ABI" for BASELINE
+// config 1, "plumbing, no GPU").
+//
+// What it is for: an integrator without a GPU can load a library with the exact symbol table of libxgcm_hip.so and
+// exercise a binding end to end (argument marshalling, shapes, strides, error paths) on small arrays.  What it is
+// NOT: a fallback.  xgcm_amd never loads it -- `xgcm_amd._hip.load()` opens libxgcm_hip.so only and the device
+// layer raises without a GPU; the only users are tests/ (tests/host_abi_device.py) and examples/.  It has its own
+// straightforward loops (one output cell at a time, index arithmetic in the open), written against the header's
+// semantics, not against the kernels or the oracle.  It serves the 1-D operators of SURVEY.md section 8(a):
+// stencil (+ pre-gathered halos), cumsum, reduce, pad, the broadcasting binary op and the synthetic generator; the
+// fused / topology / transform entry points exist and return XG_ERR_UNSUPPORTED.
+//
+// Build: g++ -O2 -std=c++17 -fPIC -shared -ffp-contract=off  (no FMA contraction: same bit contract as the kernels)
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/xgcm_hip.h"
+
+namespace {
+
+thread_local char g_err[512] = {0};
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int unsupported(const char* what) {
+  return fail(XG_ERR_UNSUPPORTED, "%s: not part of the host build of the ABI (1-D operators only)", what);
+}
+
+// a C-contiguous N-D array seen as (outer, n, inner) around `axis`
+struct View {
+  int64_t outer = 1, n = 1, inner = 1;
+};
+int make_view(const int64_t* shape, int ndim, int axis, View* v) {
+  if (!shape) return fail(XG_ERR_INVALID, "NULL shape");
+  if (ndim < 1 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [1,%d]", ndim, XG_MAX_NDIM);
+  if (axis < 0 || axis >= ndim) return fail(XG_ERR_INVALID, "axis %d out of range for ndim %d", axis, ndim);
+  for (int d = 0; d < ndim; ++d)
+    if (shape[d] < 0) return fail(XG_ERR_INVALID, "negative extent");
+  v->n = shape[axis];
+  for (int d = 0; d < axis; ++d) v->outer *= shape[d];
+  for (int d = axis + 1; d < ndim; ++d) v->inner *= shape[d];
+  return XG_OK;
+}
+
+// offset of the cell (o, k, x) of the (outer, n', inner) view in an array addressed by per-dim element strides
+// (0 = broadcast) -- the metric convention of the header
+int64_t strided_offset(const int64_t* shape, const int64_t* strides, int ndim, int axis, int64_t o, int64_t k, int64_t x) {
+  int64_t off = k * strides[axis];
+  for (int d = ndim - 1; d > axis; --d) {
+    off += (x % shape[d]) * strides[d];
+    x /= shape[d];
+  }
+  for (int d = axis - 1; d >= 0; --d) {
+    off += (o % shape[d]) * strides[d];
+    o /= shape[d];
+  }
+  return off;
+}
+
+template <typename R>
+R op2(int op, R l, R r) {
+  switch (op) {
+    case XG_OP_DIFF: return r - l;
+    case XG_OP_INTERP: return (l + r) / R(2);
+    case XG_OP_MIN: return (l != l || r != r) ? (l != l ? l : r) : (l < r ? l : r);  // NaN-propagating like np.min
+    default: return (l != l || r != r) ? (l != l ? l : r) : (l > r ? l : r);
+  }
+}
+
+// P[q] of the header: the padded, m_in-weighted input at padded index q along the axis (halo: pre-gathered values)
+template <typename R>
+int stencil1d(int op, const R* in, const R* halo, R* out, const int64_t* shape, int ndim, int axis, int64_t n_out,
+              int pad_lo, int pad_hi, int bc, R fill, const R* m_in, const int64_t* mis, const R* m_out,
+              const int64_t* mos) {
+  if (!in || !out) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
+  if ((pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "pad widths must be 0 or 1, got (%d,%d)", pad_lo, pad_hi);
+  if (bc < XG_BC_NONE || bc > XG_BC_HALO) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
+  if ((m_in && !mis) || (m_out && !mos)) return fail(XG_ERR_INVALID, "metric without strides");
+  View v;
+  if (int rc = make_view(shape, ndim, axis, &v)) return rc;
+  if (n_out != v.n + pad_lo + pad_hi - 1)
+    return fail(XG_ERR_INVALID, "n_out %lld != n_in %lld + %d + %d - 1", (long long)n_out, (long long)v.n, pad_lo, pad_hi);
+  if ((pad_lo || pad_hi) && bc == XG_BC_NONE) return fail(XG_ERR_INVALID, "halo cells requested but no boundary mode given");
+  if (v.n < 1) return fail(XG_ERR_INVALID, "empty stencil axis");
+  std::vector<int64_t> oshape(shape, shape + ndim);
+  oshape[axis] = n_out;
+  const int nhalo = pad_lo + pad_hi;
+  for (int64_t o = 0; o < v.outer; ++o)
+    for (int64_t j = 0; j < n_out; ++j)
+      for (int64_t x = 0; x < v.inner; ++x) {
+        R side[2];
+        for (int s = 0; s < 2; ++s) {
+          int64_t q = j + s - pad_lo;  // index into the unpadded input
+          if (q >= 0 && q < v.n) {
+            R val = in[(o * v.n + q) * v.inner + x];
+            if (m_in) val = val * m_in[strided_offset(shape, mis, ndim, axis, o, q, x)];
+            side[s] = val;
+          } else if (bc == XG_BC_FILL) {
+            side[s] = fill;  // the fill halo is not weighted: the reference pads after the product
+          } else if (bc == XG_BC_HALO) {
+            side[s] = halo[(o * nhalo + (q < 0 ? 0 : pad_lo)) * v.inner + x];
+          } else {
+            const int64_t src = (bc == XG_BC_PERIODIC) ? (q < 0 ? v.n - 1 : 0) : (q < 0 ? 0 : v.n - 1);
+            R val = in[(o * v.n + src) * v.inner + x];
+            if (m_in) val = val * m_in[strided_offset(shape, mis, ndim, axis, o, src, x)];
+            side[s] = val;
+          }
+        }
+        R res = op2<R>(op, side[0], side[1]);
+        if (m_out) res = res / m_out[strided_offset(oshape.data(), mos, ndim, axis, o, j, x)];
+        out[(o * n_out + j) * v.inner + x] = res;
+      }
+  return XG_OK;
+}
+
+template <typename R>
+int cumsum1d(const R* in, R* out, const int64_t* shape, int ndim, int axis, int reverse, int skipna, int trim_lo,
+             int trim_hi, int pad_lo, int pad_hi, int bc, R fill, const R* m_in, const int64_t* mis, const R* m_out,
+             const int64_t* mos) {
+  if (!in || !out) return fail(XG_ERR_INVALID, "NULL array argument");
+  if ((trim_lo | trim_hi | pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "trim/pad widths must be 0 or 1");
+  if (bc < XG_BC_NONE || bc > XG_BC_EXTEND) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
+  if ((pad_lo || pad_hi) && bc == XG_BC_NONE) return fail(XG_ERR_INVALID, "halo cells requested but no boundary mode given");
+  if ((m_in && !mis) || (m_out && !mos)) return fail(XG_ERR_INVALID, "metric without strides");
+  View v;
+  if (int rc = make_view(shape, ndim, axis, &v)) return rc;
+  const int64_t kept = v.n - trim_lo - trim_hi;
+  if (kept < 1) return fail(XG_ERR_INVALID, "nothing left after trimming (n=%lld)", (long long)v.n);
+  const int64_t n_out = kept + pad_lo + pad_hi;
+  std::vector<int64_t> oshape(shape, shape + ndim);
+  oshape[axis] = n_out;
+  std::vector<R> c(v.n);
+  for (int64_t o = 0; o < v.outer; ++o)
+    for (int64_t x = 0; x < v.inner; ++x) {
+      R acc = 0;
+      for (int64_t t = 0; t < v.n; ++t) {  // sequential in scan order, like numpy.cumsum / nancumsum
+        const int64_t k = reverse ? v.n - 1 - t : t;
+        R val = in[(o * v.n + k) * v.inner + x];
+        if (m_in) val = val * m_in[strided_offset(shape, mis, ndim, axis, o, k, x)];
+        if (skipna && val != val) val = 0;
+        acc = (t == 0) ? val : acc + val;
+        c[k] = acc;
+      }
+      for (int64_t j = 0; j < n_out; ++j) {  // pad acts on the trimmed CUMULATIVE values
+        const int64_t t = j - pad_lo;        // index into the trimmed result
+        R val;
+        if (t >= 0 && t < kept) val = c[trim_lo + t];
+        else if (bc == XG_BC_FILL) val = fill;
+        else if (bc == XG_BC_PERIODIC) val = c[trim_lo + (t < 0 ? kept - 1 : 0)];
+        else val = c[trim_lo + (t < 0 ? 0 : kept - 1)];
+        if (m_out) val = val / m_out[strided_offset(oshape.data(), mos, ndim, axis, o, j, x)];
+        out[(o * n_out + j) * v.inner + x] = val;
+      }
+    }
+  return XG_OK;
+}
+
+template <typename R>
+int reduce1d(const R* in, R* out, const int64_t* shape, int ndim, int axis, int skipna, const R* w, const int64_t* ws) {
+  if (!in || !out) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (w && !ws) return fail(XG_ERR_INVALID, "weight without strides");
+  if (skipna < 0 || skipna > 3) return fail(XG_ERR_INVALID, "skipna / count mode %d not in [0,3]", skipna);
+  View v;
+  if (int rc = make_view(shape, ndim, axis, &v)) return rc;
+  for (int64_t o = 0; o < v.outer; ++o)
+    for (int64_t x = 0; x < v.inner; ++x) {
+      R acc = 0;
+      for (int64_t k = 0; k < v.n; ++k) {  // k = 0 .. n-1 in order (numpy's order over a non-last axis)
+        R val = in[(o * v.n + k) * v.inner + x];
+        if (skipna >= 2) val = (skipna == 3 || val == val) ? R(1) : R(0);
+        if (w) val = val * w[strided_offset(shape, ws, ndim, axis, o, k, x)];
+        if (skipna && val != val) val = 0;
+        acc = (k == 0) ? val : acc + val;
+      }
+      out[o * v.inner + x] = acc;
+    }
+  return XG_OK;
+}
+
+template <typename R>
+int pad_nd(const R* in, R* out, const int64_t* shape, int ndim, const int64_t* lo, const int64_t* hi, const int* bc,
+           const R* fill, const int* order) {
+  if (!in || !out || !shape || !lo || !hi || !bc) return fail(XG_ERR_INVALID, "NULL argument");
+  if (ndim < 1 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [1,%d]", ndim, XG_MAX_NDIM);
+  // one axis at a time in application order, each step a fresh array (numpy.pad chain semantics)
+  std::vector<int64_t> cur(shape, shape + ndim);
+  int64_t total = 1;
+  for (int d = 0; d < ndim; ++d) total *= cur[d];
+  std::vector<R> a(in, in + total), b;
+  for (int step = 0; step < ndim; ++step) {
+    const int ax = order ? order[step] : step;
+    if (ax < 0 || ax >= ndim) return fail(XG_ERR_INVALID, "bad axis %d in order", ax);
+    if (lo[ax] == 0 && hi[ax] == 0) continue;
+    if (lo[ax] < 0 || hi[ax] < 0) return fail(XG_ERR_INVALID, "negative pad width");
+    if (bc[ax] < XG_BC_PERIODIC || bc[ax] > XG_BC_EXTEND) return fail(XG_ERR_INVALID, "axis %d is padded but has no boundary mode", ax);
+    View v;
+    if (int rc = make_view(cur.data(), ndim, ax, &v)) return rc;
+    if (v.n == 0 && bc[ax] != XG_BC_FILL) return fail(XG_ERR_INVALID, "can't extend empty axis %d using modes other than 'constant'", ax);
+    const int64_t n2 = v.n + lo[ax] + hi[ax];
+    b.assign((size_t)(v.outer * n2 * v.inner), R(0));
+    for (int64_t o = 0; o < v.outer; ++o)
+      for (int64_t j = 0; j < n2; ++j) {
+        int64_t q = j - lo[ax];
+        bool constant = false;
+        if (q < 0 || q >= v.n) {
+          if (bc[ax] == XG_BC_FILL) constant = true;
+          else if (bc[ax] == XG_BC_PERIODIC) q = ((q % v.n) + v.n) % v.n;  // numpy 'wrap'
+          else q = q < 0 ? 0 : v.n - 1;                                    // numpy 'edge'
+        }
+        for (int64_t x = 0; x < v.inner; ++x)
+          b[(size_t)((o * n2 + j) * v.inner + x)] = constant ? (fill ? fill[ax] : R(0)) : a[(size_t)((o * v.n + q) * v.inner + x)];
+      }
+    a.swap(b);
+    cur[ax] = n2;
+  }
+  int64_t n_out = 1;
+  for (int d = 0; d < ndim; ++d) n_out *= cur[d];
+  if (n_out) memcpy(out, a.data(), sizeof(R) * (size_t)n_out);
+  return XG_OK;
+}
+
+template <typename R>
+int binary(int op, const R* a, const int64_t* sa, const R* b, const int64_t* sb, R* out, const int64_t* shape, int ndim) {
+  if (!a || !b || !out || !shape || !sa || !sb) return fail(XG_ERR_INVALID, "NULL argument");
+  if (op < XG_BIN_MUL || op > XG_BIN_SUB) return fail(XG_ERR_INVALID, "unknown binary op %d", op);
+  if (ndim < 1 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [1,%d]", ndim, XG_MAX_NDIM);
+  int64_t total = 1;
+  for (int d = 0; d < ndim; ++d) total *= shape[d];
+  for (int64_t i = 0; i < total; ++i) {
+    int64_t r = i, oa = 0, ob = 0;
+    for (int d = ndim - 1; d >= 0; --d) {
+      const int64_t c = r % shape[d];
+      r /= shape[d];
+      oa += c * sa[d];
+      ob += c * sb[d];
+    }
+    const R x = a[oa], y = b[ob];
+    out[i] = op == XG_BIN_MUL ? x * y : op == XG_BIN_DIV ? x / y : op == XG_BIN_ADD ? x + y : x - y;
+  }
+  return XG_OK;
+}
+
+template <typename R>
+int fill_synthetic(R* out, int64_t n, uint64_t seed, uint64_t offset, double scale, double shift) {
+  if (!out && n > 0) return fail(XG_ERR_INVALID, "NULL output");
+  for (int64_t i = 0; i < n; ++i) {
+    uint64_t z = (uint64_t)i + offset + seed * 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const double u = (double)(z >> 11) * 0x1.0p-53;
+    out[i] = (R)(u * scale + shift);
+  }
+  return XG_OK;
+}
+
+// tunables: accepted and remembered so that bindings can be exercised; they have no effect on the host loops
+struct Knob { char name[32]; int value; };
+std::vector<Knob>& knobs() { static std::vector<Knob> k; return k; }
+
+}  // namespace
+
+extern "C" {
+
+int xg_version(void) { return XG_ABI_VERSION; }
+int xg_last_error(char* buf, int n) {
+  const int len = (int)strlen(g_err);
+  if (buf && n > 0) {
+    const int c = len < n - 1 ? len : n - 1;
+    memcpy(buf, g_err, c);
+    buf[c] = 0;
+  }
+  return len;
+}
+int xg_set_tunable(const char* name, int value) {
+  if (!name || !*name || strlen(name) >= 32) return fail(XG_ERR_INVALID, "bad tunable name");
+  for (auto& k : knobs())
+    if (!strcmp(k.name, name)) { k.value = value; return XG_OK; }
+  Knob k;
+  snprintf(k.name, sizeof(k.name), "%s", name);
+  k.value = value;
+  knobs().push_back(k);
+  return XG_OK;
+}
+int xg_get_tunable(const char* name, int* value) {
+  if (!name || !value) return fail(XG_ERR_INVALID, "NULL argument");
+  for (auto& k : knobs())
+    if (!strcmp(k.name, name)) { *value = k.value; return XG_OK; }
+  return fail(XG_ERR_INVALID, "unknown tunable '%s'", name);
+}
+int xg_device_count(void) { return 0; }  // the host build drives no device
+int xg_set_device(int) { return fail(XG_ERR_UNSUPPORTED, "host build of the ABI: no device"); }
+int xg_malloc(void** ptr, uint64_t bytes) {
+  if (!ptr) return fail(XG_ERR_INVALID, "NULL argument");
+  *ptr = malloc(bytes ? bytes : 1);
+  return *ptr ? XG_OK : fail(XG_ERR_HIP, "out of host memory");
+}
+int xg_free(void* ptr) { free(ptr); return XG_OK; }
+int xg_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void*) { if (bytes) memcpy(dst, src, bytes); return XG_OK; }
+int xg_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void*) { if (bytes) memcpy(dst, src, bytes); return XG_OK; }
+int xg_stream_sync(void*) { return XG_OK; }
+int xg_event_create(void** ev) {
+  if (!ev) return fail(XG_ERR_INVALID, "NULL argument");
+  *ev = calloc(1, sizeof(double));
+  return *ev ? XG_OK : fail(XG_ERR_HIP, "out of host memory");
+}
+int xg_event_record(void* ev, void*) {
+  if (!ev) return fail(XG_ERR_INVALID, "NULL event");
+  *(double*)ev = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  return XG_OK;
+}
+int xg_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!start || !stop || !ms) return fail(XG_ERR_INVALID, "NULL argument");
+  *ms = (float)(*(double*)stop - *(double*)start);
+  return XG_OK;
+}
+int xg_event_destroy(void* ev) { free(ev); return XG_OK; }
+
+#define XG_HOST_TYPED(SFX, R)                                                                                         \
+  int xg_stencil1d_##SFX(int op, const R* in, R* out, const int64_t* shape, int ndim, int axis, int64_t n_out,        \
+                         int pad_lo, int pad_hi, int bc, R fill, const R* m_in, const int64_t* mis, const R* m_out,   \
+                         const int64_t* mos, void*) {                                                                 \
+    if (bc == XG_BC_HALO) return fail(XG_ERR_INVALID, "XG_BC_HALO needs xg_stencil1d_halo");                          \
+    return stencil1d<R>(op, in, nullptr, out, shape, ndim, axis, n_out, pad_lo, pad_hi, bc, fill, m_in, mis, m_out,   \
+                        mos);                                                                                         \
+  }                                                                                                                   \
+  int xg_stencil1d_halo_##SFX(int op, const R* in, const R* halo, R* out, const int64_t* shape, int ndim, int axis,   \
+                              int64_t n_out, int pad_lo, int pad_hi, const R* m_out, const int64_t* mos, void*) {     \
+    if (!halo && (pad_lo || pad_hi)) return fail(XG_ERR_INVALID, "NULL halo buffer");                                 \
+    return stencil1d<R>(op, in, halo, out, shape, ndim, axis, n_out, pad_lo, pad_hi,                                  \
+                        (pad_lo || pad_hi) ? XG_BC_HALO : XG_BC_NONE, R(0), nullptr, nullptr, m_out, mos);            \
+  }                                                                                                                   \
+  int xg_cumsum1d_##SFX(const R* in, R* out, const int64_t* shape, int ndim, int axis, int reverse, int skipna,       \
+                        int trim_lo, int trim_hi, int pad_lo, int pad_hi, int bc, R fill, const R* m_in,              \
+                        const int64_t* mis, const R* m_out, const int64_t* mos, void*) {                              \
+    return cumsum1d<R>(in, out, shape, ndim, axis, reverse, skipna, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill,       \
+                       m_in, mis, m_out, mos);                                                                        \
+  }                                                                                                                   \
+  int xg_reduce1d_##SFX(const R* in, R* out, const int64_t* shape, int ndim, int axis, int skipna, const R* w,        \
+                        const int64_t* ws, void*) {                                                                   \
+    return reduce1d<R>(in, out, shape, ndim, axis, skipna, w, ws);                                                    \
+  }                                                                                                                   \
+  int xg_pad_##SFX(const R* in, R* out, const int64_t* shape, int ndim, const int64_t* lo, const int64_t* hi,         \
+                   const int* bc, const R* fill, const int* order, void*) {                                           \
+    return pad_nd<R>(in, out, shape, ndim, lo, hi, bc, fill, order);                                                  \
+  }                                                                                                                   \
+  int xg_binary_##SFX(int op, const R* a, const int64_t* sa, const R* b, const int64_t* sb, R* out,                   \
+                      const int64_t* shape, int ndim, void*) {                                                        \
+    return binary<R>(op, a, sa, b, sb, out, shape, ndim);                                                             \
+  }                                                                                                                   \
+  int xg_fill_synthetic_##SFX(R* out, int64_t n, uint64_t seed, uint64_t offset, double scale, double shift, void*) { \
+    return fill_synthetic<R>(out, n, seed, offset, scale, shift);                                                     \
+  }                                                                                                                   \
+  int xg_gather_##SFX(const R*, const R*, R*, const int64_t*, const int64_t*, const int64_t*, int, const int*,        \
+                      const int*, const int64_t*, const int64_t*, int64_t, const R*, int, void*) {                    \
+    return unsupported("xg_gather");                                                                                  \
+  }                                                                                                                   \
+  int xg_transform_linear_##SFX(const R*, const R*, const int64_t*, const R*, const int64_t*, int64_t, R*,            \
+                                const int64_t*, int, int, int, int, int, void*) {                                     \
+    return unsupported("xg_transform_linear");                                                                        \
+  }                                                                                                                   \
+  int xg_transform_conservative_##SFX(const R*, const R*, const int64_t*, const R*, int64_t, R*, const int64_t*, int, \
+                                      int, void*) {                                                                   \
+    return unsupported("xg_transform_conservative");                                                                  \
+  }                                                                                                                   \
+  int xg_vorticity_##SFX(const R*, const R*, const R*, const int64_t*, R*, const int64_t*, int, int, R, int, R,       \
+                         void*) {                                                                                     \
+    return unsupported("xg_vorticity");                                                                               \
+  }                                                                                                                   \
+  int xg_divergence_##SFX(const R*, const R*, const R*, const int64_t*, R*, const int64_t*, int, int, R, int, R,      \
+                          void*) {                                                                                    \
+    return unsupported("xg_divergence");                                                                              \
+  }                                                                                                                   \
+  int xg_gradient_##SFX(const R*, R*, R*, const int64_t*, int, int, R, int, R, const R*, const int64_t*, const R*,    \
+                        const int64_t*, void*) {                                                                      \
+    return unsupported("xg_gradient");                                                                                \
+  }                                                                                                                   \
+  int xg_flux_##SFX(const R*, const R*, const R*, R*, R*, const int64_t*, int, int, R, int, R, void*) {               \
+    return unsupported("xg_flux");                                                                                    \
+  }                                                                                                                   \
+  int xg_gradient_halo_##SFX(const R*, const R*, const R*, R*, R*, const int64_t*, int, int, R, int, R, const R*,     \
+                             const int64_t*, const R*, const int64_t*, void*) {                                       \
+    return unsupported("xg_gradient_halo");                                                                           \
+  }                                                                                                                   \
+  int xg_flux_halo_##SFX(const R*, const R*, const R*, const R*, const R*, R*, R*, const int64_t*, int, int, R, int,  \
+                         R, void*) {                                                                                  \
+    return unsupported("xg_flux_halo");                                                                               \
+  }                                                                                                                   \
+  int xg_vorticity_halo_##SFX(const R*, const R*, const R*, const R*, const R*, const int64_t*, R*, const int64_t*,   \
+                              int, int, R, int, R, void*) {                                                           \
+    return unsupported("xg_vorticity_halo");                                                                          \
+  }                                                                                                                   \
+  int xg_divergence_halo_##SFX(const R*, const R*, const R*, const R*, const R*, const int64_t*, R*, const int64_t*,  \
+                               int, int, R, int, R, void*) {                                                          \
+    return unsupported("xg_divergence_halo");                                                                         \
+  }                                                                                                                   \
+  int xg_stencil2d_##SFX(int, const R*, R*, const int64_t*, int, int, int, int, int, R, int, int, int, R, void*) {    \
+    return unsupported("xg_stencil2d");                                                                               \
+  }
+
+XG_HOST_TYPED(f64, double)
+XG_HOST_TYPED(f32, float)
+
+}  // extern "C"
