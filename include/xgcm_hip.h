@@ -124,7 +124,10 @@ int xg_cumsum1d_f64(const double* in, double* out, const int64_t* shape, int ndi
  * output cell (bit-identical to numpy); along the last axis it is a lane-strided tree.
  * `skipna` also selects the two denominators of a weighted mean (xarray's
  * `da.weighted(w).mean`, xgcm/grid.py:1681-1685) in the same single pass: 2 = sum of the weights of
- * the valid (non-NaN) cells of `in`, 3 = sum of the weights of all cells. */
+ * the valid (non-NaN) cells of `in`, 3 = sum of the weights of all cells -- and the mean itself, numerator
+ * and denominator marching together so that `in` is read ONCE: 4 = (mode 1) / (mode 2), the NaN-skipping
+ * weighted mean of Grid.average; 5 = (mode 0) / (mode 3).  Same sums in the same order as the separate
+ * modes, one IEEE division at the end: bit-identical to computing the two sums apart and dividing. */
 int xg_reduce1d_f64(const double* in, double* out, const int64_t* shape, int ndim, int axis,
                     int skipna, const double* w, const int64_t* w_strides, void* stream);
 

@@ -124,7 +124,7 @@ def reduce1d(x, axis, w=None, skipna=True):
     out = np.empty(shape[:axis] + shape[axis + 1:], dtype=dt)
     if out.size == 0:
         return out
-    mode = {"valid": 2, "all": 3}.get(skipna, int(bool(skipna)))
+    mode = {"valid": 2, "all": 3, "mean_valid": 4, "mean_all": 5}.get(skipna, int(bool(skipna)))
     _check(getattr(lib(), "xg_reduce1d_" + sfx)(_ptr(x), _ptr(out), _hip.i64(shape), len(shape), axis, mode, _ptr(w),
                                                _hip.i64(_strides(w, shape, "w")), None))
     return out

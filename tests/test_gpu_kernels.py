@@ -180,6 +180,16 @@ def test_reduce(dev, shape):
                     np.testing.assert_allclose(got, exp, rtol=1e-12, atol=1e-13)
                 else:
                     _eq(got, exp)
+        # the weighted mean in ONE pass (numerator and denominator together, divided in the kernel) == the two
+        # separate sums divided afterwards, bit for bit on every axis (same sums, same order, one IEEE division)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            for mode, nmode, dmode in (("mean_valid", True, "valid"), ("mean_all", False, "all")):
+                for ww in (w, None):
+                    two_pass = dev.tohost(dev.reduce1d(a, axis, ww, nmode)) / dev.tohost(dev.reduce1d(a, axis, ww, dmode))
+                    _eq(dev.tohost(dev.reduce1d(a, axis, ww, mode)), two_pass)
+                    if axis != nd - 1:
+                        ones = (~np.isnan(a)).astype(a.dtype) if dmode == "valid" else np.ones_like(a)
+                        _eq(two_pass, R.integrate(a, axis, ww, nmode) / R.integrate(ones, axis, ww, False))
 
 
 def test_pad_matches_numpy_chain(dev):

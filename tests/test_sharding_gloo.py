@@ -97,7 +97,7 @@ def test_two_rank_gloo_sharded_equals_single_process(tmp_path):
 
 
 # ---- sharding ALONG the operator's axis: neighbour planes exchanged point to point ---------------
-def _core_axis_worker(rank, world, port, tmp):
+def _core_axis_worker(rank, world, port, tmp, real_device=False):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -113,7 +113,10 @@ def _core_axis_worker(rank, world, port, tmp):
             def setattr(self, obj, name, val):
                 setattr(obj, name, val)
 
-        fake_device.install(MP())
+        if real_device:  # GPU box: both ranks compute on the one GPU through the real library, host arrays in and out
+            torch.cuda.set_device(0)
+        else:
+            fake_device.install(MP())
         from xgcm_amd import DataArray, Dataset, Grid
         from xgcm_amd.sharding import cumsum_along_sharded_axis, stencil_along_sharded_axis
 
@@ -149,14 +152,15 @@ def _core_axis_worker(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_gloo_ranks_sharded_along_the_core_axis_exchange_one_plane(tmp_path, world):
+@pytest.mark.parametrize("world,real_device", [(2, False), (3, False), pytest.param(2, True, marks=pytest.mark.gpu)])
+def test_gloo_ranks_sharded_along_the_core_axis_exchange_one_plane(tmp_path, world, real_device):
     """diff / interp / max along Z of a field split over Z: each rank gets one plane from its neighbour
     (ring closed for `periodic`, ends made locally for `fill` / `extend`); concatenated blocks ==
-    the single-process operator, bit for bit."""
+    the single-process operator, bit for bit.  On the GPU box the same two ranks run the real library with
+    HOST (numpy) shards (the block totals of the scan are HBM tensors there)."""
     from oracle import refimpl as R
 
-    mp.spawn(_core_axis_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_core_axis_worker, args=(world, _free_port(), str(tmp_path), real_device), nprocs=world, join=True)
     nz, ny, nx = 7, 5, 8
     full = R.synthetic_field((nz, ny, nx), 9)
     for bc in ("periodic", "fill", "extend"):

@@ -344,6 +344,12 @@ def main():
             out[r] = grid_s.diff(DataArray(host[r], ("Z", "YC", "XC")), "X").values
         rec("stream", "same records one by one through the synchronous numpy-in/numpy-out path", (time.perf_counter() - t0) * 1e3,
             nr * nzs * ny * nx, 16)
+        from xgcm_amd.streaming import stream_blocks
+        got = []
+        t0 = time.perf_counter()
+        stream_blocks(diff_x, (host[r:r + 1] for r in range(nr)), sink=lambda k, res: got.append(res[0, 0, 0, 0]))
+        rec("stream", f"same records handed over as an ITERABLE of blocks (stream_blocks: read-ahead + staging through pinned buffers)",
+            (time.perf_counter() - t0) * 1e3, nr * nzs * ny * nx, 16)
         ok = bool(np.array_equal(out[nr - 1], host[nr - 1] - np.roll(host[nr - 1], 1, axis=-1)))
         print(json.dumps({"config": "stream", "check": "last record == host - roll(host, 1) (periodic diff)", "ok": ok}), flush=True)
         del host, out, grid_s

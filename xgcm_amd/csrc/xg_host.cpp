@@ -174,20 +174,28 @@ template <typename R>
 int reduce1d(const R* in, R* out, const int64_t* shape, int ndim, int axis, int skipna, const R* w, const int64_t* ws) {
   if (!in || !out) return fail(XG_ERR_INVALID, "NULL array argument");
   if (w && !ws) return fail(XG_ERR_INVALID, "weight without strides");
-  if (skipna < 0 || skipna > 3) return fail(XG_ERR_INVALID, "skipna / count mode %d not in [0,3]", skipna);
+  if (skipna < 0 || skipna > 5) return fail(XG_ERR_INVALID, "skipna / count / mean mode %d not in [0,5]", skipna);
   View v;
   if (int rc = make_view(shape, ndim, axis, &v)) return rc;
+  // one sequential sum per output cell in the given mode (k = 0 .. n-1 in order: numpy's order over a non-last axis)
+  auto sum_in_mode = [&](int64_t o, int64_t x, int mode) -> R {
+    R acc = 0;
+    for (int64_t k = 0; k < v.n; ++k) {
+      R val = in[(o * v.n + k) * v.inner + x];
+      if (mode >= 2) val = (mode == 3 || val == val) ? R(1) : R(0);
+      if (w) val = val * w[strided_offset(shape, ws, ndim, axis, o, k, x)];
+      if (mode && val != val) val = 0;
+      acc = (k == 0) ? val : acc + val;
+    }
+    return acc;
+  };
   for (int64_t o = 0; o < v.outer; ++o)
     for (int64_t x = 0; x < v.inner; ++x) {
-      R acc = 0;
-      for (int64_t k = 0; k < v.n; ++k) {  // k = 0 .. n-1 in order (numpy's order over a non-last axis)
-        R val = in[(o * v.n + k) * v.inner + x];
-        if (skipna >= 2) val = (skipna == 3 || val == val) ? R(1) : R(0);
-        if (w) val = val * w[strided_offset(shape, ws, ndim, axis, o, k, x)];
-        if (skipna && val != val) val = 0;
-        acc = (k == 0) ? val : acc + val;
-      }
-      out[o * v.inner + x] = acc;
+      R res;
+      if (skipna == 4) res = sum_in_mode(o, x, 1) / sum_in_mode(o, x, 2);       // NaN-skipping weighted mean
+      else if (skipna == 5) res = sum_in_mode(o, x, 0) / sum_in_mode(o, x, 3);  // weighted mean, NaN propagates
+      else res = sum_in_mode(o, x, skipna);
+      out[o * v.inner + x] = res;
     }
   return XG_OK;
 }

@@ -416,12 +416,23 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
     mb = outer_off(g, mw, o) + inner_off(g, mw, x);
     ms = (V > 1) ? inner_off(g, mw, x + 1) - inner_off(g, mw, x) : 0;
   }
-  T acc = splat<T>(real(0));
+  T acc = splat<T>(real(0)), den = splat<T>(real(0));
   bool started = false;
+  const bool mean = skipna >= 4;  // weighted mean in ONE pass: numerator and denominator march together
   auto step = [&](int64_t k, T v) {
-    if (skipna >= 2) v = as_count(v, skipna);
-    if (HAS_W) v = v * ldm<T>(wgt, mb + k * mw.axis, ms);
-    if (skipna) v = nan0(v);
+    T wv = splat<T>(real(1));
+    if (HAS_W) wv = ldm<T>(wgt, mb + k * mw.axis, ms);
+    if (mean) {  // the two sums of modes 1 / 0 (numerator) and 2 / 3 (denominator), same order, same bits
+      T d = as_count(v, skipna == 4 ? 2 : 3);
+      if (HAS_W) { d = d * wv; v = v * wv; }
+      if (skipna == 4) v = nan0(v);
+      d = nan0(d);
+      den = started ? den + d : d;
+    } else {
+      if (skipna >= 2) v = as_count(v, skipna);
+      if (HAS_W) v = v * wv;
+      if (skipna) v = nan0(v);
+    }
     acc = started ? acc + v : v;
     started = true;
   };
@@ -457,7 +468,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
   }
   for (; k < n; ++k) step(k, ldg<T, NTL>(pin + k * inner));
   }
-  *reinterpret_cast<T*>(out + o * inner + x) = acc;
+  *reinterpret_cast<T*>(out + o * inner + x) = mean ? acc / den : acc;
 }
 
 // K4b: weighted sum along the CONTIGUOUS axis: one wave per row, lane-strided partial sums then
@@ -473,42 +484,62 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
   const real* prow = in + row * n;
   int64_t mb = 0;
   if (HAS_W) mb = outer_off(g, mw, row);
-  real acc = real(0);
+  const bool mean = skipna >= 4;  // weighted mean in one pass (numerator and denominator together)
+  const int nmode = mean ? (skipna == 4 ? 1 : 0) : skipna, dmode = skipna == 4 ? 2 : 3;
+  real acc = real(0), den = real(0);
+  // one input value and its weight -> numerator term (and, for the mean modes, the denominator term)
+  auto terms = [&](real v, real wv, real& num, real& dn) {
+    if (mean) {
+      dn = as_count(v, dmode);
+      if (HAS_W) dn = dn * wv;
+      dn = nan0(dn);
+    }
+    if (nmode >= 2) v = as_count(v, nmode);
+    if (HAS_W) v = v * wv;
+    if (nmode) v = nan0(v);
+    num = v;
+  };
   int64_t k0 = 0, lead = 0;
   if (VEC) {  // array 16-B aligned (host): 16-B loads between the row's first and last 16-B boundary, NV partial
               // sums per lane, two loads in flight; the <= NV-1 cells before / after go through the scalar loops
     lead = (NV - (int64_t)((row * (u64)n) % NV)) % NV;
-    dv a = splat<dv>(real(0));
+    dv a = splat<dv>(real(0)), ad = splat<dv>(real(0));
     const int64_t nvec = (n - lead) / NV;
     for (int64_t t = lane; t < nvec; t += WAVE) {
       const int64_t k = lead + t * NV;
       dv v = ntl ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + k)) : *reinterpret_cast<const dv*>(prow + k);
-      if (skipna >= 2) v = as_count(v, skipna);
-      if (HAS_W) v = v * ldm<dv>(wgt, mb + k * mw.axis, mw.axis);
-      if (skipna) v = nan0(v);
-      a = a + v;
+      dv wv = splat<dv>(real(1));
+      if (HAS_W) wv = ldm<dv>(wgt, mb + k * mw.axis, mw.axis);
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        real num, dn = real(0);
+        terms(v[c], wv[c], num, dn);
+        a[c] += num;
+        ad[c] += dn;
+      }
     }
 #pragma unroll
-    for (int c = 0; c < NV; ++c) acc += a[c];
+    for (int c = 0; c < NV; ++c) { acc += a[c]; den += ad[c]; }
     k0 = lead + nvec * NV;
     if (lane < lead) {  // the row's first cells, before its first 16-B boundary
-      real v = prow[lane];
-      if (skipna >= 2) v = as_count(v, skipna);
-      if (HAS_W) v = v * wgt[mb + lane * mw.axis];
-      if (skipna) v = nan0(v);
-      acc += v;
+      real num, dn = real(0);
+      terms(prow[lane], HAS_W ? wgt[mb + lane * mw.axis] : real(1), num, dn);
+      acc += num;
+      den += dn;
     }
   }
   for (int64_t k = k0 + lane; k < n; k += WAVE) {
-    real v = prow[k];
-    if (skipna >= 2) v = as_count(v, skipna);
-    if (HAS_W) v = v * wgt[mb + k * mw.axis];
-    if (skipna) v = nan0(v);
-    acc += v;
+    real num, dn = real(0);
+    terms(prow[k], HAS_W ? wgt[mb + k * mw.axis] : real(1), num, dn);
+    acc += num;
+    den += dn;
   }
 #pragma unroll
-  for (int d = WAVE / 2; d > 0; d >>= 1) acc += __shfl_down(acc, d, WAVE);
-  if (lane == 0) out[row] = acc;
+  for (int d = WAVE / 2; d > 0; d >>= 1) {
+    acc += __shfl_down(acc, d, WAVE);
+    den += __shfl_down(den, d, WAVE);
+  }
+  if (lane == 0) out[row] = mean ? acc / den : acc;
 }
 
 }  // namespace
@@ -600,7 +631,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
                     const real* w, const int64_t* w_strides, void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (w && !w_strides) return fail(XG_ERR_INVALID, "weight without strides");
-  if (skipna < 0 || skipna > 3) return fail(XG_ERR_INVALID, "skipna / count mode %d not in [0,3]", skipna);
+  if (skipna < 0 || skipna > 5) return fail(XG_ERR_INVALID, "skipna / count / mean mode %d not in [0,5]", skipna);
   Geo g; MIdx mw;
   int rc = build_geo(shape, ndim, axis, 1, w ? w_strides : nullptr, nullptr, &g, &mw, nullptr);
   if (rc) return rc;

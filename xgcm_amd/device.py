@@ -222,12 +222,13 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
     return out
 
 
-_REDUCE_MODE = {"valid": 2, "all": 3}
+_REDUCE_MODE = {"valid": 2, "all": 3, "mean_valid": 4, "mean_all": 5}
 
 
 def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
     """sum_k (x * w) along `axis`, axis removed (xg_reduce1d_f64).  `skipna` True / False, or the count modes
-    "valid" (sum of the weights of the non-NaN cells of x) / "all" (sum of the weights)."""
+    "valid" (sum of the weights of the non-NaN cells of x) / "all" (sum of the weights), or the weighted mean in
+    ONE pass over x: "mean_valid" = sum(x * w | valid) / sum(w | valid), "mean_all" = sum(x * w) / sum(w)."""
     lib = _hip.load()
     dt, sfx = _common(x, w)
     x = asdevice(x, dt)

@@ -698,8 +698,13 @@ class Grid:
             ones = _valid_mask(da) if skip else da._replace(data=_ones_like(da.data), coords=OrderedDict())
             den = (ones * weight).sum(dims, skipna=False)
         else:
-            # two passes over `da`, 8 B/cell each: sum(da * w) and sum(w over the valid cells) -- the weighting
-            # and the validity test ride inside the reduction kernel (reference: product, mask and sum arrays)
+            if len(dims) == 1:
+                # ONE pass over `da` (8 B/cell): sum(da * w) and sum(w over the valid cells) march together inside
+                # the reduction kernel and are divided there -- the same two sequential sums, the same IEEE division
+                # as the two-pass form below (reference: product, mask, two sum arrays and a quotient array)
+                out = self._weighted_reduce(da, weight, dims, "mean_valid" if skip else "mean_all")
+                return to_xarray(out) if was_xr else out
+            # several dims: sum(da * w) and sum(w over the valid cells), one reduction chain each
             num = self._weighted_reduce(da, weight, dims, skip)
             den = self._weighted_reduce(da, weight, dims, "valid" if skip else "all")
         out = num / den
