@@ -137,6 +137,13 @@ def test_long_strided_march_with_few_columns(dev, dtype):
     for skipna in (True, False):
         exp = R.integrate(a, 1, w, skipna)
         _eq(dev.tohost(dev.reduce1d(a, 1, w, skipna)), exp.astype(dtype) if exp.dtype != dtype else exp)
+    # metrics that vary along the lanes too (float32 marches with 8-byte lanes: two metric values per lane)
+    w2 = R.synthetic_metric((1, 300, 128), 90).astype(dtype)
+    m3 = R.synthetic_metric((3, 300, 128), 91).astype(dtype)
+    _eq(dev.tohost(dev.cumsum1d(a, 1, 0, 0, 0, 0, None, 0.0, False, True, w2, m3)), R.cumsum1d(a, 1, 0, 0, 0, 0, None, 0.0, False, True, w2, m3))
+    _eq(dev.tohost(dev.reduce1d(a, 1, w2, True)), R.integrate(a, 1, w2, True).astype(dtype))
+    _eq(dev.tohost(dev.reduce1d(a, 1, w2, "mean_valid")),
+        (dev.tohost(dev.reduce1d(a, 1, w2, True)) / dev.tohost(dev.reduce1d(a, 1, w2, "valid"))).astype(dtype))
 
 
 def test_cumsum_metric(dev):

@@ -301,7 +301,7 @@ def main():
             rec(3, "derivative(T,'Y') / dyC(YG,XC)", timeit(lambda: grid.derivative(T, "Y"), a.reps), cells, 16 + 8 / nz)
             rec(3, "derivative(T,'Z') / drC(Zl)", timeit(lambda: grid.derivative(T, "Z"), a.reps), cells, 16)
             rec(3, "integrate(T,'Z') * drF(Z)", timeit(lambda: grid.integrate(T, "Z"), a.reps), cells, 8 + 8 / nz)
-            rec(3, "average(T,'Z') weighted by drF(Z): sum(T*w) and sum(w | T valid), two fused passes", timeit(lambda: grid.average(T, "Z"), a.reps), cells, 16 + 16 / nz)
+            rec(3, "average(T,'Z') weighted by drF(Z): sum(T*w) / sum(w | T valid) in ONE pass over T", timeit(lambda: grid.average(T, "Z"), a.reps), cells, 8 + 16 / nz)
         del T, grid
         torch.cuda.empty_cache()
     if "pcie" in cfgs:

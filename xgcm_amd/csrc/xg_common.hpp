@@ -289,6 +289,14 @@ int build_geo(const int64_t* shape, int ndim, int axis, int64_t n_out, const int
 template <int V> struct VecT;
 template <> struct VecT<1> { typedef real type; };
 template <> struct VecT<NV> { typedef dv type; };
+// the 8-byte lane of the long marches (few, long columns): one double, or TWO floats -- a float march with one
+// element per lane moves 256 B per wave and row, too narrow for the memory system (sum along Y f32: 55 % against
+// 80 % for f64); HV elements keep the bytes per wave-row the same in both builds
+constexpr int HV = 8 / (int)sizeof(real);
+#ifdef XG_F32
+typedef real hv __attribute__((ext_vector_type(2)));
+template <> struct VecT<2> { typedef hv type; };
+#endif
 
 template <typename T, bool NT>
 __device__ __forceinline__ T ldg(const real* p) {
@@ -351,6 +359,9 @@ __device__ __forceinline__ dv splat1(real f, dv*) {
   for (int k = 0; k < NV; ++k) o[k] = f;
   return o;
 }
+#ifdef XG_F32
+__device__ __forceinline__ hv splat1(real f, hv*) { hv o; o[0] = f; o[1] = f; return o; }
+#endif
 template <typename T> __device__ __forceinline__ T splat(real f) { return splat1(f, (T*)nullptr); }
 
 // offset of flat outer index `o` in a metric (unrolled so Geo/MIdx stay in SGPRs)
@@ -427,6 +438,14 @@ __device__ __forceinline__ int64_t inner_offx(const Geo& g, const MIdx& m, int64
 // metric value(s) for a V-wide lane at metric offset `off` (second element `step` further on)
 template <typename T> __device__ __forceinline__ T ldm(const real* m, int64_t off, int64_t step);
 template <> __device__ __forceinline__ real ldm<real>(const real* m, int64_t off, int64_t) { return m[off]; }
+#ifdef XG_F32
+template <> __device__ __forceinline__ hv ldm<hv>(const real* m, int64_t off, int64_t step) {
+  hv o;
+  o[0] = m[off];
+  o[1] = m[off + step];
+  return o;
+}
+#endif
 template <> __device__ __forceinline__ dv ldm<dv>(const real* m, int64_t off, int64_t step) {
   // metric contiguous along the lanes and 16-B aligned here: one dwordx4 load instead of NV narrow ones
   if (step == 1 && (((reinterpret_cast<uintptr_t>(m) / sizeof(real)) + (uintptr_t)off) & (NV - 1)) == 0)

@@ -23,10 +23,16 @@ __device__ __forceinline__ dv nan0(dv v) {
   return o;
 }
 
+#ifdef XG_F32
+__device__ __forceinline__ hv nan0(hv v) { hv o; o[0] = nan0(v[0]); o[1] = nan0(v[1]); return o; }
+#endif
 // reduction input modes beyond plain / NaN-skipping sums (xg_reduce1d `skipna` argument):
 // 2: every valid (non-NaN) cell counts as 1, NaN cells as 0 -> sum of the weights of the valid cells,
 // 3: every cell counts as 1 -> sum of the weights (the two denominators of a weighted mean)
 __device__ __forceinline__ real as_count(real v, int mode) { return (mode == 3 || v == v) ? real(1) : real(0); }
+#ifdef XG_F32
+__device__ __forceinline__ hv as_count(hv v, int mode) { hv o; o[0] = as_count(v[0], mode); o[1] = as_count(v[1], mode); return o; }
+#endif
 __device__ __forceinline__ dv as_count(dv v, int mode) {
   dv o;
 #pragma unroll
@@ -596,7 +602,7 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
     // few, long columns (cumsum along Y of (Z,Y,X): ~2k wave-tasks for 1024 SIMDs): one element per
     // lane doubles (f64) / quadruples (f32) the number of independent marches
     const bool long_march = g.n_in >= 256;
-    if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = 1;
+    if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = HV;  // 8-byte lanes
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
     const u64 ntask = (u64)ntile * (u64)g.outer;
     const u64 nblocks = tune().march_band ? (((ntask + WPB - 1) / WPB + 7) / 8) * 8 : (ntask + WPB - 1) / WPB;
@@ -616,6 +622,9 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
 #define XG_M(V_, M) do { if (pipe == 32) XG_PL(V_, M, 32); else if (pipe == 24) XG_PL(V_, M, 24); else if (pipe == 16) XG_PL(V_, M, 16); else if (pipe == 8) XG_PL(V_, M, 8); \
                          else if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
 #define XG_V(V_) switch (met) { case 0: XG_M(V_, 0); break; case 1: XG_M(V_, 1); break; case 2: XG_M(V_, 2); break; default: XG_M(V_, 3); }
+#ifdef XG_F32
+    if (V == HV) { XG_V(HV) } else
+#endif
     if (V > 1) { XG_V(NV) } else { XG_V(1) }
 #undef XG_V
 #undef XG_M
@@ -652,7 +661,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
   } else {
     int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, w != nullptr)) ? NV : 1;
     const bool long_march = g.n_in >= 256;
-    if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = 1;
+    if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = HV;  // 8-byte lanes
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
     const u64 ntask = (u64)ntile * (u64)g.outer;
     const u64 nblocks = tune().march_band ? (((ntask + WPB - 1) / WPB + 7) / 8) * 8 : (ntask + WPB - 1) / WPB;
@@ -665,6 +674,9 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
 #define XG_PL(V_, W_, U_) hipLaunchKernelGGL((k_reduce_strided<V_, W_, true, U_, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, tune().march_band)
 #define XG_GO(V_, W_) do { if (pipe == 32) XG_PL(V_, W_, 32); else if (pipe == 24) XG_PL(V_, W_, 24); else if (pipe == 16) XG_PL(V_, W_, 16); else if (pipe == 8) XG_PL(V_, W_, 8); \
                            else if (tune().nt_load) XG_GL(V_, W_, true); else XG_GL(V_, W_, false); } while (0)
+#ifdef XG_F32
+    if (V == HV) { if (w) XG_GO(HV, true); else XG_GO(HV, false); } else
+#endif
     if (V > 1) { if (w) XG_GO(NV, true); else XG_GO(NV, false); }
     else { if (w) XG_GO(1, true); else XG_GO(1, false); }
 #undef XG_GO
