@@ -66,6 +66,13 @@ def _worker(rank, world, port, tmp):
         c = grid.cumsum(mine, "Z").values
         np.save(os.path.join(tmp, f"diff_{rank}.npy"), d)
         np.save(os.path.join(tmp, f"cumsum_{rank}.npy"), c)
+        # the same through the batch loop of the product: two records per resident batch
+        from xgcm_amd.sharding import Ranks, map_record_batches
+
+        parts = map_record_batches(lambda blk: grid.cumsum(DataArray(blk, ("time", "Z", "YC", "XC")), "Z").values,
+                                   lambda a, b: full[a:b], nt, Ranks(rank, world, rank, "gloo", dist), full[0].nbytes * 2, per_batch=2)
+        assert [p[:2] for p in parts][0][0] == lo and parts[-1][1] == hi and all(p[1] - p[0] <= 2 for p in parts)
+        assert np.array_equal(np.concatenate([p[2] for p in parts], axis=0), c)
         # scalar reductions only: checksum (order-independent integer sum) and the timing aggregate
         chk = torch.tensor([int(np.frombuffer(d.tobytes(), dtype=np.uint64).sum() % (1 << 50))], dtype=torch.int64)
         dist.all_reduce(chk, op=dist.ReduceOp.SUM)

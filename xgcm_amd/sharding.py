@@ -256,6 +256,28 @@ def record_batches(n_records: int, world: int, rank: int, per_batch: int):
     return [(s, min(s + per_batch, hi)) for s in range(lo, hi, per_batch)]
 
 
+def map_record_batches(fn, load, n_records: int, ranks: "Ranks", bytes_per_record: int, per_batch: Optional[int] = None,
+                       sink=None, headroom: float = 0.8):
+    """The record-axis shard of a job, as a loop: this rank's block of `n_records` (`shard_bounds`) is walked in
+    HBM-resident batches; per batch `load(start, stop)` brings the records in (an HBM tensor, or a host array that
+    the operators upload), `fn(block)` runs the `Grid` operators, `sink(start, stop, result)` takes the result
+    (default: results are collected and returned as a list of `(start, stop, result)`).  No data-path collective:
+    the reference's `dask="parallelized"` independence over broadcast dims (xgcm/grid.py:786-789).  The batch size
+    is agreed across the ranks (minimum of `records_per_batch` over the ranks) so that rounds line up for callers
+    that put barriers around them."""
+    lo, hi = shard_bounds(n_records, ranks.world, ranks.rank)
+    per = per_batch or records_per_batch(hi - lo, bytes_per_record, headroom=headroom)
+    per = max(1, int(ranks.min(per)))
+    out = []
+    for start, stop in record_batches(n_records, ranks.world, ranks.rank, per):
+        result = fn(load(start, stop))
+        if sink is not None:
+            sink(start, stop, result)
+        else:
+            out.append((start, stop, result))
+    return None if sink is not None else out
+
+
 # ----------------------------------------------------------------------------------------------
 # Sharding ALONG the operator's own axis (not needed by the BASELINE configs, which split an outer
 # axis): the one data-path exchange the hot path can have.  It is the analogue of the reference's
