@@ -71,3 +71,16 @@ def test_the_other_1d_operators_through_the_host_abi(host_abi):
         host_abi.stencil1d("diff", T, 2, 1, 0, None)
     with pytest.raises(_hip.XgcmHipError, match="not part of the host build"):
         grid.vorticity(DataArray(T, ("Z", "YC", "XG")), DataArray(T, ("Z", "YG", "XC")), metric_weighted=False)
+
+
+def test_host_build_knows_the_device_librarys_tunables():
+    """same names in both builds (a binding written against one works against the other); unknown names are errors"""
+    import re as _re
+
+    names = _re.findall(r'\{"(\w+)", &Tune::', open(os.path.join(ROOT, "xgcm_amd", "csrc", "xg_runtime.hip")).read())
+    lib = ctypes.CDLL(os.path.join(ROOT, "xgcm_amd", "libxgcm_host.so"))
+    v = ctypes.c_int(-1)
+    for n in names:
+        assert lib.xg_set_tunable(n.encode(), 7) == 0 and lib.xg_get_tunable(n.encode(), ctypes.byref(v)) == 0 and v.value == 7
+        assert _hip.get_tunable(n) is not None  # and the device library knows it too
+    assert lib.xg_set_tunable(b"no_such_knob", 1) != 0

@@ -277,9 +277,16 @@ int fill_synthetic(R* out, int64_t n, uint64_t seed, uint64_t offset, double sca
   return XG_OK;
 }
 
-// tunables: accepted and remembered so that bindings can be exercised; they have no effect on the host loops
-struct Knob { char name[32]; int value; };
-std::vector<Knob>& knobs() { static std::vector<Knob> k; return k; }
+// tunables: the names of the device library (xg_runtime.hip::TUNABLES), accepted and remembered so that bindings
+// can be exercised; they have no effect on the host loops
+const char* const KNOWN_TUNABLES[] = {"seg", "nt_store", "nt_load", "seg_max_tiles", "scan_narrow_below", "pad_rows", "transform_lds_kb", "transform_win", "transform_fast", "zchunk", "zband", "zb_rows", "scan_block", "strided_gen", "march_band", "scan_vec", "contig_gen", "deep_waves", "contig_rw", "rw_zshare", "met_zk", "vec_zk", "contig_rw_mi", "met_seg", "scan_pipe", "scan_u", "scan_pace", "dbg", "march_lds_kb"};
+struct Knob { const char* name; int value; bool set; };
+std::vector<Knob>& knobs() {
+  static std::vector<Knob> k;
+  if (k.empty())
+    for (const char* n : KNOWN_TUNABLES) k.push_back({n, 0, false});
+  return k;
+}
 
 }  // namespace
 
@@ -296,14 +303,10 @@ int xg_last_error(char* buf, int n) {
   return len;
 }
 int xg_set_tunable(const char* name, int value) {
-  if (!name || !*name || strlen(name) >= 32) return fail(XG_ERR_INVALID, "bad tunable name");
+  if (!name) return fail(XG_ERR_INVALID, "NULL tunable name");
   for (auto& k : knobs())
-    if (!strcmp(k.name, name)) { k.value = value; return XG_OK; }
-  Knob k;
-  snprintf(k.name, sizeof(k.name), "%s", name);
-  k.value = value;
-  knobs().push_back(k);
-  return XG_OK;
+    if (!strcmp(k.name, name)) { k.value = value; k.set = true; return XG_OK; }
+  return fail(XG_ERR_INVALID, "unknown tunable '%s'", name);
 }
 int xg_get_tunable(const char* name, int* value) {
   if (!name || !value) return fail(XG_ERR_INVALID, "NULL argument");
