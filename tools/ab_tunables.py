@@ -43,6 +43,7 @@ def main():
         "iXmw": (lambda: D.stencil1d("interp", T, 2, 1, 0, "periodic", m_in=dx2, m_out=dx), 16 + 16 / nz),
         "iYmw": (lambda: D.stencil1d("interp", T, 1, 1, 0, "extend", m_in=dx2, m_out=dx), 16 + 16 / nz),
         "divT": (lambda: D.binary("div", T, dx), 16 + 8 / nz),
+        "mulTT": (lambda: D.binary("mul", T, T2), 24),
         "cumY": (lambda: D.cumsum1d(T, 1, 0, 1, 1, 0, "fill"), 16),
         "cumZ": (lambda: D.cumsum1d(T, 0, 0, 1, 1, 0, "fill"), 16),
         "cumX": (lambda: D.cumsum1d(T, 2, 0, 1, 1, 0, "fill"), 16),
@@ -51,6 +52,7 @@ def main():
         "vort": (lambda: D.vorticity(U, V, dx, "fill", "fill"), 24 + 8 / nz),
     }
     cases = a.cases.split(",")
+    T2 = D.synthetic((nz, ny, nx), 9) if "mulTT" in cases else None
     if any(c.startswith("t") and c[1:4] in ("lin", "con") for c in cases):
         # vertical transform of the field onto 50 levels / bins (tools/bench_configs.py --configs f4): theta =
         # running sum of positive random increments ("rw") or a smooth stratification ("sm")

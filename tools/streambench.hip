@@ -266,7 +266,35 @@ __global__ __launch_bounds__(256) void k_writeonly(d2* __restrict__ out, size_t 
   st<NTS>(out + i, v);
 }
 
+// three streams (two reads, one write), one 16-B vector of each per thread: the shape of `a * b`, of the fused
+// vorticity (u, v -> zeta) and of every kernel that carries a full-size second operand
+template <bool NTL, bool NTS, bool REMAP, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_triad(const d2* __restrict__ a, const d2* __restrict__ b, d2* __restrict__ out, size_t nvec, unsigned nblk) {
+  unsigned blk = blockIdx.x;
+  if (REMAP) { unsigned per = (nblk + 7) / 8; blk = (blk % 8) * per + blk / 8; if (blk >= nblk) return; }
+  size_t i = (size_t)blk * BLOCK + threadIdx.x;
+  if (i >= nvec) return;
+  d2 x = ld<NTL>(a + i), y = ld<NTL>(b + i);
+  d2 o; o.x = x.x * y.x; o.y = x.y * y.y;
+  st<NTS>(out + i, o);
+}
+
 int main() {
+  if (getenv("SB_TRIAD")) {
+    const size_t n = 75ull * 2400 * 3600, nvec = n / 2;
+    double *a, *b, *o;
+    CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMalloc(&o, n * 8));
+    hipLaunchKernelGGL(k_rand, dim3(8192), dim3(256), 0, 0, a, n); hipLaunchKernelGGL(k_rand, dim3(8192), dim3(256), 0, 0, b, n); CK(hipDeviceSynchronize());
+    auto rep3 = [&](const char* name, float ms) { printf("%-52s %8.4f ms  %8.1f GB/s  %.3f of 8TB/s (24 B per pair of cells)\n", name, ms, 3.0 * n * 8 / ms / 1e6, 3.0 * n * 8 / ms / 1e6 / 8000); fflush(stdout); };
+#define TRIAD(NTL, NTS, REMAP, BLOCK) { unsigned nblk = (unsigned)((nvec + BLOCK - 1) / BLOCK); unsigned grid = REMAP ? ((nblk + 7) / 8) * 8 : nblk; \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_triad<NTL, NTS, REMAP, BLOCK>), dim3(grid), dim3(BLOCK), 0, 0, (const d2*)a, (const d2*)b, (d2*)o, nvec, nblk); }, 12); \
+    rep3("triad ntl=" #NTL " nts=" #NTS " banded=" #REMAP " blk=" #BLOCK, ms); }
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      TRIAD(false, false, false, 256) TRIAD(false, true, false, 256) TRIAD(true, true, false, 256) TRIAD(true, true, true, 256)
+      TRIAD(false, true, true, 256) TRIAD(true, true, false, 64) TRIAD(true, true, false, 128) TRIAD(true, true, false, 512) TRIAD(true, true, false, 1024)
+    }
+    return 0;
+  }
   const size_t n = 75ull * 2400 * 3600;  // doubles
   const size_t nvec = n / 2;
   double *in, *out;

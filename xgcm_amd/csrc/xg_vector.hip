@@ -29,11 +29,17 @@ template <int BOP> __device__ __forceinline__ real bin2(real a, real b) {
   return a - b;
 }
 
+// `nta` / `ntb`: the operand is streamed exactly once (no broadcast dim) => non-temporal loads; together with the
+// XCD-banded block order that is worth 4 points on a three-stream kernel (tools/streambench.hip SB_TRIAD: 75.4 %
+// plain, 77.8 % with non-temporal loads, 79.1 % banded as well)
 template <int BOP, int V, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, const real* __restrict__ b,
-                                                  real* __restrict__ out, BinGeo g, ZBand zb) {
+                                                  real* __restrict__ out, BinGeo g, ZBand zb, u32 nblk, int nta, int ntb) {
   typedef typename VecT<V>::type T;
-  int64_t gid = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  int64_t gid = (int64_t)lb * BLOCK + threadIdx.x;
   if (zb.on) {
     // (Z, P) items with one operand broadcast along Z (da / dx(Y,X)): band-major order keeps the
     // band of the small operand in L2 while all Z levels of the band stream by (as in K1 / K2S)
@@ -59,12 +65,12 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, co
   const int64_t sa_in = g.sa[g.ndim - 1], sb_in = g.sb[g.ndim - 1];
   if (V > 1) {
     dv av, bv, o;
-    if (sa_in == 1) av = *reinterpret_cast<const dv*>(a + oa);
+    if (sa_in == 1) av = nta ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(a + oa)) : *reinterpret_cast<const dv*>(a + oa);
     else {
 #pragma unroll
       for (int k = 0; k < NV; ++k) av[k] = a[oa + k * sa_in];
     }
-    if (sb_in == 1) bv = *reinterpret_cast<const dv*>(b + ob);
+    if (sb_in == 1) bv = ntb ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(b + ob)) : *reinterpret_cast<const dv*>(b + ob);
     else {
 #pragma unroll
       for (int k = 0; k < NV; ++k) bv[k] = b[ob + k * sb_in];
@@ -108,12 +114,15 @@ __device__ __forceinline__ int64_t area_outer_off(const AreaIdx& ai, int64_t o) 
 // ZK > 1 (z-banded launches only): the wave carries the same rows of ZK consecutive levels and loads the area
 // rows once for all of them -- L2-resident metric rows still compete with the field loads for the CU's
 // outstanding requests (measured on the 1-D kernels: derivative along X 74.8 -> 77.3 % with shared rows).
+__device__ __forceinline__ real vec_last(dv v) { return v[NV - 1]; }
+__device__ __forceinline__ real vec_last(real v) { return v; }
+
 template <int V, bool HAS_AREA, bool NTS, int SEG, int ZK = 1>
 __global__ __launch_bounds__(BLOCK) void k_vorticity(
     const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ area,
     real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile,
     FastDiv nseg, ZBand zb, int bc_x, real fill_x, int bc_y, real fill_y, AreaIdx ai, int64_t a_sy,
-    int64_t a_sx, const real* __restrict__ halo_x, const real* __restrict__ halo_y) {
+    int64_t a_sx, const real* __restrict__ halo_x, const real* __restrict__ halo_y, int ntl) {
   typedef typename VecT<V>::type T;
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
@@ -157,15 +166,28 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
         src = pu + ((bc_y == XG_BC_PERIODIC) ? ny - 1 : 0) * nx;
         if (bc_y == XG_BC_HALO) src = halo_y + ok * nx + i0;  // pre-gathered row below the first one: (outer, 1, X)
       }
-      uu[kz][0] = *reinterpret_cast<const T*>(src);
+      uu[kz][0] = *reinterpret_cast<const T*>(src);  // the previous segment's last row: an L2 hit
     }
 #pragma unroll
     for (int s_ = 0; s_ < SEG; ++s_) {
       const int64_t jr = (s_ < nrow) ? s_ : nrow - 1;  // clamp inside the array for short tails
-      uu[kz][s_ + 1] = *reinterpret_cast<const T*>(pu + (j0 + jr) * nx);
-      vv[kz][s_] = *reinterpret_cast<const T*>(pv + jr * nx + i0);
-      vl[kz][s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[ok * ny + j0 + jr]  // pre-gathered column left of the first: (outer, Y, 1)
-                                                : pv[jr * nx + nidx];
+      // rows nobody reads again stream past the caches (non-temporal); the segment's LAST u row is the next
+      // segment's halo row and the v row carries the 8-byte neighbour loads, so those stay ordinary loads
+      if (ntl && s_ + 1 < SEG) uu[kz][s_ + 1] = __builtin_nontemporal_load(reinterpret_cast<const T*>(pu + (j0 + jr) * nx));
+      else uu[kz][s_ + 1] = *reinterpret_cast<const T*>(pu + (j0 + jr) * nx);
+      if (V > 1 && ntl) {
+        // the v row is read by this wave only: non-temporal, and the value left of a lane's vector comes from
+        // the lane before it (lanes that left at the row's end are the highest ones); lane 0 loads its own
+        vv[kz][s_] = __builtin_nontemporal_load(reinterpret_cast<const T*>(pv + jr * nx + i0));
+        real left = __shfl_up(vec_last(vv[kz][s_]), 1, WAVE);
+        if ((threadIdx.x & 63) == 0 || edge)
+          left = (edge && bc_x == XG_BC_HALO) ? halo_x[ok * ny + j0 + jr] : pv[jr * nx + nidx];
+        vl[kz][s_] = left;
+      } else {
+        vv[kz][s_] = *reinterpret_cast<const T*>(pv + jr * nx + i0);
+        vl[kz][s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[ok * ny + j0 + jr]  // pre-gathered column left of the first: (outer, Y, 1)
+                                                  : pv[jr * nx + nidx];
+      }
     }
   }
   if (HAS_AREA) {
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void k_divergence(
     const real* __restrict__ u, const real* __restrict__ v, const real* __restrict__ area,
     real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile,
     FastDiv nseg, ZBand zb, int bc_x, real fill_x, int bc_y, real fill_y, AreaIdx ai, int64_t a_sy,
-    int64_t a_sx, const real* __restrict__ halo_x, const real* __restrict__ halo_y) {
+    int64_t a_sx, const real* __restrict__ halo_x, const real* __restrict__ halo_y, int ntl) {
   typedef typename VecT<V>::type T;
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
@@ -426,10 +448,14 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
   }
   const u64 nblocks = (nitems + BLOCK - 1) / BLOCK;
   int rc;
-  if ((rc = check_grid(nblocks))) return rc;
+  if ((rc = check_grid(nblocks + 8))) return rc;
+  const u32 grid = (u32)(((nblocks + 7) / 8) * 8);  // XCD-banded block order
+  // an operand without a broadcast dim is read exactly once: stream it past the caches
+  auto streamed_once = [&](const int64_t* st_) { for (int d = 0; d < n; ++d) if (st_[d] == 0 && g.shape[d] > 1) return 0; return 1; };
+  const int nta = tune().nt_load && streamed_once(g.sa), ntb = tune().nt_load && streamed_once(g.sb);
   hipStream_t st = (hipStream_t)stream;
   const bool nts = tune().nt_store;
-#define XG_GO(O, V_, NTS) hipLaunchKernelGGL((k_binary<O, V_, NTS>), dim3((u32)nblocks), dim3(BLOCK), 0, st, a, b, out, g, zb)
+#define XG_GO(O, V_, NTS) hipLaunchKernelGGL((k_binary<O, V_, NTS>), dim3(grid), dim3(BLOCK), 0, st, a, b, out, g, zb, (u32)nblocks, nta, ntb)
 #define XG_O(O) do { if (V > 1) { if (nts) XG_GO(O, NV, true); else XG_GO(O, NV, false); } else { if (nts) XG_GO(O, 1, true); else XG_GO(O, 1, false); } } while (0)
   switch (op) { case XG_BIN_MUL: XG_O(XG_BIN_MUL); break; case XG_BIN_DIV: XG_O(XG_BIN_DIV); break; case XG_BIN_ADD: XG_O(XG_BIN_ADD); break; default: XG_O(XG_BIN_SUB); }
 #undef XG_O
@@ -509,8 +535,8 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
     const u64 waves = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * zgroups * ntile : (u64)nouter * per_outer;
     const u32 nblk = (u32)((waves + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GZ(V_, A_, NTS, ZK_) do { if (div) hipLaunchKernelGGL((k_divergence<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y); \
-                                else hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y); } while (0)
+#define XG_GZ(V_, A_, NTS, ZK_) do { if (div) hipLaunchKernelGGL((k_divergence<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y, tune().nt_load); \
+                                else hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y, tune().nt_load); } while (0)
 #define XG_GO(V_, A_, NTS) XG_GZ(V_, A_, NTS, 1)
 #define XG_A(V_, A_) do { if (nts) XG_GO(V_, A_, true); else XG_GO(V_, A_, false); } while (0)
     if (zk == 4) XG_GZ(NV, true, true, 4);
