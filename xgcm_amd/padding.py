@@ -308,24 +308,21 @@ def _pad_fold(data, grid, padding_width, padding, fill_value, halo_only=None) ->
 # face connections (reference padding.py:260-572)
 # ------------------------------------------------------------------------------------------
 def _infer_vector_component_axis(grid, da) -> str:
-    """The single axis on which a bare vector component is edge-staggered (padding.py:229-257)."""
-    edge_axes = []
-    for axname, axis in grid.axes.items():
-        try:
-            position, _ = axis._get_position_name(da)
-        except KeyError:
-            continue
-        if position != "center":
-            edge_axes.append(axname)
-    if len(edge_axes) == 1:
-        return edge_axes[0]
-    raise ValueError(
-        "Could not unambiguously infer the axis of the vector component being "
-        f"padded from its staggered position (edge axes found: {edge_axes}). "
-        "Pass the component as a `{axis_name: DataArray}` dict so its "
-        "orientation is explicit, e.g. "
-        "`pad({'Y': v}, ..., other_component={'X': u})`."
-    )
+    """Which axis does a bare vector component point along?  A C-grid component sits on cell EDGES along its own
+    axis and in cell centres along the others, so the answer is the one axis that contributes a non-centre dim to
+    `da` (the rule of the reference's helper of the same name, padding.py:229-257; its error text is kept)."""
+    present = set(da.dims)
+    edge_axes = [name for name, axis in grid.axes.items()
+                 if any(dim in present for position, dim in axis.coords.items() if position != "center")]
+    if len(edge_axes) != 1:
+        raise ValueError(
+            "Could not unambiguously infer the axis of the vector component being "
+            f"padded from its staggered position (edge axes found: {edge_axes}). "
+            "Pass the component as a `{axis_name: DataArray}` dict so its "
+            "orientation is explicit, e.g. "
+            "`pad({'Y': v}, ..., other_component={'X': u})`."
+        )
+    return edge_axes[0]
 
 
 def _get_all_connection_axes(connections, facedim):
@@ -339,12 +336,10 @@ def _get_all_connection_axes(connections, facedim):
 
 def _pad_face_connections(da, grid, padding_width, padding, fill_value, other_component=None,
                           halo_only=None) -> DataArray:
-    facedim = grid._facedim
-    connections = grid._face_connections
-    if connections is None:
-        raise ValueError("Grid connections cannot be None")
-    if facedim is None:
-        raise ValueError("Face dimension cannot be None")
+    facedim, connections = grid._facedim, grid._face_connections
+    for what, value in (("Grid connections", connections), ("Face dimension", facedim)):
+        if value is None:
+            raise ValueError(f"{what} cannot be None")
 
     vectoraxis = None
     if isinstance(da, dict):
