@@ -122,3 +122,51 @@ def test_stream_blocks_through_the_grid_api():
 
     got = stream_blocks(cumsum_z, (a[i:i + 2] for i in range(0, nt, 2)))
     np.testing.assert_array_equal(got, R.grid_cumsum(a, 1, "center", "left", "fill"))
+
+
+@pytest.mark.gpu
+def test_large_host_arrays_are_streamed_blockwise(monkeypatch):
+    """numpy in -> numpy out above a size threshold goes block-wise through HBM with the copies overlapped
+    (device._streamed): same bits as the one-shot path, metrics sliced along the outermost dim when they have it"""
+    from xgcm_amd import device as dev
+
+    a = R.synthetic_field((7, 5, 6, 64), 31)
+    a[2, 1, 3, 5] = np.nan
+    m2 = R.synthetic_metric((1, 1, 6, 64), 32)          # broadcast along the block dim
+    m4 = R.synthetic_metric((7, 5, 6, 64), 33)          # has the block dim: sliced per block
+    one_shot = {
+        "diff": dev.tohost(dev.stencil1d("diff", a, 3, 1, 0, "periodic", 0.0, m4, m2)),
+        "interpY": dev.tohost(dev.stencil1d("interp", a, 2, 0, 1, "extend")),
+        "cumsum": dev.tohost(dev.cumsum1d(a, 1, 0, 1, 1, 0, "fill", 0.5, False, True, m2, m4)),
+        "reduce": dev.tohost(dev.reduce1d(a, 1, m4, True)),
+        "mean": dev.tohost(dev.reduce1d(a, 2, m2, "mean_valid")),
+    }
+    calls = []
+    from xgcm_amd import streaming
+    real = streaming.stream_records
+    monkeypatch.setattr(streaming, "stream_records", lambda *args, **kw: (calls.append(kw.get("block")), real(*args, **kw))[1])
+    monkeypatch.setattr(dev, "HOST_STREAM_MIN_BYTES", 1)
+    monkeypatch.setattr(dev, "HOST_STREAM_BLOCK_BYTES", 2 * a[0].nbytes)   # blocks of 2 records: 2 + 2 + 2 + 1
+    got = {
+        "diff": dev.stencil1d("diff", a, 3, 1, 0, "periodic", 0.0, m4, m2),
+        "interpY": dev.stencil1d("interp", a, 2, 0, 1, "extend"),
+        "cumsum": dev.cumsum1d(a, 1, 0, 1, 1, 0, "fill", 0.5, False, True, m2, m4),
+        "reduce": dev.reduce1d(a, 1, m4, True),
+        "mean": dev.reduce1d(a, 2, m2, "mean_valid"),
+    }
+    assert calls == [2] * 5
+    for k in one_shot:
+        assert isinstance(got[k], np.ndarray), k
+        np.testing.assert_array_equal(got[k], one_shot[k], err_msg=k)
+    np.testing.assert_array_equal(got["interpY"], R.stencil1d("interp", a, 2, 0, 1, "extend"))
+    # the operator's own axis outermost, or a device-resident input: never streamed
+    calls.clear()
+    dev.stencil1d("diff", a, 0, 1, 0, "periodic")
+    dev.stencil1d("diff", dev.asdevice(a), 3, 1, 0, "periodic")
+    assert calls == []
+    # and through the Grid API: host DataArray in, host DataArray out
+    ds = Dataset(coords={"XC": np.arange(64) + 0.5, "XG": np.arange(64) * 1.0})
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", autoparse_metadata=False)
+    out = grid.diff(DataArray(a, ("time", "Z", "Y", "XC")), "X")
+    assert calls == [2] and isinstance(out.data, np.ndarray)
+    np.testing.assert_array_equal(out.values, R.stencil1d("diff", a, 3, 1, 0, "periodic"))

@@ -133,10 +133,46 @@ def _prep_metric(m, dtype) -> Optional[torch.Tensor]:
     return None if m is None else asdevice(m, dtype)
 
 
+# ---- large HOST arrays: block-wise through HBM with the copies overlapped ------------------------------------
+# numpy in -> numpy out is the reference's normal case.  One synchronous pageable H2D, the kernel and one
+# synchronous D2H move a 1.4 GB field at ~8 GB/s; cutting it into blocks of the outermost dim (never the operator's
+# own axis here) and running them through xgcm_amd.streaming -- host memory page-locked in place, H2D of block k+1,
+# the kernel on block k and D2H of block k-1 on three HIP streams -- reaches ~30 GB/s each way, the PCIe rate.
+HOST_STREAM_MIN_BYTES = 256 << 20   # host arrays at least this large take the pipelined path
+HOST_STREAM_BLOCK_BYTES = 128 << 20  # target size of one block
+
+
+def _host_streamable(x, axis: int) -> bool:
+    return (isinstance(x, np.ndarray) and x.ndim >= 2 and axis % x.ndim != 0 and x.shape[0] >= 2
+            and x.dtype in (np.float32, np.float64) and x.nbytes >= HOST_STREAM_MIN_BYTES and torch.cuda.is_available())
+
+
+def _rows(m, sl):
+    """rows `sl` of a dim-aligned metric along the outermost dim (a metric broadcast there passes whole)"""
+    return m if m is None or m.shape[0] == 1 else m[sl]
+
+
+def _streamed(per_block, x: np.ndarray) -> np.ndarray:
+    """`per_block(block_tensor, rows_slice) -> HBM tensor` over consecutive blocks of the outermost dim of `x`"""
+    from .streaming import record_blocks, stream_records
+
+    x = np.ascontiguousarray(x)
+    block = max(1, int(HOST_STREAM_BLOCK_BYTES // max(1, x.nbytes // x.shape[0])))
+    spans = iter(record_blocks(x.shape[0], block))
+
+    def on_block(t):
+        a, b = next(spans)
+        return per_block(t, slice(a, b))
+
+    return stream_records(on_block, x, block=block)
+
+
 def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str], fill: float = 0.0,
               m_in=None, m_out=None) -> torch.Tensor:
     """Fused pad + diff/interp/min/max along `axis` (xg_stencil1d_f64)."""
     lib = _hip.load()
+    if _host_streamable(x, axis):  # a large host array: blocks of the outermost dim, copies overlapped with the kernel
+        return _streamed(lambda blk, sl: stencil1d(op, blk, axis, pad_lo, pad_hi, bc, fill, _rows(m_in, sl), _rows(m_out, sl)), x)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis = axis % x.dim()
@@ -193,6 +229,9 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
              fill: float = 0.0, reverse: bool = False, skipna: bool = True, m_in=None, m_out=None) -> torch.Tensor:
     """Prefix sum along `axis` with the Grid.cumsum trim/pad folded in (xg_cumsum1d_f64)."""
     lib = _hip.load()
+    if _host_streamable(x, axis):
+        return _streamed(lambda blk, sl: cumsum1d(blk, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, skipna,
+                                                  _rows(m_in, sl), _rows(m_out, sl)), x)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis = axis % x.dim()
@@ -230,6 +269,8 @@ def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
     "valid" (sum of the weights of the non-NaN cells of x) / "all" (sum of the weights), or the weighted mean in
     ONE pass over x: "mean_valid" = sum(x * w | valid) / sum(w | valid), "mean_all" = sum(x * w) / sum(w)."""
     lib = _hip.load()
+    if _host_streamable(x, axis):
+        return _streamed(lambda blk, sl: reduce1d(blk, axis, _rows(w, sl), skipna), x)
     dt, sfx = _common(x, w)
     x = asdevice(x, dt)
     axis = axis % x.dim()
