@@ -144,6 +144,17 @@ def test_long_strided_march_with_few_columns(dev, dtype):
     _eq(dev.tohost(dev.reduce1d(a, 1, w2, True)), R.integrate(a, 1, w2, True).astype(dtype))
     _eq(dev.tohost(dev.reduce1d(a, 1, w2, "mean_valid")),
         (dev.tohost(dev.reduce1d(a, 1, w2, True)) / dev.tohost(dev.reduce1d(a, 1, w2, "valid"))).astype(dtype))
+    # weights that do not depend on the outer index: four levels per wave share each weight load (K4z); 9 levels =
+    # two full groups and a short one, 4-D outer dims, every mode
+    b = _field((3, 3, 260, 64), 92, nan=True).astype(dtype)
+    wb = R.synthetic_metric((1, 1, 260, 64), 93).astype(dtype)
+    for skipna in (True, False):
+        _eq(dev.tohost(dev.reduce1d(b, 2, wb, skipna)), R.integrate(b, 2, wb, skipna).astype(dtype))
+    ones = (~np.isnan(b)).astype(dtype)
+    _eq(dev.tohost(dev.reduce1d(b, 2, wb, "valid")), R.integrate(ones, 2, wb, False).astype(dtype))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        _eq(dev.tohost(dev.reduce1d(b, 2, wb, "mean_valid")),
+            (R.integrate(b, 2, wb, True) / R.integrate(ones, 2, wb, False)).astype(dtype))
 
 
 def test_cumsum_metric(dev):

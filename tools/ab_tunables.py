@@ -49,10 +49,21 @@ def main():
         "cumX": (lambda: D.cumsum1d(T, 2, 0, 1, 1, 0, "fill"), 16),
         "sumY": (lambda: D.reduce1d(T, 1, None), 8),
         "sumZ": (lambda: D.reduce1d(T, 0, dz), 8 + 8 / nz),
+        "sumX": (lambda: D.reduce1d(T, 2, None), 8),
+        "sumXw": (lambda: D.reduce1d(T, 2, dx), 8 + 8 / nz),
+        "sumYw": (lambda: D.reduce1d(T, 1, dx), 8 + 8 / nz),
+        "sumYw1": (lambda: D.reduce1d(T, 1, dy1), 8),
+        "sumYw3": (lambda: D.reduce1d(T, 1, T3), 16),
+        "cumYw": (lambda: D.cumsum1d(T, 1, 0, 0, 0, 0, None, 0.0, False, True, dx, None), 16 + 8 / nz),
+        "cumXw": (lambda: D.cumsum1d(T, 2, 0, 0, 0, 0, None, 0.0, False, True, dx, None), 16 + 8 / nz),
+        "cumZw": (lambda: D.cumsum1d(T, 0, 0, 0, 0, 0, None, 0.0, False, True, dx, None), 16 + 8 / nz),
+        "sumZw2": (lambda: D.reduce1d(T, 0, dx), 8 + 8 / nz),
         "vort": (lambda: D.vorticity(U, V, dx, "fill", "fill"), 24 + 8 / nz),
     }
     cases = a.cases.split(",")
     T2 = D.synthetic((nz, ny, nx), 9) if "mulTT" in cases else None
+    dy1 = D.synthetic((1, ny, 1), 35, 0, 1000.0, 1000.0)
+    T3 = D.synthetic((nz, ny, nx), 10, 0, 1000.0, 1000.0) if "sumYw3" in cases else None
     if any(c.startswith("t") and c[1:4] in ("lin", "con") for c in cases):
         # vertical transform of the field onto 50 levels / bins (tools/bench_configs.py --configs f4): theta =
         # running sum of positive random increments ("rw") or a smooth stratification ("sm")

@@ -81,8 +81,11 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
   const int64_t shift = a.pad_lo - a.trim_lo;
   T acc = splat<T>(real(0)), c_first = splat<T>(real(0)), c_last = splat<T>(real(0));
   bool started = false;
-  auto step = [&](int64_t idx, T v) {
-    if (HAS_MI) v = v * ldm<T>(m_in, mi_base + idx * mi.axis, mi_step);
+  // the input metric of a row is loaded WITH the row (same window / batch): left inside `step` it was one
+  // dependent L2 round trip per row of the march (cumint along Y with dy(Y,X): 40 % of 8 TB/s)
+  auto ldw = [&](int64_t idx) -> T { return HAS_MI ? ldm<T>(m_in, mi_base + idx * mi.axis, mi_step) : splat<T>(real(1)); };
+  auto step = [&](int64_t idx, T v, T w) {
+    if (HAS_MI) v = v * w;
     if (a.skipna) v = nan0(v);
     acc = started ? acc + v : v;
     started = true;
@@ -93,41 +96,51 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
   int64_t t = 0;
   if (PIPE) {
     auto row = [&](int64_t k) -> int64_t { return a.reverse ? n - 1 - k : k; };  // k-th row in scan order
-    T v[U];
+    constexpr int UW = HAS_MI ? U : 1;
+    T v[U], wv[UW];
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (u < n) v[u] = ldg<T, NTL>(pin + row(u) * inner);
+      if (u < n) {
+        v[u] = ldg<T, NTL>(pin + row(u) * inner);
+        if (HAS_MI) wv[u % UW] = ldw(row(u));
+      }
     for (; t + 2 * U <= n; t += U) {  // steady state: consume row t + u, refill its slot with row t + U + u
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const T x = v[u];
+        const T x = v[u], xw = wv[u % UW];
         v[u] = ldg<T, NTL>(pin + row(t + U + u) * inner);
-        step(row(t + u), x);
+        if (HAS_MI) wv[u % UW] = ldw(row(t + U + u));
+        step(row(t + u), x, xw);
       }
       if (pace) __builtin_amdgcn_s_barrier();
     }
     for (; t < n; t += U) {  // the last one or two windows: refills and consumes guarded (wave-uniform tests)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const T x = v[u];
-        if (t + U + u < n) v[u] = ldg<T, NTL>(pin + row(t + U + u) * inner);
-        if (t + u < n) step(row(t + u), x);
+        const T x = v[u], xw = wv[u % UW];
+        if (t + U + u < n) {
+          v[u] = ldg<T, NTL>(pin + row(t + U + u) * inner);
+          if (HAS_MI) wv[u % UW] = ldw(row(t + U + u));
+        }
+        if (t + u < n) step(row(t + u), x, xw);
       }
     }
   } else {
   for (; t + U <= n; t += U) {
-    T v[U];
+    constexpr int UW = HAS_MI ? U : 1;
+    T v[U], wv[UW];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int64_t idx = a.reverse ? n - 1 - (t + u) : t + u;
       v[u] = ldg<T, NTL>(pin + idx * inner);
+      if (HAS_MI) wv[u % UW] = ldw(idx);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) step(a.reverse ? n - 1 - (t + u) : t + u, v[u]);
+    for (int u = 0; u < U; ++u) step(a.reverse ? n - 1 - (t + u) : t + u, v[u], wv[u % UW]);
   }
   for (; t < n; ++t) {
     int64_t idx = a.reverse ? n - 1 - t : t;
-    step(idx, ldg<T, NTL>(pin + idx * inner));
+    step(idx, ldg<T, NTL>(pin + idx * inner), ldw(idx));
   }
   }
   // halo cells of the padded cumulative result (xgcm/grid.py:1385-1391; numpy.pad semantics)
@@ -425,9 +438,9 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
   T acc = splat<T>(real(0)), den = splat<T>(real(0));
   bool started = false;
   const bool mean = skipna >= 4;  // weighted mean in ONE pass: numerator and denominator march together
-  auto step = [&](int64_t k, T v) {
-    T wv = splat<T>(real(1));
-    if (HAS_W) wv = ldm<T>(wgt, mb + k * mw.axis, ms);
+  // the weight of a row is loaded WITH the row (same window / batch), not inside `step` (see k_cumsum_strided)
+  auto ldw = [&](int64_t k) -> T { return HAS_W ? ldm<T>(wgt, mb + k * mw.axis, ms) : splat<T>(real(1)); };
+  auto step = [&](int64_t k, T v, T wv) {
     if (mean) {  // the two sums of modes 1 / 0 (numerator) and 2 / 3 (denominator), same order, same bits
       T d = as_count(v, skipna == 4 ? 2 : 3);
       if (HAS_W) { d = d * wv; v = v * wv; }
@@ -444,35 +457,47 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
   };
   int64_t k = 0;
   if (PIPE) {  // rolling window of U loads (see k_cumsum_strided)
-    T v[U];
+    constexpr int UW = HAS_W ? U : 1;
+    T v[U], wv[UW];
 #pragma unroll
     for (int u = 0; u < U; ++u)
-      if (u < n) v[u] = ldg<T, NTL>(pin + (int64_t)u * inner);
+      if (u < n) {
+        v[u] = ldg<T, NTL>(pin + (int64_t)u * inner);
+        if (HAS_W) wv[u % UW] = ldw(u);
+      }
     for (; k + 2 * U <= n; k += U) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const T x = v[u];
+        const T x = v[u], xw = HAS_W ? wv[u % UW] : splat<T>(real(1));
         v[u] = ldg<T, NTL>(pin + (k + U + u) * inner);
-        step(k + u, x);
+        if (HAS_W) wv[u % UW] = ldw(k + U + u);
+        step(k + u, x, xw);
       }
     }
     for (; k < n; k += U) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const T x = v[u];
-        if (k + U + u < n) v[u] = ldg<T, NTL>(pin + (k + U + u) * inner);
-        if (k + u < n) step(k + u, x);
+        const T x = v[u], xw = HAS_W ? wv[u % UW] : splat<T>(real(1));
+        if (k + U + u < n) {
+          v[u] = ldg<T, NTL>(pin + (k + U + u) * inner);
+          if (HAS_W) wv[u % UW] = ldw(k + U + u);
+        }
+        if (k + u < n) step(k + u, x, xw);
       }
     }
   } else {
   for (; k + U <= n; k += U) {
-    T v[U];
+    constexpr int UW = HAS_W ? U : 1;
+    T v[U], wv[UW];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = ldg<T, NTL>(pin + (k + u) * inner);
+    for (int u = 0; u < U; ++u) {
+      v[u] = ldg<T, NTL>(pin + (k + u) * inner);
+      if (HAS_W) wv[u % UW] = ldw(k + u);
+    }
 #pragma unroll
-    for (int u = 0; u < U; ++u) step(k + u, v[u]);
+    for (int u = 0; u < U; ++u) step(k + u, v[u], HAS_W ? wv[u % UW] : splat<T>(real(1)));
   }
-  for (; k < n; ++k) step(k, ldg<T, NTL>(pin + k * inner));
+  for (; k < n; ++k) step(k, ldg<T, NTL>(pin + k * inner), ldw(k));
   }
   *reinterpret_cast<T*>(out + o * inner + x) = mean ? acc / den : acc;
 }
@@ -482,8 +507,16 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
 template <bool HAS_W, bool VEC>
 __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict__ in,
                                                          real* __restrict__ out, Geo g, int skipna,
-                                                         const real* __restrict__ wgt, MIdx mw, int ntl) {
-  const u64 row = wave_id();
+                                                         const real* __restrict__ wgt, MIdx mw, int ntl, ZBand zb) {
+  u64 row = wave_id();
+  if (zb.on) {  // weights broadcast along the slow outer dim: all levels of a band of rows before the next band,
+                // so that the band's weight rows are served by the XCD's L2 (integrate along X with dx(Y,X): 48 %
+                // of 8 TB/s in level-major order, the weights re-read from the fabric once per level)
+    u32 z, y;
+    if (row >= (u64)zb.per_band.d * ((zb.Y + zb.B - 1) / zb.B)) return;
+    if (!zband_map(zb, (u32)row, z, y)) return;
+    row = (u64)z * zb.Y + y;
+  }
   if ((int64_t)row >= g.outer) return;
   const int lane = threadIdx.x & 63;
   const int64_t n = g.n_in;
@@ -613,7 +646,9 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
     // above: cumsum along Y f32 48 -> 55 %, sum along Y 59 -> 67 % f32 / 68 -> 71 % f64)
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
     // rolling-window variants exist for the default non-temporal loads + stores only; `pipe`: window length
-    const int su = tune().scan_u;
+    // window length: `scan_u` rows; with an input metric the window holds the metric values too (twice the registers:
+    // 32 rows -> 256 VGPRs, ONE wave per SIMD, cumint along Y 40 % of 8 TB/s) => 8 rows
+    const int su = (met & 2) ? (tune().scan_u < 8 ? tune().scan_u : 8) : tune().scan_u;
     const int pipe = (tune().scan_pipe && nts && tune().nt_load) ? (deep ? (su >= 32 ? 32 : su >= 24 ? 24 : su >= 16 ? 16 : 8) : (tune().scan_pipe >= 2 ? 8 : 0)) : 0;
 #define XG_PL(V_, M, U_) hipLaunchKernelGGL((k_cumsum_strided<V_, M, true, true, U_, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band | (tune().scan_pace << 1))
 #define XG_GL(V_, M, NTL_, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band | (tune().scan_pace << 1)); \
@@ -648,15 +683,26 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
   hipStream_t st = (hipStream_t)stream;
   if (g.n_in == 0) { XG_HIP(hipMemsetAsync(out, 0, sizeof(real) * g.outer * g.inner, st)); return XG_OK; }
   if (g.inner == 1) {
-    const u64 nblocks = ((u64)g.outer + WPB - 1) / WPB;
+    ZBand zb = make_zband(false, 0, 0, 1);
+    u64 nrows = (u64)g.outer;
+    if (w && tune().zband && g.n_outer == 2 && mw.outer[0] == 0 && g.outer_shape[0] >= 2) {
+      const u64 Z = (u64)g.outer_shape[0], Y = (u64)g.outer_shape[1];
+      const u32 B = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16) * 2u;  // one metric: double-height bands
+      const u64 padded = ((Y + B - 1) / B) * B * Z;
+      if (padded < 0x7fffffffull) {
+        zb = make_zband(true, Z, Y, B);
+        if (zb.on) nrows = padded;
+      }
+    }
+    const u64 nblocks = (nrows + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
     const bool vec = aligned16(in) && g.n_in >= 4 * NV;  // rows of any length: lead / tail cells go through scalar loads
     if (vec) {
-      if (w) hipLaunchKernelGGL((k_reduce_contig<true, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load);
-      else hipLaunchKernelGGL((k_reduce_contig<false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load);
+      if (w) hipLaunchKernelGGL((k_reduce_contig<true, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load, zb);
+      else hipLaunchKernelGGL((k_reduce_contig<false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load, zb);
     } else {
-      if (w) hipLaunchKernelGGL((k_reduce_contig<true, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load);
-      else hipLaunchKernelGGL((k_reduce_contig<false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load);
+      if (w) hipLaunchKernelGGL((k_reduce_contig<true, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load, zb);
+      else hipLaunchKernelGGL((k_reduce_contig<false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load, zb);
     }
   } else {
     int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, w != nullptr)) ? NV : 1;
@@ -667,11 +713,12 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     const u64 nblocks = tune().march_band ? (((ntask + WPB - 1) / WPB + 7) / 8) * 8 : (ntask + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
-#define XG_GL(V_, W_, NTL_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, tune().march_band); \
-                           else hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, tune().march_band); } while (0)
-    const int su = tune().scan_u;
+    const int rband = tune().march_band;
+#define XG_GL(V_, W_, NTL_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, rband); \
+                           else hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, rband); } while (0)
+    const int su = w ? (tune().scan_u < 8 ? tune().scan_u : 8) : tune().scan_u;  // weights ride in the window: 8 rows (registers)
     const int pipe = (tune().scan_pipe && tune().nt_load) ? (deep ? (su >= 32 ? 32 : su >= 24 ? 24 : su >= 16 ? 16 : 8) : (tune().scan_pipe >= 2 ? 8 : 0)) : 0;
-#define XG_PL(V_, W_, U_) hipLaunchKernelGGL((k_reduce_strided<V_, W_, true, U_, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, tune().march_band)
+#define XG_PL(V_, W_, U_) hipLaunchKernelGGL((k_reduce_strided<V_, W_, true, U_, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, rband)
 #define XG_GO(V_, W_) do { if (pipe == 32) XG_PL(V_, W_, 32); else if (pipe == 24) XG_PL(V_, W_, 24); else if (pipe == 16) XG_PL(V_, W_, 16); else if (pipe == 8) XG_PL(V_, W_, 8); \
                            else if (tune().nt_load) XG_GL(V_, W_, true); else XG_GL(V_, W_, false); } while (0)
 #ifdef XG_F32
