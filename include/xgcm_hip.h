@@ -127,7 +127,10 @@ int xg_cumsum1d_f64(const double* in, double* out, const int64_t* shape, int ndi
  * the valid (non-NaN) cells of `in`, 3 = sum of the weights of all cells -- and the mean itself, numerator
  * and denominator marching together so that `in` is read ONCE: 4 = (mode 1) / (mode 2), the NaN-skipping
  * weighted mean of Grid.average; 5 = (mode 0) / (mode 3).  Same sums in the same order as the separate
- * modes, one IEEE division at the end: bit-identical to computing the two sums apart and dividing. */
+ * modes, one IEEE division at the end: bit-identical to computing the two sums apart and dividing.
+ * 6 / 7 = the two sums of 4 / 5 written side by side instead of divided: `out` holds 2 N cells, numerators in
+ * out[0 : N], denominators in out[N : 2N] (N = cells of the reduced array) -- the first, full-size pass of a
+ * mean over SEVERAL dims; the caller reduces both halves over the remaining dims and divides. */
 int xg_reduce1d_f64(const double* in, double* out, const int64_t* shape, int ndim, int axis,
                     int skipna, const double* w, const int64_t* w_strides, void* stream);
 

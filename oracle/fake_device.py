@@ -49,6 +49,9 @@ def cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill=0.0, reverse=Fa
 
 def reduce1d(x, axis, w=None, skipna=True):
     x, w = _cast(_common(x, w), x, w)
+    if skipna in ("pair_valid", "pair_all"):  # numerator and denominator sums stacked along a new leading dim
+        valid = skipna == "pair_valid"
+        return np.stack([reduce1d(x, axis, w, valid), reduce1d(x, axis, w, "valid" if valid else "all")])
     if skipna in ("mean_valid", "mean_all"):  # the one-pass weighted mean == the two sums, divided
         valid = skipna == "mean_valid"
         return reduce1d(x, axis, w, valid) / reduce1d(x, axis, w, "valid" if valid else "all")

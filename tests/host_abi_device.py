@@ -121,10 +121,10 @@ def reduce1d(x, axis, w=None, skipna=True):
     axis %= x.ndim
     shape = list(x.shape)
     w = None if w is None else asdevice(w, dt)
-    out = np.empty(shape[:axis] + shape[axis + 1:], dtype=dt)
+    mode = {"valid": 2, "all": 3, "mean_valid": 4, "mean_all": 5, "pair_valid": 6, "pair_all": 7}.get(skipna, int(bool(skipna)))
+    out = np.empty(([2] if mode >= 6 else []) + shape[:axis] + shape[axis + 1:], dtype=dt)
     if out.size == 0:
         return out
-    mode = {"valid": 2, "all": 3, "mean_valid": 4, "mean_all": 5}.get(skipna, int(bool(skipna)))
     _check(getattr(lib(), "xg_reduce1d_" + sfx)(_ptr(x), _ptr(out), _hip.i64(shape), len(shape), axis, mode, _ptr(w),
                                                _hip.i64(_strides(w, shape, "w")), None))
     return out

@@ -205,6 +205,10 @@ def test_reduce(dev, shape):
                 for ww in (w, None):
                     two_pass = dev.tohost(dev.reduce1d(a, axis, ww, nmode)) / dev.tohost(dev.reduce1d(a, axis, ww, dmode))
                     _eq(dev.tohost(dev.reduce1d(a, axis, ww, mode)), two_pass)
+                    both = dev.tohost(dev.reduce1d(a, axis, ww, mode.replace("mean", "pair")))  # the two sums side by side
+                    assert both.shape == (2,) + two_pass.shape
+                    _eq(both[0], dev.tohost(dev.reduce1d(a, axis, ww, nmode)))
+                    _eq(both[1], dev.tohost(dev.reduce1d(a, axis, ww, dmode)))
                     if axis != nd - 1:
                         ones = (~np.isnan(a)).astype(a.dtype) if dmode == "valid" else np.ones_like(a)
                         _eq(two_pass, R.integrate(a, axis, ww, nmode) / R.integrate(ones, axis, ww, False))

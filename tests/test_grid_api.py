@@ -288,6 +288,47 @@ def test_integrate_with_a_weight_that_adds_dims(backend):
     assert np.allclose(out.values, want, rtol=1e-14, atol=0)
 
 
+def test_multi_axis_integrate_and_average_with_separable_metrics(backend):
+    """volume = area(Y, X) * thickness(Z): each factor rides in the reduction that removes its first dim, numerator
+    and denominator of the mean travel side by side -- same numbers as the reference's `(da * metric).sum(dims)` /
+    weighted mean (grid.py:1598-1605, :1662-1685) to rounding, NaN cells skipped"""
+    nz, ny, nx = 4, 5, 6
+    T = R.synthetic_field((nz, ny, nx), 61)
+    T[1, 2, 3] = np.nan
+    T[0, 0, :] = np.nan
+    rA, drF, dxT = R.synthetic_metric((ny, nx), 62), R.synthetic_metric((nz,), 63), R.synthetic_metric((ny, nx), 64)
+    ds = Dataset({"rA": (("YC", "XC"), rA), "drF": (("Z",), drF), "dxT": (("YC", "XC"), dxT)},
+                 coords={"XC": np.arange(nx) + 0.5, "XG": np.arange(nx) * 1.0, "YC": np.arange(ny) + 0.5, "YG": np.arange(ny) * 1.0,
+                         "Z": np.arange(nz) + 0.5, "Zl": np.arange(nz) * 1.0})
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}, "Z": {"center": "Z", "left": "Zl"}},
+                padding="fill", metrics={("X", "Y"): ["rA"], ("Z",): ["drF"], ("X",): ["dxT"]}, autoparse_metadata=False)
+    da = DataArray(T, ("Z", "YC", "XC"), name="T")
+    vol = rA[None] * drF[:, None, None]
+    valid = ~np.isnan(T)
+    T0 = np.where(valid, T, 0.0)
+    cases = {
+        ("X", "Y", "Z"): (vol, (0, 1, 2)), ("X", "Y"): (np.broadcast_to(rA, T.shape), (1, 2)),
+        ("Z", "X"): (np.broadcast_to(drF[:, None, None] * dxT[None], T.shape), (0, 2)),
+    }
+    for axes, (w, red) in cases.items():
+        got = grid.integrate(da, list(axes))
+        assert got.dims == tuple(d for i, d in enumerate(da.dims) if i not in red)
+        np.testing.assert_allclose(got.values, (T0 * w).sum(axis=red), rtol=1e-12)
+        avg = grid.average(da, list(axes))
+        with np.errstate(invalid="ignore"):
+            want = (T0 * w).sum(axis=red) / (w * valid).sum(axis=red)
+        np.testing.assert_allclose(avg.values, want, rtol=1e-12, equal_nan=True)
+        # NaN-propagating flavours
+        np.testing.assert_allclose(grid.integrate(da, list(axes), skipna=False).values, (T * w).sum(axis=red), rtol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(grid.average(da, list(axes), skipna=False).values, (T * w).sum(axis=red) / w.sum(axis=red),
+                                   rtol=1e-12, equal_nan=True)
+    # the public get_metric keeps xarray's dim order for a product; internally it is laid out like the weighted array
+    assert grid.get_metric(da, ("X", "Y", "Z")).dims == ("YC", "XC", "Z")
+    assert grid.get_metric(da, ("X", "Y", "Z"), _layout=da.dims).dims == ("Z", "YC", "XC")
+    np.testing.assert_array_equal(grid.get_metric(da, ("X", "Y", "Z"), _layout=da.dims).values,
+                                  np.transpose(grid.get_metric(da, ("X", "Y", "Z")).values, (2, 0, 1)))
+
+
 def test_vector_component_dict_input(backend):
     ds, coords, _ = cgrid()
     grid = Grid(ds, coords=coords, padding="periodic", autoparse_metadata=False)

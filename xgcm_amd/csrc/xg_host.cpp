@@ -174,7 +174,7 @@ template <typename R>
 int reduce1d(const R* in, R* out, const int64_t* shape, int ndim, int axis, int skipna, const R* w, const int64_t* ws) {
   if (!in || !out) return fail(XG_ERR_INVALID, "NULL array argument");
   if (w && !ws) return fail(XG_ERR_INVALID, "weight without strides");
-  if (skipna < 0 || skipna > 5) return fail(XG_ERR_INVALID, "skipna / count / mean mode %d not in [0,5]", skipna);
+  if (skipna < 0 || skipna > 7) return fail(XG_ERR_INVALID, "skipna / count / mean mode %d not in [0,7]", skipna);
   View v;
   if (int rc = make_view(shape, ndim, axis, &v)) return rc;
   // one sequential sum per output cell in the given mode (k = 0 .. n-1 in order: numpy's order over a non-last axis)
@@ -194,7 +194,10 @@ int reduce1d(const R* in, R* out, const int64_t* shape, int ndim, int axis, int 
       R res;
       if (skipna == 4) res = sum_in_mode(o, x, 1) / sum_in_mode(o, x, 2);       // NaN-skipping weighted mean
       else if (skipna == 5) res = sum_in_mode(o, x, 0) / sum_in_mode(o, x, 3);  // weighted mean, NaN propagates
-      else res = sum_in_mode(o, x, skipna);
+      else if (skipna >= 6) {  // numerator and denominator sums side by side
+        res = sum_in_mode(o, x, skipna == 6 ? 1 : 0);
+        out[(v.outer + o) * v.inner + x] = sum_in_mode(o, x, skipna == 6 ? 2 : 3);
+      } else res = sum_in_mode(o, x, skipna);
       out[o * v.inner + x] = res;
     }
   return XG_OK;

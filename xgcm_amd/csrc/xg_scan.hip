@@ -437,7 +437,11 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
   }
   T acc = splat<T>(real(0)), den = splat<T>(real(0));
   bool started = false;
-  const bool mean = skipna >= 4;  // weighted mean in ONE pass: numerator and denominator march together
+  // modes 4 / 5: weighted mean in ONE pass, numerator and denominator march together; 6 / 7: the same two sums
+  // written side by side (out[0 : N] numerators, out[N : 2N] denominators) for means over several dims
+  const bool pair = skipna >= 6;
+  if (pair) skipna -= 2;
+  const bool mean = skipna >= 4;
   // the weight of a row is loaded WITH the row (same window / batch), not inside `step` (see k_cumsum_strided)
   auto ldw = [&](int64_t k) -> T { return HAS_W ? ldm<T>(wgt, mb + k * mw.axis, ms) : splat<T>(real(1)); };
   auto step = [&](int64_t k, T v, T wv) {
@@ -499,7 +503,12 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
   }
   for (; k < n; ++k) step(k, ldg<T, NTL>(pin + k * inner), ldw(k));
   }
-  *reinterpret_cast<T*>(out + o * inner + x) = mean ? acc / den : acc;
+  if (pair) {
+    *reinterpret_cast<T*>(out + o * inner + x) = acc;
+    *reinterpret_cast<T*>(out + (g.outer + o) * inner + x) = den;
+  } else {
+    *reinterpret_cast<T*>(out + o * inner + x) = mean ? acc / den : acc;
+  }
 }
 
 // K4b: weighted sum along the CONTIGUOUS axis: one wave per row, lane-strided partial sums then
@@ -523,6 +532,8 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
   const real* prow = in + row * n;
   int64_t mb = 0;
   if (HAS_W) mb = outer_off(g, mw, row);
+  const bool pair = skipna >= 6;  // 6 / 7: numerator and denominator sums side by side (see k_reduce_strided)
+  if (pair) skipna -= 2;
   const bool mean = skipna >= 4;  // weighted mean in one pass (numerator and denominator together)
   const int nmode = mean ? (skipna == 4 ? 1 : 0) : skipna, dmode = skipna == 4 ? 2 : 3;
   real acc = real(0), den = real(0);
@@ -578,7 +589,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
     acc += __shfl_down(acc, d, WAVE);
     den += __shfl_down(den, d, WAVE);
   }
-  if (lane == 0) out[row] = mean ? acc / den : acc;
+  if (lane == 0) {
+    if (pair) { out[row] = acc; out[g.outer + row] = den; }
+    else out[row] = mean ? acc / den : acc;
+  }
 }
 
 }  // namespace
@@ -675,7 +689,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
                     const real* w, const int64_t* w_strides, void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (w && !w_strides) return fail(XG_ERR_INVALID, "weight without strides");
-  if (skipna < 0 || skipna > 5) return fail(XG_ERR_INVALID, "skipna / count / mean mode %d not in [0,5]", skipna);
+  if (skipna < 0 || skipna > 7) return fail(XG_ERR_INVALID, "skipna / count / mean mode %d not in [0,7]", skipna);
   Geo g; MIdx mw;
   int rc = build_geo(shape, ndim, axis, 1, w ? w_strides : nullptr, nullptr, &g, &mw, nullptr);
   if (rc) return rc;

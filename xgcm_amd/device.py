@@ -261,21 +261,24 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
     return out
 
 
-_REDUCE_MODE = {"valid": 2, "all": 3, "mean_valid": 4, "mean_all": 5}
+_REDUCE_MODE = {"valid": 2, "all": 3, "mean_valid": 4, "mean_all": 5, "pair_valid": 6, "pair_all": 7}
 
 
 def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
     """sum_k (x * w) along `axis`, axis removed (xg_reduce1d_f64).  `skipna` True / False, or the count modes
     "valid" (sum of the weights of the non-NaN cells of x) / "all" (sum of the weights), or the weighted mean in
-    ONE pass over x: "mean_valid" = sum(x * w | valid) / sum(w | valid), "mean_all" = sum(x * w) / sum(w)."""
+    ONE pass over x: "mean_valid" = sum(x * w | valid) / sum(w | valid), "mean_all" = sum(x * w) / sum(w);
+    "pair_valid" / "pair_all" return those two sums stacked along a new leading dim of 2 (means over several dims)."""
     lib = _hip.load()
-    if _host_streamable(x, axis):
+    if _host_streamable(x, axis) and skipna not in ("pair_valid", "pair_all"):
         return _streamed(lambda blk, sl: reduce1d(blk, axis, _rows(w, sl), skipna), x)
     dt, sfx = _common(x, w)
     x = asdevice(x, dt)
     axis = axis % x.dim()
     shape = list(x.shape)
     oshape = shape[:axis] + shape[axis + 1:]
+    if skipna in ("pair_valid", "pair_all"):  # numerator and denominator sums side by side: a leading dim of 2
+        oshape = [2] + oshape
     w = _prep_metric(w, dt)
     out = torch.empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:

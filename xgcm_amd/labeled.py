@@ -245,7 +245,9 @@ class DataArray:
         return self.equals(other) and self.name == other.name
 
     # ---- arithmetic on the GPU (name-based broadcasting like xarray) ---------------------
-    def _binary(self, other, op: str, reflexive: bool = False) -> "DataArray":
+    def _binary(self, other, op: str, reflexive: bool = False, dims_order: Optional[Sequence[str]] = None) -> "DataArray":
+        """`self OP other` with name-based broadcasting.  `dims_order` (internal): lay the result out with its dims in
+        that order instead of xarray's (self's dims, then other's new ones) -- same values, no transposed copy later."""
         if isinstance(other, (int, float, np.integer, np.floating)):
             # python / numpy scalars are "weak": a float32 array stays float32 (numpy, xarray)
             sdt = np.float32 if str(self.dtype).endswith("float32") else np.float64
@@ -254,6 +256,8 @@ class DataArray:
             coords = OrderedDict(self.coords)
         elif isinstance(other, DataArray):
             dims = self.dims + tuple(d for d in other.dims if d not in self.dims)
+            if dims_order is not None:
+                dims = tuple(d for d in dims_order if d in dims) + tuple(d for d in dims if d not in dims_order)
             a = _aligned_view(self, dims)
             b = _aligned_view(other, dims)
             for d in dims:
