@@ -238,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
 }
 
 // ------------------------------------------------------------------------------------------
-// K6v: cumsum along the CONTIGUOUS axis, any row length (no periodic halo).  The output ARRAY is 16-B
+// K6v: cumsum along the CONTIGUOUS axis, any row length.  The output ARRAY is 16-B
 // aligned, a row of it need not be (N + 1 outputs of center -> outer): the row starts `lead` cells before
 // a 16-B boundary and ends `tail` cells after one.  Threads own the aligned groups of NV consecutive
 // OUTPUTS in between (one 16-B store each) and fetch the NV inputs behind them with narrow consecutive
@@ -247,7 +247,9 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
 // with shuffles, wave totals go through LDS, the running carry stays in a register.  The <= NV-1 lead
 // and tail cells are summed by every thread (they seed / follow the carry) and stored by thread 0.
 // Inputs that map outside the output range (at most one, when the trim is on the side the scan starts
-// from) seed the carry.  Re-associated sum => 1e-12 parity like K6.
+// from) seed the carry.  A `periodic` halo cell repeats the kept cell at the OTHER end of the row, known only
+// when the scan gets there: whoever stores that source cell stores the halo too, and the group that holds the
+// halo cell stores its other cells one by one (no cell is written twice).  Re-associated sum => 1e-12 parity like K6.
 // ------------------------------------------------------------------------------------------
 template <int MET, bool NTS, int BS>
 __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
@@ -284,6 +286,9 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
   // halo cells of the padded cumulative result (fill / extend only): j = 0 and j = no - 1; an `extend` halo
   // repeats its inner neighbour (j = 1 resp. no - 2), which may live in another part of the row
   const bool lo_halo = a.pad_lo != 0, hi_halo = a.pad_hi != 0, fillmode = (a.bc == XG_BC_FILL);
+  const bool wrap = (a.bc == XG_BC_PERIODIC) && (lo_halo || hi_halo);
+  const int src_lo = wrap && lo_halo ? no - 1 - a.pad_hi : -1;  // output cell whose value the j = 0 halo repeats
+  const int src_hi = wrap && hi_halo ? a.pad_lo : -1;           // ... and the j = no - 1 halo
   // sequential part in scan order over output cells [j0, j1] (either direction), all threads alike, thread 0
   // stores; returns the carry after it
   auto scalars = [&](real carry, int jfirst, int count) -> real {
@@ -297,13 +302,19 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
       if (tid == 0) {
         if (is_lo || is_hi) {
           if (fillmode) put1(j, (real)a.fill);
+          else if (wrap) {}  // stored with its source cell
           else if (have_prev && ((is_lo && a.reverse) || (is_hi && !a.reverse))) put1(j, prev);  // neighbour came just before
           // otherwise the neighbour comes next (stored below) or sits in a group (its owner stores the halo)
         } else {
           put1(j, val);
-          // the neighbour of a halo cell that was passed one step earlier in scan order
-          if (!fillmode && lo_halo && j == 1 && !a.reverse && lead >= 2) put1(0, val);
-          if (!fillmode && hi_halo && j == no - 2 && a.reverse && no - gend >= 2) put1(no - 1, val);
+          if (wrap) {
+            if (j == src_lo) put1(0, val);
+            if (j == src_hi) put1(no - 1, val);
+          } else {
+            // the neighbour of a halo cell that was passed one step earlier in scan order
+            if (!fillmode && lo_halo && j == 1 && !a.reverse && lead >= 2) put1(0, val);
+            if (!fillmode && hi_halo && j == no - 2 && a.reverse && no - gend >= 2) put1(no - 1, val);
+          }
         }
       }
       prev = val;
@@ -396,14 +407,28 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
       dv res;
 #pragma unroll
       for (int k = 0; k < NV; ++k) res[k] = before + l[k];
-      // halo cells inside this group sit next to a kept cell of the same group
-      if (lo_halo && jlo == 0) res[0] = fillmode ? (real)a.fill : res[1];
-      if (hi_halo && jlo + NV == no) res[NV - 1] = fillmode ? (real)a.fill : res[NV - 2];
-      // an `extend` halo cell just outside this group (lead == 1 / one tail cell) repeats this group's edge cell
-      if (!fillmode && lo_halo && jlo == 1) put1(0, res[0]);
-      if (!fillmode && hi_halo && jlo + NV == no - 1) put1(no - 1, res[NV - 1]);
-      if (HAS_MO) res = res / ldm<dv>(m_out, mo_base + (int64_t)jlo * mo.axis, mo.axis);
-      stg<dv, NTS>(orow + jlo, res);
+      if (wrap) {
+        if (src_lo >= jlo && src_lo < jlo + NV) put1(0, res[src_lo - jlo]);
+        if (src_hi >= jlo && src_hi < jlo + NV) put1(no - 1, res[src_hi - jlo]);
+        const bool has_lo = lo_halo && jlo == 0, has_hi = hi_halo && jlo + NV == no;
+        if (has_lo || has_hi) {  // the group around a halo cell: its other cells one by one
+#pragma unroll
+          for (int k = 0; k < NV; ++k)
+            if (!(has_lo && k == 0) && !(has_hi && k == NV - 1)) put1(jlo + k, res[k]);
+        } else {
+          if (HAS_MO) res = res / ldm<dv>(m_out, mo_base + (int64_t)jlo * mo.axis, mo.axis);
+          stg<dv, NTS>(orow + jlo, res);
+        }
+      } else {
+        // halo cells inside this group sit next to a kept cell of the same group
+        if (lo_halo && jlo == 0) res[0] = fillmode ? (real)a.fill : res[1];
+        if (hi_halo && jlo + NV == no) res[NV - 1] = fillmode ? (real)a.fill : res[NV - 2];
+        // an `extend` halo cell just outside this group (lead == 1 / one tail cell) repeats this group's edge cell
+        if (!fillmode && lo_halo && jlo == 1) put1(0, res[0]);
+        if (!fillmode && hi_halo && jlo + NV == no - 1) put1(no - 1, res[NV - 1]);
+        if (HAS_MO) res = res / ldm<dv>(m_out, mo_base + (int64_t)jlo * mo.axis, mo.axis);
+        stg<dv, NTS>(orow + jlo, res);
+      }
     }
   }
   // cells after the groups in scan order
@@ -625,8 +650,7 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
   if (g.inner == 1) {
     const u64 nblocks = (u64)g.outer;
     if ((rc = check_grid(nblocks + 8))) return rc;
-    const bool periodic_halo = (pad_lo || pad_hi) && bc == XG_BC_PERIODIC;
-    if (tune().scan_vec && !periodic_halo && n_out >= 3 * NV && aligned16(out) && nblocks < 0x7ffffff0ull &&
+    if (tune().scan_vec && n_out >= 3 * NV && aligned16(out) && nblocks < 0x7ffffff0ull &&
         g.n_in < 0x7fff0000ll && n_out < 0x7fff0000ll) {
       const u32 nrows = (u32)nblocks, grid = ((nrows + 7) / 8) * 8;
       const bool nts = tune().nt_store;
