@@ -157,6 +157,38 @@ def test_long_strided_march_with_few_columns(dev, dtype):
             (R.integrate(b, 2, wb, True) / R.integrate(ones, 2, wb, False)).astype(dtype))
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_cumsum_chained_chunks(dev, dtype):
+    """K5c: the long strided-axis scan as a chained flat launch (chunks of 32 / 16 rows handing their running sum to
+    the next chunk of the column).  Forced on for short columns too (scan_chain=2): every trim / pad / boundary /
+    direction / NaN mode, ragged last chunks, metrics, several columns per XCD band -- bit-identical to the
+    sequential numpy order, and twice in a row (the workspace must come back clean)."""
+    from xgcm_amd import _hip
+    before = _hip.get_tunable("scan_chain")
+    _hip.set_tunable("scan_chain", 2)
+    try:
+        for shape in ((3, 300, 128), (2, 70, 130), (5, 64, 66), (1, 33, 2), (9, 97, 700)):
+            a = _field(shape, 7, nan=True).astype(dtype)
+            for reverse, skipna in itertools.product([False, True], [True, False]):
+                for tl, th, pl, ph in [(0, 0, 0, 0), (0, 1, 1, 0), (1, 0, 0, 1), (0, 0, 1, 0), (0, 0, 0, 1), (1, 1, 1, 1)]:
+                    for bc in BCS:
+                        exp = R.cumsum1d(a, 1, tl, th, pl, ph, bc, dtype(0.5), reverse, skipna)
+                        for _ in range(2):
+                            _eq(dev.tohost(dev.cumsum1d(a, 1, tl, th, pl, ph, bc, 0.5, reverse, skipna)), exp)
+            m_in = R.synthetic_metric((1,) + shape[1:], 43).astype(dtype)
+            m_out = R.synthetic_metric(shape, 44).astype(dtype)
+            for m_i, m_o in ((m_in, None), (None, m_out), (m_in, m_out)):
+                exp = R.cumsum1d(a, 1, 0, 1, 1, 0, "extend", dtype(0.0), False, True, m_i, m_o)
+                _eq(dev.tohost(dev.cumsum1d(a, 1, 0, 1, 1, 0, "extend", 0.0, False, True, m_i, m_o)), exp)
+        # the leading axis of a 2-D array (one outer index, many tiles) and a 4-D array (outer dims coalesce)
+        b = _field((130, 520), 8).astype(dtype)
+        _eq(dev.tohost(dev.cumsum1d(b, 0, 0, 0, 0, 0, None, 0.0, False, True)), R.cumsum1d(b, 0, 0, 0, 0, 0, None, dtype(0), False, True))
+        c4 = _field((2, 3, 80, 64), 9, nan=True).astype(dtype)
+        _eq(dev.tohost(dev.cumsum1d(c4, 2, 0, 1, 1, 0, "periodic", 0.0, True, True)), R.cumsum1d(c4, 2, 0, 1, 1, 0, "periodic", dtype(0), True, True))
+    finally:
+        _hip.set_tunable("scan_chain", before)
+
+
 def test_cumsum_metric(dev):
     shape = (4, 9, 6, 34)
     a = _field(shape, 9)

@@ -117,6 +117,8 @@ struct Tune {
   int scan_pipe;      // rolling-window loads in the marching scans / reductions (0: batches of U; 2: short marches too)
   int scan_u;         // loads in flight per lane of a long march (8 / 16 / 24 / 32)
   int scan_pace;      // experiment: workgroup barrier per window in the pipelined marching scan
+  int scan_chain;     // long strided-axis scans as a chained flat launch (K5c); 2: whenever the march has >= 2 chunks
+  int scan_chain_w;   // K5c: levels' worth of columns that advance side by side inside one XCD band
   int dbg;            // experiments only (never set in production): see the kernels that read it
   int march_lds_kb;   // optional dynamic LDS request for the column-marching kernels, only to cap residency
                       // (experiment: +8 % on a bare march in tools/streambench.hip, but -20 % on the real
@@ -124,6 +126,15 @@ struct Tune {
 };
 extern "C" __attribute__((visibility("hidden"))) Tune* xg_internal_tune(void);
 inline const Tune& tune() { return *xg_internal_tune(); }
+
+// workspace of the chained scan (K5c, xg_scan.hip), one per stream, owned by xg_runtime.hip: `slot_bytes` of running-sum
+// slots (all zero between launches: the kernel cleans up after itself), 8 ticket counters (same), and one sticky
+// host-visible word that a wave sets when it gives up waiting for a predecessor.  xg_internal_chain_ok(): 1 when
+// workgroups whose ids agree modulo 8 share an XCD on this device (probed once) -- the chain passes its sums through
+// that XCD's L2 -- and no wave has ever given up.
+struct ChainWs { void* slots; u32* ticket; u32* gave_up; };
+extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ws(void* stream, u64 slot_bytes, ChainWs* ws);
+extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ok(void);
 
 // ------------------------------------------------------------------------------------------
 // geometry: a C-contiguous N-D array seen as (outer..., n, inner...) around the op axis,

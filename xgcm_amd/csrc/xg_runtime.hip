@@ -38,6 +38,8 @@ const TuneEntry TUNABLES[] = {
     {"scan_pipe", &Tune::scan_pipe, 1},
     {"scan_u", &Tune::scan_u, 32},
     {"scan_pace", &Tune::scan_pace, 0},
+    {"scan_chain", &Tune::scan_chain, 1},
+    {"scan_chain_w", &Tune::scan_chain_w, 1},
     {"dbg", &Tune::dbg, 0},
     {"march_lds_kb", &Tune::march_lds_kb, 0},
 };
@@ -60,6 +62,92 @@ extern "C" __attribute__((visibility("hidden"))) Tune* xg_internal_tune(void) {
   return &t;
 }
 #endif
+
+#ifdef XG_PRIMARY
+// ------------------------------------------------------------------------------------------
+// workspace + device check of the chained scan (declared in xg_common.hpp)
+// ------------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+namespace {
+__global__ void k_xcc_probe(u32* ids) {
+  u32 id;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+  if (threadIdx.x == 0) ids[blockIdx.x] = id & 0xfu;
+}
+struct ChainState {
+  std::mutex mu;
+  struct PerStream { void* slots = nullptr; u64 bytes = 0; u32* ticket = nullptr; };
+  std::map<std::pair<int, void*>, PerStream> ws;  // (device, stream)
+  std::map<int, int> mapping_ok;                   // device -> probe result
+  u32* gave_up_host = nullptr;
+  u32* gave_up_dev = nullptr;
+};
+ChainState& chain_state() { static ChainState s; return s; }
+}  // namespace
+
+extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ok(void) {
+  ChainState& cs = chain_state();
+  std::lock_guard<std::mutex> lock(cs.mu);
+  if (cs.gave_up_host && *cs.gave_up_host) return 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  auto it = cs.mapping_ok.find(dev);
+  if (it != cs.mapping_ok.end()) return it->second;
+  // once per device: 1024 one-wave workgroups report the XCD they run on; the chain needs ids that agree modulo 8
+  // to share one (SPX: id % 8 IS the XCD -- profiles/r01h_xcc_probe.log; CPX: a single XCD)
+  int ok = 0;
+  const int nb = 1024;
+  u32* d = nullptr;
+  if (hipMalloc((void**)&d, nb * sizeof(u32)) == hipSuccess) {
+    hipLaunchKernelGGL(k_xcc_probe, dim3(nb), dim3(64), 0, 0, d);
+    u32 h[nb];
+    if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+      ok = 1;
+      for (int b = 8; b < nb; ++b)
+        if (h[b] != h[b & 7]) ok = 0;
+    }
+    (void)hipFree(d);
+  }
+  (void)hipGetLastError();
+  cs.mapping_ok[dev] = ok;
+  return ok;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ws(void* stream, u64 slot_bytes, ChainWs* out) {
+  ChainState& cs = chain_state();
+  std::lock_guard<std::mutex> lock(cs.mu);
+  hipStream_t st = (hipStream_t)stream;
+  int dev = 0;
+  XG_HIP(hipGetDevice(&dev));
+  if (!cs.gave_up_host) {
+    XG_HIP(hipHostMalloc((void**)&cs.gave_up_host, 64, hipHostMallocMapped));
+    *cs.gave_up_host = 0;
+    XG_HIP(hipHostGetDevicePointer((void**)&cs.gave_up_dev, cs.gave_up_host, 0));
+  }
+  ChainState::PerStream& w = cs.ws[std::make_pair(dev, stream)];
+  if (!w.ticket) {
+    XG_HIP(hipMalloc((void**)&w.ticket, 1024));  // 8 counters, 128 B apart
+    XG_HIP(hipMemsetAsync(w.ticket, 0, 1024, st));
+  }
+  if (w.bytes < slot_bytes) {
+    if (w.slots) {
+      XG_HIP(hipStreamSynchronize(st));  // an earlier launch on this stream may still use the old block
+      XG_HIP(hipFree(w.slots));
+      w.slots = nullptr;
+      w.bytes = 0;
+    }
+    u64 want = slot_bytes + slot_bytes / 4;
+    XG_HIP(hipMalloc(&w.slots, want));
+    XG_HIP(hipMemsetAsync(w.slots, 0, want, st));
+    w.bytes = want;
+  }
+  out->slots = w.slots;
+  out->ticket = w.ticket;
+  out->gave_up = cs.gave_up_dev;
+  return XG_OK;
+}
+#endif  // XG_PRIMARY
 
 namespace {
 

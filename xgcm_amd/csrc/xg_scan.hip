@@ -155,6 +155,199 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
 }
 
 // ------------------------------------------------------------------------------------------
+// K5c: cumsum along a STRIDED axis for few, LONG columns (cumsum along Y of (Z, Y, X): 4 288 marches of 2 400 rows)
+// as a CHAINED FLAT launch.  A marching wave lives for the whole column: every load it waits for sits behind its own
+// earlier stores in the in-order vmcnt queue, and the chip touches every level at once (150 read + write streams);
+// measured with tools/marchprobe.hip the march stays at 62-71 % of 8 TB/s (box to box) where a flat launch over the
+// same bytes reaches 73-80 %.  Here a wave-task is (column = (outer index, x-tile), chunk c of R rows): it loads its
+// R rows at once, waits for the running sum that chunk c - 1 of its column published, adds its rows IN SEQUENCE
+// (the march's order: bit-identical), publishes its own last sum BEFORE issuing its R stores, and ends.
+//   order: an XCD owns a band of consecutive columns, cut into sub-bands of W columns; inside a sub-band the tasks
+//     run chunk-major, so W chains advance side by side and one XCD sweeps ~W / ntile levels at a time;
+//   tickets: a workgroup takes the next 4 tasks of its band from a counter, so every task a wave can wait for is
+//     already running (no reliance on dispatch order); the last taker resets the counter for the next launch;
+//   hand-off: one 16-B slot per lane and ring position (2 deep), {payload low, epoch, payload high, epoch} with
+//     epoch = c + 1: valid at 8-B granularity, so a torn 16-B access cannot pair a fresh epoch with a stale half;
+//     written with a plain store (acknowledged by the XCD's L2 -- the chain lives behind ONE L2: agent-scope stores
+//     are acknowledged by memory behind the whole write stream, 2.9 instead of 1.9 ms; release / acquire fences cost
+//     a buffer_wbl2 / buffer_inv per task, 17 ms), polled with sc1 loads (bypass the L1); 0.3 us per hand-off when
+//     idle (tools/pingpong.hip), ~1 us under load.  The last chunk of a column zeroes its two slots: the workspace
+//     is all-zero between launches (no per-launch memset, safe under graph replay);
+//   the spin is bounded: a wave that gives up sets a sticky host-visible word and the library stops using K5c.
+// ------------------------------------------------------------------------------------------
+struct ChainArgs {
+  u32 nchunk, cpx, ncol, W, nblk;  // chunks per column, columns per XCD band, columns, sub-band width, workgroups per band
+  u32 srow;                        // slots per ring row = lanes per row of the array
+  u32* ticket;
+  u32* gave_up;
+  void* slots;
+};
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> __device__ __forceinline__ u32x4 chain_pack(T v, u32 ep);
+template <typename T> __device__ __forceinline__ T chain_unpack(u32x4 s);
+#ifdef XG_F32
+// (scalar temporaries: __builtin_bit_cast applied directly to an element of an ext_vector reads element 0)
+template <> __device__ __forceinline__ u32x4 chain_pack<hv>(hv v, u32 ep) {
+  const float f0 = v[0], f1 = v[1];
+  u32x4 o = {__float_as_uint(f0), ep, __float_as_uint(f1), ep};
+  return o;
+}
+template <> __device__ __forceinline__ hv chain_unpack<hv>(u32x4 s) {
+  const u32 b0 = s[0], b1 = s[2];
+  hv o;
+  o[0] = __uint_as_float(b0);
+  o[1] = __uint_as_float(b1);
+  return o;
+}
+#else
+template <> __device__ __forceinline__ u32x4 chain_pack<real>(real v, u32 ep) {
+  const u64 b = __builtin_bit_cast(u64, v);
+  u32x4 o = {(u32)b, ep, (u32)(b >> 32), ep};
+  return o;
+}
+template <> __device__ __forceinline__ real chain_unpack<real>(u32x4 s) {
+  const u64 b = (u64)s[0] | ((u64)s[2] << 32);
+  return __builtin_bit_cast(double, b);
+}
+#endif
+
+template <int MET, int R>
+__global__ __launch_bounds__(BLOCK) void k_cumsum_chain(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, ChainArgs ch) {
+  constexpr int V = HV;
+  typedef typename VecT<V>::type T;
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  __shared__ u32 s_ticket;
+  const u32 xcd = blockIdx.x & 7;
+  if (threadIdx.x == 0) {
+    const u32 t = atomicAdd(&ch.ticket[xcd * 32], 1u);  // one 128-B line per counter: each lives in its own XCD's L2
+    if (t == ch.nblk - 1) __hip_atomic_store(&ch.ticket[xcd * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ticket = t;
+  }
+  __syncthreads();
+  const u32 q = __builtin_amdgcn_readfirstlane(s_ticket * WPB + (threadIdx.x >> 6));
+  const u32 col_lo = xcd * ch.cpx;
+  if (col_lo >= ch.ncol) return;
+  const u32 col_hi = (ch.ncol - col_lo < ch.cpx) ? ch.ncol : col_lo + ch.cpx;
+  const u32 ncols = col_hi - col_lo;
+  if (q >= ncols * ch.nchunk) return;
+  u32 j = q / (ch.nchunk * ch.W);
+  const u32 nsub = (ncols + ch.W - 1) / ch.W;
+  if (j >= nsub) j = nsub - 1;
+  const u32 sub_lo = col_lo + j * ch.W;
+  const u32 w = (col_hi - sub_lo < ch.W) ? col_hi - sub_lo : ch.W;
+  const u32 ql = q - j * ch.nchunk * ch.W;
+  // (the divisions run on the vector unit; readfirstlane tells the compiler their results are wave-uniform again)
+  const u32 c = __builtin_amdgcn_readfirstlane(ql / w), col = sub_lo + (ql - c * w);
+  const u32 o32 = __builtin_amdgcn_readfirstlane(col / ntile), tile = col - o32 * ntile;
+  const int64_t o = o32;
+  const int lane = threadIdx.x & 63;
+  const u32 lx = tile * WAVE + lane;  // lane index along the row: the slot index
+  const int64_t x = (int64_t)lx * V;
+  if (x >= g.inner) return;
+  const int64_t inner = g.inner, n = g.n_in;
+  // row base = wave-uniform 64-bit pointer, lane part = 32-bit offset: the loads / stores take the scalar-base form and
+  // the R addresses cost no vector registers (they were 64 of this kernel's 141: 3 waves per SIMD instead of 6)
+  const u32 xo = lx * V;
+  const real* pin = in + (o * n) * inner;
+  real* pout = out + (o * g.n_out) * inner;
+
+  int64_t mi_base = 0, mo_base = 0, mi_step = 0, mo_step = 0;
+  if (HAS_MI) {
+    mi_base = outer_off(g, mi, o) + inner_off(g, mi, x);
+    mi_step = (V > 1) ? inner_off(g, mi, x + 1) - inner_off(g, mi, x) : 0;
+  }
+  if (HAS_MO) {
+    mo_base = outer_off(g, mo, o) + inner_off(g, mo, x);
+    mo_step = (V > 1) ? inner_off(g, mo, x + 1) - inner_off(g, mo, x) : 0;
+  }
+  const int64_t k0 = (int64_t)c * R;           // first row of the chunk in scan order
+  const int rows = (n - k0 < R) ? (int)(n - k0) : R;  // wave-uniform; < R in the last chunk only
+  auto row = [&](int r) -> int64_t { return a.reverse ? n - 1 - (k0 + r) : k0 + r; };
+  T v[R];
+  if (rows == R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = ldg<T, true>(pin + row(r) * inner + xo);
+    if (HAS_MI) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) v[r] = v[r] * ldm<T>(m_in, mi_base + row(r) * mi.axis, mi_step);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      v[r] = splat<T>(real(0));
+      if (r < rows) {
+        v[r] = ldg<T, true>(pin + row(r) * inner + xo);
+        if (HAS_MI) v[r] = v[r] * ldm<T>(m_in, mi_base + row(r) * mi.axis, mi_step);
+      }
+    }
+  }
+  if (a.skipna) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = nan0(v[r]);
+  }
+  // the running sum of everything before this chunk
+  u32x4* ring = reinterpret_cast<u32x4*>(ch.slots);
+  T acc = splat<T>(real(0));
+  if (c > 0) {
+    const u32x4* src = ring + ((size_t)o32 * 2 + ((c - 1) & 1)) * ch.srow + lx;
+    u32x4 got;
+    u32 tries = 0;
+    do {
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=&v"(got) : "v"(src) : "memory");
+    } while ((got[1] != c || got[3] != c) && ++tries < (1u << 22));
+    if (got[1] != c || got[3] != c) __hip_atomic_store(ch.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    acc = chain_unpack<T>(got);
+  }
+  // the chunk's cumulative values, in the march's order (the first row of the column is assigned, not added to 0)
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (r < rows) {
+      acc = (c > 0 || r > 0) ? acc + v[r] : v[r];
+      v[r] = acc;
+    }
+  }
+  if (c + 1 < ch.nchunk) {
+    ring[((size_t)o32 * 2 + (c & 1)) * ch.srow + lx] = chain_pack<T>(acc, c + 1);
+  } else if (ch.nchunk > 1) {  // end of the column: leave the ring as it was found
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    ring[((size_t)o32 * 2 + 0) * ch.srow + lx] = zero;
+    ring[((size_t)o32 * 2 + 1) * ch.srow + lx] = zero;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the hand-off leaves before the R stores below
+  // outputs: trim / pad table folded into the output index, halo cells written by the task that holds their value
+  // (xgcm/grid.py:1385-1391; numpy.pad semantics)
+  auto put = [&](int64_t jo, T val) {
+    if (HAS_MO) val = val / ldm<T>(m_out, mo_base + jo * mo.axis, mo_step);
+    stg<T, true>(pout + jo * inner + xo, val);
+  };
+  const int64_t first_kept = a.trim_lo, last_kept = n - 1 - a.trim_hi;
+  const int64_t shift = a.pad_lo - a.trim_lo;
+  const bool wrap = a.bc == XG_BC_PERIODIC, ext = a.bc == XG_BC_EXTEND;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (r < rows) {
+      const int64_t idx = row(r);
+      if (idx >= first_kept && idx <= last_kept) put(idx + shift, v[r]);
+      if (idx == first_kept) {
+        if (a.pad_lo && ext) put(0, v[r]);
+        if (a.pad_hi && wrap) put(g.n_out - 1, v[r]);
+      }
+      if (idx == last_kept) {
+        if (a.pad_lo && wrap) put(0, v[r]);
+        if (a.pad_hi && ext) put(g.n_out - 1, v[r]);
+      }
+    }
+  }
+  if (c == 0 && a.bc == XG_BC_FILL) {
+    if (a.pad_lo) put(0, splat<T>(a.fill));
+    if (a.pad_hi) put(g.n_out - 1, splat<T>(a.fill));
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // K6: cumsum along the CONTIGUOUS axis: one workgroup per row, chunks of 256 elements in scan
 // order, wave-level Hillis-Steele scan with cross-lane shuffles, 4 wave totals through LDS,
 // running carry in a register.  Re-associated sum => tolerance parity (not bit-exact).
@@ -686,6 +879,52 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
     // rolling-window variants exist for the default non-temporal loads + stores only; `pipe`: window length
     // window length: `scan_u` rows; with an input metric the window holds the metric values too (twice the registers:
     // 32 rows -> 256 VGPRs, ONE wave per SIMD, cumint along Y 40 % of 8 TB/s) => 8 rows
+    // K5c: the long march as a chained flat launch (8-byte lanes, default cache policies)
+    if (tune().scan_chain && nts && tune().nt_load && g.inner % HV == 0 && (reinterpret_cast<uintptr_t>(in) & 7u) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (HV == 1 || vec_metric_ok(g, met != 0))) {
+      const int R = 32;  // rows per chunk (16 halves the registers but doubles the links of every chain: 63 % against 69 %)
+      const u64 lanes = (u64)g.inner / HV, ctile = (lanes + WAVE - 1) / WAVE, ncol = ctile * (u64)g.outer;
+      const u64 nchunk = ((u64)g.n_in + R - 1) / R;
+      const bool wanted = tune().scan_chain >= 2 ? nchunk >= 2 : (g.n_in >= 256 && ncol < (u64)tune().deep_waves);
+      const u64 slot_bytes = (u64)g.outer * 2 * lanes * 16;
+      if (wanted && nchunk < (1u << 20) && ncol < 0x7fffffffull && slot_bytes <= (1ull << 30) && xg_internal_chain_ok()) {
+        ChainArgs ch;
+        ch.nchunk = (u32)nchunk;
+        ch.ncol = (u32)ncol;
+        ch.cpx = (u32)((ncol + 7) / 8);
+        const int lv = tune().scan_chain_w < 1 ? 1 : tune().scan_chain_w;
+        ch.W = (u32)(ctile * (u64)lv);
+        // a metric that does not depend on the outer index (dy(Y, X) under a (Z, Y, X) field): all columns of the
+        // band advance side by side, so the metric rows of a chunk are read once per XCD and found in its L2 by the
+        // other levels -- level-major order would stream the whole metric from HBM once per level (+50 % traffic)
+        bool shared_metric = false;
+        if (met) {
+          shared_metric = true;
+          for (int d = 0; d < g.n_outer; ++d) {
+            if ((met & 2) && mi.outer[d] != 0) shared_metric = false;
+            if ((met & 1) && mo.outer[d] != 0) shared_metric = false;
+          }
+        }
+        if (shared_metric && tune().scan_chain_w < 100) ch.W = ch.cpx;  // (>= 100: experiment, sub-bands of w - 100 levels anyway)
+        else if (lv >= 100) ch.W = (u32)(ctile * (u64)(lv - 100 < 1 ? 1 : lv - 100));
+        if (ch.W > ch.cpx) ch.W = ch.cpx;
+        ch.srow = (u32)lanes;
+        const u64 nblk = ((u64)ch.cpx * nchunk + WPB - 1) / WPB;
+        if (nblk * 8 <= 0x7fffffffull && (u64)ch.cpx * nchunk < 0xffffffffull) {
+          ch.nblk = (u32)nblk;
+          ChainWs ws;
+          if ((rc = xg_internal_chain_ws(stream, slot_bytes, &ws))) return rc;
+          ch.ticket = ws.ticket;
+          ch.gave_up = ws.gave_up;
+          ch.slots = ws.slots;
+#define XG_C(M, R_) hipLaunchKernelGGL((k_cumsum_chain<M, R_>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, (u32)ctile, a, m_in, mi, m_out, mo, ch)
+          switch (met) { case 0: XG_C(0, 32); break; case 1: XG_C(1, 32); break; case 2: XG_C(2, 32); break; default: XG_C(3, 32); }
+#undef XG_C
+          XG_LAUNCH_CHECK();
+          return XG_OK;
+        }
+      }
+    }
     const int su = (met & 2) ? (tune().scan_u < 8 ? tune().scan_u : 8) : tune().scan_u;
     const int pipe = (tune().scan_pipe && nts && tune().nt_load) ? (deep ? (su >= 32 ? 32 : su >= 24 ? 24 : su >= 16 ? 16 : 8) : (tune().scan_pipe >= 2 ? 8 : 0)) : 0;
 #define XG_PL(V_, M, U_) hipLaunchKernelGGL((k_cumsum_strided<V_, M, true, true, U_, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band | (tune().scan_pace << 1))
