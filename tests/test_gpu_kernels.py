@@ -185,6 +185,18 @@ def test_cumsum_chained_chunks(dev, dtype):
         _eq(dev.tohost(dev.cumsum1d(b, 0, 0, 0, 0, 0, None, 0.0, False, True)), R.cumsum1d(b, 0, 0, 0, 0, 0, None, dtype(0), False, True))
         c4 = _field((2, 3, 80, 64), 9, nan=True).astype(dtype)
         _eq(dev.tohost(dev.cumsum1d(c4, 2, 0, 1, 1, 0, "periodic", 0.0, True, True)), R.cumsum1d(c4, 2, 0, 1, 1, 0, "periodic", dtype(0), True, True))
+        # K4c, the weighted reductions in the same form: every mode against the marching kernel (scan_chain=0), which
+        # the tests above pin to the oracle -- same additions in the same order, so the same bits
+        for shape, wshape in (((3, 300, 128), (1, 300, 128)), ((2, 70, 130), (2, 70, 130)), ((4, 97, 66), (1, 97, 1)), ((2, 3, 80, 64), (1, 1, 80, 64))):
+            a = _field(shape, 17, nan=True).astype(dtype)
+            w = R.synthetic_metric(wshape, 18).astype(dtype)
+            axis = len(shape) - 2
+            for mode in (True, False, "valid", "all", "mean_valid", "mean_all", "pair_valid", "pair_all"):
+                _hip.set_tunable("scan_chain", 0)
+                ref = dev.tohost(dev.reduce1d(a, axis, w, mode))
+                _hip.set_tunable("scan_chain", 2)
+                for _ in range(2):
+                    _eq(dev.tohost(dev.reduce1d(a, axis, w, mode)), ref)
     finally:
         _hip.set_tunable("scan_chain", before)
 

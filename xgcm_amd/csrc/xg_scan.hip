@@ -212,13 +212,8 @@ template <> __device__ __forceinline__ real chain_unpack<real>(u32x4 s) {
 }
 #endif
 
-template <int MET, int R>
-__global__ __launch_bounds__(BLOCK) void k_cumsum_chain(
-    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
-    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, ChainArgs ch) {
-  constexpr int V = HV;
-  typedef typename VecT<V>::type T;
-  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+// the next wave-task of this workgroup's XCD band: chunk c of column (o32, tile); false when the band is exhausted
+__device__ __forceinline__ bool chain_task(const ChainArgs& ch, u32 ntile, u32& c, u32& o32, u32& tile) {
   __shared__ u32 s_ticket;
   const u32 xcd = blockIdx.x & 7;
   if (threadIdx.x == 0) {
@@ -229,10 +224,10 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_chain(
   __syncthreads();
   const u32 q = __builtin_amdgcn_readfirstlane(s_ticket * WPB + (threadIdx.x >> 6));
   const u32 col_lo = xcd * ch.cpx;
-  if (col_lo >= ch.ncol) return;
+  if (col_lo >= ch.ncol) return false;
   const u32 col_hi = (ch.ncol - col_lo < ch.cpx) ? ch.ncol : col_lo + ch.cpx;
   const u32 ncols = col_hi - col_lo;
-  if (q >= ncols * ch.nchunk) return;
+  if (q >= ncols * ch.nchunk) return false;
   u32 j = q / (ch.nchunk * ch.W);
   const u32 nsub = (ncols + ch.W - 1) / ch.W;
   if (j >= nsub) j = nsub - 1;
@@ -240,8 +235,33 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_chain(
   const u32 w = (col_hi - sub_lo < ch.W) ? col_hi - sub_lo : ch.W;
   const u32 ql = q - j * ch.nchunk * ch.W;
   // (the divisions run on the vector unit; readfirstlane tells the compiler their results are wave-uniform again)
-  const u32 c = __builtin_amdgcn_readfirstlane(ql / w), col = sub_lo + (ql - c * w);
-  const u32 o32 = __builtin_amdgcn_readfirstlane(col / ntile), tile = col - o32 * ntile;
+  c = __builtin_amdgcn_readfirstlane(ql / w);
+  const u32 col = sub_lo + (ql - c * w);
+  o32 = __builtin_amdgcn_readfirstlane(col / ntile);
+  tile = col - o32 * ntile;
+  return true;
+}
+
+// one hand-off slot: spin (bounded) until the epoch of both halves is `want`
+__device__ __forceinline__ u32x4 chain_wait(const u32x4* src, u32 want, u32* gave_up) {
+  u32x4 got;
+  u32 tries = 0;
+  do {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=&v"(got) : "v"(src) : "memory");
+  } while ((got[1] != want || got[3] != want) && ++tries < (1u << 22));
+  if (got[1] != want || got[3] != want) __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return got;
+}
+
+template <int MET, int R>
+__global__ __launch_bounds__(BLOCK) void k_cumsum_chain(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, ChainArgs ch) {
+  constexpr int V = HV;
+  typedef typename VecT<V>::type T;
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  u32 c, o32, tile;
+  if (!chain_task(ch, ntile, c, o32, tile)) return;
   const int64_t o = o32;
   const int lane = threadIdx.x & 63;
   const u32 lx = tile * WAVE + lane;  // lane index along the row: the slot index
@@ -293,13 +313,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_chain(
   T acc = splat<T>(real(0));
   if (c > 0) {
     const u32x4* src = ring + ((size_t)o32 * 2 + ((c - 1) & 1)) * ch.srow + lx;
-    u32x4 got;
-    u32 tries = 0;
-    do {
-      asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=&v"(got) : "v"(src) : "memory");
-    } while ((got[1] != c || got[3] != c) && ++tries < (1u << 22));
-    if (got[1] != c || got[3] != c) __hip_atomic_store(ch.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    acc = chain_unpack<T>(got);
+    acc = chain_unpack<T>(chain_wait(src, c, ch.gave_up));
   }
   // the chunk's cumulative values, in the march's order (the first row of the column is assigned, not added to 0)
 #pragma unroll
@@ -729,6 +743,110 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
   }
 }
 
+// K4c: the long WEIGHTED march (integrate / average along Y of (Z, Y, X) with dy(Y, X)) as a chained flat launch, K5c
+// without the stores: a marching wave keeps the weight of every in-flight row in registers next to the row, so its
+// window is 8 rows (52 % of 8 TB/s); a chunk task holds 32 rows + 32 weight rows once and ends.  Same order of
+// additions as the march (bit-identical); two running sums travel for the mean / pair modes.  The last chunk of a
+// column writes the result and zeroes the column's slots.
+template <bool HAS_W, int R>
+__global__ __launch_bounds__(BLOCK) void k_reduce_chain(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, int skipna,
+    const real* __restrict__ wgt, MIdx mw, ChainArgs ch) {
+  constexpr int V = HV;
+  typedef typename VecT<V>::type T;
+  u32 c, o32, tile;
+  if (!chain_task(ch, ntile, c, o32, tile)) return;
+  const int64_t o = o32;
+  const int lane = threadIdx.x & 63;
+  const u32 lx = tile * WAVE + lane;
+  const int64_t x = (int64_t)lx * V;
+  if (x >= g.inner) return;
+  const int64_t inner = g.inner, n = g.n_in;
+  const u32 xo = lx * V;
+  const real* pin = in + (o * n) * inner;
+  int64_t mb = 0, ms = 0;
+  if (HAS_W) {
+    mb = outer_off(g, mw, o) + inner_off(g, mw, x);
+    ms = (V > 1) ? inner_off(g, mw, x + 1) - inner_off(g, mw, x) : 0;
+  }
+  const bool pair = skipna >= 6;
+  if (pair) skipna -= 2;
+  const bool mean = skipna >= 4;
+  const u32 np = mean ? 2u : 1u;  // running sums per lane
+  const int64_t k0 = (int64_t)c * R;
+  const int rows = (n - k0 < R) ? (int)(n - k0) : R;
+  T v[R], d[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    v[r] = splat<T>(real(0));
+    d[r] = splat<T>(real(0));
+  }
+  if (rows == R) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = ldg<T, true>(pin + (k0 + r) * inner + xo);
+    if (HAS_W) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) d[r] = ldm<T>(wgt, mb + (k0 + r) * mw.axis, ms);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (r < rows) {
+        v[r] = ldg<T, true>(pin + (k0 + r) * inner + xo);
+        if (HAS_W) d[r] = ldm<T>(wgt, mb + (k0 + r) * mw.axis, ms);
+      }
+  }
+  // the terms of every row (k_reduce_strided's `step`, same operations in the same order)
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const T wv = d[r];
+    T x1 = v[r];
+    if (mean) {
+      T dd = as_count(x1, skipna == 4 ? 2 : 3);
+      if (HAS_W) { dd = dd * wv; x1 = x1 * wv; }
+      if (skipna == 4) x1 = nan0(x1);
+      d[r] = nan0(dd);
+    } else {
+      if (skipna >= 2) x1 = as_count(x1, skipna);
+      if (HAS_W) x1 = x1 * wv;
+      if (skipna) x1 = nan0(x1);
+    }
+    v[r] = x1;
+  }
+  u32x4* ring = reinterpret_cast<u32x4*>(ch.slots);
+  T acc = splat<T>(real(0)), den = splat<T>(real(0));
+  if (c > 0) {
+    const u32x4* src = ring + (((size_t)o32 * 2 + ((c - 1) & 1)) * ch.srow + lx) * np;
+    acc = chain_unpack<T>(chain_wait(src, c, ch.gave_up));
+    if (mean) den = chain_unpack<T>(chain_wait(src + 1, c, ch.gave_up));
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (r < rows) {
+      const bool first = (c == 0 && r == 0);
+      acc = first ? v[r] : acc + v[r];
+      if (mean) den = first ? d[r] : den + d[r];
+    }
+  }
+  if (c + 1 < ch.nchunk) {
+    u32x4* dst = ring + (((size_t)o32 * 2 + (c & 1)) * ch.srow + lx) * np;
+    dst[0] = chain_pack<T>(acc, c + 1);
+    if (mean) dst[1] = chain_pack<T>(den, c + 1);
+    return;
+  }
+  if (ch.nchunk > 1) {
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    for (u32 par = 0; par < 2; ++par)
+      for (u32 p = 0; p < np; ++p) ring[(((size_t)o32 * 2 + par) * ch.srow + lx) * np + p] = zero;
+  }
+  if (pair) {
+    *reinterpret_cast<T*>(out + o * inner + xo) = acc;
+    *reinterpret_cast<T*>(out + (g.outer + o) * inner + xo) = den;
+  } else {
+    *reinterpret_cast<T*>(out + o * inner + xo) = mean ? acc / den : acc;
+  }
+}
+
 // K4b: weighted sum along the CONTIGUOUS axis: one wave per row, lane-strided partial sums then
 // a shuffle tree (tolerance parity; numpy itself is pairwise here).
 template <bool HAS_W, bool VEC>
@@ -815,6 +933,37 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
 
 }  // namespace
 
+// Launch plan of the chained kernels (K5c / K4c): false when the march is not long-and-narrow enough, the sizes do
+// not fit the 32-bit task arithmetic, the device's workgroup -> XCD mapping was not confirmed, or the workspace cannot
+// be had (the caller then takes the marching kernel; an allocation failure leaves its message in xg_last_error).
+// R = rows per chunk (16 halves the registers but doubles the links of every chain: 63 % against 69 %).
+bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void* stream, ChainArgs* ch, u32* ctile_out, u64* nblk_out) {
+  const u64 lanes = (u64)g.inner / HV, ctile = (lanes + WAVE - 1) / WAVE, ncol = ctile * (u64)g.outer;
+  const u64 nchunk = ((u64)g.n_in + R - 1) / R;
+  const bool wanted = tune().scan_chain >= 2 ? nchunk >= 2 : (g.n_in >= 256 && ncol < (u64)tune().deep_waves);
+  const u64 slot_bytes = (u64)g.outer * 2 * lanes * 16 * (u64)sums_per_lane;
+  if (!wanted || nchunk >= (1u << 20) || ncol >= 0x7fffffffull || slot_bytes > (1ull << 30) || !xg_internal_chain_ok()) return false;
+  ch->nchunk = (u32)nchunk;
+  ch->ncol = (u32)ncol;
+  ch->cpx = (u32)((ncol + 7) / 8);
+  const int lv = tune().scan_chain_w < 1 ? 1 : tune().scan_chain_w;
+  ch->W = (u32)(ctile * (u64)(lv >= 100 ? (lv - 100 < 1 ? 1 : lv - 100) : lv));
+  if (shared_metric && lv < 100) ch->W = ch->cpx;  // (>= 100: experiment, sub-bands of lv - 100 levels whatever the metric)
+  if (ch->W > ch->cpx) ch->W = ch->cpx;
+  ch->srow = (u32)lanes;
+  const u64 nblk = ((u64)ch->cpx * nchunk + WPB - 1) / WPB;
+  if (nblk * 8 > 0x7fffffffull || (u64)ch->cpx * nchunk >= 0xffffffffull) return false;
+  ch->nblk = (u32)nblk;
+  ChainWs ws;
+  if (xg_internal_chain_ws(stream, slot_bytes, &ws)) return false;
+  ch->ticket = ws.ticket;
+  ch->gave_up = ws.gave_up;
+  ch->slots = ws.slots;
+  *ctile_out = (u32)ctile;
+  *nblk_out = nblk;
+  return true;
+}
+
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
@@ -882,47 +1031,23 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
     // K5c: the long march as a chained flat launch (8-byte lanes, default cache policies)
     if (tune().scan_chain && nts && tune().nt_load && g.inner % HV == 0 && (reinterpret_cast<uintptr_t>(in) & 7u) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (HV == 1 || vec_metric_ok(g, met != 0))) {
-      const int R = 32;  // rows per chunk (16 halves the registers but doubles the links of every chain: 63 % against 69 %)
-      const u64 lanes = (u64)g.inner / HV, ctile = (lanes + WAVE - 1) / WAVE, ncol = ctile * (u64)g.outer;
-      const u64 nchunk = ((u64)g.n_in + R - 1) / R;
-      const bool wanted = tune().scan_chain >= 2 ? nchunk >= 2 : (g.n_in >= 256 && ncol < (u64)tune().deep_waves);
-      const u64 slot_bytes = (u64)g.outer * 2 * lanes * 16;
-      if (wanted && nchunk < (1u << 20) && ncol < 0x7fffffffull && slot_bytes <= (1ull << 30) && xg_internal_chain_ok()) {
-        ChainArgs ch;
-        ch.nchunk = (u32)nchunk;
-        ch.ncol = (u32)ncol;
-        ch.cpx = (u32)((ncol + 7) / 8);
-        const int lv = tune().scan_chain_w < 1 ? 1 : tune().scan_chain_w;
-        ch.W = (u32)(ctile * (u64)lv);
-        // a metric that does not depend on the outer index (dy(Y, X) under a (Z, Y, X) field): all columns of the
-        // band advance side by side, so the metric rows of a chunk are read once per XCD and found in its L2 by the
-        // other levels -- level-major order would stream the whole metric from HBM once per level (+50 % traffic)
-        bool shared_metric = false;
-        if (met) {
-          shared_metric = true;
-          for (int d = 0; d < g.n_outer; ++d) {
-            if ((met & 2) && mi.outer[d] != 0) shared_metric = false;
-            if ((met & 1) && mo.outer[d] != 0) shared_metric = false;
-          }
-        }
-        if (shared_metric && tune().scan_chain_w < 100) ch.W = ch.cpx;  // (>= 100: experiment, sub-bands of w - 100 levels anyway)
-        else if (lv >= 100) ch.W = (u32)(ctile * (u64)(lv - 100 < 1 ? 1 : lv - 100));
-        if (ch.W > ch.cpx) ch.W = ch.cpx;
-        ch.srow = (u32)lanes;
-        const u64 nblk = ((u64)ch.cpx * nchunk + WPB - 1) / WPB;
-        if (nblk * 8 <= 0x7fffffffull && (u64)ch.cpx * nchunk < 0xffffffffull) {
-          ch.nblk = (u32)nblk;
-          ChainWs ws;
-          if ((rc = xg_internal_chain_ws(stream, slot_bytes, &ws))) return rc;
-          ch.ticket = ws.ticket;
-          ch.gave_up = ws.gave_up;
-          ch.slots = ws.slots;
-#define XG_C(M, R_) hipLaunchKernelGGL((k_cumsum_chain<M, R_>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, (u32)ctile, a, m_in, mi, m_out, mo, ch)
-          switch (met) { case 0: XG_C(0, 32); break; case 1: XG_C(1, 32); break; case 2: XG_C(2, 32); break; default: XG_C(3, 32); }
+      // a metric that does not depend on the outer index (dy(Y, X) under a (Z, Y, X) field): all columns of the
+      // band advance side by side, so the metric rows of a chunk are read once per XCD and found in its L2 by the
+      // other levels -- level-major order would stream the whole metric from HBM once per level (+50 % traffic)
+      bool shared_metric = met != 0;
+      for (int d = 0; d < g.n_outer; ++d) {
+        if ((met & 2) && mi.outer[d] != 0) shared_metric = false;
+        if ((met & 1) && mo.outer[d] != 0) shared_metric = false;
+      }
+      ChainArgs ch;
+      u32 ctile = 0;
+      u64 nblk = 0;
+      if (chain_plan(g, 32, 1, shared_metric, stream, &ch, &ctile, &nblk)) {
+#define XG_C(M, R_) hipLaunchKernelGGL((k_cumsum_chain<M, R_>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, ctile, a, m_in, mi, m_out, mo, ch)
+        switch (met) { case 0: XG_C(0, 32); break; case 1: XG_C(1, 32); break; case 2: XG_C(2, 32); break; default: XG_C(3, 32); }
 #undef XG_C
-          XG_LAUNCH_CHECK();
-          return XG_OK;
-        }
+        XG_LAUNCH_CHECK();
+        return XG_OK;
       }
     }
     const int su = (met & 2) ? (tune().scan_u < 8 ? tune().scan_u : 8) : tune().scan_u;
@@ -991,6 +1116,23 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     if ((rc = check_grid(nblocks))) return rc;
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
     const int rband = tune().march_band;
+    // K4c: the long weighted march as a chained flat launch (the unweighted one already streams at 80 %)
+    if (w && tune().scan_chain && tune().nt_load && g.inner % HV == 0 && (reinterpret_cast<uintptr_t>(in) & 7u) == 0 &&
+        (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (HV == 1 || vec_metric_ok(g, true))) {
+      bool shared_w = true;
+      for (int d = 0; d < g.n_outer; ++d)
+        if (mw.outer[d] != 0) shared_w = false;
+      // weights with an outer dim of their own (hFacC(Z, Y, X)) stream from HBM like the field: the march's window of
+      // 8 rows + 8 weight rows already runs at 76 % there, the chain at 74 %
+      ChainArgs ch;
+      u32 ctile = 0;
+      u64 nblk = 0;
+      if (shared_w && chain_plan(g, 32, skipna >= 4 ? 2 : 1, shared_w, stream, &ch, &ctile, &nblk)) {
+        hipLaunchKernelGGL((k_reduce_chain<true, 32>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, ctile, skipna, w, mw, ch);
+        XG_LAUNCH_CHECK();
+        return XG_OK;
+      }
+    }
 #define XG_GL(V_, W_, NTL_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, rband); \
                            else hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, rband); } while (0)
     const int su = w ? (tune().scan_u < 8 ? tune().scan_u : 8) : tune().scan_u;  // weights ride in the window: 8 rows (registers)
