@@ -467,6 +467,54 @@ def test_transform_resident_tensors():
     np.testing.assert_array_equal(res.values, host.values)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_linear_transform_output_staging_variants(dtype):
+    """(Z, Y, X) layout, random-walk columns: the lanes of a wave emit a target level at different source levels.  Every
+    way of getting the outputs to memory -- direct stores, level table in LDS, whole-column tile, ring of 4 / 8 / 16
+    rows with lanes running ahead of the ring and columns that fall back to the exact search in the same wave --
+    gives the oracle's bits."""
+    from xgcm_amd import _hip
+    from xgcm_amd import device as dev
+
+    nz, ny, nx, m = 40, 3, 200, 50
+    rng = np.random.default_rng(11)
+    theta = np.cumsum(rng.random((nz, ny, nx)) * 2.0 + 0.01, axis=0)
+    theta[:, 0, 5] = theta[::-1, 0, 5]          # a decreasing column (flipped)
+    theta[7, 1, 70] = np.nan                     # NaN inside a column -> exact path
+    theta[20:, 2, 130] = theta[19, 2, 130] - 1   # non-monotonic -> exact path
+    theta[:, 1, 100:110] *= 0.05                 # compressed columns: all targets right of them, far ahead of the others
+    theta[:, 2, 10:20] *= 30.0                   # stretched columns: lag behind
+    theta = theta.astype(dtype)
+    phi = (R.synthetic_field((nz, ny, nx), 12) * 10).astype(dtype)
+    levels = np.linspace(0.5, 0.9 * float(np.nanmax(theta[:, 0, 0])), m).astype(dtype)
+    want = np.moveaxis(TR.interp_1d_linear(np.moveaxis(phi, 0, -1), np.moveaxis(theta, 0, -1), levels, mask_edges=True), -1, 0)
+    lv3 = levels.reshape(m, 1, 1)
+    per_column = np.ascontiguousarray(np.broadcast_to(lv3, (m, ny, nx)))  # not shared: levels stay in memory
+    keep = {k: _hip.get_tunable(k) for k in ("transform_stage", "transform_ring", "transform_win", "transform_cwin")}
+    try:
+        for stage, ring in ((0, 8), (1, 8), (2, 8), (3, 4), (3, 8), (3, 16), (3, 32)):
+            _hip.set_tunable("transform_stage", stage)
+            _hip.set_tunable("transform_ring", ring)
+            for tg in (lv3, per_column):
+                got = dev.tohost(dev.transform_linear(phi, theta, tg, 0, mask_edges=True))
+                np.testing.assert_array_equal(got, want, err_msg=f"stage {stage} ring {ring}")
+        # the conservative remap: one accumulator window per wave (4 / 8 / 16 bins, complete rows leave when every lane's
+        # cursor has passed them) or per lane (transform_win=2), land columns and columns running backwards in the wave
+        theta_o = np.concatenate([theta[:1] - 1.0, theta], axis=0)
+        theta_o[:, 1, 30:40] = np.nan  # land
+        edges = np.linspace(0.0, 1.1 * float(np.nanmax(theta[:, 0, 0])), m + 1).astype(dtype)
+        want_c = np.moveaxis(TR.interp_1d_conservative(np.moveaxis(phi, 0, -1), np.moveaxis(theta_o, 0, -1), edges), -1, 0)
+        for win, cwin in ((2, 16), (1, 4), (1, 8), (1, 16)):
+            _hip.set_tunable("transform_win", win)
+            _hip.set_tunable("transform_cwin", cwin)
+            got = dev.tohost(dev.transform_conservative(phi, theta_o, edges, 0))
+            np.testing.assert_array_equal(got, want_c, err_msg=f"win {win} cwin {cwin}")
+    finally:
+        for k, v in keep.items():
+            _hip.set_tunable(k, v)
+
+
 def test_transform_edge_shapes(backend):
     """empty batches, single-level columns, a single target level, targets all outside the column"""
     phi = R.synthetic_field((4, 6), 41)

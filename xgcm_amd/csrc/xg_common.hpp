@@ -99,6 +99,10 @@ struct Tune {
   int transform_lds_kb;  // LDS budget of the cell-major conservative kernel (0: always the register-tile kernel)
   int transform_win;   // conservative transform: sliding window of accumulators in LDS (K9d) for up to 64 bins
   int transform_fast;  // streaming path of the linear transform for well-formed columns (0: always the exact search)
+  int transform_stage; // linear transform: 3 = ring of output rows in LDS, written out as complete rows (2: only the
+                       // level table in LDS; 1: whole-column tile; 0: direct stores)
+  int transform_ring;  // rows of that ring (8 / 16 / 32)
+  int transform_cwin;  // conservative transform: accumulators per lane in the wave's LDS window (8 / 16)
   int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
   int zb_rows;        // rows per band

@@ -20,6 +20,9 @@ const TuneEntry TUNABLES[] = {
     {"transform_lds_kb", &Tune::transform_lds_kb, 64},
     {"transform_win", &Tune::transform_win, 1},
     {"transform_fast", &Tune::transform_fast, 1},
+    {"transform_stage", &Tune::transform_stage, 3},
+    {"transform_ring", &Tune::transform_ring, 8},
+    {"transform_cwin", &Tune::transform_cwin, 8},
     {"zchunk", &Tune::zchunk, 256},
     {"zband", &Tune::zband, 1},
     {"zb_rows", &Tune::zb_rows, 16},

@@ -73,13 +73,30 @@ __device__ __forceinline__ double interp_pair(double xv, double xj, double xj1, 
   return res;
 }
 
-template <bool LOG>
-__global__ __launch_bounds__(BLOCK) void k_transform_linear(
+// STAGE: one wave per workgroup keeps its 64 columns' outputs in an LDS tile [m][64] and writes them as m complete
+// 512-B rows at the end.  The lanes of a wave reach a target level at different source levels, so emitting straight
+// to memory stores a few lanes at a time: 239 M partial write requests for 54 M lines, 9.1 GB written for 3.5 GB
+// (profiles/r02g_transform_linear_bounds.txt).  STAGE & 2: the target levels are the same for every column (a 1-D
+// `target`): they sit in LDS too, so the divergent emission loop carries no memory instruction at all.
+template <bool LOG, int STAGE, int TWIN = 16>
+__global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear(
     const real* __restrict__ phi, const real* __restrict__ theta, const real* __restrict__ target,
     real* __restrict__ out, Geo g, MIdx mt, MIdx mg, int mask_edges, int bypass_checks, int fast_path) {
-  const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-  if (c >= g.outer * g.inner) return;
+  extern __shared__ real t_lds[];
+  constexpr int TB = (STAGE & 5) ? WAVE : BLOCK;
+  const int64_t c = (int64_t)blockIdx.x * TB + threadIdx.x;
   const int64_t inner = g.inner, n = g.n_in, m = g.n_out;
+  real* tile = t_lds;                                  // [m][64]
+  real* lds_lev = t_lds + ((STAGE & 1) ? m * WAVE : (STAGE & 4) ? TWIN * WAVE : 0);  // [m]
+  if (STAGE & 2) {  // before any lane leaves: the whole workgroup fills the level table
+    for (int64_t i = threadIdx.x; i < m; i += TB) {
+      const real v = target[i * mg.axis];
+      lds_lev[i] = LOG ? xg_log_store(v) : v;
+    }
+    if (!(STAGE & 5)) __syncthreads();
+  }
+  if (c >= g.outer * g.inner) return;
+  const int lane = threadIdx.x & 63;
   const int64_t o = c / inner, x = c - o * inner;
   const real* pphi = phi + (o * n) * inner + x;
   const real* pth = theta + outer_off(g, mt, o) + inner_off(g, mt, x);
@@ -87,7 +104,24 @@ __global__ __launch_bounds__(BLOCK) void k_transform_linear(
   real* pout = out + (o * m) * inner + x;
   // theta as the reference sees it: the storage type's log first (np.log in interp_1d_linear)
   auto TH = [&](int64_t k) -> real { real v = pth[k * mt.axis]; return LOG ? xg_log_store(v) : v; };
-  auto LEV = [&](int64_t i) -> real { real v = ptg[i * mg.axis]; return LOG ? xg_log_store(v) : v; };
+  auto LEV = [&](int64_t i) -> real {
+    if (STAGE & 2) return lds_lev[i];
+    real v = ptg[i * mg.axis];
+    return LOG ? xg_log_store(v) : v;
+  };
+  // STAGE & 4: the tile is a RING of TWIN rows.  `flushed` (wave-uniform) = rows already written out: a row leaves as
+  // one complete 512-B store as soon as every lane of the wave has emitted it; a lane that runs more than TWIN rows
+  // ahead of the slowest one stores directly and remembers the row in `direct` (m <= 64), as does the exact path.
+  int64_t flushed = 0;
+  u64 direct = 0;
+  bool dir_all = false;  // exact path: every output stored directly
+  auto OUT = [&](int64_t i, real r) {
+    if (STAGE & 4) {
+      if (!dir_all && i < flushed + TWIN) tile[(i & (TWIN - 1)) * WAVE + lane] = r;
+      else { pout[i * inner] = r; direct |= 1ull << i; }
+    } else if (STAGE & 1) tile[i * WAVE + lane] = r;
+    else pout[i * inner] = r;
+  };
 
   // ---- fast path: a well-formed column (no NaN, monotonic theta) and non-decreasing, NaN-free
   // targets.  numpy's search then returns max{j: xp[j] <= key} whatever its probing path, so the
@@ -112,7 +146,7 @@ __global__ __launch_bounds__(BLOCK) void k_transform_linear(
       auto emit_and_advance = [&](double res) {
         real r = (real)res;
         if (mask_edges && (lev < tmin || lev > tmax)) r = (real)NAN;
-        pout[i * inner] = r;
+        OUT(i, r);
         ++i;
         if (i < m) {
           const real nxt = LEV(i);
@@ -120,7 +154,8 @@ __global__ __launch_bounds__(BLOCK) void k_transform_linear(
           lev = nxt;
         }
       };
-      constexpr int UT = 8;  // levels fetched ahead of use: the column loads do not wait on each other
+      constexpr int UT = (STAGE & 1) ? 16 : 8;  // levels fetched ahead of use: the column loads do not wait on each other
+                                          // (the LDS tile leaves 6 waves per CU: twice the loads per wave)
       for (int64_t k0 = 1; k0 < n && !exact; k0 += UT) {
         real tvs[UT], fvs[UT];
 #pragma unroll
@@ -159,15 +194,24 @@ __global__ __launch_bounds__(BLOCK) void k_transform_linear(
             emit_and_advance(res);
           }
           xk = xk1; fk = fk1;
+          if (STAGE & 4) {
+            // every lane still on the streaming path is here (lanes sent to the exact path rewrite their column
+            // themselves): rows that all of them have emitted leave as complete stores
+            while (flushed < m && __ballot(i <= flushed) == 0) {
+              if (!((direct >> flushed) & 1)) stg<real, true>(pout + flushed * inner, tile[(flushed & (TWIN - 1)) * WAVE + lane]);
+              ++flushed;
+            }
+          }
         }
       }
       // remaining targets are >= xp[n-1]: the last point itself (fp[n-1]) or right of it (rval == fp[n-1])
       while (i < m && !exact) emit_and_advance(fk);
     }
-    if (!exact) return;
   }
 
   // ---- exact path: numpy's search, probe for probe
+  if (exact) {
+  dir_all = true;
   bool flip = false;
   real tmin = real(0), tmax = real(0);
   bool have = false;
@@ -210,7 +254,14 @@ __global__ __launch_bounds__(BLOCK) void k_transform_linear(
     }
     real r = (real)res;
     if (mask_edges && have && (lev < tmin || lev > tmax)) r = (real)NAN;
-    pout[i * inner] = r;
+    OUT(i, r);
+  }
+  }
+  if (STAGE & 4) {  // what is still in the ring (a lane that took the exact path has nothing there)
+    for (int64_t r = 0; r < m; ++r)
+      if (!dir_all && r >= flushed && !((direct >> r) & 1)) stg<real, true>(pout + r * inner, tile[(r & (TWIN - 1)) * WAVE + lane]);
+  } else if (STAGE & 1) {  // the tile leaves as complete rows (LDS accesses of one wave are ordered: no barrier)
+    for (int64_t i = 0; i < m; ++i) stg<real, true>(pout + i * inner, tile[i * WAVE + lane]);
   }
 }
 
@@ -387,9 +438,9 @@ __global__ __launch_bounds__(CTB) void k_transform_conservative_lds(
 // NaN otherwise, a bin beyond the window (a cell thicker than CWIN bins) is read-modify-written in `out`
 // directly.  Wherever an accumulator lives, its additions arrive in cell order: same bits as K9b / K9c /
 // the reference.  Bins that never received anything get their NaN in a final pass.
-constexpr int CWIN = 16;
 constexpr int CWB = 256;
 
+template <bool UNI, int CWIN>
 __global__ __launch_bounds__(CWB) void k_transform_conservative_win(
     const real* __restrict__ phi, const real* __restrict__ theta, const real* __restrict__ bins,
     real* __restrict__ out, Geo g, MIdx mt) {
@@ -408,7 +459,7 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_win(
 #pragma unroll
   for (int s_ = 0; s_ < CWIN; ++s_) ring[s_ * CWB] = (real)NAN;
   u64 touched = 0;  // bins that hold a value, in the window or already in `out`
-  int wb = 0;       // the window covers bins [wb, wb + CWIN)
+  int wb = 0;       // the window covers bins [wb, wb + CWIN); UNI: the same for every lane of the wave (see below)
   auto was_touched = [&](int j) -> bool { return (touched >> j) & 1ull; };
   // a value this lane stored earlier: read past the L1 (the store went through to L2)
   auto reload = [&](int j) -> real { return __hip_atomic_load(pout + (int64_t)j * inner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
@@ -427,7 +478,7 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_win(
     }
   };
   auto accumulate = [&](int j, real add) {
-    if (j < wb + CWIN) {
+    if (j < wb + CWIN && (!UNI || j >= wb)) {
       real* slot = ring + (j & (CWIN - 1)) * CWB;
       const real old = *slot;
       *slot = (old != old) ? add : old + add;
@@ -438,6 +489,23 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_win(
     touched |= 1ull << j;
   };
   int jlo = 0;  // cursor: first bin whose upper edge reaches the current cell
+  // UNI: ONE window per wave.  A lane sliding its own window writes the bin it leaves on its own, a few lanes at a
+  // time (partial lines, as in the linear transform: profiles/r02g_transform_linear_bounds.txt).  Here bin wb
+  // leaves when the cursor of EVERY lane has passed it, as one complete row (NaN where a column never touched it);
+  // a lane whose cursor falls behind the window (non-monotonic column) or whose cell reaches beyond it accumulates
+  // in `out` directly, as before -- wherever an accumulator lives its additions arrive in cell order.
+  // A lane whose current cell is void (NaN bounds or NaN value: land, missing data) does not hold the window back; if
+  // it comes back to life behind the window it accumulates in `out` directly.
+  bool idle = false;
+  auto advance_window = [&]() {  // called where all lanes of the wave are present
+    while (wb < m && __ballot(!idle && jlo <= wb) == 0) {
+      real* slot = ring + (wb & (CWIN - 1)) * CWB;
+      stg<real, true>(pout + (int64_t)wb * inner, *slot);
+      const int in = wb + CWIN;
+      if (in < m) *slot = was_touched(in) ? reload(in) : (real)NAN;
+      ++wb;
+    }
+  };
   real e_lo = sb[0], e_hi = sb[1];
   real t1 = pth[0];
   constexpr int UT = 8;
@@ -452,10 +520,12 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_win(
 #pragma unroll
     for (int u = 0; u < UT; ++u) {
       if (i0 + u >= n) break;
+      if (UNI) advance_window();
       const real t2 = tts[u], p = pps[u];
       const real a1 = t1;
       t1 = t2;
       const bool n1 = a1 != a1, n2 = t2 != t2;
+      idle = (n1 && n2) || (p != p);
       if (n1 && n2) continue;
       real lo_, hi_;
       if (n1) { lo_ = hi_ = t2; }
@@ -473,7 +543,7 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_win(
         e_hi = sb[j + 1];
       }
       if (e_hi < lo_ || e_lo > hi_) continue;  // the cell lies above the last bin / below this one: no overlap at all
-      if (jlo != wb) slide_to(jlo);
+      if (!UNI && jlo != wb) slide_to(jlo);
       real e1 = e_lo, e2 = e_hi;
       for (int j = jlo;;) {
         real add;
@@ -491,6 +561,15 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_win(
         e2 = sb[j + 1];
       }
     }
+  }
+  if (UNI) {  // what is left of the window leaves as complete rows too; only bins beyond it need their NaN
+    for (int s_ = 0; s_ < CWIN; ++s_) {
+      const int b = wb + s_;
+      if (b < m) stg<real, true>(pout + (int64_t)b * inner, ring[(b & (CWIN - 1)) * CWB]);
+    }
+    for (int j = wb + CWIN; j < m; ++j)
+      if (!was_touched(j)) pout[(int64_t)j * inner] = (real)NAN;
+    return;
   }
   for (int s_ = 0; s_ < CWIN; ++s_) {
     const int b = wb + s_;
@@ -519,12 +598,50 @@ int XG_FN(xg_transform_linear)(const real* phi, const real* theta, const int64_t
   if (g.n_in < 1) return fail(XG_ERR_INVALID, "empty transform axis");
   const int64_t cols = g.outer * g.inner;
   if (cols == 0 || m == 0) return XG_OK;
-  const u64 nblocks = ((u64)cols + BLOCK - 1) / BLOCK;
-  if ((rc = check_grid(nblocks))) return rc;
   hipStream_t st = (hipStream_t)stream;
   const int fast = (tune().transform_fast ? 1 : 0) | ((tune().dbg & 4) ? 2 : 0);
-  if (logarithmic) hipLaunchKernelGGL((k_transform_linear<true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
-  else hipLaunchKernelGGL((k_transform_linear<false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
+  // outputs staged in LDS (one wave per workgroup) while the tile fits 48 KB: up to 96 (f64) / 192 (f32) target levels
+  bool shared_levels = true;
+  for (int d = 0; d < MAXD; ++d)
+    if ((d < g.n_outer && mg.outer[d] != 0) || (d < g.n_inner && mg.inner[d] != 0)) shared_levels = false;
+  const size_t lds = ((size_t)m * WAVE + (shared_levels ? (size_t)m : 0)) * sizeof(real);
+  if (tune().transform_stage == 2 && shared_levels && m <= 4096) {  // target levels in LDS only
+    const u64 nblocks = ((u64)cols + BLOCK - 1) / BLOCK;
+    if ((rc = check_grid(nblocks))) return rc;
+    if (logarithmic) hipLaunchKernelGGL((k_transform_linear<true, 2>), dim3((u32)nblocks), dim3(BLOCK), (size_t)m * sizeof(real), st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
+    else hipLaunchKernelGGL((k_transform_linear<false, 2>), dim3((u32)nblocks), dim3(BLOCK), (size_t)m * sizeof(real), st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
+    XG_LAUNCH_CHECK();
+    return XG_OK;
+  }
+  if (tune().transform_stage >= 3 && m <= 64) {  // ring of 16 output rows per wave (+ the level table)
+    const u64 nblocks = ((u64)cols + WAVE - 1) / WAVE;
+    if ((rc = check_grid(nblocks))) return rc;
+    const int tw = tune().transform_ring <= 4 ? 4 : tune().transform_ring <= 8 ? 8 : tune().transform_ring >= 32 ? 32 : 16;
+    const size_t rl = ((size_t)tw * WAVE + (shared_levels ? (size_t)m : 0)) * sizeof(real);
+#define XG_T(L, S, TW) hipLaunchKernelGGL((k_transform_linear<L, S, TW>), dim3((u32)nblocks), dim3(WAVE), rl, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast)
+#define XG_TS(L, TW) do { if (shared_levels) XG_T(L, 6, TW); else XG_T(L, 4, TW); } while (0)
+#define XG_TW(L) do { if (tw == 4) XG_TS(L, 4); else if (tw == 8) XG_TS(L, 8); else if (tw == 32) XG_TS(L, 32); else XG_TS(L, 16); } while (0)
+    if (logarithmic) XG_TW(true); else XG_TW(false);
+#undef XG_TW
+#undef XG_TS
+#undef XG_T
+    XG_LAUNCH_CHECK();
+    return XG_OK;
+  }
+  if (tune().transform_stage == 1 && lds <= 48 * 1024) {
+    const u64 nblocks = ((u64)cols + WAVE - 1) / WAVE;
+    if ((rc = check_grid(nblocks))) return rc;
+#define XG_T(L, S) hipLaunchKernelGGL((k_transform_linear<L, S>), dim3((u32)nblocks), dim3(WAVE), lds, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast)
+    if (logarithmic) { if (shared_levels) XG_T(true, 3); else XG_T(true, 1); }
+    else { if (shared_levels) XG_T(false, 3); else XG_T(false, 1); }
+#undef XG_T
+    XG_LAUNCH_CHECK();
+    return XG_OK;
+  }
+  const u64 nblocks = ((u64)cols + BLOCK - 1) / BLOCK;
+  if ((rc = check_grid(nblocks))) return rc;
+  if (logarithmic) hipLaunchKernelGGL((k_transform_linear<true, 0>), dim3((u32)nblocks), dim3(BLOCK), 0, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
+  else hipLaunchKernelGGL((k_transform_linear<false, 0>), dim3((u32)nblocks), dim3(BLOCK), 0, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast);
   XG_LAUNCH_CHECK();
   return XG_OK;
 }
@@ -541,10 +658,14 @@ int XG_FN(xg_transform_conservative)(const real* phi, const real* theta, const i
   if (cols == 0) return XG_OK;
   const int64_t m = n_edges - 1;
   if (tune().transform_win && m <= 64) {  // sliding accumulator window (K9d)
-    const size_t wlds = ((size_t)((m + 2) & ~(int64_t)1) + (size_t)CWIN * CWB) * sizeof(real);
+    const int cw = (tune().transform_win == 2 || tune().transform_cwin > 8) ? 16 : tune().transform_cwin <= 4 ? 4 : 8;
+    const size_t wlds = ((size_t)((m + 2) & ~(int64_t)1) + (size_t)cw * CWB) * sizeof(real);
     const u64 nblocks = ((u64)cols + CWB - 1) / CWB;
     if ((rc = check_grid(nblocks))) return rc;
-    hipLaunchKernelGGL(k_transform_conservative_win, dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+    if (tune().transform_win == 2) hipLaunchKernelGGL((k_transform_conservative_win<false, 16>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+    else if (cw == 16) hipLaunchKernelGGL((k_transform_conservative_win<true, 16>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+    else if (cw == 4) hipLaunchKernelGGL((k_transform_conservative_win<true, 4>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+    else hipLaunchKernelGGL((k_transform_conservative_win<true, 8>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
     XG_LAUNCH_CHECK();
     return XG_OK;
   }
