@@ -33,6 +33,7 @@ def main():
     dx = D.synthetic((1, ny, nx), 31, 0, 1000.0, 1000.0)
     dx2 = D.synthetic((1, ny, nx), 32, 0, 1000.0, 1000.0)
     dz = D.synthetic((nz, 1, 1), 33, 0, 1000.0, 1000.0)
+    dy1 = D.synthetic((1, ny, 1), 34, 0, 1000.0, 1000.0)
     U = V = None
     CASES = {
         "diffX": (lambda: D.stencil1d("diff", T, 2, 1, 0, "periodic"), 16),
@@ -40,6 +41,8 @@ def main():
         "dX": (lambda: D.stencil1d("diff", T, 2, 1, 0, "periodic", m_out=dx), 16 + 8 / nz),
         "dY": (lambda: D.stencil1d("diff", T, 1, 1, 0, "extend", m_out=dx), 16 + 8 / nz),
         "dZ": (lambda: D.stencil1d("diff", T, 0, 1, 0, "fill", m_out=dz), 16),
+        "iZmw": (lambda: D.stencil1d("interp", T, 0, 1, 0, "fill", m_in=dz, m_out=dz), 16),
+        "iYmw1": (lambda: D.stencil1d("interp", T, 1, 1, 0, "extend", m_in=dy1, m_out=dy1), 16),
         "iXmw": (lambda: D.stencil1d("interp", T, 2, 1, 0, "periodic", m_in=dx2, m_out=dx), 16 + 16 / nz),
         "iYmw": (lambda: D.stencil1d("interp", T, 1, 1, 0, "extend", m_in=dx2, m_out=dx), 16 + 16 / nz),
         "divT": (lambda: D.binary("div", T, dx), 16 + 8 / nz),

@@ -38,6 +38,7 @@ const TuneEntry TUNABLES[] = {
     {"vec_zk", &Tune::vec_zk, 2},
     {"contig_rw_mi", &Tune::contig_rw_mi, 8},
     {"met_seg", &Tune::met_seg, 2},
+    {"met_scalar", &Tune::met_scalar, 1},
     {"scan_pipe", &Tune::scan_pipe, 1},
     {"scan_u", &Tune::scan_u, 32},
     {"scan_pace", &Tune::scan_pace, 0},

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
   // `mal` (host-proven): every metric is contiguous along the lanes and each of its rows 16-B aligned, so a
   // lane vector's metric is ONE 16-B load with no per-lane alignment test
   auto ldmv = [&](const real* m, int64_t off, int64_t step) -> T {
-    if (V > 1 && mal) return *reinterpret_cast<const T*>(m + off);
+    if (V > 1 && (mal & 1)) return *reinterpret_cast<const T*>(m + off);
     return ldm<T>(m, off, step);
   };
   // banding: XCD (b % 8) owns logical blocks [xcd * pb, (xcd + 1) * pb)
@@ -457,13 +457,21 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
   const int64_t nrow = (g.n_out - j0 < SEG) ? g.n_out - j0 : SEG;  // rows this segment really has
 
   int64_t mib = 0, mob = 0, mis = 0, mos = 0;  // (host guarantees g.idx32 when metrics are present)
+  const bool ui = HAS_MI && (mal & 2), uo = HAS_MO && (mal & 4);  // row-uniform metrics: scalar loads
+  int64_t mibu = 0, mobu = 0;                                     // their wave-uniform offsets
   if (HAS_MI) {
-    inner_off_step32(g, mi, (u32)x, V > 1, mib, mis);
-    mib += outer_off32(g, mi, (u32)o);
+    if (ui) mibu = outer_off32(g, mi, (u32)o);
+    else {
+      inner_off_step32(g, mi, (u32)x, V > 1, mib, mis);
+      mib += outer_off32(g, mi, (u32)o);
+    }
   }
   if (HAS_MO) {
-    inner_off_step32(g, mo, (u32)x, V > 1, mob, mos);
-    mob += outer_off32(g, mo, (u32)o) + j0 * mo.axis;
+    if (uo) mobu = outer_off32(g, mo, (u32)o) + j0 * mo.axis;
+    else {
+      inner_off_step32(g, mo, (u32)x, V > 1, mob, mos);
+      mob += outer_off32(g, mo, (u32)o) + j0 * mo.axis;
+    }
   }
 
   // padded index k = j0 + u  ->  input row q (wave-uniform), fill flag
@@ -498,12 +506,12 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
   }
   if (HAS_MI) {
 #pragma unroll
-    for (int u = 0; u <= SEG; ++u) wm[u] = ldmv(m_in, mib + qq[u] * mi.axis, mis);
+    for (int u = 0; u <= SEG; ++u) wm[u] = ui ? splat<T>(m_in[mibu + qq[u] * mi.axis]) : ldmv(m_in, mib + qq[u] * mi.axis, mis);
   }
   T dm[SEG];  // divisors: loaded with the field rows, before the first operation
   if (HAS_MO) {
 #pragma unroll
-    for (int u = 0; u < SEG; ++u) dm[u] = ldmv(m_out, mob + ((u < nrow) ? u : 0) * mo.axis, mos);
+    for (int u = 0; u < SEG; ++u) dm[u] = uo ? splat<T>(m_out[mobu + ((u < nrow) ? u : 0) * mo.axis]) : ldmv(m_out, mob + ((u < nrow) ? u : 0) * mo.axis, mos);
   }
 #pragma unroll
   for (int kz = 0; kz < ZK; ++kz) {
@@ -885,7 +893,16 @@ int launch_seg_n(const StencilCall& c) {
   if (per_outer > MAX_ITEMS) return launch_march<OP, V, MET>(c);  // (never the case below 2^31 cells per outer index)
   const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
   const u64 outer_per = MAX_ITEMS / per_outer;
-  const int mal = (V > 1 && MET != 0 && metric_vec_ok(c.g, c.m_in, c.mi) && metric_vec_ok(c.g, c.m_out, c.mo)) ? 1 : 0;
+  int mal = (V > 1 && MET != 0 && metric_vec_ok(c.g, c.m_in, c.mi) && metric_vec_ok(c.g, c.m_out, c.mo)) ? 1 : 0;
+  // a metric that does not vary along the lanes (drF(Z) under a (Z, Y, X) field, the usual vertical metric): one value
+  // per row, wave-uniform -- a scalar load instead of a vector load of 64 equal addresses (bits 1 / 2: m_in / m_out)
+  auto row_uniform = [&](const real* m, const MIdx& mm) {
+    if (!m) return false;
+    for (int d = 0; d < c.g.n_inner; ++d)
+      if (mm.inner[d] != 0) return false;
+    return true;
+  };
+  if (tune().met_scalar && MET != 0) mal |= (row_uniform(c.m_in, c.mi) ? 2 : 0) | (row_uniform(c.m_out, c.mo) ? 4 : 0);
   // z-banding: a single outer dim along which every metric is broadcast, one launch (bands of 16 rows)
   // band height: `zb_rows` rows when two metrics share the XCD's L2, twice that for one -- a band boundary costs one
   // halo-row re-read from HBM per level (PMC: +6 % reads at 16 rows), a band must stay L2-resident for all levels
