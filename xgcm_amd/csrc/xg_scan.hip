@@ -647,23 +647,28 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
 // K4: weighted sum along a STRIDED axis: one lane per output column pair, sequential in k
 // (bit-exact with numpy's reduction over a non-last axis).
 // ------------------------------------------------------------------------------------------
-template <int V, bool HAS_W, bool NTL, int U, bool PIPE = false>
+// WMODE: 0 no weights, 1 a weight per cell of the row, 2 ONE weight per row (drF(Z) under (Z, Y, X): wave-uniform, read
+// through the scalar cache; nothing rides in the window)
+template <int V, int WMODE, bool NTL, int U, bool PIPE = false>
 __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, int skipna,
     const real* __restrict__ wgt, MIdx mw, int band) {
   typedef typename VecT<V>::type T;
+  constexpr bool HAS_W = WMODE != 0, WU = WMODE == 2;
   // U independent loads in flight per lane
   const u64 w = band ? banded_wave_id() : wave_id();
   const u32 tile = (u32)(w % ntile);
-  const int64_t o = (int64_t)(w / ntile);
+  int64_t o = (int64_t)(w / ntile);
   if (o >= g.outer) return;
+  if (WU) o = (int64_t)__builtin_amdgcn_readfirstlane((u32)o);  // (host: outer < 2^32) the division ran on the vector unit
   const int lane = threadIdx.x & 63;
   const int64_t x = ((int64_t)tile * WAVE + lane) * V;
   if (x >= g.inner) return;
   const int64_t inner = g.inner, n = g.n_in;
   const real* pin = in + (o * n) * inner + x;
   int64_t mb = 0, ms = 0;
-  if (HAS_W) {
+  if (WU) mb = outer_off(g, mw, o);
+  else if (HAS_W) {
     mb = outer_off(g, mw, o) + inner_off(g, mw, x);
     ms = (V > 1) ? inner_off(g, mw, x + 1) - inner_off(g, mw, x) : 0;
   }
@@ -675,7 +680,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
   if (pair) skipna -= 2;
   const bool mean = skipna >= 4;
   // the weight of a row is loaded WITH the row (same window / batch), not inside `step` (see k_cumsum_strided)
-  auto ldw = [&](int64_t k) -> T { return HAS_W ? ldm<T>(wgt, mb + k * mw.axis, ms) : splat<T>(real(1)); };
+  auto ldw = [&](int64_t k) -> T {
+    if (WU) return splat<T>(wgt[mb + k * mw.axis]);
+    return HAS_W ? ldm<T>(wgt, mb + k * mw.axis, ms) : splat<T>(real(1));
+  };
   auto step = [&](int64_t k, T v, T wv) {
     if (mean) {  // the two sums of modes 1 / 0 (numerator) and 2 / 3 (denominator), same order, same bits
       T d = as_count(v, skipna == 4 ? 2 : 3);
@@ -693,45 +701,45 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
   };
   int64_t k = 0;
   if (PIPE) {  // rolling window of U loads (see k_cumsum_strided)
-    constexpr int UW = HAS_W ? U : 1;
+    constexpr int UW = (HAS_W && !WU) ? U : 1;
     T v[U], wv[UW];
 #pragma unroll
     for (int u = 0; u < U; ++u)
       if (u < n) {
         v[u] = ldg<T, NTL>(pin + (int64_t)u * inner);
-        if (HAS_W) wv[u % UW] = ldw(u);
+        if (HAS_W && !WU) wv[u % UW] = ldw(u);
       }
     for (; k + 2 * U <= n; k += U) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const T x = v[u], xw = HAS_W ? wv[u % UW] : splat<T>(real(1));
+        const T x = v[u], xw = WU ? ldw(k + u) : HAS_W ? wv[u % UW] : splat<T>(real(1));
         v[u] = ldg<T, NTL>(pin + (k + U + u) * inner);
-        if (HAS_W) wv[u % UW] = ldw(k + U + u);
+        if (HAS_W && !WU) wv[u % UW] = ldw(k + U + u);
         step(k + u, x, xw);
       }
     }
     for (; k < n; k += U) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const T x = v[u], xw = HAS_W ? wv[u % UW] : splat<T>(real(1));
+        const T x = v[u], xw = (WU && k + u < n) ? ldw(k + u) : (HAS_W && !WU) ? wv[u % UW] : splat<T>(real(1));
         if (k + U + u < n) {
           v[u] = ldg<T, NTL>(pin + (k + U + u) * inner);
-          if (HAS_W) wv[u % UW] = ldw(k + U + u);
+          if (HAS_W && !WU) wv[u % UW] = ldw(k + U + u);
         }
         if (k + u < n) step(k + u, x, xw);
       }
     }
   } else {
   for (; k + U <= n; k += U) {
-    constexpr int UW = HAS_W ? U : 1;
+    constexpr int UW = (HAS_W && !WU) ? U : 1;
     T v[U], wv[UW];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       v[u] = ldg<T, NTL>(pin + (k + u) * inner);
-      if (HAS_W) wv[u % UW] = ldw(k + u);
+      if (HAS_W && !WU) wv[u % UW] = ldw(k + u);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) step(k + u, v[u], HAS_W ? wv[u % UW] : splat<T>(real(1)));
+    for (int u = 0; u < U; ++u) step(k + u, v[u], WU ? ldw(k + u) : HAS_W ? wv[u % UW] : splat<T>(real(1)));
   }
   for (; k < n; ++k) step(k, ldg<T, NTL>(pin + k * inner), ldw(k));
   }
@@ -1116,8 +1124,13 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     if ((rc = check_grid(nblocks))) return rc;
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
     const int rband = tune().march_band;
+    // one weight per row (no inner stride: drF(Z) under (Z, Y, X), dy(Y) under (Z, Y, X)): scalar loads, nothing rides
+    // in the window -- the march then streams like the unweighted one (sum along Y 55 -> 78 %; the chain below: 62 %)
+    bool wu = w && tune().met_scalar && g.outer < 0xffffffffll;
+    for (int d = 0; d < g.n_inner; ++d)
+      if (w && mw.inner[d] != 0) wu = false;
     // K4c: the long weighted march as a chained flat launch (the unweighted one already streams at 80 %)
-    if (w && tune().scan_chain && tune().nt_load && g.inner % HV == 0 && (reinterpret_cast<uintptr_t>(in) & 7u) == 0 &&
+    if (w && !wu && tune().scan_chain && tune().nt_load && g.inner % HV == 0 && (reinterpret_cast<uintptr_t>(in) & 7u) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (HV == 1 || vec_metric_ok(g, true))) {
       bool shared_w = true;
       for (int d = 0; d < g.n_outer; ++d)
@@ -1135,16 +1148,16 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     }
 #define XG_GL(V_, W_, NTL_) do { if (deep) hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, rband); \
                            else hipLaunchKernelGGL((k_reduce_strided<V_, W_, NTL_, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, rband); } while (0)
-    const int su = w ? (tune().scan_u < 8 ? tune().scan_u : 8) : tune().scan_u;  // weights ride in the window: 8 rows (registers)
+    const int su = (w && !wu) ? (tune().scan_u < 8 ? tune().scan_u : 8) : tune().scan_u;  // weights ride in the window: 8 rows (registers)
     const int pipe = (tune().scan_pipe && tune().nt_load) ? (deep ? (su >= 32 ? 32 : su >= 24 ? 24 : su >= 16 ? 16 : 8) : (tune().scan_pipe >= 2 ? 8 : 0)) : 0;
 #define XG_PL(V_, W_, U_) hipLaunchKernelGGL((k_reduce_strided<V_, W_, true, U_, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, skipna, w, mw, rband)
 #define XG_GO(V_, W_) do { if (pipe == 32) XG_PL(V_, W_, 32); else if (pipe == 24) XG_PL(V_, W_, 24); else if (pipe == 16) XG_PL(V_, W_, 16); else if (pipe == 8) XG_PL(V_, W_, 8); \
                            else if (tune().nt_load) XG_GL(V_, W_, true); else XG_GL(V_, W_, false); } while (0)
 #ifdef XG_F32
-    if (V == HV) { if (w) XG_GO(HV, true); else XG_GO(HV, false); } else
+    if (V == HV) { if (wu) XG_GO(HV, 2); else if (w) XG_GO(HV, 1); else XG_GO(HV, 0); } else
 #endif
-    if (V > 1) { if (w) XG_GO(NV, true); else XG_GO(NV, false); }
-    else { if (w) XG_GO(1, true); else XG_GO(1, false); }
+    if (V > 1) { if (wu) XG_GO(NV, 2); else if (w) XG_GO(NV, 1); else XG_GO(NV, 0); }
+    else { if (wu) XG_GO(1, 2); else if (w) XG_GO(1, 1); else XG_GO(1, 0); }
 #undef XG_GO
 #undef XG_PL
   }
