@@ -164,7 +164,7 @@ def test_cumsum_chained_chunks(dev, dtype):
     direction / NaN mode, ragged last chunks, metrics, several columns per XCD band -- bit-identical to the
     sequential numpy order, and twice in a row (the workspace must come back clean)."""
     from xgcm_amd import _hip
-    before = _hip.get_tunable("scan_chain")
+    before, before_zl = _hip.get_tunable("scan_chain"), _hip.get_tunable("reduce_zl")
     _hip.set_tunable("scan_chain", 2)
     try:
         for shape in ((3, 300, 128), (2, 70, 130), (5, 64, 66), (1, 33, 2), (9, 97, 700)):
@@ -195,10 +195,13 @@ def test_cumsum_chained_chunks(dev, dtype):
                 _hip.set_tunable("scan_chain", 0)
                 ref = dev.tohost(dev.reduce1d(a, axis, w, mode))
                 _hip.set_tunable("scan_chain", 2)
-                for _ in range(2):
-                    _eq(dev.tohost(dev.reduce1d(a, axis, w, mode)), ref)
+                for zl in (1, 2, 4):  # levels per task sharing the weight rows (K4c / K4cz)
+                    _hip.set_tunable("reduce_zl", zl)
+                    for _ in range(2):
+                        _eq(dev.tohost(dev.reduce1d(a, axis, w, mode)), ref)
     finally:
         _hip.set_tunable("scan_chain", before)
+        _hip.set_tunable("reduce_zl", before_zl)
 
 
 def test_cumsum_metric(dev):

@@ -44,6 +44,7 @@ const TuneEntry TUNABLES[] = {
     {"scan_pace", &Tune::scan_pace, 0},
     {"scan_chain", &Tune::scan_chain, 1},
     {"scan_chain_w", &Tune::scan_chain_w, 1},
+    {"reduce_zl", &Tune::reduce_zl, 2},
     {"dbg", &Tune::dbg, 0},
     {"march_lds_kb", &Tune::march_lds_kb, 0},
 };

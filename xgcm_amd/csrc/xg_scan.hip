@@ -855,6 +855,105 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_chain(
   }
 }
 
+// K4cz: K4c with the weights of a chunk loaded ONCE for ZL consecutive outer indices ("levels").  PMC on K4c
+// (tools/pmc_sumyw.sh): its HBM traffic is the minimum (the field once, the weights once per XCD), yet it stops at
+// 57 % -- what it saturates is the L2 -> CU path, which carries the field AND, for every level again, the weights
+// (9.8 TB/s; the unweighted sum moves 6.4).  A task = (x-tile, chunk of R rows, ZL levels): R weight rows + ZL x R field
+// rows in registers, then level after level: wait for that level's running sum, add the R rows in order, publish.
+// Same additions in the same order as the march: same bits.
+template <int R, int ZL>
+__global__ __launch_bounds__(BLOCK) void k_reduce_chain_z(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, int skipna,
+    const real* __restrict__ wgt, MIdx mw, ChainArgs ch) {
+  constexpr int V = HV;
+  typedef typename VecT<V>::type T;
+  u32 c, og, tile;
+  if (!chain_task(ch, ntile, c, og, tile)) return;
+  const int lane = threadIdx.x & 63;
+  const u32 lx = tile * WAVE + lane;
+  const int64_t x = (int64_t)lx * V;
+  if (x >= g.inner) return;
+  const int64_t inner = g.inner, n = g.n_in;
+  const u32 xo = lx * V;
+  const u32 o_first = og * ZL;
+  const int nlev = (g.outer - (int64_t)o_first < ZL) ? (int)(g.outer - o_first) : ZL;  // wave-uniform
+  // (host: the weights do not depend on the outer index)
+  const int64_t mb = inner_off(g, mw, x);
+  const int64_t ms = (V > 1) ? inner_off(g, mw, x + 1) - inner_off(g, mw, x) : 0;
+  const bool pair = skipna >= 6;
+  if (pair) skipna -= 2;
+  const bool mean = skipna >= 4;
+  const u32 np = mean ? 2u : 1u;
+  const int64_t k0 = (int64_t)c * R;
+  const int rows = (n - k0 < R) ? (int)(n - k0) : R;
+  T wv[R], v[ZL][R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t k = k0 + ((r < rows) ? r : rows - 1);  // a short last chunk repeats its last row (not added)
+    wv[r] = ldm<T>(wgt, mb + k * mw.axis, ms);
+  }
+#pragma unroll
+  for (int kz = 0; kz < ZL; ++kz) {
+    const int64_t o = o_first + ((kz < nlev) ? kz : nlev - 1);
+    const real* pin = in + (o * n) * inner;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t k = k0 + ((r < rows) ? r : rows - 1);
+      v[kz][r] = ldg<T, true>(pin + k * inner + xo);
+    }
+  }
+  u32x4* ring = reinterpret_cast<u32x4*>(ch.slots);
+#pragma unroll
+  for (int kz = 0; kz < ZL; ++kz) {
+    if (kz >= nlev) break;
+    const u32 o32 = o_first + kz;
+    T acc = splat<T>(real(0)), den = splat<T>(real(0));
+    if (c > 0) {
+      const u32x4* src = ring + (((size_t)o32 * 2 + ((c - 1) & 1)) * ch.srow + lx) * np;
+      acc = chain_unpack<T>(chain_wait(src, c, ch.gave_up));
+      if (mean) den = chain_unpack<T>(chain_wait(src + 1, c, ch.gave_up));
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (r < rows) {
+        T x1 = v[kz][r];
+        const T w1 = wv[r];
+        const bool first = (c == 0 && r == 0);
+        if (mean) {  // k_reduce_strided's `step`, same operations in the same order
+          T dd = as_count(x1, skipna == 4 ? 2 : 3);
+          dd = dd * w1;
+          x1 = x1 * w1;
+          if (skipna == 4) x1 = nan0(x1);
+          dd = nan0(dd);
+          den = first ? dd : den + dd;
+        } else {
+          if (skipna >= 2) x1 = as_count(x1, skipna);
+          x1 = x1 * w1;
+          if (skipna) x1 = nan0(x1);
+        }
+        acc = first ? x1 : acc + x1;
+      }
+    }
+    if (c + 1 < ch.nchunk) {
+      u32x4* dst = ring + (((size_t)o32 * 2 + (c & 1)) * ch.srow + lx) * np;
+      dst[0] = chain_pack<T>(acc, c + 1);
+      if (mean) dst[1] = chain_pack<T>(den, c + 1);
+    } else {
+      if (ch.nchunk > 1) {
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+        for (u32 par = 0; par < 2; ++par)
+          for (u32 p = 0; p < np; ++p) ring[(((size_t)o32 * 2 + par) * ch.srow + lx) * np + p] = zero;
+      }
+      if (pair) {
+        *reinterpret_cast<T*>(out + (int64_t)o32 * inner + xo) = acc;
+        *reinterpret_cast<T*>(out + (g.outer + (int64_t)o32) * inner + xo) = den;
+      } else {
+        *reinterpret_cast<T*>(out + (int64_t)o32 * inner + xo) = mean ? acc / den : acc;
+      }
+    }
+  }
+}
+
 // K4b: weighted sum along the CONTIGUOUS axis: one wave per row, lane-strided partial sums then
 // a shuffle tree (tolerance parity; numpy itself is pairwise here).
 template <bool HAS_W, bool VEC>
@@ -945,8 +1044,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
 // not fit the 32-bit task arithmetic, the device's workgroup -> XCD mapping was not confirmed, or the workspace cannot
 // be had (the caller then takes the marching kernel; an allocation failure leaves its message in xg_last_error).
 // R = rows per chunk (16 halves the registers but doubles the links of every chain: 63 % against 69 %).
-bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void* stream, ChainArgs* ch, u32* ctile_out, u64* nblk_out) {
-  const u64 lanes = (u64)g.inner / HV, ctile = (lanes + WAVE - 1) / WAVE, ncol = ctile * (u64)g.outer;
+bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void* stream, ChainArgs* ch, u32* ctile_out, u64* nblk_out,
+                int zl = 1) {
+  // zl: outer indices ("levels") one task carries for its x-tile; a column of the plan is then (level group, x-tile)
+  const u64 lanes = (u64)g.inner / HV, ctile = (lanes + WAVE - 1) / WAVE, ncol = ctile * (((u64)g.outer + zl - 1) / zl);
   const u64 nchunk = ((u64)g.n_in + R - 1) / R;
   const bool wanted = tune().scan_chain >= 2 ? nchunk >= 2 : (g.n_in >= 256 && ncol < (u64)tune().deep_waves);
   const u64 slot_bytes = (u64)g.outer * 2 * lanes * 16 * (u64)sums_per_lane;
@@ -1140,6 +1241,14 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
       ChainArgs ch;
       u32 ctile = 0;
       u64 nblk = 0;
+      const int zl = tune().reduce_zl;  // levels per task sharing the weight rows (K4cz); 1: K4c
+      // (measured: 2 levels x 16 rows 61-63 %, 3 x 16 59 %, 4 x 16 55 %, 4 x 8 59 %, 2 x 32 50 %, K4c 56-57 %, the march 51 %)
+      if (shared_w && zl >= 2 && g.outer >= 2 && chain_plan(g, 16, skipna >= 4 ? 2 : 1, shared_w, stream, &ch, &ctile, &nblk, zl >= 4 ? 4 : 2)) {
+        if (zl >= 4) hipLaunchKernelGGL((k_reduce_chain_z<16, 4>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, ctile, skipna, w, mw, ch);
+        else hipLaunchKernelGGL((k_reduce_chain_z<16, 2>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, ctile, skipna, w, mw, ch);
+        XG_LAUNCH_CHECK();
+        return XG_OK;
+      }
       if (shared_w && chain_plan(g, 32, skipna >= 4 ? 2 : 1, shared_w, stream, &ch, &ctile, &nblk)) {
         hipLaunchKernelGGL((k_reduce_chain<true, 32>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, ctile, skipna, w, mw, ch);
         XG_LAUNCH_CHECK();
