@@ -16,12 +16,18 @@ Pinning status
 * `seam_partner`, pivot aliases, fold-spec validation: pinned against outputs of the REAL reference
   functions (`_seam_partner_indices`, `_resolve_pivot`, `_parse_fold_padding` import and run under
   oracle/make_golden.py's placeholder modules) -> tests/golden/fold_reference.json.
-* fold halos / face-connection halos as a whole: the reference implementation needs xarray
-  (absent), so these are pinned by the explicit known answers of the reference's own tests
-  (xgcm/test/test_fold.py, test_faceconnections.py, test_padding.py:341-1205), restated with
-  numpy in tests/test_topology.py.
-* Deviation shared with the product: the reference iterates the padded axes in `set` (hash) order;
-  here the order is the caller's `pad_axes` list.  Only corner cells can depend on it.
+* fold halos / face-connection halos as a whole: pinned against outputs of the REAL reference functions
+  `_pad_face_connections` and `_pad_fold`: oracle/make_golden_topology.py loads the reference's padding.py
+  unmodified, gives it a numpy-backed container for the handful of DataArray operations it uses (xarray
+  itself is absent) and records 236 seeded cases -- 2-face links of every kind, the cubed sphere, the 13-face
+  LLC topology, scalars and vector components, four width sets, three boundary modes; every fold pivot x
+  position x width, scalar and vector, including the cases that must raise ->
+  tests/golden/topology_reference.{npz,json}, tests/test_topology.py::test_oracle_topology_equals_reference_outputs.
+  The explicit known answers of the reference's own tests (xgcm/test/test_fold.py, test_faceconnections.py,
+  test_padding.py:341-1205), restated with numpy in tests/test_topology.py, stay as a second pin.
+* The reference iterates the padded axes in `set` (hash) order (padding.py:305-307), so where the halos of
+  two axes overlap (corners) ITS OWN output depends on PYTHONHASHSEED; here the order is the caller's
+  `pad_axes` list, and the golden vectors were recorded under a hash seed that gives the same order (X, Y).
 
 `gather_tokens` is the numpy decode of the product's token map (the kernel's semantics), used as
 the checker of `xg_gather_f64` and by the CPU test double oracle/fake_device.py.

@@ -2,6 +2,8 @@
 
 * the reference's OWN helper outputs (tests/golden/fold_reference.json, written by
   oracle/make_golden.py from xgcm/padding.py:94-177) pin both the oracle and the product helpers;
+* the reference's OWN halo filling (tests/golden/topology_reference.*: `_pad_face_connections` / `_pad_fold` loaded
+  unmodified by oracle/make_golden_topology.py and run on seeded inputs) pins the oracle and the product on 236 cases;
 * the known answers of the reference's tests (xgcm/test/test_fold.py, test_faceconnections.py,
   test_padding.py:341-1205; file:line in each docstring) are restated with numpy and checked against
   the oracle (oracle/topology.py) AND the product (`xgcm_amd.padding.pad`, Grid operators);
@@ -269,6 +271,84 @@ def test_fold_product_equals_oracle_seeded(backend, pivot, name, widths):
                           {"X": "periodic", "Y": None}, {"X": 0.0, "Y": -7.5}, isvector)
         np.testing.assert_array_equal(got.values, want)
         assert got.dims == da.dims
+
+
+# ----------------------------------------------------------------------------------------------
+# the reference's OWN halo filling (tests/golden/topology_reference.*: xgcm/padding.py::_pad_face_connections and
+# _pad_fold, loaded unmodified and run on seeded inputs through a numpy-backed container by
+# oracle/make_golden_topology.py) vs the oracle and the product
+# ----------------------------------------------------------------------------------------------
+with open(os.path.join(GOLDEN, "topology_reference.json")) as f:
+    TOPO_REF = json.load(f)["cases"]
+TOPO_NPZ = np.load(os.path.join(GOLDEN, "topology_reference.npz"))
+
+
+def _case_id(c):
+    w = "_".join(f"{k}{v[0]}{v[1]}" for k, v in c["widths"].items())
+    if c["kind"] == "fold":
+        return f"fold-{c['pivot']}-{c['field']}-{w}-{'vec' if c['vector'] else 'sca'}"
+    return f"{c['kind']}-{c['conn']}-{c['field']}-{w}-{c['mode']}"
+
+
+@pytest.mark.parametrize("case", TOPO_REF, ids=_case_id)
+def test_oracle_topology_equals_reference_outputs(case):
+    """oracle/topology.py against what the reference's own code returned (not against a restatement)."""
+    pw = {k: tuple(v) for k, v in case["widths"].items()}
+    if case["kind"] == "fold":
+        a = TOPO_NPZ["in/fold/field"]
+        dd = case["dims"]
+        pos = {"X": "center" if dd[1] == "xh" else "left", "Y": "center" if dd[0] == "yh" else "left"}
+        args = (a, {"X": 3, "Y": 2}, pos, "Y", "X", _roles(pole_on_edges(case["pivot"], "Y", "X")), "fill", pw,
+                {"X": "periodic", "Y": None}, case["fill"], case["vector"])
+        if "raises" in case:
+            with pytest.raises((NotImplementedError, ValueError)):
+                T.pad_fold(*args)
+            return
+        np.testing.assert_array_equal(T.pad_fold(*args), TOPO_NPZ[case["out"]])
+        return
+    conn = {"x2x": X_TO_X, "x2y": X_TO_Y, "x2y_rev": X_TO_Y_REV, "x2x_rev": X_TO_X_REV, "cubed_sphere": CUBED_SPHERE, "llc": LLC}[case["conn"]]
+    dims_of = {"data_c": ("face", "y", "x"), "u": ("face", "xl", "y"), "v": ("face", "x", "yl")}
+    a = TOPO_NPZ[f"in/{case['conn']}/{case['field']}"]
+    dims = dims_of[case["field"]]
+    ax_dim = lambda dd: {"X": [d for d in ("x", "xl") if d in dd][0], "Y": [d for d in ("y", "yl") if d in dd][0]}  # noqa: E731
+    kw = {}
+    if case["kind"] == "faces_vector":
+        other = TOPO_NPZ[f"in/{case['conn']}/{case['other']}"]
+        kw = dict(partner=other, partner_dims=dims_of[case["other"]], vectoraxis=case["axis"], partner_axis_dim=ax_dim(dims_of[case["other"]]))
+    got = T.pad_face_connections(a, dims, "face", ax_dim(dims), conn["face"], ["X", "Y"], pw, {"X": case["mode"], "Y": case["mode"]},
+                                 case["fill"], **kw)
+    np.testing.assert_array_equal(got, TOPO_NPZ[case["out"]])
+
+
+@pytest.mark.parametrize("case", TOPO_REF, ids=_case_id)
+def test_product_topology_equals_reference_outputs(backend, case):
+    """`xgcm_amd.padding.pad` (token map + gather; on the GPU through xg_gather_*) against the reference's outputs."""
+    pw = {k: tuple(v) for k, v in case["widths"].items()}
+    if case["kind"] == "fold":
+        a = TOPO_NPZ["in/fold/field"]
+        da = DataArray(a, dims=("time", "z") + tuple(case["dims"]))
+        grid = _fold_grid(_fold_ds(), case["pivot"])
+        arg = {("X" if case["field"] == "u" else "Y"): da} if case["vector"] else da
+        if "raises" in case:
+            with pytest.raises((NotImplementedError, ValueError)):
+                pad(arg, grid, padding_width=dict(pw), fill_value=case["fill"])
+            return
+        got = pad(arg, grid, padding_width=dict(pw), fill_value=case["fill"])
+        np.testing.assert_array_equal(got.values, TOPO_NPZ[case["out"]])
+        return
+    conn = {"x2x": X_TO_X, "x2y": X_TO_Y, "x2y_rev": X_TO_Y_REV, "x2x_rev": X_TO_X_REV, "cubed_sphere": CUBED_SPHERE, "llc": LLC}[case["conn"]]
+    dims_of = {"data_c": ("face", "y", "x"), "u": ("face", "xl", "y"), "v": ("face", "x", "yl")}
+    nf = len(conn["face"])
+    n = TOPO_NPZ[f"in/{case['conn']}/data_c"].shape[-1]
+    ds = Dataset({k: (list(dims_of[k]), TOPO_NPZ[f"in/{case['conn']}/{k}"]) for k in dims_of},
+                 coords={"x": np.arange(n), "xl": np.arange(n) - 0.5, "y": np.arange(n), "yl": np.arange(n) - 0.5, "face": np.arange(nf)})
+    grid = Grid(ds, coords=COORDS, face_connections=conn, autoparse_metadata=False)
+    if case["kind"] == "faces_scalar":
+        got = pad(ds[case["field"]], grid, padding_width=dict(pw), padding=case["mode"], fill_value=case["fill"])
+    else:
+        got = pad({case["axis"]: ds[case["field"]]}, grid, padding_width=dict(pw), padding=case["mode"], fill_value=case["fill"],
+                  other_component={case["other_axis"]: ds[case["other"]]})
+    np.testing.assert_array_equal(got.values, TOPO_NPZ[case["out"]])
 
 
 # ----------------------------------------------------------------------------------------------
