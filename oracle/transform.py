@@ -16,6 +16,13 @@ Pinning status
 * the `cases` table of the reference's test-suite (xgcm/test/test_transform.py:40-686: inputs and
   expected outputs, 24 cases) is evaluated in the build container by oracle/make_golden.py and
   committed as tests/golden/transform_cases.json;
+* the BODIES of the two gufuncs are plain Python over numpy scalars and `np.interp`: oracle/make_golden_transform.py
+  loads the reference's transform.py unmodified with a stand-in `numba` whose `guvectorize` runs the body column by
+  column, and records what `interp_1d_linear` / `interp_1d_conservative` return on the seeded hard columns of
+  tests/test_transform.py (NaN head / tail / holes, duplicates, decreasing, non-monotonic; float64 and float32; every
+  mask_edges / bypass_checks combination, logarithmic, increasing / decreasing / fine bins) ->
+  tests/golden/transform_kernels_reference.npz, tests/test_transform.py::test_transform_kernels_equal_reference_kernel_outputs
+  (this oracle AND the product, bit-exact; float32 log within the stated tolerance);
 * the low-level property tests of the same file (:849-921) are re-created in tests/test_transform.py;
 * parity unpinned: behaviour on an all-NaN theta column (numba indexes an empty array there,
   undefined); here such a column is neither flipped nor masked.

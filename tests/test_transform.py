@@ -376,6 +376,54 @@ def test_linear_kernel_equals_numpy_interp(backend, kind, dtype):
                                equal_nan=True)  # float32: 1-ulp log differences, amplified by steep slopes
 
 
+KERNEL_REF = np.load(os.path.join(os.path.dirname(__file__), "golden", "transform_kernels_reference.npz"))
+
+
+def _kernel_ref_cases(dn, kind):
+    """(what, args, reference output) for every recorded call of the reference's own kernel bodies
+    (oracle/make_golden_transform.py: xgcm/transform.py loaded unmodified, its numba gufuncs run column by column)."""
+    g = lambda k: KERNEL_REF[f"{dn}/{kind}/{k}"]  # noqa: E731
+    phi = KERNEL_REF[f"{dn}/phi"]
+    for ln in ("levels", "clean"):
+        for mask in (False, True):
+            for bypass in (False, True):
+                key = f"{dn}/{kind}/{ln}/linear/m{int(mask)}b{int(bypass)}"
+                if key in KERNEL_REF.files:
+                    yield "linear", (phi, g("theta"), g(ln)), dict(mask_edges=mask, bypass_checks=bypass), KERNEL_REF[key]
+    if f"{dn}/{kind}/log/linear" in KERNEL_REF.files:
+        yield "log", (phi, g("log_theta"), g("log_levels")), dict(mask_edges=True, logarithmic=True), g("log/linear")
+    for bn in ("inc", "dec", "fine"):
+        ref = g(f"conservative/{bn}")
+        if bn == "dec":  # the reference flips axis 0 of the N-D result (transform.py:190-192); here the bin axis (DESIGN.md section 2)
+            ref = ref[::-1][..., ::-1]
+        yield "conservative", (phi, g("theta_outer"), g(f"bins_{bn}")), {}, ref
+
+
+@pytest.mark.parametrize("kind", ["increasing", "decreasing", "duplicates", "nan_tail", "nan_head", "nan_holes", "nonmonotonic"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_transform_kernels_equal_reference_kernel_outputs(backend, kind, dtype):
+    """Oracle AND product against the outputs of the reference's own `_interp_1d_linear` / `_interp_1d_conservative`
+    bodies on the hard columns (NaN head / tail / holes, duplicates, non-monotonic), both dtypes."""
+    dn = np.dtype(dtype).name
+    n = 0
+    for what, args, kw, ref in _kernel_ref_cases(dn, kind):
+        n += 1
+        assert ref.dtype == dtype
+        if what == "conservative":
+            np.testing.assert_array_equal(TR.interp_1d_conservative(*args), ref)
+            np.testing.assert_array_equal(X.interp_1d_conservative(*args), ref)
+        elif what == "log" and dtype == np.float32:  # log in double, rounded once (DESIGN.md deviations): tolerance
+            for f in (TR.interp_1d_linear, X.interp_1d_linear):
+                np.testing.assert_allclose(f(*args, **kw), ref, rtol=5e-3, atol=1e-4, equal_nan=True)
+        elif what == "log":
+            np.testing.assert_array_equal(TR.interp_1d_linear(*args, **kw), ref)
+            np.testing.assert_allclose(X.interp_1d_linear(*args, **kw), ref, rtol=1e-12, atol=0, equal_nan=True)  # device log: 1 ulp
+        else:
+            np.testing.assert_array_equal(TR.interp_1d_linear(*args, **kw), ref)
+            np.testing.assert_array_equal(X.interp_1d_linear(*args, **kw), ref)
+    assert n >= 4
+
+
 @pytest.mark.parametrize("kind", ["increasing", "decreasing", "duplicates", "nan_tail", "nan_head", "nan_holes", "nonmonotonic"])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_conservative_kernel_equals_oracle(backend, kind, dtype):
