@@ -204,6 +204,33 @@ def test_cumsum_chained_chunks(dev, dtype):
         _hip.set_tunable("reduce_zl", before_zl)
 
 
+def test_chained_scans_on_two_streams(dev):
+    """The chained kernels keep their hand-off slots and ticket counters in a workspace PER STREAM: two streams running
+    long scans / weighted reductions at the same time do not see each other's running sums."""
+    import torch
+
+    shape = (6, 1200, 256)
+    a = dev.asdevice(_field(shape, 31, nan=True))
+    b = dev.asdevice(_field(shape, 32))
+    w = dev.asdevice(R.synthetic_metric((1,) + shape[1:], 33))
+    want = [dev.tohost(dev.cumsum1d(a, 1, 0, 1, 1, 0, "extend", 0.0, False, True)), dev.tohost(dev.reduce1d(b, 1, w, "mean_valid")),
+            dev.tohost(dev.cumsum1d(b, 1, 1, 0, 0, 1, "periodic", 0.0, True, True, w, None))]
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    got = []
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            g0 = dev.cumsum1d(a, 1, 0, 1, 1, 0, "extend", 0.0, False, True)
+        with torch.cuda.stream(s2):
+            g1 = dev.reduce1d(b, 1, w, "mean_valid")
+            g2 = dev.cumsum1d(b, 1, 1, 0, 0, 1, "periodic", 0.0, True, True, w, None)
+        got.append((g0, g1, g2))
+    torch.cuda.synchronize()
+    for g in got:
+        for x, y in zip(g, want):
+            _eq(dev.tohost(x), y)
+
+
 def test_cumsum_metric(dev):
     shape = (4, 9, 6, 34)
     a = _field(shape, 9)

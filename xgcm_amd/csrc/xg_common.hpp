@@ -141,6 +141,8 @@ inline const Tune& tune() { return *xg_internal_tune(); }
 struct ChainWs { void* slots; u32* ticket; u32* gave_up; };
 extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ws(void* stream, u64 slot_bytes, ChainWs* ws);
 extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ok(void);
+// 1 exactly once after a wave has given up: the entry points that may have produced the damaged result report it loudly
+extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_poisoned(void);
 
 // ------------------------------------------------------------------------------------------
 // geometry: a C-contiguous N-D array seen as (outer..., n, inner...) around the op axis,

@@ -119,6 +119,16 @@ extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ok(void) 
   return ok;
 }
 
+extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_poisoned(void) {
+  ChainState& cs = chain_state();
+  std::lock_guard<std::mutex> lock(cs.mu);
+  if (cs.gave_up_host && *cs.gave_up_host == 1) {
+    *cs.gave_up_host = 2;  // reported; xg_internal_chain_ok() keeps answering 0
+    return 1;
+  }
+  return 0;
+}
+
 extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ws(void* stream, u64 slot_bytes, ChainWs* out) {
   ChainState& cs = chain_state();
   std::lock_guard<std::mutex> lock(cs.mu);

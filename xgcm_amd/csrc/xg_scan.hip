@@ -1084,6 +1084,9 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
                     const int64_t* m_out_strides, void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if ((trim_lo | trim_hi | pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "trim/pad widths must be 0 or 1");
+  if (xg_internal_chain_poisoned())
+    return fail(XG_ERR_HIP, "an earlier chained scan / reduction on this device gave up waiting for a predecessor chunk: its result is invalid; "
+                            "the library has switched to the marching kernels (XG_SCAN_CHAIN=0 avoids the chained kernels from the start)");
   if (bc < XG_BC_NONE || bc > XG_BC_EXTEND) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
   if ((pad_lo || pad_hi) && bc == XG_BC_NONE) return fail(XG_ERR_INVALID, "halo cells requested but no boundary mode given");
   if ((m_in && !m_in_strides) || (m_out && !m_out_strides)) return fail(XG_ERR_INVALID, "metric without strides");
@@ -1186,6 +1189,9 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
                     const real* w, const int64_t* w_strides, void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (w && !w_strides) return fail(XG_ERR_INVALID, "weight without strides");
+  if (xg_internal_chain_poisoned())
+    return fail(XG_ERR_HIP, "an earlier chained scan / reduction on this device gave up waiting for a predecessor chunk: its result is invalid; "
+                            "the library has switched to the marching kernels (XG_SCAN_CHAIN=0 avoids the chained kernels from the start)");
   if (skipna < 0 || skipna > 7) return fail(XG_ERR_INVALID, "skipna / count / mean mode %d not in [0,7]", skipna);
   Geo g; MIdx mw;
   int rc = build_geo(shape, ndim, axis, 1, w ? w_strides : nullptr, nullptr, &g, &mw, nullptr);
