@@ -461,12 +461,19 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
 template <int MET, bool NTS, int BS>
 __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 nrows, ScanArgs a,
-    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo) {
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, ZBand zb, u32 nwork) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   constexpr int NW = BS / WAVE;
   __shared__ real wtot[2][NW];
-  const u32 pb = (nrows + 7) >> 3;
-  const u32 row = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);  // XCD banding over rows
+  const u32 pb = (nwork + 7) >> 3;
+  u32 row = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);  // XCD banding over the work sequence
+  if (row >= nwork) return;
+  if (zb.on) {  // metrics broadcast along the slow outer dim (cumint along X with dx(Y, X)): all levels of a band of rows
+                // before the next band, so the band's metric rows are served by the XCD's L2 instead of the fabric
+    u32 z, y;
+    if (!zband_map(zb, row, z, y)) return;
+    row = z * zb.Y + y;
+  }
   if (row >= nrows) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = (int)g.n_in, no = (int)g.n_out;  // the host selects this kernel for rows below 2^31 cells only
@@ -1106,10 +1113,22 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
     if ((rc = check_grid(nblocks + 8))) return rc;
     if (tune().scan_vec && n_out >= 3 * NV && aligned16(out) && nblocks < 0x7ffffff0ull &&
         g.n_in < 0x7fff0000ll && n_out < 0x7fff0000ll) {
-      const u32 nrows = (u32)nblocks, grid = ((nrows + 7) / 8) * 8;
+      const u32 nrows = (u32)nblocks;
+      ZBand zb = make_zband(false, 0, 0, 1);
+      u32 nwork = nrows;
+      if (met && tune().zband && g.n_outer == 2 && g.outer_shape[0] >= 2 && (!m_in || mi.outer[0] == 0) && (!m_out || mo.outer[0] == 0)) {
+        const u64 Z = (u64)g.outer_shape[0], Y = (u64)g.outer_shape[1];
+        const u32 B = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16) * ((m_in && m_out) ? 1u : 2u);
+        const u64 padded = ((Y + B - 1) / B) * B * Z;
+        if (padded < 0x7ffffff0ull) {
+          zb = make_zband(true, Z, Y, B);
+          if (zb.on) nwork = (u32)padded;
+        }
+      }
+      const u32 grid = ((nwork + 7) / 8) * 8;
       const bool nts = tune().nt_store;
       const int bs = tune().scan_block;
-#define XG_L(M, NTS_, BS_) hipLaunchKernelGGL((k_cumsum_contig_vec<M, NTS_, BS_>), dim3(grid), dim3(BS_), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo)
+#define XG_L(M, NTS_, BS_) hipLaunchKernelGGL((k_cumsum_contig_vec<M, NTS_, BS_>), dim3(grid), dim3(BS_), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo, zb, nwork)
 #define XG_B(M, NTS_) do { if (bs == 512) XG_L(M, NTS_, 512); else if (bs == 1024) XG_L(M, NTS_, 1024); else if (bs == 128) XG_L(M, NTS_, 128); else if (bs == 64) XG_L(M, NTS_, 64); else XG_L(M, NTS_, 256); } while (0)
 #define XG_M(M) do { if (nts) XG_B(M, true); else XG_B(M, false); } while (0)
       switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
