@@ -1063,7 +1063,10 @@ bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void
   ch->ncol = (u32)ncol;
   ch->cpx = (u32)((ncol + 7) / 8);
   const int lv = tune().scan_chain_w < 1 ? 1 : tune().scan_chain_w;
-  ch->W = (u32)(ctile * (u64)(lv >= 100 ? (lv - 100 < 1 ? 1 : lv - 100) : lv));
+  // whole levels side by side in a sub-band: at least ~56 chains must advance together or the hand-off latency of the
+  // 75 links of a column, not the bandwidth, sets the pace (f32 rows have half the tiles of f64 rows: two levels)
+  const u64 min_lv = tune().scan_chain_w == 1 ? (56 + ctile - 1) / ctile : 1;
+  ch->W = (u32)(ctile * (u64)(lv >= 100 ? (lv - 100 < 1 ? 1 : lv - 100) : (lv > (int)min_lv ? (u64)lv : min_lv)));
   if (shared_metric && lv < 100) ch->W = ch->cpx;  // (>= 100: experiment, sub-bands of lv - 100 levels whatever the metric)
   if (ch->W > ch->cpx) ch->W = ch->cpx;
   ch->srow = (u32)lanes;
