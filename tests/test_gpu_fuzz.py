@@ -68,9 +68,21 @@ def test_fuzz_stencil(dev, seed, dtype):
                                                            None if m_out is None else m_out.shape)
 
 
+@pytest.fixture(params=[1, 2], ids=["default-kernels", "chained-kernels-forced"])
+def scan_chain(request):
+    """The fuzz shapes are too short for the chained scans / reductions (K5c / K4c) to be picked: run them a second time
+    with the chain forced onto every strided march of two chunks or more."""
+    from xgcm_amd import _hip
+
+    before = _hip.get_tunable("scan_chain")
+    _hip.set_tunable("scan_chain", request.param)
+    yield request.param
+    _hip.set_tunable("scan_chain", before)
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f64", "f32"])
 @pytest.mark.parametrize("seed", range(8))
-def test_fuzz_cumsum_reduce(dev, seed, dtype):
+def test_fuzz_cumsum_reduce(dev, seed, dtype, scan_chain):
     rng = np.random.default_rng(2000 + seed)
     rtol, atol = (1e-12, 1e-9) if dtype == np.float64 else (3e-5, 3e-2)
     tables = [(0, 0, 0, 0), (0, 1, 1, 0), (0, 1, 0, 0), (0, 0, 1, 0), (1, 0, 0, 1), (1, 0, 0, 0), (0, 0, 0, 1)]
