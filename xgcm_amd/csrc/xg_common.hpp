@@ -114,7 +114,8 @@ struct Tune {
   int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
   int contig_rw;      // rows per wave-task of the row-wave contiguous-axis metric kernel K1r (0: flat K1)
   int rw_zshare;      // K1r: the rows of a wave-task are one row of consecutive LEVELS sharing the metric vector
-  int met_zk;         // K2S with metrics, z-banded: outer levels per wave-task sharing the metric rows (1 / 2 / 4)
+  int met_zk;         // K2S with two metrics, z-banded: outer levels per wave-task sharing the metric rows (1 / 2 / 4)
+  int met_zk1;        // the same with ONE metric (derivative: a divisor only)
   int vec_zk;         // fused vorticity / divergence with an area, z-banded: levels per wave-task sharing the area rows
   int contig_rw_mi;   // K1r rows per wave-task when an input metric rides along too (three metric loads per row)
   int met_seg;        // rows per wave-task of the strided-axis kernel K2S when metrics ride along (1 / 2 / 4)

@@ -32,9 +32,10 @@ const TuneEntry TUNABLES[] = {
     {"scan_vec", &Tune::scan_vec, 1},
     {"contig_gen", &Tune::contig_gen, 1},
     {"deep_waves", &Tune::deep_waves, 8192},  // neutral on its own, pays together with scan_narrow_below
-    {"contig_rw", &Tune::contig_rw, 4},
+    {"contig_rw", &Tune::contig_rw, 2},
     {"rw_zshare", &Tune::rw_zshare, 1},
     {"met_zk", &Tune::met_zk, 4},
+    {"met_zk1", &Tune::met_zk1, 2},
     {"vec_zk", &Tune::vec_zk, 2},
     {"contig_rw_mi", &Tune::contig_rw_mi, 8},
     {"met_seg", &Tune::met_seg, 2},
