@@ -118,7 +118,8 @@ struct Tune {
   int met_zk1;        // the same with ONE metric (derivative: a divisor only)
   int vec_zk;         // fused vorticity / divergence with an area, z-banded: levels per wave-task sharing the area rows
   int contig_rw_mi;   // K1r rows per wave-task when an input metric rides along too (three metric loads per row)
-  int met_seg;        // rows per wave-task of the strided-axis kernel K2S when metrics ride along (1 / 2 / 4)
+  int met_seg;        // rows per wave-task of the strided-axis kernel K2S with two metrics (1 / 2 / 4)
+  int met_seg1;       // the same with ONE metric
   int met_scalar;     // K2S: metrics that do not vary along the lanes (drF(Z)) through scalar loads
   int scan_pipe;      // rolling-window loads in the marching scans / reductions (0: batches of U; 2: short marches too)
   int scan_u;         // loads in flight per lane of a long march (8 / 16 / 24 / 32)

@@ -38,7 +38,8 @@ const TuneEntry TUNABLES[] = {
     {"met_zk1", &Tune::met_zk1, 2},
     {"vec_zk", &Tune::vec_zk, 2},
     {"contig_rw_mi", &Tune::contig_rw_mi, 8},
-    {"met_seg", &Tune::met_seg, 2},
+    {"met_seg", &Tune::met_seg, 4},
+    {"met_seg1", &Tune::met_seg1, 2},
     {"met_scalar", &Tune::met_scalar, 1},
     {"scan_pipe", &Tune::scan_pipe, 1},
     {"scan_u", &Tune::scan_u, 32},
