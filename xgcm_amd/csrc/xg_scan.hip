@@ -1052,11 +1052,16 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
 // be had (the caller then takes the marching kernel; an allocation failure leaves its message in xg_last_error).
 // R = rows per chunk (16 halves the registers but doubles the links of every chain: 63 % against 69 %).
 bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void* stream, ChainArgs* ch, u32* ctile_out, u64* nblk_out,
-                int zl = 1) {
+                int zl = 1, bool stores = false) {
   // zl: outer indices ("levels") one task carries for its x-tile; a column of the plan is then (level group, x-tile)
   const u64 lanes = (u64)g.inner / HV, ctile = (lanes + WAVE - 1) / WAVE, ncol = ctile * (((u64)g.outer + zl - 1) / zl);
   const u64 nchunk = ((u64)g.n_in + R - 1) / R;
-  const bool wanted = tune().scan_chain >= 2 ? nchunk >= 2 : (g.n_in >= 256 && ncol < (u64)tune().deep_waves);
+  // a long march that STORES (the scans) is better off chained however many columns there are, as long as its rows are
+  // short (few x-tiles: Y of (Z, Y, X); measured +6 ... +18 points on six shapes from 40 to 4000 outer indices, while
+  // whole-plane rows -- the Z axis -- lose 4); the weighted reductions only while the columns are few
+  // (sum(T * dy) along Y of (2000, 300, 1024): 72 % marching, 54 % chained)
+  const bool few = ncol < (u64)tune().deep_waves;
+  const bool wanted = tune().scan_chain >= 2 ? nchunk >= 2 : (g.n_in >= 256 && (few || (stores && ctile <= (u64)tune().seg_max_tiles)));
   const u64 slot_bytes = (u64)g.outer * 2 * lanes * 16 * (u64)sums_per_lane;
   if (!wanted || nchunk >= (1u << 20) || ncol >= 0x7fffffffull || slot_bytes > (1ull << 30) || !xg_internal_chain_ok()) return false;
   ch->nchunk = (u32)nchunk;
@@ -1176,7 +1181,7 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
       ChainArgs ch;
       u32 ctile = 0;
       u64 nblk = 0;
-      if (chain_plan(g, 32, 1, shared_metric, stream, &ch, &ctile, &nblk)) {
+      if (chain_plan(g, 32, 1, shared_metric, stream, &ch, &ctile, &nblk, 1, true)) {
 #define XG_C(M, R_) hipLaunchKernelGGL((k_cumsum_chain<M, R_>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, ctile, a, m_in, mi, m_out, mo, ch)
         switch (met) { case 0: XG_C(0, 32); break; case 1: XG_C(1, 32); break; case 2: XG_C(2, 32); break; default: XG_C(3, 32); }
 #undef XG_C
