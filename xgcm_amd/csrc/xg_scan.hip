@@ -1061,7 +1061,10 @@ bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void
   // whole-plane rows -- the Z axis -- lose 4); the weighted reductions only while the columns are few
   // (sum(T * dy) along Y of (2000, 300, 1024): 72 % marching, 54 % chained)
   const bool few = ncol < (u64)tune().deep_waves;
-  const bool wanted = tune().scan_chain >= 2 ? nchunk >= 2 : (g.n_in >= 256 && (few || (stores && ctile <= (u64)tune().seg_max_tiles)));
+  // (columns of 64 rows and more: +10-12 points at n = 64 ... 250; shorter ones gain 3-6 without metrics but lose with
+  // them -- a ragged single chunk -- so they stay with the march)
+  const bool wanted = tune().scan_chain >= 3 ? true : tune().scan_chain >= 2 ? nchunk >= 2
+                      : (stores && ctile <= (u64)tune().seg_max_tiles) ? g.n_in >= 64 : (g.n_in >= 256 && few);
   const u64 slot_bytes = (u64)g.outer * 2 * lanes * 16 * (u64)sums_per_lane;
   if (!wanted || nchunk >= (1u << 20) || ncol >= 0x7fffffffull || slot_bytes > (1ull << 30) || !xg_internal_chain_ok()) return false;
   ch->nchunk = (u32)nchunk;
