@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round 2, session P (final evidence): full GPU suite, smoke, bench line (plain and through RCCL with one rank), config
+# Round 2, session T (final evidence, after the last kernel changes): full GPU suite, smoke, bench line (plain and through RCCL with one rank), config
 # tables, kernel tables (f64 / f32), operator survey, rocprofv3 kernel-trace + FETCH_SIZE / WRITE_SIZE passes per
-# BASELINE config, VALU issue share.  Usage on the GPU box: bash tools/gpu_session_r02p.sh
+# BASELINE config, VALU issue share.  Usage on the GPU box: bash tools/gpu_session_final.sh
 REPO=$PWD
 OUT=$REPO/gpurun_out
-S=$OUT/r02p
+S=$OUT/r02t
 mkdir -p $S
 export TMPDIR=/tmp
 echo "== pytest -m gpu"; timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2 | tee $S/pytest_gpu.log
@@ -29,14 +29,14 @@ prof() {  # tag, command...
   cp $OUT/pmc_traffic_$tag.json $S/ 2>/dev/null
   echo "-- $tag"; head -8 $S/rocprof_summary_$tag.txt
 }
-prof r02p_bench python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline
-prof r02p_cfg3 python $REPO/tools/bench_configs.py --configs 3 --reps 5
-prof r02p_cfg4 python $REPO/tools/bench_configs.py --gpus 1 --configs 4 --records 16 --batch-records 8
-prof r02p_cfg5 python $REPO/tools/bench_configs.py --gpus 1 --configs 5 --reps 5
-prof r02p_marches python $REPO/tools/ab_tunables.py --cases cumY,cumYw,sumYw,tlin_rw,tcon_rw --variants "scan_chain=1" --rounds 1 --reps 3
+prof r02t_bench python $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline
+prof r02t_cfg3 python $REPO/tools/bench_configs.py --configs 3 --reps 5
+prof r02t_cfg4 python $REPO/tools/bench_configs.py --gpus 1 --configs 4 --records 16 --batch-records 8
+prof r02t_cfg5 python $REPO/tools/bench_configs.py --gpus 1 --configs 5 --reps 5
+prof r02t_marches python $REPO/tools/ab_tunables.py --cases cumY,cumYw,sumYw,tlin_rw,tcon_rw --variants "scan_chain=1" --rounds 1 --reps 3
 echo "== VALU issue share"
 cd /tmp
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --kernel-trace -d $OUT/prof_valu_r02p -o valu -- python $REPO/tools/microbench.py --reps 5 --cases stencil,metric,cumsum,reduce > $OUT/prof_valu_r02p.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES --kernel-trace -d $OUT/prof_valu_r02t -o valu -- python $REPO/tools/microbench.py --reps 5 --cases stencil,metric,cumsum,reduce > $OUT/prof_valu_r02t.log 2>&1
 cd $REPO
-python tools/valu_util.py $(find $OUT/prof_valu_r02p -name "*.db" | head -1) 2>&1 | tee $S/valu_issue_share.txt | head -30
+python tools/valu_util.py $(find $OUT/prof_valu_r02t -name "*.db" | head -1) 2>&1 | tee $S/valu_issue_share.txt | head -30
 rm -rf $OUT/prof_stats_* $OUT/prof_fetch_* $OUT/prof_write_* $OUT/prof_valu_*  # raw traces stay on the box
