@@ -127,7 +127,7 @@ struct Tune {
   int scan_chain;     // long strided-axis scans as a chained flat launch (K5c); 2: whenever the march has >= 2 chunks
   int scan_chain_w;   // K5c: levels' worth of columns that advance side by side inside one XCD band
   int reduce_zl;      // K4cz: outer indices per task of the chained weighted reduction sharing the weight rows (1 / 2 / 4)
-  int dbg;            // experiments only (never set in production): see the kernels that read it
+  int dbg;            // A/B switches that do NOT change results (bit 2: the linear transform's division inside its loop)
   int march_lds_kb;   // optional dynamic LDS request for the column-marching kernels, only to cap residency
                       // (experiment: +8 % on a bare march in tools/streambench.hip, but -20 % on the real
                       // kernels whose index/metric math then has too few waves to hide behind) => default 0

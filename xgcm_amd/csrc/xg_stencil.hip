@@ -218,7 +218,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
     const real* __restrict__ in, real* __restrict__ out, u32 L, u32 Z, u32 Y, u32 nblk, FastDiv ntile, FastDiv fYG,
     ZBand zb, int pad_lo, int bc, real fill, const real* __restrict__ halo, const real* __restrict__ m_in,
     int64_t mi_z, int64_t mi_y, int64_t mi_x, const real* __restrict__ m_out, int64_t mo_z, int64_t mo_y,
-    int64_t mo_x, int mal, int ntl, int dbg) {
+    int64_t mo_x, int mal, int ntl) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   constexpr int RM = ZS ? 1 : R;  // metric vectors a wave loads
   const u32 pb = (nblk + 7) >> 3;
@@ -279,8 +279,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
     }
     if (HAS_MO) {
       const real* mrow = m_out + (zz * mo_z + yy * mo_y);
-      if (dbg & 1) wo[u] = splat<dv>(real(1.5));  // experiment: no divisor load
-      else if (mal) wo[u] = *reinterpret_cast<const dv*>(mrow + i0);
+      if (mal) wo[u] = *reinterpret_cast<const dv*>(mrow + i0);
       else {
 #pragma unroll
         for (int k = 0; k < NV; ++k) wo[u][k] = mrow[(int64_t)(i0 + k) * mo_x];
@@ -309,7 +308,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
       for (int k = 0; k < NV - 1; ++k) res[k] = op2<OP>(av[k], av[k + 1]);
       res[NV - 1] = op2<OP>(av[NV - 1], nv);
     }
-    if (HAS_MO) res = (dbg & 2) ? res * wo[um] : res / wo[um];  // (dbg & 2: experiment, a product in place of the division)
+    // (measured with the divisor load removed: 78.6 %; with a product in place of the IEEE division: no change --
+    // profiles/r02b_ab_bounds.jsonl: the L2-resident metric LOAD is the cost, not the division)
+    if (HAS_MO) res = res / wo[um];
     stg<dv, true>(out + rows[u] * L + i0, res);
   }
 }
@@ -821,7 +822,7 @@ int launch_contig_rw(const StencilCall& c) {
   const u32 nblk = (u32)((waves + WPB - 1) / WPB);
   const u32 grid = ((nblk + 7) / 8) * 8;
   const FastDiv fnt = make_fastdiv(ntile), fYG = make_fastdiv(YG);
-#define XG_RW(R_, ZS_) hipLaunchKernelGGL((k_stencil_contig_rw<OP, MET, R_, ZS_>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, (u32)g.n_in, (u32)Z, (u32)Y, nblk, fnt, fYG, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, mi_z, mi_y, mi_x, c.m_out, mo_z, mo_y, mo_x, mal, tune().nt_load, tune().dbg)
+#define XG_RW(R_, ZS_) hipLaunchKernelGGL((k_stencil_contig_rw<OP, MET, R_, ZS_>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, (u32)g.n_in, (u32)Z, (u32)Y, nblk, fnt, fYG, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, mi_z, mi_y, mi_x, c.m_out, mo_z, mo_y, mo_x, mal, tune().nt_load)
   if (zs) { if (RR == 8) XG_RW(8, true); else if (RR == 4) XG_RW(4, true); else XG_RW(2, true); }
   else { if (RR == 4) XG_RW(4, false); else if (RR == 2) XG_RW(2, false); else XG_RW(1, false); }
 #undef XG_RW
