@@ -251,6 +251,15 @@ int xg_divergence_halo_f64(const double* u, const double* v, const double* halo_
 int xg_stencil2d_f64(int op, const double* in, double* out, const int64_t* shape, int ndim, int order,
                      int padx_lo, int padx_hi, int bc_x, double fill_x, int pady_lo, int pady_hi,
                      int bc_y, double fill_y, void* stream);
+/* The same with `metric_weighted` on both axes and one metric set (Grid.interp(da, ["X", "Y"], metric_weighted=("X", "Y")):
+ * per axis the reference multiplies by the metric at the current position, applies the operator and divides by the
+ * metric at the new position, xgcm/grid.py:804-828).  Three contiguous (ny, nx) planes shared by all outer indices:
+ * m_in at the input positions, m_mid at the positions between the two axes (divisor of the first step and factor of
+ * the second), m_out at the output positions.  Bit-identical to the two metric-carrying xg_stencil1d_f64 calls. */
+int xg_stencil2d_metric_f64(int op, const double* in, double* out, const int64_t* shape, int ndim, int order,
+                            int padx_lo, int padx_hi, int bc_x, double fill_x, int pady_lo, int pady_hi,
+                            int bc_y, double fill_y, const double* m_in, const double* m_mid,
+                            const double* m_out, void* stream);
 
 /* ---- synthetic fields, bit-identical to oracle/refimpl.py:synthetic --------------------- */
 /* out[i] = u * scale + shift,  u = (splitmix64_mix(i + offset + seed*0x9E3779B97F4A7C15) >> 11)
@@ -325,6 +334,10 @@ int xg_divergence_halo_f32(const float* u, const float* v, const float* halo_x, 
 int xg_stencil2d_f32(int op, const float* in, float* out, const int64_t* shape, int ndim, int order,
                      int padx_lo, int padx_hi, int bc_x, float fill_x, int pady_lo, int pady_hi,
                      int bc_y, float fill_y, void* stream);
+int xg_stencil2d_metric_f32(int op, const float* in, float* out, const int64_t* shape, int ndim, int order,
+                     int padx_lo, int padx_hi, int bc_x, float fill_x, int pady_lo, int pady_hi,
+                     int bc_y, float fill_y, const float* m_in, const float* m_mid,
+                            const float* m_out, void* stream);
 /* value formed in float64 exactly as the _f64 variant, then rounded once to float */
 int xg_fill_synthetic_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, double scale,
                           double shift, void* stream);

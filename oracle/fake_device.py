@@ -174,14 +174,17 @@ def stencil2d_supported(x, padx, pady):
     return x.ndim >= 2 and x.shape[-1] % lane == 0 and sum(padx) == 1 and sum(pady) == 1 and x.shape[-1] > 0 and x.shape[-2] > 0
 
 
-def stencil2d(op, x, order, padx, bc_x, fill_x, pady, bc_y, fill_y):
+def stencil2d(op, x, order, padx, bc_x, fill_x, pady, bc_y, fill_y, metrics=None):
     x = asdevice(x)
     ax_x, ax_y = x.ndim - 1, x.ndim - 2
+    m1 = m2 = m3 = None
+    if metrics is not None:  # per axis: multiply by the metric at the current position, operate, divide at the new one
+        m1, m2, m3 = (np.asarray(m).astype(x.dtype) for m in metrics)
     if order == 0:
-        t = R.stencil1d(op, x, ax_x, padx[0], padx[1], bc_x, fill_x)
-        return R.stencil1d(op, t, ax_y, pady[0], pady[1], bc_y, fill_y)
-    t = R.stencil1d(op, x, ax_y, pady[0], pady[1], bc_y, fill_y)
-    return R.stencil1d(op, t, ax_x, padx[0], padx[1], bc_x, fill_x)
+        t = R.stencil1d(op, x, ax_x, padx[0], padx[1], bc_x, fill_x, m1, m2)
+        return R.stencil1d(op, t, ax_y, pady[0], pady[1], bc_y, fill_y, m2, m3)
+    t = R.stencil1d(op, x, ax_y, pady[0], pady[1], bc_y, fill_y, m1, m2)
+    return R.stencil1d(op, t, ax_x, padx[0], padx[1], bc_x, fill_x, m2, m3)
 
 
 def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None, dtype=np.float64):

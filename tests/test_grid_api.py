@@ -247,6 +247,53 @@ def test_two_axes_fused_equals_sequential(backend):
         Grid(ds, coords=gcoords, autoparse_metadata=False).interp(ds["T"], ["X", "Y"])
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_two_axes_metric_weighted_fused_equals_sequential(backend, dtype):
+    """`metric_weighted=("X", "Y")` on both axes (area-weighted interpolation to the corner points): ONE launch with the
+    three area planes (input positions, between the axes, output positions) gives the bits of the reference's per-axis
+    loop -- multiply before, divide after EACH axis (xgcm/grid.py:804-828)."""
+    nz, ny, nx = 3, 10, 16
+    m = lambda s: R.synthetic_metric((ny, nx), s).astype(dtype)  # noqa: E731
+    coords = {"XC": ("XC", np.arange(nx) + 0.5), "XG": ("XG", np.arange(nx) * 1.0),
+              "YC": ("YC", np.arange(ny) + 0.5), "YG": ("YG", np.arange(ny) * 1.0), "Z": ("Z", np.arange(nz) * 1.0)}
+    ds = Dataset({"T": (("Z", "YC", "XC"), R.synthetic_field((nz, ny, nx), 72).astype(dtype)),
+                  "rA": (("YC", "XC"), m(1)), "rAw": (("YC", "XG"), m(2)), "rAs": (("YG", "XC"), m(3)), "rAz": (("YG", "XG"), m(4))}, coords)
+    gcoords = {"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}}
+    from xgcm_amd import device as dev_mod
+
+    calls = []
+    real = dev_mod.stencil2d
+    fv = {"X": 2.0, "Y": -3.0}
+    for padding in ({"X": "periodic", "Y": "extend"}, "fill", {"X": "extend", "Y": "periodic"}):
+        grid = Grid(ds, coords=gcoords, padding=padding, metrics={("X", "Y"): ["rA", "rAw", "rAs", "rAz"]}, autoparse_metadata=False)
+        for fn in ("interp", "diff"):
+            f = getattr(grid, fn)
+            for axes in (["X", "Y"], ["Y", "X"]):
+                dev_mod.stencil2d = lambda *a, **k: (calls.append(k.get("metrics") is not None), real(*a, **k))[1]
+                try:
+                    fused = f(ds["T"], axes, fill_value=fv, metric_weighted=("X", "Y"))
+                finally:
+                    dev_mod.stencil2d = real
+                seq = f(f(ds["T"], axes[0], fill_value=fv, metric_weighted=("X", "Y")), axes[1], fill_value=fv, metric_weighted=("X", "Y"))
+                assert fused.dims == ("Z", "YG", "XG") and fused.values.dtype == dtype
+                assert np.array_equal(fused.values, seq.values, equal_nan=True), (padding, fn, axes)
+                # against the oracle written out: multiply, operate, divide -- twice
+                a, b = ("rAw", "rAz") if axes[0] == "X" else ("rAs", "rAz")
+                ax0, ax1 = (2, 1) if axes[0] == "X" else (1, 2)
+                pad0 = padding if isinstance(padding, str) else padding[axes[0]]
+                pad1 = padding if isinstance(padding, str) else padding[axes[1]]
+                t = R.stencil1d(fn, ds["T"].values, ax0, 1, 0, pad0, dtype(fv[axes[0]]), ds["rA"].values[None], ds[a].values[None])
+                want = R.stencil1d(fn, t, ax1, 1, 0, pad1, dtype(fv[axes[1]]), ds[a].values[None], ds[b].values[None])
+                assert np.array_equal(fused.values, want, equal_nan=True), (padding, fn, axes)
+    assert calls == [True] * (3 * 2 * 2)  # every call took the fused path with its three metric planes
+    # a metric that is not a plain (Y, X) plane at one of the three positions -> the per-axis kernels, same bits
+    ds2 = Dataset({"T": ds["T"], "dxC": (("XG",), R.synthetic_metric((nx,), 9).astype(dtype)), "dxT": (("XC",), R.synthetic_metric((nx,), 8).astype(dtype))}, coords)
+    grid = Grid(ds2, coords=gcoords, padding="periodic", metrics={("X",): ["dxC", "dxT"]}, autoparse_metadata=False)
+    got = grid.interp(ds2["T"], ["X", "Y"], metric_weighted="X")
+    seq = grid.interp(grid.interp(ds2["T"], "X", metric_weighted="X"), "Y", metric_weighted="X")
+    assert np.array_equal(got.values, seq.values)
+
+
 def test_two_axes_integer_input_takes_the_sequential_path(backend):
     """signed-integer data through `diff(da, [X, Y])` must give the dtype and values of the two
     single-axis calls (the reference pads the INTEGER array: numpy.pad truncates a fractional fill value)."""

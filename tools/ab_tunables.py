@@ -41,6 +41,8 @@ def main():
         "dX": (lambda: D.stencil1d("diff", T, 2, 1, 0, "periodic", m_out=dx), 16 + 8 / nz),
         "dY": (lambda: D.stencil1d("diff", T, 1, 1, 0, "extend", m_out=dx), 16 + 8 / nz),
         "dZ": (lambda: D.stencil1d("diff", T, 0, 1, 0, "fill", m_out=dz), 16),
+        "i2": (lambda: D.stencil2d("interp", T, 0, (1, 0), "periodic", 0.0, (1, 0), "extend", 0.0), 16),
+        "i2mw": (lambda: D.stencil2d("interp", T, 0, (1, 0), "periodic", 0.0, (1, 0), "extend", 0.0, metrics=(dx[0], dx2[0], dx[0])), 16 + 24 / nz),
         "iZmw": (lambda: D.stencil1d("interp", T, 0, 1, 0, "fill", m_in=dz, m_out=dz), 16),
         "iYmw1": (lambda: D.stencil1d("interp", T, 1, 1, 0, "extend", m_in=dy1, m_out=dy1), 16),
         "iXmw": (lambda: D.stencil1d("interp", T, 2, 1, 0, "periodic", m_in=dx2, m_out=dx), 16 + 16 / nz),

@@ -425,6 +425,10 @@ int xg_event_destroy(void* ev) { free(ev); return XG_OK; }
   }                                                                                                                   \
   int xg_stencil2d_##SFX(int, const R*, R*, const int64_t*, int, int, int, int, int, R, int, int, int, R, void*) {    \
     return unsupported("xg_stencil2d");                                                                               \
+  }                                                                                                                   \
+  int xg_stencil2d_metric_##SFX(int, const R*, R*, const int64_t*, int, int, int, int, int, R, int, int, int, R,      \
+                                const R*, const R*, const R*, void*) {                                                \
+    return unsupported("xg_stencil2d_metric");                                                                        \
   }
 
 XG_HOST_TYPED(f64, double)

@@ -661,27 +661,42 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_gen(
 // periodic/extend halos are the first-axis result of the wrapped/clamped row or column.
 // Length-preserving position pairs only (pads (1,0)/(0,1)), nx even; other cases run sequentially.
 // ------------------------------------------------------------------------------------------
-template <int OP, bool NTS, int SEG>
+// MET: `metric_weighted` on both axes with the same metric set (Grid.interp(da, ["X", "Y"], metric_weighted=("X", "Y")),
+// area-weighted interpolation to the corner points): the reference multiplies by the metric at the current position,
+// applies the axis, divides by the metric at the new position -- twice (xgcm/grid.py:804-828).  Three planes (ny, nx)
+// shared by all outer indices: m1 at the input positions, m2 at the positions after the first axis (divisor of the
+// first step AND factor of the second: `(t / m2) * m2` is kept as written, it is not the identity in floating point),
+// m3 at the output positions.  A fill halo replaces the PRODUCT, as in the reference (the array is padded after the
+// multiplication).
+// ZK (MET only, band-major order): outer indices per wave-task sharing the metric rows in registers -- with one level
+// per task the kernel moves 56 B per output cell from the L2 to the CUs (three metric planes + the field) and stops at
+// 46 % of 8 TB/s, the L2 -> CU path saturated like K4c's; two passes of the metric-carrying 1-D kernels take 3.6 ms.
+template <int OP, bool NTS, int SEG, bool MET, int ZK = 1>
 __global__ __launch_bounds__(BLOCK) void k_stencil2d(
     const real* __restrict__ in, real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny,
     int64_t nx, FastDiv ntile, FastDiv nseg, int order, int plx, int bcx, real fillx, int ply, int bcy,
-    real filly) {
+    real filly, const real* __restrict__ m1, const real* __restrict__ m2, const real* __restrict__ m3, ZBand zb) {
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
   if (lb >= nblk) return;
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
   const u32 r = fdiv(w, ntile);
   const u32 tile = w - r * ntile.d;
-  const u32 oo = fdiv(r, nseg);
-  if (oo >= nouter) return;
-  const u32 sg = r - oo * nseg.d;
-  const int64_t o = o0 + oo;
+  u32 oo, sg;
+  if (MET && zb.on) {  // band-major: every outer index of a band of rows before the next band (the three planes stay in L2)
+    if (!zband_map(zb, r, oo, sg)) return;
+    oo *= ZK;
+    if (oo >= nouter) return;
+  } else {
+    oo = fdiv(r, nseg);
+    if (oo >= nouter) return;
+    sg = r - oo * nseg.d;
+  }
+  const int nk = (ZK > 1 && (int64_t)nouter - (int64_t)oo < ZK) ? (int)(nouter - oo) : ZK;  // levels this wave really has
   const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * NV;
   if (i0 >= nx) return;
   const int64_t j0 = (int64_t)sg * SEG;
   const int64_t nrow = (ny - j0 < SEG) ? ny - j0 : SEG;
-  const real* pin = in + o * ny * nx;
-  real* po = out + (o * ny + j0) * nx + i0;
 
   int64_t nidx;
   bool edge;
@@ -703,9 +718,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
     return t;
   };
 
-  dv pr[SEG + 1];
-  real nb[SEG + 1];
   bool rowfill[SEG + 1];
+  int64_t qq[SEG + 1];
 #pragma unroll
   for (int u = 0; u <= SEG; ++u) {
     int64_t k = j0 + ((u <= nrow) ? u : nrow);
@@ -714,19 +728,61 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
     if (q < 0) { f = (bcy == XG_BC_FILL); q = (bcy == XG_BC_PERIODIC) ? ny - 1 : 0; }
     else if (q >= ny) { f = (bcy == XG_BC_FILL); q = (bcy == XG_BC_PERIODIC) ? 0 : ny - 1; }
     rowfill[u] = f;
-    pr[u] = *reinterpret_cast<const dv*>(pin + q * nx + i0);
-    nb[u] = pin[q * nx + nidx];
+    qq[u] = q;
+  }
+  // the field rows of every level of this task, then the metric rows (shared by the levels)
+  dv prz[ZK][SEG + 1];
+  real nbz[ZK][SEG + 1];
+#pragma unroll
+  for (int kz = 0; kz < ZK; ++kz) {
+    const real* pin = in + (o0 + oo + ((kz < nk) ? kz : nk - 1)) * ny * nx;  // a short last group repeats its last level (not stored)
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) {
+      prz[kz][u] = *reinterpret_cast<const dv*>(pin + qq[u] * nx + i0);
+      nbz[kz][u] = pin[qq[u] * nx + nidx];
+    }
+  }
+  dv a1[MET ? SEG + 1 : 1], mid[MET ? SEG + 1 : 1], d3[MET ? SEG : 1];
+  real a1n[MET ? SEG + 1 : 1], midn[MET ? SEG + 1 : 1];
+  if (MET) {
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) {
+      a1[u] = *reinterpret_cast<const dv*>(m1 + qq[u] * nx + i0);
+      a1n[u] = m1[qq[u] * nx + nidx];
+      // between the axes: (Y as the input, X as the output) when X goes first, (Y as the output, X as the input) otherwise
+      const int64_t mrow = (order == 0) ? qq[u] : j0 + ((u < nrow) ? u : 0);
+      mid[u] = *reinterpret_cast<const dv*>(m2 + mrow * nx + i0);
+      midn[u] = m2[mrow * nx + nidx];
+    }
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) d3[u] = *reinterpret_cast<const dv*>(m3 + (j0 + ((u < nrow) ? u : 0)) * nx + i0);
+  }
+#pragma unroll
+  for (int kz = 0; kz < ZK; ++kz) {
+  if (kz >= nk) break;
+  real* po = out + ((o0 + oo + kz) * ny + j0) * nx + i0;
+  dv pr[SEG + 1];
+  real nb[SEG + 1];
+#pragma unroll
+  for (int u = 0; u <= SEG; ++u) {  // the products at the input positions (a halo row / column repeats the product it copies)
+    pr[u] = MET ? prz[kz][u] * a1[u] : prz[kz][u];
+    nb[u] = MET ? nbz[kz][u] * a1n[u] : nbz[kz][u];
   }
   if (order == 0) {  // X first, then Y on the intermediate
     dv tx[SEG + 1];
 #pragma unroll
     for (int u = 0; u <= SEG; ++u) {
-      const dv t = opx(pr[u], fill_edge ? fillx : nb[u]);
+      dv t = opx(pr[u], fill_edge ? fillx : nb[u]);
+      if (MET) t = (t / mid[u]) * mid[u];
       tx[u] = rowfill[u] ? splat<dv>(filly) : t;
     }
 #pragma unroll
     for (int u = 0; u < SEG; ++u)
-      if (u < nrow) stg<dv, NTS>(po + u * nx, op2<OP>(tx[u], tx[u + 1]));
+      if (u < nrow) {
+        dv res = op2<OP>(tx[u], tx[u + 1]);
+        if (MET) res = res / d3[u];
+        stg<dv, NTS>(po + u * nx, res);
+      }
   } else {  // Y first, then X on the intermediate
 #pragma unroll
     for (int u = 0; u <= SEG; ++u) {
@@ -735,11 +791,18 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
 #pragma unroll
     for (int u = 0; u < SEG; ++u) {
       if (u < nrow) {
-        const dv ty = op2<OP>(pr[u], pr[u + 1]);
-        const real tn = op2<OP>(nb[u], nb[u + 1]);
-        stg<dv, NTS>(po + u * nx, opx(ty, fill_edge ? fillx : tn));
+        dv ty = op2<OP>(pr[u], pr[u + 1]);
+        real tn = op2<OP>(nb[u], nb[u + 1]);
+        if (MET) {
+          ty = (ty / mid[u]) * mid[u];
+          tn = (tn / midn[u]) * midn[u];
+        }
+        dv res = opx(ty, fill_edge ? fillx : tn);
+        if (MET) res = res / d3[u];
+        stg<dv, NTS>(po + u * nx, res);
       }
     }
+  }
   }
 }
 
@@ -1043,6 +1106,63 @@ int stencil_dispatch(int op, int V, int met, int kind, const StencilCall& c) {
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
+static int stencil2d_impl(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,
+                          int padx_lo, int padx_hi, int bc_x, real fill_x, int pady_lo, int pady_hi, int bc_y,
+                          real fill_y, const real* m1, const real* m2, const real* m3, void* stream) {
+  if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
+  if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
+  if (order != 0 && order != 1) return fail(XG_ERR_INVALID, "order must be 0 (X then Y) or 1 (Y then X)");
+  if (padx_lo + padx_hi != 1 || pady_lo + pady_hi != 1 || ((padx_lo | padx_hi | pady_lo | pady_hi) & ~1))
+    return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil needs length-preserving pads (1,0) or (0,1) on both axes");
+  if (bc_x < XG_BC_PERIODIC || bc_x > XG_BC_EXTEND || bc_y < XG_BC_PERIODIC || bc_y > XG_BC_EXTEND)
+    return fail(XG_ERR_INVALID, "fused 2-D stencil needs a boundary mode on both axes");
+  const int64_t ny = shape[ndim - 2], nx = shape[ndim - 1];
+  int64_t outer = 1;
+  for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
+  if (outer == 0 || ny == 0 || nx == 0) return XG_OK;
+  const bool met = m1 != nullptr;
+  if (met && (!aligned16(m1) || !aligned16(m2) || !aligned16(m3))) return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil: metric planes must be 16-byte aligned");
+  if (nx % NV || !aligned16(in) || !aligned16(out)) return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil needs an X extent that is a multiple of the 16-byte lane vector");
+  constexpr int SEG = XG_FUSED_SEG;
+  const u64 ntile = (u64)((nx + NV * WAVE - 1) / (NV * WAVE));
+  const u64 nseg = (u64)((ny + SEG - 1) / SEG);
+  const u64 per_outer = ntile * nseg;
+  if (per_outer > MAX_ITEMS) return fail(XG_ERR_UNSUPPORTED, "extent too large for the 2-D stencil kernel");
+  const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
+  const u64 outer_per = MAX_ITEMS / per_outer;
+  hipStream_t st = (hipStream_t)stream;
+  const bool nts = tune().nt_store;
+  for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_per) {
+    const u32 nouter = (u32)((outer - o0 < (int64_t)outer_per) ? outer - o0 : (int64_t)outer_per);
+    u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
+    ZBand zb = make_zband(false, 0, 0, 1);
+    constexpr int ZK2 = 4;  // levels per wave-task sharing the metric rows
+    if (met && tune().zband && nouter >= 2) {  // the metric planes are shared by the outer indices: band-major order
+      const u32 B = ((u32)(tune().zb_rows > 0 ? tune().zb_rows : 16) + SEG - 1) / SEG;
+      const u64 groups = ((u64)nouter + ZK2 - 1) / ZK2;
+      const u64 padded = ((nseg + B - 1) / B) * B * groups * ntile;
+      if (groups >= 2 && padded <= MAX_ITEMS) {
+        zb = make_zband(true, groups, nseg, B);
+        if (zb.on) nblk = (u32)((padded + WPB - 1) / WPB);
+      }
+    }
+    const u32 grid = ((nblk + 7) / 8) * 8;
+#define XG_GM(O, NTS, M) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, M>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order, padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
+#define XG_GZ(O, NTS) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, true, ZK2>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order, padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
+#define XG_GO(O, NTS) do { if (met && zb.on) XG_GZ(O, NTS); else if (met) XG_GM(O, NTS, true); else XG_GM(O, NTS, false); } while (0)
+#define XG_O(O) do { if (nts) XG_GO(O, true); else XG_GO(O, false); } while (0)
+    switch (op) { case XG_OP_DIFF: XG_O(XG_OP_DIFF); break; case XG_OP_INTERP: XG_O(XG_OP_INTERP); break; case XG_OP_MIN: XG_O(XG_OP_MIN); break; default: XG_O(XG_OP_MAX); }
+#undef XG_O
+#undef XG_GO
+#undef XG_GZ
+#undef XG_GM
+  }
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+
 extern "C" {
 
 static int stencil1d_impl(int op, const real* in, const real* halo, real* out, const int64_t* shape, int ndim,
@@ -1115,40 +1235,16 @@ int XG_FN(xg_stencil1d_halo)(int op, const real* in, const real* halo, real* out
 int XG_FN(xg_stencil2d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,
                      int padx_lo, int padx_hi, int bc_x, real fill_x, int pady_lo, int pady_hi, int bc_y,
                      real fill_y, void* stream) {
-  if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
-  if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
-  if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
-  if (order != 0 && order != 1) return fail(XG_ERR_INVALID, "order must be 0 (X then Y) or 1 (Y then X)");
-  if (padx_lo + padx_hi != 1 || pady_lo + pady_hi != 1 || ((padx_lo | padx_hi | pady_lo | pady_hi) & ~1))
-    return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil needs length-preserving pads (1,0) or (0,1) on both axes");
-  if (bc_x < XG_BC_PERIODIC || bc_x > XG_BC_EXTEND || bc_y < XG_BC_PERIODIC || bc_y > XG_BC_EXTEND)
-    return fail(XG_ERR_INVALID, "fused 2-D stencil needs a boundary mode on both axes");
-  const int64_t ny = shape[ndim - 2], nx = shape[ndim - 1];
-  int64_t outer = 1;
-  for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
-  if (outer == 0 || ny == 0 || nx == 0) return XG_OK;
-  if (nx % NV || !aligned16(in) || !aligned16(out)) return fail(XG_ERR_UNSUPPORTED, "fused 2-D stencil needs an X extent that is a multiple of the 16-byte lane vector");
-  constexpr int SEG = XG_FUSED_SEG;
-  const u64 ntile = (u64)((nx + NV * WAVE - 1) / (NV * WAVE));
-  const u64 nseg = (u64)((ny + SEG - 1) / SEG);
-  const u64 per_outer = ntile * nseg;
-  if (per_outer > MAX_ITEMS) return fail(XG_ERR_UNSUPPORTED, "extent too large for the 2-D stencil kernel");
-  const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
-  const u64 outer_per = MAX_ITEMS / per_outer;
-  hipStream_t st = (hipStream_t)stream;
-  const bool nts = tune().nt_store;
-  for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_per) {
-    const u32 nouter = (u32)((outer - o0 < (int64_t)outer_per) ? outer - o0 : (int64_t)outer_per);
-    const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
-    const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GO(O, NTS) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order, padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y)
-#define XG_O(O) do { if (nts) XG_GO(O, true); else XG_GO(O, false); } while (0)
-    switch (op) { case XG_OP_DIFF: XG_O(XG_OP_DIFF); break; case XG_OP_INTERP: XG_O(XG_OP_INTERP); break; case XG_OP_MIN: XG_O(XG_OP_MIN); break; default: XG_O(XG_OP_MAX); }
-#undef XG_O
-#undef XG_GO
-  }
-  XG_LAUNCH_CHECK();
-  return XG_OK;
+  return stencil2d_impl(op, in, out, shape, ndim, order, padx_lo, padx_hi, bc_x, fill_x, pady_lo, pady_hi, bc_y, fill_y,
+                        nullptr, nullptr, nullptr, stream);
+}
+
+int XG_FN(xg_stencil2d_metric)(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,
+                            int padx_lo, int padx_hi, int bc_x, real fill_x, int pady_lo, int pady_hi, int bc_y,
+                            real fill_y, const real* m_in, const real* m_mid, const real* m_out, void* stream) {
+  if (!m_in || !m_mid || !m_out) return fail(XG_ERR_INVALID, "NULL metric plane");
+  return stencil2d_impl(op, in, out, shape, ndim, order, padx_lo, padx_hi, bc_x, fill_x, pady_lo, pady_hi, bc_y, fill_y,
+                        m_in, m_mid, m_out, stream);
 }
 
 }  // extern "C"

@@ -572,19 +572,27 @@ def stencil2d_supported(x, padx, pady) -> bool:
             and shape[-1] > 0 and shape[-2] > 0)
 
 
-def stencil2d(op: str, x, order: int, padx, bc_x: str, fill_x: float, pady, bc_y: str, fill_y: float) -> torch.Tensor:
-    """OP along the last two axes in one pass (xg_stencil2d_f64); order 0 = X then Y, 1 = Y then X."""
+def stencil2d(op: str, x, order: int, padx, bc_x: str, fill_x: float, pady, bc_y: str, fill_y: float, metrics=None) -> torch.Tensor:
+    """OP along the last two axes in one pass (xg_stencil2d_f64); order 0 = X then Y, 1 = Y then X.  `metrics`: the
+    three (ny, nx) planes (at the input positions, between the two axes, at the output positions) of a
+    `metric_weighted` call on both axes (xg_stencil2d_metric_f64)."""
     lib = _hip.load()
-    dt, sfx = _common(x)
+    dt, sfx = _common(x, *(metrics or ()))
     x = asdevice(x, dt)
     out = torch.empty(tuple(x.shape), dtype=dt, device=x.device)
     if out.numel() == 0:
         return out
-    _hip.check(
-        getattr(lib, "xg_stencil2d_" + sfx)(_hip.OP[op], x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), x.dim(), int(order),
-                             int(padx[0]), int(padx[1]), _hip.BC[bc_x], float(fill_x), int(pady[0]), int(pady[1]),
-                             _hip.BC[bc_y], float(fill_y), _stream())
-    )
+    head = (_hip.OP[op], x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), x.dim(), int(order),
+            int(padx[0]), int(padx[1]), _hip.BC[bc_x], float(fill_x), int(pady[0]), int(pady[1]),
+            _hip.BC[bc_y], float(fill_y))
+    if metrics is None:
+        _hip.check(getattr(lib, "xg_stencil2d_" + sfx)(*head, _stream()))
+        return out
+    planes = [asdevice(m, dt).contiguous() for m in metrics]
+    for m in planes:
+        if tuple(m.shape) != tuple(x.shape[-2:]):
+            raise ValueError(f"metric plane of shape {tuple(m.shape)} for a field whose last two dims are {tuple(x.shape[-2:])}")
+    _hip.check(getattr(lib, "xg_stencil2d_metric_" + sfx)(*head, planes[0].data_ptr(), planes[1].data_ptr(), planes[2].data_ptr(), _stream()))
     return out
 
 

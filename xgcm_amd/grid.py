@@ -435,9 +435,14 @@ class Grid:
         i = 0
         while i < len(steps):
             sig, ax_name = steps[i]
-            if (i + 1 < len(steps) and vector_key is None and other_component is None and _divide_by is None
-                    and not (isinstance(metric_weighted, dict) and (metric_weighted.get(ax_name) or metric_weighted.get(steps[i + 1][1])))):
-                fused = self._two_axes_in_one_pass(funcname, array, steps[i], steps[i + 1], kwargs)
+            if i + 1 < len(steps) and vector_key is None and other_component is None and _divide_by is None:
+                w_a = metric_weighted.get(ax_name) if isinstance(metric_weighted, dict) else None
+                w_b = metric_weighted.get(steps[i + 1][1]) if isinstance(metric_weighted, dict) else None
+                fused = None
+                if not w_a and not w_b:
+                    fused = self._two_axes_in_one_pass(funcname, array, steps[i], steps[i + 1], kwargs)
+                elif w_a and w_b and tuple(w_a) == tuple(w_b):  # metric_weighted=("X", "Y") on both axes: three metric planes
+                    fused = self._two_axes_in_one_pass(funcname, array, steps[i], steps[i + 1], kwargs, weighted=tuple(w_a))
                 if fused is not None:
                     array = fused
                     i += 2
@@ -479,7 +484,7 @@ class Grid:
                 array = array / post_divide
         return to_xarray(array) if was_xr else array
 
-    def _two_axes_in_one_pass(self, funcname, array, step_a, step_b, kwargs):
+    def _two_axes_in_one_pass(self, funcname, array, step_a, step_b, kwargs, weighted=None):
         """`op` along two axes that are the LAST TWO dims of `array` in one kernel launch
         (xg_stencil2d_f64): same bits as the two sequential passes of the reference loop
         (xgcm/grid.py:800-832, whose TODO at :798-800 asks for exactly this), half the traffic.
@@ -518,8 +523,23 @@ class Grid:
         if not _dev.stencil2d_supported(array.data, padx, pady):
             return None
         host = not _is_tensor(array.data)
+        planes = None
+        if weighted is not None:
+            # the metric at the input positions, between the two axes and at the output positions (xgcm/grid.py:804-828
+            # multiplies before and divides after EACH axis); each must be a plain (Y, X) plane over the last two dims
+            dims_mid = tuple(out_a if d == dim_a else d for d in array.dims)
+            dims_out = tuple(out_b if d == dim_b else d for d in dims_mid)
+            planes = []
+            for dims in (array.dims, dims_mid, dims_out):
+                try:
+                    m = self.get_metric(_DimsOnly(dims, array.name), weighted, _layout=dims)
+                except (KeyError, ValueError):
+                    return None
+                if tuple(m.dims) != tuple(dims[-2:]) or tuple(m.shape) != tuple(array.shape[-2:]):
+                    return None  # broadcast / extra dims: the per-axis kernels take any metric pattern
+                planes.append(self._resident(m, array.data).data)
         out = _dev.stencil2d(funcname, array.data, 0 if x_is_a else 1, padx, bc[ax_x], float(fv[ax_x] or 0.0), pady,
-                             bc[ax_y], float(fv[ax_y] or 0.0))
+                             bc[ax_y], float(fv[ax_y] or 0.0), **({"metrics": planes} if planes is not None else {}))
         rename = {dim_a: out_a, dim_b: out_b}
         res = DataArray(_dev.tohost(out) if host else out, tuple(rename.get(d, d) for d in array.dims), name=array.name)
         return _reattach_coords([res], self, None, {out_a, out_b}, [array])[0]
