@@ -32,6 +32,7 @@
  *   xg_binary_f64      the xarray broadcasting `*`, `/`, `+`, `-` around the ops
  *                      (xgcm/grid.py:808,832,1578,1600; get_metric products :614-617)
  *   xg_stencil2d_f64   Grid.interp/diff/min/max over two axes (xgcm/grid.py:798-828), one pass
+ *   xg_stencil2d_metric_f64   the same with metric_weighted on both axes (xgcm/grid.py:804-828)
  *   xg_gradient_f64 / xg_flux_f64  the "Gradient" and "Advection" grid ufuncs of docs/ufunc_examples.md, fused
  *   xg_divergence_f64  the chained (diff(u,X) + diff(v,Y)) / area of docs/ufunc_examples.md, fused
  *   xg_vorticity_f64   the chained (diff(v,X) - diff(u,Y)) / area of docs/ufunc_examples.md
