@@ -275,3 +275,15 @@ def test_tunables_set_and_get_without_a_gpu():
     assert _hip.get_tunable("contig_rw") >= 0
     with pytest.raises(_hip.XgcmHipError, match="unknown tunable"):
         _hip.set_tunable("no_such_knob", 1)
+
+
+def test_graph_capture_needs_the_gpu():
+    """xgcm_amd.graphs.capture is hipGraph capture: without a GPU it fails loudly instead of running `fn` eagerly."""
+    import torch
+
+    from xgcm_amd.graphs import capture
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="needs the GPU"):
+        capture(lambda: None)
