@@ -60,6 +60,9 @@ def main():
         "sumYw1": (lambda: D.reduce1d(T, 1, dy1), 8),
         "sumYw3": (lambda: D.reduce1d(T, 1, T3), 16),
         "cumYw": (lambda: D.cumsum1d(T, 1, 0, 0, 0, 0, None, 0.0, False, True, dx, None), 16 + 8 / nz),
+        "cumXp": (lambda: D.cumsum1d(T, 2, 0, 1, 1, 0, "periodic"), 16),
+        "cumXe": (lambda: D.cumsum1d(T, 2, 0, 1, 1, 0, "extend"), 16),
+        "cumX0": (lambda: D.cumsum1d(T, 2, 0, 0, 0, 0, None), 16),
         "cumXw": (lambda: D.cumsum1d(T, 2, 0, 0, 0, 0, None, 0.0, False, True, dx, None), 16 + 8 / nz),
         "cumZw": (lambda: D.cumsum1d(T, 0, 0, 0, 0, 0, None, 0.0, False, True, dx, None), 16 + 8 / nz),
         "sumZw2": (lambda: D.reduce1d(T, 0, dx), 8 + 8 / nz),
