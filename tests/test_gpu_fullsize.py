@@ -71,6 +71,37 @@ def test_cumsum_then_diff_round_trip_full_size(env):
     assert _same(torch, tot.data, c.data[NZ])
 
 
+def test_chained_scan_along_y_full_size(env):
+    """cumsum along Y of the full 75 x 2400 x 3600 field runs as the chained flat launch (K5c: 75 chunks of 32 rows per
+    column hand their running sum on): on integer-valued data every partial sum is exact, so (a) the last kept row equals
+    the plain sum along Y, (b) differencing the scan gives the field back, (c) the marching kernel (scan_chain=0) agrees
+    bit for bit, forward and reversed; (d) spot columns against the numpy oracle."""
+    from xgcm_amd import _hip
+
+    torch, grid, D = env["torch"], env["grid"], env["D"]
+    x = env["ints"](5)
+    c = grid.cumsum(x, "Y", to="left", padding="fill")  # out[0] = 0, out[j] = sum of rows < j
+    assert c.dims == ("Z", "YG", "XC")
+    back = D.stencil1d("diff", c.data, 1, 0, 1, "fill", 0.0)  # c[j + 1] - c[j], last one against the fill
+    assert _same(torch, back[:, :-1], x.data[:, :-1])
+    total = D.reduce1d(x.data, 1, None, False)
+    incl = D.cumsum1d(x.data, 1, 0, 0, 0, 0, None)  # plain inclusive scan
+    assert _same(torch, incl[:, -1], total)
+    keep = _hip.get_tunable("scan_chain")
+    try:
+        for rev in (False, True):
+            _hip.set_tunable("scan_chain", 1)
+            chained = D.cumsum1d(x.data, 1, 0, 1, 1, 0, "extend", 0.0, rev, True)
+            _hip.set_tunable("scan_chain", 0)
+            marched = D.cumsum1d(x.data, 1, 0, 1, 1, 0, "extend", 0.0, rev, True)
+            assert _same(torch, chained, marched)
+    finally:
+        _hip.set_tunable("scan_chain", keep)
+    for z, xs in ((0, 0), (NZ // 2, NX // 2 - 1), (NZ - 1, NX - 8)):  # spot columns (8 wide) against the oracle
+        col = D.tohost(x.data[z, :, xs:xs + 8])
+        np.testing.assert_array_equal(D.tohost(incl[z, :, xs:xs + 8]), np.cumsum(col, axis=0))
+
+
 def test_linearity_and_shift_invariance_full_size(env):
     torch, grid = env["torch"], env["grid"]
     a, b = env["ints"](2), env["ints"](3)
