@@ -102,6 +102,42 @@ def test_chained_scan_along_y_full_size(env):
         np.testing.assert_array_equal(D.tohost(incl[z, :, xs:xs + 8]), np.cumsum(col, axis=0))
 
 
+def test_transforms_row_staging_full_size(env):
+    """75 -> 50 levels on the full 2400 x 3600 columns, random-walk theta (the lanes of a wave emit a target level at
+    different source levels): outputs through the LDS ring / the per-wave accumulator window == direct stores / a
+    window per lane, bit for bit; spot columns against numpy.interp and the oracle's conservative loop."""
+    from oracle import transform as TR
+    from xgcm_amd import _hip
+
+    torch, D = env["torch"], env["D"]
+    m = 50
+    phi = D.synthetic((NZ, NY, NX), 41)
+    theta = torch.cumsum(D.synthetic((NZ, NY, NX), 42, 0, 2.0, 0.01), 0)
+    theta_o = torch.cat([theta[:1] - 1.0, theta], 0)
+    levels = torch.linspace(1.0, 0.9 * NZ, m, dtype=torch.float64, device="cuda").reshape(m, 1, 1)
+    edges = torch.linspace(0.0, 1.05 * NZ, m + 1, dtype=torch.float64, device="cuda")
+    keep = {k: _hip.get_tunable(k) for k in ("transform_stage", "transform_win")}
+    try:
+        _hip.set_tunable("transform_stage", 0)
+        _hip.set_tunable("transform_win", 2)
+        lin0 = D.transform_linear(phi, theta, levels, 0)
+        con0 = D.transform_conservative(phi, theta_o, edges, 0)
+        _hip.set_tunable("transform_stage", keep["transform_stage"])
+        _hip.set_tunable("transform_win", keep["transform_win"])
+        lin1 = D.transform_linear(phi, theta, levels, 0)
+        con1 = D.transform_conservative(phi, theta_o, edges, 0)
+    finally:
+        for k, v in keep.items():
+            _hip.set_tunable(k, v)
+    assert lin1.shape == (m, NY, NX) and bool(torch.equal(torch.nan_to_num(lin0, nan=-7.0), torch.nan_to_num(lin1, nan=-7.0)))
+    assert bool(torch.equal(torch.nan_to_num(con0, nan=-7.0), torch.nan_to_num(con1, nan=-7.0)))
+    for y, x in ((0, 0), (NY // 2, NX // 3), (NY - 1, NX - 4)):
+        ph, th, tho = (D.tohost(a[:, y, x:x + 4]).T for a in (phi, theta, theta_o))  # (4 columns, levels)
+        want = TR.interp_1d_linear(ph, th, D.tohost(levels).ravel(), mask_edges=True)
+        np.testing.assert_array_equal(D.tohost(lin1[:, y, x:x + 4]).T, want)
+        np.testing.assert_array_equal(D.tohost(con1[:, y, x:x + 4]).T, TR.interp_1d_conservative(ph, tho, D.tohost(edges)))
+
+
 def test_linearity_and_shift_invariance_full_size(env):
     torch, grid = env["torch"], env["grid"]
     a, b = env["ints"](2), env["ints"](3)
