@@ -138,6 +138,30 @@ def test_transforms_row_staging_full_size(env):
         np.testing.assert_array_equal(D.tohost(con1[:, y, x:x + 4]).T, TR.interp_1d_conservative(ph, tho, D.tohost(edges)))
 
 
+def test_multi_axis_integrals_full_size(env):
+    """integrate / average over [X, Y] and [X, Y, Z] with separable metrics (area(Y, X) x thickness(Z)) at full size: on
+    integer data with power-of-two metrics every partial sum is exact whatever the order, so the staged reductions
+    (factor by factor; numerator and denominator side by side for the mean) must reproduce torch's plain sums."""
+    torch, D, DataArray, Dataset, Grid = env["torch"], env["D"], env["DataArray"], env["Dataset"], env["Grid"]
+    coords = {"XC": ("XC", np.arange(NX) + 0.5), "XG": ("XG", np.arange(NX) * 1.0), "YC": ("YC", np.arange(NY) + 0.5),
+              "YG": ("YG", np.arange(NY) * 1.0), "Z": ("Z", np.arange(NZ) + 0.5), "Zl": ("Zl", np.arange(NZ) * 1.0)}
+    area = DataArray(D.synthetic((NY, NX), 0, 0, 0.0, 2.0), ("YC", "XC"))
+    thick = DataArray(D.synthetic((NZ,), 0, 0, 0.0, 4.0), ("Z",))
+    grid = Grid(Dataset({"rA": area, "drF": thick}, coords),
+                coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}, "Z": {"center": "Z", "left": "Zl"}},
+                padding="fill", metrics={("X", "Y"): ["rA"], ("Z",): ["drF"]}, autoparse_metadata=False)
+    x = env["ints"](9)
+    per_level = x.data.sum(dim=(1, 2))
+    got = grid.integrate(x, ["X", "Y"])
+    assert got.dims == ("Z",) and _same(torch, got.data, per_level * 2.0)
+    vol = grid.integrate(x, ["X", "Y", "Z"])
+    assert vol.dims == () and float(vol.data) == float(x.data.sum() * 8.0)
+    avg = grid.average(x, ["X", "Y"])  # (tensor / tensor: torch turns a division by a Python scalar into a product with its reciprocal)
+    assert _same(torch, avg.data, (per_level * 2.0) / torch.full_like(per_level, 2.0 * NY * NX))
+    avg3 = grid.average(x, ["X", "Y", "Z"])
+    assert float(avg3.data) == float(x.data.sum() * 8.0) / (8.0 * NZ * NY * NX)
+
+
 def test_linearity_and_shift_invariance_full_size(env):
     torch, grid = env["torch"], env["grid"]
     a, b = env["ints"](2), env["ints"](3)
