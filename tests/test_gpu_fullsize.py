@@ -162,6 +162,20 @@ def test_multi_axis_integrals_full_size(env):
     assert float(avg3.data) == float(x.data.sum() * 8.0) / (8.0 * NZ * NY * NX)
 
 
+def test_two_axis_metric_weighted_full_size(env):
+    """xg_stencil2d_metric at full size (band-major order, four levels per task sharing three random metric planes, the
+    last group of 75 = 18 x 4 + 3 short) == the two metric-carrying 1-D launches, both axis orders, bit for bit."""
+    torch, D = env["torch"], env["D"]
+    T = D.synthetic((NZ, NY, NX), 61)
+    m1, m2, m3 = (D.synthetic((NY, NX), s, 0, 1000.0, 1000.0) for s in (62, 63, 64))
+    for order in (0, 1):
+        fused = D.stencil2d("interp", T, order, (1, 0), "periodic", 0.0, (1, 0), "extend", 0.0, metrics=(m1, m2, m3))
+        first, second = ((2, "periodic"), (1, "extend")) if order == 0 else ((1, "extend"), (2, "periodic"))
+        step = D.stencil1d("interp", T, first[0], 1, 0, first[1], 0.0, m_in=m1[None], m_out=m2[None])
+        seq = D.stencil1d("interp", step, second[0], 1, 0, second[1], 0.0, m_in=m2[None], m_out=m3[None])
+        assert _same(torch, fused, seq)
+
+
 def test_linearity_and_shift_invariance_full_size(env):
     torch, grid = env["torch"], env["grid"]
     a, b = env["ints"](2), env["ints"](3)
