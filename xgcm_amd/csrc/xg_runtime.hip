@@ -142,6 +142,15 @@ extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ws(void* 
     *cs.gave_up_host = 0;
     XG_HIP(hipHostGetDevicePointer((void**)&cs.gave_up_dev, cs.gave_up_host, 0));
   }
+  if (cs.ws.size() >= 16 && cs.ws.find(std::make_pair(dev, stream)) == cs.ws.end()) {
+    // many short-lived streams: give the blocks of the others back (after their work has drained)
+    XG_HIP(hipDeviceSynchronize());
+    for (auto& kv : cs.ws) {
+      if (kv.second.slots) (void)hipFree(kv.second.slots);
+      if (kv.second.ticket) (void)hipFree(kv.second.ticket);
+    }
+    cs.ws.clear();
+  }
   ChainState::PerStream& w = cs.ws[std::make_pair(dev, stream)];
   if (!w.ticket) {
     XG_HIP(hipMalloc((void**)&w.ticket, 1024));  // 8 counters, 128 B apart
