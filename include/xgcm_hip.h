@@ -82,6 +82,10 @@ int xg_free(void* ptr);
 int xg_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void* stream);
 int xg_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void* stream);
 int xg_stream_sync(void* stream);
+/* a stream of the library's own (xgcm_amd.graphs.capture records on one: the chained kernels keep their workspace per
+ * stream, so a captured graph never shares it with another capture or with eager calls) */
+int xg_stream_create(void** stream);
+int xg_stream_destroy(void* stream);
 /* hipEvent helpers so hosts without a HIP binding can time kernels on `stream` */
 int xg_event_create(void** ev);
 int xg_event_record(void* ev, void* stream);

@@ -39,6 +39,8 @@ SIGNATURES = {
     "xg_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "xg_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "xg_stream_sync": (C.c_int, [_vp]),
+    "xg_stream_create": (C.c_int, [C.POINTER(_vp)]),
+    "xg_stream_destroy": (C.c_int, [_vp]),
     "xg_event_create": (C.c_int, [C.POINTER(_vp)]),
     "xg_event_record": (C.c_int, [_vp, _vp]),
     "xg_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),

@@ -328,6 +328,12 @@ int xg_free(void* ptr) { free(ptr); return XG_OK; }
 int xg_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void*) { if (bytes) memcpy(dst, src, bytes); return XG_OK; }
 int xg_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void*) { if (bytes) memcpy(dst, src, bytes); return XG_OK; }
 int xg_stream_sync(void*) { return XG_OK; }
+int xg_stream_create(void** stream) {
+  if (!stream) return fail(XG_ERR_INVALID, "NULL argument");
+  *stream = nullptr;  // the host build runs everything on the calling thread
+  return XG_OK;
+}
+int xg_stream_destroy(void*) { return XG_OK; }
 int xg_event_create(void** ev) {
   if (!ev) return fail(XG_ERR_INVALID, "NULL argument");
   *ev = calloc(1, sizeof(double));

@@ -142,27 +142,16 @@ extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ws(void* 
     *cs.gave_up_host = 0;
     XG_HIP(hipHostGetDevicePointer((void**)&cs.gave_up_dev, cs.gave_up_host, 0));
   }
-  if (cs.ws.size() >= 16 && cs.ws.find(std::make_pair(dev, stream)) == cs.ws.end()) {
-    // many short-lived streams: give the blocks of the others back (after their work has drained)
-    XG_HIP(hipDeviceSynchronize());
-    for (auto& kv : cs.ws) {
-      if (kv.second.slots) (void)hipFree(kv.second.slots);
-      if (kv.second.ticket) (void)hipFree(kv.second.ticket);
-    }
-    cs.ws.clear();
-  }
   ChainState::PerStream& w = cs.ws[std::make_pair(dev, stream)];
   if (!w.ticket) {
     XG_HIP(hipMalloc((void**)&w.ticket, 1024));  // 8 counters, 128 B apart
     XG_HIP(hipMemsetAsync(w.ticket, 0, 1024, st));
   }
   if (w.bytes < slot_bytes) {
-    if (w.slots) {
-      XG_HIP(hipStreamSynchronize(st));  // an earlier launch on this stream may still use the old block
-      XG_HIP(hipFree(w.slots));
-      w.slots = nullptr;
-      w.bytes = 0;
-    }
+    // an outgrown block is RETIRED, never freed: a hipGraph captured on this stream holds its address (it stays
+    // all-zero and private to those replays); growth is geometric, so the retired blocks sum to less than the live one
+    w.slots = nullptr;
+    w.bytes = 0;
     u64 want = slot_bytes + slot_bytes / 4;
     XG_HIP(hipMalloc(&w.slots, want));
     XG_HIP(hipMemsetAsync(w.slots, 0, want, st));
@@ -245,6 +234,12 @@ int xg_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void* stream) {
   return 0;
 }
 int xg_stream_sync(void* stream) { XG_HIP(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+int xg_stream_create(void** stream) {
+  if (!stream) return fail(XG_ERR_INVALID, "NULL argument");
+  XG_HIP(hipStreamCreateWithFlags((hipStream_t*)stream, hipStreamNonBlocking));
+  return 0;
+}
+int xg_stream_destroy(void* stream) { XG_HIP(hipStreamDestroy((hipStream_t)stream)); return 0; }
 int xg_event_create(void** ev) { XG_HIP(hipEventCreate((hipEvent_t*)ev)); return 0; }
 int xg_event_record(void* ev, void* stream) { XG_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return 0; }
 int xg_event_elapsed_ms(void* start, void* stop, float* ms) {

@@ -45,9 +45,20 @@ def _tensors(obj, found):
 class CapturedChain:
     """The result of :func:`capture`: call it to replay; `outputs` is what `fn` returned during capture."""
 
-    def __init__(self, graph: "torch.cuda.CUDAGraph", outputs: Any):
+    def __init__(self, graph: "torch.cuda.CUDAGraph", outputs: Any, stream_handle=None):
         self._graph = graph
         self.outputs = outputs
+        self._stream_handle = stream_handle  # the capture's own stream: owns the chained kernels' workspace
+
+    def __del__(self):
+        handle, self._stream_handle = getattr(self, "_stream_handle", None), None
+        if handle:
+            try:
+                from . import _hip
+
+                _hip.load().xg_stream_destroy(handle)
+            except Exception:  # interpreter shutdown
+                pass
 
     def __call__(self):
         self._graph.replay()
@@ -61,7 +72,15 @@ def capture(fn: Callable[[], Any], warmup: int = 2) -> CapturedChain:
     library workspaces, metric uploads and halo maps are created there, outside the capture -- then capture it."""
     if not torch.cuda.is_available():
         raise RuntimeError("capture() needs the GPU: operator chains are hipGraphs")
-    side = torch.cuda.Stream()
+    # a stream of the capture's own, not one of torch's pooled 32: the chained scans / reductions keep their hand-off
+    # workspace per stream, and a graph must not share it with another capture or with eager calls
+    import ctypes
+
+    from . import _hip
+
+    handle = ctypes.c_void_p()
+    _hip.check(_hip.load().xg_stream_create(ctypes.byref(handle)))
+    side = torch.cuda.ExternalStream(handle.value)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(max(1, warmup)):
@@ -74,4 +93,4 @@ def capture(fn: Callable[[], Any], warmup: int = 2) -> CapturedChain:
     with torch.cuda.graph(graph, stream=side):
         outputs = fn()
     torch.cuda.current_stream().wait_stream(side)
-    return CapturedChain(graph, outputs)
+    return CapturedChain(graph, outputs, handle)
