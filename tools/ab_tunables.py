@@ -41,6 +41,9 @@ def main():
         "dX": (lambda: D.stencil1d("diff", T, 2, 1, 0, "periodic", m_out=dx), 16 + 8 / nz),
         "dY": (lambda: D.stencil1d("diff", T, 1, 1, 0, "extend", m_out=dx), 16 + 8 / nz),
         "dZ": (lambda: D.stencil1d("diff", T, 0, 1, 0, "fill", m_out=dz), 16),
+        "padX": (lambda: D.pad_nd(T, {2: (1, 1)}, {2: "periodic"}, {}), 16),
+        "padYX": (lambda: D.pad_nd(T, {1: (0, 1), 2: (2, 0)}, {1: "extend", 2: "fill"}, {2: 1.5}), 16),
+        "padYZ": (lambda: D.pad_nd(T, {1: (1, 1), 0: (1, 0)}, {1: "extend", 0: "fill"}, {0: 0.0}), 16),
         "i2": (lambda: D.stencil2d("interp", T, 0, (1, 0), "periodic", 0.0, (1, 0), "extend", 0.0), 16),
         "i2mw": (lambda: D.stencil2d("interp", T, 0, (1, 0), "periodic", 0.0, (1, 0), "extend", 0.0, metrics=(dx[0], dx2[0], dx[0])), 16 + 24 / nz),
         "iZmw": (lambda: D.stencil1d("interp", T, 0, 1, 0, "fill", m_in=dz, m_out=dz), 16),

@@ -96,6 +96,7 @@ struct Tune {
   int seg_max_tiles;  // rows of at most this many 64-lane tiles use the banded short-segment kernel
   int scan_narrow_below; // marching scans with fewer wave-tasks than this use one element per lane
   int pad_rows;          // row-wise generic pad (wave-uniform row logic); 0: one thread per cell
+  int pad_nt;            // row-wise pad: 1 non-temporal stores | 2 non-temporal loads of straight rows | 4 XCD-banded order
   int transform_lds_kb;  // LDS budget of the cell-major conservative kernel (0: always the register-tile kernel)
   int transform_win;   // conservative transform: sliding window of accumulators in LDS (K9d) for up to 64 bins
   int transform_fast;  // streaming path of the linear transform for well-formed columns (0: always the exact search)

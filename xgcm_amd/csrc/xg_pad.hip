@@ -74,9 +74,16 @@ __global__ __launch_bounds__(BLOCK) void k_pad(const real* __restrict__ in, real
 // V == NV when the innermost dim is not padded: rows are straight 16-B copies or fills.
 template <int V, bool INNER>
 __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in, real* __restrict__ out, PadGeo p,
-                                                    u32 nrows, FastDiv ntile) {
+                                                    u32 nrows, FastDiv ntile, int nt) {
   typedef typename VecT<V>::type T;
-  const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + (threadIdx.x >> 6));
+  // nt & 1: non-temporal vector stores, nt & 2: non-temporal loads of the straight rows (streamed once); nt & 4: the
+  // workgroups of the launch cut into 8 contiguous bands, one per XCD
+  u32 lb = blockIdx.x;
+  if (nt & 4) {
+    const u32 pb = (gridDim.x + 7) >> 3;
+    lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  }
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
   const u32 r = fdiv(w, ntile);
   if (r >= nrows) return;
   const u32 tile = w - r * ntile.d;
@@ -131,8 +138,9 @@ __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in,
     T val;
     if (fill_after) val = splat<T>(fv_after);
     else if (fill_before) val = splat<T>(fv_before);
-    else val = *reinterpret_cast<const T*>(in + src + x);
-    *reinterpret_cast<T*>(drow + x) = val;
+    else val = (nt & 2) ? ldg<T, true>(in + src + x) : *reinterpret_cast<const T*>(in + src + x);
+    if (nt & 1) stg<T, true>(drow + x, val);
+    else *reinterpret_cast<T*>(drow + x) = val;
   } else if (V > 1) {
     // any row length: the row starts `lead` cells before a 16-B boundary of the output; those cells and
     // the cells after the last whole group go out as scalars (lane 0 of tile 0 / the lane that owns them),
@@ -156,7 +164,8 @@ __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in,
 #pragma unroll
         for (int k = 0; k < NV; ++k) val[k] = elem(x + k);
       }
-      *reinterpret_cast<dv*>(drow + x) = val;
+      if (nt & 1) stg<dv, true>(drow + x, val);
+      else *reinterpret_cast<dv*>(drow + x) = val;
     } else {
       for (int64_t xx = x; xx < Lo; ++xx) drow[xx] = elem(xx);
     }
@@ -412,8 +421,10 @@ int XG_FN(xg_pad)(const real* in, real* out, const int64_t* shape, int ndim, con
       const u64 nb = (waves + WPB - 1) / WPB;
       if ((rc = check_grid(nb))) return rc;
       const FastDiv fnt = make_fastdiv(nt);
-      if (straight) hipLaunchKernelGGL((k_pad_rows<NV, false>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
-      else hipLaunchKernelGGL((k_pad_rows<NV, true>), dim3((u32)nb), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt);
+      const int band = (tune().pad_nt & 4) ? 1 : 0;
+      const u32 grid = band ? (u32)(((nb + 7) / 8) * 8) : (u32)nb;
+      if (straight) hipLaunchKernelGGL((k_pad_rows<NV, false>), dim3(grid), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt, tune().pad_nt);
+      else hipLaunchKernelGGL((k_pad_rows<NV, true>), dim3(grid), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt, tune().pad_nt);
       XG_LAUNCH_CHECK();
       return XG_OK;
     }

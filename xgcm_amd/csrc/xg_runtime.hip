@@ -17,6 +17,7 @@ const TuneEntry TUNABLES[] = {
     {"seg_max_tiles", &Tune::seg_max_tiles, 2048},
     {"scan_narrow_below", &Tune::scan_narrow_below, 8192},
     {"pad_rows", &Tune::pad_rows, 1},
+    {"pad_nt", &Tune::pad_nt, 7},
     {"transform_lds_kb", &Tune::transform_lds_kb, 64},
     {"transform_win", &Tune::transform_win, 1},
     {"transform_fast", &Tune::transform_fast, 1},
