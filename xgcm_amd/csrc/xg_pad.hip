@@ -286,8 +286,13 @@ __global__ __launch_bounds__(BLOCK) void k_gather(const real* __restrict__ in, c
 // (time, depth, face, j, i) layouts).
 __global__ __launch_bounds__(BLOCK) void k_gather_rows(const real* __restrict__ in, const real* __restrict__ partner,
                                                        real* __restrict__ out, const int64_t* __restrict__ tokens,
-                                                       GatherGeo g, u32 nrows, FastDiv ntile) {
-  const u32 w = __builtin_amdgcn_readfirstlane(blockIdx.x * WPB + (threadIdx.x >> 6));
+                                                       GatherGeo g, u32 nrows, FastDiv ntile, int band) {
+  u32 lb = blockIdx.x;
+  if (band) {  // the workgroups of the launch cut into 8 contiguous bands, one per XCD
+    const u32 pb = (gridDim.x + 7) >> 3;
+    lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  }
+  const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
   const u32 r = fdiv(w, ntile);
   if (r >= nrows) return;
   const u32 tile = w - r * ntile.d;
@@ -510,7 +515,8 @@ int XG_FN(xg_gather)(const real* in, const real* partner, real* out, const int64
     if (waves < 0x7fffffffull) {
       const u64 nb = (waves + WPB - 1) / WPB;
       if ((rc = check_grid(nb))) return rc;
-      hipLaunchKernelGGL(k_gather_rows, dim3((u32)nb), dim3(BLOCK), 0, st, in, partner, out, tokens, g, (u32)nrows64, make_fastdiv(nt));
+      const int band = (tune().pad_nt & 4) ? 1 : 0;
+      hipLaunchKernelGGL(k_gather_rows, dim3(band ? (u32)(((nb + 7) / 8) * 8) : (u32)nb), dim3(BLOCK), 0, st, in, partner, out, tokens, g, (u32)nrows64, make_fastdiv(nt), band);
       XG_LAUNCH_CHECK();
       return XG_OK;
     }
