@@ -355,9 +355,18 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(const real* __restrict__ 
   if (x0 >= Lo) return;
   if (x0 + NV <= Lo) {
     dv val;
+    const int64_t c0 = x0 - lo_in;
+    if (interior && c0 >= 0 && c0 + NV <= Li) {
+      // the whole group is interior (all but the groups touching the halo frame): NV consecutive narrow loads, no
+      // per-element interior test, no token logic
+      const real* sp = in + off + c0;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) val[k] = elem(x0 + k);
-    *reinterpret_cast<dv*>(drow + x0) = val;
+      for (int k = 0; k < NV; ++k) val[k] = sp[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) val[k] = elem(x0 + k);
+    }
+    stg<dv, true>(drow + x0, val);
   } else {
     for (int64_t x = x0; x < Lo; ++x) drow[x] = elem(x);
   }
