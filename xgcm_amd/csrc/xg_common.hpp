@@ -111,6 +111,7 @@ struct Tune {
   int strided_gen;    // flat NV-group kernel for misaligned rows of a strided stencil axis
   int march_band;     // XCD-banded wave order in the column-marching scans / reductions
   int scan_vec;       // aligned-output-group scan for cumsum along the contiguous axis
+  int scan_dpp;       // its wave scan through DPP row shifts / broadcasts instead of __shfl_up
   int contig_gen;     // pair-wise general path for odd / length-changing rows on the contiguous axis
   int deep_waves;     // marching scans/reductions with fewer wave-tasks than this keep 16 loads in flight
   int contig_rw;      // rows per wave-task of the row-wave contiguous-axis metric kernel K1r (0: flat K1)

@@ -31,6 +31,7 @@ const TuneEntry TUNABLES[] = {
     {"strided_gen", &Tune::strided_gen, 1},
     {"march_band", &Tune::march_band, 1},  // config 4 (8 records, cumsum along Z) 14.8 -> 13.1 ms
     {"scan_vec", &Tune::scan_vec, 1},
+    {"scan_dpp", &Tune::scan_dpp, 1},
     {"contig_gen", &Tune::contig_gen, 1},
     {"deep_waves", &Tune::deep_waves, 8192},  // neutral on its own, pays together with scan_narrow_below
     {"contig_rw", &Tune::contig_rw, 2},

@@ -361,6 +361,32 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_chain(
   }
 }
 
+// Inclusive wave scan with DPP row shifts / row broadcasts (VALU data path) instead of __shfl_up (ds_bpermute, the LDS
+// crossbar): 4 shifts inside each row of 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows
+// 2 / 3.  Lanes without a source add 0.  (A different association than the shuffle ladder: contiguous-axis sums are
+// re-associated by contract, 1e-12.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ real dpp_take(real v) {
+#ifdef XG_F32
+  return __uint_as_float((u32)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, ROW_MASK, 0xf, false));
+#else
+  const u64 b = __builtin_bit_cast(u64, v);
+  const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, CTRL, ROW_MASK, 0xf, false);
+  const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  const u64 r = (u64)lo | ((u64)hi << 32);
+  return __builtin_bit_cast(double, r);
+#endif
+}
+__device__ __forceinline__ real wave_scan_dpp(real s) {
+  s += dpp_take<0x111, 0xf>(s);  // row_shr:1
+  s += dpp_take<0x112, 0xf>(s);  // row_shr:2
+  s += dpp_take<0x114, 0xf>(s);  // row_shr:4
+  s += dpp_take<0x118, 0xf>(s);  // row_shr:8
+  s += dpp_take<0x142, 0xa>(s);  // row_bcast:15 -> rows 1, 3
+  s += dpp_take<0x143, 0xc>(s);  // row_bcast:31 -> rows 2, 3
+  return s;
+}
+
 // ------------------------------------------------------------------------------------------
 // K6: cumsum along the CONTIGUOUS axis: one workgroup per row, chunks of 256 elements in scan
 // order, wave-level Hillis-Steele scan with cross-lane shuffles, 4 wave totals through LDS,
@@ -461,7 +487,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
 template <int MET, bool NTS, int BS>
 __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 nrows, ScanArgs a,
-    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, ZBand zb, u32 nwork) {
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, ZBand zb, u32 nwork, int dpp) {
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   constexpr int NW = BS / WAVE;
   __shared__ real wtot[2][NW];
@@ -599,12 +625,15 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
     }
     const real mine = a.reverse ? l[0] : l[NV - 1];
     real s = mine;
+    if (dpp) s = wave_scan_dpp(s);
+    else {
 #pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-      real u = __shfl_up(s, d, WAVE);
-      if (lane >= d) s += u;
+      for (int d = 1; d < WAVE; d <<= 1) {
+        real u = __shfl_up(s, d, WAVE);
+        if (lane >= d) s += u;
+      }
     }
-    real excl = __shfl_up(s, 1, WAVE);
+    real excl = dpp ? dpp_take<0x138, 0xf>(s) : __shfl_up(s, 1, WAVE);  // wave_shr:1
     if (lane == 0) excl = real(0);
     if (lane == WAVE - 1) wtot[buf][wv] = s;
     __syncthreads();
@@ -1140,7 +1169,7 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
       const u32 grid = ((nwork + 7) / 8) * 8;
       const bool nts = tune().nt_store;
       const int bs = tune().scan_block;
-#define XG_L(M, NTS_, BS_) hipLaunchKernelGGL((k_cumsum_contig_vec<M, NTS_, BS_>), dim3(grid), dim3(BS_), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo, zb, nwork)
+#define XG_L(M, NTS_, BS_) hipLaunchKernelGGL((k_cumsum_contig_vec<M, NTS_, BS_>), dim3(grid), dim3(BS_), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo, zb, nwork, tune().scan_dpp)
 #define XG_B(M, NTS_) do { if (bs == 512) XG_L(M, NTS_, 512); else if (bs == 1024) XG_L(M, NTS_, 1024); else if (bs == 128) XG_L(M, NTS_, 128); else if (bs == 64) XG_L(M, NTS_, 64); else XG_L(M, NTS_, 256); } while (0)
 #define XG_M(M) do { if (nts) XG_B(M, true); else XG_B(M, false); } while (0)
       switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
