@@ -287,3 +287,13 @@ def test_graph_capture_needs_the_gpu():
         pytest.skip("a GPU is present")
     with pytest.raises(RuntimeError, match="needs the GPU"):
         capture(lambda: None)
+
+
+def test_every_tunable_is_documented():
+    """INTEGRATION.md's tunables table names every entry of the library's table (xg_runtime.hip)."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = re.findall(r'\{"(\w+)", &Tune::', open(os.path.join(root, "xgcm_amd", "csrc", "xg_runtime.hip")).read())
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert len(names) > 40 and not [n for n in names if f"`{n}`" not in doc]
