@@ -296,4 +296,4 @@ def test_every_tunable_is_documented():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     names = re.findall(r'\{"(\w+)", &Tune::', open(os.path.join(root, "xgcm_amd", "csrc", "xg_runtime.hip")).read())
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
-    assert len(names) > 40 and not [n for n in names if f"`{n}`" not in doc]
+    assert len(names) >= 30 and not [n for n in names if f"`{n}`" not in doc]
