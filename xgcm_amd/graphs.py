@@ -17,7 +17,8 @@ MI355X answer to its small-grid regime (BASELINE config 1 is "plumbing": 4.4 M c
 
 Rules of the capture: inputs and metrics are HBM-resident tensors (no host arrays: a pageable copy cannot be captured),
 their SHAPES are frozen, new values are written into the same storage; outputs are overwritten by every replay -- copy
-what must survive.
+what must survive.  Replays of ONE captured chain must not overlap each other (static outputs, and the chained scans'
+hand-off workspace belongs to the capture); different captured chains are independent.
 """
 from __future__ import annotations
 
