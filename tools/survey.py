@@ -38,10 +38,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--shape", default="75,2400,3600")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     a = ap.parse_args()
     nz, ny, nx = (int(v) for v in a.shape.split(","))
     cells = nz * ny * nx
-    met = lambda shape, seed: D.synthetic(shape, seed, 0, 1000.0, 1000.0)  # noqa: E731
+    tdt = torch.float32 if a.dtype == "f32" else torch.float64
+    esz = 4 if a.dtype == "f32" else 8
+    met = lambda shape, seed: D.synthetic(shape, seed, 0, 1000.0, 1000.0, dtype=tdt)  # noqa: E731
     coords = {"XC": np.arange(nx) + 0.5, "XG": np.arange(nx) * 1.0, "YC": np.arange(ny) + 0.5, "YG": np.arange(ny) * 1.0,
               "Z": np.arange(nz) + 0.5, "Zl": np.arange(nz) * 1.0}
     dv = {"dxC": DataArray(met((ny, nx), 31), ("YC", "XG")), "dxT": DataArray(met((ny, nx), 35), ("YC", "XC")),
@@ -54,7 +57,7 @@ def main():
                 padding={"X": "periodic", "Y": "extend", "Z": "fill"},
                 metrics={("X",): ["dxC", "dxT"], ("Y",): ["dyC", "dyT"], ("Z",): ["drF", "drC"], ("X", "Y"): ["rA", "rAz"]},
                 autoparse_metadata=False)
-    T = DataArray(D.synthetic((nz, ny, nx), 2), ("Z", "YC", "XC"), name="T")
+    T = DataArray(D.synthetic((nz, ny, nx), 2, dtype=tdt), ("Z", "YC", "XC"), name="T")
     mB = 8.0 / nz  # bytes per cell of a 2-D metric read once
     cases = []
     for ax in "XYZ":
@@ -80,8 +83,9 @@ def main():
         except Exception as exc:  # noqa: BLE001
             print(json.dumps({"op": name, "error": f"{type(exc).__name__}: {exc}"[:200]}), flush=True)
             continue
+        bpc = bpc * esz / 8.0  # the byte counts above are written for 8-byte elements
         gbs = cells * bpc / (ms * 1e-3) / 1e9
-        print(json.dumps({"op": name, "ms": round(ms, 3), "bytes_per_cell_fused": round(bpc, 3), "GBps": round(gbs, 1),
+        print(json.dumps({"op": name, "dtype": a.dtype, "ms": round(ms, 3), "bytes_per_cell_fused": round(bpc, 3), "GBps": round(gbs, 1),
                           "frac_8TBps": round(gbs / 8000, 4)}), flush=True)
 
 
