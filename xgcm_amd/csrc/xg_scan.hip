@@ -575,6 +575,10 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
   // bounds checks there (they were half of the loop's VALU work); one 16-B load when input and output groups
   // coincide (no shift, equal row lengths) and the arrays keep the alignment, else NV narrow loads served by L1.
   const bool vec_in = (shift == 0) && (n == no) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
+  // the usual metric runs along the row with unit stride (dx(Y, X)): a row pointer + a 32-bit index instead of a
+  // 64-bit multiply per element (this kernel has the highest VALU share of the library: 0.45)
+  const bool mi_unit = HAS_MI && mi.axis == 1;
+  const real* mi_row = m_in + mi_base;
   auto load_group = [&](int t, real (&x)[NV]) {
     if (t >= groups) {
 #pragma unroll
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
       }
       if (HAS_MI) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) x[k] = x[k] * m_in[mi_base + (int64_t)(i0 + k) * mi.axis];
+        for (int k = 0; k < NV; ++k) x[k] = x[k] * (mi_unit ? mi_row[i0 + k] : m_in[mi_base + (int64_t)(i0 + k) * mi.axis]);
       }
       if (a.skipna) {
 #pragma unroll
