@@ -28,5 +28,6 @@ PY
 sleep 4
 echo "-- rocm-smi under load"
 rocm-smi --showclocks --showpower --showtemp --showperflevel 2>/dev/null | grep -v "^=\|^$\|WARNING" | head -30
-rocm-smi --showmaxpower --showmemvendor --showvbios 2>/dev/null | grep -v "^=\|^$\|WARNING" | head -12
+rocm-smi --showmaxpower --showmemvendor --showvbios --showmemorypartition --showcomputepartition --showfwinfo 2>/dev/null | grep -v "^=\|^$\|WARNING" | head -60
+rocminfo 2>/dev/null | grep -i "Compute Unit\|Max Clock\|L2:\|L3:\|Cacheline\|Size:.*KB" | head -12
 wait
