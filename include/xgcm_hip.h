@@ -72,7 +72,10 @@ int xg_version(void);
 int xg_last_error(char* buf, int n);
 /* Launch-shape tunables (rows per wave-task, band heights, window lengths ...; names in INTEGRATION.md): each
  * starts from the environment variable XG_<NAME> or its measured default; set / read one at run time.  They
- * change speed only, never results.  Not synchronised: set them while no call is in flight. */
+ * change speed only: results are bit-identical under every setting, with one documented exception -- sums along the
+ * CONTIGUOUS axis are re-associated by contract (1e-12 relative), and `scan_dpp` / `scan_vec` / `scan_block` select
+ * among associations there.  (`dbg` holds A/B switches of the measurement tools, not a user setting.)
+ * Not synchronised: set them while no call is in flight. */
 int xg_set_tunable(const char* name, int value);
 int xg_get_tunable(const char* name, int* value);
 int xg_device_count(void);
@@ -85,7 +88,17 @@ int xg_stream_sync(void* stream);
 /* a stream of the library's own (xgcm_amd.graphs.capture records on one: the chained kernels keep their workspace per
  * stream, so a captured graph never shares it with another capture or with eager calls) */
 int xg_stream_create(void** stream);
-int xg_stream_destroy(void* stream);
+int xg_stream_destroy(void* stream); /* synchronises, releases the stream's chained-kernel workspace, destroys */
+/* The long strided-axis scans / weighted reductions run as CHAINED flat launches (chunks of a column hand their running
+ * sum on through one XCD's L2).  A chunk that gives up waiting for its predecessor (scan_chain_spin polls) cannot
+ * damage a result: every chained launch is followed on the same stream by its marching twin, which runs only if a
+ * chunk gave up and then redoes the whole call from the untouched inputs -- callers always read correct data, in
+ * stream order.  The event is reported here: *gave_up = 1 once any chunk has given up (sticky; the library plans
+ * marching kernels from then on), *redone = number of launches redone so far.  xg_chain_rearm() clears the sticky
+ * word (a device whose workgroup -> XCD mapping had not been confirmed is probed again at its next chained launch).
+ * Either pointer may be NULL. */
+int xg_chain_status(int* gave_up, int* redone);
+int xg_chain_rearm(void);
 /* hipEvent helpers so hosts without a HIP binding can time kernels on `stream` */
 int xg_event_create(void** ev);
 int xg_event_record(void* ev, void* stream);

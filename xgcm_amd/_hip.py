@@ -41,6 +41,8 @@ SIGNATURES = {
     "xg_stream_sync": (C.c_int, [_vp]),
     "xg_stream_create": (C.c_int, [C.POINTER(_vp)]),
     "xg_stream_destroy": (C.c_int, [_vp]),
+    "xg_chain_status": (C.c_int, [_intp, _intp]),
+    "xg_chain_rearm": (C.c_int, []),
     "xg_event_create": (C.c_int, [C.POINTER(_vp)]),
     "xg_event_record": (C.c_int, [_vp, _vp]),
     "xg_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
@@ -166,6 +168,43 @@ def get_tunable(name: str) -> int:
     v = C.c_int(0)
     check(load().xg_get_tunable(name.encode(), C.byref(v)))
     return int(v.value)
+
+
+class ChainRescueWarning(RuntimeWarning):
+    """A chained scan / reduction gave up on a hand-off and was redone, in stream, by its marching twin."""
+
+
+_chain_reported = [0, 0]
+
+
+def chain_status():
+    """(gave_up, redone) of xg_chain_status: sticky "some chunk of a chained launch gave up", launches redone so far"""
+    g, r = C.c_int(0), C.c_int(0)
+    check(load().xg_chain_status(C.byref(g), C.byref(r)))
+    return int(g.value), int(r.value)
+
+
+def chain_check() -> None:
+    """Called wherever results leave the library towards the host (tohost / .values, graph replays, stream syncs of
+    the streaming paths): warn ONCE per event that a chained launch had to be redone.  The data the caller reads is
+    the marching kernel's -- correct -- so this is a warning, not an error (include/xgcm_hip.h: xg_chain_status)."""
+    if _lib is None:
+        return
+    g, r = chain_status()
+    if g > _chain_reported[0] or r > _chain_reported[1]:
+        _chain_reported[0], _chain_reported[1] = g, r
+        import warnings
+
+        warnings.warn(
+            f"xgcm_amd: a chained scan / reduction kernel gave up waiting for a predecessor chunk; {r} launch(es) so far "
+            "were redone by the marching kernel on the same stream (results are correct).  The library plans marching "
+            "kernels from now on; xgcm_amd._hip.chain_rearm() re-enables the chained ones, XG_SCAN_CHAIN=0 avoids them.",
+            ChainRescueWarning, stacklevel=3)
+
+
+def chain_rearm() -> None:
+    check(load().xg_chain_rearm())
+    _chain_reported[0] = 0
 
 
 def last_error() -> str:

@@ -128,6 +128,7 @@ struct Tune {
   int scan_pace;      // experiment: workgroup barrier per window in the pipelined marching scan
   int scan_chain;     // long strided-axis scans as a chained flat launch (K5c); 2: whenever the march has >= 2 chunks
   int scan_chain_w;   // K5c: levels' worth of columns that advance side by side inside one XCD band
+  int scan_chain_spin; // polls of a hand-off slot before a chunk gives up (the launch is then redone by the march, in stream)
   int reduce_zl;      // K4cz: outer indices per task of the chained weighted reduction sharing the weight rows (1 / 2 / 4)
   int dbg;            // A/B switches that do NOT change results (bit 2: the linear transform's division inside its loop)
   int march_lds_kb;   // optional dynamic LDS request for the column-marching kernels, only to cap residency
@@ -137,16 +138,22 @@ struct Tune {
 extern "C" __attribute__((visibility("hidden"))) Tune* xg_internal_tune(void);
 inline const Tune& tune() { return *xg_internal_tune(); }
 
-// workspace of the chained scan (K5c, xg_scan.hip), one per stream, owned by xg_runtime.hip: `slot_bytes` of running-sum
-// slots (all zero between launches: the kernel cleans up after itself), 8 ticket counters (same), and one sticky
-// host-visible word that a wave sets when it gives up waiting for a predecessor.  xg_internal_chain_ok(): 1 when
-// workgroups whose ids agree modulo 8 share an XCD on this device (probed once) -- the chain passes its sums through
-// that XCD's L2 -- and no wave has ever given up.
-struct ChainWs { void* slots; u32* ticket; u32* gave_up; };
+// workspace of the chained scans / reductions (K5c, K4c: xg_scan.hip), one per (device, stream), owned by xg_runtime.hip:
+//   slots   `slot_bytes` of running-sum slots, all zero between launches (the kernels clean up after themselves);
+//   ticket  8 ticket counters, 128 B apart (same);
+//   poison  two device words of the stream: [0] set by a wave that gives up waiting for its predecessor chunk (it
+//           passes NaN on with a valid epoch, so its column is visibly poisoned and nobody waits behind it), [1] the
+//           rescue kernel's count of finished workgroups.  EVERY chained launch is followed, on the same stream, by its
+//           marching twin with poison[0] as its run-if word: zero (always, in practice) and every workgroup leaves at
+//           once; non-zero and it redoes the whole call from the untouched inputs, scrubs the slots and clears the word.
+//           A damaged result therefore never reaches a consumer, host or device, eager or under graph replay;
+//   gave_up two host-mapped words for reporting only: [0] sticky, some wave has given up (the library then plans
+//           marches until xg_chain_rearm()), [1] number of launches the rescue kernel has redone (xg_chain_status()).
+// xg_internal_chain_ok(): 1 when workgroups whose ids agree modulo 8 share an XCD on this device (probed once) -- the
+// chain passes its sums through that XCD's L2 -- and no wave has given up since the last re-arm.
+struct ChainWs { void* slots; u64 slot_bytes; u32* ticket; u32* gave_up; u32* poison; };
 extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ws(void* stream, u64 slot_bytes, ChainWs* ws);
 extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ok(void);
-// 1 exactly once after a wave has given up: the entry points that may have produced the damaged result report it loudly
-extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_poisoned(void);
 
 // ------------------------------------------------------------------------------------------
 // geometry: a C-contiguous N-D array seen as (outer..., n, inner...) around the op axis,

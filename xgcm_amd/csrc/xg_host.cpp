@@ -282,7 +282,7 @@ int fill_synthetic(R* out, int64_t n, uint64_t seed, uint64_t offset, double sca
 
 // tunables: the names of the device library (xg_runtime.hip::TUNABLES), accepted and remembered so that bindings
 // can be exercised; they have no effect on the host loops
-const char* const KNOWN_TUNABLES[] = {"seg", "nt_store", "nt_load", "seg_max_tiles", "scan_narrow_below", "pad_rows", "pad_nt", "transform_lds_kb", "transform_win", "transform_fast", "transform_stage", "transform_ring", "transform_cwin", "zchunk", "zband", "zb_rows", "scan_block", "strided_gen", "march_band", "scan_vec", "scan_dpp", "contig_gen", "deep_waves", "contig_rw", "rw_zshare", "met_zk", "met_zk1", "vec_zk", "contig_rw_mi", "met_seg", "met_seg1", "met_scalar", "scan_pipe", "scan_u", "scan_pace", "scan_chain", "scan_chain_w", "reduce_zl", "dbg", "march_lds_kb"};
+const char* const KNOWN_TUNABLES[] = {"seg", "nt_store", "nt_load", "seg_max_tiles", "scan_narrow_below", "pad_rows", "pad_nt", "transform_lds_kb", "transform_win", "transform_fast", "transform_stage", "transform_ring", "transform_cwin", "zchunk", "zband", "zb_rows", "scan_block", "strided_gen", "march_band", "scan_vec", "scan_dpp", "contig_gen", "deep_waves", "contig_rw", "rw_zshare", "met_zk", "met_zk1", "vec_zk", "contig_rw_mi", "met_seg", "met_seg1", "met_scalar", "scan_pipe", "scan_u", "scan_pace", "scan_chain", "scan_chain_w", "scan_chain_spin", "reduce_zl", "dbg", "march_lds_kb"};
 struct Knob { const char* name; int value; bool set; };
 std::vector<Knob>& knobs() {
   static std::vector<Knob> k;
@@ -334,6 +334,13 @@ int xg_stream_create(void** stream) {
   return XG_OK;
 }
 int xg_stream_destroy(void*) { return XG_OK; }
+// (no chained kernels on the host: nothing ever gives up)
+int xg_chain_status(int* gave_up, int* redone) {
+  if (gave_up) *gave_up = 0;
+  if (redone) *redone = 0;
+  return XG_OK;
+}
+int xg_chain_rearm(void) { return XG_OK; }
 int xg_event_create(void** ev) {
   if (!ev) return fail(XG_ERR_INVALID, "NULL argument");
   *ev = calloc(1, sizeof(double));

@@ -48,6 +48,7 @@ const TuneEntry TUNABLES[] = {
     {"scan_pace", &Tune::scan_pace, 0},
     {"scan_chain", &Tune::scan_chain, 1},
     {"scan_chain_w", &Tune::scan_chain_w, 1},
+    {"scan_chain_spin", &Tune::scan_chain_spin, 1 << 22},
     {"reduce_zl", &Tune::reduce_zl, 2},
     {"dbg", &Tune::dbg, 0},
     {"march_lds_kb", &Tune::march_lds_kb, 0},
@@ -74,31 +75,47 @@ extern "C" __attribute__((visibility("hidden"))) Tune* xg_internal_tune(void) {
 
 #ifdef XG_PRIMARY
 // ------------------------------------------------------------------------------------------
-// workspace + device check of the chained scan (declared in xg_common.hpp)
+// workspace + device check of the chained scans / reductions (declared in xg_common.hpp)
 // ------------------------------------------------------------------------------------------
 #include <map>
 #include <mutex>
+#include <vector>
 namespace {
 __global__ void k_xcc_probe(u32* ids) {
   u32 id;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
   if (threadIdx.x == 0) ids[blockIdx.x] = id & 0xfu;
 }
+constexpr u64 TICKET_BYTES = 2048;  // 8 counters 128 B apart, then the two poison words (xg_common.hpp)
 struct ChainState {
   std::mutex mu;
-  struct PerStream { void* slots = nullptr; u64 bytes = 0; u32* ticket = nullptr; };
+  struct PerStream {
+    void* slots = nullptr;
+    u64 bytes = 0;
+    u32* ticket = nullptr;
+    std::vector<void*> retired;  // outgrown slot blocks: a hipGraph captured on the stream may still hold their address
+  };
   std::map<std::pair<int, void*>, PerStream> ws;  // (device, stream)
   std::map<int, int> mapping_ok;                   // device -> probe result
-  u32* gave_up_host = nullptr;
-  u32* gave_up_dev = nullptr;
+  std::map<int, u32*> gave_up_dev;                 // device -> device address of the host-mapped words
+  u32* gave_up_host = nullptr;                     // [0] sticky "a wave gave up", [1] launches redone by the rescue kernel
 };
 ChainState& chain_state() { static ChainState s; return s; }
+void release(ChainState::PerStream& w) {
+  for (void* p : w.retired) (void)hipFree(p);
+  w.retired.clear();
+  if (w.slots) (void)hipFree(w.slots);
+  if (w.ticket) (void)hipFree(w.ticket);
+  w.slots = nullptr;
+  w.ticket = nullptr;
+  w.bytes = 0;
+}
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ok(void) {
   ChainState& cs = chain_state();
   std::lock_guard<std::mutex> lock(cs.mu);
-  if (cs.gave_up_host && *cs.gave_up_host) return 0;
+  if (cs.gave_up_host && __atomic_load_n(&cs.gave_up_host[0], __ATOMIC_RELAXED)) return 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   auto it = cs.mapping_ok.find(dev);
@@ -123,16 +140,6 @@ extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ok(void) 
   return ok;
 }
 
-extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_poisoned(void) {
-  ChainState& cs = chain_state();
-  std::lock_guard<std::mutex> lock(cs.mu);
-  if (cs.gave_up_host && *cs.gave_up_host == 1) {
-    *cs.gave_up_host = 2;  // reported; xg_internal_chain_ok() keeps answering 0
-    return 1;
-  }
-  return 0;
-}
-
 extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ws(void* stream, u64 slot_bytes, ChainWs* out) {
   ChainState& cs = chain_state();
   std::lock_guard<std::mutex> lock(cs.mu);
@@ -140,28 +147,35 @@ extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ws(void* 
   int dev = 0;
   XG_HIP(hipGetDevice(&dev));
   if (!cs.gave_up_host) {
-    XG_HIP(hipHostMalloc((void**)&cs.gave_up_host, 64, hipHostMallocMapped));
-    *cs.gave_up_host = 0;
-    XG_HIP(hipHostGetDevicePointer((void**)&cs.gave_up_dev, cs.gave_up_host, 0));
+    // portable: one pair of words for every device of the process (one process per GPU is the model, but a host
+    // driving several devices must not hand device 0's mapping to a kernel on device 1)
+    XG_HIP(hipHostMalloc((void**)&cs.gave_up_host, 64, hipHostMallocMapped | hipHostMallocPortable));
+    memset(cs.gave_up_host, 0, 64);
   }
+  u32*& gdev = cs.gave_up_dev[dev];
+  if (!gdev) XG_HIP(hipHostGetDevicePointer((void**)&gdev, cs.gave_up_host, 0));
   ChainState::PerStream& w = cs.ws[std::make_pair(dev, stream)];
   if (!w.ticket) {
-    XG_HIP(hipMalloc((void**)&w.ticket, 1024));  // 8 counters, 128 B apart
-    XG_HIP(hipMemsetAsync(w.ticket, 0, 1024, st));
+    XG_HIP(hipMalloc((void**)&w.ticket, TICKET_BYTES));
+    XG_HIP(hipMemsetAsync(w.ticket, 0, TICKET_BYTES, st));
   }
   if (w.bytes < slot_bytes) {
-    // an outgrown block is RETIRED, never freed: a hipGraph captured on this stream holds its address (it stays
-    // all-zero and private to those replays); growth is geometric, so the retired blocks sum to less than the live one
+    // an outgrown block is retired until the stream is destroyed: a hipGraph captured on this stream holds its address
+    // (it stays all-zero and private to those replays).  Growth doubles, so the retired blocks of a stream sum to
+    // less than its live one.
+    if (w.slots) w.retired.push_back(w.slots);
     w.slots = nullptr;
     w.bytes = 0;
-    u64 want = slot_bytes + slot_bytes / 4;
+    const u64 want = slot_bytes * 2;
     XG_HIP(hipMalloc(&w.slots, want));
     XG_HIP(hipMemsetAsync(w.slots, 0, want, st));
     w.bytes = want;
   }
   out->slots = w.slots;
+  out->slot_bytes = w.bytes;
   out->ticket = w.ticket;
-  out->gave_up = cs.gave_up_dev;
+  out->poison = w.ticket + 256;
+  out->gave_up = gdev;
   return XG_OK;
 }
 #endif  // XG_PRIMARY
@@ -241,7 +255,43 @@ int xg_stream_create(void** stream) {
   XG_HIP(hipStreamCreateWithFlags((hipStream_t*)stream, hipStreamNonBlocking));
   return 0;
 }
-int xg_stream_destroy(void* stream) { XG_HIP(hipStreamDestroy((hipStream_t)stream)); return 0; }
+int xg_stream_destroy(void* stream) {
+  if (!stream) return fail(XG_ERR_INVALID, "the null stream cannot be destroyed");
+  XG_HIP(hipStreamSynchronize((hipStream_t)stream));
+  {  // the chained kernels' workspace of this stream goes with it (a recycled handle must not inherit it)
+    ChainState& cs = chain_state();
+    std::lock_guard<std::mutex> lock(cs.mu);
+    for (auto it = cs.ws.begin(); it != cs.ws.end();) {
+      if (it->first.second == stream) {
+        release(it->second);
+        it = cs.ws.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  XG_HIP(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+int xg_chain_status(int* gave_up, int* redone) {
+  ChainState& cs = chain_state();
+  std::lock_guard<std::mutex> lock(cs.mu);
+  const u32 g = cs.gave_up_host ? __atomic_load_n(&cs.gave_up_host[0], __ATOMIC_RELAXED) : 0u;
+  const u32 r = cs.gave_up_host ? __atomic_load_n(&cs.gave_up_host[1], __ATOMIC_RELAXED) : 0u;
+  if (gave_up) *gave_up = (int)g;
+  if (redone) *redone = (int)r;
+  return 0;
+}
+int xg_chain_rearm(void) {
+  ChainState& cs = chain_state();
+  std::lock_guard<std::mutex> lock(cs.mu);
+  if (cs.gave_up_host) __atomic_store_n(&cs.gave_up_host[0], 0u, __ATOMIC_RELAXED);
+  // a device whose workgroup -> XCD mapping was NOT confirmed is probed again at its next chained launch (the
+  // partition mode may be what changed); confirmed ones keep their answer, so re-arming is legal under stream capture
+  for (auto it = cs.mapping_ok.begin(); it != cs.mapping_ok.end();)
+    it = it->second ? std::next(it) : cs.mapping_ok.erase(it);
+  return 0;
+}
 int xg_event_create(void** ev) { XG_HIP(hipEventCreate((hipEvent_t*)ev)); return 0; }
 int xg_event_record(void* ev, void* stream) { XG_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return 0; }
 int xg_event_elapsed_ms(void* start, void* stop, float* ms) {

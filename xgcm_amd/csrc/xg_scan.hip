@@ -43,10 +43,10 @@ __device__ __forceinline__ dv as_count(dv v, int mode) {
 // PIPE: the U loads of a lane form a rolling window -- every consumed row is replaced by the load of the row U
 // steps ahead, so U - 1 loads stay in flight through the whole march instead of draining at every batch of U
 // (few, long columns: cumsum along Y of (Z,Y,X) has ~4 waves per SIMD, occupancy cannot hide the drain).
-template <int V, int MET, bool NTL, bool NTS, int U, bool PIPE = false>
-__global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
-    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
-    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, int band) {
+template <int V, int MET, bool NTL, bool NTS, int U, bool PIPE>
+__device__ __forceinline__ void cumsum_strided_body(
+    const real* __restrict__ in, real* __restrict__ out, const Geo& g, u32 ntile, const ScanArgs& a,
+    const real* __restrict__ m_in, const MIdx& mi, const real* __restrict__ m_out, const MIdx& mo, int band) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   // U independent loads in flight per lane (the scan chain only consumes them)
@@ -153,6 +153,12 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
     put(g.n_out - 1, h);
   }
 }
+template <int V, int MET, bool NTL, bool NTS, int U, bool PIPE = false>
+__global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, int band) {
+  cumsum_strided_body<V, MET, NTL, NTS, U, PIPE>(in, out, g, ntile, a, m_in, mi, m_out, mo, band);
+}
 
 // ------------------------------------------------------------------------------------------
 // K5c: cumsum along a STRIDED axis for few, LONG columns (cumsum along Y of (Z, Y, X): 4 288 marches of 2 400 rows)
@@ -173,14 +179,18 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
 //     a buffer_wbl2 / buffer_inv per task, 17 ms), polled with sc1 loads (bypass the L1); 0.3 us per hand-off when
 //     idle (tools/pingpong.hip), ~1 us under load.  The last chunk of a column zeroes its two slots: the workspace
 //     is all-zero between launches (no per-launch memset, safe under graph replay);
-//   the spin is bounded: a wave that gives up sets a sticky host-visible word and the library stops using K5c.
+//   the spin is bounded (`scan_chain_spin` polls): a wave that gives up poisons its column with NaN and raises the
+//     stream's poison word, on which the rescue kernel queued behind every chained launch redoes the call (chain_wait).
 // ------------------------------------------------------------------------------------------
 struct ChainArgs {
   u32 nchunk, cpx, ncol, W, nblk;  // chunks per column, columns per XCD band, columns, sub-band width, workgroups per band
   u32 srow;                        // slots per ring row = lanes per row of the array
+  u32 spin;                        // polls of a slot before giving up
   u32* ticket;
-  u32* gave_up;
+  u32* gave_up;                    // host-mapped: [0] sticky report, [1] launches redone
+  u32* poison;                     // device: [0] run-if word of this launch's rescue kernel, [1] its workgroup count
   void* slots;
+  u64 nslot;                       // 16-B slots in the workspace block (the rescue kernel scrubs them all)
 };
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
@@ -242,15 +252,56 @@ __device__ __forceinline__ bool chain_task(const ChainArgs& ch, u32 ntile, u32& 
   return true;
 }
 
-// one hand-off slot: spin (bounded) until the epoch of both halves is `want`
-__device__ __forceinline__ u32x4 chain_wait(const u32x4* src, u32 want, u32* gave_up) {
+// one hand-off slot: spin (bounded) until the epoch of both halves is `want`.  A wave that gives up raises the
+// stream's poison word -- the rescue kernel queued behind this launch then redoes the whole call with the march --
+// and carries on with NaN under a VALID epoch: its own rows and everything downstream in the column are visibly
+// poisoned, and no later chunk spins behind it.
+template <typename T>
+__device__ __forceinline__ T chain_wait(const u32x4* src, u32 want, const ChainArgs& ch) {
   u32x4 got;
   u32 tries = 0;
   do {
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n s_waitcnt vmcnt(0)" : "=&v"(got) : "v"(src) : "memory");
-  } while ((got[1] != want || got[3] != want) && ++tries < (1u << 22));
-  if (got[1] != want || got[3] != want) __hip_atomic_store(gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  return got;
+  } while ((got[1] != want || got[3] != want) && ++tries < ch.spin);
+  if (got[1] != want || got[3] != want) {
+    __hip_atomic_store(ch.poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ch.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return splat<T>(real(__builtin_nan("")));
+  }
+  return chain_unpack<T>(got);
+}
+
+// The rescue kernels: the marching twin of a chained launch, queued right behind it on the same stream with the
+// stream's poison word as run-if.  Zero (in practice always): every workgroup leaves after one scalar load.  Non-zero:
+// the inputs are untouched, so the march redoes the whole call (same additions in the same order: the bits the chain
+// would have produced), every thread helps zeroing the hand-off slots -- a chunk that published after its successor
+// had given up leaves a stale epoch behind -- and the last workgroup to finish clears the word and counts the event.
+struct Rescue { u32* poison; u32* gave_up; u32x4* slots; u64 nslot; };
+__device__ __forceinline__ bool rescue_begin(const Rescue& rs) {
+  if (__hip_atomic_load(rs.poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return false;
+  const u32x4 zero = {0u, 0u, 0u, 0u};
+  for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < rs.nslot; i += (u64)gridDim.x * BLOCK) rs.slots[i] = zero;
+  return true;
+}
+__device__ __forceinline__ void rescue_end(const Rescue& rs) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const u32 done = atomicAdd(&rs.poison[1], 1u);
+    if (done == gridDim.x - 1) {  // every workgroup has read poison[0] (at its start) and finished its columns
+      __hip_atomic_store(&rs.poison[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&rs.poison[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&rs.gave_up[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+template <int MET>
+__global__ __launch_bounds__(BLOCK) void k_cumsum_rescue(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, int band, Rescue rs) {
+  if (!rescue_begin(rs)) return;
+  cumsum_strided_body<HV, MET, true, true, 8, true>(in, out, g, ntile, a, m_in, mi, m_out, mo, band);
+  rescue_end(rs);
 }
 
 template <int MET, int R>
@@ -313,7 +364,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_chain(
   T acc = splat<T>(real(0));
   if (c > 0) {
     const u32x4* src = ring + ((size_t)o32 * 2 + ((c - 1) & 1)) * ch.srow + lx;
-    acc = chain_unpack<T>(chain_wait(src, c, ch.gave_up));
+    acc = chain_wait<T>(src, c, ch);
   }
   // the chunk's cumulative values, in the march's order (the first row of the column is assigned, not added to 0)
 #pragma unroll
@@ -689,10 +740,10 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
 // ------------------------------------------------------------------------------------------
 // WMODE: 0 no weights, 1 a weight per cell of the row, 2 ONE weight per row (drF(Z) under (Z, Y, X): wave-uniform, read
 // through the scalar cache; nothing rides in the window)
-template <int V, int WMODE, bool NTL, int U, bool PIPE = false>
-__global__ __launch_bounds__(BLOCK) void k_reduce_strided(
-    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, int skipna,
-    const real* __restrict__ wgt, MIdx mw, int band) {
+template <int V, int WMODE, bool NTL, int U, bool PIPE>
+__device__ __forceinline__ void reduce_strided_body(
+    const real* __restrict__ in, real* __restrict__ out, const Geo& g, u32 ntile, int skipna,
+    const real* __restrict__ wgt, const MIdx& mw, int band) {
   typedef typename VecT<V>::type T;
   constexpr bool HAS_W = WMODE != 0, WU = WMODE == 2;
   // U independent loads in flight per lane
@@ -790,6 +841,20 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_strided(
     *reinterpret_cast<T*>(out + o * inner + x) = mean ? acc / den : acc;
   }
 }
+template <int V, int WMODE, bool NTL, int U, bool PIPE = false>
+__global__ __launch_bounds__(BLOCK) void k_reduce_strided(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, int skipna,
+    const real* __restrict__ wgt, MIdx mw, int band) {
+  reduce_strided_body<V, WMODE, NTL, U, PIPE>(in, out, g, ntile, skipna, wgt, mw, band);
+}
+// the rescue twin of the chained weighted reductions (see k_cumsum_rescue)
+__global__ __launch_bounds__(BLOCK) void k_reduce_rescue(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, int skipna,
+    const real* __restrict__ wgt, MIdx mw, int band, Rescue rs) {
+  if (!rescue_begin(rs)) return;
+  reduce_strided_body<HV, 1, true, 8, true>(in, out, g, ntile, skipna, wgt, mw, band);
+  rescue_end(rs);
+}
 
 // K4c: the long WEIGHTED march (integrate / average along Y of (Z, Y, X) with dy(Y, X)) as a chained flat launch, K5c
 // without the stores: a marching wave keeps the weight of every in-flight row in registers next to the row, so its
@@ -865,8 +930,8 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_chain(
   T acc = splat<T>(real(0)), den = splat<T>(real(0));
   if (c > 0) {
     const u32x4* src = ring + (((size_t)o32 * 2 + ((c - 1) & 1)) * ch.srow + lx) * np;
-    acc = chain_unpack<T>(chain_wait(src, c, ch.gave_up));
-    if (mean) den = chain_unpack<T>(chain_wait(src + 1, c, ch.gave_up));
+    acc = chain_wait<T>(src, c, ch);
+    if (mean) den = chain_wait<T>(src + 1, c, ch);
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -950,8 +1015,8 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_chain_z(
     T acc = splat<T>(real(0)), den = splat<T>(real(0));
     if (c > 0) {
       const u32x4* src = ring + (((size_t)o32 * 2 + ((c - 1) & 1)) * ch.srow + lx) * np;
-      acc = chain_unpack<T>(chain_wait(src, c, ch.gave_up));
-      if (mean) den = chain_unpack<T>(chain_wait(src + 1, c, ch.gave_up));
+      acc = chain_wait<T>(src, c, ch);
+      if (mean) den = chain_wait<T>(src + 1, c, ch);
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -1080,6 +1145,14 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
 
 }  // namespace
 
+// geometry of the marching twin (8-byte lanes, XCD-banded wave order) that follows every chained launch as its rescue
+inline int rescue_grid(const Geo& g, u32* ntile, u64* nblocks) {
+  *ntile = ceil_div_u32(g.inner, (int64_t)WAVE * HV);
+  const u64 ntask = (u64)*ntile * (u64)g.outer;
+  *nblocks = (((ntask + WPB - 1) / WPB + 7) / 8) * 8;
+  return check_grid(*nblocks);
+}
+
 // Launch plan of the chained kernels (K5c / K4c): false when the march is not long-and-narrow enough, the sizes do
 // not fit the 32-bit task arithmetic, the device's workgroup -> XCD mapping was not confirmed, or the workspace cannot
 // be had (the caller then takes the marching kernel; an allocation failure leaves its message in xg_last_error).
@@ -1119,7 +1192,10 @@ bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void
   if (xg_internal_chain_ws(stream, slot_bytes, &ws)) return false;
   ch->ticket = ws.ticket;
   ch->gave_up = ws.gave_up;
+  ch->poison = ws.poison;
   ch->slots = ws.slots;
+  ch->nslot = ws.slot_bytes / 16;
+  ch->spin = tune().scan_chain_spin < 1 ? 1u : (u32)tune().scan_chain_spin;
   *ctile_out = (u32)ctile;
   *nblk_out = nblk;
   return true;
@@ -1136,9 +1212,6 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
                     const int64_t* m_out_strides, void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if ((trim_lo | trim_hi | pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "trim/pad widths must be 0 or 1");
-  if (xg_internal_chain_poisoned())
-    return fail(XG_ERR_HIP, "an earlier chained scan / reduction on this device gave up waiting for a predecessor chunk: its result is invalid; "
-                            "the library has switched to the marching kernels (XG_SCAN_CHAIN=0 avoids the chained kernels from the start)");
   if (bc < XG_BC_NONE || bc > XG_BC_EXTEND) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
   if ((pad_lo || pad_hi) && bc == XG_BC_NONE) return fail(XG_ERR_INVALID, "halo cells requested but no boundary mode given");
   if ((m_in && !m_in_strides) || (m_out && !m_out_strides)) return fail(XG_ERR_INVALID, "metric without strides");
@@ -1220,8 +1293,17 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
       u64 nblk = 0;
       if (chain_plan(g, 32, 1, shared_metric, stream, &ch, &ctile, &nblk, 1, true)) {
 #define XG_C(M, R_) hipLaunchKernelGGL((k_cumsum_chain<M, R_>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, ctile, a, m_in, mi, m_out, mo, ch)
+        u32 rtile = 0;
+        u64 rblocks = 0;
+        if ((rc = rescue_grid(g, &rtile, &rblocks))) return rc;
+        const Rescue rs = {ch.poison, ch.gave_up, reinterpret_cast<u32x4*>(ch.slots), ch.nslot};
         switch (met) { case 0: XG_C(0, 32); break; case 1: XG_C(1, 32); break; case 2: XG_C(2, 32); break; default: XG_C(3, 32); }
 #undef XG_C
+        XG_LAUNCH_CHECK();
+        // the marching twin, run-if poisoned (k_cumsum_rescue): leaves at once unless a chunk of the launch above gave up
+#define XG_R(M) hipLaunchKernelGGL((k_cumsum_rescue<M>), dim3((u32)rblocks), dim3(BLOCK), 0, st, in, out, g, rtile, a, m_in, mi, m_out, mo, 1, rs)
+        switch (met) { case 0: XG_R(0); break; case 1: XG_R(1); break; case 2: XG_R(2); break; default: XG_R(3); }
+#undef XG_R
         XG_LAUNCH_CHECK();
         return XG_OK;
       }
@@ -1253,9 +1335,6 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
                     const real* w, const int64_t* w_strides, void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (w && !w_strides) return fail(XG_ERR_INVALID, "weight without strides");
-  if (xg_internal_chain_poisoned())
-    return fail(XG_ERR_HIP, "an earlier chained scan / reduction on this device gave up waiting for a predecessor chunk: its result is invalid; "
-                            "the library has switched to the marching kernels (XG_SCAN_CHAIN=0 avoids the chained kernels from the start)");
   if (skipna < 0 || skipna > 7) return fail(XG_ERR_INVALID, "skipna / count / mean mode %d not in [0,7]", skipna);
   Geo g; MIdx mw;
   int rc = build_geo(shape, ndim, axis, 1, w ? w_strides : nullptr, nullptr, &g, &mw, nullptr);
@@ -1313,16 +1392,25 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
       ChainArgs ch;
       u32 ctile = 0;
       u64 nblk = 0;
+      bool chained = false;
       const int zl = tune().reduce_zl;  // levels per task sharing the weight rows (K4cz); 1: K4c
       // (measured: 2 levels x 16 rows 61-63 %, 3 x 16 59 %, 4 x 16 55 %, 4 x 8 59 %, 2 x 32 50 %, K4c 56-57 %, the march 51 %)
       if (shared_w && zl >= 2 && g.outer >= 2 && chain_plan(g, 16, skipna >= 4 ? 2 : 1, shared_w, stream, &ch, &ctile, &nblk, zl >= 4 ? 4 : 2)) {
         if (zl >= 4) hipLaunchKernelGGL((k_reduce_chain_z<16, 4>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, ctile, skipna, w, mw, ch);
         else hipLaunchKernelGGL((k_reduce_chain_z<16, 2>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, ctile, skipna, w, mw, ch);
         XG_LAUNCH_CHECK();
-        return XG_OK;
-      }
-      if (shared_w && chain_plan(g, 32, skipna >= 4 ? 2 : 1, shared_w, stream, &ch, &ctile, &nblk)) {
+        chained = true;
+      } else if (shared_w && chain_plan(g, 32, skipna >= 4 ? 2 : 1, shared_w, stream, &ch, &ctile, &nblk)) {
         hipLaunchKernelGGL((k_reduce_chain<true, 32>), dim3((u32)(nblk * 8)), dim3(BLOCK), 0, st, in, out, g, ctile, skipna, w, mw, ch);
+        XG_LAUNCH_CHECK();
+        chained = true;
+      }
+      if (chained) {  // the marching twin, run-if poisoned (k_reduce_rescue)
+        u32 rtile = 0;
+        u64 rblocks = 0;
+        if ((rc = rescue_grid(g, &rtile, &rblocks))) return rc;
+        const Rescue rs = {ch.poison, ch.gave_up, reinterpret_cast<u32x4*>(ch.slots), ch.nslot};
+        hipLaunchKernelGGL(k_reduce_rescue, dim3((u32)rblocks), dim3(BLOCK), 0, st, in, out, g, rtile, skipna, w, mw, 1, rs);
         XG_LAUNCH_CHECK();
         return XG_OK;
       }

@@ -6,6 +6,10 @@ enqueued on, so `torch.cuda.Event`, `torch.distributed` and user torch code orde
 against them.  No arithmetic is delegated to torch and there is no CPU path: without a GPU or
 without the built library every function raises.
 
+Return types: an HBM `torch.Tensor`, except that `stencil1d` / `cumsum1d` / `reduce1d` handed a HOST array of
+`HOST_STREAM_MIN_BYTES` or more return a host `numpy.ndarray` (the block-wise pipelined path below brings the result
+back block by block; callers that need a tensor -- `sharding.cumsum_along_sharded_axis` -- normalise).
+
 Metric arguments (`m_in`, `m_out`, `w`, `area`) are tensors with the same number of dims as
 the array they weight, each dim either full-size or 1 (broadcast) -- the alignment xarray does
 for `da * metric` (reference xgcm/grid.py:806-808,830-832).
@@ -100,7 +104,9 @@ def _common(*arrays):
 
 def tohost(t) -> np.ndarray:
     if isinstance(t, torch.Tensor):
-        return t.detach().cpu().numpy()
+        a = t.detach().cpu().numpy()  # synchronises the producing stream
+        _hip.chain_check()            # a chained launch that had to be redone is reported where its result is read
+        return a
     return np.asarray(t)
 
 
@@ -147,9 +153,13 @@ def _host_streamable(x, axis: int) -> bool:
             and x.dtype in (np.float32, np.float64) and x.nbytes >= HOST_STREAM_MIN_BYTES and torch.cuda.is_available())
 
 
-def _rows(m, sl):
+def _rows(m, sl, ndim: int, what: str = "metric"):
     """rows `sl` of a dim-aligned metric along the outermost dim (a metric broadcast there passes whole)"""
-    return m if m is None or m.shape[0] == 1 else m[sl]
+    if m is None:
+        return None
+    if len(m.shape) != ndim:  # the check _bstrides makes for HBM inputs, before any slicing along dim 0
+        raise ValueError(f"{what}: metric has {len(m.shape)} dims, array has {ndim}")
+    return m if m.shape[0] == 1 else m[sl]
 
 
 def _streamed(per_block, x: np.ndarray) -> np.ndarray:
@@ -172,7 +182,7 @@ def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str]
     """Fused pad + diff/interp/min/max along `axis` (xg_stencil1d_f64)."""
     lib = _hip.load()
     if _host_streamable(x, axis):  # a large host array: blocks of the outermost dim, copies overlapped with the kernel
-        return _streamed(lambda blk, sl: stencil1d(op, blk, axis, pad_lo, pad_hi, bc, fill, _rows(m_in, sl), _rows(m_out, sl)), x)
+        return _streamed(lambda blk, sl: stencil1d(op, blk, axis, pad_lo, pad_hi, bc, fill, _rows(m_in, sl, x.ndim, 'm_in'), _rows(m_out, sl, x.ndim, 'm_out')), x)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis = axis % x.dim()
@@ -231,7 +241,7 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
     lib = _hip.load()
     if _host_streamable(x, axis):
         return _streamed(lambda blk, sl: cumsum1d(blk, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, skipna,
-                                                  _rows(m_in, sl), _rows(m_out, sl)), x)
+                                                  _rows(m_in, sl, x.ndim, 'm_in'), _rows(m_out, sl, x.ndim, 'm_out')), x)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis = axis % x.dim()
@@ -271,7 +281,7 @@ def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
     "pair_valid" / "pair_all" return those two sums stacked along a new leading dim of 2 (means over several dims)."""
     lib = _hip.load()
     if _host_streamable(x, axis) and skipna not in ("pair_valid", "pair_all"):
-        return _streamed(lambda blk, sl: reduce1d(blk, axis, _rows(w, sl), skipna), x)
+        return _streamed(lambda blk, sl: reduce1d(blk, axis, _rows(w, sl, x.ndim, 'w'), skipna), x)
     dt, sfx = _common(x, w)
     x = asdevice(x, dt)
     axis = axis % x.dim()

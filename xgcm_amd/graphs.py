@@ -27,6 +27,12 @@ from typing import Any, Callable
 import torch
 
 
+def _hip_chain_check():
+    from . import _hip
+
+    _hip.chain_check()
+
+
 def _tensors(obj, found):
     """every HBM tensor reachable from the return value (DataArrays, tuples, lists, dicts)"""
     data = getattr(obj, "data", None)
@@ -62,6 +68,9 @@ class CapturedChain:
                 pass
 
     def __call__(self):
+        # (a chained scan whose hand-off failed in an earlier replay was redone inside that replay by its marching
+        # twin, which is part of the graph; the event is reported at the next replay or wherever a result is read)
+        _hip_chain_check()
         self._graph.replay()
         return self.outputs
 

@@ -267,7 +267,9 @@ def map_record_batches(fn, load, n_records: int, ranks: "Ranks", bytes_per_recor
     that put barriers around them."""
     lo, hi = shard_bounds(n_records, ranks.world, ranks.rank)
     per = per_batch or records_per_batch(hi - lo, bytes_per_record, headroom=headroom)
-    per = max(1, int(ranks.min(per)))
+    # a rank without records (more ranks than records) has no say in the batch size: it contributes the job's upper
+    # bound instead of 0, which would have forced one-record batches on everybody
+    per = max(1, int(ranks.min(per if hi > lo else max(1, int(n_records)))))
     out = []
     for start, stop in record_batches(n_records, ranks.world, ranks.rank, per):
         result = fn(load(start, stop))
@@ -427,7 +429,9 @@ def cumsum_along_sharded_axis(grid, da, axis: str, dist=None, to=None, padding=N
                           (0.0 if fv is None else float(fv)) if first else 0.0, False, True)
     if world > 1:
         total = _dev.reduce1d(da.data, num, None, True)          # this block's sum: one plane
-        t = total if isinstance(total, torch.Tensor) else torch.as_tensor(total)
+        t = total if isinstance(total, torch.Tensor) else torch.as_tensor(total)  # (a large host block comes back as numpy)
+        if dist.get_backend() == "nccl" and not t.is_cuda:
+            t = t.cuda()  # RCCL moves device buffers only
         planes = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(planes, t.contiguous())
         if rank > 0:

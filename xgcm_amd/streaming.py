@@ -22,6 +22,7 @@ from typing import Callable, Iterable, Iterator, List, Optional, Tuple
 import numpy as np
 import torch
 
+from . import _hip
 from .labeled import DataArray
 
 __all__ = ["record_blocks", "stream_records", "stream_apply", "stream_blocks", "iter_stream"]
@@ -139,6 +140,7 @@ def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, 
         drain(1)
         s_out.synchronize()
         s_in.synchronize()
+        _hip.chain_check()  # results are on the host now: report a chained launch that had to be redone
     finally:
         if pin_src is not None:
             pin_src.close()
@@ -243,6 +245,7 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
             yield finish(slot)
     s_in.synchronize()
     s_out.synchronize()
+    _hip.chain_check()
 
 
 def stream_blocks(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable,
