@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--records", type=int, default=7)
     ap.add_argument("--batch-records", type=int, default=2)
+    ap.add_argument("--levels", type=int, default=5, help="config 5: levels of the field split along Z")
+    ap.add_argument("--configs", default="4,5")
     a = ap.parse_args()
     from xgcm_amd import sharding as S
 
@@ -34,8 +36,10 @@ def main():
     import bench_configs as B
 
     try:
-        B.run_config4(ranks, a.records, shape=(5, 6, 8), per_batch=a.batch_records)
-        B.run_config5(ranks, shape=(5, 6, 8), reps=2)
+        if "4" in a.configs.split(","):
+            B.run_config4(ranks, a.records, shape=(5, 6, 8), per_batch=a.batch_records or None)
+        if "5" in a.configs.split(","):
+            B.run_config5(ranks, shape=(a.levels, 6, 8), reps=2)
     finally:
         ranks.close()
 

@@ -52,6 +52,44 @@ def test_two_gloo_ranks_through_the_launcher_equal_one_rank():
     assert checks and all(ln["ok"] for ln in checks)
 
 
+def test_eight_gloo_ranks_at_the_baseline_splits():
+    """8 ranks as on the node the north star names: config 4's 360 records fall 45 per rank, config 5's 90 levels
+    12,12,11,11,11,11,11,11; every checksum of checksums equals the single-rank run's."""
+    args = ["--records", "360", "--batch-records", "23", "--levels", "90"]
+    p1, one = _run([DRIVER, "--gpus", "1"] + args)
+    assert p1.returncode == 0, p1.stderr[-2000:]
+    p8, eight = _run([DRIVER, "--gpus", "8"] + args, timeout=600)
+    assert p8.returncode == 0, p8.stderr[-2000:]
+    a, b = _by_op(one), _by_op(eight)
+    assert a.keys() == b.keys() and len(a) == 4
+    for k in a:
+        assert b[k]["n_gpus"] == 8 and len(b[k]["per_rank_device_ms"]) == 8
+        assert sum(b[k]["per_rank_cells"]) == a[k]["cells"] and a[k]["checksum_u64"] == b[k]["checksum_u64"], k
+        assert 0 < b[k]["scaling_efficiency"] <= 1
+    c4 = next(v for k, v in b.items() if k[0] == 4)
+    assert c4["records_per_rank"] == [45] * 8 and c4["records_per_resident_batch"] == 23 and c4["batch_rounds"] == 2
+    c5 = next(v for k, v in b.items() if k[0] == 5)
+    assert c5["levels_per_rank"] == [12, 12, 11, 11, 11, 11, 11, 11]
+    assert all(ln["ok"] for ln in eight if "check" in ln)
+
+
+def test_ranks_without_units_run_the_whole_driver():
+    """more ranks than records / levels: the empty ranks pass every barrier, contribute nothing to the checksums and do
+    not drag the batch size down to one record"""
+    args = ["--records", "3", "--batch-records", "0", "--levels", "5"]
+    _, one = _run([DRIVER, "--gpus", "1"] + args)
+    p8, eight = _run([DRIVER, "--gpus", "8"] + args, timeout=600)
+    assert p8.returncode == 0, p8.stderr[-2000:]
+    a, b = _by_op(one), _by_op(eight)
+    for k in a:
+        assert a[k]["checksum_u64"] == b[k]["checksum_u64"] and sum(b[k]["per_rank_cells"]) == a[k]["cells"], k
+    c4 = next(v for k, v in b.items() if k[0] == 4)
+    assert c4["records_per_rank"] == [1, 1, 1, 0, 0, 0, 0, 0] and c4["per_rank_cells"][3:] == [0] * 5
+    assert c4["records_per_resident_batch"] >= 1 and c4["batch_rounds"] == 1
+    c5 = next(v for k, v in b.items() if k[0] == 5)
+    assert c5["levels_per_rank"] == [1, 1, 1, 1, 1, 0, 0, 0]
+
+
 def test_config4_checksum_is_the_oracles():
     """the driver's checksum of checksums against the oracle's cumsum of the same synthetic records"""
     from oracle import refimpl as R

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--shape", default="75,2400,3600")
+    ap.add_argument("--mark", action="store_true", help="a marker dispatch (k_fill_synthetic of 4096 * (1 + variant * ncases + case) "
+                    "cells) before every (variant, case) block: tools/pmc_ab.py maps rocprofv3 dispatches to variants with it")
     a = ap.parse_args()
     nz, ny, nx = (int(v) for v in a.shape.split(","))
     cells = nz * ny * nx
@@ -100,6 +102,11 @@ def main():
             "tcon_rw": (lambda: D.transform_conservative(T, tho_rw, edges, 0), (2 * nz + 1 + mt) * 8 / nz),
             "tcon_sm": (lambda: D.transform_conservative(T, tho_sm, edges, 0), (2 * nz + 1 + mt) * 8 / nz),
         })
+    for c in cases:  # cumsum along Z of R records in ONE launch ("cumZr4": R = 4): what does a launch cost beyond its bytes?
+        if c.startswith("cumZr"):
+            R = int(c[5:])
+            TR = D.synthetic((R, nz, ny, nx), 4)
+            CASES[c] = ((lambda TR=TR: D.cumsum1d(TR, 1, 0, 1, 1, 0, "fill")), 16 * R)
     if "vort" in cases:
         U, V = D.synthetic((nz, ny, nx), 51), D.synthetic((nz, ny, nx), 52)
     variants = []
@@ -120,8 +127,10 @@ def main():
                 _hip.set_tunable(k, v)
             for k, v in variants[vi].items():
                 _hip.set_tunable(k, v)
-            for c in cases:
+            for ci, c in enumerate(cases):
                 fn = CASES[c][0]
+                if a.mark:
+                    D.synthetic((4096 * (1 + vi * len(cases) + ci),), 1)
                 fn()
                 ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.reps + 1)]
                 ev[0].record()

@@ -131,6 +131,9 @@ def _shard_line(ranks, cfg, op, wall_s, dev_ms, local_cells, bpc, chk, extra):
             "GBps_all_gpus": round(total * bpc / wall / 1e9, 1) if wall > 0 else None,
             "frac_8TBps_per_gpu": round(total * bpc / wall / 1e9 / 8000 / ranks.world, 4) if wall > 0 else None,
             "per_rank_device_ms": [round(v, 3) for v in per_rank_ms],
+            # min / max over the ranks that had work: 1.0 = perfectly balanced (the driver computes scaling efficiency
+            # against N = 1 itself; this is the within-run balance the north star asks to see)
+            "scaling_efficiency": (round(min(v for v in per_rank_ms if v > 0) / max(per_rank_ms), 4) if max(per_rank_ms) > 0 else None),
             "per_rank_cells": [int(v) for v in per_rank_cells], "checksum_u64": f"{chk:016x}"}
     line.update(extra)
     if ranks.rank == 0:
@@ -149,7 +152,8 @@ def run_config4(ranks, n_records=360, shape=(75, 2400, 3600), per_batch=None, op
     # checksum reads in place => 2 records + one level; the caching allocator keeps the previous batch's blocks
     bytes_per_record = 8 * (2 * cells + ny * nx)
     per = per_batch or S.records_per_batch(hi - lo, bytes_per_record, headroom=0.8)
-    per = max(1, int(ranks.min(per)))
+    # (a rank without records has no say in the batch size: it contributes the job's upper bound, not 0)
+    per = max(1, int(ranks.min(per if hi > lo else max(1, n_records))))
     batches = S.record_batches(n_records, ranks.world, ranks.rank, per)
     rounds = int(ranks.max(len(batches)))
     dims = ("time", "Z", "YC", "XC")

@@ -39,6 +39,8 @@ const TuneEntry TUNABLES[] = {
     {"met_zk", &Tune::met_zk, 4},
     {"met_zk1", &Tune::met_zk1, 2},
     {"vec_zk", &Tune::vec_zk, 2},
+    {"vec_nt", &Tune::vec_nt, 3},
+    {"vec_zb_rows", &Tune::vec_zb_rows, 16},
     {"contig_rw_mi", &Tune::contig_rw_mi, 8},
     {"met_seg", &Tune::met_seg, 4},
     {"met_seg1", &Tune::met_seg1, 2},
@@ -49,6 +51,8 @@ const TuneEntry TUNABLES[] = {
     {"scan_chain", &Tune::scan_chain, 1},
     {"scan_chain_w", &Tune::scan_chain_w, 1},
     {"scan_chain_spin", &Tune::scan_chain_spin, 1 << 22},
+    {"scan_levels", &Tune::scan_levels, 1},
+    {"scan_levels_il", &Tune::scan_levels_il, 0},
     {"reduce_zl", &Tune::reduce_zl, 2},
     {"dbg", &Tune::dbg, 0},
     {"march_lds_kb", &Tune::march_lds_kb, 0},

@@ -867,7 +867,10 @@ int launch_contig_rw(const StencilCall& c) {
   const bool zs = bcast_z && RR > 1 && tune().rw_zshare;
   if (RR == 8 && !zs) RR = 4;
   const u64 ntile = ((u64)g.n_in / NV + WAVE - 1) / WAVE;
-  const u32 brows = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16) * ((c.m_in && c.m_out) ? 1u : 2u);  // see launch_seg_n
+  // band height (see launch_seg_n): one metric 32 rows (PMC reads 1.006x the algorithmic bytes), two metrics 8 rows
+  // (16 rows: 1.17x -- the two metric bands no longer survive in the L2 next to the streams -- 8 rows: 1.017x; same speed)
+  const u32 zb_base = (u32)(tune().zb_rows > 1 ? tune().zb_rows : 16);
+  const u32 brows = (c.m_in && c.m_out) ? zb_base / 2 : zb_base * 2;
   ZBand zb = make_zband(false, 0, 0, 1);
   u64 YG = (Y + RR - 1) / RR, groups = Z * YG;
   if (zs) {  // band-major over (band of `brows` rows, level group, row)
@@ -970,7 +973,10 @@ int launch_seg_n(const StencilCall& c) {
   // z-banding: a single outer dim along which every metric is broadcast, one launch (bands of 16 rows)
   // band height: `zb_rows` rows when two metrics share the XCD's L2, twice that for one -- a band boundary costs one
   // halo-row re-read from HBM per level (PMC: +6 % reads at 16 rows), a band must stay L2-resident for all levels
-  const u32 zbr = (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16) * ((c.m_in && c.m_out) ? 1u : 2u);
+  // (round 3, PMC per band height, profiles/r03g_*: one metric 32 rows 1.106x the algorithmic reads, 16 rows 1.064x =
+  // the halo row; two metrics 16 rows 1.14x, 8 rows 1.127x = the halo row; same speed within 0.5 % => 16 / 8 rows)
+  const u32 zb_base = (u32)(tune().zb_rows > 1 ? tune().zb_rows : 16);
+  const u32 zbr = (c.m_in && c.m_out) ? zb_base / 2 : zb_base;
   const u32 ZB_SEGS = (zbr + SEG - 1) / SEG;
   const bool zb_ok = !ck.on && MET != 0 && tune().zband && c.g.n_outer == 1 && (!c.m_in || c.mi.outer[0] == 0) &&
                      (!c.m_out || c.mo.outer[0] == 0);

@@ -173,9 +173,9 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
       const int64_t jr = (s_ < nrow) ? s_ : nrow - 1;  // clamp inside the array for short tails
       // rows nobody reads again stream past the caches (non-temporal); the segment's LAST u row is the next
       // segment's halo row and the v row carries the 8-byte neighbour loads, so those stay ordinary loads
-      if (ntl && s_ + 1 < SEG) uu[kz][s_ + 1] = __builtin_nontemporal_load(reinterpret_cast<const T*>(pu + (j0 + jr) * nx));
+      if ((ntl & 2) && s_ + 1 < SEG) uu[kz][s_ + 1] = __builtin_nontemporal_load(reinterpret_cast<const T*>(pu + (j0 + jr) * nx));
       else uu[kz][s_ + 1] = *reinterpret_cast<const T*>(pu + (j0 + jr) * nx);
-      if (V > 1 && ntl) {
+      if (V > 1 && (ntl & 1)) {
         // the v row is read by this wave only: non-temporal, and the value left of a lane's vector comes from
         // the lane before it (lanes that left at the row's end are the highest ones); lane 0 loads its own
         vv[kz][s_] = __builtin_nontemporal_load(reinterpret_cast<const T*>(pv + jr * nx + i0));
@@ -506,14 +506,20 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
                  (bc_y != XG_BC_HALO || aligned16(halo_y))) ? NV : 1;
   constexpr int SEG = XG_FUSED_SEG;
   const u64 ntile = (u64)((nx + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
-  const u64 nseg = (u64)((ny + SEG - 1) / SEG);
+  const u64 nseg_rows = (u64)((ny + SEG - 1) / SEG);
+  hipStream_t st = (hipStream_t)stream;
+  const bool nts = tune().nt_store;
+  const int vnt = tune().nt_load ? tune().vec_nt : 0;  // bit 0: v rows non-temporal (neighbour by lane shuffle), bit 1: inner u rows
+  const u64 nseg = nseg_rows;
   const u64 per_outer = ntile * nseg;
   if (per_outer > MAX_ITEMS) return fail(XG_ERR_UNSUPPORTED, "extent too large for the vorticity kernel");
   const FastDiv fnt = make_fastdiv(ntile), fns = make_fastdiv(nseg);
   const u64 outer_per = MAX_ITEMS / per_outer;
-  hipStream_t st = (hipStream_t)stream;
-  const bool nts = tune().nt_store;
-  const u32 zbr = 2u * (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16);  // one metric (the area): double-height bands, see launch_seg_n
+  // band height: the area rows of a band must survive in the XCD's 4 MB L2 while TWO fields and the output of all its
+  // levels stream by.  16 rows: PMC reads 1.06x the algorithmic bytes (the halo u row of every band and level is the
+  // 6 %); 24 rows 1.17x, 32 rows 1.26x -- the area is then re-read from the fabric once per level group -- at the same
+  // speed within 1 % on an otherwise idle device (profiles/r03g_*, r03h_*)
+  const u32 zbr = (u32)(tune().vec_zb_rows > 1 ? tune().vec_zb_rows : 16);
   const u32 ZB_SEGS = (zbr + SEG - 1) / SEG;
   ZBand zb = make_zband(false, 0, 0, 1);
   u64 outer_step = outer_per;
@@ -532,11 +538,11 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
   if (!zb.on) zk = 1;
   for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_step) {
     const u32 nouter = (u32)((outer - o0 < (int64_t)outer_step) ? outer - o0 : (int64_t)outer_step);
-    const u64 waves = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * zgroups * ntile : (u64)nouter * per_outer;
-    const u32 nblk = (u32)((waves + WPB - 1) / WPB);
+    const u64 units = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * zgroups * ntile : (u64)nouter * per_outer;
+    const u32 nblk = (u32)((units + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GZ(V_, A_, NTS, ZK_) do { if (div) hipLaunchKernelGGL((k_divergence<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y, tune().nt_load); \
-                                else hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y, tune().nt_load); } while (0)
+#define XG_GZ(V_, A_, NTS, ZK_) do { if (div) hipLaunchKernelGGL((k_divergence<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y, vnt); \
+                                else hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y, vnt); } while (0)
 #define XG_GO(V_, A_, NTS) XG_GZ(V_, A_, NTS, 1)
 #define XG_A(V_, A_) do { if (nts) XG_GO(V_, A_, true); else XG_GO(V_, A_, false); } while (0)
     if (zk == 4) XG_GZ(NV, true, true, 4);
