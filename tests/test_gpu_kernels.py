@@ -204,48 +204,6 @@ def test_cumsum_chained_chunks(dev, dtype):
         _hip.set_tunable("reduce_zl", before_zl)
 
 
-@pytest.mark.parametrize("dtype", [np.float64, np.float32])
-def test_cumsum_level_major(dev, dtype):
-    """K5L: metric-free scans over whole-plane rows, level-major (a wave owns up to 24 x-tiles of a row -- one contiguous
-    piece or interleaved with the other waves' -- and sweeps the levels once; rows reached through buffer descriptors
-    whose range check drops what lies beyond a row's end).  Forced on small shapes (scan_levels = -tiles per wave):
-    ragged row ends, rows shorter than one wave's share, several outer indices, every trim / pad / boundary / direction
-    / NaN mode, signed zeros and NaNs in the first row -- bit-identical to the sequential numpy order."""
-    from xgcm_amd import _hip
-    keep = {k: _hip.get_tunable(k) for k in ("scan_levels", "scan_chain", "scan_levels_il")}
-    _hip.set_tunable("scan_chain", 0)
-    nv = 16 // np.dtype(dtype).itemsize
-    shapes = ((7, 64 * nv * 5), (5, 3, 64 * nv * 9 + 3 * nv), (3, 2, 5 * nv), (75, 2, 64 * nv * 26 + nv), (2, 64 * nv * 50))
-    widths = [(0, 0, 0, 0), (0, 1, 1, 0), (1, 0, 0, 1), (0, 0, 1, 0), (0, 0, 0, 1), (1, 1, 1, 1)]
-    try:
-        for il, shape in itertools.product((0, 1), shapes):
-            _hip.set_tunable("scan_levels_il", il)
-            a = _field(shape, 21, nan=True).astype(dtype)
-            axis = len(shape) - 2
-            for end in (0, -1):  # the first row of every column in either direction: -0.0, +0.0, NaN must come out as numpy leaves them
-                sel = [slice(None)] * a.ndim
-                sel[axis] = end
-                a[tuple(sel)][..., :6] = np.array([-0.0, 0.0, np.nan, -0.0, 1.5, -2.5], dtype)
-            for nt in (1, 3, 4, 5, 8, 23, 24):
-                _hip.set_tunable("scan_levels", -nt)
-                for reverse, skipna in itertools.product([False, True], [True, False]):
-                    for tl, th, pl, ph in widths:
-                        if shape[axis] - tl - th < 1:
-                            continue
-                        for bc in BCS:
-                            exp = R.cumsum1d(a, axis, tl, th, pl, ph, bc, dtype(0.5), reverse, skipna)
-                            got = dev.tohost(dev.cumsum1d(a, axis, tl, th, pl, ph, bc, 0.5, reverse, skipna))
-                            _eq(got, exp)
-                            assert np.array_equal(np.signbit(got), np.signbit(exp))
-        # the leading axis of a 4-D array: two inner dims coalesce into the row
-        b = _field((6, 2, 9, 32 * nv), 22).astype(dtype)
-        _hip.set_tunable("scan_levels", -2)
-        _eq(dev.tohost(dev.cumsum1d(b, 0, 0, 1, 1, 0, "fill", 0.0, False, True)), R.cumsum1d(b, 0, 0, 1, 1, 0, "fill", dtype(0), False, True))
-    finally:
-        for k, v in keep.items():
-            _hip.set_tunable(k, v)
-
-
 def test_chained_scans_on_two_streams(dev):
     """The chained kernels keep their hand-off slots and ticket counters in a workspace PER STREAM: two streams running
     long scans / weighted reductions at the same time do not see each other's running sums."""

@@ -250,11 +250,11 @@ def run_config5(ranks, shape=(90, 4320, 4320), reps=7):
         lines.append(_shard_line(ranks, 5, f"{name}; {nx}x{ny}x{nz} f64 split along Z", wall, clock.ms() / n, nl * plane,
                                  24 + 8 / nz, chk, {"levels_per_rank": levels, "passes": n}))
         del out
-    if nl:
-        same = bool(np.array_equal(D.tohost(fused().data[:1]), D.tohost(chain().data[:1])))
-        allsame = ranks.min(1.0 if same else 0.0) == 1.0
-        if ranks.rank == 0:
-            print(json.dumps({"config": 5, "check": "fused == unfused chain bit for bit (first level of every rank)", "ok": allsame}), flush=True)
+    # (every rank takes part in the reduction, also one without levels -- more ranks than levels -- or the others wait for ever)
+    same = bool(np.array_equal(D.tohost(fused().data[:1]), D.tohost(chain().data[:1]))) if nl else True
+    allsame = ranks.min(1.0 if same else 0.0) == 1.0
+    if ranks.rank == 0:
+        print(json.dumps({"config": 5, "check": "fused == unfused chain bit for bit (first level of every rank)", "ok": allsame}), flush=True)
     return lines
 
 

@@ -131,8 +131,6 @@ struct Tune {
   int scan_pace;      // experiment: workgroup barrier per window in the pipelined marching scan
   int scan_chain;     // long strided-axis scans as a chained flat launch (K5c); 2: whenever the march has >= 2 chunks
   int scan_chain_w;   // K5c: levels' worth of columns that advance side by side inside one XCD band
-  int scan_levels;    // K5L: metric-free scans over whole-plane rows level-major, one generation of waves (0: march; n > 1: from n tiles per wave)
-  int scan_levels_il; // K5L: a wave's tiles interleaved with the other waves' of the row (1) or one contiguous piece (0)
   int scan_chain_spin; // polls of a hand-off slot before a chunk gives up (the launch is then redone by the march, in stream)
   int reduce_zl;      // K4cz: outer indices per task of the chained weighted reduction sharing the weight rows (1 / 2 / 4)
   int dbg;            // A/B switches that do NOT change results (bit 2: the linear transform's division inside its loop)
@@ -489,14 +487,6 @@ template <> __device__ __forceinline__ dv ldm<dv>(const real* m, int64_t off, in
 #pragma unroll
   for (int k = 0; k < NV; ++k) o[k] = m[off + k * step];
   return o;
-}
-
-// an element offset the program knows to be wave-uniform, moved (back) into scalar registers: `base + uni(off) + lane`
-// with `base` a kernel argument then takes the scalar-base + 32-bit lane offset form of global_load / global_store
-// instead of a 64-bit address per lane
-__device__ __forceinline__ int64_t uni(int64_t v) {
-  const u32 lo = __builtin_amdgcn_readfirstlane((u32)(u64)v), hi = __builtin_amdgcn_readfirstlane((u32)((u64)v >> 32));
-  return (int64_t)((u64)lo | ((u64)hi << 32));
 }
 
 // the same with the workgroups of a launch cut into 8 contiguous bands, one per XCD (grid size = multiple of 8;

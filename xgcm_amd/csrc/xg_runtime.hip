@@ -51,8 +51,6 @@ const TuneEntry TUNABLES[] = {
     {"scan_chain", &Tune::scan_chain, 1},
     {"scan_chain_w", &Tune::scan_chain_w, 1},
     {"scan_chain_spin", &Tune::scan_chain_spin, 1 << 22},
-    {"scan_levels", &Tune::scan_levels, 1},
-    {"scan_levels_il", &Tune::scan_levels_il, 0},
     {"reduce_zl", &Tune::reduce_zl, 2},
     {"dbg", &Tune::dbg, 0},
     {"march_lds_kb", &Tune::march_lds_kb, 0},

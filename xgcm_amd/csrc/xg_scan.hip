@@ -9,6 +9,14 @@ namespace {
 // K5: cumsum along a STRIDED axis (one lane = one column pair, sequential => bit-exact with
 // numpy.cumsum / nancumsum), trim/pad table folded into the output index, halo cells written
 // from registers at the end of the march.
+// Tried in round 3 and removed again (kernel in the history, commit "K5L level-major Z scan"): the same scan LEVEL-MAJOR --
+// one generation of waves, each holding the running sums of 24 x-tiles in registers (rows through buffer descriptors,
+// straight-line levels with exact vmcnt waits), so that the whole chip sweeps one level at a time like a copy.  Bit-exact,
+// but no faster than this march in any state of the device: 0.69-0.72 against 0.72-0.76 of 8 TB/s for one record, equal
+// from 4 records per launch on (profiles/r03c_*, r03i_ab_cumZ_records.jsonl) -- the number of DRAM streams and the
+// generation tail are not what holds the march back.  What the same measurements do show: the rate of THIS kernel on
+// ONE box falls from 0.76 (a 1.7 ms launch) to 0.65 (8 records, 16 ms) with the length of the busy period, i.e. the
+// "slow boxes" of round 2 are the sustained, power-managed state of every box.
 // ------------------------------------------------------------------------------------------
 struct ScanArgs {
   int reverse, skipna, trim_lo, trim_hi, pad_lo, pad_hi, bc;
@@ -412,145 +420,6 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_chain(
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// K5L: cumsum along a STRIDED axis whose rows are long (whole planes: Z of (Z, Y, X); config 4), LEVEL-MAJOR.
-// The march (K5) gives a wave ONE x-tile and the whole column: 67 500 wave-tasks for one 75 x 2400 x 3600 record, 8.2
-// generations of resident waves whose phases drift apart until the chip reads and writes all 75 + 76 levels at once
-// (150 DRAM streams, 1-KB pieces) and whose last, quarter-full generation cannot fill the memory pipeline.  Here the
-// launch is ONE generation (or a few full ones): the `wpo` waves of a row own its x-tiles INTERLEAVED -- wave r holds
-// the running sums of tiles r, r + wpo, r + 2 wpo ... (up to NTMAX, in registers) -- and sweep the levels once.  At step
-// j of a level every wave is on tile j wpo + r: the chip reads one contiguous window of wpo KB and writes another,
-// windows that slide linearly through the plane and then through the next one -- the access pattern of a flat copy,
-// carried out by long-lived waves.  Loads run one group of G tiles ahead of the adds (double buffer, static register
-// indices: the number of active groups is even by construction); the additions of a column happen in level order
-// exactly as in the march: same bits.  Metric-free scans only (config 4, Grid.cumsum without a metric); everything
-// else stays with K5 / K5c.
-//
-// Addressing: a loop over levels with 24 tiles x 3 destinations must not keep a 64-bit address per lane and tile (the
-// compiler strength-reduces `base + lane` into exactly that: 256 VGPRs).  Rows are reached through BUFFER descriptors
-// instead, rebuilt per level on the scalar unit: base = the row (wave-uniform), `num_records` = its bytes, and one
-// 32-bit vector offset per access = tile offset (scalar) + lane offset.  The range check does the rest: the ragged
-// last tile of a row needs no predicate, and a tile the wave does not own is given an offset beyond every row.
-// ------------------------------------------------------------------------------------------
-typedef u32 lm_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t lm_rsrc(const real* base, int64_t row_off, u32 row_bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<real*>(base + row_off), 0, (int)row_bytes, 0x00020000);  // raw buffer, 32-bit data format
-}
-template <int NTMAX, int G>
-__global__ __launch_bounds__(BLOCK) void k_cumsum_levels(
-    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 nt, u32 wpo, u32 lanes_row, int ileave, ScanArgs a) {
-  typedef dv T;
-  constexpr int NG = NTMAX / G;
-  constexpr int NT_AUX = 2;  // cache policy bits of the buffer instructions: nt
-  const std::integral_constant<int, NT_AUX> nt_aux;
-  static_assert(NTMAX % G == 0 && NG % 2 == 0, "an even number of tile groups keeps the double buffer's indices static");
-  static_assert(sizeof(T) == 16, "one 16-byte vector per lane");
-  // (host: fewer than 2^31 waves, rows of at most 2^30 bytes; the division runs on the vector unit, readfirstlane makes
-  // its result scalar again)
-  const u32 w = (u32)banded_wave_id();
-  const u32 o = __builtin_amdgcn_readfirstlane(w / wpo);
-  if (o >= (u32)g.outer) return;
-  const u32 r = __builtin_amdgcn_readfirstlane(w - o * wpo);
-  // this wave's tiles of the row: t0, t0 + ts, t0 + 2 ts ... -- interleaved with the other waves of the row (ts = wpo)
-  // or one contiguous piece (ts = 1)
-  const u32 t0 = ileave ? r : r * nt, ts = ileave ? wpo : 1u;
-  const u32 tiles_row = (lanes_row + WAVE - 1) / WAVE;
-  if (t0 >= tiles_row) return;
-  const u32 own = (tiles_row - t0 + ts - 1) / ts;
-  const u32 cnt = __builtin_amdgcn_readfirstlane(own < nt ? own : nt);  // tiles owned
-  const u32 row_bytes = lanes_row * 16u;
-  const int64_t inner = g.inner, n = g.n_in;
-  const int64_t bin = uni((int64_t)o * n * inner), bout = uni((int64_t)o * g.n_out * inner);
-  const u32 xb = (threadIdx.x & 63) * 16u;  // the lane's byte offset inside a tile
-  // byte offset of the wave's j-th tile in a row (scalar) + the lane's; beyond every row for a tile it does not own.
-  // (`tk` = t0, laundered through an empty asm once per level: the 24 offsets are then recomputed per level -- one scalar
-  // multiply-add and one vector add each -- instead of being kept in 24 vector registers for the whole march)
-  u32 tk = t0;
-  auto voff = [&](int j) -> int { return (int)((((u32)j < cnt) ? (tk + (u32)j * ts) * (u32)(WAVE * 16) : 0xfffffff0u) + xb); };
-  auto row = [&](int64_t k) -> int64_t { return a.reverse ? n - 1 - k : k; };
-  const int64_t first_kept = a.trim_lo, last_kept = n - 1 - a.trim_hi;
-  const int64_t shift = a.pad_lo - a.trim_lo;
-  const bool wrap = a.bc == XG_BC_PERIODIC, ext = a.bc == XG_BC_EXTEND;
-  const int64_t olo = bout, ohi = uni(bout + (g.n_out - 1) * inner);  // halo rows 0 and n_out - 1
-  // running sums start from -0.0: (-0.0) + v == v bit for bit for every v (signed zeros, NaN payloads), so the first row
-  // of a column is "assigned" like in K5 / numpy without a special case in the loop
-  T acc[NTMAX], buf[2][G];
-#pragma unroll
-  for (int j = 0; j < NTMAX; ++j) acc[j] = splat<T>(real(-0.0));
-  auto load_group = [&](T (&dst)[G], __amdgpu_buffer_rsrc_t rs, int jg, auto aux) {  // aux: the cache policy bits, a constant
-#pragma unroll
-    for (int i = 0; i < G; ++i)
-      dst[i] = __builtin_bit_cast(T, __builtin_amdgcn_raw_buffer_load_b128(rs, voff(jg * G + i), 0, decltype(aux)::value));
-  };
-  auto put = [&](__amdgpu_buffer_rsrc_t rs, int j, T v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lm_u32x4, v), rs, voff(j), 0, NT_AUX);
-  };
-  // The loop over the levels is STRAIGHT-LINE code -- every group of every level, no branch: a join of paths with
-  // different numbers of memory operations in flight costs a drain (`s_waitcnt vmcnt(0)`), and a drain per group left
-  // each wave with less than one load in flight (53-65 % of 8 TB/s).  What would need a branch is expressed through
-  // the range check instead: tiles the wave does not own have offsets beyond every row, a trimmed level is stored
-  // through a descriptor of zero bytes, and so is the prefetch behind the last level.  Halo rows are written afterwards.
-  load_group(buf[0], lm_rsrc(in, uni(bin + row(0) * inner), row_bytes), 0, nt_aux);
-  for (int64_t k = 0; k < n; ++k) {
-    asm volatile("" : "+s"(tk));
-    const int64_t idx = row(k);
-    const __amdgpu_buffer_rsrc_t rcur = lm_rsrc(in, uni(bin + idx * inner), row_bytes);
-    const __amdgpu_buffer_rsrc_t rnext = lm_rsrc(in, uni(bin + row(k + 1 < n ? k + 1 : k) * inner), k + 1 < n ? row_bytes : 0u);
-    const bool kept = idx >= first_kept && idx <= last_kept;
-    const __amdgpu_buffer_rsrc_t ro = lm_rsrc(out, uni(bout + (idx + shift) * inner), kept ? row_bytes : 0u);
-#pragma unroll
-    for (int jg = 0; jg < NG; ++jg) {
-      // one group ahead: the next group of this level, or -- behind the last group -- the first of the next level
-      if (jg + 1 < NG) load_group(buf[(jg + 1) & 1], rcur, jg + 1, nt_aux);
-      else load_group(buf[0], rnext, 0, nt_aux);
-      // (the scheduler must not pull the loads of later groups up here: it would hoist a whole level's loads, 96 registers)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < G; ++i) {
-        const int j = jg * G + i;
-        T v = buf[jg & 1][i];
-        if (a.skipna) v = nan0(v);
-        acc[j] = acc[j] + v;
-        put(ro, j, acc[j]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  // halo rows of the padded cumulative result (xgcm/grid.py:1385-1391; numpy.pad semantics): a constant, or a copy of the
-  // first / last kept row, which this wave wrote itself -- read back once its stores have landed, past the L1
-  if (a.pad_lo || a.pad_hi) {
-    const __amdgpu_buffer_rsrc_t rl = lm_rsrc(out, olo, a.pad_lo ? row_bytes : 0u), rh = lm_rsrc(out, ohi, a.pad_hi ? row_bytes : 0u);
-    if (a.bc == XG_BC_FILL) {
-#pragma unroll
-      for (int j = 0; j < NTMAX; ++j) {
-        if ((u32)j < cnt) {
-          put(rl, j, splat<T>(a.fill));
-          put(rh, j, splat<T>(a.fill));
-        }
-      }
-    } else if (wrap || ext) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      __builtin_amdgcn_s_waitcnt(0);  // every store of the march has left
-      const __amdgpu_buffer_rsrc_t rf = lm_rsrc(out, uni(bout + (first_kept + shift) * inner), row_bytes);
-      const __amdgpu_buffer_rsrc_t rb = lm_rsrc(out, uni(bout + (last_kept + shift) * inner), row_bytes);
-      const std::integral_constant<int, 1 | 16> sc_aux;  // sc0 sc1: served by the L2 / memory, never by a stale L1 line
-#pragma unroll
-      for (int jg = 0; jg < NG; ++jg) {
-        if (jg * G < (int)cnt) {
-          T first[G], last[G];
-          load_group(first, rf, jg, sc_aux);
-          load_group(last, rb, jg, sc_aux);
-#pragma unroll
-          for (int i = 0; i < G; ++i) {
-            put(rl, jg * G + i, ext ? first[i] : last[i]);
-            put(rh, jg * G + i, ext ? last[i] : first[i]);
-          }
-        }
-      }
-    }
-  }
-}
-
 // Inclusive wave scan with DPP row shifts / row broadcasts (VALU data path) instead of __shfl_up (ds_bpermute, the LDS
 // crossbar): 4 shifts inside each row of 16 lanes, then lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows
 // 2 / 3.  Lanes without a source add 0.  (A different association than the shuffle ladder: contiguous-axis sums are
@@ -769,10 +638,38 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
   // 64-bit multiply per element (this kernel has the highest VALU share of the library: 0.45)
   const bool mi_unit = HAS_MI && mi.axis == 1;
   const real* mi_row = m_in + mi_base;
+  // ... and when its row keeps the output groups' alignment, ONE 16-B load per group instead of NV narrow ones
+  const bool mi_al = mi_unit && ((reinterpret_cast<uintptr_t>(mi_row + lead) & 15u) == 0);
+  // shift == 1 (Grid.cumsum / cumint center -> left, the default: the result moves up by one cell behind a halo cell): the
+  // inputs of output group [j, j + NV) are in[j - 1 .. j + NV - 2].  Instead of NV misaligned narrow loads of the field and
+  // NV of the metric, every thread takes the ALIGNED vectors at j, forms the products there, and the one value it lacks --
+  // the last product of the group before it in memory -- comes from the neighbouring lane (DPP wave shift; the lane at
+  // the wave's end fetches it itself).  This scan had the highest VALU share of the library (0.45).
+  const bool sh1 = (shift == 1) && (n == no) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) && (!HAS_MI || mi_unit);
   auto load_group = [&](int t, real (&x)[NV]) {
     if (t >= groups) {
 #pragma unroll
       for (int k = 0; k < NV; ++k) x[k] = real(0);
+      return;
+    }
+    if (sh1) {  // (wave-uniform; every thread with a group executes the DPP move below)
+      const int j = group_lo(t);
+      dv p = *reinterpret_cast<const dv*>(prow + j);
+      if (HAS_MI) {
+        if (mi_al) p = p * *reinterpret_cast<const dv*>(mi_row + j);
+        else {
+#pragma unroll
+          for (int k = 0; k < NV; ++k) p[k] = p[k] * mi_row[j + k];
+        }
+      }
+      if (a.skipna) p = nan0(p);
+      // the group before this one in memory belongs to the previous thread (forward scan) / the next one (reverse)
+      real before = a.reverse ? dpp_take<0x130, 0xf>(p[NV - 1]) : dpp_take<0x138, 0xf>(p[NV - 1]);  // wave_shl:1 / wave_shr:1
+      const bool has_nb = a.reverse ? (lane != WAVE - 1 && t + 1 < groups) : (lane != 0);
+      if (!has_nb) before = fetch(j - 1);
+      x[0] = before;
+#pragma unroll
+      for (int k = 1; k < NV; ++k) x[k] = p[k - 1];
       return;
     }
     const int i0 = group_lo(t) - shift;
@@ -786,8 +683,14 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
         for (int k = 0; k < NV; ++k) x[k] = prow[i0 + k];
       }
       if (HAS_MI) {
+        if (vec_in && mi_al) {
+          const dv mv = *reinterpret_cast<const dv*>(mi_row + i0);
 #pragma unroll
-        for (int k = 0; k < NV; ++k) x[k] = x[k] * (mi_unit ? mi_row[i0 + k] : m_in[mi_base + (int64_t)(i0 + k) * mi.axis]);
+          for (int k = 0; k < NV; ++k) x[k] = x[k] * mv[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < NV; ++k) x[k] = x[k] * (mi_unit ? mi_row[i0 + k] : m_in[mi_base + (int64_t)(i0 + k) * mi.axis]);
+        }
       }
       if (a.skipna) {
 #pragma unroll
@@ -1284,24 +1187,6 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
 
 }  // namespace
 
-// waves of `kernel` (a BLOCK-thread workgroup, no dynamic LDS) the current device holds at once; 0 if it cannot be told
-inline u64 levels_capacity(const void* kernel) {
-  static int cached_dev = -1;
-  static u64 cached = 0;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (dev == cached_dev) return cached;
-  int cus = 0, per_cu = 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, BLOCK, 0) != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;
-  }
-  cached = (u64)cus * (u64)per_cu * WPB;
-  cached_dev = dev;
-  return cached;
-}
-
 // geometry of the marching twin (8-byte lanes, XCD-banded wave order) that follows every chained launch as its rescue
 inline int rescue_grid(const Geo& g, u32* ntile, u64* nblocks) {
   *ntile = ceil_div_u32(g.inner, (int64_t)WAVE * HV);
@@ -1463,30 +1348,6 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
 #undef XG_R
         XG_LAUNCH_CHECK();
         return XG_OK;
-      }
-    }
-    // K5L: whole-plane rows without metrics (config 4: cumsum along Z), level-major in one generation of waves
-    if (tune().scan_levels && met == 0 && nts && tune().nt_load && V == NV && g.outer < 0x7fffffffll && (u64)g.inner * sizeof(real) <= (1ull << 30)) {
-      constexpr int LM_NT = 24, LM_G = 4;
-      const u64 cap = levels_capacity((const void*)k_cumsum_levels<LM_NT, LM_G>);  // resident waves of the device
-      const u64 lanes_row = (u64)g.inner / NV, tiles_row = (lanes_row + WAVE - 1) / WAVE, tiles = tiles_row * (u64)g.outer;
-      const int lv = tune().scan_levels;  // 1: from 4 tiles per wave; n > 1: from n; n < 0 (tests): always, -n tiles per wave
-      const u64 min_nt = lv > 1 ? (u64)lv : 4;
-      if (cap && (lv < 0 || tiles >= cap * min_nt)) {
-        const u64 ngen = (tiles + cap * LM_NT - 1) / (cap * LM_NT);
-        u64 nt = lv < 0 ? (u64)(-lv) : (tiles + ngen * cap - 1) / (ngen * cap);
-        if (nt > LM_NT) nt = LM_NT;
-        u64 wpo = (tiles_row + nt - 1) / nt;
-        while (lv > 0 && wpo * (u64)g.outer > ngen * cap && nt < LM_NT) {  // per-row rounding must not spill into one more generation
-          ++nt;
-          wpo = (tiles_row + nt - 1) / nt;
-        }
-        const u64 nwave = wpo * (u64)g.outer, lblocks = (((nwave + WPB - 1) / WPB + 7) / 8) * 8;
-        if (nwave < 0x7fffffffull && !check_grid(lblocks)) {
-          hipLaunchKernelGGL((k_cumsum_levels<LM_NT, LM_G>), dim3((u32)lblocks), dim3(BLOCK), 0, st, in, out, g, (u32)nt, (u32)wpo, (u32)lanes_row, tune().scan_levels_il, a);
-          XG_LAUNCH_CHECK();
-          return XG_OK;
-        }
       }
     }
     const int su = (met & 2) ? (tune().scan_u < 8 ? tune().scan_u : 8) : tune().scan_u;
