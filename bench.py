@@ -214,13 +214,19 @@ def main():
 
     if rank == 0:
         total_cells = cells_per_s * elapsed
-        traffic = None
+        # HBM bytes per launch of the dominant kernel: NOT measured in this run (counter passes serialise the kernels and
+        # need rocprofv3 around the process) but in separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes of this
+        # same command, whose summary is committed next to the number; `traffic_source` names it
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):  # measured offline with rocprofv3 --pmc (see profiles/README.md)
+        if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dominant)
+                table = json.load(open(pmc))
+                traffic = table.get(dominant)
+                if traffic is not None:
+                    traffic_source = "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " + str(table.get("_source", "profiles/pmc_traffic.json"))
             except Exception:
-                traffic = None
+                traffic, traffic_source = None, None
         line = {
             "metric": "stencil-cells/s, Grid.interp+Grid.diff (X periodic, Y extend) on 3600x2400x75 f64",
             "value": round(total_cells / elapsed / 1e9, 3),
@@ -240,11 +246,13 @@ def main():
                        "sharding": "record axis, no data-path collective"},
             "achieved_GBps_whole_step": round(total_cells * BYTES_PER_CELL / elapsed / 1e9 / world, 1),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
                          "per_op_ms": {f"{fn}_{ax}": round(ms, 4) for (fn, ax), ms in zip(OPS, per_op_ms)}},
             "ranks": {"world_size": n_ranks, "backend": "nccl (RCCL)" if dist is not None else "single process",
-                      "per_rank_ms_per_step": per_rank_ms_per_step},
+                      "per_rank_ms_per_step": per_rank_ms_per_step,
+                      # balance inside this run (min / max over the ranks); scaling against N = 1 is the driver's to compute
+                      "scaling_efficiency": round(min(per_rank_ms_per_step) / max(per_rank_ms_per_step), 4) if max(per_rank_ms_per_step) > 0 else None},
             "device_ms_per_step": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4),
                                    "max": round(step_ms[-1], 4)},
         }

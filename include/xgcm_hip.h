@@ -104,6 +104,10 @@ int xg_event_create(void** ev);
 int xg_event_record(void* ev, void* stream);
 int xg_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 int xg_event_destroy(void* ev);
+/* Reverse the byte order of `nelem` elements of 4 or 8 bytes in place (device buffer, 16-byte aligned): blocks read raw
+ * from big-endian files -- MITgcm's MDS .data, NetCDF-3 -- are swapped on the GPU after the PCIe copy.  The reference
+ * gets decoded native arrays from xarray's backends (xgcm/grid.py:786-818 walks their dask chunks). */
+int xg_bswap(void* data, uint64_t nelem, int elem_bytes, void* stream);
 
 /* ---- fused pad + two-point stencil along one axis -------------------------------------- */
 /* out[.., i, ..] = OP(P[i], P[i+1]) / m_out,  P = pad(in * m_in, (pad_lo, pad_hi), bc, fill)

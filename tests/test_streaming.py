@@ -170,3 +170,116 @@ def test_large_host_arrays_are_streamed_blockwise(monkeypatch):
     out = grid.diff(DataArray(a, ("time", "Z", "Y", "XC")), "X")
     assert calls == [2] and isinstance(out.data, np.ndarray)
     np.testing.assert_array_equal(out.values, R.stencil1d("diff", a, 3, 1, 0, "periodic"))
+
+
+# ---- readers of what MITgcm writes (xgcm_amd/io.py): MDS .meta / .data and NetCDF-3, big-endian on disk ----------
+def _mitgcm_like_files(tmp_path, dtype, nrec=5, shape=(3, 6, 128)):
+    """an MDS pair and a NetCDF-3 file (record variable + a fixed one) holding the same synthetic records"""
+    from scipy.io import netcdf_file
+
+    from xgcm_amd import io as xio
+
+    a = R.synthetic_field((nrec,) + shape, 41).astype(dtype)
+    prefix = str(tmp_path / "T.0000000010")
+    xio.write_mds(prefix, a, fields=["THETA"], timestep=10)
+    path = str(tmp_path / "state.nc")
+    with netcdf_file(path, "w", version=2) as nc:  # 64-bit offset, what pkg/mnc writes
+        nc.createDimension("T", None)
+        for name, n in zip(("Z", "Y", "X"), shape):
+            nc.createDimension(name, n)
+        v = nc.createVariable("Temp", np.dtype(dtype).newbyteorder(">"), ("T", "Z", "Y", "X"))
+        v[:] = a
+        e = nc.createVariable("Eta", np.dtype(dtype).newbyteorder(">"), ("T", "Y", "X"))  # a second record variable: records interleave
+        e[:] = a[:, 0]
+        d = nc.createVariable("Depth", np.dtype(dtype).newbyteorder(">"), ("Y", "X"))
+        d[:] = a[0, 0]
+    return a, prefix, path
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_mds_and_netcdf_readers_hand_over_the_stored_bytes(tmp_path, dtype):
+    """no GPU needed: header parsing, block shapes, ragged last block, rank shards, big-endian views of the memory map"""
+    from xgcm_amd import io as xio
+
+    a, prefix, path = _mitgcm_like_files(tmp_path, dtype)
+    meta = xio.read_mds_meta(prefix)
+    assert meta["shape"] == a.shape and meta["dtype"] == (">f4" if dtype == np.float32 else ">f8")
+    assert meta["fields"] == ["THETA"] and meta["timestep"] == 10 and meta["dims"] == [128, 6, 3]
+    blocks = list(xio.mds_blocks(prefix, 2))
+    assert [b.shape[0] for b in blocks] == [2, 2, 1] and all(not b.dtype.isnative for b in blocks)
+    np.testing.assert_array_equal(np.concatenate(blocks).astype(dtype), a)
+    np.testing.assert_array_equal(np.concatenate(list(xio.mds_blocks(prefix, 3, records=(1, 4)))).astype(dtype), a[1:4])
+    assert list(xio.mds_blocks(prefix, 3, records=(2, 2))) == []
+    info = xio.netcdf_variable_info(path, "Temp")
+    assert info["dims"] == ("T", "Z", "Y", "X") and info["shape"] == a.shape and info["isrec"]
+    nb = list(xio.netcdf_blocks(path, "Temp", 2))
+    assert [b.shape for b in nb] == [(2,) + a.shape[1:], (2,) + a.shape[1:], (1,) + a.shape[1:]]
+    np.testing.assert_array_equal(np.concatenate([np.asarray(b) for b in nb]).astype(dtype), a)
+    np.testing.assert_array_equal(np.concatenate([np.asarray(b) for b in xio.netcdf_blocks(path, "Depth", 4)]).astype(dtype), a[0, 0])
+    with pytest.raises(KeyError):
+        list(xio.netcdf_blocks(path, "Salt"))
+    # a per-tile header and a truncated data file are refused
+    with open(prefix + ".meta") as f:
+        text = f.read()
+    tile = str(tmp_path / "tile")
+    with open(tile + ".meta", "w") as f:
+        f.write(text.replace("  128,     1,   128", "  256,     1,   128"))
+    with pytest.raises(NotImplementedError, match="per-tile"):
+        xio.read_mds_meta(tile)
+    short = str(tmp_path / "short")
+    with open(short + ".meta", "w") as f:
+        f.write(text)
+    with open(short + ".data", "wb") as f:
+        f.write(b"\0" * 64)
+    with pytest.raises(ValueError, match="holds 64 bytes"):
+        list(xio.mds_blocks(short))
+
+
+def test_mds_header_as_mitgcm_writes_it(tmp_path):
+    """the layout of a real mdsio header (comments, blank-padded field names, 3 numbers per line)"""
+    from xgcm_amd import io as xio
+
+    p = str(tmp_path / "U.0000000072")
+    with open(p + ".meta", "w") as f:
+        f.write(" nDims = [   3 ];\n dimList = [\n    90,    1,   90,\n    40,    1,   40,\n    15,    1,   15\n ];\n"
+                " dataprec = [ 'float32' ];\n nrecords = [     2 ];\n timeStepNumber = [         72 ];\n"
+                " timeInterval = [  8.640000000000E+04 ]; /* seconds */\n nFlds = [    1 ];\n fldList = {\n 'UVEL    '\n };\n")
+    m = xio.read_mds_meta(p + ".meta")
+    assert m["shape"] == (2, 15, 40, 90) and m["dtype"] == ">f4" and m["fields"] == ["UVEL"] and m["timestep"] == 72
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_operators_streamed_over_mds_and_netcdf_files(tmp_path, dtype):
+    """diff / cumsum streamed over both on-disk formats, bit-equal to the in-memory operator; the
+    big-endian blocks cross PCIe raw and are byte-swapped in HBM (xg_bswap); results written back as MDS."""
+    from xgcm_amd import device as dev
+    from xgcm_amd import io as xio
+    from xgcm_amd.streaming import stream_blocks, stream_records
+
+    a, prefix, path = _mitgcm_like_files(tmp_path, dtype)
+    want_diff = R.stencil1d("diff", a, 3, 1, 0, "periodic")
+    want_cum = R.cumsum1d(a, 1, 0, 1, 1, 0, "fill", dtype(0), False, True)
+    ops = ((lambda x: dev.stencil1d("diff", x, 3, 1, 0, "periodic"), want_diff),
+           (lambda x: dev.cumsum1d(x, 1, 0, 1, 1, 0, "fill", 0.0, False, True), want_cum))
+    for fn, want in ops:
+        for blocks in (xio.mds_blocks(prefix, 2), xio.netcdf_blocks(path, "Temp", 2), xio.netcdf_blocks(path, "Temp", 5)):
+            got = stream_blocks(fn, blocks)
+            assert got.dtype == dtype
+            np.testing.assert_array_equal(got, want)
+    # the whole memory-mapped file as ONE host array through the record pipeline
+    mm = np.memmap(prefix + ".data", dtype=xio.read_mds_meta(prefix)["dtype"], mode="r", shape=a.shape)
+    np.testing.assert_array_equal(stream_records(ops[0][0], mm, block=2), want_diff)
+    # results back to disk in the same format, read again
+    with xio.MdsWriter(str(tmp_path / "dTdx.0000000010"), fields=["dTdx"], timestep=10) as w:
+        stream_blocks(ops[0][0], xio.mds_blocks(prefix, 2), sink=w.sink)
+    back = np.concatenate(list(xio.mds_blocks(str(tmp_path / "dTdx.0000000010"), 4))).astype(dtype)
+    np.testing.assert_array_equal(back, want_diff)
+    # the swap kernel itself: odd element counts (the 16-byte tail), both widths
+    import torch
+    from xgcm_amd import _hip
+    for n in (1, 3, 4, 5, 1027):
+        raw = R.synthetic_field((n,), 5).astype(dtype)
+        t = torch.from_numpy(raw.view(np.dtype(dtype).newbyteorder(">")).astype(dtype)).cuda()  # bytes reversed on the host
+        _hip.check(_hip.load().xg_bswap(t.data_ptr(), n, raw.itemsize, torch.cuda.current_stream().cuda_stream))
+        np.testing.assert_array_equal(t.cpu().numpy(), raw)

@@ -147,7 +147,8 @@ def main():
             gbs = cells * CASES[c][1] / (ms * 1e-3) / 1e9
             print(json.dumps({"case": c, "variant": ",".join(f"{k}={v}" for k, v in kv.items()), "median_ms": round(ms, 4),
                               "min_ms": round(ts[0], 4), "max_ms": round(ts[-1], 4), "GBps": round(gbs, 1),
-                              "frac_8TBps": round(gbs / 8000, 4), "rounds": a.rounds}), flush=True)
+                              "frac_8TBps": round(gbs / 8000, 4), "rounds": a.rounds,
+                              "alg_bytes": int(round(cells * CASES[c][1]))}), flush=True)
 
 
 if __name__ == "__main__":

@@ -44,7 +44,8 @@ def main():
         group = group.strip()
         table = {}  # (vi, ci, kernel) -> {"dur": [...], counter: [...]}
         tmp = tempfile.mkdtemp(prefix="pmcab_", dir="/tmp")
-        cmd = ["rocprofv3", "--pmc"] + group.split() + ["--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable,
+        # the group "TRACE" is a plain kernel-trace pass: durations without any counter collected
+        cmd = ["rocprofv3"] + ([] if group == "TRACE" else ["--pmc"] + group.split()) + ["--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable,
                os.path.join(REPO, "tools", "ab_tunables.py"), "--cases", a.cases, "--variants", a.variants, "--rounds", "1",
                "--reps", str(a.reps), "--mark", "--shape", a.shape]
         env = dict(os.environ, TMPDIR="/tmp")
@@ -53,6 +54,14 @@ def main():
             out, rc = r.stdout, r.returncode
         except subprocess.TimeoutExpired as exc:
             out, rc = f"timed out after {ap_timeout} s: {exc.stdout[-300:] if exc.stdout else ''}", -1
+        alg = {}  # case -> algorithmic bytes per launch, from the lines ab_tunables prints
+        for ln in str(out).splitlines():
+            if ln.startswith("{") and '"alg_bytes"' in ln:
+                try:
+                    d = json.loads(ln)
+                    alg[d["case"]] = d["alg_bytes"]
+                except ValueError:
+                    pass
         dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
         if rc != 0 or not dbs:
             print(json.dumps({"pmc": group, "error": str(out)[-600:]}), flush=True)
@@ -84,8 +93,10 @@ def main():
             if vi >= len(variants) or ci >= len(cases):
                 continue
             d = sorted(e["dur"])
-            row = {"variant": variants[vi], "case": cases[ci], "kernel": k[:70], "vgpr": e["vgpr"], "n": len(d),
-                   "us_under_pmc": round(d[len(d) // 2], 1) if d else None}
+            row = {"pass": group, "variant": variants[vi], "case": cases[ci], "kernel": k[:70], "vgpr": e["vgpr"], "n": len(d),
+                   ("us" if group == "TRACE" else "us_under_pmc"): round(d[len(d) // 2], 1) if d else None}
+            if cases[ci] in alg:
+                row["alg_bytes"] = alg[cases[ci]]
             for cname, vals in e.items():
                 if cname in ("dur", "vgpr"):
                     continue

@@ -65,7 +65,8 @@ for k, v in summary.items():
     by_base.setdefault(k.split("<")[0], []).append(v["total_bytes"])
 flat = {"_comment": "HBM bytes per full-size launch of the bench workload (3600x2400x75 f64), mean over the template "
                     "instances of each kernel; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per "
-                    f"MI355X_MICROARCH.md; source: profiles/{tag}_rocprof_summary.txt"}
+                    "MI355X_MICROARCH.md",
+        "_source": f"profiles/{tag.split('_')[0]}_rocprof_summary_{'_'.join(tag.split('_')[1:]) or 'bench'}.txt"}
 flat.update({k: sum(v) / len(v) for k, v in by_base.items()})
 with open(os.path.join(out, f"pmc_traffic_{tag}.json"), "w") as f:
     json.dump(flat, f, indent=1)

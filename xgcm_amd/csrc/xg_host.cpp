@@ -341,6 +341,14 @@ int xg_chain_status(int* gave_up, int* redone) {
   return XG_OK;
 }
 int xg_chain_rearm(void) { return XG_OK; }
+int xg_bswap(void* data, uint64_t nelem, int elem_bytes, void*) {
+  if (elem_bytes != 4 && elem_bytes != 8) return fail(XG_ERR_INVALID, "byte swap of %d-byte elements (4 or 8)", elem_bytes);
+  if (nelem && !data) return fail(XG_ERR_INVALID, "NULL buffer");
+  unsigned char* p = (unsigned char*)data;
+  for (uint64_t e = 0; e < nelem; ++e, p += elem_bytes)
+    for (int b = 0; b < elem_bytes / 2; ++b) { unsigned char t = p[b]; p[b] = p[elem_bytes - 1 - b]; p[elem_bytes - 1 - b] = t; }
+  return XG_OK;
+}
 int xg_event_create(void** ev) {
   if (!ev) return fail(XG_ERR_INVALID, "NULL argument");
   *ev = calloc(1, sizeof(double));

@@ -1,0 +1,193 @@
+"""Block readers for what MITgcm writes, without xarray ("on-disk formats").
+
+The reference never opens a file itself: xarray's backends decode NetCDF / MDS into (dask-chunked) arrays and
+`apply_ufunc(dask="parallelized")` walks the chunks (`xgcm/grid.py:786-818`).  xarray, dask and netCDF4 are not in this
+image, so the two formats a MITgcm run produces are read here directly, as ITERABLES OF RECORD BLOCKS -- the shape
+`xgcm_amd.streaming.stream_blocks / iter_stream` take -- straight from a memory map of the file:
+
+* MDS (`<prefix>.meta` + `<prefix>.data`): one text header, one raw big-endian array `(records, [Nr,] Ny, Nx)`;
+* NetCDF-3 classic / 64-bit offset (what `pkg/mnc` writes), through `scipy.io.netcdf_file(mmap=True)`.
+
+Both store big-endian numbers.  The blocks are handed over AS STORED: `iter_stream` copies the raw bytes into page-locked
+memory, sends them over PCIe and reverses the byte order on the GPU (`xg_bswap`), so no host core touches the values.
+`MdsWriter` is the matching sink.  Nothing here computes; there is no CPU path to fall back to.
+
+Not covered (say so loudly rather than guess): tiled MDS output (`<prefix>.001.001.data`, one file per tile), NetCDF-4 /
+HDF5, packed variables (`scale_factor` / `add_offset`) -- `netcdf_blocks` refuses those.
+"""
+
+from __future__ import annotations
+
+import os
+import re
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+__all__ = ["read_mds_meta", "mds_blocks", "MdsWriter", "write_mds", "netcdf_blocks", "netcdf_variable_info"]
+
+_PREC = {"float32": ">f4", "float64": ">f8", "real*4": ">f4", "real*8": ">f8"}
+
+
+def read_mds_meta(path: str) -> Dict:
+    """Parse an MDS `.meta` header: {"shape": (records, [Nr,] Ny, Nx) in C order, "dtype": '>f4' | '>f8',
+    "nrecords", "dims" (fastest first, as stored), "fields", "timestep"}.
+
+    `dimList` holds one (global extent, first index, last index) triple per dimension, fastest dimension first; a
+    triple that does not span its whole extent means a per-tile file, which is refused."""
+    if not path.endswith(".meta"):
+        path = path + ".meta"
+    with open(path, "r") as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)  # newer headers carry /* comments */
+
+    def field(name: str) -> Optional[str]:
+        m = re.search(name + r"\s*=\s*[\[{](.*?)[\]}]\s*;", text, flags=re.S)
+        return m.group(1) if m else None
+
+    ndims = field("nDims")
+    dim_list = field("dimList")
+    prec = field("dataprec") or field("format")
+    if ndims is None or dim_list is None or prec is None:
+        raise ValueError(f"{path}: not an MDS header (nDims / dimList / dataprec missing)")
+    nd = int(ndims.split()[0])
+    nums = [int(v) for v in re.findall(r"-?\d+", dim_list)]
+    if len(nums) != 3 * nd:
+        raise ValueError(f"{path}: dimList has {len(nums)} numbers for nDims = {nd}")
+    dims = []
+    for d in range(nd):
+        extent, first, last = nums[3 * d: 3 * d + 3]
+        if first != 1 or last != extent:
+            raise NotImplementedError(f"{path}: a per-tile MDS file (dimension {d} covers {first}..{last} of {extent}); "
+                                      "only global files are read")
+        dims.append(extent)
+    key = prec.replace("'", "").replace('"', "").strip().lower()
+    if key not in _PREC:
+        raise ValueError(f"{path}: unknown dataprec {prec!r}")
+    nrec = int((field("nrecords") or "1").split()[0])
+    flds = field("fldList")
+    step = field("timeStepNumber")
+    shape = (nrec,) + tuple(reversed(dims))
+    return {"shape": shape, "dtype": _PREC[key], "nrecords": nrec, "dims": dims,
+            "fields": [s.strip() for s in re.findall(r"'([^']*)'", flds)] if flds else [],
+            "timestep": int(step.split()[0]) if step and step.split() else None}
+
+
+def mds_blocks(prefix: str, records_per_block: int = 1, records: Optional[Sequence[int]] = None) -> Iterator[np.ndarray]:
+    """Yield the records of `<prefix>.data` in blocks `(n, [Nr,] Ny, Nx)`, big-endian as stored (views of one read-only
+    memory map: nothing is read until a block is consumed).  `records = (start, stop)` restricts the range -- a rank's
+    shard of the record axis (`xgcm_amd.sharding.shard_bounds`)."""
+    if records_per_block < 1:
+        raise ValueError("records_per_block must be >= 1")
+    base = prefix[:-5] if prefix.endswith((".meta", ".data")) else prefix
+    meta = read_mds_meta(base + ".meta")
+    shape = meta["shape"]
+    want = int(np.prod(shape)) * np.dtype(meta["dtype"]).itemsize
+    have = os.path.getsize(base + ".data")
+    if have != want:
+        raise ValueError(f"{base}.data holds {have} bytes, its header describes {want}")
+    lo, hi = (0, shape[0]) if records is None else (int(records[0]), int(records[1]))
+    if not 0 <= lo <= hi <= shape[0]:
+        raise ValueError(f"records {lo}..{hi} outside 0..{shape[0]}")
+    if hi == lo:
+        return
+    mm = np.memmap(base + ".data", dtype=meta["dtype"], mode="r", shape=shape)
+    for s in range(lo, hi, records_per_block):
+        yield mm[s: min(s + records_per_block, hi)]
+
+
+class MdsWriter:
+    """Sink for `stream_blocks(fn, blocks, sink=writer.sink)`: appends result blocks to `<prefix>.data` (big-endian) and
+    writes the header on `close()`.  Record shape and precision are taken from the first block."""
+
+    def __init__(self, prefix: str, fields: Sequence[str] = (), timestep: int = 0):
+        self.prefix = prefix
+        self.fields = list(fields)
+        self.timestep = int(timestep)
+        self._f = open(prefix + ".data", "wb")
+        self._rec_shape: Optional[Tuple[int, ...]] = None
+        self._dtype: Optional[np.dtype] = None
+        self.nrecords = 0
+
+    def sink(self, k: int, block: np.ndarray) -> None:
+        block = np.asarray(block)
+        if self._rec_shape is None:
+            self._rec_shape = tuple(block.shape[1:])
+            self._dtype = np.dtype(">f4") if block.dtype == np.float32 else np.dtype(">f8")
+        if tuple(block.shape[1:]) != self._rec_shape:
+            raise ValueError(f"block {k} has record shape {block.shape[1:]}, the file holds {self._rec_shape}")
+        self._f.write(np.ascontiguousarray(block, dtype=self._dtype).tobytes())
+        self.nrecords += block.shape[0]
+
+    def close(self) -> None:
+        self._f.close()
+        if self._rec_shape is None:
+            raise ValueError("nothing was written")
+        dims = list(reversed(self._rec_shape))
+        lines = [f" nDims = [ {len(dims):3d} ];", " dimList = ["]
+        lines += [f" {n:5d}, {1:5d}, {n:5d}" + ("," if i + 1 < len(dims) else "") for i, n in enumerate(dims)]
+        lines += [" ];", f" dataprec = [ '{'float32' if self._dtype.itemsize == 4 else 'float64'}' ];",
+                  f" nrecords = [ {self.nrecords:5d} ];", f" timeStepNumber = [ {self.timestep:10d} ];"]
+        if self.fields:
+            lines += [f" nFlds = [ {len(self.fields):4d} ];", " fldList = {", " " + " ".join(f"'{n:<8s}'" for n in self.fields), " };"]
+        with open(self.prefix + ".meta", "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if exc[0] is None:
+            self.close()
+        else:
+            self._f.close()
+
+
+def write_mds(prefix: str, array: np.ndarray, fields: Sequence[str] = (), timestep: int = 0) -> None:
+    """`array` = (records, [Nr,] Ny, Nx) -> `<prefix>.data` / `.meta` the way MITgcm's `mdsio` writes a global file."""
+    with MdsWriter(prefix, fields, timestep) as w:
+        w.sink(0, np.asarray(array))
+
+
+def netcdf_variable_info(path: str, name: str) -> Dict:
+    """dims, shape, dtype and whether `name` is a record variable of a NetCDF-3 file"""
+    from scipy.io import netcdf_file
+
+    with netcdf_file(path, "r", mmap=False) as nc:
+        v = nc.variables[name]
+        return {"dims": tuple(v.dimensions), "shape": tuple(int(s) for s in v.shape), "dtype": v.data.dtype.str,
+                "isrec": bool(v.isrec), "attrs": {k: getattr(v, k) for k in v._attributes}}
+
+
+def netcdf_blocks(path: str, name: str, records_per_block: int = 1, records: Optional[Sequence[int]] = None) -> Iterator[np.ndarray]:
+    """Yield variable `name` of a NetCDF-3 file in blocks of its FIRST dimension (the record / time axis), big-endian as
+    stored, from the file's memory map.  Record variables are interleaved per record on disk: the block is then a strided
+    view, which the staging copy of `iter_stream` gathers.  float32 / float64 variables without CF packing only."""
+    from scipy.io import netcdf_file
+    import warnings
+
+    if records_per_block < 1:
+        raise ValueError("records_per_block must be >= 1")
+    nc = netcdf_file(path, "r", mmap=True)
+    try:
+        if name not in nc.variables:
+            raise KeyError(f"{path}: no variable {name!r} (has {sorted(nc.variables)})")
+        v = nc.variables[name]
+        if v.data.dtype.kind != "f" or v.data.dtype.itemsize not in (4, 8):
+            raise NotImplementedError(f"{path}:{name} is {v.data.dtype}; float32 / float64 variables only")
+        if any(a in v._attributes for a in ("scale_factor", "add_offset")):
+            raise NotImplementedError(f"{path}:{name} is a packed variable (scale_factor / add_offset)")
+        if len(v.shape) < 1:
+            raise ValueError(f"{path}:{name} is a scalar")
+        n = int(v.shape[0])
+        lo, hi = (0, n) if records is None else (int(records[0]), int(records[1]))
+        if not 0 <= lo <= hi <= n:
+            raise ValueError(f"records {lo}..{hi} outside 0..{n}")
+        data = v.data
+        for s in range(lo, hi, records_per_block):
+            yield data[s: min(s + records_per_block, hi)]
+        del data, v
+    finally:
+        with warnings.catch_warnings():  # views handed out may still be alive: the map then outlives the file object
+            warnings.simplefilter("ignore", RuntimeWarning)
+            nc.close()

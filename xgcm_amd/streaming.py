@@ -28,6 +28,22 @@ from .labeled import DataArray
 __all__ = ["record_blocks", "stream_records", "stream_apply", "stream_blocks", "iter_stream"]
 
 
+def _native_view(a: np.ndarray) -> Tuple[np.ndarray, int]:
+    """(the same bytes seen as NATIVE float32 / float64, element size if the byte order must be reversed on the GPU else 0).
+
+    Files MITgcm writes (MDS, NetCDF-3: `xgcm_amd.io`) hold big-endian numbers.  Their blocks cross PCIe as raw bytes and
+    are swapped in HBM by `xg_bswap`; no host core converts them."""
+    dt = a.dtype
+    if dt.kind == "f" and dt.itemsize in (4, 8) and not dt.isnative:
+        return a.view(dt.newbyteorder("=")), dt.itemsize
+    return a, 0
+
+
+def _swap_on_device(x: torch.Tensor, itemsize: int, stream: "torch.cuda.Stream") -> None:
+    if itemsize:
+        _hip.check(_hip.load().xg_bswap(x.data_ptr(), x.numel(), itemsize, stream.cuda_stream))
+
+
 def record_blocks(n_records: int, block: int) -> List[Tuple[int, int]]:
     """[start, stop) of consecutive record blocks (the last one may be short)."""
     if block < 1:
@@ -35,12 +51,21 @@ def record_blocks(n_records: int, block: int) -> List[Tuple[int, int]]:
     return [(s, min(s + block, n_records)) for s in range(0, n_records, block)]
 
 
+def _as_tensor(arr: np.ndarray) -> torch.Tensor:
+    """torch view of a host array that is only ever READ (a read-only memory map is fine: silence torch's warning)"""
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
+        return torch.from_numpy(arr)
+
+
 class _Pinned:
     """Page-lock a numpy array in place for the lifetime of the object (fallback: not pinned)."""
 
     def __init__(self, arr: np.ndarray):
         self.arr = arr
-        self.tensor = torch.from_numpy(arr)
+        self.tensor = _as_tensor(arr)
         self.registered = False
         try:
             rt = torch.cuda.cudart()
@@ -64,7 +89,7 @@ def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, 
     C-contiguous host array record block by record block, with H2D / compute / D2H overlapped."""
     if not torch.cuda.is_available():
         raise RuntimeError("xgcm_amd.streaming needs a GPU (there is no CPU fallback)")
-    src = np.asarray(src)
+    src, swap = _native_view(np.asarray(src))  # (a big-endian array, e.g. a memory-mapped MDS file: swapped in HBM)
     if not src.flags.c_contiguous:
         raise ValueError("the host array must be C-contiguous (records along the first axis)")
     n = src.shape[0]
@@ -73,7 +98,7 @@ def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, 
     s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     s_cmp = torch.cuda.current_stream(dev)
     pin_src = _Pinned(src) if register else None
-    src_t = pin_src.tensor if pin_src is not None else torch.from_numpy(src)
+    src_t = pin_src.tensor if pin_src is not None else _as_tensor(src)
     # page-locking in place failed (or was declined): stage through two pinned buffers per direction
     stage_in = None
     if pin_src is None or not pin_src.registered:
@@ -105,6 +130,7 @@ def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, 
                 else:
                     host_block = src_t[a:b]
                 x = host_block.to(dev, non_blocking=True)
+                _swap_on_device(x, swap, s_in)
                 ev_in = torch.cuda.Event()
                 ev_in.record(s_in)
                 in_done[slot] = ev_in
@@ -188,7 +214,7 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
     out_ready: List[Optional[Tuple[torch.Tensor, torch.cuda.Event]]] = [None, None]
 
     def upload(k: int, block) -> Tuple[torch.Tensor, torch.cuda.Event]:
-        a = np.asarray(block)
+        a, swap = _native_view(np.asarray(block))
         if a.dtype not in (np.float32, np.float64):
             a = a.astype(np.float64)
         slot = k % 2
@@ -198,6 +224,7 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
         np.copyto(host.numpy(), a)  # the READ of the block (disk / page cache -> pinned memory), any strides
         with torch.cuda.stream(s_in):
             x = host.to(dev, non_blocking=True)
+            _swap_on_device(x, swap, s_in)  # a big-endian block: raw bytes came over, the order is reversed in HBM
             ev = torch.cuda.Event()
             ev.record(s_in)
         in_free[slot] = ev
