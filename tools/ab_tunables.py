@@ -72,6 +72,9 @@ def main():
         "cumZw": (lambda: D.cumsum1d(T, 0, 0, 0, 0, 0, None, 0.0, False, True, dx, None), 16 + 8 / nz),
         "sumZw2": (lambda: D.reduce1d(T, 0, dx), 8 + 8 / nz),
         "vort": (lambda: D.vorticity(U, V, dx, "fill", "fill"), 24 + 8 / nz),
+        "divg": (lambda: D.divergence(U, V, dx, "periodic", "extend"), 24 + 8 / nz),
+        "grad": (lambda: D.gradient(T, "periodic", "extend", 0.0, 0.0, dx, dx2), 24 + 16 / nz),
+        "flux": (lambda: D.flux(U, V, T, "periodic", "extend"), 40),
     }
     cases = a.cases.split(",")
     T2 = D.synthetic((nz, ny, nx), 9) if "mulTT" in cases else None
@@ -107,7 +110,7 @@ def main():
             R = int(c[5:])
             TR = D.synthetic((R, nz, ny, nx), 4)
             CASES[c] = ((lambda TR=TR: D.cumsum1d(TR, 1, 0, 1, 1, 0, "fill")), 16 * R)
-    if "vort" in cases:
+    if any(c in cases for c in ("vort", "divg", "flux")):
         U, V = D.synthetic((nz, ny, nx), 51), D.synthetic((nz, ny, nx), 52)
     variants = []
     for spec in a.variants.split(";"):

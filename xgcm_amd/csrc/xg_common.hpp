@@ -120,6 +120,8 @@ struct Tune {
   int met_zk;         // K2S with two metrics, z-banded: outer levels per wave-task sharing the metric rows (1 / 2 / 4)
   int met_zk1;        // the same with ONE metric (derivative: a divisor only)
   int vec_zk;         // fused vorticity / divergence with an area, z-banded: levels per wave-task sharing the area rows
+  int met_zk2;        // two-axis kernel with metrics: levels per wave-task sharing the three metric planes' rows (2 / 4)
+  int nb_dpp;         // contiguous-axis stencils: the value beside a lane's vector from the neighbouring lane (DPP) instead of an 8-byte load
   int vec_zb_rows;    // fused vorticity / divergence with an area: rows per band (the area rows of a band live in the XCD's L2)
   int vec_nt;         // fused vorticity: non-temporal loads of bit 0 the v rows (left neighbour by lane shuffle), bit 1 the inner u rows
   int contig_rw_mi;   // K1r rows per wave-task when an input metric rides along too (three metric loads per row)
@@ -488,6 +490,25 @@ template <> __device__ __forceinline__ dv ldm<dv>(const real* m, int64_t off, in
   for (int k = 0; k < NV; ++k) o[k] = m[off + k * step];
   return o;
 }
+
+// The value the NEXT-LOWER lane (wave_shr:1) / NEXT-HIGHER lane (wave_shl:1) holds, moved on the VALU data path (DPP).
+// A stencil along the contiguous axis needs, next to its own 16-B vector, the one element left / right of it: that is
+// the neighbouring lane's last / first element -- already in registers -- instead of a second, 8-byte load per row whose
+// 64 addresses walk over the same cache lines again.  Lane 0 (shr) / lane 63 (shl) have no source lane and read 0: the
+// caller loads that one value itself.  Source lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ real dpp_lane(real v) {
+#ifdef XG_F32
+  return __uint_as_float((u32)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+#else
+  const u64 b = __builtin_bit_cast(u64, v);
+  const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, CTRL, 0xf, 0xf, false);
+  const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, (u64)lo | ((u64)hi << 32));
+#endif
+}
+__device__ __forceinline__ real from_lane_below(real v) { return dpp_lane<0x138>(v); }  // wave_shr:1
+__device__ __forceinline__ real from_lane_above(real v) { return dpp_lane<0x130>(v); }  // wave_shl:1
 
 // the same with the workgroups of a launch cut into 8 contiguous bands, one per XCD (grid size = multiple of 8;
 // wave ids beyond the work are rejected by the caller's range check)

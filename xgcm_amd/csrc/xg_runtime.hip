@@ -41,6 +41,8 @@ const TuneEntry TUNABLES[] = {
     {"vec_zk", &Tune::vec_zk, 2},
     {"vec_nt", &Tune::vec_nt, 3},
     {"vec_zb_rows", &Tune::vec_zb_rows, 16},
+    {"nb_dpp", &Tune::nb_dpp, 1},
+    {"met_zk2", &Tune::met_zk2, 4},
     {"contig_rw_mi", &Tune::contig_rw_mi, 8},
     {"met_seg", &Tune::met_seg, 4},
     {"met_seg1", &Tune::met_seg1, 2},

@@ -252,6 +252,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
   if (pad_lo) { edge = (i0 == 0); nidx = edge ? ((bc == XG_BC_PERIODIC) ? L - 1 : 0) : i0 - 1; }
   else { edge = (i0 + NV == L); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : L - 1) : i0 + NV; }
 
+  const bool nb_dpp = (ntl & 2) != 0;
+  const int lane = threadIdx.x & 63;
+  const bool own_nb = edge || (pad_lo ? lane == 0 : lane == WAVE - 1);  // no source lane: this lane loads the value itself
   dv a[R], wi[RM], wo[RM];
   real n[R], wn[RM];
   u64 rows[R];
@@ -260,9 +263,20 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
     const u32 uu = ((u32)u < nvalid) ? (u32)u : nvalid - 1;  // a short last group repeats its last row (not stored)
     rows[u] = ZS ? (u64)(z0 + uu) * Y + y0 : (u64)z0 * Y + (y0 + uu);
     const real* prow = in + rows[u] * L;
-    a[u] = ntl ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + i0)) : *reinterpret_cast<const dv*>(prow + i0);
-    n[u] = prow[nidx];
-    if (edge && bc == XG_BC_HALO) n[u] = halo[rows[u]];  // one halo cell per row (never weighted: no m_in with halos)
+    a[u] = (ntl & 1) ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + i0)) : *reinterpret_cast<const dv*>(prow + i0);
+    if (!nb_dpp) n[u] = prow[nidx];
+  }
+  if (nb_dpp) {  // the value beside a lane's vector from the neighbouring lane's registers (see from_lane_below)
+#pragma unroll
+    for (int u = 0; u < R; ++u) n[u] = pad_lo ? from_lane_below(a[u][NV - 1]) : from_lane_above(a[u][0]);
+    if (own_nb) {
+#pragma unroll
+      for (int u = 0; u < R; ++u) n[u] = in[rows[u] * L + nidx];
+    }
+  }
+  if (edge && bc == XG_BC_HALO) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) n[u] = halo[rows[u]];  // one halo cell per row (never weighted: no m_in with halos)
   }
 #pragma unroll
   for (int u = 0; u < RM; ++u) {
@@ -275,7 +289,12 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
 #pragma unroll
         for (int k = 0; k < NV; ++k) wi[u][k] = mrow[(int64_t)(i0 + k) * mi_x];
       }
-      wn[u] = mrow[(int64_t)nidx * mi_x];
+      if (nb_dpp && mal) {
+        wn[u] = pad_lo ? from_lane_below(wi[u][NV - 1]) : from_lane_above(wi[u][0]);
+        if (own_nb) wn[u] = mrow[(int64_t)nidx * mi_x];
+      } else {
+        wn[u] = mrow[(int64_t)nidx * mi_x];
+      }
     }
     if (HAS_MO) {
       const real* mrow = m_out + (zz * mo_z + yy * mo_y);
@@ -730,30 +749,65 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
     rowfill[u] = f;
     qq[u] = q;
   }
+  // The value next to a lane's vector (left of its first element if plx, right of its last otherwise) is the
+  // neighbouring lane's last / first element: taken from that lane's registers (DPP) instead of an 8-byte load per row
+  // and array -- 21 of this kernel's 45 loads with metrics, whose addresses walk over the cache lines of the vector loads
+  // a second time.  The lane at the wave's end and the lane at the row's end load the value themselves.
+  const int lane = threadIdx.x & 63;
+  const bool nb_dpp = (order & 2) != 0;
+  order &= 1;
+  const bool own_nb = !nb_dpp || edge || (plx ? lane == 0 : lane == WAVE - 1);
+  auto beside = [&](dv v) -> real { return plx ? from_lane_below(v[NV - 1]) : from_lane_above(v[0]); };
   // the field rows of every level of this task, then the metric rows (shared by the levels)
   dv prz[ZK][SEG + 1];
   real nbz[ZK][SEG + 1];
+  dv a1[MET ? SEG + 1 : 1], mid[MET ? SEG + 1 : 1], d3[MET ? SEG : 1];
+  real a1n[MET ? SEG + 1 : 1], midn[MET ? SEG + 1 : 1];
+  int64_t mrow[SEG + 1];
 #pragma unroll
   for (int kz = 0; kz < ZK; ++kz) {
     const real* pin = in + (o0 + oo + ((kz < nk) ? kz : nk - 1)) * ny * nx;  // a short last group repeats its last level (not stored)
 #pragma unroll
-    for (int u = 0; u <= SEG; ++u) {
-      prz[kz][u] = *reinterpret_cast<const dv*>(pin + qq[u] * nx + i0);
-      nbz[kz][u] = pin[qq[u] * nx + nidx];
-    }
+    for (int u = 0; u <= SEG; ++u) prz[kz][u] = *reinterpret_cast<const dv*>(pin + qq[u] * nx + i0);
   }
-  dv a1[MET ? SEG + 1 : 1], mid[MET ? SEG + 1 : 1], d3[MET ? SEG : 1];
-  real a1n[MET ? SEG + 1 : 1], midn[MET ? SEG + 1 : 1];
   if (MET) {
 #pragma unroll
     for (int u = 0; u <= SEG; ++u) {
       a1[u] = *reinterpret_cast<const dv*>(m1 + qq[u] * nx + i0);
-      a1n[u] = m1[qq[u] * nx + nidx];
       // between the axes: (Y as the input, X as the output) when X goes first, (Y as the output, X as the input) otherwise
-      const int64_t mrow = (order == 0) ? qq[u] : j0 + ((u < nrow) ? u : 0);
-      mid[u] = *reinterpret_cast<const dv*>(m2 + mrow * nx + i0);
-      midn[u] = m2[mrow * nx + nidx];
+      mrow[u] = (order == 0) ? qq[u] : j0 + ((u < nrow) ? u : 0);
+      mid[u] = *reinterpret_cast<const dv*>(m2 + mrow[u] * nx + i0);
     }
+  }
+  if (nb_dpp) {  // every neighbour value from the lane beside ...
+#pragma unroll
+    for (int kz = 0; kz < ZK; ++kz)
+#pragma unroll
+      for (int u = 0; u <= SEG; ++u) nbz[kz][u] = beside(prz[kz][u]);
+    if (MET) {
+#pragma unroll
+      for (int u = 0; u <= SEG; ++u) {
+        a1n[u] = beside(a1[u]);
+        midn[u] = beside(mid[u]);
+      }
+    }
+  }
+  if (own_nb) {  // ... except in the lanes that have none (ONE divergent block: the wave's end lane and the row's end lane)
+#pragma unroll
+    for (int kz = 0; kz < ZK; ++kz) {
+      const real* pin = in + (o0 + oo + ((kz < nk) ? kz : nk - 1)) * ny * nx;
+#pragma unroll
+      for (int u = 0; u <= SEG; ++u) nbz[kz][u] = pin[qq[u] * nx + nidx];
+    }
+    if (MET) {
+#pragma unroll
+      for (int u = 0; u <= SEG; ++u) {
+        a1n[u] = m1[qq[u] * nx + nidx];
+        midn[u] = m2[mrow[u] * nx + nidx];
+      }
+    }
+  }
+  if (MET) {
 #pragma unroll
     for (int u = 0; u < SEG; ++u) d3[u] = *reinterpret_cast<const dv*>(m3 + (j0 + ((u < nrow) ? u : 0)) * nx + i0);
   }
@@ -888,7 +942,7 @@ int launch_contig_rw(const StencilCall& c) {
   const u32 nblk = (u32)((waves + WPB - 1) / WPB);
   const u32 grid = ((nblk + 7) / 8) * 8;
   const FastDiv fnt = make_fastdiv(ntile), fYG = make_fastdiv(YG);
-#define XG_RW(R_, ZS_) hipLaunchKernelGGL((k_stencil_contig_rw<OP, MET, R_, ZS_>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, (u32)g.n_in, (u32)Z, (u32)Y, nblk, fnt, fYG, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, mi_z, mi_y, mi_x, c.m_out, mo_z, mo_y, mo_x, mal, tune().nt_load)
+#define XG_RW(R_, ZS_) hipLaunchKernelGGL((k_stencil_contig_rw<OP, MET, R_, ZS_>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, (u32)g.n_in, (u32)Z, (u32)Y, nblk, fnt, fYG, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, mi_z, mi_y, mi_x, c.m_out, mo_z, mo_y, mo_x, mal, (tune().nt_load ? 1 : 0) | (tune().nb_dpp ? 2 : 0))
   if (zs) { if (RR == 8) XG_RW(8, true); else if (RR == 4) XG_RW(4, true); else XG_RW(2, true); }
   else { if (RR == 4) XG_RW(4, false); else if (RR == 2) XG_RW(2, false); else XG_RW(1, false); }
 #undef XG_RW
@@ -1143,7 +1197,7 @@ static int stencil2d_impl(int op, const real* in, real* out, const int64_t* shap
     const u32 nouter = (u32)((outer - o0 < (int64_t)outer_per) ? outer - o0 : (int64_t)outer_per);
     u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
     ZBand zb = make_zband(false, 0, 0, 1);
-    constexpr int ZK2 = 4;  // levels per wave-task sharing the metric rows
+    const int ZK2 = tune().met_zk2 >= 4 ? 4 : 2;  // levels per wave-task sharing the metric rows
     if (met && tune().zband && nouter >= 2) {  // the metric planes are shared by the outer indices: band-major order
       const u32 B = ((u32)(tune().zb_rows > 0 ? tune().zb_rows : 16) + SEG - 1) / SEG;
       const u64 groups = ((u64)nouter + ZK2 - 1) / ZK2;
@@ -1154,14 +1208,16 @@ static int stencil2d_impl(int op, const real* in, real* out, const int64_t* shap
       }
     }
     const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GM(O, NTS, M) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, M>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order, padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
-#define XG_GZ(O, NTS) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, true, ZK2>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order, padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
+#define XG_GM(O, NTS, M) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, M>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order | (tune().nb_dpp ? 2 : 0), padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
+#define XG_GZK(O, NTS, ZK_) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, true, ZK_>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order | (tune().nb_dpp ? 2 : 0), padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
+#define XG_GZ(O, NTS) do { if (ZK2 == 4) XG_GZK(O, NTS, 4); else XG_GZK(O, NTS, 2); } while (0)
 #define XG_GO(O, NTS) do { if (met && zb.on) XG_GZ(O, NTS); else if (met) XG_GM(O, NTS, true); else XG_GM(O, NTS, false); } while (0)
 #define XG_O(O) do { if (nts) XG_GO(O, true); else XG_GO(O, false); } while (0)
     switch (op) { case XG_OP_DIFF: XG_O(XG_OP_DIFF); break; case XG_OP_INTERP: XG_O(XG_OP_INTERP); break; case XG_OP_MIN: XG_O(XG_OP_MIN); break; default: XG_O(XG_OP_MAX); }
 #undef XG_O
 #undef XG_GO
 #undef XG_GZ
+#undef XG_GZK
 #undef XG_GM
   }
   XG_LAUNCH_CHECK();
