@@ -194,6 +194,7 @@ struct ChainArgs {
   u32 nchunk, cpx, ncol, W, nblk;  // chunks per column, columns per XCD band, columns, sub-band width, workgroups per band
   u32 srow;                        // slots per ring row = lanes per row of the array
   u32 spin;                        // polls of a slot before giving up
+  u32 tmaj;                        // 0: columns numbered (outer index, x-tile); n > 0: (x-tile, outer index) with n outer indices
   u32* ticket;
   u32* gave_up;                    // host-mapped: [0] sticky report, [1] launches redone
   u32* poison;                     // device: [0] run-if word of this launch's rescue kernel, [1] its workgroup count
@@ -255,8 +256,13 @@ __device__ __forceinline__ bool chain_task(const ChainArgs& ch, u32 ntile, u32& 
   // (the divisions run on the vector unit; readfirstlane tells the compiler their results are wave-uniform again)
   c = __builtin_amdgcn_readfirstlane(ql / w);
   const u32 col = sub_lo + (ql - c * w);
-  o32 = __builtin_amdgcn_readfirstlane(col / ntile);
-  tile = col - o32 * ntile;
+  if (ch.tmaj) {  // x-tile-major: the levels of one x-tile are neighbours in the sequence (a metric shared by the levels)
+    tile = __builtin_amdgcn_readfirstlane(col / ch.tmaj);
+    o32 = col - tile * ch.tmaj;
+  } else {
+    o32 = __builtin_amdgcn_readfirstlane(col / ntile);
+    tile = col - o32 * ntile;
+  }
   return true;
 }
 
@@ -1225,6 +1231,22 @@ bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void
   ch->W = (u32)(ctile * (u64)(lv >= 100 ? (lv - 100 < 1 ? 1 : lv - 100) : (lv > (int)min_lv ? (u64)lv : min_lv)));
   // (whole-plane rows, the Z axis, in column chunks of 256 ... 4096 tiles: 65-66 % chained, 66.5 % marching: march kept)
   if (shared_metric && lv < 100) ch->W = ch->cpx;  // (>= 100: experiment, sub-bands of lv - 100 levels whatever the metric)
+  ch->tmaj = 0;
+  if (shared_metric && tune().scan_chain_tmaj) {
+    // A metric shared by the outer indices ("levels"): number the columns x-tile-major and let a sub-band be ALL levels of
+    // a few x-tiles.  The chunk's metric rows are then fetched once for the whole chip (level-major: once per XCD, whose
+    // band holds a few levels of every tile), and the chunks of a column follow each other after W tasks instead of after
+    // a whole band: the 16-byte hand-off slots stay in the L2 (band-wide they were written back to HBM and read again:
+    // +0.6 GB of writes for `integrate` along Y, PMC traffic 1.215x).  The price: an XCD works on all levels at once.
+    // MEASURED (profiles/r03o_*): traffic as predicted -- cumint Y 1.084x -> 1.008x, integrate Y 1.215x -> 1.018x -- and the
+    // kernels 10 % / 27 % SLOWER (1.77 -> 1.94 ms, 1.13 -> 1.44 ms): the level-major sweep is worth more than the bytes,
+    // which the Infinity Cache absorbs.  Off by default; kept as the evidence that the extra traffic is a choice.
+    const u64 nout = ncol / ctile;  // outer indices (level groups) per x-tile
+    if (nout >= 2 && nout < 0x7fffffffull) {
+      ch->tmaj = (u32)nout;
+      ch->W = (u32)(nout * ((56 + nout - 1) / nout));
+    }
+  }
   if (ch->W > ch->cpx) ch->W = ch->cpx;
   ch->srow = (u32)lanes;
   const u64 nblk = ((u64)ch->cpx * nchunk + WPB - 1) / WPB;
