@@ -14,7 +14,11 @@ namespace {
 // straight-line levels with exact vmcnt waits), so that the whole chip sweeps one level at a time like a copy.  Bit-exact,
 // but no faster than this march in any state of the device: 0.69-0.72 against 0.72-0.76 of 8 TB/s for one record, equal
 // from 4 records per launch on (profiles/r03c_*, r03i_ab_cumZ_records.jsonl) -- the number of DRAM streams and the
-// generation tail are not what holds the march back.  What the same measurements do show: the rate of THIS kernel on
+// generation tail are not what holds the march back.  The stand-alone probe tools/levels_probe.hip (14 shapes: 8-32 tiles
+// per wave, groups of 2 / 4, loads 1-5 groups ahead; profiles/r03p_*): slow-kind box 0.675-0.680 whatever the depth against
+// 0.653 for the march and 0.82 for a copy; fast-kind box 0.738 against 0.766; the same waves loading only 0.83, storing
+// only 0.77 -- i.e. neither prefetch depth nor occupancy is the lever, and the two directions together cost 8 % more than
+// apart.  What the same measurements do show: the rate of THIS kernel on
 // ONE box falls from 0.76 (a 1.7 ms launch) to 0.65 (8 records, 16 ms) with the length of the busy period, i.e. the
 // "slow boxes" of round 2 are the sustained, power-managed state of every box.
 // ------------------------------------------------------------------------------------------
