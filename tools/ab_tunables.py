@@ -69,6 +69,7 @@ def main():
         "cumXe": (lambda: D.cumsum1d(T, 2, 0, 1, 1, 0, "extend"), 16),
         "cumX0": (lambda: D.cumsum1d(T, 2, 0, 0, 0, 0, None), 16),
         "cumXw": (lambda: D.cumsum1d(T, 2, 0, 0, 0, 0, None, 0.0, False, True, dx, None), 16 + 8 / nz),
+        "cumXwl": (lambda: D.cumsum1d(T, 2, 0, 1, 1, 0, "fill", 0.0, False, True, dx, None), 16 + 8 / nz),  # Grid.cumint along X
         "cumZw": (lambda: D.cumsum1d(T, 0, 0, 0, 0, 0, None, 0.0, False, True, dx, None), 16 + 8 / nz),
         "sumZw2": (lambda: D.reduce1d(T, 0, dx), 8 + 8 / nz),
         "vort": (lambda: D.vorticity(U, V, dx, "fill", "fill"), 24 + 8 / nz),

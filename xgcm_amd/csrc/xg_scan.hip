@@ -650,36 +650,15 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
   const real* mi_row = m_in + mi_base;
   // ... and when its row keeps the output groups' alignment, ONE 16-B load per group instead of NV narrow ones
   const bool mi_al = mi_unit && ((reinterpret_cast<uintptr_t>(mi_row + lead) & 15u) == 0);
-  // shift == 1 (Grid.cumsum / cumint center -> left, the default: the result moves up by one cell behind a halo cell): the
-  // inputs of output group [j, j + NV) are in[j - 1 .. j + NV - 2].  Instead of NV misaligned narrow loads of the field and
-  // NV of the metric, every thread takes the ALIGNED vectors at j, forms the products there, and the one value it lacks --
-  // the last product of the group before it in memory -- comes from the neighbouring lane (DPP wave shift; the lane at
-  // the wave's end fetches it itself).  This scan had the highest VALU share of the library (0.45).
-  const bool sh1 = (shift == 1) && (n == no) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0) && (!HAS_MI || mi_unit);
+  // (Round 3 tried two more things here, both measured in one process and both REMOVED: for the shifted scan -- center ->
+  // left, the Grid's default -- aligned vectors of field and metric with the one missing product taken from the
+  // neighbouring lane by DPP: cumsum X 0.73 -> 0.62, cumint X 0.66 -> 0.56, the lane-0 fix-up and the extra moves cost more
+  // than the misaligned narrow loads the L1 serves; and two vectors per thread and pass: 0.74 -> 0.70.
+  // profiles/r03q_ab_scan_sh1.jsonl, r03q_ab_scan_gv_nosh1.jsonl)
   auto load_group = [&](int t, real (&x)[NV]) {
     if (t >= groups) {
 #pragma unroll
       for (int k = 0; k < NV; ++k) x[k] = real(0);
-      return;
-    }
-    if (sh1) {  // (wave-uniform; every thread with a group executes the DPP move below)
-      const int j = group_lo(t);
-      dv p = *reinterpret_cast<const dv*>(prow + j);
-      if (HAS_MI) {
-        if (mi_al) p = p * *reinterpret_cast<const dv*>(mi_row + j);
-        else {
-#pragma unroll
-          for (int k = 0; k < NV; ++k) p[k] = p[k] * mi_row[j + k];
-        }
-      }
-      if (a.skipna) p = nan0(p);
-      // the group before this one in memory belongs to the previous thread (forward scan) / the next one (reverse)
-      real before = a.reverse ? dpp_take<0x130, 0xf>(p[NV - 1]) : dpp_take<0x138, 0xf>(p[NV - 1]);  // wave_shl:1 / wave_shr:1
-      const bool has_nb = a.reverse ? (lane != WAVE - 1 && t + 1 < groups) : (lane != 0);
-      if (!has_nb) before = fetch(j - 1);
-      x[0] = before;
-#pragma unroll
-      for (int k = 1; k < NV; ++k) x[k] = p[k - 1];
       return;
     }
     const int i0 = group_lo(t) - shift;
