@@ -318,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
     real* __restrict__ out_y, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile, FastDiv nseg,
     int bc_x, real fill_x, int bc_y, real fill_y, const real* __restrict__ mx, AreaIdx aix, int64_t mx_sy,
     int64_t mx_sx, const real* __restrict__ my, AreaIdx aiy, int64_t my_sy, int64_t my_sx,
-    const real* __restrict__ halo_x, const real* __restrict__ halo_y) {
+    const real* __restrict__ halo_x, const real* __restrict__ halo_y, ZBand zb) {
   typedef typename VecT<V>::type T;
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
@@ -326,9 +326,14 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
   const u32 r = fdiv(w, ntile);
   const u32 tile = w - r * ntile.d;
-  const u32 oo = fdiv(r, nseg);
-  if (oo >= nouter) return;
-  const u32 sg = r - oo * nseg.d;
+  u32 oo, sg;
+  if (zb.on) {  // band-major: the metric rows of a band of segments stay in the XCD's L2 for all outer indices (rule 4)
+    if (!zband_map(zb, r, oo, sg)) return;
+  } else {
+    oo = fdiv(r, nseg);
+    if (oo >= nouter) return;
+    sg = r - oo * nseg.d;
+  }
   const int64_t o = o0 + oo;
   const int64_t i0 = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
   if (i0 >= nx) return;
@@ -638,11 +643,29 @@ static int pair2d_impl(int mode, const real* a, const real* u, const real* v, re
   const u64 outer_per = MAX_ITEMS / per_outer;
   hipStream_t st = (hipStream_t)stream;
   const bool nts = tune().nt_store;
-  for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_per) {
-    const u32 nouter = (u32)((outer - o0 < (int64_t)outer_per) ? outer - o0 : (int64_t)outer_per);
-    const u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
+  // gradient with metrics that every outer index shares (dxC(Y,X), dyC(Y,X) under a (Z,Y,X) field): band-major order, or
+  // both planes come from the fabric again for every level (0.56 of 8 TB/s level-major).  Two metrics: 8-row bands (rule 13)
+  ZBand zb = make_zband(false, 0, 0, 1);
+  u64 outer_step = outer_per;
+  const u32 ZB_SEGS = (u32)((((mx && my) ? 8 : 16) + SEG - 1) / SEG);
+  auto shared = [](const real* m, const AreaIdx& ai) {  // absent, or broadcast along every leading dim
+    for (int d = 0; m && d < ai.n; ++d)
+      if (ai.stride[d] != 0) return false;
+    return true;
+  };
+  if (mode == 0 && (mx || my) && shared(mx, aix) && shared(my, aiy) && tune().zband && outer >= 2) {
+    const u64 padded = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * (u64)outer * ntile;
+    if (padded <= MAX_ITEMS) {
+      zb = make_zband(true, (u64)outer, nseg, ZB_SEGS);
+      if (zb.on) outer_step = (u64)outer;
+    }
+  }
+  for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_step) {
+    const u32 nouter = (u32)((outer - o0 < (int64_t)outer_step) ? outer - o0 : (int64_t)outer_step);
+    const u64 waves = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * (u64)outer * ntile : (u64)nouter * per_outer;
+    const u32 nblk = (u32)((waves + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GO(V_, M_, NTS) hipLaunchKernelGGL((k_pair2d<V_, M_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, a, u, v, out_x, out_y, o0, nouter, nblk, ny, nx, fnt, fns, bc_x, fill_x, bc_y, fill_y, mx, aix, mx_sy, mx_sx, my, aiy, my_sy, my_sx, halo_x, halo_y)
+#define XG_GO(V_, M_, NTS) hipLaunchKernelGGL((k_pair2d<V_, M_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, a, u, v, out_x, out_y, o0, nouter, nblk, ny, nx, fnt, fns, bc_x, fill_x, bc_y, fill_y, mx, aix, mx_sy, mx_sx, my, aiy, my_sy, my_sx, halo_x, halo_y, zb)
 #define XG_M(V_, M_) do { if (nts) XG_GO(V_, M_, true); else XG_GO(V_, M_, false); } while (0)
     if (V > 1) { if (mode) XG_M(NV, 1); else XG_M(NV, 0); }
     else { if (mode) XG_M(1, 1); else XG_M(1, 0); }
