@@ -24,7 +24,8 @@ def starved():
     from xgcm_amd import _hip
     from xgcm_amd import device as D
 
-    keep = {k: _hip.get_tunable(k) for k in ("scan_chain_spin", "scan_chain", "reduce_zl")}
+    keep = {k: _hip.get_tunable(k) for k in ("scan_chain_spin", "scan_chain", "reduce_zl", "reduce_ldsw")}
+    _hip.set_tunable("reduce_ldsw", 0)  # these tests are about the CHAINED reduction, not the LDS-weight march that replaced it by default
     torch.cuda.synchronize()
     _hip.chain_rearm()
     with warnings.catch_warnings():

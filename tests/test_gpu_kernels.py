@@ -164,8 +164,9 @@ def test_cumsum_chained_chunks(dev, dtype):
     direction / NaN mode, ragged last chunks, metrics, several columns per XCD band -- bit-identical to the
     sequential numpy order, and twice in a row (the workspace must come back clean)."""
     from xgcm_amd import _hip
-    before, before_zl = _hip.get_tunable("scan_chain"), _hip.get_tunable("reduce_zl")
+    before, before_zl, before_lds = _hip.get_tunable("scan_chain"), _hip.get_tunable("reduce_zl"), _hip.get_tunable("reduce_ldsw")
     _hip.set_tunable("scan_chain", 2)
+    _hip.set_tunable("reduce_ldsw", 0)  # (the LDS-weight march would take the long weighted reductions: this test is about the chain)
     try:
         for shape in ((3, 300, 128), (2, 70, 130), (5, 64, 66), (1, 33, 2), (9, 97, 700)):
             a = _field(shape, 7, nan=True).astype(dtype)
@@ -202,6 +203,36 @@ def test_cumsum_chained_chunks(dev, dtype):
     finally:
         _hip.set_tunable("scan_chain", before)
         _hip.set_tunable("reduce_zl", before_zl)
+        _hip.set_tunable("reduce_ldsw", before_lds)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_weighted_reduction_with_weights_through_lds(dev, dtype):
+    """K4L: `integrate` / `average` along a long strided axis with weights shared by the outer indices -- the 4 waves of a
+    workgroup march 4 consecutive levels of one x-tile, the weight rows of a block of 32 rows go through LDS once per
+    workgroup.  Every mode, columns that are not a multiple of the block, outer extents that are not a multiple of 4,
+    ragged x-tiles, NaNs -- against the oracle (sequential order: bit-exact) and against the marching kernel."""
+    from xgcm_amd import _hip
+    keep = {k: _hip.get_tunable(k) for k in ("reduce_ldsw", "scan_chain")}
+    try:
+        for shape, wshape in (((3, 300, 128), (1, 300, 128)), ((6, 64, 130), (1, 64, 130)), ((5, 97, 66), (1, 97, 66)),
+                              ((2, 3, 80, 64), (1, 1, 80, 64)), ((9, 1000, 70), (1, 1000, 70)), ((4, 65, 2), (1, 65, 2))):
+            a = _field(shape, 27, nan=True).astype(dtype)
+            w = R.synthetic_metric(wshape, 28).astype(dtype)
+            axis = len(shape) - 2
+            for mode in (True, False, "valid", "all", "mean_valid", "mean_all", "pair_valid", "pair_all"):
+                _hip.set_tunable("reduce_ldsw", 0)
+                _hip.set_tunable("scan_chain", 0)
+                ref = dev.tohost(dev.reduce1d(a, axis, w, mode))
+                _hip.set_tunable("reduce_ldsw", 1)
+                _hip.set_tunable("scan_chain", keep["scan_chain"])
+                for _ in range(2):
+                    _eq(dev.tohost(dev.reduce1d(a, axis, w, mode)), ref)
+            with np.errstate(invalid="ignore"):
+                _eq(dev.tohost(dev.reduce1d(a, axis, w, True)), R.integrate(a, axis, np.broadcast_to(w, shape), True).astype(dtype))
+    finally:
+        for k, v in keep.items():
+            _hip.set_tunable(k, v)
 
 
 def test_chained_scans_on_two_streams(dev):

@@ -62,6 +62,7 @@ def main():
         "sumX": (lambda: D.reduce1d(T, 2, None), 8),
         "sumXw": (lambda: D.reduce1d(T, 2, dx), 8 + 8 / nz),
         "sumYw": (lambda: D.reduce1d(T, 1, dx), 8 + 8 / nz),
+        "avgYw": (lambda: D.reduce1d(T, 1, dx, "mean_valid"), 8 + 8 / nz),  # Grid.average along Y with dy(Y, X)
         "sumYw1": (lambda: D.reduce1d(T, 1, dy1), 8),
         "sumYw3": (lambda: D.reduce1d(T, 1, T3), 16),
         "cumYw": (lambda: D.cumsum1d(T, 1, 0, 0, 0, 0, None, 0.0, False, True, dx, None), 16 + 8 / nz),

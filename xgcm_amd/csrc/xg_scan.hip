@@ -887,6 +887,114 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_rescue(
   rescue_end(rs);
 }
 
+// K4L: the long WEIGHTED march with the weights in LDS.  `integrate` / `average` along Y of (Z, Y, X) with dy(Y, X): the
+// weights are shared by the levels, and every way of sharing them through registers costs what it saves -- riding in the
+// march's window they halve the bytes in flight (K4 with weights: 0.52 of 8 TB/s), held by a chunk task for two levels they
+// need a cross-wave chain whose 16-byte hand-offs end up in HBM (K4cz: 0.58-0.63, traffic 1.22x).  Here the NWV waves of a
+// workgroup march the SAME x-tile of NWV consecutive levels side by side, block of U rows after block of U rows: each wave
+// keeps a rolling window of U field rows in registers like the unweighted march (sum along Y without weights: 0.80), and the
+// block's U weight rows are fetched ONCE per workgroup -- every wave a share -- into a double-buffered LDS tile that all of
+// them read; one barrier per block.  Sequential additions per column in row order: the bits of numpy / of K4.
+// integrate Y 0.58 -> 0.69, average Y (two running sums, which doubled K4cz's hand-offs) 0.51 -> 0.68 of 8 TB/s in one process;
+// HBM reads 1.22x (the weights once per workgroup, Infinity Cache hits), writes = the result.  No chain, no rescue twin.
+template <int U, int NWV>
+__global__ __launch_bounds__(NWV * WAVE) void k_reduce_ldsw(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, u32 nblk, int skipna,
+    const real* __restrict__ wgt, MIdx mw) {
+  constexpr int V = HV;
+  typedef typename VecT<V>::type T;
+  static_assert(U % NWV == 0, "every wave fetches U / NWV weight rows of a block");
+  constexpr int SH = U / NWV;
+  __shared__ T s_w[2][U][WAVE];
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;  // (whole workgroups leave: nobody is left waiting at a barrier)
+  const u32 og = lb / ntile, tile = lb - og * ntile;
+  const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t o = (int64_t)og * NWV + wv;
+  const int64_t x = ((int64_t)tile * WAVE + lane) * V;
+  const int64_t inner = g.inner, n = g.n_in;
+  const bool live = o < g.outer && x < inner;  // a wave beyond the last level / a lane beyond the row still fetches weights
+  const bool lane_ok = x < inner;
+  const real* pin = in + (live ? o : 0) * n * inner + (lane_ok ? x : 0);
+  const int64_t mb = lane_ok ? inner_off(g, mw, x) : 0;
+  const int64_t ms = (V > 1 && lane_ok) ? inner_off(g, mw, x + 1) - mb : 0;
+  const bool pair = skipna >= 6;
+  if (pair) skipna -= 2;
+  const bool mean = skipna >= 4;
+  T acc = splat<T>(real(0)), den = splat<T>(real(0));
+  bool started = false;
+  auto step = [&](T v, T wv_) {  // k_reduce_strided's `step`, same operations in the same order
+    if (mean) {
+      T d = as_count(v, skipna == 4 ? 2 : 3);
+      d = d * wv_;
+      v = v * wv_;
+      if (skipna == 4) v = nan0(v);
+      d = nan0(d);
+      den = started ? den + d : d;
+    } else {
+      if (skipna >= 2) v = as_count(v, skipna);
+      v = v * wv_;
+      if (skipna) v = nan0(v);
+    }
+    acc = started ? acc + v : v;
+    started = true;
+  };
+  // this wave's share of a block's weight rows: rows [b U + wv SH, + SH) -> registers -> LDS buffer b & 1
+  T wreg[SH];
+  auto fetch_w = [&](int64_t b) {
+#pragma unroll
+    for (int r = 0; r < SH; ++r) {
+      int64_t k = b * U + (int64_t)wv * SH + r;
+      if (k >= n) k = n - 1;  // (rows beyond the column: never consumed)
+      wreg[r] = lane_ok ? ldm<T>(wgt, mb + k * mw.axis, ms) : splat<T>(real(0));
+    }
+  };
+  auto park_w = [&](int64_t b) {
+#pragma unroll
+    for (int r = 0; r < SH; ++r) s_w[b & 1][wv * SH + r][lane] = wreg[r];
+  };
+  const int64_t nb = (n + U - 1) / U;
+  fetch_w(0);
+  park_w(0);
+  T v[U];  // the rolling window of field rows: row k + U is requested when row k is consumed
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (live && u < n) v[u] = ldg<T, true>(pin + (int64_t)u * inner);
+  __syncthreads();
+  for (int64_t b = 0; b < nb; ++b) {
+    if (b + 1 < nb) fetch_w(b + 1);  // in flight while this block is consumed
+    const int64_t k0 = b * U;
+    if (live) {
+      if (k0 + 2 * U <= n) {  // steady state: no bounds tests
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const T xv = v[u];
+          v[u] = ldg<T, true>(pin + (k0 + U + u) * inner);
+          step(xv, s_w[b & 1][u][lane]);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const T xv = v[u];
+          if (k0 + U + u < n) v[u] = ldg<T, true>(pin + (k0 + U + u) * inner);
+          if (k0 + u < n) step(xv, s_w[b & 1][u][lane]);
+        }
+      }
+    }
+    if (b + 1 < nb) park_w(b + 1);  // buffer (b + 1) & 1 was last read in block b - 1, before the barrier below of that block
+    __syncthreads();
+  }
+  if (!live) return;
+  if (pair) {
+    *reinterpret_cast<T*>(out + o * inner + x) = acc;
+    *reinterpret_cast<T*>(out + (g.outer + o) * inner + x) = den;
+  } else {
+    *reinterpret_cast<T*>(out + o * inner + x) = mean ? acc / den : acc;
+  }
+}
+
 // K4c: the long WEIGHTED march (integrate / average along Y of (Z, Y, X) with dy(Y, X)) as a chained flat launch, K5c
 // without the stores: a marching wave keeps the weight of every in-flight row in registers next to the row, so its
 // window is 8 rows (52 % of 8 TB/s); a chunk task holds 32 rows + 32 weight rows once and ends.  Same order of
@@ -1439,6 +1547,21 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
       ChainArgs ch;
       u32 ctile = 0;
       u64 nblk = 0;
+      // K4L: the weights of a block of rows once per workgroup through LDS, the waves of a workgroup = consecutive levels
+      if (shared_w && tune().reduce_ldsw && g.outer >= 2 && g.n_in >= 64 && g.outer < 0x7fffffffll) {
+        // (A/B of the shapes, profiles/r03u_ab_ldsw_shapes*.jsonl: blocks of 8 rows x 4 levels 0.69 / 0.68 for sum / mean;
+        // 16 x 4: 0.67 / 0.66; 4 x 4: 0.68 / 0.66; 8 x 2: 0.66 / 0.65; 24 x 4: 0.60; 8 levels per workgroup: 0.53-0.54;
+        // the chained K4cz on the same box: 0.58 / 0.51)
+        constexpr int LU = 8, LW = 4;
+        const u32 ltile = ceil_div_u32(g.inner, (int64_t)WAVE * HV);
+        const u64 groups = ((u64)g.outer + LW - 1) / LW, lblk = groups * ltile;
+        if (lblk < 0x7ffffff0ull) {
+          const u32 lgrid = (u32)(((lblk + 7) / 8) * 8);
+          hipLaunchKernelGGL((k_reduce_ldsw<LU, LW>), dim3(lgrid), dim3(LW * WAVE), 0, st, in, out, g, ltile, (u32)lblk, skipna, w, mw);
+          XG_LAUNCH_CHECK();
+          return XG_OK;
+        }
+      }
       bool chained = false;
       const int zl = tune().reduce_zl;  // levels per task sharing the weight rows (K4cz); 1: K4c
       // (measured: 2 levels x 16 rows 61-63 %, 3 x 16 59 %, 4 x 16 55 %, 4 x 8 59 %, 2 x 32 50 %, K4c 56-57 %, the march 51 %)
