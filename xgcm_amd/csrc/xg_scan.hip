@@ -193,6 +193,10 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
 //     is all-zero between launches (no per-launch memset, safe under graph replay);
 //   the spin is bounded (`scan_chain_spin` polls): a wave that gives up poisons its column with NaN and raises the
 //     stream's poison word, on which the rescue kernel queued behind every chained launch redoes the call (chain_wait).
+// (Round 3, after K4L's success with weights through LDS: the same for this scan -- the 4 waves of a workgroup = 4
+// consecutive levels of one x-tile and chunk, the chunk's 32 metric rows fetched once per workgroup into LDS instead of once
+// per wave, i.e. 40 instead of 64 loads per task: cumint Y 0.666 -> 0.673, nothing (profiles/r03v_*).  Not kept: the chain's
+// pace is set by its hand-offs and stores, not by the metric loads.)
 // ------------------------------------------------------------------------------------------
 struct ChainArgs {
   u32 nchunk, cpx, ncol, W, nblk;  // chunks per column, columns per XCD band, columns, sub-band width, workgroups per band
