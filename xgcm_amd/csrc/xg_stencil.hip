@@ -860,6 +860,150 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
   }
 }
 
+// K8y: K8 with `metric_weighted` on both axes, X first, band-major -- the case of `Grid.interp(da, ["X", "Y"],
+// metric_weighted=("X", "Y"))` -- with Y-STACKED workgroups: the WPB waves of a workgroup are WPB consecutive segments of
+// ONE x-tile and level group, and the row a segment shares with its neighbour (its halo row) is not loaded and pushed
+// through the X stencil and the `(t / m2) * m2` round trip a second time: the neighbour hands its finished intermediate row
+// over through LDS.  K8 computes SEG + 1 intermediate rows for SEG output rows (3 for 2): a third of its X-stencil work,
+// divisions, field and metric loads is that shared row.  Only the wave at the workgroup's edge (or at the array's edge,
+// where the halo follows the boundary rule) computes its halo row itself.  Same operations on the same operands: same bits.
+template <int OP, bool NTS, int SEG, int ZK>
+__global__ __launch_bounds__(BLOCK) void k_stencil2d_ys(
+    const real* __restrict__ in, real* __restrict__ out, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx,
+    FastDiv ntile, int dpp, int plx, int bcx, real fillx, int ply, int bcy, real filly,
+    const real* __restrict__ m1, const real* __restrict__ m2, const real* __restrict__ m3, ZBand zb) {
+  __shared__ dv s_tx[WPB][ZK][WAVE];
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;  // (a whole workgroup)
+  const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const u32 r = fdiv(lb, ntile);
+  const u32 tile = lb - r * ntile.d;
+  u32 oo = 0, sgrp = 0;
+  bool active = zband_map(zb, r, oo, sgrp);  // zb counts groups of WPB segments
+  oo *= ZK;
+  active = active && oo < nouter;
+  if (!active) oo = 0;
+  const u32 sg = sgrp * WPB + wib;
+  const int nk = ((int64_t)nouter - (int64_t)oo < ZK) ? (int)(nouter - oo) : ZK;  // levels this wave really has
+  const int64_t i0 = ((int64_t)tile * WAVE + lane) * NV;
+  const int64_t j0 = (int64_t)sg * SEG;
+  active = active && i0 < nx && j0 < ny;
+  const int64_t nrow = (ny - j0 < SEG) ? ny - j0 : SEG;
+  int64_t nidx;
+  bool edge;
+  if (plx) { edge = (i0 == 0); nidx = edge ? ((bcx == XG_BC_PERIODIC) ? nx - 1 : 0) : i0 - 1; }
+  else { edge = (i0 + NV == nx); nidx = edge ? ((bcx == XG_BC_PERIODIC) ? 0 : nx - 1) : i0 + NV; }
+  const bool fill_edge = edge && (bcx == XG_BC_FILL);
+  auto opx = [&](dv a, real n) -> dv {
+    dv t;
+    if (plx) {
+      t[0] = op2<OP>(n, a[0]);
+#pragma unroll
+      for (int k = 1; k < NV; ++k) t[k] = op2<OP>(a[k - 1], a[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV - 1; ++k) t[k] = op2<OP>(a[k], a[k + 1]);
+      t[NV - 1] = op2<OP>(a[NV - 1], n);
+    }
+    return t;
+  };
+  // rows u = 0 .. SEG of the intermediate array that this segment's SEG outputs need (K8's numbering): row u is array row
+  // j0 + u - ply; u = HALO is the one shared with the neighbouring segment, u = GIVE the one the neighbour needs from here
+  const int HALO = ply ? 0 : SEG, GIVE = ply ? SEG : 0;
+  // the halo row comes from the neighbouring wave when that wave exists in this workgroup and the row is an ordinary one
+  const bool recv = active && nrow == SEG && (ply ? (wib > 0) : (wib + 1 < WPB && j0 + SEG < ny));
+  bool rowfill[SEG + 1];
+  int64_t qq[SEG + 1];
+#pragma unroll
+  for (int u = 0; u <= SEG; ++u) {
+    int64_t k = j0 + ((u <= nrow) ? u : nrow);
+    int64_t q = k - ply;
+    bool f = false;
+    if (q < 0) { f = (bcy == XG_BC_FILL); q = (bcy == XG_BC_PERIODIC) ? ny - 1 : 0; }
+    else if (q >= ny) { f = (bcy == XG_BC_FILL); q = (bcy == XG_BC_PERIODIC) ? 0 : ny - 1; }
+    rowfill[u] = f;
+    qq[u] = q;
+  }
+  const bool nb_dpp = dpp != 0;
+  const bool own_nb = !nb_dpp || edge || (plx ? lane == 0 : lane == WAVE - 1);
+  auto beside = [&](dv v) -> real { return plx ? from_lane_below(v[NV - 1]) : from_lane_above(v[0]); };
+  dv tx[ZK][SEG + 1];
+  dv d3[SEG];
+  if (active) {
+    dv prz[ZK][SEG + 1], a1[SEG + 1], mid[SEG + 1];
+    real nbz[ZK][SEG + 1], a1n[SEG + 1];
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) {
+      if (u == HALO && recv) continue;  // (wave-uniform)
+#pragma unroll
+      for (int kz = 0; kz < ZK; ++kz) {
+        const real* pin = in + (o0 + oo + ((kz < nk) ? kz : nk - 1)) * ny * nx;  // a short last group repeats its last level (not stored)
+        prz[kz][u] = *reinterpret_cast<const dv*>(pin + qq[u] * nx + i0);
+      }
+      a1[u] = *reinterpret_cast<const dv*>(m1 + qq[u] * nx + i0);
+      mid[u] = *reinterpret_cast<const dv*>(m2 + qq[u] * nx + i0);  // X first: between the axes = (Y as the input, X as the output)
+    }
+    if (nb_dpp) {
+#pragma unroll
+      for (int u = 0; u <= SEG; ++u) {
+        if (u == HALO && recv) continue;
+#pragma unroll
+        for (int kz = 0; kz < ZK; ++kz) nbz[kz][u] = beside(prz[kz][u]);
+        a1n[u] = beside(a1[u]);
+      }
+    }
+    if (own_nb) {  // ONE divergent block: the wave's end lane and the row's end lane
+#pragma unroll
+      for (int u = 0; u <= SEG; ++u) {
+        if (u == HALO && recv) continue;
+#pragma unroll
+        for (int kz = 0; kz < ZK; ++kz) {
+          const real* pin = in + (o0 + oo + ((kz < nk) ? kz : nk - 1)) * ny * nx;
+          nbz[kz][u] = pin[qq[u] * nx + nidx];
+        }
+        a1n[u] = m1[qq[u] * nx + nidx];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) d3[u] = *reinterpret_cast<const dv*>(m3 + (j0 + ((u < nrow) ? u : 0)) * nx + i0);
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) {
+      if (u == HALO && recv) continue;
+#pragma unroll
+      for (int kz = 0; kz < ZK; ++kz) {
+        const dv pr = prz[kz][u] * a1[u];      // the products at the input positions
+        const real nb = nbz[kz][u] * a1n[u];
+        dv t = opx(pr, fill_edge ? fillx : nb);
+        t = (t / mid[u]) * mid[u];             // kept as written: not the identity in floating point
+        tx[kz][u] = rowfill[u] ? splat<dv>(filly) : t;
+      }
+    }
+#pragma unroll
+    for (int kz = 0; kz < ZK; ++kz) s_tx[wib][kz][lane] = tx[kz][GIVE];
+  }
+  __syncthreads();
+  if (!active) return;
+  if (recv) {
+    const u32 from = ply ? wib - 1 : wib + 1;
+#pragma unroll
+    for (int kz = 0; kz < ZK; ++kz) tx[kz][HALO] = s_tx[from][kz][lane];
+  }
+#pragma unroll
+  for (int kz = 0; kz < ZK; ++kz) {
+    if (kz >= nk) break;
+    real* po = out + ((o0 + oo + kz) * ny + j0) * nx + i0;
+#pragma unroll
+    for (int u = 0; u < SEG; ++u)
+      if (u < nrow) {
+        dv res = op2<OP>(tx[kz][u], tx[kz][u + 1]);
+        res = res / d3[u];
+        stg<dv, NTS>(po + u * nx, res);
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 
 struct StencilCall {
@@ -1198,16 +1342,32 @@ static int stencil2d_impl(int op, const real* in, real* out, const int64_t* shap
     u32 nblk = (u32)(((u64)nouter * per_outer + WPB - 1) / WPB);
     ZBand zb = make_zband(false, 0, 0, 1);
     const int ZK2 = tune().met_zk2 >= 4 ? 4 : 2;  // levels per wave-task sharing the metric rows
+    bool ys = false;  // K8y: X first with metrics, y-stacked workgroups handing the shared intermediate row on through LDS
     if (met && tune().zband && nouter >= 2) {  // the metric planes are shared by the outer indices: band-major order
       const u32 B = ((u32)(tune().zb_rows > 0 ? tune().zb_rows : 16) + SEG - 1) / SEG;
       const u64 groups = ((u64)nouter + ZK2 - 1) / ZK2;
+      if (order == 0 && nts && ZK2 == 4 && tune().met_ys && groups >= 2) {
+        const u64 nsg = (nseg + WPB - 1) / WPB;                 // groups of WPB segments = workgroups per (level group, x-tile)
+        const u32 Bg = (B + WPB - 1) / WPB;
+        const u64 blocks = ((nsg + Bg - 1) / Bg) * Bg * groups * ntile;
+        if (blocks < 0x7ffffff0ull) {
+          zb = make_zband(true, groups, nsg, Bg);
+          if (zb.on) { nblk = (u32)blocks; ys = true; }
+        }
+      }
       const u64 padded = ((nseg + B - 1) / B) * B * groups * ntile;
-      if (groups >= 2 && padded <= MAX_ITEMS) {
+      if (!ys && groups >= 2 && padded <= MAX_ITEMS) {
         zb = make_zband(true, groups, nseg, B);
         if (zb.on) nblk = (u32)((padded + WPB - 1) / WPB);
       }
     }
     const u32 grid = ((nblk + 7) / 8) * 8;
+    if (ys) {
+#define XG_YS(O) hipLaunchKernelGGL((k_stencil2d_ys<O, true, SEG, 4>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, tune().nb_dpp, padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
+      switch (op) { case XG_OP_DIFF: XG_YS(XG_OP_DIFF); break; case XG_OP_INTERP: XG_YS(XG_OP_INTERP); break; case XG_OP_MIN: XG_YS(XG_OP_MIN); break; default: XG_YS(XG_OP_MAX); }
+#undef XG_YS
+      continue;
+    }
 #define XG_GM(O, NTS, M) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, M>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order | (tune().nb_dpp ? 2 : 0), padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
 #define XG_GZK(O, NTS, ZK_) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, true, ZK_>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order | (tune().nb_dpp ? 2 : 0), padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
 #define XG_GZ(O, NTS) do { if (ZK2 == 4) XG_GZK(O, NTS, 4); else XG_GZK(O, NTS, 2); } while (0)
