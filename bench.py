@@ -34,7 +34,13 @@ NZ, NY, NX = 75, 2400, 3600
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_CELL = 16.0  # 1 f64 read + 1 f64 write per output cell
 OPS = [("interp", "X"), ("diff", "X"), ("interp", "Y"), ("diff", "Y")]
-KERNEL_OF_AXIS = {"X": "k_stencil_contig", "Y": "k_stencil_strided_seg"}  # kernel that serves each axis here
+
+
+def kernel_of_axis():
+    """the kernel that serves each axis of this workload (profiles/*_rocprof_summary_bench.txt lists them by these names)"""
+    from xgcm_amd import _hip
+
+    return {"X": "k_stencil_contig", "Y": "k_stencil_strided_ys" if _hip.get_tunable("seg_ys") else "k_stencil_strided_seg"}
 
 
 def build_grid(nz, device_field):
@@ -204,9 +210,9 @@ def main():
     # per-launch durations from the HIP events recorded on the launch stream inside the timed region
     per_op_ms = [float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(K)])) for i in range(len(OPS))]
     step_ms = sorted(ev[k][0].elapsed_time(ev[k][len(OPS)]) for k in range(K))  # device time per step
-    by_kernel = {}
+    by_kernel, of_axis = {}, kernel_of_axis()
     for (fn, ax), ms in zip(OPS, per_op_ms):
-        by_kernel.setdefault(KERNEL_OF_AXIS[ax], []).append(ms)
+        by_kernel.setdefault(of_axis[ax], []).append(ms)
     dominant = max(by_kernel, key=lambda k: sum(by_kernel[k]))
     dom_ms = float(np.mean(by_kernel[dominant]))
     alg_bytes = cells_per_op * BYTES_PER_CELL

@@ -120,6 +120,7 @@ struct Tune {
   int met_zk;         // K2S with two metrics, z-banded: outer levels per wave-task sharing the metric rows (1 / 2 / 4)
   int met_zk1;        // the same with ONE metric (derivative: a divisor only)
   int vec_zk;         // fused vorticity / divergence with an area, z-banded: levels per wave-task sharing the area rows
+  int seg_ys;         // plain strided-axis stencil with short rows: y-stacked workgroups, the lower row of a pair through LDS (K2Sy)
   int met_ys;         // two-axis kernel with metrics, X first: y-stacked workgroups, the shared intermediate row through LDS (K8y)
   int met_zk2;        // two-axis kernel with metrics: levels per wave-task sharing the three metric planes' rows (2 / 4)
   int nb_dpp;         // contiguous-axis stencils: the value beside a lane's vector from the neighbouring lane (DPP) instead of an 8-byte load

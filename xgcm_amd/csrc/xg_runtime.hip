@@ -44,6 +44,7 @@ const TuneEntry TUNABLES[] = {
     {"nb_dpp", &Tune::nb_dpp, 1},
     {"met_zk2", &Tune::met_zk2, 4},
     {"met_ys", &Tune::met_ys, 1},
+    {"seg_ys", &Tune::seg_ys, 1},
     {"contig_rw_mi", &Tune::contig_rw_mi, 4},  // (8 before the two-metric bands went from 16 to 8 rows: 0.673 -> 0.693, r03r_ab_k1r_shapes.jsonl)
     {"met_seg", &Tune::met_seg, 4},
     {"met_seg1", &Tune::met_seg1, 2},

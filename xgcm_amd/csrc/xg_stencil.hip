@@ -1148,6 +1148,59 @@ inline bool metric_vec_ok(const Geo& g, const real* m, const MIdx& mm) {
   return true;
 }
 
+// K2Sy: the plain two-point operator along a strided axis with short rows (diff / interp / min / max along Y of (Z, Y, X)),
+// Y-STACKED: the WPB waves of a workgroup are WPB CONSECUTIVE ROWS of one x-tile.  K2S gives a wave one output row and two
+// loads -- its row and the row below, which the neighbouring task loaded too (an L2 hit, but a second trip through the
+// address and L1 pipeline for every output).  Here every wave loads ONE row, the upper one of its pair, and receives the
+// lower one from the wave below through LDS; only the lowest wave of a workgroup loads both: 1.25 loads per output row.
+template <int OP, bool NTS>
+__global__ __launch_bounds__(BLOCK) void k_stencil_strided_ys(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk, FastDiv ntile,
+    FastDiv ngrp, int pad_lo, int bc, real fill, const real* __restrict__ halo) {
+  typedef dv T;
+  __shared__ T s_row[WPB][WAVE];
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;  // (whole workgroups)
+  const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const u32 r = fdiv(lb, ntile);
+  const u32 tile = lb - r * ntile.d;
+  const u32 oo = fdiv(r, ngrp);
+  if (oo >= nouter) return;
+  const int64_t j = (int64_t)(r - oo * ngrp.d) * WPB + wib;  // this wave's output row
+  const int64_t o = o0 + oo, inner = g.inner;
+  const int64_t x = ((int64_t)tile * WAVE + lane) * NV;
+  const bool active = j < g.n_out && x < inner;
+  // padded rows j and j + 1 -> input rows (wave-uniform), fill flags, pre-gathered halo rows
+  auto source = [&](int64_t k, bool& f, bool& h) -> int64_t {
+    int64_t q = k - pad_lo;
+    f = false;
+    h = false;
+    if (q < 0 || q >= g.n_in) {
+      f = (bc == XG_BC_FILL);
+      if (bc == XG_BC_HALO) { h = true; q = (q < 0) ? 0 : pad_lo; }
+      else q = (q < 0) ? ((bc == XG_BC_PERIODIC) ? g.n_in - 1 : 0) : ((bc == XG_BC_PERIODIC) ? 0 : g.n_in - 1);
+    }
+    return q;
+  };
+  T lo = splat<T>(real(0)), hi = splat<T>(real(0));
+  bool f0 = false, f1 = false, h0 = false, h1 = false;
+  if (active) {
+    const real* pin = in + (o * g.n_in) * inner + x;
+    const real* phalo = halo + (o * (g.n_out - g.n_in + 1)) * inner + x;
+    const int64_t q0 = source(j, f0, h0), q1 = source(j + 1, f1, h1);
+    hi = *reinterpret_cast<const T*>((h1 ? phalo : pin) + q1 * inner);
+    if (wib == 0) lo = *reinterpret_cast<const T*>((h0 ? phalo : pin) + q0 * inner);  // the row below the workgroup: an L2 hit
+    s_row[wib][lane] = hi;
+  }
+  __syncthreads();
+  if (!active) return;
+  if (wib > 0) lo = s_row[wib - 1][lane];  // (the wave below is active: its row index is smaller)
+  const T a = f0 ? splat<T>(fill) : lo, b = f1 ? splat<T>(fill) : hi;
+  stg<T, NTS>(out + (o * g.n_out + j) * inner + x, op2<OP>(a, b));
+}
+
 template <int OP, int V, int MET, int SEG, int ZK = 1>
 int launch_seg_n(const StencilCall& c) {
   const u64 ntile = (u64)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
@@ -1195,6 +1248,21 @@ int launch_seg_n(const StencilCall& c) {
     }
   }
   if (ZK > 1) return launch_seg_n<OP, V, MET, SEG, 1>(c);  // not z-banded: no shared metric rows
+  if (MET == 0 && V == NV && SEG == 1 && !ck.on && tune().seg_ys && c.g.n_out >= 2 * WPB) {  // K2Sy: y-stacked workgroups
+    const u64 ngrp = ((u64)c.g.n_out + WPB - 1) / WPB, per = ngrp * ntile;  // workgroups per outer index
+    if (per <= MAX_ITEMS) {
+      const FastDiv fng = make_fastdiv(ngrp);
+      const u64 ostep = MAX_ITEMS / per;
+      for (int64_t o0 = 0; o0 < c.g.outer; o0 += (int64_t)ostep) {
+        const u32 nouter = (u32)((c.g.outer - o0 < (int64_t)ostep) ? c.g.outer - o0 : (int64_t)ostep);
+        const u32 nblk = (u32)((u64)nouter * per);
+        const u32 grid = ((nblk + 7) / 8) * 8;
+        if (tune().nt_store) hipLaunchKernelGGL((k_stencil_strided_ys<OP, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fng, c.pad_lo, c.bc, c.fill, c.halo);
+        else hipLaunchKernelGGL((k_stencil_strided_ys<OP, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fng, c.pad_lo, c.bc, c.fill, c.halo);
+      }
+      return 0;
+    }
+  }
   const ZBand zoff = make_zband(false, 0, 0, 1);
   for (int64_t o0 = 0; o0 < c.g.outer; o0 += (int64_t)outer_per) {
     const u32 nouter = (u32)((c.g.outer - o0 < (int64_t)outer_per) ? c.g.outer - o0 : (int64_t)outer_per);
