@@ -517,6 +517,54 @@ def test_transform_resident_tensors():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("lean", [0, 1])
+def test_linear_transform_shared_targets_hard_cases(dtype, lean):
+    """the lean streaming loop validates the shared targets once per workgroup: NaN / decreasing / repeated targets, targets
+    on column points, left and right of every column, duplicated theta (zero-width intervals: numpy's NaN fall-backs),
+    with and without edge masking and with the monotonicity checks bypassed -- the oracle's bits, as with the general loop"""
+    from xgcm_amd import _hip
+    from xgcm_amd import device as dev
+
+    nz, ny, nx = 12, 2, 130
+    rng = np.random.default_rng(5)
+    theta = np.cumsum(rng.random((nz, ny, nx)) + 0.05, axis=0)
+    theta[:, 0, 3] = theta[::-1, 0, 3]                 # decreasing column
+    theta[5, 0, 10:14] = theta[4, 0, 10:14]            # duplicated theta: slope = x / 0
+    theta[6, 1, 20] = np.nan
+    theta[:, 1, 64:70] = np.round(theta[:, 1, 64:70])  # integers: targets fall exactly on points
+    theta = theta.astype(dtype)
+    phi = (R.synthetic_field((nz, ny, nx), 3) * 10).astype(dtype)
+    phi[5, 0, 11] = np.inf                             # inf * 0 in the interpolation formula
+    phi[4:6, 0, 12] = 7.0
+    base = np.array([-1.0, 0.0, 1.0, 2.0, 2.0, 3.0, 4.5, 5.0, 6.0, 7.0, 50.0, 60.0])
+    target_sets = {
+        "sorted": base,
+        "nan_inside": np.where(np.arange(base.size) == 5, np.nan, base),
+        "nan_first": np.where(np.arange(base.size) == 0, np.nan, base),
+        "decreasing": base[::-1].copy(),
+        "one_inversion": np.concatenate([base[:4], [1.5], base[4:]]),
+        "single": np.array([3.25]),
+        "all_left": np.array([-5.0, -4.0]),
+        "all_right": np.array([100.0, 101.0, 102.0]),
+    }
+    keep = _hip.get_tunable("transform_lean")
+    _hip.set_tunable("transform_lean", 3 * lean)
+    try:
+        for name, tg in target_sets.items():
+            tg = tg.astype(dtype)
+            for mask_edges in (True, False):
+                for bypass in (False, True):
+                    want = np.moveaxis(TR.interp_1d_linear(np.moveaxis(phi, 0, -1), np.moveaxis(theta, 0, -1), tg,
+                                                           mask_edges=mask_edges, bypass_checks=bypass), -1, 0)
+                    got = dev.tohost(dev.transform_linear(phi, theta, tg.reshape(-1, 1, 1), 0, mask_edges=mask_edges,
+                                                          bypass_checks=bypass))
+                    np.testing.assert_array_equal(got, want, err_msg=f"{name} mask_edges={mask_edges} bypass={bypass}")
+    finally:
+        _hip.set_tunable("transform_lean", keep)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_linear_transform_output_staging_variants(dtype):
     """(Z, Y, X) layout, random-walk columns: the lanes of a wave emit a target level at different source levels.  Every
     way of getting the outputs to memory -- direct stores, level table in LDS, whole-column tile, ring of 4 / 8 / 16
@@ -539,25 +587,28 @@ def test_linear_transform_output_staging_variants(dtype):
     want = np.moveaxis(TR.interp_1d_linear(np.moveaxis(phi, 0, -1), np.moveaxis(theta, 0, -1), levels, mask_edges=True), -1, 0)
     lv3 = levels.reshape(m, 1, 1)
     per_column = np.ascontiguousarray(np.broadcast_to(lv3, (m, ny, nx)))  # not shared: levels stay in memory
-    keep = {k: _hip.get_tunable(k) for k in ("transform_stage", "transform_ring", "transform_win", "transform_cwin")}
+    keep = {k: _hip.get_tunable(k) for k in ("transform_stage", "transform_ring", "transform_win", "transform_cwin", "transform_lean")}
     try:
-        for stage, ring in ((0, 8), (1, 8), (2, 8), (3, 4), (3, 8), (3, 16), (3, 32)):
+        for stage, ring, lean in ((0, 8, 0), (1, 8, 0), (2, 8, 0), (3, 4, 0), (3, 8, 0), (3, 16, 0), (3, 32, 0),
+                                  (3, 4, 1), (3, 8, 1), (3, 16, 1), (3, 32, 1)):
             _hip.set_tunable("transform_stage", stage)
             _hip.set_tunable("transform_ring", ring)
+            _hip.set_tunable("transform_lean", 3 * lean)
             for tg in (lv3, per_column):
                 got = dev.tohost(dev.transform_linear(phi, theta, tg, 0, mask_edges=True))
-                np.testing.assert_array_equal(got, want, err_msg=f"stage {stage} ring {ring}")
+                np.testing.assert_array_equal(got, want, err_msg=f"stage {stage} ring {ring} lean {lean}")
         # the conservative remap: one accumulator window per wave (4 / 8 / 16 bins, complete rows leave when every lane's
         # cursor has passed them) or per lane (transform_win=2), land columns and columns running backwards in the wave
         theta_o = np.concatenate([theta[:1] - 1.0, theta], axis=0)
         theta_o[:, 1, 30:40] = np.nan  # land
         edges = np.linspace(0.0, 1.1 * float(np.nanmax(theta[:, 0, 0])), m + 1).astype(dtype)
         want_c = np.moveaxis(TR.interp_1d_conservative(np.moveaxis(phi, 0, -1), np.moveaxis(theta_o, 0, -1), edges), -1, 0)
-        for win, cwin in ((2, 16), (1, 4), (1, 8), (1, 16)):
+        for win, cwin, lean in ((2, 16, 0), (1, 4, 0), (1, 8, 0), (1, 16, 0), (1, 4, 3), (1, 8, 3), (1, 16, 3)):
             _hip.set_tunable("transform_win", win)
             _hip.set_tunable("transform_cwin", cwin)
+            _hip.set_tunable("transform_lean", lean)  # bit 1: the lean one-window-per-wave kernel (K9e)
             got = dev.tohost(dev.transform_conservative(phi, theta_o, edges, 0))
-            np.testing.assert_array_equal(got, want_c, err_msg=f"win {win} cwin {cwin}")
+            np.testing.assert_array_equal(got, want_c, err_msg=f"win {win} cwin {cwin} lean {lean}")
     finally:
         for k, v in keep.items():
             _hip.set_tunable(k, v)

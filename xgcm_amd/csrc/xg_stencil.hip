@@ -155,6 +155,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     if (pad_lo) { edge = (i0 == 0); nidx = edge ? ((bc == XG_BC_PERIODIC) ? Li - 1 : 0) : i0 - 1; }
     else { edge = (i0 + NV == Li); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : Li - 1) : i0 + NV; }
     dv a = ntl ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + i0)) : *reinterpret_cast<const dv*>(prow + i0);
+    // (the neighbour stays an 8-B load here: taking it from the next lane's registers by DPP, which pays in the row-wise
+    // kernel K1r, +2.9 points, costs this one 0.4 -- its single load pair per lane leaves nothing to hide the branch behind;
+    // profiles/r03ab_ab_k1dpp.jsonl)
     real n = prow[nidx];
     if (HAS_MI) {
       a = a * ldm<dv>(m_in, mib + (int64_t)i0 * mi.axis, mi.axis);
@@ -1153,12 +1156,12 @@ inline bool metric_vec_ok(const Geo& g, const real* m, const MIdx& mm) {
 // loads -- its row and the row below, which the neighbouring task loaded too (an L2 hit, but a second trip through the
 // address and L1 pipeline for every output).  Here every wave loads ONE row, the upper one of its pair, and receives the
 // lower one from the wave below through LDS; only the lowest wave of a workgroup loads both: 1.25 loads per output row.
-template <int OP, bool NTS>
-__global__ __launch_bounds__(BLOCK) void k_stencil_strided_ys(
+template <int OP, bool NTS, int NW>
+__global__ __launch_bounds__(NW * WAVE) void k_stencil_strided_ys(
     const real* __restrict__ in, real* __restrict__ out, Geo g, int64_t o0, u32 nouter, u32 nblk, FastDiv ntile,
     FastDiv ngrp, int pad_lo, int bc, real fill, const real* __restrict__ halo) {
   typedef dv T;
-  __shared__ T s_row[WPB][WAVE];
+  __shared__ T s_row[NW][WAVE];
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
   if (lb >= nblk) return;  // (whole workgroups)
@@ -1168,7 +1171,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_ys(
   const u32 tile = lb - r * ntile.d;
   const u32 oo = fdiv(r, ngrp);
   if (oo >= nouter) return;
-  const int64_t j = (int64_t)(r - oo * ngrp.d) * WPB + wib;  // this wave's output row
+  const int64_t j = (int64_t)(r - oo * ngrp.d) * NW + wib;  // this wave's output row
   const int64_t o = o0 + oo, inner = g.inner;
   const int64_t x = ((int64_t)tile * WAVE + lane) * NV;
   const bool active = j < g.n_out && x < inner;
@@ -1249,7 +1252,9 @@ int launch_seg_n(const StencilCall& c) {
   }
   if (ZK > 1) return launch_seg_n<OP, V, MET, SEG, 1>(c);  // not z-banded: no shared metric rows
   if (MET == 0 && V == NV && SEG == 1 && !ck.on && tune().seg_ys && c.g.n_out >= 2 * WPB) {  // K2Sy: y-stacked workgroups
-    const u64 ngrp = ((u64)c.g.n_out + WPB - 1) / WPB, per = ngrp * ntile;  // workgroups per outer index
+    // (8 waves per workgroup -- 1.125 loads per output row -- measured slower: 0.789 against 0.802, profiles/r03aa_*)
+    const u64 nw = WPB;
+    const u64 ngrp = ((u64)c.g.n_out + nw - 1) / nw, per = ngrp * ntile;  // workgroups per outer index
     if (per <= MAX_ITEMS) {
       const FastDiv fng = make_fastdiv(ngrp);
       const u64 ostep = MAX_ITEMS / per;
@@ -1257,8 +1262,8 @@ int launch_seg_n(const StencilCall& c) {
         const u32 nouter = (u32)((c.g.outer - o0 < (int64_t)ostep) ? c.g.outer - o0 : (int64_t)ostep);
         const u32 nblk = (u32)((u64)nouter * per);
         const u32 grid = ((nblk + 7) / 8) * 8;
-        if (tune().nt_store) hipLaunchKernelGGL((k_stencil_strided_ys<OP, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fng, c.pad_lo, c.bc, c.fill, c.halo);
-        else hipLaunchKernelGGL((k_stencil_strided_ys<OP, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fng, c.pad_lo, c.bc, c.fill, c.halo);
+        if (tune().nt_store) hipLaunchKernelGGL((k_stencil_strided_ys<OP, true, WPB>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fng, c.pad_lo, c.bc, c.fill, c.halo);
+        else hipLaunchKernelGGL((k_stencil_strided_ys<OP, false, WPB>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, o0, nouter, nblk, fnt, fng, c.pad_lo, c.bc, c.fill, c.halo);
       }
       return 0;
     }

@@ -95,6 +95,20 @@ __global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear
     }
     if (!(STAGE & 5)) __syncthreads();
   }
+  // STAGE & 8 (with the ring and the shared level table): the LEAN streaming loop below.  The targets are the same for
+  // every column, so they are validated ONCE here instead of at every emission (a NaN or decreasing target sends every
+  // column to the exact path), and the table ends in +inf: "the cursor's level lies in this interval" is then one compare,
+  // false for ever once the cursor has run off the end.
+  bool levels_bad = false;
+  if ((STAGE & 8) != 0) {
+    bool bad = false;
+    for (int64_t i = threadIdx.x; i < m; i += TB) {
+      const real v = lds_lev[i];
+      if (v != v || (i > 0 && v < lds_lev[i - 1])) bad = true;
+    }
+    levels_bad = __ballot(bad) != 0;
+    if (threadIdx.x == 0) lds_lev[m] = (real)INFINITY;
+  }
   if (c >= g.outer * g.inner) return;
   const int lane = threadIdx.x & 63;
   const int64_t o = c / inner, x = c - o * inner;
@@ -136,10 +150,74 @@ __global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear
       const bool flip = !bypass_checks && (a1 < a0);
       const real tmin = flip ? a1 : a0, tmax = flip ? a0 : a1;  // == nanmin / nanmax once monotonic
       if (bypass_checks && a1 < a0) exact = true;               // decreasing but not flipped: numpy's path decides
-      int64_t i = 0;
       double xk = (double)(flip ? a1 : a0);
       double fk = (double)pphi[(flip ? n - 1 : 0) * inner];
       const double lval = fk;
+      if constexpr ((STAGE & 8) != 0) {
+        // ---- lean streaming loop: 32-bit cursors, column pointers advanced by a signed per-lane stride (no 64-bit
+        // multiply per load), targets left of the column emitted before the loop, the division skipped where no lane of
+        // the wave emits, and an emission body without branches except numpy's NaN fall-back.  Same operations on the same
+        // operands as the loop below, so the same bits.
+        if (levels_bad) exact = true;
+        const int mm = (int)m, nn = (int)n;
+        int i = 0, fl = 0;
+        real lev = lds_lev[0];
+        const int64_t sT = flip ? -mt.axis : mt.axis, sF = flip ? -inner : inner;
+        const real* pT = pth + (flip ? n - 2 : 1) * mt.axis;  // the column's second level in walking order (n >= 2)
+        const real* pF = pphi + (flip ? n - 2 : 1) * inner;
+        auto emit = [&](double res) {
+          real r = (real)res;
+          if (mask_edges && (lev < tmin || lev > tmax)) r = (real)NAN;
+          if (i < fl + TWIN) tile[(i & (TWIN - 1)) * WAVE + lane] = r;
+          else { pout[(int64_t)i * inner] = r; direct |= 1ull << i; }
+          ++i;
+          lev = lds_lev[i];
+        };
+        if (!exact) {
+          const real x0 = flip ? a1 : a0;
+          while (lev < x0) emit(lval);  // left of the column
+        }
+        constexpr int UT = 8;
+        for (int k0 = 1; k0 < nn && !exact; k0 += UT) {
+          real tvs[UT], fvs[UT];
+#pragma unroll
+          for (int u = 0; u < UT; ++u) {
+            const real tv = *pT;
+            tvs[u] = LOG ? xg_log_store(tv) : tv;
+            fvs[u] = *pF;
+            if (k0 + u + 1 < nn) { pT += sT; pF += sF; }  // (wave-uniform test; the last level is re-read by a short tail)
+          }
+#pragma unroll
+          for (int u = 0; u < UT; ++u) {
+            if (k0 + u >= nn || exact) break;
+            const real tv = tvs[u];
+            const double xk1 = (double)tv, fk1 = (double)fvs[u];
+            if (tv != tv || xk1 < xk) { exact = true; break; }
+            if (__ballot(lev < tv) != 0) {  // some lane emits in this interval
+              const double slope = (fk1 - fk) / (xk1 - xk);
+              const bool flat = (fk == fk1);
+              while (lev < tv) {
+                const double xv = (double)lev;
+                double res = slope * (xv - xk) + fk;
+                if (res != res) {  // numpy's NaN fall-backs (interp_pair)
+                  res = slope * (xv - xk1) + fk1;
+                  if (res != res && flat) res = fk;
+                }
+                if (xv == xk) res = fk;
+                emit(res);
+              }
+            }
+            xk = xk1; fk = fk1;
+            while (fl < mm && __ballot(i <= fl) == 0) {  // rows every streaming lane has emitted leave as complete stores
+              if (!((direct >> fl) & 1)) stg<real, true>(pout + (int64_t)fl * inner, tile[(fl & (TWIN - 1)) * WAVE + lane]);
+              ++fl;
+            }
+          }
+        }
+        while (i < mm && !exact) emit(fk);  // at or right of the column's last point
+        flushed = fl;
+      } else {
+      int64_t i = 0;
       // the cursor's current target level, loaded once per target and validated on load
       real lev = LEV(0);
       if (lev != lev) exact = true;
@@ -206,6 +284,7 @@ __global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear
       }
       // remaining targets are >= xp[n-1]: the last point itself (fp[n-1]) or right of it (rval == fp[n-1])
       while (i < m && !exact) emit_and_advance(fk);
+      }
     }
   }
 
@@ -579,6 +658,125 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_win(
     if (!was_touched(j)) pout[(int64_t)j * inner] = (real)NAN;
 }
 
+// K9e: K9d's one-window-per-wave form (UNI) written for instruction count -- the kernel issues VALU instructions 66 % of
+// its time (profiles/r03z_valu_issue_share.txt), so what it executes per cell is what it costs:
+//   * the cursor walks forward with its two edges in registers (one LDS read per step); the backward search is a rare
+//     separate branch (non-monotonic columns);
+//   * a bin that has left the window was stored as a complete row (NaN where a column never touched it), so an accumulation
+//     behind the window always reads `out` back: the per-bin "touched" bits are kept for accumulations AHEAD of the window
+//     only (cells thicker than the window), not updated in the common path;
+//   * the share of a bin is one expression (a cell of zero thickness selects its value after the division instead of
+//     branching around it); 32-bit bin arithmetic throughout.
+// Per bin the additions still arrive in cell order with the same operands: the same bits as K9b / K9c / K9d / the reference.
+template <int CWIN>
+__global__ __launch_bounds__(CWB) void k_transform_conservative_uni(
+    const real* __restrict__ phi, const real* __restrict__ theta, const real* __restrict__ bins,
+    real* __restrict__ out, Geo g, MIdx mt) {
+  const int64_t inner = g.inner;
+  const int n = (int)g.n_in, m = (int)g.n_out;  // m <= 64 (host)
+  real* sb = reinterpret_cast<real*>(xg_dyn_lds);       // m + 1 edges, padded to an even count
+  real* ring = sb + ((m + 2) & ~1) + threadIdx.x;       // slot s of this lane: ring[s * CWB]
+  for (int j = threadIdx.x; j <= m; j += CWB) sb[j] = bins[j];
+  __syncthreads();
+  const int64_t c = (int64_t)blockIdx.x * CWB + threadIdx.x;
+  if (c >= g.outer * g.inner) return;
+  const int64_t o = c / inner, x = c - o * inner;
+  const real* pphi = phi + (o * n) * inner + x;
+  const real* pth = theta + outer_off(g, mt, o) + inner_off(g, mt, x);
+  real* pout = out + (o * (int64_t)m) * inner + x;
+#pragma unroll
+  for (int s_ = 0; s_ < CWIN; ++s_) ring[s_ * CWB] = (real)NAN;
+  u64 ahead = 0;  // bins beyond the window that received a contribution in `out` directly
+  int wb = 0;     // the wave's window covers bins [wb, wb + CWIN)
+  auto reload = [&](int j) -> real { return __hip_atomic_load(pout + (int64_t)j * inner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  auto direct = [&](int j, real add) {  // outside the window: read-modify-write in `out`
+    real old;
+    if (j < wb) old = reload(j);  // the row left the window: it holds a value or NaN
+    else {
+      old = ((ahead >> j) & 1ull) ? reload(j) : (real)NAN;
+      ahead |= 1ull << j;
+    }
+    pout[(int64_t)j * inner] = (old != old) ? add : old + add;
+  };
+  int jlo = 0;  // cursor: first bin whose upper edge reaches the current cell
+  bool idle = false;
+  real e_lo = sb[0], e_hi = sb[1];
+  real t1 = pth[0];
+  const real* pT = pth + mt.axis;
+  const real* pF = pphi;
+  constexpr int UT = 8;
+  for (int i0 = 0; i0 < n; i0 += UT) {
+    real tts[UT], pps[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      tts[u] = *pT;
+      pps[u] = *pF;
+      if (i0 + u + 1 < n) { pT += mt.axis; pF += inner; }
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      if (i0 + u >= n) break;
+      while (wb < m && __ballot(!idle && jlo <= wb) == 0) {  // bin wb: every live lane's cursor has passed it
+        real* slot = ring + (wb & (CWIN - 1)) * CWB;
+        stg<real, true>(pout + (int64_t)wb * inner, *slot);
+        const int in = wb + CWIN;
+        if (in < m) *slot = ((ahead >> in) & 1ull) ? reload(in) : (real)NAN;
+        ++wb;
+      }
+      const real t2 = tts[u], p = pps[u];
+      const real a1 = t1;
+      t1 = t2;
+      const bool n1 = a1 != a1, n2 = t2 != t2;
+      idle = (n1 && n2) || (p != p);
+      if (idle) continue;
+      real lo_ = (a1 < t2) ? a1 : t2, hi_ = (a1 < t2) ? t2 : a1;  // (a NaN bound: both are the other one)
+      if (n1) { lo_ = t2; hi_ = t2; }
+      if (n2) { lo_ = a1; hi_ = a1; }
+      // first bin whose upper edge reaches the cell: min{j: edge[j+1] >= lo}
+      if (jlo > 0 && e_lo >= lo_) {  // the column turned back
+        int j = jlo;
+        while (j > 0 && sb[j] >= lo_) --j;
+        jlo = j;
+        e_lo = sb[j];
+        e_hi = sb[j + 1];
+      }
+      while (e_hi < lo_ && jlo < m - 1) {
+        ++jlo;
+        e_lo = e_hi;
+        e_hi = sb[jlo + 1];
+      }
+      if (e_hi < lo_ || e_lo > hi_) continue;  // the cell lies above the last bin / below this one: no overlap at all
+      const real width = hi_ - lo_;
+      const bool thin = (hi_ == lo_);
+      real e1 = e_lo, e2 = e_hi;
+      for (int j = jlo;;) {
+        const real hmin = (e1 > lo_) ? e1 : lo_;  // python max(theta_min, theta_hat_1)
+        const real hmax = (e2 < hi_) ? e2 : hi_;  // python min(theta_max, theta_hat_2)
+        real add = ((hmax - hmin) / width) * p;
+        if (thin) add = p;
+        if (j >= wb && j < wb + CWIN) {
+          real* slot = ring + (j & (CWIN - 1)) * CWB;
+          const real old = *slot;
+          *slot = (old != old) ? add : old + add;
+        } else {
+          direct(j, add);
+        }
+        if (++j >= m) break;
+        e1 = e2;
+        if (e1 > hi_) break;  // bin j starts above the cell
+        e2 = sb[j + 1];
+      }
+    }
+  }
+  // what is left of the window leaves as complete rows too; only bins beyond it need their NaN
+  for (int s_ = 0; s_ < CWIN; ++s_) {
+    const int b = wb + s_;
+    if (b < m) stg<real, true>(pout + (int64_t)b * inner, ring[(b & (CWIN - 1)) * CWB]);
+  }
+  for (int j = wb + CWIN; j < m; ++j)
+    if (!((ahead >> j) & 1ull)) pout[(int64_t)j * inner] = (real)NAN;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -617,9 +815,10 @@ int XG_FN(xg_transform_linear)(const real* phi, const real* theta, const int64_t
     const u64 nblocks = ((u64)cols + WAVE - 1) / WAVE;
     if ((rc = check_grid(nblocks))) return rc;
     const int tw = tune().transform_ring <= 4 ? 4 : tune().transform_ring <= 8 ? 8 : tune().transform_ring >= 32 ? 32 : 16;
-    const size_t rl = ((size_t)tw * WAVE + (shared_levels ? (size_t)m : 0)) * sizeof(real);
+    const size_t rl = ((size_t)tw * WAVE + (shared_levels ? (size_t)m + 1 : 0)) * sizeof(real);  // (+1: the lean loop's sentinel)
+    const bool lean = shared_levels && (tune().transform_lean & 1);
 #define XG_T(L, S, TW) hipLaunchKernelGGL((k_transform_linear<L, S, TW>), dim3((u32)nblocks), dim3(WAVE), rl, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast)
-#define XG_TS(L, TW) do { if (shared_levels) XG_T(L, 6, TW); else XG_T(L, 4, TW); } while (0)
+#define XG_TS(L, TW) do { if (lean) XG_T(L, 14, TW); else if (shared_levels) XG_T(L, 6, TW); else XG_T(L, 4, TW); } while (0)
 #define XG_TW(L) do { if (tw == 4) XG_TS(L, 4); else if (tw == 8) XG_TS(L, 8); else if (tw == 32) XG_TS(L, 32); else XG_TS(L, 16); } while (0)
     if (logarithmic) XG_TW(true); else XG_TW(false);
 #undef XG_TW
@@ -662,7 +861,11 @@ int XG_FN(xg_transform_conservative)(const real* phi, const real* theta, const i
     const size_t wlds = ((size_t)((m + 2) & ~(int64_t)1) + (size_t)cw * CWB) * sizeof(real);
     const u64 nblocks = ((u64)cols + CWB - 1) / CWB;
     if ((rc = check_grid(nblocks))) return rc;
-    if (tune().transform_win == 2) hipLaunchKernelGGL((k_transform_conservative_win<false, 16>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+    const bool lean = (tune().transform_lean & 2) != 0 && tune().transform_win != 2;
+    if (lean && cw == 16) hipLaunchKernelGGL((k_transform_conservative_uni<16>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+    else if (lean && cw == 4) hipLaunchKernelGGL((k_transform_conservative_uni<4>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+    else if (lean) hipLaunchKernelGGL((k_transform_conservative_uni<8>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
+    else if (tune().transform_win == 2) hipLaunchKernelGGL((k_transform_conservative_win<false, 16>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
     else if (cw == 16) hipLaunchKernelGGL((k_transform_conservative_win<true, 16>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
     else if (cw == 4) hipLaunchKernelGGL((k_transform_conservative_win<true, 4>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
     else hipLaunchKernelGGL((k_transform_conservative_win<true, 8>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
