@@ -165,11 +165,13 @@ __global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear
         const int64_t sT = flip ? -mt.axis : mt.axis, sF = flip ? -inner : inner;
         const real* pT = pth + (flip ? n - 2 : 1) * mt.axis;  // the column's second level in walking order (n >= 2)
         const real* pF = pphi + (flip ? n - 2 : 1) * inner;
+        const u32 inner32 = (u32)inner;
+        real* pfl = pout;  // row `fl` of this lane's column: a running pointer, no multiply per flushed row
         auto emit = [&](double res) {
           real r = (real)res;
           if (mask_edges && (lev < tmin || lev > tmax)) r = (real)NAN;
           if (i < fl + TWIN) tile[(i & (TWIN - 1)) * WAVE + lane] = r;
-          else { pout[(int64_t)i * inner] = r; direct |= 1ull << i; }
+          else { pout[(u64)((u32)i * inner32)] = r; direct |= 1ull << i; }  // (host: m * inner < 2^32 for this loop)
           ++i;
           lev = lds_lev[i];
         };
@@ -209,8 +211,9 @@ __global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear
             }
             xk = xk1; fk = fk1;
             while (fl < mm && __ballot(i <= fl) == 0) {  // rows every streaming lane has emitted leave as complete stores
-              if (!((direct >> fl) & 1)) stg<real, true>(pout + (int64_t)fl * inner, tile[(fl & (TWIN - 1)) * WAVE + lane]);
+              if (!((direct >> fl) & 1)) stg<real, true>(pfl, tile[(fl & (TWIN - 1)) * WAVE + lane]);
               ++fl;
+              pfl += inner;
             }
           }
         }
@@ -688,15 +691,20 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_uni(
   for (int s_ = 0; s_ < CWIN; ++s_) ring[s_ * CWB] = (real)NAN;
   u64 ahead = 0;  // bins beyond the window that received a contribution in `out` directly
   int wb = 0;     // the wave's window covers bins [wb, wb + CWIN)
-  auto reload = [&](int j) -> real { return __hip_atomic_load(pout + (int64_t)j * inner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  // addresses: the window's first row as a running pointer; a row outside the window through a 32-bit element offset
+  // (host: m * inner < 2^32) formed where it is needed -- no 64-bit multiply in the per-cell path
+  real* pwb = pout;
+  const u32 inner32 = (u32)inner;
+  auto reload_at = [&](const real* q) -> real { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
   auto direct = [&](int j, real add) {  // outside the window: read-modify-write in `out`
+    real* q = pout + (u64)((u32)j * inner32);
     real old;
-    if (j < wb) old = reload(j);  // the row left the window: it holds a value or NaN
+    if (j < wb) old = reload_at(q);  // the row left the window: it holds a value or NaN
     else {
-      old = ((ahead >> j) & 1ull) ? reload(j) : (real)NAN;
+      old = ((ahead >> j) & 1ull) ? reload_at(q) : (real)NAN;
       ahead |= 1ull << j;
     }
-    pout[(int64_t)j * inner] = (old != old) ? add : old + add;
+    *q = (old != old) ? add : old + add;
   };
   int jlo = 0;  // cursor: first bin whose upper edge reaches the current cell
   bool idle = false;
@@ -718,10 +726,11 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_uni(
       if (i0 + u >= n) break;
       while (wb < m && __ballot(!idle && jlo <= wb) == 0) {  // bin wb: every live lane's cursor has passed it
         real* slot = ring + (wb & (CWIN - 1)) * CWB;
-        stg<real, true>(pout + (int64_t)wb * inner, *slot);
+        stg<real, true>(pwb, *slot);
         const int in = wb + CWIN;
-        if (in < m) *slot = ((ahead >> in) & 1ull) ? reload(in) : (real)NAN;
+        if (in < m) *slot = ((ahead >> in) & 1ull) ? reload_at(pwb + (int64_t)CWIN * inner) : (real)NAN;
         ++wb;
+        pwb += inner;
       }
       const real t2 = tts[u], p = pps[u];
       const real a1 = t1;
@@ -771,7 +780,7 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_uni(
   // what is left of the window leaves as complete rows too; only bins beyond it need their NaN
   for (int s_ = 0; s_ < CWIN; ++s_) {
     const int b = wb + s_;
-    if (b < m) stg<real, true>(pout + (int64_t)b * inner, ring[(b & (CWIN - 1)) * CWB]);
+    if (b < m) stg<real, true>(pwb + (int64_t)s_ * inner, ring[(b & (CWIN - 1)) * CWB]);
   }
   for (int j = wb + CWIN; j < m; ++j)
     if (!((ahead >> j) & 1ull)) pout[(int64_t)j * inner] = (real)NAN;
@@ -816,7 +825,7 @@ int XG_FN(xg_transform_linear)(const real* phi, const real* theta, const int64_t
     if ((rc = check_grid(nblocks))) return rc;
     const int tw = tune().transform_ring <= 4 ? 4 : tune().transform_ring <= 8 ? 8 : tune().transform_ring >= 32 ? 32 : 16;
     const size_t rl = ((size_t)tw * WAVE + (shared_levels ? (size_t)m + 1 : 0)) * sizeof(real);  // (+1: the lean loop's sentinel)
-    const bool lean = shared_levels && (tune().transform_lean & 1);
+    const bool lean = shared_levels && (tune().transform_lean & 1) && (u64)m * (u64)g.inner < (1ull << 32);
 #define XG_T(L, S, TW) hipLaunchKernelGGL((k_transform_linear<L, S, TW>), dim3((u32)nblocks), dim3(WAVE), rl, st, phi, theta, target, out, g, mt, mg, mask_edges, bypass_checks, fast)
 #define XG_TS(L, TW) do { if (lean) XG_T(L, 14, TW); else if (shared_levels) XG_T(L, 6, TW); else XG_T(L, 4, TW); } while (0)
 #define XG_TW(L) do { if (tw == 4) XG_TS(L, 4); else if (tw == 8) XG_TS(L, 8); else if (tw == 32) XG_TS(L, 32); else XG_TS(L, 16); } while (0)
@@ -861,7 +870,7 @@ int XG_FN(xg_transform_conservative)(const real* phi, const real* theta, const i
     const size_t wlds = ((size_t)((m + 2) & ~(int64_t)1) + (size_t)cw * CWB) * sizeof(real);
     const u64 nblocks = ((u64)cols + CWB - 1) / CWB;
     if ((rc = check_grid(nblocks))) return rc;
-    const bool lean = (tune().transform_lean & 2) != 0 && tune().transform_win != 2;
+    const bool lean = (tune().transform_lean & 2) != 0 && tune().transform_win != 2 && (u64)m * (u64)g.inner < (1ull << 32);
     if (lean && cw == 16) hipLaunchKernelGGL((k_transform_conservative_uni<16>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
     else if (lean && cw == 4) hipLaunchKernelGGL((k_transform_conservative_uni<4>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
     else if (lean) hipLaunchKernelGGL((k_transform_conservative_uni<8>), dim3((u32)nblocks), dim3(CWB), wlds, (hipStream_t)stream, phi, theta, bins, out, g, mt);
