@@ -167,9 +167,11 @@ __global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear
         const real* pF = pphi + (flip ? n - 2 : 1) * inner;
         const u32 inner32 = (u32)inner;
         real* pfl = pout;  // row `fl` of this lane's column: a running pointer, no multiply per flushed row
-        auto emit = [&](double res) {
-          real r = (real)res;
-          if (mask_edges && (lev < tmin || lev > tmax)) r = (real)NAN;
+        // (occupancy hints, amdgpu_waves_per_eu 6 / 7 against the 5 waves its 84 VGPRs allow: +-0.3 / -2 points,
+        // profiles/r03ad_ab_linear_occupancy.jsonl -- the loop is no longer bound by what it issues)
+        // (edge masking needs no test inside the column: the cursor's level is >= the column's first point after the
+        // prologue and < its current point in the loop; only targets left / right of the column can be masked)
+        auto emit = [&](real r) {
           if (i < fl + TWIN) tile[(i & (TWIN - 1)) * WAVE + lane] = r;
           else { pout[(u64)((u32)i * inner32)] = r; direct |= 1ull << i; }  // (host: m * inner < 2^32 for this loop)
           ++i;
@@ -177,7 +179,8 @@ __global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear
         };
         if (!exact) {
           const real x0 = flip ? a1 : a0;
-          while (lev < x0) emit(lval);  // left of the column
+          const real left = mask_edges ? (real)NAN : (real)lval;
+          while (lev < x0) emit(left);  // left of the column (x0 == tmin)
         }
         constexpr int UT = 8;
         for (int k0 = 1; k0 < nn && !exact; k0 += UT) {
@@ -201,12 +204,14 @@ __global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear
               while (lev < tv) {
                 const double xv = (double)lev;
                 double res = slope * (xv - xk) + fk;
-                if (res != res) {  // numpy's NaN fall-backs (interp_pair)
-                  res = slope * (xv - xk1) + fk1;
-                  if (res != res && flat) res = fk;
+                if (__ballot(res != res) != 0) {  // numpy's NaN fall-backs (interp_pair): a wave-uniform branch, rarely taken
+                  if (res != res) {
+                    res = slope * (xv - xk1) + fk1;
+                    if (res != res && flat) res = fk;
+                  }
                 }
                 if (xv == xk) res = fk;
-                emit(res);
+                emit((real)res);
               }
             }
             xk = xk1; fk = fk1;
@@ -217,7 +222,7 @@ __global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear
             }
           }
         }
-        while (i < mm && !exact) emit(fk);  // at or right of the column's last point
+        while (i < mm && !exact) emit((mask_edges && lev > tmax) ? (real)NAN : (real)fk);  // at or right of the column's last point
         flushed = fl;
       } else {
       int64_t i = 0;
