@@ -89,6 +89,36 @@ def test_stencil_metric_weighted_bitwise(dev, shape, op):
                 _eq(got, exp)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("ys", [0, 12, 14, 18, 22])
+def test_strided_metric_stencil_y_stacked_workgroups(dev, dtype, ys):
+    """K2Sm: `derivative` / `metric_weighted` along Y of (Z, Y, X) with metrics shared by the levels -- the 4 waves of a
+    workgroup are 4 consecutive segments of one x-tile and hand their top row (already multiplied by its metric, or
+    replaced by the fill value) to the wave above through LDS.  Every task shape, row counts that are not a multiple of the
+    workgroup's rows, level counts that are not a multiple of the levels per wave, ragged x-tiles, every pad and boundary
+    condition -- the oracle's bits, as with K2S (ys = 0)."""
+    from xgcm_amd import _hip
+    keep = {k: _hip.get_tunable(k) for k in ("met_ys1", "met_ys2")}
+    _hip.set_tunable("met_ys1", ys)
+    _hip.set_tunable("met_ys2", ys)
+    try:
+        for shape in ((5, 37, 130), (3, 64, 128), (9, 33, 66), (2, 8, 256), (7, 9, 64)):
+            a = _field(shape, 41).astype(dtype)
+            for (lo, hi), bc in itertools.product([(1, 0), (0, 1), (1, 1), (0, 0)], BCS):
+                n_out = shape[1] + lo + hi - 1
+                oshape = (shape[0], n_out, shape[2])
+                for keep_dims in ({1, 2}, {1}):
+                    m_in = _metric_for(shape, keep_dims, 43).astype(dtype)
+                    m_out = _metric_for(oshape, keep_dims, 44).astype(dtype)
+                    for op in ("diff", "interp"):
+                        for kw in ({"m_out": m_out}, {"m_in": m_in, "m_out": m_out}, {"m_in": m_in}):
+                            exp = R.stencil1d(op, a, 1, lo, hi, bc, 0.75, **kw)
+                            _eq(dev.tohost(dev.stencil1d(op, a, 1, lo, hi, bc, 0.75, **kw)), exp)
+    finally:
+        for k, v in keep.items():
+            _hip.set_tunable(k, v)
+
+
 @pytest.mark.parametrize("shape", [(6, 10, 128), (3, 7, 33), (2, 5, 4, 66), (300,), (3, 700), (2, 2050), (3, 1024), (9, 4100)])
 def test_cumsum_all(dev, shape):
     a = _field(shape, 7, nan=True)

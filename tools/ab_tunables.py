@@ -43,6 +43,8 @@ def main():
         "dX": (lambda: D.stencil1d("diff", T, 2, 1, 0, "periodic", m_out=dx), 16 + 8 / nz),
         "dY": (lambda: D.stencil1d("diff", T, 1, 1, 0, "extend", m_out=dx), 16 + 8 / nz),
         "dZ": (lambda: D.stencil1d("diff", T, 0, 1, 0, "fill", m_out=dz), 16),
+        "diffZ": (lambda: D.stencil1d("diff", T, 0, 1, 0, "extend"), 16),
+        "dY3": (lambda: D.stencil1d("diff", T, 1, 1, 0, "extend", m_out=T2), 24),
         "padX": (lambda: D.pad_nd(T, {2: (1, 1)}, {2: "periodic"}, {}), 16),
         "padYX": (lambda: D.pad_nd(T, {1: (0, 1), 2: (2, 0)}, {1: "extend", 2: "fill"}, {2: 1.5}), 16),
         "padYZ": (lambda: D.pad_nd(T, {1: (1, 1), 0: (1, 0)}, {1: "extend", 0: "fill"}, {0: 0.0}), 16),
@@ -79,7 +81,7 @@ def main():
         "flux": (lambda: D.flux(U, V, T, "periodic", "extend"), 40),
     }
     cases = a.cases.split(",")
-    T2 = D.synthetic((nz, ny, nx), 9) if "mulTT" in cases else None
+    T2 = D.synthetic((nz, ny, nx), 9, 0, 1000.0, 1000.0) if ("mulTT" in cases or "dY3" in cases) else None
     dy1 = D.synthetic((1, ny, 1), 35, 0, 1000.0, 1000.0)
     T3 = D.synthetic((nz, ny, nx), 10, 0, 1000.0, 1000.0) if "sumYw3" in cases else None
     if any(c.startswith("t") and c[1:4] in ("lin", "con") for c in cases):

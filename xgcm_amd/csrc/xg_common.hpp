@@ -137,6 +137,7 @@ struct Tune {
   int scan_chain_w;   // K5c: levels' worth of columns that advance side by side inside one XCD band
   int scan_chain_tmaj; // chained kernels with a metric shared by the outer indices: columns numbered x-tile-major, a sub-band = all levels of a few x-tiles
   int scan_chain_spin; // polls of a hand-off slot before a chunk gives up (the launch is then redone by the march, in stream)
+  int met_ys1, met_ys2; // K2Sm: strided-axis metric stencils with y-stacked workgroups, 10 * rows + levels per wave (one / two metrics; 0: K2S)
   int transform_lean; // linear transform, ring + shared level table: the lean streaming loop (targets validated once, 32-bit cursors, pointer-stepped columns)
   int reduce_ldsw;    // K4L: long weighted reductions with level-shared weights as a march whose weight rows go through LDS once per workgroup (0: chained K4cz)
   int reduce_zl;      // K4cz: outer indices per task of the chained weighted reduction sharing the weight rows (1 / 2 / 4)

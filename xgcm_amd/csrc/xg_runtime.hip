@@ -57,6 +57,8 @@ const TuneEntry TUNABLES[] = {
     {"scan_chain_spin", &Tune::scan_chain_spin, 1 << 22},
     {"scan_chain_tmaj", &Tune::scan_chain_tmaj, 0},  // minimal traffic (1.01x) but 10-27 % slower: profiles/r03o_*
     {"reduce_zl", &Tune::reduce_zl, 2},
+    {"met_ys1", &Tune::met_ys1, 12},
+    {"met_ys2", &Tune::met_ys2, 0},
     {"transform_lean", &Tune::transform_lean, 3},
     {"reduce_ldsw", &Tune::reduce_ldsw, 1},
     {"dbg", &Tune::dbg, 0},

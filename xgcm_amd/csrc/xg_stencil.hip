@@ -1204,6 +1204,158 @@ __global__ __launch_bounds__(NW * WAVE) void k_stencil_strided_ys(
   stg<T, NTS>(out + (o * g.n_out + j) * inner + x, op2<OP>(a, b));
 }
 
+// K2Sm: K2S WITH metrics, z-banded and z-shared, Y-STACKED (DESIGN rule 14): the WPB waves of a workgroup are WPB consecutive
+// SEG-row segments of one x-tile and one group of ZK levels.  A wave loads only the SEG upper rows of its SEG + 1 (and their
+// input-metric rows); the lowest one -- already multiplied by its metric, or replaced by the fill value -- comes from the
+// wave below through LDS: the very product that wave formed for its own top row, so the same bits.  Only the lowest wave of a
+// workgroup loads its row 0 itself.
+template <int OP, int MET, int SEG, int ZK>
+__global__ __launch_bounds__(BLOCK) void k_stencil_strided_ysm(
+    const real* __restrict__ in, real* __restrict__ out, Geo g, u32 nouter, u32 nblk, FastDiv ntile, u32 nseg, ZBand zb,
+    int pad_lo, int bc, real fill, const real* __restrict__ halo, const real* __restrict__ m_in, MIdx mi,
+    const real* __restrict__ m_out, MIdx mo, int mal) {
+  typedef dv T;
+  constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
+  __shared__ T s_p[WPB][ZK][WAVE];
+  auto ldmv = [&](const real* m, int64_t off, int64_t step) -> T {
+    if (mal & 1) return *reinterpret_cast<const T*>(m + off);
+    return ldm<T>(m, off, step);
+  };
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;  // (whole workgroups)
+  const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const u32 r = fdiv(lb, ntile);
+  const u32 tile = lb - r * ntile.d;
+  u32 oo, ssg;
+  if (!zband_map(zb, r, oo, ssg)) return;  // band-major order over (band of super-segments, level group, super-segment)
+  oo *= ZK;
+  const u32 sg = ssg * WPB + wib;
+  const int64_t o = oo;
+  const int nk = ((int64_t)nouter - (int64_t)oo < ZK) ? (int)(nouter - oo) : ZK;  // levels this group really has
+  const int64_t inner = g.inner;
+  const int64_t x = ((int64_t)tile * WAVE + lane) * NV;
+  const bool active = sg < nseg && x < inner;
+  const int64_t j0 = (int64_t)sg * SEG;
+  const int64_t nrow = (g.n_out - j0 < SEG) ? g.n_out - j0 : SEG;  // rows this segment really has (<= 0: none)
+  T p[ZK][SEG + 1];
+  T dm[SEG];
+  if (active) {
+    int64_t mib = 0, mob = 0, mis = 0, mos = 0;
+    const bool ui = HAS_MI && (mal & 2), uo = HAS_MO && (mal & 4);  // row-uniform metrics: scalar loads
+    int64_t mibu = 0, mobu = 0;
+    if (HAS_MI) {
+      if (ui) mibu = outer_off32(g, mi, (u32)o);
+      else {
+        inner_off_step32(g, mi, (u32)x, true, mib, mis);
+        mib += outer_off32(g, mi, (u32)o);
+      }
+    }
+    if (HAS_MO) {
+      if (uo) mobu = outer_off32(g, mo, (u32)o) + j0 * mo.axis;
+      else {
+        inner_off_step32(g, mo, (u32)x, true, mob, mos);
+        mob += outer_off32(g, mo, (u32)o) + j0 * mo.axis;
+      }
+    }
+    // padded index k = j0 + u  ->  input row q (wave-uniform), fill flag, pre-gathered halo row
+    bool ff[SEG + 1], hh[SEG + 1];
+    int64_t qq[SEG + 1];
+#pragma unroll
+    for (int u = 0; u <= SEG; ++u) {
+      int64_t k = j0 + ((u <= nrow) ? u : nrow);  // clamp inside the padded range for short tails
+      int64_t q = k - pad_lo;
+      ff[u] = false;
+      hh[u] = false;
+      if (q < 0 || q >= g.n_in) {
+        ff[u] = (bc == XG_BC_FILL);
+        if (bc == XG_BC_HALO) { hh[u] = true; q = (q < 0) ? 0 : pad_lo; }
+        else q = (q < 0) ? ((bc == XG_BC_PERIODIC) ? g.n_in - 1 : 0) : ((bc == XG_BC_PERIODIC) ? 0 : g.n_in - 1);
+      }
+      qq[u] = q;
+    }
+    const int ulo = (wib == 0) ? 0 : 1;  // the lowest wave of the workgroup loads its row 0 itself
+    T v[ZK][SEG + 1], wm[SEG + 1];
+#pragma unroll
+    for (int kz = 0; kz < ZK; ++kz) {
+      const int64_t ok = o + ((kz < nk) ? kz : nk - 1);  // a short last group repeats its last level (not stored)
+      const real* pin = in + (ok * g.n_in) * inner + x;
+      const real* phalo = halo + (ok * (g.n_out - g.n_in + 1)) * inner + x;
+#pragma unroll
+      for (int u = 0; u <= SEG; ++u)
+        if (u >= ulo) v[kz][u] = *reinterpret_cast<const T*>((hh[u] ? phalo : pin) + qq[u] * inner);
+    }
+    if (HAS_MI) {
+#pragma unroll
+      for (int u = 0; u <= SEG; ++u)
+        if (u >= ulo) wm[u] = ui ? splat<T>(m_in[mibu + qq[u] * mi.axis]) : ldmv(m_in, mib + qq[u] * mi.axis, mis);
+    }
+    if (HAS_MO) {
+#pragma unroll
+      for (int u = 0; u < SEG; ++u) dm[u] = uo ? splat<T>(m_out[mobu + ((u < nrow) ? u : 0) * mo.axis]) : ldmv(m_out, mob + ((u < nrow) ? u : 0) * mo.axis, mos);
+    }
+#pragma unroll
+    for (int kz = 0; kz < ZK; ++kz) {
+#pragma unroll
+      for (int u = 0; u <= SEG; ++u) {
+        if (u >= ulo) {
+          T t = v[kz][u];
+          if (HAS_MI) t = t * wm[u];
+          p[kz][u] = ff[u] ? splat<T>(fill) : t;
+        }
+      }
+      s_p[wib][kz][lane] = p[kz][SEG];  // my top row = the row 0 of the wave above
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+#pragma unroll
+  for (int kz = 0; kz < ZK; ++kz) {
+    if (kz >= nk) break;
+    if (wib > 0) p[kz][0] = s_p[wib - 1][kz][lane];  // (the wave below is active: its segment index is smaller)
+    real* pout = out + ((o + kz) * g.n_out + j0) * inner + x;
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+      if (u < nrow) {
+        T res = op2<OP>(p[kz][u], p[kz][u + 1]);
+        if (HAS_MO) res = res / dm[u];
+        stg<T, true>(pout + u * inner, res);
+      }
+    }
+  }
+}
+
+// K2Sm launch: the geometry tests are launch_seg_n's (z-banding, one outer dim, metrics broadcast along it, 16-B lane vectors)
+template <int OP, int MET, int SEG, int ZK>
+bool launch_ysm(const StencilCall& c) {
+  const u64 ntile = (u64)((c.g.inner + (int64_t)WAVE * NV - 1) / ((int64_t)WAVE * NV));
+  const u64 nseg = (u64)((c.g.n_out + SEG - 1) / SEG);
+  if (nseg < 2 * WPB || nseg > 0x7fffffffull) return false;
+  const u64 nsseg = (nseg + WPB - 1) / WPB;  // super-segments: WPB segments, one workgroup per x-tile and level group
+  int mal = (metric_vec_ok(c.g, c.m_in, c.mi) && metric_vec_ok(c.g, c.m_out, c.mo)) ? 1 : 0;
+  auto row_uniform = [&](const real* m, const MIdx& mm) {
+    if (!m) return false;
+    for (int d = 0; d < c.g.n_inner; ++d)
+      if (mm.inner[d] != 0) return false;
+    return true;
+  };
+  if (tune().met_scalar) mal |= (row_uniform(c.m_in, c.mi) ? 2 : 0) | (row_uniform(c.m_out, c.mo) ? 4 : 0);
+  const u32 zb_base = (u32)(tune().zb_rows > 1 ? tune().zb_rows : 16);
+  const u32 zbr = (c.m_in && c.m_out) ? zb_base / 2 : zb_base;
+  const u32 per = (u32)(SEG * WPB);
+  const u32 ZB_SS = (zbr + per - 1) / per;  // band height in super-segments (at least one)
+  const u64 padded = ((nsseg + ZB_SS - 1) / ZB_SS) * ZB_SS;
+  const u64 zgroups = ((u64)c.g.outer + ZK - 1) / ZK;
+  const u64 nwg = padded * zgroups * ntile;
+  ZBand zb = make_zband(true, zgroups, nsseg, ZB_SS);
+  if (!zb.on || nwg > MAX_ITEMS) return false;
+  const u32 nblk = (u32)nwg;
+  const u32 grid = ((nblk + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_stencil_strided_ysm<OP, MET, SEG, ZK>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (u32)c.g.outer, nblk, make_fastdiv(ntile), (u32)nseg, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
+  return true;
+}
+
 template <int OP, int V, int MET, int SEG, int ZK = 1>
 int launch_seg_n(const StencilCall& c) {
   const u64 ntile = (u64)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
@@ -1251,6 +1403,9 @@ int launch_seg_n(const StencilCall& c) {
     }
   }
   if (ZK > 1) return launch_seg_n<OP, V, MET, SEG, 1>(c);  // not z-banded: no shared metric rows
+  // (K2Sy extended to metrics that are not z-banded and to whole-plane rows in column chunks, measured in one process:
+  // 3-D divisor along Y +0.6 points, plain diff along Z 0.768 -> 0.740, derivative Z 0.749 -> 0.657, metric_weighted Z
+  // 0.739 -> 0.612 -- four levels per workgroup make five plane streams per XCD; not kept, profiles/r03ah_ab_ys_ext.jsonl)
   if (MET == 0 && V == NV && SEG == 1 && !ck.on && tune().seg_ys && c.g.n_out >= 2 * WPB) {  // K2Sy: y-stacked workgroups
     // (8 waves per workgroup -- 1.125 loads per output row -- measured slower: 0.789 against 0.802, profiles/r03aa_*)
     const u64 nw = WPB;
@@ -1288,6 +1443,24 @@ int launch_seg(const StencilCall& c) {
     // box: derivative Y 66.4 -> 69.5 % / 73.5 -> 74.3 %; with two metrics 4 stays ahead: 66.5 against 64.6 %)
     // rows per wave-task: 4 with two metrics (metric_weighted Y 71.7 -> 73.5 % / 72.4 -> 73.9 % on two boxes), 2 with one
     const int ms = (MET == 3 ? tune().met_seg : tune().met_seg1), zk = tune().nt_store ? (MET == 3 ? tune().met_zk : tune().met_zk1) : 1;
+    // K2Sm (y-stacked workgroups) where launch_seg_n would z-band: `met_ys1` / `met_ys2` = 10 * rows + levels per wave.
+    // One metric (derivative Y): 1 row x 2 levels 0.733 -> 0.750 in one process, every other shape +0.7..0.9; two metrics
+    // (metric_weighted Y): 1 x 8 within +-1 point of K2S, everything else behind it => off by default
+    const int ys = (MET == 3) ? tune().met_ys2 : tune().met_ys1;
+    const u64 ntile_ = (u64)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
+    if (ys && tune().nt_store && tune().zband && c.g.n_outer == 1 && ntile_ <= (u64)tune().seg_max_tiles &&
+        (!c.m_in || c.mi.outer[0] == 0) && (!c.m_out || c.mo.outer[0] == 0)) {
+      bool done = false;
+      switch (ys) {
+        case 12: done = launch_ysm<OP, MET, 1, 2>(c); break;
+        case 14: done = launch_ysm<OP, MET, 1, 4>(c); break;
+        case 18: done = launch_ysm<OP, MET, 1, 8>(c); break;
+        case 22: done = launch_ysm<OP, MET, 2, 2>(c); break;
+        // (2 x 4, 2 x 8, 4 x 2, 4 x 4 measured too: no better than K2S, profiles/r03af_*, r03ag_*)
+        default: break;
+      }
+      if (done) return 0;
+    }
     if (zk >= 8 && ms >= 2) return launch_seg_n<OP, V, MET, 2, 8>(c);
     if (zk >= 4) {
       if (ms >= 4) return launch_seg_n<OP, V, MET, 4, 4>(c);
