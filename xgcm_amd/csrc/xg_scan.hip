@@ -1246,11 +1246,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
     lead = (NV - (int64_t)((row * (u64)n) % NV)) % NV;
     dv a = splat<dv>(real(0)), ad = splat<dv>(real(0));
     const int64_t nvec = (n - lead) / NV;
-    for (int64_t t = lane; t < nvec; t += WAVE) {
-      const int64_t k = lead + t * NV;
-      dv v = ntl ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + k)) : *reinterpret_cast<const dv*>(prow + k);
-      dv wv = splat<dv>(real(1));
-      if (HAS_W) wv = ldm<dv>(wgt, mb + k * mw.axis, mw.axis);
+    auto ldv = [&](int64_t k) -> dv {
+      return (ntl & 1) ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + k)) : *reinterpret_cast<const dv*>(prow + k);
+    };
+    auto add = [&](const dv& v, const dv& wv) {
 #pragma unroll
       for (int c = 0; c < NV; ++c) {
         real num, dn = real(0);
@@ -1258,6 +1257,28 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
         a[c] += num;
         ad[c] += dn;
       }
+    };
+    int64_t t = lane;
+    if (ntl & 2) {  // RU independent loads (and weight loads) before the first addition; the additions keep their order
+      constexpr int RU = 4;
+      for (; t + (RU - 1) * WAVE < nvec; t += RU * WAVE) {
+        dv v[RU], wv[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const int64_t k = lead + (t + u * WAVE) * NV;
+          v[u] = ldv(k);
+          wv[u] = HAS_W ? ldm<dv>(wgt, mb + k * mw.axis, mw.axis) : splat<dv>(real(1));
+        }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) add(v[u], wv[u]);
+      }
+    }
+    for (; t < nvec; t += WAVE) {
+      const int64_t k = lead + t * NV;
+      const dv v = ldv(k);
+      dv wv = splat<dv>(real(1));
+      if (HAS_W) wv = ldm<dv>(wgt, mb + k * mw.axis, mw.axis);
+      add(v, wv);
     }
 #pragma unroll
     for (int c = 0; c < NV; ++c) { acc += a[c]; den += ad[c]; }
@@ -1517,11 +1538,11 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     if ((rc = check_grid(nblocks))) return rc;
     const bool vec = aligned16(in) && g.n_in >= 4 * NV;  // rows of any length: lead / tail cells go through scalar loads
     if (vec) {
-      if (w) hipLaunchKernelGGL((k_reduce_contig<true, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load, zb);
-      else hipLaunchKernelGGL((k_reduce_contig<false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load, zb);
+      if (w) hipLaunchKernelGGL((k_reduce_contig<true, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, (tune().nt_load ? 1 : 0) | (tune().reduce_ru ? 2 : 0), zb);
+      else hipLaunchKernelGGL((k_reduce_contig<false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, (tune().nt_load ? 1 : 0) | (tune().reduce_ru ? 2 : 0), zb);
     } else {
-      if (w) hipLaunchKernelGGL((k_reduce_contig<true, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load, zb);
-      else hipLaunchKernelGGL((k_reduce_contig<false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, tune().nt_load, zb);
+      if (w) hipLaunchKernelGGL((k_reduce_contig<true, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, (tune().nt_load ? 1 : 0) | (tune().reduce_ru ? 2 : 0), zb);
+      else hipLaunchKernelGGL((k_reduce_contig<false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, (tune().nt_load ? 1 : 0) | (tune().reduce_ru ? 2 : 0), zb);
     }
   } else {
     int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, w != nullptr)) ? NV : 1;

@@ -20,6 +20,8 @@ struct BinGeo {
   int64_t total;  // number of V-wide items
   int64_t shape[XG_MAX_NDIM];  // shape[ndim-1] counts V-wide items
   int64_t sa[XG_MAX_NDIM], sb[XG_MAX_NDIM];
+  int idx32;                 // total < 2^32: the item index is peeled with multiply-shift divisions (FastDiv)
+  FastDiv fs[XG_MAX_NDIM];   // divisors shape[d]
 };
 
 template <int BOP> __device__ __forceinline__ real bin2(real a, real b) {
@@ -49,17 +51,33 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, co
     gid = (int64_t)z * zb.Y + pin;
   }
   if (gid >= g.total) return;
-  int64_t r = gid, oa = 0, ob = 0;
+  int64_t oa = 0, ob = 0;
+  if (g.idx32) {  // (a 64-bit division per dim and thread cost this kernel 5 points: 0.74 -> 0.79 for da / dx(Y,X))
+    u32 r = (u32)gid;
 #pragma unroll
-  for (int d = XG_MAX_NDIM - 1; d >= 0; --d) {
-    if (d < g.ndim) {
-      int64_t s = g.shape[d];
-      int64_t q = r / s;
-      int64_t c = r - q * s;
-      if (d == g.ndim - 1) c *= V;
-      oa += c * g.sa[d];
-      ob += c * g.sb[d];
-      r = q;
+    for (int d = XG_MAX_NDIM - 1; d >= 0; --d) {
+      if (d < g.ndim) {
+        const u32 q = (d == 0) ? 0u : fdiv(r, g.fs[d]);  // (the slowest dim needs no division: r < shape[0] there)
+        int64_t c = (int64_t)(r - q * g.fs[d].d);
+        if (d == g.ndim - 1) c *= V;
+        oa += c * g.sa[d];
+        ob += c * g.sb[d];
+        r = q;
+      }
+    }
+  } else {
+    int64_t r = gid;
+#pragma unroll
+    for (int d = XG_MAX_NDIM - 1; d >= 0; --d) {
+      if (d < g.ndim) {
+        int64_t s = g.shape[d];
+        int64_t q = r / s;
+        int64_t c = r - q * s;
+        if (d == g.ndim - 1) c *= V;
+        oa += c * g.sa[d];
+        ob += c * g.sb[d];
+        r = q;
+      }
     }
   }
   const int64_t sa_in = g.sa[g.ndim - 1], sb_in = g.sb[g.ndim - 1];
@@ -439,6 +457,8 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
   const int V = v2 ? NV : 1;
   g.shape[n - 1] = last / V;
   g.total = total / V;
+  g.idx32 = (tune().bin_idx32 && (u64)g.total < 0xffffffffull) ? 1 : 0;
+  for (int d = 0; d < XG_MAX_NDIM; ++d) g.fs[d] = make_fastdiv(d < n ? (u64)g.shape[d] : 1);
   u64 nitems = (u64)g.total;
   ZBand zb = make_zband(false, 0, 0, 1);
   if (tune().zband && n == 2 && (g.sa[0] == 0) != (g.sb[0] == 0) && g.shape[0] >= 2) {
