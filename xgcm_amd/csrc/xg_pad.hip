@@ -157,6 +157,9 @@ __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in,
       if (!fill_after && !fill_before && q0 >= 0 && q0 + NV <= Li) {
         // the group's sources lie inside the row (all but the groups touching a halo): no per-element
         // wrap / clamp / fill logic, NV consecutive narrow loads served by L1
+        // (one aligned 16-B load per lane + the next vector's cells from the neighbouring lane by DPP, rule 12, measured:
+        // padX 0.644 -> 0.566; rows whose sources ARE aligned gain nothing either, 0.673 -> 0.677 -- the loads are not what
+        // bounds this kernel; profiles/r03ak_ab_pad_dpp.jsonl)
         const real* s = in + src + q0;
 #pragma unroll
         for (int k = 0; k < NV; ++k) val[k] = s[k];
