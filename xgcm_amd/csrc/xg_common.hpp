@@ -139,6 +139,7 @@ struct Tune {
   int scan_chain_spin; // polls of a hand-off slot before a chunk gives up (the launch is then redone by the march, in stream)
   int met_ys1, met_ys2; // K2Sm: strided-axis metric stencils with y-stacked workgroups, 10 * rows + levels per wave (one / two metrics; 0: K2S)
   int transform_lean; // linear transform, ring + shared level table: the lean streaming loop (targets validated once, 32-bit cursors, pointer-stepped columns)
+  int pad_tpw;        // row-wise pad: consecutive 64-lane tiles of a row per wave-task (the row logic is paid once per task)
   int bin_idx32;      // elementwise binary op: index decomposition with 32-bit multiply-shift divisions (0: 64-bit divisions)
   int reduce_ru;      // contiguous-axis reductions: 4 independent 16-B loads per lane before the first addition
   int reduce_ldsw;    // K4L: long weighted reductions with level-shared weights as a march whose weight rows go through LDS once per workgroup (0: chained K4cz)

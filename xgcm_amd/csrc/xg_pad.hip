@@ -72,7 +72,7 @@ __global__ __launch_bounds__(BLOCK) void k_pad(const real* __restrict__ in, real
 // resolves the innermost coordinate.  The walk order of the reference's chain is kept by splitting
 // the outer steps into those applied after the innermost dim (they win) and those applied before.
 // V == NV when the innermost dim is not padded: rows are straight 16-B copies or fills.
-template <int V, bool INNER>
+template <int V, bool INNER, int TPW>
 __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in, real* __restrict__ out, PadGeo p,
                                                     u32 nrows, FastDiv ntile, int nt) {
   typedef typename VecT<V>::type T;
@@ -84,9 +84,12 @@ __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in,
     lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
   }
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
+  // ntile = wave-tasks per row; a wave-task = TPW consecutive 64-lane tiles of one row (unrolled: their loads overlap): the row
+  // logic below is a few hundred scalar instructions, more than a 1-KB tile's share of the HBM time (DESIGN rule 15)
   const u32 r = fdiv(w, ntile);
   if (r >= nrows) return;
-  const u32 tile = w - r * ntile.d;
+  constexpr u32 tpw = TPW;
+  const u32 tile0 = (w - r * ntile.d) * tpw;
   const int nd = p.ndim;
   const int t_in = p.mem_step[nd - 1];  // application step of the innermost memory dim
   // peel the row index over the outer memory dims (innermost of them first)
@@ -132,9 +135,11 @@ __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in,
     return fill_before ? fv_before : in[src + q];
   };
   real* drow = out + (int64_t)r * Lo;
+#pragma unroll
+  for (u32 tile = tile0; tile < tile0 + tpw; ++tile) {
   if (V > 1 && !INNER) {  // aligned rows, innermost dim not padded: straight vector copies or fills
     const int64_t x = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
-    if (x >= Lo) return;
+    if (x >= Lo) break;
     T val;
     if (fill_after) val = splat<T>(fv_after);
     else if (fill_before) val = splat<T>(fv_before);
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in,
     if (tile == 0 && lane == 0)
       for (int64_t xx = 0; xx < lead && xx < Lo; ++xx) drow[xx] = elem(xx);
     const int64_t x = lead + ((int64_t)tile * WAVE + lane) * NV;
-    if (x >= Lo) return;
+    if (x >= Lo) break;
     if (x + NV <= Lo) {
       dv val;
       const int64_t q0 = x - p.lo[t_in];
@@ -174,8 +179,9 @@ __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in,
     }
   } else {
     const int64_t x = (int64_t)tile * WAVE + (threadIdx.x & 63);
-    if (x >= Lo) return;
+    if (x >= Lo) break;
     drow[x] = elem(x);
+  }
   }
 }
 
@@ -432,7 +438,9 @@ int XG_FN(xg_pad)(const real* in, real* out, const int64_t* shape, int ndim, con
     // aligned rows with an untouched innermost dim: vector copies; everything else: per-element gathers,
     // 16-B stores between the row's first and last 16-B boundary
     const bool straight = !inner_padded && Lrow % NV == 0 && aligned16(in);
-    const u64 nt = (u64)((Lrow + (NV - 1) + (int64_t)WAVE * NV - 1) / ((int64_t)WAVE * NV));
+    const u64 ntiles = (u64)((Lrow + (NV - 1) + (int64_t)WAVE * NV - 1) / ((int64_t)WAVE * NV));
+    const u64 tpw = (u64)(tune().pad_tpw >= 4 ? 4 : tune().pad_tpw >= 2 ? 2 : 1);  // tiles per wave-task
+    const u64 nt = (ntiles + tpw - 1) / tpw;
     const u64 waves = (u64)nrows64 * nt;
     if (waves < 0x7fffffffull) {
       const u64 nb = (waves + WPB - 1) / WPB;
@@ -440,8 +448,11 @@ int XG_FN(xg_pad)(const real* in, real* out, const int64_t* shape, int ndim, con
       const FastDiv fnt = make_fastdiv(nt);
       const int band = (tune().pad_nt & 4) ? 1 : 0;
       const u32 grid = band ? (u32)(((nb + 7) / 8) * 8) : (u32)nb;
-      if (straight) hipLaunchKernelGGL((k_pad_rows<NV, false>), dim3(grid), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt, tune().pad_nt);
-      else hipLaunchKernelGGL((k_pad_rows<NV, true>), dim3(grid), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt, tune().pad_nt);
+      const int ntf = tune().pad_nt;
+#define XG_PR(INNER_, T_) hipLaunchKernelGGL((k_pad_rows<NV, INNER_, T_>), dim3(grid), dim3(BLOCK), 0, st, in, out, p, (u32)nrows64, fnt, ntf)
+      if (straight) { if (tpw == 4) XG_PR(false, 4); else if (tpw == 2) XG_PR(false, 2); else XG_PR(false, 1); }
+      else { if (tpw == 4) XG_PR(true, 4); else if (tpw == 2) XG_PR(true, 2); else XG_PR(true, 1); }
+#undef XG_PR
       XG_LAUNCH_CHECK();
       return XG_OK;
     }

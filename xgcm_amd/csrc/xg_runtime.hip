@@ -60,6 +60,7 @@ const TuneEntry TUNABLES[] = {
     {"met_ys1", &Tune::met_ys1, 12},
     {"met_ys2", &Tune::met_ys2, 0},
     {"transform_lean", &Tune::transform_lean, 3},
+    {"pad_tpw", &Tune::pad_tpw, 2},
     {"bin_idx32", &Tune::bin_idx32, 1},
     {"reduce_ru", &Tune::reduce_ru, 1},
     {"reduce_ldsw", &Tune::reduce_ldsw, 1},
