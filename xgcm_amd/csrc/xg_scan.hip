@@ -1204,10 +1204,13 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_chain_z(
 
 // K4b: weighted sum along the CONTIGUOUS axis: one wave per row, lane-strided partial sums then
 // a shuffle tree (tolerance parity; numpy itself is pairwise here).
-template <bool HAS_W, bool VEC>
+// SK >= 0: the mode is a compile-time constant (the plain sums, skipna False / True: `integrate`, `sum`) -- decided per element
+// through select chains it cost 17 instructions per cell where one addition is needed (DESIGN rule 15); SK < 0: any mode.
+template <bool HAS_W, bool VEC, int SK>
 __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict__ in,
-                                                         real* __restrict__ out, Geo g, int skipna,
+                                                         real* __restrict__ out, Geo g, int skipna_rt,
                                                          const real* __restrict__ wgt, MIdx mw, int ntl, ZBand zb) {
+  int skipna = (SK >= 0) ? SK : skipna_rt;
   u64 row = wave_id();
   if (zb.on) {  // weights broadcast along the slow outer dim: all levels of a band of rows before the next band,
                 // so that the band's weight rows are served by the XCD's L2 (integrate along X with dx(Y,X): 48 %
@@ -1259,8 +1262,9 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
       }
     };
     int64_t t = lane;
-    if (ntl & 2) {  // RU independent loads (and weight loads) before the first addition; the additions keep their order
-      constexpr int RU = 4;
+    // RU independent loads (and weight loads) before the first addition; the additions keep their order
+    auto batches = [&](auto ru) {
+      constexpr int RU = decltype(ru)::value;
       for (; t + (RU - 1) * WAVE < nvec; t += RU * WAVE) {
         dv v[RU], wv[RU];
 #pragma unroll
@@ -1272,7 +1276,9 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
 #pragma unroll
         for (int u = 0; u < RU; ++u) add(v[u], wv[u]);
       }
-    }
+    };
+    if (ntl & 4) batches(std::integral_constant<int, 8>{});
+    if (ntl & 6) batches(std::integral_constant<int, 4>{});
     for (; t < nvec; t += WAVE) {
       const int64_t k = lead + t * NV;
       const dv v = ldv(k);
@@ -1537,13 +1543,14 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     const u64 nblocks = (nrows + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
     const bool vec = aligned16(in) && g.n_in >= 4 * NV;  // rows of any length: lead / tail cells go through scalar loads
-    if (vec) {
-      if (w) hipLaunchKernelGGL((k_reduce_contig<true, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, (tune().nt_load ? 1 : 0) | (tune().reduce_ru ? 2 : 0), zb);
-      else hipLaunchKernelGGL((k_reduce_contig<false, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, (tune().nt_load ? 1 : 0) | (tune().reduce_ru ? 2 : 0), zb);
-    } else {
-      if (w) hipLaunchKernelGGL((k_reduce_contig<true, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, (tune().nt_load ? 1 : 0) | (tune().reduce_ru ? 2 : 0), zb);
-      else hipLaunchKernelGGL((k_reduce_contig<false, false>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, (tune().nt_load ? 1 : 0) | (tune().reduce_ru ? 2 : 0), zb);
-    }
+    const int ntf = (tune().nt_load ? 1 : 0) | (tune().reduce_ru == 1 ? 2 : tune().reduce_ru >= 2 ? 4 : 0);
+    const int sk = (tune().reduce_sk && (skipna == 0 || skipna == 1)) ? skipna : -1;
+#define XG_RC(W_, V_, S_) hipLaunchKernelGGL((k_reduce_contig<W_, V_, S_>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zb)
+#define XG_RS(W_, V_) do { if (sk == 0) XG_RC(W_, V_, 0); else if (sk == 1) XG_RC(W_, V_, 1); else XG_RC(W_, V_, -1); } while (0)
+    if (vec) { if (w) XG_RS(true, true); else XG_RS(false, true); }
+    else { if (w) XG_RS(true, false); else XG_RS(false, false); }
+#undef XG_RS
+#undef XG_RC
   } else {
     int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, w != nullptr)) ? NV : 1;
     const bool long_march = g.n_in >= 256;
