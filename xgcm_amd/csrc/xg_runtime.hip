@@ -64,7 +64,7 @@ const TuneEntry TUNABLES[] = {
     {"bin_idx32", &Tune::bin_idx32, 1},
     {"reduce_sk", &Tune::reduce_sk, 1},
     {"reduce_ru", &Tune::reduce_ru, 1},
-    {"reduce_ldsw", &Tune::reduce_ldsw, 1},
+    {"reduce_ldsw", &Tune::reduce_ldsw, 2},
     {"dbg", &Tune::dbg, 0},
     {"march_lds_kb", &Tune::march_lds_kb, 0},
 };

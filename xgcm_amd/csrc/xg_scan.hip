@@ -904,7 +904,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_rescue(
 template <int U, int NWV>
 __global__ __launch_bounds__(NWV * WAVE) void k_reduce_ldsw(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, u32 nblk, int skipna,
-    const real* __restrict__ wgt, MIdx mw) {
+    const real* __restrict__ wgt, MIdx mw, u32 ngrp) {
   constexpr int V = HV;
   typedef typename VecT<V>::type T;
   static_assert(U % NWV == 0, "every wave fetches U / NWV weight rows of a block");
@@ -913,7 +913,12 @@ __global__ __launch_bounds__(NWV * WAVE) void k_reduce_ldsw(
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
   if (lb >= nblk) return;  // (whole workgroups leave: nobody is left waiting at a barrier)
-  const u32 og = lb / ntile, tile = lb - og * ntile;
+  // ngrp != 0: level groups run fastest, so an XCD band = ALL level groups of a few x-tiles: their workgroups march down the
+  // same weight columns together and each XCD fetches only its own eighth of the weight plane (tile-fastest order: every XCD
+  // streams the whole plane once per level group it holds)
+  u32 og, tile;
+  if (ngrp) { tile = lb / ngrp; og = lb - tile * ngrp; }
+  else { og = lb / ntile; tile = lb - og * ntile; }
   const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int64_t o = (int64_t)og * NWV + wv;
@@ -1589,7 +1594,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
         const u64 groups = ((u64)g.outer + LW - 1) / LW, lblk = groups * ltile;
         if (lblk < 0x7ffffff0ull) {
           const u32 lgrid = (u32)(((lblk + 7) / 8) * 8);
-          hipLaunchKernelGGL((k_reduce_ldsw<LU, LW>), dim3(lgrid), dim3(LW * WAVE), 0, st, in, out, g, ltile, (u32)lblk, skipna, w, mw);
+          hipLaunchKernelGGL((k_reduce_ldsw<LU, LW>), dim3(lgrid), dim3(LW * WAVE), 0, st, in, out, g, ltile, (u32)lblk, skipna, w, mw, tune().reduce_ldsw >= 2 ? (u32)groups : 0u);
           XG_LAUNCH_CHECK();
           return XG_OK;
         }
