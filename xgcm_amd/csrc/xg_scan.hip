@@ -783,9 +783,18 @@ __device__ __forceinline__ void reduce_strided_body(
   constexpr bool HAS_W = WMODE != 0, WU = WMODE == 2;
   // U independent loads in flight per lane
   const u64 w = band ? banded_wave_id() : wave_id();
-  const u32 tile = (u32)(w % ntile);
-  int64_t o = (int64_t)(w / ntile);
-  if (o >= g.outer) return;
+  u32 tile;
+  int64_t o;
+  if (band & 2) {  // weights shared by all outer indices: outer indices fastest, an XCD band = all levels of a few x-tiles,
+                   // marching down the same weight columns together (the weight rows are then L2 hits; see K4L)
+    tile = (u32)(w / (u64)g.outer);
+    o = (int64_t)(w - (u64)tile * (u64)g.outer);
+    if (tile >= ntile) return;
+  } else {
+    tile = (u32)(w % ntile);
+    o = (int64_t)(w / ntile);
+    if (o >= g.outer) return;
+  }
   if (WU) o = (int64_t)__builtin_amdgcn_readfirstlane((u32)o);  // (host: outer < 2^32) the division ran on the vector unit
   const int lane = threadIdx.x & 63;
   const int64_t x = ((int64_t)tile * WAVE + lane) * V;
@@ -1565,7 +1574,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     const u64 nblocks = tune().march_band ? (((ntask + WPB - 1) / WPB + 7) / 8) * 8 : (ntask + WPB - 1) / WPB;
     if ((rc = check_grid(nblocks))) return rc;
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
-    const int rband = tune().march_band;
+    int rband = tune().march_band & 1;
     // one weight per row (no inner stride: drF(Z) under (Z, Y, X), dy(Y) under (Z, Y, X)): scalar loads, nothing rides
     // in the window -- the march then streams like the unweighted one (sum along Y 55 -> 78 %; the chain below: 62 %)
     bool wu = w && tune().met_scalar && g.outer < 0xffffffffll;
@@ -1574,6 +1583,12 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     // K4c: the long weighted march as a chained flat launch (the unweighted one already streams at 80 %)
     // (the UNWEIGHTED long march as a chain: measured 59 % against 76 % (f64), 39 % against 63 % (f32) -- no stores, no
     // weight window: nothing for the chain to fix, only its hand-offs to pay)
+    if (w && !wu && tune().march_ofast) {
+      bool shared = true;
+      for (int d = 0; d < g.n_outer; ++d)
+        if (mw.outer[d] != 0) shared = false;
+      if (shared && g.outer >= 2) rband |= 2;
+    }
     if (w && !wu && tune().scan_chain && tune().nt_load && g.inner % HV == 0 && (reinterpret_cast<uintptr_t>(in) & 7u) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (HV == 1 || vec_metric_ok(g, true))) {
       bool shared_w = true;
