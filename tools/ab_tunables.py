@@ -28,7 +28,13 @@ def main():
     ap.add_argument("--shape", default="75,2400,3600")
     ap.add_argument("--mark", action="store_true", help="a marker dispatch (k_fill_synthetic of 4096 * (1 + variant * ncases + case) "
                     "cells) before every (variant, case) block: tools/pmc_ab.py maps rocprofv3 dispatches to variants with it")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="f32: every synthetic operand in float32 (bytes per cell halve)")
     a = ap.parse_args()
+    bscale = 1.0
+    if a.dtype == "f32":  # (the transform cases build their coordinates in float64: not covered)
+        import functools
+        D.synthetic = functools.partial(D.synthetic, dtype=torch.float32)
+        bscale = 0.5
     nz, ny, nx = (int(v) for v in a.shape.split(","))
     cells = nz * ny * nx
     T = D.synthetic((nz, ny, nx), 2)
@@ -151,11 +157,11 @@ def main():
         for c in cases:
             ts = sorted(times[(vi, c)])
             ms = ts[len(ts) // 2]
-            gbs = cells * CASES[c][1] / (ms * 1e-3) / 1e9
+            gbs = cells * CASES[c][1] * bscale / (ms * 1e-3) / 1e9
             print(json.dumps({"case": c, "variant": ",".join(f"{k}={v}" for k, v in kv.items()), "median_ms": round(ms, 4),
                               "min_ms": round(ts[0], 4), "max_ms": round(ts[-1], 4), "GBps": round(gbs, 1),
                               "frac_8TBps": round(gbs / 8000, 4), "rounds": a.rounds,
-                              "alg_bytes": int(round(cells * CASES[c][1]))}), flush=True)
+                              "alg_bytes": int(round(cells * CASES[c][1] * bscale))}), flush=True)
 
 
 if __name__ == "__main__":

@@ -141,6 +141,7 @@ struct Tune {
   int transform_lean; // linear transform, ring + shared level table: the lean streaming loop (targets validated once, 32-bit cursors, pointer-stepped columns)
   int pad_tpw;        // row-wise pad: consecutive 64-lane tiles of a row per wave-task (the row logic is paid once per task)
   int bin_idx32;      // elementwise binary op: index decomposition with 32-bit multiply-shift divisions (0: 64-bit divisions)
+  int reduce_ldsw_u;  // K4L: rows per block (8 / 16)
   int march_ofast;    // marching weighted reductions whose weights are shared by the outer indices: outer indices fastest in the work order
   int reduce_sk;      // contiguous-axis reductions: kernels specialised for the plain sums (skipna False / True)
   int reduce_ru;      // contiguous-axis reductions: 4 independent 16-B loads per lane before the first addition

@@ -62,6 +62,7 @@ const TuneEntry TUNABLES[] = {
     {"transform_lean", &Tune::transform_lean, 3},
     {"pad_tpw", &Tune::pad_tpw, 2},
     {"bin_idx32", &Tune::bin_idx32, 1},
+    {"reduce_ldsw_u", &Tune::reduce_ldsw_u, 0},
     {"march_ofast", &Tune::march_ofast, 1},
     {"reduce_sk", &Tune::reduce_sk, 1},
     {"reduce_ru", &Tune::reduce_ru, 1},

@@ -1569,6 +1569,8 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     int V = (aligned16(in) && aligned16(out) && (g.inner % NV == 0) && vec_metric_ok(g, w != nullptr)) ? NV : 1;
     const bool long_march = g.n_in >= 256;
     if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = HV;  // 8-byte lanes
+    // (float32 with 4-byte lanes -- as many marches as float64 -- measured: sum along Y 0.652 -> 0.593; 8-byte lanes stay;
+    // profiles/r03ao_ab_f32_narrow4.jsonl)
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
     const u64 ntask = (u64)ntile * (u64)g.outer;
     const u64 nblocks = tune().march_band ? (((ntask + WPB - 1) / WPB + 7) / 8) * 8 : (ntask + WPB - 1) / WPB;
@@ -1609,6 +1611,11 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
         const u64 groups = ((u64)g.outer + LW - 1) / LW, lblk = groups * ltile;
         if (lblk < 0x7ffffff0ull) {
           const u32 lgrid = (u32)(((lblk + 7) / 8) * 8);
+          // rows per block: 8 in float64 (16: 0.716 -> 0.697); float32 has half the workgroups for the same bytes and wants the
+          // longer window (0.518 -> 0.541); profiles/r03ap_*
+          const int lu = tune().reduce_ldsw_u ? tune().reduce_ldsw_u : (sizeof(real) == 4 ? 16 : 8);
+          if (lu >= 16) hipLaunchKernelGGL((k_reduce_ldsw<16, LW>), dim3(lgrid), dim3(LW * WAVE), 0, st, in, out, g, ltile, (u32)lblk, skipna, w, mw, tune().reduce_ldsw >= 2 ? (u32)groups : 0u);
+          else
           hipLaunchKernelGGL((k_reduce_ldsw<LU, LW>), dim3(lgrid), dim3(LW * WAVE), 0, st, in, out, g, ltile, (u32)lblk, skipna, w, mw, tune().reduce_ldsw >= 2 ? (u32)groups : 0u);
           XG_LAUNCH_CHECK();
           return XG_OK;
