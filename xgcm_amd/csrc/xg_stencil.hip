@@ -154,17 +154,38 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     bool edge;
     if (pad_lo) { edge = (i0 == 0); nidx = edge ? ((bc == XG_BC_PERIODIC) ? Li - 1 : 0) : i0 - 1; }
     else { edge = (i0 + NV == Li); nidx = edge ? ((bc == XG_BC_PERIODIC) ? 0 : Li - 1) : i0 + NV; }
-    dv a = ntl ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + i0)) : *reinterpret_cast<const dv*>(prow + i0);
-    // (the neighbour stays an 8-B load here: taking it from the next lane's registers by DPP, which pays in the row-wise
-    // kernel K1r, +2.9 points, costs this one 0.4 -- its single load pair per lane leaves nothing to hide the branch behind;
-    // profiles/r03ab_ab_k1dpp.jsonl)
-    real n = prow[nidx];
+    dv a = (ntl & 1) ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + i0)) : *reinterpret_cast<const dv*>(prow + i0);
+    real n;
+    // ntl & 2, no metrics, a wave that lies inside ONE row (27 of 28 waves on 3600-cell rows): the neighbour comes from the
+    // next lane's registers (DPP), and the one lane that has no such lane -- the wave's first / last -- takes its value from a
+    // SCALAR load (its row and index are wave-uniform): one vector-memory instruction per wave instead of two.  (With a
+    // per-lane load for that lane the instruction count stays at two and the kernel loses 0.4 points:
+    // profiles/r03ab_ab_k1dpp.jsonl.)
+    const u32 gfirst = __builtin_amdgcn_readfirstlane(gid - (threadIdx.x & 63));
+    const u32 rfirst = fdiv(gfirst, per), rlast = fdiv(gfirst + (WAVE - 1), per);
+    if (MET == 0 && (ntl & 2) && rfirst == rlast) {
+      const int lane = threadIdx.x & 63;
+      const u32 ru = rfirst;
+      const real* prow_u = in + (row0 * (int64_t)Li + (u64)ru * Li);
+      const u32 ib = (gfirst + (pad_lo ? 0 : WAVE - 1) - ru * per.d) * V;  // first cell of the boundary lane's vector
+      u32 nb_idx;
+      bool eb;
+      if (pad_lo) { eb = (ib == 0); nb_idx = eb ? ((bc == XG_BC_PERIODIC) ? Li - 1 : 0) : ib - 1; }
+      else { eb = (ib + NV == Li); nb_idx = eb ? ((bc == XG_BC_PERIODIC) ? 0 : Li - 1) : ib + NV; }
+      real nb = prow_u[nb_idx];
+      if (eb && bc == XG_BC_FILL) nb = fill;
+      if (eb && bc == XG_BC_HALO) nb = halo[(row0 + ru) * (int64_t)(Lo - Li + 1)];
+      n = pad_lo ? from_lane_below(a[NV - 1]) : from_lane_above(a[0]);
+      if (lane == (pad_lo ? 0 : WAVE - 1)) n = nb;
+    } else {
+    n = prow[nidx];
     if (HAS_MI) {
       a = a * ldm<dv>(m_in, mib + (int64_t)i0 * mi.axis, mi.axis);
       n = n * m_in[mib + (int64_t)nidx * mi.axis];
     }
     if (edge && bc == XG_BC_FILL) n = fill;
     if (edge && bc == XG_BC_HALO) n = halo[(row0 + r) * (int64_t)(Lo - Li + 1)];  // one halo cell per row here
+    }
     dv res;
     if (pad_lo) {
       res[0] = op2<OP>(n, a[0]);
@@ -1127,9 +1148,9 @@ int launch_contig(const StencilCall& c) {
     const u32 nblk = (u32)(((u64)nrows * per + BLOCK - 1) / BLOCK);
     const u32 grid = ((nblk + 7) / 8) * 8;
     if (tune().nt_store)
-      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, tune().nt_load);
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, true>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, (tune().nt_load ? 1 : 0) | (tune().nb_dpp ? 2 : 0));
     else
-      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, tune().nt_load);
+      hipLaunchKernelGGL((k_stencil_contig<OP, V, MET, false>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)row0, nrows, nblk, fper, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, (tune().nt_load ? 1 : 0) | (tune().nb_dpp ? 2 : 0));
   }
   return 0;
 }
