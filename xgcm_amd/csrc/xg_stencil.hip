@@ -293,7 +293,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
   if (nb_dpp) {  // the value beside a lane's vector from the neighbouring lane's registers (see from_lane_below)
 #pragma unroll
     for (int u = 0; u < R; ++u) n[u] = pad_lo ? from_lane_below(a[u][NV - 1]) : from_lane_above(a[u][0]);
-    if (own_nb) {
+    if (own_nb) {  // (scalar loads for this one lane, as in the flat kernel: no change here, 0.749 / 0.722 either way --
+                   // the block's R loads issue together; profiles/r03ar_ab_k1r_scalar.jsonl)
 #pragma unroll
       for (int u = 0; u < R; ++u) n[u] = in[rows[u] * L + nidx];
     }
