@@ -243,7 +243,7 @@ def test_weighted_reduction_with_weights_through_lds(dev, dtype):
     workgroup.  Every mode, columns that are not a multiple of the block, outer extents that are not a multiple of 4,
     ragged x-tiles, NaNs -- against the oracle (sequential order: bit-exact) and against the marching kernel."""
     from xgcm_amd import _hip
-    keep = {k: _hip.get_tunable(k) for k in ("reduce_ldsw", "scan_chain")}
+    keep = {k: _hip.get_tunable(k) for k in ("reduce_ldsw", "scan_chain", "reduce_ldsw_u", "march_ofast")}
     try:
         for shape, wshape in (((3, 300, 128), (1, 300, 128)), ((6, 64, 130), (1, 64, 130)), ((5, 97, 66), (1, 97, 66)),
                               ((2, 3, 80, 64), (1, 1, 80, 64)), ((9, 1000, 70), (1, 1000, 70)), ((4, 65, 2), (1, 65, 2))):
@@ -253,11 +253,16 @@ def test_weighted_reduction_with_weights_through_lds(dev, dtype):
             for mode in (True, False, "valid", "all", "mean_valid", "mean_all", "pair_valid", "pair_all"):
                 _hip.set_tunable("reduce_ldsw", 0)
                 _hip.set_tunable("scan_chain", 0)
+                _hip.set_tunable("march_ofast", 0)  # the plain weighted march, x-tiles / outer indices fastest
                 ref = dev.tohost(dev.reduce1d(a, axis, w, mode))
-                _hip.set_tunable("reduce_ldsw", 1)
+                _hip.set_tunable("march_ofast", 1)
+                _eq(dev.tohost(dev.reduce1d(a, axis, w, mode)), ref)
                 _hip.set_tunable("scan_chain", keep["scan_chain"])
-                for _ in range(2):
-                    _eq(dev.tohost(dev.reduce1d(a, axis, w, mode)), ref)
+                for order in (1, 2):  # x-tiles fastest / level groups fastest in the work order
+                    _hip.set_tunable("reduce_ldsw", order)
+                    for lu in (8, 16):  # rows per block
+                        _hip.set_tunable("reduce_ldsw_u", lu)
+                        _eq(dev.tohost(dev.reduce1d(a, axis, w, mode)), ref)
             with np.errstate(invalid="ignore"):
                 _eq(dev.tohost(dev.reduce1d(a, axis, w, True)), R.integrate(a, axis, np.broadcast_to(w, shape), True).astype(dtype))
     finally:
@@ -363,6 +368,40 @@ def test_pad_matches_numpy_chain(dev):
         exp = R.pad_nd(a, widths, bc, fill)
         got = dev.tohost(dev.pad_nd(a, widths, bc, fill))
         _eq(got, exp)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("tpw", [1, 2, 4])
+def test_pad_long_rows_tiles_per_wave(dev, dtype, tpw):
+    """the row-wise pad kernel (rows of >= 64 cells): 1 / 2 / 4 tiles of 64 lanes per wave-task, rows that are not a multiple
+    of a tile or of a wave-task, padded and untouched innermost dim, every boundary mode, odd row lengths (rows that do not
+    start on a 16-byte boundary) -- numpy's pad chain, bit for bit; and the elementwise operator with and without its 32-bit
+    index decomposition on the same arrays"""
+    from xgcm_amd import _hip
+    keep = {k: _hip.get_tunable(k) for k in ("pad_tpw", "bin_idx32")}
+    _hip.set_tunable("pad_tpw", tpw)
+    try:
+        for shape in ((3, 5, 70), (2, 4, 130), (2, 3, 300), (2, 2, 515), (1, 2, 1026)):
+            a = _field(shape, 61).astype(dtype)
+            cases = [
+                ({2: (1, 1)}, {2: "periodic"}, {}),
+                ({2: (2, 0)}, {2: "fill"}, {2: 1.5}),
+                ({2: (0, 3)}, {2: "extend"}, {}),
+                ({1: (1, 2)}, {1: "extend"}, {}),
+                ({0: (1, 0), 1: (0, 1)}, {0: "fill", 1: "periodic"}, {0: -2.0}),
+                ({0: (1, 1), 1: (2, 1), 2: (3, 2)}, {0: "periodic", 1: "fill", 2: "extend"}, {1: 0.25}),
+                ({2: (70, 5)}, {2: "periodic"}, {}),
+            ]
+            for widths, bc, fill in cases:
+                _eq(dev.tohost(dev.pad_nd(a, widths, bc, fill)), R.pad_nd(a, widths, bc, fill))
+            b = R.synthetic_metric((1,) + shape[1:], 62).astype(dtype)
+            for idx32 in (0, 1):
+                _hip.set_tunable("bin_idx32", idx32)
+                for op in ("mul", "div"):
+                    _eq(dev.tohost(dev.binary(op, a, b)), R.binary(op, a, b))
+    finally:
+        for k, v in keep.items():
+            _hip.set_tunable(k, v)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
