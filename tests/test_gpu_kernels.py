@@ -440,6 +440,45 @@ def test_gather_random_token_maps(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("tpw", [1, 2, 4])
+def test_gather_long_rows_tiles_per_wave(dev, dtype, tpw):
+    """the row-wise gather kernel (output rows of >= 64 cells; the small cases above go through the per-cell kernel): random
+    token maps on the halo frame, interior straight from the input, a partner component, mapped dims with an unmapped one
+    between them, odd row lengths, 1 / 2 / 4 tiles per wave-task"""
+    from oracle import topology as T
+    from xgcm_amd import _hip
+
+    keep = _hip.get_tunable("pad_tpw")
+    _hip.set_tunable("pad_tpw", tpw)
+    rng = np.random.default_rng(17)
+    cases = [
+        ((3, 9, 200), (False, True, True), (0, 1, 2), (0, 2, 1), None, None),
+        ((2, 5, 131), (False, True, True), (0, 2, 0), (0, 1, 0), None, None),      # innermost dim not padded
+        ((2, 6, 3, 70), (True, False, False, True), (1, 0, 0, 3), (1, 0, 0, 2), None, None),
+        ((4, 7, 300), (True, True, True), (0, 2, 2), (0, 2, 2), (4, 300, 7), (0, 2, 1)),
+        ((1, 3, 515), (False, False, True), (0, 0, 1), (0, 0, 1), None, None),
+    ]
+    try:
+        for shape, mapped, lo, hi, pshape, perm in cases:
+            x = _field(shape, 93).astype(dtype)
+            partner = None if pshape is None else _field(pshape, 94).astype(dtype)
+            out_shape = [n + (l + h if m else 0) for n, m, l, h in zip(shape, mapped, lo, hi)]
+            p_out = int(np.prod([n for n, m in zip(out_shape, mapped) if m]))
+            p_in = int(np.prod([n for n, m in zip(shape, mapped) if m]))
+            p_partner = 0
+            if partner is not None:
+                p_partner = int(np.prod([pshape[k] for k in range(len(pshape)) if mapped[perm[k]]]))
+            fills = [0.0, -7.25, float("nan")]
+            tok = rng.integers(1, p_in + p_partner + 1, size=p_out).astype(np.int64)
+            tok = np.where(rng.random(p_out) < 0.2, T.FILL_BASE + rng.integers(0, len(fills), size=p_out), tok)
+            tok = np.where(rng.random(p_out) < 0.3, -tok, tok)
+            want = T.gather_tokens(x, partner, tok, mapped, lo, out_shape, fills, perm)
+            _eq(dev.tohost(dev.gather(x, partner, tok, mapped, lo, out_shape, fills, perm)), want)
+    finally:
+        _hip.set_tunable("pad_tpw", keep)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("shape", SHAPES + [(2, 40, 2600), (3, 2, 4, 8)])
 def test_stencil_with_pregathered_halo(dev, shape, dtype):
     """xg_stencil1d_halo: every kernel family (contiguous V/general, short segments, column chunks)

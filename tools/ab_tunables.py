@@ -115,6 +115,12 @@ def main():
             "tcon_rw": (lambda: D.transform_conservative(T, tho_rw, edges, 0), (2 * nz + 1 + mt) * 8 / nz),
             "tcon_sm": (lambda: D.transform_conservative(T, tho_sm, edges, 0), (2 * nz + 1 + mt) * 8 / nz),
         })
+    if "gatherYX" in cases:  # halo gather through a token map: periodic frame of one cell around (Y, X), every level
+        import numpy as np
+        idx = np.arange(ny * nx, dtype=np.int64).reshape(ny, nx)
+        tok = (np.pad(idx, ((1, 1), (1, 1)), mode="wrap") + 1).reshape(-1)
+        tokd = torch.from_numpy(tok).cuda()
+        CASES["gatherYX"] = (lambda: D.gather(T, None, tokd, (False, True, True), (0, 1, 1), (nz, ny + 2, nx + 2), [0.0]), 16)
     for c in cases:  # cumsum along Z of R records in ONE launch ("cumZr4": R = 4): what does a launch cost beyond its bytes?
         if c.startswith("cumZr"):
             R = int(c[5:])

@@ -293,6 +293,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather(const real* __restrict__ in, c
 // wave-uniform.  Interior cells are narrow loads of consecutive inputs; halo cells decode a token
 // (without any division when the mapped dims are the source's trailing dims, the usual
 // (time, depth, face, j, i) layouts).
+template <int TPW>
 __global__ __launch_bounds__(BLOCK) void k_gather_rows(const real* __restrict__ in, const real* __restrict__ partner,
                                                        real* __restrict__ out, const int64_t* __restrict__ tokens,
                                                        GatherGeo g, u32 nrows, FastDiv ntile, int band) {
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(const real* __restrict__ 
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
   const u32 r = fdiv(w, ntile);
   if (r >= nrows) return;
-  const u32 tile = w - r * ntile.d;
+  const u32 tile0 = (w - r * ntile.d) * TPW;  // ntile = wave-tasks per row, TPW consecutive tiles each (see k_pad_rows)
   const int nd = g.ndim;
   u32 rem = r;
   bool interior = true;   // over the outer dims
@@ -358,10 +359,12 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(const real* __restrict__ 
   real* drow = out + (int64_t)r * Lo;
   const int64_t lead = (NV - (int64_t)(((int64_t)r * Lo) % NV)) % NV;
   const int lane = threadIdx.x & 63;
-  if (tile == 0 && lane == 0)
+  if (tile0 == 0 && lane == 0)
     for (int64_t x = 0; x < lead && x < Lo; ++x) drow[x] = elem(x);
+#pragma unroll
+  for (u32 tile = tile0; tile < tile0 + TPW; ++tile) {
   const int64_t x0 = lead + ((int64_t)tile * WAVE + lane) * NV;
-  if (x0 >= Lo) return;
+  if (x0 >= Lo) break;
   if (x0 + NV <= Lo) {
     dv val;
     const int64_t c0 = x0 - lo_in;
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(const real* __restrict__ 
     stg<dv, true>(drow + x0, val);
   } else {
     for (int64_t x = x0; x < Lo; ++x) drow[x] = elem(x);
+  }
   }
 }
 
@@ -533,13 +537,19 @@ int XG_FN(xg_gather)(const real* in, const real* partner, real* out, const int64
   const int64_t Lrow = out_shape[ndim - 1];
   const int64_t nrows64 = Lrow > 0 ? total / Lrow : 0;
   if (tune().pad_rows && Lrow >= 64 && aligned16(out) && nrows64 < 0x7fffffffll) {
-    const u64 nt = (u64)((Lrow + (NV - 1) + (int64_t)WAVE * NV - 1) / ((int64_t)WAVE * NV));
+    const u64 ntiles = (u64)((Lrow + (NV - 1) + (int64_t)WAVE * NV - 1) / ((int64_t)WAVE * NV));
+    // tiles per wave-task (see xg_pad): 1 -> 2 tiles 0.641 -> 0.683 on a periodic (Y, X) frame; 4 tiles unrolled spill (22 ms
+    // for 1.9): not instantiated (profiles/r03at_ab_gather_tpw.jsonl)
+    const u64 tpw = (u64)(tune().pad_tpw >= 2 ? 2 : 1);
+    const u64 nt = (ntiles + tpw - 1) / tpw;
     const u64 waves = (u64)nrows64 * nt;
     if (waves < 0x7fffffffull) {
       const u64 nb = (waves + WPB - 1) / WPB;
       if ((rc = check_grid(nb))) return rc;
       const int band = (tune().pad_nt & 4) ? 1 : 0;
-      hipLaunchKernelGGL(k_gather_rows, dim3(band ? (u32)(((nb + 7) / 8) * 8) : (u32)nb), dim3(BLOCK), 0, st, in, partner, out, tokens, g, (u32)nrows64, make_fastdiv(nt), band);
+      const u32 ggrid = band ? (u32)(((nb + 7) / 8) * 8) : (u32)nb;
+      if (tpw == 2) hipLaunchKernelGGL(k_gather_rows<2>, dim3(ggrid), dim3(BLOCK), 0, st, in, partner, out, tokens, g, (u32)nrows64, make_fastdiv(nt), band);
+      else hipLaunchKernelGGL(k_gather_rows<1>, dim3(ggrid), dim3(BLOCK), 0, st, in, partner, out, tokens, g, (u32)nrows64, make_fastdiv(nt), band);
       XG_LAUNCH_CHECK();
       return XG_OK;
     }
