@@ -90,6 +90,24 @@ def test_stencil_metric_weighted_bitwise(dev, shape, op):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_contig_metric_stencil_many_levels(dev, dtype):
+    """K1r, z-shared: `derivative` / `metric_weighted` along X of (Z, Y, X) with metrics shared by MANY levels (the other
+    stencil tests have 2-6): level counts that are not a multiple of the levels per wave-task, ragged x-tiles, every pad and
+    boundary condition -- the oracle's bits."""
+    if True:
+        for shape in ((37, 5, 130), (33, 3, 256), (19, 4, 64), (70, 2, 66)):
+            a = _field(shape, 47).astype(dtype)
+            for (lo, hi), bc in itertools.product([(1, 0), (0, 1)], BCS):
+                for keep_dims in ({1, 2}, {2}):
+                    m_in = _metric_for(shape, keep_dims, 48).astype(dtype)
+                    m_out = _metric_for(shape, keep_dims, 49).astype(dtype)
+                    for op in ("diff", "interp"):
+                        for kw in ({"m_out": m_out}, {"m_in": m_in, "m_out": m_out}, {"m_in": m_in}):
+                            exp = R.stencil1d(op, a, 2, lo, hi, bc, 0.75, **kw)
+                            _eq(dev.tohost(dev.stencil1d(op, a, 2, lo, hi, bc, 0.75, **kw)), exp)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("ys", [0, 12, 14, 18, 22])
 def test_strided_metric_stencil_y_stacked_workgroups(dev, dtype, ys):
     """K2Sm: `derivative` / `metric_weighted` along Y of (Z, Y, X) with metrics shared by the levels -- the 4 waves of a
