@@ -1352,6 +1352,10 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_ysm(
   }
 }
 
+// (K2Sy / K2Sm with 32-bit index arithmetic and without the generic outer-offset peel -- 542 -> 317 scalar instructions per
+// K2Sm wave, 203 -> 164 per K2Sy wave -- measured against the unchanged K2S in alternating processes of one session: K2Sy's
+// lead over K2S stays at +1.7 points, K2Sm's SHRINKS from +1.7 to +0.7; the scalar unit is not what bounds these kernels, the
+// 64-bit forms stay.  profiles/r03ax_ab_lean32_old_new.jsonl)
 // K2Sm launch: the geometry tests are launch_seg_n's (z-banding, one outer dim, metrics broadcast along it, 16-B lane vectors)
 template <int OP, int MET, int SEG, int ZK>
 bool launch_ysm(const StencilCall& c) {
