@@ -27,12 +27,13 @@ for it in range(120):
     _hip.set_tunable("transform_stage", 0); _hip.set_tunable("transform_win", 2)
     lin0 = D.transform_linear(phi, theta, levels, 0, mask_edges=bool(it & 1), bypass_checks=bool(it & 8))
     con0 = D.transform_conservative(phi, theta_o, edges, 0)
-    for stage, ring, win, cwin in ((3, 4, 1, 4), (3, 8, 1, 8), (3, 16, 1, 16), (2, 8, 1, 8), (1, 8, 1, 8)):
+    for stage, ring, win, cwin, lean in ((3, 4, 1, 4, 3), (3, 8, 1, 8, 3), (3, 16, 1, 16, 3), (3, 8, 1, 8, 0), (3, 4, 1, 16, 0), (2, 8, 1, 8, 3), (1, 8, 1, 8, 3)):
+        _hip.set_tunable("transform_lean", lean)  # bit 0: lean linear loop, bit 1: lean conservative kernel (K9e)
         _hip.set_tunable("transform_stage", stage); _hip.set_tunable("transform_ring", ring)
         _hip.set_tunable("transform_win", win); _hip.set_tunable("transform_cwin", cwin)
         lin = D.transform_linear(phi, theta, levels, 0, mask_edges=bool(it & 1), bypass_checks=bool(it & 8))
         con = D.transform_conservative(phi, theta_o, edges, 0)
-        assert same(lin, lin0), (it, "linear", stage, ring, (nz, ny, nx), m, k)
-        assert same(con, con0), (it, "conservative", win, cwin, (nz, ny, nx), m, k)
+        assert same(lin, lin0), (it, "linear", stage, ring, lean, (nz, ny, nx), m, k)
+        assert same(con, con0), (it, "conservative", win, cwin, lean, (nz, ny, nx), m, k)
         n += 2
 print(f"{n} transform variant comparisons identical, {time.time()-t0:.0f} s")
