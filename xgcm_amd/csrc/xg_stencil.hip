@@ -1438,7 +1438,8 @@ int launch_seg_n(const StencilCall& c) {
   // 0.739 -> 0.612 -- four levels per workgroup make five plane streams per XCD; not kept, profiles/r03ah_ab_ys_ext.jsonl)
   if (MET == 0 && V == NV && SEG == 1 && !ck.on && tune().seg_ys && c.g.n_out >= 2 * WPB) {  // K2Sy: y-stacked workgroups
     // (8 waves per workgroup -- 1.125 loads per output row -- measured slower: 0.789 against 0.802, profiles/r03aa_*; two
-    // x-tiles per wave, the scalar row logic paid once per 2 KB: 0.780 -> 0.753, profiles/r03au_ab_k2sy_xt.jsonl)
+    // x-tiles per wave, the scalar row logic paid once per 2 KB: 0.780 -> 0.753, profiles/r03au_ab_k2sy_xt.jsonl; non-temporal
+    // loads for the rows nobody reads again: 0.785 / 0.784, profiles/r03az_ab_k2sy_nt.jsonl)
     const u64 nw = WPB;
     const u64 ngrp = ((u64)c.g.n_out + nw - 1) / nw, per = ngrp * ntile;  // workgroups per outer index
     if (per <= MAX_ITEMS) {
