@@ -1,5 +1,7 @@
 """Host <-> HBM record streaming (xgcm_amd/streaming.py; SURVEY.md §8 f4, first half)."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -235,6 +237,55 @@ def test_mds_and_netcdf_readers_hand_over_the_stored_bytes(tmp_path, dtype):
         list(xio.mds_blocks(short))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_tiled_mds_output_is_assembled_into_global_blocks(tmp_path, dtype):
+    """one file per tile (`<prefix>.<bi>.<bj>.data`, what a run without globalFiles leaves): headers with partial ranges,
+    global blocks assembled from the tiles' memory maps with the stored bytes, ragged last block, rank shards; tiles that
+    are missing, overlap or disagree are refused"""
+    from xgcm_amd import io as xio
+
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((5, 3, 6, 128)).astype(dtype)
+    prefix = str(tmp_path / "T.0000000010")
+    files = xio.write_mds_tiled(prefix, a, (2, 4), fields=["THETA"], timestep=10)
+    assert len(files) == 8 and xio.mds_tile_files(prefix) == sorted(files) and files[0].endswith(".001.001")
+    m = xio.read_mds_meta(files[1] + ".meta", allow_tile=True)  # bi = 2, bj = 1
+    assert m["shape"] == (5, 3, 3, 32) and m["first"] == [33, 1, 1] and m["last"] == [64, 3, 3] and m["global_dims"] == [128, 6, 3]
+    with pytest.raises(NotImplementedError, match="per-tile"):
+        xio.read_mds_meta(files[1] + ".meta")
+    blocks = list(xio.mds_tiled_blocks(prefix, 2))
+    assert [b.shape for b in blocks] == [(2, 3, 6, 128), (2, 3, 6, 128), (1, 3, 6, 128)] and all(not b.dtype.isnative for b in blocks)
+    np.testing.assert_array_equal(np.concatenate(blocks).astype(dtype), a)
+    np.testing.assert_array_equal(np.concatenate(list(xio.mds_tiled_blocks(prefix, 3, records=(1, 4)))).astype(dtype), a[1:4])
+    assert list(xio.mds_tiled_blocks(prefix, 3, records=(2, 2))) == []
+    # a 2-D field (no Nr), one tile per row of tiles
+    b2 = rng.standard_normal((2, 6, 128)).astype(dtype)
+    p2 = str(tmp_path / "Eta.0000000010")
+    xio.write_mds_tiled(p2, b2, (3, 1))
+    np.testing.assert_array_equal(np.concatenate(list(xio.mds_tiled_blocks(p2, 1))).astype(dtype), b2)
+    # refused: no tiles, a missing tile, a tile written twice under another name (overlap), different precision
+    with pytest.raises(FileNotFoundError):
+        list(xio.mds_tiled_blocks(str(tmp_path / "nothing")))
+    import shutil
+    for ext in (".meta", ".data"):
+        shutil.move(files[3] + ext, str(tmp_path / "gone") + ext)
+    with pytest.raises(ValueError, match="96 cells missing"):
+        list(xio.mds_tiled_blocks(prefix))
+    for ext in (".meta", ".data"):
+        shutil.copy(files[0] + ext, prefix + ".009.009" + ext)
+    with pytest.raises(ValueError, match="covered twice"):
+        list(xio.mds_tiled_blocks(prefix))
+    os.remove(prefix + ".009.009.meta")
+    for ext in (".meta", ".data"):
+        shutil.move(str(tmp_path / "gone") + ext, files[3] + ext)
+    with open(files[3] + ".meta") as f:
+        text = f.read()
+    with open(files[3] + ".meta", "w") as f:
+        f.write(text.replace("float32", "floatXX").replace("float64", "float32").replace("floatXX", "float64"))
+    with pytest.raises(ValueError, match="disagrees|holds"):
+        list(xio.mds_tiled_blocks(prefix))
+
+
 def test_mds_header_as_mitgcm_writes_it(tmp_path):
     """the layout of a real mdsio header (comments, blank-padded field names, 3 numbers per line)"""
     from xgcm_amd import io as xio
@@ -262,8 +313,11 @@ def test_operators_streamed_over_mds_and_netcdf_files(tmp_path, dtype):
     want_cum = R.cumsum1d(a, 1, 0, 1, 1, 0, "fill", dtype(0), False, True)
     ops = ((lambda x: dev.stencil1d("diff", x, 3, 1, 0, "periodic"), want_diff),
            (lambda x: dev.cumsum1d(x, 1, 0, 1, 1, 0, "fill", 0.0, False, True), want_cum))
+    tiled = str(tmp_path / "Ttiled.0000000010")
+    xio.write_mds_tiled(tiled, a, (2, 4), fields=["THETA"], timestep=10)  # 8 per-tile files of 3 x 32 cells
     for fn, want in ops:
-        for blocks in (xio.mds_blocks(prefix, 2), xio.netcdf_blocks(path, "Temp", 2), xio.netcdf_blocks(path, "Temp", 5)):
+        for blocks in (xio.mds_blocks(prefix, 2), xio.netcdf_blocks(path, "Temp", 2), xio.netcdf_blocks(path, "Temp", 5),
+                       xio.mds_tiled_blocks(tiled, 2)):
             got = stream_blocks(fn, blocks)
             assert got.dtype == dtype
             np.testing.assert_array_equal(got, want)

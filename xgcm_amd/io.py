@@ -12,8 +12,12 @@ Both store big-endian numbers.  The blocks are handed over AS STORED: `iter_stre
 memory, sends them over PCIe and reverses the byte order on the GPU (`xg_bswap`), so no host core touches the values.
 `MdsWriter` is the matching sink.  Nothing here computes; there is no CPU path to fall back to.
 
-Not covered (say so loudly rather than guess): tiled MDS output (`<prefix>.001.001.data`, one file per tile), NetCDF-4 /
-HDF5, packed variables (`scale_factor` / `add_offset`) -- `netcdf_blocks` refuses those.
+Tiled MDS output (`<prefix>.001.001.data`, one file per tile: what a run without `globalFiles` / `useSingleCpuIO` leaves) is
+assembled by `mds_tiled_blocks`: every tile's records are copied, as stored, into their place in a global block -- a strided
+copy on the host, the one pass over the bytes that the staging copy of `iter_stream` would make anyway.
+
+Not covered (say so loudly rather than guess): NetCDF-4 / HDF5, packed variables (`scale_factor` / `add_offset`) --
+`netcdf_blocks` refuses those; tiles that overlap or leave gaps are refused.
 """
 
 from __future__ import annotations
@@ -24,17 +28,19 @@ from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-__all__ = ["read_mds_meta", "mds_blocks", "MdsWriter", "write_mds", "netcdf_blocks", "netcdf_variable_info"]
+__all__ = ["read_mds_meta", "mds_blocks", "mds_tile_files", "mds_tiled_blocks", "MdsWriter", "write_mds", "write_mds_tiled",
+           "netcdf_blocks", "netcdf_variable_info"]
 
 _PREC = {"float32": ">f4", "float64": ">f8", "real*4": ">f4", "real*8": ">f8"}
 
 
-def read_mds_meta(path: str) -> Dict:
+def read_mds_meta(path: str, allow_tile: bool = False) -> Dict:
     """Parse an MDS `.meta` header: {"shape": (records, [Nr,] Ny, Nx) in C order, "dtype": '>f4' | '>f8',
     "nrecords", "dims" (fastest first, as stored), "fields", "timestep"}.
 
     `dimList` holds one (global extent, first index, last index) triple per dimension, fastest dimension first; a
-    triple that does not span its whole extent means a per-tile file, which is refused."""
+    triple that does not span its whole extent means a per-tile file, which is refused unless `allow_tile`: then "shape" is
+    the TILE's array and "global_dims" / "first" / "last" (fastest first, 1-based inclusive as stored) place it."""
     if not path.endswith(".meta"):
         path = path + ".meta"
     with open(path, "r") as f:
@@ -54,13 +60,18 @@ def read_mds_meta(path: str) -> Dict:
     nums = [int(v) for v in re.findall(r"-?\d+", dim_list)]
     if len(nums) != 3 * nd:
         raise ValueError(f"{path}: dimList has {len(nums)} numbers for nDims = {nd}")
-    dims = []
+    dims, gdims, firsts, lasts = [], [], [], []
     for d in range(nd):
         extent, first, last = nums[3 * d: 3 * d + 3]
-        if first != 1 or last != extent:
+        if not 1 <= first <= last <= extent:
+            raise ValueError(f"{path}: dimension {d} covers {first}..{last} of {extent}")
+        if (first != 1 or last != extent) and not allow_tile:
             raise NotImplementedError(f"{path}: a per-tile MDS file (dimension {d} covers {first}..{last} of {extent}); "
-                                      "only global files are read")
-        dims.append(extent)
+                                      "global files are read by mds_blocks, tiled output by mds_tiled_blocks")
+        dims.append(last - first + 1)
+        gdims.append(extent)
+        firsts.append(first)
+        lasts.append(last)
     key = prec.replace("'", "").replace('"', "").strip().lower()
     if key not in _PREC:
         raise ValueError(f"{path}: unknown dataprec {prec!r}")
@@ -68,7 +79,7 @@ def read_mds_meta(path: str) -> Dict:
     flds = field("fldList")
     step = field("timeStepNumber")
     shape = (nrec,) + tuple(reversed(dims))
-    return {"shape": shape, "dtype": _PREC[key], "nrecords": nrec, "dims": dims,
+    return {"shape": shape, "dtype": _PREC[key], "nrecords": nrec, "dims": dims, "global_dims": gdims, "first": firsts, "last": lasts,
             "fields": [s.strip() for s in re.findall(r"'([^']*)'", flds)] if flds else [],
             "timestep": int(step.split()[0]) if step and step.split() else None}
 
@@ -94,6 +105,63 @@ def mds_blocks(prefix: str, records_per_block: int = 1, records: Optional[Sequen
     mm = np.memmap(base + ".data", dtype=meta["dtype"], mode="r", shape=shape)
     for s in range(lo, hi, records_per_block):
         yield mm[s: min(s + records_per_block, hi)]
+
+
+def mds_tile_files(prefix: str) -> List[str]:
+    """the per-tile files of `<prefix>`: `<prefix>.<bi>.<bj>` (three digits each, without extension), sorted"""
+    import glob
+
+    base = prefix[:-5] if prefix.endswith((".meta", ".data")) else prefix
+    hits = sorted(h[:-5] for h in glob.glob(glob.escape(base) + ".[0-9][0-9][0-9].[0-9][0-9][0-9].meta"))
+    return hits
+
+
+def mds_tiled_blocks(prefix: str, records_per_block: int = 1, records: Optional[Sequence[int]] = None) -> Iterator[np.ndarray]:
+    """Tiled MDS output as GLOBAL record blocks `(n, [Nr,] Ny, Nx)`, big-endian as stored: every tile file
+    `<prefix>.<bi>.<bj>.data` is memory-mapped and its part of a block copied into place (bytes untouched).  The tiles must
+    cover the global (Ny, Nx) domain exactly once and agree on precision, record count and the other dimensions."""
+    if records_per_block < 1:
+        raise ValueError("records_per_block must be >= 1")
+    files = mds_tile_files(prefix)
+    if not files:
+        raise FileNotFoundError(f"no tile files {prefix}.NNN.NNN.meta")
+    tiles = []
+    ref = None
+    for f in files:
+        m = read_mds_meta(f + ".meta", allow_tile=True)
+        key = (m["dtype"], m["nrecords"], tuple(m["global_dims"]), tuple(m["dims"][2:]))
+        if ref is None:
+            ref = key
+        elif key != ref:
+            raise ValueError(f"{f}.meta disagrees with {files[0]}.meta on precision / records / global extents")
+        if any(fi != 1 or la != ex for fi, la, ex in zip(m["first"][2:], m["last"][2:], m["global_dims"][2:])):
+            raise NotImplementedError(f"{f}.meta: tiled along a dimension other than the two fastest")
+        want = int(np.prod(m["shape"])) * np.dtype(m["dtype"]).itemsize
+        have = os.path.getsize(f + ".data")
+        if have != want:
+            raise ValueError(f"{f}.data holds {have} bytes, its header describes {want}")
+        tiles.append((m, np.memmap(f + ".data", dtype=m["dtype"], mode="r", shape=m["shape"])))
+    m0 = tiles[0][0]
+    if len(m0["global_dims"]) < 2:
+        raise ValueError(f"{files[0]}.meta: fewer than two dimensions")
+    gnx, gny = m0["global_dims"][0], m0["global_dims"][1]
+    cover = np.zeros((gny, gnx), dtype=np.uint8)
+    for m, _ in tiles:
+        cover[m["first"][1] - 1: m["last"][1], m["first"][0] - 1: m["last"][0]] += 1
+    if not np.all(cover == 1):
+        raise ValueError(f"{prefix}: the tiles do not cover the {gny} x {gnx} domain exactly once "
+                         f"({int((cover == 0).sum())} cells missing, {int((cover > 1).sum())} covered twice)")
+    nrec = m0["nrecords"]
+    gshape = (nrec,) + tuple(reversed(m0["global_dims"]))
+    lo, hi = (0, nrec) if records is None else (int(records[0]), int(records[1]))
+    if not 0 <= lo <= hi <= nrec:
+        raise ValueError(f"records {lo}..{hi} outside 0..{nrec}")
+    for s in range(lo, hi, records_per_block):
+        e = min(s + records_per_block, hi)
+        blk = np.empty((e - s,) + gshape[1:], dtype=m0["dtype"])
+        for m, mm in tiles:
+            blk[..., m["first"][1] - 1: m["last"][1], m["first"][0] - 1: m["last"][0]] = mm[s:e]
+        yield blk
 
 
 class MdsWriter:
@@ -147,6 +215,37 @@ def write_mds(prefix: str, array: np.ndarray, fields: Sequence[str] = (), timest
     """`array` = (records, [Nr,] Ny, Nx) -> `<prefix>.data` / `.meta` the way MITgcm's `mdsio` writes a global file."""
     with MdsWriter(prefix, fields, timestep) as w:
         w.sink(0, np.asarray(array))
+
+
+def write_mds_tiled(prefix: str, array: np.ndarray, tiles: Tuple[int, int], fields: Sequence[str] = (), timestep: int = 0) -> List[str]:
+    """`array` = (records, [Nr,] Ny, Nx) -> one `<prefix>.<bi>.<bj>.data` / `.meta` pair per tile of a `tiles = (nty, ntx)`
+    decomposition, the way mdsio writes without `globalFiles` (bi counts along X, bj along Y, from 1).  Returns the prefixes."""
+    a = np.asarray(array)
+    nty, ntx = tiles
+    ny, nx = a.shape[-2], a.shape[-1]
+    if ny % nty or nx % ntx:
+        raise ValueError(f"{ny} x {nx} does not divide into {nty} x {ntx} tiles")
+    ty, tx = ny // nty, nx // ntx
+    dt = np.dtype(">f4") if a.dtype == np.float32 else np.dtype(">f8")
+    gdims = list(reversed(a.shape[1:]))
+    out = []
+    for bj in range(nty):
+        for bi in range(ntx):
+            p = f"{prefix}.{bi + 1:03d}.{bj + 1:03d}"
+            sub = a[..., bj * ty: (bj + 1) * ty, bi * tx: (bi + 1) * tx]
+            with open(p + ".data", "wb") as f:
+                f.write(np.ascontiguousarray(sub, dtype=dt).tobytes())
+            rng = [(nx, bi * tx + 1, (bi + 1) * tx), (ny, bj * ty + 1, (bj + 1) * ty)] + [(n, 1, n) for n in gdims[2:]]
+            lines = [f" nDims = [ {len(rng):3d} ];", " dimList = ["]
+            lines += [f" {n:5d}, {fi:5d}, {la:5d}" + ("," if i + 1 < len(rng) else "") for i, (n, fi, la) in enumerate(rng)]
+            lines += [" ];", f" dataprec = [ '{'float32' if dt.itemsize == 4 else 'float64'}' ];",
+                      f" nrecords = [ {a.shape[0]:5d} ];", f" timeStepNumber = [ {int(timestep):10d} ];"]
+            if fields:
+                lines += [f" nFlds = [ {len(fields):4d} ];", " fldList = {", " " + " ".join(f"'{n:<8s}'" for n in fields), " };"]
+            with open(p + ".meta", "w") as f:
+                f.write("\n".join(lines) + "\n")
+            out.append(p)
+    return out
 
 
 def netcdf_variable_info(path: str, name: str) -> Dict:
