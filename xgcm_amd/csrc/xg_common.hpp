@@ -355,6 +355,16 @@ __device__ __forceinline__ void stg(real* p, T v) {
   if (NT) __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
   else *reinterpret_cast<T*>(p) = v;
 }
+// 16-B store with `sc1 nt`: written through AND dropped from the XCD's L2 (plain `nt` keeps the line).  For outputs that
+// nothing in the launch reads again, in kernels whose L2 has better things to hold; measured per kernel (see the callers).
+// Inline asm ends with `s_nop 1`: the compiler pads nothing after an asm store whose source registers it may overwrite next.
+template <typename T>
+__device__ __forceinline__ void stg_drop(real* p, T v) {
+  static_assert(sizeof(T) == 16, "16-byte lane vectors only");
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  const u32x4_ w = __builtin_bit_cast(u32x4_, v);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+}
 
 // x-difference of a V-wide lane given the value just left of it
 __device__ __forceinline__ dv dvdx_of(dv vc, real vl) {

@@ -197,7 +197,10 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
       res[NV - 1] = op2<OP>(a[NV - 1], n);
     }
     if (HAS_MO) res = res / ldm<dv>(m_out, mob + (int64_t)i0 * mo.axis, mo.axis);
-    stg<dv, NTS>(orow + i0, res);
+    // plain operators: the output line is dropped from the L2 as it is written (`sc1 nt`, see stg_drop): +0.6-1.0 points in
+    // three alternating-process rounds, the bench's X operators -1 % (profiles/r03ba_*, r03bb_*); with metrics no clear gain
+    if (NTS && MET == 0) stg_drop<dv>(orow + i0, res);
+    else stg<dv, NTS>(orow + i0, res);
   } else {
     int64_t ql = (int64_t)i0 - pad_lo, qr = (int64_t)i0 + 1 - pad_lo;
     bool fl = false, fr = false;
@@ -1227,7 +1230,8 @@ __global__ __launch_bounds__(NW * WAVE) void k_stencil_strided_ys(
   if (!active) return;
   if (wib > 0) lo = s_row[wib - 1][lane];  // (the wave below is active: its row index is smaller)
   const T a = f0 ? splat<T>(fill) : lo, b = f1 ? splat<T>(fill) : hi;
-  stg<T, NTS>(out + (o * g.n_out + j) * inner + x, op2<OP>(a, b));
+  if (NTS) stg_drop<T>(out + (o * g.n_out + j) * inner + x, op2<OP>(a, b));  // (as in the flat X kernel: +0.5-0.9 points)
+  else stg<T, false>(out + (o * g.n_out + j) * inner + x, op2<OP>(a, b));
 }
 
 // K2Sm: K2S WITH metrics, z-banded and z-shared, Y-STACKED (DESIGN rule 14): the WPB waves of a workgroup are WPB consecutive
