@@ -350,10 +350,20 @@ __device__ __forceinline__ T ldg(const real* p) {
   if (NT) return __builtin_nontemporal_load(reinterpret_cast<const T*>(p));
   return *reinterpret_cast<const T*>(p);
 }
+template <typename T> __device__ __forceinline__ void stg_drop(real* p, T v);
 template <typename T, bool NT>
 __device__ __forceinline__ void stg(real* p, T v) {
+#ifdef XG_STG_DROP_ALL  // experiment builds only: every 16-B non-temporal store of the unit with `sc1 nt`
+  if constexpr (NT && sizeof(T) == 16) { stg_drop<T>(p, v); return; }
+#endif
   if (NT) __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
   else *reinterpret_cast<T*>(p) = v;
+}
+// the store of a kernel that measured faster with dropped output lines (16-B lane vectors; narrower stores stay `nt`)
+template <typename T, bool NT>
+__device__ __forceinline__ void stg_s(real* p, T v) {
+  if constexpr (NT && sizeof(T) == 16) stg_drop<T>(p, v);
+  else stg<T, NT>(p, v);
 }
 // 16-B store with `sc1 nt`: written through AND dropped from the XCD's L2 (plain `nt` keeps the line).  For outputs that
 // nothing in the launch reads again, in kernels whose L2 has better things to hold; measured per kernel (see the callers).

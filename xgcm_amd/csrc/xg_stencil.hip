@@ -358,7 +358,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
     // (measured with the divisor load removed: 78.6 %; with a product in place of the IEEE division: no change --
     // profiles/r02b_ab_bounds.jsonl: the L2-resident metric LOAD is the cost, not the division)
     if (HAS_MO) res = res / wo[um];
-    stg<dv, true>(out + rows[u] * L + i0, res);
+    stg_s<dv, true>(out + rows[u] * L + i0, res);  // (`sc1 nt`: derivative X +0.3 / +0.8 points on two boxes, two metrics +-0)
   }
 }
 
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
       if (u < nrow) {
         T res = op2<OP>(p[u], p[u + 1]);
         if (HAS_MO) res = res / dm[u];
-        stg<T, NTS>(pout + u * inner, res);
+        stg_s<T, NTS>(pout + u * inner, res);  // (`sc1 nt`: diff Z +0.7, derivative Z +1.2, metric_weighted Z +0.3, Y +-0)
       }
     }
   }
@@ -863,7 +863,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
       if (u < nrow) {
         dv res = op2<OP>(tx[u], tx[u + 1]);
         if (MET) res = res / d3[u];
-        stg<dv, NTS>(po + u * nx, res);
+        if (MET) stg<dv, NTS>(po + u * nx, res);
+        else stg_s<dv, NTS>(po + u * nx, res);  // (`sc1 nt`: two-axis interp +1.3 points; with metrics -1.2: those keep `nt`)
       }
   } else {  // Y first, then X on the intermediate
 #pragma unroll
@@ -881,7 +882,8 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
         }
         dv res = opx(ty, fill_edge ? fillx : tn);
         if (MET) res = res / d3[u];
-        stg<dv, NTS>(po + u * nx, res);
+        if (MET) stg<dv, NTS>(po + u * nx, res);
+        else stg_s<dv, NTS>(po + u * nx, res);
       }
     }
   }
@@ -1350,7 +1352,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_ysm(
       if (u < nrow) {
         T res = op2<OP>(p[kz][u], p[kz][u + 1]);
         if (HAS_MO) res = res / dm[u];
-        stg<T, true>(pout + u * inner, res);
+        stg_s<T, true>(pout + u * inner, res);  // (`sc1 nt`: +0.2 points)
       }
     }
   }

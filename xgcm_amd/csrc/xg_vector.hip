@@ -95,7 +95,7 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, co
     }
 #pragma unroll
     for (int k = 0; k < NV; ++k) o[k] = bin2<BOP>(av[k], bv[k]);
-    stg<dv, NTS>(out + gid * NV, o);
+    stg_s<dv, NTS>(out + gid * NV, o);  // (`sc1 nt`, DESIGN rule 16: da / dx +2.8, a * b +2.2 points on one box, +-0 on another)
   } else {
     stg<real, NTS>(out + gid, bin2<BOP>(a[oa], b[ob]));
   }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
         const real left = fill_edge ? fill_x : vl[kz][s_];
         T z = dvdx_of(vv[kz][s_], left) - (uu[kz][s_ + 1] - (s_ == 0 ? u0 : uu[kz][s_]));
         if (HAS_AREA) z = z / ar[s_];
-        stg<T, NTS>(po + s_ * nx, z);
+        stg_s<T, NTS>(po + s_ * nx, z);  // (`sc1 nt`, rule 16: vorticity +4.5, divergence +2.9 points; the two-output kernels keep `nt`)
       }
     }
   }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(BLOCK) void k_divergence(
         const T up = (s_ + 1 < nrow) ? vv[kz][s_ + 1] : top;
         T z = dudx_fwd(uu[kz][s_], right) + (up - vv[kz][s_]);
         if (HAS_AREA) z = z / ar[s_];
-        stg<T, NTS>(po + s_ * nx, z);
+        stg_s<T, NTS>(po + s_ * nx, z);  // (`sc1 nt`, rule 16: vorticity +4.5, divergence +2.9 points; the two-output kernels keep `nt`)
       }
     }
   }
