@@ -5,6 +5,9 @@
 
 namespace {
 
+// (Rows leaving the LDS ring / window as 16-B stores of lane pairs instead of 8-B stores per lane, with and without `sc1 nt`,
+// measured in one process on both lean kernels: -0.4 ... +0.1 points -- the 512-B row stores are not what bounds them.
+// profiles/r03bf_ab_row_store.jsonl)
 // ------------------------------------------------------------------------------------------
 // vertical coordinate transform (next-row f4; reference xgcm/transform.py:15-142, numba gufuncs)
 //
