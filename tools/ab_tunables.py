@@ -43,6 +43,7 @@ def main():
     dz = D.synthetic((nz, 1, 1), 33, 0, 1000.0, 1000.0)
     dy1 = D.synthetic((1, ny, 1), 34, 0, 1000.0, 1000.0)
     U = V = None
+    To = D.synthetic((nz, ny, nx + 1), 3) if "diffYo" in a.cases.split(",") else None
     CASES = {
         "diffX": (lambda: D.stencil1d("diff", T, 2, 1, 0, "periodic"), 16),
         "diffY": (lambda: D.stencil1d("diff", T, 1, 1, 0, "extend"), 16),
@@ -50,6 +51,8 @@ def main():
         "dY": (lambda: D.stencil1d("diff", T, 1, 1, 0, "extend", m_out=dx), 16 + 8 / nz),
         "dZ": (lambda: D.stencil1d("diff", T, 0, 1, 0, "fill", m_out=dz), 16),
         "diffZ": (lambda: D.stencil1d("diff", T, 0, 1, 0, "extend"), 16),
+        "diffXo": (lambda: D.stencil1d("diff", T, 2, 1, 1, "extend"), 16),   # center -> outer: rows of N + 1 cells (K1g)
+        "diffYo": (lambda: D.stencil1d("diff", To, 1, 1, 0, "extend"), 16),  # rows of 3601 cells along Y (K2g)
         "dY3": (lambda: D.stencil1d("diff", T, 1, 1, 0, "extend", m_out=T2), 24),
         "padX": (lambda: D.pad_nd(T, {2: (1, 1)}, {2: "periodic"}, {}), 16),
         "padYX": (lambda: D.pad_nd(T, {1: (0, 1), 2: (2, 0)}, {1: "extend", 2: "fill"}, {2: 1.5}), 16),

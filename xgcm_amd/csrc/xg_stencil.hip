@@ -435,7 +435,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
     }
   }
   if (e0 + NV <= nelem) {
-    stg<dv, NTS>(po, res);
+    stg_s<dv, NTS>(po, res);  // (`sc1 nt`, rule 16: +0.8 points in 3 of 3 rounds; the strided general kernel K2g loses 10 and keeps `nt`)
   } else {
 #pragma unroll
     for (int k = 0; k < NV; ++k)
