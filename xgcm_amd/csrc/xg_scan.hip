@@ -165,6 +165,12 @@ __device__ __forceinline__ void cumsum_strided_body(
     put(g.n_out - 1, h);
   }
 }
+// (K5p, round 3: the march as loader / storer wave PAIRS -- one wave keeps 3 groups of 4 / 5 / 8 rows in flight and drops each
+// landed group into one of two LDS stages, the other adds and stores, one LDS-only barrier per group, vmcnt(16..20) waits in
+// the steady state -- built into the library with every option of the scan, bit-exact on the whole suite, and measured in one
+// process on a slow-kind box: cumsum Z 0.6735 (this march) against 0.662-0.663 for all three shapes, 4 records in one launch
+// 0.748 against 0.740.  The probe's +2.5 points (tools/marchprobe.hip, round 2) were over a single wave WITHOUT the rolling
+// window this march has since.  Removed again; profiles/r03bk_ab_k5p.jsonl, tools/gpu_session_r03bk.sh.)
 template <int V, int MET, bool NTL, bool NTS, int U, bool PIPE = false>
 __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
