@@ -403,8 +403,8 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
         ry = vv * op2<XG_OP_INTERP>(aa[s_], aa[s_ + 1]);
       }
       // (rule 16: the flux runs at 0.77 with `sc1 nt` in every round, with `nt` at 0.77 or 0.70 from process to process; the
-      // gradient -- one input stream, two metric planes to keep in the L2 -- measured -2 / +2 by box and keeps `nt`;
-      // profiles/r03ba_*, r03be_*)
+      // gradient -- one input stream, two metric planes to keep in the L2 -- loses 2 points with `sc1 nt` on either output or on
+      // both (three rounds each, profiles/r03bl_ab_grad_drop.jsonl; r03ba_*; +2 once in r03be_*) and keeps `nt`)
       if (MODE == 1) {
         stg_s<T, NTS>(out_x + base + j * nx + i0, rx);
         stg_s<T, NTS>(out_y + base + j * nx + i0, ry);
