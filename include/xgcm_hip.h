@@ -37,6 +37,9 @@
  *   xg_divergence_f64  the chained (diff(u,X) + diff(v,Y)) / area of docs/ufunc_examples.md, fused
  *   xg_vorticity_f64   the chained (diff(v,X) - diff(u,Y)) / area of docs/ufunc_examples.md
  *                      (one fused pass instead of three apply_ufunc passes, grid.py:798-800 TODO)
+ *   xg_*_i64           the same bodies on integer arrays, which numpy keeps integral and wraps
+ *                      (xgcm/gridops.py:23-24,123-126,172-175,227-278; xgcm/padding.py:610-615)
+ *   xg_convert         numpy's dtype promotion / `astype` around them (int * float metric: xgcm/grid.py:804-808)
  */
 #ifndef XGCM_HIP_H
 #define XGCM_HIP_H
@@ -363,6 +366,60 @@ int xg_stencil2d_metric_f32(int op, const float* in, float* out, const int64_t* 
 /* value formed in float64 exactly as the _f64 variant, then rounded once to float */
 int xg_fill_synthetic_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, double scale,
                           double shift, void* stream);
+
+/* ---- integer variants (int64 lanes, two's complement, wrap-around) ------------------------- */
+/* numpy keeps integer arrays integral through diff / min / max / cumsum / pad and wraps modulo 2^bits
+ * (xgcm/gridops.py:23-24,123-126,172-175,227-278 run in the array's own dtype; xgcm/padding.py:610-615: numpy.pad keeps
+ * it and casts the fill value).  Same kernels, same argument order as the _f64 entry points, with these differences:
+ *   - arithmetic is modulo 2^64; narrower, unsigned and bool arrays are widened to int64 by xg_convert, computed here,
+ *     and narrowed back (wrap modulo 2^bits) -- uint64 shares its bits with int64 for diff / cumsum / pad, and takes
+ *     xg_convert's sign-bit flip around min / max;
+ *   - XG_OP_INTERP returns the wrapped SUM l + r: `(a[1:] + a[:-1]) / 2.0` leaves the integer domain, the host casts
+ *     the sum to the array's dtype width and halves it in float64 (xg_convert with via_type and scale 0.5);
+ *   - metric / weight arguments must be NULL and reductions are plain sums (skipna 0 / 1, no NaN exists): a metric is
+ *     float, numpy promotes `int * float64` BEFORE the operator, so the host converts the field first and runs _f64;
+ *   - XG_BIN_DIV is refused (true division is float);  fill values are int64 (numpy.pad's cast, done by the host). */
+int xg_stencil1d_i64(int op, const int64_t* in, int64_t* out, const int64_t* shape, int ndim, int axis,
+                     int64_t n_out, int pad_lo, int pad_hi, int bc, int64_t fill, const int64_t* m_in,
+                     const int64_t* m_in_strides, const int64_t* m_out, const int64_t* m_out_strides,
+                     void* stream);
+int xg_stencil1d_halo_i64(int op, const int64_t* in, const int64_t* halo, int64_t* out,
+                          const int64_t* shape, int ndim, int axis, int64_t n_out, int pad_lo,
+                          int pad_hi, const int64_t* m_out, const int64_t* m_out_strides, void* stream);
+int xg_cumsum1d_i64(const int64_t* in, int64_t* out, const int64_t* shape, int ndim, int axis,
+                    int reverse, int skipna, int trim_lo, int trim_hi, int pad_lo, int pad_hi,
+                    int bc, int64_t fill, const int64_t* m_in, const int64_t* m_in_strides,
+                    const int64_t* m_out, const int64_t* m_out_strides, void* stream);
+int xg_reduce1d_i64(const int64_t* in, int64_t* out, const int64_t* shape, int ndim, int axis,
+                    int skipna, const int64_t* w, const int64_t* w_strides, void* stream);
+int xg_pad_i64(const int64_t* in, int64_t* out, const int64_t* shape, int ndim, const int64_t* lo,
+               const int64_t* hi, const int* bc, const int64_t* fill, const int* order, void* stream);
+int xg_gather_i64(const int64_t* in, const int64_t* partner, int64_t* out, const int64_t* in_shape,
+                  const int64_t* partner_shape, const int64_t* out_shape, int ndim,
+                  const int* mapped, const int* partner_perm, const int64_t* lo,
+                  const int64_t* tokens, int64_t n_tokens, const int64_t* fills, int n_fills,
+                  void* stream);
+int xg_binary_i64(int op, const int64_t* a, const int64_t* a_strides, const int64_t* b,
+                  const int64_t* b_strides, int64_t* out, const int64_t* shape, int ndim,
+                  void* stream);
+
+/* ---- element type conversion (numpy `astype`) --------------------------------------------- */
+typedef enum xg_dtype {
+  XG_T_BOOL = 0, XG_T_I8 = 1, XG_T_I16 = 2, XG_T_I32 = 3, XG_T_I64 = 4,
+  XG_T_U8 = 5, XG_T_U16 = 6, XG_T_U32 = 7, XG_T_U64 = 8, XG_T_F32 = 9, XG_T_F64 = 10
+} xg_dtype;
+/* dst[i] = (dst_type) src[i] for n contiguous elements, with C / numpy `astype` rules: integer -> integer wraps modulo
+ * 2^bits, integer -> float rounds to nearest, float -> integer truncates toward zero, bool reads / stores `!= 0`.
+ *   via_type  XG_T_* integer type or -1: an integer source value is first wrapped to that type's width and signedness --
+ *             the value the narrow dtype would hold -- so a result computed on int64 lanes leaves as numpy's narrow-dtype
+ *             arithmetic would have it (interp of an int8 array = convert(int64 sums, via int8, to f64, scale 0.5));
+ *   scale     multiplies float destinations after the conversion (1.0: none; a power of two is exact);
+ *   flags     bit 0, 64-bit integer types on both sides: flip the sign bit on the way (uint64 order <-> int64 order, for
+ *             min / max of uint64 arrays through the signed kernels).
+ * This is also numpy's promotion before `int_array * float64_metric` (xgcm/grid.py:804-808,1600).  src == dst is allowed
+ * when the element sizes agree. */
+int xg_convert(const void* src, int src_type, void* dst, int dst_type, uint64_t n, int via_type,
+               double scale, int flags, void* stream);
 
 #ifdef __cplusplus
 }

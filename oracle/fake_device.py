@@ -13,16 +13,24 @@ from . import refimpl as R
 
 
 def asdevice(x, dtype=None):
+    """floats keep their dtype, integer / bool arrays stay integral (numpy computes them in their own dtype; the HIP
+    layer serves them on int64 lanes), anything else -> float64; mirrors device.asdevice"""
     a = np.asarray(x)
     if dtype is None:
-        dtype = np.float32 if a.dtype == np.float32 else np.float64
+        dtype = a.dtype if (a.dtype in (np.float32, np.float64) or a.dtype.kind in "biu") else np.float64
     return np.asarray(a, dtype=dtype, order="C")
 
 
 def _common(*arrays):
-    """float32 only if every operand is float32, else float64 (numpy promotion; mirrors device._common)."""
-    present = [np.asarray(a) for a in arrays if a is not None]
-    return np.float32 if present and all(a.dtype == np.float32 for a in present) else np.float64
+    """the float lanes a mix of operands computes on: numpy's promotion, float32 only where it yields float32
+    (mirrors device._common / xgcm_amd.dtypes.float_of)"""
+    present = [np.asarray(a).dtype for a in arrays if a is not None]
+    rt = np.result_type(*present) if present else np.dtype(np.float64)
+    return np.float32 if rt == np.float32 else np.float64
+
+
+def _is_int(a):
+    return a is not None and np.asarray(a).dtype.kind in "biu"
 
 
 def _cast(dt, *arrays):
@@ -38,16 +46,25 @@ def is_device_array(x):
 
 
 def stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill=0.0, m_in=None, m_out=None):
+    if _is_int(x) and m_in is None:  # numpy's own integer arithmetic is the oracle (wrap-around, dtype, fill cast)
+        x = np.asarray(x)
+        return R.stencil1d(op, x, axis % x.ndim, pad_lo, pad_hi, bc, fill, None, m_out)
     x, m_in, m_out = _cast(_common(x, m_in, m_out), x, m_in, m_out)
     return R.stencil1d(op, x, axis % x.ndim, pad_lo, pad_hi, bc, fill, m_in, m_out)
 
 
 def cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill=0.0, reverse=False, skipna=True, m_in=None, m_out=None):
+    if _is_int(x) and m_in is None:
+        x = np.asarray(x)
+        return R.cumsum1d(x, axis % x.ndim, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, False, None, m_out)
     x, m_in, m_out = _cast(_common(x, m_in, m_out), x, m_in, m_out)
     return R.cumsum1d(x, axis % x.ndim, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, skipna, m_in, m_out)
 
 
 def reduce1d(x, axis, w=None, skipna=True):
+    if _is_int(x) and w is None and isinstance(skipna, (bool, int, np.bool_)):
+        x = np.asarray(x)
+        return np.sum(x, axis=axis % x.ndim)
     x, w = _cast(_common(x, w), x, w)
     if skipna in ("pair_valid", "pair_all"):  # numerator and denominator sums stacked along a new leading dim
         valid = skipna == "pair_valid"
@@ -68,7 +85,10 @@ def pad_nd(x, widths, bc, fill):
 
 
 def stencil1d_halo(op, x, halo, axis, pad_lo, pad_hi, m_out=None):
-    x, halo, m_out = _cast(_common(x, halo, m_out), x, halo, m_out)
+    if _is_int(x) and _is_int(halo):
+        x, halo = np.asarray(x), np.asarray(halo).astype(np.asarray(x).dtype)
+    else:
+        x, halo, m_out = _cast(_common(x, halo, m_out), x, halo, m_out)
     axis = axis % x.ndim
     lo = np.take(halo, range(0, pad_lo), axis=axis)
     hi = np.take(halo, range(pad_lo, pad_lo + pad_hi), axis=axis)
@@ -101,14 +121,21 @@ def upload_tokens(tokens):
 def gather(x, partner, tokens, mapped, lo, out_shape, fills, partner_perm=None):
     from . import topology as T
 
-    if partner is not None:
+    if _is_int(x) and (partner is None or _is_int(partner)) and np.result_type(*[np.asarray(q).dtype for q in (x, partner) if q is not None]).kind in "biu":
+        rt = np.result_type(*[np.asarray(q).dtype for q in (x, partner) if q is not None])
+        x = np.asarray(x).astype(rt)
+        partner = None if partner is None else np.asarray(partner).astype(rt)
+        fills = [np.pad(np.zeros(1, dtype=rt), (1, 0), "constant", constant_values=f)[0] for f in fills]
+    elif partner is not None:
         x, partner = _cast(_common(x, partner), x, partner)
     else:
-        x = asdevice(x)
+        x = asdevice(x, _common(x))
     return T.gather_tokens(x, partner, tokens, mapped, lo, out_shape, fills, partner_perm)
 
 
 def binary(op, a, b):
+    if _is_int(a) and _is_int(b):  # numpy's own integer promotion / wrap-around / true division
+        return R.binary(op, np.asarray(a), np.asarray(b))
     a, b = _cast(_common(a, b), a, b)
     return R.binary(op, a, b)
 

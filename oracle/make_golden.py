@@ -13,7 +13,9 @@ placeholder modules carrying those three names -- no behaviour is stubbed, nothi
 xarray is re-implemented -- and then import the reference's own modules and execute:
 
   * every ``GridUFunc.ufunc`` body in ``xgcm/gridops.py`` (41 of them) on seeded arrays that
-    were padded with ``numpy.pad`` (the routine ``DataArray.pad`` forwards to);
+    were padded with ``numpy.pad`` (the routine ``DataArray.pad`` forwards to): float64 inputs
+    -> ``gridops_vectors.npz``; bool / int8..int64 / uint8..uint64 inputs with wrap-around,
+    2^53 + 1 and 2^62 cases -> ``gridops_vectors_int.npz``;
   * ``_GridUFuncSignature.from_string / equivalent / __str__`` (xgcm/grid_ufunc.py:147-301);
   * ``_select_grid_ufunc`` (xgcm/grid.py:1779-1824);
   * ``iterate_axis_combinations`` (xgcm/metrics.py:4-30);
@@ -107,6 +109,58 @@ def gridops_vectors(gridops, grid_ufunc):
             for bc, mode in modes.items():
                 kw = {"constant_values": 1.25} if mode == "constant" else {}
                 out[f"{name}|{bc}"] = np.pad(r, [(0, 0), (0, 0), (lo, hi)], mode, **kw)
+    return out
+
+
+INT_DTYPES = ("bool", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64")
+INT_FILL = 3.7  # numpy.pad casts the constant to the array's dtype: 3 (True for bool)
+
+
+def int_field(rng, dtype, shape):
+    """seeded integer field with values the float64 lanes would get wrong: the dtype's extremes (wrap-around of
+    diff / interp sums / cumsum), and for the 64-bit types neighbours of 2^53 and 2^62 (not representable in float64)"""
+    dt = np.dtype(dtype)
+    if dt == np.bool_:
+        return rng.integers(0, 2, shape).astype(dt)
+    info = np.iinfo(dt)
+    a = rng.integers(info.min, info.max, shape, dtype=dt, endpoint=True)
+    flat = a.reshape(-1)
+    flat[0], flat[-1] = info.max, info.min
+    if dt.itemsize == 8:
+        specials = [2**53 + 1, 2**53 + 3, 2**62, 2**62 + 1, 2**53 + 5]
+        if dt.kind == "i":
+            specials += [-(2**53 + 1), -(2**62) - 7]
+        else:
+            specials += [2**63 + 11, 2**64 - 2]
+        for k, v in enumerate(specials):
+            flat[3 + 2 * k] = v
+    return a
+
+
+def gridops_vectors_int(gridops, grid_ufunc):
+    """Outputs of every reference ufunc body on seeded INTEGER / bool inputs (numpy keeps them integral through diff /
+    min / max / cumsum / pad and wraps; interp leaves through `/ 2.0`).  A body that raises (diff of bool: numpy refuses
+    boolean subtract) is recorded as a 0-d string array holding the exception's class name."""
+    rng = np.random.default_rng(20260927)
+    out = {}
+    modes = {"periodic": "wrap", "fill": "constant", "extend": "edge"}
+    for name, obj in vars(gridops).items():
+        if not isinstance(obj, grid_ufunc.GridUFunc) or name == "diff_left_to_inner":
+            continue
+        lo, hi = obj.padding_width["X"]
+        for dtype in INT_DTYPES:
+            a = int_field(rng, dtype, (3, 4, 11))
+            out[f"{name}|{dtype}|in"] = a
+            for bc, mode in modes.items():
+                kw = {"constant_values": INT_FILL} if mode == "constant" else {}
+                try:
+                    if obj.pad_before_func:
+                        r = obj.ufunc(np.pad(a, [(0, 0), (0, 0), (lo, hi)], mode, **kw))
+                    else:  # pad after func (cumsum family, gridops.py:221-278): the pad acts on the cumulative values
+                        r = np.pad(obj.ufunc(a), [(0, 0), (0, 0), (lo, hi)], mode, **kw)
+                except TypeError as e:
+                    r = np.array(type(e).__name__)
+                out[f"{name}|{dtype}|{bc}"] = r
     return out
 
 
@@ -523,6 +577,7 @@ def main():
     with open(os.path.join(OUT, "gridops_table.json"), "w") as f:
         json.dump(dispatch_table(gridops, grid_ufunc), f, indent=1)
     np.savez_compressed(os.path.join(OUT, "gridops_vectors.npz"), **gridops_vectors(gridops, grid_ufunc))
+    np.savez_compressed(os.path.join(OUT, "gridops_vectors_int.npz"), **gridops_vectors_int(gridops, grid_ufunc))
     with open(os.path.join(OUT, "signatures.json"), "w") as f:
         json.dump(signature_cases(grid_ufunc), f, indent=1)
     with open(os.path.join(OUT, "select.json"), "w") as f:

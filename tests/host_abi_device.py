@@ -12,6 +12,7 @@ import os
 import numpy as np
 
 from xgcm_amd import _hip
+from xgcm_amd import dtypes as _dt
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(ROOT, "xgcm_amd", "libxgcm_host.so")
@@ -36,16 +37,66 @@ def _check(rc):
 
 
 def _common(*arrays):
-    present = [np.asarray(a) for a in arrays if a is not None]
-    f32 = bool(present) and all(a.dtype == np.float32 for a in present)
-    return (np.float32, "f32") if f32 else (np.float64, "f64")
+    present = [np.asarray(a).dtype for a in arrays if a is not None]
+    f = _dt.float_of(*present)
+    return (np.float32, "f32") if f == np.float32 else (np.float64, "f64")
+
+
+def _is_int(x):
+    return x is not None and _dt.is_integer(np.asarray(x).dtype)
+
+
+def convert(x, dst, via=None, scale=1.0, flip=False):
+    """numpy `astype` through the host build of xg_convert (the product's device.convert over host pointers)"""
+    a = np.ascontiguousarray(x)
+    dst = np.dtype(dst)
+    if a.dtype == dst and via is None and scale == 1.0 and not flip:
+        return a
+    out = np.empty(a.shape, dtype=dst)
+    if out.size:
+        _check(lib().xg_convert(_ptr(a), _hip.DTYPE[a.dtype.name], _ptr(out), _hip.DTYPE[dst.name], a.size,
+                                -1 if via is None else _hip.DTYPE[np.dtype(via).name], float(scale), 1 if flip else 0, None))
+    return out
 
 
 def asdevice(x, dtype=None):
     a = np.asarray(x)
     if dtype is None:
-        dtype = np.float32 if a.dtype == np.float32 else np.float64
-    return np.ascontiguousarray(a, dtype=dtype)
+        if a.dtype in (np.float32, np.float64) or _dt.is_integer(a.dtype):
+            return np.ascontiguousarray(a)
+        dtype = np.float64
+    a = np.ascontiguousarray(a)
+    return a if a.dtype == dtype else convert(a, dtype)
+
+
+def _widen(x, flip=False):
+    a = np.ascontiguousarray(x)
+    if not flip and a.dtype == np.int64:
+        return a
+    if not flip and a.dtype == np.uint64:
+        return a.view(np.int64)
+    return convert(a, np.int64, flip=flip)
+
+
+def _narrow(t, dst, via=None, scale=1.0, flip=False):
+    dst = np.dtype(dst)
+    if via is None and scale == 1.0 and not flip:
+        if dst == np.int64:
+            return t
+        if dst == np.uint64:
+            return t.view(np.uint64)
+    return convert(t, dst, via=via, scale=scale, flip=flip)
+
+
+def _lane_int(value, flip=False):
+    v = int(value) & 0xFFFFFFFFFFFFFFFF
+    if flip:
+        v ^= 0x8000000000000000
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _divide(res, m_out, as_dtype):
+    return res if m_out is None else binary("div", convert(res, as_dtype), m_out)
 
 
 def tohost(x):
@@ -78,6 +129,21 @@ def _strides(m, shape, what):
 
 
 def stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill=0.0, m_in=None, m_out=None):
+    plan = _dt.stencil_plan(op, np.asarray(x).dtype, None if m_in is None else np.asarray(m_in).dtype,
+                            None if m_out is None else np.asarray(m_out).dtype)
+    if plan.lanes == "int":  # the product's device._int_stencil1d over the host build of the *_i64 entry points
+        src = np.asarray(x).dtype
+        t = _widen(x, plan.flip)
+        axis %= t.ndim
+        shape = list(t.shape)
+        oshape = list(shape)
+        oshape[axis] = shape[axis] + pad_lo + pad_hi - 1
+        out = np.empty(oshape, dtype=np.int64)
+        if out.size:
+            fv = _lane_int(_dt.fill_as(src, fill), plan.flip) if (bc == "fill" and (pad_lo or pad_hi)) else 0
+            _check(lib().xg_stencil1d_i64(_hip.OP[op], _ptr(t), _ptr(out), _hip.i64(shape), len(shape), axis, oshape[axis],
+                                          int(pad_lo), int(pad_hi), _hip.BC[bc], fv, None, None, None, None, None))
+        return _divide(_narrow(out, plan.result, via=plan.via, scale=plan.scale, flip=plan.flip), m_out, plan.divide_as)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis %= x.ndim
@@ -97,6 +163,20 @@ def stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill=0.0, m_in=None, m_out=None):
 
 
 def cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill=0.0, reverse=False, skipna=True, m_in=None, m_out=None):
+    if _is_int(x) and m_in is None:
+        res_dt = _dt.cumsum_dtype(np.asarray(x).dtype)
+        t = _widen(x)
+        axis %= t.ndim
+        shape = list(t.shape)
+        oshape = list(shape)
+        oshape[axis] = shape[axis] - trim_lo - trim_hi + pad_lo + pad_hi
+        fv = _lane_int(_dt.fill_as(res_dt, fill)) if (bc == "fill" and (pad_lo or pad_hi)) else 0
+        out = np.empty(oshape, dtype=np.int64)
+        if out.size:
+            _check(lib().xg_cumsum1d_i64(_ptr(t), _ptr(out), _hip.i64(shape), len(shape), axis, int(bool(reverse)), 0,
+                                         int(trim_lo), int(trim_hi), int(pad_lo), int(pad_hi), _hip.BC[bc], fv, None, None,
+                                         None, None, None))
+        return _divide(_narrow(out, res_dt), m_out, None if m_out is None else _dt.float_of(res_dt, np.asarray(m_out).dtype))
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis %= x.ndim
@@ -116,6 +196,15 @@ def cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill=0.0, reverse=Fa
 
 
 def reduce1d(x, axis, w=None, skipna=True):
+    if _is_int(x) and w is None and isinstance(skipna, (bool, int, np.bool_)):
+        res_dt = _dt.cumsum_dtype(np.asarray(x).dtype)
+        t = _widen(x)
+        axis %= t.ndim
+        shape = list(t.shape)
+        out = np.zeros(shape[:axis] + shape[axis + 1:], dtype=np.int64)
+        if out.size and t.size:
+            _check(lib().xg_reduce1d_i64(_ptr(t), _ptr(out), _hip.i64(shape), len(shape), axis, 0, None, None, None))
+        return _narrow(out, res_dt)
     dt, sfx = _common(x, w)
     x = asdevice(x, dt)
     axis %= x.ndim
@@ -131,36 +220,45 @@ def reduce1d(x, axis, w=None, skipna=True):
 
 
 def binary(op, a, b):
-    dt, sfx = _common(a, b)
-    a, b = asdevice(a, dt), asdevice(b, dt)
+    lanes, res_dt = _dt.binary_plan(op, np.asarray(a).dtype, np.asarray(b).dtype)
+    if lanes == "int":
+        dt, sfx = np.int64, "i64"
+        a, b = _widen(a), _widen(b)
+    else:
+        dt, sfx = (np.float32, "f32") if res_dt == np.float32 else (np.float64, "f64")
+        a, b = asdevice(a, dt), asdevice(b, dt)
     shape = [max(sa, sb) if 0 not in (sa, sb) else 0 for sa, sb in zip(a.shape, b.shape)]
     out = np.empty(shape, dtype=dt)
-    if out.size == 0:
-        return out
-    _check(getattr(lib(), "xg_binary_" + sfx)(_hip.BINOP[op], _ptr(a), _hip.i64(_strides(a, shape, "a")), _ptr(b),
-                                             _hip.i64(_strides(b, shape, "b")), _ptr(out), _hip.i64(shape), len(shape), None))
-    return out
+    if out.size:
+        _check(getattr(lib(), "xg_binary_" + sfx)(_hip.BINOP[op], _ptr(a), _hip.i64(_strides(a, shape, "a")), _ptr(b),
+                                                 _hip.i64(_strides(b, shape, "b")), _ptr(out), _hip.i64(shape), len(shape), None))
+    return _narrow(out, res_dt) if lanes == "int" else out
 
 
 def pad_nd(x, widths, bc, fill):
-    dt, sfx = _common(x)
-    x = asdevice(x, dt)
+    src = np.asarray(x).dtype
+    ints = _dt.is_integer(src)
+    if ints:
+        dt, sfx, x = np.int64, "i64", _widen(x)
+    else:
+        dt, sfx = _common(x)
+        x = asdevice(x, dt)
     nd = x.ndim
-    lo, hi, bcv, fv, order = [0] * nd, [0] * nd, [0] * nd, [0.0] * nd, []
+    lo, hi, bcv, fv, order = [0] * nd, [0] * nd, [0] * nd, [0 if ints else 0.0] * nd, []
     for ax, (l, h) in widths.items():
         ax %= nd
         lo[ax], hi[ax] = int(l), int(h)
         bcv[ax] = _hip.BC[bc.get(ax)]
         f = fill.get(ax, 0.0)
-        fv[ax] = 0.0 if f is None else float(f)
+        f = 0.0 if f is None else f
+        fv[ax] = _lane_int(_dt.fill_as(src, f)) if ints else float(f)
         order.append(ax)
     order += [d for d in range(nd) if d not in order]
     out = np.empty([s + l + h for s, l, h in zip(x.shape, lo, hi)], dtype=dt)
-    if out.size == 0:
-        return out
-    _check(getattr(lib(), "xg_pad_" + sfx)(_ptr(x), _ptr(out), _hip.i64(list(x.shape)), nd, _hip.i64(lo), _hip.i64(hi),
-                                          _hip.ints(bcv), _hip.reals(fv, sfx), _hip.ints(order), None))
-    return out
+    if out.size:
+        _check(getattr(lib(), "xg_pad_" + sfx)(_ptr(x), _ptr(out), _hip.i64(list(x.shape)), nd, _hip.i64(lo), _hip.i64(hi),
+                                              _hip.ints(bcv), _hip.reals(fv, sfx), _hip.ints(order), None))
+    return _narrow(out, src) if ints else out
 
 
 def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None, dtype=np.float64):

@@ -129,7 +129,19 @@ for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_cumsum1d", "xg_reduce1d",
     SIGNATURES[_name + "_f32"] = (_res, list(_args) if _name == "xg_fill_synthetic" else
                                   [C.c_float if a is C.c_double else (C.POINTER(C.c_float) if a is _f64p else a) for a in _args])
 
-SUFFIX = {"float64": "f64", "float32": "f32"}
+# int64 twins of the entry points that serve integer arrays (numpy keeps them integral: diff / min / max / cumsum / pad /
+# gather / +,-,*): same argument order, int64 fill values; metric / weight pointers must be NULL (include/xgcm_hip.h)
+_i64p_fill = C.POINTER(C.c_int64)
+for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_cumsum1d", "xg_reduce1d", "xg_pad", "xg_gather", "xg_binary"]:
+    _res, _args = SIGNATURES[_name + "_f64"]
+    SIGNATURES[_name + "_i64"] = (_res, [C.c_int64 if a is C.c_double else (_i64p_fill if a is _f64p else a) for a in _args])
+
+# element types of xg_convert (enum xg_dtype), keyed by numpy dtype name
+DTYPE = {"bool": 0, "int8": 1, "int16": 2, "int32": 3, "int64": 4, "uint8": 5, "uint16": 6, "uint32": 7, "uint64": 8,
+         "float32": 9, "float64": 10}
+SIGNATURES["xg_convert"] = (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int, _vp])
+
+SUFFIX = {"float64": "f64", "float32": "f32", "int64": "i64"}
 
 _lib: Optional[C.CDLL] = None
 
@@ -235,5 +247,7 @@ def reals(values: Optional[Sequence[float]], suffix: str):
     """array of fill values in the C type of the `_f64` / `_f32` entry point"""
     if values is None:
         return None
+    if suffix == "i64":
+        return (C.c_int64 * len(values))(*[int(v) for v in values])
     ctype = C.c_double if suffix == "f64" else C.c_float
     return (ctype * len(values))(*[float(v) for v in values])

@@ -34,9 +34,18 @@
 
 #include "../../include/xgcm_hip.h"
 
-// The file is compiled twice into the same shared library: once with real = double (exports *_f64
-// plus the type-independent helpers) and once with -DXG_F32 (real = float, exports *_f32 only).
-#ifdef XG_F32
+// The file is compiled up to three times into the same shared library: once with real = double (exports *_f64
+// plus the type-independent helpers), once with -DXG_F32 (real = float, exports *_f32 only) and -- the units that
+// serve integer arrays: stencil, scan, pad, the elementwise binary op -- once with -DXG_I64 -fwrapv (real = int64_t,
+// exports *_i64): numpy keeps integer arrays integral through diff / min / max / cumsum / pad (xgcm/gridops.py:23-24,
+// 123-126,172-175,227-278; xgcm/padding.py:610-615) and wraps modulo 2^bits, so the same kernels run on two's-complement
+// int64 lanes (narrower and unsigned types are widened / narrowed by xg_convert).  Differences of that build: no
+// metrics (a metric is a float: numpy promotes before the operator, the host converts first), XG_OP_INTERP returns the
+// wrapped SUM l + r (the host halves it after the cast to float64, `(a + b) / 2.0`), NaN handling is a no-op.
+#if defined(XG_I64)
+typedef int64_t real;
+#define XG_FN(name) name##_i64
+#elif defined(XG_F32)
 typedef float real;
 #define XG_FN(name) name##_f32
 #else
@@ -376,6 +385,15 @@ __device__ __forceinline__ void stg_drop(real* p, T v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
 
+// what a chained scan passes on after giving up on a hand-off (the launch is redone by the rescue kernel either way)
+__device__ __forceinline__ real poison_value() {
+#ifdef XG_I64
+  return real(0x7ff8dead7ff8deadll);
+#else
+  return real(__builtin_nan(""));
+#endif
+}
+
 // x-difference of a V-wide lane given the value just left of it
 __device__ __forceinline__ dv dvdx_of(dv vc, real vl) {
   dv o;
@@ -386,6 +404,7 @@ __device__ __forceinline__ dv dvdx_of(dv vc, real vl) {
 }
 __device__ __forceinline__ real dvdx_of(real vc, real vl) { return vc - vl; }
 // two-point interpolation of a lane vector towards its LEFT neighbour `tl`: (t[k-1] + t[k]) / 2
+#ifndef XG_I64
 __device__ __forceinline__ dv interp_left_of(dv tc, real tl) {
   dv o;
   o[0] = (tl + tc[0]) * real(0.5);
@@ -394,6 +413,7 @@ __device__ __forceinline__ dv interp_left_of(dv tc, real tl) {
   return o;
 }
 __device__ __forceinline__ real interp_left_of(real tc, real tl) { return (tl + tc) * real(0.5); }
+#endif
 // forward difference of a lane vector whose RIGHT neighbour is `ur`: (u[k+1] - u[k])
 __device__ __forceinline__ dv dudx_fwd(dv uc, real ur) {
   dv o;
@@ -408,9 +428,15 @@ __device__ __forceinline__ real dudx_fwd(real uc, real ur) { return ur - uc; }
 template <int OP>
 __device__ __forceinline__ real op2(real l, real r) {
   if (OP == XG_OP_DIFF) return r - l;
+#ifdef XG_I64
+  if (OP == XG_OP_INTERP) return l + r;  // the wrapped sum; halved by the host after the conversion to float64
+  if (OP == XG_OP_MIN) return l < r ? l : r;
+  return l > r ? l : r;
+#else
   if (OP == XG_OP_INTERP) return (l + r) * real(0.5);  // == (l + r) / 2.0 bit for bit
   if (OP == XG_OP_MIN) return (l < r || l != l) ? l : r;  // NaN-propagating like np.min
   return (l > r || l != l) ? l : r;
+#endif
 }
 template <int OP> __device__ __forceinline__ dv op2(dv l, dv r) {
   dv o;
@@ -536,7 +562,7 @@ __device__ __forceinline__ real dpp_lane(real v) {
   const u64 b = __builtin_bit_cast(u64, v);
   const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, CTRL, 0xf, 0xf, false);
   const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), CTRL, 0xf, 0xf, false);
-  return __builtin_bit_cast(double, (u64)lo | ((u64)hi << 32));
+  return __builtin_bit_cast(real, (u64)lo | ((u64)hi << 32));
 #endif
 }
 __device__ __forceinline__ real from_lane_below(real v) { return dpp_lane<0x138>(v); }  // wave_shr:1

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/xgcm_hip.h"
@@ -75,7 +76,9 @@ template <typename R>
 R op2(int op, R l, R r) {
   switch (op) {
     case XG_OP_DIFF: return r - l;
-    case XG_OP_INTERP: return (l + r) / R(2);
+    case XG_OP_INTERP:
+      if constexpr (std::is_integral_v<R>) return l + r;  // _i64: the wrapped sum, halved by the caller in float64
+      else return (l + r) / R(2);
     case XG_OP_MIN: return (l != l || r != r) ? (l != l ? l : r) : (l < r ? l : r);  // NaN-propagating like np.min
     default: return (l != l || r != r) ? (l != l ? l : r) : (l > r ? l : r);
   }
@@ -91,6 +94,7 @@ int stencil1d(int op, const R* in, const R* halo, R* out, const int64_t* shape, 
   if ((pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "pad widths must be 0 or 1, got (%d,%d)", pad_lo, pad_hi);
   if (bc < XG_BC_NONE || bc > XG_BC_HALO) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
   if ((m_in && !mis) || (m_out && !mos)) return fail(XG_ERR_INVALID, "metric without strides");
+  if (std::is_integral_v<R> && (m_in || m_out)) return fail(XG_ERR_UNSUPPORTED, "integer stencils take no metrics: convert to float64 first");
   View v;
   if (int rc = make_view(shape, ndim, axis, &v)) return rc;
   if (n_out != v.n + pad_lo + pad_hi - 1)
@@ -137,6 +141,7 @@ int cumsum1d(const R* in, R* out, const int64_t* shape, int ndim, int axis, int 
   if (bc < XG_BC_NONE || bc > XG_BC_EXTEND) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
   if ((pad_lo || pad_hi) && bc == XG_BC_NONE) return fail(XG_ERR_INVALID, "halo cells requested but no boundary mode given");
   if ((m_in && !mis) || (m_out && !mos)) return fail(XG_ERR_INVALID, "metric without strides");
+  if (std::is_integral_v<R> && (m_in || m_out)) return fail(XG_ERR_UNSUPPORTED, "integer scans take no metrics: convert to float64 first");
   View v;
   if (int rc = make_view(shape, ndim, axis, &v)) return rc;
   const int64_t kept = v.n - trim_lo - trim_hi;
@@ -175,6 +180,7 @@ int reduce1d(const R* in, R* out, const int64_t* shape, int ndim, int axis, int 
   if (!in || !out) return fail(XG_ERR_INVALID, "NULL array argument");
   if (w && !ws) return fail(XG_ERR_INVALID, "weight without strides");
   if (skipna < 0 || skipna > 7) return fail(XG_ERR_INVALID, "skipna / count / mean mode %d not in [0,7]", skipna);
+  if (std::is_integral_v<R> && (w || skipna > 1)) return fail(XG_ERR_UNSUPPORTED, "integer reductions are plain sums: weights and means are float");
   View v;
   if (int rc = make_view(shape, ndim, axis, &v)) return rc;
   // one sequential sum per output cell in the given mode (k = 0 .. n-1 in order: numpy's order over a non-last axis)
@@ -249,6 +255,7 @@ template <typename R>
 int binary(int op, const R* a, const int64_t* sa, const R* b, const int64_t* sb, R* out, const int64_t* shape, int ndim) {
   if (!a || !b || !out || !shape || !sa || !sb) return fail(XG_ERR_INVALID, "NULL argument");
   if (op < XG_BIN_MUL || op > XG_BIN_SUB) return fail(XG_ERR_INVALID, "unknown binary op %d", op);
+  if (std::is_integral_v<R> && op == XG_BIN_DIV) return fail(XG_ERR_UNSUPPORTED, "true division leaves the integer domain: convert to float64 first");
   if (ndim < 1 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [1,%d]", ndim, XG_MAX_NDIM);
   int64_t total = 1;
   for (int d = 0; d < ndim; ++d) total *= shape[d];
@@ -261,7 +268,8 @@ int binary(int op, const R* a, const int64_t* sa, const R* b, const int64_t* sb,
       ob += c * sb[d];
     }
     const R x = a[oa], y = b[ob];
-    out[i] = op == XG_BIN_MUL ? x * y : op == XG_BIN_DIV ? x / y : op == XG_BIN_ADD ? x + y : x - y;
+    if constexpr (std::is_integral_v<R>) out[i] = op == XG_BIN_MUL ? x * y : op == XG_BIN_ADD ? x + y : x - y;
+    else out[i] = op == XG_BIN_MUL ? x * y : op == XG_BIN_DIV ? x / y : op == XG_BIN_ADD ? x + y : x - y;
   }
   return XG_OK;
 }
@@ -398,12 +406,15 @@ int xg_event_destroy(void* ev) { free(ev); return XG_OK; }
                       const int64_t* shape, int ndim, void*) {                                                        \
     return binary<R>(op, a, sa, b, sb, out, shape, ndim);                                                             \
   }                                                                                                                   \
-  int xg_fill_synthetic_##SFX(R* out, int64_t n, uint64_t seed, uint64_t offset, double scale, double shift, void*) { \
-    return fill_synthetic<R>(out, n, seed, offset, scale, shift);                                                     \
-  }                                                                                                                   \
   int xg_gather_##SFX(const R*, const R*, R*, const int64_t*, const int64_t*, const int64_t*, int, const int*,        \
                       const int*, const int64_t*, const int64_t*, int64_t, const R*, int, void*) {                    \
     return unsupported("xg_gather");                                                                                  \
+  }
+
+// the float-only entry points (synthetic generator; fused / transform stubs)
+#define XG_HOST_FLOAT(SFX, R)                                                                                         \
+  int xg_fill_synthetic_##SFX(R* out, int64_t n, uint64_t seed, uint64_t offset, double scale, double shift, void*) { \
+    return fill_synthetic<R>(out, n, seed, offset, scale, shift);                                                     \
   }                                                                                                                   \
   int xg_transform_linear_##SFX(const R*, const R*, const int64_t*, const R*, const int64_t*, int64_t, R*,            \
                                 const int64_t*, int, int, int, int, int, void*) {                                     \
@@ -454,5 +465,63 @@ int xg_event_destroy(void* ev) { free(ev); return XG_OK; }
 
 XG_HOST_TYPED(f64, double)
 XG_HOST_TYPED(f32, float)
+XG_HOST_TYPED(i64, int64_t)  // built with -fwrapv: overflow wraps like numpy's integer arithmetic
+XG_HOST_FLOAT(f64, double)
+XG_HOST_FLOAT(f32, float)
+
+// numpy `astype` between the storage dtype and the compute dtype (see the header); one element at a time
+int xg_convert(const void* src, int st, void* dst, int dt, uint64_t n, int via, double scale, int flags, void*) {
+  if (st < XG_T_BOOL || st > XG_T_F64 || dt < XG_T_BOOL || dt > XG_T_F64) return fail(XG_ERR_INVALID, "unknown element type (%d -> %d)", st, dt);
+  if (via < -1 || via > XG_T_U64) return fail(XG_ERR_INVALID, "via_type %d is not an integer type", via);
+  if (flags & ~1) return fail(XG_ERR_INVALID, "unknown flags %d", flags);
+  if (n == 0) return XG_OK;
+  if (!src || !dst) return fail(XG_ERR_INVALID, "NULL array argument");
+  const bool sf = st >= XG_T_F32, df = dt >= XG_T_F32;
+  if (sf && via != -1) return fail(XG_ERR_INVALID, "via_type applies to integer sources only");
+  auto bytes = [](int t) { return (t == XG_T_BOOL || t == XG_T_I8 || t == XG_T_U8) ? 1 : (t == XG_T_I16 || t == XG_T_U16) ? 2 : (t == XG_T_I32 || t == XG_T_U32 || t == XG_T_F32) ? 4 : 8; };
+  if ((flags & 1) && (bytes(st) != 8 || bytes(dt) != 8 || sf || df)) return fail(XG_ERR_INVALID, "the sign-bit flip needs 64-bit integer types on both sides");
+  auto wrap = [](int64_t w, int t) -> int64_t {
+    switch (t) {
+      case XG_T_BOOL: return w != 0;
+      case XG_T_I8: return (int8_t)w;   case XG_T_I16: return (int16_t)w;  case XG_T_I32: return (int32_t)w;
+      case XG_T_U8: return (uint8_t)w;  case XG_T_U16: return (uint16_t)w; case XG_T_U32: return (uint32_t)w;
+      default: return w;
+    }
+  };
+  const int logical = via != -1 ? via : st;
+  for (uint64_t i = 0; i < n; ++i) {
+    int64_t w = 0;
+    double f = 0.0;
+    switch (st) {  // load
+      case XG_T_BOOL: w = ((const uint8_t*)src)[i] != 0; break;
+      case XG_T_I8: w = ((const int8_t*)src)[i]; break;     case XG_T_I16: w = ((const int16_t*)src)[i]; break;
+      case XG_T_I32: w = ((const int32_t*)src)[i]; break;   case XG_T_I64: w = ((const int64_t*)src)[i]; break;
+      case XG_T_U8: w = ((const uint8_t*)src)[i]; break;    case XG_T_U16: w = ((const uint16_t*)src)[i]; break;
+      case XG_T_U32: w = ((const uint32_t*)src)[i]; break;  case XG_T_U64: w = (int64_t)((const uint64_t*)src)[i]; break;
+      case XG_T_F32: f = ((const float*)src)[i]; break;     default: f = ((const double*)src)[i]; break;
+    }
+    if (!sf) w = wrap(w, via);
+    if (df) {  // float destination
+      if (dt == XG_T_F32) {
+        const float v = sf ? (float)f : (logical == XG_T_U64 ? (float)(uint64_t)w : (float)w);
+        ((float*)dst)[i] = v * (float)scale;
+      } else {
+        const double v = sf ? f : (logical == XG_T_U64 ? (double)(uint64_t)w : (double)w);
+        ((double*)dst)[i] = v * scale;
+      }
+      continue;
+    }
+    if (sf) w = (dt == XG_T_U64) ? (int64_t)(uint64_t)f : (int64_t)f;
+    if (dt == XG_T_BOOL) { ((uint8_t*)dst)[i] = sf ? (f != 0.0) : (w != 0); continue; }
+    if (flags & 1) w ^= (int64_t)0x8000000000000000ull;
+    switch (dt) {
+      case XG_T_I8: ((int8_t*)dst)[i] = (int8_t)w; break;     case XG_T_I16: ((int16_t*)dst)[i] = (int16_t)w; break;
+      case XG_T_I32: ((int32_t*)dst)[i] = (int32_t)w; break;  case XG_T_I64: ((int64_t*)dst)[i] = w; break;
+      case XG_T_U8: ((uint8_t*)dst)[i] = (uint8_t)w; break;   case XG_T_U16: ((uint16_t*)dst)[i] = (uint16_t)w; break;
+      case XG_T_U32: ((uint32_t*)dst)[i] = (uint32_t)w; break; default: ((uint64_t*)dst)[i] = (uint64_t)w; break;
+    }
+  }
+  return XG_OK;
+}
 
 }  // extern "C"

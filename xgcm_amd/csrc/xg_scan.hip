@@ -27,7 +27,11 @@ struct ScanArgs {
   real fill;
 };
 
+#ifdef XG_I64
+__device__ __forceinline__ real nan0(real v) { return v; }  // integers hold no NaN
+#else
 __device__ __forceinline__ real nan0(real v) { return (v != v) ? real(0) : v; }
+#endif
 __device__ __forceinline__ dv nan0(dv v) {
   dv o;
 #pragma unroll
@@ -41,7 +45,11 @@ __device__ __forceinline__ hv nan0(hv v) { hv o; o[0] = nan0(v[0]); o[1] = nan0(
 // reduction input modes beyond plain / NaN-skipping sums (xg_reduce1d `skipna` argument):
 // 2: every valid (non-NaN) cell counts as 1, NaN cells as 0 -> sum of the weights of the valid cells,
 // 3: every cell counts as 1 -> sum of the weights (the two denominators of a weighted mean)
+#ifdef XG_I64
+__device__ __forceinline__ real as_count(real, int) { return real(1); }
+#else
 __device__ __forceinline__ real as_count(real v, int mode) { return (mode == 3 || v == v) ? real(1) : real(0); }
+#endif
 #ifdef XG_F32
 __device__ __forceinline__ hv as_count(hv v, int mode) { hv o; o[0] = as_count(v[0], mode); o[1] = as_count(v[1], mode); return o; }
 #endif
@@ -241,7 +249,7 @@ template <> __device__ __forceinline__ u32x4 chain_pack<real>(real v, u32 ep) {
 }
 template <> __device__ __forceinline__ real chain_unpack<real>(u32x4 s) {
   const u64 b = (u64)s[0] | ((u64)s[2] << 32);
-  return __builtin_bit_cast(double, b);
+  return __builtin_bit_cast(real, b);
 }
 #endif
 
@@ -294,7 +302,7 @@ __device__ __forceinline__ T chain_wait(const u32x4* src, u32 want, const ChainA
   if (got[1] != want || got[3] != want) {
     __hip_atomic_store(ch.poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(ch.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return splat<T>(real(__builtin_nan("")));
+    return splat<T>(poison_value());
   }
   return chain_unpack<T>(got);
 }
@@ -453,7 +461,7 @@ __device__ __forceinline__ real dpp_take(real v) {
   const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, CTRL, ROW_MASK, 0xf, false);
   const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), CTRL, ROW_MASK, 0xf, false);
   const u64 r = (u64)lo | ((u64)hi << 32);
-  return __builtin_bit_cast(double, r);
+  return __builtin_bit_cast(real, r);
 #endif
 }
 __device__ __forceinline__ real wave_scan_dpp(real s) {
@@ -1421,6 +1429,9 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
   if (bc < XG_BC_NONE || bc > XG_BC_EXTEND) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
   if ((pad_lo || pad_hi) && bc == XG_BC_NONE) return fail(XG_ERR_INVALID, "halo cells requested but no boundary mode given");
   if ((m_in && !m_in_strides) || (m_out && !m_out_strides)) return fail(XG_ERR_INVALID, "metric without strides");
+#ifdef XG_I64
+  if (m_in || m_out) return fail(XG_ERR_UNSUPPORTED, "integer scans take no metrics: convert to float64 first (numpy promotes int * float)");
+#endif
   if (axis < 0 || axis >= ndim) return fail(XG_ERR_INVALID, "axis out of range");
   const int64_t n = shape[axis];
   const int64_t n_out = n - trim_lo - trim_hi + pad_lo + pad_hi;
@@ -1516,9 +1527,9 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
     }
     const int su = (met & 2) ? (tune().scan_u < 8 ? tune().scan_u : 8) : tune().scan_u;
     const int pipe = (tune().scan_pipe && nts && tune().nt_load) ? (deep ? (su >= 32 ? 32 : su >= 24 ? 24 : su >= 16 ? 16 : 8) : (tune().scan_pipe >= 2 ? 8 : 0)) : 0;
-#define XG_PL(V_, M, U_) hipLaunchKernelGGL((k_cumsum_strided<V_, M, true, true, U_, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band | (tune().scan_pace << 1))
-#define XG_GL(V_, M, NTL_, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band | (tune().scan_pace << 1)); \
-                               else hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, tune().march_band | (tune().scan_pace << 1)); } while (0)
+#define XG_PL(V_, M, U_) hipLaunchKernelGGL((k_cumsum_strided<V_, M, true, true, U_, true>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, (tune().march_band ? 1 : 0) | (tune().scan_pace ? 2 : 0))
+#define XG_GL(V_, M, NTL_, NTS) do { if (deep) hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 16>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, (tune().march_band ? 1 : 0) | (tune().scan_pace ? 2 : 0)); \
+                               else hipLaunchKernelGGL((k_cumsum_strided<V_, M, NTL_, NTS, 4>), dim3((u32)nblocks), dim3(BLOCK), march_lds(), st, in, out, g, ntile, a, m_in, mi, m_out, mo, (tune().march_band ? 1 : 0) | (tune().scan_pace ? 2 : 0)); } while (0)
 #define XG_GO(V_, M, NTS) do { if (tune().nt_load) XG_GL(V_, M, true, NTS); else XG_GL(V_, M, false, NTS); } while (0)
 #define XG_M(V_, M) do { if (pipe == 32) XG_PL(V_, M, 32); else if (pipe == 24) XG_PL(V_, M, 24); else if (pipe == 16) XG_PL(V_, M, 16); else if (pipe == 8) XG_PL(V_, M, 8); \
                          else if (nts) XG_GO(V_, M, true); else XG_GO(V_, M, false); } while (0)
@@ -1542,6 +1553,9 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
   if (w && !w_strides) return fail(XG_ERR_INVALID, "weight without strides");
   if (skipna < 0 || skipna > 7) return fail(XG_ERR_INVALID, "skipna / count / mean mode %d not in [0,7]", skipna);
+#ifdef XG_I64
+  if (w || skipna > 1) return fail(XG_ERR_UNSUPPORTED, "integer reductions are plain sums: weights and means are float (convert first)");
+#endif
   Geo g; MIdx mw;
   int rc = build_geo(shape, ndim, axis, 1, w ? w_strides : nullptr, nullptr, &g, &mw, nullptr);
   if (rc) return rc;
@@ -1579,10 +1593,8 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     // profiles/r03ao_ab_f32_narrow4.jsonl)
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
     const u64 ntask = (u64)ntile * (u64)g.outer;
-    const u64 nblocks = tune().march_band ? (((ntask + WPB - 1) / WPB + 7) / 8) * 8 : (ntask + WPB - 1) / WPB;
-    if ((rc = check_grid(nblocks))) return rc;
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
-    int rband = tune().march_band & 1;
+    int rband = tune().march_band ? 1 : 0;
     // one weight per row (no inner stride: drF(Z) under (Z, Y, X), dy(Y) under (Z, Y, X)): scalar loads, nothing rides
     // in the window -- the march then streams like the unweighted one (sum along Y 55 -> 78 %; the chain below: 62 %)
     bool wu = w && tune().met_scalar && g.outer < 0xffffffffll;
@@ -1597,6 +1609,10 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
         if (mw.outer[d] != 0) shared = false;
       if (shared && g.outer >= 2) rband |= 2;
     }
+    // any banded order walks ceil(grid / 8) workgroups per XCD band: the grid must be a multiple of 8 whenever `rband` is
+    // non-zero, also when only the outer-fastest order (bit 1) asked for it (march_band = 0, march_ofast = 1)
+    const u64 nblocks = rband ? (((ntask + WPB - 1) / WPB + 7) / 8) * 8 : (ntask + WPB - 1) / WPB;
+    if ((rc = check_grid(nblocks))) return rc;
     if (w && !wu && tune().scan_chain && tune().nt_load && g.inner % HV == 0 && (reinterpret_cast<uintptr_t>(in) & 7u) == 0 &&
         (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (HV == 1 || vec_metric_ok(g, true))) {
       bool shared_w = true;
@@ -1628,6 +1644,9 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
         }
       }
       bool chained = false;
+      u32 rtile = 0;
+      u64 rblocks = 0;
+      if ((rc = rescue_grid(g, &rtile, &rblocks))) return rc;  // before any chained launch: a chain never runs without its twin
       const int zl = tune().reduce_zl;  // levels per task sharing the weight rows (K4cz); 1: K4c
       // (measured: 2 levels x 16 rows 61-63 %, 3 x 16 59 %, 4 x 16 55 %, 4 x 8 59 %, 2 x 32 50 %, K4c 56-57 %, the march 51 %)
       if (shared_w && zl >= 2 && g.outer >= 2 && chain_plan(g, 16, skipna >= 4 ? 2 : 1, shared_w, stream, &ch, &ctile, &nblk, zl >= 4 ? 4 : 2)) {
@@ -1641,9 +1660,6 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
         chained = true;
       }
       if (chained) {  // the marching twin, run-if poisoned (k_reduce_rescue)
-        u32 rtile = 0;
-        u64 rblocks = 0;
-        if ((rc = rescue_grid(g, &rtile, &rblocks))) return rc;
         const Rescue rs = {ch.poison, ch.gave_up, reinterpret_cast<u32x4*>(ch.slots), ch.nslot};
         hipLaunchKernelGGL(k_reduce_rescue, dim3((u32)rblocks), dim3(BLOCK), 0, st, in, out, g, rtile, skipna, w, mw, 1, rs);
         XG_LAUNCH_CHECK();

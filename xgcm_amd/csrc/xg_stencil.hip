@@ -1544,6 +1544,9 @@ int launch_strided_gen(const StencilCall& c) {
 }
 template <int OP>
 int strided_gen_met(int met, const StencilCall& c) {
+#ifdef XG_I64  // integer build: no metrics (stencil1d_impl refuses them)
+  return launch_strided_gen<OP, 0>(c);
+#endif
   switch (met) {
     case 0: return launch_strided_gen<OP, 0>(c);
     case 1: return launch_strided_gen<OP, 1>(c);
@@ -1570,6 +1573,9 @@ int stencil_kind(int kind, const StencilCall& c) {
 }
 template <int OP, int V>
 int stencil_met(int met, int kind, const StencilCall& c) {
+#ifdef XG_I64
+  return stencil_kind<OP, V, 0>(kind, c);
+#endif
   switch (met) {
     case 0: return stencil_kind<OP, V, 0>(kind, c);
     case 1: return stencil_kind<OP, V, 1>(kind, c);
@@ -1596,6 +1602,7 @@ int stencil_dispatch(int op, int V, int met, int kind, const StencilCall& c) {
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
+#ifndef XG_I64  // two axes in one pass: float builds only (integer interp leaves the integer domain between the axes)
 static int stencil2d_impl(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,
                           int padx_lo, int padx_hi, int bc_x, real fill_x, int pady_lo, int pady_hi, int bc_y,
                           real fill_y, const real* m1, const real* m2, const real* m3, void* stream) {
@@ -1669,6 +1676,7 @@ static int stencil2d_impl(int op, const real* in, real* out, const int64_t* shap
   XG_LAUNCH_CHECK();
   return XG_OK;
 }
+#endif  // !XG_I64
 
 
 extern "C" {
@@ -1684,6 +1692,9 @@ static int stencil1d_impl(int op, const real* in, const real* halo, real* out, c
   if (bc == XG_BC_HALO && !halo) return fail(XG_ERR_INVALID, "XG_BC_HALO without a halo buffer");
   if (bc == XG_BC_HALO && m_in) return fail(XG_ERR_UNSUPPORTED, "pre-gathered halos cannot be combined with an input metric");
   if ((m_in && !m_in_strides) || (m_out && !m_out_strides)) return fail(XG_ERR_INVALID, "metric without strides");
+#ifdef XG_I64
+  if (m_in || m_out) return fail(XG_ERR_UNSUPPORTED, "integer stencils take no metrics: convert to float64 first (numpy promotes int * float)");
+#endif
   Geo g; MIdx mi, mo;
   int rc = build_geo(shape, ndim, axis, n_out, m_in ? m_in_strides : nullptr, m_out ? m_out_strides : nullptr, &g, &mi, &mo);
   if (rc) return rc;
@@ -1740,6 +1751,7 @@ int XG_FN(xg_stencil1d_halo)(int op, const real* in, const real* halo, real* out
                         stream);
 }
 
+#ifndef XG_I64
 int XG_FN(xg_stencil2d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,
                      int padx_lo, int padx_hi, int bc_x, real fill_x, int pady_lo, int pady_hi, int bc_y,
                      real fill_y, void* stream) {
@@ -1754,5 +1766,6 @@ int XG_FN(xg_stencil2d_metric)(int op, const real* in, real* out, const int64_t*
   return stencil2d_impl(op, in, out, shape, ndim, order, padx_lo, padx_hi, bc_x, fill_x, pady_lo, pady_hi, bc_y, fill_y,
                         m_in, m_mid, m_out, stream);
 }
+#endif  // !XG_I64
 
 }  // extern "C"

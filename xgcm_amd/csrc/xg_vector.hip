@@ -26,7 +26,9 @@ struct BinGeo {
 
 template <int BOP> __device__ __forceinline__ real bin2(real a, real b) {
   if (BOP == XG_BIN_MUL) return a * b;
+#ifndef XG_I64
   if (BOP == XG_BIN_DIV) return a / b;
+#endif
   if (BOP == XG_BIN_ADD) return a + b;
   return a - b;
 }
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, co
   }
 }
 
+#ifndef XG_I64  // the fused two-component operators divide by / multiply with float metrics: float builds only
 // ------------------------------------------------------------------------------------------
 // K7: fused relative vorticity ((v[j,i]-v[j,i-1]) - (u[j,i]-u[j-1,i])) / area, view (outer,Y,X).
 // Same shape as K2S: lanes along X (V=2 when nx even), XCD-banded waves, each wave register-marches
@@ -416,6 +419,8 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
   }
 }
 
+#endif  // !XG_I64
+
 }  // namespace
 
 // ==========================================================================================
@@ -427,6 +432,9 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
                   real* out, const int64_t* shape, int ndim, void* stream) {
   if (!a || !b || !out || (ndim > 0 && (!shape || !a_strides || !b_strides))) return fail(XG_ERR_INVALID, "NULL argument");
   if (op < XG_BIN_MUL || op > XG_BIN_SUB) return fail(XG_ERR_INVALID, "unknown binary op %d", op);
+#ifdef XG_I64
+  if (op == XG_BIN_DIV) return fail(XG_ERR_UNSUPPORTED, "true division leaves the integer domain: convert to float64 first");
+#endif
   if (ndim < 0 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [0,%d]", ndim, XG_MAX_NDIM);
   BinGeo g;
   memset(&g, 0, sizeof(g));
@@ -497,6 +505,7 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
   return XG_OK;
 }
 
+#ifndef XG_I64
 static int curl_div_impl(bool div, const real* u, const real* v, const real* area, const int64_t* area_strides,
                          real* out, const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y,
                          void* stream, const real* halo_x = nullptr, const real* halo_y = nullptr) {
@@ -730,5 +739,7 @@ int XG_FN(xg_flux_halo)(const real* u, const real* v, const real* t, const real*
   return pair2d_impl(1, t, u, v, out_x, out_y, shape, ndim, bc_x, fill_x, bc_y, fill_y, nullptr, nullptr, nullptr, nullptr,
                      stream, halo_x, halo_y);
 }
+
+#endif  // !XG_I64
 
 }  // extern "C"

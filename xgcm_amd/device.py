@@ -1,4 +1,5 @@
-"""Unlabelled-array layer: HBM-resident float64 arrays in, HBM-resident arrays out.
+"""Unlabelled-array layer: HBM-resident arrays in, HBM-resident arrays out (float64 / float32 in their own dtype, integer
+and bool arrays exact on int64 lanes -- see xgcm_amd.dtypes).
 
 Each function is one C-ABI call (include/xgcm_hip.h).  PyTorch is used only as plumbing: it owns
 the device allocations (`torch.empty`), and its current HIP stream is the stream the kernels are
@@ -23,8 +24,10 @@ import numpy as np
 import torch
 
 from . import _hip
+from . import dtypes as _dt
 
 __all__ = [
+    "convert",
     "asdevice",
     "tohost",
     "is_device_array",
@@ -60,25 +63,18 @@ def is_device_array(x) -> bool:
 
 
 _FLOATS = (torch.float32, torch.float64)
+# storage dtypes the library serves: floats compute in their own dtype, integers / bool on int64 lanes (xgcm_amd.dtypes)
+_SERVED = ("bool", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float32", "float64")
 
 
-def asdevice(x, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """numpy / host tensor -> contiguous tensor in HBM (PCIe copy); device tensors pass.
-
-    float32 and float64 keep their dtype (the reference computes in the input's dtype); every
-    other dtype is promoted to float64 (documented deviation: the reference keeps integers)."""
+def _raw_device(x) -> torch.Tensor:
+    """numpy / host tensor -> contiguous tensor in HBM with its dtype UNCHANGED (PCIe copy of the raw bytes: an int8
+    field crosses the bus as 1 byte per cell and is widened in HBM); device tensors pass."""
     _require_gpu()
     if isinstance(x, torch.Tensor):
         t = x
     else:
-        a = np.asarray(x)
-        if a.dtype not in (np.float32, np.float64):
-            a = a.astype(np.float64)
-        t = torch.from_numpy(np.asarray(a, order="C"))
-    if dtype is None:
-        dtype = t.dtype if t.dtype in _FLOATS else torch.float64
-    if t.dtype != dtype:
-        t = t.to(dtype)
+        t = torch.from_numpy(np.ascontiguousarray(x))
     if not t.is_cuda:
         t = t.cuda()
     elif t.device.index != torch.cuda.current_device():
@@ -88,18 +84,90 @@ def asdevice(x, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     return t.contiguous()
 
 
+def convert(x, dst, via=None, scale: float = 1.0, flip: bool = False) -> torch.Tensor:
+    """numpy `astype` in HBM (xg_convert): `x` of any served dtype -> `dst` (numpy dtype); `via` / `scale` / `flip` as in
+    include/xgcm_hip.h (the narrow dtype's wrap-around, interp's 0.5, uint64 order for the signed min / max kernels)."""
+    lib = _hip.load()
+    t = _raw_device(x)
+    src, dst = _dt.np_dtype(t), np.dtype(dst)
+    if src.name not in _SERVED:
+        # float16 / bfloat16 ...: no kernel computes in them and xg_convert does not read them; the promotion numpy
+        # would apply next to a float64 metric is torch's cast here (storage plumbing, outside the hot path)
+        t, src = t.to(torch.float64), _dt.FLOAT64
+    if src == dst and via is None and scale == 1.0 and not flip:
+        return t
+    out = torch.empty(t.shape, dtype=_dt.torch_dtype(dst), device=t.device)
+    if out.numel():
+        _hip.check(lib.xg_convert(t.data_ptr(), _hip.DTYPE[src.name], out.data_ptr(), _hip.DTYPE[dst.name], t.numel(),
+                                  -1 if via is None else _hip.DTYPE[np.dtype(via).name], float(scale), 1 if flip else 0,
+                                  _stream()))
+    return out
+
+
+def asdevice(x, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """numpy / host tensor -> contiguous tensor in HBM (PCIe copy); device tensors pass.
+
+    Without `dtype` the array keeps its dtype -- float32 / float64 compute in their own dtype like numpy, integer and
+    bool arrays stay integral (the operators widen them to int64 lanes themselves; xgcm_amd.dtypes) -- and anything
+    else (float16 ...) is promoted to float64.  With `dtype` (a float dtype: the lanes a call computes on) the array is
+    converted in HBM by xg_convert, numpy's `astype`."""
+    t = _raw_device(x)
+    if dtype is None:
+        return t if _dt.np_dtype(t).name in _SERVED else convert(t, _dt.FLOAT64)
+    return t if t.dtype == dtype else convert(t, _dt._TORCH_TO_NUMPY[dtype])
+
+
 def _dtype_of(x) -> torch.dtype:
-    if isinstance(x, torch.Tensor):
-        return x.dtype if x.dtype in _FLOATS else torch.float64
-    return torch.float32 if np.asarray(x).dtype == np.float32 else torch.float64
+    """float lanes of one operand on its own: float32 stays, everything else computes in float64"""
+    return torch.float32 if _dt.np_dtype(x) == _dt.FLOAT32 else torch.float64
+
+
+def _is_int(x) -> bool:
+    return x is not None and _dt.is_integer(_dt.np_dtype(x))
 
 
 def _common(*arrays):
-    """(dtype, ABI suffix) shared by an array and its metrics: float32 only if ALL are float32
-    (mixed operands promote to float64 like numpy / xarray arithmetic does)."""
-    present = [a for a in arrays if a is not None]
-    dt = torch.float32 if present and all(_dtype_of(a) == torch.float32 for a in present) else torch.float64
-    return dt, ("f32" if dt == torch.float32 else "f64")
+    """(dtype, ABI suffix) of the float lanes an array and its metrics share: numpy's promotion -- float32 only if it
+    yields float32 (all float32, or float32 next to 8 / 16-bit integers), float64 otherwise."""
+    present = [_dt.np_dtype(a) for a in arrays if a is not None]
+    f = _dt.float_of(*present)
+    return (torch.float32, "f32") if f == _dt.FLOAT32 else (torch.float64, "f64")
+
+
+# ---- integer arrays: int64 lanes between a widening and a narrowing conversion ----------------------------------------
+def _widen(x, flip: bool = False) -> torch.Tensor:
+    """integer / bool array -> int64 tensor in HBM (int64 passes, uint64 is the same bits)"""
+    t = _raw_device(x)
+    if not flip:
+        if t.dtype == torch.int64:
+            return t
+        if t.dtype == torch.uint64:
+            return t.view(torch.int64)
+    return convert(t, _dt.INT64, flip=flip)
+
+
+def _narrow(t: torch.Tensor, dst, via=None, scale: float = 1.0, flip: bool = False) -> torch.Tensor:
+    """int64 lanes -> the dtype numpy returns (wrap modulo 2^bits; float64 for interp)"""
+    dst = np.dtype(dst)
+    if via is None and scale == 1.0 and not flip:
+        if dst == _dt.INT64:
+            return t
+        if dst == _dt.UINT64:
+            return t.view(torch.uint64)
+    return convert(t, dst, via=via, scale=scale, flip=flip)
+
+
+def _lane_int(value, flip: bool = False) -> int:
+    """a numpy integer / bool scalar as the int64 bit pattern the lanes hold (uint64 above 2^63 wraps)"""
+    v = int(value) & 0xFFFFFFFFFFFFFFFF
+    if flip:
+        v ^= 0x8000000000000000
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def _divide(res: torch.Tensor, m_out, as_dtype) -> torch.Tensor:
+    """`result / m_out` after an integer operator: numpy promotes the integral result, then divides"""
+    return res if m_out is None else binary("div", convert(res, as_dtype), m_out)
 
 
 def tohost(t) -> np.ndarray:
@@ -177,12 +245,46 @@ def _streamed(per_block, x: np.ndarray) -> np.ndarray:
     return stream_records(on_block, x, block=block)
 
 
+def _int_stencil1d(plan, op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str], fill, m_out):
+    """diff / interp / min / max of an integer or bool array on int64 lanes (xg_stencil1d_i64 / xg_stencil1d_halo_i64),
+    returned in the dtype numpy returns: the array's own for diff / min / max (wrap-around included), float64 for
+    interp -- the sum wraps in the array's dtype first, `(a[:-1] + a[1:]) / 2.0` -- and `result / m_out` promoted like
+    numpy when an output metric divides (xgcm_amd.dtypes.stencil_plan)."""
+    lib = _hip.load()
+    src = _dt.np_dtype(x)
+    t = _widen(x, plan.flip)
+    axis = axis % t.dim()
+    shape = list(t.shape)
+    n_out = shape[axis] + pad_lo + pad_hi - 1
+    oshape = list(shape)
+    oshape[axis] = n_out
+    out = torch.empty(oshape, dtype=torch.int64, device=t.device)
+    if out.numel():
+        if halo is not None:
+            h = _widen(halo if _dt.np_dtype(halo) == src else convert(halo, src), plan.flip)
+            _hip.check(lib.xg_stencil1d_halo_i64(
+                _hip.OP[op], t.data_ptr(), h.data_ptr() if h.numel() else None, out.data_ptr(), _hip.i64(shape), len(shape),
+                axis, n_out, int(pad_lo), int(pad_hi), None, None, _stream()))
+        else:
+            # numpy.pad casts the constant to the array's dtype (xgcm/padding.py:610-615)
+            fv = _lane_int(_dt.fill_as(src, fill), plan.flip) if (bc == "fill" and (pad_lo or pad_hi)) else 0
+            _hip.check(lib.xg_stencil1d_i64(
+                _hip.OP[op], t.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, n_out, int(pad_lo),
+                int(pad_hi), _hip.BC[bc], fv, None, None, None, None, _stream()))
+    res = _narrow(out, plan.result, via=plan.via, scale=plan.scale, flip=plan.flip)
+    return _divide(res, m_out, plan.divide_as)
+
+
 def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str], fill: float = 0.0,
               m_in=None, m_out=None) -> torch.Tensor:
     """Fused pad + diff/interp/min/max along `axis` (xg_stencil1d_f64)."""
     lib = _hip.load()
     if _host_streamable(x, axis):  # a large host array: blocks of the outermost dim, copies overlapped with the kernel
         return _streamed(lambda blk, sl: stencil1d(op, blk, axis, pad_lo, pad_hi, bc, fill, _rows(m_in, sl, x.ndim, 'm_in'), _rows(m_out, sl, x.ndim, 'm_out')), x)
+    plan = _dt.stencil_plan(op, _dt.np_dtype(x), None if m_in is None else _dt.np_dtype(m_in),
+                            None if m_out is None else _dt.np_dtype(m_out))
+    if plan.lanes == "int":
+        return _int_stencil1d(plan, op, x, None, axis, pad_lo, pad_hi, bc, fill, m_out)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis = axis % x.dim()
@@ -210,15 +312,18 @@ def stencil1d_halo(op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, m_out=
     """diff / interp / min / max along `axis` with pre-gathered halo cells (xg_stencil1d_halo_f64):
     `halo` is shaped like `x` with `axis` shortened to pad_lo + pad_hi, low halo first."""
     lib = _hip.load()
+    expect = list(x.shape)
+    expect[axis % len(expect)] = pad_lo + pad_hi
+    if list(halo.shape) != expect:
+        raise ValueError(f"halo buffer has shape {tuple(halo.shape)}, expected {tuple(expect)}")
+    if _is_int(x) and _is_int(halo):
+        plan = _dt.stencil_plan(op, _dt.np_dtype(x), None, None if m_out is None else _dt.np_dtype(m_out))
+        return _int_stencil1d(plan, op, x, halo, axis, pad_lo, pad_hi, "halo", 0, m_out)
     dt, sfx = _common(x, halo, m_out)
     x = asdevice(x, dt)
     halo = asdevice(halo, dt)
     axis = axis % x.dim()
     n = x.shape[axis]
-    expect = list(x.shape)
-    expect[axis] = pad_lo + pad_hi
-    if list(halo.shape) != expect:
-        raise ValueError(f"halo buffer has shape {tuple(halo.shape)}, expected {tuple(expect)}")
     n_out = n + pad_lo + pad_hi - 1
     oshape = list(x.shape)
     oshape[axis] = n_out
@@ -235,6 +340,32 @@ def stencil1d_halo(op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, m_out=
     return out
 
 
+def _int_cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int, bc: Optional[str], fill,
+                  reverse: bool, m_out):
+    """prefix sum of an integer / bool array on int64 lanes (xg_cumsum1d_i64): numpy.cumsum accumulates 8 / 16 / 32-bit
+    integers and bool in the platform integer, so the result is int64 (uint64 for unsigned), exact modulo 2^64; the halo
+    of the padded cumulative result takes the fill value cast to THAT dtype (numpy.pad on the cumsum'ed array)."""
+    lib = _hip.load()
+    res_dt = _dt.cumsum_dtype(_dt.np_dtype(x))
+    t = _widen(x)
+    axis = axis % t.dim()
+    shape = list(t.shape)
+    oshape = list(shape)
+    oshape[axis] = shape[axis] - trim_lo - trim_hi + pad_lo + pad_hi
+    fv = _lane_int(_dt.fill_as(res_dt, fill)) if (bc == "fill" and (pad_lo or pad_hi)) else 0
+    if min(oshape) > 0 and shape[axis] - trim_lo - trim_hi == 0:
+        if bc != "fill":
+            raise ValueError(f"can't extend empty axis {axis} using modes other than 'constant' or 'empty'")
+        out = torch.from_numpy(np.full(oshape, fv, dtype=np.int64)).to(t.device)  # only halo cells remain
+    else:
+        out = torch.empty(oshape, dtype=torch.int64, device=t.device)
+        if out.numel():
+            _hip.check(lib.xg_cumsum1d_i64(
+                t.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, int(bool(reverse)), 0, int(trim_lo),
+                int(trim_hi), int(pad_lo), int(pad_hi), _hip.BC[bc], fv, None, None, None, None, _stream()))
+    return _divide(_narrow(out, res_dt), m_out, None if m_out is None else _dt.float_of(res_dt, _dt.np_dtype(m_out)))
+
+
 def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int, bc: Optional[str],
              fill: float = 0.0, reverse: bool = False, skipna: bool = True, m_in=None, m_out=None) -> torch.Tensor:
     """Prefix sum along `axis` with the Grid.cumsum trim/pad folded in (xg_cumsum1d_f64)."""
@@ -242,6 +373,8 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
     if _host_streamable(x, axis):
         return _streamed(lambda blk, sl: cumsum1d(blk, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, skipna,
                                                   _rows(m_in, sl, x.ndim, 'm_in'), _rows(m_out, sl, x.ndim, 'm_out')), x)
+    if _is_int(x) and m_in is None:
+        return _int_cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, m_out)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis = axis % x.dim()
@@ -282,6 +415,18 @@ def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
     lib = _hip.load()
     if _host_streamable(x, axis) and skipna not in ("pair_valid", "pair_all"):
         return _streamed(lambda blk, sl: reduce1d(blk, axis, _rows(w, sl, x.ndim, 'w'), skipna), x)
+    if _is_int(x) and w is None and isinstance(skipna, (bool, int, np.bool_)):
+        # numpy.sum of integers: accumulated in the platform integer, exact modulo 2^64 (xg_reduce1d_i64)
+        res_dt = _dt.cumsum_dtype(_dt.np_dtype(x))
+        t = _widen(x)
+        axis = axis % t.dim()
+        shape = list(t.shape)
+        out = torch.zeros(shape[:axis] + shape[axis + 1:], dtype=torch.int64, device=t.device) if t.numel() == 0 else \
+            torch.empty(shape[:axis] + shape[axis + 1:], dtype=torch.int64, device=t.device)
+        if out.numel() and t.numel():
+            _hip.check(lib.xg_reduce1d_i64(t.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, 0, None, None,
+                                           _stream()))
+        return _narrow(out, res_dt)
     dt, sfx = _common(x, w)
     x = asdevice(x, dt)
     axis = axis % x.dim()
@@ -307,30 +452,36 @@ def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
 def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
     """Generic pad; dict keys are axis numbers, dict order is the application order (xg_pad_f64)."""
     lib = _hip.load()
-    dt, sfx = _common(x)
-    x = asdevice(x, dt)
+    src = _dt.np_dtype(x)
+    ints = _dt.is_integer(src)  # numpy.pad keeps an integer array integral and casts the constant to its dtype
+    if ints:
+        dt, sfx, x = torch.int64, "i64", _widen(x)
+    else:
+        dt, sfx = _common(x)
+        x = asdevice(x, dt)
     nd = x.dim()
     lo = [0] * nd
     hi = [0] * nd
     bcv = [0] * nd
-    fv = [0.0] * nd
+    fv = [0 if ints else 0.0] * nd
     order = []
     for ax, (l, h) in widths.items():
         ax = ax % nd
         lo[ax], hi[ax] = int(l), int(h)
         bcv[ax] = _hip.BC[bc.get(ax)]
-        fv[ax] = float(fill.get(ax, 0.0) if fill.get(ax, 0.0) is not None else 0.0)
+        f = fill.get(ax, 0.0) if fill.get(ax, 0.0) is not None else 0.0
+        fv[ax] = _lane_int(_dt.fill_as(src, f)) if ints else float(f)
         order.append(ax)
     order += [d for d in range(nd) if d not in order]
     oshape = [s + l + h for s, l, h in zip(x.shape, lo, hi)]
     out = torch.empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
-        return out
+        return _narrow(out, src) if ints else out
     _hip.check(
         getattr(lib, "xg_pad_" + sfx)(x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), nd, _hip.i64(lo),
                                       _hip.i64(hi), _hip.ints(bcv), _hip.reals(fv, sfx), _hip.ints(order), _stream())
     )
-    return out
+    return _narrow(out, src) if ints else out
 
 
 def upload_tokens(tokens: np.ndarray) -> torch.Tensor:
@@ -343,11 +494,21 @@ def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_sh
            fills: Sequence[float], partner_perm: Optional[Sequence[int]] = None) -> torch.Tensor:
     """Padded array of a complex topology through a token map (xg_gather_f64)."""
     lib = _hip.load()
-    dt, sfx = _common(x, partner) if partner is not None else _common(x)
-    x = asdevice(x, dt)
+    ints = _is_int(x) and (partner is None or _is_int(partner))
+    res_dt = None
+    if ints:  # halos of an integer field stay integral (the reference concatenates / pads the array in its own dtype)
+        res_dt = np.result_type(_dt.np_dtype(x), *([] if partner is None else [_dt.np_dtype(partner)]))
+        ints = _dt.is_integer(res_dt)  # int64 with uint64 promotes to float64
+    if ints:
+        dt, sfx = torch.int64, "i64"
+        x = _widen(x)
+        fills = [_lane_int(_dt.fill_as(res_dt, f)) for f in fills]
+    else:
+        dt, sfx = _common(x, partner) if partner is not None else _common(x)
+        x = asdevice(x, dt)
     nd = x.dim()
     if partner is not None:
-        partner = asdevice(partner, dt)
+        partner = _widen(partner) if ints else asdevice(partner, dt)
         if partner.dim() != nd:
             raise ValueError("gather: the other vector component must have as many dims as the padded one")
         if partner_perm is None:
@@ -356,7 +517,7 @@ def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_sh
         tokens = upload_tokens(tokens)
     out = torch.empty([int(v) for v in out_shape], dtype=dt, device=x.device)
     if out.numel() == 0:
-        return out
+        return _narrow(out, res_dt) if ints else out
     _hip.check(
         getattr(lib, "xg_gather_" + sfx)(
             x.data_ptr(), _ptr(partner), out.data_ptr(), _hip.i64(list(x.shape)),
@@ -365,7 +526,7 @@ def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_sh
             _hip.i64(list(lo)), tokens.data_ptr(), int(tokens.numel()), _hip.reals(list(fills) or [0.0], sfx),
             len(fills), _stream())
     )
-    return out
+    return _narrow(out, res_dt) if ints else out
 
 
 def transform_linear(phi, theta, target, axis: int, mask_edges: bool = True, bypass_checks: bool = False,
@@ -436,9 +597,14 @@ def transform_conservative(phi, theta, bins, axis: int) -> torch.Tensor:
 def binary(op: str, a, b) -> torch.Tensor:
     """Broadcasting a OP b for dim-aligned operands (same ndim, extents equal or 1)."""
     lib = _hip.load()
-    dt, sfx = _common(a, b)
-    a = asdevice(a, dt)
-    b = asdevice(b, dt)
+    lanes, res_dt = _dt.binary_plan(op, _dt.np_dtype(a), _dt.np_dtype(b))
+    if lanes == "int":  # numpy keeps int OP int integral (wrap-around in the promoted dtype): int64 lanes, narrowed
+        dt, sfx = torch.int64, "i64"
+        a, b = _widen(a), _widen(b)
+    else:
+        dt, sfx = (torch.float32, "f32") if res_dt == _dt.FLOAT32 else (torch.float64, "f64")
+        a = asdevice(a, dt)
+        b = asdevice(b, dt)
     if a.dim() != b.dim():
         raise ValueError("binary: operands must be dim-aligned (same ndim)")
     shape = []
@@ -447,13 +613,12 @@ def binary(op: str, a, b) -> torch.Tensor:
             raise ValueError(f"binary: extents {sa} and {sb} do not broadcast")
         shape.append(max(sa, sb) if 0 not in (sa, sb) else 0)
     out = torch.empty(shape, dtype=dt, device=a.device)
-    if out.numel() == 0:
-        return out
-    _hip.check(
-        getattr(lib, "xg_binary_" + sfx)(_hip.BINOP[op], a.data_ptr(), _hip.i64(_bstrides(a, shape, "a")), b.data_ptr(),
-                          _hip.i64(_bstrides(b, shape, "b")), out.data_ptr(), _hip.i64(shape), len(shape), _stream())
-    )
-    return out
+    if out.numel():
+        _hip.check(
+            getattr(lib, "xg_binary_" + sfx)(_hip.BINOP[op], a.data_ptr(), _hip.i64(_bstrides(a, shape, "a")), b.data_ptr(),
+                              _hip.i64(_bstrides(b, shape, "b")), out.data_ptr(), _hip.i64(shape), len(shape), _stream())
+        )
+    return _narrow(out, res_dt) if lanes == "int" else out
 
 
 def _pair_halos(halo_x, halo_y, shape, dt):

@@ -1,0 +1,127 @@
+"""dtype policy of the operators: which lanes an array computes on and what dtype numpy would return.
+
+The reference runs its bodies in the array's own dtype (xgcm/gridops.py:23-24,76-77,123-126,172-175,227-278 are plain
+numpy expressions; `np.pad` keeps the dtype and casts the fill value, xgcm/padding.py:610-615), so integer and bool arrays
+stay integral through diff / min / max / cumsum / pad -- wrapping modulo 2^bits -- and become float64 in `interp`
+(`/ 2.0`) or next to a metric (`int * float64`).  The kernels compute on float64, float32 or int64 lanes; this module
+decides, from dtypes alone, which lanes serve a call and how the result leaves them (pure host logic: no device, no
+arithmetic on array data).  `xgcm_amd.device` executes the plans with xg_convert / the `*_i64` entry points.
+"""
+
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import numpy as np
+
+try:  # torch is plumbing for device memory only
+    import torch
+except Exception:  # pragma: no cover
+    torch = None  # type: ignore
+
+INT64 = np.dtype(np.int64)
+UINT64 = np.dtype(np.uint64)
+FLOAT64 = np.dtype(np.float64)
+FLOAT32 = np.dtype(np.float32)
+BOOL = np.dtype(np.bool_)
+
+_TORCH_TO_NUMPY = {}
+if torch is not None:
+    for _n in ("bool", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float16", "float32", "float64"):
+        if hasattr(torch, _n):
+            _TORCH_TO_NUMPY[getattr(torch, _n)] = np.dtype(_n)
+    _TORCH_TO_NUMPY[torch.bfloat16] = np.dtype(np.float32)  # no numpy twin: treated as its float32 promotion
+
+
+def np_dtype(x) -> np.dtype:
+    """numpy dtype of a numpy array, a torch tensor, a python scalar or a dtype"""
+    if torch is not None and isinstance(x, torch.Tensor):
+        return _TORCH_TO_NUMPY[x.dtype]
+    if isinstance(x, np.dtype):
+        return x
+    dt = getattr(x, "dtype", None)
+    if dt is not None and isinstance(dt, np.dtype):
+        return dt
+    return np.asarray(x).dtype
+
+
+def torch_dtype(dt):
+    return getattr(torch, np.dtype(dt).name)
+
+
+def is_integer(dt) -> bool:
+    """bool, signed or unsigned integer: the dtypes numpy keeps integral"""
+    return np.dtype(dt).kind in "biu"
+
+
+def float_of(*dtypes) -> np.dtype:
+    """the float lanes a mix of operands computes on: numpy's array-array promotion, float32 only when it yields
+    float32 (all-float32 operands, or float32 next to 8 / 16-bit integers), float64 for everything else"""
+    rt = np.result_type(*[np.dtype(d) for d in dtypes]) if dtypes else FLOAT64
+    return FLOAT32 if rt == FLOAT32 else FLOAT64
+
+
+def fill_as(dt, fill):
+    """the constant numpy.pad writes into an array of dtype `dt` for `constant_values=fill` (xgcm/padding.py:610-615):
+    truncation toward zero for integers, OverflowError / ValueError for values the dtype cannot hold -- obtained from
+    numpy.pad itself on a one-cell array, so every corner (bool, negative into unsigned, NaN) is numpy's"""
+    dt = np.dtype(dt)
+    if fill is None:
+        fill = 0.0
+    if not is_integer(dt):
+        return float(fill)
+    return np.pad(np.zeros(1, dtype=dt), (1, 0), "constant", constant_values=fill)[0]
+
+
+class StencilPlan(NamedTuple):
+    lanes: str                 # "int": *_i64 kernels; "float": convert the field first, *_f64 / *_f32 kernels
+    compute: np.dtype          # float lanes: the float dtype; int lanes: int64
+    flip: bool                 # uint64 min / max: sign-bit flip around the signed kernels
+    result: np.dtype           # dtype of the operator's result BEFORE an output metric divides it
+    via: Optional[np.dtype]    # int lanes: wrap the int64 result to this dtype's width first (the narrow dtype's arithmetic)
+    scale: float               # int lanes, interp: 0.5 applied in float64 after the conversion
+    divide_as: Optional[np.dtype]  # int lanes with an output metric: the float dtype of `result / m_out`
+
+
+def stencil_plan(op: str, x_dt, m_in_dt=None, m_out_dt=None) -> StencilPlan:
+    """diff / interp / min / max of an array of dtype `x_dt` with optional metrics (reference order of operations:
+    `da * m_in` first, xgcm/grid.py:804-808; the body; `/ m_out`, :830-832)."""
+    x_dt = np.dtype(x_dt)
+    metrics = [np.dtype(d) for d in (m_in_dt, m_out_dt) if d is not None]
+    if not is_integer(x_dt) or m_in_dt is not None:
+        f = float_of(x_dt, *metrics)  # `int * float_metric` promotes before anything else happens
+        return StencilPlan("float", f, False, f, None, 1.0, None)
+    if x_dt == BOOL and op == "diff":
+        # a[..., 1:] - a[..., :-1] on booleans: numpy's own refusal
+        raise TypeError("numpy boolean subtract, the `-` operator, is not supported, use the bitwise_xor, the `^` operator, "
+                        "or the logical_xor function instead.")
+    if op == "interp":  # (a[:-1] + a[1:]) in the array's dtype (wraps; bool: logical or), then / 2.0 -> float64
+        result, via, scale = FLOAT64, x_dt, 0.5
+    else:
+        result, via, scale = x_dt, None, 1.0
+    divide_as = None if m_out_dt is None else float_of(result, m_out_dt)
+    return StencilPlan("int", INT64, x_dt == UINT64 and op in ("min", "max"), result, via, scale, divide_as)
+
+
+def cumsum_dtype(x_dt) -> np.dtype:
+    """numpy.cumsum / numpy.sum of integers: narrower types accumulate in the platform integer (int64 / uint64)"""
+    x_dt = np.dtype(x_dt)
+    if not is_integer(x_dt):
+        return x_dt
+    return UINT64 if x_dt.kind == "u" else INT64
+
+
+def binary_plan(op: str, a_dt, b_dt):
+    """`a OP b` of two arrays: ("int", result dtype) when numpy keeps the result integral, else ("float", float dtype)"""
+    a_dt, b_dt = np.dtype(a_dt), np.dtype(b_dt)
+    if is_integer(a_dt) and is_integer(b_dt) and op != "div":
+        if a_dt == BOOL and b_dt == BOOL and op == "sub":
+            raise TypeError("numpy boolean subtract, the `-` operator, is not supported, use the bitwise_xor, the `^` operator, "
+                            "or the logical_xor function instead.")
+        rt = np.result_type(a_dt, b_dt)
+        if is_integer(rt):
+            return "int", rt
+        return "float", FLOAT64  # int64 with uint64: numpy goes to float64
+    if is_integer(a_dt) and is_integer(b_dt):
+        return "float", FLOAT64  # true division of integers
+    return "float", float_of(a_dt, b_dt)

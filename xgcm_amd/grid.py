@@ -493,8 +493,8 @@ class Grid:
             return None
         if array.ndim < 2 or getattr(array, "chunks", None) is not None:
             return None
-        if gridops.signed_int_dtype(array.data) is not None:
-            return None  # integers: the per-axis path truncates the fill value and casts back like numpy.pad
+        if gridops.is_integer_data(array.data):
+            return None  # integers: one axis at a time on int64 lanes (interp leaves the integer domain between the axes)
         (sig_a, ax_a), (sig_b, ax_b) = step_a, step_b
         if ax_a == ax_b or gridops.complex_topology(self, ax_a) or gridops.complex_topology(self, ax_b):
             return None  # halos from other faces / the folded row: one axis at a time (xg_stencil1d_halo)
@@ -670,11 +670,11 @@ class Grid:
                 if weighted:
                     res = res / self._resident(self.get_metric(res, weighted, _layout=res.dims), res.data)
             else:
-                keep_int = gridops.signed_int_dtype(data.data) if (not weighted and m_in is None) else None
+                # integer data: numpy.cumsum's int64 / uint64 accumulator and numpy.pad's cast of the fill value, both in
+                # the device layer (xgcm_amd.dtypes)
                 out = _dev.cumsum1d(data.data, num, trim_lo, trim_hi, pad_lo, pad_hi,
-                                    bc if (pad_lo or pad_hi) else None,
-                                    gridops.int_fill(0.0 if fv is None else float(fv), keep_int), rev, True, m_in, m_out)
-                res = DataArray(gridops.restore_int(_dev.tohost(out) if host else out, keep_int), out_dims, name=data.name)
+                                    bc if (pad_lo or pad_hi) else None, 0.0 if fv is None else fv, rev, True, m_in, m_out)
+                res = DataArray(_dev.tohost(out) if host else out, out_dims, name=data.name)
             data = _reattach_coords([res], self, {ax.name: (pad_lo, pad_hi)}, {new_dim}, [data])[0]
         return to_xarray(data) if was_xr else data
 
@@ -749,7 +749,7 @@ class Grid:
         """Cumulative integral `cumsum(da * metric, axis)` (grid.py:1607-1660)."""
         da, was_xr = self._wrap_in(da)
         weight = self._resident(self.get_metric(da, axis, _layout=da.dims), da.data)
-        if [d for d in weight.dims if d not in da.dims] or gridops.signed_int_dtype(da.data) is not None:
+        if [d for d in weight.dims if d not in da.dims] or gridops.is_integer_data(da.data):
             res = self.cumsum(da * weight, axis, **kwargs)  # the product has more dims than `da` / integer data
         else:
             res = self.cumsum(da, axis, _pre_weight=weight, **kwargs)  # same products, formed inside the scan
@@ -806,6 +806,14 @@ class Grid:
         if u.dims[-2:] != (uy_dim, out_x) or v.dims[-2:] != (out_y, vx_dim) or u.dims[:-2] != v.dims[:-2]:
             raise NotImplementedError("fused vorticity needs u(..., YC, XG) and v(..., YG, XC) with (Y, X) last")
         out_dims = u.dims[:-2] + (out_y, out_x)
+        if gridops.is_integer_data(u.data) or gridops.is_integer_data(v.data):
+            # integer components: the operator chain itself, each step in numpy's dtype (the fused kernel is float-only)
+            kw = dict(padding=padding, fill_value=fill_value)
+            res = (self.diff({y_axis: v}, x_axis, other_component={x_axis: u}, **kw)
+                   - self.diff({x_axis: u}, y_axis, other_component={y_axis: v}, **kw))
+            if metric_weighted:
+                res = res / self._resident(self.get_metric(res, (x_axis, y_axis)), res.data)
+            return to_xarray(res) if (xr1 or xr2) else res
         area = None
         if metric_weighted:
             area = _aligned_view(self._resident(self.get_metric(_DimsOnly(out_dims), (x_axis, y_axis)), u.data), out_dims)
@@ -879,6 +887,14 @@ class Grid:
         if u.dims[-2:] != (uy_dim, ux_dim) or v.dims[-2:] != (vy_dim, vx_dim) or u.dims[:-2] != v.dims[:-2]:
             raise NotImplementedError("fused divergence needs u(..., YC, XG) and v(..., YG, XC) with (Y, X) last")
         out_dims = u.dims[:-2] + (out_y, out_x)
+        if gridops.is_integer_data(u.data) or gridops.is_integer_data(v.data):
+            # integer components: the operator chain itself, each step in numpy's dtype (the fused kernel is float-only)
+            kw = dict(padding=padding, fill_value=fill_value)
+            res = (self.diff({x_axis: u}, x_axis, other_component={y_axis: v}, **kw)
+                   + self.diff({y_axis: v}, y_axis, other_component={x_axis: u}, **kw))
+            if metric_weighted:
+                res = res / self._resident(self.get_metric(res, (x_axis, y_axis)), res.data)
+            return to_xarray(res) if (xr1 or xr2) else res
         area = None
         if metric_weighted:
             area = _aligned_view(self._resident(self.get_metric(_DimsOnly(out_dims), (x_axis, y_axis)), u.data), out_dims)
@@ -905,7 +921,7 @@ class Grid:
         if (x_pos, y_pos) != ("center", "center") or "left" not in xa.coords or "left" not in ya.coords:
             raise NotImplementedError("fused gradient needs a field at (Y:center, X:center) and left points on both axes")
         op = self.derivative if metric_weighted else self.diff
-        if a.dims[-2:] != (y_dim, x_dim):
+        if a.dims[-2:] != (y_dim, x_dim) or gridops.is_integer_data(a.data):  # (integers: the float-only fused kernel is not theirs)
             kw = dict(padding=padding, fill_value=fill_value)
             res = op(a, x_axis, **kw), op(a, y_axis, **kw)
             return tuple(to_xarray(r) for r in res) if was_xr else res
@@ -938,7 +954,8 @@ class Grid:
         dims_x = t.dims[:-2] + (ty_dim, xa.coords["left"])
         dims_y = t.dims[:-2] + (ya.coords["left"], tx_dim)
         was_xr = xr1 or xr2 or xr3
-        if t.dims[-2:] != (ty_dim, tx_dim) or u.dims != dims_x or v.dims != dims_y:
+        if (t.dims[-2:] != (ty_dim, tx_dim) or u.dims != dims_x or v.dims != dims_y
+                or any(gridops.is_integer_data(q.data) for q in (u, v, t))):  # integers: each step in numpy's dtype
             kw = dict(padding=padding, fill_value=fill_value)
             res = u * self.interp(t, x_axis, **kw), v * self.interp(t, y_axis, **kw)
             return tuple(to_xarray(r) for r in res) if was_xr else res

@@ -17,6 +17,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import device as _dev
+from . import dtypes as _dt
 from .grid_ufunc import (
     GridUFunc,
     _check_data_input,
@@ -56,29 +57,11 @@ def _same_residency(data, out):
     return out if _is_tensor(data) else _dev.tohost(out)
 
 
-def signed_int_dtype(data):
-    """The dtype of a signed-integer array (numpy or torch), else None.  The kernels compute in float64
-    (exact for |values| < 2**53); operators that numpy keeps integral (diff, min, max, cumsum without
-    metrics) get their result cast back, so integer inputs return what the reference returns."""
-    dt = getattr(data, "dtype", None)
-    if dt is None:
-        return None
-    if _is_tensor(data):
-        import torch
-
-        return dt if dt in (torch.int8, torch.int16, torch.int32, torch.int64) else None
-    return dt if np.issubdtype(dt, np.signedinteger) else None
-
-
-def restore_int(out, dt):
-    if dt is None:
-        return out
-    return out.to(dt) if _is_tensor(out) else out.astype(dt)
-
-
-def int_fill(fill, dt):
-    """numpy.pad casts the constant to the array's dtype: integers truncate toward zero"""
-    return float(int(fill)) if dt is not None else fill
+def is_integer_data(data) -> bool:
+    """integer or bool data (numpy or torch): numpy keeps such arrays integral through diff / min / max / cumsum / pad,
+    and so does the device layer (int64 lanes, xgcm_amd.dtypes) -- callers only need this to keep integers off the
+    float-only fused kernels"""
+    return getattr(data, "dtype", None) is not None and _dt.is_integer(_dt.np_dtype(data))
 
 
 def _stencil(data, op, *args):
@@ -176,20 +159,17 @@ class HipGridUFunc(GridUFunc):
 
         bc = grid._complete_user_kwargs_using_axis_defaults(padding, "padding")[ax_name]
         fv = grid._complete_user_kwargs_using_axis_defaults(fill_value, "fill_value")[ax_name]
-        fv = 0.0 if fv is None else float(fv)
+        fv = 0.0 if fv is None else fv  # cast to the array's dtype by the device layer, like numpy.pad does
         if (lo or hi) and bc is None:
             raise no_boundary_error(ax_name)
         if not (lo or hi):
             bc = None
-        src_int = signed_int_dtype(da.data)
-        keep_int = src_int if (self.funcname != "interp" and m_in is None and m_out is None) else None
-        fv = int_fill(fv, src_int if m_in is None else None)  # the reference pads the integer array itself
         if self.funcname == "cumsum":
             _, _, _, drop_last = _CUMSUM_TABLE[(self.from_pos, self.to_pos)]
             data = _cumsum(da.data, num, 0, 1 if drop_last else 0, lo, hi, bc, fv, False, False, m_in, m_out)
         else:
             data = _stencil(da.data, self.funcname, num, lo, hi, bc, fv, m_in, m_out)
-        res = DataArray(restore_int(data, keep_int), out_dims, name=da.name)
+        res = DataArray(data, out_dims, name=da.name)
         return _reattach_coords([res], grid, self.padding_width, {out_dim}, [da])[0]
 
 

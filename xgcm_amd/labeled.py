@@ -19,6 +19,7 @@ from typing import Any, Dict, Mapping, Optional, Sequence, Tuple
 import numpy as np
 
 from . import device as _dev
+from . import dtypes as _dt
 
 try:  # torch is plumbing for device memory only
     import torch
@@ -249,8 +250,9 @@ class DataArray:
         """`self OP other` with name-based broadcasting.  `dims_order` (internal): lay the result out with its dims in
         that order instead of xarray's (self's dims, then other's new ones) -- same values, no transposed copy later."""
         if isinstance(other, (int, float, np.integer, np.floating)):
-            # python / numpy scalars are "weak": a float32 array stays float32 (numpy, xarray)
-            sdt = np.float32 if str(self.dtype).endswith("float32") else np.float64
+            # python scalars are "weak" (numpy's promotion): a float32 array stays float32 next to 2.0, an integer array
+            # stays integral next to 2 and becomes float64 next to 2.0; numpy scalars carry their own dtype
+            sdt = np.result_type(_dt.np_dtype(self.data), other)
             o = DataArray(np.full((1,) * self.ndim, other, dtype=sdt), tuple(f"__s{i}" for i in range(self.ndim)))
             a, b, dims = self.data, o.data, self.dims
             coords = OrderedDict(self.coords)
