@@ -137,7 +137,9 @@ def test_mixed_dtypes_promote_to_float64(dev):
     assert dev.tohost(dev.binary("mul", a32, m64)).dtype == np.float64
     ints = np.arange(24).reshape(4, 6)
     out = dev.tohost(dev.stencil1d("diff", ints, 1, 1, 0, "fill"))
-    assert out.dtype == np.float64  # documented deviation: the reference would keep integers
+    assert out.dtype == ints.dtype and np.array_equal(out, R.stencil1d("diff", ints, 1, 1, 0, "fill"))  # integers stay integral
+    got = dev.tohost(dev.stencil1d("diff", ints, 1, 1, 0, "fill", 0.0, m64[0, :4, :6], None))  # int * float64 metric -> float64
+    assert got.dtype == np.float64 and np.array_equal(got, R.stencil1d("diff", ints, 1, 1, 0, "fill", 0.0, m64[0, :4, :6]))
 
 
 def test_f32_grid_surface(backend):
