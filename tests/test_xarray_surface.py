@@ -50,6 +50,9 @@ def test_xarray_in_xarray_out_with_reattached_coords(xr, funcname):
     assert out.dims == ("time", "XG") and out.name == "v"
     assert set(out.coords) == {"time", "XG", "t_label", "lon_g"}  # xc_aux lives on the old core dim: gone
     np.testing.assert_array_equal(out.coords["XG"].values, ds["XG"].values)
+    # coordinate variables come back as they are in the grid's dataset: attrs and dtype included (grid_ufunc.py:1262-1320)
+    assert out.coords["lon_g"].attrs == {"units": "degrees_east"}
+    assert out.coords["t_label"].dtype == np.int64 and out.coords["lon_g"].dtype == ds["lon_g"].dtype
     a = ds["v"].values
     want = {"diff": lambda: R.stencil1d("diff", a, 1, 1, 0, "periodic"),
             "interp": lambda: R.stencil1d("interp", a, 1, 1, 0, "periodic"),
@@ -73,8 +76,10 @@ def test_user_coords_on_noncore_dims_survive(xr):
     v = xr.DataArray(ds["v"].values, dims=["time", "XC"], name="v",
                      coords={"time": new_time, "t_label": ("time", new_label),
                              "xc_aux": ("XC", (np.arange(N) + 500).astype(np.float32)), "XC": ds["XC"].values})
+    v.coords["t_label"].attrs["long_name"] = "recast label"
     for out in (grid.interp(v, "X"), grid.diff(v, "X"), grid.cumsum(v, "X", to="left")):
         assert L.is_xarray(out)
+        assert out.coords["t_label"].attrs == {"long_name": "recast label"}  # attrs of a DataArray's own coords survive too
         assert out.coords["time"].dtype == np.float32
         np.testing.assert_array_equal(out.coords["time"].values, new_time)
         assert out.coords["t_label"].dtype == np.float32

@@ -440,7 +440,7 @@ def from_xarray(obj):
     if tname == "DataArray" and getattr(obj, "chunks", None) is not None:
         raise NotImplementedError(CHUNKED_INPUT_MESSAGE)
     if tname == "DataArray":
-        coords = {k: (tuple(v.dims), np.asarray(v.values)) for k, v in obj.coords.items()}
+        coords = {k: (tuple(v.dims), np.asarray(v.values), dict(v.attrs)) for k, v in obj.coords.items()}
         return DataArray(np.asarray(obj.values), tuple(obj.dims), coords=coords, name=obj.name, attrs=dict(obj.attrs))
     if tname == "Dataset":
         coords = {k: (tuple(v.dims), np.asarray(v.values), dict(v.attrs)) for k, v in obj.coords.items()}
@@ -452,5 +452,7 @@ def from_xarray(obj):
 def to_xarray(da: DataArray):
     import xarray as xr  # only reached when the caller handed us xarray objects
 
-    coords = {k: (c.dims, c.values) for k, c in da.coords.items()}
+    # coordinate variables leave as they came in: dims, values in their own dtype AND attrs (the reference takes them
+    # from `grid._ds` unchanged, xgcm/grid_ufunc.py:1262-1320)
+    coords = {k: (c.dims, c.values, dict(c.attrs)) for k, c in da.coords.items()}
     return xr.DataArray(da.values, dims=da.dims, coords=coords, name=da.name, attrs=da.attrs)
