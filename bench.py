@@ -204,6 +204,12 @@ def main():
 
     local_cells = K * len(OPS) * cells_per_op
     per_rank_ms_per_step = [round(v / K * 1e3, 4) for v in ranks.gather_floats(elapsed)]
+    # what a < 7x curve would have to be explained with: where each rank ran (GPU, NUMA node, CPUs it was bound to) and how
+    # much of its wall time per step was NOT device time (Python dispatch of the 4 launches, barrier skew)
+    local_dev_ms = sorted(ev[k][0].elapsed_time(ev[k][len(OPS)]) for k in range(K))
+    placement = ranks.gather_objects(dict(ranks.placement, rank=rank,
+                                          device_ms_per_step=round(local_dev_ms[len(local_dev_ms) // 2], 4),
+                                          host_overhead_ms_per_step=round(elapsed / K * 1e3 - float(np.mean(local_dev_ms)), 4)))
     cells_per_s, elapsed = S.whole_job_throughput(local_cells, elapsed, dist, "cuda")
     n_ranks = dist.get_world_size() if dist is not None else 1  # the rank count RCCL itself reports
 
@@ -240,6 +246,7 @@ def main():
             "n_gpus": n_ranks,
             "steps": K,
             "warmup": args.warmup,
+            "prime_steps": prime,  # untimed steps BEFORE the contracted warmup (XG_BENCH_PRIME; allocator, code objects, clocks)
             "ms_per_step": round(elapsed / K * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -253,16 +260,22 @@ def main():
             "achieved_GBps_whole_step": round(total_cells * BYTES_PER_CELL / elapsed / 1e9 / world, 1),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_measured_in_run": False,  # replayed from the committed PMC passes named in traffic_source
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
                          "per_op_ms": {f"{fn}_{ax}": round(ms, 4) for (fn, ax), ms in zip(OPS, per_op_ms)}},
             "ranks": {"world_size": n_ranks, "backend": "nccl (RCCL)" if dist is not None else "single process",
                       "per_rank_ms_per_step": per_rank_ms_per_step,
-                      # balance inside this run (min / max over the ranks); scaling against N = 1 is the driver's to compute
-                      "scaling_efficiency": round(min(per_rank_ms_per_step) / max(per_rank_ms_per_step), 4) if max(per_rank_ms_per_step) > 0 else None},
+                      # load balance INSIDE this run (min / max over the ranks' times) -- not scaling efficiency: scaling
+                      # against N = 1 is the driver's to compute from the per-N values
+                      "rank_balance_min_over_max": round(min(per_rank_ms_per_step) / max(per_rank_ms_per_step), 4) if max(per_rank_ms_per_step) > 0 else None,
+                      "placement": placement, "numa_bind": os.environ.get("XG_NUMA_BIND", "1") != "0"},
             "device_ms_per_step": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4),
                                    "max": round(step_ms[-1], 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
+            before = ranks.placement.get("affinity_before")
+            if ranks.placement.get("bound") and before:  # the CPU baseline is timed on ALL the box's host cores again
+                os.sched_setaffinity(0, S.parse_cpulist(before))
             line["cpu_baseline"] = cpu_baseline()
             line["parity_spot_check"] = spot_check(spot)
         print(json.dumps(line), flush=True)

@@ -91,7 +91,7 @@ int xg_stream_sync(void* stream);
 /* a stream of the library's own (xgcm_amd.graphs.capture records on one: the chained kernels keep their workspace per
  * stream, so a captured graph never shares it with another capture or with eager calls) */
 int xg_stream_create(void** stream);
-int xg_stream_destroy(void* stream); /* synchronises, releases the stream's chained-kernel workspace, destroys */
+int xg_stream_destroy(void* stream); /* synchronises the DEVICE (a graph captured on the stream may be replaying elsewhere), releases the stream's chained-kernel workspace, destroys */
 /* The long strided-axis scans / weighted reductions run as CHAINED flat launches (chunks of a column hand their running
  * sum on through one XCD's L2).  A chunk that gives up waiting for its predecessor (scan_chain_spin polls) cannot
  * damage a result: every chained launch is followed on the same stream by its marching twin, which runs only if a
@@ -111,6 +111,10 @@ int xg_event_destroy(void* ev);
  * from big-endian files -- MITgcm's MDS .data, NetCDF-3 -- are swapped on the GPU after the PCIe copy.  The reference
  * gets decoded native arrays from xarray's backends (xgcm/grid.py:786-818 walks their dask chunks). */
 int xg_bswap(void* data, uint64_t nelem, int elem_bytes, void* stream);
+/* Cells of a float32 / float64 device buffer (elem_bytes 4 / 8) that equal `value` become NaN, in place: the _FillValue /
+ * missing_value of a file variable, which xarray's mask_and_scale decoding turns into NaN before the reference sees the
+ * array (so that skipna reductions and cumsum skip land / missing cells). */
+int xg_mask_value(void* data, uint64_t nelem, int elem_bytes, double value, void* stream);
 
 /* ---- fused pad + two-point stencil along one axis -------------------------------------- */
 /* out[.., i, ..] = OP(P[i], P[i+1]) / m_out,  P = pad(in * m_in, (pad_lo, pad_hi), bc, fill)

@@ -288,6 +288,40 @@ def test_weighted_reduction_with_weights_through_lds(dev, dtype):
             _hip.set_tunable(k, v)
 
 
+def test_weighted_march_orders_under_every_banding_setting(dev):
+    """`march_ofast` orders the plain weighted march outer-indices-fastest through the banded wave id,
+    which walks ceil(grid / 8) workgroups per XCD band -- the grid must be rounded to a multiple of 8 for it also when
+    `march_band` is off (it was not: task ids below the count stayed unvisited, part of the output unwritten).  Shapes whose
+    workgroup count is NOT a multiple of 8, every combination of the two tunables, against the oracle (poisoned output)."""
+    import torch
+
+    from xgcm_amd import _hip
+    keep = {k: _hip.get_tunable(k) for k in ("reduce_ldsw", "scan_chain", "march_ofast", "march_band")}
+    try:
+        _hip.set_tunable("reduce_ldsw", 0)
+        _hip.set_tunable("scan_chain", 0)
+        for shape, wshape in (((3, 40, 130), (1, 40, 130)), ((5, 33, 66), (1, 33, 66)), ((7, 20, 1000), (1, 20, 1000)),
+                              ((2, 3, 17, 640), (1, 1, 17, 640)), ((9, 300, 70), (1, 300, 70))):
+            a = _field(shape, 71, nan=True)
+            w = R.synthetic_metric(wshape, 72)
+            axis = len(shape) - 2
+            with np.errstate(invalid="ignore"):
+                want = R.integrate(a, axis, np.broadcast_to(w, shape), True)
+            for band in (0, 1, 2):
+                for ofast in (0, 1):
+                    _hip.set_tunable("march_band", band)
+                    _hip.set_tunable("march_ofast", ofast)
+                    # poison the allocator's next block so that an unwritten cell cannot pass by luck
+                    junk = torch.full(want.shape, float("nan"), dtype=torch.float64, device="cuda")
+                    del junk
+                    _eq(dev.tohost(dev.reduce1d(a, axis, w, True)), want)
+                    got = dev.tohost(dev.cumsum1d(a, axis, 0, 0, 0, 0, None, 0.0, False, True))
+                    _eq(got, R.cumsum1d(a, axis, 0, 0, 0, 0, None, 0.0, False, True))
+    finally:
+        for k, v in keep.items():
+            _hip.set_tunable(k, v)
+
+
 def test_chained_scans_on_two_streams(dev):
     """The chained kernels keep their hand-off slots and ticket counters in a workspace PER STREAM: two streams running
     long scans / weighted reductions at the same time do not see each other's running sums."""

@@ -65,7 +65,7 @@ def test_eight_gloo_ranks_at_the_baseline_splits():
     for k in a:
         assert b[k]["n_gpus"] == 8 and len(b[k]["per_rank_device_ms"]) == 8
         assert sum(b[k]["per_rank_cells"]) == a[k]["cells"] and a[k]["checksum_u64"] == b[k]["checksum_u64"], k
-        assert 0 < b[k]["scaling_efficiency"] <= 1
+        assert 0 < b[k]["rank_balance_min_over_max"] <= 1
     c4 = next(v for k, v in b.items() if k[0] == 4)
     assert c4["records_per_rank"] == [45] * 8 and c4["records_per_resident_batch"] == 23 and c4["batch_rounds"] == 2
     c5 = next(v for k, v in b.items() if k[0] == 5)

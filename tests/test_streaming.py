@@ -299,6 +299,63 @@ def test_mds_header_as_mitgcm_writes_it(tmp_path):
     assert m["shape"] == (2, 15, 40, 90) and m["dtype"] == ">f4" and m["fields"] == ["UVEL"] and m["timestep"] == 72
 
 
+def _netcdf_with_fill(tmp_path, dtype, fill=-999.0):
+    from scipy.io import netcdf_file
+
+    a = R.synthetic_field((4, 3, 6, 32), 43).astype(dtype)
+    a[:, :, 2, 5:9] = fill   # "land"
+    a[1, 0, 0, 0] = fill
+    path = str(tmp_path / "masked.nc")
+    with netcdf_file(path, "w", version=2) as nc:
+        nc.createDimension("T", None)
+        for name, n in zip(("Z", "Y", "X"), a.shape[1:]):
+            nc.createDimension(name, n)
+        v = nc.createVariable("Temp", np.dtype(dtype).newbyteorder(">"), ("T", "Z", "Y", "X"))
+        v[:] = a
+        v._FillValue = np.array(fill, dtype=np.dtype(dtype).newbyteorder(">"))
+        m = nc.createVariable("Salt", np.dtype(dtype).newbyteorder(">"), ("T", "Z", "Y", "X"))
+        m[:] = a
+        m.missing_value = np.array(fill, dtype=np.dtype(dtype).newbyteorder(">"))
+    return a, path
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_netcdf_fill_values_are_not_ignored_silently(tmp_path, dtype):
+    """a variable with _FillValue / missing_value holds NaN in the reference's pipeline (xarray decoding); the
+    raw blocks are refused unless asked for, and the value to mask is exposed"""
+    from xgcm_amd import io as xio
+
+    a, path = _netcdf_with_fill(tmp_path, dtype)
+    for name in ("Temp", "Salt"):
+        with pytest.raises(NotImplementedError, match="_FillValue / missing_value"):
+            list(xio.netcdf_blocks(path, name, 2))
+        assert xio.netcdf_missing_value(path, name) == -999.0
+        raw = np.concatenate([np.asarray(b) for b in xio.netcdf_blocks(path, name, 2, missing="raw")]).astype(dtype)
+        np.testing.assert_array_equal(raw, a)
+    with pytest.raises(ValueError):
+        list(xio.netcdf_blocks(path, "Temp", 2, missing="whatever"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fill_values_become_nan_in_hbm(tmp_path, dtype):
+    """the streamed cumsum / sum of a variable with missing cells equals the reference pipeline's: mask to NaN, then the
+    NaN-skipping operators"""
+    from xgcm_amd import device as dev
+    from xgcm_amd import io as xio
+    from xgcm_amd.streaming import stream_blocks
+
+    a, path = _netcdf_with_fill(tmp_path, dtype)
+    masked = np.where(a == dtype(-999.0), np.nan, a).astype(dtype)
+    mv = xio.netcdf_missing_value(path, "Temp")
+    got = stream_blocks(lambda x: dev.cumsum1d(x, 1, 0, 0, 0, 0, None, 0.0, False, True),
+                        xio.netcdf_blocks(path, "Temp", 3, missing="raw"), mask_value=mv)
+    np.testing.assert_array_equal(got, R.cumsum1d(masked, 1, 0, 0, 0, 0, None, 0.0, False, True))
+    ident = stream_blocks(lambda x: dev.stencil1d("max", x, 3, 0, 0, None), xio.netcdf_blocks(path, "Salt", 2, missing="raw"),
+                          mask_value=mv)
+    assert np.isnan(ident).sum() > 0 and not (ident == dtype(-999.0)).any()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_operators_streamed_over_mds_and_netcdf_files(tmp_path, dtype):

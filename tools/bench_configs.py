@@ -131,9 +131,9 @@ def _shard_line(ranks, cfg, op, wall_s, dev_ms, local_cells, bpc, chk, extra):
             "GBps_all_gpus": round(total * bpc / wall / 1e9, 1) if wall > 0 else None,
             "frac_8TBps_per_gpu": round(total * bpc / wall / 1e9 / 8000 / ranks.world, 4) if wall > 0 else None,
             "per_rank_device_ms": [round(v, 3) for v in per_rank_ms],
-            # min / max over the ranks that had work: 1.0 = perfectly balanced (the driver computes scaling efficiency
-            # against N = 1 itself; this is the within-run balance the north star asks to see)
-            "scaling_efficiency": (round(min(v for v in per_rank_ms if v > 0) / max(per_rank_ms), 4) if max(per_rank_ms) > 0 else None),
+            # min / max over the ranks that had work: 1.0 = perfectly balanced.  Load balance inside ONE run, not scaling
+            # efficiency (that is the driver's to compute against N = 1 from the per-N lines)
+            "rank_balance_min_over_max": (round(min(v for v in per_rank_ms if v > 0) / max(per_rank_ms), 4) if max(per_rank_ms) > 0 else None),
             "per_rank_cells": [int(v) for v in per_rank_cells], "checksum_u64": f"{chk:016x}"}
     line.update(extra)
     if ranks.rank == 0:

@@ -46,6 +46,14 @@ def main():
     a = ap.parse_args()
     ngpu = visible_gpus()
     rows, skipped = [], []
+    placements = {}
+    # the node's link / NUMA topology next to the numbers (rocm-smi is on the GPU box; absent elsewhere)
+    topo = ""
+    for cmd in (["rocm-smi", "--showtopo"], ["rocm-smi", "--showtoponuma"]):
+        try:
+            topo += "$ " + " ".join(cmd) + "\n" + subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60).stdout + "\n"
+        except Exception as exc:  # noqa: BLE001
+            topo += "$ " + " ".join(cmd) + f"\n(not available: {exc})\n"
     for n in [int(v) for v in a.ns.split(",")]:
         if n > max(ngpu, 1) and os.environ.get("XG_DIST_BACKEND", "") != "gloo":
             skipped.append(n)
@@ -55,6 +63,7 @@ def main():
             for ln in lines:
                 if "value" in ln:
                     per = ln["ranks"]["per_rank_ms_per_step"]
+                    placements[n] = ln["ranks"].get("placement")
                     rows.append({"what": "bench: interp+diff X,Y, one record per GPU (weak)", "n": n, "GBps": ln["achieved_GBps_whole_step"] * n,
                                  "rank_ms_max_over_min": round(max(per) / min(per), 4) if min(per) > 0 else None})
             if rc != 0:
@@ -85,6 +94,11 @@ def main():
     if a.out:
         with open(a.out + ".md", "w") as f:
             f.write("Generated by tools/scale_table.py.\n\n" + text)
+            f.write("\nRank placement of the bench runs (GPU, NUMA node, CPUs bound to, device and host-side ms per step):\n\n")
+            for n, pl in placements.items():
+                f.write(f"N = {n}: {json.dumps(pl)}\n")
+        with open(a.out + "_topo.txt", "w") as f:
+            f.write(topo)
         with open(a.out + ".jsonl", "w") as f:
             for r in rows:
                 f.write(json.dumps(r) + "\n")

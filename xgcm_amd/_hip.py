@@ -48,6 +48,7 @@ SIGNATURES = {
     "xg_event_elapsed_ms": (C.c_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "xg_event_destroy": (C.c_int, [_vp]),
     "xg_bswap": (C.c_int, [_vp, C.c_uint64, C.c_int, _vp]),
+    "xg_mask_value": (C.c_int, [_vp, C.c_uint64, C.c_int, C.c_double, _vp]),
     "xg_stencil1d_f64": (
         C.c_int,
         [C.c_int, _vp, _vp, _i64p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_double,

@@ -357,6 +357,13 @@ int xg_bswap(void* data, uint64_t nelem, int elem_bytes, void*) {
     for (int b = 0; b < elem_bytes / 2; ++b) { unsigned char t = p[b]; p[b] = p[elem_bytes - 1 - b]; p[elem_bytes - 1 - b] = t; }
   return XG_OK;
 }
+int xg_mask_value(void* data, uint64_t nelem, int elem_bytes, double value, void*) {
+  if (elem_bytes != 4 && elem_bytes != 8) return fail(XG_ERR_INVALID, "masking of %d-byte elements (float32 / float64 only)", elem_bytes);
+  if (nelem && !data) return fail(XG_ERR_INVALID, "NULL buffer");
+  if (elem_bytes == 4) { float* p = (float*)data; for (uint64_t i = 0; i < nelem; ++i) if (p[i] == (float)value) p[i] = NAN; }
+  else { double* p = (double*)data; for (uint64_t i = 0; i < nelem; ++i) if (p[i] == value) p[i] = NAN; }
+  return XG_OK;
+}
 int xg_event_create(void** ev) {
   if (!ev) return fail(XG_ERR_INVALID, "NULL argument");
   *ev = calloc(1, sizeof(double));

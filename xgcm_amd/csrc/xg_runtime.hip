@@ -199,6 +199,13 @@ extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ws(void* 
 
 #ifdef XG_PRIMARY
 namespace {
+// cells equal to `value` become NaN (the _FillValue / missing_value of a file variable: xarray's mask_and_scale decoding,
+// which the reference's inputs have been through -- done here in HBM after the byte swap)
+template <typename T>
+__global__ __launch_bounds__(BLOCK) void k_mask_value(T* __restrict__ data, u64 n, T value) {
+  for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK)
+    if (data[i] == value) data[i] = (T)__builtin_nan("");
+}
 // byte order of 4- / 8-byte elements reversed in place: what MITgcm (MDS) and NetCDF-3 files hold is big-endian, and a
 // block read from them is swapped HERE, after the PCIe copy of the raw bytes, instead of on a host core (the reference
 // gets native arrays from xarray's decoding, on the CPU).  16 B per lane; the <= 15 trailing bytes' elements one by one.
@@ -300,7 +307,9 @@ int xg_stream_create(void** stream) {
 }
 int xg_stream_destroy(void* stream) {
   if (!stream) return fail(XG_ERR_INVALID, "the null stream cannot be destroyed");
-  XG_HIP(hipStreamSynchronize((hipStream_t)stream));
+  // the workspace below may still be in use by a graph that was CAPTURED on this stream but is replayed on another one
+  // (xgcm_amd.graphs.CapturedChain replays on torch's current stream): wait for the whole device, not just this stream
+  XG_HIP(hipDeviceSynchronize());
   {  // the chained kernels' workspace of this stream goes with it (a recycled handle must not inherit it)
     ChainState& cs = chain_state();
     std::lock_guard<std::mutex> lock(cs.mu);
@@ -343,6 +352,18 @@ int xg_event_elapsed_ms(void* start, void* stop, float* ms) {
   return 0;
 }
 int xg_event_destroy(void* ev) { XG_HIP(hipEventDestroy((hipEvent_t)ev)); return 0; }
+
+int xg_mask_value(void* data, uint64_t nelem, int elem_bytes, double value, void* stream) {
+  if (elem_bytes != 4 && elem_bytes != 8) return fail(XG_ERR_INVALID, "masking of %d-byte elements (float32 / float64 only)", elem_bytes);
+  if (nelem == 0) return XG_OK;
+  if (!data) return fail(XG_ERR_INVALID, "NULL buffer");
+  u64 nblocks = (nelem + BLOCK - 1) / BLOCK;
+  if (nblocks > 256ull * 64) nblocks = 256ull * 64;  // grid-stride above that
+  if (elem_bytes == 4) hipLaunchKernelGGL(k_mask_value<float>, dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, (float*)data, (u64)nelem, (float)value);
+  else hipLaunchKernelGGL(k_mask_value<double>, dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, (double*)data, (u64)nelem, value);
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
 
 int xg_bswap(void* data, uint64_t nelem, int elem_bytes, void* stream) {
   if (elem_bytes != 4 && elem_bytes != 8) return fail(XG_ERR_INVALID, "byte swap of %d-byte elements (4 or 8)", elem_bytes);

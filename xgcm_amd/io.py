@@ -258,10 +258,27 @@ def netcdf_variable_info(path: str, name: str) -> Dict:
                 "isrec": bool(v.isrec), "attrs": {k: getattr(v, k) for k in v._attributes}}
 
 
-def netcdf_blocks(path: str, name: str, records_per_block: int = 1, records: Optional[Sequence[int]] = None) -> Iterator[np.ndarray]:
+def netcdf_missing_value(path: str, name: str) -> Optional[float]:
+    """The `_FillValue` (else `missing_value`) of a NetCDF-3 variable, or None.  xarray (mask_and_scale=True, the decoding
+    the reference's inputs go through) turns those cells into NaN; hand the value to `iter_stream(..., mask_value=...)` /
+    `stream_blocks` and the blocks are masked in HBM after the byte swap (xg_mask_value)."""
+    attrs = netcdf_variable_info(path, name)["attrs"]
+    for key in ("_FillValue", "missing_value"):
+        if key in attrs:
+            return float(np.asarray(attrs[key]).reshape(-1)[0])
+    return None
+
+
+def netcdf_blocks(path: str, name: str, records_per_block: int = 1, records: Optional[Sequence[int]] = None,
+                  missing: str = "refuse") -> Iterator[np.ndarray]:
     """Yield variable `name` of a NetCDF-3 file in blocks of its FIRST dimension (the record / time axis), big-endian as
     stored, from the file's memory map.  Record variables are interleaved per record on disk: the block is then a strided
-    view, which the staging copy of `iter_stream` gathers.  float32 / float64 variables without CF packing only."""
+    view, which the staging copy of `iter_stream` gathers.  float32 / float64 variables without CF packing only.
+
+    A variable that declares `_FillValue` / `missing_value` (MITgcm's mnc can) is refused unless `missing="raw"`: the raw
+    blocks still hold the fill value where the reference's pipeline (xarray decoding) holds NaN, and skipna reductions /
+    cumsum over land cells would differ silently.  With `missing="raw"` pass `mask_value=netcdf_missing_value(path, name)`
+    to the streaming call and the cells become NaN on the GPU."""
     from scipy.io import netcdf_file
     import warnings
 
@@ -276,6 +293,13 @@ def netcdf_blocks(path: str, name: str, records_per_block: int = 1, records: Opt
             raise NotImplementedError(f"{path}:{name} is {v.data.dtype}; float32 / float64 variables only")
         if any(a in v._attributes for a in ("scale_factor", "add_offset")):
             raise NotImplementedError(f"{path}:{name} is a packed variable (scale_factor / add_offset)")
+        if missing not in ("refuse", "raw"):
+            raise ValueError("missing must be 'refuse' or 'raw'")
+        if missing == "refuse" and any(a in v._attributes for a in ("_FillValue", "missing_value")):
+            raise NotImplementedError(
+                f"{path}:{name} declares _FillValue / missing_value: xarray would mask those cells to NaN.  Read it with "
+                "missing='raw' and pass mask_value=xgcm_amd.io.netcdf_missing_value(path, name) to iter_stream / "
+                "stream_blocks (masked in HBM), or accept the raw fill values knowingly.")
         if len(v.shape) < 1:
             raise ValueError(f"{path}:{name} is a scalar")
         n = int(v.shape[0])

@@ -117,12 +117,136 @@ def ensure_ranks(n_gpus: int, script: str, argv: Sequence[str]) -> None:
     sys.exit(subprocess.call(cmd, env=env))
 
 
+# ----------------------------------------------------------------------------------------------
+# Placement: a rank drives its GPU from Python (4 launches of ~1.6 ms per bench step), so on a two-socket 8-GPU
+# host its process belongs on the CPUs of the NUMA node its GPU hangs off -- a rank scheduled across the socket
+# link pays that latency on every launch and on every pinned-memory copy.  The binding is read from sysfs
+# (PCI device -> local_cpulist / numa_node), opt-out with XG_NUMA_BIND=0, and REPORTED whether or not it was
+# applied, so that the first 8-GPU run explains itself.
+# ----------------------------------------------------------------------------------------------
+def parse_cpulist(text: str):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the kernel's cpulist format)"""
+    cpus = []
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-", 1)
+            cpus.extend(range(int(a), int(b) + 1))
+        else:
+            cpus.append(int(part))
+    return sorted(set(cpus))
+
+
+def format_cpulist(cpus) -> str:
+    """[0, 1, 2, 3, 8] -> '0-3,8'"""
+    cpus = sorted(set(int(c) for c in cpus))
+    out, i = [], 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
+def pci_placement(pci_bus_id: Optional[str], sysfs: str = "/sys") -> dict:
+    """{pci_bus_id, numa_node, cpus} of a PCI device from sysfs: `local_cpulist` of the device, else the cpulist of its
+    `numa_node`; numa_node -1 / unreadable files leave `cpus` empty (a single-node host: nothing to bind)."""
+    import os
+
+    info = {"pci_bus_id": pci_bus_id, "numa_node": None, "cpus": []}
+    if not pci_bus_id:
+        return info
+    dev = os.path.join(sysfs, "bus", "pci", "devices", pci_bus_id.lower())
+
+    def read(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except OSError:
+            return None
+
+    node = read(os.path.join(dev, "numa_node"))
+    if node is not None:
+        try:
+            info["numa_node"] = int(node)
+        except ValueError:
+            pass
+    cpulist = read(os.path.join(dev, "local_cpulist"))
+    if not cpulist and info["numa_node"] is not None and info["numa_node"] >= 0:
+        cpulist = read(os.path.join(sysfs, "devices", "system", "node", f"node{info['numa_node']}", "cpulist"))
+    if cpulist:
+        try:
+            info["cpus"] = parse_cpulist(cpulist)
+        except ValueError:
+            info["cpus"] = []
+    return info
+
+
+def gpu_pci_bus_id(index: int) -> Optional[str]:
+    """'0000:c1:00.0' of cuda:index (None without a GPU)"""
+    import torch
+
+    if not torch.cuda.is_available():
+        return None
+    try:
+        p = torch.cuda.get_device_properties(index)
+        return f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0"
+    except Exception:
+        return None
+
+
+def bind_to_gpu_numa(local_rank: int, sysfs: str = "/sys", pci_bus_id: Optional[str] = None, apply: Optional[bool] = None) -> dict:
+    """Restrict this process to the CPUs local to its GPU (`os.sched_setaffinity`) and return what was found and done:
+    {local_rank, pci_bus_id, numa_node, cpus (cpulist text), n_cpus, bound, affinity_before / affinity (cpulists the
+    process ran / runs on)}.
+    `apply` None = on unless XG_NUMA_BIND=0.  Never raises: an unreadable sysfs or a refused affinity call is reported."""
+    import os
+
+    if apply is None:
+        apply = os.environ.get("XG_NUMA_BIND", "1") != "0"
+    info = pci_placement(pci_bus_id if pci_bus_id is not None else gpu_pci_bus_id(local_rank), sysfs)
+    cpus = info.pop("cpus")
+    out = {"local_rank": int(local_rank), "pci_bus_id": info["pci_bus_id"], "numa_node": info["numa_node"],
+           "cpus": format_cpulist(cpus), "n_cpus": len(cpus), "bound": False}
+    try:
+        out["affinity_before"] = format_cpulist(os.sched_getaffinity(0))  # to undo the binding (bench.py's CPU-baseline leg)
+    except (AttributeError, OSError):
+        out["affinity_before"] = None
+    if apply and cpus and hasattr(os, "sched_setaffinity"):
+        try:
+            allowed = set(os.sched_getaffinity(0))
+            target = sorted(set(cpus) & allowed)  # never widen a cpuset the launcher / container imposed
+            if target:
+                os.sched_setaffinity(0, target)
+                out["bound"] = True
+        except OSError as exc:
+            out["error"] = str(exc)
+    try:
+        out["affinity"] = format_cpulist(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        out["affinity"] = None
+    return out
+
+
 class Ranks:
     """The process group as this rank sees it: RCCL ("nccl") on the GPU box, gloo in CPU tests.  Only
     barriers and scalar reductions go through it -- the record-axis split has no data-path collective."""
 
-    def __init__(self, rank: int, world: int, local_rank: int, backend: Optional[str], dist):
+    def __init__(self, rank: int, world: int, local_rank: int, backend: Optional[str], dist, placement: Optional[dict] = None):
         self.rank, self.world, self.local_rank, self.backend, self.dist = rank, world, local_rank, backend, dist
+        self.placement = placement or {"local_rank": local_rank, "bound": False}  # bind_to_gpu_numa's report
+
+    def gather_objects(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank (small picklable records: placement, timings)"""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
     @property
     def scalar_device(self) -> str:
@@ -213,8 +337,11 @@ def init_ranks(n_gpus: int, backend: Optional[str] = None) -> Ranks:
             torch.cuda.set_device(local_rank)
     elif backend == "nccl":
         raise SystemExit("backend nccl (RCCL) needs a GPU")
+    # this rank's process onto the CPUs of its GPU's NUMA node (reported in any case; XG_NUMA_BIND=0 leaves it alone)
+    placement = bind_to_gpu_numa(local_rank if not shared or not torch.cuda.is_available() else local_rank % torch.cuda.device_count())
+    placement["local_rank"] = local_rank
     if "WORLD_SIZE" not in os.environ:
-        return Ranks(0, 1, 0, None, None)
+        return Ranks(0, 1, 0, None, None, placement)
     import torch.distributed as dist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -226,7 +353,7 @@ def init_ranks(n_gpus: int, backend: Optional[str] = None) -> Ranks:
         dist.init_process_group(backend, rank=rank, world_size=world)
     if dist.get_world_size() != int(n_gpus):
         raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {n_gpus} asked")
-    return Ranks(rank, world, local_rank, backend, dist)
+    return Ranks(rank, world, local_rank, backend, dist, placement)
 
 
 # ----------------------------------------------------------------------------------------------

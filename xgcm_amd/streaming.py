@@ -197,8 +197,13 @@ class _Stage:
         return b[:n].view(tuple(shape))
 
 
-def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, copy: bool = True) -> Iterator[np.ndarray]:
+def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, copy: bool = True,
+                mask_value: Optional[float] = None) -> Iterator[np.ndarray]:
     """Yield `fn(block)` for every host block of `blocks`, in order, as host arrays.
+
+    `mask_value`: cells of the uploaded block equal to it become NaN before `fn` sees the block (xg_mask_value, in HBM
+    after the byte swap) -- the `_FillValue` / `missing_value` of a file variable, which xarray's decoding masks for the
+    reference (`xgcm_amd.io.netcdf_missing_value`).
 
     `blocks`: any iterable of array-likes (float32 / float64, records along the first axis; anything
     `numpy.asarray` accepts, e.g. `numpy.memmap`).  `fn`: HBM tensor -> HBM tensor (e.g. a closure over
@@ -225,6 +230,9 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
         with torch.cuda.stream(s_in):
             x = host.to(dev, non_blocking=True)
             _swap_on_device(x, swap, s_in)  # a big-endian block: raw bytes came over, the order is reversed in HBM
+            if mask_value is not None and x.numel():
+                _hip.check(_hip.load().xg_mask_value(x.data_ptr(), x.numel(), x.element_size(), float(mask_value),
+                                                     s_in.cuda_stream))
             ev = torch.cuda.Event()
             ev.record(s_in)
         in_free[slot] = ev
@@ -276,12 +284,13 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
 
 
 def stream_blocks(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable,
-                  sink: Optional[Callable[[int, np.ndarray], None]] = None) -> Optional[np.ndarray]:
+                  sink: Optional[Callable[[int, np.ndarray], None]] = None,
+                  mask_value: Optional[float] = None) -> Optional[np.ndarray]:
     """Run `iter_stream` to completion.  With `sink(k, result_block)` every result is handed over as it arrives
     (write it to a file, a zarr store ...) and None is returned; without it the results are concatenated along
     the record axis and returned."""
     parts = []
-    for k, res in enumerate(iter_stream(fn, blocks, copy=sink is None)):
+    for k, res in enumerate(iter_stream(fn, blocks, copy=sink is None, mask_value=mask_value)):
         if sink is not None:
             sink(k, res)
         else:
