@@ -5,6 +5,13 @@ algorithmic bytes of the FUSED form.  Its purpose is to find cliffs -- combinati
 siblings -- not to produce the judged numbers (bench.py, tools/bench_configs.py).
 
     python tools/survey.py [--reps 5] [--shape 75,2400,3600]
+    python tools/survey.py --trace          # the same run under `rocprofv3 --kernel-trace`: kernel time per call next to
+                                            # the event-timed wall time of the SAME process
+
+`--trace` answers "is a slow operator slow in its kernels or around them": `trace_us` is the summed duration of every kernel
+the operator launches per call (profiler's clock), `ms` the HIP-event time per call of the same process.  When two tools
+disagree on one operator (r03end: cumsum Z 1.749 ms in roofline_table.py, 1.91 ms here) the pair tells whether the path
+(extra launches, allocation) or the state of the device (what ran before, for how long) makes the difference.
 """
 import argparse
 import json
@@ -34,12 +41,67 @@ def timeit(fn, reps):
     return ts[len(ts) // 2]
 
 
+def traced(argv):
+    """re-run this script with --mark under rocprofv3 --kernel-trace and join the kernel durations to its JSON lines"""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    tmp = tempfile.mkdtemp(prefix="survey_", dir="/tmp")
+    cmd = ["rocprofv3", "--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--mark"] + argv
+    r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    dbs = glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True)
+    if r.returncode != 0 or not dbs:
+        print(json.dumps({"error": r.stdout[-600:]}), flush=True)
+        return
+    con = sqlite3.connect(dbs[0])
+    blocks, cur = {}, None
+    for name, dur, gx in con.execute("select name, duration, grid_x from kernels order by start"):
+        k = name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
+        if k.startswith("k_fill_synthetic") and gx % 4096 == 0 and gx < 4096 * 512:
+            cur = gx // 4096 - 1
+            continue
+        if cur is not None:
+            e = blocks.setdefault(cur, {})
+            e.setdefault(k, []).append(dur / 1e3)
+    shutil.rmtree(tmp, ignore_errors=True)
+    for i, ln in enumerate(lines):
+        if "error" in ln:
+            print(json.dumps(ln), flush=True)
+            continue
+        kern = blocks.get(ln.get("index", i), {})
+        calls = ln.get("calls", 1)
+        # per call: every kernel's launches of the block / calls, each at its median duration (the first call runs on cold caches)
+        per_call = 0.0
+        detail = {}
+        for k, ds in kern.items():
+            ds = sorted(ds)
+            med = ds[len(ds) // 2]
+            n = len(ds) / calls
+            per_call += med * n
+            if med * n > 20:
+                detail[k[:60]] = {"us": round(med, 1), "launches_per_call": round(n, 2)}
+        ln["trace_us_per_call"] = round(per_call, 1)
+        ln["wall_over_trace"] = round(ln["ms"] * 1e3 / per_call, 4) if per_call else None
+        ln["kernels"] = detail
+        print(json.dumps(ln), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--shape", default="75,2400,3600")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--only", default="", help="comma-separated substrings: run the operators whose name contains one of them")
+    ap.add_argument("--mark", action="store_true", help="a marker dispatch (k_fill_synthetic of 4096 * (1 + index) cells) before every operator")
+    ap.add_argument("--trace", action="store_true", help="run under rocprofv3 --kernel-trace and print kernel time per call next to the wall time")
     a = ap.parse_args()
+    if a.trace:
+        traced([x for x in sys.argv[1:] if x != "--trace"])
+        return
     nz, ny, nx = (int(v) for v in a.shape.split(","))
     cells = nz * ny * nx
     tdt = torch.float32 if a.dtype == "f32" else torch.float64
@@ -77,15 +139,19 @@ def main():
               ("diff [Y,X]", lambda: grid.diff(T, ["Y", "X"]), 16),
               ("interp [X,Y] metric_weighted (X,Y)", lambda: grid.interp(T, ["X", "Y"], metric_weighted=("X", "Y")), 16 + 2 * mB),
               ("T * hFacC (3-D metric)", lambda: T * dv["hFacC"], 24), ("T / dxT (2-D)", lambda: T / dv["dxT"], 16 + mB)]
-    for name, fn, bpc in cases:
+    for index, (name, fn, bpc) in enumerate(cases):
+        if a.only and not any(w.strip() and w.strip() in name for w in a.only.split(",")):
+            continue
         try:
+            if a.mark:
+                D.synthetic((4096 * (1 + index),), 1)
             ms = timeit(fn, a.reps)
         except Exception as exc:  # noqa: BLE001
             print(json.dumps({"op": name, "error": f"{type(exc).__name__}: {exc}"[:200]}), flush=True)
             continue
         bpc = bpc * esz / 8.0  # the byte counts above are written for 8-byte elements
         gbs = cells * bpc / (ms * 1e-3) / 1e9
-        print(json.dumps({"op": name, "dtype": a.dtype, "ms": round(ms, 3), "bytes_per_cell_fused": round(bpc, 3), "GBps": round(gbs, 1),
+        print(json.dumps({"op": name, "index": index, "calls": a.reps + 2, "dtype": a.dtype, "ms": round(ms, 3), "bytes_per_cell_fused": round(bpc, 3), "GBps": round(gbs, 1),
                           "frac_8TBps": round(gbs / 8000, 4)}), flush=True)
 
 
