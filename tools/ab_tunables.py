@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--mark", action="store_true", help="a marker dispatch (k_fill_synthetic of 4096 * (1 + variant * ncases + case) "
                     "cells) before every (variant, case) block: tools/pmc_ab.py maps rocprofv3 dispatches to variants with it")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="f32: every synthetic operand in float32 (bytes per cell halve)")
+    ap.add_argument("--realloc", action="store_true", help="every round on FRESH buffers (allocator cache emptied, the next allocations "
+                    "shifted): a kernel's rate depends on where the driver placed its buffers -- cumsum Z 1.71 to 2.03 ms on one box, "
+                    "profiles/r04a_addr_probe.jsonl -- so a table that is to agree with another process's must report the median over placements")
     a = ap.parse_args()
     bscale = 1.0
     if a.dtype == "f32":  # (the transform cases build their coordinates in float64: not covered)
@@ -141,7 +144,26 @@ def main():
         for _ in range(3):
             CASES[c][0]()
     torch.cuda.synchronize()
+    _shift = None
     for rnd in range(a.rounds):
+        if a.realloc and rnd > 0:  # the big full-size operands on fresh allocations (small metrics and transform tables stay)
+            _shift = None
+            T = U = V = None
+            T2k, T3k = T2 is not None, T3 is not None
+            T2 = T3 = None
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            _shift = torch.empty((rnd * 37 + 1) << 20, dtype=torch.uint8, device="cuda")
+            T = D.synthetic((nz, ny, nx), 2)
+            if T2k:
+                T2 = D.synthetic((nz, ny, nx), 9, 0, 1000.0, 1000.0)
+            if T3k:
+                T3 = D.synthetic((nz, ny, nx), 10, 0, 1000.0, 1000.0)
+            if any(c in cases for c in ("vort", "divg", "flux")):
+                U, V = D.synthetic((nz, ny, nx), 51), D.synthetic((nz, ny, nx), 52)
+            for c in cases:
+                CASES[c][0]()
+            torch.cuda.synchronize()
         order = list(range(len(variants)))
         order = order[rnd % len(order):] + order[:rnd % len(order)]
         for vi in order:

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--shape", default="75,2400,3600")
     ap.add_argument("--min-us", type=float, default=200.0, help="dispatches shorter than this are not reported")
     ap.add_argument("--pass-timeout", type=int, default=150, help="seconds one rocprofv3 pass may take")
+    ap.add_argument("--placements", type=int, default=1, help="rounds on fresh buffers (ab_tunables --realloc): the reported duration is "
+                    "the median over all of them")
     a = ap.parse_args()
     cases = a.cases.split(",")
     variants = a.variants.split(";")
@@ -46,8 +48,8 @@ def main():
         tmp = tempfile.mkdtemp(prefix="pmcab_", dir="/tmp")
         # the group "TRACE" is a plain kernel-trace pass: durations without any counter collected
         cmd = ["rocprofv3"] + ([] if group == "TRACE" else ["--pmc"] + group.split()) + ["--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable,
-               os.path.join(REPO, "tools", "ab_tunables.py"), "--cases", a.cases, "--variants", a.variants, "--rounds", "1",
-               "--reps", str(a.reps), "--mark", "--shape", a.shape]
+               os.path.join(REPO, "tools", "ab_tunables.py"), "--cases", a.cases, "--variants", a.variants, "--rounds", str(max(1, a.placements)),
+               "--reps", str(a.reps), "--mark", "--shape", a.shape] + (["--realloc"] if a.placements > 1 else [])
         env = dict(os.environ, TMPDIR="/tmp")
         try:  # a counter group the profiler cannot serve must not cost the session (TA_* counters hung a pass for 15 minutes)
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=ap_timeout)
@@ -95,6 +97,8 @@ def main():
             d = sorted(e["dur"])
             row = {"pass": group, "variant": variants[vi], "case": cases[ci], "kernel": k[:70], "vgpr": e["vgpr"], "n": len(d),
                    ("us" if group == "TRACE" else "us_under_pmc"): round(d[len(d) // 2], 1) if d else None}
+            if group == "TRACE" and d:
+                row["us_min"], row["us_max"] = round(d[0], 1), round(d[-1], 1)
             if cases[ci] in alg:
                 row["alg_bytes"] = alg[cases[ci]]
             for cname, vals in e.items():

@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--shape", default="75,2400,3600")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--placements", type=int, default=3, help="fresh placements of the field (allocator cache emptied, allocations "
+                    "shifted) each operator is timed on; `ms` is the median over them, `ms_min` / `ms_max` the spread")
     ap.add_argument("--only", default="", help="comma-separated substrings: run the operators whose name contains one of them")
     ap.add_argument("--mark", action="store_true", help="a marker dispatch (k_fill_synthetic of 4096 * (1 + index) cells) before every operator")
     ap.add_argument("--trace", action="store_true", help="run under rocprofv3 --kernel-trace and print kernel time per call next to the wall time")
@@ -120,6 +122,17 @@ def main():
                 metrics={("X",): ["dxC", "dxT"], ("Y",): ["dyC", "dyT"], ("Z",): ["drF", "drC"], ("X", "Y"): ["rA", "rAz"]},
                 autoparse_metadata=False)
     T = DataArray(D.synthetic((nz, ny, nx), 2, dtype=tdt), ("Z", "YC", "XC"), name="T")
+    shift = [None]
+
+    def replace_field(k):
+        """the field on a fresh allocation (the lambdas below read `T.data` at call time)"""
+        T.data = None
+        shift[0] = None
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        shift[0] = torch.empty((k * 37 + 1) << 20, dtype=torch.uint8, device="cuda")
+        T.data = D.synthetic((nz, ny, nx), 2, dtype=tdt)
+
     mB = 8.0 / nz  # bytes per cell of a 2-D metric read once
     cases = []
     for ax in "XYZ":
@@ -145,13 +158,20 @@ def main():
         try:
             if a.mark:
                 D.synthetic((4096 * (1 + index),), 1)
-            ms = timeit(fn, a.reps)
+            per = []
+            for k in range(max(1, a.placements)):
+                if k > 0:
+                    replace_field(k)
+                per.append(timeit(fn, a.reps))
+            per.sort()
+            ms = per[len(per) // 2]
         except Exception as exc:  # noqa: BLE001
             print(json.dumps({"op": name, "error": f"{type(exc).__name__}: {exc}"[:200]}), flush=True)
             continue
         bpc = bpc * esz / 8.0  # the byte counts above are written for 8-byte elements
         gbs = cells * bpc / (ms * 1e-3) / 1e9
-        print(json.dumps({"op": name, "index": index, "calls": a.reps + 2, "dtype": a.dtype, "ms": round(ms, 3), "bytes_per_cell_fused": round(bpc, 3), "GBps": round(gbs, 1),
+        print(json.dumps({"op": name, "index": index, "calls": (a.reps + 2) * max(1, a.placements), "dtype": a.dtype, "ms": round(ms, 3),
+                          "ms_min": round(per[0], 3), "ms_max": round(per[-1], 3), "bytes_per_cell_fused": round(bpc, 3), "GBps": round(gbs, 1),
                           "frac_8TBps": round(gbs / 8000, 4)}), flush=True)
 
 

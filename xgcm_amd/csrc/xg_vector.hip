@@ -684,7 +684,8 @@ static int pair2d_impl(int mode, const real* a, const real* u, const real* v, re
   // both planes come from the fabric again for every level (0.56 of 8 TB/s level-major).  Two metrics: 8-row bands (rule 13)
   ZBand zb = make_zband(false, 0, 0, 1);
   u64 outer_step = outer_per;
-  const u32 ZB_SEGS = (u32)((((mx && my) ? 8 : 16) + SEG - 1) / SEG);
+  const u32 gzb = (u32)(tune().vec_zb_rows > 1 ? tune().vec_zb_rows : 16);  // rows per band with ONE metric; two: half
+  const u32 ZB_SEGS = (u32)((((mx && my) ? (gzb / 2 < 2 ? 2 : gzb / 2) : gzb) + SEG - 1) / SEG);
   auto shared = [](const real* m, const AreaIdx& ai) {  // absent, or broadcast along every leading dim
     for (int d = 0; m && d < ai.n; ++d)
       if (ai.stride[d] != 0) return false;
