@@ -137,49 +137,6 @@ def test_strided_metric_stencil_y_stacked_workgroups(dev, dtype, ys):
             _hip.set_tunable(k, v)
 
 
-def test_banded_kernels_with_x_chunked_rows(dev):
-    """Round 4 (DESIGN rule 17): the band-major launches can cut their rows into chunks of `zb_xc` x-tiles and visit
-    (band, chunk) pairs, growing the band at equal L2 footprint.  A pure permutation of the work order: every banded
-    kernel -- K2S, K2Sm, the two-axis kernels with metrics, fused vorticity / divergence / gradient -- under chunk widths
-    that divide the row, that leave a ragged last chunk and that exceed it, bit for bit against the oracle."""
-    from xgcm_amd import _hip
-    keep = {k: _hip.get_tunable(k) for k in ("zb_xc", "met_ys1", "met_ys", "zb_rows", "vec_zb_rows")}
-    try:
-        for shape in ((6, 40, 512), (5, 37, 700), (9, 70, 1280)):
-            nz, ny, nx = shape
-            a = _field(shape, 81)
-            u, v = _field(shape, 82), _field(shape, 83)
-            m1, m2, m3 = (R.synthetic_metric((1, ny, nx), 84 + k) for k in range(3))
-            want = {
-                "iY": R.stencil1d("interp", a, 1, 1, 0, "extend", 0.0, m1, m2),
-                "dY": R.stencil1d("diff", a, 1, 0, 1, "periodic", 0.0, None, m1),
-                "i2x": R.stencil1d("interp", R.stencil1d("interp", a, 2, 1, 0, "periodic", 0.0, m1, m2), 1, 1, 0, "extend", 0.0, m2, m3),
-                "i2y": R.stencil1d("interp", R.stencil1d("interp", a, 1, 1, 0, "extend", 0.0, m1, m2), 2, 1, 0, "periodic", 0.0, m2, m3),
-                "vort": R.vorticity(u, v, m1, "fill", "extend", 0.5, 0.0),
-                "divg": R.divergence(u, v, m2, "periodic", "fill", 0.0, -1.0),
-                "grad": R.gradient(a, "periodic", "extend", 0.0, 0.0, m1, m2),
-            }
-            for xc, rows in ((0, 16), (1, 16), (2, 4), (3, 16), (64, 16)):
-                _hip.set_tunable("zb_xc", xc)
-                _hip.set_tunable("zb_rows", rows)
-                _hip.set_tunable("vec_zb_rows", rows)
-                for ys1, ys in ((keep["met_ys1"], keep["met_ys"]), (0, 0)):  # y-stacked forms and the plain ones
-                    _hip.set_tunable("met_ys1", ys1)
-                    _hip.set_tunable("met_ys", ys)
-                    _eq(dev.tohost(dev.stencil1d("interp", a, 1, 1, 0, "extend", 0.0, m1, m2)), want["iY"])
-                    _eq(dev.tohost(dev.stencil1d("diff", a, 1, 0, 1, "periodic", 0.0, None, m1)), want["dY"])
-                    _eq(dev.tohost(dev.stencil2d("interp", a, 0, (1, 0), "periodic", 0.0, (1, 0), "extend", 0.0, metrics=(m1[0], m2[0], m3[0]))), want["i2x"])
-                    _eq(dev.tohost(dev.stencil2d("interp", a, 1, (1, 0), "periodic", 0.0, (1, 0), "extend", 0.0, metrics=(m1[0], m2[0], m3[0]))), want["i2y"])
-                _eq(dev.tohost(dev.vorticity(u, v, m1, "fill", "extend", 0.5, 0.0)), want["vort"])
-                _eq(dev.tohost(dev.divergence(u, v, m2, "periodic", "fill", 0.0, -1.0)), want["divg"])
-                gx, gy = dev.gradient(a, "periodic", "extend", 0.0, 0.0, m1, m2)
-                _eq(dev.tohost(gx), want["grad"][0])
-                _eq(dev.tohost(gy), want["grad"][1])
-    finally:
-        for k, val in keep.items():
-            _hip.set_tunable(k, val)
-
-
 @pytest.mark.parametrize("shape", [(6, 10, 128), (3, 7, 33), (2, 5, 4, 66), (300,), (3, 700), (2, 2050), (3, 1024), (9, 4100)])
 def test_cumsum_all(dev, shape):
     a = _field(shape, 7, nan=True)

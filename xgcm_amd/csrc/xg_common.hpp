@@ -117,7 +117,6 @@ struct Tune {
   int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
   int zb_rows;        // rows per band
-  int zb_xc;          // x-tiles per chunk of a banded row (0: whole rows); the band grows by ntile / zb_xc
   int scan_block;     // workgroup size of the contiguous-axis scan (128 / 256 / 512 / 1024)
   int strided_gen;    // flat NV-group kernel for misaligned rows of a strided stencil axis
   int march_band;     // XCD-banded wave order in the column-marching scans / reductions
@@ -215,43 +214,21 @@ __device__ __forceinline__ u32 fdiv(u32 n, const FastDiv& f) {
 // dx(Y,X) weighting a (Z,Y,X) field), rows are visited band by band -- all Z levels of a band of
 // B rows before the next band -- so the band's metric values are fetched once and then served by
 // the XCD's L2 for the other Z-1 levels instead of being re-read from the Infinity Cache per level.
-// "x-chunking" (round 4): a band costs one halo row per level at its lower edge (the row below was read a whole band's
-// worth of levels ago: an HBM fetch, 1 / B of the field reads), and B is capped by what must survive in the L2 for a
-// level: B x (row bytes) x (metric planes).  Cutting the rows into chunks of `xc` x-tiles and visiting (band, chunk) pairs
-// -- all levels of one chunk of a band before the next chunk -- shrinks that footprint by ntile / xc, so the band grows by
-// the same factor at equal footprint and the halo re-reads shrink with it.  The kernels' decode stays `r = w / ntile,
-// tile = w % ntile` with the CHUNK WIDTH passed as `ntile`; zband_xmap() adds the chunk's first tile.
 struct ZBand {
   u32 on, Z, B, Y;       // Y = rows (or segments) per level, B = rows (segments) per band
   FastDiv per_band, fB;  // divisors Z*B and B
-  u32 nxc, xc, ntile;    // x-chunks per row (0 / 1: whole rows), tiles per chunk, tiles per row
-  FastDiv fnxc;
 };
-inline ZBand make_zband(bool on, u64 Z, u64 Y, u32 B, u32 xc = 0, u64 ntile = 0) {
+inline ZBand make_zband(bool on, u64 Z, u64 Y, u32 B) {
   ZBand z;
   memset(&z, 0, sizeof(z));
   z.per_band = make_fastdiv(1);
   z.fB = make_fastdiv(1);
-  z.fnxc = make_fastdiv(1);
   if (!on || Z < 2 || Z * (u64)B > 0x7fffffffull) return z;
   z.on = 1; z.Z = (u32)Z; z.B = B; z.Y = (u32)Y;
   z.per_band = make_fastdiv(Z * B);
   z.fB = make_fastdiv(B);
-  if (xc > 0 && ntile > xc && ntile < 0x7fffffffull) {
-    z.xc = xc;
-    z.ntile = (u32)ntile;
-    z.nxc = (u32)((ntile + xc - 1) / xc);
-    z.fnxc = make_fastdiv(z.nxc);
-  }
   return z;
 }
-// tiles a row occupies in the work sequence (chunked rows are padded to whole chunks) and the divisor the kernels split
-// a wave index with
-inline u64 zband_row_tiles(const ZBand& zb, u64 ntile) { return zb.nxc > 1 ? (u64)zb.nxc * zb.xc : ntile; }
-inline FastDiv zband_tile_div(const ZBand& zb, u64 ntile) { return make_fastdiv(zb.nxc > 1 ? (u64)zb.xc : ntile); }
-// band height and chunk width for a banded launch: `rows` rows per band with whole rows; with the tunable `zb_xc` (tiles
-// per chunk) the rows are cut into chunks and the band grows by ntile / zb_xc (same L2 footprint), at most `max_rows`
-inline void zband_shape(u64 ntile, u32 rows, u32 max_rows, u32* band_rows, u32* xc);
 // work index r (band-major) -> (z, y); false if the band's tail row does not exist
 __device__ __forceinline__ bool zband_map(const ZBand& zb, u32 r, u32& z, u32& y) {
   const u32 b = fdiv(r, zb.per_band);
@@ -259,19 +236,6 @@ __device__ __forceinline__ bool zband_map(const ZBand& zb, u32 r, u32& z, u32& y
   z = fdiv(rem, zb.fB);
   y = b * zb.B + (rem - z * zb.B);
   return y < zb.Y;
-}
-
-// the same with x-chunks: `tile` comes in as the tile inside the chunk (w % xc) and leaves as the tile of the row
-__device__ __forceinline__ bool zband_xmap(const ZBand& zb, u32 r, u32& z, u32& y, u32& tile) {
-  if (zb.nxc <= 1) return zband_map(zb, r, z, y);
-  const u32 b = fdiv(r, zb.per_band);          // (band of rows, chunk) pair
-  const u32 rem = r - b * zb.per_band.d;
-  const u32 band = fdiv(b, zb.fnxc);
-  const u32 xch = b - band * zb.nxc;
-  z = fdiv(rem, zb.fB);
-  y = band * zb.B + (rem - z * zb.B);
-  tile += xch * zb.xc;
-  return y < zb.Y && tile < zb.ntile;
 }
 
 // Column chunking for the short-segment kernel when a "row" of the strided axis is a whole plane
@@ -643,18 +607,6 @@ inline int check_grid(u64 nblocks) {
     hipError_t e_ = hipGetLastError();                                                 \
     if (e_ != hipSuccess) return fail(XG_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(e_)); \
   } while (0)
-
-inline void zband_shape(u64 ntile, u32 rows, u32 max_rows, u32* band_rows, u32* xc) {
-  *band_rows = rows;
-  *xc = 0;
-  const int t = tune().zb_xc;
-  if (t <= 0 || ntile <= (u64)t) return;
-  const u64 grow = ntile / (u64)t;
-  u64 r = (u64)rows * grow;
-  if (r > max_rows) r = max_rows;
-  *band_rows = (u32)r;
-  *xc = (u32)t;
-}
 
 inline unsigned march_lds() {
   int kb = tune().march_lds_kb;

@@ -27,7 +27,6 @@ const TuneEntry TUNABLES[] = {
     {"zchunk", &Tune::zchunk, 256},
     {"zband", &Tune::zband, 1},
     {"zb_rows", &Tune::zb_rows, 16},
-    {"zb_xc", &Tune::zb_xc, 0},
     {"scan_block", &Tune::scan_block, 256},
     {"strided_gen", &Tune::strided_gen, 1},
     {"march_band", &Tune::march_band, 1},  // config 4 (8 records, cumsum along Z) 14.8 -> 13.1 ms

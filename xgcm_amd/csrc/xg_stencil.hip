@@ -485,10 +485,10 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
     tile = (cg - oo * ck.fnchunk.d) * ck.ch.d + (rem - sg * ck.ch.d);
     if (oo >= nouter || tile >= ntile.d) return;
   } else {
-    const u32 r = fdiv(w, ntile);  // (x-chunked bands: `ntile` is the chunk width and zband_xmap adds the chunk's first tile)
+    const u32 r = fdiv(w, ntile);
     tile = w - r * ntile.d;
-    if (MET != 0 && zb.on) {  // band-major order over (segment band [, x-chunk], outer [group], segment)
-      if (!zband_xmap(zb, r, oo, sg, tile)) return;
+    if (MET != 0 && zb.on) {  // band-major order over (segment band, outer [group], segment)
+      if (!zband_map(zb, r, oo, sg)) return;
       oo *= ZK;
     } else {
       oo = fdiv(r, nseg);
@@ -727,11 +727,11 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d(
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
   if (lb >= nblk) return;
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
-  const u32 r = fdiv(w, ntile);  // (x-chunked bands: `ntile` is the chunk width, zband_xmap adds the chunk's first tile)
-  u32 tile = w - r * ntile.d;
+  const u32 r = fdiv(w, ntile);
+  const u32 tile = w - r * ntile.d;
   u32 oo, sg;
   if (MET && zb.on) {  // band-major: every outer index of a band of rows before the next band (the three planes stay in L2)
-    if (!zband_xmap(zb, r, oo, sg, tile)) return;
+    if (!zband_map(zb, r, oo, sg)) return;
     oo *= ZK;
     if (oo >= nouter) return;
   } else {
@@ -909,10 +909,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil2d_ys(
   const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const u32 r = fdiv(lb, ntile);
-  u32 tile = lb - r * ntile.d;
+  const u32 tile = lb - r * ntile.d;
   u32 oo = 0, sgrp = 0;
-  bool active = zband_xmap(zb, r, oo, sgrp, tile);  // zb counts groups of WPB segments
-  if (!active) tile = 0;
+  bool active = zband_map(zb, r, oo, sgrp);  // zb counts groups of WPB segments
   oo *= ZK;
   active = active && oo < nouter;
   if (!active) oo = 0;
@@ -1260,9 +1259,9 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_ysm(
   const u32 wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const u32 r = fdiv(lb, ntile);
-  u32 tile = lb - r * ntile.d;
+  const u32 tile = lb - r * ntile.d;
   u32 oo, ssg;
-  if (!zband_xmap(zb, r, oo, ssg, tile)) return;  // band-major order over (band of super-segments [, x-chunk], level group, super-segment)
+  if (!zband_map(zb, r, oo, ssg)) return;  // band-major order over (band of super-segments, level group, super-segment)
   oo *= ZK;
   const u32 sg = ssg * WPB + wib;
   const int64_t o = oo;
@@ -1381,18 +1380,17 @@ bool launch_ysm(const StencilCall& c) {
   const u32 zb_base = (u32)(tune().zb_rows > 1 ? tune().zb_rows : 16);
   // one metric: bands of 2 x zb_rows = 32 rows hold here (reads 1.062 -> 1.032x, +0.6 points, profiles/r03bh_pmc_dy_bands.jsonl):
   // the output lines are dropped from the L2 as they are written (rule 16), the band's one metric plane and the halo rows stay
-  u32 zbr, zxc;  // rows per band, x-tiles per chunk (zb_xc: the band grows as the rows are cut, rule 17)
-  zband_shape(ntile, (c.m_in && c.m_out) ? zb_base / 2 : zb_base * 2, 512, &zbr, &zxc);
+  const u32 zbr = (c.m_in && c.m_out) ? zb_base / 2 : zb_base * 2;
   const u32 per = (u32)(SEG * WPB);
   const u32 ZB_SS = (zbr + per - 1) / per;  // band height in super-segments (at least one)
   const u64 padded = ((nsseg + ZB_SS - 1) / ZB_SS) * ZB_SS;
   const u64 zgroups = ((u64)c.g.outer + ZK - 1) / ZK;
-  ZBand zb = make_zband(true, zgroups, nsseg, ZB_SS, zxc, ntile);
-  const u64 nwg = padded * zgroups * zband_row_tiles(zb, ntile);
+  const u64 nwg = padded * zgroups * ntile;
+  ZBand zb = make_zband(true, zgroups, nsseg, ZB_SS);
   if (!zb.on || nwg > MAX_ITEMS) return false;
   const u32 nblk = (u32)nwg;
   const u32 grid = ((nblk + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_stencil_strided_ysm<OP, MET, SEG, ZK>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (u32)c.g.outer, nblk, zband_tile_div(zb, ntile), (u32)nseg, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
+  hipLaunchKernelGGL((k_stencil_strided_ysm<OP, MET, SEG, ZK>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (u32)c.g.outer, nblk, make_fastdiv(ntile), (u32)nseg, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
   return true;
 }
 
@@ -1422,8 +1420,7 @@ int launch_seg_n(const StencilCall& c) {
   // (round 3, PMC per band height, profiles/r03g_*: one metric 32 rows 1.106x the algorithmic reads, 16 rows 1.064x =
   // the halo row; two metrics 16 rows 1.14x, 8 rows 1.127x = the halo row; same speed within 0.5 % => 16 / 8 rows)
   const u32 zb_base = (u32)(tune().zb_rows > 1 ? tune().zb_rows : 16);
-  u32 zbr, zxc;  // rows per band, x-tiles per chunk (0: whole rows): the band grows as the rows are cut (zb_xc, rule 17)
-  zband_shape(ntile, (c.m_in && c.m_out) ? zb_base / 2 : zb_base, 512, &zbr, &zxc);
+  const u32 zbr = (c.m_in && c.m_out) ? zb_base / 2 : zb_base;
   const u32 ZB_SEGS = (zbr + SEG - 1) / SEG;
   const bool zb_ok = !ck.on && MET != 0 && tune().zband && c.g.n_outer == 1 && (!c.m_in || c.mi.outer[0] == 0) &&
                      (!c.m_out || c.mo.outer[0] == 0);
@@ -1431,16 +1428,15 @@ int launch_seg_n(const StencilCall& c) {
   if (zb_ok) {
     const u64 padded_segs = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS;
     const u64 zgroups = ((u64)c.g.outer + ZK - 1) / ZK;  // ZK levels per wave share the metric rows
-    ZBand zb = make_zband(true, zgroups, nseg, ZB_SEGS, zxc, ntile);
-    const u64 waves = padded_segs * zgroups * zband_row_tiles(zb, ntile);
+    const u64 waves = padded_segs * zgroups * ntile;
+    ZBand zb = make_zband(true, zgroups, nseg, ZB_SEGS);
     if (zb.on && waves <= MAX_ITEMS) {
       const u32 nblk = (u32)((waves + WPB - 1) / WPB);
       const u32 grid = ((nblk + 7) / 8) * 8;
-      const FastDiv fxt = zband_tile_div(zb, ntile);
       if (tune().nt_store)
-        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG, ZK>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fxt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG, ZK>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
       else
-        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fxt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
       return 0;
     }
   }
@@ -1640,37 +1636,33 @@ static int stencil2d_impl(int op, const real* in, real* out, const int64_t* shap
     ZBand zb = make_zband(false, 0, 0, 1);
     const int ZK2 = tune().met_zk2 >= 4 ? 4 : 2;  // levels per wave-task sharing the metric rows
     bool ys = false;  // K8y: X first with metrics, y-stacked workgroups handing the shared intermediate row on through LDS
-    FastDiv fxt = fnt;
     if (met && tune().zband && nouter >= 2) {  // the metric planes are shared by the outer indices: band-major order
-      u32 brows, zxc;  // rows per band, x-tiles per chunk (zb_xc: the band grows as the rows are cut, rule 17)
-      zband_shape(ntile, (u32)(tune().zb_rows > 0 ? tune().zb_rows : 16), 512, &brows, &zxc);
-      const u32 B = (brows + SEG - 1) / SEG;
+      const u32 B = ((u32)(tune().zb_rows > 0 ? tune().zb_rows : 16) + SEG - 1) / SEG;
       const u64 groups = ((u64)nouter + ZK2 - 1) / ZK2;
       if (order == 0 && nts && ZK2 == 4 && tune().met_ys && groups >= 2) {
         const u64 nsg = (nseg + WPB - 1) / WPB;                 // groups of WPB segments = workgroups per (level group, x-tile)
         const u32 Bg = (B + WPB - 1) / WPB;
-        zb = make_zband(true, groups, nsg, Bg, zxc, ntile);
-        const u64 blocks = ((nsg + Bg - 1) / Bg) * Bg * groups * zband_row_tiles(zb, ntile);
-        if (zb.on && blocks < 0x7ffffff0ull) { nblk = (u32)blocks; ys = true; }
-        else zb = make_zband(false, 0, 0, 1);
+        const u64 blocks = ((nsg + Bg - 1) / Bg) * Bg * groups * ntile;
+        if (blocks < 0x7ffffff0ull) {
+          zb = make_zband(true, groups, nsg, Bg);
+          if (zb.on) { nblk = (u32)blocks; ys = true; }
+        }
       }
-      if (!ys && groups >= 2) {
-        zb = make_zband(true, groups, nseg, B, zxc, ntile);
-        const u64 padded = ((nseg + B - 1) / B) * B * groups * zband_row_tiles(zb, ntile);
-        if (zb.on && padded <= MAX_ITEMS) nblk = (u32)((padded + WPB - 1) / WPB);
-        else zb = make_zband(false, 0, 0, 1);
+      const u64 padded = ((nseg + B - 1) / B) * B * groups * ntile;
+      if (!ys && groups >= 2 && padded <= MAX_ITEMS) {
+        zb = make_zband(true, groups, nseg, B);
+        if (zb.on) nblk = (u32)((padded + WPB - 1) / WPB);
       }
-      fxt = zband_tile_div(zb, ntile);
     }
     const u32 grid = ((nblk + 7) / 8) * 8;
     if (ys) {
-#define XG_YS(O) hipLaunchKernelGGL((k_stencil2d_ys<O, true, SEG, 4>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fxt, tune().nb_dpp, padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
+#define XG_YS(O) hipLaunchKernelGGL((k_stencil2d_ys<O, true, SEG, 4>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, tune().nb_dpp, padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
       switch (op) { case XG_OP_DIFF: XG_YS(XG_OP_DIFF); break; case XG_OP_INTERP: XG_YS(XG_OP_INTERP); break; case XG_OP_MIN: XG_YS(XG_OP_MIN); break; default: XG_YS(XG_OP_MAX); }
 #undef XG_YS
       continue;
     }
-#define XG_GM(O, NTS, M) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, M>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fxt, fns, order | (tune().nb_dpp ? 2 : 0), padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
-#define XG_GZK(O, NTS, ZK_) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, true, ZK_>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fxt, fns, order | (tune().nb_dpp ? 2 : 0), padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
+#define XG_GM(O, NTS, M) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, M>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order | (tune().nb_dpp ? 2 : 0), padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
+#define XG_GZK(O, NTS, ZK_) hipLaunchKernelGGL((k_stencil2d<O, NTS, SEG, true, ZK_>), dim3(grid), dim3(BLOCK), 0, st, in, out, o0, nouter, nblk, ny, nx, fnt, fns, order | (tune().nb_dpp ? 2 : 0), padx_lo, bc_x, fill_x, pady_lo, bc_y, fill_y, m1, m2, m3, zb)
 #define XG_GZ(O, NTS) do { if (ZK2 == 4) XG_GZK(O, NTS, 4); else XG_GZK(O, NTS, 2); } while (0)
 #define XG_GO(O, NTS) do { if (met && zb.on) XG_GZ(O, NTS); else if (met) XG_GM(O, NTS, true); else XG_GM(O, NTS, false); } while (0)
 #define XG_O(O) do { if (nts) XG_GO(O, true); else XG_GO(O, false); } while (0)

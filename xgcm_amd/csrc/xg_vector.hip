@@ -149,11 +149,11 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
   if (lb >= nblk) return;
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
-  const u32 r = fdiv(w, ntile);  // (x-chunked bands: `ntile` is the chunk width, zband_xmap adds the chunk's first tile)
-  u32 tile = w - r * ntile.d;
+  const u32 r = fdiv(w, ntile);
+  const u32 tile = w - r * ntile.d;
   u32 oo, sg;
   if (HAS_AREA && zb.on) {  // band-major: a (Y,X) area band stays in the XCD's L2 for all levels
-    if (!zband_xmap(zb, r, oo, sg, tile)) return;
+    if (!zband_map(zb, r, oo, sg)) return;
     oo *= ZK;
   } else {
     oo = fdiv(r, nseg);
@@ -253,10 +253,10 @@ __global__ __launch_bounds__(BLOCK) void k_divergence(
   if (lb >= nblk) return;
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
   const u32 r = fdiv(w, ntile);
-  u32 tile = w - r * ntile.d;
+  const u32 tile = w - r * ntile.d;
   u32 oo, sg;
   if (HAS_AREA && zb.on) {
-    if (!zband_xmap(zb, r, oo, sg, tile)) return;
+    if (!zband_map(zb, r, oo, sg)) return;
     oo *= ZK;
   } else {
     oo = fdiv(r, nseg);
@@ -346,10 +346,10 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
   if (lb >= nblk) return;
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
   const u32 r = fdiv(w, ntile);
-  u32 tile = w - r * ntile.d;
+  const u32 tile = w - r * ntile.d;
   u32 oo, sg;
   if (zb.on) {  // band-major: the metric rows of a band of segments stay in the XCD's L2 for all outer indices (rule 4)
-    if (!zband_xmap(zb, r, oo, sg, tile)) return;
+    if (!zband_map(zb, r, oo, sg)) return;
   } else {
     oo = fdiv(r, nseg);
     if (oo >= nouter) return;
@@ -561,8 +561,7 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
   // levels stream by.  16 rows: PMC reads 1.06x the algorithmic bytes (the halo u row of every band and level is the
   // 6 %); 24 rows 1.17x, 32 rows 1.26x -- the area is then re-read from the fabric once per level group -- at the same
   // speed within 1 % on an otherwise idle device (profiles/r03g_*, r03h_*)
-  u32 zbr, zxc;  // rows per band, x-tiles per chunk (zb_xc: the band grows as the rows are cut, rule 17)
-  zband_shape(ntile, (u32)(tune().vec_zb_rows > 1 ? tune().vec_zb_rows : 16), 512, &zbr, &zxc);
+  const u32 zbr = (u32)(tune().vec_zb_rows > 1 ? tune().vec_zb_rows : 16);
   const u32 ZB_SEGS = (zbr + SEG - 1) / SEG;
   ZBand zb = make_zband(false, 0, 0, 1);
   u64 outer_step = outer_per;
@@ -573,19 +572,19 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
   if (area && area_bcast_all && tune().zband && outer >= 2) {
     const u64 padded_segs = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS;
     zgroups = ((u64)outer + zk - 1) / zk;
-    zb = make_zband(true, zgroups, nseg, ZB_SEGS, zxc, ntile);
-    if (zb.on && padded_segs * zgroups * zband_row_tiles(zb, ntile) <= MAX_ITEMS) outer_step = (u64)outer;  // one launch over all levels
-    else zb = make_zband(false, 0, 0, 1);
+    if (padded_segs * zgroups * ntile <= MAX_ITEMS) {
+      zb = make_zband(true, zgroups, nseg, ZB_SEGS);
+      if (zb.on) outer_step = (u64)outer;  // one launch over all levels
+    }
   }
   if (!zb.on) zk = 1;
-  const FastDiv fxt = zband_tile_div(zb, ntile);
   for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_step) {
     const u32 nouter = (u32)((outer - o0 < (int64_t)outer_step) ? outer - o0 : (int64_t)outer_step);
-    const u64 units = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * zgroups * zband_row_tiles(zb, ntile) : (u64)nouter * per_outer;
+    const u64 units = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * zgroups * ntile : (u64)nouter * per_outer;
     const u32 nblk = (u32)((units + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GZ(V_, A_, NTS, ZK_) do { if (div) hipLaunchKernelGGL((k_divergence<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fxt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y, vnt); \
-                                else hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fxt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y, vnt); } while (0)
+#define XG_GZ(V_, A_, NTS, ZK_) do { if (div) hipLaunchKernelGGL((k_divergence<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y, vnt); \
+                                else hipLaunchKernelGGL((k_vorticity<V_, A_, NTS, SEG, ZK_>), dim3(grid), dim3(BLOCK), 0, st, u, v, area, out, o0, nouter, nblk, ny, nx, fnt, fns, zb, bc_x, fill_x, bc_y, fill_y, ai, a_sy, a_sx, halo_x, halo_y, vnt); } while (0)
 #define XG_GO(V_, A_, NTS) XG_GZ(V_, A_, NTS, 1)
 #define XG_A(V_, A_) do { if (nts) XG_GO(V_, A_, true); else XG_GO(V_, A_, false); } while (0)
     if (zk == 4) XG_GZ(NV, true, true, 4);
@@ -685,30 +684,26 @@ static int pair2d_impl(int mode, const real* a, const real* u, const real* v, re
   // both planes come from the fabric again for every level (0.56 of 8 TB/s level-major).  Two metrics: 8-row bands (rule 13)
   ZBand zb = make_zband(false, 0, 0, 1);
   u64 outer_step = outer_per;
-  // rows per band: 32 with one metric plane, 16 with two (round 4, with the outputs no longer competing for the L2 --
-  // `nt` stores of two outputs: 8 -> 16 rows reads 5.97 -> 5.65 GB at the same speed, profiles/r04b_ab_bands_grad.log),
-  // growing with x-chunked rows (zb_xc, rule 17)
-  u32 gzr, gxc;
-  zband_shape(ntile, (mx && my) ? 16u : 32u, 512, &gzr, &gxc);
-  const u32 ZB_SEGS = (u32)((gzr + SEG - 1) / SEG);
+  const u32 gzb = (u32)(tune().vec_zb_rows > 1 ? tune().vec_zb_rows : 16);  // rows per band with ONE metric; two: half
+  const u32 ZB_SEGS = (u32)((((mx && my) ? (gzb / 2 < 2 ? 2 : gzb / 2) : gzb) + SEG - 1) / SEG);
   auto shared = [](const real* m, const AreaIdx& ai) {  // absent, or broadcast along every leading dim
     for (int d = 0; m && d < ai.n; ++d)
       if (ai.stride[d] != 0) return false;
     return true;
   };
   if (mode == 0 && (mx || my) && shared(mx, aix) && shared(my, aiy) && tune().zband && outer >= 2) {
-    zb = make_zband(true, (u64)outer, nseg, ZB_SEGS, gxc, ntile);
-    const u64 padded = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * (u64)outer * zband_row_tiles(zb, ntile);
-    if (zb.on && padded <= MAX_ITEMS) outer_step = (u64)outer;
-    else zb = make_zband(false, 0, 0, 1);
+    const u64 padded = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * (u64)outer * ntile;
+    if (padded <= MAX_ITEMS) {
+      zb = make_zband(true, (u64)outer, nseg, ZB_SEGS);
+      if (zb.on) outer_step = (u64)outer;
+    }
   }
-  const FastDiv fxt = zband_tile_div(zb, ntile);
   for (int64_t o0 = 0; o0 < outer; o0 += (int64_t)outer_step) {
     const u32 nouter = (u32)((outer - o0 < (int64_t)outer_step) ? outer - o0 : (int64_t)outer_step);
-    const u64 waves = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * (u64)outer * zband_row_tiles(zb, ntile) : (u64)nouter * per_outer;
+    const u64 waves = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * (u64)outer * ntile : (u64)nouter * per_outer;
     const u32 nblk = (u32)((waves + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GO(V_, M_, NTS) hipLaunchKernelGGL((k_pair2d<V_, M_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, a, u, v, out_x, out_y, o0, nouter, nblk, ny, nx, fxt, fns, bc_x, fill_x, bc_y, fill_y, mx, aix, mx_sy, mx_sx, my, aiy, my_sy, my_sx, halo_x, halo_y, zb)
+#define XG_GO(V_, M_, NTS) hipLaunchKernelGGL((k_pair2d<V_, M_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, a, u, v, out_x, out_y, o0, nouter, nblk, ny, nx, fnt, fns, bc_x, fill_x, bc_y, fill_y, mx, aix, mx_sy, mx_sx, my, aiy, my_sy, my_sx, halo_x, halo_y, zb)
 #define XG_M(V_, M_) do { if (nts) XG_GO(V_, M_, true); else XG_GO(V_, M_, false); } while (0)
     if (V > 1) { if (mode) XG_M(NV, 1); else XG_M(NV, 0); }
     else { if (mode) XG_M(1, 1); else XG_M(1, 0); }
