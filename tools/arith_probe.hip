@@ -76,6 +76,44 @@ __global__ __launch_bounds__(256) void k_flat(const double* __restrict__ a, doub
   __builtin_nontemporal_store(x, (d2*)(out + cell));
 }
 
+// the same arithmetic with ZK consecutive LEVELS per thread sharing the metric vectors (what the product's metric kernels do:
+// the metric loads, L2 hits, compete with the field loads for the CU's outstanding-request capacity)
+template <int MODE, int ZK>
+__global__ __launch_bounds__(256) void k_flat_zk(const double* __restrict__ a, double* __restrict__ out, const double* __restrict__ m1,
+                                                 const double* __restrict__ m2, const double* __restrict__ m3, u32 nblk) {
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 wave = lb * 4 + (threadIdx.x >> 6);
+  constexpr u32 ZG = (NZ + ZK - 1) / ZK;
+  const u32 tiles = (VPR + 63) / 64;
+  const u32 row_w = wave / tiles, tile = wave - row_w * tiles;
+  const u32 per_band = ZG * BAND;
+  const u32 band = row_w / per_band, rem = row_w - band * per_band;
+  const u32 zg = rem / BAND, y = band * BAND + (rem - zg * BAND);
+  if (y >= NY) return;
+  const u32 v = tile * 64 + (threadIdx.x & 63);
+  if (v >= VPR) return;
+  const size_t plane = (size_t)NY * NX;
+  const size_t mcell = (size_t)y * NX + 2 * (size_t)v;
+  const u32 z0 = zg * ZK;
+  d2 x[ZK];
+#pragma unroll
+  for (int k = 0; k < ZK; ++k) x[k] = __builtin_nontemporal_load((const d2*)(a + (size_t)((z0 + k < NZ) ? z0 + k : NZ - 1) * plane + mcell));
+  const d2 p1 = *(const d2*)(m1 + mcell);
+  d2 p2 = p1, p3 = p1;
+  if (MODE >= 2) p2 = *(const d2*)(m2 + mcell);
+  if (MODE >= 3) p3 = *(const d2*)(m3 + mcell);
+#pragma unroll
+  for (int k = 0; k < ZK; ++k) {
+    d2 t = x[k];
+    if (MODE == 1) t = t / p1;
+    if (MODE >= 2) t = (t * p1) / p2;
+    if (MODE >= 3) t = (t * p2) / p3;
+    if (z0 + k < NZ) __builtin_nontemporal_store(t, (d2*)(out + (size_t)(z0 + k) * plane + mcell));
+  }
+}
+
 // one lane = one column pair; D divisions per input cell; 50 output rows per column
 template <int D>
 __global__ __launch_bounds__(256) void k_march(const double* __restrict__ phi, const double* __restrict__ theta, double* __restrict__ out,
@@ -102,6 +140,7 @@ __global__ __launch_bounds__(256) void k_march(const double* __restrict__ phi, c
       d2 v = p[u];
 #pragma unroll
       for (int d = 0; d < D; ++d) v = v / dz;  // dependent IEEE divisions (the overlap fraction feeds the accumulation)
+      if (D == 0) v = v + dz;                  // (keeps the theta loads alive without a division)
       acc = acc + v;
       t0 = t[u];
       // 50 rows out per 75 in: two rows every three cells
@@ -150,6 +189,15 @@ int main() {
     FLAT(2, "A 1 mul 1 div      (metric_weighted, one axis)", 2)
     FLAT(3, "A 2 mul 2 div      (metric_weighted, two axes)", 3)
     FLAT(4, "A 3 mul 2 div      (+ neighbour product recomputed)", 3)
+#define FLATZK(MODE, ZK, name, planes) { const u32 zg = (NZ + ZK - 1) / ZK; const size_t rw = (size_t)((NY + BAND - 1) / BAND) * BAND * zg; \
+    const u32 nb = (u32)((rw * tiles + 3) / 4), gr = ((nb + 7) / 8) * 8; \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_flat_zk<MODE, ZK>), dim3(gr), dim3(256), 0, 0, a, o, m1, m2, m3, nb); }); \
+    rep(name, ms, 16.0 * n + planes * 8.0 * plane); }
+    FLATZK(0, 4, "A copy, 4 levels per thread", 0)
+    FLATZK(1, 2, "A 1 div, 2 levels per thread sharing the metric", 1)
+    FLATZK(2, 4, "A 1 mul 1 div, 4 levels per thread", 2)
+    FLATZK(3, 4, "A 2 mul 2 div, 4 levels per thread", 3)
+    FLATZK(3, 8, "A 2 mul 2 div, 8 levels per thread", 3)
     const u32 ncol2 = (u32)(plane / 2);
 #define MARCH(D, name) { float ms = timeit([&] { hipLaunchKernelGGL((k_march<D>), dim3((ncol2 + 255) / 256), dim3(256), 0, 0, a, th, o, ncol2, m); }); \
     rep(name, ms, 8.0 * (2.0 * n + plane + (double)m * plane)); }

@@ -146,7 +146,6 @@ struct Tune {
   int scan_chain_w;   // K5c: levels' worth of columns that advance side by side inside one XCD band
   int scan_chain_tmaj; // chained kernels with a metric shared by the outer indices: columns numbered x-tile-major, a sub-band = all levels of a few x-tiles
   int scan_chain_spin; // polls of a hand-off slot before a chunk gives up (the launch is then redone by the march, in stream)
-  int chain_drop;      // chained scans: output rows stored `sc1 nt` (1: with a metric shared by the outer indices, 2: always)
   int met_ys1, met_ys2; // K2Sm: strided-axis metric stencils with y-stacked workgroups, 10 * rows + levels per wave (one / two metrics; 0: K2S)
   int transform_lean; // linear transform, ring + shared level table: the lean streaming loop (targets validated once, 32-bit cursors, pointer-stepped columns)
   int pad_tpw;        // row-wise pad: consecutive 64-lane tiles of a row per wave-task (the row logic is paid once per task)
@@ -393,15 +392,6 @@ __device__ __forceinline__ real poison_value() {
 #else
   return real(__builtin_nan(""));
 #endif
-}
-
-// the same for the 8-byte lanes of the long marches / chained scans
-template <typename T>
-__device__ __forceinline__ void stg_drop8(real* p, T v) {
-  static_assert(sizeof(T) == 8, "8-byte lanes only");
-  typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
-  const u32x2_ w = __builtin_bit_cast(u32x2_, v);
-  asm volatile("global_store_dwordx2 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
 }
 
 // x-difference of a V-wide lane given the value just left of it

@@ -55,7 +55,6 @@ const TuneEntry TUNABLES[] = {
     {"scan_chain", &Tune::scan_chain, 1},
     {"scan_chain_w", &Tune::scan_chain_w, 1},
     {"scan_chain_spin", &Tune::scan_chain_spin, 1 << 22},
-    {"chain_drop", &Tune::chain_drop, 0},  // (experiment of round 4; default decided by profiles/r04b_*)
     {"scan_chain_tmaj", &Tune::scan_chain_tmaj, 0},  // minimal traffic (1.01x) but 10-27 % slower: profiles/r03o_*
     {"reduce_zl", &Tune::reduce_zl, 2},
     {"met_ys1", &Tune::met_ys1, 12},

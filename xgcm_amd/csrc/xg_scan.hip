@@ -217,7 +217,6 @@ struct ChainArgs {
   u32 srow;                        // slots per ring row = lanes per row of the array
   u32 spin;                        // polls of a slot before giving up
   u32 tmaj;                        // 0: columns numbered (outer index, x-tile); n > 0: (x-tile, outer index) with n outer indices
-  u32 drop;                        // output rows stored `sc1 nt` (dropped from the L2 as written) instead of `nt`
   u32* ticket;
   u32* gave_up;                    // host-mapped: [0] sticky report, [1] launches redone
   u32* poison;                     // device: [0] run-if word of this launch's rescue kernel, [1] its workgroup count
@@ -423,10 +422,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_chain(
   // (xgcm/grid.py:1385-1391; numpy.pad semantics)
   auto put = [&](int64_t jo, T val) {
     if (HAS_MO) val = val / ldm<T>(m_out, mo_base + jo * mo.axis, mo_step);
-    // `drop`: the output rows of a sweep are what pushes the hand-off slots (and a shared metric's rows) out of the XCD's
-    // L2 before the next chunk of the column reads them
-    if (sizeof(T) == 8 && ch.drop) stg_drop8<T>(pout + jo * inner + xo, val);
-    else stg<T, true>(pout + jo * inner + xo, val);
+    stg<T, true>(pout + jo * inner + xo, val);
   };
   const int64_t first_kept = a.trim_lo, last_kept = n - 1 - a.trim_hi;
   const int64_t shift = a.pad_lo - a.trim_lo;
@@ -1386,7 +1382,6 @@ bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void
   // (whole-plane rows, the Z axis, in column chunks of 256 ... 4096 tiles: 65-66 % chained, 66.5 % marching: march kept)
   if (shared_metric && lv < 100) ch->W = ch->cpx;  // (>= 100: experiment, sub-bands of lv - 100 levels whatever the metric)
   ch->tmaj = 0;
-  ch->drop = (tune().chain_drop == 2 || (tune().chain_drop == 1 && shared_metric)) ? 1u : 0u;
   if (shared_metric && tune().scan_chain_tmaj) {
     // A metric shared by the outer indices ("levels"): number the columns x-tile-major and let a sub-band be ALL levels of
     // a few x-tiles.  The chunk's metric rows are then fetched once for the whole chip (level-major: once per XCD, whose
@@ -1396,6 +1391,8 @@ bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void
     // MEASURED (profiles/r03o_*): traffic as predicted -- cumint Y 1.084x -> 1.008x, integrate Y 1.215x -> 1.018x -- and the
     // kernels 10 % / 27 % SLOWER (1.77 -> 1.94 ms, 1.13 -> 1.44 ms): the level-major sweep is worth more than the bytes,
     // which the Infinity Cache absorbs.  Off by default; kept as the evidence that the extra traffic is a choice.
+    // (Round 4: the band-wide order with the output rows stored `sc1 nt` -- dropped from the L2 as written, so that they
+    // would not push the hand-off slots out -- reads 5.87 -> 6.08 GB and is no faster; profiles/r04b_ab_chain_pmc.log.)
     const u64 nout = ncol / ctile;  // outer indices (level groups) per x-tile
     if (nout >= 2 && nout < 0x7fffffffull) {
       ch->tmaj = (u32)nout;

@@ -684,8 +684,12 @@ static int pair2d_impl(int mode, const real* a, const real* u, const real* v, re
   // both planes come from the fabric again for every level (0.56 of 8 TB/s level-major).  Two metrics: 8-row bands (rule 13)
   ZBand zb = make_zband(false, 0, 0, 1);
   u64 outer_step = outer_per;
-  const u32 gzb = (u32)(tune().vec_zb_rows > 1 ? tune().vec_zb_rows : 16);  // rows per band with ONE metric; two: half
-  const u32 ZB_SEGS = (u32)((((mx && my) ? (gzb / 2 < 2 ? 2 : gzb / 2) : gzb) + SEG - 1) / SEG);
+  // rows per band: twice `vec_zb_rows` (32) with one metric plane, `vec_zb_rows` (16) with two -- round 4, PMC per band
+  // height (profiles/r04b_ab_bands_grad.log): two metrics 8 -> 16 rows reads 5.97 -> 5.65 GB (traffic 1.041 -> 1.021x), 32
+  // rows 5.61 GB, all at the same speed; the two `nt`-stored outputs leave the L2 room the one-output kernels do not have
+  // (their cliff sits between 8 and 16 rows for two metrics, r04b_ab_bands_met.log)
+  const u32 gzb = (u32)(tune().vec_zb_rows > 1 ? tune().vec_zb_rows : 16);
+  const u32 ZB_SEGS = (u32)((((mx && my) ? gzb : 2 * gzb) + SEG - 1) / SEG);
   auto shared = [](const real* m, const AreaIdx& ai) {  // absent, or broadcast along every leading dim
     for (int d = 0; m && d < ai.n; ++d)
       if (ai.stride[d] != 0) return false;
