@@ -26,6 +26,7 @@
  *   xg_pad_f64         xgcm/padding.py:765-871 (pad) for user grid-ufuncs of any width
  *   xg_gather_f64      xgcm/padding.py:260-572 (_pad_face_connections) and :619-762 (_fold_north_halo,
  *                      _pad_fold): halos of complex topologies as one gather through a token map
+ *   xg_halo_put_f64    xgcm/grid.py:1385-1395 (Grid.cumsum pads the cumulative field) on such topologies, in place
  *   xg_transform_linear_f64 / xg_transform_conservative_f64
  *                      xgcm/transform.py:15-41 (_interp_1d_linear) and :88-142
  *                      (_interp_1d_conservative), the numba gufuncs behind Grid.transform
@@ -188,6 +189,14 @@ int xg_gather_f64(const double* in, const double* partner, double* out, const in
                   const int64_t* tokens, int64_t n_tokens, const double* fills, int n_fills,
                   void* stream);
 
+/* Halo cells written IN PLACE: `out` (shape[ndim], its interior already there) receives along `axis` the slab `halo`
+ * -- shaped like `out` with the axis shortened to pad_lo + pad_hi, low halo first -- in its first pad_lo and last pad_hi
+ * cells.  Grid.cumsum on a connected axis (xgcm/grid.py:1385-1395 pads the CUMULATIVE field through the topology): the
+ * scan writes the padded layout in one pass (xg_cumsum1d with XG_BC_FILL as a placeholder), the halo cells are gathered
+ * from that buffer (xg_gather over the halo cells only) and put in place -- the padded copy the reference makes is gone. */
+int xg_halo_put_f64(const double* halo, double* out, const int64_t* shape, int ndim, int axis,
+                    int pad_lo, int pad_hi, void* stream);
+
 /* ---- vertical coordinate transform (xgcm/transform.py:15-142) ----------------------------- */
 /* Per column along `axis` of `phi` (shape[ndim], C-contiguous):
  *   linear:       out[.., i, ..] = numpy.interp(target[i], theta[:], phi[:]) with the reference's
@@ -322,6 +331,8 @@ int xg_gather_f32(const float* in, const float* partner, float* out, const int64
                   const int* mapped, const int* partner_perm, const int64_t* lo,
                   const int64_t* tokens, int64_t n_tokens, const float* fills, int n_fills,
                   void* stream);
+int xg_halo_put_f32(const float* halo, float* out, const int64_t* shape, int ndim, int axis, int pad_lo, int pad_hi,
+                    void* stream);
 int xg_transform_linear_f32(const float* phi, const float* theta, const int64_t* theta_strides,
                             const float* target, const int64_t* target_strides, int64_t m,
                             float* out, const int64_t* shape, int ndim, int axis, int mask_edges,
@@ -403,6 +414,8 @@ int xg_gather_i64(const int64_t* in, const int64_t* partner, int64_t* out, const
                   const int* mapped, const int* partner_perm, const int64_t* lo,
                   const int64_t* tokens, int64_t n_tokens, const int64_t* fills, int n_fills,
                   void* stream);
+int xg_halo_put_i64(const int64_t* halo, int64_t* out, const int64_t* shape, int ndim, int axis, int pad_lo, int pad_hi,
+                    void* stream);
 int xg_binary_i64(int op, const int64_t* a, const int64_t* a_strides, const int64_t* b,
                   const int64_t* b_strides, int64_t* out, const int64_t* shape, int ndim,
                   void* stream);

@@ -133,6 +133,16 @@ def gather(x, partner, tokens, mapped, lo, out_shape, fills, partner_perm=None):
     return T.gather_tokens(x, partner, tokens, mapped, lo, out_shape, fills, partner_perm)
 
 
+def put_halo(out, halo, axis, pad_lo, pad_hi):
+    axis = axis % out.ndim
+    halo = np.asarray(halo).astype(out.dtype)
+    idx = [slice(None)] * out.ndim
+    for h in range(pad_lo + pad_hi):
+        idx[axis] = h if h < pad_lo else out.shape[axis] - (pad_lo + pad_hi) + h
+        out[tuple(idx)] = np.take(halo, h, axis=axis)
+    return out
+
+
 def binary(op, a, b):
     if _is_int(a) and _is_int(b):  # numpy's own integer promotion / wrap-around / true division
         return R.binary(op, np.asarray(a), np.asarray(b))
@@ -218,7 +228,7 @@ def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None, dtype=np.f
     return R.synthetic(int(np.prod(shape)), seed, offset, scale, shift).reshape(tuple(shape)).astype(dtype)
 
 
-_NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "stencil1d_halo", "cumsum1d", "reduce1d", "pad_nd", "gather", "upload_tokens", "transform_linear", "transform_conservative", "binary",
+_NAMES = ["asdevice", "tohost", "is_device_array", "stencil1d", "stencil1d_halo", "cumsum1d", "reduce1d", "pad_nd", "gather", "put_halo", "upload_tokens", "transform_linear", "transform_conservative", "binary",
           "vorticity", "divergence", "gradient", "flux", "stencil2d", "stencil2d_supported", "synthetic"]
 
 

@@ -280,7 +280,7 @@ def _not_in_host_build(name):
 
 _SERVED = ["asdevice", "tohost", "is_device_array", "stencil1d", "cumsum1d", "reduce1d", "pad_nd", "binary", "synthetic",
            "stencil2d_supported"]
-_ABSENT = ["stencil1d_halo", "gather", "upload_tokens", "transform_linear", "transform_conservative", "vorticity",
+_ABSENT = ["stencil1d_halo", "gather", "put_halo", "upload_tokens", "transform_linear", "transform_conservative", "vorticity",
            "divergence", "gradient", "flux", "stencil2d"]
 
 

@@ -719,6 +719,62 @@ def test_cumsum_on_connected_grid(backend):
     np.testing.assert_array_equal(out[1, :, 0], out[0, :, -1])
 
 
+@pytest.mark.parametrize("conn", ["x2x", "x2y", "x2x_rev", "cubed_sphere", "llc"])
+def test_cumsum_on_connected_axes_is_scan_then_topology_pad(backend, conn):
+    """Round 4: `Grid.cumsum` along a connected axis scans straight into the padded layout and fills
+    the halo cells of the CUMULATIVE field from that buffer (xg_gather over the halo slab through re-indexed tokens +
+    xg_halo_put) instead of making the reference's padded copy.  Every position pair, both directions, both horizontal
+    axes, leading / interleaved extra dims: equal to the reference's own sequence -- scan, trim, then `pad` of the trimmed
+    cumulative field through the topology (xgcm/grid.py:1316-1395)."""
+    connections = {"x2x": X_TO_X, "x2y": X_TO_Y, "x2x_rev": X_TO_X_REV, "cubed_sphere": CUBED_SPHERE, "llc": LLC}[conn]
+    nf, n = len(connections["face"]), 5
+    a = R.synthetic_field((2, nf, 3, n, n), 91) + 0.25
+    ds = Dataset(coords={"x": np.arange(n), "xl": np.arange(n) - 0.5, "y": np.arange(n), "yl": np.arange(n) - 0.5,
+                         "face": np.arange(nf), "t": np.arange(2), "z": np.arange(3)})
+    grid = Grid(ds, coords=COORDS, face_connections=connections, padding="fill", fill_value=1.5, autoparse_metadata=False)
+    for ax, from_dims, to in (("X", ("y", "x"), "left"), ("X", ("y", "xl"), "center"), ("Y", ("y", "x"), "left"),
+                              ("Y", ("yl", "x"), "center")):
+        da = DataArray(a, ("t", "face", "z") + from_dims)
+        dim = "x" if ax == "X" and "x" in from_dims else ("xl" if ax == "X" else ("y" if "y" in from_dims else "yl"))
+        num = da.dims.index(dim)
+        for reverse in (False, True):
+            # the reference's sequence with this package's general pad (itself pinned to the reference's padding.py outputs by
+            # test_product_topology_equals_reference_outputs): scan + trim, then pad the trimmed cumulative field
+            from_pos = "center" if dim in ("x", "y") else "left"
+            tl, th, pl, ph = R.cumsum_trim_pad(from_pos, to, reverse)
+            trimmed = R.cumsum1d(a, num, tl, th, 0, 0, None, 0.0, reverse, True)
+            want = pad(DataArray(trimmed, da.dims), grid, {ax: (pl, ph)}, padding="fill", fill_value=1.5) if (pl or ph) else DataArray(trimmed, da.dims)
+            if want.shape != a.shape:
+                # axis-swapping links (LLC) and a trimmed, hence non-square, face: no consistent result exists (the general
+                # pad returns faces of the wrong shape); the operator says so
+                with pytest.raises(ValueError, match="no longer square"):
+                    grid.cumsum(da, ax, to=to, reverse=reverse)
+                continue
+            got = grid.cumsum(da, ax, to=to, reverse=reverse)
+            assert got.shape == want.shape
+            np.testing.assert_allclose(got.values, want.values, rtol=1e-12, atol=1e-12)  # (contiguous-axis scans re-associate)
+            if num != a.ndim - 1:
+                np.testing.assert_array_equal(got.values, want.values)  # strided-axis scans are sequential: bit-exact
+
+
+def test_cumsum_along_a_fold_axis_is_scan_then_fold_pad(backend):
+    """the same on a north-fold grid: cumsum along the folded Y axis towards the right / outer position pads its HIGH halo
+    through the fold (mirror row of the cumulative field, sign kept for a scalar)"""
+    ds = Dataset(coords={"xh": np.arange(Nx), "xl": np.arange(Nx), "yh": np.arange(Ny), "yr": np.arange(Ny) + 0.5, "yl": np.arange(Ny)})
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", UserWarning)
+        grid = Grid(ds, coords={"X": {"center": "xh", "left": "xl"}, "Y": {"center": "yh", "left": "yl", "right": "yr"}},
+                    padding={"X": "periodic", "Y": {"fold": "corner"}}, autoparse_metadata=False)
+    a = R.synthetic_field((3, Ny, Nx), 93)
+    da = DataArray(a, ("z", "yh", "xh"))
+    for to, reverse in (("right", True), ("left", False), ("right", False)):
+        got = grid.cumsum(da, "Y", to=to, reverse=reverse)
+        tl, th, pl, ph = R.cumsum_trim_pad("center", to, reverse)
+        trimmed = R.cumsum1d(a, 1, tl, th, 0, 0, None, 0.0, reverse, True)
+        want = pad(DataArray(trimmed, da.dims), grid, {"Y": (pl, ph)}) if (pl or ph) else DataArray(trimmed, da.dims)
+        np.testing.assert_array_equal(got.values, want.values)
+
+
 def test_metrics_on_connected_grid(backend):
     """derivative (output metric fused with the pre-gathered halo) and metric_weighted (input metric:
     the reference's multiply -> pad -> op -> divide sequence, grid.py:804-832) on a cubed sphere."""

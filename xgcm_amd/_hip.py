@@ -69,6 +69,7 @@ SIGNATURES = {
         C.c_int,
         [_vp, _vp, _vp, _i64p, _i64p, _i64p, C.c_int, _intp, _intp, _i64p, _vp, C.c_int64, _f64p, C.c_int, _vp],
     ),
+    "xg_halo_put_f64": (C.c_int, [_vp, _vp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "xg_transform_linear_f64": (
         C.c_int,
         [_vp, _vp, _i64p, _vp, _i64p, C.c_int64, _vp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
@@ -124,7 +125,7 @@ SIGNATURES = {
 
 # float32 twins of the compute entry points: same argument order, `float` fill values
 # (xg_fill_synthetic_f32 keeps double scale/shift: the value is formed in f64 and rounded once)
-for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_cumsum1d", "xg_reduce1d", "xg_pad", "xg_gather", "xg_transform_linear", "xg_transform_conservative", "xg_binary", "xg_vorticity", "xg_divergence", "xg_vorticity_halo", "xg_divergence_halo", "xg_gradient", "xg_flux", "xg_gradient_halo", "xg_flux_halo", "xg_stencil2d", "xg_stencil2d_metric",
+for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_cumsum1d", "xg_reduce1d", "xg_pad", "xg_gather", "xg_halo_put", "xg_transform_linear", "xg_transform_conservative", "xg_binary", "xg_vorticity", "xg_divergence", "xg_vorticity_halo", "xg_divergence_halo", "xg_gradient", "xg_flux", "xg_gradient_halo", "xg_flux_halo", "xg_stencil2d", "xg_stencil2d_metric",
               "xg_fill_synthetic"]:
     _res, _args = SIGNATURES[_name + "_f64"]
     SIGNATURES[_name + "_f32"] = (_res, list(_args) if _name == "xg_fill_synthetic" else
@@ -133,7 +134,7 @@ for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_cumsum1d", "xg_reduce1d",
 # int64 twins of the entry points that serve integer arrays (numpy keeps them integral: diff / min / max / cumsum / pad /
 # gather / +,-,*): same argument order, int64 fill values; metric / weight pointers must be NULL (include/xgcm_hip.h)
 _i64p_fill = C.POINTER(C.c_int64)
-for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_cumsum1d", "xg_reduce1d", "xg_pad", "xg_gather", "xg_binary"]:
+for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_cumsum1d", "xg_reduce1d", "xg_pad", "xg_gather", "xg_halo_put", "xg_binary"]:
     _res, _args = SIGNATURES[_name + "_f64"]
     SIGNATURES[_name + "_i64"] = (_res, [C.c_int64 if a is C.c_double else (_i64p_fill if a is _f64p else a) for a in _args])
 

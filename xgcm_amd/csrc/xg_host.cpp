@@ -413,6 +413,19 @@ int xg_event_destroy(void* ev) { free(ev); return XG_OK; }
                       const int64_t* shape, int ndim, void*) {                                                        \
     return binary<R>(op, a, sa, b, sb, out, shape, ndim);                                                             \
   }                                                                                                                   \
+  int xg_halo_put_##SFX(const R* halo, R* out, const int64_t* shape, int ndim, int axis, int pad_lo, int pad_hi, void*) { \
+    View v;                                                                                                           \
+    if (int rc = make_view(shape, ndim, axis, &v)) return rc;                                                         \
+    const int64_t nh = (int64_t)pad_lo + pad_hi;                                                                      \
+    if (pad_lo < 0 || pad_hi < 0 || v.n < nh) return fail(XG_ERR_INVALID, "bad halo widths");                         \
+    if (v.outer * nh * v.inner == 0) return XG_OK;                                                                    \
+    if (!halo || !out) return fail(XG_ERR_INVALID, "NULL array argument");                                            \
+    for (int64_t o = 0; o < v.outer; ++o)                                                                             \
+      for (int64_t h = 0; h < nh; ++h)                                                                                \
+        for (int64_t x = 0; x < v.inner; ++x)                                                                         \
+          out[(o * v.n + (h < pad_lo ? h : v.n - nh + h)) * v.inner + x] = halo[(o * nh + h) * v.inner + x];          \
+    return XG_OK;                                                                                                     \
+  }                                                                                                                   \
   int xg_gather_##SFX(const R*, const R*, R*, const int64_t*, const int64_t*, const int64_t*, int, const int*,        \
                       const int*, const int64_t*, const int64_t*, int64_t, const R*, int, void*) {                    \
     return unsupported("xg_gather");                                                                                  \

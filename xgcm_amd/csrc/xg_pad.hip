@@ -385,6 +385,21 @@ __global__ __launch_bounds__(BLOCK) void k_gather_rows(const real* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// halo slab -> the halo cells of an array that already holds its interior (Grid.cumsum on a connected axis: the scan
+// writes the padded layout in one pass, the halo cells of the cumulative field -- the neighbouring faces' edge values --
+// are gathered from that very buffer and put in place here; no padded copy).  One thread per halo cell.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_halo_put(const real* __restrict__ halo, real* __restrict__ out, u64 total, u64 inner,
+                                                   u64 n_out, u32 lo, u32 nh) {
+  const u64 gid = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (gid >= total) return;
+  const u64 x = gid % inner, r = gid / inner;
+  const u64 h = r % nh, o = r / nh;
+  const u64 j = (h < lo) ? h : n_out - nh + h;  // low halo cells first, then the high ones
+  out[(o * n_out + j) * inner + x] = halo[gid];
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -558,6 +573,29 @@ int XG_FN(xg_gather)(const real* in, const real* partner, real* out, const int64
   if ((rc = check_grid(nblocks))) return rc;
   if (total < 0x7fffffffll) hipLaunchKernelGGL((k_gather<u32>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, partner, out, tokens, g);
   else hipLaunchKernelGGL((k_gather<u64>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, partner, out, tokens, g);
+  XG_LAUNCH_CHECK();
+  return XG_OK;
+}
+
+int XG_FN(xg_halo_put)(const real* halo, real* out, const int64_t* shape, int ndim, int axis, int pad_lo, int pad_hi,
+                       void* stream) {
+  if (!shape) return fail(XG_ERR_INVALID, "NULL shape");
+  if (ndim < 1 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [1,%d]", ndim, XG_MAX_NDIM);
+  if (axis < 0 || axis >= ndim) return fail(XG_ERR_INVALID, "axis %d out of range for ndim %d", axis, ndim);
+  if (pad_lo < 0 || pad_hi < 0) return fail(XG_ERR_INVALID, "negative halo width");
+  const int64_t nh = (int64_t)pad_lo + pad_hi;
+  if (shape[axis] < nh) return fail(XG_ERR_INVALID, "axis of %lld cells cannot hold %lld halo cells", (long long)shape[axis], (long long)nh);
+  int64_t outer = 1, inner = 1;
+  for (int d = 0; d < axis; ++d) outer *= shape[d];
+  for (int d = axis + 1; d < ndim; ++d) inner *= shape[d];
+  const u64 total = (u64)outer * (u64)nh * (u64)inner;
+  if (total == 0) return XG_OK;
+  if (!halo || !out) return fail(XG_ERR_INVALID, "NULL array argument");
+  const u64 nblocks = (total + BLOCK - 1) / BLOCK;
+  int rc;
+  if ((rc = check_grid(nblocks))) return rc;
+  hipLaunchKernelGGL(k_halo_put, dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, halo, out, total, (u64)inner, (u64)shape[axis],
+                     (u32)pad_lo, (u32)nh);
   XG_LAUNCH_CHECK();
   return XG_OK;
 }

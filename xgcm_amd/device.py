@@ -37,6 +37,7 @@ __all__ = [
     "reduce1d",
     "pad_nd",
     "gather",
+    "put_halo",
     "upload_tokens",
     "transform_linear",
     "transform_conservative",
@@ -527,6 +528,31 @@ def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_sh
             len(fills), _stream())
     )
     return _narrow(out, res_dt) if ints else out
+
+
+def put_halo(out: torch.Tensor, halo, axis: int, pad_lo: int, pad_hi: int) -> torch.Tensor:
+    """Write the pre-gathered halo slab `halo` (shaped like `out` with `axis` shortened to pad_lo + pad_hi, low halo first)
+    into the halo cells of `out` IN PLACE (xg_halo_put): `Grid.cumsum` on a connected axis scans straight into the padded
+    layout and fills the halo cells of the cumulative field afterwards -- no padded copy."""
+    lib = _hip.load()
+    if not (isinstance(out, torch.Tensor) and out.is_cuda and out.is_contiguous()):
+        raise ValueError("put_halo writes in place: `out` must be a contiguous HBM tensor")
+    axis = axis % out.dim()
+    expect = list(out.shape)
+    expect[axis] = pad_lo + pad_hi
+    if list(halo.shape) != expect:
+        raise ValueError(f"halo buffer has shape {tuple(halo.shape)}, expected {tuple(expect)}")
+    odt = _dt.np_dtype(out)
+    if odt.name not in ("float64", "float32", "int64", "uint64"):
+        raise TypeError(f"put_halo serves float64 / float32 / int64 / uint64 arrays, not {odt}")
+    h = _raw_device(halo)
+    if _dt.np_dtype(h) != odt:
+        h = convert(h, odt)
+    sfx = {"float64": "f64", "float32": "f32"}.get(odt.name, "i64")
+    if h.numel():
+        _hip.check(getattr(lib, "xg_halo_put_" + sfx)(h.data_ptr(), out.data_ptr(), _hip.i64(list(out.shape)), out.dim(), axis,
+                                                     int(pad_lo), int(pad_hi), _stream()))
+    return out
 
 
 def transform_linear(phi, theta, target, axis: int, mask_edges: bool = True, bypass_checks: bool = False,

@@ -43,7 +43,7 @@ from .grid_ufunc import (
 )
 from .labeled import CHUNKED_INPUT_MESSAGE, DataArray, Dataset, _aligned_view, _is_tensor, from_xarray, is_xarray, to_xarray
 from .metrics import iterate_axis_combinations
-from .padding import FoldSpec, halo_cells, no_boundary_error, pad
+from .padding import FoldSpec, InteriorOf, halo_cells, no_boundary_error, pad
 
 
 def _maybe_promote_str_to_list(a):
@@ -662,11 +662,28 @@ class Grid:
             host = not _is_tensor(data.data)
             # xarray's DataArray.cumsum skips NaN for floats (numpy.nancumsum); see DESIGN.md "unpinned"
             if generic_pad:
-                # complex topology: scan without halo, then the reference's own pad (grid.py:1389-1395)
-                out = _dev.cumsum1d(data.data, num, trim_lo, trim_hi, 0, 0, None, 0.0, rev, True, m_in, None)
-                trimmed = DataArray(_dev.tohost(out) if host else out, data.dims, name=data.name)
-                padded = pad(trimmed, self, {ax.name: (pad_lo, pad_hi)}, padding=padding, fill_value=fill_value)
-                res = DataArray(padded.data, out_dims, name=data.name)
+                # complex topology: the reference pads the TRIMMED cumulative field through the topology (grid.py:1389-1395),
+                # i.e. its halo cells are the neighbouring faces' (the folded row's) cumulative edge values
+                if pad_lo or pad_hi:
+                    # one pass: the scan writes the padded layout (halo cells hold a placeholder), the halo cells are
+                    # gathered from that very buffer -- a (pad_lo + pad_hi)-wide slab -- and put in place: no padded copy
+                    src = data.data
+                    if host and getattr(src, "nbytes", 0) >= getattr(_dev, "HOST_STREAM_MIN_BYTES", float("inf")):
+                        src = _dev.asdevice(src)  # (the block-streamed host route hands back host blocks: keep this one in HBM)
+                    out = _dev.cumsum1d(src, num, trim_lo, trim_hi, pad_lo, pad_hi, "fill", 0, rev, True, m_in, None)
+                    buf = DataArray(out, data.dims, name=data.name)
+                    halo = halo_cells(InteriorOf(buf, dim, pad_lo, pad_hi), self, ax.name, (pad_lo, pad_hi), padding=padding,
+                                      fill_value=fill_value)
+                    if tuple(halo.shape) != tuple(n if i != num else pad_lo + pad_hi for i, n in enumerate(out.shape)):
+                        # links that swap axes need square faces, and trimming the cumulative field along one of them
+                        # (center -> left ...) breaks that: the reference's pad of the trimmed field is ill-defined too
+                        raise ValueError(
+                            f"cumsum along {ax.name!r} from {pos!r} to {ax_to!r} trims the field along an axis whose face "
+                            "connections swap axes: the trimmed faces are no longer square and cannot exchange halos")
+                    out = _dev.put_halo(out, halo.data, num, pad_lo, pad_hi)
+                else:
+                    out = _dev.cumsum1d(data.data, num, trim_lo, trim_hi, 0, 0, None, 0.0, rev, True, m_in, None)
+                res = DataArray(_dev.tohost(out) if host else out, out_dims, name=data.name)
                 if weighted:
                     res = res / self._resident(self.get_metric(res, weighted, _layout=res.dims), res.data)
             else:

@@ -97,7 +97,7 @@ def _pad_basic(data: DataArray, grid, padding_width, padding, fill_value) -> Dat
         widths[num] = (int(w[0]), int(w[1]))
         bc[num] = mode
         f = fill_value[ax]
-        fv[num] = 0.0 if f is None else float(f)
+        fv[num] = 0.0 if f is None else f  # (cast to the array's dtype by the device layer, like numpy.pad)
     if not widths:
         return data
     host = not _is_tensor(data.data)
@@ -198,12 +198,57 @@ def halo_cells(data, grid, ax_name: str, widths: Tuple[int, int], padding=None, 
                other_component=other_component, _halo_only=ax_name)
 
 
+class InteriorOf(DataArray):
+    """The interior of an array that ALREADY holds its padded layout along one dim (cells lo : n - hi), without slicing
+    it: it reports the interior's sizes to the builders of a token plane while `.data` stays the whole contiguous buffer,
+    and `_gather` reads that buffer through tokens re-indexed to its extents.  `Grid.cumsum` on a connected axis uses it to
+    gather the halo cells of the cumulative field from the buffer the scan has just written (reference: pad the trimmed
+    cumsum, xgcm/grid.py:1385-1395) -- no padded copy."""
+
+    __slots__ = ("src_pad",)
+
+    def __init__(self, buffer: DataArray, dim: str, lo: int, hi: int):
+        super().__init__(buffer.data, buffer.dims, name=buffer.name)
+        self.src_pad = (dim, int(lo), int(hi))
+
+    @property
+    def shape(self):
+        dim, lo, hi = self.src_pad
+        return tuple(int(n) - (lo + hi if d == dim else 0) for d, n in zip(self.dims, self.data.shape))
+
+    def _replace(self, data=None, dims=None, coords=None, name="__keep__"):
+        if data is not None or dims is not None:
+            raise NotImplementedError("the interior view of a padded buffer cannot be re-shaped")
+        return self  # (coords are never set on it)
+
+
+def _reindex_tokens(tokens: np.ndarray, src_sizes, k: int, lo: int, hi: int) -> np.ndarray:
+    """tokens counting source cells row-major over `src_sizes` -> the same cells counted over the extents of a buffer
+    that carries `lo` / `hi` extra cells along mapped dim number `k` (fill tokens and signs untouched)"""
+    t = np.asarray(tokens, dtype=np.int64)
+    a = np.abs(t)
+    is_cell = (a >= 1) & (a < _hm.FILL_BASE)
+    src = np.where(is_cell, a - 1, 0)
+    if src.size and int(src.max()) >= int(np.prod(src_sizes)):
+        # (no partner component reaches here: the plane was built for faces that are not what the links assume)
+        raise ValueError("the face connections swap axes and the faces of this field are no longer square: they cannot "
+                         "exchange halos")
+    coords = list(np.unravel_index(src, tuple(int(v) for v in src_sizes)))
+    coords[k] = coords[k] + int(lo)
+    new_sizes = [int(v) + ((lo + hi) if i == k else 0) for i, v in enumerate(src_sizes)]
+    moved = np.ravel_multi_index(coords, new_sizes) + 1
+    return np.where(is_cell, np.sign(t) * moved, t).astype(np.int64)
+
+
 def _gather(data: DataArray, partner: Optional[DataArray], grid, key, build, partner_same_as=None,
             halo_dim: Optional[str] = None) -> DataArray:
     """Run (or reuse) the token-plane builder `build()` -> (plane, mapped dims, lo per dim, fills)
     and move the data through it.  With `halo_dim` only the halo cells along that dim are produced."""
     cache = grid.__dict__.setdefault("_halo_maps", {})
-    key = key + (halo_dim,)
+    src_pad = getattr(data, "src_pad", None)  # `data` is an InteriorOf: its buffer is read in place
+    if src_pad is not None and (halo_dim != src_pad[0] or partner is not None):
+        raise NotImplementedError("a padded buffer serves as the source of its own halo cells only")
+    key = key + (halo_dim, src_pad)
     entry = cache.get(key)
     if entry is None:
         plane, lo_of_dim, fills = build()
@@ -216,7 +261,11 @@ def _gather(data: DataArray, partner: Optional[DataArray], grid, key, build, par
                                      halo_dim)
             lo_of_dim = dict(lo_of_dim)
             lo_of_dim[halo_dim] = plane.size(halo_dim) + n_in + 1  # no cell of this plane is an interior cell
-        entry = {"tokens": np.ascontiguousarray(plane.a), "sizes": dict(zip(mapped_dims, plane.a.shape)),
+        tokens_h = np.ascontiguousarray(plane.a)
+        if src_pad is not None:
+            tokens_h = np.ascontiguousarray(_reindex_tokens(tokens_h, [data.sizes[d] for d in mapped_dims],
+                                                            mapped_dims.index(halo_dim), src_pad[1], src_pad[2]))
+        entry = {"tokens": tokens_h, "sizes": dict(zip(mapped_dims, plane.a.shape)),
                  "lo": lo_of_dim, "fills": list(fills.values), "device": None}
         if len(cache) > 64:
             cache.clear()
