@@ -138,6 +138,16 @@ int xg_stencil1d_halo_f64(int op, const double* in, const double* halo, double* 
                           int pad_hi, const double* m_out, const int64_t* m_out_strides,
                           void* stream);
 
+/* The same with an INPUT metric (`metric_weighted` operators on a complex topology, xgcm/grid.py:804-808: the reference
+ * multiplies, THEN pads the product through the topology): `in` is multiplied by m_in inside the kernel; `halo` holds the
+ * halo cells of the PRODUCT in * m_in, which the caller forms from two halo-slab gathers -- gather(in) * gather(m_in), the
+ * very operands the reference multiplies -- and which are not weighted again.  One pass over the field instead of a
+ * product pass plus the operator. */
+int xg_stencil1d_halo_w_f64(int op, const double* in, const double* halo, double* out,
+                            const int64_t* shape, int ndim, int axis, int64_t n_out, int pad_lo,
+                            int pad_hi, const double* m_in, const int64_t* m_in_strides,
+                            const double* m_out, const int64_t* m_out_strides, void* stream);
+
 /* ---- prefix sum along one axis with the reference's trim/pad folded in ------------------ */
 /* c = inclusive cumsum of (in * m_in) along axis (from the high end if `reverse`; NaN counted
  * as 0 if `skipna`);  t = c[trim_lo : n - trim_hi];  out = pad(t, (pad_lo, pad_hi), bc, fill)
@@ -318,6 +328,10 @@ int xg_stencil1d_f32(int op, const float* in, float* out, const int64_t* shape, 
 int xg_stencil1d_halo_f32(int op, const float* in, const float* halo, float* out,
                           const int64_t* shape, int ndim, int axis, int64_t n_out, int pad_lo,
                           int pad_hi, const float* m_out, const int64_t* m_out_strides, void* stream);
+int xg_stencil1d_halo_w_f32(int op, const float* in, const float* halo, float* out,
+                            const int64_t* shape, int ndim, int axis, int64_t n_out, int pad_lo,
+                            int pad_hi, const float* m_in, const int64_t* m_in_strides,
+                            const float* m_out, const int64_t* m_out_strides, void* stream);
 int xg_cumsum1d_f32(const float* in, float* out, const int64_t* shape, int ndim, int axis,
                     int reverse, int skipna, int trim_lo, int trim_hi, int pad_lo, int pad_hi,
                     int bc, float fill, const float* m_in, const int64_t* m_in_strides,

@@ -84,11 +84,13 @@ def pad_nd(x, widths, bc, fill):
                     {k % x.ndim: (0.0 if v is None else v) for k, v in fill.items()})
 
 
-def stencil1d_halo(op, x, halo, axis, pad_lo, pad_hi, m_out=None):
-    if _is_int(x) and _is_int(halo):
+def stencil1d_halo(op, x, halo, axis, pad_lo, pad_hi, m_out=None, m_in=None):
+    if _is_int(x) and _is_int(halo) and m_in is None:
         x, halo = np.asarray(x), np.asarray(halo).astype(np.asarray(x).dtype)
     else:
-        x, halo, m_out = _cast(_common(x, halo, m_out), x, halo, m_out)
+        x, halo, m_out, m_in = _cast(_common(x, halo, m_out, m_in), x, halo, m_out, m_in)
+    if m_in is not None:  # `halo` holds the halo cells of the product already
+        x = x * m_in
     axis = axis % x.ndim
     lo = np.take(halo, range(0, pad_lo), axis=axis)
     hi = np.take(halo, range(pad_lo, pad_lo + pad_hi), axis=axis)

@@ -795,6 +795,47 @@ def test_metrics_on_connected_grid(backend):
     np.testing.assert_array_equal(got, ((wpad[..., :-1] + wpad[..., 1:]) / 2.0) / dxl)
 
 
+@pytest.mark.parametrize("conn", ["x2x", "x2y", "cubed_sphere"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_metric_weighted_on_connected_axes_in_one_pass(backend, conn, dtype):
+    """Round 4: `metric_weighted` operators of a scalar field on a connected axis read the field once
+    -- weighted inside the kernel, the halo cells of the PRODUCT formed from two halo-slab gathers (xg_stencil1d_halo_w) --
+    and equal the reference's multiply -> pad through the topology -> operate -> divide (xgcm/grid.py:804-832) bit for bit:
+    both axes, every operator, extra leading / interleaved dims (several levels per wave-task on the GPU), a fill value
+    that must NOT be weighted at unconnected edges, a metric that lacks the operator's dim."""
+    connections = {"x2x": X_TO_X, "x2y": X_TO_Y, "cubed_sphere": CUBED_SPHERE}[conn]
+    nf, n = len(connections["face"]), 6
+    a = (R.synthetic_field((2, nf, 5, n, n), 95) + 0.25).astype(dtype)
+    mk = lambda shape, seed: R.synthetic_metric(shape, seed).astype(dtype)  # noqa: E731
+    ds = Dataset({"dxc": (("face", "y", "x"), mk((nf, n, n), 96)), "dxl": (("face", "y", "xl"), mk((nf, n, n), 97)),
+                  "dyc": (("face", "y", "x"), mk((nf, n, n), 98)), "dyl": (("face", "yl", "x"), mk((nf, n, n), 99))},
+                 coords={"x": np.arange(n), "xl": np.arange(n) - 0.5, "y": np.arange(n), "yl": np.arange(n) - 0.5,
+                         "face": np.arange(nf), "t": np.arange(2), "z": np.arange(5)})
+    grid = Grid(ds, coords=COORDS, face_connections=connections, padding="fill", fill_value=2.5,
+                metrics={("X",): ["dxc", "dxl"], ("Y",): ["dyc", "dyl"]}, autoparse_metadata=False)
+    da = DataArray(a, ("t", "face", "z", "y", "x"))
+    for ax, m_in, m_out, num in (("X", "dxc", "dxl", 4), ("Y", "dyc", "dyl", 3)):
+        prod = DataArray(a * ds[m_in].values[None, :, None], da.dims)
+        padded = pad(prod, grid, {ax: (1, 0)}, padding="fill", fill_value=2.5).values  # the reference's order: product, then pad
+        lo, hi = np.take(padded, range(0, n), axis=num), np.take(padded, range(1, n + 1), axis=num)
+        for op, body in (("interp", lambda l, r: (l + r) / dtype(2.0)), ("diff", lambda l, r: r - l),
+                         ("min", np.minimum), ("max", np.maximum)):
+            want = body(lo, hi) / ds[m_out].values[None, :, None]
+            got = getattr(grid, op)(da, ax, metric_weighted=ax)
+            assert got.values.dtype == dtype
+            np.testing.assert_array_equal(got.values, want.astype(dtype))
+    # a metric without the operator's dim rides along as it is (its "halo" is itself)
+    ds2 = Dataset({"wy": (("face", "y"), mk((nf, n), 90)), "wyl": (("face", "y"), mk((nf, n), 89))},
+                  coords={"x": np.arange(n), "xl": np.arange(n) - 0.5, "y": np.arange(n), "yl": np.arange(n) - 0.5,
+                          "face": np.arange(nf), "t": np.arange(2), "z": np.arange(5)})
+    grid2 = Grid(ds2, coords=COORDS, face_connections=connections, padding="fill", fill_value=2.5,
+                 metrics={("X",): ["wy"]}, autoparse_metadata=False)
+    w = ds2["wy"].values[None, :, None, :, None]
+    padded = pad(DataArray(a * w, da.dims), grid2, {"X": (1, 0)}, padding="fill", fill_value=2.5).values
+    want = ((padded[..., :-1] + padded[..., 1:]) / dtype(2.0)) / w
+    np.testing.assert_array_equal(grid2.interp(da, "X", metric_weighted="X").values, want.astype(dtype))
+
+
 def test_two_axes_on_connected_grid_run_one_axis_at_a_time(backend):
     """`diff(da, ["X", "Y"])` must not take the simple-topology two-axis kernel on a connected grid."""
     ds = _faces_ds(6, 4, seed=61)

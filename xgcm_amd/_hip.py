@@ -58,6 +58,10 @@ SIGNATURES = {
         C.c_int,
         [C.c_int, _vp, _vp, _vp, _i64p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _vp, _i64p, _vp],
     ),
+    "xg_stencil1d_halo_w_f64": (
+        C.c_int,
+        [C.c_int, _vp, _vp, _vp, _i64p, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, _vp, _i64p, _vp, _i64p, _vp],
+    ),
     "xg_cumsum1d_f64": (
         C.c_int,
         [_vp, _vp, _i64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -125,7 +129,7 @@ SIGNATURES = {
 
 # float32 twins of the compute entry points: same argument order, `float` fill values
 # (xg_fill_synthetic_f32 keeps double scale/shift: the value is formed in f64 and rounded once)
-for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_cumsum1d", "xg_reduce1d", "xg_pad", "xg_gather", "xg_halo_put", "xg_transform_linear", "xg_transform_conservative", "xg_binary", "xg_vorticity", "xg_divergence", "xg_vorticity_halo", "xg_divergence_halo", "xg_gradient", "xg_flux", "xg_gradient_halo", "xg_flux_halo", "xg_stencil2d", "xg_stencil2d_metric",
+for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_stencil1d_halo_w", "xg_cumsum1d", "xg_reduce1d", "xg_pad", "xg_gather", "xg_halo_put", "xg_transform_linear", "xg_transform_conservative", "xg_binary", "xg_vorticity", "xg_divergence", "xg_vorticity_halo", "xg_divergence_halo", "xg_gradient", "xg_flux", "xg_gradient_halo", "xg_flux_halo", "xg_stencil2d", "xg_stencil2d_metric",
               "xg_fill_synthetic"]:
     _res, _args = SIGNATURES[_name + "_f64"]
     SIGNATURES[_name + "_f32"] = (_res, list(_args) if _name == "xg_fill_synthetic" else

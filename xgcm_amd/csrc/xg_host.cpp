@@ -433,6 +433,13 @@ int xg_event_destroy(void* ev) { free(ev); return XG_OK; }
 
 // the float-only entry points (synthetic generator; fused / transform stubs)
 #define XG_HOST_FLOAT(SFX, R)                                                                                         \
+  int xg_stencil1d_halo_w_##SFX(int op, const R* in, const R* halo, R* out, const int64_t* shape, int ndim, int axis, \
+                                int64_t n_out, int pad_lo, int pad_hi, const R* m_in, const int64_t* mis,             \
+                                const R* m_out, const int64_t* mos, void*) {                                          \
+    if (!halo && (pad_lo || pad_hi)) return fail(XG_ERR_INVALID, "NULL halo buffer");                                 \
+    return stencil1d<R>(op, in, halo, out, shape, ndim, axis, n_out, pad_lo, pad_hi,                                  \
+                        (pad_lo || pad_hi) ? XG_BC_HALO : XG_BC_NONE, R(0), m_in, mis, m_out, mos);                   \
+  }                                                                                                                   \
   int xg_fill_synthetic_##SFX(R* out, int64_t n, uint64_t seed, uint64_t offset, double scale, double shift, void*) { \
     return fill_synthetic<R>(out, n, seed, offset, scale, shift);                                                     \
   }                                                                                                                   \

@@ -569,7 +569,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
 #pragma unroll
     for (int u = 0; u <= SEG; ++u) {
       T t = v[kz][u];
-      if (HAS_MI) t = t * wm[u];
+      if (HAS_MI && !hh[u]) t = t * wm[u];  // (pre-gathered halo rows are those of the PRODUCT: not weighted again)
       p[u] = ff[u] ? splat<T>(fill) : t;
     }
 #pragma unroll
@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_ysm(
       for (int u = 0; u <= SEG; ++u) {
         if (u >= ulo) {
           T t = v[kz][u];
-          if (HAS_MI) t = t * wm[u];
+          if (HAS_MI && !hh[u]) t = t * wm[u];  // (pre-gathered halo rows are those of the PRODUCT: not weighted again)
           p[kz][u] = ff[u] ? splat<T>(fill) : t;
         }
       }
@@ -1690,7 +1690,6 @@ static int stencil1d_impl(int op, const real* in, const real* halo, real* out, c
   if ((pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "pad widths must be 0 or 1, got (%d,%d)", pad_lo, pad_hi);
   if (bc < XG_BC_NONE || bc > XG_BC_HALO) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
   if (bc == XG_BC_HALO && !halo) return fail(XG_ERR_INVALID, "XG_BC_HALO without a halo buffer");
-  if (bc == XG_BC_HALO && m_in) return fail(XG_ERR_UNSUPPORTED, "pre-gathered halos cannot be combined with an input metric");
   if ((m_in && !m_in_strides) || (m_out && !m_out_strides)) return fail(XG_ERR_INVALID, "metric without strides");
 #ifdef XG_I64
   if (m_in || m_out) return fail(XG_ERR_UNSUPPORTED, "integer stencils take no metrics: convert to float64 first (numpy promotes int * float)");
@@ -1750,6 +1749,18 @@ int XG_FN(xg_stencil1d_halo)(int op, const real* in, const real* halo, real* out
                         (pad_lo || pad_hi) ? XG_BC_HALO : XG_BC_NONE, real(0), nullptr, nullptr, m_out, m_out_strides,
                         stream);
 }
+
+#ifndef XG_I64
+int XG_FN(xg_stencil1d_halo_w)(int op, const real* in, const real* halo, real* out, const int64_t* shape, int ndim,
+                            int axis, int64_t n_out, int pad_lo, int pad_hi, const real* m_in,
+                            const int64_t* m_in_strides, const real* m_out, const int64_t* m_out_strides,
+                            void* stream) {
+  if (!halo && (pad_lo || pad_hi)) return fail(XG_ERR_INVALID, "NULL halo buffer");
+  return stencil1d_impl(op, in, halo, out, shape, ndim, axis, n_out, pad_lo, pad_hi,
+                        (pad_lo || pad_hi) ? XG_BC_HALO : XG_BC_NONE, real(0), m_in, m_in_strides, m_out, m_out_strides,
+                        stream);
+}
+#endif
 
 #ifndef XG_I64
 int XG_FN(xg_stencil2d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,

@@ -309,18 +309,20 @@ def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str]
     return out
 
 
-def stencil1d_halo(op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, m_out=None) -> torch.Tensor:
+def stencil1d_halo(op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, m_out=None, m_in=None) -> torch.Tensor:
     """diff / interp / min / max along `axis` with pre-gathered halo cells (xg_stencil1d_halo_f64):
-    `halo` is shaped like `x` with `axis` shortened to pad_lo + pad_hi, low halo first."""
+    `halo` is shaped like `x` with `axis` shortened to pad_lo + pad_hi, low halo first.  With an input metric `m_in`
+    (xg_stencil1d_halo_w_f64) the field is weighted inside the kernel and `halo` holds the halo cells of the PRODUCT
+    x * m_in (gathered as gather(x) * gather(m_in)), which are not weighted again."""
     lib = _hip.load()
     expect = list(x.shape)
     expect[axis % len(expect)] = pad_lo + pad_hi
     if list(halo.shape) != expect:
         raise ValueError(f"halo buffer has shape {tuple(halo.shape)}, expected {tuple(expect)}")
-    if _is_int(x) and _is_int(halo):
+    if _is_int(x) and _is_int(halo) and m_in is None:
         plan = _dt.stencil_plan(op, _dt.np_dtype(x), None, None if m_out is None else _dt.np_dtype(m_out))
         return _int_stencil1d(plan, op, x, halo, axis, pad_lo, pad_hi, "halo", 0, m_out)
-    dt, sfx = _common(x, halo, m_out)
+    dt, sfx = _common(x, halo, m_out, m_in)
     x = asdevice(x, dt)
     halo = asdevice(halo, dt)
     axis = axis % x.dim()
@@ -332,6 +334,16 @@ def stencil1d_halo(op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, m_out=
     if out.numel() == 0:
         return out
     m_out = _prep_metric(m_out, dt)
+    if m_in is not None:
+        m_in = _prep_metric(m_in, dt)
+        _hip.check(
+            getattr(lib, "xg_stencil1d_halo_w_" + sfx)(
+                _hip.OP[op], x.data_ptr(), halo.data_ptr() if halo.numel() else None, out.data_ptr(),
+                _hip.i64(list(x.shape)), x.dim(), axis, n_out, int(pad_lo), int(pad_hi), _ptr(m_in),
+                _hip.i64(_bstrides(m_in, list(x.shape), "m_in")), _ptr(m_out), _hip.i64(_bstrides(m_out, oshape, "m_out")),
+                _stream())
+        )
+        return out
     _hip.check(
         getattr(lib, "xg_stencil1d_halo_" + sfx)(
             _hip.OP[op], x.data_ptr(), halo.data_ptr() if halo.numel() else None, out.data_ptr(),

@@ -464,10 +464,11 @@ class Grid:
                     post_divide = dx  # two successive divisions cannot be merged bit-exactly
             arg = {vector_key: array} if vector_key is not None else array
             if isinstance(ufunc, gridops.HipGridUFunc):
-                if m_in is not None and gridops.complex_topology(self, ax_name):
-                    # halos come from other faces / the folded row and must be halos of the PRODUCT (the
-                    # reference multiplies first, grid.py:804-808): one product pass, then the halo-fused
-                    # kernel with the output metric -- 2 passes instead of product, padded copy, op, divide
+                if m_in is not None and gridops.complex_topology(self, ax_name) and (vector_key is not None or other_component is not None):
+                    # halos come from other faces / the folded row and must be halos of the PRODUCT (the reference
+                    # multiplies first, grid.py:804-808).  A scalar field takes them as the product of two halo slabs and
+                    # stays in ONE pass (gridops._fused); a vector component's halos mix components: explicit product
+                    # pass, then the halo-fused kernel with the output metric
                     array = array * m_in
                     arg = {vector_key: array} if vector_key is not None else array
                     m_in = None

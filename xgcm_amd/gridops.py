@@ -104,9 +104,14 @@ class HipGridUFunc(GridUFunc):
         if kwargs.get("pad_before_func", self.pad_before_func) != self.pad_before_func:
             return False
         if complex_topology(grid, axis[0][0]):
-            # halos come from neighbouring faces / the folded row: gathered first, then the same
-            # kernels (xg_stencil1d_halo); scans and input metrics keep the reference's pad-then-apply
-            return self.funcname != "cumsum" and kwargs.get("metric_in") is None
+            # halos come from neighbouring faces / the folded row: gathered first, then the same kernels
+            # (xg_stencil1d_halo); scans keep the reference's scan-then-pad (Grid.cumsum has its own one-pass route).  An
+            # input metric rides along for scalar fields (the product's halo = the two halos' product, xg_stencil1d_halo_w);
+            # vector components with a metric keep the explicit product (their halos mix components)
+            if self.funcname == "cumsum":
+                return False
+            if kwargs.get("metric_in") is not None:
+                return not isinstance(args[0], dict) and kwargs.get("other_component") is None
         return True
 
     def __call__(self, grid=None, *args, axis, **kwargs):
@@ -153,7 +158,19 @@ class HipGridUFunc(GridUFunc):
             # the ordinary kernel reads the field once: no padded copy (reference: pad, then apply)
             halo = halo_cells(arg, grid, ax_name, (lo, hi), padding=padding, fill_value=fill_value,
                               other_component=other_component)
-            data = _same_residency(da.data, _dev.stencil1d_halo(self.funcname, da.data, halo.data, num, lo, hi, m_out))
+            if metric_in is not None:
+                # the reference multiplies, then pads the PRODUCT through the topology (grid.py:804-808): its halo cells are
+                # field[src] * metric[src] -- the product of the two halo slabs (a fill cell stays the fill value: the
+                # metric's slab holds 1 there) -- so the field is read once, weighted inside the kernel
+                mh = metric_in
+                if in_dim not in mh.dims:
+                    # a metric without the operator's dim still changes from face to face (and along the other axis of an
+                    # axis-swapping link): give it that dim (a small broadcast plane) so that it travels through the topology
+                    zeros = np.zeros(da.sizes[in_dim], dtype=_dt.float_of(_dt.np_dtype(mh.data)))
+                    mh = mh + DataArray(zeros, (in_dim,))
+                mh = halo_cells(mh, grid, ax_name, (lo, hi), padding=padding, fill_value=1.0)
+                halo = halo._binary(mh, "mul", dims_order=da.dims)
+            data = _same_residency(da.data, _dev.stencil1d_halo(self.funcname, da.data, halo.data, num, lo, hi, m_out, m_in))
             res = DataArray(data, out_dims, name=da.name)
             return _reattach_coords([res], grid, self.padding_width, {out_dim}, [da])[0]
 
