@@ -400,11 +400,14 @@ def main():
             4: {"X": ((3, "Y", True), (1, "Y", False)), "Y": ((2, "Y", True), (0, "Y", False))},
             5: {"X": ((3, "Y", False), (1, "Y", True)), "Y": ((0, "Y", False), (2, "Y", True))},
         }
-        dsf = Dataset({}, {"i": ("i", np.arange(n) + 0.5), "i_g": ("i_g", np.arange(n) * 1.0),
-                           "j": ("j", np.arange(n) + 0.5), "j_g": ("j_g", np.arange(n) * 1.0),
-                           "face": ("face", np.arange(nf))})
+        metf = lambda seed: D.synthetic((nf, n, n), seed, 0, 1000.0, 1000.0)  # noqa: E731
+        dsf = Dataset({"dxc": DataArray(metf(64), ("face", "j", "i")), "dxg": DataArray(metf(65), ("face", "j", "i_g")),
+                       "dyc": DataArray(metf(66), ("face", "j", "i")), "dyg": DataArray(metf(67), ("face", "j_g", "i"))},
+                      {"i": ("i", np.arange(n) + 0.5), "i_g": ("i_g", np.arange(n) * 1.0),
+                       "j": ("j", np.arange(n) + 0.5), "j_g": ("j_g", np.arange(n) * 1.0),
+                       "face": ("face", np.arange(nf))})
         gridf = Grid(dsf, coords={"X": {"center": "i", "left": "i_g"}, "Y": {"center": "j", "left": "j_g"}},
-                     face_connections={"face": links}, autoparse_metadata=False)
+                     face_connections={"face": links}, metrics={("X",): ["dxc", "dxg"], ("Y",): ["dyc", "dyg"]}, autoparse_metadata=False)
         Tf = DataArray(D.synthetic((nzc, nf, n, n), 61), ("Z", "face", "j", "i"))
         cf = nzc * nf * n * n
         import time as _time
@@ -414,6 +417,13 @@ def main():
             for ax in ("X", "Y"):
                 rec("f2", f"{fn}(T,'{ax}') on the cubed sphere (6x2160x2160x25), halos from face connections",
                     timeit(lambda: getattr(gridf, fn)(Tf, ax), a.reps), cf, 16)
+        # round 4: the two rows that used to take extra passes -- cumsum along a connected axis (scan into the padded layout,
+        # halo cells of the cumulative field put in place) and metric_weighted operators (product halo from two slab gathers)
+        for ax in ("X", "Y"):
+            rec("f2", f"cumsum(T,'{ax}') on the cubed sphere: one pass + halo slab", timeit(lambda: gridf.cumsum(Tf, ax), a.reps), cf, 16)
+            rec("f2", f"interp(T,'{ax}', metric_weighted) on the cubed sphere: one pass, product halo from two slab gathers",
+                timeit(lambda: gridf.interp(Tf, ax, metric_weighted=ax), a.reps), cf, 16 + 16 / nzc)
+            rec("f2", f"derivative(T,'{ax}') on the cubed sphere", timeit(lambda: gridf.derivative(Tf, ax), a.reps), cf, 16 + 8 / nzc)
         from xgcm_amd.padding import pad as _pad
         rec("f2", "pad(T, X:(1,1), Y:(1,1)) alone (xg_gather)", timeit(lambda: _pad(Tf, gridf, {"X": (1, 1), "Y": (1, 1)}), a.reps), cf, 16)
         # full-size check: halo columns of the X difference against neighbour-face data (host arithmetic on slices)
