@@ -137,6 +137,34 @@ def test_strided_metric_stencil_y_stacked_workgroups(dev, dtype, ys):
             _hip.set_tunable(k, v)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("ys", [0, 1])
+def test_two_axis_metric_kernels_every_form(dev, dtype, ys):
+    """`xg_stencil2d_metric` (metric_weighted on both axes) through both of its kernels -- K8 (met_ys 0) and the y-stacked
+    K8y (1): every operator, both pads on both axes, every boundary pair incl. non-zero fills, level counts that are not a
+    multiple of the four a task carries, row lengths around multiples of the wave, heights that are not a multiple of the
+    workgroup's rows -- equal to the two metric-carrying 1-D passes of the oracle, bit for bit.  (Round 4 also ran a third
+    form through this test, a march along Y with overlapped x-tiles: bit-exact, no faster, removed -- profiles/EXPERIMENTS.md.)"""
+    from xgcm_amd import _hip
+    keep = _hip.get_tunable("met_ys")
+    _hip.set_tunable("met_ys", ys)
+    nv = 2 if dtype == np.float64 else 4
+    try:
+        for nz, ny, nvec in ((9, 37, 130), (6, 16, 63 * 2), (5, 19, 63 * 2 + 1), (4, 8, 64), (7, 33, 63 * 3 - 1)):
+            shape = (nz, ny, nvec * nv)
+            a = _field(shape, 75).astype(dtype)
+            m1, m2, m3 = (R.synthetic_metric((1,) + shape[1:], 76 + k).astype(dtype) for k in range(3))
+            for op in OPS:
+                for (padx, pady), (bcx, bcy) in itertools.product(itertools.product([(1, 0), (0, 1)], [(1, 0), (0, 1)]),
+                                                                 [("periodic", "extend"), ("fill", "periodic"), ("extend", "fill")]):
+                    t = R.stencil1d(op, a, 2, *padx, bcx, dtype(0.75), m1, m2)
+                    want = R.stencil1d(op, t, 1, *pady, bcy, dtype(-1.5), m2, m3)
+                    got = dev.tohost(dev.stencil2d(op, a, 0, padx, bcx, 0.75, pady, bcy, -1.5, metrics=(m1[0], m2[0], m3[0])))
+                    _eq(got, want)
+    finally:
+        _hip.set_tunable("met_ys", keep)
+
+
 @pytest.mark.parametrize("shape", [(6, 10, 128), (3, 7, 33), (2, 5, 4, 66), (300,), (3, 700), (2, 2050), (3, 1024), (9, 4100)])
 def test_cumsum_all(dev, shape):
     a = _field(shape, 7, nan=True)

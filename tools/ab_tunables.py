@@ -189,7 +189,11 @@ def main():
             ts = sorted(times[(vi, c)])
             ms = ts[len(ts) // 2]
             gbs = cells * CASES[c][1] * bscale / (ms * 1e-3) / 1e9
+            # paired statistic: within a round every variant ran on the same buffers (the rate of a kernel depends on where
+            # the driver placed them), so the ratio to the FIRST variant round by round is far tighter than the two medians
+            ratios = sorted(a_ / b_ for a_, b_ in zip(times[(vi, c)], times[(0, c)]) if b_ > 0)
             print(json.dumps({"case": c, "variant": ",".join(f"{k}={v}" for k, v in kv.items()), "median_ms": round(ms, 4),
+                              "time_vs_first_paired": round(ratios[len(ratios) // 2], 4) if ratios else None,
                               "min_ms": round(ts[0], 4), "max_ms": round(ts[-1], 4), "GBps": round(gbs, 1),
                               "frac_8TBps": round(gbs / 8000, 4), "rounds": a.rounds,
                               "alg_bytes": int(round(cells * CASES[c][1] * bscale))}), flush=True)

@@ -114,6 +114,76 @@ __global__ __launch_bounds__(256) void k_flat_zk(const double* __restrict__ a, d
   }
 }
 
+// The LADDER from the flat 4-levels-per-thread kernel towards the product's two-axis metric_weighted interp (K8 / K8y / K8m):
+//   SEGR = 0: as k_flat_zk<3>: no stencil at all (reference point);
+//   SEGR = 1, XS only (YS false): + the X stencil -- the neighbour product from the lane below by DPP, interp -- still one
+//             intermediate row per output row;
+//   SEGR = 1, YS: + the Y stencil with the row below RECOMPUTED: two X stages (loads, products, division round trip) per
+//             output row -- K8 with one row per task;
+//   SEGR = 2, YS: three X stages for two output rows -- K8's shape (SEG = 2);
+//   SEGR = 4, YS: five for four.
+// No boundary logic (indices clamped), no LDS, no barrier: what the operator's data flow costs by itself.
+__device__ __forceinline__ double lane_below(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x138, 0xf, 0xf, false);
+  const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x138, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+template <int ZK, int SEGR, bool YS>
+__global__ __launch_bounds__(256) void k_ladder(const double* __restrict__ a, double* __restrict__ out, const double* __restrict__ m1,
+                                                const double* __restrict__ m2, const double* __restrict__ m3, u32 nblk) {
+  const u32 pb = (nblk + 7) >> 3;
+  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
+  if (lb >= nblk) return;
+  const u32 wave = lb * 4 + (threadIdx.x >> 6);
+  constexpr u32 ZG = (NZ + ZK - 1) / ZK;
+  constexpr u32 NSEG = NY / SEGR;                 // (2400 is a multiple of 1, 2, 4)
+  constexpr u32 BSEG = BAND / SEGR;
+  const u32 tiles = (VPR + 63) / 64;
+  const u32 row_w = wave / tiles, tile = wave - row_w * tiles;
+  const u32 per_band = ZG * BSEG;
+  const u32 band = row_w / per_band, rem = row_w - band * per_band;
+  const u32 zg = rem / BSEG, sg = band * BSEG + (rem - zg * BSEG);
+  if (sg >= NSEG) return;
+  const u32 v = tile * 64 + (threadIdx.x & 63);
+  if (v >= VPR) return;
+  const size_t plane = (size_t)NY * NX;
+  const u32 z0 = zg * ZK;
+  const u32 j0 = sg * SEGR;
+  constexpr int NR = YS ? SEGR + 1 : SEGR;  // intermediate rows this thread computes
+  d2 t[ZK][NR];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const u32 y = YS ? ((j0 + u == 0) ? 0 : j0 + u - 1) : j0 + u;
+    const size_t mcell = (size_t)y * NX + 2 * (size_t)v;
+    const d2 p1 = *(const d2*)(m1 + mcell), p2 = *(const d2*)(m2 + mcell);
+    d2 x[ZK];
+#pragma unroll
+    for (int k = 0; k < ZK; ++k) x[k] = __builtin_nontemporal_load((const d2*)(a + (size_t)((z0 + k < NZ) ? z0 + k : NZ - 1) * plane + mcell));
+#pragma unroll
+    for (int k = 0; k < ZK; ++k) {
+      const d2 pr = x[k] * p1;
+      double nb = lane_below(pr.y);
+      if ((threadIdx.x & 63) == 0) nb = pr.x;  // (the product's scalar load for this lane is not modelled)
+      d2 i;
+      i.x = (nb + pr.x) * 0.5;
+      i.y = (pr.x + pr.y) * 0.5;
+      t[k][u] = (i / p2) * p2;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < SEGR; ++u) {
+    const size_t mcell = (size_t)(j0 + u) * NX + 2 * (size_t)v;
+    const d2 p3 = *(const d2*)(m3 + mcell);
+#pragma unroll
+    for (int k = 0; k < ZK; ++k) {
+      d2 r = YS ? (t[k][u] + t[k][u + 1]) * 0.5 : t[k][u];
+      r = r / p3;
+      if (z0 + k < NZ) __builtin_nontemporal_store(r, (d2*)(out + (size_t)(z0 + k) * plane + mcell));
+    }
+  }
+}
+
 // one lane = one column pair; D divisions per input cell; 50 output rows per column
 template <int D>
 __global__ __launch_bounds__(256) void k_march(const double* __restrict__ phi, const double* __restrict__ theta, double* __restrict__ out,
@@ -138,8 +208,15 @@ __global__ __launch_bounds__(256) void k_march(const double* __restrict__ phi, c
     for (int u = 0; u < 5; ++u) {
       d2 dz = t[u] - t0;
       d2 v = p[u];
+      if (D == 99) {  // DIVERGENT: a cell overlaps 0 .. 4 bins depending on its own thickness (random-walk columns): every
+                      // lane its own trip count (mean 1.67), the wave runs the longest of its 64
+        const int trips = (int)((__builtin_bit_cast(unsigned long long, dz.x) >> 40) % 6u);  // 0..5 from mantissa bits
+        const int nt = trips < 2 ? 1 : (trips < 4 ? 2 : (trips == 4 ? 0 : 4));                // 1,1,2,2,0,4 -> mean 1.67
+        for (int d = 0; d < nt; ++d) v = v / dz;
+      } else {
 #pragma unroll
       for (int d = 0; d < D; ++d) v = v / dz;  // dependent IEEE divisions (the overlap fraction feeds the accumulation)
+      }
       if (D == 0) v = v + dz;                  // (keeps the theta loads alive without a division)
       acc = acc + v;
       t0 = t[u];
@@ -198,12 +275,22 @@ int main() {
     FLATZK(2, 4, "A 1 mul 1 div, 4 levels per thread", 2)
     FLATZK(3, 4, "A 2 mul 2 div, 4 levels per thread", 3)
     FLATZK(3, 8, "A 2 mul 2 div, 8 levels per thread", 3)
+#define LADDER(ZK, SEGR, YS, name) { const u32 zg = (NZ + ZK - 1) / ZK; const size_t rw = (size_t)((NY / SEGR + BAND / SEGR - 1) / (BAND / SEGR)) * (BAND / SEGR) * zg; \
+    const u32 nb = (u32)((rw * tiles + 3) / 4), gr = ((nb + 7) / 8) * 8; \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_ladder<ZK, SEGR, YS>), dim3(gr), dim3(256), 0, 0, a, o, m1, m2, m3, nb); }); \
+    rep(name, ms, 16.0 * n + 3 * 8.0 * plane); }
+    LADDER(4, 1, false, "L 2 mul 2 div + X stencil (DPP neighbour), 4 levels")
+    LADDER(4, 1, true, "L + Y stencil, row below recomputed: 2 X stages per row")
+    LADDER(4, 2, true, "L + Y stencil, 3 X stages per 2 rows (K8's shape)")
+    LADDER(4, 4, true, "L + Y stencil, 5 X stages per 4 rows")
+    LADDER(2, 4, true, "L + Y stencil, 5 X stages per 4 rows, 2 levels")
     const u32 ncol2 = (u32)(plane / 2);
 #define MARCH(D, name) { float ms = timeit([&] { hipLaunchKernelGGL((k_march<D>), dim3((ncol2 + 255) / 256), dim3(256), 0, 0, a, th, o, ncol2, m); }); \
     rep(name, ms, 8.0 * (2.0 * n + plane + (double)m * plane)); }
     MARCH(0, "B march: 75 + 76 rows in, 50 rows out, no arithmetic")
     MARCH(1, "B march + 1 division per cell")
     MARCH(2, "B march + 2 divisions per cell (conservative: 1.67 on average)")
+    MARCH(99, "B march + 0..4 divisions per cell, DIVERGENT per lane (mean 1.67)")
   }
   return 0;
 }
