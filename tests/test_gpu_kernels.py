@@ -165,6 +165,39 @@ def test_two_axis_metric_kernels_every_form(dev, dtype, ys):
         _hip.set_tunable("met_ys", keep)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("ys", [0, 12, 14, 22])
+def test_strided_metric_stencil_with_per_face_metrics(dev, dtype, ys):
+    """Round 4 (DESIGN rule 17): a (Z, face, Y, X) field -- MITgcm's LLC / cubed-sphere layout -- whose metrics (face, Y, X)
+    change from face to face and are shared by the levels only.  Two outer dims, the metric broadcast along the slower one:
+    the band-major launches (K2S, K2Sm) now run over (face, row) under the levels instead of falling back to the unbanded
+    order (derivative Y on the cubed sphere: 0.57, metric_weighted Y 0.45 of 8 TB/s, profiles/r04d_f2.log).  Level counts
+    that are not a multiple of the levels per task, one face, many faces, every pad / boundary / metric combination, a leading
+    record dim on top: the oracle's bits."""
+    from xgcm_amd import _hip
+    keep = {k: _hip.get_tunable(k) for k in ("met_ys1", "met_ys2")}
+    _hip.set_tunable("met_ys1", ys)
+    _hip.set_tunable("met_ys2", ys)
+    try:
+        for shape in ((5, 3, 37, 130), (7, 6, 33, 128), (2, 1, 40, 64), (3, 2, 4, 9, 256)):
+            a = _field(shape, 47).astype(dtype)
+            ax = len(shape) - 2
+            for (lo, hi), bc in itertools.product([(1, 0), (0, 1), (1, 1), (0, 0)], BCS):
+                oshape = list(shape)
+                oshape[ax] = shape[ax] + lo + hi - 1
+                mshape_in = (1,) * (len(shape) - 3) + tuple(shape[-3:])
+                mshape_out = (1,) * (len(shape) - 3) + tuple(oshape[-3:])
+                m_in = R.synthetic_metric(mshape_in, 48).astype(dtype)
+                m_out = R.synthetic_metric(mshape_out, 49).astype(dtype)
+                for op in ("diff", "interp"):
+                    for kw in ({"m_out": m_out}, {"m_in": m_in, "m_out": m_out}, {"m_in": m_in}):
+                        exp = R.stencil1d(op, a, ax, lo, hi, bc, 0.75, **kw)
+                        _eq(dev.tohost(dev.stencil1d(op, a, ax, lo, hi, bc, 0.75, **kw)), exp)
+    finally:
+        for k, v in keep.items():
+            _hip.set_tunable(k, v)
+
+
 @pytest.mark.parametrize("shape", [(6, 10, 128), (3, 7, 33), (2, 5, 4, 66), (300,), (3, 700), (2, 2050), (3, 1024), (9, 4100)])
 def test_cumsum_all(dev, shape):
     a = _field(shape, 7, nan=True)

@@ -213,19 +213,29 @@ __device__ __forceinline__ u32 fdiv(u32 n, const FastDiv& f) {
 // dx(Y,X) weighting a (Z,Y,X) field), rows are visited band by band -- all Z levels of a band of
 // B rows before the next band -- so the band's metric values are fetched once and then served by
 // the XCD's L2 for the other Z-1 levels instead of being re-read from the Infinity Cache per level.
+// "faces" (round 4): the metrics of a (Z, face, Y, X) field -- MITgcm's LLC / cubed-sphere layout -- change from face to
+// face and are shared by the levels only: two outer dims, the metric broadcast along the SLOWER one.  The banded index y
+// then runs over nf x (rows or segments of one face) -- the (face, Y) block of a level is contiguous -- and the kernels
+// split it again (zband_face); the levels a wave-task shares its metric rows across are `nf` outer indices apart.
 struct ZBand {
   u32 on, Z, B, Y;       // Y = rows (or segments) per level, B = rows (segments) per band
   FastDiv per_band, fB;  // divisors Z*B and B
+  u32 nf;                // faces under each level (1: none)
+  FastDiv fper;          // rows (segments) per face
 };
-inline ZBand make_zband(bool on, u64 Z, u64 Y, u32 B) {
+inline ZBand make_zband(bool on, u64 Z, u64 Y, u32 B, u64 nf = 1) {
   ZBand z;
   memset(&z, 0, sizeof(z));
   z.per_band = make_fastdiv(1);
   z.fB = make_fastdiv(1);
-  if (!on || Z < 2 || Z * (u64)B > 0x7fffffffull) return z;
+  z.fper = make_fastdiv(1);
+  z.nf = 1;
+  if (!on || Z < 2 || Z * (u64)B > 0x7fffffffull || nf < 1 || nf > 0xffffull || Y % nf) return z;
   z.on = 1; z.Z = (u32)Z; z.B = B; z.Y = (u32)Y;
   z.per_band = make_fastdiv(Z * B);
   z.fB = make_fastdiv(B);
+  z.nf = (u32)nf;
+  z.fper = make_fastdiv(Y / nf);
   return z;
 }
 // work index r (band-major) -> (z, y); false if the band's tail row does not exist
@@ -235,6 +245,16 @@ __device__ __forceinline__ bool zband_map(const ZBand& zb, u32 r, u32& z, u32& y
   z = fdiv(rem, zb.fB);
   y = b * zb.B + (rem - z * zb.B);
   return y < zb.Y;
+}
+
+// (level group, banded row index over nf faces) -> first flattened outer index of the task, the step between its
+// levels, the row index inside the face; `zl` = first level of the group
+__device__ __forceinline__ void zband_face(const ZBand& zb, u32 zl, u32& y, u32& first, u32& step) {
+  if (zb.nf <= 1) { first = zl; step = 1; return; }
+  const u32 f = fdiv(y, zb.fper);
+  y -= f * zb.fper.d;
+  first = zl * zb.nf + f;
+  step = zb.nf;
 }
 
 // Column chunking for the short-segment kernel when a "row" of the strided axis is a whole plane

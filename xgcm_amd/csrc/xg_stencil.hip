@@ -476,7 +476,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
   if (lb >= nblk) return;
   const u32 w = __builtin_amdgcn_readfirstlane(lb * WPB + (threadIdx.x >> 6));
-  u32 oo, sg, tile;
+  u32 oo, sg, tile, zl = 0, ostep = 1;
   if (ck.on) {  // (outer, chunk, segment, tile in chunk)
     const u32 cg = fdiv(w, ck.per_group);
     const u32 rem = w - cg * ck.per_group.d;
@@ -484,20 +484,23 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
     oo = fdiv(cg, ck.fnchunk);
     tile = (cg - oo * ck.fnchunk.d) * ck.ch.d + (rem - sg * ck.ch.d);
     if (oo >= nouter || tile >= ntile.d) return;
+    zl = oo;
   } else {
     const u32 r = fdiv(w, ntile);
     tile = w - r * ntile.d;
     if (MET != 0 && zb.on) {  // band-major order over (segment band, outer [group], segment)
       if (!zband_map(zb, r, oo, sg)) return;
-      oo *= ZK;
+      zl = oo * ZK;
+      zband_face(zb, zl, sg, oo, ostep);  // (faces under the levels: `nouter` counts LEVELS, the levels of a task lie `ostep` apart)
     } else {
       oo = fdiv(r, nseg);
       if (oo >= nouter) return;
       sg = r - oo * nseg.d;
+      zl = oo;
     }
   }
   const int64_t o = o0 + oo;
-  const int nk = (ZK > 1 && (int64_t)nouter - (int64_t)oo < ZK) ? (int)(nouter - oo) : ZK;  // levels this wave really has
+  const int nk = (ZK > 1 && (int64_t)nouter - (int64_t)zl < ZK) ? (int)(nouter - zl) : ZK;  // levels this wave really has
   const int64_t inner = g.inner;
   const int64_t x = ((int64_t)tile * WAVE + (threadIdx.x & 63)) * V;
   if (x >= inner) return;
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
   }
 #pragma unroll
   for (int kz = 0; kz < ZK; ++kz) {
-    const int64_t ok = o + ((kz < nk) ? kz : nk - 1);  // a short last group repeats its last level (not stored)
+    const int64_t ok = o + (int64_t)((kz < nk) ? kz : nk - 1) * ostep;  // a short last group repeats its last level (not stored)
     const real* pin = in + (ok * g.n_in) * inner + x;
     const real* phalo = halo + (ok * (g.n_out - g.n_in + 1)) * inner + x;
 #pragma unroll
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_seg(
 #pragma unroll
   for (int kz = 0; kz < ZK; ++kz) {
     if (kz >= nk) break;
-    real* pout = out + ((o + kz) * g.n_out + j0) * inner + x;
+    real* pout = out + ((o + (int64_t)kz * ostep) * g.n_out + j0) * inner + x;
     T p[SEG + 1];
 #pragma unroll
     for (int u = 0; u <= SEG; ++u) {
@@ -1260,12 +1263,13 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_ysm(
   const int lane = threadIdx.x & 63;
   const u32 r = fdiv(lb, ntile);
   const u32 tile = lb - r * ntile.d;
-  u32 oo, ssg;
+  u32 oo, ssg, ostep;
   if (!zband_map(zb, r, oo, ssg)) return;  // band-major order over (band of super-segments, level group, super-segment)
-  oo *= ZK;
+  const u32 zl = oo * ZK;
+  zband_face(zb, zl, ssg, oo, ostep);  // (faces under the levels: `nouter` counts LEVELS, the levels of a task lie `ostep` apart)
   const u32 sg = ssg * WPB + wib;
   const int64_t o = oo;
-  const int nk = ((int64_t)nouter - (int64_t)oo < ZK) ? (int)(nouter - oo) : ZK;  // levels this group really has
+  const int nk = ((int64_t)nouter - (int64_t)zl < ZK) ? (int)(nouter - zl) : ZK;  // levels this group really has
   const int64_t inner = g.inner;
   const int64_t x = ((int64_t)tile * WAVE + lane) * NV;
   const bool active = sg < nseg && x < inner;
@@ -1311,7 +1315,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_ysm(
     T v[ZK][SEG + 1], wm[SEG + 1];
 #pragma unroll
     for (int kz = 0; kz < ZK; ++kz) {
-      const int64_t ok = o + ((kz < nk) ? kz : nk - 1);  // a short last group repeats its last level (not stored)
+      const int64_t ok = o + (int64_t)((kz < nk) ? kz : nk - 1) * ostep;  // a short last group repeats its last level (not stored)
       const real* pin = in + (ok * g.n_in) * inner + x;
       const real* phalo = halo + (ok * (g.n_out - g.n_in + 1)) * inner + x;
 #pragma unroll
@@ -1346,7 +1350,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_ysm(
   for (int kz = 0; kz < ZK; ++kz) {
     if (kz >= nk) break;
     if (wib > 0) p[kz][0] = s_p[wib - 1][kz][lane];  // (the wave below is active: its segment index is smaller)
-    real* pout = out + ((o + kz) * g.n_out + j0) * inner + x;
+    real* pout = out + ((o + (int64_t)kz * ostep) * g.n_out + j0) * inner + x;
 #pragma unroll
     for (int u = 0; u < SEG; ++u) {
       if (u < nrow) {
@@ -1363,6 +1367,17 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_ysm(
 // lead over K2S stays at +1.7 points, K2Sm's SHRINKS from +1.7 to +0.7; the scalar unit is not what bounds these kernels, the
 // 64-bit forms stay.  profiles/r03ax_ab_lean32_old_new.jsonl)
 // K2Sm launch: the geometry tests are launch_seg_n's (z-banding, one outer dim, metrics broadcast along it, 16-B lane vectors)
+// z-banding geometry of a strided-axis launch with metrics: ONE outer dim along which every metric is broadcast (levels), or
+// TWO with the metrics broadcast along the slower one only -- (Z, face | Y | X) fields with per-face metrics (rule 17).
+// Returns false when the metrics do not allow banding; else the number of levels and of faces under each level.
+inline bool zband_levels(const StencilCall& c, u64* levels, u64* faces) {
+  if (c.g.n_outer < 1 || c.g.n_outer > 2) return false;
+  if ((c.m_in && c.mi.outer[0] != 0) || (c.m_out && c.mo.outer[0] != 0)) return false;
+  *levels = (u64)c.g.outer_shape[0];
+  *faces = c.g.n_outer == 2 ? (u64)c.g.outer_shape[1] : 1;
+  return true;
+}
+
 template <int OP, int MET, int SEG, int ZK>
 bool launch_ysm(const StencilCall& c) {
   const u64 ntile = (u64)((c.g.inner + (int64_t)WAVE * NV - 1) / ((int64_t)WAVE * NV));
@@ -1383,14 +1398,17 @@ bool launch_ysm(const StencilCall& c) {
   const u32 zbr = (c.m_in && c.m_out) ? zb_base / 2 : zb_base * 2;
   const u32 per = (u32)(SEG * WPB);
   const u32 ZB_SS = (zbr + per - 1) / per;  // band height in super-segments (at least one)
-  const u64 padded = ((nsseg + ZB_SS - 1) / ZB_SS) * ZB_SS;
-  const u64 zgroups = ((u64)c.g.outer + ZK - 1) / ZK;
+  u64 levels = 0, faces = 1;
+  if (!zband_levels(c, &levels, &faces)) return false;
+  const u64 rows = nsseg * faces;           // super-segments under one level (whole faces: none straddles two)
+  const u64 padded = ((rows + ZB_SS - 1) / ZB_SS) * ZB_SS;
+  const u64 zgroups = (levels + ZK - 1) / ZK;
   const u64 nwg = padded * zgroups * ntile;
-  ZBand zb = make_zband(true, zgroups, nsseg, ZB_SS);
+  ZBand zb = make_zband(true, zgroups, rows, ZB_SS, faces);
   if (!zb.on || nwg > MAX_ITEMS) return false;
   const u32 nblk = (u32)nwg;
   const u32 grid = ((nblk + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_stencil_strided_ysm<OP, MET, SEG, ZK>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (u32)c.g.outer, nblk, make_fastdiv(ntile), (u32)nseg, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
+  hipLaunchKernelGGL((k_stencil_strided_ysm<OP, MET, SEG, ZK>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (u32)levels, nblk, make_fastdiv(ntile), (u32)nseg, zb, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
   return true;
 }
 
@@ -1422,21 +1440,22 @@ int launch_seg_n(const StencilCall& c) {
   const u32 zb_base = (u32)(tune().zb_rows > 1 ? tune().zb_rows : 16);
   const u32 zbr = (c.m_in && c.m_out) ? zb_base / 2 : zb_base;
   const u32 ZB_SEGS = (zbr + SEG - 1) / SEG;
-  const bool zb_ok = !ck.on && MET != 0 && tune().zband && c.g.n_outer == 1 && (!c.m_in || c.mi.outer[0] == 0) &&
-                     (!c.m_out || c.mo.outer[0] == 0);
+  u64 levels = 0, faces = 1;  // one outer dim (levels), or (levels, faces) with per-face metrics shared by the levels
+  const bool zb_ok = !ck.on && MET != 0 && tune().zband && zband_levels(c, &levels, &faces);
   if (ZK > 1 && !tune().nt_store) return launch_seg_n<OP, V, MET, SEG, 1>(c);  // z-shared tasks exist with non-temporal stores only
   if (zb_ok) {
-    const u64 padded_segs = ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS;
-    const u64 zgroups = ((u64)c.g.outer + ZK - 1) / ZK;  // ZK levels per wave share the metric rows
+    const u64 rows = nseg * faces;  // segments under one level
+    const u64 padded_segs = ((rows + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS;
+    const u64 zgroups = (levels + ZK - 1) / ZK;  // ZK levels per wave share the metric rows
     const u64 waves = padded_segs * zgroups * ntile;
-    ZBand zb = make_zband(true, zgroups, nseg, ZB_SEGS);
+    ZBand zb = make_zband(true, zgroups, rows, ZB_SEGS, faces);
     if (zb.on && waves <= MAX_ITEMS) {
       const u32 nblk = (u32)((waves + WPB - 1) / WPB);
       const u32 grid = ((nblk + 7) / 8) * 8;
       if (tune().nt_store)
-        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG, ZK>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, true, SEG, ZK>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)levels, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
       else
-        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)c.g.outer, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
+        hipLaunchKernelGGL((k_stencil_strided_seg<OP, V, MET, false, SEG>), dim3(grid), dim3(BLOCK), 0, c.st, c.in, c.out, c.g, (int64_t)0, (u32)levels, nblk, fnt, fns, zb, noch, c.pad_lo, c.bc, c.fill, c.halo, c.m_in, c.mi, c.m_out, c.mo, mal);
       return 0;
     }
   }
@@ -1488,8 +1507,8 @@ int launch_seg(const StencilCall& c) {
     // (metric_weighted Y): 1 x 8 within +-1 point of K2S, everything else behind it => off by default
     const int ys = (MET == 3) ? tune().met_ys2 : tune().met_ys1;
     const u64 ntile_ = (u64)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
-    if (ys && tune().nt_store && tune().zband && c.g.n_outer == 1 && ntile_ <= (u64)tune().seg_max_tiles &&
-        (!c.m_in || c.mi.outer[0] == 0) && (!c.m_out || c.mo.outer[0] == 0)) {
+    u64 lv_ = 0, fc_ = 1;
+    if (ys && tune().nt_store && tune().zband && ntile_ <= (u64)tune().seg_max_tiles && zband_levels(c, &lv_, &fc_)) {
       bool done = false;
       switch (ys) {
         case 12: done = launch_ysm<OP, MET, 1, 2>(c); break;
