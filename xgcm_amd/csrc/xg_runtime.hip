@@ -58,7 +58,7 @@ const TuneEntry TUNABLES[] = {
     {"scan_chain_tmaj", &Tune::scan_chain_tmaj, 0},  // minimal traffic (1.01x) but 10-27 % slower: profiles/r03o_*
     {"reduce_zl", &Tune::reduce_zl, 2},
     {"met_ys1", &Tune::met_ys1, 12},
-    {"met_ys2", &Tune::met_ys2, 0},
+    {"met_ys2", &Tune::met_ys2, 14},
     {"transform_lean", &Tune::transform_lean, 3},
     {"pad_tpw", &Tune::pad_tpw, 2},
     {"bin_idx32", &Tune::bin_idx32, 1},

@@ -1395,7 +1395,9 @@ bool launch_ysm(const StencilCall& c) {
   const u32 zb_base = (u32)(tune().zb_rows > 1 ? tune().zb_rows : 16);
   // one metric: bands of 2 x zb_rows = 32 rows hold here (reads 1.062 -> 1.032x, +0.6 points, profiles/r03bh_pmc_dy_bands.jsonl):
   // the output lines are dropped from the L2 as they are written (rule 16), the band's one metric plane and the halo rows stay
-  const u32 zbr = (c.m_in && c.m_out) ? zb_base / 2 : zb_base * 2;
+  // two metrics: 16-row bands hold in the y-stacked form, where K2S needs 8 (round 4: reads 6.00 -> 5.72 GB, traffic 1.064 ->
+  // 1.038x at the same speed, nine placements paired; profiles/r04h_ab_iymw_*.log)
+  const u32 zbr = (c.m_in && c.m_out) ? zb_base : zb_base * 2;
   const u32 per = (u32)(SEG * WPB);
   const u32 ZB_SS = (zbr + per - 1) / per;  // band height in super-segments (at least one)
   u64 levels = 0, faces = 1;
@@ -1504,7 +1506,9 @@ int launch_seg(const StencilCall& c) {
     const int ms = (MET == 3 ? tune().met_seg : tune().met_seg1), zk = tune().nt_store ? (MET == 3 ? tune().met_zk : tune().met_zk1) : 1;
     // K2Sm (y-stacked workgroups) where launch_seg_n would z-band: `met_ys1` / `met_ys2` = 10 * rows + levels per wave.
     // One metric (derivative Y): 1 row x 2 levels 0.733 -> 0.750 in one process, every other shape +0.7..0.9; two metrics
-    // (metric_weighted Y): 1 x 8 within +-1 point of K2S, everything else behind it => off by default
+    // (metric_weighted Y): 1 x 8 within +-1 point of K2S, everything else behind it => off in round 3; round 4, paired over nine
+    // buffer placements: 1 x 4 is 0.9 % ahead of K2S with 8-row bands and level with it at 16 rows, where it re-reads half
+    // as many halo rows => `met_ys2` = 14
     const int ys = (MET == 3) ? tune().met_ys2 : tune().met_ys1;
     const u64 ntile_ = (u64)((c.g.inner + (int64_t)WAVE * V - 1) / ((int64_t)WAVE * V));
     u64 lv_ = 0, fc_ = 1;
