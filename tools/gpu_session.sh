@@ -19,7 +19,6 @@
 #     valu                        SQ_INSTS_VALU / SALU / WAVES over the kernel table    -> valu_issue_share.txt
 #     roofline [args]             tools/roofline_table.py                              -> roofline.md / .jsonl
 #     scale [args]                tools/scale_table.py --records 45                    -> scale_table.md / .jsonl / _topo.txt
-#     boxkind                     tools/box_kind_pmc.sh                                 -> box_kind.txt
 #     run <label> <secs> <cmd..>  any command under `timeout <secs>`                    -> <label>.log
 NAME=${1:?session name}
 STEPS=${2:?steps file}
@@ -69,7 +68,6 @@ while IFS= read -r line || [ -n "$line" ]; do
       rm -rf $OUT/prof_valu_$NAME ;;
     roofline) timeout 1200 python tools/roofline_table.py --out $S/roofline "$@" 2>&1 | tail -40 ;;
     scale) timeout 600 python tools/scale_table.py --records 45 --out $S/scale_table "$@" 2>&1 | tail -10 ;;
-    boxkind) bash tools/box_kind_pmc.sh $S/box_kind.txt > /dev/null 2>&1; head -2 $S/box_kind.txt | cut -c1-160 ;;
     run) label=$1; secs=$2; shift 2; timeout $secs "$@" 2>&1 | tee $S/$label.log | tail -40 ;;
     *) echo "unknown step: $step" ;;
   esac

@@ -178,7 +178,7 @@ __device__ __forceinline__ void cumsum_strided_body(
 // the steady state -- built into the library with every option of the scan, bit-exact on the whole suite, and measured in one
 // process on a slow-kind box: cumsum Z 0.6735 (this march) against 0.662-0.663 for all three shapes, 4 records in one launch
 // 0.748 against 0.740.  The probe's +2.5 points (tools/marchprobe.hip, round 2) were over a single wave WITHOUT the rolling
-// window this march has since.  Removed again; profiles/r03bk_ab_k5p.jsonl, tools/gpu_session_r03bk.sh.)
+// window this march has since.  Removed again; profiles/EXPERIMENTS.md.)
 template <int V, int MET, bool NTL, bool NTS, int U, bool PIPE = false>
 __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, ScanArgs a,
@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_chain(
 }
 
 // K4cz: K4c with the weights of a chunk loaded ONCE for ZL consecutive outer indices ("levels").  PMC on K4c
-// (tools/pmc_sumyw.sh): its HBM traffic is the minimum (the field once, the weights once per XCD), yet it stops at
+// (FETCH_SIZE / WRITE_SIZE passes, round 2): its HBM traffic is the minimum (the field once, the weights once per XCD), yet it stops at
 // 57 % -- what it saturates is the L2 -> CU path, which carries the field AND, for every level again, the weights
 // (9.8 TB/s; the unweighted sum moves 6.4).  A task = (x-tile, chunk of R rows, ZL levels): R weight rows + ZL x R field
 // rows in registers, then level after level: wait for that level's running sum, add the R rows in order, publish.

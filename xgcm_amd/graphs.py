@@ -1,7 +1,7 @@
 """Operator chains on small grids as ONE hipGraph launch.
 
 A `Grid` operator on a small HBM-resident array is launch-bound: ~45 us of Python dispatch + ctypes + kernel launch
-for a kernel that runs a few microseconds (`tools/hostprof.py`).  Every kernel of the library takes its stream as an
+for a kernel that runs a few microseconds (measured with a host-side profile of the dispatch path, round 2).  Every kernel of the library takes its stream as an
 argument and keeps no per-launch host state -- the chained scans clean their workspace up inside the kernel, tickets
 included -- so a whole sequence of operators can be captured once and replayed:
 
