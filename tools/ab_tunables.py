@@ -154,6 +154,8 @@ def main():
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
             _shift = torch.empty((rnd * 37 + 1) << 20, dtype=torch.uint8, device="cuda")
+            if a.mark:  # a marker that belongs to no (variant, case) block: tools/pmc_ab.py drops what follows it
+                D.synthetic((4096 * (1 + len(variants) * len(cases)),), 1)
             T = D.synthetic((nz, ny, nx), 2)
             if T2k:
                 T2 = D.synthetic((nz, ny, nx), 9, 0, 1000.0, 1000.0)
@@ -161,8 +163,6 @@ def main():
                 T3 = D.synthetic((nz, ny, nx), 10, 0, 1000.0, 1000.0)
             if any(c in cases for c in ("vort", "divg", "flux")):
                 U, V = D.synthetic((nz, ny, nx), 51), D.synthetic((nz, ny, nx), 52)
-            if a.mark:  # a marker that belongs to no (variant, case) block: tools/pmc_ab.py drops what follows it
-                D.synthetic((4096 * (1 + len(variants) * len(cases)),), 1)
             for c in cases:
                 CASES[c][0]()
             torch.cuda.synchronize()
