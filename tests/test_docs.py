@@ -1,0 +1,56 @@
+"""The documents name evidence files; every one of them must exist.
+
+A path may carry shell-style alternatives (`r04end_rocprof_summary_{bench,cfg3}.txt`) or a `*`; each expansion must
+match at least one file under the repository root.
+"""
+
+import glob
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DOCS = ["DESIGN.md", "README.md", "INTEGRATION.md", os.path.join("profiles", "README.md")]
+PATH = re.compile(r"profiles/[A-Za-z0-9_./*{},-]+")
+
+
+def _expand(pattern):
+    m = re.search(r"\{([^{}]*)\}", pattern)
+    if not m:
+        return [pattern]
+    out = []
+    for alt in m.group(1).split(","):
+        out += _expand(pattern[: m.start()] + alt.strip() + pattern[m.end():])
+    return out
+
+
+def cited_paths(text, prefix=""):
+    for tok in PATH.findall(text):
+        tok = tok.rstrip(".,")
+        if tok.endswith("/") or tok == "profiles/":
+            tok = tok.rstrip("/")
+        for p in _expand(tok):
+            yield prefix + p
+
+
+@pytest.mark.parametrize("doc", DOCS)
+def test_every_profiles_path_named_in_the_documents_exists(doc):
+    text = open(os.path.join(ROOT, doc)).read()
+    missing = [p for p in cited_paths(text) if not glob.glob(os.path.join(ROOT, p))]
+    assert not missing, f"{doc} names files that do not exist: {sorted(set(missing))}"
+
+
+def test_files_listed_in_the_profiles_index_exist():
+    """profiles/README.md lists its files by bare name in the first column of its tables"""
+    text = open(os.path.join(ROOT, "profiles", "README.md")).read()
+    names = re.findall(r"`(r04[A-Za-z0-9_.*{},-]+)`", text)
+    assert names
+    missing = [n for n in names for p in _expand(n) if not glob.glob(os.path.join(ROOT, "profiles", p))]
+    assert not missing, sorted(set(missing))
+
+
+def test_design_document_stays_readable():
+    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 40 * 1024
+    tools = [f for f in os.listdir(os.path.join(ROOT, "tools")) if not f.startswith("__")]
+    assert len(tools) <= 30, tools

@@ -3,7 +3,7 @@
 // One generation of waves; a wave keeps the running sums of NT consecutive x-tiles (64 lanes x 16 B) in registers and
 // sweeps the levels once; rows through buffer descriptors; straight-line levels; loads run D - 1 groups of G tiles ahead.
 // Variants <NT, G, D>: registers = 4 NT (sums) + 4 G D (buffers) + ~25.  Every variant is checked bit for bit against the
-// march.  Results go to stdout (profiles/r03p_levels_probe.txt).
+// march.  Results go to stdout (profiles/history/r03p_levels_probe_*.txt).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

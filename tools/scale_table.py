@@ -4,7 +4,7 @@ configs that are defined as 8-GPU runs (config 4: cumsum along Z over 360 record
 vorticity on 4320 x 4320 x 90 split along Z) at N = 1, 2, 4, 8 ranks -- one process per GPU over RCCL, launched exactly
 as the driver launches them (`python bench.py --gpus N` re-executes itself under torch.distributed.run).
 
-    python tools/scale_table.py [--ns 1,2,4,8] [--records 360] [--steps 20] [--out profiles/r03_scale_table]
+    python tools/scale_table.py [--ns 1,2,4,8] [--records 360] [--steps 20] [--out gpurun_out/scale_table]
 
 An N above the number of visible GPUs is skipped and listed as such (the GPU box of this round has one GPU; the driver's
 SCALE run is the first with N > 1).  Columns: aggregate GB/s, fraction of N x 8 TB/s, speed-up against N = 1 (weak

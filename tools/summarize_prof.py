@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 (rocpd sqlite) outputs into the text summary committed under profiles/.
 
-    python tools/summarize_prof.py gpurun_out r01 > profiles/r01_rocprof_summary.txt
+    python tools/summarize_prof.py gpurun_out r01 > profiles/history/r01_rocprof_summary.txt
 
 Kernel stats come from the --kernel-trace --stats run; FETCH_SIZE / WRITE_SIZE from two separate
 --pmc passes.  Counter units: KiB.  On gfx950 FETCH_SIZE reports exactly half of a wide coalesced

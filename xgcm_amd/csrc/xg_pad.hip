@@ -164,7 +164,7 @@ __global__ __launch_bounds__(BLOCK) void k_pad_rows(const real* __restrict__ in,
         // wrap / clamp / fill logic, NV consecutive narrow loads served by L1
         // (one aligned 16-B load per lane + the next vector's cells from the neighbouring lane by DPP, rule 12, measured:
         // padX 0.644 -> 0.566; rows whose sources ARE aligned gain nothing either, 0.673 -> 0.677 -- the loads are not what
-        // bounds this kernel; profiles/r03ak_ab_pad_dpp.jsonl)
+        // bounds this kernel; profiles/history/r03ak_ab_pad_dpp.jsonl)
         const real* s = in + src + q0;
 #pragma unroll
         for (int k = 0; k < NV; ++k) val[k] = s[k];
@@ -554,7 +554,7 @@ int XG_FN(xg_gather)(const real* in, const real* partner, real* out, const int64
   if (tune().pad_rows && Lrow >= 64 && aligned16(out) && nrows64 < 0x7fffffffll) {
     const u64 ntiles = (u64)((Lrow + (NV - 1) + (int64_t)WAVE * NV - 1) / ((int64_t)WAVE * NV));
     // tiles per wave-task (see xg_pad): 1 -> 2 tiles 0.641 -> 0.683 on a periodic (Y, X) frame; 4 tiles unrolled spill (22 ms
-    // for 1.9): not instantiated (profiles/r03at_ab_gather_tpw.jsonl)
+    // for 1.9): not instantiated (profiles/history/r03at_ab_gather_tpw.jsonl)
     const u64 tpw = (u64)(tune().pad_tpw >= 2 ? 2 : 1);
     const u64 nt = (ntiles + tpw - 1) / tpw;
     const u64 waves = (u64)nrows64 * nt;

@@ -55,7 +55,7 @@ const TuneEntry TUNABLES[] = {
     {"scan_chain", &Tune::scan_chain, 1},
     {"scan_chain_w", &Tune::scan_chain_w, 1},
     {"scan_chain_spin", &Tune::scan_chain_spin, 1 << 22},
-    {"scan_chain_tmaj", &Tune::scan_chain_tmaj, 0},  // minimal traffic (1.01x) but 10-27 % slower: profiles/r03o_*
+    {"scan_chain_tmaj", &Tune::scan_chain_tmaj, 0},  // minimal traffic (1.01x) but 10-27 % slower: profiles/history/r03o_*
     {"reduce_zl", &Tune::reduce_zl, 2},
     {"met_ys1", &Tune::met_ys1, 12},
     {"met_ys2", &Tune::met_ys2, 14},
@@ -138,7 +138,7 @@ extern "C" __attribute__((visibility("hidden"))) int xg_internal_chain_ok(void) 
   auto it = cs.mapping_ok.find(dev);
   if (it != cs.mapping_ok.end()) return it->second;
   // once per device: 1024 one-wave workgroups report the XCD they run on; the chain needs ids that agree modulo 8
-  // to share one (SPX: id % 8 IS the XCD -- profiles/r01h_xcc_probe.log; CPX: a single XCD)
+  // to share one (SPX: id % 8 IS the XCD -- profiles/history/r01h_xcc_probe.log; CPX: a single XCD)
   int ok = 0;
   const int nb = 1024;
   u32* d = nullptr;

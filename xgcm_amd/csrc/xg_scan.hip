@@ -13,9 +13,9 @@ namespace {
 // one generation of waves, each holding the running sums of 24 x-tiles in registers (rows through buffer descriptors,
 // straight-line levels with exact vmcnt waits), so that the whole chip sweeps one level at a time like a copy.  Bit-exact,
 // but no faster than this march in any state of the device: 0.69-0.72 against 0.72-0.76 of 8 TB/s for one record, equal
-// from 4 records per launch on (profiles/r03c_*, r03i_ab_cumZ_records.jsonl) -- the number of DRAM streams and the
+// from 4 records per launch on (profiles/history/r03c_*, r03i_ab_cumZ_records.jsonl) -- the number of DRAM streams and the
 // generation tail are not what holds the march back.  The stand-alone probe tools/levels_probe.hip (14 shapes: 8-32 tiles
-// per wave, groups of 2 / 4, loads 1-5 groups ahead; profiles/r03p_*): slow-kind box 0.675-0.680 whatever the depth against
+// per wave, groups of 2 / 4, loads 1-5 groups ahead; profiles/history/r03p_*): slow-kind box 0.675-0.680 whatever the depth against
 // 0.653 for the march and 0.82 for a copy; fast-kind box 0.738 against 0.766; the same waves loading only 0.83, storing
 // only 0.77 -- i.e. neither prefetch depth nor occupancy is the lever, and the two directions together cost 8 % more than
 // apart.  What the same measurements do show: the rate of THIS kernel on
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
 //     stream's poison word, on which the rescue kernel queued behind every chained launch redoes the call (chain_wait).
 // (Round 3, after K4L's success with weights through LDS: the same for this scan -- the 4 waves of a workgroup = 4
 // consecutive levels of one x-tile and chunk, the chunk's 32 metric rows fetched once per workgroup into LDS instead of once
-// per wave, i.e. 40 instead of 64 loads per task: cumint Y 0.666 -> 0.673, nothing (profiles/r03v_*).  Not kept: the chain's
+// per wave, i.e. 40 instead of 64 loads per task: cumint Y 0.666 -> 0.673, nothing (profiles/history/r03v_*).  Not kept: the chain's
 // pace is set by its hand-offs and stores, not by the metric loads.)
 // ------------------------------------------------------------------------------------------
 struct ChainArgs {
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
   // left, the Grid's default -- aligned vectors of field and metric with the one missing product taken from the
   // neighbouring lane by DPP: cumsum X 0.73 -> 0.62, cumint X 0.66 -> 0.56, the lane-0 fix-up and the extra moves cost more
   // than the misaligned narrow loads the L1 serves; and two vectors per thread and pass: 0.74 -> 0.70.
-  // profiles/r03q_ab_scan_sh1.jsonl, r03q_ab_scan_gv_nosh1.jsonl)
+  // profiles/history/r03q_ab_scan_sh1.jsonl, r03q_ab_scan_gv_nosh1.jsonl)
   auto load_group = [&](int t, real (&x)[NV]) {
     if (t >= groups) {
 #pragma unroll
@@ -1388,7 +1388,7 @@ bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void
     // band holds a few levels of every tile), and the chunks of a column follow each other after W tasks instead of after
     // a whole band: the 16-byte hand-off slots stay in the L2 (band-wide they were written back to HBM and read again:
     // +0.6 GB of writes for `integrate` along Y, PMC traffic 1.215x).  The price: an XCD works on all levels at once.
-    // MEASURED (profiles/r03o_*): traffic as predicted -- cumint Y 1.084x -> 1.008x, integrate Y 1.215x -> 1.018x -- and the
+    // MEASURED (profiles/history/r03o_*): traffic as predicted -- cumint Y 1.084x -> 1.008x, integrate Y 1.215x -> 1.018x -- and the
     // kernels 10 % / 27 % SLOWER (1.77 -> 1.94 ms, 1.13 -> 1.44 ms): the level-major sweep is worth more than the bytes,
     // which the Infinity Cache absorbs.  Off by default; kept as the evidence that the extra traffic is a choice.
     // (Round 4: the band-wide order with the output rows stored `sc1 nt` -- dropped from the L2 as written, so that they
@@ -1592,7 +1592,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     const bool long_march = g.n_in >= 256;
     if (V > 1 && long_march && (u64)ceil_div_u32(g.inner, (int64_t)WAVE * V) * (u64)g.outer < (u64)tune().scan_narrow_below) V = HV;  // 8-byte lanes
     // (float32 with 4-byte lanes -- as many marches as float64 -- measured: sum along Y 0.652 -> 0.593; 8-byte lanes stay;
-    // profiles/r03ao_ab_f32_narrow4.jsonl)
+    // profiles/history/r03ao_ab_f32_narrow4.jsonl)
     const u32 ntile = ceil_div_u32(g.inner, (int64_t)WAVE * V);
     const u64 ntask = (u64)ntile * (u64)g.outer;
     const bool deep = long_march && ntask < (u64)tune().deep_waves;
@@ -1627,7 +1627,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
       u64 nblk = 0;
       // K4L: the weights of a block of rows once per workgroup through LDS, the waves of a workgroup = consecutive levels
       if (shared_w && tune().reduce_ldsw && g.outer >= 2 && g.n_in >= 64 && g.outer < 0x7fffffffll) {
-        // (A/B of the shapes, profiles/r03u_ab_ldsw_shapes*.jsonl: blocks of 8 rows x 4 levels 0.69 / 0.68 for sum / mean;
+        // (A/B of the shapes, profiles/history/r03u_ab_ldsw_shapes*.jsonl: blocks of 8 rows x 4 levels 0.69 / 0.68 for sum / mean;
         // 16 x 4: 0.67 / 0.66; 4 x 4: 0.68 / 0.66; 8 x 2: 0.66 / 0.65; 24 x 4: 0.60; 8 levels per workgroup: 0.53-0.54;
         // the chained K4cz on the same box: 0.58 / 0.51)
         constexpr int LU = 8, LW = 4;
@@ -1636,7 +1636,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
         if (lblk < 0x7ffffff0ull) {
           const u32 lgrid = (u32)(((lblk + 7) / 8) * 8);
           // rows per block: 8 in float64 (16: 0.716 -> 0.697); float32 has half the workgroups for the same bytes and wants the
-          // longer window (0.518 -> 0.541); profiles/r03ap_*
+          // longer window (0.518 -> 0.541); profiles/history/r03ap_*
           const int lu = tune().reduce_ldsw_u ? tune().reduce_ldsw_u : (sizeof(real) == 4 ? 16 : 8);
           if (lu >= 16) hipLaunchKernelGGL((k_reduce_ldsw<16, LW>), dim3(lgrid), dim3(LW * WAVE), 0, st, in, out, g, ltile, (u32)lblk, skipna, w, mw, tune().reduce_ldsw >= 2 ? (u32)groups : 0u);
           else

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided(
 }
 
 // ------------------------------------------------------------------------------------------
-// Linear-order stencil kernels.  Measured on MI355X (profiles/r01_streambench_*.txt): a kernel
+// Linear-order stencil kernels.  Measured on MI355X (profiles/history/r01_streambench_*.txt): a kernel
 // whose threads each move ONE 16-byte vector, with thread id == linear memory order, streams at
 // the copy ceiling (~79 % of 8 TB/s); giving a thread several rows/tiles costs 10-25 %.  So the
 // output is walked as a flat list of V-wide items: item -> (row, position) by one 32-bit
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     // next lane's registers (DPP), and the one lane that has no such lane -- the wave's first / last -- takes its value from a
     // SCALAR load (its row and index are wave-uniform): one vector-memory instruction per wave instead of two.  (With a
     // per-lane load for that lane the instruction count stays at two and the kernel loses 0.4 points:
-    // profiles/r03ab_ab_k1dpp.jsonl.)
+    // profiles/history/r03ab_ab_k1dpp.jsonl.)
     const u32 gfirst = __builtin_amdgcn_readfirstlane(gid - (threadIdx.x & 63));
     const u32 rfirst = fdiv(gfirst, per), rlast = fdiv(gfirst + (WAVE - 1), per);
     if (MET == 0 && (ntl & 2) && rfirst == rlast) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig(
     }
     if (HAS_MO) res = res / ldm<dv>(m_out, mob + (int64_t)i0 * mo.axis, mo.axis);
     // plain operators: the output line is dropped from the L2 as it is written (`sc1 nt`, see stg_drop): +0.6-1.0 points in
-    // three alternating-process rounds, the bench's X operators -1 % (profiles/r03ba_*, r03bb_*); with metrics no clear gain
+    // three alternating-process rounds, the bench's X operators -1 % (profiles/history/r03ba_*, r03bb_*); with metrics no clear gain
     if (NTS && MET == 0) stg_drop<dv>(orow + i0, res);
     else stg<dv, NTS>(orow + i0, res);
   } else {
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
 #pragma unroll
     for (int u = 0; u < R; ++u) n[u] = pad_lo ? from_lane_below(a[u][NV - 1]) : from_lane_above(a[u][0]);
     if (own_nb) {  // (scalar loads for this one lane, as in the flat kernel: no change here, 0.749 / 0.722 either way --
-                   // the block's R loads issue together; profiles/r03ar_ab_k1r_scalar.jsonl)
+                   // the block's R loads issue together; profiles/history/r03ar_ab_k1r_scalar.jsonl)
 #pragma unroll
       for (int u = 0; u < R; ++u) n[u] = in[rows[u] * L + nidx];
     }
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_rw(
       res[NV - 1] = op2<OP>(av[NV - 1], nv);
     }
     // (measured with the divisor load removed: 78.6 %; with a product in place of the IEEE division: no change --
-    // profiles/r02b_ab_bounds.jsonl: the L2-resident metric LOAD is the cost, not the division)
+    // profiles/history/r02b_ab_bounds.jsonl: the L2-resident metric LOAD is the cost, not the division)
     if (HAS_MO) res = res / wo[um];
     stg_s<dv, true>(out + rows[u] * L + i0, res);  // (`sc1 nt`: derivative X +0.3 / +0.8 points on two boxes, two metrics +-0)
   }
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_contig_gen(
 
 // ------------------------------------------------------------------------------------------
 // K2S: stencil along a STRIDED axis, the small-row case (few x-tiles per row, e.g. Y of a
-// (Z,Y,X) field).  Measured on MI355X with random data (profiles/r01_streambench_d_*.txt):
+// (Z,Y,X) field).  Measured on MI355X with random data (profiles/history/r01_streambench_d_*.txt):
 //   * the set of rows in flight must stay compact: each wave register-marches only SEG (= 4)
 //     rows -- SEG+1 independent 16-B loads, then SEG stores -- instead of a long segment;
 //   * the halo row a segment re-reads must come from the SAME XCD's L2: workgroup b runs on XCD
@@ -1098,7 +1098,7 @@ int launch_contig_rw(const StencilCall& c) {
   // (z-STACKED workgroups -- the 4 waves = 4 consecutive level groups of one row and x-tile, the metric vectors loaded by one
   // wave and handed on through LDS, as K4L does for weight rows -- built and measured: L1->L2 requests -22 %, but derivative
   // X 0.744 -> 0.689, metric_weighted X 0.687 -> 0.659, HBM reads 1.01 -> 1.12x: a workgroup then streams 8 level planes at
-  // once; profiles/r03av_*)
+  // once; profiles/history/r03av_*)
   const bool zs = bcast_z && RR > 1 && tune().rw_zshare;
   if (RR == 8 && !zs) RR = 4;
   const u64 ntile = ((u64)g.n_in / NV + WAVE - 1) / WAVE;
@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(BLOCK) void k_stencil_strided_ysm(
 // (K2Sy / K2Sm with 32-bit index arithmetic and without the generic outer-offset peel -- 542 -> 317 scalar instructions per
 // K2Sm wave, 203 -> 164 per K2Sy wave -- measured against the unchanged K2S in alternating processes of one session: K2Sy's
 // lead over K2S stays at +1.7 points, K2Sm's SHRINKS from +1.7 to +0.7; the scalar unit is not what bounds these kernels, the
-// 64-bit forms stay.  profiles/r03ax_ab_lean32_old_new.jsonl)
+// 64-bit forms stay.  profiles/history/r03ax_ab_lean32_old_new.jsonl)
 // K2Sm launch: the geometry tests are launch_seg_n's (z-banding, one outer dim, metrics broadcast along it, 16-B lane vectors)
 // z-banding geometry of a strided-axis launch with metrics: ONE outer dim along which every metric is broadcast (levels), or
 // TWO with the metrics broadcast along the slower one only -- (Z, face | Y | X) fields with per-face metrics (rule 17).
@@ -1393,7 +1393,7 @@ bool launch_ysm(const StencilCall& c) {
   };
   if (tune().met_scalar) mal |= (row_uniform(c.m_in, c.mi) ? 2 : 0) | (row_uniform(c.m_out, c.mo) ? 4 : 0);
   const u32 zb_base = (u32)(tune().zb_rows > 1 ? tune().zb_rows : 16);
-  // one metric: bands of 2 x zb_rows = 32 rows hold here (reads 1.062 -> 1.032x, +0.6 points, profiles/r03bh_pmc_dy_bands.jsonl):
+  // one metric: bands of 2 x zb_rows = 32 rows hold here (reads 1.062 -> 1.032x, +0.6 points, profiles/history/r03bh_pmc_dy_bands.jsonl):
   // the output lines are dropped from the L2 as they are written (rule 16), the band's one metric plane and the halo rows stay
   // two metrics: 16-row bands hold in the y-stacked form, where K2S needs 8 (round 4: reads 6.00 -> 5.72 GB, traffic 1.064 ->
   // 1.038x at the same speed, nine placements paired; profiles/r04h_ab_iymw_*.log)
@@ -1437,7 +1437,7 @@ int launch_seg_n(const StencilCall& c) {
   // z-banding: a single outer dim along which every metric is broadcast, one launch (bands of 16 rows)
   // band height: `zb_rows` rows when two metrics share the XCD's L2, twice that for one -- a band boundary costs one
   // halo-row re-read from HBM per level (PMC: +6 % reads at 16 rows), a band must stay L2-resident for all levels
-  // (round 3, PMC per band height, profiles/r03g_*: one metric 32 rows 1.106x the algorithmic reads, 16 rows 1.064x =
+  // (round 3, PMC per band height, profiles/history/r03g_*: one metric 32 rows 1.106x the algorithmic reads, 16 rows 1.064x =
   // the halo row; two metrics 16 rows 1.14x, 8 rows 1.127x = the halo row; same speed within 0.5 % => 16 / 8 rows)
   const u32 zb_base = (u32)(tune().zb_rows > 1 ? tune().zb_rows : 16);
   const u32 zbr = (c.m_in && c.m_out) ? zb_base / 2 : zb_base;
@@ -1464,11 +1464,11 @@ int launch_seg_n(const StencilCall& c) {
   if (ZK > 1) return launch_seg_n<OP, V, MET, SEG, 1>(c);  // not z-banded: no shared metric rows
   // (K2Sy extended to metrics that are not z-banded and to whole-plane rows in column chunks, measured in one process:
   // 3-D divisor along Y +0.6 points, plain diff along Z 0.768 -> 0.740, derivative Z 0.749 -> 0.657, metric_weighted Z
-  // 0.739 -> 0.612 -- four levels per workgroup make five plane streams per XCD; not kept, profiles/r03ah_ab_ys_ext.jsonl)
+  // 0.739 -> 0.612 -- four levels per workgroup make five plane streams per XCD; not kept, profiles/history/r03ah_ab_ys_ext.jsonl)
   if (MET == 0 && V == NV && SEG == 1 && !ck.on && tune().seg_ys && c.g.n_out >= 2 * WPB) {  // K2Sy: y-stacked workgroups
-    // (8 waves per workgroup -- 1.125 loads per output row -- measured slower: 0.789 against 0.802, profiles/r03aa_*; two
-    // x-tiles per wave, the scalar row logic paid once per 2 KB: 0.780 -> 0.753, profiles/r03au_ab_k2sy_xt.jsonl; non-temporal
-    // loads for the rows nobody reads again: 0.785 / 0.784, profiles/r03az_ab_k2sy_nt.jsonl)
+    // (8 waves per workgroup -- 1.125 loads per output row -- measured slower: 0.789 against 0.802, profiles/history/r03aa_*; two
+    // x-tiles per wave, the scalar row logic paid once per 2 KB: 0.780 -> 0.753, profiles/history/r03au_ab_k2sy_xt.jsonl; non-temporal
+    // loads for the rows nobody reads again: 0.785 / 0.784, profiles/history/r03az_ab_k2sy_nt.jsonl)
     const u64 nw = WPB;
     const u64 ngrp = ((u64)c.g.n_out + nw - 1) / nw, per = ngrp * ntile;  // workgroups per outer index
     if (per <= MAX_ITEMS) {
@@ -1519,7 +1519,7 @@ int launch_seg(const StencilCall& c) {
         case 14: done = launch_ysm<OP, MET, 1, 4>(c); break;
         case 18: done = launch_ysm<OP, MET, 1, 8>(c); break;
         case 22: done = launch_ysm<OP, MET, 2, 2>(c); break;
-        // (2 x 4, 2 x 8, 4 x 2, 4 x 4 measured too: no better than K2S, profiles/r03af_*, r03ag_*)
+        // (2 x 4, 2 x 8, 4 x 2, 4 x 4 measured too: no better than K2S, profiles/history/r03af_*, r03ag_*)
         default: break;
       }
       if (done) return 0;

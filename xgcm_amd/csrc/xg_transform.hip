@@ -7,7 +7,7 @@ namespace {
 
 // (Rows leaving the LDS ring / window as 16-B stores of lane pairs instead of 8-B stores per lane, with and without `sc1 nt`,
 // measured in one process on both lean kernels: -0.4 ... +0.1 points -- the 512-B row stores are not what bounds them.
-// profiles/r03bf_ab_row_store.jsonl)
+// profiles/history/r03bf_ab_row_store.jsonl)
 // ------------------------------------------------------------------------------------------
 // vertical coordinate transform (next-row f4; reference xgcm/transform.py:15-142, numba gufuncs)
 //
@@ -79,7 +79,7 @@ __device__ __forceinline__ double interp_pair(double xv, double xj, double xj1, 
 // STAGE: one wave per workgroup keeps its 64 columns' outputs in an LDS tile [m][64] and writes them as m complete
 // 512-B rows at the end.  The lanes of a wave reach a target level at different source levels, so emitting straight
 // to memory stores a few lanes at a time: 239 M partial write requests for 54 M lines, 9.1 GB written for 3.5 GB
-// (profiles/r02g_transform_linear_bounds.txt).  STAGE & 2: the target levels are the same for every column (a 1-D
+// (profiles/history/r02g_transform_linear_bounds.txt).  STAGE & 2: the target levels are the same for every column (a 1-D
 // `target`): they sit in LDS too, so the divergent emission loop carries no memory instruction at all.
 template <bool LOG, int STAGE, int TWIN = 16>
 __global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear(
@@ -171,7 +171,7 @@ __global__ __launch_bounds__((STAGE & 5) ? WAVE : BLOCK) void k_transform_linear
         const u32 inner32 = (u32)inner;
         real* pfl = pout;  // row `fl` of this lane's column: a running pointer, no multiply per flushed row
         // (occupancy hints, amdgpu_waves_per_eu 6 / 7 against the 5 waves its 84 VGPRs allow: +-0.3 / -2 points,
-        // profiles/r03ad_ab_linear_occupancy.jsonl -- the loop is no longer bound by what it issues)
+        // profiles/history/r03ad_ab_linear_occupancy.jsonl -- the loop is no longer bound by what it issues)
         // (edge masking needs no test inside the column: the cursor's level is >= the column's first point after the
         // prologue and < its current point in the loop; only targets left / right of the column can be masked)
         auto emit = [&](real r) {
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_win(
   };
   int jlo = 0;  // cursor: first bin whose upper edge reaches the current cell
   // UNI: ONE window per wave.  A lane sliding its own window writes the bin it leaves on its own, a few lanes at a
-  // time (partial lines, as in the linear transform: profiles/r02g_transform_linear_bounds.txt).  Here bin wb
+  // time (partial lines, as in the linear transform: profiles/history/r02g_transform_linear_bounds.txt).  Here bin wb
   // leaves when the cursor of EVERY lane has passed it, as one complete row (NaN where a column never touched it);
   // a lane whose cursor falls behind the window (non-monotonic column) or whose cell reaches beyond it accumulates
   // in `out` directly, as before -- wherever an accumulator lives its additions arrive in cell order.
@@ -670,7 +670,7 @@ __global__ __launch_bounds__(CWB) void k_transform_conservative_win(
 }
 
 // K9e: K9d's one-window-per-wave form (UNI) written for instruction count -- the kernel issues VALU instructions 66 % of
-// its time (profiles/r03z_valu_issue_share.txt), so what it executes per cell is what it costs:
+// its time (profiles/history/r03z_valu_issue_share.txt), so what it executes per cell is what it costs:
 //   * the cursor walks forward with its two edges in registers (one LDS read per step); the backward search is a rare
 //     separate branch (non-monotonic columns);
 //   * a bin that has left the window was stored as a complete row (NaN where a column never touched it), so an accumulation

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
       }
       // (rule 16: the flux runs at 0.77 with `sc1 nt` in every round, with `nt` at 0.77 or 0.70 from process to process; the
       // gradient -- one input stream, two metric planes to keep in the L2 -- loses 2 points with `sc1 nt` on either output or on
-      // both (three rounds each, profiles/r03bl_ab_grad_drop.jsonl; r03ba_*; +2 once in r03be_*) and keeps `nt`)
+      // both (three rounds each, profiles/history/r03bl_ab_grad_drop.jsonl; r03ba_*; +2 once in r03be_*) and keeps `nt`)
       if (MODE == 1) {
         stg_s<T, NTS>(out_x + base + j * nx + i0, rx);
         stg_s<T, NTS>(out_y + base + j * nx + i0, ry);
@@ -560,7 +560,7 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
   // band height: the area rows of a band must survive in the XCD's 4 MB L2 while TWO fields and the output of all its
   // levels stream by.  16 rows: PMC reads 1.06x the algorithmic bytes (the halo u row of every band and level is the
   // 6 %); 24 rows 1.17x, 32 rows 1.26x -- the area is then re-read from the fabric once per level group -- at the same
-  // speed within 1 % on an otherwise idle device (profiles/r03g_*, r03h_*)
+  // speed within 1 % on an otherwise idle device (profiles/history/r03g_*, r03h_*)
   const u32 zbr = (u32)(tune().vec_zb_rows > 1 ? tune().vec_zb_rows : 16);
   const u32 ZB_SEGS = (zbr + SEG - 1) / SEG;
   ZBand zb = make_zband(false, 0, 0, 1);
