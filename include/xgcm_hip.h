@@ -62,7 +62,9 @@ typedef enum xg_status {
 } xg_status;
 
 /* raw two-point bodies, xgcm/gridops.py:23-24,76-77,123-126,172-175 */
-typedef enum xg_op { XG_OP_DIFF = 0, XG_OP_INTERP = 1, XG_OP_MIN = 2, XG_OP_MAX = 3 } xg_op;
+/* XG_OP_MINU / XG_OP_MAXU: integer entry points (*_i64, *_i32) only -- min / max of lanes that hold an UNSIGNED array
+ * (uint64 / uint32 compare differently from the two's-complement lanes they are stored in). */
+typedef enum xg_op { XG_OP_DIFF = 0, XG_OP_INTERP = 1, XG_OP_MIN = 2, XG_OP_MAX = 3, XG_OP_MINU = 4, XG_OP_MAXU = 5 } xg_op;
 
 /* boundary modes, xgcm/padding.py:15-19.  XG_BC_NONE is only legal when no halo cell is read. */
 /* XG_BC_HALO (internal to xg_stencil1d_halo_*): halo values were gathered beforehand. */
@@ -396,13 +398,15 @@ int xg_stencil2d_metric_f32(int op, const float* in, float* out, const int64_t* 
 int xg_fill_synthetic_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, double scale,
                           double shift, void* stream);
 
-/* ---- integer variants (int64 lanes, two's complement, wrap-around) ------------------------- */
+/* ---- integer variants (int64 / int32 lanes, two's complement, wrap-around) ------------------ */
 /* numpy keeps integer arrays integral through diff / min / max / cumsum / pad and wraps modulo 2^bits
  * (xgcm/gridops.py:23-24,123-126,172-175,227-278 run in the array's own dtype; xgcm/padding.py:610-615: numpy.pad keeps
  * it and casts the fill value).  Same kernels, same argument order as the _f64 entry points, with these differences:
- *   - arithmetic is modulo 2^64; narrower, unsigned and bool arrays are widened to int64 by xg_convert, computed here,
- *     and narrowed back (wrap modulo 2^bits) -- uint64 shares its bits with int64 for diff / cumsum / pad, and takes
- *     xg_convert's sign-bit flip around min / max;
+ *   - arithmetic is modulo 2^64 (_i64) or 2^32 (_i32); int64 / uint64 arrays run on _i64 and int32 / uint32 arrays on
+ *     _i32 as they are (an unsigned array shares its bits with the signed lanes for diff / cumsum / pad; its min / max
+ *     are XG_OP_MINU / XG_OP_MAXU); narrower and bool arrays are widened to int32 lanes by xg_convert, computed, and
+ *     narrowed back (wrap modulo 2^bits).  Scans and sums exist as _i64 only: numpy accumulates every integer dtype
+ *     in 64 bits;
  *   - XG_OP_INTERP returns the wrapped SUM l + r: `(a[1:] + a[:-1]) / 2.0` leaves the integer domain, the host casts
  *     the sum to the array's dtype width and halves it in float64 (xg_convert with via_type and scale 0.5);
  *   - metric / weight arguments must be NULL and reductions are plain sums (skipna 0 / 1, no NaN exists): a metric is
@@ -432,6 +436,28 @@ int xg_halo_put_i64(const int64_t* halo, int64_t* out, const int64_t* shape, int
                     void* stream);
 int xg_binary_i64(int op, const int64_t* a, const int64_t* a_strides, const int64_t* b,
                   const int64_t* b_strides, int64_t* out, const int64_t* shape, int ndim,
+                  void* stream);
+
+/* the same on int32 lanes (int32 / uint32 arrays as they are, bool / 8 / 16-bit arrays widened to 4 bytes): the entry
+ * points whose result keeps the array's width */
+int xg_stencil1d_i32(int op, const int32_t* in, int32_t* out, const int64_t* shape, int ndim, int axis,
+                     int64_t n_out, int pad_lo, int pad_hi, int bc, int32_t fill, const int32_t* m_in,
+                     const int64_t* m_in_strides, const int32_t* m_out, const int64_t* m_out_strides,
+                     void* stream);
+int xg_stencil1d_halo_i32(int op, const int32_t* in, const int32_t* halo, int32_t* out,
+                          const int64_t* shape, int ndim, int axis, int64_t n_out, int pad_lo,
+                          int pad_hi, const int32_t* m_out, const int64_t* m_out_strides, void* stream);
+int xg_pad_i32(const int32_t* in, int32_t* out, const int64_t* shape, int ndim, const int64_t* lo,
+               const int64_t* hi, const int* bc, const int32_t* fill, const int* order, void* stream);
+int xg_gather_i32(const int32_t* in, const int32_t* partner, int32_t* out, const int64_t* in_shape,
+                  const int64_t* partner_shape, const int64_t* out_shape, int ndim,
+                  const int* mapped, const int* partner_perm, const int64_t* lo,
+                  const int64_t* tokens, int64_t n_tokens, const int32_t* fills, int n_fills,
+                  void* stream);
+int xg_halo_put_i32(const int32_t* halo, int32_t* out, const int64_t* shape, int ndim, int axis, int pad_lo, int pad_hi,
+                    void* stream);
+int xg_binary_i32(int op, const int32_t* a, const int64_t* a_strides, const int32_t* b,
+                  const int64_t* b_strides, int32_t* out, const int64_t* shape, int ndim,
                   void* stream);
 
 /* ---- element type conversion (numpy `astype`) --------------------------------------------- */

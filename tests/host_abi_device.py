@@ -69,30 +69,28 @@ def asdevice(x, dtype=None):
     return a if a.dtype == dtype else convert(a, dtype)
 
 
-def _widen(x, flip=False):
+_LANE_SFX = {"int64": "i64", "int32": "i32"}
+
+
+def _widen(x, lane=np.int64):
     a = np.ascontiguousarray(x)
-    if not flip and a.dtype == np.int64:
-        return a
-    if not flip and a.dtype == np.uint64:
-        return a.view(np.int64)
-    return convert(a, np.int64, flip=flip)
+    lane = np.dtype(lane)
+    if _dt.same_bits(a.dtype, lane):
+        return a.view(lane)
+    return convert(a, lane)
 
 
-def _narrow(t, dst, via=None, scale=1.0, flip=False):
+def _narrow(t, dst, via=None, scale=1.0):
     dst = np.dtype(dst)
-    if via is None and scale == 1.0 and not flip:
-        if dst == np.int64:
-            return t
-        if dst == np.uint64:
-            return t.view(np.uint64)
-    return convert(t, dst, via=via, scale=scale, flip=flip)
+    if via is None and scale == 1.0 and _dt.same_bits(dst, t.dtype):
+        return t.view(dst)
+    return convert(t, dst, via=via, scale=scale)
 
 
-def _lane_int(value, flip=False):
-    v = int(value) & 0xFFFFFFFFFFFFFFFF
-    if flip:
-        v ^= 0x8000000000000000
-    return v - (1 << 64) if v >= (1 << 63) else v
+def _lane_int(value, lane=np.int64):
+    bits = 8 * np.dtype(lane).itemsize
+    v = int(value) & ((1 << bits) - 1)
+    return v - (1 << bits) if v >= (1 << (bits - 1)) else v
 
 
 def _divide(res, m_out, as_dtype):
@@ -133,17 +131,19 @@ def stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill=0.0, m_in=None, m_out=None):
                             None if m_out is None else np.asarray(m_out).dtype)
     if plan.lanes == "int":  # the product's device._int_stencil1d over the host build of the *_i64 entry points
         src = np.asarray(x).dtype
-        t = _widen(x, plan.flip)
+        lane = plan.compute
+        t = _widen(x, lane)
         axis %= t.ndim
         shape = list(t.shape)
         oshape = list(shape)
         oshape[axis] = shape[axis] + pad_lo + pad_hi - 1
-        out = np.empty(oshape, dtype=np.int64)
+        out = np.empty(oshape, dtype=lane)
         if out.size:
-            fv = _lane_int(_dt.fill_as(src, fill), plan.flip) if (bc == "fill" and (pad_lo or pad_hi)) else 0
-            _check(lib().xg_stencil1d_i64(_hip.OP[op], _ptr(t), _ptr(out), _hip.i64(shape), len(shape), axis, oshape[axis],
+            fv = _lane_int(_dt.fill_as(src, fill), lane) if (bc == "fill" and (pad_lo or pad_hi)) else 0
+            code = _hip.OP[op + "u"] if plan.unsigned else _hip.OP[op]
+            _check(getattr(lib(), "xg_stencil1d_" + _LANE_SFX[lane.name])(code, _ptr(t), _ptr(out), _hip.i64(shape), len(shape), axis, oshape[axis],
                                           int(pad_lo), int(pad_hi), _hip.BC[bc], fv, None, None, None, None, None))
-        return _divide(_narrow(out, plan.result, via=plan.via, scale=plan.scale, flip=plan.flip), m_out, plan.divide_as)
+        return _divide(_narrow(out, plan.result, via=plan.via, scale=plan.scale), m_out, plan.divide_as)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis %= x.ndim
@@ -222,8 +222,10 @@ def reduce1d(x, axis, w=None, skipna=True):
 def binary(op, a, b):
     lanes, res_dt = _dt.binary_plan(op, np.asarray(a).dtype, np.asarray(b).dtype)
     if lanes == "int":
-        dt, sfx = np.int64, "i64"
-        a, b = _widen(a), _widen(b)
+        lane = _dt.lane_of(res_dt)
+        dt, sfx = lane, _LANE_SFX[lane.name]
+        a = _widen(a if _dt.same_bits(np.asarray(a).dtype, lane) else convert(a, res_dt), lane)
+        b = _widen(b if _dt.same_bits(np.asarray(b).dtype, lane) else convert(b, res_dt), lane)
     else:
         dt, sfx = (np.float32, "f32") if res_dt == np.float32 else (np.float64, "f64")
         a, b = asdevice(a, dt), asdevice(b, dt)
@@ -239,7 +241,8 @@ def pad_nd(x, widths, bc, fill):
     src = np.asarray(x).dtype
     ints = _dt.is_integer(src)
     if ints:
-        dt, sfx, x = np.int64, "i64", _widen(x)
+        lane = _dt.lane_of(src)
+        dt, sfx, x = lane, _LANE_SFX[lane.name], _widen(x, lane)
     else:
         dt, sfx = _common(x)
         x = asdevice(x, dt)
@@ -251,7 +254,7 @@ def pad_nd(x, widths, bc, fill):
         bcv[ax] = _hip.BC[bc.get(ax)]
         f = fill.get(ax, 0.0)
         f = 0.0 if f is None else f
-        fv[ax] = _lane_int(_dt.fill_as(src, f)) if ints else float(f)
+        fv[ax] = _lane_int(_dt.fill_as(src, f), lane) if ints else float(f)
         order.append(ax)
     order += [d for d in range(nd) if d not in order]
     out = np.empty([s + l + h for s, l, h in zip(x.shape, lo, hi)], dtype=dt)

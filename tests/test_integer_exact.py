@@ -83,7 +83,8 @@ def test_policy_matches_numpy_promotion():
                 continue
             plan = DT.stencil_plan(op, dt)
             assert plan.lanes == "int" and plan.result == R.stencil1d(op, a, 0, 0, 0, None).dtype
-            assert plan.flip == (name == "uint64" and op in ("min", "max"))
+            assert plan.compute == (np.int64 if dt.itemsize == 8 else np.int32)  # 64-bit types on int64 lanes, the rest on int32
+            assert plan.unsigned == (name in ("uint64", "uint32") and op in ("min", "max"))
         for mdt in (np.float32, np.float64):
             m = np.ones(4, dtype=mdt)
             assert DT.stencil_plan("diff", dt, mdt, mdt).compute == (a * m).dtype  # metric first: float lanes
@@ -226,6 +227,31 @@ def test_unsigned_wraps_and_keeps_its_dtype(ibackend):
     for op in ("diff", "min", "max", "interp"):
         _same(getattr(grid, op)(DataArray(big, ("xc",)), "X", padding="fill", fill_value=2**63 + 1).values,
               R.stencil1d(op, big, 0, 1, 0, "fill", 2**63 + 1))
+
+
+def test_32_bit_arrays_run_on_their_own_lanes(ibackend):
+    """int32 / uint32 compute on int32 lanes as they are (no widening): wrap at 32 bits, unsigned order for min / max,
+    numpy.pad's cast of the fill value; mixed-width labelled arithmetic promotes like numpy before it reaches the lanes"""
+    grid = _xgrid(8)
+    u = np.array([2**32 - 1, 2**31 + 5, 3, 2**31 - 1, 0, 2**32 - 2, 7, 2**31], dtype=np.uint32)
+    i = np.array([2**31 - 1, -2**31, 3, -1, 0, 2**31 - 2, -7, 12], dtype=np.int32)
+    for a, fill in ((u, 2**31 + 1), (i, -5)):
+        for op in ("diff", "min", "max", "interp"):
+            for pad in ("fill", "periodic", "extend"):
+                got = getattr(grid, op)(DataArray(a, ("xc",)), "X", padding=pad, fill_value=fill).values
+                _same(got, R.stencil1d(op, a, 0, 1, 0, pad, fill))
+        _same(grid.cumsum(DataArray(a, ("xc",)), "X", padding="fill", fill_value=0).values,
+              R.grid_cumsum(a, 0, "center", "left", "fill", 0, skipna=False))
+    da = DataArray(i.reshape(2, 4), ("y", "x"))
+    for other in (np.int8, np.uint16, np.uint32, np.int64, np.uint8):
+        b = (np.arange(8).reshape(2, 4) * 37 - 100).astype(other)
+        db = DataArray(b, ("y", "x"))
+        for f, g in ((lambda p, q: p + q, np.add), (lambda p, q: p - q, np.subtract), (lambda p, q: p * q, np.multiply)):
+            _same(f(da, db).values, g(i.reshape(2, 4), b))
+            _same(f(db, da).values, g(b, i.reshape(2, 4)))
+    n8, u16 = DataArray(np.array([-128, -1, 0, 127], dtype=np.int8), ("x",)), DataArray(np.array([65535, 1, 0, 40000], dtype=np.uint16), ("x",))
+    _same((n8 * u16).values, n8.values * u16.values)  # int8 next to uint16 -> int32: sign- and zero-extended into the lanes
+    _same((n8 - n8).values, n8.values - n8.values)
 
 
 def test_bool_follows_numpy(ibackend):

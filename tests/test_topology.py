@@ -660,6 +660,42 @@ def test_face_connections_product_equals_oracle_scalar(backend, conn, pw, mode):
     assert got.dims == ds.data_c.dims
 
 
+@pytest.mark.parametrize("conn", [X_TO_X, X_TO_Y_REV, CUBED_SPHERE], ids=["x2x", "x2y_rev", "cubed_sphere"])
+@pytest.mark.parametrize("dtype", ["int16", "int32", "uint32", "int64", "uint8"])
+def test_integer_fields_on_connected_grids_stay_integral(backend, conn, dtype):
+    """the reference moves an integer field's values through concat / pad in the field's own dtype (xgcm/padding.py:
+    260-572, 610-615): halos gathered on integer lanes (xg_gather_i32 / _i64) equal the float64 gather of the same small
+    integers, the dtype survives, the fill value is cast like numpy.pad casts it; diff / max / cumsum follow"""
+    nf = 6 if conn is CUBED_SPHERE else 2
+    ds = _faces_ds(nf, 5, seed=17)
+    ints = np.floor(ds.data_c.values * 40).astype(np.int64)
+    ints = (ints % 200).astype(dtype) if np.dtype(dtype).kind == "u" else ints.astype(dtype)
+    dsi = Dataset({"data_c": (["face", "y", "x"], ints)}, coords={k: ds[k].values for k in ("x", "xl", "y", "yl", "face")})
+    dsf = Dataset({"data_c": (["face", "y", "x"], ints.astype(np.float64))}, coords={k: ds[k].values for k in ("x", "xl", "y", "yl", "face")})
+    gi = Grid(dsi, coords=COORDS, face_connections=conn, autoparse_metadata=False)
+    gf = Grid(dsf, coords=COORDS, face_connections=conn, autoparse_metadata=False)
+    for pw in ({"X": (1, 1)}, {"X": (2, 1), "Y": (1, 2)}):
+        got = pad(dsi.data_c, gi, padding_width=dict(pw), padding="fill", fill_value={"X": 3.7, "Y": 2.2})
+        want = pad(dsf.data_c, gf, padding_width=dict(pw), padding="fill", fill_value={"X": 3.0, "Y": 2.0})  # numpy.pad truncates
+        assert got.values.dtype == np.dtype(dtype)
+        np.testing.assert_array_equal(got.values.astype(np.float64), want.values)
+    for ax in ("X", "Y"):
+        for op in ("diff", "max"):
+            got = getattr(gi, op)(dsi.data_c, ax, padding="extend").values
+            want = getattr(gf, op)(dsf.data_c, ax, padding="extend").values
+            assert got.dtype == np.dtype(dtype)
+            np.testing.assert_array_equal(got, want.astype(np.int64).astype(dtype))  # the wrap of the narrow dtype
+        got = gi.interp(dsi.data_c, ax, padding="extend").values
+        assert got.dtype == np.float64
+        if np.dtype(dtype).itemsize >= 2:  # no wrap of the sum at these magnitudes
+            np.testing.assert_array_equal(got, gf.interp(dsf.data_c, ax, padding="extend").values)
+    if conn is not X_TO_Y_REV:
+        got = gi.cumsum(dsi.data_c, "X", to="left", padding="fill", fill_value=0).values
+        want = gf.cumsum(dsf.data_c, "X", to="left", padding="fill", fill_value=0).values
+        assert got.dtype == (np.uint64 if np.dtype(dtype).kind == "u" else np.int64)
+        np.testing.assert_array_equal(got.astype(np.float64), want)
+
+
 @pytest.mark.parametrize("conn", [X_TO_X, X_TO_Y, X_TO_Y_REV, X_TO_X_REV, CUBED_SPHERE],
                          ids=["x2x", "x2y", "x2y_rev", "x2x_rev", "cubed_sphere"])
 @pytest.mark.parametrize("pw", [{"X": (1, 1)}, {"X": (0, 1), "Y": (1, 0)}, {"X": (2, 2), "Y": (2, 2)}])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Rates of the integer paths (int64 lanes between xg_convert calls) next to their float64 twins, through the device layer
+"""Rates of the integer paths (int64 / int32 lanes, xg_convert around the narrower dtypes) next to their float64 twins, through the device layer
 at full size: what exactness costs.  One JSON line per (dtype, operator)."""
 import json
 import os
@@ -36,6 +36,7 @@ def main():
     base["int64"] = f.view(torch.int64)
     base["uint64"] = f.view(torch.uint64)
     base["int32"] = D.convert(base["int64"], np.int32)
+    base["uint32"] = base["int32"].view(torch.uint32)
     base["int16"] = D.convert(base["int64"], np.int16)
     base["uint8"] = D.convert(base["int64"], np.uint8)
     ops = [("diff X", lambda t: D.stencil1d("diff", t, 2, 1, 0, "periodic")),

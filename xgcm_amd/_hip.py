@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XG_HIP_LIB") or os.path.join(_HERE, "libxgcm_hip.so")
 
 # enums of include/xgcm_hip.h
-OP = {"diff": 0, "interp": 1, "min": 2, "max": 3}
+OP = {"diff": 0, "interp": 1, "min": 2, "max": 3, "minu": 4, "maxu": 5}  # minu / maxu: integer entry points, unsigned arrays
 BC = {None: 0, "periodic": 1, "fill": 2, "extend": 3, "halo": 4}
 BINOP = {"mul": 0, "div": 1, "add": 2, "sub": 3}
 MAX_NDIM = 8
@@ -141,13 +141,18 @@ _i64p_fill = C.POINTER(C.c_int64)
 for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_cumsum1d", "xg_reduce1d", "xg_pad", "xg_gather", "xg_halo_put", "xg_binary"]:
     _res, _args = SIGNATURES[_name + "_f64"]
     SIGNATURES[_name + "_i64"] = (_res, [C.c_int64 if a is C.c_double else (_i64p_fill if a is _f64p else a) for a in _args])
+# int32 twins: the entry points whose integer result keeps the array's width (scans / sums accumulate in 64 bits)
+_i32p_fill = C.POINTER(C.c_int32)
+for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_pad", "xg_gather", "xg_halo_put", "xg_binary"]:
+    _res, _args = SIGNATURES[_name + "_f64"]
+    SIGNATURES[_name + "_i32"] = (_res, [C.c_int32 if a is C.c_double else (_i32p_fill if a is _f64p else a) for a in _args])
 
 # element types of xg_convert (enum xg_dtype), keyed by numpy dtype name
 DTYPE = {"bool": 0, "int8": 1, "int16": 2, "int32": 3, "int64": 4, "uint8": 5, "uint16": 6, "uint32": 7, "uint64": 8,
          "float32": 9, "float64": 10}
 SIGNATURES["xg_convert"] = (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int, _vp])
 
-SUFFIX = {"float64": "f64", "float32": "f32", "int64": "i64"}
+SUFFIX = {"float64": "f64", "float32": "f32", "int64": "i64", "int32": "i32"}
 
 _lib: Optional[C.CDLL] = None
 
@@ -255,5 +260,7 @@ def reals(values: Optional[Sequence[float]], suffix: str):
         return None
     if suffix == "i64":
         return (C.c_int64 * len(values))(*[int(v) for v in values])
+    if suffix == "i32":
+        return (C.c_int32 * len(values))(*[int(v) for v in values])
     ctype = C.c_double if suffix == "f64" else C.c_float
     return (ctype * len(values))(*[float(v) for v in values])

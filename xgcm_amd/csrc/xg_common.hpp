@@ -34,20 +34,34 @@
 
 #include "../../include/xgcm_hip.h"
 
-// The file is compiled up to three times into the same shared library: once with real = double (exports *_f64
+// The file is compiled up to four times into the same shared library: once with real = double (exports *_f64
 // plus the type-independent helpers), once with -DXG_F32 (real = float, exports *_f32 only) and -- the units that
 // serve integer arrays: stencil, scan, pad, the elementwise binary op -- once with -DXG_I64 -fwrapv (real = int64_t,
 // exports *_i64): numpy keeps integer arrays integral through diff / min / max / cumsum / pad (xgcm/gridops.py:23-24,
 // 123-126,172-175,227-278; xgcm/padding.py:610-615) and wraps modulo 2^bits, so the same kernels run on two's-complement
 // int64 lanes (narrower and unsigned types are widened / narrowed by xg_convert).  Differences of that build: no
 // metrics (a metric is a float: numpy promotes before the operator, the host converts first), XG_OP_INTERP returns the
-// wrapped SUM l + r (the host halves it after the cast to float64, `(a + b) / 2.0`), NaN handling is a no-op.
+// wrapped SUM l + r (the host halves it after the cast to float64, `(a + b) / 2.0`), NaN handling is a no-op,
+// XG_OP_MINU / XG_OP_MAXU compare the lanes as unsigned (uint64 / uint32 arrays).  The units whose integer results keep
+// the array's width (stencil, pad, binary -- not the scans / sums, which numpy accumulates in 64 bits) are compiled a
+// fourth time with -DXG_I32 -fwrapv (real = int32_t, exports *_i32): int32 / uint32 arrays run on their own 4-byte lanes
+// at the float32 byte rate, and the narrower types widen to 4 instead of 8 bytes.
+// XG_INT: an integer build (either width); XG_REAL4: a build with 4-byte elements (float or int32).
 #if defined(XG_I64)
 typedef int64_t real;
+typedef uint64_t ureal;
 #define XG_FN(name) name##_i64
+#define XG_INT 1
+#elif defined(XG_I32)
+typedef int32_t real;
+typedef uint32_t ureal;
+#define XG_FN(name) name##_i32
+#define XG_INT 1
+#define XG_REAL4 1
 #elif defined(XG_F32)
 typedef float real;
 #define XG_FN(name) name##_f32
+#define XG_REAL4 1
 #else
 typedef double real;
 #define XG_FN(name) name##_f64
@@ -369,7 +383,7 @@ template <> struct VecT<NV> { typedef dv type; };
 // element per lane moves 256 B per wave and row, too narrow for the memory system (sum along Y f32: 55 % against
 // 80 % for f64); HV elements keep the bytes per wave-row the same in both builds
 constexpr int HV = 8 / (int)sizeof(real);
-#ifdef XG_F32
+#ifdef XG_REAL4
 typedef real hv __attribute__((ext_vector_type(2)));
 template <> struct VecT<2> { typedef hv type; };
 #endif
@@ -407,7 +421,7 @@ __device__ __forceinline__ void stg_drop(real* p, T v) {
 
 // what a chained scan passes on after giving up on a hand-off (the launch is redone by the rescue kernel either way)
 __device__ __forceinline__ real poison_value() {
-#ifdef XG_I64
+#ifdef XG_INT
   return real(0x7ff8dead7ff8deadll);
 #else
   return real(__builtin_nan(""));
@@ -424,7 +438,7 @@ __device__ __forceinline__ dv dvdx_of(dv vc, real vl) {
 }
 __device__ __forceinline__ real dvdx_of(real vc, real vl) { return vc - vl; }
 // two-point interpolation of a lane vector towards its LEFT neighbour `tl`: (t[k-1] + t[k]) / 2
-#ifndef XG_I64
+#ifndef XG_INT
 __device__ __forceinline__ dv interp_left_of(dv tc, real tl) {
   dv o;
   o[0] = (tl + tc[0]) * real(0.5);
@@ -448,9 +462,11 @@ __device__ __forceinline__ real dudx_fwd(real uc, real ur) { return ur - uc; }
 template <int OP>
 __device__ __forceinline__ real op2(real l, real r) {
   if (OP == XG_OP_DIFF) return r - l;
-#ifdef XG_I64
+#ifdef XG_INT
   if (OP == XG_OP_INTERP) return l + r;  // the wrapped sum; halved by the host after the conversion to float64
   if (OP == XG_OP_MIN) return l < r ? l : r;
+  if (OP == XG_OP_MINU) return (ureal)l < (ureal)r ? l : r;  // the lanes of an unsigned array
+  if (OP == XG_OP_MAXU) return (ureal)l > (ureal)r ? l : r;
   return l > r ? l : r;
 #else
   if (OP == XG_OP_INTERP) return (l + r) * real(0.5);  // == (l + r) / 2.0 bit for bit
@@ -472,7 +488,7 @@ __device__ __forceinline__ dv splat1(real f, dv*) {
   for (int k = 0; k < NV; ++k) o[k] = f;
   return o;
 }
-#ifdef XG_F32
+#ifdef XG_REAL4
 __device__ __forceinline__ hv splat1(real f, hv*) { hv o; o[0] = f; o[1] = f; return o; }
 #endif
 template <typename T> __device__ __forceinline__ T splat(real f) { return splat1(f, (T*)nullptr); }
@@ -551,7 +567,7 @@ __device__ __forceinline__ int64_t inner_offx(const Geo& g, const MIdx& m, int64
 // metric value(s) for a V-wide lane at metric offset `off` (second element `step` further on)
 template <typename T> __device__ __forceinline__ T ldm(const real* m, int64_t off, int64_t step);
 template <> __device__ __forceinline__ real ldm<real>(const real* m, int64_t off, int64_t) { return m[off]; }
-#ifdef XG_F32
+#ifdef XG_REAL4
 template <> __device__ __forceinline__ hv ldm<hv>(const real* m, int64_t off, int64_t step) {
   hv o;
   o[0] = m[off];
@@ -576,8 +592,8 @@ template <> __device__ __forceinline__ dv ldm<dv>(const real* m, int64_t off, in
 // caller loads that one value itself.  Source lanes must be active.
 template <int CTRL>
 __device__ __forceinline__ real dpp_lane(real v) {
-#ifdef XG_F32
-  return __uint_as_float((u32)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+#ifdef XG_REAL4
+  return __builtin_bit_cast(real, (u32)__builtin_amdgcn_update_dpp(0, (int)__builtin_bit_cast(u32, v), CTRL, 0xf, 0xf, false));
 #else
   const u64 b = __builtin_bit_cast(u64, v);
   const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, CTRL, 0xf, 0xf, false);

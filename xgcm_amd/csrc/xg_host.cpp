@@ -80,6 +80,12 @@ R op2(int op, R l, R r) {
       if constexpr (std::is_integral_v<R>) return l + r;  // _i64: the wrapped sum, halved by the caller in float64
       else return (l + r) / R(2);
     case XG_OP_MIN: return (l != l || r != r) ? (l != l ? l : r) : (l < r ? l : r);  // NaN-propagating like np.min
+    case XG_OP_MINU:  // integer entry points: the lanes hold an unsigned array
+      if constexpr (std::is_integral_v<R>) return std::make_unsigned_t<R>(l) < std::make_unsigned_t<R>(r) ? l : r;
+      else return l;
+    case XG_OP_MAXU:
+      if constexpr (std::is_integral_v<R>) return std::make_unsigned_t<R>(l) > std::make_unsigned_t<R>(r) ? l : r;
+      else return l;
     default: return (l != l || r != r) ? (l != l ? l : r) : (l > r ? l : r);
   }
 }
@@ -90,7 +96,7 @@ int stencil1d(int op, const R* in, const R* halo, R* out, const int64_t* shape, 
               int pad_lo, int pad_hi, int bc, R fill, const R* m_in, const int64_t* mis, const R* m_out,
               const int64_t* mos) {
   if (!in || !out) return fail(XG_ERR_INVALID, "NULL array argument");
-  if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
+  if (op < XG_OP_DIFF || op > (std::is_integral_v<R> ? XG_OP_MAXU : XG_OP_MAX)) return fail(XG_ERR_INVALID, "unknown op %d", op);
   if ((pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "pad widths must be 0 or 1, got (%d,%d)", pad_lo, pad_hi);
   if (bc < XG_BC_NONE || bc > XG_BC_HALO) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
   if ((m_in && !mis) || (m_out && !mos)) return fail(XG_ERR_INVALID, "metric without strides");
@@ -381,7 +387,8 @@ int xg_event_elapsed_ms(void* start, void* stop, float* ms) {
 }
 int xg_event_destroy(void* ev) { free(ev); return XG_OK; }
 
-#define XG_HOST_TYPED(SFX, R)                                                                                         \
+// the entry points whose results keep the lanes' width (every build: f64, f32, i64, i32)
+#define XG_HOST_LANES(SFX, R)                                                                                         \
   int xg_stencil1d_##SFX(int op, const R* in, R* out, const int64_t* shape, int ndim, int axis, int64_t n_out,        \
                          int pad_lo, int pad_hi, int bc, R fill, const R* m_in, const int64_t* mis, const R* m_out,   \
                          const int64_t* mos, void*) {                                                                 \
@@ -394,16 +401,6 @@ int xg_event_destroy(void* ev) { free(ev); return XG_OK; }
     if (!halo && (pad_lo || pad_hi)) return fail(XG_ERR_INVALID, "NULL halo buffer");                                 \
     return stencil1d<R>(op, in, halo, out, shape, ndim, axis, n_out, pad_lo, pad_hi,                                  \
                         (pad_lo || pad_hi) ? XG_BC_HALO : XG_BC_NONE, R(0), nullptr, nullptr, m_out, mos);            \
-  }                                                                                                                   \
-  int xg_cumsum1d_##SFX(const R* in, R* out, const int64_t* shape, int ndim, int axis, int reverse, int skipna,       \
-                        int trim_lo, int trim_hi, int pad_lo, int pad_hi, int bc, R fill, const R* m_in,              \
-                        const int64_t* mis, const R* m_out, const int64_t* mos, void*) {                              \
-    return cumsum1d<R>(in, out, shape, ndim, axis, reverse, skipna, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill,       \
-                       m_in, mis, m_out, mos);                                                                        \
-  }                                                                                                                   \
-  int xg_reduce1d_##SFX(const R* in, R* out, const int64_t* shape, int ndim, int axis, int skipna, const R* w,        \
-                        const int64_t* ws, void*) {                                                                   \
-    return reduce1d<R>(in, out, shape, ndim, axis, skipna, w, ws);                                                    \
   }                                                                                                                   \
   int xg_pad_##SFX(const R* in, R* out, const int64_t* shape, int ndim, const int64_t* lo, const int64_t* hi,         \
                    const int* bc, const R* fill, const int* order, void*) {                                           \
@@ -429,6 +426,19 @@ int xg_event_destroy(void* ev) { free(ev); return XG_OK; }
   int xg_gather_##SFX(const R*, const R*, R*, const int64_t*, const int64_t*, const int64_t*, int, const int*,        \
                       const int*, const int64_t*, const int64_t*, int64_t, const R*, int, void*) {                    \
     return unsupported("xg_gather");                                                                                  \
+  }
+
+// scans and sums (numpy accumulates integers in 64 bits: no i32 build)
+#define XG_HOST_SUMS(SFX, R)                                                                                          \
+  int xg_cumsum1d_##SFX(const R* in, R* out, const int64_t* shape, int ndim, int axis, int reverse, int skipna,       \
+                        int trim_lo, int trim_hi, int pad_lo, int pad_hi, int bc, R fill, const R* m_in,              \
+                        const int64_t* mis, const R* m_out, const int64_t* mos, void*) {                              \
+    return cumsum1d<R>(in, out, shape, ndim, axis, reverse, skipna, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill,       \
+                       m_in, mis, m_out, mos);                                                                        \
+  }                                                                                                                   \
+  int xg_reduce1d_##SFX(const R* in, R* out, const int64_t* shape, int ndim, int axis, int skipna, const R* w,        \
+                        const int64_t* ws, void*) {                                                                   \
+    return reduce1d<R>(in, out, shape, ndim, axis, skipna, w, ws);                                                    \
   }
 
 // the float-only entry points (synthetic generator; fused / transform stubs)
@@ -490,9 +500,13 @@ int xg_event_destroy(void* ev) { free(ev); return XG_OK; }
     return unsupported("xg_stencil2d_metric");                                                                        \
   }
 
-XG_HOST_TYPED(f64, double)
-XG_HOST_TYPED(f32, float)
-XG_HOST_TYPED(i64, int64_t)  // built with -fwrapv: overflow wraps like numpy's integer arithmetic
+XG_HOST_LANES(f64, double)
+XG_HOST_LANES(f32, float)
+XG_HOST_LANES(i64, int64_t)  // built with -fwrapv: overflow wraps like numpy's integer arithmetic
+XG_HOST_LANES(i32, int32_t)
+XG_HOST_SUMS(f64, double)
+XG_HOST_SUMS(f32, float)
+XG_HOST_SUMS(i64, int64_t)
 XG_HOST_FLOAT(f64, double)
 XG_HOST_FLOAT(f32, float)
 

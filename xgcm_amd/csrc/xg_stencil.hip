@@ -1567,7 +1567,7 @@ int launch_strided_gen(const StencilCall& c) {
 }
 template <int OP>
 int strided_gen_met(int met, const StencilCall& c) {
-#ifdef XG_I64  // integer build: no metrics (stencil1d_impl refuses them)
+#ifdef XG_INT  // integer build: no metrics (stencil1d_impl refuses them)
   return launch_strided_gen<OP, 0>(c);
 #endif
   switch (met) {
@@ -1582,6 +1582,10 @@ int strided_gen_dispatch(int op, int met, const StencilCall& c) {
     case XG_OP_DIFF: return strided_gen_met<XG_OP_DIFF>(met, c);
     case XG_OP_INTERP: return strided_gen_met<XG_OP_INTERP>(met, c);
     case XG_OP_MIN: return strided_gen_met<XG_OP_MIN>(met, c);
+#ifdef XG_INT
+    case XG_OP_MINU: return strided_gen_met<XG_OP_MINU>(met, c);
+    case XG_OP_MAXU: return strided_gen_met<XG_OP_MAXU>(met, c);
+#endif
     default: return strided_gen_met<XG_OP_MAX>(met, c);
   }
 }
@@ -1596,7 +1600,7 @@ int stencil_kind(int kind, const StencilCall& c) {
 }
 template <int OP, int V>
 int stencil_met(int met, int kind, const StencilCall& c) {
-#ifdef XG_I64
+#ifdef XG_INT
   return stencil_kind<OP, V, 0>(kind, c);
 #endif
   switch (met) {
@@ -1615,6 +1619,10 @@ int stencil_dispatch(int op, int V, int met, int kind, const StencilCall& c) {
     case XG_OP_DIFF: return stencil_vec<XG_OP_DIFF>(V, met, kind, c);
     case XG_OP_INTERP: return stencil_vec<XG_OP_INTERP>(V, met, kind, c);
     case XG_OP_MIN: return stencil_vec<XG_OP_MIN>(V, met, kind, c);
+#ifdef XG_INT
+    case XG_OP_MINU: return stencil_vec<XG_OP_MINU>(V, met, kind, c);
+    case XG_OP_MAXU: return stencil_vec<XG_OP_MAXU>(V, met, kind, c);
+#endif
     default: return stencil_vec<XG_OP_MAX>(V, met, kind, c);
   }
 }
@@ -1625,7 +1633,7 @@ int stencil_dispatch(int op, int V, int met, int kind, const StencilCall& c) {
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
-#ifndef XG_I64  // two axes in one pass: float builds only (integer interp leaves the integer domain between the axes)
+#ifndef XG_INT  // two axes in one pass: float builds only (integer interp leaves the integer domain between the axes)
 static int stencil2d_impl(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,
                           int padx_lo, int padx_hi, int bc_x, real fill_x, int pady_lo, int pady_hi, int bc_y,
                           real fill_y, const real* m1, const real* m2, const real* m3, void* stream) {
@@ -1699,7 +1707,7 @@ static int stencil2d_impl(int op, const real* in, real* out, const int64_t* shap
   XG_LAUNCH_CHECK();
   return XG_OK;
 }
-#endif  // !XG_I64
+#endif  // !XG_INT
 
 
 extern "C" {
@@ -1709,12 +1717,16 @@ static int stencil1d_impl(int op, const real* in, const real* halo, real* out, c
                           const int64_t* m_in_strides, const real* m_out, const int64_t* m_out_strides,
                           void* stream) {
   if (!in || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+#ifdef XG_INT
+  if (op < XG_OP_DIFF || op > XG_OP_MAXU) return fail(XG_ERR_INVALID, "unknown op %d", op);
+#else
   if (op < XG_OP_DIFF || op > XG_OP_MAX) return fail(XG_ERR_INVALID, "unknown op %d", op);
+#endif
   if ((pad_lo | pad_hi) & ~1) return fail(XG_ERR_INVALID, "pad widths must be 0 or 1, got (%d,%d)", pad_lo, pad_hi);
   if (bc < XG_BC_NONE || bc > XG_BC_HALO) return fail(XG_ERR_INVALID, "unknown boundary mode %d", bc);
   if (bc == XG_BC_HALO && !halo) return fail(XG_ERR_INVALID, "XG_BC_HALO without a halo buffer");
   if ((m_in && !m_in_strides) || (m_out && !m_out_strides)) return fail(XG_ERR_INVALID, "metric without strides");
-#ifdef XG_I64
+#ifdef XG_INT
   if (m_in || m_out) return fail(XG_ERR_UNSUPPORTED, "integer stencils take no metrics: convert to float64 first (numpy promotes int * float)");
 #endif
   Geo g; MIdx mi, mo;
@@ -1773,7 +1785,7 @@ int XG_FN(xg_stencil1d_halo)(int op, const real* in, const real* halo, real* out
                         stream);
 }
 
-#ifndef XG_I64
+#ifndef XG_INT
 int XG_FN(xg_stencil1d_halo_w)(int op, const real* in, const real* halo, real* out, const int64_t* shape, int ndim,
                             int axis, int64_t n_out, int pad_lo, int pad_hi, const real* m_in,
                             const int64_t* m_in_strides, const real* m_out, const int64_t* m_out_strides,
@@ -1785,7 +1797,7 @@ int XG_FN(xg_stencil1d_halo_w)(int op, const real* in, const real* halo, real* o
 }
 #endif
 
-#ifndef XG_I64
+#ifndef XG_INT
 int XG_FN(xg_stencil2d)(int op, const real* in, real* out, const int64_t* shape, int ndim, int order,
                      int padx_lo, int padx_hi, int bc_x, real fill_x, int pady_lo, int pady_hi, int bc_y,
                      real fill_y, void* stream) {
@@ -1800,6 +1812,6 @@ int XG_FN(xg_stencil2d_metric)(int op, const real* in, real* out, const int64_t*
   return stencil2d_impl(op, in, out, shape, ndim, order, padx_lo, padx_hi, bc_x, fill_x, pady_lo, pady_hi, bc_y, fill_y,
                         m_in, m_mid, m_out, stream);
 }
-#endif  // !XG_I64
+#endif  // !XG_INT
 
 }  // extern "C"

@@ -26,7 +26,7 @@ struct BinGeo {
 
 template <int BOP> __device__ __forceinline__ real bin2(real a, real b) {
   if (BOP == XG_BIN_MUL) return a * b;
-#ifndef XG_I64
+#ifndef XG_INT
   if (BOP == XG_BIN_DIV) return a / b;
 #endif
   if (BOP == XG_BIN_ADD) return a + b;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, co
   }
 }
 
-#ifndef XG_I64  // the fused two-component operators divide by / multiply with float metrics: float builds only
+#ifndef XG_INT  // the fused two-component operators divide by / multiply with float metrics: float builds only
 // ------------------------------------------------------------------------------------------
 // K7: fused relative vorticity ((v[j,i]-v[j,i-1]) - (u[j,i]-u[j-1,i])) / area, view (outer,Y,X).
 // Same shape as K2S: lanes along X (V=2 when nx even), XCD-banded waves, each wave register-marches
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
   }
 }
 
-#endif  // !XG_I64
+#endif  // !XG_INT
 
 }  // namespace
 
@@ -432,7 +432,7 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
                   real* out, const int64_t* shape, int ndim, void* stream) {
   if (!a || !b || !out || (ndim > 0 && (!shape || !a_strides || !b_strides))) return fail(XG_ERR_INVALID, "NULL argument");
   if (op < XG_BIN_MUL || op > XG_BIN_SUB) return fail(XG_ERR_INVALID, "unknown binary op %d", op);
-#ifdef XG_I64
+#ifdef XG_INT
   if (op == XG_BIN_DIV) return fail(XG_ERR_UNSUPPORTED, "true division leaves the integer domain: convert to float64 first");
 #endif
   if (ndim < 0 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [0,%d]", ndim, XG_MAX_NDIM);
@@ -505,7 +505,7 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
   return XG_OK;
 }
 
-#ifndef XG_I64
+#ifndef XG_INT
 static int curl_div_impl(bool div, const real* u, const real* v, const real* area, const int64_t* area_strides,
                          real* out, const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y,
                          void* stream, const real* halo_x = nullptr, const real* halo_y = nullptr) {
@@ -745,6 +745,6 @@ int XG_FN(xg_flux_halo)(const real* u, const real* v, const real* t, const real*
                      stream, halo_x, halo_y);
 }
 
-#endif  // !XG_I64
+#endif  // !XG_INT
 
 }  // extern "C"

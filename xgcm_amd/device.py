@@ -135,35 +135,33 @@ def _common(*arrays):
     return (torch.float32, "f32") if f == _dt.FLOAT32 else (torch.float64, "f64")
 
 
-# ---- integer arrays: int64 lanes between a widening and a narrowing conversion ----------------------------------------
-def _widen(x, flip: bool = False) -> torch.Tensor:
-    """integer / bool array -> int64 tensor in HBM (int64 passes, uint64 is the same bits)"""
+# ---- integer arrays: int64 / int32 lanes between a widening and a narrowing conversion (xgcm_amd.dtypes.lane_of) -------
+_LANE_SFX = {"int64": "i64", "int32": "i32"}
+
+
+def _widen(x, lane=_dt.INT64) -> torch.Tensor:
+    """integer / bool array -> tensor of `lane` (int64 / int32) in HBM; an array that IS its lanes (int64 / uint64 on
+    int64, int32 / uint32 on int32) passes as the same bits"""
     t = _raw_device(x)
-    if not flip:
-        if t.dtype == torch.int64:
-            return t
-        if t.dtype == torch.uint64:
-            return t.view(torch.int64)
-    return convert(t, _dt.INT64, flip=flip)
+    lane = np.dtype(lane)
+    if _dt.same_bits(_dt.np_dtype(t), lane):
+        return t if _dt.np_dtype(t) == lane else t.view(_dt.torch_dtype(lane))
+    return convert(t, lane)
 
 
-def _narrow(t: torch.Tensor, dst, via=None, scale: float = 1.0, flip: bool = False) -> torch.Tensor:
-    """int64 lanes -> the dtype numpy returns (wrap modulo 2^bits; float64 for interp)"""
+def _narrow(t: torch.Tensor, dst, via=None, scale: float = 1.0) -> torch.Tensor:
+    """integer lanes -> the dtype numpy returns (wrap modulo 2^bits; float64 for interp)"""
     dst = np.dtype(dst)
-    if via is None and scale == 1.0 and not flip:
-        if dst == _dt.INT64:
-            return t
-        if dst == _dt.UINT64:
-            return t.view(torch.uint64)
-    return convert(t, dst, via=via, scale=scale, flip=flip)
+    if via is None and scale == 1.0 and _dt.same_bits(dst, _dt.np_dtype(t)):
+        return t if _dt.np_dtype(t) == dst else t.view(_dt.torch_dtype(dst))
+    return convert(t, dst, via=via, scale=scale)
 
 
-def _lane_int(value, flip: bool = False) -> int:
-    """a numpy integer / bool scalar as the int64 bit pattern the lanes hold (uint64 above 2^63 wraps)"""
-    v = int(value) & 0xFFFFFFFFFFFFFFFF
-    if flip:
-        v ^= 0x8000000000000000
-    return v - (1 << 64) if v >= (1 << 63) else v
+def _lane_int(value, lane=_dt.INT64) -> int:
+    """a numpy integer / bool scalar as the two's-complement value the lanes hold (uint64 above 2^63 wraps)"""
+    bits = 8 * np.dtype(lane).itemsize
+    v = int(value) & ((1 << bits) - 1)
+    return v - (1 << bits) if v >= (1 << (bits - 1)) else v
 
 
 def _divide(res: torch.Tensor, m_out, as_dtype) -> torch.Tensor:
@@ -247,32 +245,34 @@ def _streamed(per_block, x: np.ndarray) -> np.ndarray:
 
 
 def _int_stencil1d(plan, op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str], fill, m_out):
-    """diff / interp / min / max of an integer or bool array on int64 lanes (xg_stencil1d_i64 / xg_stencil1d_halo_i64),
-    returned in the dtype numpy returns: the array's own for diff / min / max (wrap-around included), float64 for
+    """diff / interp / min / max of an integer or bool array on integer lanes (xg_stencil1d_i64 / _i32 and their _halo
+    twins), returned in the dtype numpy returns: the array's own for diff / min / max (wrap-around included), float64 for
     interp -- the sum wraps in the array's dtype first, `(a[:-1] + a[1:]) / 2.0` -- and `result / m_out` promoted like
     numpy when an output metric divides (xgcm_amd.dtypes.stencil_plan)."""
     lib = _hip.load()
     src = _dt.np_dtype(x)
-    t = _widen(x, plan.flip)
+    lane, sfx = plan.compute, _LANE_SFX[plan.compute.name]
+    t = _widen(x, lane)
     axis = axis % t.dim()
     shape = list(t.shape)
     n_out = shape[axis] + pad_lo + pad_hi - 1
     oshape = list(shape)
     oshape[axis] = n_out
-    out = torch.empty(oshape, dtype=torch.int64, device=t.device)
+    out = torch.empty(oshape, dtype=_dt.torch_dtype(lane), device=t.device)
+    code = _hip.OP[op + "u"] if plan.unsigned else _hip.OP[op]
     if out.numel():
         if halo is not None:
-            h = _widen(halo if _dt.np_dtype(halo) == src else convert(halo, src), plan.flip)
-            _hip.check(lib.xg_stencil1d_halo_i64(
-                _hip.OP[op], t.data_ptr(), h.data_ptr() if h.numel() else None, out.data_ptr(), _hip.i64(shape), len(shape),
+            h = _widen(halo if _dt.np_dtype(halo) == src else convert(halo, src), lane)
+            _hip.check(getattr(lib, "xg_stencil1d_halo_" + sfx)(
+                code, t.data_ptr(), h.data_ptr() if h.numel() else None, out.data_ptr(), _hip.i64(shape), len(shape),
                 axis, n_out, int(pad_lo), int(pad_hi), None, None, _stream()))
         else:
             # numpy.pad casts the constant to the array's dtype (xgcm/padding.py:610-615)
-            fv = _lane_int(_dt.fill_as(src, fill), plan.flip) if (bc == "fill" and (pad_lo or pad_hi)) else 0
-            _hip.check(lib.xg_stencil1d_i64(
-                _hip.OP[op], t.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, n_out, int(pad_lo),
+            fv = _lane_int(_dt.fill_as(src, fill), lane) if (bc == "fill" and (pad_lo or pad_hi)) else 0
+            _hip.check(getattr(lib, "xg_stencil1d_" + sfx)(
+                code, t.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, n_out, int(pad_lo),
                 int(pad_hi), _hip.BC[bc], fv, None, None, None, None, _stream()))
-    res = _narrow(out, plan.result, via=plan.via, scale=plan.scale, flip=plan.flip)
+    res = _narrow(out, plan.result, via=plan.via, scale=plan.scale)
     return _divide(res, m_out, plan.divide_as)
 
 
@@ -467,8 +467,10 @@ def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
     lib = _hip.load()
     src = _dt.np_dtype(x)
     ints = _dt.is_integer(src)  # numpy.pad keeps an integer array integral and casts the constant to its dtype
+    lane = None
     if ints:
-        dt, sfx, x = torch.int64, "i64", _widen(x)
+        lane = _dt.lane_of(src)
+        dt, sfx, x = _dt.torch_dtype(lane), _LANE_SFX[lane.name], _widen(x, lane)
     else:
         dt, sfx = _common(x)
         x = asdevice(x, dt)
@@ -483,7 +485,7 @@ def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
         lo[ax], hi[ax] = int(l), int(h)
         bcv[ax] = _hip.BC[bc.get(ax)]
         f = fill.get(ax, 0.0) if fill.get(ax, 0.0) is not None else 0.0
-        fv[ax] = _lane_int(_dt.fill_as(src, f)) if ints else float(f)
+        fv[ax] = _lane_int(_dt.fill_as(src, f), lane) if ints else float(f)
         order.append(ax)
     order += [d for d in range(nd) if d not in order]
     oshape = [s + l + h for s, l, h in zip(x.shape, lo, hi)]
@@ -512,16 +514,18 @@ def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_sh
     if ints:  # halos of an integer field stay integral (the reference concatenates / pads the array in its own dtype)
         res_dt = np.result_type(_dt.np_dtype(x), *([] if partner is None else [_dt.np_dtype(partner)]))
         ints = _dt.is_integer(res_dt)  # int64 with uint64 promotes to float64
+    lane = None
     if ints:
-        dt, sfx = torch.int64, "i64"
-        x = _widen(x)
-        fills = [_lane_int(_dt.fill_as(res_dt, f)) for f in fills]
+        lane = _dt.lane_of(res_dt)
+        dt, sfx = _dt.torch_dtype(lane), _LANE_SFX[lane.name]
+        x = _widen(x if _dt.np_dtype(x) == res_dt else convert(x, res_dt), lane)
+        fills = [_lane_int(_dt.fill_as(res_dt, f), lane) for f in fills]
     else:
         dt, sfx = _common(x, partner) if partner is not None else _common(x)
         x = asdevice(x, dt)
     nd = x.dim()
     if partner is not None:
-        partner = _widen(partner) if ints else asdevice(partner, dt)
+        partner = _widen(partner if _dt.np_dtype(partner) == res_dt else convert(partner, res_dt), lane) if ints else asdevice(partner, dt)
         if partner.dim() != nd:
             raise ValueError("gather: the other vector component must have as many dims as the padded one")
         if partner_perm is None:
@@ -555,12 +559,12 @@ def put_halo(out: torch.Tensor, halo, axis: int, pad_lo: int, pad_hi: int) -> to
     if list(halo.shape) != expect:
         raise ValueError(f"halo buffer has shape {tuple(halo.shape)}, expected {tuple(expect)}")
     odt = _dt.np_dtype(out)
-    if odt.name not in ("float64", "float32", "int64", "uint64"):
-        raise TypeError(f"put_halo serves float64 / float32 / int64 / uint64 arrays, not {odt}")
+    if odt.name not in ("float64", "float32", "int64", "uint64", "int32", "uint32"):
+        raise TypeError(f"put_halo serves float64 / float32 / 64- and 32-bit integer arrays, not {odt}")
     h = _raw_device(halo)
     if _dt.np_dtype(h) != odt:
         h = convert(h, odt)
-    sfx = {"float64": "f64", "float32": "f32"}.get(odt.name, "i64")
+    sfx = {"float64": "f64", "float32": "f32"}.get(odt.name) or _LANE_SFX[_dt.lane_of(odt).name]
     if h.numel():
         _hip.check(getattr(lib, "xg_halo_put_" + sfx)(h.data_ptr(), out.data_ptr(), _hip.i64(list(out.shape)), out.dim(), axis,
                                                      int(pad_lo), int(pad_hi), _stream()))
@@ -636,9 +640,12 @@ def binary(op: str, a, b) -> torch.Tensor:
     """Broadcasting a OP b for dim-aligned operands (same ndim, extents equal or 1)."""
     lib = _hip.load()
     lanes, res_dt = _dt.binary_plan(op, _dt.np_dtype(a), _dt.np_dtype(b))
-    if lanes == "int":  # numpy keeps int OP int integral (wrap-around in the promoted dtype): int64 lanes, narrowed
-        dt, sfx = torch.int64, "i64"
-        a, b = _widen(a), _widen(b)
+    if lanes == "int":  # numpy keeps int OP int integral (wrap-around in the promoted dtype): its lanes, narrowed
+        lane = _dt.lane_of(res_dt)
+        dt, sfx = _dt.torch_dtype(lane), _LANE_SFX[lane.name]
+        # an operand narrower than the promoted dtype is converted to IT first (int8 next to uint16 -> int32: sign-extended)
+        a = _widen(a if _dt.same_bits(_dt.np_dtype(a), lane) else convert(a, res_dt), lane)
+        b = _widen(b if _dt.same_bits(_dt.np_dtype(b), lane) else convert(b, res_dt), lane)
     else:
         dt, sfx = (torch.float32, "f32") if res_dt == _dt.FLOAT32 else (torch.float64, "f64")
         a = asdevice(a, dt)

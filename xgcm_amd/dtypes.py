@@ -3,9 +3,9 @@
 The reference runs its bodies in the array's own dtype (xgcm/gridops.py:23-24,76-77,123-126,172-175,227-278 are plain
 numpy expressions; `np.pad` keeps the dtype and casts the fill value, xgcm/padding.py:610-615), so integer and bool arrays
 stay integral through diff / min / max / cumsum / pad -- wrapping modulo 2^bits -- and become float64 in `interp`
-(`/ 2.0`) or next to a metric (`int * float64`).  The kernels compute on float64, float32 or int64 lanes; this module
-decides, from dtypes alone, which lanes serve a call and how the result leaves them (pure host logic: no device, no
-arithmetic on array data).  `xgcm_amd.device` executes the plans with xg_convert / the `*_i64` entry points.
+(`/ 2.0`) or next to a metric (`int * float64`).  The kernels compute on float64, float32, int64 or int32 lanes; this
+module decides, from dtypes alone, which lanes serve a call and how the result leaves them (pure host logic: no device,
+no arithmetic on array data).  `xgcm_amd.device` executes the plans with xg_convert / the `*_i64` / `*_i32` entry points.
 """
 
 from __future__ import annotations
@@ -20,6 +20,7 @@ except Exception:  # pragma: no cover
     torch = None  # type: ignore
 
 INT64 = np.dtype(np.int64)
+INT32 = np.dtype(np.int32)
 UINT64 = np.dtype(np.uint64)
 FLOAT64 = np.dtype(np.float64)
 FLOAT32 = np.dtype(np.float32)
@@ -73,12 +74,29 @@ def fill_as(dt, fill):
     return np.pad(np.zeros(1, dtype=dt), (1, 0), "constant", constant_values=fill)[0]
 
 
+def lane_of(dt) -> np.dtype:
+    """the integer lanes an array whose result keeps its width computes on (diff / min / max / pad / gather / + - *):
+    64-bit types on int64 lanes as they are, everything narrower on int32 lanes -- int32 / uint32 as they are, bool /
+    8 / 16-bit widened by xg_convert.  Two's-complement arithmetic in the lane width followed by narrowing IS the narrow
+    dtype's wrap-around."""
+    dt = np.dtype(dt)
+    if not is_integer(dt):
+        raise TypeError(f"{dt} is not an integer dtype")
+    return INT64 if dt.itemsize == 8 else INT32
+
+
+def same_bits(dt, lane) -> bool:
+    """an integer array that IS its lanes (int64 / uint64 on int64 lanes, int32 / uint32 on int32 lanes): no conversion"""
+    dt, lane = np.dtype(dt), np.dtype(lane)
+    return dt.kind in "iu" and dt.itemsize == lane.itemsize
+
+
 class StencilPlan(NamedTuple):
-    lanes: str                 # "int": *_i64 kernels; "float": convert the field first, *_f64 / *_f32 kernels
-    compute: np.dtype          # float lanes: the float dtype; int lanes: int64
-    flip: bool                 # uint64 min / max: sign-bit flip around the signed kernels
+    lanes: str                 # "int": *_i64 / *_i32 kernels; "float": convert the field first, *_f64 / *_f32 kernels
+    compute: np.dtype          # float lanes: the float dtype; int lanes: int64 or int32 (lane_of)
+    unsigned: bool             # min / max of an array that fills its lanes unsigned (uint64, uint32): XG_OP_MINU / MAXU
     result: np.dtype           # dtype of the operator's result BEFORE an output metric divides it
-    via: Optional[np.dtype]    # int lanes: wrap the int64 result to this dtype's width first (the narrow dtype's arithmetic)
+    via: Optional[np.dtype]    # int lanes: wrap the lane result to this dtype's width first (the narrow dtype's arithmetic)
     scale: float               # int lanes, interp: 0.5 applied in float64 after the conversion
     divide_as: Optional[np.dtype]  # int lanes with an output metric: the float dtype of `result / m_out`
 
@@ -100,7 +118,10 @@ def stencil_plan(op: str, x_dt, m_in_dt=None, m_out_dt=None) -> StencilPlan:
     else:
         result, via, scale = x_dt, None, 1.0
     divide_as = None if m_out_dt is None else float_of(result, m_out_dt)
-    return StencilPlan("int", INT64, x_dt == UINT64 and op in ("min", "max"), result, via, scale, divide_as)
+    lane = lane_of(x_dt)
+    # narrower unsigned arrays are zero-extended into their lanes: the signed comparison is already right
+    unsigned = x_dt.kind == "u" and same_bits(x_dt, lane) and op in ("min", "max")
+    return StencilPlan("int", lane, unsigned, result, via, scale, divide_as)
 
 
 def cumsum_dtype(x_dt) -> np.dtype:
