@@ -128,3 +128,49 @@ def test_against_an_installed_reference_package(backend):
         a, b = call(mine), call(ref)
         assert a.dims == b.dims and set(a.coords) == set(b.coords)
         np.testing.assert_allclose(a.values, b.values, rtol=1e-12, atol=1e-12, equal_nan=True)
+
+
+_CUBE = {"face": {0: {"X": ((3, "X", False), (1, "X", False)), "Y": ((4, "Y", False), (5, "Y", False))},
+                  1: {"X": ((0, "X", False), (2, "X", False)), "Y": ((4, "X", False), (5, "X", True))},
+                  2: {"X": ((1, "X", False), (3, "X", False)), "Y": ((4, "Y", True), (5, "Y", True))},
+                  3: {"X": ((2, "X", False), (0, "X", False)), "Y": ((4, "X", True), (5, "X", False))},
+                  4: {"X": ((3, "Y", True), (1, "Y", False)), "Y": ((2, "Y", True), (0, "Y", False))},
+                  5: {"X": ((3, "Y", False), (1, "Y", True)), "Y": ((0, "Y", False), (2, "Y", True))}}}
+_TWO = {"face": {0: {"X": (None, (1, "Y", True))}, 1: {"Y": (None, (0, "X", True))}}}
+
+
+@pytest.mark.parametrize("conn", [_TWO, _CUBE], ids=["x2y_rev", "cubed_sphere"])
+def test_face_connections_against_an_installed_reference_package(backend, conn):
+    """PINS f2 without the stand-in: the reference's own `_pad_face_connections` on REAL xarray objects (the committed
+    topology fixtures come from the same code over a numpy-backed stand-in for DataArray, oracle/make_golden_topology.py).
+    Scalars and the two components of a C-grid vector, through `pad` and through the operators."""
+    xgcm = pytest.importorskip("xgcm")
+    from xgcm.padding import pad as ref_pad
+
+    from xgcm_amd.padding import pad as my_pad
+
+    nf, n = len(conn["face"]), 6
+    rng = np.random.default_rng(23)
+    ds = xr.Dataset({"c": (("face", "y", "x"), rng.standard_normal((nf, n, n))), "u": (("face", "y", "xl"), rng.standard_normal((nf, n, n))),
+                     "v": (("face", "yl", "x"), rng.standard_normal((nf, n, n)))},
+                    coords={"x": np.arange(n), "xl": np.arange(n) - 0.5, "y": np.arange(n), "yl": np.arange(n) - 0.5, "face": np.arange(nf)})
+    coords = {"X": {"center": "x", "left": "xl"}, "Y": {"center": "y", "left": "yl"}}
+    ref = xgcm.Grid(ds, coords=coords, face_connections=conn, autoparse_metadata=False)
+    mine = Grid(ds, coords=coords, face_connections=conn, autoparse_metadata=False)
+    for pw in ({"X": (1, 1)}, {"X": (2, 1), "Y": (1, 2)}):
+        for mode in ("fill", "extend"):
+            a = my_pad(ds["c"], mine, padding_width=dict(pw), padding=mode, fill_value=1.5)
+            b = ref_pad(ds["c"], ref, padding_width=dict(pw), padding=mode, fill_value=1.5)
+            assert a.dims == b.dims
+            np.testing.assert_array_equal(a.values, b.values)
+        for this, other in ((("X", "u"), ("Y", "v")), (("Y", "v"), ("X", "u"))):  # a vector component + its partner
+            va = my_pad({this[0]: ds[this[1]]}, mine, padding_width=dict(pw), padding="fill", fill_value=0.0,
+                        other_component={other[0]: ds[other[1]]})
+            vb = ref_pad({this[0]: ds[this[1]]}, ref, padding_width=dict(pw), padding="fill", fill_value=0.0,
+                         other_component={other[0]: ds[other[1]]})
+            np.testing.assert_array_equal(va.values, vb.values)
+    for op in ("diff", "interp"):
+        for ax in ("X", "Y"):
+            np.testing.assert_array_equal(getattr(mine, op)(ds["c"], ax, padding="extend").values,
+                                          getattr(ref, op)(ds["c"], ax, padding="extend").values)
+
