@@ -91,6 +91,12 @@ int xg_free(void* ptr);
 int xg_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void* stream);
 int xg_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void* stream);
 int xg_stream_sync(void* stream);
+/* page-lock / release a range of HOST memory in place (hipHostRegister): asynchronous copies to and from it then run at
+ * the link rate and overlap with kernels (xgcm_amd/streaming.py locks the record blocks of a host array ahead of its
+ * copies).  A range that cannot be locked (a read-only file mapping ...) returns XG_ERR_HIP and leaves NO pending HIP
+ * error behind; such memory still copies, through the runtime's pageable path. */
+int xg_pin_host(void* ptr, uint64_t bytes);
+int xg_unpin_host(void* ptr);
 /* a stream of the library's own (xgcm_amd.graphs.capture records on one: the chained kernels keep their workspace per
  * stream, so a captured graph never shares it with another capture or with eager calls) */
 int xg_stream_create(void** stream);

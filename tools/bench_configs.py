@@ -347,7 +347,7 @@ def main():
         def diff_x(block):
             return grid_s.diff(DataArray(block, ("time", "Z", "YC", "XC")), "X").data
 
-        for reg, label in ((True, "page-locked in place"), (False, "staged through pinned buffers")):
+        for reg, label in ((True, "page-locked in place block by block"), (False, "pageable copies, D2H in a worker thread")):
             stream_records(diff_x, host[:2], block=1, out=out[:2], register=reg)
             t0 = time.perf_counter()
             stream_records(diff_x, host, block=1, out=out, register=reg)
@@ -364,7 +364,7 @@ def main():
         got = []
         t0 = time.perf_counter()
         stream_blocks(diff_x, (host[r:r + 1] for r in range(nr)), sink=lambda k, res: got.append(res[0, 0, 0, 0]))
-        rec("stream", f"same records handed over as an ITERABLE of blocks (stream_blocks: read-ahead + staging through pinned buffers)",
+        rec("stream", f"same records handed over as an ITERABLE of blocks (stream_blocks: read-ahead; in-memory blocks page-locked in place, others staged)",
             (time.perf_counter() - t0) * 1e3, nr * nzs * ny * nx, 16)
         ok = bool(np.array_equal(out[nr - 1], host[nr - 1] - np.roll(host[nr - 1], 1, axis=-1)))
         print(json.dumps({"config": "stream", "check": "last record == host - roll(host, 1) (periodic diff)", "ok": ok}), flush=True)

@@ -37,6 +37,8 @@ SIGNATURES = {
     "xg_malloc": (C.c_int, [C.POINTER(_vp), C.c_uint64]),
     "xg_free": (C.c_int, [_vp]),
     "xg_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
+    "xg_pin_host": (C.c_int, [_vp, C.c_uint64]),
+    "xg_unpin_host": (C.c_int, [_vp]),
     "xg_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "xg_stream_sync": (C.c_int, [_vp]),
     "xg_stream_create": (C.c_int, [C.POINTER(_vp)]),

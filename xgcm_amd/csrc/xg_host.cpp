@@ -342,6 +342,8 @@ int xg_free(void* ptr) { free(ptr); return XG_OK; }
 int xg_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void*) { if (bytes) memcpy(dst, src, bytes); return XG_OK; }
 int xg_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void*) { if (bytes) memcpy(dst, src, bytes); return XG_OK; }
 int xg_stream_sync(void*) { return XG_OK; }
+int xg_pin_host(void* ptr, uint64_t bytes) { return (ptr && bytes) ? XG_OK : fail(XG_ERR_INVALID, "empty host range"); }  // nothing to lock
+int xg_unpin_host(void*) { return XG_OK; }
 int xg_stream_create(void** stream) {
   if (!stream) return fail(XG_ERR_INVALID, "NULL argument");
   *stream = nullptr;  // the host build runs everything on the calling thread

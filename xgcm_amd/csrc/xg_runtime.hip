@@ -300,6 +300,23 @@ int xg_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void* stream) {
   return 0;
 }
 int xg_stream_sync(void* stream) { XG_HIP(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+int xg_pin_host(void* ptr, uint64_t bytes) {
+  if (!ptr || !bytes) return fail(XG_ERR_INVALID, "empty host range");
+  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // a refusal is an answer, not a fault: nothing may surface at the caller's next launch check
+    return fail(XG_ERR_HIP, "hipHostRegister(%p, %llu) refused: %s", ptr, (unsigned long long)bytes, hipGetErrorString(e));
+  }
+  return XG_OK;
+}
+int xg_unpin_host(void* ptr) {
+  hipError_t e = hipHostUnregister(ptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(XG_ERR_HIP, "hipHostUnregister(%p): %s", ptr, hipGetErrorString(e));
+  }
+  return XG_OK;
+}
 int xg_stream_create(void** stream) {
   if (!stream) return fail(XG_ERR_INVALID, "NULL argument");
   XG_HIP(hipStreamCreateWithFlags((hipStream_t*)stream, hipStreamNonBlocking));

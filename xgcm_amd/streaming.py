@@ -10,13 +10,18 @@ pipeline over the record (outermost, e.g. time) axis of a HOST array:
 
 so a record batch that does not fit the 288 GB of HBM -- or that simply lives on the host -- is
 processed at the PCIe rate instead of (PCIe in) + (kernel) + (PCIe out) + pageable-copy overheads.
-Host memory is page-locked in place (`hipHostRegister` through torch's runtime handle) when
-possible, else staged through pinned buffers.  PyTorch provides streams, events and the caching
-allocator here; the arithmetic is the HIP library's as everywhere else.
+Host memory is page-locked in place (`hipHostRegister` through torch's runtime handle), record block by record block
+in a helper thread that runs AHEAD of the copies -- page-locking 27 GB up front cost as much as moving half of it
+(tools/pcie_probe.py) -- and blocks that cannot be locked (a read-only memory map) take the runtime's pageable copies,
+the copy back to the host running in a worker thread so that both directions still overlap.  PyTorch provides
+streams, events and the caching allocator here; the arithmetic is the HIP library's as everywhere else.
 """
 
 from __future__ import annotations
 
+import mmap
+import threading
+from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, Iterable, Iterator, List, Optional, Tuple
 
 import numpy as np
@@ -44,6 +49,15 @@ def _swap_on_device(x: torch.Tensor, itemsize: int, stream: "torch.cuda.Stream")
         _hip.check(_hip.load().xg_bswap(x.data_ptr(), x.numel(), itemsize, stream.cuda_stream))
 
 
+def _lock(ptr: int, nbytes: int) -> bool:
+    """page-lock host memory in place (xg_pin_host); False if the range cannot be locked"""
+    return nbytes > 0 and _hip.load().xg_pin_host(ptr, nbytes) == 0
+
+
+def _unlock(ptr: int) -> None:
+    _hip.load().xg_unpin_host(ptr)
+
+
 def record_blocks(n_records: int, block: int) -> List[Tuple[int, int]]:
     """[start, stop) of consecutive record blocks (the last one may be short)."""
     if block < 1:
@@ -60,27 +74,129 @@ def _as_tensor(arr: np.ndarray) -> torch.Tensor:
         return torch.from_numpy(arr)
 
 
-class _Pinned:
-    """Page-lock a numpy array in place for the lifetime of the object (fallback: not pinned)."""
+class _BlockPinner:
+    """Page-lock the record blocks of a C-contiguous host array one after the other in a helper thread, so that the
+    pipeline's first copy starts after ONE block has been locked instead of the whole array.  Block ranges are cut at
+    page boundaries (a page two blocks share belongs to the earlier one: blocks are locked in order, so by the time
+    block k is copied every page it touches is locked).  An asynchronous copy must stay inside ONE locked range, so a
+    block is moved in `pieces(k)`: its first bytes up to the page boundary (they lie in the previous block's range),
+    then the rest.  Arrays under 256 MB are locked whole.  `wait(k)` -> True if block k is page-locked."""
 
-    def __init__(self, arr: np.ndarray):
-        self.arr = arr
+    WHOLE_BELOW = 256 << 20
+    THREADS = 4
+
+    def __init__(self, arr: np.ndarray, blocks: List[Tuple[int, int]], enabled: bool = True, prefault: bool = False):
+        """`prefault` (an OUTPUT array, every cell of which is about to be overwritten): write one element per page
+        before locking a block -- page-locking never-touched memory takes its page faults inside the driver call, one
+        thread at a time; touched here, they are taken by THREADS threads at once"""
         self.tensor = _as_tensor(arr)
-        self.registered = False
-        try:
-            rt = torch.cuda.cudart()
-            err = rt.cudaHostRegister(self.tensor.data_ptr(), self.tensor.numel() * self.tensor.element_size(), 0)
-            self.registered = int(err) == 0
-        except Exception:
-            self.registered = False
+        self.flat = self.tensor.reshape(-1)  # (C-contiguous: a view)
+        self.ready = [threading.Event() for _ in blocks]
+        self.pinned = [False] * len(blocks)
+        self._ranges: List[int] = []
+        self._threads: List[threading.Thread] = []
+        item = arr.itemsize
+        per = (arr.size // arr.shape[0]) if arr.ndim and arr.shape[0] else 1  # elements per record
+        self._pieces = [[(a * per, b * per)] for a, b in blocks]
+        if not enabled or not blocks or arr.size == 0:
+            for ev in self.ready:
+                ev.set()
+            return
+        base = self.tensor.data_ptr()
+        row = per * item
+        page = mmap.PAGESIZE
+        up = lambda p: (p + page - 1) // page * page  # noqa: E731
+        if arr.nbytes < self.WHOLE_BELOW or len(blocks) == 1 or base % item:
+            spans = [(base, arr.nbytes)] + [(0, 0)] * (len(blocks) - 1)
+        else:
+            spans = []
+            for k, (a, b) in enumerate(blocks):
+                lo = base + a * row if k == 0 else up(base + a * row)
+                hi = base + b * row if k == len(blocks) - 1 else up(base + b * row)
+                spans.append((lo, max(hi - lo, 0)))
+                cut = (lo - base) // item  # first element of the block that lies in its OWN range
+                if k and a * per < cut < b * per:
+                    self._pieces[k] = [(a * per, cut), (cut, b * per)]
+        dev = torch.cuda.current_device()
+        lock = threading.Lock()
+        todo = iter(range(len(spans)))
+        failed = [False]
+
+        def work():
+            # a few threads lock consecutive blocks at once: page-locking never-touched memory (an output array fresh from
+            # numpy.empty) is bound by the page faults of the locking thread, 25 GB/s -- under the copy rate
+            torch.cuda.set_device(dev)
+            while True:
+                with lock:
+                    k = next(todo, None)
+                if k is None:
+                    return
+                lo, nbytes = spans[k]
+                ok = not failed[0]
+                if ok and nbytes and prefault:
+                    e0 = (lo - base) // item
+                    self.flat[e0:e0 + nbytes // item:max(page // item, 1)] = 0
+                if ok and nbytes:
+                    ok = _lock(lo, nbytes)
+                    if ok:
+                        with lock:
+                            self._ranges.append(lo)
+                    else:
+                        failed[0] = True  # (a read-only mapping ...): the remaining blocks stay pageable
+                self.pinned[k] = ok
+                self.ready[k].set()
+
+        nthreads = 1 if spans[0][1] == arr.nbytes else min(self.THREADS, len(spans))
+        self._threads = [threading.Thread(target=work, name="xgcm-amd-pin", daemon=True) for _ in range(nthreads)]
+        for t in self._threads:
+            t.start()
+
+    def pieces(self, k: int) -> List[Tuple[int, int]]:
+        """[first, last) flat element ranges of block k, each inside one page-locked range"""
+        return self._pieces[k]
+
+    def wait(self, k: int) -> bool:
+        """block k may be copied: its own range and the one holding its first bytes are done"""
+        if k:
+            self.ready[k - 1].wait()
+        self.ready[k].wait()
+        return self.pinned[k]
 
     def close(self) -> None:
-        if self.registered:
-            try:
-                torch.cuda.cudart().cudaHostUnregister(self.tensor.data_ptr())
-            except Exception:
-                pass
-            self.registered = False
+        for t in self._threads:
+            t.join()
+        self._threads = []
+        for lo in self._ranges:
+            _unlock(lo)
+        self._ranges = []
+
+
+def _copy_threads(dst: np.ndarray, src: np.ndarray, threads: int = 8) -> None:
+    """`numpy.copyto(dst, src)` cut into pieces for a few threads: one core moves ~10 GB/s, a memory-mapped source also
+    takes its page faults in parallel (numpy releases the GIL in the copy loop).  Contiguous pairs are cut flat, others
+    along their first axis long enough to share."""
+    src = np.asarray(src)
+    if dst.nbytes < (64 << 20) or dst.ndim == 0 or src.shape != dst.shape:
+        np.copyto(dst, src)
+        return
+    if dst.flags.c_contiguous and src.flags.c_contiguous:
+        d, s_, ax = dst.reshape(-1), src.reshape(-1), 0
+    else:
+        ax = next((i for i, e in enumerate(dst.shape) if e >= threads), None)
+        if ax is None:
+            np.copyto(dst, src)
+            return
+        d, s_ = dst, src
+    n = d.shape[ax]
+    cuts = [n * i // threads for i in range(threads + 1)]
+    pre = (slice(None),) * ax
+
+    def part(i):
+        sl = pre + (slice(cuts[i], cuts[i + 1]),)
+        np.copyto(d[sl], s_[sl])
+
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(part, range(threads)))
 
 
 def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, block: int = 1,
@@ -97,48 +213,44 @@ def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, 
     dev = torch.device("cuda", torch.cuda.current_device())
     s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     s_cmp = torch.cuda.current_stream(dev)
-    pin_src = _Pinned(src) if register else None
-    src_t = pin_src.tensor if pin_src is not None else _as_tensor(src)
-    # page-locking in place failed (or was declined): stage through two pinned buffers per direction
-    stage_in = None
-    if pin_src is None or not pin_src.registered:
-        stage_in = [torch.empty((block,) + src.shape[1:], dtype=src_t.dtype).pin_memory() for _ in range(2)]
-    in_done: List[Optional[torch.cuda.Event]] = [None, None]
-    pin_out: Optional[_Pinned] = None
+    pin_src = _BlockPinner(src, blocks, register)
+    src_t = pin_src.tensor
+    pin_out: Optional[_BlockPinner] = None
     out_t: Optional[torch.Tensor] = None
-    stage_out: Optional[List[torch.Tensor]] = None
-    pending: List[Optional[Tuple[int, int, torch.cuda.Event]]] = [None, None]
+    pool = ThreadPoolExecutor(1, thread_name_prefix="xgcm-amd-d2h")
+    futs: list = []
 
-    def drain(slot: int) -> None:
-        """finish the D2H that went into staging buffer `slot` and move it to its place in `out`"""
-        if stage_out is None or pending[slot] is None:
-            return
-        a0, b0, ev = pending[slot]
-        ev.synchronize()
-        out_t[a0:b0].copy_(stage_out[slot][: b0 - a0])
-        pending[slot] = None
+    def copy_out(k: int, a: int, b: int, y: torch.Tensor, ev_cmp: "torch.cuda.Event") -> None:
+        """worker thread: result of block k back to its place in `out` (an asynchronous copy when that block of `out` is
+        page-locked, the runtime's pageable copy otherwise -- either way off the thread that feeds the GPU)"""
+        torch.cuda.set_device(dev)
+        pin_out.wait(k)
+        yf = y.reshape(-1)
+        e0 = pin_out.pieces(k)[0][0]
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(ev_cmp)
+            for p0, p1 in pin_out.pieces(k):
+                pin_out.flat[p0:p1].copy_(yf[p0 - e0:p1 - e0], non_blocking=True)
+        s_out.synchronize()  # `y` is dropped when this returns
 
     try:
         for k, (a, b) in enumerate(blocks):
-            slot = k % 2
+            pin_src.wait(k)
             with torch.cuda.stream(s_in):
-                if stage_in is not None:
-                    if in_done[slot] is not None:
-                        in_done[slot].synchronize()      # the H2D that last read this staging buffer is done
-                    stage_in[slot][: b - a].copy_(src_t[a:b])
-                    host_block = stage_in[slot][: b - a]
-                else:
-                    host_block = src_t[a:b]
-                x = host_block.to(dev, non_blocking=True)
+                x = torch.empty((b - a,) + tuple(src.shape[1:]), dtype=src_t.dtype, device=dev)
+                xf, e0 = x.reshape(-1), pin_src.pieces(k)[0][0]
+                for p0, p1 in pin_src.pieces(k):  # (a block that could not be locked: pageable copy, blocks here)
+                    xf[p0 - e0:p1 - e0].copy_(pin_src.flat[p0:p1], non_blocking=True)
                 _swap_on_device(x, swap, s_in)
                 ev_in = torch.cuda.Event()
                 ev_in.record(s_in)
-                in_done[slot] = ev_in
             s_cmp.wait_event(ev_in)
             x.record_stream(s_cmp)
             y = fn(x)
             if y.shape[0] != b - a:
                 raise ValueError("fn must keep the record axis (first dim) of its block")
+            if not y.is_contiguous():
+                y = y.contiguous()
             ev_cmp = torch.cuda.Event()
             ev_cmp.record(s_cmp)
             if out_t is None:
@@ -146,30 +258,25 @@ def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, 
                     out = np.empty((n,) + tuple(y.shape[1:]), dtype=np.float32 if y.dtype == torch.float32 else np.float64)
                 if not out.flags.c_contiguous or out.shape[0] != n or tuple(out.shape[1:]) != tuple(y.shape[1:]):
                     raise ValueError("`out` must be C-contiguous with the result's shape")
-                pin_out = _Pinned(out) if register else None
-                out_t = pin_out.tensor if pin_out is not None else torch.from_numpy(out)
-                if pin_out is None or not pin_out.registered:
-                    stage_out = [torch.empty((block,) + tuple(y.shape[1:]), dtype=y.dtype).pin_memory() for _ in range(2)]
-            drain(slot)
-            with torch.cuda.stream(s_out):
-                s_out.wait_event(ev_cmp)
-                y.record_stream(s_out)
-                if stage_out is not None:
-                    stage_out[slot][: b - a].copy_(y, non_blocking=True)
-                else:
-                    out_t[a:b].copy_(y, non_blocking=True)
-                ev_out = torch.cuda.Event()
-                ev_out.record(s_out)
-            pending[slot] = (a, b, ev_out)
+                pin_out = _BlockPinner(out, blocks, register, prefault=True)
+                out_t = pin_out.tensor
+            while len(futs) >= 2:  # at most two results parked in HBM
+                futs.pop(0).result()
+            futs.append(pool.submit(copy_out, k, a, b, y, ev_cmp))
             del x, y
-        drain(0)
-        drain(1)
-        s_out.synchronize()
+        for f in futs:
+            f.result()
+        futs = []
         s_in.synchronize()
         _hip.chain_check()  # results are on the host now: report a chained launch that had to be redone
     finally:
-        if pin_src is not None:
-            pin_src.close()
+        for f in futs:
+            try:
+                f.result()
+            except Exception:
+                pass
+        pool.shutdown(wait=True)
+        pin_src.close()
         if pin_out is not None:
             pin_out.close()
     return out
@@ -183,18 +290,53 @@ def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, 
 # (page faults of a memory map included), staged into page-locked memory and copied in, and the result of
 # block k-1 is copied out.  Blocks may differ in length along the record axis (ragged last chunk).
 # ------------------------------------------------------------------------------------------------------
+def _prefault(a: np.ndarray, threads: int = 4) -> None:
+    """first touch of a fresh array by a few threads at once (one write per page): 27 GB/s for one thread, 100 GB/s for
+    four on the GPU box (tools/pcie_probe.py)"""
+    flat = a.reshape(-1)
+    step = max(mmap.PAGESIZE // a.itemsize, 1)
+    if flat.size < threads * step * 1024:
+        flat[::step] = 0
+        return
+    cuts = [flat.size * i // threads // step * step for i in range(threads)] + [flat.size]
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(lambda i: flat[cuts[i]:cuts[i + 1]:step].__setitem__(slice(None), 0), range(threads)))
+
+
 class _Stage:
-    """two rotating page-locked host buffers that grow to the largest block seen"""
+    """two rotating page-locked host buffers that grow to the largest block seen.  A buffer is numpy memory, touched by a
+    few threads and then page-locked in place: `hipHostMalloc` (torch's pin_memory) hands out 8 GB/s, which for two
+    input and two output buffers of a 1.7 GB record was two thirds of the whole stream (tools/pcie_probe.py)."""
 
     def __init__(self):
         self.buf: List[Optional[torch.Tensor]] = [None, None]
+        self._locked: List[Optional[int]] = [None, None]
+
+    def _release(self, slot: int) -> None:
+        if self._locked[slot] is not None:
+            _unlock(self._locked[slot])
+            self._locked[slot] = None
+        self.buf[slot] = None
 
     def get(self, slot: int, shape, dtype) -> torch.Tensor:
         n = int(np.prod(shape))
         b = self.buf[slot]
         if b is None or b.dtype != dtype or b.numel() < n:
-            self.buf[slot] = b = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+            self._release(slot)
+            a = np.empty(max(n, 1), dtype=np.float32 if dtype == torch.float32 else np.float64)
+            _prefault(a)
+            b = torch.from_numpy(a)
+            ok = _lock(b.data_ptr(), a.nbytes)
+            if ok:
+                self._locked[slot] = b.data_ptr()
+            else:
+                b = torch.empty(max(n, 1), dtype=dtype).pin_memory()
+            self.buf[slot] = b
         return b[:n].view(tuple(shape))
+
+    def close(self) -> None:
+        self._release(0)
+        self._release(1)
 
 
 def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, copy: bool = True,
@@ -218,6 +360,15 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
     in_free: List[Optional[torch.cuda.Event]] = [None, None]   # H2D that last read staging slot i
     out_ready: List[Optional[Tuple[torch.Tensor, torch.cuda.Event]]] = [None, None]
 
+    locked: List[Optional[Tuple[int, np.ndarray]]] = [None, None]  # source blocks page-locked in place, per slot
+    direct = [True]
+    ends: List[Optional[torch.Tensor]] = [None, None]  # page-locked scrap for the sub-page ends of a block locked in place
+
+    def release(slot: int) -> None:
+        if locked[slot] is not None:
+            _unlock(locked[slot][0])
+            locked[slot] = None
+
     def upload(k: int, block) -> Tuple[torch.Tensor, torch.cuda.Event]:
         a, swap = _native_view(np.asarray(block))
         if a.dtype not in (np.float32, np.float64):
@@ -225,10 +376,39 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
         slot = k % 2
         if in_free[slot] is not None:
             in_free[slot].synchronize()
-        host = st_in.get(slot, a.shape, torch.float32 if a.dtype == np.float32 else torch.float64)
-        np.copyto(host.numpy(), a)  # the READ of the block (disk / page cache -> pinned memory), any strides
+        release(slot)
+        # a block that already sits in memory (a numpy chunk handed over by a reader) is page-locked where it is and
+        # copied straight from there; one that cannot be locked (a file mapping: its pages are read here) is staged
+        host, cut = None, None
+        if direct[0] and a.nbytes >= (8 << 20) and a.flags.c_contiguous and not isinstance(block, np.memmap):
+            # whole pages only: consecutive blocks cut from one array share their boundary pages, and a page is locked once
+            t = _as_tensor(a)
+            page, lo = mmap.PAGESIZE, t.data_ptr()
+            alo, ahi = (lo + page - 1) // page * page, (lo + a.nbytes) // page * page
+            if lo % a.itemsize == 0 and _lock(alo, ahi - alo):
+                locked[slot] = (alo, a)  # (the array stays referenced until its copy is done)
+                host, cut = t, ((alo - lo) // a.itemsize, (ahi - lo) // a.itemsize)
+            else:
+                direct[0] = False  # memory that cannot be locked (or oddly aligned): stage from here on
+        if host is None:
+            host = st_in.get(slot, a.shape, torch.float32 if a.dtype == np.float32 else torch.float64)
+            _copy_threads(host.numpy(), a)  # the READ of the block (disk / page cache -> pinned memory), any strides
         with torch.cuda.stream(s_in):
-            x = host.to(dev, non_blocking=True)
+            if cut is None:
+                x = host.to(dev, non_blocking=True)
+            else:  # the locked middle asynchronously, the two sub-page ends through the pageable path
+                x = torch.empty(tuple(a.shape), dtype=host.dtype, device=dev)
+                xf, hf = x.reshape(-1), host.reshape(-1)
+                xf[cut[0]:cut[1]].copy_(hf[cut[0]:cut[1]], non_blocking=True)
+                nh, nt = cut[0], hf.numel() - cut[1]
+                if nh or nt:  # (through a page-locked scrap buffer: a pageable copy would wait for the stream)
+                    if ends[slot] is None or ends[slot].dtype != host.dtype:
+                        ends[slot] = torch.empty(2 * mmap.PAGESIZE // a.itemsize, dtype=host.dtype).pin_memory()
+                    e = ends[slot]
+                    e[:nh].copy_(hf[:nh])
+                    e[nh:nh + nt].copy_(hf[cut[1]:])
+                    xf[:nh].copy_(e[:nh], non_blocking=True)
+                    xf[cut[1]:].copy_(e[nh:nh + nt], non_blocking=True)
             _swap_on_device(x, swap, s_in)  # a big-endian block: raw bytes came over, the order is reversed in HBM
             if mask_value is not None and x.numel():
                 _hip.check(_hip.load().xg_mask_value(x.data_ptr(), x.numel(), x.element_size(), float(mask_value),
@@ -242,8 +422,26 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
         host, ev = out_ready[slot]
         ev.synchronize()
         out_ready[slot] = None
-        return np.array(host.numpy(), copy=True) if copy else host.numpy()
+        if not copy:
+            return host.numpy()
+        res = np.empty(tuple(host.shape), dtype=host.numpy().dtype)
+        _copy_threads(res, host.numpy())
+        return res
 
+    try:
+        yield from _pump(fn, blocks, upload, finish, out_ready, st_out, s_cmp, s_out)
+        s_in.synchronize()
+        s_out.synchronize()
+        _hip.chain_check()
+    finally:
+        torch.cuda.synchronize(dev)  # (an abandoned generator: no copy may still target the staging buffers)
+        release(0)
+        release(1)
+        st_in.close()
+        st_out.close()
+
+
+def _pump(fn, blocks, upload, finish, out_ready, st_out, s_cmp, s_out):
     it = iter(blocks)
     nxt = next(it, None)
     ahead = upload(0, nxt) if nxt is not None else None
@@ -278,9 +476,6 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
     for slot in ((k % 2), ((k + 1) % 2)):
         if out_ready[slot] is not None:
             yield finish(slot)
-    s_in.synchronize()
-    s_out.synchronize()
-    _hip.chain_check()
 
 
 def stream_blocks(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable,
