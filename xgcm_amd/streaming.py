@@ -133,16 +133,19 @@ class _BlockPinner:
                     return
                 lo, nbytes = spans[k]
                 ok = not failed[0]
-                if ok and nbytes and prefault:
-                    e0 = (lo - base) // item
-                    self.flat[e0:e0 + nbytes // item:max(page // item, 1)] = 0
-                if ok and nbytes:
-                    ok = _lock(lo, nbytes)
-                    if ok:
-                        with lock:
-                            self._ranges.append(lo)
-                    else:
-                        failed[0] = True  # (a read-only mapping ...): the remaining blocks stay pageable
+                try:
+                    if ok and nbytes and prefault:
+                        e0 = (lo - base) // item
+                        self.flat[e0:e0 + nbytes // item:max(page // item, 1)] = 0
+                    if ok and nbytes:
+                        ok = _lock(lo, nbytes)
+                        if ok:
+                            with lock:
+                                self._ranges.append(lo)
+                except Exception:  # (a read-only output array ...): never leave the pipeline waiting for this block
+                    ok = False
+                if not ok:
+                    failed[0] = True  # (a read-only mapping ...): the remaining blocks stay pageable
                 self.pinned[k] = ok
                 self.ready[k].set()
 
