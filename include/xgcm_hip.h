@@ -466,6 +466,17 @@ int xg_binary_i32(int op, const int32_t* a, const int64_t* a_strides, const int3
                   const int64_t* b_strides, int32_t* out, const int64_t* shape, int ndim,
                   void* stream);
 
+/* ---- strided N-d copy: the data movement around the operators ------------------------------ */
+/* dst[i0, i1, ...] = src[i0, i1, ...] for every index of `shape`, with ELEMENT strides per dim on both sides: the
+ * materialisation of a transposed / flipped / broadcast / sliced view, which the reference leaves to numpy behind
+ * `DataArray.transpose` (xgcm/grid_ufunc.py:56-103), `[..., ::-1]` (xgcm/transform.py:180-192) and `xr.concat`.
+ * Source strides may be negative (flip: `src` then points at the element with index 0, i.e. the END of the flipped
+ * range) or 0 (broadcast); destination strides must be positive and must not make two indices share a cell.
+ * elem_bytes 1, 2, 4 or 8 (the bytes are moved, never interpreted).  Rows that run along the same unit-stride dim on both
+ * sides move as 16-byte lane vectors, true transposes through 32 x 32 LDS tiles, anything else one element per lane. */
+int xg_copy_nd(const void* src, const int64_t* src_strides, void* dst, const int64_t* dst_strides,
+               const int64_t* shape, int ndim, int elem_bytes, void* stream);
+
 /* ---- element type conversion (numpy `astype`) --------------------------------------------- */
 typedef enum xg_dtype {
   XG_T_BOOL = 0, XG_T_I8 = 1, XG_T_I16 = 2, XG_T_I32 = 3, XG_T_I64 = 4,

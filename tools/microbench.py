@@ -146,6 +146,25 @@ def main():
         ms, b = timeit(lambda: D.binary("mul", T, dz), args.reps)
         rec("binary_mul_bcast1D", ms, b, 16)
         del B
+    if "layout" in cases:  # xg_copy_nd against torch's own copy kernels on the same views
+        views = [("copy (rows, 16-B lanes)", lambda: T[:, 1:, :]), ("transpose (Z,Y,X)->(Z,X,Y) (LDS tiles)", lambda: T.permute(0, 2, 1)),
+                 ("transpose (Z,Y,X)->(X,Y,Z)", lambda: T.permute(2, 1, 0)), ("transpose (Z,Y,X)->(Y,X,Z)", lambda: T.permute(1, 2, 0)),
+                 ("every second column (gather)", lambda: T[:, :, ::2])]
+        for name, mk in views:
+            v = mk()
+            nc = v.numel()
+            ms, b = timeit(lambda: D.materialize(v), args.reps)
+            rec("layout: " + name, ms, b, 16, ncell=nc)
+            ms, b = timeit(lambda: v.contiguous(), args.reps)
+            rec("  torch .contiguous() of the same view", ms, b, 16, ncell=nc)
+        ms, b = timeit(lambda: D.flip(T, [2]), args.reps)
+        rec("layout: flip X (reversed rows)", ms, b, 16)
+        ms, b = timeit(lambda: T.flip(2), args.reps)
+        rec("  torch .flip(2)", ms, b, 16)
+        ms, b = timeit(lambda: D.flip(T, [0]), args.reps)
+        rec("layout: flip Z", ms, b, 16)
+        ms, b = timeit(lambda: T.flip(0), args.reps)
+        rec("  torch .flip(0)", ms, b, 16)
     if "vort" in cases:
         U = D.synthetic(shape, 51)
         V = D.synthetic(shape, 52)

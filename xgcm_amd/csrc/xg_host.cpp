@@ -512,6 +512,35 @@ XG_HOST_SUMS(i64, int64_t)
 XG_HOST_FLOAT(f64, double)
 XG_HOST_FLOAT(f32, float)
 
+// strided N-d copy (see the header): an odometer over the index space, bytes moved with memcpy
+int xg_copy_nd(const void* src, const int64_t* ss, void* dst, const int64_t* ds, const int64_t* shape, int ndim, int eb, void*) {
+  if (!shape || !ss || !ds) return fail(XG_ERR_INVALID, "NULL shape / stride argument");
+  if (ndim < 0 || ndim > XG_MAX_NDIM) return fail(XG_ERR_INVALID, "ndim %d not in [0,%d]", ndim, XG_MAX_NDIM);
+  if (eb != 1 && eb != 2 && eb != 4 && eb != 8) return fail(XG_ERR_INVALID, "element size %d not 1, 2, 4 or 8", eb);
+  int64_t total = 1;
+  for (int d = 0; d < ndim; ++d) {
+    if (shape[d] < 0) return fail(XG_ERR_INVALID, "negative extent");
+    if (ds[d] < 0) return fail(XG_ERR_INVALID, "destination strides must be positive");
+    if (shape[d] > 1 && ds[d] == 0) return fail(XG_ERR_INVALID, "destination stride 0 on a dim of extent %lld (cells written more than once)", (long long)shape[d]);
+    total *= shape[d];
+  }
+  if (total == 0) return XG_OK;
+  if (!src || !dst) return fail(XG_ERR_INVALID, "NULL array argument");
+  int64_t idx[XG_MAX_NDIM] = {0};
+  const char* s = static_cast<const char*>(src);
+  char* o = static_cast<char*>(dst);
+  for (int64_t i = 0; i < total; ++i) {
+    int64_t so = 0, dof = 0;
+    for (int d = 0; d < ndim; ++d) { so += idx[d] * ss[d]; dof += idx[d] * ds[d]; }
+    memcpy(o + dof * eb, s + so * eb, (size_t)eb);
+    for (int d = ndim - 1; d >= 0; --d) {
+      if (++idx[d] < shape[d]) break;
+      idx[d] = 0;
+    }
+  }
+  return XG_OK;
+}
+
 // numpy `astype` between the storage dtype and the compute dtype (see the header); one element at a time
 int xg_convert(const void* src, int st, void* dst, int dt, uint64_t n, int via, double scale, int flags, void*) {
   if (st < XG_T_BOOL || st > XG_T_F64 || dt < XG_T_BOOL || dt > XG_T_F64) return fail(XG_ERR_INVALID, "unknown element type (%d -> %d)", st, dt);

@@ -82,7 +82,68 @@ def _raw_device(x) -> torch.Tensor:
         # kernels are enqueued on the CURRENT device's stream (one process per GPU is the model)
         raise RuntimeError(f"array lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
                            "call torch.cuda.set_device() for that GPU first")
-    return t.contiguous()
+    return materialize(t)
+
+
+def _copy_nd(src_ptr: int, src_strides: Sequence[int], dst: torch.Tensor, shape: Sequence[int]) -> None:
+    """dst[...] = the strided source (xg_copy_nd): `dst` is an HBM tensor or view with positive strides, `src_ptr` the
+    address of the source element with index 0, strides in elements (negative: flip, 0: broadcast)"""
+    if len(shape) > _hip.MAX_NDIM:
+        raise ValueError(f"strided copy of a {len(shape)}-d array (at most {_hip.MAX_NDIM} dims)")
+    if dst.numel():
+        _hip.check(_hip.load().xg_copy_nd(src_ptr, _hip.i64(list(src_strides)), dst.data_ptr(), _hip.i64(list(dst.stride())),
+                                          _hip.i64(list(shape)), len(shape), dst.element_size(), _stream()))
+
+
+def materialize(t: torch.Tensor) -> torch.Tensor:
+    """an HBM tensor as a C-contiguous one: transposed / expanded / sliced views are laid out by the library's strided
+    copy (rows as 16-byte lanes, true transposes through LDS tiles), contiguous tensors pass"""
+    if t.is_contiguous():
+        return t
+    out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+    _copy_nd(t.data_ptr(), t.stride(), out, t.shape)
+    return out
+
+
+def flip(t, axes: Sequence[int]) -> torch.Tensor:
+    """numpy.flip(t, axes) of an HBM tensor as a new contiguous tensor (one strided copy with negative source strides)"""
+    t = _raw_device(t)
+    axes = sorted({a % t.dim() for a in axes})
+    strides = list(t.stride())
+    off = 0
+    for a in axes:
+        if t.shape[a]:
+            off += (t.shape[a] - 1) * strides[a]
+        strides[a] = -strides[a]
+    out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+    _copy_nd(t.data_ptr() + off * t.element_size(), strides, out, t.shape)
+    return out
+
+
+def copy_into(dst: torch.Tensor, src) -> torch.Tensor:
+    """dst[...] = src for an HBM destination VIEW (a slice of a larger tensor: concatenation without torch.cat); `src`
+    must have dst's shape and dtype"""
+    src = _raw_device(src)
+    if tuple(src.shape) != tuple(dst.shape) or src.dtype != dst.dtype:
+        raise ValueError(f"copy_into: source {tuple(src.shape)} {src.dtype} does not match destination {tuple(dst.shape)} {dst.dtype}")
+    _copy_nd(src.data_ptr(), src.stride(), dst, dst.shape)
+    return dst
+
+
+def concatenate(parts: Sequence, axis: int) -> torch.Tensor:
+    """numpy.concatenate of HBM tensors along `axis`: one strided copy per part into its slice of the result"""
+    parts = [_raw_device(p) for p in parts]
+    if len(parts) == 1:
+        return parts[0]
+    axis = axis % parts[0].dim()
+    shape = list(parts[0].shape)
+    shape[axis] = sum(int(p.shape[axis]) for p in parts)
+    out = torch.empty(shape, dtype=parts[0].dtype, device=parts[0].device)
+    at = 0
+    for p in parts:
+        copy_into(out.narrow(axis, at, p.shape[axis]), p)
+        at += p.shape[axis]
+    return out
 
 
 def convert(x, dst, via=None, scale: float = 1.0, flip: bool = False) -> torch.Tensor:

@@ -435,8 +435,17 @@ def exchange_halo(local, axis: int, pad: Tuple[int, int], bc: Optional[str], fil
         raise ValueError("a rank owns no cells along the sharded axis")
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0
-    first = t.narrow(axis, 0, 1).contiguous()
-    last = t.narrow(axis, t.shape[axis] - 1, 1).contiguous()
+    # edge planes and the halo slab are laid out by the library's strided copy when they live in HBM (host tensors -- the
+    # gloo tests -- stay with torch)
+    def plane(at):
+        p = t.narrow(axis, at, 1)
+        if t.is_cuda:
+            from . import device as _dev
+            return _dev.materialize(p)
+        return p.contiguous()
+
+    first = plane(0)
+    last = plane(t.shape[axis] - 1)
     if (lo or hi) and bc is None:
         raise ValueError("no boundary condition for the sharded axis")
 
@@ -482,7 +491,11 @@ def exchange_halo(local, axis: int, pad: Tuple[int, int], bc: Optional[str], fil
         shape[axis] = 0
         halo = t.new_empty(shape)
     else:
-        halo = torch.cat(parts, dim=axis) if len(parts) > 1 else parts[0]
+        if len(parts) > 1 and all(p.is_cuda for p in parts):
+            from . import device as _dev
+            halo = _dev.concatenate(parts, axis)
+        else:
+            halo = torch.cat(parts, dim=axis) if len(parts) > 1 else parts[0]
     return halo.numpy() if is_np else halo
 
 

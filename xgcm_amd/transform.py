@@ -78,13 +78,13 @@ def interp_1d_conservative(phi, theta, target_theta_bins):
     out = _dev.transform_conservative(phi, theta, np.ascontiguousarray(bins), -1)
     if flip:
         # un-flip along the BIN axis (the reference writes out[::-1], equal to this for 1-D input)
-        out = out.flip(-1) if _is_tensor(out) else out[..., ::-1]
+        out = _dev.flip(out, [-1]) if _is_tensor(out) else out[..., ::-1]
     return _dev.tohost(out) if host else out
 
 
 def _broadcast_copy(a, shape):
     if _is_tensor(a):
-        return a.expand(*shape).contiguous()
+        return _dev.materialize(a.expand(*shape))
     return np.ascontiguousarray(np.broadcast_to(a, shape))
 
 
@@ -147,7 +147,7 @@ def _column_call(kind: str, phi: DataArray, theta: DataArray, target: DataArray,
             raise ValueError("Target values are not monotonic")
         out = _dev.transform_conservative(phi_arr, theta_arr, np.ascontiguousarray(bins), axis)
         if flip:
-            out = out.flip(axis) if _is_tensor(out) else np.flip(out, axis=axis)
+            out = _dev.flip(out, [axis]) if _is_tensor(out) else np.flip(out, axis=axis)
     if host:
         out = _dev.tohost(out)
     out_dims_work = tuple(target_dim if d == phi_dim else d for d in work_dims)
