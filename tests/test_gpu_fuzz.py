@@ -68,6 +68,48 @@ def test_fuzz_stencil(dev, seed, dtype):
                                                            None if m_out is None else m_out.shape)
 
 
+INT_DTYPES = ["bool", "int8", "uint8", "int16", "uint16", "int32", "uint32", "int64", "uint64"]
+
+
+@pytest.mark.parametrize("dtype", INT_DTYPES)
+@pytest.mark.parametrize("seed", range(4))
+def test_fuzz_integer_lanes(dev, seed, dtype):
+    """the integer builds (*_i32: bool / 8 / 16 / 32-bit arrays, *_i64: 64-bit arrays and every scan / sum) over the same
+    random shapes: values over the dtype's whole range, so wrap-around, unsigned order and the narrowing are all exercised;
+    dtype-exact and bit-exact against numpy on the same integers"""
+    rng = np.random.default_rng(5000 + 97 * seed + INT_DTYPES.index(dtype))
+    dt = np.dtype(dtype)
+    for case in range(12):
+        shape = _shape(rng)
+        a = rng.integers(0, 2, shape).astype(dt) if dtype == "bool" else \
+            rng.integers(np.iinfo(dt).min, np.iinfo(dt).max, shape, dtype=dt, endpoint=True)
+        axis = int(rng.integers(0, len(shape)))
+        lo, hi = PADS[int(rng.integers(0, 4))]
+        bc = str(rng.choice(BCS))
+        fill = [0, 1, 3.7, 100][int(rng.integers(0, 4))]
+        if shape[axis] + lo + hi - 1 >= 1:
+            for op in ("diff", "interp", "min", "max"):
+                if dtype == "bool" and op == "diff":
+                    continue
+                exp = R.stencil1d(op, a, axis, lo, hi, bc, fill)
+                got = dev.tohost(dev.stencil1d(op, a, axis, lo, hi, bc if (lo or hi) else None, fill))
+                assert got.dtype == exp.dtype and np.array_equal(got, exp), (dtype, shape, axis, op, (lo, hi), bc)
+        rev = bool(rng.integers(0, 2))
+        trims = [(0, 0, 0, 0), (0, 1, 1, 0), (1, 0, 0, 1), (0, 0, 1, 0), (0, 0, 0, 1)][int(rng.integers(0, 5))]
+        if shape[axis] - trims[0] - trims[1] >= 1:
+            exp = R.cumsum1d(a, axis, *trims, bc, fill, rev, False)
+            got = dev.tohost(dev.cumsum1d(a, axis, *trims, bc if (trims[2] or trims[3]) else None, fill, rev, True))
+            assert got.dtype == exp.dtype and np.array_equal(got, exp), (dtype, shape, axis, trims, bc, rev)
+        got = dev.tohost(dev.reduce1d(a, axis, None, True))
+        exp = np.sum(a, axis=axis)
+        assert got.dtype == exp.dtype and np.array_equal(got, exp), (dtype, shape, axis)
+        w = {axis: (int(rng.integers(0, 3)), int(rng.integers(0, 3)))}
+        if shape[axis] >= 2:
+            exp = R.pad_nd(a, w, {axis: bc}, {axis: fill})
+            got = dev.tohost(dev.pad_nd(a, w, {axis: bc}, {axis: fill}))
+            assert got.dtype == exp.dtype and np.array_equal(got, exp), (dtype, shape, w, bc)
+
+
 @pytest.fixture(params=[1, 2], ids=["default-kernels", "chained-kernels-forced"])
 def scan_chain(request):
     """The fuzz shapes are too short for the chained scans / reductions (K5c / K4c) to be picked: run them a second time
