@@ -71,6 +71,44 @@ def test_cumsum_then_diff_round_trip_full_size(env):
     assert _same(torch, tot.data, c.data[NZ])
 
 
+@pytest.mark.parametrize("dtype", ["int64", "int32", "uint32"])
+def test_integer_fields_full_size(env, dtype):
+    """integer lanes at BASELINE size (*_i64 / *_i32 builds): values over the whole range of the dtype, so every sum and
+    difference WRAPS -- and the round trips still close exactly, because two's-complement arithmetic is a ring:
+    diff(outer->center) of cumsum(center->outer) is the identity modulo 2^64, a periodic diff sums to zero along its axis,
+    min <= max in the dtype's own order; spot slabs against numpy."""
+    torch, grid, DataArray = env["torch"], env["grid"], env["DataArray"]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    raw = torch.randint(-(2 ** 63), 2 ** 63 - 1, (NZ, NY, NX), device="cuda", dtype=torch.int64, generator=g)
+    tdt = getattr(torch, dtype)
+    x = raw if dtype == "int64" else raw.to(torch.int32).view(tdt)
+    da = DataArray(x, ("Z", "YC", "XC"))
+    c = grid.cumsum(da, "Z", to="outer")
+    want_c = {"int64": torch.int64, "int32": torch.int64, "uint32": torch.uint64}[dtype]
+    assert c.data.dtype == want_c and c.shape == (NZ + 1, NY, NX)
+    back = grid.diff(c, "Z")
+    wide = x.to(torch.int64) if dtype != "uint32" else x.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+    assert _same(torch, back.data.view(torch.int64), wide)
+    for ax, dim in (("X", 2), ("Y", 1)):
+        d = grid.diff(da, ax, padding="periodic")
+        assert d.data.dtype == tdt
+        lanes = d.data if dtype == "int64" else d.data.view(torch.int32)
+        total = lanes.to(torch.int64).sum(dim)  # wraps modulo 2^64; the true sum of a periodic difference is 0 modulo 2^bits
+        mod = total if dtype == "int64" else total & 0xFFFFFFFF
+        assert not bool(mod.any())
+        lo, hi = grid.min(da, ax, padding="periodic").data, grid.max(da, ax, padding="periodic").data
+        if dtype == "uint32":
+            lo, hi = lo.view(torch.int32).to(torch.int64) & 0xFFFFFFFF, hi.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        assert bool((lo <= hi).all())
+    k = min(2, NZ - 1)
+    slab = x[k:k + 1, 100 % NY:100 % NY + 3].cpu().numpy() if dtype != "uint32" else x.view(torch.int32)[k:k + 1, 100 % NY:100 % NY + 3].cpu().numpy().view(np.uint32)
+    for op in ("diff", "max", "interp"):
+        got = getattr(grid, op)(da, "X", padding="periodic").data[k:k + 1, 100 % NY:100 % NY + 3]
+        got = got.view(torch.int32).cpu().numpy().view(np.uint32) if got.dtype == getattr(torch, "uint32", None) else got.cpu().numpy()
+        np.testing.assert_array_equal(got, R.stencil1d(op, slab, 2, 1, 0, "periodic"))
+
+
 def test_chained_scan_along_y_full_size(env):
     """cumsum along Y of the full 75 x 2400 x 3600 field runs as the chained flat launch (K5c: 75 chunks of 32 rows per
     column hand their running sum on): on integer-valued data every partial sum is exact, so (a) the last kept row equals

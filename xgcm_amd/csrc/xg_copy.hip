@@ -138,6 +138,35 @@ __global__ void __launch_bounds__(BLOCK) k_copy_gather(const T* __restrict__ src
   dst[dof] = src[so];
 }
 
+// the same with 16-byte destination groups: the destination's last dim has unit stride and a multiple of V elements, every
+// row starts 16-B aligned -- V strided loads, one vector store (4-byte lanes moved 256 B per wave and store: 0.38 of 8 TB/s)
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_copy_gather_vec(const T* __restrict__ src, T* __restrict__ dst, CopyGeo g, u64 groups) {
+  constexpr int V = 16 / (int)sizeof(T);
+  typedef T tv __attribute__((ext_vector_type(V)));
+  const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= groups) return;
+  const int L = g.nd - 1;
+  const u64 per_row = (u64)g.shape[L] / V;
+  u64 r = i / per_row;
+  const int64_t x0 = (int64_t)(i - r * per_row) * V;
+  int64_t so = x0 * g.ss[L], dof = x0;
+#pragma unroll
+  for (int d = CMAX - 2; d >= 0; --d) {
+    if (d < L) {
+      const u64 q = r / (u64)g.shape[d];
+      const int64_t k = (int64_t)(r - q * (u64)g.shape[d]);
+      so += k * g.ss[d];
+      dof += k * g.ds[d];
+      r = q;
+    }
+  }
+  tv v;
+#pragma unroll
+  for (int k = 0; k < V; ++k) v[k] = src[so + k * g.ss[L]];
+  *reinterpret_cast<tv*>(dst + dof) = v;
+}
+
 template <typename T>
 int copy_launch(const void* src_, void* dst_, const CopyGeo& g, hipStream_t st) {
   const T* src = static_cast<const T*>(src_);
@@ -198,6 +227,17 @@ int copy_launch(const void* src_, void* dst_, const CopyGeo& g, hipStream_t st) 
       XG_LAUNCH_CHECK();
       return XG_OK;
     }
+  }
+  bool gvec = dst_unit && sizeof(T) < 8 && g.shape[L] % V == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+  for (int d = 0; d < L && gvec; ++d)
+    if (g.shape[d] > 1 && g.ds[d] % V) gvec = false;
+  if (gvec) {
+    const u64 groups = total / V, nb = (groups + BLOCK - 1) / BLOCK;
+    int rc = check_grid(nb);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_copy_gather_vec<T>), dim3((u32)nb), dim3(BLOCK), 0, st, src, dst, g, groups);
+    XG_LAUNCH_CHECK();
+    return XG_OK;
   }
   const u64 nblocks = (total + BLOCK - 1) / BLOCK;
   int rc = check_grid(nblocks);
