@@ -1396,7 +1396,13 @@ bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void
     const u64 nout = ncol / ctile;  // outer indices (level groups) per x-tile
     if (nout >= 2 && nout < 0x7fffffffull) {
       ch->tmaj = (u32)nout;
-      ch->W = (u32)(nout * ((56 + nout - 1) / nout));
+      // (scan_chain_tmaj = k > 1: all levels of k x-tiles side by side -- k times the chains in flight, k times the
+      // distance between the chunks of a column.  Round 4, paired over 5 placements, cumint Y: k = 1 / 2 / 3 / 4 / 6 -> time
+      // +7.3 / +3.0 / +2.9 / +2.5 / +2.7 %, traffic 1.008 / 1.010 / 1.013 / 1.017 / 1.026x against 1.106x: the stall of the
+      // single-tile order goes with the second tile, a 2.5 % cost of sweeping all levels at once stays.  Still off: the
+      // default is the fastest order; k = 4 is the setting for whoever shares the HBM.  profiles/r04q_ab_tmaj_*.log)
+      const u64 tiles = (56 + nout - 1) / nout > (u64)tune().scan_chain_tmaj ? (56 + nout - 1) / nout : (u64)tune().scan_chain_tmaj;
+      ch->W = (u32)(nout * tiles);
     }
   }
   if (ch->W > ch->cpx) ch->W = ch->cpx;
