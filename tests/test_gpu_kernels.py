@@ -383,6 +383,33 @@ def test_weighted_march_orders_under_every_banding_setting(dev):
             _hip.set_tunable(k, v)
 
 
+def test_chained_scan_orders_with_a_metric_shared_by_the_levels(dev):
+    """`scan_chain_tmaj = k`: the chained cumint / weighted reduction whose metric is shared by the outer indices numbers
+    its columns x-tile-major and advances all levels of k x-tiles side by side (a traffic / time trade).
+    Every order hands the same running sums on: bit-identical results for k = 0 (level-major bands) ... 6, column counts that
+    do and do not fill the sub-bands, forward and reversed."""
+    from xgcm_amd import _hip
+    keep = {k: _hip.get_tunable(k) for k in ("scan_chain_tmaj", "reduce_ldsw")}
+    try:
+        _hip.set_tunable("reduce_ldsw", 0)  # the chained weighted reduction, not K4L
+        for shape in ((7, 300, 200), (3, 130, 1100), (11, 96, 64)):
+            a = _field(shape, 91, nan=True)
+            w = R.synthetic_metric((1,) + shape[1:], 92)
+            m_out = R.synthetic_metric((1, shape[1], shape[2]), 93)
+            want_c = R.cumsum1d(a, 1, 0, 1, 1, 0, "fill", 0.0, False, True, np.broadcast_to(w, shape), m_out)
+            want_r = R.cumsum1d(a, 1, 0, 0, 0, 0, None, 0.0, True, True, np.broadcast_to(w, shape), None)
+            with np.errstate(invalid="ignore"):
+                want_s = R.integrate(a, 1, np.broadcast_to(w, shape), True)
+            for k in (0, 1, 2, 4, 6):
+                _hip.set_tunable("scan_chain_tmaj", k)
+                _eq(dev.tohost(dev.cumsum1d(a, 1, 0, 1, 1, 0, "fill", 0.0, False, True, w, m_out)), want_c)
+                _eq(dev.tohost(dev.cumsum1d(a, 1, 0, 0, 0, 0, None, 0.0, True, True, w, None)), want_r)
+                _eq(dev.tohost(dev.reduce1d(a, 1, w, True)), want_s)
+    finally:
+        for k, v in keep.items():
+            _hip.set_tunable(k, v)
+
+
 def test_chained_scans_on_two_streams(dev):
     """The chained kernels keep their hand-off slots and ticket counters in a workspace PER STREAM: two streams running
     long scans / weighted reductions at the same time do not see each other's running sums."""

@@ -17,4 +17,7 @@ for seed in range(1000, 1150):
         _hip.set_tunable("scan_chain", 1)
         F.test_fuzz_row_scan_any_length(dev, seed, dtype); n += 1
         F.test_fuzz_two_axis_and_vorticity(dev, seed, dtype); n += 1
+for seed in range(1000, 1020):  # the integer builds (*_i32 / *_i64): every dtype, 20 further seeds
+    for dtype in F.INT_DTYPES:
+        F.test_fuzz_integer_lanes(dev, seed, dtype); n += 1
 print(f"{n} extra fuzz runs passed in {time.time()-t0:.0f} s")
