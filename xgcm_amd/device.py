@@ -271,9 +271,13 @@ def _prep_metric(m, dtype) -> Optional[torch.Tensor]:
 # numpy in -> numpy out is the reference's normal case.  One synchronous pageable H2D, the kernel and one
 # synchronous D2H move a 1.4 GB field at ~8 GB/s; cutting it into blocks of the outermost dim (never the operator's
 # own axis here) and running them through xgcm_amd.streaming -- host memory page-locked in place, H2D of block k+1,
-# the kernel on block k and D2H of block k-1 on three HIP streams -- reaches ~30 GB/s each way, the PCIe rate.
+# the kernel on block k and D2H of block k-1 on three HIP streams -- reaches ~40 GB/s each way (the link: 48.6).
 HOST_STREAM_MIN_BYTES = 256 << 20   # host arrays at least this large take the pipelined path
-HOST_STREAM_BLOCK_BYTES = 128 << 20  # target size of one block
+# one block: a sixth of the array, between 64 MB and 2 GB.  Every block costs hand-offs between the threads and streams of
+# the pipeline and its own page-locking call, the first and the last block travel alone: a 5.2 GB record into a fresh
+# result array in 75 / 25 / 13 / 6 blocks: 0.19 / 0.19 / 0.19 / 0.14 s = 38 GB/s each way (into a reused, touched array:
+# 0.19 s in 75 blocks, 0.13 s in 19 or 5; tools/pcie_probe.py)
+HOST_STREAM_BLOCK_BYTES = (64 << 20, 2 << 30)
 
 
 def _host_streamable(x, axis: int) -> bool:
@@ -295,7 +299,9 @@ def _streamed(per_block, x: np.ndarray) -> np.ndarray:
     from .streaming import record_blocks, stream_records
 
     x = np.ascontiguousarray(x)
-    block = max(1, int(HOST_STREAM_BLOCK_BYTES // max(1, x.nbytes // x.shape[0])))
+    lo, hi = HOST_STREAM_BLOCK_BYTES if isinstance(HOST_STREAM_BLOCK_BYTES, tuple) else (HOST_STREAM_BLOCK_BYTES,) * 2
+    target = min(max(x.nbytes // 6, lo), hi)
+    block = max(1, int(target // max(1, x.nbytes // x.shape[0])))
     spans = iter(record_blocks(x.shape[0], block))
 
     def on_block(t):
