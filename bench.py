@@ -126,6 +126,51 @@ def cpu_baseline(levels=8, budget_s=20.0):
     return out
 
 
+def pmc_passes(dominant: str, levels: int, alg_bytes: float, timeout_s: int = 120):
+    """HBM bytes per launch of the dominant kernel measured NOW: two child runs of this file under `rocprofv3 --pmc`, one
+    counter per pass (FETCH_SIZE, WRITE_SIZE) with `--kernel-trace` only -- never combined with another trace domain --
+    and the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE counts KiB and reports half of a wide streaming read:
+    bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE * 1024).  Returns (bytes or None, how / why not, seconds spent)."""
+    import glob
+    import shutil
+    import signal
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    t0 = time.perf_counter()
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found", 0.0
+    tmp = tempfile.mkdtemp(prefix="xg_pmc_", dir="/tmp")
+    env = dict(os.environ, XG_BENCH_PMC="0", XG_BENCH_PRIME="1", TMPDIR="/tmp")
+    kib = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "1", "--levels", str(levels), "--no-cpu-baseline", "--no-pmc"]
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                proc.wait(timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)
+                return None, f"the {counter} pass did not finish in {timeout_s} s", time.perf_counter() - t0
+            dbs = sorted(glob.glob(os.path.join(out, "**", "*.db"), recursive=True))
+            if proc.returncode != 0 or not dbs:
+                return None, f"the {counter} pass failed (rc {proc.returncode})", time.perf_counter() - t0
+            rows = sqlite3.connect(dbs[0]).execute(
+                "select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
+            # full-size launches of the dominant kernel (the one-level spot check launches the same kernels on 1 / 75 of the data)
+            vals = [v for name, v in rows if dominant in name and v * 1024 > 0.2 * alg_bytes]
+            if not vals:
+                return None, f"no {dominant} dispatch in the {counter} pass", time.perf_counter() - t0
+            kib[counter] = sum(vals) / len(vals)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return kib["FETCH_SIZE"] * 1024 * 2 + kib["WRITE_SIZE"] * 1024, "measured", time.perf_counter() - t0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,6 +178,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--levels", type=int, default=NZ, help="Z levels (default = the full 75; smaller only for debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child passes (N = 1 only; "
+                    "also XG_BENCH_PMC=0): the committed figure of profiles/pmc_traffic.json is reported instead")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -229,16 +276,27 @@ def main():
         # HBM bytes per launch of the dominant kernel: NOT measured in this run (counter passes serialise the kernels and
         # need rocprofv3 around the process) but in separate `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes of this
         # same command, whose summary is committed next to the number; `traffic_source` names it
-        traffic, traffic_source = None, None
+        traffic, traffic_source, measured_now, pmc_s = None, None, False, 0.0
+        under_profiler = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+        if world == 1 and dist is None and not args.no_pmc and os.environ.get("XG_BENCH_PMC", "1") != "0" and not under_profiler:
+            # N = 1: measured in THIS run, after the timed region, by two short child passes of this command
+            traffic, how, pmc_s = pmc_passes(dominant, nz, alg_bytes)
+            if traffic is not None:
+                measured_now = True
+                traffic_source = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command after the timed region "
+                                  f"({pmc_s:.0f} s; FETCH_SIZE doubled per MI355X_MICROARCH.md)")
+            else:
+                traffic_source = f"live PMC passes unavailable ({how}); "
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if traffic is None and os.path.exists(pmc):
             try:
                 table = json.load(open(pmc))
                 traffic = table.get(dominant)
                 if traffic is not None:
-                    traffic_source = "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " + str(table.get("_source", "profiles/pmc_traffic.json"))
+                    traffic_source = (traffic_source or "") + "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " + \
+                        str(table.get("_source", "profiles/pmc_traffic.json"))
             except Exception:
-                traffic, traffic_source = None, None
+                traffic = None
         line = {
             "metric": "stencil-cells/s, Grid.interp+Grid.diff (X periodic, Y extend) on 3600x2400x75 f64",
             "value": round(total_cells / elapsed / 1e9, 3),
@@ -260,7 +318,9 @@ def main():
             "achieved_GBps_whole_step": round(total_cells * BYTES_PER_CELL / elapsed / 1e9 / world, 1),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "traffic_measured_in_run": False,  # replayed from the committed PMC passes named in traffic_source
+                         # True: the two PMC child passes above ran now; False: replayed from the committed passes named in
+                         # traffic_source (N > 1, --no-pmc, no rocprofv3, or a pass that failed)
+                         "traffic_measured_in_run": measured_now, "traffic_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
                          "per_op_ms": {f"{fn}_{ax}": round(ms, 4) for (fn, ax), ms in zip(OPS, per_op_ms)}},
             "ranks": {"world_size": n_ranks, "backend": "nccl (RCCL)" if dist is not None else "single process",

@@ -59,6 +59,24 @@ def test_two_ranks_on_the_real_library_equal_one_rank_and_the_oracle():
     assert ops1[2]["checksum_u64"] == chk and ops1[3]["checksum_u64"] == chk
 
 
+def test_bench_line_measures_its_hbm_traffic_in_the_run():
+    """`roofline.traffic` of the N = 1 line comes from two `rocprofv3 --pmc` child passes of the same command made after the
+    timed region (FETCH_SIZE, WRITE_SIZE, one per pass); the flat stencils move their algorithmic bytes and nothing else.
+    Without rocprofv3 the committed figure is reported and flagged."""
+    import shutil
+
+    p, lines = _run([BENCH, "--steps", "3", "--warmup", "1", "--levels", "12", "--no-cpu-baseline"], timeout=500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    roof = lines[-1]["roofline"]
+    if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):
+        assert roof["traffic_measured_in_run"] is True, roof["traffic_source"]
+        assert 0.98 <= roof["traffic_over_algorithmic"] <= 1.05, roof
+    else:
+        assert roof["traffic_measured_in_run"] is False
+    p, lines = _run([BENCH, "--steps", "2", "--warmup", "0", "--levels", "4", "--no-cpu-baseline", "--no-pmc"])
+    assert p.returncode == 0 and lines[-1]["roofline"]["traffic_measured_in_run"] is False
+
+
 def test_bench_through_rccl_with_one_rank():
     p, lines = _run([BENCH, "--gpus", "1", "--steps", "2", "--warmup", "1", "--levels", "4", "--no-cpu-baseline"],
                     {"XG_BENCH_FORCE_DIST": "1"})

@@ -59,7 +59,7 @@ def main():
             skipped.append(n)
             continue
         if not a.skip_bench:
-            rc, lines, err = run([sys.executable, "bench.py", "--gpus", str(n), "--steps", str(a.steps), "--warmup", str(a.warmup), "--no-cpu-baseline"])
+            rc, lines, err = run([sys.executable, "bench.py", "--gpus", str(n), "--steps", str(a.steps), "--warmup", str(a.warmup), "--no-cpu-baseline", "--no-pmc"])
             for ln in lines:
                 if "value" in ln:
                     per = ln["ranks"]["per_rank_ms_per_step"]
