@@ -34,7 +34,7 @@ def main():
                     "profiles/r04a_addr_probe.jsonl -- so a table that is to agree with another process's must report the median over placements")
     a = ap.parse_args()
     bscale = 1.0
-    if a.dtype == "f32":  # (the transform cases build their coordinates in float64: not covered)
+    if a.dtype == "f32":
         import functools
         D.synthetic = functools.partial(D.synthetic, dtype=torch.float32)
         bscale = 0.5
@@ -115,6 +115,8 @@ def main():
         del zz, yy, xx, wave2
         levels = torch.linspace(1.0, 0.9 * nz, mt, dtype=torch.float64, device="cuda").reshape(mt, 1, 1)
         edges = torch.linspace(0.0, 1.6 * (nz + 1), mt + 1, dtype=torch.float64, device="cuda")
+        if a.dtype == "f32":  # coordinates of a float32 field are float32 too (MITgcm / LLC4320 output)
+            th_sm, tho_sm, levels, edges = th_sm.float(), tho_sm.float(), levels.float(), edges.float()
         CASES.update({
             "tlin_rw": (lambda: D.transform_linear(T, th_rw, levels, 0), (2 * nz + mt) * 8 / nz),
             "tlin_sm": (lambda: D.transform_linear(T, th_sm, levels, 0), (2 * nz + mt) * 8 / nz),
