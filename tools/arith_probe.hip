@@ -226,6 +226,42 @@ __global__ __launch_bounds__(256) void k_march(const double* __restrict__ phi, c
   }
 }
 
+// the same march on FLOAT32 data with V columns per lane (4-, 8-, 16-byte lanes): what a float32 transform column costs
+// when a lane owns one column (a 256-B wave-row) against two or four
+template <int V, int D>
+__global__ __launch_bounds__(256) void k_march_f32(const float* __restrict__ phi, const float* __restrict__ theta, float* __restrict__ out,
+                                                   u32 ngroups, int m) {
+  typedef float fv __attribute__((ext_vector_type(V)));
+  const u32 c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ngroups) return;
+  const size_t plane = (size_t)NY * NX;
+  const float* pp = phi + (size_t)V * c;
+  const float* pt = theta + (size_t)V * c;
+  float* po = out + (size_t)V * c;
+  fv acc = 0.0f;
+  fv t0 = __builtin_nontemporal_load((const fv*)pt);
+  int jo = 0;
+  for (int k = 0; k < NZ; k += 5) {
+    fv p[5], t[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      p[u] = __builtin_nontemporal_load((const fv*)(pp + (size_t)(k + u) * plane));
+      t[u] = __builtin_nontemporal_load((const fv*)(pt + (size_t)(k + u + 1) * plane));
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      fv dz = t[u] - t0;
+      fv v = p[u];
+#pragma unroll
+      for (int d = 0; d < D; ++d) v = v / dz;
+      if (D == 0) v = v + dz;
+      acc = acc + v;
+      t0 = t[u];
+      if ((k + u) % 3 != 2 && jo < m) { __builtin_nontemporal_store(acc, (fv*)(po + (size_t)jo * plane)); ++jo; }
+    }
+  }
+}
+
 template <typename F>
 float timeit(F f, int reps = 9) {
   hipEvent_t e0, e1;
@@ -291,6 +327,16 @@ int main() {
     MARCH(1, "B march + 1 division per cell")
     MARCH(2, "B march + 2 divisions per cell (conservative: 1.67 on average)")
     MARCH(99, "B march + 0..4 divisions per cell, DIVERGENT per lane (mean 1.67)")
+    // float32: the same buffers read as floats (twice the columns per plane are not needed: the first half of every plane)
+#define MARCHF(V, D, name) { const u32 ng = (u32)(plane / V); \
+    float ms = timeit([&] { hipLaunchKernelGGL((k_march_f32<V, D>), dim3((ng + 255) / 256), dim3(256), 0, 0, (const float*)a, (const float*)th, (float*)o, ng, m); }); \
+    rep(name, ms, 4.0 * (2.0 * n + plane + (double)m * plane)); }
+    MARCHF(1, 0, "F float32 march, 1 column per lane (4-byte lanes), no arithmetic")
+    MARCHF(2, 0, "F float32 march, 2 columns per lane (8-byte lanes)")
+    MARCHF(4, 0, "F float32 march, 4 columns per lane (16-byte lanes)")
+    MARCHF(1, 1, "F float32 march, 1 column per lane + 1 division per cell")
+    MARCHF(2, 1, "F float32 march, 2 columns per lane + 1 division per cell")
+    MARCHF(4, 1, "F float32 march, 4 columns per lane + 1 division per cell")
   }
   return 0;
 }
