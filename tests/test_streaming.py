@@ -47,6 +47,70 @@ def test_stream_records_matches_oracle(register, block, dtype):
 
 
 @pytest.mark.gpu
+def test_stream_records_large_blocks_locked_piecewise(tmp_path):
+    """arrays above the whole-array threshold are page-locked block by block in helper threads, every block's copy cut at
+    the page boundary its neighbour's range ends on (`_BlockPinner.pieces`): records whose size is NOT a multiple of the
+    page, into a fresh output and into a caller's; a read-only memory map as the source (locked or not, as the driver
+    allows); the same array again afterwards (nothing stays locked behind a call)"""
+    from xgcm_amd import device as dev
+    from xgcm_amd import streaming as S
+
+    old = S._BlockPinner.WHOLE_BELOW
+    S._BlockPinner.WHOLE_BELOW = 1 << 20  # 1 MB: the test arrays take the block-wise path
+    try:
+        nrec, shape = 7, (3, 41, 517)  # 508 728 bytes per record: no block boundary falls on a page boundary
+        src = R.synthetic_field((nrec,) + shape, 21)
+        want = R.stencil1d("diff", src, 3, 1, 0, "periodic")
+        fn = lambda x: dev.stencil1d("diff", x, 3, 1, 0, "periodic")  # noqa: E731
+        for block in (1, 2, 3):
+            np.testing.assert_array_equal(stream_records(fn, src, block=block), want)
+        out = np.full_like(src, 7.0)
+        assert stream_records(fn, src, block=2, out=out) is out
+        np.testing.assert_array_equal(out, want)
+        np.testing.assert_array_equal(stream_records(fn, src, block=2), want)  # the same memory locked again: nothing leaked
+        path = tmp_path / "records.bin"
+        src.tofile(path)
+        mm = np.memmap(path, dtype=np.float64, mode="r", shape=src.shape)
+        np.testing.assert_array_equal(stream_records(fn, mm, block=2), want)
+        ro = np.empty_like(src)
+        ro.flags.writeable = False
+        with pytest.raises(ValueError, match="read-only"):
+            stream_records(fn, src, block=2, out=ro)
+        with pytest.raises(ValueError, match="dtype"):
+            stream_records(fn, src, block=2, out=np.empty(src.shape, dtype=np.float32))
+    finally:
+        S._BlockPinner.WHOLE_BELOW = old
+
+
+@pytest.mark.gpu
+def test_stream_records_survives_a_failing_block():
+    """an exception raised by `fn` in the middle of the stream reaches the caller, the helper threads and page locks are
+    gone, and the next call on the same arrays runs"""
+    from xgcm_amd import device as dev
+    from xgcm_amd import streaming as S
+
+    old = S._BlockPinner.WHOLE_BELOW
+    S._BlockPinner.WHOLE_BELOW = 1 << 20
+    try:
+        src = R.synthetic_field((6, 4, 64, 512), 22)
+        calls = []
+
+        def fn(x):
+            calls.append(1)
+            if len(calls) == 3:
+                raise RuntimeError("block 3 refuses")
+            return dev.stencil1d("interp", x, 3, 0, 1, "extend")
+
+        with pytest.raises(RuntimeError, match="block 3 refuses"):
+            stream_records(fn, src, block=1)
+        calls.clear()
+        calls.extend([0] * 10)  # (never 3 again)
+        np.testing.assert_array_equal(stream_records(fn, src, block=1), R.stencil1d("interp", src, 3, 0, 1, "extend"))
+    finally:
+        S._BlockPinner.WHOLE_BELOW = old
+
+
+@pytest.mark.gpu
 def test_stream_apply_through_the_grid():
     nt, nz, ny, nx = 4, 3, 5, 64
     ds = Dataset(coords={"XC": np.arange(nx) + 0.5, "XG": np.arange(nx) * 1.0})

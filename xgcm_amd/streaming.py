@@ -261,6 +261,10 @@ def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, 
                     out = np.empty((n,) + tuple(y.shape[1:]), dtype=np.float32 if y.dtype == torch.float32 else np.float64)
                 if not out.flags.c_contiguous or out.shape[0] != n or tuple(out.shape[1:]) != tuple(y.shape[1:]):
                     raise ValueError("`out` must be C-contiguous with the result's shape")
+                if not out.flags.writeable:
+                    raise ValueError("`out` is read-only")
+                if out.dtype != (np.float32 if y.dtype == torch.float32 else np.float64):
+                    raise ValueError(f"`out` has dtype {out.dtype}, the result is {str(y.dtype).replace('torch.', '')}")
                 pin_out = _BlockPinner(out, blocks, register, prefault=True)
                 out_t = pin_out.tensor
             while len(futs) >= 2:  # at most two results parked in HBM
