@@ -71,6 +71,23 @@ class Grid:
         if not isinstance(ds, Dataset):
             raise TypeError(f"ds argument to `xgcm.Grid` must be of type xarray.Dataset, but is of type {type(ds)}")
         self._ds = ds
+        if autoparse_metadata:
+            # COMODO attributes / SGRID topology of the dataset supply what the caller left out; what BOTH supply is a
+            # conflict, never a silent choice (xgcm/grid.py:151-195 -- `coords` is always among the parsed kwargs, so
+            # explicit `coords` need `autoparse_metadata=False` exactly as there)
+            from .metadata import parse_metadata
+
+            parsed = parse_metadata(ds)
+            given = {"coords": coords, "fill_value": fill_value, "default_shifts": default_shifts, "padding": padding,
+                     "face_connections": face_connections, "metrics": metrics}
+            duplicates = [k for k in given if k in parsed and given[k] is not None]
+            if duplicates:
+                raise ValueError(
+                    f"Autoparsed Grid kwargs: '{', '.join(duplicates)}' conflict with "
+                    f"user-supplied kwargs. Run with 'autoparse_metadata=False', or "
+                    f"autoparse and amend kwargs before calling Grid constructer."
+                )
+            coords = parsed.get("coords", coords)
         if "periodic" in kwargs:
             raise ValueError(
                 "The `periodic` argument has been removed. Use "
@@ -88,8 +105,7 @@ class Grid:
                 "in future versions. Provide `fill_value=0.0` to preserve previous behavior.",
                 category=DeprecationWarning,
             )
-        if coords is None:
-            # COMODO / SGRID attribute parsing (reference metadata_parsers.py) is outside the hot path
+        if not coords:  # (nothing given and nothing parsed: the reference fails on its first use of the empty mapping)
             raise ValueError(
                 "Could not determine Axis names - please provide them in the coords kwarg "
                 "or provide a dataset from which they can be parsed"
