@@ -187,3 +187,25 @@ def test_face_connections_against_an_installed_reference_package(backend, conn):
             np.testing.assert_array_equal(getattr(mine, op)(ds["c"], ax, padding="extend").values,
                                           getattr(ref, op)(ds["c"], ax, padding="extend").values)
 
+
+def test_grid_from_comodo_attributes_on_real_xarray(backend):
+    """`Grid(ds)` with the reference's default `autoparse_metadata=True`: axes read off the coordinates' `axis` /
+    `c_grid_axis_shift` attributes (xgcm/comodo.py:23-142), data variables untouched until a metric is asked for; the same
+    grid as an installed reference package builds, where there is one"""
+    ds = _dataset()
+    ds["XC"].attrs["axis"] = "X"
+    ds["XG"].attrs.update({"axis": "X", "c_grid_axis_shift": -0.5})
+    grid = Grid(ds, padding="periodic", metrics={("X",): ["dx"]})
+    assert dict(grid.axes["X"].coords) == {"center": "XC", "left": "XG"}
+    with pytest.raises(ValueError, match="Autoparsed Grid kwargs: 'coords' conflict"):
+        Grid(ds, coords={"X": {"center": "XC", "left": "XG"}})
+    out = grid.derivative(ds["v"], "X")
+    assert isinstance(out, xr.DataArray) and out.dims == ("time", "XG")
+    try:
+        import xgcm
+    except ImportError:
+        return
+    ref = xgcm.Grid(ds, padding="periodic", metrics={("X",): ["dx"]})
+    assert dict(ref.axes["X"].coords) == dict(grid.axes["X"].coords)
+    np.testing.assert_allclose(out.values, ref.derivative(ds["v"], "X").values, rtol=1e-12, atol=1e-12)
+

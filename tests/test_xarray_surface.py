@@ -30,7 +30,9 @@ def test_bridge_recognises_the_package_by_name(xr):
     ds = _dataset(xr)
     assert L.is_xarray(ds) and L.is_xarray(ds["v"]) and not L.is_xarray(np.zeros(3))
     inner = L.from_xarray(ds)
-    assert isinstance(inner, L.Dataset) and set(inner.data_vars) == {"v", "dx"} and inner.attrs == {"title": "toy"}
+    assert isinstance(inner, L.Dataset) and "v" in inner and "dx" in inner and inner.attrs == {"title": "toy"}
+    assert not inner.data_vars  # data variables are fetched when they are indexed, not when the dataset is converted
+    assert set(inner.variables) >= {"v", "dx"} and set(inner.data_vars) == {"v", "dx"}
     assert inner.coords["lon_g"].attrs == {"units": "degrees_east"} and inner["v"].dims == ("time", "XC")
     back = L.to_xarray(L.from_xarray(ds["v"]))
     assert type(back).__name__ == "DataArray" and L.is_xarray(back)
@@ -100,6 +102,32 @@ def test_integrate_average_and_user_grid_ufunc_return_xarray(xr):
                               signature="(X:center)->(X:left)", padding_width={"X": (1, 0)})
     assert L.is_xarray(out) and out.dims == ("time", "XG")
     np.testing.assert_array_equal(out.values, R.stencil1d("diff", ds["v"].values, 1, 1, 0, "periodic"))
+
+
+def test_grid_of_a_dataset_reads_coordinates_and_metrics_only(xr):
+    """`Grid(ds)` of a model run must not read the run: converting an xarray.Dataset takes the coordinates, the data variables
+    stay in the source until one is indexed (a metric named in `metrics=`); COMODO attributes on real-xarray-shaped
+    coordinates are enough to build the grid"""
+    ds = _dataset(xr)
+
+    class Untouchable:
+        dims, shape, attrs, chunks, dtype = ("time", "XC"), (8, 8), {"units": "K"}, None, np.dtype("float64")
+
+        @property
+        def values(self):
+            raise AssertionError("the model output was read")
+
+    ds.data_vars["theta"] = Untouchable()
+    ds.coords["XC"].attrs["axis"] = "X"
+    ds.coords["XG"].attrs.update({"axis": "X", "c_grid_axis_shift": -0.5})
+    grid = Grid(ds, padding="periodic", metrics={("X",): ["dx"]})  # autoparsed from the attributes
+    assert dict(grid.axes["X"].coords) == {"center": "XC", "left": "XG"}
+    inner = grid._ds
+    assert "theta" in inner and "theta" not in inner.data_vars and "dx" in inner.data_vars
+    out = grid.diff(ds["v"], "X")
+    np.testing.assert_array_equal(out.values, R.stencil1d("diff", ds["v"].values, 1, 1, 0, "periodic"))
+    with pytest.raises(AssertionError, match="the model output was read"):
+        inner["theta"]
 
 
 def test_chunked_input_is_refused_with_the_documented_message(xr):

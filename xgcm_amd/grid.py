@@ -294,7 +294,7 @@ class Grid:
             raise KeyError(f"Metric axes {missing!r} not compatible with grid axes {tuple(self.axes)!r}")
         varnames = _maybe_promote_str_to_list(value)
         for v in varnames:
-            if v not in self._ds.variables:
+            if v not in self._ds:  # (membership only: a converted xarray.Dataset loads a variable when it is indexed)
                 raise KeyError(f"Metric variable {v} not found in dataset.")
         if metric_axes in self._metrics:
             # NB the reference only considers the LAST name of `value` here (grid.py:488-512)

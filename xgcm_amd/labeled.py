@@ -348,6 +348,9 @@ class Dataset:
         self.coords: "OrderedDict[str, DataArray]" = OrderedDict()
         self.attrs = dict(attrs) if attrs else {}
         self._sizes: Dict[str, int] = {}
+        # data variables of a converted xarray.Dataset stay where they are until somebody asks for one (`from_xarray`):
+        # a Grid needs coordinates and a handful of metrics, not the model output
+        self._lazy: "OrderedDict[str, Tuple[dict, Any]]" = OrderedDict()  # name -> (attrs, loader)
         for k, v in (coords or {}).items():
             self._add(k, v, True)
         for k, v in (data_vars or {}).items():
@@ -380,16 +383,31 @@ class Dataset:
 
     sizes = dims
 
+    def _load(self, key: str) -> None:
+        attrs, loader = self._lazy.pop(key)
+        self._add(key, loader(), False)
+
     @property
     def variables(self) -> Dict[str, DataArray]:
+        for key in list(self._lazy):
+            self._load(key)
         out = OrderedDict(self.coords)
         out.update(self.data_vars)
         return out
 
+    def variable_attrs(self) -> Dict[str, dict]:
+        """attrs of every variable, without loading the data of those still waiting in the source dataset"""
+        out = OrderedDict((k, c.attrs) for k, c in self.coords.items())
+        out.update((k, v.attrs) for k, v in self.data_vars.items())
+        out.update((k, a) for k, (a, _) in self._lazy.items())
+        return out
+
     def __contains__(self, key) -> bool:
-        return key in self.data_vars or key in self.coords
+        return key in self.data_vars or key in self.coords or key in self._lazy
 
     def __getitem__(self, key: str) -> DataArray:
+        if key in self._lazy:
+            self._load(key)
         if key in self.data_vars:
             base = self.data_vars[key]
         elif key in self.coords:
@@ -415,10 +433,11 @@ class Dataset:
         out.coords = OrderedDict(self.coords)
         out.data_vars = OrderedDict(self.data_vars)
         out._sizes = dict(self._sizes)
+        out._lazy = OrderedDict(self._lazy)
         return out
 
     def __repr__(self) -> str:
-        return f"<xgcm_amd.Dataset dims={self._sizes} data_vars={list(self.data_vars)} coords={list(self.coords)}>"
+        return f"<xgcm_amd.Dataset dims={self._sizes} data_vars={list(self.data_vars) + list(self._lazy)} coords={list(self.coords)}>"
 
 
 # ---- optional bridges to real xarray ------------------------------------------------------
@@ -443,9 +462,17 @@ def from_xarray(obj):
         coords = {k: (tuple(v.dims), np.asarray(v.values), dict(v.attrs)) for k, v in obj.coords.items()}
         return DataArray(np.asarray(obj.values), tuple(obj.dims), coords=coords, name=obj.name, attrs=dict(obj.attrs))
     if tname == "Dataset":
+        # coordinates now; data variables only when asked for (`Grid(ds)` of a model run must not read the run): their
+        # names, dims and attrs are known at once, their values are fetched by `ds[name]`
         coords = {k: (tuple(v.dims), np.asarray(v.values), dict(v.attrs)) for k, v in obj.coords.items()}
-        dvars = {k: (tuple(v.dims), np.asarray(v.values), dict(v.attrs)) for k, v in obj.data_vars.items()}
-        return Dataset(dvars, coords, attrs=dict(obj.attrs))
+        out = Dataset(None, coords, attrs=dict(obj.attrs))
+        for k, v in obj.data_vars.items():
+            dims, shape = tuple(v.dims), tuple(getattr(v, "shape", ()))
+            for d, n in zip(dims, shape):
+                if out._sizes.setdefault(d, int(n)) != int(n):
+                    raise ValueError(f"conflicting sizes for dimension {d!r}: length {n} on {k!r} and length {out._sizes[d]}")
+            out._lazy[k] = (dict(v.attrs), (lambda v=v, k=k: DataArray(np.asarray(v.values), tuple(v.dims), name=k, attrs=dict(v.attrs))))
+        return out
     raise TypeError(type(obj))
 
 

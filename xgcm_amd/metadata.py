@@ -105,9 +105,9 @@ def is_sgrid(ds) -> bool:
 
 
 def _topology(ds) -> Tuple[str, dict]:
-    for name, var in ds.variables.items():
-        if var.attrs.get("cf_role") == "grid_topology":
-            return name, var.attrs
+    for name, attrs in ds.variable_attrs().items():  # (attrs only: no variable's data is read for this)
+        if attrs.get("cf_role") == "grid_topology":
+            return name, attrs
     raise ValueError("Could not find identify SGRID grid in input dataset.")
 
 
