@@ -263,8 +263,8 @@ int xg_copy_nd(const void* src, const int64_t* src_strides, void* dst, const int
     if (shape[d] < 0) return fail(XG_ERR_INVALID, "negative extent");
     if (shape[d] == 0) return XG_OK;
     if (shape[d] >= 0x7fffffffll) return fail(XG_ERR_UNSUPPORTED, "extent of 2^31 or more");
+    if (shape[d] == 1) continue;  // (whatever stride a dim of one element carries)
     if (dst_strides[d] < 0) return fail(XG_ERR_INVALID, "destination strides must be positive");
-    if (shape[d] == 1) continue;
     if (dst_strides[d] == 0) return fail(XG_ERR_INVALID, "destination stride 0 on a dim of extent %lld (cells written more than once)", (long long)shape[d]);
     sh[nd] = shape[d]; ss[nd] = src_strides[d]; ds[nd] = dst_strides[d];
     ++nd;

@@ -520,7 +520,7 @@ int xg_copy_nd(const void* src, const int64_t* ss, void* dst, const int64_t* ds,
   int64_t total = 1;
   for (int d = 0; d < ndim; ++d) {
     if (shape[d] < 0) return fail(XG_ERR_INVALID, "negative extent");
-    if (ds[d] < 0) return fail(XG_ERR_INVALID, "destination strides must be positive");
+    if (shape[d] > 1 && ds[d] < 0) return fail(XG_ERR_INVALID, "destination strides must be positive");
     if (shape[d] > 1 && ds[d] == 0) return fail(XG_ERR_INVALID, "destination stride 0 on a dim of extent %lld (cells written more than once)", (long long)shape[d]);
     total *= shape[d];
   }

@@ -69,7 +69,7 @@ def _comodo_positions(ds, axis: str, dims: List[str]) -> "OrderedDict[str, str]"
             found["outer"] = d
         elif length[d] == n - 1:
             found["inner"] = d
-        elif shift[d] in _SHIFT_OF and shift[d] is not True:
+        elif isinstance(shift[d], float) and shift[d] in _SHIFT_OF:
             side = _SHIFT_OF[shift[d]]
             if length[d] != n:
                 raise ValueError("%s coordinate %s has incompatible length %g (axis_len=%g)" % (side.capitalize(), d, length[d], n))
