@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--pmc", required=True, help="'|'-separated counter groups, each a space-separated list")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--shape", default="75,2400,3600")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--min-us", type=float, default=200.0, help="dispatches shorter than this are not reported")
     ap.add_argument("--pass-timeout", type=int, default=150, help="seconds one rocprofv3 pass may take")
     ap.add_argument("--placements", type=int, default=1, help="rounds on fresh buffers (ab_tunables --realloc): the reported duration is "
@@ -49,7 +50,7 @@ def main():
         # the group "TRACE" is a plain kernel-trace pass: durations without any counter collected
         cmd = ["rocprofv3"] + ([] if group == "TRACE" else ["--pmc"] + group.split()) + ["--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable,
                os.path.join(REPO, "tools", "ab_tunables.py"), "--cases", a.cases, "--variants", a.variants, "--rounds", str(max(1, a.placements)),
-               "--reps", str(a.reps), "--mark", "--shape", a.shape] + (["--realloc"] if a.placements > 1 else [])
+               "--reps", str(a.reps), "--mark", "--shape", a.shape, "--dtype", a.dtype] + (["--realloc"] if a.placements > 1 else [])
         env = dict(os.environ, TMPDIR="/tmp")
         try:  # a counter group the profiler cannot serve must not cost the session (TA_* counters hung a pass for 15 minutes)
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=ap_timeout)

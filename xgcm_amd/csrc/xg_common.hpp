@@ -131,7 +131,7 @@ struct Tune {
   int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
   int zb_rows;        // rows per band
-  int scan_block;     // workgroup size of the contiguous-axis scan (128 / 256 / 512 / 1024)
+  int scan_block;     // workgroup size of the contiguous-axis scan (64 / 128 / 256 / 512 / 1024; 0: 256, 128 for plain float32 rows)
   int strided_gen;    // flat NV-group kernel for misaligned rows of a strided stencil axis
   int march_band;     // XCD-banded wave order in the column-marching scans / reductions
   int scan_vec;       // aligned-output-group scan for cumsum along the contiguous axis
@@ -168,6 +168,7 @@ struct Tune {
   int march_ofast;    // marching weighted reductions whose weights are shared by the outer indices: outer indices fastest in the work order
   int reduce_sk;      // contiguous-axis reductions: kernels specialised for the plain sums (skipna False / True)
   int reduce_ru;      // contiguous-axis reductions: 4 independent 16-B loads per lane before the first addition
+  int reduce_wfast;   // contiguous-axis weighted reductions: unit-stride, row-aligned weights as one vector load per lane
   int reduce_ldsw;    // K4L: long weighted reductions with level-shared weights as a march whose weight rows go through LDS once per workgroup (0: chained K4cz)
   int reduce_zl;      // K4cz: outer indices per task of the chained weighted reduction sharing the weight rows (1 / 2 / 4)
   int dbg;            // A/B switches that do NOT change results (bit 2: the linear transform's division inside its loop)
@@ -569,6 +570,9 @@ template <typename T> __device__ __forceinline__ T ldm(const real* m, int64_t of
 template <> __device__ __forceinline__ real ldm<real>(const real* m, int64_t off, int64_t) { return m[off]; }
 #ifdef XG_REAL4
 template <> __device__ __forceinline__ hv ldm<hv>(const real* m, int64_t off, int64_t step) {
+  // metric contiguous along the lanes and 8-B aligned here: one dwordx2 load instead of two narrow ones
+  if (step == 1 && ((reinterpret_cast<uintptr_t>(m) / sizeof(real) + (uintptr_t)off) & 1) == 0)
+    return *reinterpret_cast<const hv*>(m + off);
   hv o;
   o[0] = m[off];
   o[1] = m[off + step];

@@ -27,7 +27,7 @@ const TuneEntry TUNABLES[] = {
     {"zchunk", &Tune::zchunk, 256},
     {"zband", &Tune::zband, 1},
     {"zb_rows", &Tune::zb_rows, 16},
-    {"scan_block", &Tune::scan_block, 256},
+    {"scan_block", &Tune::scan_block, 0},
     {"strided_gen", &Tune::strided_gen, 1},
     {"march_band", &Tune::march_band, 1},  // config 4 (8 records, cumsum along Z) 14.8 -> 13.1 ms
     {"scan_vec", &Tune::scan_vec, 1},
@@ -66,6 +66,7 @@ const TuneEntry TUNABLES[] = {
     {"march_ofast", &Tune::march_ofast, 1},
     {"reduce_sk", &Tune::reduce_sk, 1},
     {"reduce_ru", &Tune::reduce_ru, 1},
+    {"reduce_wfast", &Tune::reduce_wfast, 1},
     {"reduce_ldsw", &Tune::reduce_ldsw, 2},
     {"dbg", &Tune::dbg, 0},
     {"march_lds_kb", &Tune::march_lds_kb, 0},

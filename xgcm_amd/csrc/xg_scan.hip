@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_chain_z(
 // a shuffle tree (tolerance parity; numpy itself is pairwise here).
 // SK >= 0: the mode is a compile-time constant (the plain sums, skipna False / True: `integrate`, `sum`) -- decided per element
 // through select chains it cost 17 instructions per cell where one addition is needed (DESIGN rule 15); SK < 0: any mode.
-template <bool HAS_W, bool VEC, int SK>
+template <bool HAS_W, bool VEC, int SK, bool WFAST = false>
 __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict__ in,
                                                          real* __restrict__ out, Geo g, int skipna_rt,
                                                          const real* __restrict__ wgt, MIdx mw, int ntl, ZBand zb) {
@@ -1254,6 +1254,13 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
   const real* prow = in + row * n;
   int64_t mb = 0;
   if (HAS_W) mb = outer_off(g, mw, row);
+  // WFAST (host): the weights run along the rows with unit stride and every weight row starts on a 16-B boundary like
+  // the field's -- the weight vector of a lane is then ONE load at the field vector's own index from a wave-uniform row
+  // pointer.  The general form (`ldm`: a 64-bit multiply by the runtime stride and an alignment test per load) costs 5x
+  // the scalar and 2.2x the vector instructions of the unweighted kernel: float32 rows 0.76 -> 0.60 of 8 TB/s.  A
+  // compile-time switch: decided per load at run time it broke up the batch of independent loads (float32 0.60 -> 0.47).
+  constexpr bool wfast = HAS_W && WFAST;
+  const real* wrow = HAS_W ? wgt + mb : nullptr;
   const bool pair = skipna >= 6;  // 6 / 7: numerator and denominator sums side by side (see k_reduce_strided)
   if (pair) skipna -= 2;
   const bool mean = skipna >= 4;  // weighted mean in one pass (numerator and denominator together)
@@ -1299,7 +1306,9 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
         for (int u = 0; u < RU; ++u) {
           const int64_t k = lead + (t + u * WAVE) * NV;
           v[u] = ldv(k);
-          wv[u] = HAS_W ? ldm<dv>(wgt, mb + k * mw.axis, mw.axis) : splat<dv>(real(1));
+          if constexpr (!HAS_W) wv[u] = splat<dv>(real(1));
+          else if constexpr (wfast) wv[u] = *reinterpret_cast<const dv*>(wrow + k);
+          else wv[u] = ldm<dv>(wgt, mb + k * mw.axis, mw.axis);
         }
 #pragma unroll
         for (int u = 0; u < RU; ++u) add(v[u], wv[u]);
@@ -1311,7 +1320,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
       const int64_t k = lead + t * NV;
       const dv v = ldv(k);
       dv wv = splat<dv>(real(1));
-      if (HAS_W) wv = ldm<dv>(wgt, mb + k * mw.axis, mw.axis);
+      if constexpr (HAS_W) {
+        if constexpr (wfast) wv = *reinterpret_cast<const dv*>(wrow + k);
+        else wv = ldm<dv>(wgt, mb + k * mw.axis, mw.axis);
+      }
       add(v, wv);
     }
 #pragma unroll
@@ -1470,7 +1482,9 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
       }
       const u32 grid = ((nwork + 7) / 8) * 8;
       const bool nts = tune().nt_store;
-      const int bs = tune().scan_block;
+      // rows of float32 are half as long in bytes: 128 threads per row measured -4.6 % on the plain scan there (0.710 -> 0.744;
+      // with a metric +-0, float64 +4 %: profiles/r04aa_ab_f32_rowshapes.log), 256 everywhere else
+      const int bs = tune().scan_block ? tune().scan_block : (sizeof(real) == 4 && !met ? 128 : 256);
 #define XG_L(M, NTS_, BS_) hipLaunchKernelGGL((k_cumsum_contig_vec<M, NTS_, BS_>), dim3(grid), dim3(BS_), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo, zb, nwork, tune().scan_dpp)
 #define XG_B(M, NTS_) do { if (bs == 512) XG_L(M, NTS_, 512); else if (bs == 1024) XG_L(M, NTS_, 1024); else if (bs == 128) XG_L(M, NTS_, 128); else if (bs == 64) XG_L(M, NTS_, 64); else XG_L(M, NTS_, 256); } while (0)
 #define XG_M(M) do { if (nts) XG_B(M, true); else XG_B(M, false); } while (0)
@@ -1586,11 +1600,18 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     if ((rc = check_grid(nblocks))) return rc;
     const bool vec = aligned16(in) && g.n_in >= 4 * NV;  // rows of any length: lead / tail cells go through scalar loads
     const int ntf = (tune().nt_load ? 1 : 0) | (tune().reduce_ru == 1 ? 2 : tune().reduce_ru >= 2 ? 4 : 0);
+    bool wfast = w && vec && tune().reduce_wfast && mw.axis == 1 && g.n_in % NV == 0 && aligned16(w);
+    for (int d = 0; d < g.n_outer && wfast; ++d)
+      if (g.outer_shape[d] > 1 && mw.outer[d] % NV) wfast = false;
     const int sk = (tune().reduce_sk && (skipna == 0 || skipna == 1)) ? skipna : -1;
 #define XG_RC(W_, V_, S_) hipLaunchKernelGGL((k_reduce_contig<W_, V_, S_>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zb)
 #define XG_RS(W_, V_) do { if (sk == 0) XG_RC(W_, V_, 0); else if (sk == 1) XG_RC(W_, V_, 1); else XG_RC(W_, V_, -1); } while (0)
+#define XG_RF(S_) hipLaunchKernelGGL((k_reduce_contig<true, true, S_, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zb)
+    if (wfast) { if (sk == 0) XG_RF(0); else if (sk == 1) XG_RF(1); else XG_RF(-1); }
+    else
     if (vec) { if (w) XG_RS(true, true); else XG_RS(false, true); }
     else { if (w) XG_RS(true, false); else XG_RS(false, false); }
+#undef XG_RF
 #undef XG_RS
 #undef XG_RC
   } else {
