@@ -574,7 +574,8 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_contig(
 template <int MET, bool NTS, int BS>
 __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 nrows, ScanArgs a,
-    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, ZBand zb, u32 nwork, int dpp) {
+    const real* __restrict__ m_in, MIdx mi, const real* __restrict__ m_out, MIdx mo, ZBand zb, u32 nwork, int flags) {
+  const bool dpp = (flags & 1) != 0;  // wave scan on DPP; bit 1: the shifted-by-one input path (scan_sh1)
   constexpr bool HAS_MO = (MET & 1) != 0, HAS_MI = (MET & 2) != 0;
   constexpr int NW = BS / WAVE;
   __shared__ real wtot[2][NW];
@@ -673,6 +674,14 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
   // neighbouring lane by DPP: cumsum X 0.73 -> 0.62, cumint X 0.66 -> 0.56, the lane-0 fix-up and the extra moves cost more
   // than the misaligned narrow loads the L1 serves; and two vectors per thread and pass: 0.74 -> 0.70.
   // profiles/history/r03q_ab_scan_sh1.jsonl, r03q_ab_scan_gv_nosh1.jsonl)
+  // shift == 1 (center -> left with its leading halo cell: the Grid's default): output group t takes the input cell BEFORE
+  // its own aligned group and the group's first NV - 1 cells.  With 4-byte elements that is one aligned 16-B load + one
+  // narrow load instead of four narrow ones (per array: the metric the same) -- float32 cumint X through the Grid ran at
+  // 0.51 where the unshifted scan reaches 0.70.  (8-byte elements: two loads either way.  The round-3 variant took the
+  // extra cell from the neighbouring LANE and paid for the fix-ups; this one reads it, an L1 hit.)
+  // (with an input metric only: the plain scan's four narrow loads were no slower -- 0.93 against 1.00 ms with this path)
+  const bool sh1_in = (NV == 4) && HAS_MI && (flags & 2) && (shift == 1) && (n == no) && ((reinterpret_cast<uintptr_t>(in) & 15u) == 0);
+  const bool sh1_mi = sh1_in && mi_unit && ((reinterpret_cast<uintptr_t>(mi_row + lead) & 15u) == 0);
   auto load_group = [&](int t, real (&x)[NV]) {
     if (t >= groups) {
 #pragma unroll
@@ -680,6 +689,28 @@ __global__ __launch_bounds__(BS) void k_cumsum_contig_vec(
       return;
     }
     const int i0 = group_lo(t) - shift;
+    if (sh1_in && i0 >= 0 && i0 + 1 + NV <= n) {
+      const dv v = *reinterpret_cast<const dv*>(prow + i0 + 1);  // the output group's own (aligned) cells
+      x[0] = prow[i0];
+#pragma unroll
+      for (int k = 1; k < NV; ++k) x[k] = v[k - 1];
+      if (HAS_MI) {
+        if (sh1_mi) {
+          const dv mv = *reinterpret_cast<const dv*>(mi_row + i0 + 1);
+          x[0] = x[0] * mi_row[i0];
+#pragma unroll
+          for (int k = 1; k < NV; ++k) x[k] = x[k] * mv[k - 1];
+        } else {
+#pragma unroll
+          for (int k = 0; k < NV; ++k) x[k] = x[k] * (mi_unit ? mi_row[i0 + k] : m_in[mi_base + (int64_t)(i0 + k) * mi.axis]);
+        }
+      }
+      if (a.skipna) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) x[k] = nan0(x[k]);
+      }
+      return;
+    }
     if (i0 >= 0 && i0 + NV <= n) {
       if (vec_in) {
         const dv v = *reinterpret_cast<const dv*>(prow + i0);
@@ -1485,7 +1516,7 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
       // rows of float32 are half as long in bytes: 128 threads per row measured -4.6 % on the plain scan there (0.710 -> 0.744;
       // with a metric +-0, float64 +4 %: profiles/r04aa_ab_f32_rowshapes.log), 256 everywhere else
       const int bs = tune().scan_block ? tune().scan_block : (sizeof(real) == 4 && !met ? 128 : 256);
-#define XG_L(M, NTS_, BS_) hipLaunchKernelGGL((k_cumsum_contig_vec<M, NTS_, BS_>), dim3(grid), dim3(BS_), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo, zb, nwork, tune().scan_dpp)
+#define XG_L(M, NTS_, BS_) hipLaunchKernelGGL((k_cumsum_contig_vec<M, NTS_, BS_>), dim3(grid), dim3(BS_), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo, zb, nwork, (tune().scan_dpp ? 1 : 0) | (tune().scan_sh1 ? 2 : 0))
 #define XG_B(M, NTS_) do { if (bs == 512) XG_L(M, NTS_, 512); else if (bs == 1024) XG_L(M, NTS_, 1024); else if (bs == 128) XG_L(M, NTS_, 128); else if (bs == 64) XG_L(M, NTS_, 64); else XG_L(M, NTS_, 256); } while (0)
 #define XG_M(M) do { if (nts) XG_B(M, true); else XG_B(M, false); } while (0)
       switch (met) { case 0: XG_M(0); break; case 1: XG_M(1); break; case 2: XG_M(2); break; default: XG_M(3); }
