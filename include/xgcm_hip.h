@@ -116,9 +116,11 @@ int xg_event_create(void** ev);
 int xg_event_record(void* ev, void* stream);
 int xg_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 int xg_event_destroy(void* ev);
-/* Reverse the byte order of `nelem` elements of 4 or 8 bytes in place (device buffer, 16-byte aligned): blocks read raw
- * from big-endian files -- MITgcm's MDS .data, NetCDF-3 -- are swapped on the GPU after the PCIe copy.  The reference
- * gets decoded native arrays from xarray's backends (xgcm/grid.py:786-818 walks their dask chunks). */
+/* Reverse the byte order of `nelem` elements of 2, 4 or 8 bytes in place (device buffer, 16-byte aligned): blocks read raw
+ * from big-endian files -- MITgcm's MDS .data, NetCDF-3 -- and any numpy array of non-native byte order handed to an
+ * operator (`np.fromfile(..., ">f4")`; the reference's numpy bodies accept them, xgcm/gridops.py:23-24,76-77, and
+ * `np.pad` keeps the dtype, xgcm/padding.py:610-615) cross PCIe as raw bytes and are swapped on the GPU.  The reference
+ * otherwise gets decoded native arrays from xarray's backends (xgcm/grid.py:786-818 walks their dask chunks). */
 int xg_bswap(void* data, uint64_t nelem, int elem_bytes, void* stream);
 /* Cells of a float32 / float64 device buffer (elem_bytes 4 / 8) that equal `value` become NaN, in place: the _FillValue /
  * missing_value of a file variable, which xarray's mask_and_scale decoding turns into NaN before the reference sees the
@@ -480,10 +482,12 @@ int xg_copy_nd(const void* src, const int64_t* src_strides, void* dst, const int
 /* ---- element type conversion (numpy `astype`) --------------------------------------------- */
 typedef enum xg_dtype {
   XG_T_BOOL = 0, XG_T_I8 = 1, XG_T_I16 = 2, XG_T_I32 = 3, XG_T_I64 = 4,
-  XG_T_U8 = 5, XG_T_U16 = 6, XG_T_U32 = 7, XG_T_U64 = 8, XG_T_F32 = 9, XG_T_F64 = 10
+  XG_T_U8 = 5, XG_T_U16 = 6, XG_T_U32 = 7, XG_T_U64 = 8, XG_T_F32 = 9, XG_T_F64 = 10,
+  XG_T_F16 = 11 /* IEEE binary16: a STORAGE type -- float16 arrays are widened to float32 lanes and results narrowed */
 } xg_dtype;
 /* dst[i] = (dst_type) src[i] for n contiguous elements, with C / numpy `astype` rules: integer -> integer wraps modulo
- * 2^bits, integer -> float rounds to nearest, float -> integer truncates toward zero, bool reads / stores `!= 0`.
+ * 2^bits, integer -> float rounds to nearest, float -> integer truncates toward zero, bool reads / stores `!= 0`,
+ * float -> narrower float rounds once to nearest-even (float16 overflows to inf, keeps subnormals).
  *   via_type  XG_T_* integer type or -1: an integer source value is first wrapped to that type's width and signedness --
  *             the value the narrow dtype would hold -- so a result computed on int64 lanes leaves as numpy's narrow-dtype
  *             arithmetic would have it (interp of an int8 array = convert(int64 sums, via int8, to f64, scale 0.5));

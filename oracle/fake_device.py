@@ -12,21 +12,35 @@ import numpy as np
 from . import refimpl as R
 
 
-def asdevice(x, dtype=None):
-    """floats keep their dtype, integer / bool arrays stay integral (numpy computes them in their own dtype; the HIP
-    layer serves them on int64 lanes), anything else -> float64; mirrors device.asdevice"""
+def _nat(x):
+    """the array as numpy holds its VALUES in native byte order (`astype`, numpy's own conversion -- never a view by dtype
+    name): numpy computes a `>f8` / `>i4` array as it is and returns native results, so feeding the native twin to the
+    oracle is the reference's arithmetic on the same values.  complex / object / datetime arrays are refused like the
+    product refuses them."""
+    if x is None:
+        return None
     a = np.asarray(x)
-    if dtype is None:
-        dtype = a.dtype if (a.dtype in (np.float32, np.float64) or a.dtype.kind in "biu") else np.float64
-    return np.asarray(a, dtype=dtype, order="C")
+    if a.dtype.kind not in "biuf" or a.dtype.itemsize > 8:
+        kind = "complex arrays are" if a.dtype.kind == "c" else f"dtype {a.dtype} is"
+        raise TypeError(f"array: {kind} not supported by the MI355X backend (served: bool, (u)int8-64, float16 / 32 / 64, "
+                        "in either byte order)")
+    return a if a.dtype.isnative else a.astype(a.dtype.newbyteorder("="))
+
+
+def asdevice(x, dtype=None):
+    """every served dtype keeps itself (floats -- float16 included -- and integers / bool: numpy computes them in their
+    own dtype); mirrors device.asdevice"""
+    a = _nat(x)
+    return np.asarray(a, dtype=a.dtype if dtype is None else dtype, order="C")
 
 
 def _common(*arrays):
     """the float lanes a mix of operands computes on: numpy's promotion, float32 only where it yields float32
-    (mirrors device._common / xgcm_amd.dtypes.float_of)"""
-    present = [np.asarray(a).dtype for a in arrays if a is not None]
+    (mirrors device._common / xgcm_amd.dtypes.float_of); used by the FUSED operators only -- the reference-level
+    operators below hand numpy the operands in their own dtypes and let IT promote, step by step"""
+    present = [_nat(a).dtype for a in arrays if a is not None]
     rt = np.result_type(*present) if present else np.dtype(np.float64)
-    return np.float32 if rt == np.float32 else np.float64
+    return np.float32 if rt in (np.float32, np.float16) else np.float64
 
 
 def _is_int(a):
@@ -46,26 +60,26 @@ def is_device_array(x):
 
 
 def stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill=0.0, m_in=None, m_out=None):
-    if _is_int(x) and m_in is None:  # numpy's own integer arithmetic is the oracle (wrap-around, dtype, fill cast)
-        x = np.asarray(x)
-        return R.stencil1d(op, x, axis % x.ndim, pad_lo, pad_hi, bc, fill, None, m_out)
-    x, m_in, m_out = _cast(_common(x, m_in, m_out), x, m_in, m_out)
+    # numpy's own arithmetic in the operands' own dtypes is the oracle: integer wrap-around, fill cast, float16, and the
+    # step-by-step promotion of `(x * m_in)` -> body -> `/ m_out` (a float32 difference is rounded before a float64 metric
+    # divides it)
+    x, m_in, m_out = _nat(x), _nat(m_in), _nat(m_out)
     return R.stencil1d(op, x, axis % x.ndim, pad_lo, pad_hi, bc, fill, m_in, m_out)
 
 
 def cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill=0.0, reverse=False, skipna=True, m_in=None, m_out=None):
+    x, m_in, m_out = _nat(x), _nat(m_in), _nat(m_out)
     if _is_int(x) and m_in is None:
-        x = np.asarray(x)
-        return R.cumsum1d(x, axis % x.ndim, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, False, None, m_out)
-    x, m_in, m_out = _cast(_common(x, m_in, m_out), x, m_in, m_out)
+        skipna = False
     return R.cumsum1d(x, axis % x.ndim, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, skipna, m_in, m_out)
 
 
 def reduce1d(x, axis, w=None, skipna=True):
+    x, w = _nat(x), _nat(w)
     if _is_int(x) and w is None and isinstance(skipna, (bool, int, np.bool_)):
-        x = np.asarray(x)
         return np.sum(x, axis=axis % x.ndim)
-    x, w = _cast(_common(x, w), x, w)
+    if x.dtype.kind in "biu" or (w is not None and np.result_type(x, w) != x.dtype):
+        x = x.astype(np.result_type(x, w) if w is not None else np.float64)  # the dtype of `x * w`, for the count modes
     if skipna in ("pair_valid", "pair_all"):  # numerator and denominator sums stacked along a new leading dim
         valid = skipna == "pair_valid"
         return np.stack([reduce1d(x, axis, w, valid), reduce1d(x, axis, w, "valid" if valid else "all")])
@@ -85,12 +99,10 @@ def pad_nd(x, widths, bc, fill):
 
 
 def stencil1d_halo(op, x, halo, axis, pad_lo, pad_hi, m_out=None, m_in=None):
-    if _is_int(x) and _is_int(halo) and m_in is None:
-        x, halo = np.asarray(x), np.asarray(halo).astype(np.asarray(x).dtype)
-    else:
-        x, halo, m_out, m_in = _cast(_common(x, halo, m_out, m_in), x, halo, m_out, m_in)
+    x, halo, m_out, m_in = _nat(x), _nat(halo), _nat(m_out), _nat(m_in)
     if m_in is not None:  # `halo` holds the halo cells of the product already
         x = x * m_in
+    halo = halo.astype(x.dtype)
     axis = axis % x.ndim
     lo = np.take(halo, range(0, pad_lo), axis=axis)
     hi = np.take(halo, range(pad_lo, pad_lo + pad_hi), axis=axis)
@@ -146,10 +158,7 @@ def put_halo(out, halo, axis, pad_lo, pad_hi):
 
 
 def binary(op, a, b):
-    if _is_int(a) and _is_int(b):  # numpy's own integer promotion / wrap-around / true division
-        return R.binary(op, np.asarray(a), np.asarray(b))
-    a, b = _cast(_common(a, b), a, b)
-    return R.binary(op, a, b)
+    return R.binary(op, _nat(a), _nat(b))  # numpy's own promotion / wrap-around / true division / float16
 
 
 def _with_halo(a, halo, axis, low, bc):

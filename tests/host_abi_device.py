@@ -36,19 +36,44 @@ def _check(rc):
         raise _hip.XgcmHipError(f"xgcm host ABI status {rc}: {buf.value.decode(errors='replace')}")
 
 
+def _in(x):
+    """the product's device._raw_device over host memory: a contiguous array in NATIVE byte order; an array of the other
+    byte order is copied as raw bytes and reversed by the host build of xg_bswap -- the SAME intake rule
+    (xgcm_amd.dtypes.host_intake), never a reinterpretation by dtype name"""
+    a, swap = _dt.host_intake(np.ascontiguousarray(x))
+    if swap:
+        a = a.copy()
+        if a.size:
+            _check(lib().xg_bswap(_ptr(a), a.size, swap, None))
+    return a
+
+
 def _common(*arrays):
-    present = [np.asarray(a).dtype for a in arrays if a is not None]
+    present = [_dt.np_dtype(a) for a in arrays if a is not None]
     f = _dt.float_of(*present)
     return (np.float32, "f32") if f == np.float32 else (np.float64, "f64")
 
 
 def _is_int(x):
-    return x is not None and _dt.is_integer(np.asarray(x).dtype)
+    return x is not None and _dt.is_integer(_dt.np_dtype(x))
+
+
+def _half(*arrays):
+    return _dt.half_result(*[_dt.np_dtype(a) for a in arrays if a is not None])
+
+
+def _out(res, half):
+    return convert(res, np.float16) if half else res
+
+
+def _steps(x, m_in, m_out):
+    return _dt.metric_steps(_dt.np_dtype(x), None if m_in is None else _dt.np_dtype(m_in),
+                            None if m_out is None else _dt.np_dtype(m_out))
 
 
 def convert(x, dst, via=None, scale=1.0, flip=False):
     """numpy `astype` through the host build of xg_convert (the product's device.convert over host pointers)"""
-    a = np.ascontiguousarray(x)
+    a = _in(x)
     dst = np.dtype(dst)
     if a.dtype == dst and via is None and scale == 1.0 and not flip:
         return a
@@ -60,12 +85,9 @@ def convert(x, dst, via=None, scale=1.0, flip=False):
 
 
 def asdevice(x, dtype=None):
-    a = np.asarray(x)
+    a = _in(x)
     if dtype is None:
-        if a.dtype in (np.float32, np.float64) or _dt.is_integer(a.dtype):
-            return np.ascontiguousarray(a)
-        dtype = np.float64
-    a = np.ascontiguousarray(a)
+        return a
     return a if a.dtype == dtype else convert(a, dtype)
 
 
@@ -73,7 +95,7 @@ _LANE_SFX = {"int64": "i64", "int32": "i32"}
 
 
 def _widen(x, lane=np.int64):
-    a = np.ascontiguousarray(x)
+    a = _in(x)
     lane = np.dtype(lane)
     if _dt.same_bits(a.dtype, lane):
         return a.view(lane)
@@ -127,10 +149,10 @@ def _strides(m, shape, what):
 
 
 def stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill=0.0, m_in=None, m_out=None):
-    plan = _dt.stencil_plan(op, np.asarray(x).dtype, None if m_in is None else np.asarray(m_in).dtype,
-                            None if m_out is None else np.asarray(m_out).dtype)
+    plan = _dt.stencil_plan(op, _dt.np_dtype(x), None if m_in is None else _dt.np_dtype(m_in),
+                            None if m_out is None else _dt.np_dtype(m_out))
     if plan.lanes == "int":  # the product's device._int_stencil1d over the host build of the *_i64 entry points
-        src = np.asarray(x).dtype
+        src = _dt.np_dtype(x)
         lane = plan.compute
         t = _widen(x, lane)
         axis %= t.ndim
@@ -144,6 +166,12 @@ def stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill=0.0, m_in=None, m_out=None):
             _check(getattr(lib(), "xg_stencil1d_" + _LANE_SFX[lane.name])(code, _ptr(t), _ptr(out), _hip.i64(shape), len(shape), axis, oshape[axis],
                                           int(pad_lo), int(pad_hi), _hip.BC[bc], fv, None, None, None, None, None))
         return _divide(_narrow(out, plan.result, via=plan.via, scale=plan.scale), m_out, plan.divide_as)
+    pre_mul, post_div = _steps(x, m_in, m_out)
+    if pre_mul:
+        x, m_in = binary("mul", x, m_in), None
+    if post_div:
+        return binary("div", stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill, m_in, None), m_out)
+    half = _half(x, m_in, m_out)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis %= x.ndim
@@ -154,17 +182,17 @@ def stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill=0.0, m_in=None, m_out=None):
     m_out = None if m_out is None else asdevice(m_out, dt)
     out = np.empty(oshape, dtype=dt)
     if out.size == 0:
-        return out
+        return _out(out, half)
     _check(getattr(lib(), "xg_stencil1d_" + sfx)(
         _hip.OP[op], _ptr(x), _ptr(out), _hip.i64(shape), len(shape), axis, oshape[axis], int(pad_lo), int(pad_hi),
         _hip.BC[bc], float(fill), _ptr(m_in), _hip.i64(_strides(m_in, shape, "m_in")), _ptr(m_out),
         _hip.i64(_strides(m_out, oshape, "m_out")), None))
-    return out
+    return _out(out, half)
 
 
 def cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill=0.0, reverse=False, skipna=True, m_in=None, m_out=None):
     if _is_int(x) and m_in is None:
-        res_dt = _dt.cumsum_dtype(np.asarray(x).dtype)
+        res_dt = _dt.cumsum_dtype(_dt.np_dtype(x))
         t = _widen(x)
         axis %= t.ndim
         shape = list(t.shape)
@@ -176,7 +204,13 @@ def cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill=0.0, reverse=Fa
             _check(lib().xg_cumsum1d_i64(_ptr(t), _ptr(out), _hip.i64(shape), len(shape), axis, int(bool(reverse)), 0,
                                          int(trim_lo), int(trim_hi), int(pad_lo), int(pad_hi), _hip.BC[bc], fv, None, None,
                                          None, None, None))
-        return _divide(_narrow(out, res_dt), m_out, None if m_out is None else _dt.float_of(res_dt, np.asarray(m_out).dtype))
+        return _divide(_narrow(out, res_dt), m_out, None if m_out is None else _dt.float_of(res_dt, _dt.np_dtype(m_out)))
+    pre_mul, post_div = _steps(x, m_in, m_out)
+    if pre_mul:
+        x, m_in = binary("mul", x, m_in), None
+    if post_div:
+        return binary("div", cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, skipna, m_in, None), m_out)
+    half = _half(x, m_in, m_out)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis %= x.ndim
@@ -187,17 +221,17 @@ def cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill=0.0, reverse=Fa
     m_out = None if m_out is None else asdevice(m_out, dt)
     out = np.empty(oshape, dtype=dt)
     if out.size == 0:
-        return out
+        return _out(out, half)
     _check(getattr(lib(), "xg_cumsum1d_" + sfx)(
         _ptr(x), _ptr(out), _hip.i64(shape), len(shape), axis, int(bool(reverse)), int(bool(skipna)), int(trim_lo),
         int(trim_hi), int(pad_lo), int(pad_hi), _hip.BC[bc], float(fill), _ptr(m_in),
         _hip.i64(_strides(m_in, shape, "m_in")), _ptr(m_out), _hip.i64(_strides(m_out, oshape, "m_out")), None))
-    return out
+    return _out(out, half)
 
 
 def reduce1d(x, axis, w=None, skipna=True):
     if _is_int(x) and w is None and isinstance(skipna, (bool, int, np.bool_)):
-        res_dt = _dt.cumsum_dtype(np.asarray(x).dtype)
+        res_dt = _dt.cumsum_dtype(_dt.np_dtype(x))
         t = _widen(x)
         axis %= t.ndim
         shape = list(t.shape)
@@ -205,6 +239,9 @@ def reduce1d(x, axis, w=None, skipna=True):
         if out.size and t.size:
             _check(lib().xg_reduce1d_i64(_ptr(t), _ptr(out), _hip.i64(shape), len(shape), axis, 0, None, None, None))
         return _narrow(out, res_dt)
+    half = _half(x, w)
+    if half and w is not None and skipna not in ("valid", "all"):
+        x, w = binary("mul", x, w), None
     dt, sfx = _common(x, w)
     x = asdevice(x, dt)
     axis %= x.ndim
@@ -213,32 +250,34 @@ def reduce1d(x, axis, w=None, skipna=True):
     mode = {"valid": 2, "all": 3, "mean_valid": 4, "mean_all": 5, "pair_valid": 6, "pair_all": 7}.get(skipna, int(bool(skipna)))
     out = np.empty(([2] if mode >= 6 else []) + shape[:axis] + shape[axis + 1:], dtype=dt)
     if out.size == 0:
-        return out
+        return _out(out, half)
     _check(getattr(lib(), "xg_reduce1d_" + sfx)(_ptr(x), _ptr(out), _hip.i64(shape), len(shape), axis, mode, _ptr(w),
                                                _hip.i64(_strides(w, shape, "w")), None))
-    return out
+    return _out(out, half)
 
 
 def binary(op, a, b):
-    lanes, res_dt = _dt.binary_plan(op, np.asarray(a).dtype, np.asarray(b).dtype)
+    lanes, res_dt = _dt.binary_plan(op, _dt.np_dtype(a), _dt.np_dtype(b))
+    half = False
     if lanes == "int":
         lane = _dt.lane_of(res_dt)
         dt, sfx = lane, _LANE_SFX[lane.name]
-        a = _widen(a if _dt.same_bits(np.asarray(a).dtype, lane) else convert(a, res_dt), lane)
-        b = _widen(b if _dt.same_bits(np.asarray(b).dtype, lane) else convert(b, res_dt), lane)
+        a = _widen(a if _dt.same_bits(_dt.np_dtype(a), lane) else convert(a, res_dt), lane)
+        b = _widen(b if _dt.same_bits(_dt.np_dtype(b), lane) else convert(b, res_dt), lane)
     else:
         dt, sfx = (np.float32, "f32") if res_dt == np.float32 else (np.float64, "f64")
+        half = _half(a, b)
         a, b = asdevice(a, dt), asdevice(b, dt)
     shape = [max(sa, sb) if 0 not in (sa, sb) else 0 for sa, sb in zip(a.shape, b.shape)]
     out = np.empty(shape, dtype=dt)
     if out.size:
         _check(getattr(lib(), "xg_binary_" + sfx)(_hip.BINOP[op], _ptr(a), _hip.i64(_strides(a, shape, "a")), _ptr(b),
                                                  _hip.i64(_strides(b, shape, "b")), _ptr(out), _hip.i64(shape), len(shape), None))
-    return _narrow(out, res_dt) if lanes == "int" else out
+    return _narrow(out, res_dt) if lanes == "int" else _out(out, half)
 
 
 def pad_nd(x, widths, bc, fill):
-    src = np.asarray(x).dtype
+    src = _dt.np_dtype(x)
     ints = _dt.is_integer(src)
     if ints:
         lane = _dt.lane_of(src)
@@ -261,7 +300,7 @@ def pad_nd(x, widths, bc, fill):
     if out.size:
         _check(getattr(lib(), "xg_pad_" + sfx)(_ptr(x), _ptr(out), _hip.i64(list(x.shape)), nd, _hip.i64(lo), _hip.i64(hi),
                                               _hip.ints(bcv), _hip.reals(fv, sfx), _hip.ints(order), None))
-    return _narrow(out, src) if ints else out
+    return _narrow(out, src) if ints else _out(out, src == np.float16)
 
 
 def synthetic(shape, seed, offset=0, scale=1.0, shift=-0.5, out=None, dtype=np.float64):

@@ -132,8 +132,10 @@ def test_f32_pad_binary_vorticity_stencil2d_synthetic(dev):
 def test_mixed_dtypes_promote_to_float64(dev):
     a32, m64 = f32((4, 6, 32), 3), R.synthetic_metric((1, 6, 32), 31)
     got = dev.tohost(dev.stencil1d("diff", a32, 2, 1, 0, "periodic", 0.0, None, m64))
-    exp = R.stencil1d("diff", a32.astype(np.float64), 2, 1, 0, "periodic", 0.0, None, m64)
+    exp = R.stencil1d("diff", a32, 2, 1, 0, "periodic", 0.0, None, m64)  # numpy: the float32 difference, then / float64
     assert got.dtype == np.float64 and np.array_equal(got, exp)
+    got = dev.tohost(dev.stencil1d("diff", a32, 2, 1, 0, "periodic", 0.0, m64, m64))  # float64 product first: all float64
+    assert got.dtype == np.float64 and np.array_equal(got, R.stencil1d("diff", a32, 2, 1, 0, "periodic", 0.0, m64, m64))
     assert dev.tohost(dev.binary("mul", a32, m64)).dtype == np.float64
     ints = np.arange(24).reshape(4, 6)
     out = dev.tohost(dev.stencil1d("diff", ints, 1, 1, 0, "fill"))

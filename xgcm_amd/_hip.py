@@ -151,7 +151,7 @@ for _name in ["xg_stencil1d", "xg_stencil1d_halo", "xg_pad", "xg_gather", "xg_ha
 
 # element types of xg_convert (enum xg_dtype), keyed by numpy dtype name
 DTYPE = {"bool": 0, "int8": 1, "int16": 2, "int32": 3, "int64": 4, "uint8": 5, "uint16": 6, "uint32": 7, "uint64": 8,
-         "float32": 9, "float64": 10}
+         "float32": 9, "float64": 10, "float16": 11}
 SIGNATURES["xg_copy_nd"] = (C.c_int, [_vp, _i64p, _vp, _i64p, _i64p, C.c_int, C.c_int, _vp])
 SIGNATURES["xg_convert"] = (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_uint64, C.c_int, C.c_double, C.c_int, _vp])
 

@@ -25,13 +25,14 @@ template <> struct TypeOf<XG_T_U32> { typedef uint32_t type; };
 template <> struct TypeOf<XG_T_U64> { typedef uint64_t type; };
 template <> struct TypeOf<XG_T_F32> { typedef float type; };
 template <> struct TypeOf<XG_T_F64> { typedef double type; };
+template <> struct TypeOf<XG_T_F16> { typedef _Float16 type; };  // storage only: float16 arrays compute on float32 lanes
 
-constexpr bool is_float_type(int t) { return t == XG_T_F32 || t == XG_T_F64; }
+constexpr bool is_float_type(int t) { return t == XG_T_F32 || t == XG_T_F64 || t == XG_T_F16; }
 constexpr bool is_unsigned_type(int t) { return t == XG_T_BOOL || (t >= XG_T_U8 && t <= XG_T_U64); }
 inline int type_bytes(int t) {
   switch (t) {
     case XG_T_BOOL: case XG_T_I8: case XG_T_U8: return 1;
-    case XG_T_I16: case XG_T_U16: return 2;
+    case XG_T_I16: case XG_T_U16: case XG_T_F16: return 2;
     case XG_T_I32: case XG_T_U32: case XG_T_F32: return 4;
     default: return 8;
   }
@@ -57,6 +58,8 @@ __device__ __forceinline__ typename TypeOf<D>::type convert1(typename TypeOf<S>:
                                                              int flip) {
   typedef typename TypeOf<D>::type DT;
   if constexpr (is_float_type(S)) {
+    // float32 / float16 -> float16 straight from the float (v_cvt_f16_f32: one rounding, numpy's astype)
+    if constexpr (D == XG_T_F16 && S != XG_T_F64) return (DT)((DT)(float)x * (DT)scale);
     const double f = (double)x;
     if constexpr (is_float_type(D)) return (DT)((DT)f * (DT)scale);
     else if constexpr (D == XG_T_BOOL) return (DT)(f != 0.0);
@@ -132,6 +135,7 @@ int launch_dst(int D, const void* src, void* dst, u64 n, int via, int logical, d
     case XG_T_U32: return launch<S, XG_T_U32>(src, dst, n, via, logical, scale, flip, st);
     case XG_T_U64: return launch<S, XG_T_U64>(src, dst, n, via, logical, scale, flip, st);
     case XG_T_F32: return launch<S, XG_T_F32>(src, dst, n, via, logical, scale, flip, st);
+    case XG_T_F16: return launch<S, XG_T_F16>(src, dst, n, via, logical, scale, flip, st);
     default: return launch<S, XG_T_F64>(src, dst, n, via, logical, scale, flip, st);
   }
 }
@@ -140,7 +144,7 @@ int launch_dst(int D, const void* src, void* dst, u64 n, int via, int logical, d
 
 extern "C" int xg_convert(const void* src, int src_type, void* dst, int dst_type, uint64_t n, int via_type, double scale,
                           int flags, void* stream) {
-  if (src_type < XG_T_BOOL || src_type > XG_T_F64 || dst_type < XG_T_BOOL || dst_type > XG_T_F64)
+  if (src_type < XG_T_BOOL || src_type > XG_T_F16 || dst_type < XG_T_BOOL || dst_type > XG_T_F16)
     return fail(XG_ERR_INVALID, "unknown element type (%d -> %d)", src_type, dst_type);
   if (via_type < -1 || via_type > XG_T_U64) return fail(XG_ERR_INVALID, "via_type %d is not an integer type", via_type);
   if (flags & ~1) return fail(XG_ERR_INVALID, "unknown flags %d", flags);
@@ -165,6 +169,7 @@ extern "C" int xg_convert(const void* src, int src_type, void* dst, int dst_type
     case XG_T_U32: launch_dst<XG_T_U32>(dst_type, src, dst, n, via_type, logical, scale, flip, st); break;
     case XG_T_U64: launch_dst<XG_T_U64>(dst_type, src, dst, n, via_type, logical, scale, flip, st); break;
     case XG_T_F32: launch_dst<XG_T_F32>(dst_type, src, dst, n, via_type, logical, scale, flip, st); break;
+    case XG_T_F16: launch_dst<XG_T_F16>(dst_type, src, dst, n, via_type, logical, scale, flip, st); break;
     default: launch_dst<XG_T_F64>(dst_type, src, dst, n, via_type, logical, scale, flip, st); break;
   }
   XG_LAUNCH_CHECK();

@@ -358,7 +358,7 @@ int xg_chain_status(int* gave_up, int* redone) {
 }
 int xg_chain_rearm(void) { return XG_OK; }
 int xg_bswap(void* data, uint64_t nelem, int elem_bytes, void*) {
-  if (elem_bytes != 4 && elem_bytes != 8) return fail(XG_ERR_INVALID, "byte swap of %d-byte elements (4 or 8)", elem_bytes);
+  if (elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return fail(XG_ERR_INVALID, "byte swap of %d-byte elements (2, 4 or 8)", elem_bytes);
   if (nelem && !data) return fail(XG_ERR_INVALID, "NULL buffer");
   unsigned char* p = (unsigned char*)data;
   for (uint64_t e = 0; e < nelem; ++e, p += elem_bytes)
@@ -542,15 +542,45 @@ int xg_copy_nd(const void* src, const int64_t* ss, void* dst, const int64_t* ds,
 }
 
 // numpy `astype` between the storage dtype and the compute dtype (see the header); one element at a time
+// IEEE binary16 <-> double without compiler support (gcc 11 has no _Float16): one round-to-nearest-even from the double
+static uint16_t half_from_double(double d) {
+  uint64_t b;
+  memcpy(&b, &d, 8);
+  const uint16_t sign = (uint16_t)((b >> 48) & 0x8000u);
+  int64_t e = (int64_t)((b >> 52) & 0x7ff);
+  uint64_t m = b & 0xfffffffffffffull;
+  if (e == 0x7ff) return (uint16_t)(sign | 0x7c00u | (m ? (0x200u | (uint16_t)(m >> 42)) : 0u));  // inf / quiet NaN
+  e = e - 1023 + 15;
+  if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+  int shift = 42;
+  if (e <= 0) {  // subnormal half (or zero): the implicit one joins the mantissa, the shift grows
+    if (e < -10) return sign;
+    m |= 1ull << 52;
+    shift = 42 + (int)(1 - e);
+    e = 0;
+  }
+  uint64_t q = m >> shift;
+  const uint64_t rem = m & ((1ull << shift) - 1), half = 1ull << (shift - 1);
+  if (rem > half || (rem == half && (q & 1))) ++q;  // a carry out of the mantissa bumps the exponent (up to inf): correct
+  return (uint16_t)(sign | (uint16_t)(((uint64_t)e << 10) + q));
+}
+static double half_to_double(uint16_t h) {
+  const int e = (h >> 10) & 31, m = h & 0x3ff;
+  double v;
+  if (e == 0) v = std::ldexp((double)m, -24);
+  else if (e == 31) v = m ? NAN : INFINITY;
+  else v = std::ldexp((double)(m | 0x400), e - 25);
+  return (h & 0x8000) ? -v : v;
+}
 int xg_convert(const void* src, int st, void* dst, int dt, uint64_t n, int via, double scale, int flags, void*) {
-  if (st < XG_T_BOOL || st > XG_T_F64 || dt < XG_T_BOOL || dt > XG_T_F64) return fail(XG_ERR_INVALID, "unknown element type (%d -> %d)", st, dt);
+  if (st < XG_T_BOOL || st > XG_T_F16 || dt < XG_T_BOOL || dt > XG_T_F16) return fail(XG_ERR_INVALID, "unknown element type (%d -> %d)", st, dt);
   if (via < -1 || via > XG_T_U64) return fail(XG_ERR_INVALID, "via_type %d is not an integer type", via);
   if (flags & ~1) return fail(XG_ERR_INVALID, "unknown flags %d", flags);
   if (n == 0) return XG_OK;
   if (!src || !dst) return fail(XG_ERR_INVALID, "NULL array argument");
   const bool sf = st >= XG_T_F32, df = dt >= XG_T_F32;
   if (sf && via != -1) return fail(XG_ERR_INVALID, "via_type applies to integer sources only");
-  auto bytes = [](int t) { return (t == XG_T_BOOL || t == XG_T_I8 || t == XG_T_U8) ? 1 : (t == XG_T_I16 || t == XG_T_U16) ? 2 : (t == XG_T_I32 || t == XG_T_U32 || t == XG_T_F32) ? 4 : 8; };
+  auto bytes = [](int t) { return (t == XG_T_BOOL || t == XG_T_I8 || t == XG_T_U8) ? 1 : (t == XG_T_I16 || t == XG_T_U16 || t == XG_T_F16) ? 2 : (t == XG_T_I32 || t == XG_T_U32 || t == XG_T_F32) ? 4 : 8; };
   if ((flags & 1) && (bytes(st) != 8 || bytes(dt) != 8 || sf || df)) return fail(XG_ERR_INVALID, "the sign-bit flip needs 64-bit integer types on both sides");
   auto wrap = [](int64_t w, int t) -> int64_t {
     switch (t) {
@@ -570,11 +600,16 @@ int xg_convert(const void* src, int st, void* dst, int dt, uint64_t n, int via, 
       case XG_T_I32: w = ((const int32_t*)src)[i]; break;   case XG_T_I64: w = ((const int64_t*)src)[i]; break;
       case XG_T_U8: w = ((const uint8_t*)src)[i]; break;    case XG_T_U16: w = ((const uint16_t*)src)[i]; break;
       case XG_T_U32: w = ((const uint32_t*)src)[i]; break;  case XG_T_U64: w = (int64_t)((const uint64_t*)src)[i]; break;
-      case XG_T_F32: f = ((const float*)src)[i]; break;     default: f = ((const double*)src)[i]; break;
+      case XG_T_F32: f = ((const float*)src)[i]; break;     case XG_T_F16: f = half_to_double(((const uint16_t*)src)[i]); break;
+      default: f = ((const double*)src)[i]; break;
     }
     if (!sf) w = wrap(w, via);
     if (df) {  // float destination
-      if (dt == XG_T_F32) {
+      if (dt == XG_T_F16) {  // one rounding into binary16, then the scale in binary16 (a power of two: exact unless subnormal)
+        const double v = sf ? f : (logical == XG_T_U64 ? (double)(uint64_t)w : (double)w);
+        const uint16_t h = half_from_double(v);
+        ((uint16_t*)dst)[i] = scale == 1.0 ? h : half_from_double(half_to_double(h) * half_to_double(half_from_double(scale)));
+      } else if (dt == XG_T_F32) {
         const float v = sf ? (float)f : (logical == XG_T_U64 ? (float)(uint64_t)w : (float)w);
         ((float*)dst)[i] = v * (float)scale;
       } else {

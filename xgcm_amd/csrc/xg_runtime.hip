@@ -216,16 +216,23 @@ __global__ __launch_bounds__(BLOCK) void k_bswap(u32* __restrict__ data, u64 nve
   typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
   const u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x;
   auto sw = [](u32 v) -> u32 { return __builtin_bswap32(v); };
+  auto sw16 = [](u32 v) -> u32 { return ((v & 0x00ff00ffu) << 8) | ((v >> 8) & 0x00ff00ffu); };  // both halves of a word
   if (i < nvec) {
     u32x4_t v = reinterpret_cast<u32x4_t*>(data)[i], o;
-    if (EB == 4) { o[0] = sw(v[0]); o[1] = sw(v[1]); o[2] = sw(v[2]); o[3] = sw(v[3]); }
+    if (EB == 2) { o[0] = sw16(v[0]); o[1] = sw16(v[1]); o[2] = sw16(v[2]); o[3] = sw16(v[3]); }
+    else if (EB == 4) { o[0] = sw(v[0]); o[1] = sw(v[1]); o[2] = sw(v[2]); o[3] = sw(v[3]); }
     else { o[0] = sw(v[1]); o[1] = sw(v[0]); o[2] = sw(v[3]); o[3] = sw(v[2]); }
     reinterpret_cast<u32x4_t*>(data)[i] = o;
   } else if (i == nvec) {  // the tail (the buffer holds whole elements)
     for (u64 e = nvec * (16 / EB); e < nelem; ++e) {
-      u32* p = data + e * (EB / 4);
-      if (EB == 4) p[0] = sw(p[0]);
-      else { const u32 lo = p[0], hi = p[1]; p[0] = sw(hi); p[1] = sw(lo); }
+      if (EB == 2) {
+        unsigned short* q = reinterpret_cast<unsigned short*>(data) + e;
+        q[0] = (unsigned short)((q[0] << 8) | (q[0] >> 8));
+      } else {
+        u32* p = data + e * (EB / 4);
+        if (EB == 4) p[0] = sw(p[0]);
+        else { const u32 lo = p[0], hi = p[1]; p[0] = sw(hi); p[1] = sw(lo); }
+      }
     }
   }
 }
@@ -385,14 +392,15 @@ int xg_mask_value(void* data, uint64_t nelem, int elem_bytes, double value, void
 }
 
 int xg_bswap(void* data, uint64_t nelem, int elem_bytes, void* stream) {
-  if (elem_bytes != 4 && elem_bytes != 8) return fail(XG_ERR_INVALID, "byte swap of %d-byte elements (4 or 8)", elem_bytes);
+  if (elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return fail(XG_ERR_INVALID, "byte swap of %d-byte elements (2, 4 or 8)", elem_bytes);
   if (nelem == 0) return XG_OK;
   if (!data) return fail(XG_ERR_INVALID, "NULL buffer");
   if (reinterpret_cast<uintptr_t>(data) & 15u) return fail(XG_ERR_INVALID, "the buffer must be 16-byte aligned");
   const u64 nvec = nelem * (u64)elem_bytes / 16, nblocks = (nvec + 1 + BLOCK - 1) / BLOCK;
   int rc;
   if ((rc = check_grid(nblocks))) return rc;
-  if (elem_bytes == 4) hipLaunchKernelGGL(k_bswap<4>, dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, (u32*)data, nvec, (u64)nelem);
+  if (elem_bytes == 2) hipLaunchKernelGGL(k_bswap<2>, dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, (u32*)data, nvec, (u64)nelem);
+  else if (elem_bytes == 4) hipLaunchKernelGGL(k_bswap<4>, dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, (u32*)data, nvec, (u64)nelem);
   else hipLaunchKernelGGL(k_bswap<8>, dim3((u32)nblocks), dim3(BLOCK), 0, (hipStream_t)stream, (u32*)data, nvec, (u64)nelem);
   XG_LAUNCH_CHECK();
   return XG_OK;

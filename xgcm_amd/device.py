@@ -64,20 +64,31 @@ def is_device_array(x) -> bool:
 
 
 _FLOATS = (torch.float32, torch.float64)
-# storage dtypes the library serves: floats compute in their own dtype, integers / bool on int64 lanes (xgcm_amd.dtypes)
-_SERVED = ("bool", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float32", "float64")
+# storage dtypes the library serves: float64 / float32 compute in their own dtype, float16 on float32 lanes (narrowed on
+# the way out), integers / bool on int64 / int32 lanes (xgcm_amd.dtypes)
+_SERVED = _dt.SERVED
 
 
 def _raw_device(x) -> torch.Tensor:
     """numpy / host tensor -> contiguous tensor in HBM with its dtype UNCHANGED (PCIe copy of the raw bytes: an int8
-    field crosses the bus as 1 byte per cell and is widened in HBM); device tensors pass."""
+    field crosses the bus as 1 byte per cell and is widened in HBM); device tensors pass.  An array of non-native byte
+    order (`np.fromfile(f, ">f4")`, MDS / xmitgcm output -- the reference's numpy bodies take them as they are,
+    xgcm/gridops.py:23-24,76-77) crosses as raw bytes too and is byte-swapped in HBM (xg_bswap): the tensor holds the
+    VALUES in the native twin of the dtype, which is also what numpy returns.  complex / object / datetime arrays are
+    refused with a TypeError (xgcm_amd.dtypes.check_served)."""
     _require_gpu()
+    swap = 0
     if isinstance(x, torch.Tensor):
         t = x
+        if t.dtype not in _dt._TORCH_TO_NUMPY:
+            raise TypeError(f"array: dtype {t.dtype} is not supported by the MI355X backend")
     else:
-        t = torch.from_numpy(np.ascontiguousarray(x))
+        a, swap = _dt.host_intake(np.ascontiguousarray(x))
+        t = torch.from_numpy(a) if a.flags.writeable else torch.from_numpy(a.copy())
     if not t.is_cuda:
         t = t.cuda()
+        if swap and t.numel():  # (a fresh private copy: swapped in place)
+            _hip.check(_hip.load().xg_bswap(t.data_ptr(), t.numel(), swap, _stream()))
     elif t.device.index != torch.cuda.current_device():
         # kernels are enqueued on the CURRENT device's stream (one process per GPU is the model)
         raise RuntimeError(f"array lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
@@ -152,10 +163,10 @@ def convert(x, dst, via=None, scale: float = 1.0, flip: bool = False) -> torch.T
     lib = _hip.load()
     t = _raw_device(x)
     src, dst = _dt.np_dtype(t), np.dtype(dst)
-    if src.name not in _SERVED:
-        # float16 / bfloat16 ...: no kernel computes in them and xg_convert does not read them; the promotion numpy
-        # would apply next to a float64 metric is torch's cast here (storage plumbing, outside the hot path)
-        t, src = t.to(torch.float64), _dt.FLOAT64
+    if t.dtype == torch.bfloat16:
+        # no numpy twin and xg_convert does not read it: torch's cast to its float32 promotion (storage plumbing, outside
+        # the hot path)
+        t, src = t.to(torch.float32), _dt.FLOAT32
     if src == dst and via is None and scale == 1.0 and not flip:
         return t
     out = torch.empty(t.shape, dtype=_dt.torch_dtype(dst), device=t.device)
@@ -169,14 +180,35 @@ def convert(x, dst, via=None, scale: float = 1.0, flip: bool = False) -> torch.T
 def asdevice(x, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """numpy / host tensor -> contiguous tensor in HBM (PCIe copy); device tensors pass.
 
-    Without `dtype` the array keeps its dtype -- float32 / float64 compute in their own dtype like numpy, integer and
-    bool arrays stay integral (the operators widen them to int64 lanes themselves; xgcm_amd.dtypes) -- and anything
-    else (float16 ...) is promoted to float64.  With `dtype` (a float dtype: the lanes a call computes on) the array is
-    converted in HBM by xg_convert, numpy's `astype`."""
+    Without `dtype` the array keeps its dtype (in native byte order) -- float32 / float64 compute in their own dtype like
+    numpy, float16 arrays are stored as they are and widened to float32 lanes by the operators, integer and bool arrays
+    stay integral (the operators widen them to integer lanes themselves; xgcm_amd.dtypes); bfloat16 tensors become
+    float32.  With `dtype` (a float dtype: the lanes a call computes on) the array is converted in HBM by xg_convert,
+    numpy's `astype`."""
     t = _raw_device(x)
     if dtype is None:
-        return t if _dt.np_dtype(t).name in _SERVED else convert(t, _dt.FLOAT64)
+        return t if t.dtype != torch.bfloat16 else convert(t, _dt.FLOAT32)
     return t if t.dtype == dtype else convert(t, _dt._TORCH_TO_NUMPY[dtype])
+
+
+def _half(*arrays) -> bool:
+    """numpy returns float16 for these operands (xgcm_amd.dtypes.half_result): narrow the float32-lane result"""
+    return _dt.half_result(*[_dt.np_dtype(a) for a in arrays if a is not None])
+
+
+def _out(res, half: bool):
+    """a float32-lane result as numpy's float16 where numpy returns float16 (one rounding, xg_convert)"""
+    if not half:
+        return res
+    if isinstance(res, tuple):
+        return tuple(_out(r, True) for r in res)
+    return convert(res, _dt.FLOAT16)
+
+
+def _metric_steps(x, m_in, m_out):
+    """(pre_mul, post_div) of xgcm_amd.dtypes.metric_steps for these operands"""
+    return _dt.metric_steps(_dt.np_dtype(x), None if m_in is None else _dt.np_dtype(m_in),
+                            None if m_out is None else _dt.np_dtype(m_out))
 
 
 def _dtype_of(x) -> torch.dtype:
@@ -281,8 +313,10 @@ HOST_STREAM_BLOCK_BYTES = (64 << 20, 2 << 30)
 
 
 def _host_streamable(x, axis: int) -> bool:
+    # (float32 / float64 in either byte order: the streamer moves raw bytes and swaps big-endian blocks in HBM)
     return (isinstance(x, np.ndarray) and x.ndim >= 2 and axis % x.ndim != 0 and x.shape[0] >= 2
-            and x.dtype in (np.float32, np.float64) and x.nbytes >= HOST_STREAM_MIN_BYTES and torch.cuda.is_available())
+            and _dt.native(x.dtype) in (_dt.FLOAT32, _dt.FLOAT64) and x.nbytes >= HOST_STREAM_MIN_BYTES
+            and torch.cuda.is_available())
 
 
 def _rows(m, sl, ndim: int, what: str = "metric"):
@@ -353,6 +387,12 @@ def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str]
                             None if m_out is None else _dt.np_dtype(m_out))
     if plan.lanes == "int":
         return _int_stencil1d(plan, op, x, None, axis, pad_lo, pad_hi, bc, fill, m_out)
+    pre_mul, post_div = _metric_steps(x, m_in, m_out)
+    if pre_mul:  # a float16 product: rounded to float16 before the body sees it
+        x, m_in = binary("mul", x, m_in), None
+    if post_div:  # the body's result is rounded to ITS dtype before the (wider, or float16) division
+        return binary("div", stencil1d(op, x, axis, pad_lo, pad_hi, bc, fill, m_in, None), m_out)
+    half = _half(x, m_in, m_out)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis = axis % x.dim()
@@ -364,7 +404,7 @@ def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str]
     m_out = _prep_metric(m_out, dt)
     out = torch.empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:  # empty outer dims: nothing to launch (a NULL data_ptr is not a valid ABI argument)
-        return out
+        return _out(out, half)
     _hip.check(
         getattr(lib, "xg_stencil1d_" + sfx)(
             _hip.OP[op], x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, n_out,
@@ -373,7 +413,7 @@ def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str]
             _ptr(m_out), _hip.i64(_bstrides(m_out, oshape, "m_out")), _stream(),
         )
     )
-    return out
+    return _out(out, half)
 
 
 def stencil1d_halo(op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, m_out=None, m_in=None) -> torch.Tensor:
@@ -389,6 +429,12 @@ def stencil1d_halo(op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, m_out=
     if _is_int(x) and _is_int(halo) and m_in is None:
         plan = _dt.stencil_plan(op, _dt.np_dtype(x), None, None if m_out is None else _dt.np_dtype(m_out))
         return _int_stencil1d(plan, op, x, halo, axis, pad_lo, pad_hi, "halo", 0, m_out)
+    pre_mul, post_div = _metric_steps(x, m_in, m_out)
+    if pre_mul:  # float16: the product (and, by the caller's contract, the halo of the product) is float16 already
+        x, m_in = binary("mul", x, m_in), None
+    if post_div:
+        return binary("div", stencil1d_halo(op, x, halo, axis, pad_lo, pad_hi, None, m_in), m_out)
+    half = _half(x, halo, m_out, m_in)
     dt, sfx = _common(x, halo, m_out, m_in)
     x = asdevice(x, dt)
     halo = asdevice(halo, dt)
@@ -399,7 +445,7 @@ def stencil1d_halo(op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, m_out=
     oshape[axis] = n_out
     out = torch.empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
-        return out
+        return _out(out, half)
     m_out = _prep_metric(m_out, dt)
     if m_in is not None:
         m_in = _prep_metric(m_in, dt)
@@ -410,14 +456,14 @@ def stencil1d_halo(op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, m_out=
                 _hip.i64(_bstrides(m_in, list(x.shape), "m_in")), _ptr(m_out), _hip.i64(_bstrides(m_out, oshape, "m_out")),
                 _stream())
         )
-        return out
+        return _out(out, half)
     _hip.check(
         getattr(lib, "xg_stencil1d_halo_" + sfx)(
             _hip.OP[op], x.data_ptr(), halo.data_ptr() if halo.numel() else None, out.data_ptr(),
             _hip.i64(list(x.shape)), x.dim(), axis, n_out, int(pad_lo), int(pad_hi), _ptr(m_out),
             _hip.i64(_bstrides(m_out, oshape, "m_out")), _stream())
     )
-    return out
+    return _out(out, half)
 
 
 def _int_cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int, bc: Optional[str], fill,
@@ -455,6 +501,12 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
                                                   _rows(m_in, sl, x.ndim, 'm_in'), _rows(m_out, sl, x.ndim, 'm_out')), x)
     if _is_int(x) and m_in is None:
         return _int_cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, m_out)
+    pre_mul, post_div = _metric_steps(x, m_in, m_out)
+    if pre_mul:
+        x, m_in = binary("mul", x, m_in), None
+    if post_div:
+        return binary("div", cumsum1d(x, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, skipna, m_in, None), m_out)
+    half = _half(x, m_in, m_out)
     dt, sfx = _common(x, m_in, m_out)
     x = asdevice(x, dt)
     axis = axis % x.dim()
@@ -465,14 +517,14 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
     m_out = _prep_metric(m_out, dt)
     out = torch.empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
-        return out
+        return _out(out, half)
     if shape[axis] - trim_lo - trim_hi == 0:
         # everything trimmed away: only halo cells remain.  numpy.pad can fill an empty axis with a
         # constant but refuses to wrap/extend it -- same here.
         if bc != "fill":
             raise ValueError(f"can't extend empty axis {axis} using modes other than 'constant' or 'empty'")
         synthetic(tuple(oshape), 0, 0, 0.0, float(fill), out=out)
-        return out if m_out is None else binary("div", out, m_out)
+        return _out(out if m_out is None else binary("div", out, m_out), half)
     _hip.check(
         getattr(lib, "xg_cumsum1d_" + sfx)(
             x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, int(bool(reverse)), int(bool(skipna)),
@@ -481,7 +533,7 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
             _ptr(m_out), _hip.i64(_bstrides(m_out, oshape, "m_out")), _stream(),
         )
     )
-    return out
+    return _out(out, half)
 
 
 _REDUCE_MODE = {"valid": 2, "all": 3, "mean_valid": 4, "mean_all": 5, "pair_valid": 6, "pair_all": 7}
@@ -507,6 +559,9 @@ def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
             _hip.check(lib.xg_reduce1d_i64(t.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, 0, None, None,
                                            _stream()))
         return _narrow(out, res_dt)
+    half = _half(x, w)
+    if half and w is not None and skipna not in ("valid", "all"):  # the float16 product is rounded before it is summed
+        x, w = binary("mul", x, w), None
     dt, sfx = _common(x, w)
     x = asdevice(x, dt)
     axis = axis % x.dim()
@@ -517,16 +572,16 @@ def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
     w = _prep_metric(w, dt)
     out = torch.empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
-        return out
+        return _out(out, half)
     if x.numel() == 0:  # sum over an empty axis is 0
-        return synthetic(tuple(oshape), 0, 0, 0.0, 0.0, out=out)
+        return _out(synthetic(tuple(oshape), 0, 0, 0.0, 0.0, out=out), half)
     _hip.check(
         getattr(lib, "xg_reduce1d_" + sfx)(
             x.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, _REDUCE_MODE.get(skipna, int(bool(skipna))),
             _ptr(w), _hip.i64(_bstrides(w, shape, "w")), _stream(),
         )
     )
-    return out
+    return _out(out, half)
 
 
 def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
@@ -541,6 +596,7 @@ def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
     else:
         dt, sfx = _common(x)
         x = asdevice(x, dt)
+    half = src == _dt.FLOAT16
     nd = x.dim()
     lo = [0] * nd
     hi = [0] * nd
@@ -558,12 +614,12 @@ def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
     oshape = [s + l + h for s, l, h in zip(x.shape, lo, hi)]
     out = torch.empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
-        return _narrow(out, src) if ints else out
+        return _narrow(out, src) if ints else _out(out, half)
     _hip.check(
         getattr(lib, "xg_pad_" + sfx)(x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), nd, _hip.i64(lo),
                                       _hip.i64(hi), _hip.ints(bcv), _hip.reals(fv, sfx), _hip.ints(order), _stream())
     )
-    return _narrow(out, src) if ints else out
+    return _narrow(out, src) if ints else _out(out, half)
 
 
 def upload_tokens(tokens: np.ndarray) -> torch.Tensor:
@@ -578,6 +634,7 @@ def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_sh
     lib = _hip.load()
     ints = _is_int(x) and (partner is None or _is_int(partner))
     res_dt = None
+    half = False
     if ints:  # halos of an integer field stay integral (the reference concatenates / pads the array in its own dtype)
         res_dt = np.result_type(_dt.np_dtype(x), *([] if partner is None else [_dt.np_dtype(partner)]))
         ints = _dt.is_integer(res_dt)  # int64 with uint64 promotes to float64
@@ -589,6 +646,7 @@ def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_sh
         fills = [_lane_int(_dt.fill_as(res_dt, f), lane) for f in fills]
     else:
         dt, sfx = _common(x, partner) if partner is not None else _common(x)
+        half = _half(x, partner)
         x = asdevice(x, dt)
     nd = x.dim()
     if partner is not None:
@@ -601,7 +659,7 @@ def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_sh
         tokens = upload_tokens(tokens)
     out = torch.empty([int(v) for v in out_shape], dtype=dt, device=x.device)
     if out.numel() == 0:
-        return _narrow(out, res_dt) if ints else out
+        return _narrow(out, res_dt) if ints else _out(out, half)
     _hip.check(
         getattr(lib, "xg_gather_" + sfx)(
             x.data_ptr(), _ptr(partner), out.data_ptr(), _hip.i64(list(x.shape)),
@@ -610,7 +668,7 @@ def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_sh
             _hip.i64(list(lo)), tokens.data_ptr(), int(tokens.numel()), _hip.reals(list(fills) or [0.0], sfx),
             len(fills), _stream())
     )
-    return _narrow(out, res_dt) if ints else out
+    return _narrow(out, res_dt) if ints else _out(out, half)
 
 
 def put_halo(out: torch.Tensor, halo, axis: int, pad_lo: int, pad_hi: int) -> torch.Tensor:
@@ -626,7 +684,10 @@ def put_halo(out: torch.Tensor, halo, axis: int, pad_lo: int, pad_hi: int) -> to
     if list(halo.shape) != expect:
         raise ValueError(f"halo buffer has shape {tuple(halo.shape)}, expected {tuple(expect)}")
     odt = _dt.np_dtype(out)
+    if odt == _dt.FLOAT16:  # no float16 lanes: through float32 and back (both exact); callers use the RETURNED tensor
+        return convert(put_halo(convert(out, _dt.FLOAT32), halo, axis, pad_lo, pad_hi), _dt.FLOAT16)
     if odt.name not in ("float64", "float32", "int64", "uint64", "int32", "uint32"):
+        # (narrower integers never get here: scans / sums of 8 / 16-bit integers return 64-bit)
         raise TypeError(f"put_halo serves float64 / float32 / 64- and 32-bit integer arrays, not {odt}")
     h = _raw_device(halo)
     if _dt.np_dtype(h) != odt:
@@ -707,6 +768,7 @@ def binary(op: str, a, b) -> torch.Tensor:
     """Broadcasting a OP b for dim-aligned operands (same ndim, extents equal or 1)."""
     lib = _hip.load()
     lanes, res_dt = _dt.binary_plan(op, _dt.np_dtype(a), _dt.np_dtype(b))
+    half = False
     if lanes == "int":  # numpy keeps int OP int integral (wrap-around in the promoted dtype): its lanes, narrowed
         lane = _dt.lane_of(res_dt)
         dt, sfx = _dt.torch_dtype(lane), _LANE_SFX[lane.name]
@@ -715,6 +777,7 @@ def binary(op: str, a, b) -> torch.Tensor:
         b = _widen(b if _dt.same_bits(_dt.np_dtype(b), lane) else convert(b, res_dt), lane)
     else:
         dt, sfx = (torch.float32, "f32") if res_dt == _dt.FLOAT32 else (torch.float64, "f64")
+        half = _half(a, b)  # one float32 operation rounded once to float16 IS numpy's float16 operation
         a = asdevice(a, dt)
         b = asdevice(b, dt)
     if a.dim() != b.dim():
@@ -730,7 +793,7 @@ def binary(op: str, a, b) -> torch.Tensor:
             getattr(lib, "xg_binary_" + sfx)(_hip.BINOP[op], a.data_ptr(), _hip.i64(_bstrides(a, shape, "a")), b.data_ptr(),
                               _hip.i64(_bstrides(b, shape, "b")), out.data_ptr(), _hip.i64(shape), len(shape), _stream())
         )
-    return _narrow(out, res_dt) if lanes == "int" else out
+    return _narrow(out, res_dt) if lanes == "int" else _out(out, half)
 
 
 def _pair_halos(halo_x, halo_y, shape, dt):

@@ -24,6 +24,7 @@ INT32 = np.dtype(np.int32)
 UINT64 = np.dtype(np.uint64)
 FLOAT64 = np.dtype(np.float64)
 FLOAT32 = np.dtype(np.float32)
+FLOAT16 = np.dtype(np.float16)
 BOOL = np.dtype(np.bool_)
 
 _TORCH_TO_NUMPY = {}
@@ -34,16 +35,51 @@ if torch is not None:
     _TORCH_TO_NUMPY[torch.bfloat16] = np.dtype(np.float32)  # no numpy twin: treated as its float32 promotion
 
 
+def native(dt) -> np.dtype:
+    """`dt` in the machine's byte order: what every numpy operation RETURNS for an array of dtype `dt` (the reference's
+    bodies are numpy expressions, xgcm/gridops.py:23-24,76-77: a big-endian field in, a native result out)"""
+    dt = np.dtype(dt)
+    return dt if dt.isnative else dt.newbyteorder("=")
+
+
 def np_dtype(x) -> np.dtype:
-    """numpy dtype of a numpy array, a torch tensor, a python scalar or a dtype"""
+    """numpy dtype, in NATIVE byte order, of a numpy array, a torch tensor, a python scalar or a dtype: everything that
+    plans lanes and result dtypes reasons about values, and `>f8` holds the values of float64"""
     if torch is not None and isinstance(x, torch.Tensor):
         return _TORCH_TO_NUMPY[x.dtype]
     if isinstance(x, np.dtype):
-        return x
+        return native(x)
     dt = getattr(x, "dtype", None)
     if dt is not None and isinstance(dt, np.dtype):
-        return dt
-    return np.asarray(x).dtype
+        return native(dt)
+    return native(np.asarray(x).dtype)
+
+
+SERVED = ("bool", "int8", "int16", "int32", "int64", "uint8", "uint16", "uint32", "uint64", "float16", "float32", "float64")
+
+
+def check_served(dt, what: str = "array") -> np.dtype:
+    """native twin of `dt` if the kernels serve it, else a TypeError that names the dtype (complex, object, str,
+    datetime64, float128 ...: numpy would compute some of them, this backend does not -- say so instead of failing on a
+    table lookup further down)"""
+    dt = native(dt)
+    if dt.name not in SERVED:
+        kind = "complex arrays are" if dt.kind == "c" else f"dtype {dt} is"
+        raise TypeError(f"{what}: {kind} not supported by the MI355X backend (served: bool, (u)int8-64, float16 / 32 / 64, "
+                        "in either byte order)")
+    return dt
+
+
+def host_intake(a: np.ndarray):
+    """(`a`'s bytes seen as a NATIVE-order array -- a view, no copy --, element size if the byte order must be reversed
+    after the copy else 0).  ONE intake rule for every backend (HIP: PCIe copy of the raw bytes, `xg_bswap` in HBM; host
+    ABI double: copy, `xg_bswap` of the host build): an array of non-native byte order -- `np.fromfile(f, ">f4")`, an
+    MDS / NetCDF-3 record, xmitgcm output -- is never reinterpreted by its dtype NAME (`np.dtype(">f8").name` is
+    "float64")."""
+    dt = check_served(a.dtype)
+    if a.dtype.isnative or a.dtype.itemsize == 1:
+        return (a if a.dtype == dt else a.view(dt)), 0
+    return a.view(dt), a.dtype.itemsize
 
 
 def torch_dtype(dt):
@@ -57,9 +93,34 @@ def is_integer(dt) -> bool:
 
 def float_of(*dtypes) -> np.dtype:
     """the float lanes a mix of operands computes on: numpy's array-array promotion, float32 only when it yields
-    float32 (all-float32 operands, or float32 next to 8 / 16-bit integers), float64 for everything else"""
-    rt = np.result_type(*[np.dtype(d) for d in dtypes]) if dtypes else FLOAT64
-    return FLOAT32 if rt == FLOAT32 else FLOAT64
+    float32 (all-float32 operands, or float32 next to 8 / 16-bit integers) or float16 (no float16 lanes exist: float16
+    arrays are widened to float32, see `half_result`), float64 for everything else"""
+    rt = np.result_type(*[native(d) for d in dtypes]) if dtypes else FLOAT64
+    return FLOAT32 if rt in (FLOAT32, FLOAT16) else FLOAT64
+
+
+def half_result(*dtypes) -> bool:
+    """does numpy return float16 for this mix of operands (all float16, or float16 next to bool / 8-bit integers)?
+    Then the float32-lane result is narrowed to float16 on the way out: every single numpy operation on float16 is the
+    float32 operation rounded once (numpy's half loops do exactly that), so `diff`, `min`, `max`, `pad`, `a OP b` are bit
+    for bit numpy's; `interp` differs where `a + b` overflows float16 (numpy: inf, here the finite mean), and sums /
+    prefix sums carry float32 partial sums where numpy rounds every partial sum to float16 (stated tolerance in
+    tests/test_dtype_intake.py)."""
+    present = [native(d) for d in dtypes if d is not None]
+    return bool(present) and np.result_type(*present) == FLOAT16
+
+
+def metric_steps(x_dt, m_in_dt=None, m_out_dt=None):
+    """(pre_mul, post_div): numpy evaluates `(x * m_in)` -> body -> `/ m_out` (xgcm/grid.py:804-808,830-832) one operation
+    at a time, each in ITS promoted dtype and rounded to it.  The kernels fuse the three on ONE set of lanes, which is the
+    same arithmetic only when every step runs in that dtype; otherwise the step numpy rounds differently runs on its own:
+    `x * m_in` first when the product is float16, `/ m_out` afterwards when the quotient is wider than the body's dtype
+    (float32 field, float64 metric: the difference is rounded to float32 BEFORE it is divided) or float16."""
+    x_dt = native(x_dt)
+    pre = x_dt if m_in_dt is None else np.result_type(x_dt, native(m_in_dt))
+    pre_mul = m_in_dt is not None and pre == FLOAT16
+    post_div = m_out_dt is not None and (pre == FLOAT16 or float_of(pre, m_out_dt) != float_of(pre))
+    return pre_mul, post_div
 
 
 def fill_as(dt, fill):
