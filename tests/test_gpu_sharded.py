@@ -39,7 +39,7 @@ def test_two_ranks_on_the_real_library_equal_one_rank_and_the_oracle():
     assert p2.returncode == 0, p2.stderr[-3000:]
     ops1 = [ln for ln in one if "op" in ln]
     ops2 = [ln for ln in two if "op" in ln]
-    assert len(ops1) == len(ops2) == 4
+    assert len(ops1) == len(ops2) == 5   # config 4: two operators; config 5: fused, chain, chain as written under grid.fused()
     for a, b in zip(ops1, ops2):
         assert a["op"] == b["op"] and a["n_gpus"] == 1 and b["n_gpus"] == 2
         assert a["checksum_u64"] == b["checksum_u64"] and a["cells"] == b["cells"]
@@ -56,7 +56,7 @@ def test_two_ranks_on_the_real_library_equal_one_rank_and_the_oracle():
     area = R.synthetic(ny * nx, 53, 0, 1000.0, 1000.0).reshape(ny, nx)
     want = (R.stencil1d("diff", V, 2, 1, 0, "fill") - R.stencil1d("diff", U, 1, 1, 0, "fill")) / area
     chk = f"{int(np.ascontiguousarray(want).view(np.uint64).sum(dtype=np.uint64)):016x}"
-    assert ops1[2]["checksum_u64"] == chk and ops1[3]["checksum_u64"] == chk
+    assert ops1[2]["checksum_u64"] == chk and ops1[3]["checksum_u64"] == chk and ops1[4]["checksum_u64"] == chk
 
 
 def test_bench_line_measures_its_hbm_traffic_in_the_run():

@@ -38,7 +38,7 @@ def test_two_gloo_ranks_through_the_launcher_equal_one_rank():
     assert p2.returncode == 0, p2.stderr[-2000:]
     assert "torch.distributed.run" in p2.stderr  # the launcher re-executed itself with 2 ranks
     a, b = _by_op(one), _by_op(two)
-    assert a.keys() == b.keys() and len(a) == 4
+    assert a.keys() == b.keys() and len(a) == 5  # config 4: two operators; config 5: fused, chain, chain as written under grid.fused()
     for k in a:
         assert a[k]["n_gpus"] == 1 and b[k]["n_gpus"] == 2 and b[k]["backend"] == "gloo"
         assert a[k]["cells"] == b[k]["cells"] and sum(b[k]["per_rank_cells"]) == a[k]["cells"]
@@ -61,7 +61,7 @@ def test_eight_gloo_ranks_at_the_baseline_splits():
     p8, eight = _run([DRIVER, "--gpus", "8"] + args, timeout=600)
     assert p8.returncode == 0, p8.stderr[-2000:]
     a, b = _by_op(one), _by_op(eight)
-    assert a.keys() == b.keys() and len(a) == 4
+    assert a.keys() == b.keys() and len(a) == 5  # config 4: two operators; config 5: fused, chain, chain as written under grid.fused()
     for k in a:
         assert b[k]["n_gpus"] == 8 and len(b[k]["per_rank_device_ms"]) == 8
         assert sum(b[k]["per_rank_cells"]) == a[k]["cells"] and a[k]["checksum_u64"] == b[k]["checksum_u64"], k

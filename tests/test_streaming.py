@@ -175,6 +175,50 @@ def test_stream_blocks_from_memory_mapped_files(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("in_place", [True, False])
+def test_iter_stream_with_a_reader_that_refills_one_buffer(in_place):
+    """blocks of 8 MB or more are page-locked in place and copied asynchronously from the READER's
+    memory; a generator that refills one buffer (`readinto(buf); yield buf`) must not be asked for its next block before
+    that copy has finished -- every block, the first included, arrives uncorrupted; the buffer is locked once"""
+    from xgcm_amd import device as dev
+    from xgcm_amd.streaming import iter_stream
+
+    nz, ny, nx = 4, 512, 640            # 10 MB per block: above the in-place threshold
+    nblocks = 6
+    buf = np.empty((1, nz, ny, nx))
+
+    def reader():
+        for k in range(nblocks):
+            buf[...] = R.synthetic_field(buf.shape, 300 + k)     # overwrites the buffer the previous copy read from
+            yield buf
+
+    diff_x = lambda x: dev.stencil1d("diff", x, 3, 1, 0, "periodic")  # noqa: E731
+    got = list(iter_stream(diff_x, reader(), in_place=in_place))
+    assert len(got) == nblocks
+    for k, g in enumerate(got):
+        np.testing.assert_array_equal(g, R.stencil1d("diff", R.synthetic_field(buf.shape, 300 + k), 3, 1, 0, "periodic"))
+
+
+@pytest.mark.gpu
+def test_iter_stream_keeps_the_dtype_of_integer_and_bool_results():
+    """the staging buffers take the RESULT's dtype (they used to be float32 / float64 only: an int64 or
+    bool tensor returned by `fn` came back as floats)"""
+    import torch
+
+    from xgcm_amd.streaming import iter_stream, stream_blocks
+
+    a = R.synthetic_field((5, 3, 8, 64), 41)
+    counts = lambda x: (x > 0).sum(dim=1)          # int64  # noqa: E731
+    masks = lambda x: x > 0                         # bool   # noqa: E731
+    got = stream_blocks(counts, (a[i:i + 2] for i in range(0, 5, 2)))
+    assert got.dtype == np.int64 and np.array_equal(got, (a > 0).sum(axis=1))
+    got = np.concatenate(list(iter_stream(masks, (a[i:i + 2] for i in range(0, 5, 2)))))
+    assert got.dtype == np.bool_ and np.array_equal(got, a > 0)
+    with pytest.raises(TypeError, match="not served"):
+        list(iter_stream(lambda x: x.to(torch.bfloat16), [a[:1]]))
+
+
+@pytest.mark.gpu
 def test_stream_blocks_through_the_grid_api():
     from xgcm_amd.streaming import stream_blocks
 

@@ -21,9 +21,11 @@ and rejected loudly: dask-chunked inputs, metadata autoparsing (SURVEY.md sectio
 
 from __future__ import annotations
 
+import contextlib
 import functools
 import itertools
 import operator
+import threading
 import warnings
 from collections import OrderedDict
 from typing import Any, Dict, Iterable, List, Mapping, Optional, Tuple
@@ -41,6 +43,7 @@ from .grid_ufunc import (
     _reattach_coords,
     apply_as_grid_ufunc,
 )
+from . import lazy as _lazy
 from .labeled import CHUNKED_INPUT_MESSAGE, DataArray, Dataset, _aligned_view, _is_tensor, from_xarray, is_xarray, to_xarray
 from .metrics import iterate_axis_combinations
 from .padding import FoldSpec, InteriorOf, halo_cells, no_boundary_error, pad
@@ -63,7 +66,7 @@ class Grid:
 
     def __init__(self, ds, coords: Optional[Mapping[str, Mapping[str, str]]] = None, fill_value=None,
                  default_shifts=None, padding=None, face_connections=None, metrics=None,
-                 autoparse_metadata: bool = True, **kwargs):
+                 autoparse_metadata: bool = True, fuse: bool = False, **kwargs):
         if "boundary" in kwargs:
             raise ValueError("Argument 'boundary' has been renamed to 'padding'. Please use 'padding' instead.")
         if is_xarray(ds):
@@ -71,6 +74,11 @@ class Grid:
         if not isinstance(ds, Dataset):
             raise TypeError(f"ds argument to `xgcm.Grid` must be of type xarray.Dataset, but is of type {type(ds)}")
         self._ds = ds
+        # `fuse=True` (or `with grid.fused():`): diff / interp / min / max / derivative return deferred results whose
+        # chains -- `(grid.diff(v, "X") - grid.diff(u, "Y")) / area` -- run as ONE fused kernel when the value is used
+        # (xgcm_amd.lazy; the reference's own TODO, xgcm/grid.py:797-799).  Off by default: results are computed at the call.
+        self._fuse = bool(fuse)
+        self._fuse_local = threading.local()
         if autoparse_metadata:
             # COMODO attributes / SGRID topology of the dataset supply what the caller left out; what BOTH supply is a
             # conflict, never a silent choice (xgcm/grid.py:151-195 -- `coords` is always among the parsed kwargs, so
@@ -262,6 +270,25 @@ class Grid:
             lines += axis._coord_desc()
         return "\n".join(lines)
 
+    # ---- deferred results (xgcm_amd.lazy) -----------------------------------------------------
+    @contextlib.contextmanager
+    def fused(self):
+        """Inside the block the built-in 1-D operators return deferred results (`xgcm_amd.lazy.LazyArray`): chains of
+        them and `+ - * /` are matched against the fused kernels when a value is first used -- bit-identical to the
+        eager chain, one launch instead of three or four.  Per thread; nests."""
+        depth = getattr(self._fuse_local, "depth", 0)
+        self._fuse_local.depth = depth + 1
+        _lazy.enter()
+        try:
+            yield self
+        finally:
+            _lazy.leave()
+            self._fuse_local.depth = depth
+
+    @property
+    def _fusing(self) -> bool:
+        return self._fuse or getattr(self._fuse_local, "depth", 0) > 0
+
     # ---- residency helpers ------------------------------------------------------------------
     def _resident(self, da: DataArray, like) -> DataArray:
         """Metric arrays of grid._ds are uploaded once and kept in HBM while HBM data is processed."""
@@ -451,7 +478,8 @@ class Grid:
         i = 0
         while i < len(steps):
             sig, ax_name = steps[i]
-            if i + 1 < len(steps) and vector_key is None and other_component is None and _divide_by is None:
+            if (i + 1 < len(steps) and vector_key is None and other_component is None and _divide_by is None
+                    and not (self._fusing and isinstance(array, _lazy.LazyArray))):
                 w_a = metric_weighted.get(ax_name) if isinstance(metric_weighted, dict) else None
                 w_b = metric_weighted.get(steps[i + 1][1]) if isinstance(metric_weighted, dict) else None
                 fused = None
@@ -470,10 +498,10 @@ class Grid:
             m_in = m_out = None
             post_divide = None
             if weighted:
-                m_in = self._resident(self.get_metric(array, weighted, _layout=array.dims), array.data)
-                m_out = self._resident(self.get_metric(_DimsOnly(out_dims, array.name), weighted, _layout=out_dims), array.data)
+                m_in = self._resident(self.get_metric(array, weighted, _layout=array.dims), _lazy.like(array))
+                m_out = self._resident(self.get_metric(_DimsOnly(out_dims, array.name), weighted, _layout=out_dims), _lazy.like(array))
             if _divide_by is not None:
-                dx = self._resident(self.get_metric(_DimsOnly(out_dims, array.name), _divide_by, _layout=out_dims), array.data)
+                dx = self._resident(self.get_metric(_DimsOnly(out_dims, array.name), _divide_by, _layout=out_dims), _lazy.like(array))
                 if m_out is None:
                     m_out = dx
                 else:
@@ -488,8 +516,14 @@ class Grid:
                     array = array * m_in
                     arg = {vector_key: array} if vector_key is not None else array
                     m_in = None
-                array = ufunc(self, arg, axis=[(ax_name,)], other_component=other_component, metric_in=m_in,
-                              metric_out=m_out, **remaining)
+                if self._fusing and post_divide is None:
+                    deferred = _lazy.defer_stencil(self, funcname, ufunc, sig, arg, ax_name, other_component, m_in, m_out,
+                                                   remaining, out_dims)
+                    if deferred is not None:
+                        array = deferred
+                        continue
+                array = ufunc(self, _lazy.plain(arg), axis=[(ax_name,)], other_component=_lazy.plain(other_component),
+                              metric_in=m_in, metric_out=m_out, **remaining)
             else:  # a plain GridUFunc registered in gridops (none of the built-ins): unfused sequence
                 if m_in is not None:
                     array = array * m_in

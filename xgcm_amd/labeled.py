@@ -27,6 +27,9 @@ except Exception:  # pragma: no cover
     torch = None  # type: ignore
 
 
+_LAZY_HOOK = None  # set by xgcm_amd.lazy: (self, other, op, reflexive, dims_order) -> deferred result or None
+
+
 def _is_tensor(x) -> bool:
     return torch is not None and isinstance(x, torch.Tensor)
 
@@ -249,6 +252,10 @@ class DataArray:
     def _binary(self, other, op: str, reflexive: bool = False, dims_order: Optional[Sequence[str]] = None) -> "DataArray":
         """`self OP other` with name-based broadcasting.  `dims_order` (internal): lay the result out with its dims in
         that order instead of xarray's (self's dims, then other's new ones) -- same values, no transposed copy later."""
+        if _LAZY_HOOK is not None:  # `array OP deferred_result`, `field * metric` inside `grid.fused()`: xgcm_amd.lazy
+            res = _LAZY_HOOK(self, other, op, reflexive, dims_order)
+            if res is not None:
+                return res
         if isinstance(other, (int, float, np.integer, np.floating)):
             # python scalars are "weak" (numpy's promotion): a float32 array stays float32 next to 2.0, an integer array
             # stays integral next to 2 and becomes float64 next to 2.0; numpy scalars carry their own dtype

@@ -52,6 +52,7 @@ def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding
         other_component=None, **kwargs):
     """Pad `data` along the given grid axes according to the boundary conditions."""
     halo_only = kwargs.pop("_halo_only", None)  # internal: see `halo_cells`
+    dry = kwargs.pop("_dry", False)  # internal (xgcm_amd.lazy): validate and build the halo map, move nothing, return None
     if "boundary" in kwargs:
         raise ValueError("Argument 'boundary' has been renamed to 'padding'. Please use 'padding' instead.")
     if "boundary_width" in kwargs:
@@ -69,9 +70,9 @@ def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding
             halo_only is not None or any(ax in connected and any(w) for ax, w in padding_width.items())):
         # (padding only axes that no link touches is the ordinary per-axis pad: `_pad_face_connections`
         # pre-pads them with `_pad_basic`, overwrites nothing and trims the other axes back to zero width)
-        return _pad_face_connections(data, grid, padding_width, padding, fill_value, other_component, halo_only)
+        return _pad_face_connections(data, grid, padding_width, padding, fill_value, other_component, halo_only, dry)
     if getattr(grid, "_folds", None) and any(ax in grid._folds for ax in padding_width):
-        return _pad_fold(data, grid, padding_width, padding, fill_value, halo_only)
+        return _pad_fold(data, grid, padding_width, padding, fill_value, halo_only, dry)
     if halo_only is not None:
         raise ValueError("halo-only padding is meant for complex topologies")
     if isinstance(data, dict):
@@ -241,7 +242,7 @@ def _reindex_tokens(tokens: np.ndarray, src_sizes, k: int, lo: int, hi: int) -> 
 
 
 def _gather(data: DataArray, partner: Optional[DataArray], grid, key, build, partner_same_as=None,
-            halo_dim: Optional[str] = None) -> DataArray:
+            halo_dim: Optional[str] = None, dry: bool = False) -> DataArray:
     """Run (or reuse) the token-plane builder `build()` -> (plane, mapped dims, lo per dim, fills)
     and move the data through it.  With `halo_dim` only the halo cells along that dim are produced."""
     cache = grid.__dict__.setdefault("_halo_maps", {})
@@ -270,6 +271,8 @@ def _gather(data: DataArray, partner: Optional[DataArray], grid, key, build, par
         if len(cache) > 64:
             cache.clear()
         cache[key] = entry
+    if dry:  # the map exists (every check of the topology has run); the caller moves the data later
+        return None
     mapped = [d in entry["sizes"] for d in data.dims]
     out_shape = [entry["sizes"].get(d, n) for d, n in zip(data.dims, data.shape)]
     lo = [int(entry["lo"].get(d, 0)) for d in data.dims]
@@ -303,7 +306,7 @@ def _fill_key(fill_value: Mapping) -> Tuple:
 # ------------------------------------------------------------------------------------------
 # north fold (reference padding.py:689-762)
 # ------------------------------------------------------------------------------------------
-def _pad_fold(data, grid, padding_width, padding, fill_value, halo_only=None) -> DataArray:
+def _pad_fold(data, grid, padding_width, padding, fill_value, halo_only=None, dry: bool = False) -> DataArray:
     isvector = isinstance(data, dict)
     if isvector:
         # a fold is a 180-degree pivot: the lone component flips sign, no partner is needed
@@ -323,7 +326,7 @@ def _pad_fold(data, grid, padding_width, padding, fill_value, halo_only=None) ->
             basic_width[ax] = tuple(w)
             basic_padding[ax] = padding[ax]
     if not fold_axes and halo_only is None:
-        return _pad_basic(data, grid, basic_width, basic_padding, fill_value)
+        return None if dry else _pad_basic(data, grid, basic_width, basic_padding, fill_value)
 
     fax = fold_axes[0] if fold_axes else halo_only
     info = grid._folds[fax]
@@ -350,7 +353,7 @@ def _pad_fold(data, grid, padding_width, padding, fill_value, halo_only=None) ->
 
     key = ("fold", data.dims, sizes, fax, tuple((k, tuple(v)) for k, v in padding_width.items()),
            tuple(sorted(basic_padding.items(), key=str)), _fill_key(fill_value), isvector, repr(info["pivot"]))
-    return _gather(data, None, grid, key, build, None, None if halo_only is None else dim_of_axis[halo_only])
+    return _gather(data, None, grid, key, build, None, None if halo_only is None else dim_of_axis[halo_only], dry)
 
 
 # ------------------------------------------------------------------------------------------
@@ -384,7 +387,7 @@ def _get_all_connection_axes(connections, facedim):
 
 
 def _pad_face_connections(da, grid, padding_width, padding, fill_value, other_component=None,
-                          halo_only=None) -> DataArray:
+                          halo_only=None, dry: bool = False) -> DataArray:
     facedim, connections = grid._facedim, grid._face_connections
     for what, value in (("Grid connections", connections), ("Face dimension", facedim)):
         if value is None:
@@ -473,4 +476,4 @@ def _pad_face_connections(da, grid, padding_width, padding, fill_value, other_co
                     own = [c for c in cand if c in da.dims]
                     if own:
                         same_as[d] = own[0]
-    return _gather(da, partner, grid, key, build, same_as, None if halo_only is None else dims_own[halo_only])
+    return _gather(da, partner, grid, key, build, same_as, None if halo_only is None else dims_own[halo_only], dry)

@@ -463,19 +463,30 @@ def exchange_halo(local, axis: int, pad: Tuple[int, int], bc: Optional[str], fil
     if world > 1:
         ring = bc == "periodic"
         prev_r, next_r = (rank - 1) % world, (rank + 1) % world
+        # RCCL moves HBM buffers peer to peer over xGMI; a transport that only moves host memory (gloo: ranks sharing one
+        # GPU in the tests, or a CPU run) gets the planes staged through the host -- one plane each way, the same values
+        staged = t.is_cuda and dist.get_backend() != "nccl"
+        wire = (lambda p: p.cpu()) if staged else (lambda p: p)
+        w_lo = wire(recv_lo) if lo else None
+        w_hi = wire(recv_hi) if hi else None
         ops = []
         # order matters when prev == next (two ranks): sends (last, first) pair with recvs (lo, hi)
         if lo and (rank < world - 1 or ring):
-            ops.append(dist.P2POp(dist.isend, last, next_r))
+            ops.append(dist.P2POp(dist.isend, wire(last), next_r))
         if lo and (rank > 0 or ring):
-            ops.append(dist.P2POp(dist.irecv, recv_lo, prev_r))
+            ops.append(dist.P2POp(dist.irecv, w_lo, prev_r))
         if hi and (rank > 0 or ring):
-            ops.append(dist.P2POp(dist.isend, first, prev_r))
+            ops.append(dist.P2POp(dist.isend, wire(first), prev_r))
         if hi and (rank < world - 1 or ring):
-            ops.append(dist.P2POp(dist.irecv, recv_hi, next_r))
+            ops.append(dist.P2POp(dist.irecv, w_hi, next_r))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if staged:
+            if lo:
+                recv_lo.copy_(w_lo)
+            if hi:
+                recv_hi.copy_(w_hi)
         if lo and rank == 0 and not ring:
             recv_lo = boundary(first, None)
         if hi and rank == world - 1 and not ring:
@@ -572,8 +583,12 @@ def cumsum_along_sharded_axis(grid, da, axis: str, dist=None, to=None, padding=N
         t = total if isinstance(total, torch.Tensor) else torch.as_tensor(total)  # (a large host block comes back as numpy)
         if dist.get_backend() == "nccl" and not t.is_cuda:
             t = t.cuda()  # RCCL moves device buffers only
+        elif dist.get_backend() != "nccl" and t.is_cuda:
+            t = t.cpu()   # ... and gloo host buffers only (ranks sharing one GPU in the tests): totals staged through the host
         planes = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(planes, t.contiguous())
+        if not host and not planes[0].is_cuda:
+            planes = [p.cuda() for p in planes]
         if rank > 0:
             plane = (lambda p: _dev.tohost(p)) if host else (lambda p: p)  # reduce1d returns HBM tensors on a GPU box
             carry = DataArray(plane(planes[0]), tuple(d for d in da.dims if d != dim))

@@ -93,6 +93,7 @@ class _BlockPinner:
         self.flat = self.tensor.reshape(-1)  # (C-contiguous: a view)
         self.ready = [threading.Event() for _ in blocks]
         self.pinned = [False] * len(blocks)
+        self._cancelled = False
         self._ranges: List[int] = []
         self._threads: List[threading.Thread] = []
         item = arr.itemsize
@@ -132,7 +133,7 @@ class _BlockPinner:
                 if k is None:
                     return
                 lo, nbytes = spans[k]
-                ok = not failed[0]
+                ok = not failed[0] and not self._cancelled  # (an aborted stream: the remaining blocks stay pageable)
                 try:
                     if ok and nbytes and prefault:
                         e0 = (lo - base) // item
@@ -164,6 +165,10 @@ class _BlockPinner:
             self.ready[k - 1].wait()
         self.ready[k].wait()
         return self.pinned[k]
+
+    def cancel(self) -> None:
+        """stop locking further blocks (the stream was aborted); `close` still joins and unlocks what was locked"""
+        self._cancelled = True
 
     def close(self) -> None:
         for t in self._threads:
@@ -277,12 +282,16 @@ def stream_records(fn: Callable[[torch.Tensor], torch.Tensor], src: np.ndarray, 
         s_in.synchronize()
         _hip.chain_check()  # results are on the host now: report a chained launch that had to be redone
     finally:
+        torch.cuda.synchronize(dev)  # (an error path: no copy may still read / write memory that is about to be unlocked)
         for f in futs:
             try:
                 f.result()
             except Exception:
                 pass
         pool.shutdown(wait=True)
+        pin_src.cancel()
+        if pin_out is not None:
+            pin_out.cancel()
         pin_src.close()
         if pin_out is not None:
             pin_out.close()
@@ -330,7 +339,11 @@ class _Stage:
         b = self.buf[slot]
         if b is None or b.dtype != dtype or b.numel() < n:
             self._release(slot)
-            a = np.empty(max(n, 1), dtype=np.float32 if dtype == torch.float32 else np.float64)
+            from . import dtypes as _dt
+
+            if dtype not in _dt._TORCH_TO_NUMPY or dtype == torch.bfloat16:
+                raise TypeError(f"streaming: blocks / results of dtype {dtype} are not served (numpy has no twin)")
+            a = np.empty(max(n, 1), dtype=_dt._TORCH_TO_NUMPY[dtype])  # the result's OWN dtype: int64 / bool results stay what they are
             _prefault(a)
             b = torch.from_numpy(a)
             ok = _lock(b.data_ptr(), a.nbytes)
@@ -347,8 +360,14 @@ class _Stage:
 
 
 def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, copy: bool = True,
-                mask_value: Optional[float] = None) -> Iterator[np.ndarray]:
+                mask_value: Optional[float] = None, in_place: bool = True) -> Iterator[np.ndarray]:
     """Yield `fn(block)` for every host block of `blocks`, in order, as host arrays.
+
+    Ownership of the blocks: a C-contiguous in-memory block of 8 MB or more is page-locked WHERE IT IS and copied to the
+    GPU straight from the caller's memory (`in_place=True`, no staging copy).  The generator is not asked for its next
+    block before that copy has completed, so a reader that refills ONE buffer (`f.readinto(buf); yield buf`) is safe --
+    it only loses the overlap of its read with that copy.  `in_place=False` stages every block through the streamer's
+    own page-locked buffers (a host copy per block; the reader's memory is never locked).
 
     `mask_value`: cells of the uploaded block equal to it become NaN before `fn` sees the block (xg_mask_value, in HBM
     after the byte swap) -- the `_FillValue` / `missing_value` of a file variable, which xarray's decoding masks for the
@@ -368,13 +387,37 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
     out_ready: List[Optional[Tuple[torch.Tensor, torch.cuda.Event]]] = [None, None]
 
     locked: List[Optional[Tuple[int, np.ndarray]]] = [None, None]  # source blocks page-locked in place, per slot
-    direct = [True]
+    regs: dict = {}  # page-locked range -> [bytes, slots using it]: a reader that reuses one buffer locks it once
+    direct = [bool(in_place)]
     ends: List[Optional[torch.Tensor]] = [None, None]  # page-locked scrap for the sub-page ends of a block locked in place
+    in_flight: List[Optional[torch.cuda.Event]] = [None]  # H2D reading the CALLER's memory (a block locked in place)
 
     def release(slot: int) -> None:
         if locked[slot] is not None:
-            _unlock(locked[slot][0])
+            alo = locked[slot][0]
+            regs[alo][1] -= 1
+            if regs[alo][1] == 0:
+                _unlock(alo)
+                del regs[alo]
             locked[slot] = None
+
+    def lock_range(alo: int, nbytes: int) -> bool:
+        """page-lock [alo, alo + nbytes) once, however many slots copy from it"""
+        hit = regs.get(alo)
+        if hit is not None and hit[0] >= nbytes:
+            hit[1] += 1
+            return True
+        if hit is None and _lock(alo, nbytes):
+            regs[alo] = [nbytes, 1]
+            return True
+        return False
+
+    def before_next_block() -> None:
+        """called before the generator is asked for another block: a copy that still reads the caller's memory finishes
+        first (the reader may be about to overwrite that buffer)"""
+        if in_flight[0] is not None:
+            in_flight[0].synchronize()
+            in_flight[0] = None
 
     def upload(k: int, block) -> Tuple[torch.Tensor, torch.cuda.Event]:
         a, swap = _native_view(np.asarray(block))
@@ -392,7 +435,7 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
             t = _as_tensor(a)
             page, lo = mmap.PAGESIZE, t.data_ptr()
             alo, ahi = (lo + page - 1) // page * page, (lo + a.nbytes) // page * page
-            if lo % a.itemsize == 0 and _lock(alo, ahi - alo):
+            if lo % a.itemsize == 0 and lock_range(alo, ahi - alo):
                 locked[slot] = (alo, a)  # (the array stays referenced until its copy is done)
                 host, cut = t, ((alo - lo) // a.itemsize, (ahi - lo) // a.itemsize)
             else:
@@ -423,6 +466,8 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
             ev = torch.cuda.Event()
             ev.record(s_in)
         in_free[slot] = ev
+        if cut is not None:
+            in_flight[0] = ev
         return x, ev
 
     def finish(slot: int) -> np.ndarray:
@@ -436,7 +481,7 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
         return res
 
     try:
-        yield from _pump(fn, blocks, upload, finish, out_ready, st_out, s_cmp, s_out)
+        yield from _pump(fn, blocks, upload, finish, out_ready, st_out, s_cmp, s_out, before_next_block)
         s_in.synchronize()
         s_out.synchronize()
         _hip.chain_check()
@@ -448,13 +493,14 @@ def iter_stream(fn: Callable[[torch.Tensor], torch.Tensor], blocks: Iterable, co
         st_out.close()
 
 
-def _pump(fn, blocks, upload, finish, out_ready, st_out, s_cmp, s_out):
+def _pump(fn, blocks, upload, finish, out_ready, st_out, s_cmp, s_out, before_next=lambda: None):
     it = iter(blocks)
     nxt = next(it, None)
     ahead = upload(0, nxt) if nxt is not None else None
     k = 0
     while ahead is not None:
         x, ev_in = ahead
+        before_next()                              # (a copy straight from the reader's buffer completes before it refills it)
         nxt = next(it, None)                       # read + stage + enqueue the NEXT block before computing this one
         ahead = upload(k + 1, nxt) if nxt is not None else None
         s_cmp.wait_event(ev_in)
