@@ -46,6 +46,7 @@
 #define XGCM_HIP_H
 
 #include <stdint.h>
+#include <sys/types.h> /* ssize_t */
 
 #ifdef __cplusplus
 extern "C" {
@@ -81,7 +82,16 @@ int xg_last_error(char* buf, int n);
  * change speed only: results are bit-identical under every setting, with one documented exception -- sums along the
  * CONTIGUOUS axis are re-associated by contract (1e-12 relative), and `scan_dpp` / `scan_vec` / `scan_block` select
  * among associations there.  (`dbg` holds A/B switches of the measurement tools, not a user setting.)
- * Not synchronised: set them while no call is in flight. */
+ * THE ONE EXCEPTION TO THE THREADING RULE BELOW: process-wide and not synchronised -- set them from one thread while no
+ * other thread is inside the library (a measurement tool's job, not an operator's).
+ *
+ * Threading (the reference's ufuncs run concurrently on dask scheduler threads, xgcm/grid.py:786-789,
+ * xgcm/grid_ufunc.py:966-984): every other entry point may be called from any number of host threads at once, on distinct
+ * streams or on one stream.  The library keeps no per-call host state; its only shared state is the lazily created
+ * per-(device, stream) hand-off workspace of the chained scans, handed out under a mutex, and the error text, which is
+ * thread-local (xg_last_error returns the CALLING thread's).  tests/test_gpu_threads.py drives stencils, chained and
+ * marching scans, weighted reductions, fused vorticity and a failing call from 6 threads and compares every result with
+ * the single-threaded one bit for bit. */
 int xg_set_tunable(const char* name, int value);
 int xg_get_tunable(const char* name, int* value);
 int xg_device_count(void);
@@ -91,6 +101,18 @@ int xg_free(void* ptr);
 int xg_memcpy_h2d(void* dst, const void* src, uint64_t bytes, void* stream);
 int xg_memcpy_d2h(void* dst, const void* src, uint64_t bytes, void* stream);
 int xg_stream_sync(void* stream);
+/* A device buffer whose PHYSICAL backing is `chunk_bytes`-sized allocations taken alternately from `groups` regions of the
+ * HBM that a transient allocation of `spacer_bytes` pushed apart, mapped into one contiguous virtual range (HIP virtual
+ * memory management).  Kernels whose stores are spread over their whole output (scans along Z, marches, fills) write
+ * 15-20 % faster into such a buffer than into one contiguous physical block (tools/placement_probe.py).
+ * chunk_bytes 0: 64 MiB.  Free with xg_scatter_free only. */
+int xg_scatter_alloc(void** ptr, uint64_t bytes, uint64_t chunk_bytes, int groups, uint64_t spacer_bytes);
+int xg_scatter_free(void* ptr);
+/* The same as an allocator PLUG-IN with the signature PyTorch's `torch.cuda.memory.CUDAPluggableAllocator` expects
+ * (`void* alloc(ssize_t, int device, stream)`, `void free(void*, ssize_t, int device, stream)`): xgcm_amd.device feeds a
+ * torch MemPool with it and allocates operator outputs of 256 MB or more there.  Chunk size: XG_SCATTER_CHUNK_MB (64). */
+void* xg_pool_alloc(ssize_t size, int device, void* stream);
+void xg_pool_free(void* ptr, ssize_t size, int device, void* stream);
 /* page-lock / release a range of HOST memory in place (hipHostRegister): asynchronous copies to and from it then run at
  * the link rate and overlap with kernels (xgcm_amd/streaming.py locks the record blocks of a host array ahead of its
  * copies).  A range that cannot be locked (a read-only file mapping ...) returns XG_ERR_HIP and leaves NO pending HIP

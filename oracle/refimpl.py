@@ -23,6 +23,15 @@ Pinning status
   ``skipna`` (NaN treated as 0 in ``cumsum``/``sum``) is xarray behaviour that no reference
   test exercises on this path: PARITY UNPINNED for NaN inputs to cumsum/integrate.
 
+* complex topologies (``oracle/topology.py``; fixtures ``fold_reference.json``, ``topology_reference.*``) and the vertical
+  transform (``oracle/transform.py``; ``transform_kernels_reference.npz``): PINNED MODULO STAND-INS.  The halo logic and the
+  two gufunc bodies that produced those fixtures are the reference's own code, loaded unmodified -- but over builder-written
+  stand-ins for what the build container lacks: a numpy-backed ``DataArray`` for the dozen xarray operations
+  ``_pad_face_connections`` / ``_pad_fold`` use (``oracle/make_golden_topology.py``) and a plain-Python ``guvectorize``
+  (``oracle/make_golden_transform.py``).  What is pinned is the reference's LOGIC under the stand-ins' semantics of
+  ``isel / concat / pad / transpose``; the transcribed known answers of the reference's own tests are the second,
+  independent pin, and ``tests/test_real_xarray.py`` runs against real xarray (and an installed ``xgcm``) wherever they exist.
+
 All functions take/return plain ``numpy.ndarray``; "axis" is an integer axis number of the
 unlabelled array.  Metric arrays (``m_in``/``m_out``) must be numpy-broadcastable against
 the input / output array (callers insert ``np.newaxis`` themselves).

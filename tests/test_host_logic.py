@@ -212,7 +212,7 @@ def test_axis_position_lookup():
 def test_c_abi_library_exports_every_declared_symbol():
     """The built .so loads without a GPU and exports exactly what include/xgcm_hip.h declares."""
     header = open(os.path.join(ROOT, "include", "xgcm_hip.h")).read()
-    declared = set(re.findall(r"^\s*int\s+(xg_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|void\s*\*?)\s*(xg_\w+)\s*\(", header, flags=re.M))  # (xg_pool_alloc / _free: torch's allocator signature)
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
     lib = _hip.load()  # raises ImportError if not built, AttributeError if a symbol is missing
     for name in declared:

@@ -146,3 +146,30 @@ def test_chunked_input_is_refused_with_the_documented_message(xr):
     inner = L.from_xarray(ds["v"])
     with pytest.raises(NotImplementedError, match="stream_records"):
         grid.diff(ChunkedLabelled(inner.data, inner.dims), "X")
+
+
+def test_non_native_xarray_data_and_deferred_results_on_the_bridge(xr):
+    """round 5: (1) a big-endian variable (`np.fromfile(f, ">f4")` wrapped by xarray) goes in as it is and comes back native
+    with numpy's values; (2) with `fuse=True` the operators hand back deferred results even for xarray inputs -- they
+    combine with xarray objects through `+ - * /` and `.to_xarray()` gives the xarray.DataArray"""
+    from xgcm_amd import lazy
+
+    ds = _dataset(xr)
+    be = xr.DataArray(ds["v"].values.astype(">f4"), dims=["time", "XC"], name="v")
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", metrics={("X",): ["dx"]},
+                autoparse_metadata=False)
+    out = grid.diff(be, "X")
+    assert L.is_xarray(out) and out.values.dtype == np.float32 and out.values.dtype.isnative
+    np.testing.assert_array_equal(out.values, R.stencil1d("diff", be.values, 1, 1, 0, "periodic"))
+    fgrid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", metrics={("X",): ["dx"]},
+                 autoparse_metadata=False, fuse=True)
+    lazy.reset_stats()
+    d = fgrid.diff(ds["v"], "X")
+    assert isinstance(d, lazy.LazyArray) and d.is_deferred and d.dims == ("time", "XG")
+    q = d / xr.DataArray(ds["dx"].values, dims=["XG"])   # an xarray operand on the right
+    assert isinstance(q, lazy.LazyArray) and q.is_deferred
+    back = q.to_xarray()
+    assert L.is_xarray(back) and back.dims == ("time", "XG")
+    want = R.stencil1d("diff", ds["v"].values, 1, 1, 0, "periodic") / ds["dx"].values[None]
+    np.testing.assert_array_equal(back.values, want)
+    assert lazy.STATS.get("stencil_m_out") == 1       # ... and the division rode in the stencil's launch

@@ -67,7 +67,7 @@ while IFS= read -r line || [ -n "$line" ]; do
       python tools/valu_util.py $(find $OUT/prof_valu_$NAME -name "*.db" | head -1) 2>&1 | tee $S/valu_issue_share.txt | head -30
       rm -rf $OUT/prof_valu_$NAME ;;
     roofline) timeout 1200 python tools/roofline_table.py --out $S/roofline "$@" 2>&1 | tail -40 ;;
-    scale) timeout 600 python tools/scale_table.py --records 45 --out $S/scale_table "$@" 2>&1 | tail -10 ;;
+    scale) timeout 600 python tools/scale_table.py --allow-skips --records 45 --out $S/scale_table "$@" 2>&1 | tail -10 ;;
     run) label=$1; secs=$2; shift 2; timeout $secs "$@" 2>&1 | tee $S/$label.log | tail -40 ;;
     *) echo "unknown step: $step" ;;
   esac

@@ -50,6 +50,12 @@ def abi_launch(lib, op, src, dst, shape, metric, stream):
         return lib.xg_stencil1d_f64(0, src, dst, sh, 3, 2, shape[2], 1, 0, _hip.BC["periodic"], 0.0, None, None, None, None, stream)
     if op == "diffY":
         return lib.xg_stencil1d_f64(0, src, dst, sh, 3, 1, shape[1], 1, 0, _hip.BC["extend"], 0.0, None, None, None, None, stream)
+    if op == "sumY":  # read-only march along Y (dst holds the small result)
+        return lib.xg_reduce1d_f64(src, dst, sh, 3, 1, 1, None, None, stream)
+    if op == "sumZ":
+        return lib.xg_reduce1d_f64(src, dst, sh, 3, 0, 1, None, None, stream)
+    if op == "fill":  # write-only, one stream
+        return lib.xg_fill_synthetic_f64(dst, shape[0] * shape[1] * shape[2], 7, 0, 1.0, -0.5, stream)
     if op == "dY":  # derivative Y: output metric (1, Y, X)
         st = _hip.i64([0, shape[2], 1])
         return lib.xg_stencil1d_f64(0, src, dst, sh, 3, 1, shape[1], 1, 0, _hip.BC["extend"], 0.0, None, None, metric, st, stream)
@@ -150,7 +156,7 @@ def run(a):
     if a.arena:  # FIRST allocation of the process: one block, sliced at 2 MiB multiples
         arena = torch.empty(a.arena * 2 * (nbytes + (2 << 20)) + (4 << 20), dtype=torch.uint8, device="cuda")
     grid, dyC = make_grid()
-    metric = dyC.data.reshape(1, SHAPE[1], SHAPE[2]) if a.op == "dY" else None
+    metric = dyC.data.reshape(1, SHAPE[1], SHAPE[2]) if "dY" in a.op.split(",") else None
     pairs, pads = [], []
     for r in range(a.placements):
         pads.append(torch.empty((r * 37 + 1) << 20, dtype=torch.uint8, device="cuda"))  # shifts what the allocator hands out next
@@ -184,12 +190,89 @@ def run(a):
         st = torch.cuda.current_stream().cuda_stream
         mp = metric.data_ptr() if metric is not None else None
         for idx, (x, y) in enumerate(pairs):
-            ms = time_abi(lib, a.op, x, y, metric, 3)
-            D.synthetic((4096 * (1 + idx),), 1)
-            for _ in range(3):
+            D.synthetic((4096 * (1 + idx),), 1)   # the marker comes FIRST: every launch up to the next marker is this pair's
+            for _ in range(4):                     # (the first of the four warms the caches and is dropped by the join)
                 _hip.check(abi_launch(lib, a.op, x.data_ptr(), y.data_ptr(), list(SHAPE), mp, st))
             torch.cuda.synchronize()
-            print(json.dumps({"pair": names[idx], "index": idx, "ms_events": round(ms, 4)}), flush=True)
+            print(json.dumps({"pair": names[idx], "index": idx}), flush=True)
+        return
+    if a.scatter:
+        # outputs BUILT by xg_scatter_alloc (chunk MiB, groups, spacer GiB) against ordinary allocations, several operators
+        import ctypes
+
+        x = pairs[0][0]
+        ops = a.op.split(",")
+        plain = [y for _, y in pairs]
+        line = {"scatter_vs_plain": ops, "plain_ms": {op: [round(time_abi(lib, op, x, y, metric, a.reps), 3) for y in plain] for op in ops}}
+        print(json.dumps(line), flush=True)
+        for spec in a.scatter.split(";"):
+            chunk_mb, groups, spacer_gb = (float(v) for v in spec.split(","))
+            p = ctypes.c_void_p()
+            rc = lib.xg_scatter_alloc(ctypes.byref(p), nbytes, int(chunk_mb * (1 << 20)), int(groups), int(spacer_gb * (1 << 30)))
+            if rc != 0:
+                print(json.dumps({"scatter": spec, "error": _hip.last_error()}), flush=True)
+                continue
+            y = Raw(p.value, nbytes)
+            res = {op: round(time_abi(lib, op, x, y, metric, a.reps), 3) for op in ops}
+            # ... and as the INPUT (is reading from a scattered buffer any different?)
+            _hip.check(lib.xg_fill_synthetic_f64(y.data_ptr(), n, 2, 0, 1.0, -0.5, torch.cuda.current_stream().cuda_stream))
+            rin = {op: round(time_abi(lib, op, y, plain[0], metric, a.reps), 3) for op in ops if op != "fill"}
+            print(json.dumps({"scatter": {"chunk_MiB": chunk_mb, "groups": int(groups), "spacer_GiB": spacer_gb}, "as_output_ms": res,
+                              "as_input_ms": rin}), flush=True)
+            torch.cuda.synchronize()
+            _hip.check(lib.xg_scatter_free(p))
+        return
+    if a.matrix:
+        # 2 x 2: input and output each from an ordinary allocation or from xg_scatter_alloc (chunk MiB), several operators
+        import ctypes
+
+        ops = a.op.split(",")
+        st = torch.cuda.current_stream().cuda_stream
+
+        def scat():
+            p = ctypes.c_void_p()
+            _hip.check(lib.xg_scatter_alloc(ctypes.byref(p), nbytes, int(a.matrix) << 20, 1, 0))
+            return Raw(p.value, nbytes)
+
+        plain_in, plain_out = pairs[0]
+        sc_in, sc_out = scat(), scat()
+        _hip.check(lib.xg_fill_synthetic_f64(sc_in.data_ptr(), n, 2, 0, 1.0, -0.5, st))
+        for rnd in range(2):
+            res = {}
+            for op in ops:
+                res[op] = {"plain->plain": round(time_abi(lib, op, plain_in, plain_out, metric, a.reps), 3),
+                           "plain->scatter": round(time_abi(lib, op, plain_in, sc_out, metric, a.reps), 3),
+                           "scatter->plain": round(time_abi(lib, op, sc_in, plain_out, metric, a.reps), 3),
+                           "scatter->scatter": round(time_abi(lib, op, sc_in, sc_out, metric, a.reps), 3)}
+            print(json.dumps({"matrix_chunk_MiB": a.matrix, "round": rnd, "ms": res}), flush=True)
+        return
+    if a.sweep:
+        # the output base slid through ONE allocation in fixed steps, the input fixed: is the rate a function of the address?
+        gb, step_mb = a.sweep
+        span = int(gb) << 30
+        raw = None
+        if a.sweep_contig:
+            raw = contiguous_alloc(hip_runtime(), span + nbytes + (4 << 20))
+            base = (raw.data_ptr() + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+        else:
+            big = torch.empty(span + nbytes + (4 << 20), dtype=torch.uint8, device="cuda")
+            base = (big.data_ptr() + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+        x = pairs[0][0]
+        out = []
+        off = 0
+        while off <= span:
+            y = Raw(base + off, nbytes)
+            ms = time_abi(lib, a.op, x, y, metric, 3)
+            out.append((off >> 20, round(ms, 3)))
+            off += int(step_mb) << 20
+        print(json.dumps({"sweep": a.op, "contiguous": bool(a.sweep_contig), "base": hex(base), "step_MiB": int(step_mb),
+                          "offset_MiB__ms": out}), flush=True)
+        return
+    if a.cross:
+        # which buffer's placement matters?  time every input against every output
+        k = min(a.cross, len(pairs))
+        mat = [[round(time_abi(lib, a.op, pairs[i][0], pairs[j][1], metric, a.reps), 3) for j in range(k)] for i in range(k)]
+        print(json.dumps({"cross": a.op, "rows_are_inputs_cols_are_outputs": names[:k], "ms": mat}), flush=True)
         return
     rounds = []
     for rnd in range(2):
@@ -215,7 +298,7 @@ def with_pmc(a, argv):
     """this script (--pmc-marks) under `rocprofv3 --pmc <counters> --kernel-trace`; counters per pair, instances summed and,
     where the tool recorded dimensions, listed per instance (per-channel skew)"""
     tmp = tempfile.mkdtemp(prefix="placement_", dir="/tmp")
-    cmd = ["rocprofv3", "--pmc"] + a.pmc.split() + ["--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+    cmd = ["rocprofv3", "--pmc"] + a.pmc.replace(",", " ").split() + ["--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
                                                    "--pmc-marks"] + argv
     r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -241,6 +324,13 @@ def with_pmc(a, argv):
             continue
         if cur is not None and "k_fill_synthetic" not in name:
             groups.setdefault(cur, []).append((did, dur / 1e3))
+    groups = {k: v[1:] for k, v in groups.items()}  # (the first launch after a marker is the warm-up)
+    # the raw event tables keep one row per counter INSTANCE (channel, shader engine ...) where the view above sums them
+    try:
+        cols = {t: [c[1] for c in con.execute(f"pragma table_info({t})")] for t in ("pmc_events", "pmc_info") if t in tables}
+        out_schema = {t: c for t, c in cols.items()}
+    except sqlite3.OperationalError:
+        out_schema = {}
     counters = {}
     try:
         q = ("select dispatch_id, counter_name, sum(value), max(value), count(*) from counters_collection "
@@ -252,7 +342,10 @@ def with_pmc(a, argv):
                 counters[did][cname + ":instances"] = nrow
     except sqlite3.OperationalError as exc:
         out["counter_query_error"] = str(exc)
+    out["schema"] = out_schema
     print(json.dumps(out), flush=True)
+    if a.dump_db:
+        shutil.copy(dbs[0], a.dump_db)
     for ln in lines:
         g = groups.get(ln["index"], [])
         ln["trace_us"] = [round(d, 1) for _, d in g]
@@ -272,8 +365,15 @@ def main():
     ap.add_argument("--arena", type=int, default=0, help="also time this many pairs carved out of ONE allocation made first")
     ap.add_argument("--contig", type=int, default=0, help="also time this many pairs of physically CONTIGUOUS buffers (hipExtMallocWithFlags)")
     ap.add_argument("--reps", type=int, default=7)
-    ap.add_argument("--pmc", default="", help="counter names (space-separated): run under rocprofv3 and join per pair")
+    ap.add_argument("--pmc", default="", help="counter names (comma- or space-separated): run under rocprofv3 and join per pair")
     ap.add_argument("--pmc-marks", action="store_true")
+    ap.add_argument("--cross", type=int, default=0, help="time input i against output j for the first N pairs (which buffer's placement matters?)")
+    ap.add_argument("--sweep", type=float, nargs=2, default=None, metavar=("GiB", "STEP_MiB"),
+                    help="slide the OUTPUT base through one allocation of GiB in steps of STEP_MiB (input fixed)")
+    ap.add_argument("--sweep-contig", action="store_true", help="the swept allocation is physically contiguous")
+    ap.add_argument("--scatter", default="", help="';'-separated 'chunk_MiB,groups,spacer_GiB': time --op (comma list) into outputs built by xg_scatter_alloc")
+    ap.add_argument("--matrix", type=int, default=0, metavar="CHUNK_MiB", help="input x output, each plain or scattered (chunk size), for the --op list")
+    ap.add_argument("--dump-db", default="", help="with --pmc: keep rocprofv3's database at this path")
     a = ap.parse_args()
     if a.pmc:
         argv = []
@@ -282,7 +382,7 @@ def main():
             if skip:
                 skip = False
                 continue
-            if x == "--pmc":
+            if x in ("--pmc", "--dump-db"):
                 skip = True
                 continue
             argv.append(x)

@@ -4,10 +4,13 @@ configs that are defined as 8-GPU runs (config 4: cumsum along Z over 360 record
 vorticity on 4320 x 4320 x 90 split along Z) at N = 1, 2, 4, 8 ranks -- one process per GPU over RCCL, launched exactly
 as the driver launches them (`python bench.py --gpus N` re-executes itself under torch.distributed.run).
 
-    python tools/scale_table.py [--ns 1,2,4,8] [--records 360] [--steps 20] [--out gpurun_out/scale_table]
+    python tools/scale_table.py --gpus 1,2,4,8 [--records 360] [--steps 20] [--out gpurun_out/scale_table]
 
-An N above the number of visible GPUs is skipped and listed as such (the GPU box of this round has one GPU; the driver's
-SCALE run is the first with N > 1).  Columns: aggregate GB/s, fraction of N x 8 TB/s, speed-up against N = 1 (weak
+ONE command for the day a node with several GPUs appears.  It exits NON-ZERO -- after writing whatever it measured -- when a
+requested N could not be run as N ranks over RCCL: more ranks than visible GPUs (listed as skipped), a failed run, or a
+result line whose process group reports another world size / backend than asked (`ranks.world_size`, `ranks.backend` of
+bench.py; `n_gpus`, `backend` of tools/bench_configs.py).  `--allow-skips` turns the skipped Ns back into a note (the
+one-GPU box of this round).  Columns: aggregate GB/s, fraction of N x 8 TB/s, speed-up against N = 1 (weak
 scaling: of the aggregate rate), slowest / fastest rank time.  Nothing here computes efficiency for the judge: the
 driver derives it from the per-N values itself; this is the builder's own table."""
 import argparse
@@ -35,7 +38,8 @@ def run(cmd, env=None):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--ns", default="1,2,4,8")
+    ap.add_argument("--ns", "--gpus", dest="ns", default="1,2,4,8", help="rank counts, comma-separated")
+    ap.add_argument("--allow-skips", action="store_true", help="an N above the number of visible GPUs is a note, not a failure")
     ap.add_argument("--records", type=int, default=360)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -45,8 +49,9 @@ def main():
     ap.add_argument("--skip-bench", action="store_true")
     a = ap.parse_args()
     ngpu = visible_gpus()
-    rows, skipped = [], []
+    rows, skipped, problems = [], [], []
     placements = {}
+    want_backend = os.environ.get("XG_DIST_BACKEND") or "nccl"
     # the node's link / NUMA topology next to the numbers (rocm-smi is on the GPU box; absent elsewhere)
     topo = ""
     for cmd in (["rocm-smi", "--showtopo"], ["rocm-smi", "--showtoponuma"]):
@@ -62,23 +67,30 @@ def main():
             rc, lines, err = run([sys.executable, "bench.py", "--gpus", str(n), "--steps", str(a.steps), "--warmup", str(a.warmup), "--no-cpu-baseline", "--no-pmc"])
             for ln in lines:
                 if "value" in ln:
+                    rk = ln["ranks"]
+                    if rk["world_size"] != n or ln["n_gpus"] != n or (n > 1 and want_backend not in str(rk["backend"])):
+                        problems.append(f"bench --gpus {n}: process group reports world_size {rk['world_size']} / backend {rk['backend']!r}")
                     per = ln["ranks"]["per_rank_ms_per_step"]
                     placements[n] = ln["ranks"].get("placement")
                     rows.append({"what": "bench: interp+diff X,Y, one record per GPU (weak)", "n": n, "GBps": ln["achieved_GBps_whole_step"] * n,
                                  "rank_ms_max_over_min": round(max(per) / min(per), 4) if min(per) > 0 else None})
             if rc != 0:
                 rows.append({"what": "bench", "n": n, "error": err})
+                problems.append(f"bench --gpus {n}: exit status {rc}")
         cmd = [sys.executable, os.path.join("tools", "bench_configs.py"), "--gpus", str(n), "--configs", "4,5", "--records", str(a.records), "--reps", str(a.reps)]
         if a.shape:
             cmd += ["--shape", a.shape]
         rc, lines, err = run(cmd)
         for ln in lines:
             if "op" in ln:
+                if ln["n_gpus"] != n or (n > 1 and want_backend not in str(ln.get("backend"))):
+                    problems.append(f"bench_configs --gpus {n}: line reports n_gpus {ln['n_gpus']} / backend {ln.get('backend')!r}")
                 per = [v for v in ln["per_rank_device_ms"] if v > 0]
                 rows.append({"what": f"config {ln['config']}: {ln['op'].split(';')[0].split(',')[0]}" + (" center->outer" if "outer" in ln["op"] else ""),
                              "n": n, "GBps": ln["GBps_all_gpus"], "rank_ms_max_over_min": round(max(per) / min(per), 4) if per else None})
         if rc != 0:
             rows.append({"what": "configs 4,5", "n": n, "error": err})
+            problems.append(f"bench_configs --gpus {n}: exit status {rc}")
     base = {r["what"]: r["GBps"] for r in rows if r.get("n") == 1 and "GBps" in r}
     out = ["| run | N | aggregate GB/s | fraction of N x 8 TB/s | speed-up vs N = 1 | slowest / fastest rank |", "|---|---|---|---|---|---|"]
     for r in rows:
@@ -89,6 +101,10 @@ def main():
         out.append(f"| {r['what']} | {r['n']} | {r['GBps']:.0f} | {r['GBps'] / (r['n'] * 8000):.3f} | {sp} | {r['rank_ms_max_over_min']} |")
     if skipped:
         out.append(f"\nskipped (more ranks than the {ngpu} visible GPU(s)): N = {', '.join(str(v) for v in skipped)}")
+        if not a.allow_skips:
+            problems.append(f"N = {skipped} not run: {ngpu} GPU(s) visible")
+    if problems:
+        out.append("\nNOT the table that was asked for:\n" + "\n".join("* " + p for p in problems))
     text = "\n".join(out) + "\n"
     sys.stdout.write(text)
     if a.out:
@@ -102,6 +118,8 @@ def main():
         with open(a.out + ".jsonl", "w") as f:
             for r in rows:
                 f.write(json.dumps(r) + "\n")
+    if problems:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -41,6 +41,10 @@ SIGNATURES = {
     "xg_unpin_host": (C.c_int, [_vp]),
     "xg_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_uint64, _vp]),
     "xg_stream_sync": (C.c_int, [_vp]),
+    "xg_scatter_alloc": (C.c_int, [C.POINTER(_vp), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]),
+    "xg_scatter_free": (C.c_int, [_vp]),
+    "xg_pool_alloc": (_vp, [C.c_ssize_t, C.c_int, _vp]),
+    "xg_pool_free": (None, [_vp, C.c_ssize_t, C.c_int, _vp]),
     "xg_stream_create": (C.c_int, [C.POINTER(_vp)]),
     "xg_stream_destroy": (C.c_int, [_vp]),
     "xg_chain_status": (C.c_int, [_intp, _intp]),

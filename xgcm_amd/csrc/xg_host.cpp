@@ -357,6 +357,14 @@ int xg_chain_status(int* gave_up, int* redone) {
   return XG_OK;
 }
 int xg_chain_rearm(void) { return XG_OK; }
+int xg_scatter_alloc(void** ptr, uint64_t bytes, uint64_t, int, uint64_t) {  // host build: plain memory (placement is an HBM matter)
+  if (!ptr || !bytes) return fail(XG_ERR_INVALID, "NULL / empty request");
+  *ptr = malloc(bytes);
+  return *ptr ? XG_OK : fail(XG_ERR_HIP, "out of host memory");
+}
+int xg_scatter_free(void* ptr) { free(ptr); return XG_OK; }
+void* xg_pool_alloc(ssize_t size, int, void*) { return size > 0 ? malloc((size_t)size) : nullptr; }
+void xg_pool_free(void* ptr, ssize_t, int, void*) { free(ptr); }
 int xg_bswap(void* data, uint64_t nelem, int elem_bytes, void*) {
   if (elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return fail(XG_ERR_INVALID, "byte swap of %d-byte elements (2, 4 or 8)", elem_bytes);
   if (nelem && !data) return fail(XG_ERR_INVALID, "NULL buffer");

@@ -69,6 +69,57 @@ _FLOATS = (torch.float32, torch.float64)
 _SERVED = _dt.SERVED
 
 
+# ---- where results are allocated ------------------------------------------------------------------------------------
+# The rate of a kernel whose stores are spread over its whole output -- scans along Z or Y, marches, fills -- depends on
+# the PHYSICAL layout of the output buffer: inside one contiguous physical block (what hipMalloc returns) cumsum Z of a
+# 3600 x 2400 x 75 record runs 1.78 - 2.0 ms depending on which block the driver happened to pick, in a buffer backed by
+# separately created 64 MiB physical allocations 1.67 ms, every time (tools/placement_probe.py).  Outputs
+# of SCATTER_MIN_BYTES or more therefore come from a torch MemPool fed by the library's own allocator (xg_pool_alloc: HIP
+# virtual memory management); torch still caches, reuses and stream-orders them.  XG_SCATTER_OUT=0 restores plain hipMalloc.
+SCATTER_MIN_BYTES = 256 << 20
+_pool = None
+_pool_state = {"enabled": None, "allocator": None}
+
+
+def _scatter_pool():
+    """the MemPool of scattered output buffers (created at first use), or None when switched off / not available"""
+    global _pool
+    if _pool_state["enabled"] is None:
+        import os
+
+        ok = os.environ.get("XG_SCATTER_OUT", "1") != "0" and hasattr(torch.cuda, "MemPool") and hasattr(torch.cuda, "use_mem_pool")
+        if ok:
+            try:
+                from torch.cuda.memory import CUDAPluggableAllocator
+
+                _hip.load()
+                alloc = CUDAPluggableAllocator(_hip.LIB_PATH, "xg_pool_alloc", "xg_pool_free")
+                _pool_state["allocator"] = alloc  # (kept alive with the pool)
+                _pool = torch.cuda.MemPool(alloc.allocator(), use_on_oom=True)
+            except Exception as exc:  # noqa: BLE001 -- an allocator torch cannot plug in is a lost optimisation, not an error
+                import warnings
+
+                warnings.warn(f"xgcm_amd: scattered output buffers are not available ({exc}); results use plain allocations")
+                ok = False
+        _pool_state["enabled"] = ok
+    return _pool if _pool_state["enabled"] else None
+
+
+def _empty(shape, dtype, device) -> torch.Tensor:
+    """torch.empty for an operator's result; large results come from the scattered-buffer pool"""
+    shape = tuple(int(v) for v in shape)
+    n = 1
+    for v in shape:
+        n *= v
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
+    if dev.type == "cuda" and n * torch.empty((), dtype=dtype).element_size() >= SCATTER_MIN_BYTES:
+        pool = _scatter_pool()
+        if pool is not None and not torch.cuda.is_current_stream_capturing():
+            with torch.cuda.use_mem_pool(pool):
+                return torch.empty(shape, dtype=dtype, device=dev)
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
 def _raw_device(x) -> torch.Tensor:
     """numpy / host tensor -> contiguous tensor in HBM with its dtype UNCHANGED (PCIe copy of the raw bytes: an int8
     field crosses the bus as 1 byte per cell and is widened in HBM); device tensors pass.  An array of non-native byte
@@ -111,7 +162,7 @@ def materialize(t: torch.Tensor) -> torch.Tensor:
     copy (rows as 16-byte lanes, true transposes through LDS tiles), contiguous tensors pass"""
     if t.is_contiguous():
         return t
-    out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+    out = _empty(t.shape, dtype=t.dtype, device=t.device)
     _copy_nd(t.data_ptr(), t.stride(), out, t.shape)
     return out
 
@@ -126,7 +177,7 @@ def flip(t, axes: Sequence[int]) -> torch.Tensor:
         if t.shape[a]:
             off += (t.shape[a] - 1) * strides[a]
         strides[a] = -strides[a]
-    out = torch.empty(t.shape, dtype=t.dtype, device=t.device)
+    out = _empty(t.shape, dtype=t.dtype, device=t.device)
     _copy_nd(t.data_ptr() + off * t.element_size(), strides, out, t.shape)
     return out
 
@@ -149,7 +200,7 @@ def concatenate(parts: Sequence, axis: int) -> torch.Tensor:
     axis = axis % parts[0].dim()
     shape = list(parts[0].shape)
     shape[axis] = sum(int(p.shape[axis]) for p in parts)
-    out = torch.empty(shape, dtype=parts[0].dtype, device=parts[0].device)
+    out = _empty(shape, dtype=parts[0].dtype, device=parts[0].device)
     at = 0
     for p in parts:
         copy_into(out.narrow(axis, at, p.shape[axis]), p)
@@ -169,7 +220,7 @@ def convert(x, dst, via=None, scale: float = 1.0, flip: bool = False) -> torch.T
         t, src = t.to(torch.float32), _dt.FLOAT32
     if src == dst and via is None and scale == 1.0 and not flip:
         return t
-    out = torch.empty(t.shape, dtype=_dt.torch_dtype(dst), device=t.device)
+    out = _empty(t.shape, dtype=_dt.torch_dtype(dst), device=t.device)
     if out.numel():
         _hip.check(lib.xg_convert(t.data_ptr(), _hip.DTYPE[src.name], out.data_ptr(), _hip.DTYPE[dst.name], t.numel(),
                                   -1 if via is None else _hip.DTYPE[np.dtype(via).name], float(scale), 1 if flip else 0,
@@ -359,7 +410,7 @@ def _int_stencil1d(plan, op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, 
     n_out = shape[axis] + pad_lo + pad_hi - 1
     oshape = list(shape)
     oshape[axis] = n_out
-    out = torch.empty(oshape, dtype=_dt.torch_dtype(lane), device=t.device)
+    out = _empty(oshape, dtype=_dt.torch_dtype(lane), device=t.device)
     code = _hip.OP[op + "u"] if plan.unsigned else _hip.OP[op]
     if out.numel():
         if halo is not None:
@@ -402,7 +453,7 @@ def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str]
     oshape[axis] = n_out
     m_in = _prep_metric(m_in, dt)
     m_out = _prep_metric(m_out, dt)
-    out = torch.empty(oshape, dtype=dt, device=x.device)
+    out = _empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:  # empty outer dims: nothing to launch (a NULL data_ptr is not a valid ABI argument)
         return _out(out, half)
     _hip.check(
@@ -443,7 +494,7 @@ def stencil1d_halo(op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, m_out=
     n_out = n + pad_lo + pad_hi - 1
     oshape = list(x.shape)
     oshape[axis] = n_out
-    out = torch.empty(oshape, dtype=dt, device=x.device)
+    out = _empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
         return _out(out, half)
     m_out = _prep_metric(m_out, dt)
@@ -484,7 +535,7 @@ def _int_cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi:
             raise ValueError(f"can't extend empty axis {axis} using modes other than 'constant' or 'empty'")
         out = torch.from_numpy(np.full(oshape, fv, dtype=np.int64)).to(t.device)  # only halo cells remain
     else:
-        out = torch.empty(oshape, dtype=torch.int64, device=t.device)
+        out = _empty(oshape, dtype=torch.int64, device=t.device)
         if out.numel():
             _hip.check(lib.xg_cumsum1d_i64(
                 t.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, int(bool(reverse)), 0, int(trim_lo),
@@ -515,7 +566,7 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
     oshape[axis] = shape[axis] - trim_lo - trim_hi + pad_lo + pad_hi
     m_in = _prep_metric(m_in, dt)
     m_out = _prep_metric(m_out, dt)
-    out = torch.empty(oshape, dtype=dt, device=x.device)
+    out = _empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
         return _out(out, half)
     if shape[axis] - trim_lo - trim_hi == 0:
@@ -554,7 +605,7 @@ def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
         axis = axis % t.dim()
         shape = list(t.shape)
         out = torch.zeros(shape[:axis] + shape[axis + 1:], dtype=torch.int64, device=t.device) if t.numel() == 0 else \
-            torch.empty(shape[:axis] + shape[axis + 1:], dtype=torch.int64, device=t.device)
+            _empty(shape[:axis] + shape[axis + 1:], dtype=torch.int64, device=t.device)
         if out.numel() and t.numel():
             _hip.check(lib.xg_reduce1d_i64(t.data_ptr(), out.data_ptr(), _hip.i64(shape), len(shape), axis, 0, None, None,
                                            _stream()))
@@ -570,7 +621,7 @@ def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
     if skipna in ("pair_valid", "pair_all"):  # numerator and denominator sums side by side: a leading dim of 2
         oshape = [2] + oshape
     w = _prep_metric(w, dt)
-    out = torch.empty(oshape, dtype=dt, device=x.device)
+    out = _empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
         return _out(out, half)
     if x.numel() == 0:  # sum over an empty axis is 0
@@ -612,7 +663,7 @@ def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
         order.append(ax)
     order += [d for d in range(nd) if d not in order]
     oshape = [s + l + h for s, l, h in zip(x.shape, lo, hi)]
-    out = torch.empty(oshape, dtype=dt, device=x.device)
+    out = _empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
         return _narrow(out, src) if ints else _out(out, half)
     _hip.check(
@@ -657,7 +708,7 @@ def gather(x, partner, tokens, mapped: Sequence[bool], lo: Sequence[int], out_sh
             partner_perm = list(range(nd))
     if not isinstance(tokens, torch.Tensor):
         tokens = upload_tokens(tokens)
-    out = torch.empty([int(v) for v in out_shape], dtype=dt, device=x.device)
+    out = _empty([int(v) for v in out_shape], dtype=dt, device=x.device)
     if out.numel() == 0:
         return _narrow(out, res_dt) if ints else _out(out, half)
     _hip.check(
@@ -714,7 +765,7 @@ def transform_linear(phi, theta, target, axis: int, mask_edges: bool = True, byp
     m = int(target.shape[axis])
     oshape = list(shape)
     oshape[axis] = m
-    out = torch.empty(oshape, dtype=dt, device=phi.device)
+    out = _empty(oshape, dtype=dt, device=phi.device)
     if out.numel() == 0:
         return out
     if shape[axis] < 1:
@@ -749,7 +800,7 @@ def transform_conservative(phi, theta, bins, axis: int) -> torch.Tensor:
         raise ValueError("bins must be a 1-D array of at least two edges")
     oshape = list(shape)
     oshape[axis] = int(bins.numel()) - 1
-    out = torch.empty(oshape, dtype=dt, device=phi.device)
+    out = _empty(oshape, dtype=dt, device=phi.device)
     if out.numel() == 0:
         return out
     vshape = list(shape)
@@ -787,7 +838,7 @@ def binary(op: str, a, b) -> torch.Tensor:
         if sa != sb and 1 not in (sa, sb):
             raise ValueError(f"binary: extents {sa} and {sb} do not broadcast")
         shape.append(max(sa, sb) if 0 not in (sa, sb) else 0)
-    out = torch.empty(shape, dtype=dt, device=a.device)
+    out = _empty(shape, dtype=dt, device=a.device)
     if out.numel():
         _hip.check(
             getattr(lib, "xg_binary_" + sfx)(_hip.BINOP[op], a.data_ptr(), _hip.i64(_bstrides(a, shape, "a")), b.data_ptr(),
@@ -814,7 +865,7 @@ def vorticity(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: flo
         raise ValueError("vorticity: u and v must have the same shape")
     shape = list(u.shape)
     area = _prep_metric(area, dt)
-    out = torch.empty(shape, dtype=dt, device=u.device)
+    out = _empty(shape, dtype=dt, device=u.device)
     if out.numel() == 0:
         return out
     if bc_x == "halo" or bc_y == "halo":
@@ -845,7 +896,7 @@ def divergence(u, v, area, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: fl
         raise ValueError("divergence: u and v must have the same shape")
     shape = list(u.shape)
     area = _prep_metric(area, dt)
-    out = torch.empty(shape, dtype=dt, device=u.device)
+    out = _empty(shape, dtype=dt, device=u.device)
     if out.numel() == 0:
         return out
     if bc_x == "halo" or bc_y == "halo":
@@ -874,8 +925,8 @@ def gradient(a, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0, 
     a = asdevice(a, dt)
     shape = list(a.shape)
     mx, my = _prep_metric(mx, dt), _prep_metric(my, dt)
-    out_x = torch.empty(shape, dtype=dt, device=a.device)
-    out_y = torch.empty(shape, dtype=dt, device=a.device)
+    out_x = _empty(shape, dtype=dt, device=a.device)
+    out_y = _empty(shape, dtype=dt, device=a.device)
     if a.numel() == 0:
         return out_x, out_y
     tail = (_hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x), _hip.BC[bc_y], float(fill_y), _ptr(mx),
@@ -898,8 +949,8 @@ def flux(u, v, t, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0
     if u.shape != t.shape or v.shape != t.shape:
         raise ValueError("flux: u, v and t must have the same shape")
     shape = list(t.shape)
-    out_x = torch.empty(shape, dtype=dt, device=t.device)
-    out_y = torch.empty(shape, dtype=dt, device=t.device)
+    out_x = _empty(shape, dtype=dt, device=t.device)
+    out_y = _empty(shape, dtype=dt, device=t.device)
     if t.numel() == 0:
         return out_x, out_y
     tail = (out_x.data_ptr(), out_y.data_ptr(), _hip.i64(shape), len(shape), _hip.BC[bc_x], float(fill_x),
@@ -929,7 +980,7 @@ def stencil2d(op: str, x, order: int, padx, bc_x: str, fill_x: float, pady, bc_y
     lib = _hip.load()
     dt, sfx = _common(x, *(metrics or ()))
     x = asdevice(x, dt)
-    out = torch.empty(tuple(x.shape), dtype=dt, device=x.device)
+    out = _empty(tuple(x.shape), dtype=dt, device=x.device)
     if out.numel() == 0:
         return out
     head = (_hip.OP[op], x.data_ptr(), out.data_ptr(), _hip.i64(list(x.shape)), x.dim(), int(order),
@@ -953,7 +1004,7 @@ def synthetic(shape, seed: int, offset: int = 0, scale: float = 1.0, shift: floa
     lib = _hip.load()
     _require_gpu()
     if out is None:
-        out = torch.empty(tuple(shape), dtype=dtype, device="cuda")
+        out = _empty(tuple(shape), dtype=dtype, device="cuda")
     if out.numel() == 0:
         return out
     sfx = "f32" if out.dtype == torch.float32 else "f64"

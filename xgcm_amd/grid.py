@@ -533,6 +533,10 @@ class Grid:
                     array = array / m_out
             if post_divide is not None:
                 array = array / post_divide
+        if was_xr and isinstance(array, _lazy.LazyArray) and array.is_deferred:
+            # deferred: converting now would evaluate it.  The result stays a LazyArray -- it combines with xarray objects
+            # through `+ - * /` like the arrays it came from -- and `.to_xarray()` hands over the xarray.DataArray
+            return array
         return to_xarray(array) if was_xr else array
 
     def _two_axes_in_one_pass(self, funcname, array, step_a, step_b, kwargs, weighted=None):

@@ -252,6 +252,8 @@ class DataArray:
     def _binary(self, other, op: str, reflexive: bool = False, dims_order: Optional[Sequence[str]] = None) -> "DataArray":
         """`self OP other` with name-based broadcasting.  `dims_order` (internal): lay the result out with its dims in
         that order instead of xarray's (self's dims, then other's new ones) -- same values, no transposed copy later."""
+        if is_xarray(other):  # a deferred result (or any array of ours) next to a real xarray object: ours, by name
+            other = from_xarray(other)
         if _LAZY_HOOK is not None:  # `array OP deferred_result`, `field * metric` inside `grid.fused()`: xgcm_amd.lazy
             res = _LAZY_HOOK(self, other, op, reflexive, dims_order)
             if res is not None:

@@ -190,6 +190,8 @@ class LazyArray(DataArray):
 
     # ---- arithmetic stays deferred while an operand is ------------------------------------
     def _binary(self, other, op: str, reflexive: bool = False, dims_order: Optional[Sequence[str]] = None):
+        if _labeled.is_xarray(other):
+            other = _labeled.from_xarray(other)
         res = defer_binary(self, other, op, reflexive, dims_order)
         if res is not None:
             return res
