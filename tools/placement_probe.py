@@ -222,6 +222,33 @@ def run(a):
             torch.cuda.synchronize()
             _hip.check(lib.xg_scatter_free(p))
         return
+    if a.alloc_cost:
+        # what does a scattered buffer cost to MAKE (the pool pays it once per cached block)?
+        import ctypes
+        import time
+
+        for gb in (1, 5, 13):
+            size = gb << 30
+            for label, chunk in (("hipMalloc (torch.empty, allocator cache emptied)", 0), ("scatter 64 MiB", 64), ("scatter 256 MiB", 256)):
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                t0 = time.perf_counter()
+                if chunk == 0:
+                    buf = torch.empty(size, dtype=torch.uint8, device="cuda")
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    del buf
+                    torch.cuda.empty_cache()
+                    t2 = time.perf_counter()
+                else:
+                    p = ctypes.c_void_p()
+                    _hip.check(lib.xg_scatter_alloc(ctypes.byref(p), size, chunk << 20, 1, 0))
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    _hip.check(lib.xg_scatter_free(p))
+                    t2 = time.perf_counter()
+                print(json.dumps({"alloc_cost": label, "GiB": gb, "alloc_ms": round((t1 - t0) * 1e3, 2), "free_ms": round((t2 - t1) * 1e3, 2)}), flush=True)
+        return
     if a.matrix:
         # 2 x 2: input and output each from an ordinary allocation or from xg_scatter_alloc (chunk MiB), several operators
         import ctypes
@@ -373,6 +400,7 @@ def main():
     ap.add_argument("--sweep-contig", action="store_true", help="the swept allocation is physically contiguous")
     ap.add_argument("--scatter", default="", help="';'-separated 'chunk_MiB,groups,spacer_GiB': time --op (comma list) into outputs built by xg_scatter_alloc")
     ap.add_argument("--matrix", type=int, default=0, metavar="CHUNK_MiB", help="input x output, each plain or scattered (chunk size), for the --op list")
+    ap.add_argument("--alloc-cost", action="store_true", help="time making / releasing plain and scattered buffers of 1, 5, 13 GiB")
     ap.add_argument("--dump-db", default="", help="with --pmc: keep rocprofv3's database at this path")
     a = ap.parse_args()
     if a.pmc:

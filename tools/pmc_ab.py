@@ -48,7 +48,7 @@ def main():
         table = {}  # (vi, ci, kernel) -> {"dur": [...], counter: [...]}
         tmp = tempfile.mkdtemp(prefix="pmcab_", dir="/tmp")
         # the group "TRACE" is a plain kernel-trace pass: durations without any counter collected
-        cmd = ["rocprofv3"] + ([] if group == "TRACE" else ["--pmc"] + group.split()) + ["--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable,
+        cmd = ["rocprofv3"] + ([] if group == "TRACE" else ["--pmc"] + group.replace("@", " ").split()) + ["--kernel-trace", "-d", tmp, "-o", "p", "--", sys.executable,
                os.path.join(REPO, "tools", "ab_tunables.py"), "--cases", a.cases, "--variants", a.variants, "--rounds", str(max(1, a.placements)),
                "--reps", str(a.reps), "--mark", "--shape", a.shape, "--dtype", a.dtype] + (["--realloc"] if a.placements > 1 else [])
         env = dict(os.environ, TMPDIR="/tmp")

@@ -77,6 +77,10 @@ _SERVED = _dt.SERVED
 # of SCATTER_MIN_BYTES or more therefore come from a torch MemPool fed by the library's own allocator (xg_pool_alloc: HIP
 # virtual memory management); torch still caches, reuses and stream-orders them.  XG_SCATTER_OUT=0 restores plain hipMalloc.
 SCATTER_MIN_BYTES = 256 << 20
+# ... and up to SCATTER_MAX_BYTES: a result of tens of GB (a whole batch of records in one array) spans many of the driver's
+# physical blocks by itself -- config 4's 111 GB outputs ran at the good rate from plain allocations (0.78) -- and a second
+# allocator cache of that size next to torch's own would not fit the HBM
+SCATTER_MAX_BYTES = 16 << 30
 _pool = None
 _pool_state = {"enabled": None, "allocator": None}
 
@@ -112,11 +116,21 @@ def _empty(shape, dtype, device) -> torch.Tensor:
     for v in shape:
         n *= v
     dev = torch.device(device) if not isinstance(device, torch.device) else device
-    if dev.type == "cuda" and n * torch.empty((), dtype=dtype).element_size() >= SCATTER_MIN_BYTES:
+    if dev.type == "cuda" and SCATTER_MIN_BYTES <= n * torch.empty((), dtype=dtype).element_size() <= SCATTER_MAX_BYTES:
         pool = _scatter_pool()
         if pool is not None and not torch.cuda.is_current_stream_capturing():
-            with torch.cuda.use_mem_pool(pool):
-                return torch.empty(shape, dtype=dtype, device=dev)
+            try:
+                with torch.cuda.use_mem_pool(pool):
+                    return torch.empty(shape, dtype=dtype, device=dev)
+            except torch.OutOfMemoryError:
+                # the pool's cache and torch's own do not lend each other their idle blocks: release both, once; if the
+                # HBM is simply full the plain allocation below raises the error the caller should see
+                torch.cuda.empty_cache()
+                try:
+                    with torch.cuda.use_mem_pool(pool):
+                        return torch.empty(shape, dtype=dtype, device=dev)
+                except torch.OutOfMemoryError:
+                    pass
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
