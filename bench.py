@@ -331,15 +331,27 @@ def main():
                       "placement": placement, "numa_bind": os.environ.get("XG_NUMA_BIND", "1") != "0"},
             "device_ms_per_step": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4),
                                    "max": round(step_ms[-1], 4)},
+            # where the results live (DESIGN section 8 "Placement"): scattered = separately created 64 MiB physical
+            # allocations behind one virtual range (xg_pool_alloc); pool_fallbacks > 0 = some result fell back to hipMalloc
+            "result_buffers": dict(_result_buffer_stats(), scattered=os.environ.get("XG_SCATTER_OUT", "1") != "0"),
         }
         if world == 1 and not args.no_cpu_baseline:
             before = ranks.placement.get("affinity_before")
             if ranks.placement.get("bound") and before:  # the CPU baseline is timed on ALL the box's host cores again
-                os.sched_setaffinity(0, S.parse_cpulist(before))
+                S.set_affinity_all_threads(S.parse_cpulist(before))
             line["cpu_baseline"] = cpu_baseline()
             line["parity_spot_check"] = spot_check(spot)
         print(json.dumps(line), flush=True)
     ranks.close()
+
+
+def _result_buffer_stats():
+    try:
+        from xgcm_amd import _hip
+
+        return _hip.scatter_stats()
+    except Exception as exc:  # noqa: BLE001
+        return {"error": str(exc)[:100]}
 
 
 if __name__ == "__main__":

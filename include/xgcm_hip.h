@@ -111,6 +111,8 @@ int xg_scatter_free(void* ptr);
 /* The same as an allocator PLUG-IN with the signature PyTorch's `torch.cuda.memory.CUDAPluggableAllocator` expects
  * (`void* alloc(ssize_t, int device, stream)`, `void free(void*, ssize_t, int device, stream)`): xgcm_amd.device feeds a
  * torch MemPool with it and allocates operator outputs of 256 MB or more there.  Chunk size: XG_SCATTER_CHUNK_MB (64). */
+/* scattered buffers made so far, bytes of them alive, and requests xg_pool_alloc had to serve with plain hipMalloc */
+int xg_scatter_stats(uint64_t* buffers_made, uint64_t* live_bytes, uint64_t* pool_fallbacks);
 void* xg_pool_alloc(ssize_t size, int device, void* stream);
 void xg_pool_free(void* ptr, ssize_t size, int device, void* stream);
 /* page-lock / release a range of HOST memory in place (hipHostRegister): asynchronous copies to and from it then run at

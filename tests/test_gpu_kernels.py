@@ -171,7 +171,7 @@ def test_strided_metric_stencil_with_per_face_metrics(dev, dtype, ys):
     """Round 4 (DESIGN rule 17): a (Z, face, Y, X) field -- MITgcm's LLC / cubed-sphere layout -- whose metrics (face, Y, X)
     change from face to face and are shared by the levels only.  Two outer dims, the metric broadcast along the slower one:
     the band-major launches (K2S, K2Sm) now run over (face, row) under the levels instead of falling back to the unbanded
-    order (derivative Y on the cubed sphere: 0.57, metric_weighted Y 0.45 of 8 TB/s, profiles/r04d_f2.log).  Level counts
+    order (derivative Y on the cubed sphere: 0.57, metric_weighted Y 0.45 of 8 TB/s, profiles/history/r04d_f2.log).  Level counts
     that are not a multiple of the levels per task, one face, many faces, every pad / boundary / metric combination, a leading
     record dim on top: the oracle's bits."""
     from xgcm_amd import _hip

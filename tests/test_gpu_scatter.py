@@ -69,6 +69,10 @@ def test_large_results_come_from_the_scattered_pool_and_are_the_same_bits(monkey
     assert np.array_equal(D.tohost(got["diffY"]), R.stencil1d("diff", a, 1, 1, 0, "extend"))
     assert np.array_equal(D.tohost(got["intZ"]), R.integrate(a, 0, m))
     assert np.array_equal(D.tohost(got["mul"]), a * m)
+    from xgcm_amd import _hip
+
+    stats = _hip.scatter_stats()
+    assert stats["buffers_made"] >= 1 and stats["pool_fallbacks"] == 0 and stats["live_bytes"] > 0
     # results are ordinary tensors: freed blocks go back to the pool's cache and serve the next result of that size
     ptr = got["cumZ"].data_ptr()
     del got

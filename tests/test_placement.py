@@ -64,6 +64,40 @@ def test_bind_applies_reports_and_never_widens(tmp_path):
         os.sched_setaffinity(0, allowed)
 
 
+@pytest.mark.skipif(not hasattr(os, "sched_setaffinity") or not os.path.isdir("/proc/self/task"), reason="needs /proc and sched_setaffinity")
+def test_bind_moves_threads_that_already_exist(tmp_path):
+    """`sched_setaffinity(0, ...)` binds the calling thread only; a pool thread started BEFORE the binding must
+    end up on the GPU's CPUs too (and come back when bench.py restores the mask for its CPU-baseline leg)"""
+    import threading
+
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip("one CPU: nothing to narrow")
+    stop, seen = threading.Event(), {}
+    ready = threading.Event()
+
+    def worker():
+        seen["tid"] = threading.get_native_id()
+        ready.set()
+        stop.wait()
+
+    th = threading.Thread(target=worker)
+    th.start()
+    ready.wait()
+    try:
+        keep = allowed[:1]
+        sysfs = _fake_sysfs(tmp_path, {"0000:c1:00.0": (0, S.format_cpulist(keep))}, {})
+        rep = S.bind_to_gpu_numa(0, sysfs=sysfs, pci_bus_id="0000:c1:00.0", apply=True)
+        assert rep["bound"] and rep["threads_bound"] >= 2
+        assert sorted(os.sched_getaffinity(seen["tid"])) == keep      # the thread that existed before the binding
+        assert S.set_affinity_all_threads(allowed) >= 2
+        assert sorted(os.sched_getaffinity(seen["tid"])) == allowed
+    finally:
+        stop.set()
+        th.join()
+        S.set_affinity_all_threads(allowed)
+
+
 def test_env_switch(monkeypatch, tmp_path):
     allowed = sorted(os.sched_getaffinity(0))
     sysfs = _fake_sysfs(tmp_path, {"0000:c1:00.0": (0, S.format_cpulist(allowed[:1]))}, {})

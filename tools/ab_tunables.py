@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="f32: every synthetic operand in float32 (bytes per cell halve)")
     ap.add_argument("--realloc", action="store_true", help="every round on FRESH buffers (allocator cache emptied, the next allocations "
                     "shifted): a kernel's rate depends on where the driver placed its buffers -- cumsum Z 1.71 to 2.03 ms on one box, "
-                    "profiles/r04a_addr_probe.jsonl -- so a table that is to agree with another process's must report the median over placements")
+                    "profiles/history/r04a_addr_probe.jsonl -- so a table that is to agree with another process's must report the median over placements")
     a = ap.parse_args()
     bscale = 1.0
     if a.dtype == "f32":

@@ -43,6 +43,7 @@ SIGNATURES = {
     "xg_stream_sync": (C.c_int, [_vp]),
     "xg_scatter_alloc": (C.c_int, [C.POINTER(_vp), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]),
     "xg_scatter_free": (C.c_int, [_vp]),
+    "xg_scatter_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "xg_pool_alloc": (_vp, [C.c_ssize_t, C.c_int, _vp]),
     "xg_pool_free": (None, [_vp, C.c_ssize_t, C.c_int, _vp]),
     "xg_stream_create": (C.c_int, [C.POINTER(_vp)]),
@@ -236,6 +237,13 @@ def chain_check() -> None:
 def chain_rearm() -> None:
     check(load().xg_chain_rearm())
     _chain_reported[0] = 0
+
+
+def scatter_stats() -> dict:
+    """scattered result buffers made so far, bytes alive, and pool requests that fell back to plain hipMalloc"""
+    a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    check(load().xg_scatter_stats(C.byref(a), C.byref(b), C.byref(c)))
+    return {"buffers_made": int(a.value), "live_bytes": int(b.value), "pool_fallbacks": int(c.value)}
 
 
 def last_error() -> str:

@@ -338,7 +338,15 @@ namespace {
 struct ScatterBuf { u64 total = 0, chunk = 0; std::vector<hipMemGenericAllocationHandle_t> handles; };
 std::mutex g_scatter_mu;
 std::map<void*, ScatterBuf> g_scatter;
+u64 g_scatter_made = 0, g_scatter_live_bytes = 0, g_pool_fallbacks = 0;
 }  // namespace
+int xg_scatter_stats(uint64_t* buffers_made, uint64_t* live_bytes, uint64_t* pool_fallbacks) {
+  std::lock_guard<std::mutex> lock(g_scatter_mu);
+  if (buffers_made) *buffers_made = g_scatter_made;
+  if (live_bytes) *live_bytes = g_scatter_live_bytes;
+  if (pool_fallbacks) *pool_fallbacks = g_pool_fallbacks;
+  return XG_OK;
+}
 int xg_scatter_alloc(void** ptr, uint64_t bytes, uint64_t chunk_bytes, int groups, uint64_t spacer_bytes) {
   if (!ptr || !bytes) return fail(XG_ERR_INVALID, "NULL / empty request");
   if (groups < 1) groups = 1;
@@ -390,6 +398,8 @@ int xg_scatter_alloc(void** ptr, uint64_t bytes, uint64_t chunk_bytes, int group
   }
   {
     std::lock_guard<std::mutex> lock(g_scatter_mu);
+    ++g_scatter_made;
+    g_scatter_live_bytes += sb.total;
     g_scatter[va] = std::move(sb);
   }
   *ptr = va;
@@ -404,6 +414,7 @@ int xg_scatter_free(void* ptr) {
     if (it == g_scatter.end()) return fail(XG_ERR_INVALID, "%p was not returned by xg_scatter_alloc", ptr);
     sb = std::move(it->second);
     g_scatter.erase(it);
+    g_scatter_live_bytes -= sb.total;
   }
   XG_HIP(hipDeviceSynchronize());
   (void)hipMemUnmap(ptr, sb.total);
@@ -426,6 +437,10 @@ void* xg_pool_alloc(ssize_t size, int device, void* stream) {
   void* p = nullptr;
   if (xg_scatter_alloc(&p, (uint64_t)size, chunk, 1, 0) == XG_OK) return p;
   if (hipMalloc(&p, (size_t)size) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  {
+    std::lock_guard<std::mutex> lock(g_scatter_mu);
+    ++g_pool_fallbacks;  // (reported by xg_scatter_stats: a result that lies in one plain block after all)
+  }
   return p;
 }
 void xg_pool_free(void* ptr, ssize_t size, int device, void* stream) {

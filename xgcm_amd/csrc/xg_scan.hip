@@ -1435,7 +1435,7 @@ bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void
     // kernels 10 % / 27 % SLOWER (1.77 -> 1.94 ms, 1.13 -> 1.44 ms): the level-major sweep is worth more than the bytes,
     // which the Infinity Cache absorbs.  Off by default; kept as the evidence that the extra traffic is a choice.
     // (Round 4: the band-wide order with the output rows stored `sc1 nt` -- dropped from the L2 as written, so that they
-    // would not push the hand-off slots out -- reads 5.87 -> 6.08 GB and is no faster; profiles/r04b_ab_chain_pmc.log.)
+    // would not push the hand-off slots out -- reads 5.87 -> 6.08 GB and is no faster; profiles/history/r04b_ab_chain_pmc.log.)
     const u64 nout = ncol / ctile;  // outer indices (level groups) per x-tile
     if (nout >= 2 && nout < 0x7fffffffull) {
       ch->tmaj = (u32)nout;
@@ -1443,7 +1443,7 @@ bool chain_plan(const Geo& g, int R, int sums_per_lane, bool shared_metric, void
       // distance between the chunks of a column.  Round 4, paired over 5 placements, cumint Y: k = 1 / 2 / 3 / 4 / 6 -> time
       // +7.3 / +3.0 / +2.9 / +2.5 / +2.7 %, traffic 1.008 / 1.010 / 1.013 / 1.017 / 1.026x against 1.106x: the stall of the
       // single-tile order goes with the second tile, a 2.5 % cost of sweeping all levels at once stays.  Still off: the
-      // default is the fastest order; k = 4 is the setting for whoever shares the HBM.  profiles/r04q_ab_tmaj_*.log)
+      // default is the fastest order; k = 4 is the setting for whoever shares the HBM.  profiles/history/r04q_ab_tmaj_*.log)
       const u64 tiles = (56 + nout - 1) / nout > (u64)tune().scan_chain_tmaj ? (56 + nout - 1) / nout : (u64)tune().scan_chain_tmaj;
       ch->W = (u32)(nout * tiles);
     }
@@ -1514,7 +1514,7 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
       const u32 grid = ((nwork + 7) / 8) * 8;
       const bool nts = tune().nt_store;
       // rows of float32 are half as long in bytes: 128 threads per row measured -4.6 % on the plain scan there (0.710 -> 0.744;
-      // with a metric +-0, float64 +4 %: profiles/r04aa_ab_f32_rowshapes.log), 256 everywhere else
+      // with a metric +-0, float64 +4 %: profiles/history/r04aa_ab_f32_rowshapes.log), 256 everywhere else
       const int bs = tune().scan_block ? tune().scan_block : (sizeof(real) == 4 && !met ? 128 : 256);
 #define XG_L(M, NTS_, BS_) hipLaunchKernelGGL((k_cumsum_contig_vec<M, NTS_, BS_>), dim3(grid), dim3(BS_), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo, zb, nwork, (tune().scan_dpp ? 1 : 0) | (tune().scan_sh1 ? 2 : 0))
 #define XG_B(M, NTS_) do { if (bs == 512) XG_L(M, NTS_, 512); else if (bs == 1024) XG_L(M, NTS_, 1024); else if (bs == 128) XG_L(M, NTS_, 128); else if (bs == 64) XG_L(M, NTS_, 64); else XG_L(M, NTS_, 256); } while (0)

@@ -1396,7 +1396,7 @@ bool launch_ysm(const StencilCall& c) {
   // one metric: bands of 2 x zb_rows = 32 rows hold here (reads 1.062 -> 1.032x, +0.6 points, profiles/history/r03bh_pmc_dy_bands.jsonl):
   // the output lines are dropped from the L2 as they are written (rule 16), the band's one metric plane and the halo rows stay
   // two metrics: 16-row bands hold in the y-stacked form, where K2S needs 8 (round 4: reads 6.00 -> 5.72 GB, traffic 1.064 ->
-  // 1.038x at the same speed, nine placements paired; profiles/r04h_ab_iymw_*.log)
+  // 1.038x at the same speed, nine placements paired; profiles/history/r04h_ab_iymw_*.log)
   const u32 zbr = (c.m_in && c.m_out) ? zb_base : zb_base * 2;
   const u32 per = (u32)(SEG * WPB);
   const u32 ZB_SS = (zbr + per - 1) / per;  // band height in super-segments (at least one)

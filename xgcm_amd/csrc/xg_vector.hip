@@ -685,7 +685,7 @@ static int pair2d_impl(int mode, const real* a, const real* u, const real* v, re
   ZBand zb = make_zband(false, 0, 0, 1);
   u64 outer_step = outer_per;
   // rows per band: twice `vec_zb_rows` (32) with one metric plane, `vec_zb_rows` (16) with two -- round 4, PMC per band
-  // height (profiles/r04b_ab_bands_grad.log): two metrics 8 -> 16 rows reads 5.97 -> 5.65 GB (traffic 1.041 -> 1.021x), 32
+  // height (profiles/history/r04b_ab_bands_grad.log): two metrics 8 -> 16 rows reads 5.97 -> 5.65 GB (traffic 1.041 -> 1.021x), 32
   // rows 5.61 GB, all at the same speed; the two `nt`-stored outputs leave the L2 room the one-output kernels do not have
   // (their cliff sits between 8 and 16 rows for two metrics, r04b_ab_bands_met.log)
   const u32 gzb = (u32)(tune().vec_zb_rows > 1 ? tune().vec_zb_rows : 16);

@@ -176,6 +176,8 @@ def materialize(t: torch.Tensor) -> torch.Tensor:
     copy (rows as 16-byte lanes, true transposes through LDS tiles), contiguous tensors pass"""
     if t.is_contiguous():
         return t
+    if t.dim() > _hip.MAX_NDIM or t.element_size() not in (1, 2, 4, 8):
+        return t.contiguous()  # (more dims / wider elements than xg_copy_nd takes: torch's copy, plumbing outside the hot path)
     out = _empty(t.shape, dtype=t.dtype, device=t.device)
     _copy_nd(t.data_ptr(), t.stride(), out, t.shape)
     return out

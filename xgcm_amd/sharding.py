@@ -199,8 +199,32 @@ def gpu_pci_bus_id(index: int) -> Optional[str]:
         return None
 
 
+def set_affinity_all_threads(cpus) -> int:
+    """`os.sched_setaffinity` for every thread of this process (/proc/self/task); returns how many were moved.  A thread
+    that exits meanwhile, or a platform without /proc, leaves the calling thread bound at least."""
+    import os
+
+    cpus = sorted(cpus)
+    os.sched_setaffinity(0, cpus)
+    moved = 1
+    try:
+        me = os.getpid()
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except OSError:
+        return moved
+    for tid in tids:
+        if tid == me:
+            continue
+        try:
+            os.sched_setaffinity(tid, cpus)
+            moved += 1
+        except OSError:
+            pass
+    return moved
+
+
 def bind_to_gpu_numa(local_rank: int, sysfs: str = "/sys", pci_bus_id: Optional[str] = None, apply: Optional[bool] = None) -> dict:
-    """Restrict this process to the CPUs local to its GPU (`os.sched_setaffinity`) and return what was found and done:
+    """Restrict this process -- every thread it has -- to the CPUs local to its GPU and return what was found and done:
     {local_rank, pci_bus_id, numa_node, cpus (cpulist text), n_cpus, bound, affinity_before / affinity (cpulists the
     process ran / runs on)}.
     `apply` None = on unless XG_NUMA_BIND=0.  Never raises: an unreadable sysfs or a refused affinity call is reported."""
@@ -221,8 +245,11 @@ def bind_to_gpu_numa(local_rank: int, sysfs: str = "/sys", pci_bus_id: Optional[
             allowed = set(os.sched_getaffinity(0))
             target = sorted(set(cpus) & allowed)  # never widen a cpuset the launcher / container imposed
             if target:
-                os.sched_setaffinity(0, target)
+                # `sched_setaffinity(0, ...)` moves the CALLING thread only: threads that already exist (torch's / OpenMP's
+                # pools) would keep the old mask while new ones inherit the narrow one.  Every task of the process moves.
+                n = set_affinity_all_threads(target)
                 out["bound"] = True
+                out["threads_bound"] = n
         except OSError as exc:
             out["error"] = str(exc)
     try:
