@@ -387,3 +387,24 @@ def test_config5_as_written_at_llc_scale():
     with grid.fused():
         zeta = (grid.diff(v, "X") - grid.diff(u, "Y")) / ds["rAz"]
     assert torch.equal(zeta.data, eager.data) and lazy.STATS.get("vorticity") == 1
+
+
+def test_an_evaluated_result_lets_its_inputs_go(backend):
+    """a deferred result references its operands until it is evaluated -- and not a moment longer (5 GB fields)"""
+    import gc
+    import weakref
+
+    grid, ds = _cgrid(padding="fill")
+    u_arr, v_arr = _np(ds["U"]).copy(), _np(ds["V"]).copy()
+    refs = [weakref.ref(u_arr), weakref.ref(v_arr)]
+    u, v = DataArray(u_arr, ds["U"].dims), DataArray(v_arr, ds["V"].dims)
+    with grid.fused():
+        zeta = (grid.diff(v, "X") - grid.diff(u, "Y")) / ds["rAz"]
+    want = _np((grid.diff(v, "X") - grid.diff(u, "Y")) / ds["rAz"])
+    del u, v, u_arr, v_arr
+    gc.collect()
+    assert all(r() is not None for r in refs)          # still needed: nothing has been computed
+    assert np.array_equal(_np(zeta), want)
+    gc.collect()
+    assert all(r() is None for r in refs)              # evaluated: the expression tree is gone
+    assert np.array_equal(_np(zeta), want)

@@ -1020,7 +1020,11 @@ def synthetic(shape, seed: int, offset: int = 0, scale: float = 1.0, shift: floa
     lib = _hip.load()
     _require_gpu()
     if out is None:
-        out = _empty(tuple(shape), dtype=dtype, device="cuda")
+        # a synthetic field is an INPUT (like an uploaded array): torch's own allocation, unless XG_SCATTER_INPUTS=1 asks for
+        # the results' pool (tools: what does the placement of an input cost a reader?)
+        import os
+
+        out = (_empty if os.environ.get("XG_SCATTER_INPUTS") == "1" else torch.empty)(tuple(shape), dtype=dtype, device="cuda")
     if out.numel() == 0:
         return out
     sfx = "f32" if out.dtype == torch.float32 else "f64"

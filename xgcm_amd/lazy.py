@@ -67,8 +67,17 @@ class Node:
 
     def get(self):
         if self.value is None:
-            self.value = self._compute()
+            self.set(self._compute())
         return self.value
+
+    def set(self, value) -> None:
+        """the node's value; its operands are let go (a result must not keep its inputs alive any longer than the eager
+        call would have)"""
+        self.value = value
+        self._release()
+
+    def _release(self) -> None:
+        pass
 
     def _compute(self):  # pragma: no cover
         raise NotImplementedError
@@ -206,13 +215,21 @@ class LazyArray(DataArray):
 # stencil nodes: one axis of Grid.diff / interp / min / max / derivative
 # ==============================================================================================
 _PENDING = "_lazy_pending"
+_PENDING_LOCK = threading.Lock()  # one Grid may be used from several threads: its set of unevaluated nodes is shared
 
 
-def _pending(grid) -> "weakref.WeakSet":
-    ws = grid.__dict__.get(_PENDING)
-    if ws is None:
-        ws = grid.__dict__[_PENDING] = weakref.WeakSet()
-    return ws
+def _pending_add(grid, node) -> None:
+    with _PENDING_LOCK:
+        ws = grid.__dict__.get(_PENDING)
+        if ws is None:
+            ws = grid.__dict__[_PENDING] = weakref.WeakSet()
+        ws.add(node)
+
+
+def _pending_list(grid) -> list:
+    with _PENDING_LOCK:
+        ws = grid.__dict__.get(_PENDING)
+        return list(ws) if ws is not None else []
 
 
 class StencilNode(Node):
@@ -223,6 +240,9 @@ class StencilNode(Node):
         self.value = None
         for k, v in kw.items():
             setattr(self, k, v)
+
+    def _release(self) -> None:
+        self.arg = self.source = self.other_component = self.m_in = self.m_out = None
 
     # -- the eager call, optionally with metrics that a surrounding expression contributes ------------
     def run(self, extra_m_out: Optional[DataArray] = None):
@@ -343,7 +363,7 @@ def defer_stencil(grid, funcname, ufunc, sig, arg, ax_name, other_component, m_i
     shape = tuple(n + lo + hi - 1 if d == in_dim else n for d, n in zip(da.dims, da.shape))
     res = LazyArray(node, out_dims, shape, dt, _is_host(da), name=da.name)
     res = _reattach_coords([res], grid, ufunc.padding_width, {out_dim}, [da])[0]
-    _pending(grid).add(node)
+    _pending_add(grid, node)
     _count("deferred_stencil")
     return res
 
@@ -357,6 +377,9 @@ class BinaryNode(Node):
     def __init__(self, op, a, b, reflexive, dims_order, dims):
         self.value = None
         self.op, self.a, self.b, self.reflexive, self.dims_order, self.dims = op, a, b, reflexive, dims_order, tuple(dims)
+
+    def _release(self) -> None:
+        self.a = self.b = None
 
     def eager(self):
         a = plain(self.a)
@@ -431,7 +454,7 @@ def defer_binary(self_operand, other, op: str, reflexive: bool, dims_order, forc
     for x in (a, other):  # sibling rules (flux) look pending products up through the grid of their stencil operand
         n = _unforced(x, StencilNode)
         if n is not None:
-            _pending(n.grid).add(node)
+            _pending_add(n.grid, node)
     _count("deferred_binary")
     return LazyArray(node, dims, shape, rt, host, coords=coords, name=a.name)
 
@@ -533,7 +556,7 @@ def _siblings(node, cls):
     grid = node.grid if isinstance(node, StencilNode) else None
     if grid is None:
         return []
-    return [n for n in list(_pending(grid)) if n is not node and isinstance(n, cls) and n.value is None]
+    return [n for n in _pending_list(grid) if n is not node and isinstance(n, cls) and n.value is None]
 
 
 def _try_gradient(s: StencilNode):
@@ -565,9 +588,10 @@ def _try_gradient(s: StencilNode):
             bcy, fy, hy = sy.halo((1, 0))
             gx, gy = _dev.gradient(field.data, bcx, bcy, fx, fy, mx, my, hx, hy)
             host = _is_host(field)
-            sx.value, sy.value = _finish(gx, host), _finish(gy, host)
+            vx, vy = _finish(gx, host), _finish(gy, host)
+            (sy if s is sx else sx).set(vy if s is sx else vx)   # the sibling has its value now; `s` gets its own from the caller
             _count("gradient")
-            return s.value
+            return vx if s is sx else vy
     return None
 
 
@@ -598,7 +622,7 @@ def _try_flux(root: BinaryNode):
     comp, s = mine
     t = s.source
     key = _source_key(t)
-    for other in [n for n in list(_pending(s.grid)) if n is not root and isinstance(n, BinaryNode) and n.value is None]:
+    for other in [n for n in _pending_list(s.grid) if n is not root and isinstance(n, BinaryNode) and n.value is None]:
         parts = _flux_parts(other)
         if parts is None:
             continue
@@ -619,9 +643,10 @@ def _try_flux(root: BinaryNode):
         bcy, fy, hy = sy.halo((1, 0))
         qx, qy = _dev.flux(u.data, v.data, tracer.data, bcx, bcy, fx, fy, hx, hy)
         host = _is_host(tracer)
-        nx.value, ny.value = _finish(qx, host), _finish(qy, host)
+        vx, vy = _finish(qx, host), _finish(qy, host)
+        (ny if root is nx else nx).set(vy if root is nx else vx)
         _count("flux")
-        return root.value
+        return vx if root is nx else vy
     return None
 
 
