@@ -408,3 +408,104 @@ def test_an_evaluated_result_lets_its_inputs_go(backend):
     gc.collect()
     assert all(r() is None for r in refs)              # evaluated: the expression tree is gone
     assert np.array_equal(_np(zeta), want)
+
+
+# ----------------------------------------------------------------------------------------------
+# differential fuzzing: random operator / arithmetic expressions, deferred == eager bit for bit
+# ----------------------------------------------------------------------------------------------
+def _random_expression(rng, grid, ds, depth=0):
+    """a random expression over the C-grid fields as a function g -> labelled array, built from the operators and the
+    arithmetic the rules know AND from the ones they do not (min / max, scalars, reversed operands, mixed positions)"""
+    fields = {"U": ds["U"], "V": ds["V"], "T": ds["T"]}
+    metrics = [ds[k] for k in ("rAz", "rA", "dxC", "dyC", "dyG", "dxG")]
+
+    def leaf():
+        name = rng.choice(sorted(fields))
+        f = fields[name]
+        if rng.random() < 0.3:
+            m = metrics[rng.integers(len(metrics))]
+            if set(m.dims) <= set(f.dims):
+                return lambda g, f=f, m=m: f * m
+        return lambda g, f=f: f
+
+    def stencil(sub):
+        op = rng.choice(["diff", "interp", "min", "max", "derivative"])
+        ax = rng.choice(["X", "Y"])
+        def run(g, sub=sub, op=op, ax=ax):
+            x = sub(g)
+            try:
+                return getattr(g, op)(x, ax)
+            except (KeyError, ValueError, NotImplementedError):   # (no metric at that position ...): leave the operand as it is
+                return x
+        return run
+
+    def binary(a, b):
+        op = rng.choice(["add", "sub", "mul", "div"])
+        def run(g, a=a, b=b, op=op):
+            x, y = a(g), b(g)
+            if isinstance(y, DataArray) and isinstance(x, DataArray) and (set(x.dims) != set(y.dims) and not (set(y.dims) <= set(x.dims))):
+                y = 2.5   # operands on different points do not broadcast: a scalar instead
+            return {"add": lambda: x + y, "sub": lambda: x - y, "mul": lambda: x * y, "div": lambda: x / y}[op]()
+        return run
+
+    def template():
+        """the shapes the fused rules look for, with random boundary modes, operand orders and trimmings"""
+        modes = ["periodic", "extend", "fill"]
+        kx = {"padding": str(rng.choice(modes)), "fill_value": float(rng.integers(-2, 3))}
+        ky = {"padding": str(rng.choice(modes)), "fill_value": float(rng.integers(-2, 3))}
+        which, tail, swap = rng.integers(4), rng.integers(3), rng.random() < 0.5
+        U, V, T = fields["U"], fields["V"], fields["T"]
+
+        def finish(g, x, area):
+            return x / area if tail == 0 else (x / 3.0 if tail == 1 else x)
+
+        if which == 0:    # curl
+            return lambda g: finish(g, (g.diff(U, "Y", **ky) - g.diff(V, "X", **kx)) if swap else
+                                    (g.diff(V, "X", **kx) - g.diff(U, "Y", **ky)), ds["rAz"])
+        if which == 1:    # divergence
+            return lambda g: finish(g, (g.diff(V, "Y", **ky) + g.diff(U, "X", **kx)) if swap else
+                                    (g.diff(U, "X", **kx) + g.diff(V, "Y", **ky)), ds["rA"])
+        if which == 2:    # gradient pair (plain or metric-weighted), both used
+            op = "derivative" if swap else "diff"
+            return lambda g: getattr(g, op)(T, "X", **kx) + g.interp(g.interp(getattr(g, op)(T, "Y", **ky), "Y"), "X")
+        # flux pair -> divergence of the fluxes (the advection step of docs/ufunc_examples.md)
+        return lambda g: finish(g, g.diff(U * g.interp(T, "X", **kx), "X") + g.diff(g.interp(T, "Y", **ky) * V, "Y"), ds["rA"])
+
+    if depth == 0 and rng.random() < 0.35:
+        return template()
+    if depth >= 3 or (depth > 0 and rng.random() < 0.25):
+        return leaf()
+    kind = rng.random()
+    if kind < 0.45:
+        return stencil(_random_expression(rng, grid, ds, depth + 1))
+    if kind < 0.85:
+        return binary(_random_expression(rng, grid, ds, depth + 1), _random_expression(rng, grid, ds, depth + 1))
+    m = metrics[rng.integers(len(metrics))]
+    sub = _random_expression(rng, grid, ds, depth + 1)
+
+    def over_metric(g, sub=sub, m=m):
+        x = sub(g)
+        return x / m if isinstance(x, DataArray) and set(m.dims) <= set(x.dims) else x
+    return over_metric
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_expressions_deferred_equal_eager(backend, seed):
+    rng = np.random.default_rng(1000 + seed)
+    grid, ds = _cgrid(nz=2, ny=6, nx=8, padding={"X": "periodic", "Y": "extend"})
+    routes = {}
+    for k in range(25):
+        expr = _random_expression(rng, grid, ds)
+        with np.errstate(all="ignore"):
+            eager = expr(grid)
+            lazy.reset_stats()
+            with grid.fused():
+                got = expr(grid)
+            if not isinstance(eager, DataArray):
+                continue
+            _same_labelled(got, eager)
+        for key, n in lazy.STATS.items():
+            routes[key] = routes.get(key, 0) + n
+    # the generator reaches the fused rules AND the fallbacks (otherwise this test proves nothing about either)
+    assert routes.get("deferred_stencil", 0) > 10 and routes.get("binary_eager", 0) + routes.get("stencil_eager", 0) > 5
+    assert sum(routes.get(k, 0) for k in ("vorticity", "divergence", "gradient", "flux")) >= 3, routes

@@ -149,7 +149,14 @@ def _raw_device(x) -> torch.Tensor:
             raise TypeError(f"array: dtype {t.dtype} is not supported by the MI355X backend")
     else:
         a, swap = _dt.host_intake(np.ascontiguousarray(x))
-        t = torch.from_numpy(a) if a.flags.writeable else torch.from_numpy(a.copy())
+        if a.flags.writeable:
+            t = torch.from_numpy(a)
+        else:  # (a read-only memory map of a file: only ever READ here -- no copy, no warning)
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
+                t = torch.from_numpy(a)
     if not t.is_cuda:
         t = t.cuda()
         if swap and t.numel():  # (a fresh private copy: swapped in place)
