@@ -47,7 +47,8 @@ def test_real_xarray_in_real_xarray_out(backend, funcname):
     ds = _dataset()
     out = getattr(_grid(ds), funcname)(ds["v"], "X")
     assert isinstance(out, xr.DataArray)
-    assert out.dims == ("time", "XG") and out.name == "v"
+    # (`diff / dx`, `cumsum(v * dx)`: xarray keeps a name only while every operand carries it -- xgcm/grid.py:1576-1578, :1656-1660)
+    assert out.dims == ("time", "XG") and out.name == (None if funcname in ("derivative", "cumint") else "v")
     assert set(out.coords) == {"time", "XG", "t_label", "lon_g"}  # xc_aux lives on the old core dim: gone
     xr.testing.assert_identical(out.coords["lon_g"].variable, ds["lon_g"].variable)  # values, dims, dtype AND attrs
     assert out.coords["lon_g"].attrs == {"units": "degrees_east"}

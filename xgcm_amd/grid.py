@@ -53,6 +53,15 @@ def _maybe_promote_str_to_list(a):
     return [a] if isinstance(a, str) else a
 
 
+def _name_after(name, *metrics):
+    """name of `array OP metric ...` by xarray's rule (kept only while every operand carries it): the fused kernels
+    take the metrics into the operator's launch, the NAME still follows the reference's explicit products / quotients"""
+    for m in metrics:
+        if m is not None and getattr(m, "name", None) != name:
+            return None
+    return name
+
+
 class _DimsOnly:
     """Stand-in carrying only `.dims`/`.name`: all `get_metric` needs of its `array` argument."""
 
@@ -212,6 +221,18 @@ class Grid:
         for links in face_links.values():
             for pair in links.values():
                 self._connected_axes.update(link[1] for link in pair if link is not None)
+
+    def _links_swap_axes(self, ax_name: str) -> bool:
+        """does any face link on `ax_name` lead to ANOTHER axis of the neighbour (or any link of another axis lead here)?"""
+        if self._face_connections is None:
+            return False
+        for faces in self._face_connections.values():
+            for links in faces.values():
+                for axis, pair in links.items():
+                    for link in pair:
+                        if link is not None and (axis == ax_name or link[1] == ax_name) and link[1] != axis:
+                            return True
+        return False
 
     def _validate_folds(self) -> None:
         """Resolve north-fold paddings: the seam is the one explicitly periodic other axis."""
@@ -502,7 +523,12 @@ class Grid:
                 m_out = self._resident(self.get_metric(_DimsOnly(out_dims, array.name), weighted, _layout=out_dims), _lazy.like(array))
             if _divide_by is not None:
                 dx = self._resident(self.get_metric(_DimsOnly(out_dims, array.name), _divide_by, _layout=out_dims), _lazy.like(array))
-                if m_out is None:
+                if any(d not in out_dims for d in dx.dims):
+                    # the metric found for the result does not live on the result's points (drC on Zp1 interpolated to Z
+                    # for a difference that went to Zl ...): the reference's `diff / dx` then BROADCASTS by name into an
+                    # outer product (xgcm/grid.py:1576-1578) -- the explicit quotient does the same
+                    post_divide = dx
+                elif m_out is None:
                     m_out = dx
                 else:
                     post_divide = dx  # two successive divisions cannot be merged bit-exactly
@@ -531,6 +557,8 @@ class Grid:
                 array = ufunc(self, arg, axis=[(ax_name,)], other_component=other_component, **remaining)
                 if m_out is not None:
                     array = array / m_out
+            if (m_in is not None or m_out is not None) and array.name is not None:
+                array = array._replace(name=_name_after(array.name, m_in, m_out))
             if post_divide is not None:
                 array = array / post_divide
         if was_xr and isinstance(array, _lazy.LazyArray) and array.is_deferred:
@@ -579,6 +607,7 @@ class Grid:
             return None
         host = not _is_tensor(array.data)
         planes = None
+        named = array.name
         if weighted is not None:
             # the metric at the input positions, between the two axes and at the output positions (xgcm/grid.py:804-828
             # multiplies before and divides after EACH axis); each must be a plain (Y, X) plane over the last two dims
@@ -593,10 +622,11 @@ class Grid:
                 if tuple(m.dims) != tuple(dims[-2:]) or tuple(m.shape) != tuple(array.shape[-2:]):
                     return None  # broadcast / extra dims: the per-axis kernels take any metric pattern
                 planes.append(self._resident(m, array.data).data)
+                named = _name_after(named, m)
         out = _dev.stencil2d(funcname, array.data, 0 if x_is_a else 1, padx, bc[ax_x], float(fv[ax_x] or 0.0), pady,
                              bc[ax_y], float(fv[ax_y] or 0.0), **({"metrics": planes} if planes is not None else {}))
         rename = {dim_a: out_a, dim_b: out_b}
-        res = DataArray(_dev.tohost(out) if host else out, tuple(rename.get(d, d) for d in array.dims), name=array.name)
+        res = DataArray(_dev.tohost(out) if host else out, tuple(rename.get(d, d) for d in array.dims), name=named)
         return _reattach_coords([res], self, None, {out_a, out_b}, [array])[0]
 
     def interp(self, da, axis, **kwargs):
@@ -703,22 +733,32 @@ class Grid:
             out_dims = tuple(new_dim if d == dim else d for d in data.dims)
             weighted = metric_weighted.get(ax.name) if isinstance(metric_weighted, dict) else None
             m_in = m_out = None
+            weight_names = []  # the DataArrays whose products / quotients decide the result's name (xarray's rule)
             if pre_weight is not None:
                 if weighted or generic_pad:  # two input factors / pad-after route: explicit product first
                     data = data * pre_weight
                 else:
                     m_in = _aligned_view(pre_weight, data.dims)
+                    weight_names.append(pre_weight)
                 pre_weight = None
             if weighted:
-                m_in = _aligned_view(self._resident(self.get_metric(data, weighted, _layout=data.dims), data.data), data.dims)
-                m_out = _aligned_view(
-                    self._resident(self.get_metric(_DimsOnly(out_dims, data.name), weighted, _layout=out_dims), data.data), out_dims)
+                w_in = self.get_metric(data, weighted, _layout=data.dims)
+                w_out = self.get_metric(_DimsOnly(out_dims, data.name), weighted, _layout=out_dims)
+                weight_names += [w_in, w_out]
+                m_in = _aligned_view(self._resident(w_in, data.data), data.dims)
+                m_out = _aligned_view(self._resident(w_out, data.data), out_dims)
             num = data.get_axis_num(dim)
             host = not _is_tensor(data.data)
             # xarray's DataArray.cumsum skips NaN for floats (numpy.nancumsum); see DESIGN.md "unpinned"
             if generic_pad:
                 # complex topology: the reference pads the TRIMMED cumulative field through the topology (grid.py:1389-1395),
                 # i.e. its halo cells are the neighbouring faces' (the folded row's) cumulative edge values
+                if (pad_lo or pad_hi) and (trim_lo or trim_hi) and self._links_swap_axes(ax.name):
+                    # the reference pads the TRIMMED cumulative field through the topology (xgcm/grid.py:1385-1395): across a
+                    # link that swaps axes the trimmed faces (n x (n - 1)) no longer fit each other and its concat fails
+                    raise ValueError(
+                        f"cumsum along {ax.name!r} from {pos!r} to {ax_to!r} trims the field along an axis whose face "
+                        "connections swap axes: the trimmed faces are no longer square and cannot exchange halos")
                 if pad_lo or pad_hi:
                     # one pass: the scan writes the padded layout (halo cells hold a placeholder), the halo cells are
                     # gathered from that very buffer -- a (pad_lo + pad_hi)-wide slab -- and put in place: no padded copy
@@ -741,12 +781,21 @@ class Grid:
                 res = DataArray(_dev.tohost(out) if host else out, out_dims, name=data.name)
                 if weighted:
                     res = res / self._resident(self.get_metric(res, weighted, _layout=res.dims), res.data)
+
             else:
                 # integer data: numpy.cumsum's int64 / uint64 accumulator and numpy.pad's cast of the fill value, both in
                 # the device layer (xgcm_amd.dtypes)
                 out = _dev.cumsum1d(data.data, num, trim_lo, trim_hi, pad_lo, pad_hi,
                                     bc if (pad_lo or pad_hi) else None, 0.0 if fv is None else fv, rev, True, m_in, m_out)
                 res = DataArray(_dev.tohost(out) if host else out, out_dims, name=data.name)
+            if (m_in is not None or m_out is not None) and res.name is not None:
+                res = res._replace(name=_name_after(res.name, *weight_names))
+            if (pad_lo or pad_hi) and self._facedim is not None and self._facedim in res.dims and res.dims[0] != self._facedim:
+                # on a grid with face connections the reference pads EVERY axis through `_pad_face_connections`, which
+                # rebuilds the array with `xr.concat(faces, dim=facedim)` -- the face dim comes out FIRST -- and `Grid.cumsum`
+                # (unlike diff / interp) does not restore the input's order (xgcm/padding.py:540-572, xgcm/grid.py:1385-1395):
+                # the same dims order here, as a view (no copy)
+                res = res.transpose(self._facedim, *[d for d in res.dims if d != self._facedim])
             data = _reattach_coords([res], self, {ax.name: (pad_lo, pad_hi)}, {new_dim}, [data])[0]
         return to_xarray(data) if was_xr else data
 
@@ -765,6 +814,9 @@ class Grid:
             out = (da * weight).sum(dims, skipna=skip, keep_attrs=keep_attrs)
         else:
             out = self._weighted_reduce(da, factors, dims, skip, keep_attrs)
+            # `da * weight` of the reference: nameless unless the weight carries the field's name (xarray's rule); a
+            # product of several metrics is nameless itself
+            out = out._replace(name=_name_after(da.name, *(factors if len(factors) == 1 else [None, _DimsOnly((), None)])))
         return to_xarray(out) if was_xr else out
 
     def _weight_factors(self, da, axis, dims):

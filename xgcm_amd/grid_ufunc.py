@@ -387,6 +387,8 @@ def _apply(func, args: Sequence[DataArray], in_core_dims, out_core_dims, **kwarg
             elif bsize[d] != s:
                 raise ValueError(f"operands could not be broadcast together on dimension {d!r}")
     raw = [_move_core_last(a, cd, bdims) for a, cd in zip(args, in_core_dims)]
+    names = {a.name for a in args}
+    name = names.pop() if len(names) == 1 else None  # xarray: an output keeps the name all the inputs share
     result = func(*raw, **kwargs)
     if not isinstance(result, tuple):
         result = (result,)
@@ -403,7 +405,7 @@ def _apply(func, args: Sequence[DataArray], in_core_dims, out_core_dims, **kwarg
             raise ValueError(
                 f"applied function returned data with {len(r.shape)} dimensions, expected {len(dims)}: {dims}"
             )
-        out.append(DataArray(r, dims))
+        out.append(DataArray(r, dims, name=name))
     return tuple(out)
 
 

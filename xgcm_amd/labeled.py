@@ -285,7 +285,7 @@ class DataArray:
         res = _dev.binary(op, a, b)
         if host:
             res = _dev.tohost(res)
-        return DataArray(res, dims, coords=coords, name=self.name)
+        return DataArray(res, dims, coords=coords, name=_result_name(self, other))
 
     def __mul__(self, o): return self._binary(o, "mul")
     def __rmul__(self, o): return self._binary(o, "mul", True)
@@ -332,6 +332,14 @@ class DataArray:
         if not isinstance(key, tuple):
             key = (key,)
         return self.isel({d: k for d, k in zip(self.dims, key)})
+
+
+def _result_name(a, b):
+    """xarray's rule for `a OP b`: the name survives only if every named operand carries the same one (a scalar has none
+    to disagree with) -- so `grid.diff(T, "X") / dxC` is nameless, as in the reference (xgcm/grid.py:1576-1578)"""
+    if isinstance(b, DataArray):
+        return a.name if a.name == b.name else None
+    return a.name
 
 
 def _aligned_view(da: DataArray, dims: Sequence[str]):

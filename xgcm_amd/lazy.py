@@ -361,7 +361,11 @@ def defer_stencil(grid, funcname, ufunc, sig, arg, ax_name, other_component, m_i
                        other_component=other_component, remaining=kwargs, m_in=m_in, m_out=m_out, in_dim=in_dim,
                        out_dim=out_dim, out_dims=tuple(out_dims), lo=int(lo), hi=int(hi), bc=bc, fv=fv, complex=complex_)
     shape = tuple(n + lo + hi - 1 if d == in_dim else n for d, n in zip(da.dims, da.shape))
-    res = LazyArray(node, out_dims, shape, dt, _is_host(da), name=da.name)
+    name = da.name
+    for m in (m_in, m_out):  # xarray's name rule for the explicit `* metric` / `/ metric` of the reference
+        if m is not None and getattr(m, "name", None) != name:
+            name = None
+    res = LazyArray(node, out_dims, shape, dt, _is_host(da), name=name)
     res = _reattach_coords([res], grid, ufunc.padding_width, {out_dim}, [da])[0]
     _pending_add(grid, node)
     _count("deferred_stencil")
@@ -456,7 +460,7 @@ def defer_binary(self_operand, other, op: str, reflexive: bool, dims_order, forc
         if n is not None:
             _pending_add(n.grid, node)
     _count("deferred_binary")
-    return LazyArray(node, dims, shape, rt, host, coords=coords, name=a.name)
+    return LazyArray(node, dims, shape, rt, host, coords=coords, name=_labeled._result_name(a, other))
 
 
 # ==============================================================================================
