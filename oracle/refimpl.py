@@ -23,6 +23,10 @@ Pinning status
   ``skipna`` (NaN treated as 0 in ``cumsum``/``sum``) is xarray behaviour that no reference
   test exercises on this path: PARITY UNPINNED for NaN inputs to cumsum/integrate.
 
+* the ``Grid`` LEVEL (dispatch, per-axis kwargs, the cumsum table, metric selection / interpolation, derivative / integrate /
+  average / cumint, coordinate re-attachment, dim order, names, errors): PINNED MODULO A STAND-IN since round 5 --
+  ``oracle/make_golden_grid.py`` runs the reference's own ``xgcm/grid.py`` stack over ``oracle/xr_min.py`` (numpy-backed
+  stand-in for the xarray calls it makes) and ``tests/test_grid_reference.py`` replays its 426 calls through ``xgcm_amd.Grid``.
 * complex topologies (``oracle/topology.py``; fixtures ``fold_reference.json``, ``topology_reference.*``) and the vertical
   transform (``oracle/transform.py``; ``transform_kernels_reference.npz``): PINNED MODULO STAND-INS.  The halo logic and the
   two gufunc bodies that produced those fixtures are the reference's own code, loaded unmodified -- but over builder-written
