@@ -814,9 +814,10 @@ class Grid:
             out = (da * weight).sum(dims, skipna=skip, keep_attrs=keep_attrs)
         else:
             out = self._weighted_reduce(da, factors, dims, skip, keep_attrs)
-            # `da * weight` of the reference: nameless unless the weight carries the field's name (xarray's rule); a
-            # product of several metrics is nameless itself
-            out = out._replace(name=_name_after(da.name, *(factors if len(factors) == 1 else [None, _DimsOnly((), None)])))
+            # `da * weight` of the reference: nameless unless the weight carries the field's name (xarray's rule); a weight
+            # that is itself a product of several metrics has no name
+            weight_name = factors[0].name if len(factors) == 1 else None
+            out = out._replace(name=da.name if weight_name == da.name else None)
         return to_xarray(out) if was_xr else out
 
     def _weight_factors(self, da, axis, dims):
