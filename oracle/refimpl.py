@@ -27,6 +27,8 @@ Pinning status
   average / cumint, coordinate re-attachment, dim order, names, errors): PINNED MODULO A STAND-IN since round 5 --
   ``oracle/make_golden_grid.py`` runs the reference's own ``xgcm/grid.py`` stack over ``oracle/xr_min.py`` (numpy-backed
   stand-in for the xarray calls it makes) and ``tests/test_grid_reference.py`` replays its 426 calls through ``xgcm_amd.Grid``.
+  ``oracle/make_golden_metadata.py`` does the same for ``Grid(ds)`` from COMODO / SGRID metadata (57 dataset descriptions,
+  ``tests/test_metadata_reference.py``).
 * complex topologies (``oracle/topology.py``; fixtures ``fold_reference.json``, ``topology_reference.*``) and the vertical
   transform (``oracle/transform.py``; ``transform_kernels_reference.npz``): PINNED MODULO STAND-INS.  The halo logic and the
   two gufunc bodies that produced those fixtures are the reference's own code, loaded unmodified -- but over builder-written

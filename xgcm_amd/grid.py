@@ -122,7 +122,7 @@ class Grid:
                 "in future versions. Provide `fill_value=0.0` to preserve previous behavior.",
                 category=DeprecationWarning,
             )
-        if not coords:  # (nothing given and nothing parsed: the reference fails on its first use of the empty mapping)
+        if coords is None:  # (a dataset whose metadata names no axis parses to {}: an empty Grid, as in the reference)
             raise ValueError(
                 "Could not determine Axis names - please provide them in the coords kwarg "
                 "or provide a dataset from which they can be parsed"
