@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""The reference's OWN test suite, unmodified, run against `xgcm_amd`.
+
+TEST INFRASTRUCTURE -- build container only (reads /root/reference at run time; nothing of it is copied into the repo),
+never shipped, never on the GPU box.
+
+    python oracle/run_reference_suite.py [--backend host-abi|oracle-double|hip] [--report out.json] [pytest args]
+
+How: a scratch directory under /tmp gets a package NAMED `xgcm` whose modules re-export `xgcm_amd`'s (`xgcm.grid` is
+`xgcm_amd.grid`, ... -- the import lines of the reference's tests resolve to THIS package), its `test` sub-package is a
+symlink to `/root/reference/xgcm/test` (the test files are read where they lie), a module NAMED `xarray` is
+`oracle/xr_min.py` + `oracle/xr_suite.py` (xarray is not installable here: numpy-backed stand-in, see those files), `dask`
+is an empty stub (tests that need chunked arrays are reported as `needs-dask`, the product refuses dask inputs by design,
+DESIGN section 10), and `xgcm_amd.device` is one of the CPU test doubles (the host build of the C ABI by default) or, on a
+GPU box that has the reference, the real library.  pytest then collects `xgcm/test/*.py` as the reference's CI does.
+
+What a pass means: the reference's assertion, written by its authors against its own implementation, holds for
+`xgcm_amd` under the stand-in's container semantics ("pinned modulo the stand-in", as DESIGN section 7 says for every
+fixture made this way).  Every outcome is written to a JSON report; `tests/golden/reference_suite_report.json` is the
+committed one and `tests/test_reference_suite_live.py` re-runs the suite wherever /root/reference exists and fails on any
+test that passed in the committed report and no longer does.
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("XGCM_REFERENCE", "/root/reference")
+
+SHIM_MODULES = ["grid", "grid_ufunc", "padding", "axis", "metadata_parsers", "metrics", "transform", "gridops", "comodo", "sgrid"]
+
+INIT = '''"""scratch shim: the name `xgcm` bound to xgcm_amd (written by oracle/run_reference_suite.py)"""
+from xgcm_amd import *  # noqa
+from xgcm_amd import Grid, Axis, as_grid_ufunc, apply_as_grid_ufunc  # noqa
+import xgcm_amd as _pkg
+__version__ = _pkg.__version__
+'''
+
+SHIM = '''"""scratch shim: xgcm.{name} is xgcm_amd.{source} (written by oracle/run_reference_suite.py)"""
+import xgcm_amd.{source} as _m
+globals().update({{k: v for k, v in vars(_m).items() if not (k.startswith("__") and k.endswith("__"))}})
+if "{name}" == "padding":
+    from oracle.refsuite_adapters import extras as _extras
+    globals().update(_extras(_m))
+'''
+
+CONFTEST = '''"""scratch conftest (written by oracle/run_reference_suite.py): stand-in `xarray`, stub `dask`, a device for xgcm_amd"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import pytest
+
+ROOT = {root!r}
+BACKEND = {backend!r}
+REPORT = {report!r}
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _load_as(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+xr = _load_as("xarray", os.path.join(ROOT, "oracle", "xr_min.py"))        # classes live in a module NAMED xarray
+suite = _load_as("xarray._suite", os.path.join(ROOT, "oracle", "xr_suite.py"))
+suite.extend(xr)
+
+dask = types.ModuleType("dask")
+dask_array = types.ModuleType("dask.array")
+dask_array.Array = type("Array", (), {{}})
+dask.array = dask_array
+sys.modules["dask"] = dask
+sys.modules["dask.array"] = dask_array
+
+
+class _MP:
+    """the two calls the doubles' install() makes on a pytest monkeypatch, for the whole session"""
+
+    def setattr(self, target, name=None, value=None, raising=True):
+        if value is None and isinstance(target, str):
+            mod, _, attr = target.rpartition(".")
+            import importlib
+
+            setattr(importlib.import_module(mod), attr, name)
+        else:
+            setattr(target, name, value)
+
+    def setitem(self, mapping, key, value):
+        mapping[key] = value
+
+
+if BACKEND == "host-abi":
+    import host_abi_device
+
+    host_abi_device.install(_MP())
+elif BACKEND == "oracle-double":
+    from oracle import fake_device
+
+    fake_device.install(_MP())
+elif BACKEND != "hip":
+    raise RuntimeError(BACKEND)
+
+_results = {{}}
+
+
+def pytest_runtest_logreport(report):
+    key = report.nodeid
+    if report.when == "call" or (report.when == "setup" and report.outcome != "passed"):
+        entry = {{"outcome": report.outcome}}
+        if report.outcome != "passed":
+            text = str(report.longrepr)
+            entry["why"] = text.strip().splitlines()[-1][:300] if text.strip() else ""
+            if report.outcome == "skipped" and isinstance(report.longrepr, tuple):
+                entry["why"] = str(report.longrepr[2])[:300]
+        if hasattr(report, "wasxfail"):
+            entry["outcome"] = "xfailed" if report.outcome == "skipped" else "xpassed"
+        _results[key] = entry
+
+
+def pytest_collectreport(report):
+    if report.failed:
+        _results[report.nodeid] = {{"outcome": "collect-error", "why": str(report.longrepr).strip().splitlines()[-1][:300]}}
+
+
+def pytest_sessionfinish(session, exitstatus):
+    with open(REPORT, "w") as f:
+        json.dump(_results, f, indent=0, sort_keys=True)
+'''
+
+
+def build_scratch(backend, report):
+    scratch = tempfile.mkdtemp(prefix="xgcm_refsuite_")
+    pkg = os.path.join(scratch, "xgcm")
+    os.makedirs(pkg)
+    with open(os.path.join(pkg, "__init__.py"), "w") as f:
+        f.write(INIT)
+    for name in SHIM_MODULES:
+        source = {"metadata_parsers": "metadata", "comodo": "metadata", "sgrid": "metadata"}.get(name, name)
+        with open(os.path.join(pkg, name + ".py"), "w") as f:
+            f.write(SHIM.format(name=name, source=source))
+    os.symlink(os.path.join(REF, "xgcm", "test"), os.path.join(pkg, "test"))
+    with open(os.path.join(scratch, "conftest.py"), "w") as f:
+        f.write(CONFTEST.format(root=ROOT, backend=backend, report=report))
+    return scratch
+
+
+def run(backend="host-abi", report=None, extra=(), quiet=True):
+    if not os.path.isdir(os.path.join(REF, "xgcm", "test")):
+        raise FileNotFoundError(f"{REF}/xgcm/test: the reference is not on this box")
+    own_report = report is None
+    if own_report:
+        fd, report = tempfile.mkstemp(suffix=".json", prefix="xgcm_refsuite_")
+        os.close(fd)
+    scratch = build_scratch(backend, report)
+    try:
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=scratch + os.pathsep + ROOT)
+        cmd = [sys.executable, "-m", "pytest", "-p", "no:cacheprovider", "--rootdir", scratch, "-c", os.devnull,
+               "-o", "python_files=test_*.py", "-q", "-x" if False else "-q", "--no-header", "-W", "ignore",
+               *(extra or [os.path.join(scratch, "xgcm", "test")])]
+        proc = subprocess.run(cmd, cwd=scratch, env=env, capture_output=quiet, text=True)
+        with open(report) as f:
+            results = json.load(f)
+        return results, proc
+    finally:
+        shutil.rmtree(scratch, ignore_errors=True)
+        if own_report:
+            os.unlink(report)
+
+
+def summarize(results):
+    counts = {}
+    for v in results.values():
+        counts[v["outcome"]] = counts.get(v["outcome"], 0) + 1
+    return counts
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="host-abi", choices=["host-abi", "oracle-double", "hip"])
+    ap.add_argument("--report", default=None)
+    ap.add_argument("--show", action="store_true", help="pytest's own output")
+    args, extra = ap.parse_known_args()
+    results, proc = run(args.backend, args.report, extra, quiet=not args.show)
+    if not args.show:
+        print(proc.stdout[-3000:])
+        print(proc.stderr[-2000:], file=sys.stderr)
+    print(json.dumps(summarize(results)))
+
+
+if __name__ == "__main__":
+    main()

@@ -28,17 +28,17 @@ def _comodo_1d(position, axis="X"):
 @pytest.mark.parametrize("position", ["left", "right", "inner", "outer"])
 def test_comodo_positions_from_attributes_and_lengths(position):
     ds = _comodo_1d(position)
-    assert M.parse_metadata(ds) == {"coords": {"X": {"center": "xc", position: "xs"}}}
-    assert M.parse_comodo(ds)["coords"]["X"] == {"center": "xc", position: "xs"}
-    assert list(M.parse_comodo(ds)["coords"]["X"]) == ["center", position]  # centre first, like the reference's OrderedDict
+    assert M.parse_metadata(ds) == (ds, {"coords": {"X": {"center": "xc", position: "xs"}}})  # (ds, kwargs), xgcm/metadata_parsers.py:45
+    assert M.parse_comodo(ds)[1]["coords"]["X"] == {"center": "xc", position: "xs"}
+    assert list(M.parse_comodo(ds)[1]["coords"]["X"]) == ["center", position]  # centre first, like the reference's OrderedDict
 
 
 def test_comodo_two_axes_and_unlabelled_dims():
     ds = Dataset(coords={"xc": ("xc", np.arange(6) + 0.5, {"axis": "X"}), "xg": ("xg", np.arange(6.0), {"axis": "X", "c_grid_axis_shift": -0.5}),
                          "yc": ("yc", np.arange(4) + 0.5, {"axis": "Y"}), "yp1": ("yp1", np.arange(5.0), {"axis": "Y", "c_grid_axis_shift": -0.5}),
                          "time": ("time", np.arange(3.0)), "k": ("k", np.arange(2.0), {"long_name": "no axis attribute"})})
-    assert M.parse_metadata(ds)["coords"] == {"X": {"center": "xc", "left": "xg"}, "Y": {"center": "yc", "outer": "yp1"}}
-    assert M.parse_metadata(Dataset(coords={"time": ("time", np.arange(3.0))})) == {"coords": {}}
+    assert M.parse_metadata(ds)[1]["coords"] == {"X": {"center": "xc", "left": "xg"}, "Y": {"center": "yc", "outer": "yp1"}}
+    assert M.parse_metadata(Dataset(coords={"time": ("time", np.arange(3.0))}))[1] == {"coords": {}}
 
 
 def test_comodo_malformed_attributes():
@@ -56,7 +56,7 @@ def test_comodo_malformed_attributes():
         M.parse_metadata(odd)
     # a shift that is set but not a number (old xmitgcm) still marks the coordinate as staggered: lengths decide
     listy = Dataset(coords={"a": ("a", np.arange(5.0), {"axis": "X"}), "b": ("b", np.arange(6.0), {"axis": "X", "c_grid_axis_shift": [-0.5]})})
-    assert M.parse_metadata(listy)["coords"]["X"] == {"center": "a", "outer": "b"}
+    assert M.parse_metadata(listy)[1]["coords"]["X"] == {"center": "a", "outer": "b"}
 
 
 def test_grid_from_comodo_metadata_computes(backend):
@@ -120,7 +120,7 @@ def test_sgrid_topology_to_positions(case):
     for key, conv in (("Conventions", "SGRID-0.3"), ("conventions", "CF-1.8, sgrid-0.3")):
         ds = _sgrid(topology, conv, key)
         assert M.is_sgrid(ds)
-        assert M.parse_metadata(ds) == {"coords": want} == M.parse_sgrid(ds)
+        assert M.parse_metadata(ds)[1] == {"coords": want} == M.parse_sgrid(ds)[1]
     assert {ax: dict(a.coords) for ax, a in Grid(_sgrid(topology)).axes.items()} == want
 
 

@@ -94,7 +94,7 @@ class Grid:
             # explicit `coords` need `autoparse_metadata=False` exactly as there)
             from .metadata import parse_metadata
 
-            parsed = parse_metadata(ds)
+            _, parsed = parse_metadata(ds)
             given = {"coords": coords, "fill_value": fill_value, "default_shifts": default_shifts, "padding": padding,
                      "face_connections": face_connections, "metrics": metrics}
             duplicates = [k for k in given if k in parsed and given[k] is not None]
@@ -384,6 +384,9 @@ class Grid:
         as a PRODUCT of registered metrics (a volume = area(Y,X) * thickness(Z)) is laid out with its dims in that
         order.  xarray's order -- first factor's dims, then the new ones: (Y, X, Z) -- made every use a transposed
         5 GB copy: `integrate(T, [X, Y, Z])` took 16 ms.  Same factors in the same order, same values."""
+        if is_xarray(array):  # xarray in -> xarray out, like every other method (the reference hands back `grid._ds`'s own)
+            return to_xarray(self.get_metric(from_xarray(array), axes))
+
         def product(parts):
             if _factors:  # internal: the factors themselves (separable weights are applied stage by stage)
                 return tuple(parts)
@@ -456,7 +459,10 @@ class Grid:
                 shifted.append(name)
         # like the reference (grid.py:710-715) the target position is NOT passed on: each axis moves by
         # its default shift, which is `like`'s position on the usual two-position (center + one edge) axes
-        return self._1d_grid_ufunc_dispatch("interp", array, shifted, fill_value=fill_value, padding=padding)
+        out = self._1d_grid_ufunc_dispatch("interp", array, shifted, fill_value=fill_value, padding=padding)
+        if is_xarray(like) and isinstance(out, DataArray):  # (a registered metric of ours interpolated like an xarray field)
+            out = to_xarray(out)
+        return out
 
     # ---- the hot path: 1-D operators ---------------------------------------------------------
     def _create_1d_grid_ufunc_signatures(self, da, axis, to) -> List[_GridUFuncSignature]:

@@ -12,7 +12,8 @@ import re
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
-__all__ = ["parse_metadata", "parse_comodo", "parse_sgrid", "is_sgrid"]
+__all__ = ["parse_metadata", "parse_comodo", "parse_sgrid", "is_sgrid", "assert_valid_sgrid", "get_sgrid_grid",
+           "get_all_axes", "get_axis_positions_and_coords"]
 
 _SHIFT_OF = {-0.5: "left", 0.5: "right"}
 
@@ -82,9 +83,18 @@ def _comodo_positions(ds, axis: str, dims: List[str]) -> "OrderedDict[str, str]"
     return found
 
 
-def parse_comodo(ds) -> Dict[str, dict]:
-    """`{"coords": {axis: {position: dim}}}` from COMODO attributes; no attributes, no axes"""
-    return {"coords": {axis: _comodo_positions(ds, axis, dims) for axis, dims in _comodo_axes(ds).items()}}
+def _own(ds):
+    """an xarray.Dataset read through the product's lazy view (coordinates and attrs; no data variable is loaded)"""
+    from .labeled import from_xarray, is_xarray
+
+    return from_xarray(ds) if is_xarray(ds) else ds
+
+
+def parse_comodo(ds) -> Tuple[object, Dict[str, dict]]:
+    """`(ds, {"coords": {axis: {position: dim}}})` from COMODO attributes (the dataset is handed back untouched, the
+    return shape of xgcm/metadata_parsers.py:74-97); no attributes, no axes"""
+    own = _own(ds)
+    return ds, {"coords": {axis: _comodo_positions(own, axis, dims) for axis, dims in _comodo_axes(own).items()}}
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -154,12 +164,28 @@ def _sgrid_positions(name: str, topo: dict, axis: str) -> "OrderedDict[str, str]
     return OrderedDict([("center", cell), (_NODE_POSITION[pad], node)])
 
 
-def parse_sgrid(ds) -> Dict[str, dict]:
-    name, topo = _topology(ds)
-    return {"coords": {axis: _sgrid_positions(name, topo, axis) for axis in _sgrid_axes(name, topo)}}
+def parse_sgrid(ds) -> Tuple[object, Dict[str, dict]]:
+    name, topo = _topology(_own(ds))
+    return ds, {"coords": {axis: _sgrid_positions(name, topo, axis) for axis in _sgrid_axes(name, topo)}}
 
 
-def parse_metadata(ds) -> Dict[str, dict]:
-    """Grid kwargs a dataset's metadata provides: SGRID when the conventions attribute says so, COMODO otherwise
-    (xgcm/metadata_parsers.py:26-45)"""
+def parse_metadata(ds) -> Tuple[object, Dict[str, dict]]:
+    """`(ds, grid kwargs)` a dataset's metadata provides: SGRID when the conventions attribute says so, COMODO otherwise
+    (xgcm/metadata_parsers.py:4-45)"""
     return parse_sgrid(ds) if is_sgrid(ds) else parse_comodo(ds)
+
+
+# the SGRID helpers under the names of xgcm/sgrid.py (:6, :29, :53, :88)
+assert_valid_sgrid = is_sgrid
+
+
+def get_sgrid_grid(ds) -> str:
+    return _topology(_own(ds))[0]
+
+
+def get_all_axes(ds):
+    return dict.fromkeys(_sgrid_axes(*_topology(_own(ds)))).keys()
+
+
+def get_axis_positions_and_coords(ds, axis_name: str) -> "OrderedDict[str, str]":
+    return _sgrid_positions(*_topology(_own(ds)), axis_name)

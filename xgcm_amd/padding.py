@@ -26,7 +26,7 @@ import numpy as np
 
 from . import device as _dev
 from . import halo_map as _hm
-from .labeled import DataArray, _is_tensor
+from .labeled import DataArray, _is_tensor, from_xarray, is_xarray, to_xarray
 
 _XGCM_BOUNDARY_KWARG_TO_XARRAY_PAD_KWARG = {"periodic": "wrap", "fill": "constant", "extend": "edge"}
 
@@ -51,6 +51,13 @@ def _strip_all_coords(obj):
 def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding=None, fill_value=None,
         other_component=None, **kwargs):
     """Pad `data` along the given grid axes according to the boundary conditions."""
+    def _xr(v):
+        return any(_xr(x) for x in v.values()) if isinstance(v, dict) else is_xarray(v)
+
+    if _xr(data) or _xr(other_component):  # called directly with xarray objects: xarray out, as the reference's `pad`
+        conv = lambda v: ({k: conv(x) for k, x in v.items()} if isinstance(v, dict) else (from_xarray(v) if is_xarray(v) else v))  # noqa: E731
+        out = pad(conv(data), grid, padding_width, padding, fill_value, None if other_component is None else conv(other_component), **kwargs)
+        return to_xarray(out) if isinstance(out, DataArray) else out
     halo_only = kwargs.pop("_halo_only", None)  # internal: see `halo_cells`
     dry = kwargs.pop("_dry", False)  # internal (xgcm_amd.lazy): validate and build the halo map, move nothing, return None
     if "boundary" in kwargs:
