@@ -228,6 +228,27 @@ def extend(xr):
                          __invert__=lambda self: self._new(~self.data, self.dims)).items():
         setattr(DataArray, name, fn)
     DataArray.__hash__ = None
+
+    def array_ufunc(self, ufunc, method, *inputs, **kw):  # np.sin(da), np.float64(2) * da
+        if method != "__call__":
+            return NotImplemented
+        first = next(x for x in inputs if isinstance(x, DataArray))
+        if sum(isinstance(x, DataArray) for x in inputs) == 2 and len(inputs) == 2:
+            a, b = inputs
+            return a._binary(b, ufunc)
+        raw = [x.data if isinstance(x, DataArray) else x for x in inputs]
+        return first._new(ufunc(*raw, **kw), first.dims)
+
+    DataArray.__array_ufunc__ = array_ufunc
+
+    def da_getattr(self, key):  # `da.time`: coordinates (and dims without one) as attributes
+        if not key.startswith("_"):
+            coords = self.__dict__.get("_coords", {})
+            if key in coords or key in self.__dict__.get("dims", ()):
+                return self[key]
+        raise AttributeError(f"'DataArray' object has no attribute {key!r}")
+
+    DataArray.__getattr__ = da_getattr
     DataArray.T = property(lambda self: self.transpose())
     DataArray.nbytes = property(lambda self: self.data.nbytes)
     DataArray.indexes = property(lambda self: {d: self._coords[d][1] for d in self.dims if d in self._coords})
@@ -304,12 +325,45 @@ def extend(xr):
     def ds_transpose(self, *dims, **kw):
         return _ds_map(self, lambda a: a.transpose(*[d for d in dims if d in a.dims or d is Ellipsis]) if a.ndim > 1 else a)
 
+    def ds_expand_dims(self, dim=None, axis=0, **kw):
+        new = dict(dim if isinstance(dim, dict) else ({} if dim is None else {dim: 1}), **kw)
+
+        def grow(a):
+            for d, n in reversed(list(new.items())):
+                a = a._new(np.repeat(np.expand_dims(a.data, 0), n, axis=0), (d,) + a.dims)
+            return a
+
+        return _ds_map(self, grow, coords_too=False)
+
+    def da_expand_dims(self, dim=None, axis=0, **kw):
+        if isinstance(dim, dict) or kw:  # {name: length}: a new leading dim of that length
+            out = self
+            for d, n in reversed(list(dict(dim or {}, **kw).items())):
+                n = len(n) if np.ndim(n) else int(n)
+                out = out._new(np.repeat(np.expand_dims(out.data, axis), n, axis=axis), out.dims[:axis] + (d,) + out.dims[axis:])
+            return out
+        dims = [dim] if isinstance(dim, str) else list(dim)
+        out = self
+        for d in reversed(dims):
+            out = out._new(np.expand_dims(out.data, axis), out.dims[:axis] + (d,) + out.dims[axis:])
+        return out
+
+    DataArray.expand_dims = da_expand_dims
+
+    def _ds_binary(op):
+        def method(self, other):
+            return _ds_map(self, lambda a: getattr(a, op)(other), coords_too=False)
+        return method
+
+    for _op in ("__mul__", "__rmul__", "__add__", "__radd__", "__sub__", "__truediv__"):
+        setattr(Dataset, _op, _ds_binary(_op))
+
     def ds_items(self):
         return [(k, self[k]) for k in self._vars]
 
     for name, fn in dict(isel=ds_isel, rename=ds_rename, assign_coords=ds_assign_coords, drop_vars=ds_drop_vars, drop=ds_drop_vars,
                          reset_coords=ds_reset_coords, set_coords=ds_set_coords, merge=ds_merge, update=ds_update, assign=ds_assign,
-                         transpose=ds_transpose, items=ds_items, chunk=_needs_dask,
+                         transpose=ds_transpose, items=ds_items, chunk=_needs_dask, expand_dims=ds_expand_dims,
                          compute=lambda self, **k: self, load=lambda self, **k: self,
                          values=lambda self: [self[k] for k in self._vars],
                          __len__=lambda self: len(self._vars)).items():
@@ -382,8 +436,14 @@ def extend(xr):
                 if d not in dims:
                     dims.append(d)
                     sizes[d] = n
+        def one(a):
+            return a._new(np.broadcast_to(xr._aligned(a, dims), tuple(sizes[d] for d in dims)).copy(), tuple(dims))
+
         out = []
         for a in args:
+            if isinstance(a, Dataset):
+                out.append(_ds_map(a, one, coords_too=False))
+                continue
             coords = OrderedDict()
             for b in args:
                 for k, v in b._coords.items():

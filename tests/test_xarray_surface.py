@@ -123,7 +123,7 @@ def test_grid_of_a_dataset_reads_coordinates_and_metrics_only(xr):
     ds.coords["XG"].attrs.update({"axis": "X", "c_grid_axis_shift": -0.5})
     grid = Grid(ds, padding="periodic", metrics={("X",): ["dx"]})  # autoparsed from the attributes
     assert dict(grid.axes["X"].coords) == {"center": "XC", "left": "XG"}
-    inner = grid._ds
+    inner = grid._own_ds  # the library's lazy view (`grid._ds` is the dataset as given)
     assert "theta" in inner and "theta" not in inner.data_vars and "dx" in inner.data_vars
     out = grid.diff(ds["v"], "X")
     np.testing.assert_array_equal(out.values, R.stencil1d("diff", ds["v"].values, 1, 1, 0, "periodic"))

@@ -239,7 +239,7 @@ def _substitute_dummy_axis_names(padding_width, mapping):
 
 
 def _reattach_coords(results, grid, padding_width, out_core_dim_names: Optional[Set[str]] = None, input_args=None):
-    """Coords of grid._ds whose dims all survive, overridden by input coords on non-core dims
+    """Coords of grid._own_ds whose dims all survive, overridden by input coords on non-core dims
     (first input wins).  Reference grid_ufunc.py:1262-1320."""
     out_core_dim_names = out_core_dim_names or set()
     from_inputs: Dict[str, DataArray] = OrderedDict()
@@ -251,7 +251,7 @@ def _reattach_coords(results, grid, padding_width, out_core_dim_names: Optional[
     out = []
     for res in results:
         rdims = set(res.dims)
-        chosen = OrderedDict((k, c) for k, c in grid._ds.coords.items() if all(d in rdims for d in c.dims))
+        chosen = OrderedDict((k, c) for k, c in grid._own_ds.coords.items() if all(d in rdims for d in c.dims))
         for k, c in from_inputs.items():
             if all(d in rdims for d in c.dims):
                 chosen[k] = c
@@ -309,6 +309,10 @@ class GridUFunc:
         self.pad_before_func = kwargs.pop("pad_before_func", True)
         if kwargs:
             raise TypeError(f"Unsupported keyword argument(s) provided: {list(kwargs.keys())}")
+
+    @property
+    def boundary(self):
+        raise AttributeError("Attribute 'boundary' has been renamed to 'padding'. Please use 'padding' instead.")
 
     @property
     def boundary_width(self):
@@ -433,12 +437,17 @@ def apply_as_grid_ufunc(func: Callable, *args, axis=None, grid=None, signature: 
             return {k: _unwrap(v) for k, v in a.items()}
         return from_xarray(a) if is_xarray(a) else a
 
-    was_xr = any(is_xarray(v) for a in args for v in (a.values() if isinstance(a, dict) else (a,)))
+    def _any_xr(seq):
+        return any(is_xarray(v) for a in seq for v in (a.values() if isinstance(a, dict) else (a,)))
+
+    others = other_component if isinstance(other_component, (list, tuple)) else [other_component]
+    was_xr = _any_xr(args) or _any_xr(o for o in others if o is not None)
     if was_xr:
         res = apply_as_grid_ufunc(func, *[_unwrap(a) for a in args], axis=axis, grid=grid, signature=signature,
                                   padding_width=padding_width, padding=padding, fill_value=fill_value, dask=dask,
                                   map_overlap=map_overlap, pad_before_func=pad_before_func,
-                                  other_component=_unwrap(other_component) if other_component is not None else None,
+                                  other_component=([_unwrap(o) for o in other_component] if isinstance(other_component, (list, tuple))
+                                                   else _unwrap(other_component)) if other_component is not None else None,
                                   **kwargs)
         return tuple(to_xarray(r) for r in res) if isinstance(res, tuple) else to_xarray(res)
 

@@ -236,6 +236,8 @@ class DataArray:
 
     # ---- comparisons --------------------------------------------------------------------
     def equals(self, other: "DataArray") -> bool:
+        if is_xarray(other) and type(other).__name__ == "DataArray":
+            other = from_xarray(other)
         if not isinstance(other, DataArray) or self.dims != other.dims or self.shape != other.shape:
             return False
         if not np.array_equal(self.values, other.values, equal_nan=True):

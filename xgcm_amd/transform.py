@@ -158,7 +158,12 @@ def _column_call(kind: str, phi: DataArray, theta: DataArray, target: DataArray,
     return res
 
 
-def _input_handling(kind: str, phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, suffix="", **kwargs):
+def _input_handling(kind: str, args, suffix="", **kwargs):
+    # six positional arguments, unpacked as the reference's wrapper does (transform.py:201-203): a call with fewer is its
+    # ValueError, which test_transform.py:923-947 relies on
+    phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim = args
+    was_xr = any(is_xarray(v) for v in (phi, theta, target_theta_levels))
+    phi, theta, target_theta_levels = (from_xarray(v) if is_xarray(v) else v for v in (phi, theta, target_theta_levels))
     _check_labelled(("phi", phi), ("theta", theta), ("target_theta_levels", target_theta_levels))
     res = _column_call(kind, phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs)
     coords = _merge_coords(res.dims, (phi, phi_dim), (theta, theta_dim), (target_theta_levels, None))
@@ -168,17 +173,19 @@ def _input_handling(kind: str, phi, theta, target_theta_levels, phi_dim, theta_d
         coords.pop(target_dim, None)
         coords[target_dim] = DataArray((levels[1:] + levels[:-1]) / 2, (target_dim,))
     res = DataArray(res.data, res.dims, coords=coords, name=(phi.name + suffix) if phi.name else None)
-    return res
+    return to_xarray(res) if was_xr else res
 
 
-def linear_interpolation(phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs):
-    """`phi` on the `target_theta_levels` isosurfaces of `theta` (reference transform.py:237-253)."""
-    return _input_handling("linear", phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs)
+def linear_interpolation(*args, **kwargs):
+    """`linear_interpolation(phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs)`: `phi` on the
+    `target_theta_levels` isosurfaces of `theta` (reference transform.py:233-250)."""
+    return _input_handling("linear", args, **kwargs)
 
 
-def conservative_interpolation(phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs):
-    """Extensive `phi` binned between `target_theta_levels` (reference transform.py:256-281)."""
-    return _input_handling("conservative", phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs)
+def conservative_interpolation(*args, **kwargs):
+    """`conservative_interpolation(phi, theta, target_theta_levels, phi_dim, theta_dim, target_dim, **kwargs)`: extensive
+    `phi` binned between `target_theta_levels` (reference transform.py:252-276)."""
+    return _input_handling("conservative", args, **kwargs)
 
 
 # ------------------------------------------------------------------------------------------
@@ -219,7 +226,7 @@ def transform(grid, axis_name, da, target, target_data=None, target_dim=None, me
 
     def parse_target(target, target_dim, target_data_dim, target_data):
         if target_data is None:
-            target_data = grid._ds[target_data_dim]
+            target_data = grid._own_ds[target_data_dim]
         if target_dim is None:
             if isinstance(target, DataArray):
                 if len(target.dims) == 1:
