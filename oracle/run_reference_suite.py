@@ -129,6 +129,29 @@ elif BACKEND == "oracle-double":
 elif BACKEND != "hip":
     raise RuntimeError(BACKEND)
 
+if {fused!r}:
+    # every Grid of the suite built with fuse=True: diff / interp / min / max / derivative return deferred results
+    # (xgcm_amd.lazy) and the suite's assertions force them -- a differential test of the deferred mode against the
+    # reference's expectations.  `xarray.testing.*` is where a deferred result meets an xarray object: there (only)
+    # `.to_xarray()` is applied, the documented hand-over (DESIGN 1a)
+    import xgcm_amd.grid as _g
+    import xgcm_amd.lazy as _lz
+
+    _init = _g.Grid.__init__
+
+    def _fused_init(self, *a, **k):
+        k.setdefault("fuse", True)
+        _init(self, *a, **k)
+
+    _g.Grid.__init__ = _fused_init
+    for _name in ("assert_allclose", "assert_equal", "assert_identical"):
+        def _wrap(f):
+            def g(a, b, *rest, **kw):
+                a, b = (v.to_xarray() if isinstance(v, _lz.LazyArray) else v for v in (a, b))
+                return f(a, b, *rest, **kw)
+            return g
+        setattr(xr.testing, _name, _wrap(getattr(xr.testing, _name)))
+
 _results = {{}}
 
 
@@ -158,7 +181,7 @@ def pytest_sessionfinish(session, exitstatus):
 '''
 
 
-def build_scratch(backend, report):
+def build_scratch(backend, report, fused=False):
     scratch = tempfile.mkdtemp(prefix="xgcm_refsuite_")
     pkg = os.path.join(scratch, "xgcm")
     os.makedirs(pkg)
@@ -170,18 +193,18 @@ def build_scratch(backend, report):
             f.write(SHIM.format(name=name, source=source))
     os.symlink(os.path.join(REF, "xgcm", "test"), os.path.join(pkg, "test"))
     with open(os.path.join(scratch, "conftest.py"), "w") as f:
-        f.write(CONFTEST.format(root=ROOT, backend=backend, report=report))
+        f.write(CONFTEST.format(root=ROOT, backend=backend, report=report, fused=bool(fused)))
     return scratch
 
 
-def run(backend="host-abi", report=None, extra=(), quiet=True):
+def run(backend="host-abi", report=None, extra=(), quiet=True, fused=False):
     if not os.path.isdir(os.path.join(REF, "xgcm", "test")):
         raise FileNotFoundError(f"{REF}/xgcm/test: the reference is not on this box")
     own_report = report is None
     if own_report:
         fd, report = tempfile.mkstemp(suffix=".json", prefix="xgcm_refsuite_")
         os.close(fd)
-    scratch = build_scratch(backend, report)
+    scratch = build_scratch(backend, report, fused)
     try:
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=scratch + os.pathsep + ROOT)
         cmd = [sys.executable, "-m", "pytest", "-p", "no:cacheprovider", "--rootdir", scratch, "-c", os.devnull,
@@ -222,8 +245,8 @@ def committed_report():
     out = {"what": "outcomes of the reference's own test suite (xgcm/test/*.py, unmodified, read in place) run against xgcm_amd "
                    "by oracle/run_reference_suite.py; pinned modulo the xarray stand-in (oracle/xr_min.py + xr_suite.py)",
            "backends": {}}
-    for backend in ("oracle-double", "host-abi"):
-        results, _ = run(backend)
+    for backend in ("oracle-double", "oracle-double+fused", "host-abi"):
+        results, _ = run(backend.split("+")[0], fused=backend.endswith("+fused"))
         failed = {k: v.get("why", "") for k, v in results.items() if v["outcome"] in ("failed", "collect-error")}
         skipped = {}
         for v in results.values():
@@ -231,7 +254,7 @@ def committed_report():
                 why = v.get("why", "").replace("Skipped: ", "")[:60]
                 skipped[why] = skipped.get(why, 0) + 1
         out["backends"][backend] = {"summary": summarize(results), "skip_reasons": skipped,
-                                    "failed": dict(sorted(failed.items())) if backend == "oracle-double" else
+                                    "failed": dict(sorted(failed.items())) if backend != "host-abi" else
                                     {"count": len(failed), "all_outside_the_host_build": all(HOST_BUILD_GAP in w or "XgcmHipError" in w for w in failed.values())},
                                     "functions": by_function(results)}
     return out
@@ -242,6 +265,7 @@ def main():
     ap.add_argument("--backend", default="host-abi", choices=["host-abi", "oracle-double", "hip"])
     ap.add_argument("--report", default=None)
     ap.add_argument("--show", action="store_true", help="pytest's own output")
+    ap.add_argument("--fused", action="store_true", help="every Grid with fuse=True (deferred results, xgcm_amd.lazy)")
     ap.add_argument("--write-report", action="store_true", help="run both CPU backends, rewrite tests/golden/reference_suite_report.json")
     args, extra = ap.parse_known_args()
     if args.write_report:
@@ -250,7 +274,7 @@ def main():
             json.dump(rep, f, indent=1, sort_keys=True)
         print(json.dumps({b: v["summary"] for b, v in rep["backends"].items()}))
         return
-    results, proc = run(args.backend, args.report, extra, quiet=not args.show)
+    results, proc = run(args.backend, args.report, extra, quiet=not args.show, fused=args.fused)
     if not args.show:
         print(proc.stdout[-3000:])
         print(proc.stderr[-2000:], file=sys.stderr)

@@ -25,8 +25,9 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(H.REF, "xgcm", "t
 
 @pytest.fixture(scope="module")
 def outcomes():
-    with ThreadPoolExecutor(2) as pool:
-        runs = {b: pool.submit(H.run, b) for b in ("oracle-double", "host-abi")}
+    with ThreadPoolExecutor(3) as pool:
+        runs = {b: pool.submit(H.run, b.split("+")[0], fused=b.endswith("+fused"))
+                for b in ("oracle-double", "oracle-double+fused", "host-abi")}
         return {b: f.result()[0] for b, f in runs.items()}
 
 
@@ -44,6 +45,17 @@ def test_reference_suite_on_the_oracle_double(outcomes, committed):
     _no_function_lost_a_pass(H.by_function(res), committed["oracle-double"]["functions"])
     why = {v.get("why", "") for v in res.values() if v["outcome"] == "skipped"}
     assert all("needs-dask" in w or "skip" in w.lower() for w in why), why
+
+
+def test_reference_suite_with_deferred_results(outcomes, committed):
+    """Every Grid of the suite built with `fuse=True`: diff / interp / min / max / derivative hand back deferred results
+    (xgcm_amd.lazy) and the reference's assertions force them -- the deferred mode against the reference's own
+    expectations.  `xarray.testing.*` applies `.to_xarray()` to a deferred operand (the documented hand-over), nothing else
+    changes."""
+    res = outcomes["oracle-double+fused"]
+    bad = {k: v.get("why") for k, v in res.items() if v["outcome"] in ("failed", "collect-error")}
+    assert not bad, f"{len(bad)} of the reference's tests fail with deferred results: {dict(list(bad.items())[:5])}"
+    _no_function_lost_a_pass(H.by_function(res), committed["oracle-double+fused"]["functions"])
 
 
 def test_reference_suite_on_the_host_build_of_the_c_abi(outcomes, committed):

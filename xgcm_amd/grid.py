@@ -582,7 +582,9 @@ class Grid:
                 array = array / post_divide
         if was_xr and isinstance(array, _lazy.LazyArray) and array.is_deferred:
             # deferred: converting now would evaluate it.  The result stays a LazyArray -- it combines with xarray objects
-            # through `+ - * /` like the arrays it came from -- and `.to_xarray()` hands over the xarray.DataArray
+            # through `+ - * /` like the arrays it came from -- and `.compute()` / `.to_xarray()` hand over the
+            # xarray.DataArray, as `.compute()` of a dask-backed result does there
+            array._xr = True
             return array
         return to_xarray(array) if was_xr else array
 

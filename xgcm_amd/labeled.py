@@ -42,6 +42,12 @@ class DataArray:
     """N-D array with named dimensions and coordinates (subset of xarray.DataArray)."""
 
     __slots__ = ("data", "dims", "coords", "name", "attrs")
+    # numpy interop as xarray's: `np.asarray(da)` / `np.testing.assert_allclose(da, ...)` see the values (HBM data comes
+    # to the host for that); `ndarray OP da` is left to the reflected operators below, not broadcast over an object array
+    __array_ufunc__ = None
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.values, dtype=dtype)
 
     def __init__(self, data, dims: Optional[Sequence[str]] = None, coords=None, name: Optional[str] = None,
                  attrs: Optional[dict] = None):
@@ -297,6 +303,24 @@ class DataArray:
     def __radd__(self, o): return self._binary(o, "add", True)
     def __sub__(self, o): return self._binary(o, "sub")
     def __rsub__(self, o): return self._binary(o, "sub", True)
+
+    def __neg__(self):
+        return self._binary(-1.0 if np.dtype(self.dtype).kind == "f" else -1, "mul", True)
+
+    def __abs__(self):
+        data = self.data
+        return self._replace(data=data.abs() if _is_tensor(data) else np.abs(data))
+
+    def __getattr__(self, key: str):
+        """`da.time`: coordinates as attributes, as xarray allows"""
+        if not key.startswith("_"):
+            try:
+                coords = object.__getattribute__(self, "coords")
+            except AttributeError:
+                coords = None
+            if coords and key in coords:
+                return coords[key]
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {key!r}")
 
     def sum(self, dim=None, skipna: Optional[bool] = None, keep_attrs: bool = False, **kwargs) -> "DataArray":
         """Sum over `dim` (str or list); float default skips NaN like xarray."""

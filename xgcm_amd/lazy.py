@@ -93,7 +93,7 @@ def _unforced(x, cls=None):
 def plain(x):
     """a LazyArray as an ordinary DataArray (computing it), dict components likewise; anything else unchanged"""
     if isinstance(x, LazyArray):
-        return x.compute()
+        return x._plain()
     if isinstance(x, dict):
         return {k: plain(v) for k, v in x.items()}
     return x
@@ -123,13 +123,14 @@ class LazyArray(DataArray):
     """A DataArray whose data is a deferred operation (see the module docstring).  Metadata never computes; `.data`,
     `.values` and everything built on them do, once, and the value is shared by every relabelled copy."""
 
-    __slots__ = ("_node", "_lshape", "_ldtype", "_host")
+    __slots__ = ("_node", "_lshape", "_ldtype", "_host", "_xr")
 
     def __init__(self, node: Node, dims, shape, dtype, host: bool, coords=None, name=None, attrs=None):
         self._node = node
         self._lshape = tuple(int(s) for s in shape)
         self._ldtype = np.dtype(dtype)
         self._host = bool(host)
+        self._xr = False  # results of xarray inputs hand an xarray.DataArray over when computed (set by Grid, kept by + - * /)
         self.dims = tuple(dims)
         self.name = name
         self.attrs = dict(attrs) if attrs else {}
@@ -150,8 +151,15 @@ class LazyArray(DataArray):
     def is_deferred(self) -> bool:
         return self._node.value is None
 
-    def compute(self) -> DataArray:
-        """the same labelled array with its data evaluated (an ordinary DataArray)"""
+    def compute(self):
+        """the same labelled array with its data evaluated: an ordinary DataArray -- an `xarray.DataArray` when the
+        chain started from xarray objects, which is what `.compute()` of a dask-backed result gives there"""
+        out = self._plain()
+        return _labeled.to_xarray(out) if self._xr else out
+
+    load = compute
+
+    def _plain(self) -> DataArray:
         out = DataArray.__new__(DataArray)
         out.data = self.data
         out.dims, out.name, out.attrs, out.coords = self.dims, self.name, dict(self.attrs), OrderedDict(self.coords)
@@ -178,9 +186,10 @@ class LazyArray(DataArray):
 
     def _replace(self, data=None, dims=None, coords=None, name="__keep__"):
         if data is not None or (dims is not None and len(tuple(dims)) != len(self.dims)):
-            return self.compute()._replace(data=data, dims=dims, coords=coords, name=name)
+            return self._plain()._replace(data=data, dims=dims, coords=coords, name=name)
         out = LazyArray.__new__(LazyArray)
         out._node, out._lshape, out._ldtype, out._host = self._node, self._lshape, self._ldtype, self._host
+        out._xr = self._xr
         out.dims = self.dims if dims is None else tuple(dims)  # (a rename: same cells, same order)
         out.name = self.name if name == "__keep__" else name
         out.attrs = dict(self.attrs)
@@ -189,7 +198,7 @@ class LazyArray(DataArray):
 
     def copy(self, deep: bool = False, data=None):
         if deep or data is not None:
-            return self.compute().copy(deep=deep, data=data)
+            return self._plain().copy(deep=deep, data=data)
         return self._replace()
 
     def to_xarray(self):
@@ -199,12 +208,19 @@ class LazyArray(DataArray):
 
     # ---- arithmetic stays deferred while an operand is ------------------------------------
     def _binary(self, other, op: str, reflexive: bool = False, dims_order: Optional[Sequence[str]] = None):
+        xr_out = self._xr or getattr(other, "_xr", False)
         if _labeled.is_xarray(other):
-            other = _labeled.from_xarray(other)
+            other, xr_out = _labeled.from_xarray(other), True
         res = defer_binary(self, other, op, reflexive, dims_order)
         if res is not None:
+            res._xr = xr_out
             return res
-        return DataArray._binary(self.compute(), plain(other), op, reflexive, dims_order)
+        res = DataArray._binary(self._plain(), plain(other), op, reflexive, dims_order)
+        return _labeled.to_xarray(res) if xr_out else res
+
+    def __abs__(self):
+        out = DataArray.__abs__(self._plain())
+        return _labeled.to_xarray(out) if self._xr else out
 
     def __repr__(self) -> str:
         state = "deferred" if self.is_deferred else ("HBM" if self.is_device else "host")
