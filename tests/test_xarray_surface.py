@@ -174,3 +174,95 @@ def test_non_native_xarray_data_and_deferred_results_on_the_bridge(xr):
     want = R.stencil1d("diff", ds["v"].values, 1, 1, 0, "periodic") / ds["dx"].values[None]
     np.testing.assert_array_equal(back.values, want)
     assert lazy.STATS.get("stencil_m_out") == 1       # ... and the division rode in the stencil's launch
+
+
+# ---- round 5: what running the reference's own test suite against this package asked for (oracle/run_reference_suite.py) ----
+def _metric_grid(xr, **kw):
+    ds = _dataset(xr)
+    return ds, Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", metrics={("X",): ["dx"]},
+                    autoparse_metadata=False, **kw)
+
+
+def test_grid_keeps_the_dataset_as_given_and_its_metrics_in_that_container(xr):
+    """the reference's tests read `grid._ds.<coord>` (69 times) and `grid._metrics[...]`: an xarray.Dataset stays one"""
+    ds, grid = _metric_grid(xr)
+    assert grid._ds is ds and isinstance(grid._own_ds, L.Dataset)
+    [m] = grid._metrics[frozenset(["X"])]
+    assert L.is_xarray(m) and m.dims == ("XC",)
+    np.testing.assert_array_equal(m.values, ds["dx"].values)
+    assert isinstance(grid._own_metrics[frozenset(["X"])][0], L.DataArray)
+    assert grid._own_metrics[frozenset(["X"])][0].equals(m)  # `.equals` takes the xarray twin
+
+
+def test_get_metric_interp_like_and_pad_hand_back_xarray_for_xarray_inputs(xr):
+    """test_grid.py:331-350 multiplies a field by `grid.get_metric(...)`; test_padding.py calls `pad` directly"""
+    from xgcm_amd.padding import pad
+
+    ds, grid = _metric_grid(xr)
+    w = grid.get_metric(ds["v"], ("X",))
+    assert L.is_xarray(w) and w.dims == ("XC",)
+    own = grid.get_metric(L.from_xarray(ds["v"]), ("X",))
+    assert isinstance(own, L.DataArray)
+    like = grid.interp_like(grid._own_metrics[frozenset(["X"])][0], grid.diff(ds["v"], "X"))
+    assert L.is_xarray(like) and like.dims == ("XG",)
+    padded = pad(ds["v"], grid, {"X": (2, 1)}, padding="periodic")
+    assert L.is_xarray(padded) and padded.dims == ("time", "XC") and not list(padded.coords)
+    np.testing.assert_array_equal(padded.values, np.pad(ds["v"].values, ((0, 0), (2, 1)), mode="wrap"))
+
+
+def test_deferred_results_of_xarray_inputs_compute_to_xarray(xr):
+    ds, grid = _metric_grid(xr, fuse=True)
+    eager = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", autoparse_metadata=False)
+    lazy = grid.diff(ds["v"], "X")
+    assert not L.is_xarray(lazy) and lazy.is_deferred
+    twice = lazy * 2.0
+    assert twice.is_deferred
+    out = twice.compute()
+    assert L.is_xarray(out) and out.dims == ("time", "XG")
+    np.testing.assert_array_equal(out.values, eager.diff(ds["v"], "X").values * 2.0)
+    np.testing.assert_array_equal(np.asarray(lazy), eager.diff(ds["v"], "X").values)  # numpy sees the values
+    assert L.is_xarray(abs(lazy)) and L.is_xarray(lazy.load())
+    own = Grid(L.from_xarray(ds), coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", autoparse_metadata=False, fuse=True)
+    assert isinstance(own.diff(own._ds["v"], "X").compute(), L.DataArray)  # the library's arrays stay the library's
+
+
+def test_labelled_arrays_meet_numpy_like_xarray_does(backend):
+    a = L.DataArray(np.array([[1.0, -2.0], [0.0, 4.0]]), ("t", "x"), coords={"t": np.array([10.0, 20.0])}, name="a")
+    np.testing.assert_array_equal(np.asarray(a), a.values)
+    np.testing.assert_allclose(a, a.values)
+    np.testing.assert_array_equal(abs(a).values, np.abs(a.values))
+    neg = -a
+    np.testing.assert_array_equal(neg.values, -a.values)
+    assert np.signbit(neg.values[1, 0])  # -(0.0) is -0.0, as numpy's negation
+    np.testing.assert_array_equal((np.array([1.0, 2.0]) * a).values, a.values * np.array([1.0, 2.0]))  # reflected, not an object array
+    np.testing.assert_array_equal(a.t.values, [10.0, 20.0])
+    with pytest.raises(AttributeError):
+        a.nothing_of_that_name
+
+
+def test_reference_names_of_helpers_and_return_shapes():
+    from xgcm_amd import as_grid_ufunc, metadata
+    from xgcm_amd.grid import _select_grid_ufunc
+    from xgcm_amd.grid_ufunc import _GridUFuncSignature
+    from xgcm_amd.labeled import Dataset
+    from xgcm_amd.transform import linear_interpolation
+
+    ds = Dataset(coords={"xc": ("xc", np.arange(4.0), {"axis": "X"}), "xg": ("xg", np.arange(4.0) - 0.5, {"axis": "X", "c_grid_axis_shift": -0.5})})
+    same, kwargs = metadata.parse_comodo(ds)  # (ds, grid_kwargs): xgcm/metadata_parsers.py:74-97
+    assert same is ds and kwargs == {"coords": {"X": {"center": "xc", "left": "xg"}}}
+    assert metadata.parse_metadata(ds)[1] == kwargs and not metadata.assert_valid_sgrid(ds)
+    with pytest.raises(ValueError, match="Could not find identify SGRID grid"):
+        metadata.get_sgrid_grid(ds)
+
+    class Namespace:  # a class used like the gridops module (xgcm/test/test_grid_ufunc.py:1368-1397)
+        @staticmethod
+        @as_grid_ufunc(signature="(X:center)->(X:left)")
+        def diff_center_to_left(a):
+            return a
+
+    found, _ = _select_grid_ufunc("diff", _GridUFuncSignature.from_string("(Y:center)->(Y:left)"), module=Namespace)
+    assert found is Namespace.diff_center_to_left
+    with pytest.raises(AttributeError, match="Attribute 'boundary' has been renamed to 'padding'"):
+        found.boundary
+    with pytest.raises(ValueError):  # five positional arguments: the reference's six-way unpack (xgcm/transform.py:201-203)
+        linear_interpolation(1, 2, 3, "z", "z")

@@ -285,11 +285,18 @@ class DataArray:
             coords = OrderedDict(self.coords)
             for k, v in other.coords.items():
                 coords.setdefault(k, v)
+        elif (isinstance(other, np.ndarray) or _is_tensor(other)) and other.ndim <= self.ndim:
+            # an unlabelled array: numpy's positional broadcasting against this array's shape, as in xarray
+            shape = (1,) * (self.ndim - other.ndim) + tuple(int(n) for n in other.shape)
+            if any(m not in (1, n) for m, n in zip(shape, self.shape)):
+                raise ValueError(f"operands could not be broadcast together with shapes {self.shape} {tuple(other.shape)}")
+            a, b, dims = self.data, other.reshape(shape), self.dims
+            coords = OrderedDict(self.coords)
         else:
             return NotImplemented
         if reflexive:
             a, b = b, a
-        host = not (_is_tensor(self.data) or (isinstance(other, DataArray) and _is_tensor(other.data)))
+        host = not (_is_tensor(self.data) or _is_tensor(other) or (isinstance(other, DataArray) and _is_tensor(other.data)))
         res = _dev.binary(op, a, b)
         if host:
             res = _dev.tohost(res)
