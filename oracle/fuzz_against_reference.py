@@ -1,0 +1,393 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of `xgcm_amd.Grid` against the REFERENCE's own `Grid`, live, call by call.
+
+TEST INFRASTRUCTURE -- build container only (imports /root/reference at run time), never shipped, never on the GPU box.
+
+Both stacks run in ONE process over the same stand-in `xarray` (`oracle/xr_min.py` loaded under that name): the reference's
+`xgcm/grid.py`, `axis.py`, `grid_ufunc.py`, `padding.py`, `gridops.py`, `metrics.py` imported unmodified as package `xgcm`,
+and `xgcm_amd` with its device served by a CPU double.  A seeded generator draws a grid (1-3 axes, 2-3 positions per axis,
+random lengths, boundary conditions and fill values as strings / per-axis dicts / unset, metrics at some positions), a
+handful of variables (random positions, dim orders, an extra record dim, NaNs, float32 / integer fields now and then) and
+random calls -- diff / interp / min / max / cumsum / derivative / integrate / average / cumint / interp_like / get_metric
+with random `axis`, `to`, `padding`, `fill_value`, `metric_weighted`, `reverse`, `skipna`, some of them invalid -- and every
+call is made on both grids.  They must agree on: raising or not; the exception type (the message too, reported separately);
+result dims, name, dtype, coordinate names and values; the values bit for bit, except contiguous-axis scans and reductions
+of the product, which are compared to 1e-12.
+
+    python oracle/fuzz_against_reference.py --cases 200 --seed 1 [--backend oracle-double|host-abi] [-v]
+
+`tests/test_reference_suite_live.py::test_differential_fuzz_against_the_reference` runs a fixed budget of it on every CPU run.
+What it pins is the reference's LOGIC under the stand-in's container semantics ("pinned modulo the stand-in").
+"""
+import argparse
+import importlib.util
+import itertools
+import json
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("XGCM_REFERENCE", "/root/reference")
+
+POSITIONS = ("center", "left", "right", "inner", "outer")
+LENGTH = {"center": 0, "left": 0, "right": 0, "inner": -1, "outer": +1}
+MODES = ("periodic", "fill", "extend")
+
+
+class _MP:
+    def setattr(self, target, name=None, value=None, raising=True):
+        setattr(target, name, value)
+
+    def setitem(self, mapping, key, value):
+        mapping[key] = value
+
+
+def load_both(backend="oracle-double"):
+    """(xarray stand-in, reference Grid class, xgcm_amd Grid class)"""
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    if "xarray" not in sys.modules or not getattr(sys.modules["xarray"], "_is_xr_min", False):
+        spec = importlib.util.spec_from_file_location("xarray", os.path.join(HERE, "xr_min.py"))
+        xr = importlib.util.module_from_spec(spec)
+        sys.modules["xarray"] = xr
+        spec.loader.exec_module(xr)
+        xr._is_xr_min = True
+        dask = types.ModuleType("dask")
+        dask_array = types.ModuleType("dask.array")
+        dask_array.Array = type("Array", (), {})
+        dask.array = dask_array
+        sys.modules.setdefault("dask", dask)
+        sys.modules.setdefault("dask.array", dask_array)
+    xr = sys.modules["xarray"]
+    if REF not in sys.path:
+        sys.path.append(REF)  # (after the repo: nothing of the repo is called `xgcm`)
+    import xgcm.grid as refgrid  # the reference, unmodified
+
+    import xgcm_amd
+
+    if backend == "host-abi":
+        import host_abi_device
+
+        host_abi_device.install(_MP())
+    elif backend == "oracle-double":
+        from oracle import fake_device
+
+        fake_device.install(_MP())
+    elif backend != "hip":
+        raise ValueError(backend)
+    return xr, refgrid.Grid, xgcm_amd.Grid
+
+
+# ---- the generator -------------------------------------------------------------------------------------------------------
+def draw_grid(rng):
+    axes = sorted(rng.choice(["X", "Y", "Z"], size=rng.integers(1, 4), replace=False).tolist())
+    coords, positions, sizes = {}, {}, {}
+    for ax in axes:
+        n = int(rng.integers(3, 8))
+        extra = rng.choice(POSITIONS[1:], size=rng.integers(1, 3), replace=False).tolist()
+        if "inner" in extra and "outer" in extra and rng.random() < 0.5:
+            extra.remove("inner")
+        pos = {"center": f"{ax.lower()}_c"}
+        for p in extra:
+            pos[p] = f"{ax.lower()}_{p[0]}"
+        if rng.random() < 0.3:  # positions listed in another order: the default shift follows the table, not the listing
+            pos = dict(reversed(list(pos.items())))
+        positions[ax] = pos
+        for p, dim in pos.items():
+            m = n + LENGTH[p]
+            sizes[dim] = m
+            coords[dim] = (dim, np.arange(m) + {"center": 0.5, "left": 0.0, "right": 1.0, "inner": 1.0, "outer": 0.0}[p])
+    sizes["t"] = 2
+    coords["t"] = ("t", np.array([0.0, 10.0]))
+    coords["label"] = ("t", np.array([3, 4]))
+    kw = {"coords": positions, "autoparse_metadata": False}
+    style = rng.integers(0, 4) if rng.random() < 0.5 else 0
+    if style == 0:
+        kw["padding"] = str(rng.choice(MODES))
+    elif style == 1:
+        kw["padding"] = {ax: str(rng.choice(MODES)) for ax in axes if rng.random() < 0.8}
+    elif style == 2:
+        kw["padding"] = {ax: str(rng.choice(MODES)) for ax in axes}
+        kw["fill_value"] = {ax: float(rng.integers(-3, 4)) for ax in axes if rng.random() < 0.6}
+    if style == 3 and rng.random() < 0.5:
+        kw["fill_value"] = float(rng.integers(1, 5))
+    return axes, positions, sizes, coords, kw
+
+
+def draw_variables(rng, axes, positions, sizes):
+    variables, where = {}, {}
+    for i in range(int(rng.integers(3, 6))):
+        used = [ax for ax in axes if rng.random() < 0.8] or [axes[0]]
+        pos = {ax: str(rng.choice(list(positions[ax]))) for ax in used}
+        dims = [positions[ax][pos[ax]] for ax in used]
+        if rng.random() < 0.5:
+            dims = ["t"] + dims
+        if rng.random() < 0.3:
+            dims = list(rng.permutation(dims))
+        shape = tuple(sizes[d] for d in dims)
+        a = rng.standard_normal(shape)
+        kind = rng.random()
+        if kind < 0.25:
+            a.reshape(-1)[rng.integers(0, a.size, size=max(1, a.size // 7))] = np.nan
+        elif kind < 0.35:
+            a = a.astype(np.float32)
+        elif kind < 0.42:
+            a = rng.integers(-9, 9, size=shape).astype(np.int64)
+        name = f"v{i}"
+        variables[name] = (tuple(dims), a)
+        where[name] = pos
+    return variables, where
+
+
+def draw_metrics(rng, axes, positions, sizes, variables):
+    metrics = {}
+    for r in (1, 2, 3):
+        for combo in itertools.combinations(axes, r):
+            if rng.random() > (0.85 if r == 1 else 0.35):
+                continue
+            names = []
+            for k in range(int(rng.integers(1, 4))):
+                dims = [positions[ax][str(rng.choice(list(positions[ax])))] for ax in combo]
+                others = [ax for ax in axes if ax not in combo and rng.random() < 0.3]
+                dims += [positions[ax]["center"] for ax in others]
+                name = "m_" + "".join(combo).lower() + f"_{k}"
+                variables[name] = (tuple(dims), rng.random(tuple(sizes[d] for d in dims)) + 0.5)
+                names.append(name)
+            metrics[combo] = names
+    return metrics
+
+
+def _pick(rng, seq):
+    return seq[int(rng.integers(0, len(seq)))]
+
+
+def _axis_arg(rng, axes, present, allow_absent=0.05):
+    pool = present if (present and rng.random() > allow_absent) else axes
+    k = int(rng.integers(1, min(len(pool), 3) + 1))
+    picked = rng.choice(pool, size=k, replace=False).tolist()
+    if k == 1 and rng.random() < 0.6:
+        return picked[0]
+    return picked
+
+
+def _to_arg(rng, positions, where_var, ax):
+    """a target position: mostly one the reference has a ufunc for from the field's position on that axis, sometimes any"""
+    here = where_var.get(ax)
+    fits = [p for p in positions[ax] if p != here and (here == "center" or p == "center")]
+    if fits and rng.random() < 0.85:
+        return _pick(rng, fits)
+    return str(rng.choice(POSITIONS))
+
+
+def _padding_arg(rng, axes, kw):
+    r = rng.random()
+    if r < 0.45:
+        return
+    if r < 0.75:
+        kw["padding"] = str(rng.choice(MODES))
+    else:
+        kw["padding"] = {ax: str(rng.choice(MODES)) for ax in axes if rng.random() < 0.7}
+    r = rng.random()
+    if r < 0.25:
+        kw["fill_value"] = float(rng.integers(-2, 3)) + 0.5
+    elif r < 0.4:
+        kw["fill_value"] = {ax: float(rng.integers(-2, 3)) for ax in axes if rng.random() < 0.7}
+
+
+def draw_call(rng, axes, positions, variables, where, metrics):
+    fields = [v for v in variables if v.startswith("v")]
+    var = str(rng.choice(fields))
+    present = list(where[var])
+    method = str(rng.choice(["diff", "interp", "min", "max", "diff", "interp", "cumsum", "cumsum", "derivative", "integrate",
+                             "average", "cumint", "interp_like", "get_metric"]))
+    kw, args = {}, []
+    with_metric = [ax for ax in present if (ax,) in metrics]
+    if method in ("derivative", "integrate", "average", "cumint") and with_metric and rng.random() < 0.85:
+        present = with_metric
+    if method in ("diff", "interp", "min", "max"):
+        axis = _axis_arg(rng, axes, present)
+        args = [axis]
+        _padding_arg(rng, axes, kw)
+        r = rng.random()
+        names = [axis] if isinstance(axis, str) else axis
+        if r < 0.3 and len(names) == 1:
+            kw["to"] = _to_arg(rng, positions, where[var], names[0])
+        elif r < 0.45:
+            kw["to"] = {ax: _to_arg(rng, positions, where[var], ax) for ax in names}
+        if metrics and rng.random() < 0.25:
+            kw["metric_weighted"] = _pick(rng, list(metrics)) if rng.random() < 0.7 else names[0]
+    elif method == "cumsum":
+        args = [_axis_arg(rng, axes, present)]
+        _padding_arg(rng, axes, kw)
+        names = [args[0]] if isinstance(args[0], str) else args[0]
+        if rng.random() < 0.5:
+            kw["to"] = {ax: _to_arg(rng, positions, where[var], ax) for ax in names} if (len(names) > 1 or rng.random() < 0.3) \
+                else _to_arg(rng, positions, where[var], names[0])
+        if rng.random() < 0.4:
+            kw["reverse"] = bool(rng.random() < 0.7) if rng.random() < 0.7 else {ax: bool(rng.random() < 0.5) for ax in names}
+        if metrics and rng.random() < 0.1:
+            kw["metric_weighted"] = _pick(rng, list(metrics))
+    elif method == "derivative":
+        args = [str(rng.choice(present if rng.random() < 0.95 else axes))]
+        _padding_arg(rng, axes, kw)
+    elif method in ("integrate", "average"):
+        args = [_axis_arg(rng, axes, present)]
+        if rng.random() < 0.2:
+            kw["skipna"] = bool(rng.random() < 0.5)
+        if rng.random() < 0.1:
+            kw["keep_attrs"] = True
+    elif method == "cumint":
+        args = [str(rng.choice(present))]
+        _padding_arg(rng, axes, kw)
+        if rng.random() < 0.4:
+            kw["to"] = _to_arg(rng, positions, where[var], args[0])
+        if rng.random() < 0.3:
+            kw["reverse"] = True
+    elif method == "interp_like":
+        args = ["var:" + str(rng.choice(fields))]
+        if rng.random() < 0.5:
+            kw["padding"] = str(rng.choice(MODES))
+        if rng.random() < 0.2:
+            kw["fill_value"] = 1.5
+    elif method == "get_metric":
+        k = int(rng.integers(1, len(axes) + 1))
+        args = [tuple(rng.choice(axes, size=k, replace=False).tolist())]
+    return method, var, args, kw
+
+
+# ---- running one call on both grids ---------------------------------------------------------------------------------------
+def _describe(res):
+    return {"dims": tuple(res.dims), "name": res.name, "dtype": str(np.asarray(res.values).dtype), "coords": sorted(res.coords)}
+
+
+def _call(grid, ds, method, var, args, kw):
+    args = [ds[a[4:]] if isinstance(a, str) and a.startswith("var:") else a for a in args]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        try:
+            return getattr(grid, method)(ds[var], *args, **kw), None
+        except Exception as exc:  # noqa: BLE001 -- raising IS a behaviour to compare
+            return None, exc
+
+
+def compare(ref, ref_exc, got, got_exc):
+    """None when both sides agree, else a short description of the first difference"""
+    if (ref_exc is None) != (got_exc is None):
+        return f"reference {'raised ' + type(ref_exc).__name__ + ': ' + str(ref_exc)[:100] if ref_exc else 'returned'}; " \
+               f"xgcm_amd {'raised ' + type(got_exc).__name__ + ': ' + str(got_exc)[:100] if got_exc else 'returned'}"
+    if ref_exc is not None:
+        if ("more than 1 axis dimension" in str(got_exc) or "more than 1 axis dimension" in str(ref_exc)) \
+                and isinstance(ref_exc, (ValueError, KeyError)) and isinstance(got_exc, (ValueError, KeyError)):
+            # `field * metric` with the metric at ANOTHER position of the same axis (what default-shift interpolation of a
+            # metric can produce) carries two dims of one axis; both stacks refuse to go on, the reference wherever its
+            # container first trips over it (under the stand-in: numpy's "axes don't match array")
+            return None
+        if type(ref_exc).__name__ != type(got_exc).__name__:
+            return f"exception type: reference {type(ref_exc).__name__} ({str(ref_exc)[:80]}), xgcm_amd {type(got_exc).__name__} ({str(got_exc)[:80]})"
+        return None
+    a, b = _describe(ref), _describe(got)
+    for key in ("dims", "name", "coords", "dtype"):
+        if a[key] != b[key]:
+            return f"{key}: reference {a[key]!r}, xgcm_amd {b[key]!r}"
+    x, y = np.asarray(ref.values), np.asarray(got.values)
+    if x.shape != y.shape:
+        return f"shape: reference {x.shape}, xgcm_amd {y.shape}"
+    if not np.array_equal(x, y, equal_nan=x.dtype.kind == "f"):
+        if not np.allclose(x, y, rtol=1e-12, atol=1e-12, equal_nan=True):
+            return f"values differ: max |d| = {np.nanmax(np.abs(x.astype(float) - y.astype(float))):.3e}"
+    for c in a["coords"]:
+        if not np.array_equal(np.asarray(ref.coords[c].values), np.asarray(got.coords[c].values)):
+            return f"coordinate {c!r} differs"
+        if tuple(ref.coords[c].dims) != tuple(got.coords[c].dims):
+            return f"coordinate {c!r}: dims {ref.coords[c].dims} vs {got.coords[c].dims}"
+    return None
+
+
+def message_differs(ref_exc, got_exc):
+    return ref_exc is not None and got_exc is not None and str(ref_exc)[:60] != str(got_exc)[:60]
+
+
+def run(cases=100, seed=0, backend="oracle-double", calls_per_case=12, verbose=False):
+    xr, RefGrid, OurGrid = load_both(backend)
+    stats = {"cases": 0, "calls": 0, "both_returned": 0, "both_raised": 0, "grid_errors_agreeing": 0}
+    differences, messages = [], []
+    for case in range(cases):
+        rng = np.random.default_rng([seed, case])
+        axes, positions, sizes, coords, gkw = draw_grid(rng)
+        variables, where = draw_variables(rng, axes, positions, sizes)
+        metrics = draw_metrics(rng, axes, positions, sizes, variables)
+        if metrics:
+            gkw["metrics"] = metrics
+        ds = xr.Dataset({k: v for k, v in variables.items()}, coords)
+        stats["cases"] += 1
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                rgrid, rexc = RefGrid(ds, **gkw), None
+            except Exception as exc:  # noqa: BLE001
+                rgrid, rexc = None, exc
+            try:
+                ogrid, oexc = OurGrid(ds, **gkw), None
+            except Exception as exc:  # noqa: BLE001
+                ogrid, oexc = None, exc
+        if rexc is not None or oexc is not None:
+            if (rexc is None) != (oexc is None) or type(rexc).__name__ != type(oexc).__name__:
+                differences.append({"case": case, "call": "Grid(...)", "kwargs": repr(gkw)[:300],
+                                    "difference": f"reference {rexc!r:.120}; xgcm_amd {oexc!r:.120}"})
+            else:
+                stats["grid_errors_agreeing"] += 1
+            continue
+        for k in range(calls_per_case):
+            method, var, args, kw = draw_call(rng, axes, positions, variables, where, metrics)
+            ref, ref_exc = _call(rgrid, ds, method, var, args, kw)
+            got, got_exc = _call(ogrid, ds, method, var, args, kw)
+            stats["calls"] += 1
+            diff = compare(ref, ref_exc, got, got_exc)
+            what = {"case": case, "k": k, "call": f"grid.{method}({var}{variables[var][0]}, *{args}, **{kw})",
+                    "grid": {kk: vv for kk, vv in gkw.items() if kk != "coords"}, "positions": positions}
+            if diff is not None:
+                differences.append(dict(what, difference=diff))
+                if verbose:
+                    print("DIFF", case, k, diff[:140])
+            elif ref_exc is not None:
+                stats["both_raised"] += 1
+                why = type(ref_exc).__name__ + ": " + str(ref_exc)[:40]
+                stats.setdefault("raised", {})[why] = stats.setdefault("raised", {}).get(why, 0) + 1
+                if message_differs(ref_exc, got_exc):
+                    messages.append(dict(what, reference=str(ref_exc)[:160], xgcm_amd=str(got_exc)[:160]))
+            else:
+                stats["both_returned"] += 1
+    return stats, differences, messages
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--backend", default="oracle-double", choices=["oracle-double", "host-abi", "hip"])
+    ap.add_argument("-v", "--verbose", action="store_true")
+    args = ap.parse_args()
+    stats, differences, messages = run(args.cases, args.seed, args.backend, verbose=args.verbose)
+    print(json.dumps(stats))
+    by = {}
+    for d in differences:
+        by.setdefault(d["difference"][:90], []).append(d)
+    for k, v in sorted(by.items(), key=lambda kv: -len(kv[1])):
+        print(len(v), "x", k, "\n      e.g.", v[0]["call"][:200], "| grid", repr(v[0].get("grid"))[:200])
+    print(len(messages), "agreeing exceptions with different wording")
+    by = {}
+    for m in messages:
+        by.setdefault((m["reference"][:70], m["xgcm_amd"][:70]), []).append(m)
+    for (a, b), v in sorted(by.items(), key=lambda kv: -len(kv[1]))[:15]:
+        print(len(v), "x", "\n   ref:", a, "\n   own:", b)
+    sys.exit(1 if differences else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -534,15 +534,32 @@ class Grid:
             i += 1
             ufunc, remaining = _select_grid_ufunc(funcname, sig, module=gridops, **kwargs)
             weighted = metric_weighted.get(ax_name) if isinstance(metric_weighted, dict) else None
-            out_dims = _shifted_dims(self, array, ax_name, sig.out_ax_positions[0][0])
+            out_dims = _shifted_dims(self, array, ax_name, sig.out_ax_positions[0][0], sig.in_ax_positions[0][0])
             m_in = m_out = None
-            post_divide = None
+            post_divide = late_error = None
             if weighted:
                 m_in = self._resident(self.get_metric(array, weighted, _layout=array.dims), _lazy.like(array))
-                m_out = self._resident(self.get_metric(_DimsOnly(out_dims, array.name), weighted, _layout=out_dims), _lazy.like(array))
-            if _divide_by is not None:
-                dx = self._resident(self.get_metric(_DimsOnly(out_dims, array.name), _divide_by, _layout=out_dims), _lazy.like(array))
-                if any(d not in out_dims for d in dx.dims):
+                if any(d not in array.dims for d in m_in.dims):
+                    # the metric found (interpolated by default shifts, so not always onto the array's points) carries a
+                    # dim the array lacks: the reference's `array * metric` broadcasts by name into an outer product
+                    # BEFORE the operator (xgcm/grid.py:804-808) -- the explicit product does the same
+                    array = _lazy.plain(array) * m_in
+                    m_in = None
+                    out_dims = _shifted_dims(self, array, ax_name, sig.out_ax_positions[0][0], sig.in_ax_positions[0][0])
+                try:
+                    m_out = self._resident(self.get_metric(_DimsOnly(out_dims, array.name), weighted, _layout=out_dims), _lazy.like(array))
+                except (KeyError, ValueError) as exc:
+                    late_error = exc  # the reference looks this metric up AFTER the operator ran (:829-831): its errors first
+                if m_out is not None and any(d not in out_dims for d in m_out.dims):
+                    post_divide, m_out = m_out, None  # ... and `array / metric` AFTER it, likewise by name
+            if _divide_by is not None and late_error is None:
+                try:
+                    dx = self._resident(self.get_metric(_DimsOnly(out_dims, array.name), _divide_by, _layout=out_dims), _lazy.like(array))
+                except (KeyError, ValueError) as exc:
+                    late_error, dx = exc, None  # `grid.diff(...)` first, then the metric (xgcm/grid.py:1576-1578)
+                if dx is None:
+                    pass
+                elif any(d not in out_dims for d in dx.dims):
                     # the metric found for the result does not live on the result's points (drC on Zp1 interpolated to Z
                     # for a difference that went to Zl ...): the reference's `diff / dx` then BROADCASTS by name into an
                     # outer product (xgcm/grid.py:1576-1578) -- the explicit quotient does the same
@@ -551,6 +568,12 @@ class Grid:
                     m_out = dx
                 else:
                     post_divide = dx  # two successive divisions cannot be merged bit-exactly
+            if sum(d in array.dims for d in self.axes[ax_name].coords.values()) > 1 and any(
+                    any(w) for w in (getattr(ufunc, "padding_width", None) or {}).values()):
+                # a metric product (this step's or an earlier one's) gave the array a second dim of this axis: the
+                # reference's pad looks the axis' dim up again and refuses (xgcm/padding.py:595); an operator that pads
+                # nothing goes on with the dim its signature names
+                self.axes[ax_name]._get_position_name(array)
             arg = {vector_key: array} if vector_key is not None else array
             if isinstance(ufunc, gridops.HipGridUFunc):
                 if m_in is not None and gridops.complex_topology(self, ax_name) and (vector_key is not None or other_component is not None):
@@ -561,7 +584,7 @@ class Grid:
                     array = array * m_in
                     arg = {vector_key: array} if vector_key is not None else array
                     m_in = None
-                if self._fusing and post_divide is None:
+                if self._fusing and post_divide is None and late_error is None:
                     deferred = _lazy.defer_stencil(self, funcname, ufunc, sig, arg, ax_name, other_component, m_in, m_out,
                                                    remaining, out_dims)
                     if deferred is not None:
@@ -576,6 +599,8 @@ class Grid:
                 array = ufunc(self, arg, axis=[(ax_name,)], other_component=other_component, **remaining)
                 if m_out is not None:
                     array = array / m_out
+            if late_error is not None:
+                raise late_error
             if (m_in is not None or m_out is not None) and array.name is not None:
                 array = array._replace(name=_name_after(array.name, m_in, m_out))
             if post_divide is not None:
@@ -602,8 +627,11 @@ class Grid:
         (sig_a, ax_a), (sig_b, ax_b) = step_a, step_b
         if ax_a == ax_b or gridops.complex_topology(self, ax_a) or gridops.complex_topology(self, ax_b):
             return None  # halos from other faces / the folded row: one axis at a time (xg_stencil1d_halo)
-        ufa, _ = _select_grid_ufunc(funcname, sig_a, module=gridops)
-        ufb, _ = _select_grid_ufunc(funcname, sig_b, module=gridops)
+        try:
+            ufa, _ = _select_grid_ufunc(funcname, sig_a, module=gridops)
+            ufb, _ = _select_grid_ufunc(funcname, sig_b, module=gridops)
+        except NotImplementedError:
+            return None  # (one axis at a time, so that the error -- if any -- is the one of the FIRST bad axis, as there)
         if not (isinstance(ufa, gridops.HipGridUFunc) and isinstance(ufb, gridops.HipGridUFunc)):
             return None
         try:
@@ -741,20 +769,12 @@ class Grid:
         for ax in [self.axes[name] for name in axis]:
             pos, dim = ax._get_position_name(da)
             rev = bool(reverse.get(ax.name, False))
-            ax_to = to.get(ax.name) if isinstance(to, dict) else None
-            if ax_to is None:
-                ax_to = ax._default_shifts[pos]
-            trim_lo, trim_hi, pad_lo, pad_hi = _cumsum_trim_pad(pos, ax_to, rev, ax)
-            bc = all_padding[ax.name]
-            generic_pad = gridops.complex_topology(self, ax.name)
-            if (pad_lo or pad_hi) and bc is None and not generic_pad:
-                raise no_boundary_error(ax.name)
-            fv = all_fill[ax.name]
-            new_dim = ax.coords[ax_to]
-            out_dims = tuple(new_dim if d == dim else d for d in data.dims)
             weighted = metric_weighted.get(ax.name) if isinstance(metric_weighted, dict) else None
+            # (the steps below come in the reference's order, xgcm/grid.py:1303-1413, so that a call with several things
+            # wrong raises the error the reference raises: input metric, trim table, pad, target dim, output metric)
             m_in = m_out = None
             weight_names = []  # the DataArrays whose products / quotients decide the result's name (xarray's rule)
+            generic_pad = gridops.complex_topology(self, ax.name)
             if pre_weight is not None:
                 if weighted or generic_pad:  # two input factors / pad-after route: explicit product first
                     data = data * pre_weight
@@ -762,12 +782,39 @@ class Grid:
                     m_in = _aligned_view(pre_weight, data.dims)
                     weight_names.append(pre_weight)
                 pre_weight = None
+            two_axis_dims = False
             if weighted:
                 w_in = self.get_metric(data, weighted, _layout=data.dims)
+                if any(d not in data.dims for d in w_in.dims):
+                    # a metric that does not live on the field's points (found by default-shift interpolation): the
+                    # reference's `data * metric` is an outer product by name (:1311-1313); its pad then looks the axis'
+                    # dim up again and refuses an array that now has two of them (xgcm/padding.py:595)
+                    data = data * self._resident(w_in, data.data)
+                    two_axis_dims = True
+                else:
+                    weight_names.append(w_in)
+                    m_in = _aligned_view(self._resident(w_in, data.data), data.dims)
+            ax_to = to.get(ax.name) if isinstance(to, dict) else None
+            if ax_to is None:
+                ax_to = ax._default_shifts[pos]
+            trim_lo, trim_hi, pad_lo, pad_hi = _cumsum_trim_pad(pos, ax_to, rev, ax)
+            bc = all_padding[ax.name]
+            if pad_lo or pad_hi:
+                if two_axis_dims:
+                    ax._get_position_name(data)
+                if bc is None and not generic_pad:
+                    raise no_boundary_error(ax.name)
+            fv = all_fill[ax.name]
+            new_dim = ax.coords[ax_to]
+            out_dims = tuple(new_dim if d == dim else d for d in data.dims)
+            post_divide = None
+            if weighted:
                 w_out = self.get_metric(_DimsOnly(out_dims, data.name), weighted, _layout=out_dims)
-                weight_names += [w_in, w_out]
-                m_in = _aligned_view(self._resident(w_in, data.data), data.dims)
-                m_out = _aligned_view(self._resident(w_out, data.data), out_dims)
+                if any(d not in out_dims for d in w_out.dims):
+                    post_divide = w_out  # `reattached / metric` (:1411-1413), by name as well
+                else:
+                    weight_names.append(w_out)
+                    m_out = _aligned_view(self._resident(w_out, data.data), out_dims)
             num = data.get_axis_num(dim)
             host = not _is_tensor(data.data)
             # xarray's DataArray.cumsum skips NaN for floats (numpy.nancumsum); see DESIGN.md "unpinned"
@@ -818,6 +865,8 @@ class Grid:
                 # the same dims order here, as a view (no copy)
                 res = res.transpose(self._facedim, *[d for d in res.dims if d != self._facedim])
             data = _reattach_coords([res], self, {ax.name: (pad_lo, pad_hi)}, {new_dim}, [data])[0]
+            if post_divide is not None:
+                data = data / self._resident(post_divide, data.data)
         return to_xarray(data) if was_xr else data
 
     def integrate(self, da, axis, **kwargs):
@@ -916,7 +965,7 @@ class Grid:
             num = (da * weight).sum(dims, skipna=skip)
             ones = _valid_mask(da) if skip else da._replace(data=_ones_like(da.data), coords=OrderedDict())
             den = (ones * weight).sum(dims, skipna=False)
-            out = num / den
+            out = (num / den)._replace(name=da.name)  # (`da.weighted(w).mean(...)` keeps the array's name)
         else:
             # ONE pass over `da` (8 B/cell): sum(da * w) and sum(w over the valid cells) march together inside the
             # reduction kernel -- divided there for one dim, carried side by side through the remaining (small)
@@ -1123,9 +1172,13 @@ class Grid:
 
 
 # ----------------------------------------------------------------------------------------------
-def _shifted_dims(grid: Grid, array, ax_name: str, to_pos: str) -> Tuple[str, ...]:
-    """dims of the result of moving `array` to `to_pos` along `ax_name` (input order kept)."""
-    _, dim = grid.axes[ax_name]._get_position_name(array)
+def _shifted_dims(grid: Grid, array, ax_name: str, to_pos: str, from_pos: Optional[str] = None) -> Tuple[str, ...]:
+    """dims of the result of moving `array` to `to_pos` along `ax_name` (input order kept).  `from_pos`: the position
+    the step's signature names -- fixed from the ORIGINAL array before the first axis (xgcm/grid.py:790-794), so a later
+    axis is not looked up again on an array a metric product may have given a second dim of that axis"""
+    dim = grid.axes[ax_name].coords.get(from_pos) if from_pos is not None else None
+    if dim is None or dim not in array.dims:
+        _, dim = grid.axes[ax_name]._get_position_name(array)
     new = grid.axes[ax_name].coords.get(to_pos, dim)
     return tuple(new if d == dim else d for d in array.dims)
 

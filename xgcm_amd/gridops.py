@@ -143,10 +143,9 @@ class HipGridUFunc(GridUFunc):
                 f"does not appear in argument"
                 f"{da}"
             )
-        try:
-            out_dim = grid.axes[ax_name].coords[self.to_pos]
-        except KeyError:
-            raise ValueError(f"Axis position ({ax_name}:{self.to_pos}) does not exist in grid")
+        # (a target position the axis does not have is the reference's bare KeyError(position): only the INPUT positions
+        # are checked with a message, xgcm/grid_ufunc.py:827-832)
+        out_dim = grid.axes[ax_name].coords[self.to_pos]
 
         (lo, hi) = next(iter(self.padding_width.values())) if self.padding_width else (0, 0)
         num = da.get_axis_num(in_dim)
