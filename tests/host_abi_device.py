@@ -40,7 +40,7 @@ def _in(x):
     """the product's device._raw_device over host memory: a contiguous array in NATIVE byte order; an array of the other
     byte order is copied as raw bytes and reversed by the host build of xg_bswap -- the SAME intake rule
     (xgcm_amd.dtypes.host_intake), never a reinterpretation by dtype name"""
-    a, swap = _dt.host_intake(np.ascontiguousarray(x))
+    a, swap = _dt.host_intake(np.asarray(x, order="C"))
     if swap:
         a = a.copy()
         if a.size:
@@ -268,6 +268,8 @@ def binary(op, a, b):
         dt, sfx = (np.float32, "f32") if res_dt == np.float32 else (np.float64, "f64")
         half = _half(a, b)
         a, b = asdevice(a, dt), asdevice(b, dt)
+    if a.ndim == 0 and b.ndim == 0:  # (mirrors device.binary: two scalars are one cell of a 1-d launch)
+        return binary(op, a.reshape(1), b.reshape(1)).reshape(())
     shape = [max(sa, sb) if 0 not in (sa, sb) else 0 for sa, sb in zip(a.shape, b.shape)]
     out = np.empty(shape, dtype=dt)
     if out.size:

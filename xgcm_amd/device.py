@@ -148,7 +148,7 @@ def _raw_device(x) -> torch.Tensor:
         if t.dtype not in _dt._TORCH_TO_NUMPY:
             raise TypeError(f"array: dtype {t.dtype} is not supported by the MI355X backend")
     else:
-        a, swap = _dt.host_intake(np.ascontiguousarray(x))
+        a, swap = _dt.host_intake(np.asarray(x, order="C"))
         if a.flags.writeable:
             t = torch.from_numpy(a)
         else:  # (a read-only memory map of a file: only ever READ here -- no copy, no warning)
@@ -856,6 +856,9 @@ def binary(op: str, a, b) -> torch.Tensor:
         b = asdevice(b, dt)
     if a.dim() != b.dim():
         raise ValueError("binary: operands must be dim-aligned (same ndim)")
+    if a.dim() == 0:  # two scalars (a mean over every dim: total / total weight): one cell of a 1-d launch
+        one = binary(op, a.reshape(1), b.reshape(1))
+        return one.reshape(())
     shape = []
     for sa, sb in zip(a.shape, b.shape):
         if sa != sb and 1 not in (sa, sb):
