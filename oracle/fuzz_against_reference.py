@@ -117,6 +117,31 @@ def draw_grid(rng):
         kw["fill_value"] = {ax: float(rng.integers(-3, 4)) for ax in axes if rng.random() < 0.6}
     if style == 3 and rng.random() < 0.5:
         kw["fill_value"] = float(rng.integers(1, 5))
+    r = rng.random()
+    if r < 0.12:  # default shifts of the user's (valid ones; now and then a position the axis lacks)
+        ax = _pick(rng, axes)
+        others = [p for p in positions[ax] if p != "center"]
+        shifts = {"center": _pick(rng, others) if rng.random() < 0.85 else str(rng.choice(POSITIONS))}
+        if rng.random() < 0.5:
+            shifts[_pick(rng, others)] = "center"
+        kw["default_shifts"] = {ax: shifts}
+    elif r < 0.15:
+        kw["padding"] = "cyclic"  # not a mode
+    elif r < 0.17:
+        kw["padding"] = {"Q": "fill"}  # not an axis
+    elif r < 0.19:
+        kw["periodic"] = True  # removed argument
+    elif r < 0.21:
+        kw["boundary"] = "fill"  # renamed argument
+    elif r < 0.23:
+        ax = _pick(rng, axes)  # (the Grid is told of a dim the dataset lacks; the variables keep the real ones)
+        kw["coords"] = dict(positions, **{ax: dict(positions[ax], **{_pick(rng, list(positions[ax])): "no_such_dim"})})
+    elif r < 0.25:
+        ax = _pick(rng, axes)  # a coordinate of the wrong length for its position
+        p = _pick(rng, [q for q in positions[ax] if q != "center"])
+        dim = positions[ax][p]
+        sizes[dim] += 2
+        coords[dim] = (dim, np.arange(sizes[dim]) * 1.0)
     return axes, positions, sizes, coords, kw
 
 
@@ -200,13 +225,82 @@ def _padding_arg(rng, axes, kw):
         kw["fill_value"] = {ax: float(rng.integers(-2, 3)) for ax in axes if rng.random() < 0.7}
 
 
+def _ufunc_same(a):
+    return a * 2.0
+
+
+def _ufunc_centered(a):  # width (1, 1), output as long as the input
+    return a[..., 2:] - 2.0 * a[..., 1:-1] + a[..., :-2]
+
+
+def _ufunc_forward(a):  # width (0, 1)
+    return a[..., 1:] - a[..., :-1]
+
+
+def _ufunc_backward(a):  # width (1, 0)
+    return 0.5 * (a[..., 1:] + a[..., :-1])
+
+
+def _ufunc_wide(a):  # width (2, 1)
+    return a[..., 3:] + a[..., :-3]
+
+
+def _ufunc_two_outputs(a):
+    return a[..., 1:] - a[..., :-1], a[..., 1:] + a[..., :-1]
+
+
+def _ufunc_two_axes(a):  # (Y, X) with width (1, 0) on both
+    return a[..., 1:, 1:] - a[..., :-1, :-1]
+
+
+def _ufunc_reduce(a):
+    return a.sum(axis=-1)
+
+
+USER_UFUNCS = {
+    "same": (_ufunc_same, "({A}:{p})->({A}:{p})", None),
+    "centered": (_ufunc_centered, "({A}:{p})->({A}:{p})", {"{A}": (1, 1)}),
+    "forward": (_ufunc_forward, "({A}:{p})->({A}:{q})", {"{A}": (0, 1)}),
+    "backward": (_ufunc_backward, "({A}:{p})->({A}:{q})", {"{A}": (1, 0)}),
+    "wide": (_ufunc_wide, "({A}:{p})->({A}:{p})", {"{A}": (2, 1)}),
+    "two_outputs": (_ufunc_two_outputs, "({A}:{p})->({A}:{q}),({A}:{q})", {"{A}": (1, 0)}),
+    "reduce": (_ufunc_reduce, "({A}:{p})->()", None),
+    "untrimmed": (_ufunc_same, "({A}:{p})->({A}:{p})", {"{A}": (1, 0)}),  # forgets to trim its padding: both must refuse
+}
+
+
+def draw_user_ufunc(rng, axes, positions, where_var, present):
+    name = _pick(rng, list(USER_UFUNCS))
+    func, sig, widths = USER_UFUNCS[name]
+    ax = _pick(rng, present) if (present and rng.random() < 0.95) else _pick(rng, axes)
+    here = where_var.get(ax, "center")
+    p = here if rng.random() < 0.9 else str(rng.choice(POSITIONS))
+    q = _to_arg(rng, positions, where_var, ax) if ax in where_var else "center"
+    dummy = "X" if rng.random() < 0.5 else ax  # a dummy axis name in the signature, mapped by `axis=`
+    kw = {"axis": [(ax,)], "signature": sig.format(A=dummy, p=p, q=q)}
+    if widths is not None:
+        kw["padding_width"] = {ax: w for w in widths.values()}
+    _padding_arg(rng, axes, kw)
+    if rng.random() < 0.15:
+        kw["pad_before_func"] = False
+    return name, kw
+
+
 def draw_call(rng, axes, positions, variables, where, metrics):
     fields = [v for v in variables if v.startswith("v")]
     var = str(rng.choice(fields))
     present = list(where[var])
     method = str(rng.choice(["diff", "interp", "min", "max", "diff", "interp", "cumsum", "cumsum", "derivative", "integrate",
-                             "average", "cumint", "interp_like", "get_metric"]))
+                             "average", "cumint", "interp_like", "get_metric", "apply_as_grid_ufunc", "apply_as_grid_ufunc", "pad"]))
     kw, args = {}, []
+    if method == "apply_as_grid_ufunc":
+        name, kw = draw_user_ufunc(rng, axes, positions, where[var], present)
+        return "apply_as_grid_ufunc:" + name, var, [], kw
+    if method == "pad":
+        widths = {ax: (int(rng.integers(0, 3)), int(rng.integers(0, 3))) for ax in (present if rng.random() < 0.9 else axes)
+                  if rng.random() < 0.7}
+        _padding_arg(rng, axes, kw)
+        return "pad", var, [widths if (widths or rng.random() < 0.5) else None], kw
     with_metric = [ax for ax in present if (ax,) in metrics]
     if method in ("derivative", "integrate", "average", "cumint") and with_metric and rng.random() < 0.85:
         present = with_metric
@@ -266,12 +360,20 @@ def _describe(res):
     return {"dims": tuple(res.dims), "name": res.name, "dtype": str(np.asarray(res.values).dtype), "coords": sorted(res.coords)}
 
 
-def _call(grid, ds, method, var, args, kw):
+def _call(grid, ds, method, var, args, kw, pad_function=None):
     args = [ds[a[4:]] if isinstance(a, str) and a.startswith("var:") else a for a in args]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         try:
-            return getattr(grid, method)(ds[var], *args, **kw), None
+            if method.startswith("apply_as_grid_ufunc:"):
+                res = grid.apply_as_grid_ufunc(USER_UFUNCS[method.split(":")[1]][0], ds[var], **kw)
+            elif method == "pad":
+                res = pad_function(ds[var], grid, args[0], **kw)
+            else:
+                res = getattr(grid, method)(ds[var], *args, **kw)
+            if hasattr(res, "compute") and type(res).__name__ == "LazyArray":
+                res = res.compute()  # (the deferred mode: the value is what is compared)
+            return res, None
         except Exception as exc:  # noqa: BLE001 -- raising IS a behaviour to compare
             return None, exc
 
@@ -288,9 +390,13 @@ def compare(ref, ref_exc, got, got_exc):
             # metric can produce) carries two dims of one axis; both stacks refuse to go on, the reference wherever its
             # container first trips over it (under the stand-in: numpy's "axes don't match array")
             return None
-        if type(ref_exc).__name__ != type(got_exc).__name__:
+        if type(ref_exc).__name__ not in [c.__name__ for c in type(got_exc).__mro__]:  # (same class or a subclass of it)
             return f"exception type: reference {type(ref_exc).__name__} ({str(ref_exc)[:80]}), xgcm_amd {type(got_exc).__name__} ({str(got_exc)[:80]})"
         return None
+    if isinstance(ref, tuple) or isinstance(got, tuple):
+        if not (isinstance(ref, tuple) and isinstance(got, tuple) and len(ref) == len(got)):
+            return f"number of results: reference {type(ref).__name__}, xgcm_amd {type(got).__name__}"
+        return next((d for d in (compare(r, None, g, None) for r, g in zip(ref, got)) if d is not None), None)
     a, b = _describe(ref), _describe(got)
     for key in ("dims", "name", "coords", "dtype"):
         if a[key] != b[key]:
@@ -313,18 +419,15 @@ def message_differs(ref_exc, got_exc):
     return ref_exc is not None and got_exc is not None and str(ref_exc)[:60] != str(got_exc)[:60]
 
 
-def run(cases=100, seed=0, backend="oracle-double", calls_per_case=12, verbose=False):
+def run(cases=100, seed=0, backend="oracle-double", calls_per_case=12, verbose=False, fused=False):
     xr, RefGrid, OurGrid = load_both(backend)
+    from xgcm.padding import pad as ref_pad  # the reference's
+    from xgcm_amd.padding import pad as our_pad
     stats = {"cases": 0, "calls": 0, "both_returned": 0, "both_raised": 0, "grid_errors_agreeing": 0}
     differences, messages = [], []
     for case in range(cases):
-        rng = np.random.default_rng([seed, case])
-        axes, positions, sizes, coords, gkw = draw_grid(rng)
-        variables, where = draw_variables(rng, axes, positions, sizes)
-        metrics = draw_metrics(rng, axes, positions, sizes, variables)
-        if metrics:
-            gkw["metrics"] = metrics
-        ds = xr.Dataset({k: v for k, v in variables.items()}, coords)
+        ds, gkw, variables, calls = build_case(xr.Dataset, seed, case, calls_per_case)
+        positions = gkw["coords"]
         stats["cases"] += 1
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -333,7 +436,7 @@ def run(cases=100, seed=0, backend="oracle-double", calls_per_case=12, verbose=F
             except Exception as exc:  # noqa: BLE001
                 rgrid, rexc = None, exc
             try:
-                ogrid, oexc = OurGrid(ds, **gkw), None
+                ogrid, oexc = OurGrid(ds, **dict(gkw, fuse=True) if fused else gkw), None
             except Exception as exc:  # noqa: BLE001
                 ogrid, oexc = None, exc
         if rexc is not None or oexc is not None:
@@ -343,10 +446,9 @@ def run(cases=100, seed=0, backend="oracle-double", calls_per_case=12, verbose=F
             else:
                 stats["grid_errors_agreeing"] += 1
             continue
-        for k in range(calls_per_case):
-            method, var, args, kw = draw_call(rng, axes, positions, variables, where, metrics)
-            ref, ref_exc = _call(rgrid, ds, method, var, args, kw)
-            got, got_exc = _call(ogrid, ds, method, var, args, kw)
+        for k, (method, var, args, kw) in enumerate(calls):
+            ref, ref_exc = _call(rgrid, ds, method, var, args, kw, ref_pad)
+            got, got_exc = _call(ogrid, ds, method, var, args, kw, our_pad)
             stats["calls"] += 1
             diff = compare(ref, ref_exc, got, got_exc)
             what = {"case": case, "k": k, "call": f"grid.{method}({var}{variables[var][0]}, *{args}, **{kw})",
@@ -366,14 +468,121 @@ def run(cases=100, seed=0, backend="oracle-double", calls_per_case=12, verbose=F
     return stats, differences, messages
 
 
+def build_case(make_dataset, seed, case, calls_per_case=12):
+    """the seeded inputs of one case WITHOUT the reference: (dataset, grid kwargs, variables, [(method, var, args, kwargs)])"""
+    rng = np.random.default_rng([seed, case])
+    axes, positions, sizes, coords, gkw = draw_grid(rng)
+    variables, where = draw_variables(rng, axes, positions, sizes)
+    metrics = draw_metrics(rng, axes, positions, sizes, variables)
+    if metrics:
+        gkw["metrics"] = metrics
+    ds = make_dataset({k: v for k, v in variables.items()}, coords)
+    calls = [draw_call(rng, axes, positions, variables, where, metrics) for _ in range(calls_per_case)]
+    return ds, gkw, variables, calls
+
+
+def _pack(res):
+    outs = res if isinstance(res, tuple) else (res,)
+    return [{"dims": list(o.dims), "name": o.name, "coords": {c: list(o.coords[c].dims) for c in sorted(o.coords)}} for o in outs]
+
+
+def record(cases, seed, out_prefix):
+    """The reference's answers to the generator's calls as a fixture: `<out_prefix>.json` (per call: raised type, or dims /
+    name / coordinate names of every result) + `<out_prefix>.npz` (values of results and of their coordinates).  The
+    INPUTS are not stored: `build_case(seed, case)` regenerates them anywhere numpy is."""
+    xr, RefGrid, _ = load_both()
+    from xgcm.padding import pad as ref_pad
+
+    meta = {"seed": seed, "cases": cases, "calls_per_case": 12, "what": "expected outcomes of oracle/fuzz_against_reference.py's "
+            "seeded calls, produced by the reference's own Grid (over the xarray stand-in); inputs are regenerated from the seed",
+            "outcomes": []}
+    arrays = {}
+    for case in range(cases):
+        ds, gkw, variables, calls = build_case(xr.Dataset, seed, case)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                grid = RefGrid(ds, **gkw)
+            except Exception as exc:  # noqa: BLE001
+                meta["outcomes"].append({"grid_raises": type(exc).__name__})
+                continue
+        per_call = []
+        for k, (method, var, args, kw) in enumerate(calls):
+            res, exc = _call(grid, ds, method, var, args, kw, ref_pad)
+            if exc is not None:
+                per_call.append({"raises": type(exc).__name__, "message": str(exc)[:80]})
+                continue
+            outs = res if isinstance(res, tuple) else (res,)
+            per_call.append({"results": _pack(res)})
+            for j, o in enumerate(outs):
+                arrays[f"{case}/{k}/{j}"] = np.asarray(o.values)
+                for c in o.coords:
+                    arrays[f"{case}/{k}/{j}/coord/{c}"] = np.asarray(o.coords[c].values)
+        meta["outcomes"].append({"calls": per_call})
+    with open(out_prefix + ".json", "w") as f:
+        json.dump(meta, f, indent=0)
+    np.savez_compressed(out_prefix + ".npz", **arrays)
+    n = sum(len(o.get("calls", [])) for o in meta["outcomes"])
+    print(f"{cases} cases, {n} calls ({sum('results' in c for o in meta['outcomes'] for c in o.get('calls', []))} results) -> {out_prefix}.json/.npz")
+
+
+def record_stable(cases, seed, out_prefix, hash_seeds=(1, 2, 3, 4)):
+    """`record` under several PYTHONHASHSEEDs: where the reference's answer depends on the iteration order of a set of
+    strings (`iterate_axis_combinations` walks `combinations(frozenset(axes))`: WHICH metrics get multiplied, and in which
+    dim order, for a multi-axis metric) the call is marked `hash_seed_dependent` and carries no expectation -- such
+    behaviour is excluded from every fixture of this repository.  Within one process both stacks
+    iterate the same sets the same way: the live comparison (`run`) covers those calls."""
+    import subprocess
+    import tempfile
+
+    tmp = tempfile.mkdtemp(prefix="xgcm_fuzz_record_")
+    metas, npzs = [], []
+    for hs in hash_seeds:
+        prefix = os.path.join(tmp, f"h{hs}")
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--cases", str(cases), "--seed", str(seed), "--record-raw", prefix],
+                       env=dict(os.environ, PYTHONHASHSEED=str(hs)), check=True, capture_output=True)
+        with open(prefix + ".json") as f:
+            metas.append(json.load(f))
+        npzs.append(np.load(prefix + ".npz"))
+    meta, keep, unstable = metas[0], {}, 0
+    for case, outcome in enumerate(meta["outcomes"]):
+        for k, call in enumerate(outcome.get("calls", [])):
+            same = all(m["outcomes"][case]["calls"][k] == call for m in metas[1:])
+            keys = [key for key in npzs[0].files if key.startswith(f"{case}/{k}/")]
+            if same:
+                same = all(set(keys) == {key for key in z.files if key.startswith(f"{case}/{k}/")} and
+                           all(np.array_equal(npzs[0][key], z[key], equal_nan=npzs[0][key].dtype.kind == "f") for key in keys)
+                           for z in npzs[1:])
+            if same:
+                keep.update({key: npzs[0][key] for key in keys})
+            else:
+                outcome["calls"][k] = {"hash_seed_dependent": True}
+                unstable += 1
+    meta["hash_seeds_compared"] = list(hash_seeds)
+    with open(out_prefix + ".json", "w") as f:
+        json.dump(meta, f, indent=0)
+    np.savez_compressed(out_prefix + ".npz", **keep)
+    n = sum(len(o.get("calls", [])) for o in meta["outcomes"])
+    print(f"{cases} cases, {n} calls, {unstable} of them hash-seed dependent and left out -> {out_prefix}.json/.npz")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--backend", default="oracle-double", choices=["oracle-double", "host-abi", "hip"])
     ap.add_argument("-v", "--verbose", action="store_true")
+    ap.add_argument("--fused", action="store_true", help="xgcm_amd.Grid(fuse=True): deferred results, computed for the comparison")
+    ap.add_argument("--record-raw", metavar="PREFIX", help=argparse.SUPPRESS)
+    ap.add_argument("--record", metavar="PREFIX", help="write the reference's answers as a fixture (tests/golden/fuzz_reference)")
     args = ap.parse_args()
-    stats, differences, messages = run(args.cases, args.seed, args.backend, verbose=args.verbose)
+    if args.record_raw:
+        record(args.cases, args.seed, args.record_raw)
+        return
+    if args.record:
+        record_stable(args.cases, args.seed, args.record)
+        return
+    stats, differences, messages = run(args.cases, args.seed, args.backend, verbose=args.verbose, fused=args.fused)
     print(json.dumps(stats))
     by = {}
     for d in differences:

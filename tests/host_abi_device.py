@@ -33,7 +33,7 @@ def _check(rc):
     if rc != 0:
         buf = C.create_string_buffer(512)
         lib().xg_last_error(buf, 512)
-        raise _hip.XgcmHipError(f"xgcm host ABI status {rc}: {buf.value.decode(errors='replace')}")
+        raise _hip.error_for(rc, f"xgcm host ABI status {rc}: {buf.value.decode(errors='replace')}")
 
 
 def _in(x):

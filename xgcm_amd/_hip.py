@@ -169,6 +169,15 @@ class XgcmHipError(RuntimeError):
     """A C-ABI call returned a negative status (message from xg_last_error)."""
 
 
+class XgcmInvalidArgument(XgcmHipError, ValueError):
+    """XG_ERR_INVALID: the library refused its arguments (an empty axis padded with 'wrap' / 'edge', widths that do not
+    fit ...).  numpy raises ValueError for the same requests, and code written against the reference catches that."""
+
+
+def error_for(status: int, text: str) -> XgcmHipError:
+    return (XgcmInvalidArgument if status == -1 else XgcmHipError)(text)
+
+
 def load() -> C.CDLL:
     """Load the shared library (once) and type every export.  Raises if it is not built."""
     global _lib
@@ -254,7 +263,7 @@ def last_error() -> str:
 
 def check(status: int) -> None:
     if status != 0:
-        raise XgcmHipError(f"xgcm_hip status {status}: {last_error()}")
+        raise error_for(status, f"xgcm_hip status {status}: {last_error()}")
 
 
 def i64(values: Optional[Sequence[int]]):

@@ -497,7 +497,9 @@ def apply_as_grid_ufunc(func: Callable, *args, axis=None, grid=None, signature: 
         results = _apply(func, padded, in_core_dims, out_core_dims, **kwargs)
     else:
         unpadded = _apply(func, unpacked, in_core_dims, out_core_dims, **kwargs)
-        results = tuple(pad_all(unpadded, [None] * len(unpadded)))
+        # the reference pairs the unpadded RESULTS with the per-INPUT `other_component` list (grid_ufunc.py:915-923 ->
+        # :1016-1026, a `zip`): a function with more outputs than inputs loses the surplus outputs there, and so here
+        results = tuple(pad_all(unpadded, other_component))
 
     out_core_dim_names = set(d for arg in out_core_dims for d in arg)
     results = _reattach_coords(results, grid, padding_width, out_core_dim_names, unpacked)
