@@ -29,6 +29,11 @@ Pinning status
   stand-in for the xarray calls it makes) and ``tests/test_grid_reference.py`` replays its 426 calls through ``xgcm_amd.Grid``.
   ``oracle/make_golden_metadata.py`` does the same for ``Grid(ds)`` from COMODO / SGRID metadata (57 dataset descriptions,
   ``tests/test_metadata_reference.py``).
+* the reference's OWN TEST SUITE and its OWN ``Grid``, live (round 5): ``oracle/run_reference_suite.py`` runs ``xgcm/test/*.py``,
+  unmodified and read in place, against ``xgcm_amd`` (4032 passed on the oracle double, the same with deferred results, 3805 on
+  the host build of the C ABI); ``oracle/fuzz_against_reference.py`` runs the reference's ``Grid`` and ``xgcm_amd.Grid`` side by
+  side on seeded random grids / fields / calls and records the reference's answers as ``tests/golden/fuzz_reference.*``.  Both
+  over the same numpy stand-in for xarray: PINNED MODULO THE STAND-IN.
 * complex topologies (``oracle/topology.py``; fixtures ``fold_reference.json``, ``topology_reference.*``) and the vertical
   transform (``oracle/transform.py``; ``transform_kernels_reference.npz``): PINNED MODULO STAND-INS.  The halo logic and the
   two gufunc bodies that produced those fixtures are the reference's own code, loaded unmodified -- but over builder-written
