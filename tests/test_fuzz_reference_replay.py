@@ -1,11 +1,12 @@
 """Replay of `oracle/fuzz_against_reference.py`'s seeded calls against the answers the REFERENCE's own `Grid` gave.
 
-`tests/golden/fuzz_reference.{json,npz}` (written by `python oracle/fuzz_against_reference.py --cases 120 --seed 2026 --record
+`tests/golden/fuzz_reference.{json,npz}` (written by `python oracle/fuzz_against_reference.py --cases 150 --seed 2026 --record
 tests/golden/fuzz_reference` in the build container, where the reference can be imported) hold, per call, the exception type
 the reference raised or the dims / name / coordinates / values of what it returned.  The INPUTS are regenerated here from
 the seed by the same generator (numpy only), so the test runs wherever the fixture is: oracle double, the host build of the
 C ABI and -- marked gpu -- the HIP library through the C ABI.  Random grids (1-3 axes, 2-3 positions each, any boundary
-condition spelling, user default shifts, metrics at odd positions), random fields (NaNs, float32, integers, permuted dims)
+condition spelling, user default shifts, metrics at odd positions; squares of faces tied by random links; north folds),
+random fields (NaNs, float32, integers, permuted dims)
 and random calls, valid and invalid: diff / interp / min / max / cumsum / derivative / integrate / average / cumint /
 interp_like / get_metric / user grid ufuncs / `pad`.  Live counterpart (fresh seeds, both stacks side by side):
 tests/test_reference_suite_live.py.  Pinned modulo the xarray stand-in the reference ran over.
@@ -80,6 +81,8 @@ def test_seeded_calls_agree_with_the_reference(device_backend, chunk):
             if "hash_seed_dependent" in want:
                 continue  # the reference's answer follows the iteration order of a set of strings: no expectation (see `record_stable`)
             got, exc = F._call(grid, ds, method, var, args, kw, our_pad)
+            if device_backend == "host-abi" and exc is not None and "not part of the host build" in str(exc):
+                continue  # token gathers of connected topologies: outside the host build of the C ABI, and it says so
             if "raises" in want:
                 assert exc is not None, (case, k, method, "the reference raised", want)
                 ill_formed = "more than 1 axis dimension" in str(exc) or "more than 1 axis dimension" in want["message"]

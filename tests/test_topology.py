@@ -730,7 +730,11 @@ def test_faces_with_leading_and_interleaved_dims(backend):
     grid = Grid(ds, coords=COORDS, face_connections=CUBED_SPHERE, autoparse_metadata=False)
     a = R.synthetic_field((2, 6, 3, 4, 4), 32)
     da = DataArray(a, dims=("time", "face", "z", "y", "x"))
-    got = pad(da, grid, padding_width={"X": (1, 1), "Y": (1, 0)}).values
+    got = pad(da, grid, padding_width={"X": (1, 1), "Y": (1, 0)})
+    # a direct `pad` hands the array back as the reference's `xr.concat(faces, dim=facedim)` leaves it: face dim first
+    # (xgcm/padding.py:555; found by oracle/fuzz_against_reference.py); the operators restore the input's order
+    assert got.dims == ("face", "time", "z", "y", "x")
+    got = got.transpose("time", "face", "z", "y", "x").values
     for t in range(2):
         for k in range(3):
             want = T.pad_face_connections(a[t, :, k], ("face", "y", "x"), "face", {"X": "x", "Y": "y"},
@@ -856,7 +860,8 @@ def test_metric_weighted_on_connected_axes_in_one_pass(backend, conn, dtype):
     da = DataArray(a, ("t", "face", "z", "y", "x"))
     for ax, m_in, m_out, num in (("X", "dxc", "dxl", 4), ("Y", "dyc", "dyl", 3)):
         prod = DataArray(a * ds[m_in].values[None, :, None], da.dims)
-        padded = pad(prod, grid, {ax: (1, 0)}, padding="fill", fill_value=2.5).values  # the reference's order: product, then pad
+        # the reference's order: product, then pad (a direct `pad` is face-first, like its concat: back to the input's order)
+        padded = pad(prod, grid, {ax: (1, 0)}, padding="fill", fill_value=2.5).transpose(*da.dims).values
         lo, hi = np.take(padded, range(0, n), axis=num), np.take(padded, range(1, n + 1), axis=num)
         for op, body in (("interp", lambda l, r: (l + r) / dtype(2.0)), ("diff", lambda l, r: r - l),
                          ("min", np.minimum), ("max", np.maximum)):
@@ -871,7 +876,7 @@ def test_metric_weighted_on_connected_axes_in_one_pass(backend, conn, dtype):
     grid2 = Grid(ds2, coords=COORDS, face_connections=connections, padding="fill", fill_value=2.5,
                  metrics={("X",): ["wy"]}, autoparse_metadata=False)
     w = ds2["wy"].values[None, :, None, :, None]
-    padded = pad(DataArray(a * w, da.dims), grid2, {"X": (1, 0)}, padding="fill", fill_value=2.5).values
+    padded = pad(DataArray(a * w, da.dims), grid2, {"X": (1, 0)}, padding="fill", fill_value=2.5).transpose(*da.dims).values
     want = ((padded[..., :-1] + padded[..., 1:]) / dtype(2.0)) / w
     np.testing.assert_array_equal(grid2.interp(da, "X", metric_weighted="X").values, want.astype(dtype))
 
@@ -950,7 +955,7 @@ def test_complex_topology_edge_shapes(backend):
     g4 = Grid(ds4, coords=COORDS, face_connections=X_TO_X, padding="fill", autoparse_metadata=False)
     empty = DataArray(np.zeros((0, 2, 4, 4)), dims=("time", "face", "y", "x"))
     assert g4.diff(empty, "X").shape == (0, 2, 4, 4)
-    assert pad(empty, g4, {"X": (1, 1)}).shape == (0, 2, 4, 6)
+    assert pad(empty, g4, {"X": (1, 1)}).transpose("time", "face", "y", "x").shape == (0, 2, 4, 6)
 
 
 @pytest.mark.parametrize("conn", [X_TO_X, X_TO_Y, X_TO_Y_REV, CUBED_SPHERE], ids=["x2x", "x2y", "x2y_rev", "cubed_sphere"])
@@ -1083,9 +1088,11 @@ def test_unconnected_axes_of_a_connected_grid_keep_the_fused_kernels(backend):
     cz = grid.cumsum(da, "Z", to="left", padding="fill")
     assert cz.dims == ("face", "zl", "y", "x")   # the reference pads every axis of a connected grid through its face concat: face first
     np.testing.assert_array_equal(cz.transpose("zl", "face", "y", "x").values, R.cumsum1d(a, 0, 0, 1, 1, 0, "fill", 0.0, False, True))
-    np.testing.assert_array_equal(pad(da, grid, {"Z": (2, 1)}).values, np.pad(a, [(2, 1), (0, 0), (0, 0), (0, 0)], mode="edge"))
+    pz = pad(da, grid, {"Z": (2, 1)})
+    assert pz.dims == ("face", "z", "y", "x")  # (face first, also when only an unlinked axis is padded: xgcm/padding.py:849-857)
+    np.testing.assert_array_equal(pz.transpose(*da.dims).values, np.pad(a, [(2, 1), (0, 0), (0, 0), (0, 0)], mode="edge"))
     # a pad that mixes a linked and an unlinked axis still goes through the connection logic
-    both = pad(da, grid, {"Z": (1, 0), "X": (1, 1)}).values
+    both = pad(da, grid, {"Z": (1, 0), "X": (1, 1)}).transpose(*da.dims).values
     want = T.pad_face_connections(np.pad(a, [(1, 0), (0, 0), (0, 0), (0, 0)], mode="edge"), ("z", "face", "y", "x"), "face",
                                   {"X": "x", "Y": "y"}, CUBED_SPHERE["face"], ["X", "Y"], {"X": (1, 1)},
                                   {"X": None, "Y": None}, {"X": 0.0, "Y": 0.0})

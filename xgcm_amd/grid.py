@@ -227,17 +227,21 @@ class Grid:
             for pair in links.values():
                 self._connected_axes.update(link[1] for link in pair if link is not None)
 
-    def _links_swap_axes(self, ax_name: str) -> bool:
-        """does any face link on `ax_name` lead to ANOTHER axis of the neighbour (or any link of another axis lead here)?"""
+    def _links_swap_axes(self, ax_name: str, first_face: bool = False):
+        """does any face link on `ax_name` lead to ANOTHER axis of the neighbour (or any link of another axis lead here)?
+        `first_face`: the lowest face number that has such a link (None if none) instead of a bool"""
         if self._face_connections is None:
-            return False
+            return None if first_face else False
+        hits = []
         for faces in self._face_connections.values():
-            for links in faces.values():
+            for face, links in faces.items():
                 for axis, pair in links.items():
                     for link in pair:
                         if link is not None and (axis == ax_name or link[1] == ax_name) and link[1] != axis:
-                            return True
-        return False
+                            hits.append(face)
+        if first_face:
+            return min(hits) if hits else None
+        return bool(hits)
 
     def _validate_folds(self) -> None:
         """Resolve north-fold paddings: the seam is the one explicitly periodic other axis."""
@@ -804,6 +808,25 @@ class Grid:
                     ax._get_position_name(data)
                 if bc is None and not generic_pad:
                     raise no_boundary_error(ax.name)
+                if generic_pad:
+                    # the topology's own refusals (a face the connections leave out, an open edge without a boundary
+                    # condition) come from the reference's pad, i.e. BEFORE the target dim is looked up: run the checks now
+                    swapping = self._links_swap_axes(ax.name, first_face=True) if (trim_lo or trim_hi) else None
+                    trimmed_faces_do_not_fit = ValueError(
+                        # the reference pads the TRIMMED cumulative field through the topology (xgcm/grid.py:1385-1395): across
+                        # a link that swaps axes the trimmed faces (n x (n - 1)) no longer fit each other and its concat fails
+                        f"cumsum along {ax.name!r} from {pos!r} to {ax_to!r} trims the field along an axis whose face "
+                        "connections swap axes: the trimmed faces are no longer square and cannot exchange halos")
+                    try:
+                        pad(data, self, {ax.name: (pad_lo, pad_hi)}, padding=padding, fill_value=fill_value, _dry=True)
+                    except KeyError as missing_face:
+                        # (it walks the faces by number: the concat of a lower face fails before a missing one is looked up)
+                        if swapping is not None and missing_face.args and isinstance(missing_face.args[0], int) \
+                                and swapping < missing_face.args[0]:
+                            raise trimmed_faces_do_not_fit from None
+                        raise
+                    if swapping is not None:
+                        raise trimmed_faces_do_not_fit
             fv = all_fill[ax.name]
             new_dim = ax.coords[ax_to]
             out_dims = tuple(new_dim if d == dim else d for d in data.dims)
@@ -821,12 +844,6 @@ class Grid:
             if generic_pad:
                 # complex topology: the reference pads the TRIMMED cumulative field through the topology (grid.py:1389-1395),
                 # i.e. its halo cells are the neighbouring faces' (the folded row's) cumulative edge values
-                if (pad_lo or pad_hi) and (trim_lo or trim_hi) and self._links_swap_axes(ax.name):
-                    # the reference pads the TRIMMED cumulative field through the topology (xgcm/grid.py:1385-1395): across a
-                    # link that swaps axes the trimmed faces (n x (n - 1)) no longer fit each other and its concat fails
-                    raise ValueError(
-                        f"cumsum along {ax.name!r} from {pos!r} to {ax_to!r} trims the field along an axis whose face "
-                        "connections swap axes: the trimmed faces are no longer square and cannot exchange halos")
                 if pad_lo or pad_hi:
                     # one pass: the scan writes the padded layout (halo cells hold a placeholder), the halo cells are
                     # gathered from that very buffer -- a (pad_lo + pad_hi)-wide slab -- and put in place: no padded copy

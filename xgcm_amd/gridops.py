@@ -157,6 +157,7 @@ class HipGridUFunc(GridUFunc):
             # the ordinary kernel reads the field once: no padded copy (reference: pad, then apply)
             halo = halo_cells(arg, grid, ax_name, (lo, hi), padding=padding, fill_value=fill_value,
                               other_component=other_component)
+            slab_name = halo.name  # (`halo_cells` names its slab as the reference's pad would name the array: face_concat_name)
             if metric_in is not None:
                 # the reference multiplies, then pads the PRODUCT through the topology (grid.py:804-808): its halo cells are
                 # field[src] * metric[src] -- the product of the two halo slabs (a fill cell stays the fill value: the
@@ -170,7 +171,7 @@ class HipGridUFunc(GridUFunc):
                 mh = halo_cells(mh, grid, ax_name, (lo, hi), padding=padding, fill_value=1.0)
                 halo = halo._binary(mh, "mul", dims_order=da.dims)
             data = _same_residency(da.data, _dev.stencil1d_halo(self.funcname, da.data, halo.data, num, lo, hi, m_out, m_in))
-            res = DataArray(data, out_dims, name=da.name)
+            res = DataArray(data, out_dims, name=slab_name if metric_in is None else da.name)
             return _reattach_coords([res], grid, self.padding_width, {out_dim}, [da])[0]
 
         bc = grid._complete_user_kwargs_using_axis_defaults(padding, "padding")[ax_name]

@@ -378,6 +378,12 @@ def defer_stencil(grid, funcname, ufunc, sig, arg, ax_name, other_component, m_i
                        out_dim=out_dim, out_dims=tuple(out_dims), lo=int(lo), hi=int(hi), bc=bc, fv=fv, complex=complex_)
     shape = tuple(n + lo + hi - 1 if d == in_dim else n for d, n in zip(da.dims, da.shape))
     name = da.name
+    if complex_ and (lo or hi) and m_in is None:
+        # (on connected faces the reference's pad may leave the PARTNER's name on a vector component: face_concat_name)
+        from .padding import face_concat_name
+
+        partner = None if other_component is None else _maybe_unpack_vector_component(plain(other_component))
+        name = face_concat_name(grid, da, partner, {ax_name: (lo, hi)})
     for m in (m_in, m_out):  # xarray's name rule for the explicit `* metric` / `/ metric` of the reference
         if m is not None and getattr(m, "name", None) != name:
             name = None

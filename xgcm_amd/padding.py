@@ -73,18 +73,35 @@ def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding
         return data
     data = _strip_all_coords(data)
     connected = getattr(grid, "_connected_axes", ())
-    if getattr(grid, "_face_connections", None) is not None and (
-            halo_only is not None or any(ax in connected and any(w) for ax, w in padding_width.items())):
+    faces = getattr(grid, "_face_connections", None)
+    if faces is not None:
+        # the reference sends EVERY pad of such a grid through `_pad_face_connections` (xgcm/padding.py:849-857), which
+        # walks the faces by number and looks each one up in the connections (:394-396): a face the dict leaves out is
+        # its KeyError, whatever is being padded
+        facedim = grid._facedim
+        first = next(iter(data.values())) if isinstance(data, dict) else data
+        if facedim in first.dims:
+            for i in range(first.sizes[facedim]):
+                if i not in faces[facedim]:
+                    raise KeyError(i)
+    if faces is not None and (halo_only is not None or any(ax in connected and any(w) for ax, w in padding_width.items())):
         # (padding only axes that no link touches is the ordinary per-axis pad: `_pad_face_connections`
         # pre-pads them with `_pad_basic`, overwrites nothing and trims the other axes back to zero width)
-        return _pad_face_connections(data, grid, padding_width, padding, fill_value, other_component, halo_only, dry)
-    if getattr(grid, "_folds", None) and any(ax in grid._folds for ax in padding_width):
-        return _pad_fold(data, grid, padding_width, padding, fill_value, halo_only, dry)
-    if halo_only is not None:
-        raise ValueError("halo-only padding is meant for complex topologies")
-    if isinstance(data, dict):
-        [data] = list(data.values())
-    return _pad_basic(data, grid, padding_width, padding, fill_value)
+        out = _pad_face_connections(data, grid, padding_width, padding, fill_value, other_component, halo_only, dry)
+    elif getattr(grid, "_folds", None) and any(ax in grid._folds for ax in padding_width):
+        out = _pad_fold(data, grid, padding_width, padding, fill_value, halo_only, dry)
+    else:
+        if halo_only is not None:
+            raise ValueError("halo-only padding is meant for complex topologies")
+        if isinstance(data, dict):
+            [data] = list(data.values())
+        out = _pad_basic(data, grid, padding_width, padding, fill_value)
+    if faces is not None and halo_only is None and isinstance(out, DataArray) and grid._facedim in out.dims \
+            and out.dims[0] != grid._facedim:
+        # ... and rebuilds the array with `xr.concat(faces, dim=facedim)` (:555): the face dim comes out FIRST.  The
+        # operators restore the input's order afterwards (`_restore_input_dim_order`); a direct call sees this one (a view)
+        out = out.transpose(grid._facedim, *[d for d in out.dims if d != grid._facedim])
+    return out
 
 
 def _pad_basic(data: DataArray, grid, padding_width, padding, fill_value) -> DataArray:
@@ -366,6 +383,32 @@ def _pad_fold(data, grid, padding_width, padding, fill_value, halo_only=None, dr
 # ------------------------------------------------------------------------------------------
 # face connections (reference padding.py:260-572)
 # ------------------------------------------------------------------------------------------
+def face_concat_name(grid, da, partner, padding_width):
+    """The NAME the reference's face-by-face rebuild leaves on a padded array (xgcm/padding.py:394-555).  Every face is
+    put together by `xr.concat([source_slice, target_slice])` for a LEFT link and `[target_slice, source_slice]` for a right
+    one, over every connected axis (whether padded or not) with the largest requested width; `concat` names its result after
+    its FIRST piece, and the faces are concatenated with face 0 first.  So the name is the one of the source of face 0's
+    last left link: the array's own, or -- for a vector component across an axis-swapping link -- its PARTNER's.  The axes
+    are walked in the order of the reference's `list(set(...))` (:307-309), rebuilt here the same way; results that depend
+    on it are no fixture's business."""
+    links = getattr(grid, "_face_connections", None)
+    if links is None or not isinstance(da, DataArray):
+        return getattr(da, "name", None)
+    facedim = grid._facedim
+    named = []
+    for c in links[facedim].values():
+        named.extend(list(c.keys()))
+    pad_axes = list(set(list(set(named)) + list(padding_width.keys())))
+    if max([v for w in padding_width.values() for v in w] + [0]) == 0:
+        return da.name
+    name = da.name
+    for ax in pad_axes:
+        left = links[facedim].get(0, {}).get(ax, (None, None))[0]
+        if left:
+            name = partner.name if (partner is not None and left[1] != ax) else da.name
+    return name
+
+
 def _infer_vector_component_axis(grid, da) -> str:
     """Which axis does a bare vector component point along?  A C-grid component sits on cell EDGES along its own
     axis and in cell centres along the others, so the answer is the one axis that contributes a non-centre dim to
@@ -483,4 +526,7 @@ def _pad_face_connections(da, grid, padding_width, padding, fill_value, other_co
                     own = [c for c in cand if c in da.dims]
                     if own:
                         same_as[d] = own[0]
-    return _gather(da, partner, grid, key, build, same_as, None if halo_only is None else dims_own[halo_only], dry)
+    out = _gather(da, partner, grid, key, build, same_as, None if halo_only is None else dims_own[halo_only], dry)
+    if isinstance(out, DataArray):
+        out = out._replace(name=face_concat_name(grid, da, partner, padding_width))
+    return out
