@@ -927,7 +927,8 @@ def test_resident_tensors_on_complex_topologies():
                                       ["X", "Y"], {"Y": (1, 0)}, {"X": None, "Y": None}, {"X": 0.0, "Y": 0.0})
         np.testing.assert_array_equal(out.values, want[:, :, 1:] - want[:, :, :-1])
     padded = pad(da, grid, {"X": (1, 1)})
-    assert isinstance(padded.data, torch.Tensor) and padded.shape == (3, 6, 8, 10)
+    # (a direct pad is face-first, like the reference's concat: a VIEW of the resident result)
+    assert isinstance(padded.data, torch.Tensor) and padded.dims == ("face", "z", "y", "x") and padded.shape == (6, 3, 8, 10)
     entries = [e for e in grid._halo_maps.values() if e["device"] is not None]
     assert entries and all(isinstance(e["device"], torch.Tensor) for e in entries)
 
