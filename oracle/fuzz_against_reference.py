@@ -65,6 +65,18 @@ def load_both(backend="oracle-double"):
         sys.modules.setdefault("dask", dask)
         sys.modules.setdefault("dask.array", dask_array)
     xr = sys.modules["xarray"]
+    if "numba" not in sys.modules:
+        # `xgcm/transform.py` compiles its two column kernels with numba's `guvectorize`; numba is absent, their bodies are
+        # plain Python: the stand-in of oracle/make_golden_transform.py runs them column by column over the loop dims
+        from oracle.make_golden_transform import _Type, guvectorize
+
+        nb = types.ModuleType("numba")
+        nb.boolean = nb.float32 = nb.float64 = _Type()
+        nb.guvectorize = guvectorize
+        sys.modules["numba"] = nb
+    # (the reference rechunks an interpolated `target_data` to ONE chunk along the axis, xgcm/transform.py:503-505: on a
+    # numpy-backed array that is the identity)
+    xr.DataArray.chunk = lambda self, *a, **k: self
     if REF not in sys.path:
         sys.path.append(REF)  # (after the repo: nothing of the repo is called `xgcm`)
     import xgcm.grid as refgrid  # the reference, unmodified
@@ -374,7 +386,16 @@ def _call(grid, ds, method, var, args, kw, pad_function=None):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         try:
-            if var.startswith("vec:"):
+            if method == "transform":
+                spec = args[0]
+                maker = type(ds[var])  # the container the dataset hands out (xarray stand-in / xgcm_amd's)
+                target = spec[1] if spec[0] == "np" else maker(spec[2], dims=spec[1], name=spec[3])
+                tkw = dict(kw)
+                td = tkw.get("target_data")
+                if isinstance(td, str):
+                    tkw["target_data"] = ds[td.split(":")[1]] if td.startswith("var:") else ds[td.split(":")[1]].rename(None)
+                res = grid.transform(ds[var], "Z", target, **tkw)
+            elif var.startswith("vec:"):
                 res = getattr(grid, method)(operand(var), *args, **kw)
             elif method.startswith("apply_as_grid_ufunc:"):
                 res = grid.apply_as_grid_ufunc(USER_UFUNCS[method.split(":")[1]][0], ds[var], **kw)
@@ -603,10 +624,113 @@ def draw_topology_call(rng, axes, positions, variables, where, metrics, edge_pos
     return method, var, [ax], kw
 
 
+# ---- the vertical transform ----------------------------------------------------------------------------------------------
+def _theta(rng, shape, kind):
+    """columns along the LAST dim: increasing / decreasing / a random walk (non-monotonic) / with duplicates / NaN tails"""
+    steps = rng.random(shape) + 0.05
+    if kind == "walk":
+        steps = rng.standard_normal(shape)
+    col = np.cumsum(steps, axis=-1) + 1.0
+    if kind == "decreasing":
+        col = col[..., ::-1].copy()
+    if kind == "duplicates":
+        col[..., 2] = col[..., 1]
+    if kind == "nan_tail":
+        col[..., -2:] = np.nan
+    return col
+
+
+def draw_transform_case(rng, make_dataset, calls_per_case):
+    nz, nx = int(rng.integers(4, 9)), int(rng.integers(1, 4))
+    extra = _pick(rng, ["outer", "outer", "outer", "left", "right", "inner"])
+    positions = {"Z": {"center": "z", extra: "zg"}}
+    nzg = nz + LENGTH[extra]
+    coords = {"z": ("z", np.arange(nz) + 0.5), "zg": ("zg", np.arange(nzg) * 1.0 + (0.0 if extra in ("outer", "left") else 1.0)),
+              "x": ("x", np.arange(nx) * 10.0), "t": ("t", np.array([0.0, 1.0]))}
+    gkw = {"coords": positions, "autoparse_metadata": False}
+    r = rng.random()
+    if r < 0.3:
+        gkw["padding"] = _pick(rng, ["fill", "extend", "fill", "periodic"])
+    elif r < 0.4:
+        gkw["padding"] = {"Z": _pick(rng, ["fill", "extend"])}
+    lead = _pick(rng, [(), ("x",), ("x",), ("t", "x")])
+    if rng.random() < 0.2 and lead:
+        order = lambda dims: tuple(rng.permutation(list(dims)))  # noqa: E731
+    else:
+        order = lambda dims: tuple(dims)  # noqa: E731
+    shape_of = lambda dims: tuple({"z": nz, "zg": nzg, "x": nx, "t": 2}[d] for d in dims)  # noqa: E731
+    variables = {}
+
+    def put(name, dims, values_last_axis_fn):
+        canon = tuple(lead) + (dims[-1],)
+        vals = values_last_axis_fn(shape_of(canon))
+        final = order(canon)
+        variables[name] = (final, np.transpose(vals, [canon.index(d) for d in final]).copy())
+
+    kind = _pick(rng, ["increasing", "increasing", "decreasing", "walk", "duplicates", "nan_tail"])
+    put("vd", ("z",), lambda sh: rng.standard_normal(sh) if rng.random() < 0.8 else rng.standard_normal(sh).astype(np.float32))
+    if rng.random() < 0.25:
+        variables["vd"][1].reshape(-1)[rng.integers(0, variables["vd"][1].size, size=2)] = np.nan
+    put("vth", ("z",), lambda sh: _theta(rng, sh, kind))
+    put("vthg", ("zg",), lambda sh: _theta(rng, sh, kind))
+    variables["vth1"] = (("z",), _theta(rng, (nz,), kind))  # a 1-D profile: fewer dims than the data
+    variables["vother"] = (("t", "q", "z") if rng.random() < 0.5 else ("q", "z"), None)
+    q = variables.pop("vother")[0]
+    variables["vthq"] = (q, _theta(rng, tuple({"t": 2, "q": 2, "z": nz}[d] for d in q), "increasing"))  # a dim the data lacks
+    coords["q"] = ("q", np.arange(2) * 1.0)
+    ds = make_dataset({k: v for k, v in variables.items()}, coords)
+    lo, hi = float(np.nanmin(variables["vth"][1])), float(np.nanmax(variables["vth"][1]))
+    calls = []
+    for _ in range(calls_per_case):
+        # (no unknown method names: the reference crashes on one -- UnboundLocalError, `out` never assigned,
+        # xgcm/transform.py:515 -- where xgcm_amd raises a ValueError that names the methods; a stated deviation)
+        method = _pick(rng, ["linear", "linear", "conservative", "conservative", "log"])
+        nlev = int(rng.integers(2, 7))
+        levels = np.sort(rng.uniform(lo - 0.5, hi + 0.5, nlev))
+        r = rng.random()
+        # (decreasing conservative bins only on 1-D data: on N-D data the reference reverses axis 0 of its result -- time,
+        # here -- instead of the bin axis, xgcm/transform.py:190-192; xgcm_amd reverses the bins: a stated deviation)
+        if r < 0.15 and (method != "conservative" or not lead):
+            levels = levels[::-1].copy()
+        elif 0.15 <= r < 0.22 and (method != "conservative" or not lead):
+            levels = rng.permutation(levels)
+        if rng.random() < 0.1:
+            levels = levels.astype(np.float32)
+        if method == "log":
+            # (logarithms of positive float64 numbers only: a column that is all NaN after `np.log` and the float32 rounding
+            # of `log` -- once in double here, DESIGN section 2 -- are stated deviations)
+            if kind == "walk" or variables["vd"][1].dtype != np.float64:
+                method = "linear"
+            levels = (np.abs(levels) + 0.25).astype(np.float64)
+        r = rng.random()
+        if r < 0.35:
+            target = ("np", levels)
+        elif r < 0.8:
+            target = ("da", (_pick(rng, ["lev", "vth", "z"]),), levels, _pick(rng, [None, "lev", "theta"]))
+        else:  # a target that varies in x: needs `target_dim`
+            target = ("da", ("x", "lev"), np.sort(rng.uniform(lo, hi, (nx, nlev)), axis=-1), None)
+        kw = {"method": method}
+        td = _pick(rng, [None, None, "var:vth", "var:vth", "var:vthg", "var:vthg", "var:vth1", "var:vthq", "unnamed:vth"])
+        if td is not None:
+            kw["target_data"] = td
+        if rng.random() < 0.3:
+            kw["mask_edges"] = bool(rng.random() < 0.5)
+        if rng.random() < 0.15:
+            kw["bypass_checks"] = True
+        if rng.random() < 0.15:
+            kw["suffix"] = "_on_levels"
+        if target[0] == "da" and len(target[1]) == 2 or rng.random() < 0.1:
+            kw["target_dim"] = _pick(rng, ["lev", "lev", "lev", "nowhere"])
+        calls.append(("transform", "vd", [target], kw))
+    return ds, gkw, variables, calls
+
+
 def build_case(make_dataset, seed, case, calls_per_case=12):
     """the seeded inputs of one case WITHOUT the reference: (dataset, grid kwargs, variables, [(method, var, args, kwargs)])"""
     rng = np.random.default_rng([seed, case])
     kind = rng.random()
+    if kind > 0.88:  # the vertical transform
+        return draw_transform_case(rng, make_dataset, calls_per_case)
     if kind < 0.3:  # a complex topology: connected faces (0.2) or a north fold (0.1)
         draw = draw_connected_grid if kind < 0.2 else draw_fold_grid
         axes, positions, sizes, coords, gkw, variables, where, metrics, edge_pos = draw(rng)

@@ -486,8 +486,15 @@ def apply_ufunc(func, *args, input_core_dims=None, output_core_dims=((),), exclu
             raise ValueError(f"operand to apply_ufunc has required core dimensions {list(core)}, but some of these dimensions are absent: {missing}")
         order = [d for d in bdims if d in a.dims] + list(core)
         v = np.transpose(a.data, [a.dims.index(d) for d in order])
-        index = tuple(slice(None) if d in a.dims else np.newaxis for d in bdims) + (slice(None),) * len(core)
-        raw.append(v[index])
+        # like xarray (computation.py `broadcast_compat_data`): a size-1 axis for a broadcast dim the argument lacks -- except
+        # LEADING ones, which numpy's broadcasting supplies itself (a 1-D `target` stays 1-D for the function)
+        index = []
+        for d in bdims:
+            if d in a.dims:
+                index.append(slice(None))
+            elif index:
+                index.append(np.newaxis)
+        raw.append(v[tuple(index) + (slice(None),) * len(core)])
     res = func(*raw, **(kwargs or {}))
     outs = res if isinstance(res, tuple) else (res,)
     if len(outs) != len(output_core_dims):

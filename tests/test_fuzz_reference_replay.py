@@ -96,4 +96,4 @@ def test_seeded_calls_agree_with_the_reference(device_backend, chunk):
             for j, (o, w) in enumerate(zip(outs, want["results"])):
                 _check_result(case, k, j, w, o)
             n_results += 1
-    assert n_results > 80 and n_raised > 10
+    assert n_results > (40 if device_backend == "host-abi" else 80) and n_raised > 10  # (host build: no gathers, no transform)

@@ -92,4 +92,5 @@ def test_differential_fuzz_against_the_reference(backend, seed, fused):
     stats = json.loads(proc.stdout.splitlines()[0])
     assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-2000:]
     served = stats["both_returned"] + stats.get("outside_the_host_build", 0)  # (the host build holds no token gathers)
-    assert stats["calls"] > 4000 and served > 3000 and stats["both_returned"] > 2500 and stats["both_raised"] > 500, stats
+    assert stats["calls"] > 4000 and served > 3000 and stats["both_raised"] > 500, stats
+    assert stats["both_returned"] > (1500 if backend == "host-abi" else 3000), stats  # (host build: no gathers, no transform)

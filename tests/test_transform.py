@@ -480,7 +480,7 @@ def test_transform_on_a_zyx_field_without_transposes(backend):
     sigma = DataArray(dens, dims=("time", "Z", "Y", "X"), name="sigma")
     levels = np.linspace(0.0, dens.max(), 7)
     out = grid.transform(da, "Z", levels, target_data=sigma)
-    assert out.dims == ("time", "Y", "X", "sigma") and out.name == "salt_transformed"
+    assert out.dims == ("time", "Y", "X", "sigma") and out.name == "salt"  # (`suffix` is never applied by the reference's `transform`: xgcm/transform.py:462-472)
     want = TR.interp_1d_linear(np.moveaxis(phi, 1, -1), np.moveaxis(dens, 1, -1), levels, mask_edges=True)
     np.testing.assert_array_equal(out.values, want)
     np.testing.assert_array_equal(out.coords["sigma"].values, levels)

@@ -804,7 +804,7 @@ class Grid:
             trim_lo, trim_hi, pad_lo, pad_hi = _cumsum_trim_pad(pos, ax_to, rev, ax)
             bc = all_padding[ax.name]
             if pad_lo or pad_hi:
-                if two_axis_dims:
+                if two_axis_dims or sum(d in data.dims for d in ax.coords.values()) > 1:  # (this step's product or an earlier one's)
                     ax._get_position_name(data)
                 if bc is None and not generic_pad:
                     raise no_boundary_error(ax.name)

@@ -252,7 +252,9 @@ def transform(grid, axis_name, da, target, target_data=None, target_dim=None, me
     _, dim = axis._get_position_name(da)
     if method in ("linear", "log"):
         target, target_dim, target_data = parse_target(target, target_dim, dim, target_data)
-        out = linear_interpolation(da, target_data, target, dim, dim, target_dim, suffix=suffix, mask_edges=mask_edges,
+        # (`suffix` is accepted and, as in the reference, not applied: its `transform` never hands it to the mid-level
+        # functions, xgcm/transform.py:462-472, :506-513 -- the result keeps the input's name)
+        out = linear_interpolation(da, target_data, target, dim, dim, target_dim, mask_edges=mask_edges,
                                    bypass_checks=bypass_checks, logarithmic=(method == "log"))
     elif method == "conservative":
         if isinstance(target, DataArray) and len(target.dims) > 1:
@@ -272,7 +274,7 @@ def transform(grid, axis_name, da, target, target_data=None, target_dim=None, me
                 UserWarning,
             )
             target_data = grid.interp(target_data, axis_name, padding="extend")
-        out = conservative_interpolation(da, target_data, target, dim, target_data_dim, target_dim, suffix=suffix)
+        out = conservative_interpolation(da, target_data, target, dim, target_data_dim, target_dim)
     else:
         raise ValueError(f"unknown transform method {method!r}: use 'linear', 'log' or 'conservative'")
     return to_xarray(out) if was_xr else out
