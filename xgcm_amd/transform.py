@@ -122,6 +122,22 @@ def _check_labelled(*named):
 def _column_call(kind: str, phi: DataArray, theta: DataArray, target: DataArray, phi_dim: str, theta_dim: str,
                  target_dim: str, **kwargs) -> DataArray:
     """Shared plumbing of the two interpolations: align dims, one kernel launch, reference dim order."""
+    # what `xr.apply_ufunc` and the column kernels refuse, refused HERE -- before any pointer reaches a kernel
+    for what, arr, core in (("phi", phi, phi_dim), ("theta", theta, theta_dim), ("target", target, target_dim)):
+        if core not in arr.dims:
+            raise ValueError(f"operand to apply_ufunc has required core dimensions {[core]}, but some of these dimensions are "
+                             f"absent on an input variable: {[core]}")
+    n_phi, n_theta = phi.sizes[phi_dim], theta.sizes[theta_dim]
+    if kind == "linear" and n_theta != n_phi:
+        raise ValueError(f"fp and xp are not of the same length: {n_phi} values of the field along {phi_dim!r}, {n_theta} of "
+                         f"`target_data` along {theta_dim!r}")
+    if kind == "conservative" and n_theta != n_phi + 1:  # (the reference's `assert`, xgcm/transform.py:169)
+        raise AssertionError(f"conservative interpolation needs `target_data` on the {n_phi + 1} cell bounds of the {n_phi} cells "
+                         f"along {phi_dim!r}; it has {n_theta} along {theta_dim!r}")
+    for a, b in ((phi, theta), (phi, target), (theta, target)):
+        for d in a.dims:
+            if d in b.dims and d not in (phi_dim, theta_dim, target_dim) and a.sizes[d] != b.sizes[d]:
+                raise ValueError(f"operands could not be broadcast together: dimension {d!r} has sizes {a.sizes[d]} and {b.sizes[d]}")
     others = _ordered_union([d for d in phi.dims if d != phi_dim], [d for d in theta.dims if d != theta_dim],
                             [d for d in target.dims if d != target_dim] if kind == "linear" else [])
     extra = [d for d in others if d not in phi.dims]
