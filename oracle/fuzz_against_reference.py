@@ -176,8 +176,13 @@ def draw_variables(rng, axes, positions, sizes):
             a = a.astype(np.float32)
         elif kind < 0.42:
             a = rng.integers(-9, 9, size=shape).astype(np.int64)
+        elif kind < 0.50:  # what files hold: other byte orders, narrow integers, bool (numpy computes them as they are)
+            a = _pick(rng, [lambda: a.astype(">f8"), lambda: a.astype(">f4"), lambda: rng.integers(-9, 9, size=shape).astype(np.int32),
+                            lambda: rng.integers(0, 200, size=shape).astype(np.uint8), lambda: rng.integers(-9, 9, size=shape).astype(">i4"),
+                            lambda: rng.integers(0, 9, size=shape).astype(np.uint32), lambda: rng.random(shape) < 0.5,
+                            lambda: rng.integers(-90, 90, size=shape).astype(np.int16)])()
         name = f"v{i}"
-        variables[name] = (tuple(dims), a)
+        variables[name] = (tuple(dims), a) if rng.random() < 0.7 else (tuple(dims), a, {"units": "K", "long_name": name})
         where[name] = pos
     return variables, where
 
@@ -364,12 +369,15 @@ def draw_call(rng, axes, positions, variables, where, metrics):
     elif method == "get_metric":
         k = int(rng.integers(1, len(axes) + 1))
         args = [tuple(rng.choice(axes, size=k, replace=False).tolist())]
+    if method not in ("get_metric", "interp_like") and rng.random() < 0.12:
+        kw["_recast"] = True
     return method, var, args, kw
 
 
 # ---- running one call on both grids ---------------------------------------------------------------------------------------
 def _describe(res):
-    return {"dims": tuple(res.dims), "name": res.name, "dtype": str(np.asarray(res.values).dtype), "coords": sorted(res.coords)}
+    return {"dims": tuple(res.dims), "name": res.name, "dtype": str(np.asarray(res.values).dtype), "coords": sorted(res.coords),
+            "attrs": dict(res.attrs)}
 
 
 def _call(grid, ds, method, var, args, kw, pad_function=None):
@@ -402,7 +410,12 @@ def _call(grid, ds, method, var, args, kw, pad_function=None):
             elif method == "pad":
                 res = pad_function(ds[var], grid, args[0], **kw)
             else:
-                res = getattr(grid, method)(ds[var], *args, **kw)
+                da = ds[var]
+                if kw.get("_recast"):  # coordinates the user changed on the INPUT (non-core ones must survive, GH #496)
+                    kw = {k: v for k, v in kw.items() if k != "_recast"}
+                    if "t" in da.dims:
+                        da = da.assign_coords(t=np.array([100.0, 200.0]), label=("t", np.array([7, 8])), extra=("t", np.array([0.5, 1.5])))
+                res = getattr(grid, method)(da, *args, **kw)
             if hasattr(res, "compute") and type(res).__name__ == "LazyArray":
                 res = res.compute()  # (the deferred mode: the value is what is compared)
             return res, None
@@ -432,7 +445,7 @@ def compare(ref, ref_exc, got, got_exc):
             return f"number of results: reference {type(ref).__name__}, xgcm_amd {type(got).__name__}"
         return next((d for d in (compare(r, None, g, None) for r, g in zip(ref, got)) if d is not None), None)
     a, b = _describe(ref), _describe(got)
-    for key in ("dims", "name", "coords", "dtype"):
+    for key in ("dims", "name", "coords", "dtype", "attrs"):
         if a[key] != b[key]:
             return f"{key}: reference {a[key]!r}, xgcm_amd {b[key]!r}"
     x, y = np.asarray(ref.values), np.asarray(got.values)

@@ -34,6 +34,7 @@ from typing import Any, Dict, Iterable, List, Mapping, Optional, Tuple
 import numpy as np
 
 from . import device as _dev
+from . import dtypes as _dt
 from . import gridops
 from .axis import Axis
 from .grid_ufunc import (
@@ -674,6 +675,8 @@ class Grid:
                     return None
                 if tuple(m.dims) != tuple(dims[-2:]) or tuple(m.shape) != tuple(array.shape[-2:]):
                     return None  # broadcast / extra dims: the per-axis kernels take any metric pattern
+                if _dt.np_dtype(m.data) != _dt.np_dtype(array.data):
+                    return None  # mixed precision (a float32 field, float64 metrics): numpy's steps, one axis at a time
                 planes.append(self._resident(m, array.data).data)
                 named = _name_after(named, m)
         out = _dev.stencil2d(funcname, array.data, 0 if x_is_a else 1, padx, bc[ax_x], float(fv[ax_x] or 0.0), pady,
@@ -900,7 +903,9 @@ class Grid:
             weight = self._resident(self.get_metric(da, axis, _layout=da.dims), da.data)
             out = (da * weight).sum(dims, skipna=skip, keep_attrs=keep_attrs)
         else:
-            out = self._weighted_reduce(da, factors, dims, skip, keep_attrs)
+            # (`keep_attrs` keeps the attrs of what is summed -- the PRODUCT `da * metric`, which has none: xarray's binary
+            # operators drop them; the reference's results carry no attrs either way)
+            out = self._weighted_reduce(da, factors, dims, skip, False)
             # `da * weight` of the reference: nameless unless the weight carries the field's name (xarray's rule); a weight
             # that is itself a product of several metrics has no name
             weight_name = factors[0].name if len(factors) == 1 else None
@@ -1226,6 +1231,8 @@ def _ones_like(data):
 def _valid_mask(da: DataArray) -> DataArray:
     """1.0 where `da` is not NaN else 0.0, computed on the GPU as (da - da) == 0 -> via min/max-free arithmetic."""
     # x - x is 0 for finite x and NaN for NaN/inf; nan-skipping sum of (x - x + 1) over a length-1 axis gives the mask
+    if gridops.is_integer_data(da.data):  # integers and bool hold no NaN (and numpy refuses `bool - bool`)
+        return da._replace(data=_ones_like(da.data), coords=OrderedDict(), name=None)
     z = da - da
     one = z + 1.0
     host = not _is_tensor(one.data)

@@ -31,6 +31,11 @@ from .labeled import DataArray, _is_tensor, from_xarray, is_xarray, to_xarray
 _XGCM_BOUNDARY_KWARG_TO_XARRAY_PAD_KWARG = {"periodic": "wrap", "fill": "constant", "extend": "edge"}
 
 
+def _np_dtype_of(da):
+    data = getattr(da, "data", None)
+    return data.dtype if isinstance(data, np.ndarray) else None
+
+
 def no_boundary_error(ax: str) -> ValueError:
     """The reference's message for a padded axis with `padding=None` (padding.py:601-608)."""
     return ValueError(
@@ -77,13 +82,12 @@ def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding
     if faces is not None:
         # the reference sends EVERY pad of such a grid through `_pad_face_connections` (xgcm/padding.py:849-857), which
         # walks the faces by number and looks each one up in the connections (:394-396): a face the dict leaves out is
-        # its KeyError, whatever is being padded
+        # its KeyError, whatever is being padded -- raised below, once nothing else has objected
         facedim = grid._facedim
         first = next(iter(data.values())) if isinstance(data, dict) else data
+        missing_face = None
         if facedim in first.dims:
-            for i in range(first.sizes[facedim]):
-                if i not in faces[facedim]:
-                    raise KeyError(i)
+            missing_face = next((i for i in range(first.sizes[facedim]) if i not in faces[facedim]), None)
     if faces is not None and (halo_only is not None or any(ax in connected and any(w) for ax, w in padding_width.items())):
         # (padding only axes that no link touches is the ordinary per-axis pad: `_pad_face_connections`
         # pre-pads them with `_pad_basic`, overwrites nothing and trims the other axes back to zero width)
@@ -96,6 +100,16 @@ def pad(data, grid, padding_width: Optional[Dict[str, Tuple[int, int]]], padding
         if isinstance(data, dict):
             [data] = list(data.values())
         out = _pad_basic(data, grid, padding_width, padding, fill_value)
+    if faces is not None and missing_face is not None:
+        raise KeyError(missing_face)  # (after the refusals above: the reference checks boundary conditions before it walks the faces)
+    if halo_only is None and isinstance(out, DataArray):
+        # `DataArray.pad` keeps the array's attrs, and `numpy.pad` its dtype -- byte order included (the operators go on
+        # computing, which makes numpy's results native; a direct call sees the padded array itself)
+        first = next(iter(data.values())) if isinstance(data, dict) else data
+        out.attrs = dict(getattr(first, "attrs", None) or {})
+        want = _np_dtype_of(first)
+        if want is not None and not want.isnative and not _is_tensor(out.data) and np.asarray(out.data).dtype != want:
+            out = out._replace(data=np.asarray(out.data).astype(want))
     if faces is not None and halo_only is None and isinstance(out, DataArray) and grid._facedim in out.dims \
             and out.dims[0] != grid._facedim:
         # ... and rebuilds the array with `xr.concat(faces, dim=facedim)` (:555): the face dim comes out FIRST.  The
