@@ -686,6 +686,20 @@ def pad_nd(x, widths: dict, bc: dict, fill: dict) -> torch.Tensor:
         order.append(ax)
     order += [d for d in range(nd) if d not in order]
     oshape = [s + l + h for s, l, h in zip(x.shape, lo, hi)]
+    if x.numel() == 0 and any(oshape):
+        # nothing to read, cells only from the padding (a user ufunc that consumed its whole short axis, padded afterwards):
+        # numpy.pad's own rules on the empty array -- 'constant' fills, any other mode on an empty axis is its ValueError --
+        # then one upload; there is no kernel to launch over zero input cells
+        modes = {0: None, _hip.BC["fill"]: "constant", _hip.BC["periodic"]: "wrap", _hip.BC["extend"]: "edge"}
+        host = np.empty(tuple(x.shape), dtype=_dt._TORCH_TO_NUMPY[dt])
+        for ax in order:
+            if lo[ax] or hi[ax]:
+                width = [(0, 0)] * nd
+                width[ax] = (lo[ax], hi[ax])
+                mode = modes[bcv[ax]]
+                host = np.pad(host, width, mode=mode, **({"constant_values": fv[ax]} if mode == "constant" else {}))
+        out = asdevice(host, dt)
+        return _narrow(out, src) if ints else _out(out, half)
     out = _empty(oshape, dtype=dt, device=x.device)
     if out.numel() == 0:
         return _narrow(out, src) if ints else _out(out, half)
