@@ -1,6 +1,6 @@
 """Replay of `oracle/fuzz_against_reference.py`'s seeded calls against the answers the REFERENCE's own `Grid` gave.
 
-`tests/golden/fuzz_reference.{json,npz}` (written by `python oracle/fuzz_against_reference.py --cases 150 --seed 2026 --record
+`tests/golden/fuzz_reference.{json,npz}` (written by `python oracle/fuzz_against_reference.py --cases 400 --seed 2026 --record
 tests/golden/fuzz_reference` in the build container, where the reference can be imported) hold, per call, the exception type
 the reference raised or the dims / name / coordinates / values of what it returned.  The INPUTS are regenerated here from
 the seed by the same generator (numpy only), so the test runs wherever the fixture is: oracle double, the host build of the
