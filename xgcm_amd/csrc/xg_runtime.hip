@@ -67,6 +67,7 @@ const TuneEntry TUNABLES[] = {
     {"reduce_sk", &Tune::reduce_sk, 1},
     {"reduce_ru", &Tune::reduce_ru, 1},
     {"reduce_wfast", &Tune::reduce_wfast, 1},
+    {"reduce_wg", &Tune::reduce_wg, 0},
     {"scan_sh1", &Tune::scan_sh1, 1},
     {"reduce_ldsw", &Tune::reduce_ldsw, 2},
     {"dbg", &Tune::dbg, 0},

@@ -1384,6 +1384,123 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
   }
 }
 
+// K4w: the same sums with one WORKGROUP per row: the 4 waves of a workgroup read ADJACENT 1-KB pieces of the row, so a
+// workgroup streams one contiguous 4-KB window per step (a 28.8-KB row of the bench grid is ONE batch of 8 loads per lane)
+// and the launch keeps a quarter as many separate row streams open at any moment as K4b does.  Per-wave shuffle trees, the
+// 4 partial sums through LDS in wave order (re-associated like K4b: tolerance parity).  Aligned vector rows only (VEC),
+// weights in the WFAST form or none.
+template <bool HAS_W, int SK>
+__global__ __launch_bounds__(BLOCK) void k_reduce_contig_wg(const real* __restrict__ in, real* __restrict__ out, Geo g,
+                                                            int skipna_rt, const real* __restrict__ wgt, MIdx mw, int ntl, ZBand zb) {
+  __shared__ real part[2][WPB];
+  int skipna = (SK >= 0) ? SK : skipna_rt;
+  // workgroup b runs on XCD b mod 8: the linear row order is cut into 8 contiguous bands, one per XCD (rule 3), so that
+  // the levels of a band that share weight rows meet in ONE L2
+  u64 row = (u64)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (zb.on) {
+    u32 z, y;
+    if (row >= (u64)zb.per_band.d * ((zb.Y + zb.B - 1) / zb.B)) return;
+    if (!zband_map(zb, (u32)row, z, y)) return;
+    row = (u64)z * zb.Y + y;
+  }
+  if ((int64_t)row >= g.outer) return;
+  const int lane = threadIdx.x & 63;
+  const int wv_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n = g.n_in;
+  const real* prow = in + row * n;
+  int64_t mb = 0;
+  if (HAS_W) mb = outer_off(g, mw, row);
+  const real* wrow = HAS_W ? wgt + mb : nullptr;
+  const bool pair = skipna >= 6;
+  if (pair) skipna -= 2;
+  const bool mean = skipna >= 4;
+  const int nmode = mean ? (skipna == 4 ? 1 : 0) : skipna, dmode = skipna == 4 ? 2 : 3;
+  real acc = real(0), den = real(0);
+  auto terms = [&](real v, real wv, real& num, real& dn) {
+    if (mean) {
+      dn = as_count(v, dmode);
+      if (HAS_W) dn = dn * wv;
+      dn = nan0(dn);
+    }
+    if (nmode >= 2) v = as_count(v, nmode);
+    if (HAS_W) v = v * wv;
+    if (nmode) v = nan0(v);
+    num = v;
+  };
+  const int64_t lead = (NV - (int64_t)((row * (u64)n) % NV)) % NV;
+  dv a = splat<dv>(real(0)), ad = splat<dv>(real(0));
+  const int64_t nvec = (n - lead) / NV;
+  auto ldv = [&](int64_t k) -> dv {
+    return (ntl & 1) ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(prow + k)) : *reinterpret_cast<const dv*>(prow + k);
+  };
+  auto add = [&](const dv& v, const dv& wv) {
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      real num, dn = real(0);
+      terms(v[c], wv[c], num, dn);
+      a[c] += num;
+      ad[c] += dn;
+    }
+  };
+  int64_t t = threadIdx.x;  // vector index within the row: thread id == memory order across the whole workgroup
+  auto batches = [&](auto ru) {
+    constexpr int RU = decltype(ru)::value;
+    for (; t + (RU - 1) * BLOCK < nvec; t += RU * BLOCK) {
+      dv v[RU], wv[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int64_t k = lead + (t + u * BLOCK) * NV;
+        v[u] = ldv(k);
+        if constexpr (!HAS_W) wv[u] = splat<dv>(real(1));
+        else wv[u] = *reinterpret_cast<const dv*>(wrow + k);
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) add(v[u], wv[u]);
+    }
+  };
+  batches(std::integral_constant<int, 8>{});
+  batches(std::integral_constant<int, 4>{});
+  batches(std::integral_constant<int, 2>{});
+  for (; t < nvec; t += BLOCK) {
+    const int64_t k = lead + t * NV;
+    const dv v = ldv(k);
+    dv wv = splat<dv>(real(1));
+    if constexpr (HAS_W) wv = *reinterpret_cast<const dv*>(wrow + k);
+    add(v, wv);
+  }
+#pragma unroll
+  for (int c = 0; c < NV; ++c) { acc += a[c]; den += ad[c]; }
+  if (wv_id == 0) {  // the cells before the row's first / after its last 16-B boundary (<= NV - 1 each)
+    const int64_t k0 = lead + nvec * NV;
+    if (lane < lead) {
+      real num, dn = real(0);
+      terms(prow[lane], HAS_W ? wrow[lane] : real(1), num, dn);
+      acc += num;
+      den += dn;
+    }
+    if (k0 + lane < n) {
+      real num, dn = real(0);
+      terms(prow[k0 + lane], HAS_W ? wrow[k0 + lane] : real(1), num, dn);
+      acc += num;
+      den += dn;
+    }
+  }
+#pragma unroll
+  for (int d = WAVE / 2; d > 0; d >>= 1) {
+    acc += __shfl_down(acc, d, WAVE);
+    den += __shfl_down(den, d, WAVE);
+  }
+  if (lane == 0) { part[0][wv_id] = acc; part[1][wv_id] = den; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    real s = part[0][0], sd = part[1][0];
+#pragma unroll
+    for (int w = 1; w < WPB; ++w) { s += part[0][w]; sd += part[1][w]; }
+    if (pair) { out[row] = s; out[g.outer + row] = sd; }
+    else out[row] = mean ? s / sd : s;
+  }
+}
+
 }  // namespace
 
 // geometry of the marching twin (8-byte lanes, XCD-banded wave order) that follows every chained launch as its rescue
@@ -1638,10 +1755,18 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
 #define XG_RC(W_, V_, S_) hipLaunchKernelGGL((k_reduce_contig<W_, V_, S_>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zb)
 #define XG_RS(W_, V_) do { if (sk == 0) XG_RC(W_, V_, 0); else if (sk == 1) XG_RC(W_, V_, 1); else XG_RC(W_, V_, -1); } while (0)
 #define XG_RF(S_) hipLaunchKernelGGL((k_reduce_contig<true, true, S_, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zb)
+    // K4w: a workgroup per row (weights as in WFAST: unit stride, rows 16-B aligned like the field's)
+    const bool wg_ok = tune().reduce_wg && vec && (!w || wfast) && nrows <= 0x7ffffff0ull && g.n_in >= (int64_t)BLOCK * NV;
+#define XG_RW(W_, S_) hipLaunchKernelGGL((k_reduce_contig_wg<W_, S_>), dim3((u32)(((nrows + 7) / 8) * 8)), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zb)
+    if (wg_ok) {
+      if (w) { if (sk == 0) XG_RW(true, 0); else if (sk == 1) XG_RW(true, 1); else XG_RW(true, -1); }
+      else { if (sk == 0) XG_RW(false, 0); else if (sk == 1) XG_RW(false, 1); else XG_RW(false, -1); }
+    } else
     if (wfast) { if (sk == 0) XG_RF(0); else if (sk == 1) XG_RF(1); else XG_RF(-1); }
     else
     if (vec) { if (w) XG_RS(true, true); else XG_RS(false, true); }
     else { if (w) XG_RS(true, false); else XG_RS(false, false); }
+#undef XG_RW
 #undef XG_RF
 #undef XG_RS
 #undef XG_RC
