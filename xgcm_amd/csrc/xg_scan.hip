@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig(const real* __restrict_
 // and the launch keeps a quarter as many separate row streams open at any moment as K4b does.  Per-wave shuffle trees, the
 // 4 partial sums through LDS in wave order (re-associated like K4b: tolerance parity).  Aligned vector rows only (VEC),
 // weights in the WFAST form or none.
-template <bool HAS_W, int SK>
+template <bool HAS_W, int SK, int RUMAX = 8>
 __global__ __launch_bounds__(BLOCK) void k_reduce_contig_wg(const real* __restrict__ in, real* __restrict__ out, Geo g,
                                                             int skipna_rt, const real* __restrict__ wgt, MIdx mw, int ntl, ZBand zb) {
   __shared__ real part[2][WPB];
@@ -1458,7 +1458,7 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig_wg(const real* __restri
       for (int u = 0; u < RU; ++u) add(v[u], wv[u]);
     }
   };
-  batches(std::integral_constant<int, 8>{});
+  if constexpr (RUMAX >= 8) batches(std::integral_constant<int, 8>{});
   batches(std::integral_constant<int, 4>{});
   batches(std::integral_constant<int, 2>{});
   for (; t < nvec; t += BLOCK) {
@@ -1756,11 +1756,14 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
 #define XG_RS(W_, V_) do { if (sk == 0) XG_RC(W_, V_, 0); else if (sk == 1) XG_RC(W_, V_, 1); else XG_RC(W_, V_, -1); } while (0)
 #define XG_RF(S_) hipLaunchKernelGGL((k_reduce_contig<true, true, S_, true>), dim3((u32)nblocks), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zb)
     // K4w: a workgroup per row (weights as in WFAST: unit stride, rows 16-B aligned like the field's)
-    const bool wg_ok = tune().reduce_wg && vec && (!w || wfast) && nrows <= 0x7ffffff0ull && g.n_in >= (int64_t)BLOCK * NV;
-#define XG_RW(W_, S_) hipLaunchKernelGGL((k_reduce_contig_wg<W_, S_>), dim3((u32)(((nrows + 7) / 8) * 8)), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zb)
+    // (reduce_wg: bit 0 the unweighted sums, bit 1 the weighted ones, bit 2 the weighted ones with batches of 4 loads)
+    const int wgm = tune().reduce_wg;
+    const bool wg_ok = (w ? (wgm & 6) : (wgm & 1)) && vec && (!w || wfast) && nrows <= 0x7ffffff0ull && g.n_in >= (int64_t)BLOCK * NV;
+#define XG_RW(W_, S_, R_) hipLaunchKernelGGL((k_reduce_contig_wg<W_, S_, R_>), dim3((u32)(((nrows + 7) / 8) * 8)), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zb)
     if (wg_ok) {
-      if (w) { if (sk == 0) XG_RW(true, 0); else if (sk == 1) XG_RW(true, 1); else XG_RW(true, -1); }
-      else { if (sk == 0) XG_RW(false, 0); else if (sk == 1) XG_RW(false, 1); else XG_RW(false, -1); }
+      if (w && (wgm & 4)) { if (sk == 0) XG_RW(true, 0, 4); else if (sk == 1) XG_RW(true, 1, 4); else XG_RW(true, -1, 4); }
+      else if (w) { if (sk == 0) XG_RW(true, 0, 8); else if (sk == 1) XG_RW(true, 1, 8); else XG_RW(true, -1, 8); }
+      else { if (sk == 0) XG_RW(false, 0, 8); else if (sk == 1) XG_RW(false, 1, 8); else XG_RW(false, -1, 8); }
     } else
     if (wfast) { if (sk == 0) XG_RF(0); else if (sk == 1) XG_RF(1); else XG_RF(-1); }
     else
