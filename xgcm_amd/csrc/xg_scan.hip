@@ -1501,6 +1501,104 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_contig_wg(const real* __restri
   }
 }
 
+// K4wz: weighted sums along the contiguous axis whose weights are shared by the levels (dx(Y, X) under (Z, Y, X)): one
+// workgroup takes the SAME row of ZL consecutive levels and loads the row's weight vectors ONCE for all of them (rule 8: an
+// L2 hit is not free) -- a row that fits one batch (<= RU * BLOCK vectors) keeps them in registers.  WFAST form only.
+template <int SK, int ZL>
+__global__ __launch_bounds__(BLOCK) void k_reduce_contig_wgz(const real* __restrict__ in, real* __restrict__ out, Geo g,
+                                                             int skipna_rt, const real* __restrict__ wgt, MIdx mw, int ntl, ZBand zb,
+                                                             u32 Z) {
+  constexpr int RU = 8;
+  __shared__ real part[2][ZL][WPB];
+  int skipna = (SK >= 0) ? SK : skipna_rt;
+  const u32 r = (u32)((u64)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+  u32 zg, y;
+  if (r >= (u64)zb.per_band.d * ((zb.Y + zb.B - 1) / zb.B)) return;
+  if (!zband_map(zb, r, zg, y)) return;
+  const u32 z0 = zg * ZL;
+  const int lane = threadIdx.x & 63;
+  const int wv_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t n = g.n_in;
+  const int64_t nvec = n / NV;  // WFAST: rows start on 16-B boundaries and hold whole vectors
+  const u64 row0 = (u64)z0 * zb.Y + y;
+  const real* wrow = wgt + outer_off(g, mw, row0);
+  const bool pair = skipna >= 6;
+  if (pair) skipna -= 2;
+  const bool mean = skipna >= 4;
+  const int nmode = mean ? (skipna == 4 ? 1 : 0) : skipna, dmode = skipna == 4 ? 2 : 3;
+  auto terms = [&](real v, real wv, real& num, real& dn) {
+    if (mean) {
+      dn = as_count(v, dmode);
+      dn = dn * wv;
+      dn = nan0(dn);
+    }
+    if (nmode >= 2) v = as_count(v, nmode);
+    v = v * wv;
+    if (nmode) v = nan0(v);
+    num = v;
+  };
+  auto ldv = [&](const real* p) -> dv {
+    return (ntl & 1) ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(p)) : *reinterpret_cast<const dv*>(p);
+  };
+  dv a[ZL], ad[ZL];
+#pragma unroll
+  for (int l = 0; l < ZL; ++l) { a[l] = splat<dv>(real(0)); ad[l] = splat<dv>(real(0)); }
+  for (int64_t t0 = threadIdx.x; t0 < nvec; t0 += (int64_t)RU * BLOCK) {
+    dv wv[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int64_t t = t0 + (int64_t)u * BLOCK;
+      wv[u] = t < nvec ? *reinterpret_cast<const dv*>(wrow + t * NV) : splat<dv>(real(0));
+    }
+#pragma unroll
+    for (int l = 0; l < ZL; ++l) {
+      if (z0 + l >= Z) break;
+      const real* prow = in + (row0 + (u64)l * zb.Y) * n;
+      dv v[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int64_t t = t0 + (int64_t)u * BLOCK;
+        if (t < nvec) v[u] = ldv(prow + t * NV);
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int64_t t = t0 + (int64_t)u * BLOCK;
+        if (t < nvec) {
+#pragma unroll
+          for (int c = 0; c < NV; ++c) {
+            real num, dn = real(0);
+            terms(v[u][c], wv[u][c], num, dn);
+            a[l][c] += num;
+            ad[l][c] += dn;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < ZL; ++l) {
+    real acc = real(0), den = real(0);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) { acc += a[l][c]; den += ad[l][c]; }
+#pragma unroll
+    for (int d = WAVE / 2; d > 0; d >>= 1) {
+      acc += __shfl_down(acc, d, WAVE);
+      den += __shfl_down(den, d, WAVE);
+    }
+    if (lane == 0) { part[0][l][wv_id] = acc; part[1][l][wv_id] = den; }
+  }
+  __syncthreads();
+  if (threadIdx.x < ZL && z0 + threadIdx.x < Z) {
+    const int l = threadIdx.x;
+    real s = part[0][l][0], sd = part[1][l][0];
+#pragma unroll
+    for (int w = 1; w < WPB; ++w) { s += part[0][l][w]; sd += part[1][l][w]; }
+    const u64 row = row0 + (u64)l * zb.Y;
+    if (pair) { out[row] = s; out[g.outer + row] = sd; }
+    else out[row] = mean ? s / sd : s;
+  }
+}
+
 }  // namespace
 
 // geometry of the marching twin (8-byte lanes, XCD-banded wave order) that follows every chained launch as its rescue
@@ -1760,6 +1858,23 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
     const int wgm = tune().reduce_wg;
     const bool wg_ok = (w ? (wgm & 6) : (wgm & 1)) && vec && (!w || wfast) && nrows <= 0x7ffffff0ull && g.n_in >= (int64_t)BLOCK * NV;
 #define XG_RW(W_, S_, R_) hipLaunchKernelGGL((k_reduce_contig_wg<W_, S_, R_>), dim3((u32)(((nrows + 7) / 8) * 8)), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zb)
+    // K4wz: level-shared weights, ZL levels of one row per workgroup (reduce_wg bits 3 / 4: ZL = 2 / 4)
+    if (w && wfast && zb.on && (wgm & 24) && vec && g.n_in >= (int64_t)BLOCK * NV) {
+      const u32 Z = (u32)g.outer_shape[0];
+      const int ZL = (wgm & 16) ? 4 : 2;
+      const u64 Zg = ((u64)Z + ZL - 1) / ZL;
+      ZBand zg = make_zband(true, Zg, (u64)g.outer_shape[1], zb.B);
+      const u64 nwork = ((((u64)g.outer_shape[1] + zb.B - 1) / zb.B) * zb.B) * Zg;
+      if (zg.on && nwork < 0x7ffffff0ull) {
+        const u32 grid = (u32)(((nwork + 7) / 8) * 8);
+#define XG_RZ(S_, L_) hipLaunchKernelGGL((k_reduce_contig_wgz<S_, L_>), dim3(grid), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zg, Z)
+        if (ZL == 4) { if (sk == 0) XG_RZ(0, 4); else if (sk == 1) XG_RZ(1, 4); else XG_RZ(-1, 4); }
+        else { if (sk == 0) XG_RZ(0, 2); else if (sk == 1) XG_RZ(1, 2); else XG_RZ(-1, 2); }
+#undef XG_RZ
+        XG_LAUNCH_CHECK();
+        return XG_OK;
+      }
+    }
     if (wg_ok) {
       if (w && (wgm & 4)) { if (sk == 0) XG_RW(true, 0, 4); else if (sk == 1) XG_RW(true, 1, 4); else XG_RW(true, -1, 4); }
       else if (w) { if (sk == 0) XG_RW(true, 0, 8); else if (sk == 1) XG_RW(true, 1, 8); else XG_RW(true, -1, 8); }
