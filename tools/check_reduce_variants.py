@@ -25,7 +25,9 @@ for shape in [(75, 240, 3600), (7, 33, 1024), (5, 40, 1026), (3, 17, 4098), (2, 
             for v in (1, 3, 5, 8, 16, 9, 17):
                 setv(v)
                 got = D.reduce1d(T, 2, wt, mode).double().cpu().numpy()
-                ok = np.allclose(got, ref, rtol=1e-12, atol=0, equal_nan=True)
+                # re-associated sums: the error is relative to the sum of the |terms| (a row of mean-zero values cancels)
+                scale = float(np.nanmax(np.abs(ref))) if np.isfinite(np.nanmax(np.abs(ref))) else 1.0
+                ok = np.allclose(got, ref, rtol=1e-12, atol=1e-12 * scale, equal_nan=True)
                 if not ok:
                     bad += 1
                     print("MISMATCH", shape, wname, mode, v, np.nanmax(np.abs(got - ref) / np.abs(ref)))
