@@ -240,3 +240,57 @@ def test_deferred_results_with_real_xarray_operands(backend):
     back = q.to_xarray()
     assert isinstance(back, xr.DataArray) and back.dims == eager.dims
     np.testing.assert_array_equal(back.values, eager.values)
+
+
+# ---- round 5, second half: what the reference's own suite and the differential fuzz asked for, on real xarray -------------
+def test_private_state_the_reference_tests_read_is_real_xarray(backend):
+    ds = _dataset()
+    grid = _grid(ds)
+    assert grid._ds is ds
+    [m] = grid._metrics[frozenset(["X"])]
+    assert isinstance(m, xr.DataArray) and m.dims == ("XC",)
+    xr.testing.assert_equal(m, ds["dx"].reset_coords(drop=True))
+    w = grid.get_metric(ds["v"], ("X",))
+    assert isinstance(w, xr.DataArray)
+    xr.testing.assert_allclose(grid.cumsum(ds["v"] * w, "X", padding="fill"), grid.cumint(ds["v"], "X", padding="fill"))
+    assert isinstance(grid.interp_like(ds["dx"], grid.diff(ds["v"], "X")), xr.DataArray)
+
+
+def test_direct_pad_on_real_xarray_keeps_attrs_and_strips_coords(backend):
+    from xgcm_amd.padding import pad
+
+    ds = _dataset()
+    out = pad(ds["v"], _grid(ds), {"X": (2, 1)}, padding="periodic")
+    want = ds["v"].reset_coords(drop=True).drop_vars(["time", "XC"]).pad(XC=(2, 1), mode="wrap")
+    assert isinstance(out, xr.DataArray) and not list(out.coords)
+    xr.testing.assert_identical(out, want)  # values, dims, name and attrs ({"units": "m s-1"}): DataArray.pad keeps attrs
+
+
+def test_deferred_results_compute_to_real_xarray(backend):
+    ds = _dataset()
+    fused, eager = _grid(ds, fuse=True), _grid(ds)
+    lazy = (fused.diff(ds["v"], "X") * 2.0) / ds["dx"].rename({"XC": "XG"}).assign_coords(XG=ds["XG"].values)
+    out = lazy.compute()
+    assert isinstance(out, xr.DataArray)
+    want = (eager.diff(ds["v"], "X") * 2.0) / ds["dx"].rename({"XC": "XG"}).assign_coords(XG=ds["XG"].values)
+    xr.testing.assert_allclose(out, want)
+    assert out.dims == want.dims and out.name == want.name
+    np.testing.assert_array_equal(np.asarray(fused.diff(ds["v"], "X")), eager.diff(ds["v"], "X").values)
+
+
+def test_transform_keeps_the_input_name_like_the_reference(backend):
+    """xgcm/transform.py:462-472: `suffix` is accepted and never applied"""
+    nz, nx = 6, 4
+    rng = np.random.default_rng(5)
+    ds = xr.Dataset({"salt": (("x", "z"), rng.standard_normal((nx, nz))),
+                     "sigma": (("x", "z"), np.cumsum(rng.random((nx, nz)) + 0.1, axis=1))},
+                    {"z": ("z", np.arange(nz) + 0.5), "zo": ("zo", np.arange(nz + 1) * 1.0), "x": ("x", np.arange(nx) * 1.0)})
+    grid = Grid(ds, coords={"Z": {"center": "z", "outer": "zo"}}, autoparse_metadata=False)
+    out = grid.transform(ds["salt"], "Z", np.linspace(0.2, 3.0, 5), target_data=ds["sigma"])
+    assert isinstance(out, xr.DataArray) and out.name == "salt" and out.dims == ("x", "sigma")
+    try:
+        import xgcm
+    except ImportError:
+        return
+    ref = xgcm.Grid(ds, coords={"Z": {"center": "z", "outer": "zo"}}, autoparse_metadata=False)
+    xr.testing.assert_identical(out, ref.transform(ds["salt"], "Z", np.linspace(0.2, 3.0, 5), target_data=ds["sigma"]))
