@@ -310,6 +310,13 @@ def draw_call(rng, axes, positions, variables, where, metrics):
     method = str(rng.choice(["diff", "interp", "min", "max", "diff", "interp", "cumsum", "cumsum", "derivative", "integrate",
                              "average", "cumint", "interp_like", "get_metric", "apply_as_grid_ufunc", "apply_as_grid_ufunc", "pad"]))
     kw, args = {}, []
+    if metrics and rng.random() < 0.04:
+        # the grid's metrics change under way: a registered name again (refused unless overwrite), another position, an
+        # unknown variable, an unknown axis -- every later call of the case sees the same state on both grids
+        names = [n for n in variables if n.startswith("m_")]
+        key = _pick(rng, list(metrics)) if rng.random() < 0.85 else ("Q",)
+        value = _pick(rng, names) if rng.random() < 0.85 else "no_such_variable"
+        return "set_metrics", var, [key if rng.random() < 0.7 else list(key), value], {"overwrite": bool(rng.random() < 0.5)}
     if method == "apply_as_grid_ufunc":
         name, kw = draw_user_ufunc(rng, axes, positions, where[var], present)
         return "apply_as_grid_ufunc:" + name, var, [], kw
@@ -394,6 +401,9 @@ def _call(grid, ds, method, var, args, kw, pad_function=None):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         try:
+            if method == "set_metrics":
+                grid.set_metrics(*args, **kw)
+                return None, None
             if method == "transform":
                 spec = args[0]
                 maker = type(ds[var])  # the container the dataset hands out (xarray stand-in / xgcm_amd's)
@@ -440,6 +450,8 @@ def compare(ref, ref_exc, got, got_exc):
         if type(ref_exc).__name__ not in [c.__name__ for c in type(got_exc).__mro__]:  # (same class or a subclass of it)
             return f"exception type: reference {type(ref_exc).__name__} ({str(ref_exc)[:80]}), xgcm_amd {type(got_exc).__name__} ({str(got_exc)[:80]})"
         return None
+    if ref is None or got is None:  # (a call made for its effect on the grid)
+        return None if (ref is None and got is None) else f"reference {type(ref).__name__}, xgcm_amd {type(got).__name__}"
     if isinstance(ref, tuple) or isinstance(got, tuple):
         if not (isinstance(ref, tuple) and isinstance(got, tuple) and len(ref) == len(got)):
             return f"number of results: reference {type(ref).__name__}, xgcm_amd {type(got).__name__}"
@@ -792,6 +804,9 @@ def record(cases, seed, out_prefix):
             res, exc = _call(grid, ds, method, var, args, kw, ref_pad)
             if exc is not None:
                 per_call.append({"raises": type(exc).__name__, "message": str(exc)[:80]})
+                continue
+            if res is None:
+                per_call.append({"results": []})
                 continue
             outs = res if isinstance(res, tuple) else (res,)
             per_call.append({"results": _pack(res)})

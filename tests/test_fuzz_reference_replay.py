@@ -91,7 +91,7 @@ def test_seeded_calls_agree_with_the_reference(device_backend, chunk):
                 n_raised += 1
                 continue
             assert exc is None, (case, k, method, args, kw, repr(exc))
-            outs = got if isinstance(got, tuple) else (got,)
+            outs = () if got is None else (got if isinstance(got, tuple) else (got,))
             assert len(outs) == len(want["results"]), (case, k)
             for j, (o, w) in enumerate(zip(outs, want["results"])):
                 _check_result(case, k, j, w, o)

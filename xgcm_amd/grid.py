@@ -811,6 +811,11 @@ class Grid:
                     ax._get_position_name(data)
                 if bc is None and not generic_pad:
                     raise no_boundary_error(ax.name)
+                if not generic_pad and self._face_connections is not None and self._facedim in data.dims:
+                    # (an axis no link touches: the reference's pad still walks the faces, xgcm/padding.py:394-396)
+                    for i in range(data.sizes[self._facedim]):
+                        if i not in self._face_connections[self._facedim]:
+                            raise KeyError(i)
                 if generic_pad:
                     # the topology's own refusals (a face the connections leave out, an open edge without a boundary
                     # condition) come from the reference's pad, i.e. BEFORE the target dim is looked up: run the checks now
@@ -938,9 +943,18 @@ class Grid:
         mean = mode in ("mean_valid", "mean_all")
         pair = mean and len(dims) > 1
         lead = []  # the leading pair dim once numerator / denominator travel together
+        # a factor that has NONE of the summed dims (a metric registered under an axis it does not run along) still weights
+        # every cell: it rides in the first launch, broadcast along the summed dim -- `(da * w).sum(d)`, not `w * da.sum(d)`
+        loose = [f for f in factors if not any(d in f.dims for d in dims)]
+        if factors and not loose and not any(dims[0] in f.dims for f in factors):
+            # mixed precision with an unweighted first stage (a float32 field, float64 metrics that lack the first summed
+            # dim): numpy has promoted the PRODUCT before it sums anything -- the field is widened first (x * 1.0 is exact)
+            wide = np.result_type(_dt.np_dtype(data), *[_dt.np_dtype(f.data) for f in factors])
+            if wide != _dt.np_dtype(data) and wide.kind == "f" and _dt.np_dtype(data).kind == "f":
+                data = (da * wide.type(1.0)).data
         for i, d in enumerate(dims):
-            now = [f for f in factors if d in f.dims]
-            factors = [f for f in factors if d not in f.dims]
+            now = [f for f in factors if d in f.dims] + (loose if i == 0 else [])
+            factors = [f for f in factors if d not in f.dims and not any(f is x for x in loose)]
             w = None
             if now:
                 wf = functools.reduce(lambda a, b: a._binary(b, "mul", dims_order=tuple(cur_dims)), now[1:], now[0])

@@ -179,6 +179,13 @@ class HipGridUFunc(GridUFunc):
         fv = 0.0 if fv is None else fv  # cast to the array's dtype by the device layer, like numpy.pad does
         if (lo or hi) and bc is None:
             raise no_boundary_error(ax_name)
+        faces = getattr(grid, "_face_connections", None)
+        if faces is not None and (lo or hi) and grid._facedim in da.dims:
+            # an axis no link touches keeps the fused kernels, but the reference pads it through its face loop all the same
+            # (xgcm/padding.py:849-857, :394-396): a face the connections leave out is its KeyError here too
+            for i in range(da.sizes[grid._facedim]):
+                if i not in faces[grid._facedim]:
+                    raise KeyError(i)
         if not (lo or hi):
             bc = None
         if self.funcname == "cumsum":
