@@ -401,6 +401,10 @@ def _call(grid, ds, method, var, args, kw, pad_function=None):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         try:
+            if var.startswith("vec2:"):
+                _, ux, vy = var.split(":")
+                res = getattr(grid, method)({"X": ds[ux], "Y": ds[vy]}, **kw)
+                return (res["X"], res["Y"]), None
             if method == "set_metrics":
                 grid.set_metrics(*args, **kw)
                 return None, None
@@ -629,6 +633,12 @@ def draw_topology_call(rng, axes, positions, variables, where, metrics, edge_pos
             kw["fill_value"] = float(rng.integers(-2, 3)) + 0.25
     if method == "pad":
         return "pad", var, [{ax: (int(rng.integers(0, 3)), int(rng.integers(0, 3)))}], kw
+    if method == "vector" and rng.random() < 0.25:
+        # both components at once (the deprecated pair of methods the reference keeps: xgcm/grid.py:1420-1500)
+        ux, vy = vector_names
+        if rng.random() < 0.15:
+            kw["to"] = _pick(rng, ["center", edge_pos])
+        return _pick(rng, ["interp_2d_vector", "diff_2d_vector"]), f"vec2:{ux}:{vy}", [], kw
     if method == "vector":  # a vector component with its partner: halos across rotated / reversed links take the partner
         ux, vy = vector_names
         comp, other = (("X", ux), ("Y", vy)) if rng.random() < 0.5 else (("Y", vy), ("X", ux))
