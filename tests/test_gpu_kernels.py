@@ -454,7 +454,10 @@ def test_cumsum_metric(dev):
                 _eq(got, exp)
 
 
-@pytest.mark.parametrize("shape", [(6, 10, 128), (3, 7, 33), (2, 5, 4, 66), (300,), (75, 6, 10)])
+# (rows of 512 cells or more take the workgroup-per-row kernels along the last axis -- K4w, and K4wz with its odd last level
+# when the weights are shared by the levels: 5 and 3 levels here)
+@pytest.mark.parametrize("shape", [(6, 10, 128), (3, 7, 33), (2, 5, 4, 66), (300,), (75, 6, 10), (5, 6, 1024), (3, 7, 1538),
+                                   (2, 2, 4096)])
 def test_reduce(dev, shape):
     a = _field(shape, 13, nan=True)
     nd = len(shape)
