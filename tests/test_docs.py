@@ -55,4 +55,4 @@ def test_design_document_stays_readable():
     # and two pins (the reference's own suite, differential fuzzing)
     assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 53 * 1024
     tools = [f for f in os.listdir(os.path.join(ROOT, "tools")) if not f.startswith("__")]
-    assert len(tools) <= 33, tools
+    assert len(tools) <= 32, tools

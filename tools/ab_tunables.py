@@ -68,7 +68,6 @@ def main():
         "iYmw": (lambda: D.stencil1d("interp", T, 1, 1, 0, "extend", m_in=dx2, m_out=dx), 16 + 16 / nz),
         "divT": (lambda: D.binary("div", T, dx), 16 + 8 / nz),
         "mulTT": (lambda: D.binary("mul", T, T2), 24),
-        "mulmT": (lambda: D.binary("mul", dx, T), 16 + 8 / nz),  # the broadcast operand first (metric * field)
         "cumY": (lambda: D.cumsum1d(T, 1, 0, 1, 1, 0, "fill"), 16),
         "cumZ": (lambda: D.cumsum1d(T, 0, 0, 1, 1, 0, "fill"), 16),
         "cumX": (lambda: D.cumsum1d(T, 2, 0, 1, 1, 0, "fill"), 16),

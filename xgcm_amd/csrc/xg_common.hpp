@@ -169,7 +169,6 @@ struct Tune {
   int reduce_sk;      // contiguous-axis reductions: kernels specialised for the plain sums (skipna False / True)
   int reduce_ru;      // contiguous-axis reductions: 4 independent 16-B loads per lane before the first addition
   int reduce_wfast;   // contiguous-axis weighted reductions: unit-stride, row-aligned weights as one vector load per lane
-  int bin_zl;         // elementwise binary op with one operand broadcast along the slow dim: levels per thread sharing it (0 / 2 / 4)
   int reduce_wg;      // contiguous-axis reductions: one WORKGROUP per row (its 4 waves read adjacent 1-KB pieces) instead of one wave
   int scan_sh1;       // contiguous-axis scan, 4-byte elements, inputs shifted by one cell: aligned vector + one narrow load
   int reduce_ldsw;    // K4L: long weighted reductions with level-shared weights as a march whose weight rows go through LDS once per workgroup (0: chained K4cz)

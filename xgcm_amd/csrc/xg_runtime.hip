@@ -67,7 +67,6 @@ const TuneEntry TUNABLES[] = {
     {"reduce_sk", &Tune::reduce_sk, 1},
     {"reduce_ru", &Tune::reduce_ru, 1},
     {"reduce_wfast", &Tune::reduce_wfast, 1},
-    {"bin_zl", &Tune::bin_zl, 0},
     {"reduce_wg", &Tune::reduce_wg, 9},  // bit 0: plain sums; bit 3 / 4: level-shared weights, 2 / 4 levels per workgroup
     {"scan_sh1", &Tune::scan_sh1, 1},
     {"reduce_ldsw", &Tune::reduce_ldsw, 2},

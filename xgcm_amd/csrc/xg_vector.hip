@@ -103,43 +103,6 @@ __global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, co
   }
 }
 
-// (Z, P) items with ONE operand broadcast along Z (da / dx(Y,X), da * area): a thread takes the same 16-byte item of R
-// consecutive levels and loads the broadcast operand once for all of them -- rule 8: an L2 hit is not free (the one-level
-// kernel above re-reads the band from the L2 once per level).  BA: the broadcast operand is `a`.  Band-major order as above,
-// over level GROUPS.
-template <int BOP, bool NTS, bool BA, int R>
-__global__ __launch_bounds__(BLOCK) void k_binary_zl(const real* __restrict__ a, const real* __restrict__ b, real* __restrict__ out,
-                                                     ZBand zb, u32 nblk, u32 Z, u32 P, int nts_load) {
-  const u32 pb = (nblk + 7) >> 3;
-  const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
-  if (lb >= nblk) return;
-  const int64_t gid = (int64_t)lb * BLOCK + threadIdx.x;
-  u32 zg, pin;
-  if (gid >= (int64_t)zb.per_band.d * ((zb.Y + zb.B - 1) / zb.B)) return;
-  if (!zband_map(zb, (u32)gid, zg, pin)) return;
-  const u32 z0 = zg * R;
-  const real* small = BA ? a : b;
-  const real* big = BA ? b : a;
-  const dv sv = *reinterpret_cast<const dv*>(small + (int64_t)pin * NV);
-  dv x[R];
-#pragma unroll
-  for (int l = 0; l < R; ++l) {
-    if (z0 + l < Z) {
-      const real* p = big + ((int64_t)(z0 + l) * P + pin) * NV;
-      x[l] = nts_load ? __builtin_nontemporal_load(reinterpret_cast<const dv*>(p)) : *reinterpret_cast<const dv*>(p);
-    }
-  }
-#pragma unroll
-  for (int l = 0; l < R; ++l) {
-    if (z0 + l < Z) {
-      dv o;
-#pragma unroll
-      for (int k = 0; k < NV; ++k) o[k] = BA ? bin2<BOP>(sv[k], x[l][k]) : bin2<BOP>(x[l][k], sv[k]);
-      stg_s<dv, NTS>(out + ((int64_t)(z0 + l) * P + pin) * NV, o);
-    }
-  }
-}
-
 #ifndef XG_INT  // the fused two-component operators divide by / multiply with float metrics: float builds only
 // ------------------------------------------------------------------------------------------
 // K7: fused relative vorticity ((v[j,i]-v[j,i-1]) - (u[j,i]-u[j-1,i])) / area, view (outer,Y,X).
@@ -524,37 +487,8 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
       if (zb.on) nitems = padded;
     }
   }
-  int rc;
-  // level-shared broadcast operand (bin_zl = R levels per thread: 2 / 4; 0: off)
-  const int RZ = tune().bin_zl;
-  if (zb.on && V == NV && (RZ == 2 || RZ == 4) && g.sa[1] <= 1 && g.sb[1] <= 1 &&
-      ((g.sa[0] == 0 && g.sa[1] == 1 && g.sb[1] == 1 && g.sb[0] == g.shape[1] * NV) ||
-       (g.sb[0] == 0 && g.sb[1] == 1 && g.sa[1] == 1 && g.sa[0] == g.shape[1] * NV))) {
-    const bool ba = g.sa[0] == 0;
-    const u64 Z = (u64)g.shape[0], P = (u64)g.shape[1], Zg = (Z + RZ - 1) / RZ;
-    ZBand zg = make_zband(true, Zg, P, zb.B);
-    const u64 padded = ((P + zb.B - 1) / zb.B) * zb.B * Zg;
-    if (zg.on && padded < 0x7fffffffull && Z < 0xffffffffull) {
-      const u64 nb = (padded + BLOCK - 1) / BLOCK;
-      if ((rc = check_grid(nb + 8))) return rc;
-      const u32 grid_z = (u32)(((nb + 7) / 8) * 8);
-      hipStream_t stz = (hipStream_t)stream;
-      const bool ntsz = tune().nt_store;
-      const int ntl = tune().nt_load ? 1 : 0;
-#define XG_BZ(O, S_, A_, R_) hipLaunchKernelGGL((k_binary_zl<O, S_, A_, R_>), dim3(grid_z), dim3(BLOCK), 0, stz, a, b, out, zg, (u32)nb, (u32)Z, (u32)P, ntl)
-#define XG_BZR(O, S_, A_) do { if (RZ == 4) XG_BZ(O, S_, A_, 4); else XG_BZ(O, S_, A_, 2); } while (0)
-#define XG_BZA(O, S_) do { if (ba) XG_BZR(O, S_, true); else XG_BZR(O, S_, false); } while (0)
-#define XG_BZO(O) do { if (ntsz) XG_BZA(O, true); else XG_BZA(O, false); } while (0)
-      switch (op) { case XG_BIN_MUL: XG_BZO(XG_BIN_MUL); break; case XG_BIN_DIV: XG_BZO(XG_BIN_DIV); break; case XG_BIN_ADD: XG_BZO(XG_BIN_ADD); break; default: XG_BZO(XG_BIN_SUB); }
-#undef XG_BZO
-#undef XG_BZA
-#undef XG_BZR
-#undef XG_BZ
-      XG_LAUNCH_CHECK();
-      return XG_OK;
-    }
-  }
   const u64 nblocks = (nitems + BLOCK - 1) / BLOCK;
+  int rc;
   if ((rc = check_grid(nblocks + 8))) return rc;
   const u32 grid = (u32)(((nblocks + 7) / 8) * 8);  // XCD-banded block order
   // an operand without a broadcast dim is read exactly once: stream it past the caches
