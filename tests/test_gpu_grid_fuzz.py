@@ -18,21 +18,23 @@ from xgcm_amd.padding import pad as our_pad
 pytestmark = pytest.mark.gpu
 
 
-def _outcomes(seed, case):
+def _outcomes(seed, case, fused=False):
     ds, gkw, variables, calls = F.build_case(Dataset, seed, case)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         try:
-            grid = Grid(ds, **gkw)
+            grid = Grid(ds, **(dict(gkw, fuse=True) if fused else gkw))
         except Exception as exc:  # noqa: BLE001
             return [("grid", None, exc)]
         return [(f"{m}({v}, {a}, {kw})",) + F._call(grid, ds, m, v, a, kw, our_pad) for m, v, a, kw in calls]
 
 
-@pytest.mark.parametrize("seed", [7001, 7002, 7003])
-def test_hip_and_the_oracle_double_agree_on_fresh_seeds(seed, monkeypatch):
+@pytest.mark.parametrize("seed, fused", [(7001, False), (7002, False), (7003, False), (7004, True)])
+def test_hip_and_the_oracle_double_agree_on_fresh_seeds(seed, fused, monkeypatch):
+    """`fused`: every Grid on the HIP side built `fuse=True` (deferred results, computed for the comparison) against the EAGER
+    double -- the deferred mode's kernels against the operator-by-operator chain"""
     n = 120
-    on_hip = [_outcomes(seed, case) for case in range(n)]
+    on_hip = [_outcomes(seed, case, fused) for case in range(n)]
     with monkeypatch.context() as mp:
         fake_device.install(mp)
         on_double = [_outcomes(seed, case) for case in range(n)]
