@@ -317,6 +317,20 @@ def draw_call(rng, axes, positions, variables, where, metrics):
         key = _pick(rng, list(metrics)) if rng.random() < 0.85 else ("Q",)
         value = _pick(rng, names) if rng.random() < 0.85 else "no_such_variable"
         return "set_metrics", var, [key if rng.random() < 0.7 else list(key), value], {"overwrite": bool(rng.random() < 0.5)}
+    if rng.random() < 0.06:
+        # an operator CHAIN as a user writes it -- `(grid.diff(v, "X") - grid.diff(u, "Y")) / area`, `u * grid.interp(T, "X")`:
+        # two operator results (or a result and a field) under + - * /, optionally over a metric variable; with `--fused` the
+        # product defers and fuses what it can, and must agree with the reference's operator-by-operator chain
+        def one():
+            v = str(rng.choice(fields))
+            ax = _pick(rng, list(where[v]) or axes)
+            k = {}
+            _padding_arg(rng, axes, k)
+            return (_pick(rng, ["diff", "interp", "diff", "interp", "min", "max", "derivative"]), v, ax, k)
+        left = one()
+        right = one() if rng.random() < 0.75 else ("field", str(rng.choice(fields)), None, {})
+        over = _pick(rng, [n for n in variables if n.startswith("m_")] or [None]) if rng.random() < 0.5 else None
+        return "expr", left[1], [left, _pick(rng, ["add", "sub", "mul", "truediv"]), right, over], {}
     if method == "apply_as_grid_ufunc":
         name, kw = draw_user_ufunc(rng, axes, positions, where[var], present)
         return "apply_as_grid_ufunc:" + name, var, [], kw
@@ -401,6 +415,25 @@ def _call(grid, ds, method, var, args, kw, pad_function=None):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         try:
+            if method == "expr":
+                import operator as _op
+
+                def term(t):
+                    m, v, ax, k = t
+                    return ds[v] if m == "field" else getattr(grid, m)(ds[v], ax, **k)
+                left, binop, right, over = args
+                lt, rt = term(left), term(right)
+                if type(rt).__name__ == "LazyArray" and type(lt).__name__ != "LazyArray":
+                    # an xarray object on the LEFT of a deferred result: xarray treats the stranger as an unlabelled array
+                    # (operands meet by POSITION, xarray/core/variable.py `_broadcast_compat_data`) -- the documented way is
+                    # to compute the deferred operand first; the chain then broadcasts by name as there
+                    rt = rt.compute()
+                res = getattr(_op, binop)(lt, rt)
+                if over is not None:
+                    res = res / ds[over]
+                if type(res).__name__ == "LazyArray":
+                    res = res.compute()
+                return res, None
             if var.startswith("vec2:"):
                 _, ux, vy = var.split(":")
                 res = getattr(grid, method)({"X": ds[ux], "Y": ds[vy]}, **kw)
