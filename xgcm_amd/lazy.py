@@ -356,6 +356,12 @@ def defer_stencil(grid, funcname, ufunc, sig, arg, ax_name, other_component, m_i
         return None
     if in_dim not in da.dims:
         return None
+    try:  # a metric that does not fit the array (ill-formed products of odd metric positions): the eager call raises now
+        for m, dims in ((m_in, da.dims), (m_out, tuple(out_dims))):
+            if m is not None:
+                _labeled._aligned_view(m, dims)
+    except Exception:  # noqa: BLE001
+        return None
     lo, hi = next(iter(ufunc.padding_width.values())) if ufunc.padding_width else (0, 0)
     complex_ = gridops.complex_topology(grid, ax_name)
     bc = fv = None
