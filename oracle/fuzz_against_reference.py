@@ -181,6 +181,14 @@ def draw_variables(rng, axes, positions, sizes):
                             lambda: rng.integers(0, 200, size=shape).astype(np.uint8), lambda: rng.integers(-9, 9, size=shape).astype(">i4"),
                             lambda: rng.integers(0, 9, size=shape).astype(np.uint32), lambda: rng.random(shape) < 0.5,
                             lambda: rng.integers(-90, 90, size=shape).astype(np.int16)])()
+        layout = rng.random()
+        if layout < 0.08:
+            a = np.asfortranarray(a)  # column-major memory (what a transposed model output is)
+        elif layout < 0.14:
+            a = a[..., ::-1]  # a reversed view: negative stride
+        elif layout < 0.20:
+            wide = np.repeat(a, 2, axis=-1)
+            a = wide[..., ::2]  # every second element of a wider buffer: a strided view
         name = f"v{i}"
         variables[name] = (tuple(dims), a) if rng.random() < 0.7 else (tuple(dims), a, {"units": "K", "long_name": name})
         where[name] = pos
