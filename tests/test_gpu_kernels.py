@@ -933,3 +933,15 @@ def test_c_abi_from_plain_c(tmp_path):
     res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "0 mismatching cells" in res.stdout
+
+
+def test_binary_with_more_dims_than_the_abi_addresses(dev):
+    """`interp(a, X) * derivative(b, Y)` of fields on different positions of three axes (+ a record dim) is a 9-D outer
+    product by name: more dims than xg_binary takes (8).  Found by tools/gpu_grid_fuzz_sweep.py; numpy is the expectation."""
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((2, 3, 1, 2, 1, 3, 1, 2, 1))
+    b = rng.standard_normal((1, 1, 2, 1, 3, 1, 2, 1, 2))
+    for op, f in (("mul", np.multiply), ("add", np.add), ("sub", np.subtract), ("div", np.divide)):
+        _eq(dev.tohost(dev.binary(op, a, b)), f(a, b))
+    c = rng.standard_normal((2, 1, 1, 1, 1, 1, 1, 1, 3))  # nine dims, two real ones: merged, one launch
+    _eq(dev.tohost(dev.binary("mul", c, c)), c * c)

@@ -855,6 +855,15 @@ def transform_conservative(phi, theta, bins, axis: int) -> torch.Tensor:
 def binary(op: str, a, b) -> torch.Tensor:
     """Broadcasting a OP b for dim-aligned operands (same ndim, extents equal or 1)."""
     lib = _hip.load()
+    nd = getattr(a, "ndim", 0)
+    if nd > _hip.MAX_NDIM and nd == getattr(b, "ndim", -1):
+        extents = [max(int(x), int(y)) for x, y in zip(a.shape, b.shape)]
+        if sum(n != 1 for n in extents) > _hip.MAX_NDIM:
+            # more named dims than the ABI addresses (an outer product of two operator results on different positions of
+            # three axes plus a record dim): slice by slice along the first real dim -- each slice has one dim fewer
+            d0 = next(d for d, n in enumerate(extents) if n != 1)
+            cut = lambda x, i: x if x.shape[d0] == 1 else x[(slice(None),) * d0 + (slice(i, i + 1),)]  # noqa: E731
+            return torch.cat([binary(op, cut(a, i), cut(b, i)) for i in range(extents[d0])], dim=d0)
     lanes, res_dt = _dt.binary_plan(op, _dt.np_dtype(a), _dt.np_dtype(b))
     half = False
     if lanes == "int":  # numpy keeps int OP int integral (wrap-around in the promoted dtype): its lanes, narrowed
@@ -880,9 +889,23 @@ def binary(op: str, a, b) -> torch.Tensor:
         shape.append(max(sa, sb) if 0 not in (sa, sb) else 0)
     out = _empty(shape, dtype=dt, device=a.device)
     if out.numel():
+        sa, sb = _bstrides(a, shape, "a"), _bstrides(b, shape, "b")
+        kshape = list(shape)
+        if len(kshape) > _hip.MAX_NDIM:
+            # an outer product of many named dims (two operator results on different positions of three axes): extent-1 dims
+            # go, neighbours that both operands walk like one dim merge; what still has more dims than the ABI takes is
+            # refused below with its message
+            keep = [d for d, n in enumerate(kshape) if n != 1] or [0]
+            kshape, sa, sb = [kshape[d] for d in keep], [sa[d] for d in keep], [sb[d] for d in keep]
+            d = len(kshape) - 2
+            while d >= 0:
+                if sa[d] == sa[d + 1] * kshape[d + 1] and sb[d] == sb[d + 1] * kshape[d + 1]:
+                    kshape[d] *= kshape.pop(d + 1)
+                    sa[d], sb[d] = sa.pop(d + 1), sb.pop(d + 1)
+                d -= 1
         _hip.check(
-            getattr(lib, "xg_binary_" + sfx)(_hip.BINOP[op], a.data_ptr(), _hip.i64(_bstrides(a, shape, "a")), b.data_ptr(),
-                              _hip.i64(_bstrides(b, shape, "b")), out.data_ptr(), _hip.i64(shape), len(shape), _stream())
+            getattr(lib, "xg_binary_" + sfx)(_hip.BINOP[op], a.data_ptr(), _hip.i64(sa), b.data_ptr(),
+                              _hip.i64(sb), out.data_ptr(), _hip.i64(kshape), len(kshape), _stream())
         )
     return _narrow(out, res_dt) if lanes == "int" else _out(out, half)
 
