@@ -116,8 +116,13 @@ def draw_grid(rng):
             sizes[dim] = m
             coords[dim] = (dim, np.arange(m) + {"center": 0.5, "left": 0.0, "right": 1.0, "inner": 1.0, "outer": 0.0}[p])
     sizes["t"] = 2
-    coords["t"] = ("t", np.array([0.0, 10.0]))
+    coords["t"] = ("t", np.array([0.0, 10.0])) if rng.random() < 0.7 else ("t", np.array(["2001-01-01", "2001-02-01"], dtype="datetime64[ns]"))
     coords["label"] = ("t", np.array([3, 4]))
+    if rng.random() < 0.4:  # a scalar coordinate and a 2-D one (on two centre dims, or centre x record): they ride along where their dims survive
+        coords["ref_level"] = ((), np.float64(5.0))
+        a0 = axes[0]
+        two = (positions[a0]["center"], positions[axes[1]]["center"]) if len(axes) > 1 else ("t", positions[a0]["center"])
+        coords["depth2d"] = (two, np.arange(sizes[two[0]] * sizes[two[1]], dtype=np.float32).reshape(sizes[two[0]], sizes[two[1]]), {"units": "m"})
     kw = {"coords": positions, "autoparse_metadata": False}
     style = rng.integers(0, 4) if rng.random() < 0.5 else 0
     if style == 0:
