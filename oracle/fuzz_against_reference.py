@@ -180,6 +180,16 @@ def draw_grid(rng):
         dim = positions[ax][p]
         sizes[dim] += 2
         coords[dim] = (dim, np.arange(sizes[dim]) * 1.0)
+    if r >= 0.25 and rng.random() < 0.08:
+        # the grid from the dataset's COMODO attributes instead of `coords=` (autoparse_metadata, the reference's default):
+        # every dim names its axis and its shift; what position a length and a shift make is for the two parsers to say
+        shift = {"left": -0.5, "outer": -0.5, "right": 0.5, "inner": 0.5}
+        for ax in axes:
+            for p, dim in positions[ax].items():
+                attrs = {"axis": ax} if p == "center" else {"axis": ax, "c_grid_axis_shift": shift[p] if rng.random() < 0.9 else 1.0}
+                coords[dim] = (coords[dim][0], coords[dim][1], attrs)
+        del kw["coords"], kw["autoparse_metadata"]
+        kw["_autoparsed"] = True
     return axes, positions, sizes, coords, kw
 
 
@@ -558,7 +568,7 @@ def run(cases=100, seed=0, backend="oracle-double", calls_per_case=12, verbose=F
     differences, messages = [], []
     for case in range(cases):
         ds, gkw, variables, calls = build_case(xr.Dataset, seed, case, calls_per_case)
-        positions = gkw["coords"]
+        positions = gkw.get("coords", "autoparsed from the dataset's attributes")
         stats["cases"] += 1
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -848,6 +858,7 @@ def build_case(make_dataset, seed, case, calls_per_case=12):
         gkw["metrics"] = metrics
     ds = make_dataset({k: v for k, v in variables.items()}, coords)
     calls = [draw_call(rng, axes, positions, variables, where, metrics) for _ in range(calls_per_case)]
+    gkw.pop("_autoparsed", None)
     return ds, gkw, variables, calls
 
 
