@@ -374,7 +374,7 @@ def draw_call(rng, axes, positions, variables, where, metrics):
         left = one()
         right = one() if rng.random() < 0.75 else ("field", str(rng.choice(fields)), None, {})
         over = _pick(rng, [n for n in variables if n.startswith("m_")] or [None]) if rng.random() < 0.5 else None
-        return "expr", left[1], [left, _pick(rng, ["add", "sub", "mul", "truediv"]), right, over], {}
+        return "expr", left[1], [left, _pick(rng, ["add", "sub", "mul", "truediv"]), right, over], ({"_recast_left": True} if rng.random() < 0.3 else {})
     if method == "apply_as_grid_ufunc":
         name, kw = draw_user_ufunc(rng, axes, positions, where[var], present)
         return "apply_as_grid_ufunc:" + name, var, [], kw
@@ -462,11 +462,14 @@ def _call(grid, ds, method, var, args, kw, pad_function=None):
             if method == "expr":
                 import operator as _op
 
-                def term(t):
+                def term(t, recast=False):
                     m, v, ax, k = t
-                    return ds[v] if m == "field" else getattr(grid, m)(ds[v], ax, **k)
+                    da = ds[v]
+                    if recast and "t" in da.dims:  # the two operands then disagree on `label` / `extra`: arithmetic drops those
+                        da = da.assign_coords(label=("t", np.array([7, 8])), extra=("t", np.array([0.5, 1.5])))
+                    return da if m == "field" else getattr(grid, m)(da, ax, **k)
                 left, binop, right, over = args
-                lt, rt = term(left), term(right)
+                lt, rt = term(left, recast=bool(kw.get("_recast_left"))), term(right)
                 if type(rt).__name__ == "LazyArray" and type(lt).__name__ != "LazyArray":
                     # an xarray object on the LEFT of a deferred result: xarray treats the stranger as an unlabelled array
                     # (operands meet by POSITION, xarray/core/variable.py `_broadcast_compat_data`) -- the documented way is

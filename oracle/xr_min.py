@@ -280,7 +280,11 @@ class DataArray:
             b = _aligned(other, dims)
             coords = OrderedDict(self._coords)
             for k, v in other._coords.items():
-                coords.setdefault(k, v)
+                mine = coords.get(k)
+                if mine is None:
+                    coords[k] = v
+                elif k not in dims and not (mine[0] == v[0] and np.shape(mine[1]) == np.shape(v[1]) and np.array_equal(mine[1], v[1])):
+                    del coords[k]  # xarray: non-index coordinates whose values conflict are dropped by arithmetic
             name = self.name if self.name == other.name else None
         elif isinstance(other, Dataset):
             return NotImplemented

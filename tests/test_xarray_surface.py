@@ -266,3 +266,14 @@ def test_reference_names_of_helpers_and_return_shapes():
         found.boundary
     with pytest.raises(ValueError):  # five positional arguments: the reference's six-way unpack (xgcm/transform.py:201-203)
         linear_interpolation(1, 2, 3, "z", "z")
+
+
+def test_arithmetic_drops_conflicting_non_index_coordinates_like_xarray(backend):
+    """xarray's rule for `a OP b` (user guide, "Coordinates" of computation): index coordinates are kept, other coordinates
+    must agree or are dropped silently -- eager and deferred results alike"""
+    t = np.array([0.0, 1.0])
+    a = L.DataArray(np.ones((2, 3)), ("t", "x"), coords={"t": t, "label": ("t", np.array([3, 4])), "same": ("t", np.array([1, 1]))}, name="a")
+    b = L.DataArray(np.ones((2, 3)), ("t", "x"), coords={"t": t, "label": ("t", np.array([7, 8])), "same": ("t", np.array([1, 1])), "only_b": ("x", np.arange(3))})
+    out = a * b
+    assert sorted(out.coords) == ["only_b", "same", "t"] and out.name is None
+    assert sorted((a * a).coords) == ["label", "same", "t"] and (a * a).name == "a"

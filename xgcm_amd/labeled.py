@@ -284,7 +284,13 @@ class DataArray:
                     raise ValueError(f"cannot broadcast: dimension {d!r} has sizes {self.sizes[d]} and {other.sizes[d]}")
             coords = OrderedDict(self.coords)
             for k, v in other.coords.items():
-                coords.setdefault(k, v)
+                mine = coords.get(k)
+                if mine is None:
+                    coords[k] = v
+                elif k not in dims and not _same_coord(mine, v):
+                    # xarray: "other [than index] coordinates are not aligned, and if their values conflict, they will be
+                    # dropped" (`arr[0] - arr[1]` loses its scalar coordinate)
+                    del coords[k]
         elif (isinstance(other, np.ndarray) or _is_tensor(other)) and other.ndim <= self.ndim:
             # an unlabelled array: numpy's positional broadcasting against this array's shape, as in xarray
             shape = (1,) * (self.ndim - other.ndim) + tuple(int(n) for n in other.shape)
@@ -365,6 +371,10 @@ class DataArray:
         if not isinstance(key, tuple):
             key = (key,)
         return self.isel({d: k for d, k in zip(self.dims, key)})
+
+
+def _same_coord(a, b) -> bool:
+    return a.dims == b.dims and a.shape == b.shape and bool(np.array_equal(a.values, b.values))
 
 
 def _result_name(a, b):

@@ -476,8 +476,12 @@ def defer_binary(self_operand, other, op: str, reflexive: bool, dims_order, forc
                 raise ValueError(f"cannot broadcast: dimension {d!r} has sizes {sa[d]} and {sb[d]}")
         shape = tuple(sa[d] if d in sa else sb[d] for d in dims)
         coords = OrderedDict(a.coords)
-        for k, v in other.coords.items():
-            coords.setdefault(k, v)
+        for k, v in other.coords.items():  # (the eager rule, labeled.DataArray._binary: conflicting non-index coordinates go)
+            mine = coords.get(k)
+            if mine is None:
+                coords[k] = v
+            elif k not in dims and not _labeled._same_coord(mine, v):
+                del coords[k]
         rt = _NP_OP[op](np.ones(1, _dtype_of(a)), np.ones(1, _dtype_of(other))).dtype
         host = _is_host(a) and _is_host(other)
     else:
