@@ -372,6 +372,22 @@ def test_config3_vertical_derivative_and_integrals_full_size(env3, env):
         assert np.array_equal(_h(c3.data[:, b, :]), R.grid_cumsum(cols, 0, "left", "center", "fill", m_in=w))
 
 
+def test_config3_integrals_along_the_contiguous_axis_full_size(env3):
+    """integrate / average along X at full size -- the workgroup-per-row kernels (K4w; two levels share the row's dxT
+    vectors) and the plain `sum`: whole levels 0 / 37 / 74 against numpy's own sums of the same products.  The kernels
+    re-associate (numpy is pairwise along the last axis): 1e-12 relative to the sum of the |terms|, NaN cells skipped."""
+    grid, T, m = env3["grid"], env3["T"], env3["m"]
+    iX, aX, sX = grid.integrate(T, "X"), grid.average(T, "X"), T.sum("XC")
+    assert iX.dims == aX.dims == sX.dims == ("Z", "YC")
+    for z in LEVELS:
+        slab = _h(T.data[z])
+        w = m["dxT"]
+        scale = np.abs(slab * w).sum(axis=1)
+        np.testing.assert_allclose(_h(iX.data[z]), (slab * w).sum(axis=1), rtol=0, atol=1e-12 * scale.max())
+        np.testing.assert_allclose(_h(aX.data[z]), (slab * w).sum(axis=1) / w.sum(axis=1), rtol=0, atol=1e-12 * (scale / w.sum(axis=1)).max())
+        np.testing.assert_allclose(_h(sX.data[z]), slab.sum(axis=1), rtol=0, atol=1e-12 * np.abs(slab).sum(axis=1).max())
+
+
 def test_config4_cumsum_center_to_outer_full_size(env3):
     """cumsum(T,'Z') center->left and center->outer (fill) against oracle column blocks (config 4's two ops)"""
     T = env3["T"]
