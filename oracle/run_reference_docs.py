@@ -1,0 +1,243 @@
+#!/usr/bin/env python3
+"""The code blocks of the reference's documentation, executed against the reference AND against `xgcm_amd`, compared.
+
+TEST INFRASTRUCTURE -- build container only (reads /root/reference/docs at run time; nothing is copied into the repo).
+
+    python oracle/run_reference_docs.py [--fused] [--backend oracle-double|host-abi] [-v]
+
+The reference's user guide is executable markdown (`docs/*.md`, "execute: true"): grids, boundary conditions, grid ufuncs,
+the vector-calculus examples (divergence / gradient / vorticity written as user grid ufuncs), grid topology.  For every page
+the python blocks run in order in ONE namespace, twice, in two child processes: `import xgcm` is the reference's package in
+the first and a shim over `xgcm_amd` in the second (same trick as `oracle/run_reference_suite.py`); `xarray` is the real
+package where importable, else the stand-in (`oracle/xr_min.py` + `xr_suite.py`); plotting is stubbed.  After each block
+every labelled array in the namespace is snapshotted (dims, name, coordinate names, values) -- the parent compares the two
+runs block by block: same variables, same snapshots (1e-12 for re-associated scans), same exception class where a block
+raises.  `tests/test_reference_suite_live.py::test_documentation_examples` runs it wherever the reference tree is.
+"""
+import argparse
+import json
+import os
+import pickle
+import re
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("XGCM_REFERENCE", "/root/reference")
+PAGES = ["grids.md", "boundary_conditions.md", "grid_ufuncs.md", "ufunc_examples.md", "grid_topology.md"]
+
+
+def blocks_of(page):
+    text = open(os.path.join(REF, "docs", page)).read()
+    return [m.group(1) for m in re.finditer(r"^```python[^\n]*\n(.*?)^```", text, flags=re.S | re.M)]
+
+
+# ---- child: run one implementation over every page --------------------------------------------------------------------
+def child(which, backend, fused, out_path):
+    import types
+    import warnings
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import fuzz_against_reference as F
+
+    xr, RefGrid, OurGrid = F.load_both(backend)  # registers xarray (stand-in unless installed), numba stand-in, the device double
+    if getattr(xr, "_is_xr_min", False):
+        from oracle import xr_suite
+
+        xr_suite.extend(xr)
+
+    class _Plot:  # `.plot`, `.plot.quiver(...)`, `plt.figure()` ...: anything, returning itself
+        def __call__(self, *a, **k):
+            return self
+
+        def __getattr__(self, name):
+            return self
+
+        def __iter__(self):
+            return iter((self, self))
+
+    for cls in (xr.DataArray, xr.Dataset):
+        try:
+            cls.plot = property(lambda self: _Plot())
+        except (AttributeError, TypeError):
+            pass
+    mpl = types.ModuleType("matplotlib")
+    plt = types.ModuleType("matplotlib.pyplot")
+    plt.__getattr__ = lambda name: _Plot()
+    mpl.pyplot = plt
+    sys.modules.setdefault("matplotlib", mpl)
+    sys.modules.setdefault("matplotlib.pyplot", plt)
+
+    if which == "own":
+        import xgcm_amd
+
+        if fused:
+            _init = xgcm_amd.Grid.__init__
+
+            def _fused_init(self, *a, **k):
+                k.setdefault("fuse", True)
+                _init(self, *a, **k)
+
+            xgcm_amd.Grid.__init__ = _fused_init
+        shim = types.ModuleType("xgcm")
+        for k in ("Grid", "Axis", "as_grid_ufunc", "apply_as_grid_ufunc", "GridUFunc"):
+            setattr(shim, k, getattr(xgcm_amd, k))
+        shim.__path__ = []
+        for name, source in (("grid", "grid"), ("grid_ufunc", "grid_ufunc"), ("padding", "padding"), ("axis", "axis"),
+                             ("metrics", "metrics"), ("gridops", "gridops"), ("metadata_parsers", "metadata"), ("sgrid", "metadata"),
+                             ("comodo", "metadata"), ("transform", "transform")):
+            mod = __import__(f"xgcm_amd.{source}", fromlist=["*"])
+            sys.modules[f"xgcm.{name}"] = mod
+            setattr(shim, name, mod)
+        sys.modules["xgcm"] = shim
+
+    def snap(v):
+        if type(v).__name__ == "LazyArray":
+            v = v.compute()
+        if type(v).__name__ == "DataArray" and hasattr(v, "dims"):
+            vals = np.asarray(v.values)
+            return {"kind": "DataArray", "dims": tuple(v.dims), "name": v.name, "coords": sorted(v.coords),
+                    "dtype": str(vals.dtype), "values": vals}
+        if type(v).__name__ == "Dataset" and hasattr(v, "data_vars"):
+            return {"kind": "Dataset", "vars": {k: snap(v[k]) for k in v.data_vars}}
+        if isinstance(v, np.ndarray) and v.dtype.kind in "biuf" and v.size < 10 ** 6:
+            return {"kind": "ndarray", "values": v}
+        if isinstance(v, (tuple, list)) and v and all(type(x).__name__ in ("DataArray", "LazyArray") for x in v):
+            return {"kind": "tuple", "items": [snap(x) for x in v]}
+        if isinstance(v, dict) and v and all(type(x).__name__ in ("DataArray", "LazyArray") for x in v.values()):
+            return {"kind": "dict", "items": {str(k): snap(x) for k, x in v.items()}}
+        return None
+
+    report = {}
+    for page in PAGES:
+        ns = {"__name__": "__docs__"}
+        np.random.seed(0)
+        per_block = []
+        for i, code in enumerate(blocks_of(page)):
+            entry = {"raised": None, "vars": {}}
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    exec(compile(code, f"{page}[{i}]", "exec"), ns)  # noqa: S102 -- the documentation's own code
+            except (KeyboardInterrupt, SystemExit):
+                raise
+            except BaseException as exc:  # noqa: BLE001  (pytest's Skipped -- a block that chunks with dask -- is a BaseException)
+                entry["raised"] = (type(exc).__name__, str(exc)[:200])
+            for k, v in list(ns.items()):
+                if k.startswith("_"):
+                    continue
+                try:
+                    s = snap(v)
+                except Exception as exc:  # noqa: BLE001
+                    s = {"kind": "unreadable", "why": repr(exc)[:200]}
+                if s is not None:
+                    entry["vars"][k] = s
+            per_block.append(entry)
+        report[page] = per_block
+    with open(out_path, "wb") as f:
+        pickle.dump(report, f)
+
+
+# ---- parent: compare the two runs -----------------------------------------------------------------------------------------
+def _same(a, b, path, out):
+    import numpy as np
+
+    if a is None or b is None or a.get("kind") != b.get("kind"):
+        out.append(f"{path}: {None if a is None else a.get('kind')} vs {None if b is None else b.get('kind')}")
+        return
+    if a["kind"] == "DataArray":
+        for key in ("dims", "name", "coords", "dtype"):
+            if a[key] != b[key]:
+                out.append(f"{path}: {key} {a[key]!r} vs {b[key]!r}")
+                return
+    if a["kind"] in ("DataArray", "ndarray"):
+        x, y = a["values"], b["values"]
+        if x.shape != y.shape:
+            out.append(f"{path}: shape {x.shape} vs {y.shape}")
+        elif not np.array_equal(x, y, equal_nan=x.dtype.kind == "f") and not np.allclose(x, y, rtol=1e-12, atol=1e-12, equal_nan=True):
+            out.append(f"{path}: values differ, max |d| = {np.nanmax(np.abs(x.astype(float) - y.astype(float))):.3e}")
+    elif a["kind"] == "Dataset":
+        if sorted(a["vars"]) != sorted(b["vars"]):
+            out.append(f"{path}: variables {sorted(a['vars'])} vs {sorted(b['vars'])}")
+        else:
+            for k in a["vars"]:
+                _same(a["vars"][k], b["vars"][k], f"{path}.{k}", out)
+    elif a["kind"] == "tuple":
+        if len(a["items"]) != len(b["items"]):
+            out.append(f"{path}: {len(a['items'])} vs {len(b['items'])} items")
+        else:
+            for i, (p, q) in enumerate(zip(a["items"], b["items"])):
+                _same(p, q, f"{path}[{i}]", out)
+    elif a["kind"] == "dict":
+        if sorted(a["items"]) != sorted(b["items"]):
+            out.append(f"{path}: keys differ")
+        else:
+            for k in a["items"]:
+                _same(a["items"][k], b["items"][k], f"{path}[{k}]", out)
+
+
+def run(backend="oracle-double", fused=False):
+    if not os.path.isdir(os.path.join(REF, "docs")):
+        raise FileNotFoundError(f"{REF}/docs: the reference is not on this box")
+    results = {}
+    for which in ("ref", "own"):
+        fd, path = tempfile.mkstemp(suffix=".pkl", prefix=f"xgcm_docs_{which}_")
+        os.close(fd)
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--child", which, "--backend", backend, "--out", path] + (["--fused"] if fused else [])
+            proc = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+            if proc.returncode != 0:
+                raise RuntimeError(f"{which} run failed:\n{proc.stderr[-3000:]}")
+            with open(path, "rb") as f:
+                results[which] = pickle.load(f)
+        finally:
+            os.unlink(path)
+    summary = {"pages": {}, "differences": []}
+    for page in PAGES:
+        ref, own = results["ref"][page], results["own"][page]
+        n_vars = n_raised = 0
+        for i, (r, o) in enumerate(zip(ref, own)):
+            where = f"{page}[{i}]"
+            if (r["raised"] is None) != (o["raised"] is None):
+                summary["differences"].append(f"{where}: reference {r['raised']}, xgcm_amd {o['raised']}")
+                continue
+            if r["raised"] is not None:
+                n_raised += 1
+                if r["raised"][0] != o["raised"][0]:
+                    summary["differences"].append(f"{where}: exception {r['raised']} vs {o['raised']}")
+            names = sorted(set(r["vars"]) | set(o["vars"]))
+            for k in names:
+                found = []
+                _same(r["vars"].get(k), o["vars"].get(k), f"{where}:{k}", found)
+                summary["differences"] += found
+                n_vars += 1
+        summary["pages"][page] = {"blocks": len(ref), "blocks_raising_in_both": n_raised, "snapshots_compared": n_vars}
+    return summary
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--child", default=None)
+    ap.add_argument("--backend", default="oracle-double", choices=["oracle-double", "host-abi", "hip"])
+    ap.add_argument("--fused", action="store_true")
+    ap.add_argument("--out", default=None)
+    ap.add_argument("-v", "--verbose", action="store_true")
+    args = ap.parse_args()
+    if args.child:
+        child(args.child, args.backend, args.fused, args.out)
+        return
+    summary = run(args.backend, args.fused)
+    print(json.dumps(summary["pages"]))
+    for d in summary["differences"][: (None if args.verbose else 30)]:
+        print("DIFF", d[:300])
+    print(len(summary["differences"]), "differences")
+    sys.exit(1 if summary["differences"] else 0)
+
+
+if __name__ == "__main__":
+    main()

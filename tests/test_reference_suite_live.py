@@ -94,3 +94,17 @@ def test_differential_fuzz_against_the_reference(backend, seed, fused):
     served = stats["both_returned"] + stats.get("outside_the_host_build", 0)  # (the host build holds no token gathers)
     assert stats["calls"] > 4000 and served > 3000 and stats["both_raised"] > 500, stats
     assert stats["both_returned"] > (1500 if backend == "host-abi" else 3000), stats  # (host build: no gathers, no transform)
+
+
+@pytest.mark.parametrize("backend", ["oracle-double", "host-abi"])
+def test_documentation_examples(backend):
+    """`oracle/run_reference_docs.py`: the 77 python blocks of the reference's user guide (grids, boundary conditions, grid
+    ufuncs, the divergence / gradient / vorticity examples, grid topology) executed against the reference and against
+    xgcm_amd; after every block every labelled array in the namespace must be the same (dims, name, coordinates, values)."""
+    from oracle import run_reference_docs as D
+
+    summary = D.run(backend)
+    gap = [d for d in summary["differences"] if "not part of the host build" in d]
+    assert len(summary["differences"]) == len(gap) and (backend == "host-abi" or not gap), summary["differences"][:10]
+    assert sum(p["blocks"] for p in summary["pages"].values()) >= 70
+    assert sum(p["snapshots_compared"] for p in summary["pages"].values()) >= 350
