@@ -216,7 +216,7 @@ def draw_variables(rng, axes, positions, sizes):
             a = _pick(rng, [lambda: a.astype(">f8"), lambda: a.astype(">f4"), lambda: rng.integers(-9, 9, size=shape).astype(np.int32),
                             lambda: rng.integers(0, 200, size=shape).astype(np.uint8), lambda: rng.integers(-9, 9, size=shape).astype(">i4"),
                             lambda: rng.integers(0, 9, size=shape).astype(np.uint32), lambda: rng.random(shape) < 0.5,
-                            lambda: rng.integers(-90, 90, size=shape).astype(np.int16)])()
+                            lambda: rng.integers(-90, 90, size=shape).astype(np.int16), lambda: a.astype(np.float16)])()
         layout = rng.random()
         if layout < 0.08:
             a = np.asfortranarray(a)  # column-major memory (what a transposed model output is)
@@ -548,7 +548,9 @@ def compare(ref, ref_exc, got, got_exc):
     if x.shape != y.shape:
         return f"shape: reference {x.shape}, xgcm_amd {y.shape}"
     if not np.array_equal(x, y, equal_nan=x.dtype.kind == "f"):
-        tol = 1e-12 if x.dtype == np.float64 else 2e-6  # (re-associated contiguous-axis scans / sums of the product, per dtype)
+        # (re-associated contiguous-axis scans / sums of the product, per dtype; float16 is a storage type of the product --
+        # float32 lanes, one rounding on the way out: sums of float16 fields carry float32 partial sums)
+        tol = 1e-12 if x.dtype == np.float64 else (2e-6 if x.dtype == np.float32 else 4e-3)
         if not np.allclose(x, y, rtol=tol, atol=tol, equal_nan=True):
             return f"values differ: max |d| = {np.nanmax(np.abs(x.astype(float) - y.astype(float))):.3e}"
     for c in a["coords"]:
