@@ -225,6 +225,15 @@ def test_float16_computes_like_numpy(tbackend, order):
     _same(grid.derivative(ds["T"], "X").values, R.stencil1d("diff", T, 2, 1, 0, "periodic", m_out=m16[None]))
     _same(grid.diff(ds["T"], "X", metric_weighted=("X",)).values,
           R.stencil1d("diff", T, 2, 1, 0, "periodic", m_in=(m16 + np.float16(1))[None], m_out=m16[None]))
+    # two axes in one call: numpy rounds to float16 BETWEEN the axes, so the fused two-axis kernel (float32 throughout) is not
+    # taken -- one axis at a time (a 16-cell row AND, on a second grid, an 18-cell one: not a multiple of the float32 lane vector)
+    _same(grid.interp(ds["T"], ["X", "Y"]).values, R.stencil1d("interp", R.stencil1d("interp", T, 2, 1, 0, "periodic"), 1, 1, 0, "extend"))
+    _same(grid.max(ds["T"], ["Y", "X"]).values, R.stencil1d("max", R.stencil1d("max", T, 1, 1, 0, "extend"), 2, 1, 0, "periodic"))
+    T18 = _half_field((nz, ny, 18), 5, order)
+    ds18 = Dataset({"T": (("Z", "YC", "XC"), T18)}, dict(coords, XC=("XC", np.arange(18) + 0.5), XG=("XG", np.arange(18) * 1.0)))
+    g18 = Grid(ds18, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}},
+               padding={"X": "periodic", "Y": "extend"}, autoparse_metadata=False)
+    _same(g18.interp(ds18["T"], ["X", "Y"]).values, R.stencil1d("interp", R.stencil1d("interp", T18, 2, 1, 0, "periodic"), 1, 1, 0, "extend"))
     _same((ds["T"] * 0.5).values, T * 0.5)
     _same((ds["T"] / ds["dxF"]).values, T / (m16 + np.float16(1))[None])
     # float16 next to a float32 / float64 operand promotes like numpy

@@ -1029,7 +1029,7 @@ def flux(u, v, t, bc_x: str, bc_y: str, fill_x: float = 0.0, fill_y: float = 0.0
 def stencil2d_supported(x, padx, pady) -> bool:
     """Can xg_stencil2d_f64 serve this call (else run the two axes one after the other)?"""
     shape = tuple(x.shape)  # numpy (host) or torch (HBM) data
-    lane = 4 if _dtype_of(x) == torch.float32 else 2  # elements of the 16-byte lane vector
+    lane = 2 if _dt.np_dtype(x).itemsize == 8 else 4  # elements of the 16-byte lane vector (float16 computes on float32 lanes)
     if isinstance(x, torch.Tensor) and x.is_cuda and (x.data_ptr() % 16 or not x.is_contiguous()):
         return False  # a contiguous view at an odd element offset: the two 1-D launches handle it (8-byte lanes)
     return (len(shape) >= 2 and shape[-1] % lane == 0 and sum(padx) == 1 and sum(pady) == 1

@@ -629,6 +629,8 @@ class Grid:
             return None
         if gridops.is_integer_data(array.data):
             return None  # integers: one axis at a time on int64 lanes (interp leaves the integer domain between the axes)
+        if _dt.np_dtype(array.data) == np.float16:
+            return None  # float16 is a storage type: numpy rounds to it BETWEEN the axes -- one axis at a time (found by the GPU sweep)
         (sig_a, ax_a), (sig_b, ax_b) = step_a, step_b
         if ax_a == ax_b or gridops.complex_topology(self, ax_a) or gridops.complex_topology(self, ax_b):
             return None  # halos from other faces / the folded row: one axis at a time (xg_stencil1d_halo)
