@@ -121,8 +121,9 @@ def load_both(backend="oracle-double"):
 def draw_grid(rng):
     axes = sorted(rng.choice(["X", "Y", "Z"], size=rng.integers(1, 4), replace=False).tolist())
     coords, positions, sizes = {}, {}, {}
+    long_axis = _pick(rng, axes) if rng.random() < 0.12 else None  # one axis with rows long enough for the vector / workgroup kernels
     for ax in axes:
-        n = int(rng.integers(3, 8))
+        n = int(rng.integers(3, 8)) if ax != long_axis else int(_pick(rng, [33, 64, 130, 257, 516, 1030]))
         extra = rng.choice(POSITIONS[1:], size=rng.integers(1, 3), replace=False).tolist()
         if "inner" in extra and "outer" in extra and rng.random() < 0.5:
             extra.remove("inner")
