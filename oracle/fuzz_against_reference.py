@@ -121,9 +121,13 @@ def load_both(backend="oracle-double"):
 def draw_grid(rng):
     axes = sorted(rng.choice(["X", "Y", "Z"], size=rng.integers(1, 4), replace=False).tolist())
     coords, positions, sizes = {}, {}, {}
-    long_axis = _pick(rng, axes) if rng.random() < 0.12 else None  # one axis with rows long enough for the vector / workgroup kernels
+    # one axis with rows long enough for the vector / workgroup kernels -- on grids of one or two axes only, and shorter on two:
+    # two operator results on different positions of EVERY axis are an outer product over all of them (sizes multiply)
+    long_axis = _pick(rng, axes) if (rng.random() < 0.15 and len(axes) <= 2) else None
     for ax in axes:
-        n = int(rng.integers(3, 8)) if ax != long_axis else int(_pick(rng, [33, 64, 130, 257, 516, 1030]))
+        # (516 / 1030 only on one-axis grids: an operator result next to a field on another position of the long axis is an
+        # outer product -- 1030 x 1031 x the other dims must stay megabytes, on the GPU box too)
+        n = int(rng.integers(3, 8)) if ax != long_axis else int(_pick(rng, [33, 64, 130] + ([257, 516, 1030] if len(axes) == 1 else [])))
         extra = rng.choice(POSITIONS[1:], size=rng.integers(1, 3), replace=False).tolist()
         if "inner" in extra and "outer" in extra and rng.random() < 0.5:
             extra.remove("inner")
@@ -191,14 +195,20 @@ def draw_grid(rng):
                 coords[dim] = (coords[dim][0], coords[dim][1], attrs)
         del kw["coords"], kw["autoparse_metadata"]
         kw["_autoparsed"] = True
+    if long_axis is not None:
+        # every field and metric takes ONE position on the long axis: two positions of it in one expression are an outer
+        # product of 1000 x 1000 x ... cells -- gigabytes, on either side
+        kw["_long"] = (long_axis, _pick(rng, list(positions[long_axis])))
     return axes, positions, sizes, coords, kw
 
 
-def draw_variables(rng, axes, positions, sizes):
+def draw_variables(rng, axes, positions, sizes, long=None):
     variables, where = {}, {}
     for i in range(int(rng.integers(3, 6))):
         used = [ax for ax in axes if rng.random() < 0.8] or [axes[0]]
         pos = {ax: str(rng.choice(list(positions[ax]))) for ax in used}
+        if long is not None and long[0] in pos:
+            pos[long[0]] = long[1]
         dims = [positions[ax][pos[ax]] for ax in used]
         if rng.random() < 0.5:
             dims = ["t"] + dims
@@ -232,7 +242,7 @@ def draw_variables(rng, axes, positions, sizes):
     return variables, where
 
 
-def draw_metrics(rng, axes, positions, sizes, variables):
+def draw_metrics(rng, axes, positions, sizes, variables, long=None):
     metrics = {}
     for r in (1, 2, 3):
         for combo in itertools.combinations(axes, r):
@@ -240,9 +250,9 @@ def draw_metrics(rng, axes, positions, sizes, variables):
                 continue
             names = []
             for k in range(int(rng.integers(1, 4))):
-                dims = [positions[ax][str(rng.choice(list(positions[ax])))] for ax in combo]
+                dims = [positions[ax][str(rng.choice(list(positions[ax]))) if (long is None or ax != long[0]) else long[1]] for ax in combo]
                 others = [ax for ax in axes if ax not in combo and rng.random() < 0.3]
-                dims += [positions[ax]["center"] for ax in others]
+                dims += [positions[ax]["center" if (long is None or ax != long[0]) else long[1]] for ax in others]
                 name = "m_" + "".join(combo).lower() + f"_{k}"
                 variables[name] = (tuple(dims), rng.random(tuple(sizes[d] for d in dims)) + 0.5)
                 names.append(name)
@@ -858,8 +868,9 @@ def build_case(make_dataset, seed, case, calls_per_case=12):
         calls = [draw_topology_call(rng, axes, positions, variables, where, metrics, edge_pos, vector_names) for _ in range(calls_per_case)]
         return ds, gkw, variables, calls
     axes, positions, sizes, coords, gkw = draw_grid(rng)
-    variables, where = draw_variables(rng, axes, positions, sizes)
-    metrics = draw_metrics(rng, axes, positions, sizes, variables)
+    long = gkw.pop("_long", None)
+    variables, where = draw_variables(rng, axes, positions, sizes, long)
+    metrics = draw_metrics(rng, axes, positions, sizes, variables, long)
     if metrics:
         gkw["metrics"] = metrics
     ds = make_dataset({k: v for k, v in variables.items()}, coords)
@@ -868,9 +879,17 @@ def build_case(make_dataset, seed, case, calls_per_case=12):
     return ds, gkw, variables, calls
 
 
+SAMPLE_ABOVE = 20000  # results with more cells are stored as every k-th cell (shape kept): the fixture stays a few MB
+
+
+def sample_step(size):
+    return 1 if size <= SAMPLE_ABOVE else -(-size // 4096)
+
+
 def _pack(res):
     outs = res if isinstance(res, tuple) else (res,)
-    return [{"dims": list(o.dims), "name": o.name, "coords": {c: list(o.coords[c].dims) for c in sorted(o.coords)}} for o in outs]
+    return [{"dims": list(o.dims), "name": o.name, "coords": {c: list(o.coords[c].dims) for c in sorted(o.coords)},
+             "shape": [int(n) for n in np.asarray(o.values).shape]} for o in outs]
 
 
 def record(cases, seed, out_prefix):
@@ -905,7 +924,9 @@ def record(cases, seed, out_prefix):
             outs = res if isinstance(res, tuple) else (res,)
             per_call.append({"results": _pack(res)})
             for j, o in enumerate(outs):
-                arrays[f"{case}/{k}/{j}"] = np.asarray(o.values)
+                vals = np.asarray(o.values)
+                step = sample_step(vals.size)
+                arrays[f"{case}/{k}/{j}"] = vals if step == 1 else np.ascontiguousarray(vals.reshape(-1)[::step])
                 for c in o.coords:
                     arrays[f"{case}/{k}/{j}/coord/{c}"] = np.asarray(o.coords[c].values)
         meta["outcomes"].append({"calls": per_call})

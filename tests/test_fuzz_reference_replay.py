@@ -54,6 +54,10 @@ def _check_result(case, k, j, want, got):
     assert got.name == want["name"], (case, k, "name", got.name, want["name"])
     assert sorted(got.coords) == sorted(want["coords"]), (case, k, "coords", sorted(got.coords), sorted(want["coords"]))
     x, y = arrays[f"{case}/{k}/{j}"], np.asarray(got.values)
+    assert list(y.shape) == want["shape"], (case, k, y.shape, want["shape"])
+    step = F.sample_step(y.size)
+    if step > 1:  # a big result (a long axis): the fixture holds every `step`-th cell of it
+        y = y.reshape(-1)[::step]
     assert x.dtype == y.dtype and x.shape == y.shape, (case, k, x.dtype, y.dtype, x.shape, y.shape)
     if not np.array_equal(x, y, equal_nan=x.dtype.kind == "f"):  # (contiguous-axis scans / sums re-associate on the GPU)
         tol = 1e-12 if x.dtype == np.float64 else (2e-6 if x.dtype == np.float32 else 4e-3)  # (float16: float32 partial sums)
