@@ -210,7 +210,7 @@ def test_get_metric_interp_like_and_pad_hand_back_xarray_for_xarray_inputs(xr):
     np.testing.assert_array_equal(padded.values, np.pad(ds["v"].values, ((0, 0), (2, 1)), mode="wrap"))
 
 
-def test_deferred_results_of_xarray_inputs_compute_to_xarray(xr):
+def test_deferred_results_of_xarray_inputs_compute_to_xarray(xr, monkeypatch):
     ds, grid = _metric_grid(xr, fuse=True)
     eager = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", autoparse_metadata=False)
     lazy = grid.diff(ds["v"], "X")
@@ -224,6 +224,15 @@ def test_deferred_results_of_xarray_inputs_compute_to_xarray(xr):
     assert L.is_xarray(abs(lazy)) and L.is_xarray(lazy.load())
     own = Grid(L.from_xarray(ds), coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", autoparse_metadata=False, fuse=True)
     assert isinstance(own.diff(own._ds["v"], "X").compute(), L.DataArray)  # the library's arrays stay the library's
+    # what a deferred result does not define itself, the xarray object it stands for answers (`.plot`, `.sel`, `.isel` ...)
+    monkeypatch.setattr(xr.DataArray, "fillna", lambda self, v: xr.DataArray(np.nan_to_num(self.values, nan=v), dims=self.dims), raising=False)
+    filled = lazy.fillna(0.0)
+    assert L.is_xarray(filled) and filled.dims == ("time", "XG")
+    np.testing.assert_array_equal(filled.values, eager.diff(ds["v"], "X").values)
+    with pytest.raises(AttributeError):
+        lazy.no_such_thing
+    with pytest.raises(AttributeError):
+        own.diff(own._ds["v"], "X").fillna  # the library's own labelled arrays do not grow xarray's methods
 
 
 def test_labelled_arrays_meet_numpy_like_xarray_does(backend):

@@ -222,6 +222,22 @@ class LazyArray(DataArray):
         out = DataArray.__abs__(self._plain())
         return _labeled.to_xarray(out) if self._xr else out
 
+    def __getattr__(self, key: str):
+        """What this class does not have, the computed xarray object does (`.plot`, `.sel`, `.isel`, `.where` ...):
+        a deferred result of xarray inputs answers like the `xarray.DataArray` it stands for, as a dask-backed one does."""
+        try:
+            return DataArray.__getattr__(self, key)
+        except AttributeError:
+            if key.startswith("_"):
+                raise
+            try:
+                from_xarray = object.__getattribute__(self, "_xr")
+            except AttributeError:
+                from_xarray = False
+            if not from_xarray:
+                raise
+        return getattr(self.compute(), key)
+
     def __repr__(self) -> str:
         state = "deferred" if self.is_deferred else ("HBM" if self.is_device else "host")
         return f"<xgcm_amd.LazyArray {self.name!r} {dict(self.sizes)} [{state}] coords={list(self.coords)}>"
