@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", default="8000:8010")
     ap.add_argument("--cases", type=int, default=200)
+    ap.add_argument("--fused", action="store_true", help="every grid with fuse=True: HIP's fused templates against the double's")
     args = ap.parse_args()
     import test_gpu_grid_fuzz as T
     from oracle import fake_device
@@ -27,10 +28,10 @@ def main():
     real = {n: getattr(dev, n) for n in fake_device._NAMES}
     total = differences = 0
     for seed in range(lo, hi):
-        on_hip = [T._outcomes(seed, case) for case in range(args.cases)]
+        on_hip = [T._outcomes(seed, case, args.fused) for case in range(args.cases)]
         fake_device.install(F._MP())
         try:
-            on_double = [T._outcomes(seed, case) for case in range(args.cases)]
+            on_double = [T._outcomes(seed, case, args.fused) for case in range(args.cases)]
         finally:
             for n, f in real.items():
                 setattr(dev, n, f)
@@ -44,7 +45,7 @@ def main():
                     print(json.dumps({"seed": seed, "case": case, "call": what[:200], "difference": diff[:200]}))
         print(json.dumps({"seed": seed, "calls": n, "differences": bad}))
         total, differences = total + n, differences + bad
-    print(json.dumps({"seeds": [lo, hi], "cases_per_seed": args.cases, "calls": total, "differences": differences}))
+    print(json.dumps({"seeds": [lo, hi], "cases_per_seed": args.cases, "fused": bool(args.fused), "calls": total, "differences": differences}))
     sys.exit(1 if differences else 0)
 
 
