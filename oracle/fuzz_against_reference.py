@@ -563,7 +563,9 @@ def compare(ref, ref_exc, got, got_exc):
         # float32 lanes, one rounding on the way out: sums of float16 fields carry float32 partial sums)
         # (float16 sums: numpy rounds every partial sum to float16 -- n * 2^-11 * max|sum| of its own -- the lanes do not)
         tol = 1e-12 if x.dtype == np.float64 else (2e-6 if x.dtype == np.float32 else 3e-2)
-        if not np.allclose(x, y, rtol=tol, atol=tol, equal_nan=True):
+        finite = np.abs(x[np.isfinite(x)].astype(float)) if x.dtype.kind == "f" else np.zeros(0)
+        scale = max(1.0, float(finite.max())) if finite.size else 1.0  # (a re-associated scan errs by eps * its largest partial sum, also where it crosses zero)
+        if not np.allclose(x, y, rtol=tol, atol=tol * scale, equal_nan=True):
             return f"values differ: max |d| = {np.nanmax(np.abs(x.astype(float) - y.astype(float))):.3e}"
     for c in a["coords"]:
         if not np.array_equal(np.asarray(ref.coords[c].values), np.asarray(got.coords[c].values)):
