@@ -99,7 +99,8 @@ def test_differential_fuzz_against_the_reference(backend, seed, fused):
 @pytest.mark.parametrize("backend", ["oracle-double", "host-abi"])
 def test_documentation_examples(backend):
     """`oracle/run_reference_docs.py`: the 77 python blocks of the reference's user guide (grids, boundary conditions, grid
-    ufuncs, the divergence / gradient / vorticity examples, grid topology) executed against the reference and against
+    ufuncs, the divergence / gradient / vorticity examples, grid topology) and the 52 cells of its `Grid.transform` notebook
+    executed against the reference and against
     xgcm_amd; after every block every labelled array in the namespace must be the same (dims, name, coordinates, values)."""
     from oracle import run_reference_docs as D
 
@@ -108,3 +109,6 @@ def test_documentation_examples(backend):
     assert len(summary["differences"]) == len(gap) and (backend == "host-abi" or not gap), summary["differences"][:10]
     assert sum(p["blocks"] for p in summary["pages"].values()) >= 70
     assert sum(p["snapshots_compared"] for p in summary["pages"].values()) >= 350
+    if backend != "host-abi":  # the `Grid.transform` notebook too (its network cells raise alike in both runs)
+        nb = summary["pages"]["transform.ipynb"]
+        assert nb["blocks"] == 52 and nb["blocks"] - nb["blocks_raising_in_both"] >= 18 and nb["snapshots_compared"] >= 600, nb
