@@ -99,8 +99,8 @@ def test_differential_fuzz_against_the_reference(backend, seed, fused):
 @pytest.mark.parametrize("backend", ["oracle-double", "host-abi"])
 def test_documentation_examples(backend):
     """`oracle/run_reference_docs.py`: the 77 python blocks of the reference's user guide (grids, boundary conditions, grid
-    ufuncs, the divergence / gradient / vorticity examples, grid topology) and the 52 cells of its `Grid.transform` notebook
-    executed against the reference and against
+    ufuncs, the divergence / gradient / vorticity examples, grid topology), the 52 cells of its `Grid.transform` notebook and
+    the 26 of its metrics notebook (integrate / average / cumint / derivative / metric-weighted interp on a C grid) executed against the reference and against
     xgcm_amd; after every block every labelled array in the namespace must be the same (dims, name, coordinates, values)."""
     from oracle import run_reference_docs as D
 
@@ -109,6 +109,9 @@ def test_documentation_examples(backend):
     assert len(summary["differences"]) == len(gap) and (backend == "host-abi" or not gap), summary["differences"][:10]
     assert sum(p["blocks"] for p in summary["pages"].values()) >= 70
     assert sum(p["snapshots_compared"] for p in summary["pages"].values()) >= 350
+    nb = summary["pages"]["grid_metrics.ipynb"]  # the metrics notebook on a synthetic MITgcm-like dataset: every cell runs, both ways
+    assert nb["blocks"] == 26 and nb["blocks_raising_in_both"] == 0 and nb["snapshots_compared"] >= 150, nb
+    assert summary["assert_equal_held_to_1e-12"] <= 1  # (its `assert_equal` of a two-axis integral with the hand-written sum)
     if backend != "host-abi":  # the `Grid.transform` notebook too (its network cells raise alike in both runs)
         nb = summary["pages"]["transform.ipynb"]
         assert nb["blocks"] == 52 and nb["blocks"] - nb["blocks_raising_in_both"] >= 18 and nb["snapshots_compared"] >= 600, nb
