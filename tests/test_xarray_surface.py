@@ -214,7 +214,7 @@ def test_deferred_results_of_xarray_inputs_compute_to_xarray(xr, monkeypatch):
     ds, grid = _metric_grid(xr, fuse=True)
     eager = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", autoparse_metadata=False)
     lazy = grid.diff(ds["v"], "X")
-    assert not L.is_xarray(lazy) and lazy.is_deferred
+    assert type(lazy).__name__ == "LazyArray" and lazy.is_deferred
     twice = lazy * 2.0
     assert twice.is_deferred
     out = twice.compute()
@@ -224,6 +224,14 @@ def test_deferred_results_of_xarray_inputs_compute_to_xarray(xr, monkeypatch):
     assert L.is_xarray(abs(lazy)) and L.is_xarray(lazy.load())
     own = Grid(L.from_xarray(ds), coords={"X": {"center": "XC", "left": "XG"}}, padding="periodic", autoparse_metadata=False, fuse=True)
     assert isinstance(own.diff(own._ds["v"], "X").compute(), L.DataArray)  # the library's arrays stay the library's
+    assert L.is_xarray(lazy)  # it stands for an xarray object: fed back into the grid it counts as one ...
+    again = grid.interp(lazy, "X")
+    assert type(again).__name__ == "LazyArray" and L.is_xarray(again.compute())  # ... and what comes of it is xarray again
+    np.testing.assert_array_equal(again.values, eager.interp(eager.diff(ds["v"], "X"), "X").values)
+    sel = lazy.isel(XG=0)  # the labelled-array methods this class shares with xarray answer with xarray objects
+    assert L.is_xarray(sel) and type(sel).__name__ == "DataArray" and sel.dims == ("time",)
+    np.testing.assert_array_equal(sel.values, eager.diff(ds["v"], "X").values[:, 0])
+    assert L.is_xarray(lazy.transpose("XG", "time")) and lazy.transpose("XG", "time").dims == ("XG", "time")
     # what a deferred result does not define itself, the xarray object it stands for answers (`.plot`, `.sel`, `.isel` ...)
     monkeypatch.setattr(xr.DataArray, "fillna", lambda self, v: xr.DataArray(np.nan_to_num(self.values, nan=v), dims=self.dims), raising=False)
     filled = lazy.fillna(0.0)

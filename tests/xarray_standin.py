@@ -46,6 +46,15 @@ def install(monkeypatch):
         def __getitem__(self, key):
             return self.coords[key]
 
+        def isel(self, **indexers):  # (integers only; coordinates of the kept dims)
+            index = tuple(indexers.get(d, slice(None)) for d in self.dims)
+            dims = tuple(d for d in self.dims if d not in indexers)
+            keep = OrderedDict((k, c) for k, c in self.coords.items() if set(c.dims) <= set(dims))
+            return DataArray(self.values[index], dims, keep, self.name, self.attrs)
+
+        def transpose(self, *dims):
+            return DataArray(self.values.transpose([self.dims.index(d) for d in dims]), dims, self.coords, self.name, self.attrs)
+
         def chunk(self, spec):
             blocks = tuple((spec.get(d, n),) * (n // spec.get(d, n)) for d, n in zip(self.dims, self.shape))
             return DataArray(self.values, self.dims, self.coords, self.name, self.attrs, chunks=blocks)

@@ -502,8 +502,10 @@ class Dataset:
 
 # ---- optional bridges to real xarray ------------------------------------------------------
 def is_xarray(obj) -> bool:
+    """an object of the package named `xarray` -- or a deferred result that stands for one (`lazy.LazyArray` born of xarray
+    inputs: it comes back in as xarray came in, and what is computed from it goes out as xarray)"""
     mod = type(obj).__module__ or ""
-    return mod.startswith("xarray")
+    return mod.startswith("xarray") or (type(obj).__name__ == "LazyArray" and bool(getattr(obj, "_xr", False)))
 
 
 CHUNKED_INPUT_MESSAGE = (
@@ -516,6 +518,10 @@ def from_xarray(obj):
     """xarray.DataArray / Dataset -> xgcm_amd labelled object (host data).  A dask-backed DataArray is refused
     instead of being computed behind the caller's back (reference: `dask="parallelized"`, grid.py:786-818)."""
     tname = type(obj).__name__
+    if tname == "LazyArray":  # a deferred result standing for an xarray object: the same deferred value, as one of ours
+        out = obj._replace()
+        out._xr = False
+        return out
     if tname == "DataArray" and getattr(obj, "chunks", None) is not None:
         raise NotImplementedError(CHUNKED_INPUT_MESSAGE)
     if tname == "DataArray":

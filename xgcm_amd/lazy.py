@@ -222,6 +222,38 @@ class LazyArray(DataArray):
         out = DataArray.__abs__(self._plain())
         return _labeled.to_xarray(out) if self._xr else out
 
+    # ---- a deferred result of xarray inputs answers xarray's methods with xarray objects ----
+    def isel(self, *a, **k):
+        return self.compute().isel(*a, **k) if self._xr else DataArray.isel(self, *a, **k)
+
+    def transpose(self, *a, **k):
+        return self.compute().transpose(*a, **k) if self._xr else DataArray.transpose(self, *a, **k)
+
+    @property
+    def T(self):
+        return self.compute().T if self._xr else DataArray.T.fget(self)
+
+    def rename(self, *a, **k):
+        return self.compute().rename(*a, **k) if self._xr else DataArray.rename(self, *a, **k)
+
+    def reset_coords(self, *a, **k):
+        return self.compute().reset_coords(*a, **k) if self._xr else DataArray.reset_coords(self, *a, **k)
+
+    def drop_vars(self, *a, **k):
+        return self.compute().drop_vars(*a, **k) if self._xr else DataArray.drop_vars(self, *a, **k)
+
+    def assign_coords(self, *a, **k):
+        return self.compute().assign_coords(*a, **k) if self._xr else DataArray.assign_coords(self, *a, **k)
+
+    def to_dataset(self, *a, **k):
+        return self.compute().to_dataset(*a, **k) if self._xr else DataArray.to_dataset(self, *a, **k)
+
+    def sum(self, *a, **k):
+        return self.compute().sum(*a, **k) if self._xr else DataArray.sum(self, *a, **k)
+
+    def cumsum(self, *a, **k):
+        return self.compute().cumsum(*a, **k) if self._xr else DataArray.cumsum(self, *a, **k)
+
     def __getattr__(self, key: str):
         """What this class does not have, the computed xarray object does (`.plot`, `.sel`, `.isel`, `.where` ...):
         a deferred result of xarray inputs answers like the `xarray.DataArray` it stands for, as a dask-backed one does."""
