@@ -115,3 +115,44 @@ def test_documentation_examples(backend):
     if backend != "host-abi":  # the `Grid.transform` notebook too (its network cells raise alike in both runs)
         nb = summary["pages"]["transform.ipynb"]
         assert nb["blocks"] == 52 and nb["blocks"] - nb["blocks_raising_in_both"] >= 18 and nb["snapshots_compared"] >= 600, nb
+
+
+def test_public_surface_matches_the_reference():
+    """Every public member of the reference's `Grid` exists on `xgcm_amd.Grid` and every callable one takes the reference's
+    parameters, in the reference's order (more may follow: `pad_before_func`, internal layout hints); the same for
+    `as_grid_ufunc` / `apply_as_grid_ufunc` / `GridUFunc` (`docs/api.md` lists exactly these)."""
+    import subprocess
+
+    code = r"""
+import inspect, json, sys
+sys.path.insert(0, %r)
+from oracle import fuzz_against_reference as F
+xr, RefGrid, OurGrid = F.load_both("oracle-double")
+import xgcm, xgcm_amd
+out = {"missing": [], "parameters": {}}
+pairs = [("Grid", RefGrid, OurGrid), ("GridUFunc", xgcm.grid_ufunc.GridUFunc, xgcm_amd.GridUFunc)]
+def named(f):  # positional / keyword parameters in order; then whether *args / **kwargs are taken
+    ps = inspect.signature(f).parameters.values()
+    return [p.name for p in ps if p.kind not in (p.VAR_POSITIONAL, p.VAR_KEYWORD)], sorted(p.kind.name for p in ps if p.kind in (p.VAR_POSITIONAL, p.VAR_KEYWORD))
+def fits(ref, own):
+    (a, va), (b, vb) = named(ref), named(own)
+    return b[: len(a)] == a and set(va) <= set(vb)
+for cname, ref, own in pairs:
+    for name, member in inspect.getmembers(ref):
+        if name.startswith("_"):
+            continue
+        if not hasattr(own, name):
+            out["missing"].append(f"{cname}.{name}")
+        elif callable(member):
+            if not fits(member, getattr(own, name)):
+                out["parameters"][f"{cname}.{name}"] = [named(member), named(getattr(own, name))]
+for name in ("as_grid_ufunc", "apply_as_grid_ufunc"):
+    if not fits(getattr(xgcm, name), getattr(xgcm_amd, name)):
+        out["parameters"][name] = [named(getattr(xgcm, name)), named(getattr(xgcm_amd, name))]
+out["grid_members"] = len([n for n, _ in inspect.getmembers(RefGrid) if not n.startswith("_")])
+print(json.dumps(out))
+""" % ROOT
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    out = json.loads(proc.stdout.splitlines()[-1])
+    assert out["missing"] == [] and out["parameters"] == {} and out["grid_members"] >= 15, out
