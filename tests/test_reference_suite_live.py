@@ -120,7 +120,9 @@ def test_documentation_examples(backend):
 def test_public_surface_matches_the_reference():
     """Every public member of the reference's `Grid` exists on `xgcm_amd.Grid` and every callable one takes the reference's
     parameters, in the reference's order (more may follow: `pad_before_func`, internal layout hints); the same for
-    `as_grid_ufunc` / `apply_as_grid_ufunc` / `GridUFunc` (`docs/api.md` lists exactly these)."""
+    `as_grid_ufunc` / `apply_as_grid_ufunc` / `GridUFunc` (`docs/api.md` lists exactly these); and every public function, class
+    and registered grid ufunc of its `padding`, `axis`, `metrics`, `gridops`, `transform`, `grid_ufunc` and metadata modules
+    is reachable under the same name here."""
     import subprocess
 
     code = r"""
@@ -149,10 +151,22 @@ for cname, ref, own in pairs:
 for name in ("as_grid_ufunc", "apply_as_grid_ufunc"):
     if not fits(getattr(xgcm, name), getattr(xgcm_amd, name)):
         out["parameters"][name] = [named(getattr(xgcm, name)), named(getattr(xgcm_amd, name))]
+import importlib
+modules = {"grid_ufunc": "grid_ufunc", "padding": "padding", "axis": "axis", "metrics": "metrics", "gridops": "gridops",
+           "transform": "transform", "comodo": "metadata", "sgrid": "metadata", "metadata_parsers": "metadata"}
+out["module_names"] = 0
+for rname, oname in modules.items():
+    rm, om = importlib.import_module("xgcm." + rname), importlib.import_module("xgcm_amd." + oname)
+    for name, v in vars(rm).items():
+        public = not name.startswith("_") and getattr(v, "__module__", "") == rm.__name__ and (inspect.isfunction(v) or inspect.isclass(v))
+        if public or type(v).__name__ == "GridUFunc":
+            out["module_names"] += 1
+            if not hasattr(om, name) and (rname, name) != ("transform", "input_handling"):  # (a decorator of its two column functions)
+                out["missing"].append(f"{rname}.{name}")
 out["grid_members"] = len([n for n, _ in inspect.getmembers(RefGrid) if not n.startswith("_")])
 print(json.dumps(out))
 """ % ROOT
     proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0, proc.stderr[-3000:]
     out = json.loads(proc.stdout.splitlines()[-1])
-    assert out["missing"] == [] and out["parameters"] == {} and out["grid_members"] >= 15, out
+    assert out["missing"] == [] and out["parameters"] == {} and out["grid_members"] >= 15 and out["module_names"] >= 60, out

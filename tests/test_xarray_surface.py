@@ -283,6 +283,19 @@ def test_reference_names_of_helpers_and_return_shapes():
         found.boundary
     with pytest.raises(ValueError):  # five positional arguments: the reference's six-way unpack (xgcm/transform.py:201-203)
         linear_interpolation(1, 2, 3, "z", "z")
+    # the small public helpers of the metadata modules (xgcm/comodo.py:11-52, metadata_parsers.py:100-119)
+    assert metadata.get_axis_coords(ds, "X") == ["xc", "xg"] and metadata.get_axis_coords(ds, "Y") == []
+    assert metadata.assert_valid_comodo(ds) is None and metadata.cf_parser(ds) == (ds, {})
+
+
+def test_raw_bodies_under_the_reference_names(backend):
+    """`gridops.diff_forward` & co (xgcm/gridops.py:23-24, :76-77, :123-126, :172-175): padded array in, two-point result out"""
+    from xgcm_amd import gridops as G
+
+    a = R.synthetic_field((3, 7), 5)
+    for body, want in ((G.diff_forward, a[..., 1:] - a[..., :-1]), (G.interp_forward, (a[..., :-1] + a[..., 1:]) / 2.0),
+                       (G.pairwise_forward_min, np.minimum(a[..., :-1], a[..., 1:])), (G.pairwise_forward_max, np.maximum(a[..., :-1], a[..., 1:]))):
+        np.testing.assert_array_equal(np.asarray(body(a)), want)
 
 
 def test_arithmetic_drops_conflicting_non_index_coordinates_like_xarray(backend):

@@ -206,6 +206,11 @@ def _raw_stencil(op: str):
     return body
 
 
+# the raw bodies under the reference's names (gridops.py:23, :76, :123, :172): a padded array in, the two-point result out
+diff_forward, interp_forward = _raw_stencil("diff"), _raw_stencil("interp")
+pairwise_forward_min, pairwise_forward_max = _raw_stencil("min"), _raw_stencil("max")
+
+
 def _raw_cumsum(drop_last: bool):
     def body(a):
         """np.cumsum(a, -1)[..., :-1 if drop_last] (reference gridops.py:227-278); NaN propagates."""

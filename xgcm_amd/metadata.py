@@ -189,3 +189,18 @@ def get_all_axes(ds):
 
 def get_axis_positions_and_coords(ds, axis_name: str) -> "OrderedDict[str, str]":
     return _sgrid_positions(*_topology(_own(ds)), axis_name)
+
+
+# ---- the remaining public helpers of the reference's metadata modules --------------------------------------------------
+def get_axis_coords(ds, axis_name: str) -> List[str]:
+    """dims of `ds` whose coordinate carries `axis == axis_name` (reference `comodo.py:31-52`)"""
+    return list(_comodo_axes(_own(ds)).get(axis_name, []))
+
+
+def assert_valid_comodo(ds) -> None:
+    """accepts every dataset, as the reference's does (`comodo.py:11-20`: an unimplemented check)"""
+
+
+def cf_parser(ds):
+    """`(ds, {})`: the reference's CF parser is a placeholder that finds nothing (`metadata_parsers.py:100-119`)"""
+    return ds, {}
