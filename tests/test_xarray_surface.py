@@ -288,9 +288,14 @@ def test_reference_names_of_helpers_and_return_shapes():
     assert metadata.assert_valid_comodo(ds) is None and metadata.cf_parser(ds) == (ds, {})
 
 
-def test_raw_bodies_under_the_reference_names(backend):
-    """`gridops.diff_forward` & co (xgcm/gridops.py:23-24, :76-77, :123-126, :172-175): padded array in, two-point result out"""
+def test_raw_bodies_under_the_reference_names(monkeypatch):
+    """`gridops.diff_forward` & co (xgcm/gridops.py:23-24, :76-77, :123-126, :172-175): padded array in, two-point result out
+    (the same bodies the registered ufuncs carry as `.ufunc`, which `test_grid_api.py` / `test_integer_exact.py` run on HIP)"""
+    from oracle import fake_device
     from xgcm_amd import gridops as G
+
+    fake_device.install(monkeypatch)
+    assert G.diff_center_to_left.ufunc.__name__ == G.diff_forward.__name__ == "diff_forward"
 
     a = R.synthetic_field((3, 7), 5)
     for body, want in ((G.diff_forward, a[..., 1:] - a[..., :-1]), (G.interp_forward, (a[..., :-1] + a[..., 1:]) / 2.0),
