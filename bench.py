@@ -16,6 +16,15 @@ reduction only => weak scaling, value = cells of all ranks / max-over-ranks time
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the timed
 region) and `cpu_baseline` (the numpy oracle = the reference's eager call sequence, timed on a
 bounded sample on this box's host cores; N=1 only).
+
+AFTER the headline's timed region (value / ms_per_step are not touched by it) the same process puts
+one-rank shares of BASELINE configs[2..4] under the same clock and adds them to the line as `configs`
+(`--no-configs` skips it): config 3 `derivative` X / Y / Z with random 2-D / 1-D metrics + `integrate` Z,
+config 4 `cumsum` Z center->left / center->outer over a resident batch of records, config 5 the fused
+vorticity and the chain AS WRITTEN under `grid.fused()` on 4320 x 4320 x 90 -- each with HIP-event ms,
+fraction of 8 TB/s on SURVEY section 8(d)'s bytes, and a bit check of a slab against the oracle (made in
+the cpu_baseline leg, after every timed span).  `box_probe` = three launches of cumsum Z on ONE record:
+the figure that tells a fast box (1.65 - 1.70 ms) from a slow one (2.0), DESIGN section 8.
 """
 
 import argparse
@@ -126,6 +135,12 @@ def cpu_baseline(levels=8, budget_s=20.0):
     return out
 
 
+def _kernel_base(name: str) -> str:
+    """`void k_stencil_strided_ys<0, 1>(Args) [clone .kd]` -> `k_stencil_strided_ys`"""
+    head = name.split("<")[0].split("(")[0].strip()
+    return head.split()[-1].split("::")[-1].replace(".kd", "") if head else ""
+
+
 def pmc_passes(dominant: str, levels: int, alg_bytes: float, timeout_s: int = 120):
     """HBM bytes per launch of the dominant kernel measured NOW: two child runs of this file under `rocprofv3 --pmc`, one
     counter per pass (FETCH_SIZE, WRITE_SIZE) with `--kernel-trace` only -- never combined with another trace domain --
@@ -149,7 +164,7 @@ def pmc_passes(dominant: str, levels: int, alg_bytes: float, timeout_s: int = 12
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "3", "--warmup", "1", "--levels", str(levels), "--no-cpu-baseline", "--no-pmc"]
+                   "--steps", "3", "--warmup", "1", "--levels", str(levels), "--no-cpu-baseline", "--no-pmc", "--no-configs"]
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 proc.wait(timeout_s)
@@ -162,13 +177,215 @@ def pmc_passes(dominant: str, levels: int, alg_bytes: float, timeout_s: int = 12
             rows = sqlite3.connect(dbs[0]).execute(
                 "select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
             # full-size launches of the dominant kernel (the one-level spot check launches the same kernels on 1 / 75 of the data)
-            vals = [v for name, v in rows if dominant in name and v * 1024 > 0.2 * alg_bytes]
+            # (the name up to its template list: `k_stencil_strided_ys` must not also match `k_stencil_strided_ysm<...>`)
+            vals = [v for name, v in rows if _kernel_base(name) == dominant and v * 1024 > 0.2 * alg_bytes]
             if not vals:
                 return None, f"no {dominant} dispatch in the {counter} pass", time.perf_counter() - t0
             kib[counter] = sum(vals) / len(vals)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return kib["FETCH_SIZE"] * 1024 * 2 + kib["WRITE_SIZE"] * 1024, "measured", time.perf_counter() - t0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# `configs`: BASELINE configs[2..4] under the driver's clock (VERDICT r05 "next round" 1).  reference: xgcm/grid.py:1534-1605
+# (derivative / integrate), :1183-1418 (cumsum), docs/ufunc_examples.md:96-311 (vorticity)
+# ---------------------------------------------------------------------------------------------------------------------
+def _timed(fn, reps, sync, warm_s=0.15):
+    """HIP events on the launch stream around `reps` back-to-back calls, after at least `warm_s` of untimed calls
+    (allocator steady state, clocks); returns (median ms, mean ms, last result)"""
+    t0 = time.perf_counter()
+    out = fn()
+    sync()
+    calls = 1
+    while time.perf_counter() - t0 < warm_s or calls < 2:
+        out = fn()
+        sync()
+        calls += 1
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        out = fn()
+        ev[i + 1].record()
+    sync()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+    return ts[len(ts) // 2], float(np.mean(ts)), out
+
+
+def _entry(name, kernel_bytes_per_cell, cells, med_ms, mean_ms, **extra):
+    gbs = cells * kernel_bytes_per_cell / (med_ms * 1e-3) / 1e9
+    e = {"op": name, "ms": round(med_ms, 4), "mean_ms": round(mean_ms, 4), "cells": int(cells),
+         "bytes_per_cell": round(kernel_bytes_per_cell, 4), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBPS, 4)}
+    e.update(extra)
+    return e
+
+
+def run_configs(ranks, field, reps, records4):
+    """One rank's share of configs[2..4], every rank of the job at once (barrier before each config; no data-path
+    collective).  Returns (block, slabs): `block` goes into the JSON line, `slabs` are small host copies of inputs and
+    of the HIP results that `check_configs` hands to the oracle AFTER all timed spans."""
+    from tools.bench_configs import config5_grid, mitgcm_grid
+    from xgcm_amd import DataArray
+    from xgcm_amd import device as D
+    from xgcm_amd import sharding as S
+
+    sync = torch.cuda.synchronize
+    world, rank = ranks.world, ranks.rank
+    nz, ny, nx = NZ, NY, NX
+    cells = nz * ny * nx
+    block, slabs = {}, {}
+    t_all = time.perf_counter()
+
+    def gather(entries):
+        """per-op figures of every rank -> rank 0's entry carries the slowest rank's time and the job's aggregate"""
+        if world == 1:
+            return entries
+        per_rank = ranks.gather_objects([(e["ms"], e["cells"]) for e in entries])
+        if rank == 0:
+            for i, e in enumerate(entries):
+                ms = [r[i][0] for r in per_rank]
+                tot = sum(r[i][1] for r in per_rank)
+                e["per_rank_ms"] = ms
+                e["job_gcell_s"] = round(tot / (max(ms) * 1e-3) / 1e9, 2)
+        return entries
+
+    # ---- config 3: derivative X / Y / Z (random metrics dxC(YC,XG), dyC(YG,XC), drC(Zl)) and integrate Z (drF(Z)) ----
+    ranks.barrier()
+    grid = mitgcm_grid(nz, ny, nx)
+    T = DataArray(field, ("Z", "YC", "XC"), name="T")
+    c3 = []
+    for name, fn, bpc in (("derivative(T,'X') / dxC(YC,XG), periodic", lambda: grid.derivative(T, "X"), 16 + 8 / nz),
+                          ("derivative(T,'Y') / dyC(YG,XC), extend", lambda: grid.derivative(T, "Y"), 16 + 8 / nz),
+                          ("derivative(T,'Z') / drC(Zl), fill", lambda: grid.derivative(T, "Z"), 16.0),
+                          ("integrate(T,'Z') * drF(Z)", lambda: grid.integrate(T, "Z"), 8 + 8 / nz)):
+        med, mean, out = _timed(fn, reps, sync)
+        c3.append(_entry(name, bpc, cells, med, mean))
+        key = name.split(" ")[0]
+        if rank == 0:
+            if "'Z'" in name:   # all levels of two rows
+                slabs[key] = (D.tohost(field[:, :2].contiguous()), D.tohost(out.data[..., :2, :].contiguous()))
+            else:               # level 0
+                slabs[key] = (D.tohost(field[:1].contiguous()), D.tohost(out.data[:1].contiguous()))
+        del out
+    if rank == 0:
+        slabs["metrics"] = {k: D.tohost(grid._ds[k].data) for k in ("dxC", "dyC", "drF", "drC")}
+    block["config3"] = {"workload": f"configs[2]: Grid.derivative X/Y/Z + Grid.integrate Z on {nx}x{ny}x{nz} f64 with random dx/dy/dz metrics, one record per GPU",
+                        "ops": gather(c3)}
+
+    # ---- box probe: three launches of cumsum Z on ONE record (DESIGN section 8: 1.65 - 1.70 ms fast boxes, 2.0 slow ones) ----
+    grid.cumsum(T, "Z")
+    sync()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record()
+    for i in range(3):
+        grid.cumsum(T, "Z")
+        ev[i + 1].record()
+    sync()
+    probe = [round(ev[i].elapsed_time(ev[i + 1]), 4) for i in range(3)]
+    block["box_probe"] = {"op": f"cumsum(T,'Z') center->left on one {nx}x{ny}x{nz} f64 record, 3 launches", "ms": probe,
+                          "frac": round(cells * 16 / (min(probe) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+    if world > 1:
+        allp = ranks.gather_objects(probe)
+        if rank == 0:
+            block["box_probe"]["per_rank_ms"] = allp
+    del T
+    torch.cuda.empty_cache()
+
+    # ---- config 4: cumsum Z over a resident batch of this rank's records (360 records over the record axis) ----
+    lo, hi = S.shard_bounds(360, world, rank)
+    nrec = max(1, min(records4, hi - lo))
+    T4 = DataArray(D.synthetic((nrec, nz, ny, nx), 4, offset=lo * cells), ("time", "Z", "YC", "XC"))
+    c4 = []
+    for to in ("left", "outer"):
+        kw = {} if to == "left" else {"to": to}
+        ranks.barrier()
+        med, mean, out = _timed(lambda: grid.cumsum(T4, "Z", **kw), reps, sync, warm_s=0.3)
+        c4.append(_entry(f"cumsum(T,'Z') center->{to}, fill, {nrec} resident records of {nx}x{ny}x{nz} f64", 16.0, nrec * cells, med, mean,
+                         ms_per_record=round(med / nrec, 4)))
+        if rank == 0:
+            slabs["cumsum_" + to] = (D.tohost(T4.data[nrec - 1, :, :2].contiguous()), D.tohost(out.data[nrec - 1, :, :2].contiguous()))
+        del out
+        torch.cuda.empty_cache()
+    block["config4"] = {"workload": f"configs[3]: Grid.cumsum along Z (75 levels) on 3600x2400x75x360 sharded over t: this job's ranks each scan a resident "
+                                    f"batch of {nrec} of their {hi - lo} records", "ops": gather(c4)}
+    del T4, grid
+    torch.cuda.empty_cache()
+
+    # ---- config 5: vorticity on 4320 x 4320 x 90 split along Z over the ranks, `fill` ----
+    nz5, n5 = 90, 4320
+    l5, h5 = S.shard_bounds(nz5, world, rank)
+    nl = h5 - l5
+    g5 = config5_grid(n5, n5)
+    plane = n5 * n5
+    c5 = []
+    if nl:
+        U = DataArray(D.synthetic((nl, n5, n5), 51, offset=l5 * plane), ("Z", "YC", "XG"))
+        V = DataArray(D.synthetic((nl, n5, n5), 52, offset=l5 * plane), ("Z", "YG", "XC"))
+        area = g5._ds["rAz"].reset_coords(drop=True)
+
+        def as_written():
+            with g5.fused():
+                zeta = (g5.diff(V, "X") - g5.diff(U, "Y")) / area
+            zeta.data  # the use
+            return zeta
+
+        def chain():
+            return (g5.diff(V, "X") - g5.diff(U, "Y")) / area
+
+        bpc5 = 24 + 8 / nl
+        ranks.barrier()
+        for name, fn, n in (("vorticity fused: grid.vorticity(U,V) = (diff(v,X)-diff(u,Y))/rAz, one launch", lambda: g5.vorticity(U, V), reps),
+                            ("vorticity chain AS WRITTEN under grid.fused(): (grid.diff(V,'X') - grid.diff(U,'Y')) / rAz", as_written, reps),
+                            ("vorticity chain eager (4 launches, the reference's order), fused-equivalent bytes", chain, max(3, reps // 2))):
+            med, mean, out = _timed(fn, n, sync, warm_s=0.3)
+            c5.append(_entry(name, bpc5, nl * plane, med, mean))
+            if rank == 0:
+                slabs.setdefault("vorticity", []).append(D.tohost(out.data[:1].contiguous()))
+            del out
+        if rank == 0:
+            slabs["vorticity_in"] = (D.tohost(U.data[:1].contiguous()), D.tohost(V.data[:1].contiguous()), D.tohost(area.data))
+        del U, V
+    else:
+        ranks.barrier()
+    if world > 1 and not nl:  # more ranks than levels: still part of the gather
+        c5 = [_entry("(no levels on this rank)", 24.0, 0, 1.0, 1.0) for _ in range(3)]
+    levels = [S.shard_bounds(nz5, world, r)[1] - S.shard_bounds(nz5, world, r)[0] for r in range(world)]
+    block["config5"] = {"workload": f"configs[4]: chained vorticity (diff(v,'X')-diff(u,'Y'))/area on {n5}x{n5}x{nz5} f64, fill, split along Z over the ranks "
+                                    f"(levels per rank {levels})", "ops": gather(c5)}
+    torch.cuda.empty_cache()
+    ranks.barrier()
+    block["seconds"] = round(time.perf_counter() - t_all, 1)
+    return block, slabs
+
+
+def check_configs(block, slabs):
+    """Part of the cpu_baseline leg: the slabs the timed spans kept (host copies of a few rows of inputs and HIP results)
+    against the oracle, bit for bit."""
+    from oracle import refimpl as R
+
+    m = slabs["metrics"]
+    eq = lambda a, b: bool(a.shape == b.shape and np.array_equal(a, b, equal_nan=True))  # noqa: E731
+    a, got = slabs["derivative(T,'X')"]
+    ok3 = [eq(got, R.derivative(a, 2, 1, 0, "periodic", 0.0, m["dxC"][None]))]
+    a, got = slabs["derivative(T,'Y')"]
+    ok3.append(eq(got, R.derivative(a, 1, 1, 0, "extend", 0.0, m["dyC"][None])))
+    a, got = slabs["derivative(T,'Z')"]
+    ok3.append(eq(got, R.derivative(a, 0, 1, 0, "fill", 0.0, m["drC"][:, None, None])))
+    a, got = slabs["integrate(T,'Z')"]
+    ok3.append(eq(got, R.integrate(a, 0, m["drF"][:, None, None])))
+    for e, ok in zip(block["config3"]["ops"], ok3):
+        e["bit_exact_vs_oracle"] = ok
+    for e, to in zip(block["config4"]["ops"], ("left", "outer")):
+        a, got = slabs["cumsum_" + to]
+        e["bit_exact_vs_oracle"] = eq(got, R.grid_cumsum(a, 0, "center", to, "fill", 0.0))
+    if "vorticity_in" in slabs:
+        u, v, area = slabs["vorticity_in"]
+        want = R.vorticity(u, v, area[None], "fill", "fill")
+        for e, got in zip(block["config5"]["ops"], slabs["vorticity"]):
+            e["bit_exact_vs_oracle"] = eq(got, want)
+    block["checked"] = ("level 0 (X, Y ops, vorticity) or all levels of rows 0-1 (Z ops; last record of the batch) of every HIP result "
+                        "against oracle/refimpl.py on the same slab of the input, numpy.array_equal")
+
 
 
 def main():
@@ -178,6 +395,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--levels", type=int, default=NZ, help="Z levels (default = the full 75; smaller only for debugging)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (configs[2..4] after the headline's timed region)")
+    ap.add_argument("--config4-records", type=int, default=6, help="`configs`: records of 3600x2400x75 in the resident batch of config 4 (per rank)")
+    ap.add_argument("--config-reps", type=int, default=7, help="`configs`: timed launches per operator")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child passes (N = 1 only; "
                     "also XG_BENCH_PMC=0): the committed figure of profiles/pmc_traffic.json is reported instead")
     args = ap.parse_args()
@@ -271,6 +491,10 @@ def main():
     alg_bytes = cells_per_op * BYTES_PER_CELL
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
 
+    cfg_block = cfg_slabs = None
+    if not args.no_configs and nz == NZ:
+        cfg_block, cfg_slabs = run_configs(ranks, field, args.config_reps, args.config4_records)
+
     if rank == 0:
         total_cells = cells_per_s * elapsed
         # HBM bytes per launch of the dominant kernel: NOT measured in this run (counter passes serialise the kernels and
@@ -341,6 +565,10 @@ def main():
                 S.set_affinity_all_threads(S.parse_cpulist(before))
             line["cpu_baseline"] = cpu_baseline()
             line["parity_spot_check"] = spot_check(spot)
+        if cfg_block is not None:
+            if not args.no_cpu_baseline:  # the oracle is the checker of the slabs kept by the timed spans, nothing else
+                check_configs(cfg_block, cfg_slabs)
+            line["configs"] = cfg_block
         print(json.dumps(line), flush=True)
     ranks.close()
 
