@@ -304,3 +304,34 @@ def test_bswap_and_half_conversion_on_the_gpu():
             assert down.dtype == np.float16 and np.array_equal(down.view(np.uint16)[~np.isnan(x)], x.astype(np.float16).view(np.uint16)[~np.isnan(x)])
             assert np.isnan(down[np.isnan(x)]).all()
     assert _hip.load().xg_bswap(None, 0, 2, None) == 0
+
+
+@pytest.mark.parametrize("wdtype", (np.float16, np.int8, np.bool_))
+def test_float16_average_divides_by_the_sum_of_the_weights(tbackend, wdtype):
+    """`Grid.average` of a float16 field with a float16 / int8 / bool metric is sum(x * w) / sum(w) over the
+    valid cells -- the float16 branch of `device.reduce1d` once folded the weight into the field and left the kernel a plain COUNT
+    for its denominator (sum(x * w) / N).  One dim (the one-pass mean mode) and two dims (the pair mode)."""
+    nz, ny, nx = 3, 6, 16
+    T = _half_field((nz, ny, nx), 9, "=")
+    T[1, 2, 3] = np.nan
+    if wdtype is np.bool_:
+        w = (R.synthetic_field((ny, nx), 11) > -0.25)
+        w[0, 0] = True
+    else:
+        w = (np.round(R.synthetic_metric((ny, nx), 31) / 400.0) + 3.0).astype(wdtype)  # 5 ... 8: far from 1
+    coords = {"XC": ("XC", np.arange(nx) + 0.5), "XG": ("XG", np.arange(nx) * 1.0), "YC": ("YC", np.arange(ny) + 0.5),
+              "YG": ("YG", np.arange(ny) * 1.0), "Z": ("Z", np.arange(nz) + 0.5)}
+    ds = Dataset({"T": (("Z", "YC", "XC"), T), "dxF": (("YC", "XC"), w), "rA": (("YC", "XC"), w)}, coords)
+    grid = Grid(ds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}, "Z": {"center": "Z"}},
+                padding={"X": "periodic", "Y": "extend"}, metrics={("X",): ["dxF"], ("X", "Y"): ["rA"]}, autoparse_metadata=False)
+    x64, w64 = T.astype(np.float64), w.astype(np.float64)[None]
+    valid = ~np.isnan(x64)
+    for dims, red in ((["X"], (2,)), (["X", "Y"], (1, 2))):
+        got = grid.average(ds["T"], dims).values
+        want = np.where(valid, x64 * w64, 0.0).sum(red) / np.where(valid, w64, 0.0).sum(red)
+        wrong = np.where(valid, x64 * w64, 0.0).sum(red) / valid.sum(red)  # what the folded weight computed
+        assert got.dtype == np.float16 and got.shape == want.shape
+        tol = 8 * nx * ny * 2.0**-10 * np.abs(want).max() + 2.0**-9
+        assert np.abs(got.astype(np.float64) - want).max() <= tol
+        if wdtype is not np.bool_:
+            assert np.abs(wrong - want).max() > 4 * tol  # (the test can tell the two apart)

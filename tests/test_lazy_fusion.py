@@ -343,6 +343,20 @@ def test_connected_grid_errors_raise_at_the_call(backend):
     v = DataArray(np.ones((2, TT.N, TT.N)), dims=("face", "x", "yl"))
     with pytest.raises(ValueError, match="requires `other_component`"):
         g2.interp({"Y": v}, "X")
+    # the argument checks of the eager call run at the deferred call too -- a malformed vector component ...
+    with pytest.raises(ValueError, match="exactly one key/value pair"):
+        g2.diff({"X": ds.data_c, "Y": ds.data_c}, "X")
+    with pytest.raises(ValueError, match="Vector component with unknown axis"):
+        g2.diff({"W": ds.data_c}, "X")
+    # ... and a face the connections leave out, on an axis NO link touches (the fused kernels serve it; the reference's face
+    # loop raises KeyError(face)): at the call, not at the first use of the result
+    three = TT._faces_ds(nf=3)
+    g3 = Grid(three, coords=TT.COORDS, face_connections=TT.X_TO_X, padding="fill", autoparse_metadata=False)
+    with pytest.raises(KeyError):
+        g3.diff(three.data_c, "Y")
+    with g3.fused():
+        with pytest.raises(KeyError):
+            g3.diff(three.data_c, "Y")
 
 
 def test_vorticity_chain_on_a_fold_grid(backend):

@@ -2,7 +2,7 @@
 // STRIPPED kernel reach that moves the same bytes and executes the same count of IEEE divisions / products per cell,
 // with nothing else (no halo logic, no neighbour exchange, no searches)?  Tuning aid, not part of the product.
 //
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/arith_probe.hip -o build/arith_probe && build/arith_probe
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/probes/arith_probe.hip -o tools/probes/arith_probe && tools/probes/arith_probe
 //
 // A. flat kernels on a (75, 2400, 3600) f64 field, one 16-B vector per thread, XCD-banded, band-major row order (all
 //    levels of a band of 16 rows before the next band: the metric planes stay in the XCD's L2), non-temporal loads / stores:

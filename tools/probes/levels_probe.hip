@@ -1,5 +1,5 @@
 // levels_probe.hip -- the level-major Z scan (K5L, round 3) as a stand-alone probe: does ANY shape of it beat the march?
-//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/levels_probe.hip -o tools/levels_probe && tools/levels_probe
+//   hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/probes/levels_probe.hip -o tools/levels_probe && tools/levels_probe
 // One generation of waves; a wave keeps the running sums of NT consecutive x-tiles (64 lanes x 16 B) in registers and
 // sweeps the levels once; rows through buffer descriptors; straight-line levels; loads run D - 1 groups of G tiles ahead.
 // Variants <NT, G, D>: registers = 4 NT (sums) + 4 G D (buffers) + ~25.  Every variant is checked bit for bit against the

@@ -4,7 +4,7 @@
 // that store's write acknowledgement; flat kernels hide it by wave turnover, a long-lived marching wave cannot.
 // Test: split the roles -- a LOADER wave (loads only) hands rows through LDS to a STORER wave (stores only).
 // Tuning aid for xgcm_amd/csrc/xg_scan.hip (not part of the product).
-//   hipcc -O3 --offload-arch=gfx950 tools/marchprobe.hip -o gpurun_out/marchprobe && gpurun_out/marchprobe
+//   hipcc -O3 --offload-arch=gfx950 tools/probes/marchprobe.hip -o gpurun_out/marchprobe && gpurun_out/marchprobe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

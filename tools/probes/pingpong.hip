@@ -2,7 +2,7 @@
 // flavour of the polling load and the publishing store.  Decides how the chained scan (xg_scan.hip, K5c) passes its
 // running sums.  Every poll loop gives up after 2^20 tries (reported as GAVE UP): a flavour that reads a stale L1 line
 // must not hang the box.  Tuning aid, not part of the product.
-//   hipcc -O3 --offload-arch=gfx950 tools/pingpong.hip -o build/pingpong && build/pingpong
+//   hipcc -O3 --offload-arch=gfx950 tools/probes/pingpong.hip -o build/pingpong && build/pingpong
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,5 +1,5 @@
 // store_probe.hip -- the KERNEL-side variables of the Z scan's store pattern (VERDICT r05 "next round" 2).
-//   hipcc -O3 --offload-arch=gfx950 tools/store_probe.hip -o tools/store_probe && tools/store_probe [P ny nx]
+//   hipcc -O3 --offload-arch=gfx950 tools/probes/store_probe.hip -o tools/probes/store_probe && tools/probes/store_probe [P ny nx]
 // The scan along Z of (Z, Y, X) writes P = 75 planes 69 MB apart AT ONCE; round 5 varied where the output lives (plain /
 // scattered physical memory) and found one time per box, 1.65 - 2.02 ms.  This probe varies what the KERNEL does instead:
 //   NT   bytes one wave writes to one plane in one go: NT x (64 lanes x LB bytes), LB = 8 or 16  -> 512 B ... 8 KB
@@ -345,7 +345,7 @@ int main(int argc, char** argv) {
   for (int scat = 0; scat < 2; ++scat) {
     Buf out = make(bytes, scat != 0);
     if (pmc) {
-      // a fixed sequence for tools/store_probe_pmc.py: every line below = 9 dispatches (2 warm-ups + 7 timed) of ONE kernel,
+      // a fixed sequence for tools/probes/store_probe_pmc.py: every line below = 9 dispatches (2 warm-ups + 7 timed) of ONE kernel,
       // in this order, on this buffer kind; the counters of the last 3 dispatches of each group are averaged
       const int64_t nvec = (int64_t)(bytes / 16);
       const u32 nb = (u32)(((nvec + 255) / 256 + 7) / 8 * 8);

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""TCC counters of the store-pattern probe's variants (tools/store_probe.hip, section `pmc`): one `rocprofv3 --pmc` pass with
+"""TCC counters of the store-pattern probe's variants (tools/probes/store_probe.hip, section `pmc`): one `rocprofv3 --pmc` pass with
 --kernel-trace only, dispatches joined to the probe's own lines by ORDER (every line = 9 dispatches of one kernel; the k_diffcount /
 memset helpers are skipped by name).
 
-    python tools/store_probe_pmc.py [--counters TCC_TAG_STALL,TCC_EA0_RDREQ_DRAM_CREDIT_STALL,TCC_EA0_WRREQ_STALL,TCC_BUSY]
+    python tools/probes/store_probe_pmc.py [--counters TCC_TAG_STALL,TCC_EA0_RDREQ_DRAM_CREDIT_STALL,TCC_EA0_WRREQ_STALL,TCC_BUSY]
 """
 import argparse
 import glob
@@ -14,7 +14,7 @@ import sqlite3
 import subprocess
 import tempfile
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main():
@@ -24,7 +24,7 @@ def main():
     counters = a.counters.split(",")
     tmp = tempfile.mkdtemp(prefix="xg_sp_", dir="/tmp")
     try:
-        cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", tmp, "-o", "p", "--", os.path.join(REPO, "tools", "store_probe"), "75", "2400", "3600", "pmc"]
+        cmd = ["rocprofv3", "--pmc", *counters, "--kernel-trace", "-d", tmp, "-o", "p", "--", os.path.join(REPO, "tools", "probes", "store_probe"), "75", "2400", "3600", "pmc"]
         p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=280)
         lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith("{") and "variant" in ln]
         dbs = sorted(glob.glob(os.path.join(tmp, "**", "*.db"), recursive=True))

@@ -1,6 +1,6 @@
 // streambench.hip -- what HBM streaming rate can a read-one/write-one f64 kernel reach on this
 // MI355X, and with which launch shape?  Tuning aid for xgcm_amd/csrc/xg_*.hip (not part of the product).
-//   hipcc -O3 --offload-arch=gfx950 tools/streambench.hip -o gpurun_out/streambench && ./streambench
+//   hipcc -O3 --offload-arch=gfx950 tools/probes/streambench.hip -o gpurun_out/streambench && ./streambench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -1,6 +1,6 @@
 // xcc_probe: which XCD (XCC_ID hardware register) does workgroup b of a 1-D launch land on?
 // The kernels' "banding" assumes b % 8 (round-robin dispatch, SPX mode); this prints the observed map.
-//   hipcc --offload-arch=gfx950 tools/xcc_probe.hip -o build/xcc_probe && build/xcc_probe
+//   hipcc --offload-arch=gfx950 tools/probes/xcc_probe.hip -o build/xcc_probe && build/xcc_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -175,7 +175,7 @@ struct Tune {
   int reduce_zl;      // K4cz: outer indices per task of the chained weighted reduction sharing the weight rows (1 / 2 / 4)
   int dbg;            // A/B switches that do NOT change results (bit 2: the linear transform's division inside its loop)
   int march_lds_kb;   // optional dynamic LDS request for the column-marching kernels, only to cap residency
-                      // (experiment: +8 % on a bare march in tools/streambench.hip, but -20 % on the real
+                      // (experiment: +8 % on a bare march in tools/probes/streambench.hip, but -20 % on the real
                       // kernels whose index/metric math then has too few waves to hide behind) => default 0
 };
 extern "C" __attribute__((visibility("hidden"))) Tune* xg_internal_tune(void);

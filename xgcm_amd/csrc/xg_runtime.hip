@@ -381,7 +381,11 @@ int xg_scatter_alloc(void** ptr, uint64_t bytes, uint64_t chunk_bytes, int group
     }
   }
   for (void* sp : spacers) (void)hipFree(sp);
-  for (u64 i = 0; i < n && err == hipSuccess; ++i) err = hipMemMap((char*)va + i * chunk, chunk, 0, sb.handles[i], 0);
+  u64 mapped = 0;  // chunks [0, mapped) are mapped: an error half way is undone chunk by chunk
+  for (; mapped < n && err == hipSuccess; ++mapped) {
+    err = hipMemMap((char*)va + mapped * chunk, chunk, 0, sb.handles[mapped], 0);
+    if (err != hipSuccess) break;
+  }
   if (err == hipSuccess) {
     hipMemAccessDesc desc;
     memset(&desc, 0, sizeof(desc));
@@ -391,7 +395,9 @@ int xg_scatter_alloc(void** ptr, uint64_t bytes, uint64_t chunk_bytes, int group
     err = hipMemSetAccess(va, sb.total, &desc, 1);
   }
   if (err != hipSuccess) {
-    (void)hipMemUnmap(va, sb.total);
+    // only what was mapped is unmapped, one chunk at a time (a single hipMemUnmap over a partially mapped range fails and
+    // would leave chunks mapped inside an address range that is freed below)
+    for (u64 i = 0; i < mapped; ++i) (void)hipMemUnmap((char*)va + i * chunk, chunk);
     for (auto h : sb.handles) if (h) (void)hipMemRelease(h);
     (void)hipMemAddressFree(va, sb.total);
     (void)hipGetLastError();
@@ -430,15 +436,21 @@ int xg_scatter_free(void* ptr) {
 void* xg_pool_alloc(ssize_t size, int device, void* stream) {
   (void)stream;
   if (size <= 0) return nullptr;
+  // an allocation must not change the caller's current device as a side effect: switch for the duration only
   int cur = -1;
-  if (hipGetDevice(&cur) != hipSuccess || cur != device) {
-    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  }
+  const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+  const bool switched = !have_cur || cur != device;
+  if (switched && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   static const u64 chunk = (u64)env_int("XG_SCATTER_CHUNK_MB", 64) << 20;
   void* p = nullptr;
-  if (xg_scatter_alloc(&p, (uint64_t)size, chunk, 1, 0) == XG_OK) return p;
-  if (hipMalloc(&p, (size_t)size) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  {
+  bool fallback = false;
+  if (xg_scatter_alloc(&p, (uint64_t)size, chunk, 1, 0) != XG_OK) {
+    p = nullptr;
+    if (hipMalloc(&p, (size_t)size) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    else fallback = true;
+  }
+  if (switched && have_cur) (void)hipSetDevice(cur);
+  if (fallback) {
     std::lock_guard<std::mutex> lock(g_scatter_mu);
     ++g_pool_fallbacks;  // (reported by xg_scatter_stats: a result that lies in one plain block after all)
   }

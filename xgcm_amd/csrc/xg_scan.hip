@@ -14,7 +14,7 @@ namespace {
 // straight-line levels with exact vmcnt waits), so that the whole chip sweeps one level at a time like a copy.  Bit-exact,
 // but no faster than this march in any state of the device: 0.69-0.72 against 0.72-0.76 of 8 TB/s for one record, equal
 // from 4 records per launch on (profiles/history/r03c_*, r03i_ab_cumZ_records.jsonl) -- the number of DRAM streams and the
-// generation tail are not what holds the march back.  The stand-alone probe tools/levels_probe.hip (14 shapes: 8-32 tiles
+// generation tail are not what holds the march back.  The stand-alone probe tools/probes/levels_probe.hip (14 shapes: 8-32 tiles
 // per wave, groups of 2 / 4, loads 1-5 groups ahead; profiles/history/r03p_*): slow-kind box 0.675-0.680 whatever the depth against
 // 0.653 for the march and 0.82 for a copy; fast-kind box 0.738 against 0.766; the same waves loading only 0.83, storing
 // only 0.77 -- i.e. neither prefetch depth nor occupancy is the lever, and the two directions together cost 8 % more than
@@ -177,7 +177,7 @@ __device__ __forceinline__ void cumsum_strided_body(
 // landed group into one of two LDS stages, the other adds and stores, one LDS-only barrier per group, vmcnt(16..20) waits in
 // the steady state -- built into the library with every option of the scan, bit-exact on the whole suite, and measured in one
 // process on a slow-kind box: cumsum Z 0.6735 (this march) against 0.662-0.663 for all three shapes, 4 records in one launch
-// 0.748 against 0.740.  The probe's +2.5 points (tools/marchprobe.hip, round 2) were over a single wave WITHOUT the rolling
+// 0.748 against 0.740.  The probe's +2.5 points (tools/probes/marchprobe.hip, round 2) were over a single wave WITHOUT the rolling
 // window this march has since.  Removed again; profiles/EXPERIMENTS.md.)
 template <int V, int MET, bool NTL, bool NTS, int U, bool PIPE = false>
 __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
 // K5c: cumsum along a STRIDED axis for few, LONG columns (cumsum along Y of (Z, Y, X): 4 288 marches of 2 400 rows)
 // as a CHAINED FLAT launch.  A marching wave lives for the whole column: every load it waits for sits behind its own
 // earlier stores in the in-order vmcnt queue, and the chip touches every level at once (150 read + write streams);
-// measured with tools/marchprobe.hip the march stays at 62-71 % of 8 TB/s (box to box) where a flat launch over the
+// measured with tools/probes/marchprobe.hip the march stays at 62-71 % of 8 TB/s (box to box) where a flat launch over the
 // same bytes reaches 73-80 %.  Here a wave-task is (column = (outer index, x-tile), chunk c of R rows): it loads its
 // R rows at once, waits for the running sum that chunk c - 1 of its column published, adds its rows IN SEQUENCE
 // (the march's order: bit-identical), publishes its own last sum BEFORE issuing its R stores, and ends.
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_strided(
 //     written with a plain store (acknowledged by the XCD's L2 -- the chain lives behind ONE L2: agent-scope stores
 //     are acknowledged by memory behind the whole write stream, 2.9 instead of 1.9 ms; release / acquire fences cost
 //     a buffer_wbl2 / buffer_inv per task, 17 ms), polled with sc1 loads (bypass the L1); 0.3 us per hand-off when
-//     idle (tools/pingpong.hip), ~1 us under load.  The last chunk of a column zeroes its two slots: the workspace
+//     idle (tools/probes/pingpong.hip), ~1 us under load.  The last chunk of a column zeroes its two slots: the workspace
 //     is all-zero between launches (no per-launch memset, safe under graph replay);
 //   the spin is bounded (`scan_chain_spin` polls): a wave that gives up poisons its column with NaN and raises the
 //     stream's poison word, on which the rescue kernel queued behind every chained launch redoes the call (chain_wait).

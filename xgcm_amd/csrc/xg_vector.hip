@@ -34,7 +34,7 @@ template <int BOP> __device__ __forceinline__ real bin2(real a, real b) {
 }
 
 // `nta` / `ntb`: the operand is streamed exactly once (no broadcast dim) => non-temporal loads; together with the
-// XCD-banded block order that is worth 4 points on a three-stream kernel (tools/streambench.hip SB_TRIAD: 75.4 %
+// XCD-banded block order that is worth 4 points on a three-stream kernel (tools/probes/streambench.hip SB_TRIAD: 75.4 %
 // plain, 77.8 % with non-temporal loads, 79.1 % banded as well)
 template <int BOP, int V, bool NTS>
 __global__ __launch_bounds__(BLOCK) void k_binary(const real* __restrict__ a, const real* __restrict__ b,

@@ -390,6 +390,13 @@ def defer_stencil(grid, funcname, ufunc, sig, arg, ax_name, other_component, m_i
     call_kw = dict(kwargs, other_component=other_component, metric_in=m_in, metric_out=m_out)
     if not ufunc._fusable(grid, (arg,), [(ax_name,)], call_kw):
         return None
+    try:  # the argument checks of the eager call (gridops._fused -> _check_data_input): a malformed argument raises NOW
+        from .grid_ufunc import _check_data_input
+
+        _check_data_input(arg, grid)
+        _check_data_input(other_component, grid)
+    except Exception:  # noqa: BLE001 -- the eager call the caller falls back to raises it
+        return None
     da = _maybe_unpack_vector_component(arg)
     dt = _dtype_of(da)
     if dt not in _FUSABLE_FLOATS:
@@ -425,6 +432,10 @@ def defer_stencil(grid, funcname, ufunc, sig, arg, ax_name, other_component, m_i
         fv = grid._complete_user_kwargs_using_axis_defaults(kwargs.get("fill_value"), "fill_value")[ax_name]
         if (lo or hi) and not isinstance(bc, str):
             return None  # no boundary condition: the eager call raises the reference's error now
+        faces = getattr(grid, "_face_connections", None)
+        if faces is not None and (lo or hi) and grid._facedim in da.dims and \
+                any(i not in faces[grid._facedim] for i in range(da.sizes[grid._facedim])):
+            return None  # a face the connections leave out, on an axis no link touches: the eager call's KeyError, now
         if not (lo or hi):
             bc = None
     node = StencilNode(grid=grid, funcname=funcname, ufunc=ufunc, sig=sig, arg=arg, source=da, ax_name=ax_name,

@@ -404,7 +404,10 @@ def face_concat_name(grid, da, partner, padding_width):
     its FIRST piece, and the faces are concatenated with face 0 first.  So the name is the one of the source of face 0's
     last left link: the array's own, or -- for a vector component across an axis-swapping link -- its PARTNER's.  The axes
     are walked in the order of the reference's `list(set(...))` (:307-309), rebuilt here the same way; results that depend
-    on it are no fixture's business."""
+    on it are no fixture's business.  (ADVICE r05 asked for a deterministic order instead.  Kept as the reference has it, on
+    purpose: the order follows PYTHONHASHSEED there too, and the live differential fuzz -- reference and product in ONE
+    process, tests/test_reference_suite_live.py -- compares this very name; the grid's axis order made 17 of 400 calls of
+    seed 101 disagree with the reference.  Only the NAME of a padded vector component on an axis-swapping topology is affected.)"""
     links = getattr(grid, "_face_connections", None)
     if links is None or not isinstance(da, DataArray):
         return getattr(da, "name", None)

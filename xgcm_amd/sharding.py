@@ -207,8 +207,10 @@ def set_affinity_all_threads(cpus) -> int:
     cpus = sorted(cpus)
     os.sched_setaffinity(0, cpus)
     moved = 1
+    import threading
+
     try:
-        me = os.getpid()
+        me = threading.get_native_id()  # the CALLING thread's tid (os.getpid() is the main thread's: ADVICE r05)
         tids = [int(t) for t in os.listdir("/proc/self/task")]
     except OSError:
         return moved
