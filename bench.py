@@ -40,9 +40,40 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 NZ, NY, NX = 75, 2400, 3600
+CONFIG5_SHAPE = (90, 4320, 4320)
+BASELINE_SHAPES = ((NZ, NY, NX), CONFIG5_SHAPE)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_PER_CELL = 16.0  # 1 f64 read + 1 f64 write per output cell
 OPS = [("interp", "X"), ("diff", "X"), ("interp", "Y"), ("diff", "Y")]
+
+
+class Mark:
+    """a point on the launch stream: a HIP event (torch's current stream = the stream the kernels go to).  Without a GPU the
+    device layer raises long before a Mark is made -- except in the CPU dry run of tests/test_bench_dryrun.py, where the TEST
+    harness has swapped the device layer's memory for the host build of the C ABI to drive this file's launcher / rank / JSON
+    path with 8 gloo ranks; the marks are then host clock readings (no number of such a run is a measurement)."""
+
+    def __init__(self):
+        if torch.cuda.is_available():
+            self.ev = torch.cuda.Event(enable_timing=True)
+            self.ev.record()
+        else:
+            self.t = time.perf_counter()
+
+    def ms_until(self, later: "Mark") -> float:
+        if torch.cuda.is_available():
+            return self.ev.elapsed_time(later.ev)
+        return (later.t - self.t) * 1e3
+
+
+def _empty_cache():
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
+def sync():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
 
 
 def kernel_of_axis():
@@ -202,13 +233,12 @@ def _timed(fn, reps, sync, warm_s=0.15):
         out = fn()
         sync()
         calls += 1
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-    ev[0].record()
+    ev = [Mark()]
     for i in range(reps):
         out = fn()
-        ev[i + 1].record()
+        ev.append(Mark())
     sync()
-    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))
+    ts = sorted(ev[i].ms_until(ev[i + 1]) for i in range(reps))
     return ts[len(ts) // 2], float(np.mean(ts)), out
 
 
@@ -229,7 +259,6 @@ def run_configs(ranks, field, reps, records4):
     from xgcm_amd import device as D
     from xgcm_amd import sharding as S
 
-    sync = torch.cuda.synchronize
     world, rank = ranks.world, ranks.rank
     nz, ny, nx = NZ, NY, NX
     cells = nz * ny * nx
@@ -275,13 +304,12 @@ def run_configs(ranks, field, reps, records4):
     # ---- box probe: three launches of cumsum Z on ONE record (1.65 - 1.70 ms fast boxes, 2.0 slow ones) ----
     grid.cumsum(T, "Z")
     sync()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-    ev[0].record()
+    ev = [Mark()]
     for i in range(3):
         grid.cumsum(T, "Z")
-        ev[i + 1].record()
+        ev.append(Mark())
     sync()
-    probe = [round(ev[i].elapsed_time(ev[i + 1]), 4) for i in range(3)]
+    probe = [round(ev[i].ms_until(ev[i + 1]), 4) for i in range(3)]
     block["box_probe"] = {"op": f"cumsum(T,'Z') center->left on one {nx}x{ny}x{nz} f64 record, 3 launches", "ms": probe,
                           "frac": round(cells * 16 / (min(probe) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
     if world > 1:
@@ -289,7 +317,7 @@ def run_configs(ranks, field, reps, records4):
         if rank == 0:
             block["box_probe"]["per_rank_ms"] = allp
     del T
-    torch.cuda.empty_cache()
+    _empty_cache()
 
     # ---- config 4: cumsum Z over a resident batch of this rank's records (360 records over the record axis) ----
     lo, hi = S.shard_bounds(360, world, rank)
@@ -305,22 +333,22 @@ def run_configs(ranks, field, reps, records4):
         if rank == 0:
             slabs["cumsum_" + to] = (D.tohost(T4.data[nrec - 1, :, :2].contiguous()), D.tohost(out.data[nrec - 1, :, :2].contiguous()))
         del out
-        torch.cuda.empty_cache()
+        _empty_cache()
     block["config4"] = {"workload": f"configs[3]: Grid.cumsum along Z (75 levels) on 3600x2400x75x360 sharded over t: this job's ranks each scan a resident "
                                     f"batch of {nrec} of their {hi - lo} records", "ops": gather(c4)}
     del T4, grid
-    torch.cuda.empty_cache()
+    _empty_cache()
 
     # ---- config 5: vorticity on 4320 x 4320 x 90 split along Z over the ranks, `fill` ----
-    nz5, n5 = 90, 4320
+    nz5, n5y, n5 = CONFIG5_SHAPE
     l5, h5 = S.shard_bounds(nz5, world, rank)
     nl = h5 - l5
-    g5 = config5_grid(n5, n5)
-    plane = n5 * n5
+    g5 = config5_grid(n5y, n5)
+    plane = n5y * n5
     c5 = []
     if nl:
-        U = DataArray(D.synthetic((nl, n5, n5), 51, offset=l5 * plane), ("Z", "YC", "XG"))
-        V = DataArray(D.synthetic((nl, n5, n5), 52, offset=l5 * plane), ("Z", "YG", "XC"))
+        U = DataArray(D.synthetic((nl, n5y, n5), 51, offset=l5 * plane), ("Z", "YC", "XG"))
+        V = DataArray(D.synthetic((nl, n5y, n5), 52, offset=l5 * plane), ("Z", "YG", "XC"))
         area = g5._ds["rAz"].reset_coords(drop=True)
 
         def as_written():
@@ -350,9 +378,9 @@ def run_configs(ranks, field, reps, records4):
     if world > 1 and not nl:  # more ranks than levels: still part of the gather
         c5 = [_entry("(no levels on this rank)", 24.0, 0, 1.0, 1.0) for _ in range(3)]
     levels = [S.shard_bounds(nz5, world, r)[1] - S.shard_bounds(nz5, world, r)[0] for r in range(world)]
-    block["config5"] = {"workload": f"configs[4]: chained vorticity (diff(v,'X')-diff(u,'Y'))/area on {n5}x{n5}x{nz5} f64, fill, split along Z over the ranks "
+    block["config5"] = {"workload": f"configs[4]: chained vorticity (diff(v,'X')-diff(u,'Y'))/area on {n5}x{n5y}x{nz5} f64, fill, split along Z over the ranks "
                                     f"(levels per rank {levels})", "ops": gather(c5)}
-    torch.cuda.empty_cache()
+    _empty_cache()
     ranks.barrier()
     block["seconds"] = round(time.perf_counter() - t_all, 1)
     return block, slabs
@@ -389,11 +417,14 @@ def check_configs(block, slabs):
 
 
 def main():
+    global NZ, NY, NX, CONFIG5_SHAPE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--levels", type=int, default=NZ, help="Z levels (default = the full 75; smaller only for debugging)")
+    ap.add_argument("--shape", default="", help="Z,Y,X of the record and Z,Y,X of config 5, ';'-separated -- plumbing checks only (the CPU dry run of "
+                    "tests/test_bench_dryrun.py): a line from another shape than BASELINE's says so in `config.workload` and is no measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (configs[2..4] after the headline's timed region)")
     ap.add_argument("--config4-records", type=int, default=6, help="`configs`: records of 3600x2400x75 in the resident batch of config 4 (per rank)")
@@ -401,15 +432,22 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child passes (N = 1 only; "
                     "also XG_BENCH_PMC=0): the committed figure of profiles/pmc_traffic.json is reported instead")
     args = ap.parse_args()
+    if args.shape:
+        rec, _, c5 = args.shape.partition(";")
+        NZ, NY, NX = (int(v) for v in rec.split(","))
+        if c5:
+            CONFIG5_SHAPE = tuple(int(v) for v in c5.split(","))
+        if args.levels == 75:
+            args.levels = NZ
+    toy = ((NZ, NY, NX), CONFIG5_SHAPE) != BASELINE_SHAPES
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     from xgcm_amd import sharding as S
 
     # `--gpus N` means N ranks whoever started us: under torchrun we ARE one of them (WORLD_SIZE must agree),
     # started by hand we re-execute under torch.distributed.run; fewer visible GPUs than ranks is an error
     S.ensure_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:])
-    ranks = S.init_ranks(args.gpus, backend="nccl")
+    # RCCL ("nccl") wherever there is a GPU; XG_DIST_BACKEND=gloo only in the CPU dry run (tests/test_bench_dryrun.py)
+    ranks = S.init_ranks(args.gpus, backend=os.environ.get("XG_DIST_BACKEND") or "nccl")
     world, rank, local_rank, dist = ranks.world, ranks.rank, ranks.local_rank, ranks.dist
 
     import __graft_entry__ as entry
@@ -417,8 +455,7 @@ def main():
     if entry._stale():  # clean checkout: the .so is a git-ignored build artefact
         if rank == 0:
             entry.build()
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank])
+        ranks.barrier()
     from xgcm_amd import device as D
 
     nz = args.levels
@@ -427,17 +464,13 @@ def main():
     field = D.synthetic((nz, NY, NX), 2, offset=rank * cells_per_op)
     grid, T = build_grid(nz, field)
 
-    def step(events=None):
+    def step(marks=None):
         for i, (fn, ax) in enumerate(OPS):
             getattr(grid, fn)(T, ax)
-            if events is not None:
-                events[i + 1].record()
+            if marks is not None:
+                marks.append(Mark())
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
+    barrier = ranks.barrier  # synchronize, barrier over the process group (RCCL), synchronize
 
     # one level through the HIP path, kept for the parity spot-check that the cpu_baseline leg makes
     # against the oracle after the timed region (the oracle is touched nowhere else in this file)
@@ -451,11 +484,11 @@ def main():
     prime = int(os.environ.get("XG_BENCH_PRIME", "5"))
     for _ in range(prime):
         step()
-    torch.cuda.synchronize()
+    sync()
     for _ in range(args.warmup):
         step()
     K = args.steps
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(OPS) + 1)] for _ in range(K)]
+    ev = [[] for _ in range(K)]
     import gc
 
     gc.collect()
@@ -463,7 +496,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(K):
-        ev[k][0].record()
+        ev[k].append(Mark())
         step(ev[k])
     barrier()
     elapsed = time.perf_counter() - t0
@@ -473,16 +506,16 @@ def main():
     per_rank_ms_per_step = [round(v / K * 1e3, 4) for v in ranks.gather_floats(elapsed)]
     # what a < 7x curve would have to be explained with: where each rank ran (GPU, NUMA node, CPUs it was bound to) and how
     # much of its wall time per step was NOT device time (Python dispatch of the 4 launches, barrier skew)
-    local_dev_ms = sorted(ev[k][0].elapsed_time(ev[k][len(OPS)]) for k in range(K))
+    local_dev_ms = sorted(ev[k][0].ms_until(ev[k][len(OPS)]) for k in range(K))
     placement = ranks.gather_objects(dict(ranks.placement, rank=rank,
                                           device_ms_per_step=round(local_dev_ms[len(local_dev_ms) // 2], 4),
                                           host_overhead_ms_per_step=round(elapsed / K * 1e3 - float(np.mean(local_dev_ms)), 4)))
-    cells_per_s, elapsed = S.whole_job_throughput(local_cells, elapsed, dist, "cuda")
+    cells_per_s, elapsed = S.whole_job_throughput(local_cells, elapsed, dist, ranks.scalar_device)
     n_ranks = dist.get_world_size() if dist is not None else 1  # the rank count RCCL itself reports
 
     # per-launch durations from the HIP events recorded on the launch stream inside the timed region
-    per_op_ms = [float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(K)])) for i in range(len(OPS))]
-    step_ms = sorted(ev[k][0].elapsed_time(ev[k][len(OPS)]) for k in range(K))  # device time per step
+    per_op_ms = [float(np.mean([ev[k][i].ms_until(ev[k][i + 1]) for k in range(K)])) for i in range(len(OPS))]
+    step_ms = sorted(ev[k][0].ms_until(ev[k][len(OPS)]) for k in range(K))  # device time per step
     by_kernel, of_axis = {}, kernel_of_axis()
     for (fn, ax), ms in zip(OPS, per_op_ms):
         by_kernel.setdefault(of_axis[ax], []).append(ms)
@@ -512,7 +545,7 @@ def main():
             else:
                 traffic_source = f"live PMC passes unavailable ({how}); "
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if traffic is None and os.path.exists(pmc):
+        if traffic is None and os.path.exists(pmc) and not toy:  # (the committed passes are of BASELINE's shape)
             try:
                 table = json.load(open(pmc))
                 traffic = table.get(dominant)
@@ -522,7 +555,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "stencil-cells/s, Grid.interp+Grid.diff (X periodic, Y extend) on 3600x2400x75 f64",
+            "metric": f"stencil-cells/s, Grid.interp+Grid.diff (X periodic, Y extend) on {NX}x{NY}x{nz} f64",
             "value": round(total_cells / elapsed / 1e9, 3),
             "unit": "Gcell/s",
             "n_gpus": n_ranks,
@@ -535,7 +568,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: Grid.interp+Grid.diff along X (periodic) and Y (extend) on one "
+            "config": {"workload": ("NOT BASELINE's shape (plumbing check): " if toy else "") + f"configs[1]: Grid.interp+Grid.diff along X (periodic) and Y (extend) on one "
                                    f"{NX}x{NY}x{nz} f64 C-grid record per GPU, HBM-resident",
                        "cells_per_step_per_gpu": len(OPS) * cells_per_op, "records_per_gpu": 1,
                        "sharding": "record axis, no data-path collective"},
@@ -547,7 +580,7 @@ def main():
                          "traffic_measured_in_run": measured_now, "traffic_over_algorithmic": round(traffic / alg_bytes, 4) if traffic else None,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
                          "per_op_ms": {f"{fn}_{ax}": round(ms, 4) for (fn, ax), ms in zip(OPS, per_op_ms)}},
-            "ranks": {"world_size": n_ranks, "backend": "nccl (RCCL)" if dist is not None else "single process",
+            "ranks": {"world_size": n_ranks, "backend": ("nccl (RCCL)" if ranks.backend == "nccl" else str(ranks.backend)) if dist is not None else "single process",
                       "per_rank_ms_per_step": per_rank_ms_per_step,
                       # load balance INSIDE this run (min / max over the ranks' times) -- not scaling efficiency: scaling
                       # against N = 1 is the driver's to compute from the per-N values

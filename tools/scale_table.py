@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--reps", type=int, default=7)
     ap.add_argument("--out", default="")
     ap.add_argument("--shape", default="", help="Z,Y,X override for configs 4 and 5 (plumbing checks)")
+    ap.add_argument("--bench-shape", default="", help="bench.py --shape (plumbing checks: the CPU dry run of tests/test_bench_dryrun.py)")
     ap.add_argument("--skip-bench", action="store_true")
     a = ap.parse_args()
     ngpu = visible_gpus()
@@ -64,7 +65,8 @@ def main():
             skipped.append(n)
             continue
         if not a.skip_bench:
-            rc, lines, err = run([sys.executable, "bench.py", "--gpus", str(n), "--steps", str(a.steps), "--warmup", str(a.warmup), "--no-cpu-baseline", "--no-pmc"])
+            rc, lines, err = run([sys.executable, "bench.py", "--gpus", str(n), "--steps", str(a.steps), "--warmup", str(a.warmup), "--no-cpu-baseline", "--no-pmc"]
+                                 + (["--shape", a.bench_shape, "--config4-records", "2", "--config-reps", "2"] if a.bench_shape else []))
             for ln in lines:
                 if "value" in ln:
                     rk = ln["ranks"]
@@ -73,7 +75,9 @@ def main():
                     per = ln["ranks"]["per_rank_ms_per_step"]
                     placements[n] = ln["ranks"].get("placement")
                     rows.append({"what": "bench: interp+diff X,Y, one record per GPU (weak)", "n": n, "GBps": ln["achieved_GBps_whole_step"] * n,
-                                 "rank_ms_max_over_min": round(max(per) / min(per), 4) if min(per) > 0 else None})
+                                 "rank_ms_max_over_min": round(max(per) / min(per), 4) if min(per) > 0 else None,
+                                 "world_size": rk["world_size"], "backend": rk["backend"], "placements": len(rk.get("placement") or []),
+                                 "value": ln["value"], "unit": ln["unit"], "configs_in_line": sorted(k for k in (ln.get("configs") or {}) if k.startswith("config"))})
             if rc != 0:
                 rows.append({"what": "bench", "n": n, "error": err})
                 problems.append(f"bench --gpus {n}: exit status {rc}")

@@ -305,6 +305,53 @@ std::vector<Knob>& knobs() {
   return k;
 }
 
+// fused vorticity / divergence of the header (docs/ufunc_examples.md): the operator chain's arithmetic cell by cell --
+// (dx - dy) / area resp. (dx + dy) / area with the two one-cell halos from bc_x / bc_y -- so that the host build serves the
+// config-5 workload of bench.py's CPU dry run (tests/test_bench_dryrun.py); shapes (.., Y, X), area through broadcast strides
+template <typename R>
+int curl_or_div(bool curl, const R* u, const R* v, const R* area, const int64_t* as, R* out, const int64_t* shape, int ndim,
+                int bc_x, R fill_x, int bc_y, R fill_y) {
+  if (!u || !v || !out || !shape) return fail(XG_ERR_INVALID, "NULL array argument");
+  if (ndim < 2 || ndim > XG_MAX_NDIM) return fail(XG_ERR_UNSUPPORTED, "ndim %d not in [2,%d]", ndim, XG_MAX_NDIM);
+  if (area && !as) return fail(XG_ERR_INVALID, "metric without strides");
+  for (int b : {bc_x, bc_y})
+    if (b < XG_BC_PERIODIC || b > XG_BC_EXTEND) return fail(XG_ERR_INVALID, "boundary mode %d: periodic, fill or extend", b);
+  const int64_t ny = shape[ndim - 2], nx = shape[ndim - 1];
+  int64_t outer = 1;
+  for (int d = 0; d < ndim - 2; ++d) outer *= shape[d];
+  if (outer == 0 || ny == 0 || nx == 0) return XG_OK;
+  // neighbour along one axis: index k + s (s = -1 for the curl's center->left, +1 for the divergence's left->center)
+  auto nb = [](const R* row, int64_t k, int64_t n, int64_t stride, int s, int bc, R fill) -> R {
+    const int64_t q = k + s;
+    if (q >= 0 && q < n) return row[q * stride];
+    if (bc == XG_BC_FILL) return fill;
+    if (bc == XG_BC_PERIODIC) return row[((q % n + n) % n) * stride];
+    return row[(q < 0 ? 0 : n - 1) * stride];
+  };
+  for (int64_t o = 0; o < outer; ++o) {
+    int64_t rem = o, aoff = 0;  // the outer index decomposed for the area's broadcast strides
+    for (int d = ndim - 3; d >= 0; --d) { const int64_t i = rem % shape[d]; rem /= shape[d]; if (area) aoff += i * as[d]; }
+    const R *pu = u + o * ny * nx, *pv = v + o * ny * nx;
+    R* po = out + o * ny * nx;
+    for (int64_t j = 0; j < ny; ++j)
+      for (int64_t i = 0; i < nx; ++i) {
+        R r;
+        if (curl) {
+          const R dvdx = pv[j * nx + i] - nb(pv + j * nx, i, nx, 1, -1, bc_x, fill_x);
+          const R dudy = pu[j * nx + i] - nb(pu + i, j, ny, nx, -1, bc_y, fill_y);
+          r = dvdx - dudy;
+        } else {
+          const R dudx = nb(pu + j * nx, i, nx, 1, +1, bc_x, fill_x) - pu[j * nx + i];
+          const R dvdy = nb(pv + i, j, ny, nx, +1, bc_y, fill_y) - pv[j * nx + i];
+          r = dudx + dvdy;
+        }
+        po[j * nx + i] = area ? r / area[aoff + j * as[ndim - 2] + i * as[ndim - 1]] : r;
+      }
+  }
+  return XG_OK;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -472,13 +519,13 @@ int xg_event_destroy(void* ev) { free(ev); return XG_OK; }
                                       int, void*) {                                                                   \
     return unsupported("xg_transform_conservative");                                                                  \
   }                                                                                                                   \
-  int xg_vorticity_##SFX(const R*, const R*, const R*, const int64_t*, R*, const int64_t*, int, int, R, int, R,       \
-                         void*) {                                                                                     \
-    return unsupported("xg_vorticity");                                                                               \
+  int xg_vorticity_##SFX(const R* u, const R* v, const R* area, const int64_t* as, R* out, const int64_t* shape,      \
+                         int ndim, int bc_x, R fill_x, int bc_y, R fill_y, void*) {                                   \
+    return curl_or_div<R>(true, u, v, area, as, out, shape, ndim, bc_x, fill_x, bc_y, fill_y);                        \
   }                                                                                                                   \
-  int xg_divergence_##SFX(const R*, const R*, const R*, const int64_t*, R*, const int64_t*, int, int, R, int, R,      \
-                          void*) {                                                                                    \
-    return unsupported("xg_divergence");                                                                              \
+  int xg_divergence_##SFX(const R* u, const R* v, const R* area, const int64_t* as, R* out, const int64_t* shape,     \
+                          int ndim, int bc_x, R fill_x, int bc_y, R fill_y, void*) {                                  \
+    return curl_or_div<R>(false, u, v, area, as, out, shape, ndim, bc_x, fill_x, bc_y, fill_y);                       \
   }                                                                                                                   \
   int xg_gradient_##SFX(const R*, R*, R*, const int64_t*, int, int, R, int, R, const R*, const int64_t*, const R*,    \
                         const int64_t*, void*) {                                                                      \

@@ -72,7 +72,7 @@ class HipMemory:
         return _hip.load()
 
     def stream(self):
-        return _MEM.stream()
+        return torch.cuda.current_stream().cuda_stream
 
     def holds(self, t: torch.Tensor) -> bool:
         return t.is_cuda
