@@ -167,9 +167,12 @@ def cpu_baseline(levels=8, budget_s=20.0):
 
 
 def _kernel_base(name: str) -> str:
-    """`void k_stencil_strided_ys<0, 1>(Args) [clone .kd]` -> `k_stencil_strided_ys`"""
-    head = name.split("<")[0].split("(")[0].strip()
-    return head.split()[-1].split("::")[-1].replace(".kd", "") if head else ""
+    """`void (anonymous namespace)::k_stencil_strided_ys<0, 1>(Args) [clone .kd]` -> `k_stencil_strided_ys` (every kernel of the
+    library is named k_...; the name up to its template list, so that `..._ys` does not also match `..._ysm<...>`)"""
+    import re
+
+    m = re.search(r"\b(k_[A-Za-z0-9_]+)", name)
+    return m.group(1) if m else ""
 
 
 def pmc_passes(dominant: str, levels: int, alg_bytes: float, timeout_s: int = 120):
