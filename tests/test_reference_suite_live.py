@@ -4,7 +4,7 @@ Runs wherever the reference tree exists (the build container; skipped on the GPU
 `oracle/run_reference_suite.py`: a scratch package named `xgcm` over `xgcm_amd`, a numpy-backed stand-in named `xarray`
 (`oracle/xr_min.py` + `oracle/xr_suite.py`), the device served by the oracle double and by the host build of the C ABI.
 Passing = every assertion the reference's authors wrote about their own implementation holds here (pinned modulo the
-stand-in; tests that need dask-chunked arrays skip themselves -- the product refuses those by design).
+stand-in; tests that need dask itself (`dask.array`, `.chunk()`) skip themselves -- dask is not installable here; chunked inputs as such: tests/test_chunked_inputs.py).
 
 `tests/golden/reference_suite_report.json` is the committed outcome (per test function and backend); a function whose
 passed count drops below the committed one fails this test, as does any failure outside the documented host-build gap.

@@ -42,6 +42,13 @@ def install(monkeypatch):
             self.chunks = chunks  # a tuple of per-dim block sizes = dask-backed in real xarray
             self.shape = self.values.shape
             self.dtype = self.values.dtype
+            # `.data`: the array behind the variable -- numpy, or (chunked) what a dask array is to the bridge: a container
+            # with `.chunks`, slicing and numpy.asarray (dask is not installable: xgcm_amd.chunked.BlockArray plays it)
+            self.data = self.values
+            if chunks is not None:
+                from xgcm_amd.chunked import BlockArray
+
+                self.data = BlockArray.from_array(self.values, chunks)
 
         def __getitem__(self, key):
             return self.coords[key]

@@ -385,6 +385,8 @@ def _divide(res: torch.Tensor, m_out, as_dtype) -> torch.Tensor:
 
 
 def tohost(t) -> np.ndarray:
+    if _is_chunked(t):
+        return t  # a chunked host array (xgcm_amd.chunked.BlockArray, dask ...) IS on the host; numpy.asarray assembles it
     if isinstance(t, torch.Tensor):
         a = t.detach().cpu().numpy()  # synchronises the producing stream
         _MEM.after_read()
@@ -467,6 +469,73 @@ def _streamed(per_block, x: np.ndarray) -> np.ndarray:
     return stream_records(on_block, x, block=block)
 
 
+# ---- chunked HOST arrays (dask / zarr / xgcm_amd.chunked.BlockArray): block by block through HBM -------------------------
+# The reference walks the chunks of a dask-backed field with `apply_ufunc(dask="parallelized")` over the broadcast dims and
+# `map_overlap` along a chunked core dim (xgcm/grid.py:786-818, xgcm/grid_ufunc.py:1057-1133).  Here a block of the NON-core
+# dims -- whole along the operator's own axis: chunks along it are read together, which is what map_overlap's halo exchange
+# computes -- is one ordinary call of this module; with a GPU the blocks go through `streaming.iter_stream` (the next block is
+# read and copied in while this one is computed and the previous result is copied out).  The result keeps the input's
+# chunking (along the operator's axis too when its length did not change) and is never concatenated on the host.
+def _is_chunked(x) -> bool:
+    from . import chunked as _ch
+
+    return _ch.is_chunked(x)
+
+
+def _block_of(m, sl, axis: Optional[int], ndim: int, what: str = "metric"):
+    """the part of a dim-aligned metric that belongs to block `sl` of the array (a dim the metric broadcasts along, and the
+    operator's own axis, pass whole); a chunked metric is read for just that part"""
+    if m is None:
+        return None
+    if len(m.shape) != ndim:
+        raise ValueError(f"{what}: metric has {len(m.shape)} dims, array has {ndim}")
+    key = tuple(slice(None) if (d == axis or m.shape[d] == 1) else sl[d] for d in range(ndim))
+    return np.asarray(m[key]) if _is_chunked(m) else m[key]
+
+
+def _blockwise(per_block, x, axis: Optional[int], n_out: Optional[int] = None, drop_axis: bool = False, lead: int = 0):
+    """`per_block(host block, slices) -> result` for every block of the chunked host array `x`, blocks whole along `axis`
+    (None: every dim split).  `n_out`: length of the result along `axis`; `drop_axis`: the result has no such dim (sums);
+    `lead`: a leading dim of that length the result gains (the stacked numerator / denominator of the pair modes)."""
+    from . import chunked as _ch
+
+    chunks = _ch.normalize_chunks(x.chunks, x.shape)
+    nd = len(chunks)
+    if axis is not None:
+        axis %= nd
+    todo = list(_ch.block_slices(chunks, whole=() if axis is None else (axis,)))
+    blocks = {}
+    src_dt = _dt.native(np.dtype(x.dtype))
+    if _MEM.streams_host_blocks() and len(todo) > 1 and src_dt in (_dt.FLOAT32, _dt.FLOAT64):
+        from .streaming import iter_stream
+
+        at = [0]
+
+        def on_block(t):  # (called once per block, in order)
+            _, sl = todo[at[0]]
+            at[0] += 1
+            return asdevice(per_block(t, sl))
+
+        for (idx, _), res in zip(todo, iter_stream(on_block, (np.asarray(x[sl]) for _, sl in todo))):
+            blocks[idx] = res
+    else:
+        for idx, sl in todo:
+            blocks[idx] = tohost(per_block(np.asarray(x[sl]), sl))
+    dtype = next(iter(blocks.values())).dtype if blocks else x.dtype
+    if drop_axis:
+        blocks = {idx[:axis] + idx[axis + 1:]: b for idx, b in blocks.items()}
+        chunks = chunks[:axis] + chunks[axis + 1:]
+    elif axis is not None:
+        if n_out == sum(chunks[axis]) and len(chunks[axis]) > 1:
+            blocks, chunks = _ch.rechunk_blocks(blocks, chunks, axis, chunks[axis])  # the axis keeps the input's chunks
+        else:
+            chunks = chunks[:axis] + ((int(n_out),),) + chunks[axis + 1:]
+    if lead:
+        blocks = {(0,) + idx: b for idx, b in blocks.items()}
+        chunks = ((int(lead),),) + chunks
+    return _ch.BlockArray(blocks, chunks, dtype)
+
+
 def _int_stencil1d(plan, op: str, x, halo, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str], fill, m_out):
     """diff / interp / min / max of an integer or bool array on integer lanes (xg_stencil1d_i64 / _i32 and their _halo
     twins), returned in the dtype numpy returns: the array's own for diff / min / max (wrap-around included), float64 for
@@ -503,6 +572,10 @@ def stencil1d(op: str, x, axis: int, pad_lo: int, pad_hi: int, bc: Optional[str]
               m_in=None, m_out=None) -> torch.Tensor:
     """Fused pad + diff/interp/min/max along `axis` (xg_stencil1d_f64)."""
     lib = _MEM.lib()
+    if _is_chunked(x):  # a dask-style chunked host array: block by block, whole along `axis` (xgcm/grid.py:786-818)
+        ax, nd = axis % x.ndim, x.ndim
+        return _blockwise(lambda blk, sl: stencil1d(op, blk, ax, pad_lo, pad_hi, bc, fill, _block_of(m_in, sl, ax, nd, "m_in"),
+                                                    _block_of(m_out, sl, ax, nd, "m_out")), x, ax, x.shape[ax] + pad_lo + pad_hi - 1)
     if _host_streamable(x, axis):  # a large host array: blocks of the outermost dim, copies overlapped with the kernel
         return _streamed(lambda blk, sl: stencil1d(op, blk, axis, pad_lo, pad_hi, bc, fill, _rows(m_in, sl, x.ndim, 'm_in'), _rows(m_out, sl, x.ndim, 'm_out')), x)
     plan = _dt.stencil_plan(op, _dt.np_dtype(x), None if m_in is None else _dt.np_dtype(m_in),
@@ -618,6 +691,11 @@ def cumsum1d(x, axis: int, trim_lo: int, trim_hi: int, pad_lo: int, pad_hi: int,
              fill: float = 0.0, reverse: bool = False, skipna: bool = True, m_in=None, m_out=None) -> torch.Tensor:
     """Prefix sum along `axis` with the Grid.cumsum trim/pad folded in (xg_cumsum1d_f64)."""
     lib = _MEM.lib()
+    if _is_chunked(x):  # chunks along `axis` are scanned together (the reference: "it would need blockwise", grid.py:1305)
+        ax, nd = axis % x.ndim, x.ndim
+        return _blockwise(lambda blk, sl: cumsum1d(blk, ax, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, skipna,
+                                                   _block_of(m_in, sl, ax, nd, "m_in"), _block_of(m_out, sl, ax, nd, "m_out")),
+                          x, ax, x.shape[ax] - trim_lo - trim_hi + pad_lo + pad_hi)
     if _host_streamable(x, axis):
         return _streamed(lambda blk, sl: cumsum1d(blk, axis, trim_lo, trim_hi, pad_lo, pad_hi, bc, fill, reverse, skipna,
                                                   _rows(m_in, sl, x.ndim, 'm_in'), _rows(m_out, sl, x.ndim, 'm_out')), x)
@@ -667,6 +745,10 @@ def reduce1d(x, axis: int, w=None, skipna=True) -> torch.Tensor:
     ONE pass over x: "mean_valid" = sum(x * w | valid) / sum(w | valid), "mean_all" = sum(x * w) / sum(w);
     "pair_valid" / "pair_all" return those two sums stacked along a new leading dim of 2 (means over several dims)."""
     lib = _MEM.lib()
+    if _is_chunked(x):
+        ax, nd = axis % x.ndim, x.ndim
+        return _blockwise(lambda blk, sl: reduce1d(blk, ax, _block_of(w, sl, ax, nd, "w"), skipna), x, ax, drop_axis=True,
+                          lead=2 if skipna in ("pair_valid", "pair_all") else 0)
     if _host_streamable(x, axis) and skipna not in ("pair_valid", "pair_all"):
         return _streamed(lambda blk, sl: reduce1d(blk, axis, _rows(w, sl, x.ndim, 'w'), skipna), x)
     if _is_int(x) and w is None and isinstance(skipna, (bool, int, np.bool_)):
@@ -913,6 +995,8 @@ def transform_conservative(phi, theta, bins, axis: int) -> torch.Tensor:
 def binary(op: str, a, b) -> torch.Tensor:
     """Broadcasting a OP b for dim-aligned operands (same ndim, extents equal or 1)."""
     lib = _MEM.lib()
+    if _is_chunked(a) or _is_chunked(b):
+        return _binary_blockwise(op, a, b)
     nd = getattr(a, "ndim", 0)
     if nd > _hip.MAX_NDIM and nd == getattr(b, "ndim", -1):
         extents = [max(int(x), int(y)) for x, y in zip(a.shape, b.shape)]
@@ -966,6 +1050,30 @@ def binary(op: str, a, b) -> torch.Tensor:
                               _hip.i64(sb), out.data_ptr(), _hip.i64(kshape), len(kshape), _stream())
         )
     return _narrow(out, res_dt) if lanes == "int" else _out(out, half)
+
+
+def _binary_blockwise(op: str, a, b):
+    """a OP b with a chunked operand: the blocks of the chunked one (of `a` when both are), the other operand's matching part"""
+    from . import chunked as _ch
+
+    lead, other, flipped = (a, b, False) if _is_chunked(a) else (b, a, True)
+    if len(lead.shape) != len(other.shape):
+        raise ValueError("binary: operands must be dim-aligned (same ndim)")
+    nd = len(lead.shape)
+    for ls, os_ in zip(lead.shape, other.shape):
+        if ls != os_ and 1 not in (ls, os_):
+            raise ValueError(f"binary: extents {ls} and {os_} do not broadcast")
+
+    def per_block(blk, sl):
+        # a dim one of the two only broadcasts along passes whole on the other side
+        key = tuple(slice(None) if (lead.shape[d] == 1 or other.shape[d] == 1) else sl[d] for d in range(nd))
+        part = np.asarray(other[key]) if _is_chunked(other) else other[key]
+        return binary(op, part, blk) if flipped else binary(op, blk, part)
+
+    res = _blockwise(per_block, lead, None)
+    # where the chunked operand had extent 1 and the other one more, the single block there is as long as the other operand
+    chunks = tuple((int(os_),) if (ls == 1 and os_ != 1) else c for c, ls, os_ in zip(res.chunks, lead.shape, other.shape))
+    return _ch.BlockArray(res.blocks, chunks, res.dtype)
 
 
 def _pair_halos(halo_x, halo_y, shape, dt):

@@ -16,7 +16,7 @@ Metadata logic (axis lookup, default shifts, per-axis kwargs, metric search, coo
 re-attachment, error types and messages) is restated from the reference so that the parity tests
 read like the reference's own.  Grids with face connections or a north fold take the generic
 pad-then-apply route (halo gather `xg_gather_f64`, then the un-padded stencil kernel).  Out of scope
-and rejected loudly: dask-chunked inputs, metadata autoparsing.
+(dask-style chunked inputs are walked block by block: xgcm_amd.chunked).
 """
 
 from __future__ import annotations
@@ -70,6 +70,26 @@ class _DimsOnly:
     def __init__(self, dims, name=None):
         self.dims = tuple(dims)
         self.name = name
+
+
+def _refuse_chunked_core_dim_with_changing_length(grid, da, ax_name, sig):
+    """The reference maps a ufunc over the chunks of a chunked CORE dim with `dask.array.map_overlap` and refuses signatures
+    whose positions change the dim's length (`xgcm/grid_ufunc.py:1136-1159`, reached from `xgcm/grid.py:810-816`; `cumsum` is
+    exempt there).  Chunks along the operator's axis are read together here, so nothing would go wrong -- but the same call
+    raises the same error, so that code written against this backend also runs on the reference."""
+    chunks = getattr(da, "chunks", None)
+    if chunks is None:
+        return
+    _, dim = grid.axes[ax_name]._get_position_name(da)
+    if len(chunks[da.dims.index(dim)]) <= 1:
+        return
+    positions = {p for ps in list(sig.in_ax_positions) + list(sig.out_ax_positions) for p in ps}
+    if positions & {"inner", "outer"}:
+        raise NotImplementedError(
+            "Cannot chunk along a core dimension for a grid ufunc which has a signature which "
+            "includes one of the axis positions ['inner', 'outer']."
+            "Consider rechunking to a single chunk along this dimension if possible."
+        )
 
 
 class Grid:
@@ -509,8 +529,9 @@ class Grid:
             axis = [axis]
         data = _check_data_input(data, self)
         first = _maybe_unpack_vector_component(data)
-        if getattr(first, "chunks", None) is not None:
-            raise NotImplementedError(CHUNKED_INPUT_MESSAGE)
+        chunked = getattr(first, "chunks", None) is not None
+        if chunked and (isinstance(data, dict) or other_component is not None or any(gridops.complex_topology(self, a) for a in axis)):
+            raise NotImplementedError(CHUNKED_INPUT_MESSAGE)  # (halos from other faces / partner components: whole arrays)
         to = self._map_kwargs_over_axes(to)
         if isinstance(metric_weighted, str):
             metric_weighted = (metric_weighted,)
@@ -538,6 +559,8 @@ class Grid:
                     continue
             i += 1
             ufunc, remaining = _select_grid_ufunc(funcname, sig, module=gridops, **kwargs)
+            if chunked and funcname != "cumsum":
+                _refuse_chunked_core_dim_with_changing_length(self, first, ax_name, sig)
             weighted = metric_weighted.get(ax_name) if isinstance(metric_weighted, dict) else None
             out_dims = _shifted_dims(self, array, ax_name, sig.out_ax_positions[0][0], sig.in_ax_positions[0][0])
             m_in = m_out = None

@@ -34,6 +34,12 @@ def _is_tensor(x) -> bool:
     return torch is not None and isinstance(x, torch.Tensor)
 
 
+def _is_chunked(x) -> bool:
+    from .chunked import is_chunked
+
+    return is_chunked(x)
+
+
 def _shape(x) -> Tuple[int, ...]:
     return tuple(int(s) for s in x.shape)
 
@@ -56,7 +62,7 @@ class DataArray:
             coords = data.coords if coords is None else coords
             name = data.name if name is None else name
             data = data.data
-        if not _is_tensor(data):
+        if not _is_tensor(data) and not _is_chunked(data):  # (a dask-style chunked host array stays what it is: xgcm_amd.chunked)
             data = np.asarray(data)
         if dims is None:
             dims = tuple(f"dim_{i}" for i in range(data.ndim))
@@ -127,15 +133,20 @@ class DataArray:
 
     @property
     def values(self) -> np.ndarray:
-        return _dev.tohost(self.data)
+        return np.asarray(_dev.tohost(self.data))
 
     @property
     def is_device(self) -> bool:
         return _is_tensor(self.data) and self.data.is_cuda
 
     @property
-    def chunks(self):  # never dask-backed
-        return None
+    def chunks(self):
+        """block lengths per dim (dask's tuple of tuples) of a chunked host array, else None"""
+        if not _is_chunked(self.data):
+            return None
+        from .chunked import normalize_chunks
+
+        return normalize_chunks(self.data.chunks, self.data.shape)
 
     def get_axis_num(self, dim: str) -> int:
         try:
@@ -394,6 +405,13 @@ def _aligned_view(da: DataArray, dims: Sequence[str]):
         v = data.permute(*perm) if perm != list(range(len(perm))) else data
         index = tuple(slice(None) if d in da.dims else None for d in dims)
         return v[index]
+    if _is_chunked(data):
+        # a chunked host array stays chunked under name-based broadcasting: a view with its dims reordered / extended by name
+        if len(present) == len(dims) and perm == list(range(len(perm))):
+            return data
+        from .chunked import ExpandedView
+
+        return ExpandedView(data, [da.dims.index(d) if d in da.dims else None for d in dims])
     v = np.transpose(data, perm) if perm != list(range(len(perm))) else data
     index = tuple(slice(None) if d in da.dims else np.newaxis for d in dims)
     return v[index]
@@ -508,22 +526,24 @@ def is_xarray(obj) -> bool:
     return mod.startswith("xarray") or (type(obj).__name__ == "LazyArray" and bool(getattr(obj, "_xr", False)))
 
 
-CHUNKED_INPUT_MESSAGE = (
-    "dask-chunked inputs are not supported by the MI355X backend: compute the array first, or hand its blocks "
+CHUNKED_INPUT_MESSAGE = (  # what the chunked path does not serve (connected topologies, vector components, user ufuncs)
+    "this call does not take dask-chunked inputs on the MI355X backend: compute the array first, or hand its blocks "
     "to xgcm_amd.streaming.stream_records (record blocks streamed through HBM)"
 )
 
 
 def from_xarray(obj):
-    """xarray.DataArray / Dataset -> xgcm_amd labelled object (host data).  A dask-backed DataArray is refused
-    instead of being computed behind the caller's back (reference: `dask="parallelized"`, grid.py:786-818)."""
+    """xarray.DataArray / Dataset -> xgcm_amd labelled object (host data).  A dask-backed DataArray keeps its dask array as
+    `.data` -- nothing is computed here; the operators walk its blocks (xgcm_amd.chunked; reference: `dask="parallelized"`,
+    grid.py:786-818)."""
     tname = type(obj).__name__
     if tname == "LazyArray":  # a deferred result standing for an xarray object: the same deferred value, as one of ours
         out = obj._replace()
         out._xr = False
         return out
     if tname == "DataArray" and getattr(obj, "chunks", None) is not None:
-        raise NotImplementedError(CHUNKED_INPUT_MESSAGE)
+        coords = {k: (tuple(v.dims), np.asarray(v.values), dict(v.attrs)) for k, v in obj.coords.items()}
+        return DataArray(obj.data, tuple(obj.dims), coords=coords, name=obj.name, attrs=dict(obj.attrs))
     if tname == "DataArray":
         coords = {k: (tuple(v.dims), np.asarray(v.values), dict(v.attrs)) for k, v in obj.coords.items()}
         return DataArray(np.asarray(obj.values), tuple(obj.dims), coords=coords, name=obj.name, attrs=dict(obj.attrs))
@@ -548,4 +568,16 @@ def to_xarray(da: DataArray):
     # coordinate variables leave as they came in: dims, values in their own dtype AND attrs (the reference takes them
     # from `grid._ds` unchanged, xgcm/grid_ufunc.py:1262-1320)
     coords = {k: (c.dims, c.values, dict(c.attrs)) for k, c in da.coords.items()}
-    return xr.DataArray(da.values, dims=da.dims, coords=coords, name=da.name, attrs=da.attrs)
+    data = da.values
+    if _is_chunked(da.data):  # a chunked result leaves as a dask array of the same blocks where dask exists (else: assembled)
+        try:
+            import dask.array as dsa
+
+            blocks = da.data.blocks
+            nested = np.empty(da.data.numblocks, dtype=object)
+            for idx, blk in blocks.items():
+                nested[idx] = dsa.from_array(blk, chunks=blk.shape)
+            data = dsa.block(nested.tolist())
+        except Exception:  # noqa: BLE001 -- no dask (this image), or a container without `.blocks`
+            pass
+    return xr.DataArray(data, dims=da.dims, coords=coords, name=da.name, attrs=da.attrs)

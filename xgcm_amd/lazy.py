@@ -148,6 +148,10 @@ class LazyArray(DataArray):
         raise AttributeError("the data of a deferred result is computed, not assigned")
 
     @property
+    def chunks(self):
+        return None  # (asking must not force the value: DataArray.chunks looks at `.data`)
+
+    @property
     def is_deferred(self) -> bool:
         return self._node.value is None
 
