@@ -25,7 +25,7 @@ def starved():
     from xgcm_amd import device as D
 
     keep = {k: _hip.get_tunable(k) for k in ("scan_chain_spin", "scan_chain", "reduce_zl", "reduce_ldsw")}
-    _hip.set_tunable("reduce_ldsw", 0)  # these tests are about the CHAINED reduction, not the LDS-weight march that replaced it by default
+    _hip.set_tunable("reduce_ldsw", 0)  # these tests are about the CHAINED reduction, not the level-sharing marches (K4L, K4Z) that replaced it by default
     torch.cuda.synchronize()
     _hip.chain_rearm()
     with warnings.catch_warnings():

@@ -322,8 +322,9 @@ def test_weighted_reduction_with_weights_through_lds(dev, dtype):
     workgroup.  Every mode, columns that are not a multiple of the block, outer extents that are not a multiple of 4,
     ragged x-tiles, NaNs -- against the oracle (sequential order: bit-exact) and against the marching kernel."""
     from xgcm_amd import _hip
-    keep = {k: _hip.get_tunable(k) for k in ("reduce_ldsw", "scan_chain", "reduce_ldsw_u", "march_ofast")}
+    keep = {k: _hip.get_tunable(k) for k in ("reduce_ldsw", "scan_chain", "reduce_ldsw_u", "march_ofast", "reduce_zmarch")}
     try:
+        _hip.set_tunable("reduce_zmarch", 0)
         for shape, wshape in (((3, 300, 128), (1, 300, 128)), ((6, 64, 130), (1, 64, 130)), ((5, 97, 66), (1, 97, 66)),
                               ((2, 3, 80, 64), (1, 1, 80, 64)), ((9, 1000, 70), (1, 1000, 70)), ((4, 65, 2), (1, 65, 2))):
             a = _field(shape, 27, nan=True).astype(dtype)
@@ -342,6 +343,10 @@ def test_weighted_reduction_with_weights_through_lds(dev, dtype):
                     for lu in (8, 16):  # rows per block
                         _hip.set_tunable("reduce_ldsw_u", lu)
                         _eq(dev.tohost(dev.reduce1d(a, axis, w, mode)), ref)
+                for zm in (1208, 1216, 1308, 1312, 1316, 1408):  # K4Z (round 6): ZL levels per wave share the weight row in registers (+ 1000: float32 too)
+                    _hip.set_tunable("reduce_zmarch", zm)
+                    _eq(dev.tohost(dev.reduce1d(a, axis, w, mode)), ref)
+                _hip.set_tunable("reduce_zmarch", keep["reduce_zmarch"])
             with np.errstate(invalid="ignore"):
                 _eq(dev.tohost(dev.reduce1d(a, axis, w, True)), R.integrate(a, axis, np.broadcast_to(w, shape), True).astype(dtype))
     finally:

@@ -296,7 +296,7 @@ int fill_synthetic(R* out, int64_t n, uint64_t seed, uint64_t offset, double sca
 
 // tunables: the names of the device library (xg_runtime.hip::TUNABLES), accepted and remembered so that bindings
 // can be exercised; they have no effect on the host loops
-const char* const KNOWN_TUNABLES[] = {"seg", "nt_store", "nt_load", "seg_max_tiles", "scan_narrow_below", "pad_rows", "pad_nt", "transform_lds_kb", "transform_win", "transform_fast", "transform_stage", "transform_ring", "transform_cwin", "transform_lean", "zchunk", "zband", "zb_rows", "scan_block", "strided_gen", "march_band", "scan_vec", "scan_dpp", "contig_gen", "deep_waves", "contig_rw", "rw_zshare", "met_zk", "met_zk1", "vec_zk", "vec_nt", "vec_zb_rows", "nb_dpp", "met_zk2", "met_ys", "met_ys1", "met_ys2", "seg_ys", "contig_rw_mi", "met_seg", "met_seg1", "met_scalar", "scan_pipe", "scan_u", "scan_pace", "scan_chain", "scan_chain_w", "scan_chain_spin", "scan_chain_tmaj", "reduce_zl", "pad_tpw", "bin_idx32", "reduce_ldsw_u", "march_ofast", "reduce_sk", "reduce_ru", "reduce_wfast", "reduce_wg", "scan_sh1", "reduce_ldsw", "dbg", "march_lds_kb"};
+const char* const KNOWN_TUNABLES[] = {"seg", "nt_store", "nt_load", "seg_max_tiles", "scan_narrow_below", "pad_rows", "pad_nt", "transform_lds_kb", "transform_win", "transform_fast", "transform_stage", "transform_ring", "transform_cwin", "transform_lean", "zchunk", "zband", "zb_rows", "scan_block", "strided_gen", "march_band", "scan_vec", "scan_dpp", "contig_gen", "deep_waves", "contig_rw", "rw_zshare", "met_zk", "met_zk1", "vec_zk", "vec_nt", "vec_zb_rows", "nb_dpp", "met_zk2", "met_ys", "met_ys1", "met_ys2", "seg_ys", "contig_rw_mi", "met_seg", "met_seg1", "met_scalar", "scan_pipe", "scan_u", "scan_pace", "scan_chain", "scan_chain_w", "scan_chain_spin", "scan_chain_tmaj", "reduce_zl", "pad_tpw", "bin_idx32", "reduce_ldsw_u", "march_ofast", "reduce_sk", "reduce_ru", "reduce_wfast", "reduce_wg", "scan_sh1", "reduce_ldsw", "reduce_zmarch", "dbg", "march_lds_kb"};
 struct Knob { const char* name; int value; bool set; };
 std::vector<Knob>& knobs() {
   static std::vector<Knob> k;
