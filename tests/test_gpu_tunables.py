@@ -1,0 +1,132 @@
+"""Every launch-shape tunable, at every value it is documented to take, computes what the defaults compute.
+
+`xg_set_tunable` / `XG_<NAME>` choose among kernels and work orders -- speed, never results (include/xgcm_hip.h "tunables";
+VERDICT r05 weak #10: "30+ knobs reachable from environment variables are a large untested configuration surface").  Here a
+battery of calls that reaches every kernel family -- flat and marching stencils with and without metrics, the three scans, the
+reductions in every mode, pads, the fused vector operators, both transforms -- is run once under the defaults and then again
+under each alternative value of each tunable, float64 and float32: bit for bit the same, except along the contiguous axis where
+sums are re-associated by contract (rtol 1e-12 / 1e-5)."""
+import numpy as np
+import pytest
+
+from oracle import refimpl as R
+
+pytestmark = pytest.mark.gpu
+
+# name -> alternative values (the default is whatever the library starts with); values outside a kernel's template list fall
+# back to a served one inside the library
+ALTERNATIVES = {
+    "seg": [8, 64], "nt_store": [0], "nt_load": [0], "seg_max_tiles": [1, 16], "scan_narrow_below": [0, 1 << 30], "pad_rows": [0],
+    "pad_nt": [0, 1, 2, 4], "transform_lds_kb": [16, 32], "transform_win": [0], "transform_fast": [0], "transform_stage": [0, 1, 2],
+    "transform_ring": [4, 16], "transform_cwin": [0, 4], "zchunk": [0, 16, 1024], "zband": [0], "zb_rows": [4, 8, 32], "scan_block": [64, 128, 512, 1024],
+    "strided_gen": [0], "march_band": [0], "scan_vec": [0], "scan_dpp": [0], "contig_gen": [0], "deep_waves": [0, 1 << 30], "contig_rw": [0, 1],
+    "rw_zshare": [0], "met_zk": [1, 2], "met_zk1": [1, 4], "vec_zk": [1, 4], "vec_nt": [0, 1, 2], "vec_zb_rows": [8, 32], "nb_dpp": [0],
+    "met_zk2": [1, 2], "met_ys": [0], "seg_ys": [0], "contig_rw_mi": [2, 8], "met_seg": [1, 2], "met_seg1": [1, 4], "met_scalar": [0],
+    "scan_pipe": [0, 2], "scan_u": [8, 16, 24], "scan_pace": [1], "scan_chain": [0, 2, 3], "scan_chain_w": [2, 104], "scan_chain_tmaj": [1, 4],
+    "reduce_zl": [1, 4], "met_ys1": [0, 4], "met_ys2": [0, 6], "transform_lean": [0, 1, 2], "pad_tpw": [1, 4], "bin_idx32": [0],
+    "reduce_ldsw_u": [8, 16], "march_ofast": [0], "reduce_sk": [0, 2], "reduce_ru": [0, 2], "reduce_wfast": [0], "reduce_wg": [0, 1, 8, 16, 25],
+    "scan_sh1": [0], "reduce_zmarch": [0, 208, 308, 316, 408, 1312], "reduce_ldsw": [0, 1], "march_lds_kb": [32],
+}
+NOT_SWEPT = {"scan_chain_spin": "forces the rescue path: tests/test_gpu_chain_rescue.py", "dbg": "debug switches of single experiments"}
+
+
+def _battery(D, dtype):
+    """name -> (thunk, exact?) ; small shapes that still cross the thresholds (long marches >= 256 rows, rows >= 3 groups,
+    >= 3 levels with level-shared metrics, unaligned row lengths)"""
+    f = lambda shape, seed: R.synthetic_field(shape, seed).astype(dtype)  # noqa: E731
+    m = lambda shape, seed: R.synthetic_metric(shape, seed).astype(dtype)  # noqa: E731
+    a = f((5, 300, 264), 1)
+    a[1, 7, 9] = np.nan
+    odd = f((3, 65, 131), 2)
+    wide = f((2, 4, 40, 4100), 3)
+    mxy, mxy2, mz, my = m((1, 300, 264), 4), m((1, 300, 264), 5), m((5, 1, 1), 6), m((1, 300, 1), 7)
+    calls = {}
+    for op in ("diff", "interp", "max"):
+        for ax, bc in ((2, "periodic"), (1, "extend"), (0, "fill")):
+            calls[f"{op}{ax}"] = (lambda op=op, ax=ax, bc=bc: D.stencil1d(op, a, ax, 1, 0, bc, 1.5), True)
+            calls[f"{op}{ax}odd"] = (lambda op=op, ax=ax, bc=bc: D.stencil1d(op, odd, ax, 0, 1, bc, 1.5), True)
+        calls[f"{op}w"] = (lambda op=op: D.stencil1d(op, wide, 3, 1, 0, "periodic"), True)
+    for ax in (2, 1):
+        calls[f"deriv{ax}"] = (lambda ax=ax: D.stencil1d("diff", a, ax, 1, 0, "extend", 0.0, None, mxy), True)
+        calls[f"mw{ax}"] = (lambda ax=ax: D.stencil1d("interp", a, ax, 1, 0, "periodic", 0.0, mxy, mxy2), True)
+    calls["deriv0"] = (lambda: D.stencil1d("diff", a, 0, 1, 0, "fill", 0.0, None, mz), True)
+    calls["mwy1d"] = (lambda: D.stencil1d("diff", a, 1, 1, 0, "extend", 0.0, my, None), True)
+    for ax in (0, 1, 2):
+        exact = ax != 2
+        calls[f"cum{ax}"] = (lambda ax=ax: D.cumsum1d(a, ax, 0, 1, 1, 0, "fill"), exact)
+        calls[f"cum{ax}r"] = (lambda ax=ax: D.cumsum1d(a, ax, 1, 0, 0, 1, "extend", 0.0, True, True), exact)
+        calls[f"cumint{ax}"] = (lambda ax=ax: D.cumsum1d(a, ax, 0, 1, 1, 0, "fill", 0.0, False, True, mxy if ax else mz, None), exact)
+        calls[f"cum{ax}odd"] = (lambda ax=ax: D.cumsum1d(odd, ax, 0, 0, 0, 0, None), exact)
+        for mode in (True, False, "valid", "mean_valid", "pair_all"):
+            calls[f"sum{ax}{mode}"] = (lambda ax=ax, mode=mode: D.reduce1d(a, ax, mxy if ax else mz, mode), exact)
+        calls[f"sum{ax}plain"] = (lambda ax=ax: D.reduce1d(a, ax, None), exact)
+    calls["sumw"] = (lambda: D.reduce1d(wide, 3, None), False)
+    calls["pad"] = (lambda: D.pad_nd(odd, {2: (1, 2), 1: (2, 0)}, {2: "periodic", 1: "extend"}, {2: 0.0, 1: 0.0}), True)
+    calls["padz"] = (lambda: D.pad_nd(a, {0: (1, 1)}, {0: "fill"}, {0: 3.0}), True)
+    calls["mul"] = (lambda: D.binary("mul", a, mxy), True)
+    calls["div"] = (lambda: D.binary("div", a, mz), True)
+    u, v = f((6, 64, 256), 8), f((6, 64, 256), 9)
+    area = m((1, 64, 256), 10)
+    calls["vort"] = (lambda: D.vorticity(u, v, area, "fill", "fill"), True)
+    calls["divg"] = (lambda: D.divergence(u, v, area, "periodic", "extend"), True)
+    calls["grad"] = (lambda: D.gradient(u, "periodic", "extend", 0.0, 0.0, area, area), True)
+    calls["flux"] = (lambda: D.flux(u, v, u, "periodic", "extend"), True)
+    calls["i2"] = (lambda: D.stencil2d("interp", u, 0, (1, 0), "periodic", 0.0, (1, 0), "extend", 0.0), True)
+    calls["i2mw"] = (lambda: D.stencil2d("interp", u, 0, (1, 0), "periodic", 0.0, (1, 0), "extend", 0.0, (area[0], area[0], area[0])), True)
+    phi = f((20, 24, 128), 11)
+    theta = np.cumsum(R.synthetic_field((20, 24, 128), 12).astype(dtype) + dtype(0.55), axis=0)
+    theta_o = np.cumsum(R.synthetic_field((21, 24, 128), 13).astype(dtype) + dtype(0.55), axis=0)
+    calls["tlin"] = (lambda: D.transform_linear(phi, theta, np.linspace(0.5, 9.0, 12).astype(dtype).reshape(12, 1, 1), 0), True)
+    calls["tcon"] = (lambda: D.transform_conservative(phi, theta_o, np.linspace(0.0, 12.0, 14).astype(dtype), 0), True)
+    return calls
+
+
+def _run(D, calls):
+    out = {}
+    for k, (fn, _) in calls.items():
+        r = fn()
+        out[k] = [D.tohost(x) for x in r] if isinstance(r, tuple) else [D.tohost(r)]
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+def test_every_tunable_value_computes_the_same(dtype):
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import warnings
+
+    from xgcm_amd import _hip
+    from xgcm_amd import device as D
+
+    calls = _battery(D, dtype)
+    want = _run(D, calls)
+    rtol = 1e-12 if dtype is np.float64 else 2e-5
+    names = set(ALTERNATIVES) | set(NOT_SWEPT)
+    import os
+    import re
+
+    known = set(re.findall(r'\{"(\w+)", &Tune::', open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                       "xgcm_amd", "csrc", "xg_runtime.hip")).read()))
+    assert known == names, f"tunables without a sweep entry: {sorted(known - names)}; entries without a tunable: {sorted(names - known)}"
+    bad = []
+    for name, values in ALTERNATIVES.items():
+        before = _hip.get_tunable(name)
+        try:
+            for val in values:
+                _hip.set_tunable(name, val)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    got = _run(D, calls)
+                for k, (_, exact) in calls.items():
+                    for g, w in zip(got[k], want[k]):
+                        ok = g.shape == w.shape and (np.array_equal(g, w, equal_nan=True) if exact
+                                                     else np.allclose(g, w, rtol=rtol, atol=rtol * 300, equal_nan=True))
+                        if not ok:
+                            bad.append((name, val, k))
+        finally:
+            _hip.set_tunable(name, before)
+    torch.cuda.synchronize()
+    _hip.chain_rearm()
+    assert not bad, bad[:20]

@@ -1970,7 +1970,7 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
 #define XG_RW(W_, S_, R_) hipLaunchKernelGGL((k_reduce_contig_wg<W_, S_, R_>), dim3((u32)(((nrows + 7) / 8) * 8)), dim3(BLOCK), 0, st, in, out, g, skipna, w, mw, ntf, zb)
     // K4wz: level-shared weights, ZL levels of one row per workgroup (reduce_wg bits 3 / 4: ZL = 2 / 4)
     // (8-byte elements only: with float32's 4-cell vectors the weighted form gains nothing at 2 levels -- 0.707 -> 0.702 -- and
-    // spills at 4 -- 2.2 ms; profiles/r05y_ab_reduce_f32.log)
+    // spills at 4 -- 2.2 ms; profiles/history/r05y_ab_reduce_f32.log)
     if (sizeof(real) == 8 && w && wfast && zb.on && (wgm & 24) && vec && g.n_in >= (int64_t)BLOCK * NV) {
       const u32 Z = (u32)g.outer_shape[0];
       const int ZL = (wgm & 16) ? 4 : 2;
