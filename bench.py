@@ -137,6 +137,11 @@ def cpu_baseline(levels=8, budget_s=20.0):
         if el > budget_s * 0.4 or passes >= 8:
             break
     out = {"value": round(cells / el / 1e9, 4), "unit": "Gcell/s", "cores": 1, "kind": "port",
+           # what the port restates (the reference is Python over xarray: not importable on the GPU box): per axis
+           # `DataArray.pad` = numpy.pad copy, then the sliced two-point body on the padded array
+           "restates": "oracle/refimpl.py::stencil1d = xgcm/grid.py:728-836 (_1d_grid_ufunc_dispatch, one grid ufunc per axis) -> "
+                       "xgcm/grid_ufunc.py:885-904 (pad, then apply) -> xgcm/padding.py:575-616 (_pad_basic: numpy.pad wrap / edge) -> "
+                       "xgcm/gridops.py:23-24, 76-77 (diff_forward, interp_forward); pinned bit for bit by tests/golden/gridops_vectors.npz",
            "sample": f"{passes} pass(es) of the 4 ops on a {levels}x{NY}x{NX} f64 slab (numpy pad copy + sliced op, "
                      f"single thread = the reference's eager path), {el:.1f} s; host has {os.cpu_count()} cores"}
     # every host core (the dask threaded scheduler's default), bounded only by host memory: a task holds its
@@ -160,6 +165,8 @@ def cpu_baseline(levels=8, budget_s=20.0):
             if el > budget_s * 0.4 or rounds >= 4:
                 break
     out["threaded"] = {"value": round(tcells / el / 1e9, 4), "unit": "Gcell/s", "cores": nthreads,
+                       "what": "NOT dask: the same numpy sequence, one level per task in a thread pool (numpy releases the GIL) -- a memory-bound "
+                               "stand-in for the reference's dask threaded scheduler over a field chunked along Z (xgcm/grid.py:786-789)",
                        "host_cores": os.cpu_count(), "numpy": np.__version__,
                        "sample": f"{rounds} round(s), one 1x{NY}x{NX} level per task on {nthreads} threads "
                                  f"(all {os.cpu_count()} host cores unless host memory bounds it), {el:.1f} s"}
