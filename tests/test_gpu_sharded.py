@@ -95,3 +95,23 @@ def test_more_ranks_than_gpus_is_an_error():
         p, lines = _run([script, "--gpus", str(n)] + extra)
         assert p.returncode != 0 and not lines
         assert "GPU(s) are visible" in p.stderr
+
+
+@pytest.mark.parametrize("ranks", [1, 2], ids=["one-process", "two-gloo-ranks-on-one-gpu"])
+def test_bench_configs_block_on_the_real_library(ranks):
+    """bench.py's `configs` block (configs 3 / 4 / 5 after the headline's timed region) through HIP at a plumbing shape: nine
+    operators timed with HIP events, every kept slab equal to the oracle bit for bit, the box probe's three launches; with two
+    ranks (gloo, sharing the one GPU) the per-rank times of every operator and the job's aggregate."""
+    env = {} if ranks == 1 else {"XG_DIST_BACKEND": "gloo", "XG_SHARE_GPU": "1"}
+    p, lines = _run([BENCH, "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--shape", "6,64,256;8,64,128", "--no-pmc",
+                     "--config4-records", "2", "--config-reps", "3"], env)
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-3000:]
+    ln = lines[0]
+    assert ln["n_gpus"] == ranks and ln["config"]["workload"].startswith("NOT BASELINE's shape")
+    c = ln["configs"]
+    ops = [e for k in ("config3", "config4", "config5") for e in c[k]["ops"]]
+    assert len(ops) == 9 and all(e["bit_exact_vs_oracle"] is True and e["ms"] > 0 for e in ops)
+    assert len(c["box_probe"]["ms"]) == 3
+    if ranks == 2:
+        assert all(len(e["per_rank_ms"]) == 2 and e["job_gcell_s"] > 0 for e in ops)
+        assert "levels per rank [4, 4]" in c["config5"]["workload"]
