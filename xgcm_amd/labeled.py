@@ -568,7 +568,7 @@ def to_xarray(da: DataArray):
     # coordinate variables leave as they came in: dims, values in their own dtype AND attrs (the reference takes them
     # from `grid._ds` unchanged, xgcm/grid_ufunc.py:1262-1320)
     coords = {k: (c.dims, c.values, dict(c.attrs)) for k, c in da.coords.items()}
-    data = da.values
+    data = None
     if _is_chunked(da.data):  # a chunked result leaves as a dask array of the same blocks where dask exists (else: assembled)
         try:
             import dask.array as dsa
@@ -579,5 +579,7 @@ def to_xarray(da: DataArray):
                 nested[idx] = dsa.from_array(blk, chunks=blk.shape)
             data = dsa.block(nested.tolist())
         except Exception:  # noqa: BLE001 -- no dask (this image), or a container without `.blocks`
-            pass
+            data = None
+    if data is None:
+        data = da.values
     return xr.DataArray(data, dims=da.dims, coords=coords, name=da.name, attrs=da.attrs)
