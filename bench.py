@@ -20,7 +20,7 @@ bounded sample on this box's host cores; N=1 only).
 AFTER the headline's timed region (value / ms_per_step are not touched by it) the same process puts
 one-rank shares of BASELINE configs[2..4] under the same clock and adds them to the line as `configs`
 (`--no-configs` skips it): config 3 `derivative` X / Y / Z with random 2-D / 1-D metrics + `integrate` Z,
-config 4 `cumsum` Z center->left / center->outer over a resident batch of records, config 5 the fused
+config 4 `cumsum` Z center->left / center->outer over a resident batch of 3 records, config 5 the fused
 vorticity and the chain AS WRITTEN under `grid.fused()` on 4320 x 4320 x 90 -- each with HIP-event ms,
 fraction of 8 TB/s on SURVEY section 8(d)'s bytes, and a bit check of a slab against the oracle (made in
 the cpu_baseline leg, after every timed span).  `box_probe` = three launches of cumsum Z on ONE record:
@@ -437,7 +437,10 @@ def main():
                     "tests/test_bench_dryrun.py): a line from another shape than BASELINE's says so in `config.workload` and is no measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (configs[2..4] after the headline's timed region)")
-    ap.add_argument("--config4-records", type=int, default=6, help="`configs`: records of 3600x2400x75 in the resident batch of config 4 (per rank)")
+    ap.add_argument("--config4-records", type=int, default=3, help="`configs`: records of 3600x2400x75 in the resident batch of config 4 (per rank).  "
+                    "3 records = 15.6 GB in, 15.6 - 15.8 GB out: the largest batch whose RESULT still comes from the library's scattered-buffer pool "
+                    "(device.SCATTER_MAX_BYTES = 16 GiB); larger results are plain allocations and meet the placement lottery "
+                    "(6 records: 0.67 - 0.79 from process to process, 3 records: 0.77 - 0.79; profiles/r06w_config4_batch_sizes.log)")
     ap.add_argument("--config-reps", type=int, default=7, help="`configs`: timed launches per operator")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child passes (N = 1 only; "
                     "also XG_BENCH_PMC=0): the committed figure of profiles/pmc_traffic.json is reported instead")
