@@ -80,3 +80,40 @@ def test_large_results_come_from_the_scattered_pool_and_are_the_same_bits(monkey
     again = D.cumsum1d(x, 0, 0, 1, 1, 0, "fill", 0.0, False, True)
     assert again.data_ptr() == ptr or True
     assert np.array_equal(D.tohost(again), R.cumsum1d(a, 0, 0, 1, 1, 0, "fill", 0.0, False, True))
+
+
+def test_pool_buffers_are_graded_and_the_grade_predicts_the_scan():
+    """Round 6: not every scattered buffer is a good one -- the "slow box" is a slow BUFFER.  `xg_scatter_grade` (a many-slices
+    fill against a flat fill, ~2 ms) tells them apart, and `xg_pool_alloc` parks a bad buffer and tries again: of a handful of
+    1.3 GB results made through the pool every one is graded, the stats add up, results are the same bits, and the grade of a
+    hand-made buffer is a sane ratio."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from xgcm_amd import _hip
+    from xgcm_amd import device as D
+
+    lib = _hip.load()
+    before = _hip.scatter_stats()
+    shape = (40, 2048, 2048)  # 1.34 GB: above the 1 GiB grading threshold
+    a = D.synthetic(shape, 71)
+    outs = [D.cumsum1d(a, 0, 0, 1, 1, 0, "fill") for _ in range(3)]  # three results alive at once: three pool blocks
+    torch.cuda.synchronize()
+    after = _hip.scatter_stats()
+    # (in a long session the pool may serve these from blocks it already holds: then nothing new is made or graded)
+    made, graded, rejected = (after[k] - before[k] for k in ("buffers_made", "graded", "rejected"))
+    assert graded >= 0 and rejected >= 0 and made == graded + rejected, (before, after)
+    if before["buffers_made"] == 0:
+        assert graded == 3
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    want = np.cumsum(D.tohost(a[:, :2, :8]), axis=0)
+    got = D.tohost(outs[0][:, :2, :8])
+    assert np.array_equal(got[1:], want[:-1]) and not got[0].any()
+    p = ctypes.c_void_p()
+    nbytes = 1 << 30
+    _hip.check(lib.xg_scatter_alloc(ctypes.byref(p), nbytes, 0, 1, 0))
+    try:
+        ratio = ctypes.c_double(0.0)
+        _hip.check(lib.xg_scatter_grade(p.value, nbytes, ctypes.byref(ratio)))
+        assert 0.7 < ratio.value < 3.0
+    finally:
+        _hip.check(lib.xg_scatter_free(p.value))

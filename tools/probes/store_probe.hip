@@ -342,6 +342,31 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&ticket, 8 * 32 * 4)); CK(hipMemset(ticket, 0, 8 * 32 * 4));
   CK(hipMalloc(&flag, (size_t)(plane_bytes / 16 / 64 + 64) * 4)); CK(hipMemset(flag, 0, (size_t)(plane_bytes / 16 / 64 + 64) * 4));
   CK(hipMalloc(&gave_up, 4)); CK(hipMalloc(&cnt, 8));
+  if (strcmp(what, "grade") == 0) {
+    // Is a slow placement a property of the PROCESS or of the BUFFER?  NB scattered buffers alive at once; for each: the flat fill,
+    // the many-plane fill (the candidate GRADING kernel: write-only, no input needed) and the scan-shaped march it should predict
+    const int NB = argc > 5 ? atoi(argv[5]) : 10;
+    std::vector<Buf> bufs;
+    for (int b = 0; b < NB; ++b) bufs.push_back(make(bytes, true));
+    const int64_t nvec = (int64_t)(bytes / 16);
+    const u32 nb = (u32)(((nvec + 255) / 256 + 7) / 8 * 8);
+    for (int pass = 0; pass < 2; ++pass)
+      for (int b = 0; b < NB; ++b) {
+        Buf& out = bufs[b];
+        double f_med, f_mn, w_med, w_mn, r_med, r_mn;
+        timeit([&] { hipLaunchKernelGGL((k_flat<0>), dim3(nb), dim3(256), 0, 0, (const dv*)in.p, (dv*)out.p, nvec); }, &f_med, &f_mn);
+        Plan p; p.P = P; p.G = P; p.ngroup = 1; p.plane = plane_bytes / 16; p.band = 1;
+        p.nsuper = (u32)((p.plane + 63) / 64); p.W = (p.nsuper + 7) / 8;
+        const u64 ntask = (u64)((p.nsuper + p.W - 1) / p.W) * p.W;
+        const u32 nblk = (u32)((((ntask + 3) / 4) + 7) / 8 * 8);
+        timeit([&] { hipLaunchKernelGGL((k_pattern<dv, 1, 0>), dim3(nblk), dim3(256), 0, 0, (const dv*)in.p, (dv*)out.p, p); }, &w_med, &w_mn);
+        timeit([&] { hipLaunchKernelGGL((k_pattern<dv, 1, 1>), dim3(nblk), dim3(256), 0, 0, (const dv*)in.p, (dv*)out.p, p); }, &r_med, &r_mn);
+        printf("{\"variant\": \"grade\", \"pass\": %d, \"buffer\": %d, \"flat_fill_ms\": %.4f, \"planes_fill_ms\": %.4f, \"planes_over_flat\": %.3f, \"march_rw_ms\": %.4f}\n",
+               pass, b, f_med, w_med, w_med / f_med, r_med);
+        fflush(stdout);
+      }
+    return 0;
+  }
   for (int scat = 0; scat < 2; ++scat) {
     Buf out = make(bytes, scat != 0);
     if (pmc) {

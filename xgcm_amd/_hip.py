@@ -44,6 +44,8 @@ SIGNATURES = {
     "xg_scatter_alloc": (C.c_int, [C.POINTER(_vp), C.c_uint64, C.c_uint64, C.c_int, C.c_uint64]),
     "xg_scatter_free": (C.c_int, [_vp]),
     "xg_scatter_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "xg_scatter_grade": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(C.c_double)]),
+    "xg_scatter_grade_stats": (C.c_int, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "xg_pool_alloc": (_vp, [C.c_ssize_t, C.c_int, _vp]),
     "xg_pool_free": (None, [_vp, C.c_ssize_t, C.c_int, _vp]),
     "xg_stream_create": (C.c_int, [C.POINTER(_vp)]),
@@ -252,7 +254,11 @@ def scatter_stats() -> dict:
     """scattered result buffers made so far, bytes alive, and pool requests that fell back to plain hipMalloc"""
     a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     check(load().xg_scatter_stats(C.byref(a), C.byref(b), C.byref(c)))
-    return {"buffers_made": int(a.value), "live_bytes": int(b.value), "pool_fallbacks": int(c.value)}
+    g, r = C.c_uint64(0), C.c_uint64(0)
+    check(load().xg_scatter_grade_stats(C.byref(g), C.byref(r)))
+    # graded: pool requests of 1 GiB or more whose buffer was graded; rejected: buffers parked and released on the way to a good one
+    return {"buffers_made": int(a.value), "live_bytes": int(b.value), "pool_fallbacks": int(c.value), "graded": int(g.value),
+            "rejected": int(r.value)}
 
 
 def last_error() -> str:

@@ -411,6 +411,8 @@ int xg_scatter_alloc(void** ptr, uint64_t bytes, uint64_t, int, uint64_t) {  // 
 }
 int xg_scatter_free(void* ptr) { free(ptr); return XG_OK; }
 int xg_scatter_stats(uint64_t* a, uint64_t* b, uint64_t* c) { if (a) *a = 0; if (b) *b = 0; if (c) *c = 0; return XG_OK; }
+int xg_scatter_grade(void* p, uint64_t, double* ratio) { if (!p || !ratio) return fail(XG_ERR_INVALID, "NULL argument"); *ratio = 1.0; return XG_OK; }  // host memory: nothing to grade
+int xg_scatter_grade_stats(uint64_t* a, uint64_t* b) { if (a) *a = 0; if (b) *b = 0; return XG_OK; }
 void* xg_pool_alloc(ssize_t size, int, void*) { return size > 0 ? malloc((size_t)size) : nullptr; }
 void xg_pool_free(void* ptr, ssize_t, int, void*) { free(ptr); }
 int xg_bswap(void* data, uint64_t nelem, int elem_bytes, void*) {
