@@ -117,7 +117,7 @@ int xg_scatter_stats(uint64_t* buffers_made, uint64_t* live_bytes, uint64_t* poo
  * 1.69 ms, the others at 1.86 - 2.04, each the same every time).  xg_scatter_grade times a write-only fill that walks 64 equal
  * slices of the buffer side by side -- the scan's store pattern -- against a flat fill of the same bytes (about 2 ms for 5 GB;
  * the buffer's contents are overwritten): `ratio` 1.03 - 1.09 = good, 1.17 - 1.38 = bad.  xg_pool_alloc grades every buffer
- * of 1 GiB or more it creates, parks bad ones while it tries again (XG_SCATTER_TRIES, 5) and keeps the best
+ * of 1 GiB or more it creates, parks bad ones while it tries again (up to 8 times; XG_SCATTER_TRIES) and keeps the best
  * (XG_SCATTER_GRADE_PCT, 112; 0 switches grading off); xg_scatter_grade_stats: requests graded, buffers rejected on the way. */
 int xg_scatter_grade(void* ptr, uint64_t bytes, double* ratio);
 int xg_scatter_grade_stats(uint64_t* graded, uint64_t* rejected);

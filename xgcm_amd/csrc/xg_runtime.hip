@@ -466,8 +466,8 @@ int xg_scatter_free(void* ptr) {
 // walks 64 equal slices of the buffer side by side (the scan's store pattern) against a flat fill of the same bytes.  Good
 // buffers take 1.03 - 1.09 x the flat fill's time, bad ones 1.17 - 1.38 x, and the ratio predicts the scan's time.
 // xg_pool_alloc grades every buffer of 1 GiB or more it creates and, while the grade is bad, PARKS the buffer (so that the
-// driver cannot hand the same physical memory out again), creates another -- up to XG_SCATTER_TRIES (5) -- and keeps the
-// best; the parked ones are released afterwards.  XG_SCATTER_GRADE_PCT (112; 0: no grading) is the accepted ratio in %.
+// driver cannot hand the same physical memory out again), creates another -- up to 8 times, fewer for large results: the
+// parked candidates of a request stay under 64 GiB (XG_SCATTER_TRIES overrides) -- and keeps the best; the parked ones are released afterwards.  XG_SCATTER_GRADE_PCT (112; 0: no grading) is the accepted ratio in %.
 // ------------------------------------------------------------------------------------------
 namespace {
 typedef double gv2 __attribute__((ext_vector_type(2)));
@@ -538,7 +538,11 @@ void* xg_pool_alloc(ssize_t size, int device, void* stream) {
   if (switched && hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   static const u64 chunk = (u64)env_int("XG_SCATTER_CHUNK_MB", 64) << 20;
   static const int grade_pct = env_int("XG_SCATTER_GRADE_PCT", 112);
-  static const int max_tries = env_int("XG_SCATTER_TRIES", 5);
+  // tries: as many as keep the parked candidates of one request under 64 GiB, between 2 and 8 (5.2 GB results: 8 -- with four
+  // good buffers in ten the chance of finding none is 2 %; 15.6 GB results: 4); XG_SCATTER_TRIES overrides
+  static const int env_tries = env_int("XG_SCATTER_TRIES", 0);
+  const u64 by_budget = (64ull << 30) / ((u64)size > 0 ? (u64)size : 1);
+  const int max_tries = env_tries > 0 ? env_tries : (int)(by_budget < 2 ? 2 : (by_budget > 8 ? 8 : by_budget));
   void* p = nullptr;
   bool fallback = false;
   if (xg_scatter_alloc(&p, (uint64_t)size, chunk, 1, 0) != XG_OK) {
