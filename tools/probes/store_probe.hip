@@ -342,6 +342,67 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&ticket, 8 * 32 * 4)); CK(hipMemset(ticket, 0, 8 * 32 * 4));
   CK(hipMalloc(&flag, (size_t)(plane_bytes / 16 / 64 + 64) * 4)); CK(hipMemset(flag, 0, (size_t)(plane_bytes / 16 / 64 + 64) * 4));
   CK(hipMalloc(&gave_up, 4)); CK(hipMalloc(&cnt, 8));
+  if (strcmp(what, "anatomy") == 0) {
+    // What makes a scattered buffer bad -- the SET of physical chunks or their ORDER?  NB buffers graded; the worst one's
+    // chunks are then mapped again in other orders (and mixed with the best one's) into fresh address ranges and graded
+    const int NB = argc > 5 ? atoi(argv[5]) : 8;
+    const size_t chunk = 64ull << 20;
+    const size_t nchunk = (bytes + chunk - 1) / chunk;
+    std::vector<Buf> bufs;
+    for (int b = 0; b < NB; ++b) bufs.push_back(make(bytes, true));
+    auto planes_ms = [&](void* base, int p0, int p1) {
+      Plan p; p.P = p1 - p0; p.G = p.P; p.ngroup = 1; p.plane = plane_bytes / 16; p.band = 1;
+      p.nsuper = (u32)((p.plane + 63) / 64); p.W = (p.nsuper + 7) / 8;
+      const u64 ntask = (u64)((p.nsuper + p.W - 1) / p.W) * p.W;
+      const u32 nblk = (u32)((((ntask + 3) / 4) + 7) / 8 * 8);
+      double med, mn;
+      dv* o = (dv*)((char*)base + (size_t)p0 * plane_bytes);
+      timeit([&] { hipLaunchKernelGGL((k_pattern<dv, 1, 0>), dim3(nblk), dim3(256), 0, 0, (const dv*)in.p, o, p); }, &med, &mn);
+      return med;
+    };
+    std::vector<double> g(NB);
+    int worst = 0, best = 0;
+    for (int b = 0; b < NB; ++b) {
+      g[b] = planes_ms(bufs[b].p, 0, P);
+      if (g[b] > g[worst]) worst = b;
+      if (g[b] < g[best]) best = b;
+      printf("{\"variant\": \"anatomy\", \"buffer\": %d, \"planes_fill_ms\": %.4f}\n", b, g[b]);
+    }
+    for (int b : {worst, best}) {
+      printf("{\"variant\": \"anatomy\", \"buffer\": %d, \"which\": \"%s\", \"first_half_ms\": %.4f, \"second_half_ms\": %.4f, \"q1\": %.4f, \"q2\": %.4f, \"q3\": %.4f, \"q4\": %.4f}\n",
+             b, b == worst ? "worst" : "best", planes_ms(bufs[b].p, 0, P / 2), planes_ms(bufs[b].p, P / 2, P), planes_ms(bufs[b].p, 0, P / 4),
+             planes_ms(bufs[b].p, P / 4, P / 2), planes_ms(bufs[b].p, P / 2, 3 * P / 4), planes_ms(bufs[b].p, 3 * P / 4, P));
+    }
+    fflush(stdout);
+    // remap: the same physical chunks behind a fresh address range in another order
+    auto remap_grade = [&](const char* name, const std::vector<hipMemGenericAllocationHandle_t>& hs) {
+      void* va = nullptr;
+      CK(hipMemAddressReserve(&va, hs.size() * chunk, 0, nullptr, 0));
+      for (size_t i = 0; i < hs.size(); ++i) CK(hipMemMap((char*)va + i * chunk, chunk, 0, hs[i], 0));
+      hipMemAccessDesc acc; acc.location.type = hipMemLocationTypeDevice; acc.location.id = 0; acc.flags = hipMemAccessFlagsProtReadWrite;
+      CK(hipMemSetAccess(va, hs.size() * chunk, &acc, 1));
+      const double ms = planes_ms(va, 0, P);
+      printf("{\"variant\": \"anatomy\", \"remap\": \"%s\", \"planes_fill_ms\": %.4f}\n", name, ms);
+      fflush(stdout);
+      CK(hipDeviceSynchronize());
+      for (size_t i = 0; i < hs.size(); ++i) CK(hipMemUnmap((char*)va + i * chunk, chunk));
+      // (the range is not given back: a reused range served stale pages in the library's pool)
+    };
+    const auto& hw = bufs[worst].h; const auto& hb = bufs[best].h;
+    remap_grade("worst, same order", hw);
+    remap_grade("best, same order", hb);
+    { auto v = hw; std::reverse(v.begin(), v.end()); remap_grade("worst, reversed", v); }
+    { std::vector<hipMemGenericAllocationHandle_t> v; for (size_t i = 0; i < nchunk; i += 2) v.push_back(hw[i]); for (size_t i = 1; i < nchunk; i += 2) v.push_back(hw[i]); remap_grade("worst, evens then odds", v); }
+    for (int seed = 1; seed <= 3; ++seed) {
+      auto v = hw; u64 st = 88172645463325252ull * seed;
+      for (size_t i = v.size() - 1; i > 0; --i) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; std::swap(v[i], v[st % (i + 1)]); }
+      remap_grade("worst, shuffled", v);
+    }
+    { std::vector<hipMemGenericAllocationHandle_t> v; for (size_t i = 0; i < nchunk; ++i) v.push_back((i & 1) ? hw[i] : hb[i]); remap_grade("even chunks of the best, odd of the worst", v); }
+    { std::vector<hipMemGenericAllocationHandle_t> v; for (size_t i = 0; i < nchunk; ++i) v.push_back(i < nchunk / 2 ? hb[i] : hw[i]); remap_grade("first half best, second half worst", v); }
+    { auto v = hb; std::reverse(v.begin(), v.end()); remap_grade("best, reversed", v); }
+    return 0;
+  }
   if (strcmp(what, "grade") == 0) {
     // Is a slow placement a property of the PROCESS or of the BUFFER?  NB scattered buffers alive at once; for each: the flat fill,
     // the many-plane fill (the candidate GRADING kernel: write-only, no input needed) and the scan-shaped march it should predict

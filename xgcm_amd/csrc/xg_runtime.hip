@@ -486,13 +486,18 @@ std::mutex g_grade_mu;
 u64 g_graded = 0, g_rejected = 0;
 // time of the many-slices fill over the time of the flat fill on this buffer (1.0 = as good as a flat sweep); < 0: could not grade
 double grade_buffer(void* p, u64 bytes) {
-  static hipStream_t s = nullptr;
-  static hipEvent_t e[3] = {nullptr, nullptr, nullptr};
-  if (!s) {
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); s = nullptr; return -1.0; }
-    for (auto& ev : e)
+  struct Ctx { hipStream_t s = nullptr; hipEvent_t e[3] = {nullptr, nullptr, nullptr}; };
+  static std::map<int, Ctx> per_device;  // (a stream and its events belong to the device that was current when they were made)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
+  Ctx& c = per_device[dev];
+  if (!c.s) {
+    if (hipStreamCreateWithFlags(&c.s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c.s = nullptr; return -1.0; }
+    for (auto& ev : c.e)
       if (hipEventCreate(&ev) != hipSuccess) { (void)hipGetLastError(); return -1.0; }
   }
+  hipStream_t s = c.s;
+  hipEvent_t* e = c.e;
   constexpr int P = 64;
   const int64_t plane = (int64_t)(bytes / 16 / P), nvec = plane * P;
   if (plane < 4096) return -1.0;
