@@ -99,9 +99,13 @@ class BlockArray:
                 raise IndexError("BlockArray: integers and unit-step slices only")
             lo, hi, _ = k.indices(n)
             spans.append((lo, max(lo, hi)))
-        out = np.empty([b - a for a, b in spans], dtype=self.dtype)
         per_dim = [bounds(c) for c in self.chunks]
         hit = [[i for i, (a, b) in enumerate(pd) if a < hi and b > lo] for pd, (lo, hi) in zip(per_dim, spans)]
+        if not squeeze and all(len(h) == 1 and per_dim[d][h[0]] == spans[d] for d, h in enumerate(hit)):
+            # exactly one whole block: the block itself, no copy (what the block walk asks for: a 345 MB block assembled by a
+            # single-threaded copy cost more than its trip through the GPU -- 5.2 GB through `diff` 0.97 s instead of 0.3)
+            return self.blocks[tuple(h[0] for h in hit)]
+        out = np.empty([b - a for a, b in spans], dtype=self.dtype)
         for idx in itertools.product(*hit):
             src, dst = [], []
             for d, i in enumerate(idx):
