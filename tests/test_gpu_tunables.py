@@ -25,7 +25,7 @@ ALTERNATIVES = {
     "scan_pipe": [0, 2], "scan_u": [8, 16, 24], "scan_pace": [1], "scan_chain": [0, 2, 3], "scan_chain_w": [2, 104], "scan_chain_tmaj": [1, 4],
     "reduce_zl": [1, 4], "met_ys1": [0, 4], "met_ys2": [0, 6], "transform_lean": [0, 1, 2], "pad_tpw": [1, 4], "bin_idx32": [0],
     "reduce_ldsw_u": [8, 16], "march_ofast": [0], "reduce_sk": [0, 2], "reduce_ru": [0, 2], "reduce_wfast": [0], "reduce_wg": [0, 1, 8, 16, 25],
-    "scan_sh1": [0], "reduce_zmarch": [0, 208, 308, 316, 408, 1312], "reduce_ldsw": [0, 1], "march_lds_kb": [32],
+    "scan_sh1": [0], "reduce_zmarch": [0, 208, 308, 312, 316, 408, 1308, 1316], "reduce_ldsw": [0, 1], "march_lds_kb": [32],
 }
 NOT_SWEPT = {"scan_chain_spin": "forces the rescue path: tests/test_gpu_chain_rescue.py", "dbg": "debug switches of single experiments"}
 

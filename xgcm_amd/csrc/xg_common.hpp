@@ -171,7 +171,7 @@ struct Tune {
   int reduce_wfast;   // contiguous-axis weighted reductions: unit-stride, row-aligned weights as one vector load per lane
   int reduce_wg;      // contiguous-axis reductions: one WORKGROUP per row (its 4 waves read adjacent 1-KB pieces) instead of one wave
   int scan_sh1;       // contiguous-axis scan, 4-byte elements, inputs shifted by one cell: aligned vector + one narrow load
-  int reduce_zmarch;  // K4Z: long weighted reductions with level-shared weights as a march of ZL levels per wave (100 * ZL + U: 312 = 3 levels, 12 row steps in flight; + 1000: float32 too; 0: K4L)
+  int reduce_zmarch;  // K4Z: long weighted reductions with level-shared weights as a march of ZL levels per wave (100 * ZL + U: 312 = 3 levels, 12 row steps in flight; + 1000: float32 too -- the default; 0: K4L)
   int reduce_ldsw;    // K4L: long weighted reductions with level-shared weights as a march whose weight rows go through LDS once per workgroup (0: chained K4cz)
   int reduce_zl;      // K4cz: outer indices per task of the chained weighted reduction sharing the weight rows (1 / 2 / 4)
   int dbg;            // A/B switches that do NOT change results (bit 2: the linear transform's division inside its loop)

@@ -70,7 +70,7 @@ const TuneEntry TUNABLES[] = {
     {"reduce_wfast", &Tune::reduce_wfast, 1},
     {"reduce_wg", &Tune::reduce_wg, 9},  // bit 0: plain sums; bit 3 / 4: level-shared weights, 2 / 4 levels per workgroup
     {"scan_sh1", &Tune::scan_sh1, 1},
-    {"reduce_zmarch", &Tune::reduce_zmarch, 312},
+    {"reduce_zmarch", &Tune::reduce_zmarch, 1312},
     {"reduce_ldsw", &Tune::reduce_ldsw, 2},
     {"dbg", &Tune::dbg, 0},
     {"march_lds_kb", &Tune::march_lds_kb, 0},

@@ -1064,14 +1064,20 @@ __global__ __launch_bounds__(NWV * WAVE) void k_reduce_ldsw(
 // costs 1 / ZL of a load per field row instead of K4's whole one.  Few waves (75 levels x 57 tiles / 5 = 855: one per SIMD)
 // with 36 - 48 loads in flight each instead of K4L's four-wave workgroups in lock step.  Sequential additions per column in
 // row order: the bits of numpy / of K4.  Workgroup = ONE wave, so that the few waves spread over all the chip's SIMDs.
-// MODE (compile time, so that the row loop carries no mode tests): 0 = sum(x * w), 1 = the same skipping NaN, 2 = the count /
-// mean / pair modes of xg_reduce1d (runtime `skipna` >= 2).  Accumulators start at -0.0: (-0.0) + v == v for every v (the
-// first row is ASSIGNED, as numpy's reduction does: a column of -0.0 sums to -0.0), so no "first row" test rides in the loop.
+// MODE (compile time, so that the row loop carries no mode tests): 0 = sum(x * w), 1 = the same skipping NaN, 2 / 3 = the
+// weights of the valid / of all cells (`skipna` 2 / 3), 4 / 5 = the one-pass mean over the valid / over all cells (`skipna`
+// 4 / 5; 6 / 7 = the same with numerator and denominator stored side by side, a runtime flag read after the loop only).
+// WV (decided once per wave, then a compile-time constant of the row loop): the lane's V weights are one aligned vector
+// load in every row -- float32's two-element lanes otherwise test alignment and step at EVERY weight load, a divergent
+// branch per row step that cut the loop into fragments (float32 average Y 0.37 of 8 TB/s, K4L 0.54; profiles/EXPERIMENTS.md).
+// Accumulators start at -0.0: (-0.0) + v == v for every v (the first row is ASSIGNED, as numpy's reduction does: a column
+// of -0.0 sums to -0.0), so no "first row" test rides in the loop.
 template <int U, int ZL, int MODE>
 __global__ __launch_bounds__(WAVE) void k_reduce_zmarch(
     const real* __restrict__ in, real* __restrict__ out, Geo g, u32 ntile, u32 ngrp, u32 ntask, int skipna,
     const real* __restrict__ wgt, MIdx mw) {
   constexpr int V = HV;
+  constexpr bool TWO = MODE >= 4;  // numerator and denominator march together
   typedef typename VecT<V>::type T;
   // XCD banding over (tile, level group) with the level groups fastest: the groups of one x-tile run side by side on ONE
   // XCD and find each other's weight rows in its L2
@@ -1093,76 +1099,87 @@ __global__ __launch_bounds__(WAVE) void k_reduce_zmarch(
   for (int l = 0; l < ZL; ++l) pin[l] = in + (o0 + (l < nlev ? l : 0)) * n * inner;  // (a level beyond the last re-reads level o0: never stored)
   const int64_t mb = inner_off(g, mw, x);
   const int64_t ms = (V > 1) ? inner_off(g, mw, x + 1) - mb : 0;
-  const bool pair = MODE == 2 && skipna >= 6;
-  if (pair) skipna -= 2;
-  const bool mean = MODE == 2 && skipna >= 4;
-  T acc[ZL], den[MODE == 2 ? ZL : 1];
+  T acc[ZL], den[TWO ? ZL : 1];
 #pragma unroll
   for (int l = 0; l < ZL; ++l) acc[l] = splat<T>(real(-0.0));
 #pragma unroll
-  for (int l = 0; l < (MODE == 2 ? ZL : 1); ++l) den[l] = splat<T>(real(-0.0));
+  for (int l = 0; l < (TWO ? ZL : 1); ++l) den[l] = splat<T>(real(-0.0));
   auto step = [&](int l, T v, T wv_) {  // k_reduce_strided's `step`, same operations in the same order
-    if (MODE == 2) {
-      if (mean) {
-        T d = as_count(v, skipna == 4 ? 2 : 3);
-        d = d * wv_;
-        v = v * wv_;
-        if (skipna == 4) v = nan0(v);
-        d = nan0(d);
-        den[MODE == 2 ? l : 0] = den[MODE == 2 ? l : 0] + d;
-      } else {
-        v = as_count(v, skipna);
-        v = v * wv_;
-        v = nan0(v);
-      }
+    if (TWO) {
+      T d = as_count(v, MODE == 4 ? 2 : 3);
+      d = d * wv_;
+      v = v * wv_;
+      if (MODE == 4) v = nan0(v);
+      d = nan0(d);
+      den[TWO ? l : 0] = den[TWO ? l : 0] + d;
+    } else if (MODE >= 2) {
+      v = as_count(v, MODE);
+      v = v * wv_;
+      v = nan0(v);
     } else {
       v = v * wv_;
       if (MODE == 1) v = nan0(v);
     }
     acc[l] = acc[l] + v;
   };
-  T v[U][ZL], wv[U];
+  auto march = [&](auto wvec) {
+    constexpr bool WV = decltype(wvec)::value;
+    auto ldw = [&](int64_t k) -> T {
+      if constexpr (WV) return *reinterpret_cast<const T*>(wgt + mb + k * mw.axis);
+      else return ldm<T>(wgt, mb + k * mw.axis, ms);
+    };
+    T v[U][ZL], wv[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u)
-    if (u < n) {
-      wv[u] = ldm<T>(wgt, mb + (int64_t)u * mw.axis, ms);
+    for (int u = 0; u < U; ++u)
+      if (u < n) {
+        wv[u] = ldw(u);
 #pragma unroll
-      for (int l = 0; l < ZL; ++l) v[u][l] = ldg<T, true>(pin[l] + (int64_t)u * inner + xo);
-    }
-  int64_t k0 = 0;
-  for (; k0 + 2 * U <= n; k0 += U) {  // steady state: no bounds tests; row k0 + u is consumed, row k0 + U + u requested
+        for (int l = 0; l < ZL; ++l) v[u][l] = ldg<T, true>(pin[l] + (int64_t)u * inner + xo);
+      }
+    int64_t k0 = 0;
+    for (; k0 + 2 * U <= n; k0 += U) {  // steady state: no bounds tests; row k0 + u is consumed, row k0 + U + u requested
 #pragma unroll
-    for (int u = 0; u < U; ++u) {  // consume slot u, then refill it in place (no copies of the window's registers)
-#pragma unroll
-      for (int l = 0; l < ZL; ++l) step(l, v[u][l], wv[u]);
-      wv[u] = ldm<T>(wgt, mb + (k0 + U + u) * mw.axis, ms);
-#pragma unroll
-      for (int l = 0; l < ZL; ++l) v[u][l] = ldg<T, true>(pin[l] + (k0 + U + u) * inner + xo);
-    }
-  }
-  for (; k0 < n; k0 += U) {  // the last one or two windows (wave-uniform tests)
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (k0 + u < n) {
+      for (int u = 0; u < U; ++u) {  // consume slot u, then refill it in place (no copies of the window's registers)
 #pragma unroll
         for (int l = 0; l < ZL; ++l) step(l, v[u][l], wv[u]);
-      }
-      if (k0 + U + u < n) {
-        wv[u] = ldm<T>(wgt, mb + (k0 + U + u) * mw.axis, ms);
+        wv[u] = ldw(k0 + U + u);
 #pragma unroll
         for (int l = 0; l < ZL; ++l) v[u][l] = ldg<T, true>(pin[l] + (k0 + U + u) * inner + xo);
       }
     }
+    for (; k0 < n; k0 += U) {  // the last one or two windows (wave-uniform tests)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (k0 + u < n) {
+#pragma unroll
+          for (int l = 0; l < ZL; ++l) step(l, v[u][l], wv[u]);
+        }
+        if (k0 + U + u < n) {
+          wv[u] = ldw(k0 + U + u);
+#pragma unroll
+          for (int l = 0; l < ZL; ++l) v[u][l] = ldg<T, true>(pin[l] + (k0 + U + u) * inner + xo);
+        }
+      }
+    }
+  };
+  if (V > 1) {
+    // every active lane's V weights sit side by side, vector-aligned in row 0, and the row step keeps that alignment
+    const bool lane_ok = ms == 1 && (mw.axis % V) == 0 && ((reinterpret_cast<uintptr_t>(wgt) / sizeof(real) + (uintptr_t)mb) % V) == 0;
+    if (__all(lane_ok)) march(std::true_type{});
+    else march(std::false_type{});
+  } else {
+    march(std::false_type{});
   }
+  const bool pair = TWO && skipna >= 6;
 #pragma unroll
   for (int l = 0; l < ZL; ++l) {
     if (l < nlev) {
       const int64_t o = o0 + l;
       if (pair) {
         *reinterpret_cast<T*>(out + o * inner + x) = acc[l];
-        *reinterpret_cast<T*>(out + (g.outer + o) * inner + x) = den[MODE == 2 ? l : 0];
+        *reinterpret_cast<T*>(out + (g.outer + o) * inner + x) = den[TWO ? l : 0];
       } else {
-        *reinterpret_cast<T*>(out + o * inner + x) = mean ? acc[l] / den[MODE == 2 ? l : 0] : acc[l];
+        *reinterpret_cast<T*>(out + o * inner + x) = TWO ? acc[l] / den[TWO ? l : 0] : acc[l];
       }
     }
   }
@@ -2039,10 +2056,11 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
       u32 ctile = 0;
       u64 nblk = 0;
       // K4Z: ZL levels per wave share the weight row in registers (round 6)
-      // (float64 only unless forced with 1000 + value: float32 rows have half the x-tiles, K4Z then has too few waves --
-      // sum 0.59 -> 0.76 - 1.12 ms, profiles/r06_kernels/; K4L keeps those.  A/B on 75 x 2400 x 3600 f64, paired over 6
-      // placements: integrate Y 0.953 -> 0.872 ms (0.689 -> 0.753 of 8 TB/s) with 3 levels x 12 rows in flight, 0.891 with
-      // 3 x 8, 0.949 with 2 x 8, 0.988 with 4 x 8; average Y 0.962 -> 0.918 (3 x 8; 3 x 12: 0.932, 3 x 16: 1.34))
+      // (float32 with 1000 + value -- the default: float32 rows have half the x-tiles and K4Z few waves, yet it beats K4L
+      // since the weight-load form left the row loop: sum 0.56 -> 0.70 of 8 TB/s, mean 0.54 -> 0.59, profiles/r06_kernels/r06ai_*.
+      // A/B on 75 x 2400 x 3600 f64, paired over 6 placements: integrate Y 0.953 -> 0.872 ms (0.689 -> 0.753 of 8 TB/s) with
+      // 3 levels x 12 rows in flight, 0.891 with 3 x 8, 0.949 with 2 x 8, 0.988 with 4 x 8; average Y 0.962 -> 0.918 (3 x 8;
+      // 3 x 12: 0.932, 3 x 16: 1.34))
       // (`reduce_ldsw` = 0 switches BOTH level-sharing marches off: the chained kernels / the plain march below)
       if (shared_w && tune().reduce_zmarch && tune().reduce_ldsw && (sizeof(real) == 8 || tune().reduce_zmarch >= 1000) && g.outer >= 3 && g.n_in >= 64 &&
           g.outer < 0x7fffffffll) {
@@ -2053,11 +2071,15 @@ int XG_FN(xg_reduce1d)(const real* in, real* out, const int64_t* shape, int ndim
         if (ztask < 0x7ffffff0ull) {
           const u32 zgrid = (u32)(((ztask + 7) / 8) * 8);
 #define XG_ZM(U_, ZL_, M_) hipLaunchKernelGGL((k_reduce_zmarch<U_, ZL_, M_>), dim3(zgrid), dim3(WAVE), 0, st, in, out, g, ztile, (u32)zgrp, (u32)ztask, skipna, w, mw)
-#define XG_Z(U_, ZL_) do { if (skipna >= 2) XG_ZM(U_, ZL_, 2); else if (skipna) XG_ZM(U_, ZL_, 1); else XG_ZM(U_, ZL_, 0); } while (0)
-          const int zu = (skipna >= 2 && zm % 100 > 8) ? 8 : zm % 100;  // two running sums per level: the shorter window
-          if (zl == 2) { if (zu >= 24) XG_Z(24, 2); else if (zu >= 16) XG_Z(16, 2); else if (zu >= 12) XG_Z(12, 2); else XG_Z(8, 2); }
+#define XG_Z(U_, ZL_) do { if (skipna) XG_ZM(U_, ZL_, 1); else XG_ZM(U_, ZL_, 0); } while (0)
+          // the count / mean / pair modes (two running sums per level in the means): the 8-row window
+#define XG_ZC(ZL_) do { if (skipna == 2) XG_ZM(8, ZL_, 2); else if (skipna == 3) XG_ZM(8, ZL_, 3); else if (skipna == 4 || skipna == 6) XG_ZM(8, ZL_, 4); else XG_ZM(8, ZL_, 5); } while (0)
+          const int zu = zm % 100;
+          if (skipna >= 2) { if (zl == 2) XG_ZC(2); else if (zl == 4) XG_ZC(4); else XG_ZC(3); }
+          else if (zl == 2) { if (zu >= 24) XG_Z(24, 2); else if (zu >= 16) XG_Z(16, 2); else if (zu >= 12) XG_Z(12, 2); else XG_Z(8, 2); }
           else if (zl == 4) XG_Z(8, 4);
           else { if (zu >= 16) XG_Z(16, 3); else if (zu >= 12) XG_Z(12, 3); else XG_Z(8, 3); }
+#undef XG_ZC
 #undef XG_Z
 #undef XG_ZM
           XG_LAUNCH_CHECK();
