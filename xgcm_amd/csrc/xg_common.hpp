@@ -131,7 +131,7 @@ struct Tune {
   int zchunk;         // x-tiles per column chunk when the short-segment kernel serves whole-plane rows (0: march)
   int zband;          // band-major row order when all metrics are broadcast along the slowest dim
   int zb_rows;        // rows per band
-  int scan_block;     // workgroup size of the contiguous-axis scan (64 / 128 / 256 / 512 / 1024; 0: 256, 128 for plain float32 rows)
+  int scan_block;     // workgroup size of the contiguous-axis scan (64 / 128 / 256 / 512 / 1024; 0: 256, 128 for float32 rows)
   int strided_gen;    // flat NV-group kernel for misaligned rows of a strided stencil axis
   int march_band;     // XCD-banded wave order in the column-marching scans / reductions
   int scan_vec;       // aligned-output-group scan for cumsum along the contiguous axis
@@ -568,6 +568,16 @@ __device__ __forceinline__ int64_t inner_offx(const Geo& g, const MIdx& m, int64
   return g.idx32 ? inner_off32(g, m, (u32)x) : inner_off(g, m, x);
 }
 
+// Is the metric of EVERY active lane of this wave one aligned V-vector in every row (elements side by side, row 0 aligned,
+// row step a multiple of V)?  Kernels whose row loops load metrics ask once and run the loop with plain vector loads: the
+// test inside `ldm` is a lane-divergent branch per load that cuts an unrolled row loop into fragments, every product then
+// waits for its own metric load (float32's two-element lanes: cumint Y 0.59 against cumsum Y's 0.74 of 8 TB/s).
+template <int V>
+__device__ __forceinline__ bool met_vec_all(const real* m, int64_t base, int64_t step, int64_t axis) {
+  if (V == 1) return false;
+  const bool ok = step == 1 && (axis % V) == 0 && ((reinterpret_cast<uintptr_t>(m) / sizeof(real) + (uintptr_t)base) % V) == 0;
+  return __all(ok) != 0;
+}
 // metric value(s) for a V-wide lane at metric offset `off` (second element `step` further on)
 template <typename T> __device__ __forceinline__ T ldm(const real* m, int64_t off, int64_t step);
 template <> __device__ __forceinline__ real ldm<real>(const real* m, int64_t off, int64_t) { return m[off]; }

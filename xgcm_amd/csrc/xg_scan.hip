@@ -103,7 +103,6 @@ __device__ __forceinline__ void cumsum_strided_body(
   bool started = false;
   // the input metric of a row is loaded WITH the row (same window / batch): left inside `step` it was one
   // dependent L2 round trip per row of the march (cumint along Y with dy(Y,X): 40 % of 8 TB/s)
-  auto ldw = [&](int64_t idx) -> T { return HAS_MI ? ldm<T>(m_in, mi_base + idx * mi.axis, mi_step) : splat<T>(real(1)); };
   auto step = [&](int64_t idx, T v, T w) {
     if (HAS_MI) v = v * w;
     if (a.skipna) v = nan0(v);
@@ -112,6 +111,13 @@ __device__ __forceinline__ void cumsum_strided_body(
     if (idx == first_kept) c_first = acc;
     if (idx == last_kept) c_last = acc;
     if (idx >= first_kept && idx <= last_kept) put(idx + shift, acc);
+  };
+  // (the form of the metric load -- one aligned vector or element by element -- is decided once per wave: see met_vec_all)
+  auto march = [&](auto wvec) {
+  constexpr bool WV = decltype(wvec)::value;
+  auto ldw = [&](int64_t idx) -> T {
+    if constexpr (WV) return *reinterpret_cast<const T*>(m_in + mi_base + idx * mi.axis);
+    else return HAS_MI ? ldm<T>(m_in, mi_base + idx * mi.axis, mi_step) : splat<T>(real(1));
   };
   int64_t t = 0;
   if (PIPE) {
@@ -163,6 +169,9 @@ __device__ __forceinline__ void cumsum_strided_body(
     step(idx, ldg<T, NTL>(pin + idx * inner), ldw(idx));
   }
   }
+  };
+  if (V > 1 && HAS_MI && met_vec_all<V>(m_in, mi_base, mi_step, mi.axis)) march(std::true_type{});
+  else march(std::false_type{});
   // halo cells of the padded cumulative result (xgcm/grid.py:1385-1391; numpy.pad semantics)
   if (a.pad_lo) {
     T h = (a.bc == XG_BC_FILL) ? splat<T>(a.fill) : (a.bc == XG_BC_PERIODIC ? c_last : c_first);
@@ -378,8 +387,13 @@ __global__ __launch_bounds__(BLOCK) void k_cumsum_chain(
 #pragma unroll
     for (int r = 0; r < R; ++r) v[r] = ldg<T, true>(pin + row(r) * inner + xo);
     if (HAS_MI) {
+      if (V > 1 && met_vec_all<V>(m_in, mi_base, mi_step, mi.axis)) {  // the load form decided once, outside the row loop
 #pragma unroll
-      for (int r = 0; r < R; ++r) v[r] = v[r] * ldm<T>(m_in, mi_base + row(r) * mi.axis, mi_step);
+        for (int r = 0; r < R; ++r) v[r] = v[r] * *reinterpret_cast<const T*>(m_in + mi_base + row(r) * mi.axis);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = v[r] * ldm<T>(m_in, mi_base + row(r) * mi.axis, mi_step);
+      }
     }
   } else {
 #pragma unroll
@@ -860,10 +874,6 @@ __device__ __forceinline__ void reduce_strided_body(
   if (pair) skipna -= 2;
   const bool mean = skipna >= 4;
   // the weight of a row is loaded WITH the row (same window / batch), not inside `step` (see k_cumsum_strided)
-  auto ldw = [&](int64_t k) -> T {
-    if (WU) return splat<T>(wgt[mb + k * mw.axis]);
-    return HAS_W ? ldm<T>(wgt, mb + k * mw.axis, ms) : splat<T>(real(1));
-  };
   auto step = [&](int64_t k, T v, T wv) {
     if (mean) {  // the two sums of modes 1 / 0 (numerator) and 2 / 3 (denominator), same order, same bits
       T d = as_count(v, skipna == 4 ? 2 : 3);
@@ -878,6 +888,14 @@ __device__ __forceinline__ void reduce_strided_body(
     }
     acc = started ? acc + v : v;
     started = true;
+  };
+  // (the form of the per-cell weight load -- one aligned vector or element by element -- is decided once per wave: see met_vec_all)
+  auto march = [&](auto wvec) {
+  constexpr bool WV = decltype(wvec)::value;
+  auto ldw = [&](int64_t k) -> T {
+    if (WU) return splat<T>(wgt[mb + k * mw.axis]);
+    if constexpr (WV) return *reinterpret_cast<const T*>(wgt + mb + k * mw.axis);
+    else return HAS_W ? ldm<T>(wgt, mb + k * mw.axis, ms) : splat<T>(real(1));
   };
   int64_t k = 0;
   if (PIPE) {  // rolling window of U loads (see k_cumsum_strided)
@@ -923,6 +941,9 @@ __device__ __forceinline__ void reduce_strided_body(
   }
   for (; k < n; ++k) step(k, ldg<T, NTL>(pin + k * inner), ldw(k));
   }
+  };
+  if (V > 1 && HAS_W && !WU && met_vec_all<V>(wgt, mb, ms, mw.axis)) march(std::true_type{});
+  else march(std::false_type{});
   if (pair) {
     *reinterpret_cast<T*>(out + o * inner + x) = acc;
     *reinterpret_cast<T*>(out + (g.outer + o) * inner + x) = den;
@@ -1856,8 +1877,10 @@ int XG_FN(xg_cumsum1d)(const real* in, real* out, const int64_t* shape, int ndim
       const u32 grid = ((nwork + 7) / 8) * 8;
       const bool nts = tune().nt_store;
       // rows of float32 are half as long in bytes: 128 threads per row measured -4.6 % on the plain scan there (0.710 -> 0.744;
-      // with a metric +-0, float64 +4 %: profiles/history/r04aa_ab_f32_rowshapes.log), 256 everywhere else
-      const int bs = tune().scan_block ? tune().scan_block : (sizeof(real) == 4 && !met ? 128 : 256);
+      // with a metric +-0 when round 4 measured it, float64 +4 %: profiles/history/r04aa_ab_f32_rowshapes.log).  Since the
+      // shifted weighted scan (the Grid's cumint X: `scan_sh1`) 128 wins there too: 1.131 -> 0.994 ms, 0.577 -> 0.656 of
+      // 8 TB/s, the unshifted one unchanged (profiles/r06_kernels/r06ak_ab_scan_block_f32.log); 256 for 8-byte elements
+      const int bs = tune().scan_block ? tune().scan_block : (sizeof(real) == 4 ? 128 : 256);
 #define XG_L(M, NTS_, BS_) hipLaunchKernelGGL((k_cumsum_contig_vec<M, NTS_, BS_>), dim3(grid), dim3(BS_), 0, st, in, out, g, nrows, a, m_in, mi, m_out, mo, zb, nwork, (tune().scan_dpp ? 1 : 0) | (tune().scan_sh1 ? 2 : 0))
 #define XG_B(M, NTS_) do { if (bs == 512) XG_L(M, NTS_, 512); else if (bs == 1024) XG_L(M, NTS_, 1024); else if (bs == 128) XG_L(M, NTS_, 128); else if (bs == 64) XG_L(M, NTS_, 64); else XG_L(M, NTS_, 256); } while (0)
 #define XG_M(M) do { if (nts) XG_B(M, true); else XG_B(M, false); } while (0)
