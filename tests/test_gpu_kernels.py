@@ -354,6 +354,36 @@ def test_weighted_reduction_with_weights_through_lds(dev, dtype):
             _hip.set_tunable(k, v)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_metric_views_unaligned_and_strided(dev, dtype):
+    """The marches along a strided axis decide the FORM of their metric loads once per wave (`met_vec_all`: one aligned vector
+    per lane, or element by element).  A metric handed over as a VIEW -- starting one element into its allocation with an odd
+    row pitch, or stored transposed (element step != 1 along the lanes) -- must take the element-wise form and give the bits
+    of the same metric laid out contiguously: weighted sums / means along Y (K4Z), along Z with a (Y, X) weight, and the
+    weighted scans along Y (chained) and Z (march)."""
+    import torch
+
+    shape = (5, 130, 132)
+    a = _field(shape, 41, nan=True).astype(dtype)
+    w = R.synthetic_metric((1, 130, 132), 42).astype(dtype)
+    t = dev.asdevice(a)
+    wc = dev.asdevice(w)
+    pitch = torch.zeros((1, 130, 133), dtype=wc.dtype, device=wc.device)
+    pitch[:, :, 1:] = wc
+    transposed = wc.permute(0, 2, 1).contiguous().permute(0, 2, 1)
+    assert transposed.stride(2) == 130 and pitch[:, :, 1:].storage_offset() == 1
+    for view in (pitch[:, :, 1:], transposed):
+        for mode in (True, False, "valid", "all", "mean_valid", "mean_all", "pair_valid", "pair_all"):
+            _eq(dev.tohost(dev.reduce1d(t, 1, view, mode)), dev.tohost(dev.reduce1d(t, 1, wc, mode)))
+            _eq(dev.tohost(dev.reduce1d(t, 0, view, mode)), dev.tohost(dev.reduce1d(t, 0, wc, mode)))
+        for axis in (0, 1):
+            for rev in (False, True):
+                _eq(dev.tohost(dev.cumsum1d(t, axis, 0, 1, 1, 0, "fill", 0.0, rev, True, view, None)),
+                    dev.tohost(dev.cumsum1d(t, axis, 0, 1, 1, 0, "fill", 0.0, rev, True, wc, None)))
+    with np.errstate(invalid="ignore"):
+        _eq(dev.tohost(dev.reduce1d(t, 1, pitch[:, :, 1:], True)), R.integrate(a, 1, np.broadcast_to(w, shape), True).astype(dtype))
+
+
 def test_weighted_march_orders_under_every_banding_setting(dev):
     """`march_ofast` orders the plain weighted march outer-indices-fastest through the banded wave id,
     which walks ceil(grid / 8) workgroups per XCD band -- the grid must be rounded to a multiple of 8 for it also when
