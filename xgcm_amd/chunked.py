@@ -123,6 +123,16 @@ class BlockArray:
     def __repr__(self) -> str:
         return f"BlockArray(shape={self.shape}, dtype={self.dtype}, chunks={self.chunks})"
 
+    def to_dask(self):
+        """the same blocks as ONE dask array (no copy, nothing computed): how a chunked result leaves for xarray where dask
+        exists (`labeled.to_xarray`) -- the form the reference's `dask="parallelized"` result has (xgcm/grid.py:786-818)"""
+        import dask.array as dsa
+
+        nested = np.empty(self.numblocks, dtype=object)
+        for idx, blk in self.blocks.items():
+            nested[idx] = dsa.from_array(blk, chunks=blk.shape)
+        return dsa.block(nested.tolist())
+
 
 def rechunk_blocks(result_blocks: Dict[Tuple[int, ...], np.ndarray], chunks: Chunks, axis: int, lengths: Sequence[int]):
     """blocks that are whole along `axis` cut into `lengths` there (views): the operator's axis keeps the input's chunks when

@@ -326,13 +326,162 @@ def netcdf_blocks(path: str, name: str, records_per_block: int = 1, records: Opt
 # `.zattrs` (`_ARRAY_DIMENSIONS`), so it is read here directly.  A `ZarrArray` is a CHUNKED CONTAINER in the sense of
 # xgcm_amd.chunked (`.chunks`, `.shape`, `.dtype`, slicing): handed to a DataArray, the operators walk its chunks block
 # by block -- a chunk file is read (and inflated) when its block is due, never the whole array.
-# Codecs: none, zlib, gzip, bz2, lzma (python's own).  blosc / zstd / lz4 (zarr's default is blosc) need libraries this
-# image lacks: refused by name, never guessed.  Filters: refused.
+# Codecs: none, zlib, gzip, bz2, lzma (python's own); zstd and lz4 (numcodecs' framings) through the system's libzstd /
+# liblz4 (ctypes); blosc -- zarr's DEFAULT compressor, i.e. what an `xarray.Dataset.to_zarr` without an encoding holds --
+# decoded here: the c-blosc 1 container (16-byte header, block starts, per-block split streams, byte / bit unshuffle) around
+# lz4 / lz4hc / zstd / zlib streams; its own `blosclz` codec only where a libblosc can be loaded.  Pinned against chunks the
+# real c-blosc 1.21 / libzstd / liblz4 compressed (tests/golden/codec_chunks.npz, oracle/make_golden_codecs.py).
+# Filters: refused.
 # ------------------------------------------------------------------------------------------------------
+_CLIBS: Dict[str, object] = {}
+
+
+def _clib(name: str):
+    """libzstd / liblz4 / libblosc through ctypes, loaded once; None when this box has none"""
+    if name not in _CLIBS:
+        import ctypes
+        import ctypes.util
+
+        lib = None
+        cands = [os.environ.get(f"XG_{name.upper()}_LIB"), ctypes.util.find_library(name), f"lib{name}.so.1", f"/opt/conda/lib/lib{name}.so.1"]
+        for cand in cands:
+            if cand:
+                try:
+                    lib = ctypes.CDLL(cand)
+                    break
+                except OSError:
+                    continue
+        if lib is not None:
+            c = ctypes
+            if name == "zstd":
+                lib.ZSTD_decompress.restype, lib.ZSTD_decompress.argtypes = c.c_size_t, [c.c_void_p, c.c_size_t, c.c_char_p, c.c_size_t]
+                lib.ZSTD_getFrameContentSize.restype, lib.ZSTD_getFrameContentSize.argtypes = c.c_ulonglong, [c.c_char_p, c.c_size_t]
+                lib.ZSTD_isError.restype, lib.ZSTD_isError.argtypes = c.c_uint, [c.c_size_t]
+            elif name == "lz4":
+                lib.LZ4_decompress_safe.restype, lib.LZ4_decompress_safe.argtypes = c.c_int, [c.c_char_p, c.c_void_p, c.c_int, c.c_int]
+            elif name == "blosc":
+                lib.blosc_decompress_ctx.restype, lib.blosc_decompress_ctx.argtypes = c.c_int, [c.c_char_p, c.c_void_p, c.c_size_t, c.c_int]
+        _CLIBS[name] = lib
+    return _CLIBS[name]
+
+
+def _need(name: str, what: str):
+    lib = _clib(name)
+    if lib is None:
+        raise NotImplementedError(f"{what} needs lib{name} (not found on this box; XG_{name.upper()}_LIB names one)")
+    return lib
+
+
+def _zstd_decode(raw: bytes, nbytes: Optional[int] = None) -> bytes:
+    import ctypes
+
+    lib = _need("zstd", "zarr compressor 'zstd'")
+    if nbytes is None:
+        nbytes = lib.ZSTD_getFrameContentSize(raw, len(raw))
+        if nbytes >= 2 ** 63:  # ZSTD_CONTENTSIZE_UNKNOWN / _ERROR: numcodecs writes one frame with its size
+            raise ValueError("zstd chunk without a content size in its frame header")
+    dst = ctypes.create_string_buffer(max(1, int(nbytes)))
+    n = lib.ZSTD_decompress(dst, int(nbytes), raw, len(raw))
+    if lib.ZSTD_isError(n) or n != nbytes:
+        raise ValueError("corrupt zstd stream in a zarr chunk")
+    return dst.raw[:n]
+
+
+def _lz4_block(raw: bytes, nbytes: int) -> bytes:
+    import ctypes
+
+    lib = _need("lz4", "zarr compressor 'lz4'")
+    dst = ctypes.create_string_buffer(max(1, nbytes))
+    n = lib.LZ4_decompress_safe(raw, dst, len(raw), nbytes)
+    if n != nbytes:
+        raise ValueError("corrupt lz4 stream in a zarr chunk")
+    return dst.raw[:n]
+
+
+_BLOSC_FORMATS = {0: "blosclz", 1: "lz4", 2: "snappy", 3: "zlib", 4: "zstd"}  # header flags bits 5-7 (lz4hc shares lz4's format)
+
+
+def _blosc_decode(raw: bytes) -> bytes:
+    """One c-blosc 1 buffer -> the chunk's bytes.  Header: version, versionlz, flags (1 byte shuffle, 2 plain copy, 4 bit shuffle,
+    16 blocks not split, bits 5-7 the inner format), typesize, then uint32 LE nbytes / blocksize / cbytes; int32 block starts;
+    a block is `typesize` streams (one per byte position of the shuffled elements: when split) or one, each an int32 length
+    followed by the inner codec's stream -- or by the plain bytes when the length equals the stream's decoded size."""
+    if len(raw) < 16:
+        raise ValueError("blosc chunk shorter than its header")
+    flags, typesize = raw[2], raw[3]
+    nbytes, blocksize, cbytes = (int.from_bytes(raw[o:o + 4], "little") for o in (4, 8, 12))
+    if cbytes != len(raw):
+        raise ValueError(f"blosc chunk of {len(raw)} bytes whose header says {cbytes}")
+    if flags & 2:  # stored as it was
+        return raw[16:16 + nbytes]
+    fmt = _BLOSC_FORMATS.get(flags >> 5)
+    if fmt in ("blosclz", "snappy", None):  # no decoder of ours: the library itself, where there is one
+        import ctypes
+
+        lib = _clib("blosc")
+        if lib is None:
+            raise NotImplementedError(f"blosc chunk with inner codec {fmt!r}: served are lz4 / lz4hc / zstd / zlib (libblosc, which "
+                                      "has the others, was not found; XG_BLOSC_LIB names one)")
+        dst = ctypes.create_string_buffer(max(1, nbytes))
+        if lib.blosc_decompress_ctx(raw, dst, nbytes, 1) != nbytes:
+            raise ValueError("corrupt blosc chunk")
+        return dst.raw[:nbytes]
+    if nbytes == 0:
+        return b""
+    nblocks = (nbytes + blocksize - 1) // blocksize
+    starts = np.frombuffer(raw, dtype="<i4", count=nblocks, offset=16)
+    out = bytearray(nbytes)
+    for b in range(nblocks):
+        bsize = min(blocksize, nbytes - b * blocksize)
+        leftover = bsize != blocksize
+        split = not (flags & 16) and typesize <= 16 and blocksize // typesize >= 128 and not leftover
+        nstreams = typesize if split else 1
+        per = bsize // nstreams
+        pos, parts = int(starts[b]), []
+        for _ in range(nstreams):
+            clen = int.from_bytes(raw[pos:pos + 4], "little", signed=True)
+            pos += 4
+            if clen < 0 or pos + clen > len(raw):
+                raise ValueError("corrupt blosc chunk (stream length)")
+            piece = raw[pos:pos + clen]
+            pos += clen
+            if clen == per:
+                parts.append(piece)
+            elif fmt == "lz4":
+                parts.append(_lz4_block(piece, per))
+            elif fmt == "zstd":
+                parts.append(_zstd_decode(piece, per))
+            else:
+                import zlib
+
+                parts.append(zlib.decompress(piece))
+        blk = b"".join(parts)
+        if len(blk) != bsize:
+            raise ValueError("corrupt blosc chunk (block size)")
+        nel = bsize // typesize
+        if flags & 1 and typesize > 1:  # byte shuffle: byte j of every element, then byte j + 1 ...; trailing bytes as they are
+            body = np.frombuffer(blk, dtype="u1", count=nel * typesize).reshape(typesize, nel).T.tobytes()
+            blk = body + blk[nel * typesize:]
+        elif flags & 4 and nel % 8 == 0 and nel:  # bit shuffle (bitshuffle's element transpose): row (j, k) holds bit k of byte
+            # j of every element, 8 elements to a byte; c-blosc leaves a block whose element count is no multiple of 8 as it is
+            rows = np.frombuffer(blk, dtype="u1", count=nel * typesize).reshape(typesize * 8, nel // 8)
+            bits = np.unpackbits(rows, axis=1, bitorder="little")               # (typesize * 8, nel): bit (j, k) of element i
+            elems = np.packbits(bits.T.reshape(nel, typesize, 8), axis=2, bitorder="little")
+            blk = elems.tobytes() + blk[nel * typesize:]
+        out[b * blocksize:b * blocksize + bsize] = blk
+    return bytes(out)
+
+
 def _zarr_decode(raw: bytes, codec: Optional[dict]) -> bytes:
     if codec is None:
         return raw
     cid = codec.get("id")
+    if cid == "blosc":
+        return _blosc_decode(raw)
+    if cid == "zstd":
+        return _zstd_decode(raw)
+    if cid == "lz4":  # numcodecs.LZ4: the raw size (uint32, little endian), then one lz4 block
+        return _lz4_block(raw[4:], int.from_bytes(raw[:4], "little"))
     if cid == "zlib":
         import zlib
 
@@ -349,8 +498,10 @@ def _zarr_decode(raw: bytes, codec: Optional[dict]) -> bytes:
         import lzma
 
         return lzma.decompress(raw)
-    raise NotImplementedError(f"zarr compressor {cid!r} is not available here (served: none, zlib, gzip, bz2, lzma); "
-                              "rewrite the store with one of those, e.g. `encoding={var: {'compressor': numcodecs.Zlib()}}`")
+    raise NotImplementedError(f"zarr compressor {cid!r} is not served (served: none, blosc, zstd, lz4, zlib, gzip, bz2, lzma)")
+
+
+_ZARR_CODECS = ("blosc", "zstd", "lz4", "zlib", "gzip", "bz2", "lzma")
 
 
 class ZarrArray:
@@ -378,8 +529,11 @@ class ZarrArray:
         fv = meta.get("fill_value")
         self._fill = (np.nan if fv in ("NaN", None) and self.dtype.kind == "f" else
                       {"Infinity": np.inf, "-Infinity": -np.inf}.get(fv, 0 if fv is None else fv))
-        if self._codec is not None and self._codec.get("id") not in ("zlib", "gzip", "bz2", "lzma"):
+        if self._codec is not None and self._codec.get("id") not in _ZARR_CODECS:
             _zarr_decode(b"", self._codec)  # refused at open (by name), not at the first read
+        for cid, lib in (("zstd", "zstd"), ("lz4", "lz4")):
+            if self._codec is not None and self._codec.get("id") == cid:
+                _need(lib, f"zarr compressor {cid!r}")  # ... and so is a library this box lacks
         self.attrs: Dict = {}
         za = os.path.join(path, ".zattrs")
         if os.path.exists(za):

@@ -571,14 +571,8 @@ def to_xarray(da: DataArray):
     data = None
     if _is_chunked(da.data):  # a chunked result leaves as a dask array of the same blocks where dask exists (else: assembled)
         try:
-            import dask.array as dsa
-
-            blocks = da.data.blocks
-            nested = np.empty(da.data.numblocks, dtype=object)
-            for idx, blk in blocks.items():
-                nested[idx] = dsa.from_array(blk, chunks=blk.shape)
-            data = dsa.block(nested.tolist())
-        except Exception:  # noqa: BLE001 -- no dask (this image), or a container without `.blocks`
+            data = da.data.to_dask()
+        except Exception:  # noqa: BLE001 -- no dask for this interpreter, or a container that is not a BlockArray
             data = None
     if data is None:
         data = da.values
