@@ -1,0 +1,148 @@
+"""NetCDF-4 / HDF5 files as chunked inputs (xgcm_amd/hdf5.py).
+
+The reference's users reach such files through `xr.open_dataset(path, chunks=...)`: dask arrays over libhdf5 hyperslab reads,
+walked by `apply_ufunc(dask="parallelized")` (`xgcm/grid.py:786-818`).  The file under test was written by REAL h5py 3.3 /
+HDF5 1.10.6 in the netCDF-4 library's layout (oracle/make_golden_netcdf4.py -> tests/golden/netcdf4_state.nc + the arrays that
+went in, netcdf4_state.npz); it is read here through the same libhdf5 via ctypes.  Skipped on a box without a loadable libhdf5."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from xgcm_amd import DataArray, Dataset, Grid
+from xgcm_amd import hdf5 as H
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+NC, NPZ = os.path.join(GOLD, "netcdf4_state.nc"), os.path.join(GOLD, "netcdf4_state.npz")
+needs_hdf5 = pytest.mark.skipif(not H.hdf5_available(), reason="no loadable libhdf5 on this box (XG_HDF5_LIB)")
+
+
+@pytest.fixture(params=["oracle-double", "host-abi", pytest.param("hip", marks=pytest.mark.gpu)])
+def tbackend(request, monkeypatch):
+    if request.param == "oracle-double":
+        from oracle import fake_device
+
+        fake_device.install(monkeypatch)
+    elif request.param == "host-abi":
+        import host_abi_device
+
+        host_abi_device.install(monkeypatch)
+    return request.param
+
+
+def _expected():
+    z = np.load(NPZ)
+    T = z["T"].copy()
+    T[T == -999.0] = np.nan          # xarray's mask_and_scale: _FillValue cells are NaN in what the reference computes on
+    S = z["S"].copy()
+    S[S == np.float32(1e20)] = np.nan
+    return z, T, S
+
+
+@needs_hdf5
+def test_the_file_opens_as_the_netcdf_library_laid_it_out():
+    z, T, S = _expected()
+    ds = H.open_netcdf4(NC)
+    assert sorted(ds.data_vars) == ["S", "T", "Tbe", "Z_bnds", "eta", "rho0"] and sorted(ds.coords) == ["XC", "YC", "Z", "iter", "time"]
+    assert ds.attrs["Conventions"] == "CF-1.8" and "_NCProperties" not in ds.attrs
+    for name in ("time", "Z", "YC", "XC"):
+        np.testing.assert_array_equal(ds[name].values, z["c_" + name])
+    assert ds["XC"].attrs == {"units": "degrees_east"}      # `_Netcdf4Dimid`, CLASS, NAME, REFERENCE_LIST stay inside
+    t = ds["T"]
+    assert isinstance(t.data, H.H5Array) and t.dims == ("time", "Z", "YC", "XC") and t.data.layout == "chunked"
+    assert t.chunks == ((1, 1, 1), (2, 2), (3, 3), (8, 8)) and t.dtype == np.float64
+    assert t.attrs == {"_FillValue": t.attrs["_FillValue"], "units": "degC", "long_name": "potential temperature"}
+    assert list(t.coords) == ["XC", "YC", "Z", "iter", "time"]            # `coordinates = "iter"` rides along `time`
+    np.testing.assert_array_equal(ds["iter"].values, z["iter"])
+    assert np.array_equal(np.asarray(t.data), T, equal_nan=True) and np.isnan(T).sum() == 3
+    assert np.array_equal(t.data[1:3, 1:4, 2:5, 3:11], T[1:3, 1:4, 2:5, 3:11], equal_nan=True)
+    assert t.data[:, 2:2].shape == (3, 0, 6, 16)
+    s = ds["S"]                                                            # contiguous on disk: one block unless asked otherwise
+    assert s.data.layout == "contiguous" and s.dtype == np.float32 and s.chunks == ((3,), (4,), (6,), (16,))
+    assert np.array_equal(np.asarray(s.data), S, equal_nan=True) and np.isnan(S).sum() == 1
+    be = ds["Tbe"]                                                         # big-endian + fletcher32 on disk: native out of libhdf5
+    assert be.dtype == np.float32 and be.data.dtype.isnative and np.array_equal(np.asarray(be.data), z["T"].astype("f4"), equal_nan=True)
+    assert ds["eta"].dtype == np.int16 and np.array_equal(np.asarray(ds["eta"].data), z["eta"])
+    assert ds["Z_bnds"].dims == ("Z", "nv") and "nv" not in ds.coords     # a dimension without a coordinate variable
+    assert np.array_equal(np.asarray(ds["Z_bnds"].data), z["Z_bnds"]) and float(ds["rho0"].values) == 1029.0
+    raw = H.H5Array(NC, "T", mask=False)
+    assert np.array_equal(np.asarray(raw), z["T"], equal_nan=True)
+    re = H.open_netcdf4(NC, chunks={"time": -1, "YC": 2})["S"]            # xarray's `chunks=`
+    assert re.chunks == ((3,), (4,), (2, 2, 2), (16,))
+
+
+@needs_hdf5
+def test_operators_walk_a_netcdf4_variable_hyperslab_by_hyperslab(tbackend):
+    z, T, S = _expected()
+    ds = H.open_netcdf4(NC)
+    NT, NZ, NY, NX = T.shape
+    gds = Dataset({}, {"XC": ("XC", z["c_XC"]), "XG": ("XG", z["c_XC"] - 1.0), "YC": ("YC", z["c_YC"]), "YG": ("YG", z["c_YC"] - 0.5),
+                       "Z": ("Z", z["c_Z"]), "Zl": ("Zl", z["c_Z"] - 5.0), "time": ("time", z["c_time"])})
+    grid = Grid(gds, coords={"X": {"center": "XC", "left": "XG"}, "Y": {"center": "YC", "left": "YG"}, "Z": {"center": "Z", "left": "Zl"}},
+                padding={"X": "periodic", "Y": "extend", "Z": "fill"}, autoparse_metadata=False)
+    tcoords = {"iter": ("time", z["iter"]), "time": ("time", z["c_time"]), "XC": ("XC", z["c_XC"]), "YC": ("YC", z["c_YC"]), "Z": ("Z", z["c_Z"])}
+    eager = DataArray(T, ("time", "Z", "YC", "XC"), coords=tcoords, name="T")
+    reads = []
+    orig = H.H5Array.__getitem__
+    H.H5Array.__getitem__ = lambda self, key: (reads.append((self.name, tuple((k.start, k.stop) for k in key))), orig(self, key))[1]
+    try:
+        got = grid.diff(ds["T"], "X")
+    finally:
+        H.H5Array.__getitem__ = orig
+    # blocks of the non-core dims, whole along X: 3 x 2 x 2 hyperslabs, each once (libhdf5 inflates the two chunks each crosses)
+    if tbackend == "oracle-double":  # (the double computes on the assembled array: one read of everything)
+        assert len(reads) == 1
+    else:
+        assert len(reads) == len(set(reads)) == 12 and all(r[1][3] == (0, NX) for r in reads)
+    want = grid.diff(eager, "X")
+    assert got.dims == want.dims and np.array_equal(np.asarray(got.values), np.asarray(want.values), equal_nan=True)
+    for call in (lambda v: grid.interp(v, "Y"), lambda v: grid.cumsum(v, "Z"), lambda v: grid.diff(v, "Z"), lambda v: grid.max(v, "X")):
+        g, w = call(ds["T"]), call(eager)
+        assert g.dims == w.dims and np.array_equal(np.asarray(g.values), np.asarray(w.values), equal_nan=True)
+    if tbackend != "oracle-double":
+        assert got.chunks == ds["T"].chunks          # the result in the file's own chunking
+    s_eager = DataArray(S, ("time", "Z", "YC", "XC"), name="S")  # float32, contiguous (one block), a missing_value cell
+    g, w = grid.diff(ds["S"], "Y"), grid.diff(s_eager, "Y")
+    assert g.dtype == np.float32 and np.array_equal(np.asarray(g.values), np.asarray(w.values), equal_nan=True)
+    e_eager = DataArray(z["eta"], ("time", "YC", "XC"), name="eta")  # int16 on disk: numpy's integer rules
+    g, w = grid.diff(ds["eta"], "X"), grid.diff(e_eager, "X")
+    assert g.dtype == w.dtype and np.array_equal(np.asarray(g.values), np.asarray(w.values))
+
+
+@needs_hdf5
+def test_concurrent_hyperslab_reads_hold_the_library_lock():
+    z, T, S = _expected()
+    arr = H.open_netcdf4(NC)["T"].data
+    out, errs = {}, []
+
+    def work(k):
+        try:
+            for _ in range(20):
+                out[k] = arr[k % 3:k % 3 + 1, :, :, :]
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs and all(np.array_equal(out[k], T[k % 3:k % 3 + 1], equal_nan=True) for k in range(8))
+
+
+@needs_hdf5
+def test_what_is_not_read_says_so(tmp_path):
+    with pytest.raises(OSError, match="not an HDF5"):
+        H.open_netcdf4(os.path.join(GOLD, "kats.json"))
+    with pytest.raises(KeyError, match="no such dataset"):
+        H.H5Array(NC, "nope")
+    with pytest.raises(IndexError, match="unit-step"):
+        H.H5Array(NC, "T")[::2]
+
+
+def test_without_a_libhdf5_every_entry_point_names_the_library(monkeypatch):
+    monkeypatch.setattr(H, "_LIB", [None])
+    assert not H.hdf5_available()
+    with pytest.raises(NotImplementedError, match="libhdf5"):
+        H.open_netcdf4(NC)
+    with pytest.raises(NotImplementedError, match="libhdf5"):
+        H.H5Array(NC, "T")

@@ -1,26 +1,30 @@
 """Block readers for what MITgcm writes, without xarray ("on-disk formats").
 
-The reference never opens a file itself: xarray's backends decode NetCDF / MDS into (dask-chunked) arrays and
-`apply_ufunc(dask="parallelized")` walks the chunks (`xgcm/grid.py:786-818`).  xarray, dask and netCDF4 are not in this
-image, so the two formats a MITgcm run produces are read here directly, as ITERABLES OF RECORD BLOCKS -- the shape
-`xgcm_amd.streaming.stream_blocks / iter_stream` take -- straight from a memory map of the file:
+The reference never opens a file itself: xarray's backends decode NetCDF / zarr / MDS into (dask-chunked) arrays and
+`apply_ufunc(dask="parallelized")` walks the chunks (`xgcm/grid.py:786-818`).  xarray and netCDF4-python are not in this
+image, so the formats a model run is kept in are read here directly:
 
 * MDS (`<prefix>.meta` + `<prefix>.data`): one text header, one raw big-endian array `(records, [Nr,] Ny, Nx)`;
-* NetCDF-3 classic / 64-bit offset (what `pkg/mnc` writes), through `scipy.io.netcdf_file(mmap=True)`;
+* NetCDF-3 classic / 64-bit offset (what `pkg/mnc` writes), through `scipy.io.netcdf_file(mmap=True)`
+  -- both as ITERABLES OF RECORD BLOCKS, the shape `xgcm_amd.streaming.stream_blocks / iter_stream` take, straight from a
+  memory map of the file;
 * zarr format 2 directory stores (what `xarray.Dataset.to_zarr` writes; round 6), as CHUNKED CONTAINERS the operators walk
-  block by block (`ZarrArray`, `open_zarr`, `write_zarr`; xgcm_amd.chunked) -- codecs none / zlib / gzip / bz2 / lzma.
+  block by block (`ZarrArray`, `open_zarr`, `write_zarr`; xgcm_amd.chunked) -- codecs none / blosc (zarr's default) / zstd /
+  lz4 / zlib / gzip / bz2 / lzma;
+* NetCDF-4 / HDF5 (`open_netcdf4`, `H5Array`: xgcm_amd.hdf5), chunked containers over libhdf5 hyperslab reads -- where a
+  libhdf5 can be loaded (the image's Anaconda tree has one; the library is never bundled or guessed at).
 
-Both store big-endian numbers.  The blocks are handed over AS STORED: `iter_stream` copies the raw bytes into page-locked
-memory, sends them over PCIe and reverses the byte order on the GPU (`xg_bswap`), so no host core touches the values.
-`MdsWriter` is the matching sink.  Nothing here computes; there is no CPU path to fall back to.
+MDS and NetCDF-3 store big-endian numbers.  Their blocks are handed over AS STORED: `iter_stream` copies the raw bytes into
+page-locked memory, sends them over PCIe and reverses the byte order on the GPU (`xg_bswap`), so no host core touches the
+values.  `MdsWriter` is the matching sink.  Nothing here computes; there is no CPU path to fall back to.
 
 Tiled MDS output (`<prefix>.001.001.data`, one file per tile: what a run without `globalFiles` / `useSingleCpuIO` leaves) is
 assembled by `mds_tiled_blocks`: every tile's records are copied, as stored, into their place in a global block -- a strided
 copy on the host, the one pass over the bytes that the staging copy of `iter_stream` would make anyway.
 
-Not covered (say so loudly rather than guess): NetCDF-4 / HDF5, zarr stores compressed with blosc / zstd / lz4 (libraries the
-image lacks: refused by codec name), packed variables (`scale_factor` / `add_offset`) --
-`netcdf_blocks` refuses those; tiles that overlap or leave gaps are refused.
+Not covered (say so loudly rather than guess): zarr filters and format 3, blosc's own `blosclz` codec without a libblosc,
+packed variables (`scale_factor` / `add_offset`: `netcdf_blocks` and `H5Array` refuse those), HDF5 types other than integers
+and floats; tiles that overlap or leave gaps are refused.
 """
 
 from __future__ import annotations
@@ -32,7 +36,9 @@ from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 import numpy as np
 
 __all__ = ["read_mds_meta", "mds_blocks", "mds_tile_files", "mds_tiled_blocks", "MdsWriter", "write_mds", "write_mds_tiled",
-           "netcdf_blocks", "netcdf_variable_info", "ZarrArray", "open_zarr", "write_zarr"]
+           "netcdf_blocks", "netcdf_variable_info", "ZarrArray", "open_zarr", "write_zarr", "H5Array", "open_netcdf4"]
+
+from .hdf5 import H5Array, open_netcdf4  # noqa: E402,F401 -- NetCDF-4 / HDF5: its own module (ctypes over libhdf5)
 
 _PREC = {"float32": ">f4", "float64": ">f8", "real*4": ">f4", "real*8": ">f8"}
 
