@@ -54,8 +54,8 @@ def test_files_listed_in_the_profiles_index_exist():
 
 def test_design_document_stays_readable():
     # 40 KB through round 4; round 5 added two subsystems it has to state (deferred results, where results are allocated)
-    # and two pins (the reference's own suite, differential fuzzing)
-    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 55 * 1024
+    # and two pins (the reference's own suite, differential fuzzing); round 6: chunked inputs, the graded pool, on-disk formats
+    assert os.path.getsize(os.path.join(ROOT, "DESIGN.md")) <= 58 * 1024
     tools = [f for f in os.listdir(os.path.join(ROOT, "tools")) if not f.startswith("__")]
     assert len(tools) <= 32, tools
 
