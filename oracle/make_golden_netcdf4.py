@@ -76,6 +76,10 @@ def main():
         var("iter", it, ("time",), chunks=(2,), maxshape=(None,))
         var("Z_bnds", bnds, ("Z", "nv"))
         f.create_dataset("rho0", data=np.float64(1029.0))               # a scalar variable
+        v = var("station", np.array([b"alpha", b"beta", b"gamma"], dtype="S8"), ("time",))  # NC_CHAR-like: not a numeric field
+        v = var("packed", (eta // 2).astype("i2"), ("time", "YC", "XC"))  # CF packing: refused by name
+        v.attrs["scale_factor"] = np.float32(0.01)
+        v.attrs["add_offset"] = np.float32(10.0)
     np.savez_compressed(NPZ, T=T, S=S, eta=eta, Z_bnds=bnds, iter=it, **{"c_" + k: v for k, v in coords.items()})
     print(f"{NC}: {os.path.getsize(NC)} bytes; {NPZ}: {os.path.getsize(NPZ)} bytes; h5py {h5py.__version__}, HDF5 {h5py.version.hdf5_version}")
 

@@ -43,7 +43,10 @@ def _expected():
 @needs_hdf5
 def test_the_file_opens_as_the_netcdf_library_laid_it_out():
     z, T, S = _expected()
-    ds = H.open_netcdf4(NC)
+    with pytest.warns(UserWarning) as rec:  # a string variable and a packed one sit next to the fields: left out, by name
+        ds = H.open_netcdf4(NC)
+    said = " ".join(str(w.message) for w in rec)
+    assert "station" in said and "string" in said and "packed" in said and "scale_factor" in said
     assert sorted(ds.data_vars) == ["S", "T", "Tbe", "Z_bnds", "eta", "rho0"] and sorted(ds.coords) == ["XC", "YC", "Z", "iter", "time"]
     assert ds.attrs["Conventions"] == "CF-1.8" and "_NCProperties" not in ds.attrs
     for name in ("time", "Z", "YC", "XC"):
@@ -137,6 +140,10 @@ def test_what_is_not_read_says_so(tmp_path):
         H.H5Array(NC, "nope")
     with pytest.raises(IndexError, match="unit-step"):
         H.H5Array(NC, "T")[::2]
+    with pytest.raises(NotImplementedError, match="packed variable"):
+        H.H5Array(NC, "packed")
+    with pytest.raises(NotImplementedError, match="type class string"):
+        H.H5Array(NC, "station")
 
 
 def test_without_a_libhdf5_every_entry_point_names_the_library(monkeypatch):

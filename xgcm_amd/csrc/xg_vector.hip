@@ -135,6 +135,23 @@ __device__ __forceinline__ int64_t area_outer_off(const AreaIdx& ai, int64_t o) 
 // ZK > 1 (z-banded launches only): the wave carries the same rows of ZK consecutive levels and loads the area
 // rows once for all of them -- L2-resident metric rows still compete with the field loads for the CU's
 // outstanding requests (measured on the 1-D kernels: derivative along X 74.8 -> 77.3 % with shared rows).
+// SEG rows of a metric / area plane for a V-wide lane, row r at m[off + r * sy] (short tails repeat the last row), elements
+// `sx` apart.  The FORM of the load -- one aligned vector, or element by element -- is the HOST's decision (`vec`: unit step,
+// base, row step and every outer stride keep the vector's alignment -- `plane_vec_ok`), one scalar branch per plane: `ldm`'s
+// own test is a lane-divergent branch per load, a row loop with such loads in it issues them one by one, each after the wait
+// for the one before (the gradient: four round trips to the L2 in a row after the field had arrived), and a test made in the
+// kernel joins its paths in front of the loads, where the wave then waits for everything in flight.
+template <typename T, int SEG>
+__device__ __forceinline__ void load_rows(T (&dst)[SEG], const real* __restrict__ m, int64_t off, int64_t sy, int64_t sx, int64_t nrow, bool vec) {
+  if (sizeof(T) > sizeof(real) && vec) {
+#pragma unroll
+    for (int s_ = 0; s_ < SEG; ++s_) dst[s_] = *reinterpret_cast<const T*>(m + off + ((s_ < nrow) ? s_ : nrow - 1) * sy);
+  } else {
+#pragma unroll
+    for (int s_ = 0; s_ < SEG; ++s_) dst[s_] = ldm<T>(m, off + ((s_ < nrow) ? s_ : nrow - 1) * sy, sx);
+  }
+}
+
 __device__ __forceinline__ real vec_last(dv v) { return v[NV - 1]; }
 __device__ __forceinline__ real vec_last(real v) { return v; }
 
@@ -198,12 +215,13 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
       else uu[kz][s_ + 1] = *reinterpret_cast<const T*>(pu + (j0 + jr) * nx);
       if (V > 1 && (ntl & 1)) {
         // the v row is read by this wave only: non-temporal, and the value left of a lane's vector comes from
-        // the lane before it (lanes that left at the row's end are the highest ones); lane 0 loads its own
+        // the lane before it (lanes that left at the row's end are the highest ones); lane 0 loads its own.  The
+        // shuffles come AFTER every load of the task has been issued (below): taken here, each one made the wave wait for
+        // its row before the next row's loads went out -- four round trips to the memory one after the other
         vv[kz][s_] = __builtin_nontemporal_load(reinterpret_cast<const T*>(pv + jr * nx + i0));
-        real left = __shfl_up(vec_last(vv[kz][s_]), 1, WAVE);
+        vl[kz][s_] = real(0);
         if ((threadIdx.x & 63) == 0 || edge)
-          left = (edge && bc_x == XG_BC_HALO) ? halo_x[ok * ny + j0 + jr] : pv[jr * nx + nidx];
-        vl[kz][s_] = left;
+          vl[kz][s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[ok * ny + j0 + jr] : pv[jr * nx + nidx];
       } else {
         vv[kz][s_] = *reinterpret_cast<const T*>(pv + jr * nx + i0);
         vl[kz][s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[ok * ny + j0 + jr]  // pre-gathered column left of the first: (outer, Y, 1)
@@ -211,11 +229,16 @@ __global__ __launch_bounds__(BLOCK) void k_vorticity(
       }
     }
   }
-  if (HAS_AREA) {
+  if (HAS_AREA) load_rows<T, SEG>(ar, area, a_base + j0 * a_sy + i0 * a_sx, a_sy, a_sx, nrow, (ntl & 4) != 0);
+  if (V > 1 && (ntl & 1)) {
+    const bool own = (threadIdx.x & 63) == 0 || edge;
 #pragma unroll
-    for (int s_ = 0; s_ < SEG; ++s_) {
-      const int64_t jr = (s_ < nrow) ? s_ : nrow - 1;
-      ar[s_] = ldm<T>(area, a_base + (j0 + jr) * a_sy + i0 * a_sx, a_sx);
+    for (int kz = 0; kz < ZK; ++kz) {
+#pragma unroll
+      for (int s_ = 0; s_ < SEG; ++s_) {
+        const real left = from_lane_below(vec_last(vv[kz][s_]));  // DPP wave_shr:1 (lane 0 reads 0 and is `own`)
+        if (!own) vl[kz][s_] = left;
+      }
     }
   }
 #pragma unroll
@@ -301,13 +324,7 @@ __global__ __launch_bounds__(BLOCK) void k_divergence(
       vv[kz][SEG] = *reinterpret_cast<const T*>(src);
     }
   }
-  if (HAS_AREA) {
-#pragma unroll
-    for (int s_ = 0; s_ < SEG; ++s_) {
-      const int64_t jr = (s_ < nrow) ? s_ : nrow - 1;
-      ar[s_] = ldm<T>(area, a_base + (j0 + jr) * a_sy + i0 * a_sx, a_sx);
-    }
-  }
+  if (HAS_AREA) load_rows<T, SEG>(ar, area, a_base + j0 * a_sy + i0 * a_sx, a_sy, a_sx, nrow, (ntl & 4) != 0);
 #pragma unroll
   for (int kz = 0; kz < ZK; ++kz) {
     if (kz >= nk) break;
@@ -388,6 +405,11 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
   }
   const int64_t mxb = (MODE == 0 && mx) ? area_outer_off(aix, o) : 0;
   const int64_t myb = (MODE == 0 && my) ? area_outer_off(aiy, o) : 0;
+  // (round 6: the metric rows / the u and v rows of all SEG rows loaded HERE, behind the field's loads and before anything
+  // waits, in a host-decided vector form -- in the loop below each of them goes out only after the row before has been
+  // stored, four round trips to the L2 one after the other -- made the gradient 9 % SLOWER (2.74 -> 3.00 ms, two process
+  // pairs on one box) and left the flux where it was: what the row-by-row order has is stores leaving while later loads
+  // arrive, the lesson of the scans' batch form.  profiles/r06_kernels/r06bb_ab_loads_first_vector_kernels.log)
 #pragma unroll
   for (int s_ = 0; s_ < SEG; ++s_) {
     if (s_ < nrow) {
@@ -506,6 +528,15 @@ int XG_FN(xg_binary)(int op, const real* a, const int64_t* a_strides, const real
 }
 
 #ifndef XG_INT
+// may every lane of a V-wide kernel load its piece of a metric / area plane as ONE aligned vector in every row and at
+// every outer index?  (lanes start at multiples of NV along X)
+static bool plane_vec_ok(const real* m, const AreaIdx& ai, int64_t sy, int64_t sx) {
+  if (!m || sx != 1 || sy % NV != 0 || !aligned16(m)) return false;
+  for (int d = 0; d < ai.n; ++d)
+    if (ai.stride[d] % NV != 0) return false;
+  return true;
+}
+
 static int curl_div_impl(bool div, const real* u, const real* v, const real* area, const int64_t* area_strides,
                          real* out, const int64_t* shape, int ndim, int bc_x, real fill_x, int bc_y, real fill_y,
                          void* stream, const real* halo_x = nullptr, const real* halo_y = nullptr) {
@@ -551,7 +582,8 @@ static int curl_div_impl(bool div, const real* u, const real* v, const real* are
   const u64 nseg_rows = (u64)((ny + SEG - 1) / SEG);
   hipStream_t st = (hipStream_t)stream;
   const bool nts = tune().nt_store;
-  const int vnt = tune().nt_load ? tune().vec_nt : 0;  // bit 0: v rows non-temporal (neighbour by lane shuffle), bit 1: inner u rows
+  // bit 0: v rows non-temporal (neighbour by lane shuffle), bit 1: inner u rows, bit 2: the area rows are aligned vectors
+  const int vnt = (tune().nt_load ? (tune().vec_nt & 3) : 0) | ((V > 1 && plane_vec_ok(area, ai, a_sy, a_sx)) ? 4 : 0);
   const u64 nseg = nseg_rows;
   const u64 per_outer = ntile * nseg;
   if (per_outer > MAX_ITEMS) return fail(XG_ERR_UNSUPPORTED, "extent too large for the vorticity kernel");

@@ -372,7 +372,16 @@ def open_netcdf4(path: str, chunks: Optional[Dict[str, int]] = None, mask: bool 
                 kinds[n] = lib.H5Iget_type(oid)  # H5I_GROUP 2, H5I_DATASET 5
                 lib.H5Oclose(oid)
         gattrs = {k: v for k, v in _attrs(lib, f.id).items() if k not in _INTERNAL_ATTRS}
-    arrays = {n: H5Array(f, n, mask=mask) for n in names if kinds.get(n) == 5}
+    arrays = {}
+    for n in names:
+        if kinds.get(n) != 5:
+            continue  # (sub-groups are not walked: the classic data model keeps everything in the root group)
+        try:
+            arrays[n] = H5Array(f, n, mask=mask)
+        except NotImplementedError as exc:  # a string / compound / packed variable next to the fields: left out by name
+            import warnings
+
+            warnings.warn(f"{exc}: variable left out of the dataset", stacklevel=2)
     arrays = {n: a for n, a in arrays.items() if not a.scale_only}  # a bare dimension: a size, no values
     for n, a in arrays.items():
         if a.dims is None and a.ndim:
