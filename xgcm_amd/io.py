@@ -360,11 +360,15 @@ def _clib(name: str):
         if lib is not None:
             c = ctypes
             if name == "zstd":
-                lib.ZSTD_decompress.restype, lib.ZSTD_decompress.argtypes = c.c_size_t, [c.c_void_p, c.c_size_t, c.c_char_p, c.c_size_t]
+                lib.ZSTD_decompress.restype, lib.ZSTD_decompress.argtypes = c.c_size_t, [c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t]
                 lib.ZSTD_getFrameContentSize.restype, lib.ZSTD_getFrameContentSize.argtypes = c.c_ulonglong, [c.c_char_p, c.c_size_t]
                 lib.ZSTD_isError.restype, lib.ZSTD_isError.argtypes = c.c_uint, [c.c_size_t]
+                lib.ZSTD_createDCtx.restype, lib.ZSTD_createDCtx.argtypes = c.c_void_p, []
+                lib.ZSTD_freeDCtx.restype, lib.ZSTD_freeDCtx.argtypes = c.c_size_t, [c.c_void_p]
+                lib.ZSTD_decompressDCtx.restype = c.c_size_t
+                lib.ZSTD_decompressDCtx.argtypes = [c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p, c.c_size_t]
             elif name == "lz4":
-                lib.LZ4_decompress_safe.restype, lib.LZ4_decompress_safe.argtypes = c.c_int, [c.c_char_p, c.c_void_p, c.c_int, c.c_int]
+                lib.LZ4_decompress_safe.restype, lib.LZ4_decompress_safe.argtypes = c.c_int, [c.c_void_p, c.c_void_p, c.c_int, c.c_int]
             elif name == "blosc":
                 lib.blosc_decompress_ctx.restype, lib.blosc_decompress_ctx.argtypes = c.c_int, [c.c_char_p, c.c_void_p, c.c_size_t, c.c_int]
         _CLIBS[name] = lib
@@ -379,39 +383,59 @@ def _need(name: str, what: str):
 
 
 def _zstd_decode(raw: bytes, nbytes: Optional[int] = None) -> bytes:
-    import ctypes
-
     lib = _need("zstd", "zarr compressor 'zstd'")
     if nbytes is None:
         nbytes = lib.ZSTD_getFrameContentSize(raw, len(raw))
         if nbytes >= 2 ** 63:  # ZSTD_CONTENTSIZE_UNKNOWN / _ERROR: numcodecs writes one frame with its size
             raise ValueError("zstd chunk without a content size in its frame header")
-    dst = ctypes.create_string_buffer(max(1, int(nbytes)))
-    n = lib.ZSTD_decompress(dst, int(nbytes), raw, len(raw))
-    if lib.ZSTD_isError(n) or n != nbytes:
-        raise ValueError("corrupt zstd stream in a zarr chunk")
-    return dst.raw[:n]
+    out = np.empty(max(1, int(nbytes)), dtype="u1")
+    _inner_decode("zstd", np.frombuffer(raw, dtype="u1").ctypes.data if raw else 0, len(raw), out.ctypes.data, int(nbytes))
+    return out[:nbytes].data  # (a buffer, not a copy of one: numpy.frombuffer takes it as it is)
 
 
 def _lz4_block(raw: bytes, nbytes: int) -> bytes:
+    out = np.empty(max(1, nbytes), dtype="u1")
+    _inner_decode("lz4", np.frombuffer(raw, dtype="u1").ctypes.data if raw else 0, len(raw), out.ctypes.data, nbytes)
+    return out[:nbytes].data
+
+
+def _inner_decode(fmt: str, src: int, nsrc: int, dst: int, ndst: int, dctx: Optional[int] = None) -> None:
+    """one lz4 block / zstd frame / zlib stream at address `src` into `ndst` bytes at address `dst` (no copies on the way);
+    `dctx`: a zstd decompression context to reuse (a blosc chunk is thousands of small frames: one context for all of them)"""
     import ctypes
 
-    lib = _need("lz4", "zarr compressor 'lz4'")
-    dst = ctypes.create_string_buffer(max(1, nbytes))
-    n = lib.LZ4_decompress_safe(raw, dst, len(raw), nbytes)
-    if n != nbytes:
-        raise ValueError("corrupt lz4 stream in a zarr chunk")
-    return dst.raw[:n]
+    if fmt == "lz4":
+        if _need("lz4", "lz4 streams").LZ4_decompress_safe(ctypes.c_void_p(src), ctypes.c_void_p(dst), nsrc, ndst) != ndst:
+            raise ValueError("corrupt lz4 stream in a zarr chunk")
+    elif fmt == "zstd":
+        lib = _need("zstd", "zstd streams")
+        if dctx:
+            n = lib.ZSTD_decompressDCtx(ctypes.c_void_p(dctx), ctypes.c_void_p(dst), ndst, ctypes.c_void_p(src), nsrc)
+        else:
+            n = lib.ZSTD_decompress(ctypes.c_void_p(dst), ndst, ctypes.c_void_p(src), nsrc)
+        if lib.ZSTD_isError(n) or n != ndst:
+            raise ValueError("corrupt zstd stream in a zarr chunk")
+    else:
+        import zlib
+
+        got = zlib.decompress(ctypes.string_at(src, nsrc))
+        if len(got) != ndst:
+            raise ValueError("corrupt zlib stream in a zarr chunk")
+        ctypes.memmove(dst, got, ndst)
 
 
 _BLOSC_FORMATS = {0: "blosclz", 1: "lz4", 2: "snappy", 3: "zlib", 4: "zstd"}  # header flags bits 5-7 (lz4hc shares lz4's format)
 
 
-def _blosc_decode(raw: bytes) -> bytes:
+def _blosc_decode(raw: bytes, use_lib: bool = True) -> bytes:
     """One c-blosc 1 buffer -> the chunk's bytes.  Header: version, versionlz, flags (1 byte shuffle, 2 plain copy, 4 bit shuffle,
     16 blocks not split, bits 5-7 the inner format), typesize, then uint32 LE nbytes / blocksize / cbytes; int32 block starts;
     a block is `typesize` streams (one per byte position of the shuffled elements: when split) or one, each an int32 length
-    followed by the inner codec's stream -- or by the plain bytes when the length equals the stream's decoded size."""
+    followed by the inner codec's stream -- or by the plain bytes when the length equals the stream's decoded size.
+
+    Where a libblosc loads, it does the work (about 2 GB/s on one core against 0.6 GB/s of the walk below: 345 MB of a smooth
+    float64 field, lz4 or zstd + shuffle, page faults of the fresh buffer included); the walk serves every box that has
+    liblz4 / libzstd only.  The golden chunks pin both."""
     if len(raw) < 16:
         raise ValueError("blosc chunk shorter than its header")
     flags, typesize = raw[2], raw[3]
@@ -421,61 +445,71 @@ def _blosc_decode(raw: bytes) -> bytes:
     if flags & 2:  # stored as it was
         return raw[16:16 + nbytes]
     fmt = _BLOSC_FORMATS.get(flags >> 5)
-    if fmt in ("blosclz", "snappy", None):  # no decoder of ours: the library itself, where there is one
-        import ctypes
-
-        lib = _clib("blosc")
-        if lib is None:
-            raise NotImplementedError(f"blosc chunk with inner codec {fmt!r}: served are lz4 / lz4hc / zstd / zlib (libblosc, which "
-                                      "has the others, was not found; XG_BLOSC_LIB names one)")
-        dst = ctypes.create_string_buffer(max(1, nbytes))
-        if lib.blosc_decompress_ctx(raw, dst, nbytes, 1) != nbytes:
+    lib = _clib("blosc") if use_lib or fmt in ("blosclz", "snappy", None) else None
+    if lib is not None:
+        out = np.empty(max(1, nbytes), dtype="u1")
+        if lib.blosc_decompress_ctx(raw, out.ctypes.data, nbytes, 1) != nbytes:
             raise ValueError("corrupt blosc chunk")
-        return dst.raw[:nbytes]
+        return out[:nbytes].data
+    if fmt in ("blosclz", "snappy", None):  # no decoder of ours: the library itself, where there is one
+        raise NotImplementedError(f"blosc chunk with inner codec {fmt!r}: served are lz4 / lz4hc / zstd / zlib (libblosc, which "
+                                  "has the others, was not found; XG_BLOSC_LIB names one)")
     if nbytes == 0:
         return b""
+    if blocksize <= 0 or typesize <= 0:
+        raise ValueError("corrupt blosc chunk (header)")
     nblocks = (nbytes + blocksize - 1) // blocksize
+    if 16 + 4 * nblocks > len(raw):
+        raise ValueError("corrupt blosc chunk (block starts)")
+    src = np.frombuffer(raw, dtype="u1")
     starts = np.frombuffer(raw, dtype="<i4", count=nblocks, offset=16)
-    out = bytearray(nbytes)
+    out, tmp = np.empty(nbytes, dtype="u1"), np.empty(blocksize, dtype="u1")
+    shuffled = (flags & 1 and typesize > 1) or flags & 4
+    dctx = _need("zstd", "blosc chunks with zstd inside").ZSTD_createDCtx() if fmt == "zstd" else None
+    try:
+        _blosc_walk(raw, src, starts, out, tmp, fmt, flags, typesize, nbytes, blocksize, shuffled, dctx)
+    finally:
+        if dctx:
+            _clib("zstd").ZSTD_freeDCtx(dctx)
+    return out.data
+
+
+def _blosc_walk(raw, src, starts, out, tmp, fmt, flags, typesize, nbytes, blocksize, shuffled, dctx) -> None:
+    nblocks = len(starts)
     for b in range(nblocks):
         bsize = min(blocksize, nbytes - b * blocksize)
         leftover = bsize != blocksize
         split = not (flags & 16) and typesize <= 16 and blocksize // typesize >= 128 and not leftover
         nstreams = typesize if split else 1
         per = bsize // nstreams
-        pos, parts = int(starts[b]), []
-        for _ in range(nstreams):
+        into = tmp if shuffled else out[b * blocksize:b * blocksize + bsize]  # (unshuffled blocks decode in place)
+        pos = int(starts[b])
+        for k in range(nstreams):
+            if pos < 0 or pos + 4 > len(raw):
+                raise ValueError("corrupt blosc chunk (stream start)")
             clen = int.from_bytes(raw[pos:pos + 4], "little", signed=True)
             pos += 4
             if clen < 0 or pos + clen > len(raw):
                 raise ValueError("corrupt blosc chunk (stream length)")
-            piece = raw[pos:pos + clen]
-            pos += clen
             if clen == per:
-                parts.append(piece)
-            elif fmt == "lz4":
-                parts.append(_lz4_block(piece, per))
-            elif fmt == "zstd":
-                parts.append(_zstd_decode(piece, per))
+                into[k * per:(k + 1) * per] = src[pos:pos + clen]
             else:
-                import zlib
-
-                parts.append(zlib.decompress(piece))
-        blk = b"".join(parts)
-        if len(blk) != bsize:
-            raise ValueError("corrupt blosc chunk (block size)")
+                _inner_decode(fmt, src.ctypes.data + pos, clen, into.ctypes.data + k * per, per, dctx)
+            pos += clen
+        if not shuffled:
+            continue
+        dst = out[b * blocksize:b * blocksize + bsize]
         nel = bsize // typesize
         if flags & 1 and typesize > 1:  # byte shuffle: byte j of every element, then byte j + 1 ...; trailing bytes as they are
-            body = np.frombuffer(blk, dtype="u1", count=nel * typesize).reshape(typesize, nel).T.tobytes()
-            blk = body + blk[nel * typesize:]
-        elif flags & 4 and nel % 8 == 0 and nel:  # bit shuffle (bitshuffle's element transpose): row (j, k) holds bit k of byte
-            # j of every element, 8 elements to a byte; c-blosc leaves a block whose element count is no multiple of 8 as it is
-            rows = np.frombuffer(blk, dtype="u1", count=nel * typesize).reshape(typesize * 8, nel // 8)
-            bits = np.unpackbits(rows, axis=1, bitorder="little")               # (typesize * 8, nel): bit (j, k) of element i
-            elems = np.packbits(bits.T.reshape(nel, typesize, 8), axis=2, bitorder="little")
-            blk = elems.tobytes() + blk[nel * typesize:]
-        out[b * blocksize:b * blocksize + bsize] = blk
-    return bytes(out)
+            dst[:nel * typesize].reshape(nel, typesize)[...] = tmp[:nel * typesize].reshape(typesize, nel).T
+            dst[nel * typesize:] = tmp[nel * typesize:bsize]
+        elif nel % 8 == 0 and nel:  # bit shuffle (bitshuffle's element transpose): row (j, k) holds bit k of byte j of every
+            # element, 8 elements to a byte; c-blosc leaves a block whose element count is no multiple of 8 as it is
+            bits = np.unpackbits(tmp[:nel * typesize].reshape(typesize * 8, nel // 8), axis=1, bitorder="little")
+            dst[:nel * typesize] = np.packbits(bits.T.reshape(nel, typesize, 8), axis=2, bitorder="little").reshape(-1)
+            dst[nel * typesize:] = tmp[nel * typesize:bsize]
+        else:
+            dst[...] = tmp[:bsize]
 
 
 def _zarr_decode(raw: bytes, codec: Optional[dict]) -> bytes:
