@@ -90,9 +90,19 @@ def main():
         "vort": (lambda: D.vorticity(U, V, dx, "fill", "fill"), 24 + 8 / nz),
         "divg": (lambda: D.divergence(U, V, dx, "periodic", "extend"), 24 + 8 / nz),
         "grad": (lambda: D.gradient(T, "periodic", "extend", 0.0, 0.0, dx, dx2), 24 + 16 / nz),
+        "grad0": (lambda: D.gradient(T, "periodic", "extend", 0.0, 0.0, None, None), 24),  # one stream in, two out, no metric: the shape's ceiling
+        "grad1": (lambda: D.gradient(T, "periodic", "extend", 0.0, 0.0, dx, None), 24 + 8 / nz),
+        "grad_same": (lambda: D.gradient(T, "periodic", "extend", 0.0, 0.0, dx, dx), 24 + 8 / nz),      # two metric loads per row, ONE plane
+        "grad_off": (lambda: D.gradient(T, "periodic", "extend", 0.0, 0.0, dx, dx2_off), 24 + 16 / nz),  # the second plane 2 KiB + 256 B further on
         "flux": (lambda: D.flux(U, V, T, "periodic", "extend"), 40),
     }
     cases = a.cases.split(",")
+    dx2_off = None
+    if "grad_off" in cases:
+        pad = (2048 + 256) // dx2.element_size()
+        big = torch.empty(ny * nx + pad, dtype=dx2.dtype, device="cuda")
+        dx2_off = big[pad:].view(1, ny, nx)
+        dx2_off.copy_(dx2)
     T2 = D.synthetic((nz, ny, nx), 9, 0, 1000.0, 1000.0) if ("mulTT" in cases or "dY3" in cases) else None
     dy1 = D.synthetic((1, ny, 1), 35, 0, 1000.0, 1000.0)
     T3 = D.synthetic((nz, ny, nx), 10, 0, 1000.0, 1000.0) if "sumYw3" in cases else None

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
     real* __restrict__ out_y, int64_t o0, u32 nouter, u32 nblk, int64_t ny, int64_t nx, FastDiv ntile, FastDiv nseg,
     int bc_x, real fill_x, int bc_y, real fill_y, const real* __restrict__ mx, AreaIdx aix, int64_t mx_sy,
     int64_t mx_sx, const real* __restrict__ my, AreaIdx aiy, int64_t my_sy, int64_t my_sx,
-    const real* __restrict__ halo_x, const real* __restrict__ halo_y, ZBand zb) {
+    const real* __restrict__ halo_x, const real* __restrict__ halo_y, ZBand zb, int ntl) {
   typedef typename VecT<V>::type T;
   const u32 pb = (nblk + 7) >> 3;
   const u32 lb = (blockIdx.x & 7) * pb + (blockIdx.x >> 3);
@@ -396,12 +396,32 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
     const T t = *reinterpret_cast<const T*>(src);
     aa[0] = f ? splat<T>(fill_y) : t;
   }
+  // `ntl` bit 0 (vector lanes): rows the next segment does not need again are loaded non-temporally and the value left of a
+  // lane's vector comes from the lane before it (DPP, after the loads) instead of an 8-byte load over the same cache lines --
+  // K7's scheme.  Gradient without metrics 2.505 -> 2.401 ms (0.776 -> 0.810 of 8 TB/s), with one / two metric planes +1 %
+  // (profiles/r06_kernels/r06be_ab_pair_nt.log).  What the metrics cost is their DIVISIONS, not their planes: none 0.805, one
+  // 0.749, two 0.675 -- and the same plane passed twice 0.681, a second plane at shifted addresses 0.681 (r06bf_ab_grad_planes.log)
+  const bool shl = V > 1 && (ntl & 1);
+  const bool own = (threadIdx.x & 63) == 0 || edge;
 #pragma unroll
   for (int s_ = 0; s_ < SEG; ++s_) {
     const int64_t jr = j0 + ((s_ < nrow) ? s_ : nrow - 1);
-    aa[s_ + 1] = *reinterpret_cast<const T*>(pa + jr * nx);
-    al[s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[o * ny + jr]  // pre-gathered column left of the first: (outer, Y, 1)
-                                          : a[base + jr * nx + nidx];
+    if (shl && s_ + 1 < SEG) aa[s_ + 1] = __builtin_nontemporal_load(reinterpret_cast<const T*>(pa + jr * nx));
+    else aa[s_ + 1] = *reinterpret_cast<const T*>(pa + jr * nx);
+    if (shl) {
+      al[s_] = real(0);
+      if (own) al[s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[o * ny + jr] : a[base + jr * nx + nidx];
+    } else {
+      al[s_] = (edge && bc_x == XG_BC_HALO) ? halo_x[o * ny + jr]  // pre-gathered column left of the first: (outer, Y, 1)
+                                            : a[base + jr * nx + nidx];
+    }
+  }
+  if (shl) {
+#pragma unroll
+    for (int s_ = 0; s_ < SEG; ++s_) {
+      const real left = from_lane_below(vec_last(aa[s_ + 1]));
+      if (!own) al[s_] = left;
+    }
   }
   const int64_t mxb = (MODE == 0 && mx) ? area_outer_off(aix, o) : 0;
   const int64_t myb = (MODE == 0 && my) ? area_outer_off(aiy, o) : 0;
@@ -422,6 +442,7 @@ __global__ __launch_bounds__(BLOCK) void k_pair2d(
         if (mx) rx = rx / ldm<T>(mx, mxb + j * mx_sy + i0 * mx_sx, mx_sx);
         if (my) ry = ry / ldm<T>(my, myb + j * my_sy + i0 * my_sx, my_sx);
       } else {
+        // (u and v are read once; loading them non-temporally changed nothing: 4.234 / 4.262 ms, r06be_ab_pair_nt.log)
         const T uu = *reinterpret_cast<const T*>(u + base + j * nx + i0);
         const T vv = *reinterpret_cast<const T*>(v + base + j * nx + i0);
         rx = uu * interp_left_of(aa[s_ + 1], left);
@@ -712,6 +733,7 @@ static int pair2d_impl(int mode, const real* a, const real* u, const real* v, re
   const u64 outer_per = MAX_ITEMS / per_outer;
   hipStream_t st = (hipStream_t)stream;
   const bool nts = tune().nt_store;
+  const int vnt = tune().nt_load ? (tune().vec_nt & 1) : 0;  // bit 0: field rows non-temporal + the left neighbour by DPP
   // gradient with metrics that every outer index shares (dxC(Y,X), dyC(Y,X) under a (Z,Y,X) field): band-major order, or
   // both planes come from the fabric again for every level (0.56 of 8 TB/s level-major).  Two metrics: 8-row bands (rule 13)
   ZBand zb = make_zband(false, 0, 0, 1);
@@ -739,7 +761,7 @@ static int pair2d_impl(int mode, const real* a, const real* u, const real* v, re
     const u64 waves = zb.on ? ((nseg + ZB_SEGS - 1) / ZB_SEGS) * ZB_SEGS * (u64)outer * ntile : (u64)nouter * per_outer;
     const u32 nblk = (u32)((waves + WPB - 1) / WPB);
     const u32 grid = ((nblk + 7) / 8) * 8;
-#define XG_GO(V_, M_, NTS) hipLaunchKernelGGL((k_pair2d<V_, M_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, a, u, v, out_x, out_y, o0, nouter, nblk, ny, nx, fnt, fns, bc_x, fill_x, bc_y, fill_y, mx, aix, mx_sy, mx_sx, my, aiy, my_sy, my_sx, halo_x, halo_y, zb)
+#define XG_GO(V_, M_, NTS) hipLaunchKernelGGL((k_pair2d<V_, M_, NTS, SEG>), dim3(grid), dim3(BLOCK), 0, st, a, u, v, out_x, out_y, o0, nouter, nblk, ny, nx, fnt, fns, bc_x, fill_x, bc_y, fill_y, mx, aix, mx_sy, mx_sx, my, aiy, my_sy, my_sx, halo_x, halo_y, zb, vnt)
 #define XG_M(V_, M_) do { if (nts) XG_GO(V_, M_, true); else XG_GO(V_, M_, false); } while (0)
     if (V > 1) { if (mode) XG_M(NV, 1); else XG_M(NV, 0); }
     else { if (mode) XG_M(1, 1); else XG_M(1, 0); }
