@@ -324,3 +324,48 @@ def test_a_store_as_xarray_writes_it_by_default_is_walked(tbackend, tmp_path, wh
     grid = Grid(Dataset({}, coords), coords={"X": {"center": "XC", "left": "XG"}}, padding={"X": "periodic"}, autoparse_metadata=False)
     got, want = grid.diff(T, "X"), grid.diff(DataArray(full, ("Z", "YC", "XC")), "X")
     assert got.dims == want.dims and np.array_equal(np.asarray(got.values), np.asarray(want.values))
+
+
+def test_blocks_are_fetched_ahead_in_order_and_errors_surface():
+    """`chunked.read_ahead`: helper threads fetch the next blocks while the caller works; order kept, never more than `workers`
+    blocks ahead, a failing read raises at its place in the sequence"""
+    import threading
+    import time
+
+    from xgcm_amd.chunked import read_ahead
+
+    class Slow:
+        chunks, shape, dtype = ((1,) * 12,), (12,), np.dtype("f8")
+
+        def __init__(self):
+            self.lock, self.active, self.peak, self.threads, self.done = threading.Lock(), 0, 0, set(), []
+
+        def __getitem__(self, sl):
+            with self.lock:
+                self.active += 1
+                self.peak = max(self.peak, self.active)
+                self.threads.add(threading.get_ident())
+            time.sleep(0.02)
+            if sl[0].start == 9 and getattr(self, "fail", False):
+                raise OSError("chunk 9 is damaged")
+            with self.lock:
+                self.active -= 1
+                self.done.append(sl[0].start)
+            return np.full(1, float(sl[0].start))
+
+    src = Slow()
+    sls = [(slice(i, i + 1),) for i in range(12)]
+    seen = []
+    for blk in read_ahead(src, sls, workers=4):
+        seen.append(float(blk[0]))
+        assert len(src.done) - len(seen) <= 4          # never further ahead than the helpers there are
+    assert seen == [float(i) for i in range(12)] and src.peak > 1 and threading.get_ident() not in src.threads
+    src2 = Slow()
+    assert [float(b[0]) for b in read_ahead(src2, sls, workers=0)] == seen and src2.threads == {threading.get_ident()}
+    bad = Slow()
+    bad.fail = True
+    got = []
+    with pytest.raises(OSError, match="chunk 9"):
+        for blk in read_ahead(bad, sls, workers=3):
+            got.append(float(blk[0]))
+    assert got == [float(i) for i in range(9)]

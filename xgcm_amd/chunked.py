@@ -61,6 +61,42 @@ def block_slices(chunks: Chunks, whole: Sequence[int] = ()) -> Iterator[Tuple[Tu
         yield idx, tuple(slice(*per_dim[d][i]) for d, i in enumerate(idx))
 
 
+def read_ahead(x, slices, workers: int = None):
+    """`numpy.asarray(x[sl])` for every `sl` of `slices`, IN ORDER, the next few fetched by helper threads while the caller
+    works on the current one.  Fetching a block of a chunked container is file reads and decompression (zarr: 0.6 - 2 GB/s per
+    core; a dask graph: whatever it computes) -- far below what the PCIe link takes (~50 GB/s), and both release the GIL
+    (zlib / ctypes / numpy), so several blocks are fetched side by side; at most `workers` blocks are held ahead of the caller.
+    `XG_READ_AHEAD` sets the number of helper threads (default: min(8, cores); 0: fetch in the caller's thread)."""
+    import os
+
+    slices = list(slices)
+    if workers is None:
+        workers = int(os.environ.get("XG_READ_AHEAD", min(8, os.cpu_count() or 1)))
+    if workers <= 0 or len(slices) <= 1:
+        for sl in slices:
+            yield np.asarray(x[sl])
+        return
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="xg-read") as pool:
+        pending, it = deque(), iter(slices)
+        try:
+            for sl in it:
+                pending.append(pool.submit(lambda sl=sl: np.asarray(x[sl])))
+                if len(pending) >= workers:
+                    break
+            while pending:
+                block = pending.popleft().result()
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append(pool.submit(lambda sl=nxt: np.asarray(x[sl])))
+                yield block
+        finally:
+            for f in pending:
+                f.cancel()
+
+
 class BlockArray:
     """A host array kept as a grid of numpy blocks.  `.chunks` as dask's; slicing (unit-step slices) assembles just the blocks a
     slice crosses; `numpy.asarray` the whole."""

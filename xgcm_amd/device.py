@@ -516,11 +516,11 @@ def _blockwise(per_block, x, axis: Optional[int], n_out: Optional[int] = None, d
             at[0] += 1
             return asdevice(per_block(t, sl))
 
-        for (idx, _), res in zip(todo, iter_stream(on_block, (np.asarray(x[sl]) for _, sl in todo))):
+        for (idx, _), res in zip(todo, iter_stream(on_block, _ch.read_ahead(x, [sl for _, sl in todo]))):
             blocks[idx] = res
     else:
-        for idx, sl in todo:
-            blocks[idx] = tohost(per_block(np.asarray(x[sl]), sl))
+        for (idx, sl), blk in zip(todo, _ch.read_ahead(x, [sl for _, sl in todo])):
+            blocks[idx] = tohost(per_block(blk, sl))
     dtype = next(iter(blocks.values())).dtype if blocks else x.dtype
     if drop_axis:
         blocks = {idx[:axis] + idx[axis + 1:]: b for idx, b in blocks.items()}

@@ -16,8 +16,8 @@ hyperslab is read; packed variables (`scale_factor` / `add_offset`) and types ot
 libhdf5 is NOT part of this package and is never guessed at: it is loaded through ctypes from `$XG_HDF5_LIB`, the loader's
 search path, or the image's Anaconda tree (`/opt/conda/lib/libhdf5.so*`, HDF5 1.10.6); where none loads, every entry point raises
 `NotImplementedError` naming the library.  All calls hold one lock (the usual libhdf5 build is not thread-safe; the block walk
-reads from a staging thread).  Pinned against files real h5py 3.3 / HDF5 1.10.6 wrote (tests/golden/netcdf4_*.nc,
-oracle/make_golden_netcdf4.py)."""
+reads from a staging thread).  Pinned against files real h5py 3.3 / HDF5 1.10.6 wrote (tests/golden/netcdf4_state.nc; generator:
+make_golden_netcdf4.py)."""
 
 from __future__ import annotations
 

@@ -336,7 +336,7 @@ def netcdf_blocks(path: str, name: str, records_per_block: int = 1, records: Opt
 # liblz4 (ctypes); blosc -- zarr's DEFAULT compressor, i.e. what an `xarray.Dataset.to_zarr` without an encoding holds --
 # decoded here: the c-blosc 1 container (16-byte header, block starts, per-block split streams, byte / bit unshuffle) around
 # lz4 / lz4hc / zstd / zlib streams; its own `blosclz` codec only where a libblosc can be loaded.  Pinned against chunks the
-# real c-blosc 1.21 / libzstd / liblz4 compressed (tests/golden/codec_chunks.npz, oracle/make_golden_codecs.py).
+# real c-blosc 1.21 / libzstd / liblz4 compressed (tests/golden/codec_chunks.npz; generator: make_golden_codecs.py).
 # Filters: refused.
 # ------------------------------------------------------------------------------------------------------
 _CLIBS: Dict[str, object] = {}
