@@ -76,6 +76,10 @@ def main():
         var("iter", it, ("time",), chunks=(2,), maxshape=(None,))
         var("Z_bnds", bnds, ("Z", "nv"))
         f.create_dataset("rho0", data=np.float64(1029.0))               # a scalar variable
+        sp = f.create_dataset("sparse", shape=(NZ, NY, NX), dtype="f8", chunks=(2, 3, 8), fillvalue=-1.0, compression="gzip")
+        sp[0:2, 0:3, 0:8] = T[0, 0:2, 0:3, 0:8]                          # one chunk of eight written: the others were never allocated
+        for i, dname in enumerate(("Z", "YC", "XC")):
+            sp.dims[i].attach_scale(scales[dname])
         v = var("station", np.array([b"alpha", b"beta", b"gamma"], dtype="S8"), ("time",))  # NC_CHAR-like: not a numeric field
         v = var("packed", (eta // 2).astype("i2"), ("time", "YC", "XC"))  # CF packing: refused by name
         v.attrs["scale_factor"] = np.float32(0.01)

@@ -47,7 +47,7 @@ def test_the_file_opens_as_the_netcdf_library_laid_it_out():
         ds = H.open_netcdf4(NC)
     said = " ".join(str(w.message) for w in rec)
     assert "station" in said and "string" in said and "packed" in said and "scale_factor" in said
-    assert sorted(ds.data_vars) == ["S", "T", "Tbe", "Z_bnds", "eta", "rho0"] and sorted(ds.coords) == ["XC", "YC", "Z", "iter", "time"]
+    assert sorted(ds.data_vars) == ["S", "T", "Tbe", "Z_bnds", "eta", "rho0", "sparse"] and sorted(ds.coords) == ["XC", "YC", "Z", "iter", "time"]
     assert ds.attrs["Conventions"] == "CF-1.8" and "_NCProperties" not in ds.attrs
     for name in ("time", "Z", "YC", "XC"):
         np.testing.assert_array_equal(ds[name].values, z["c_" + name])
@@ -111,6 +111,29 @@ def test_operators_walk_a_netcdf4_variable_hyperslab_by_hyperslab(tbackend):
     e_eager = DataArray(z["eta"], ("time", "YC", "XC"), name="eta")  # int16 on disk: numpy's integer rules
     g, w = grid.diff(ds["eta"], "X"), grid.diff(e_eager, "X")
     assert g.dtype == w.dtype and np.array_equal(np.asarray(g.values), np.asarray(w.values))
+
+
+@needs_hdf5
+def test_raw_chunk_reads_decoded_here_equal_the_librarys_own_pipeline():
+    """chunked variables whose filters are deflate / shuffle / fletcher32 are read as RAW chunks and decoded outside the library
+    lock (so blocks fetched side by side inflate side by side); everything must equal what `H5Dread` hands back"""
+    z, T, S = _expected()
+    for name, filters in (("T", (2, 1)), ("Tbe", (3,)), ("eta", (1,)), ("iter", ()), ("S", None), ("sparse", (1,))):
+        a = H.H5Array(NC, name, mask=False)
+        assert a._filters == filters, (name, a._filters)
+        direct = np.asarray(a)
+        part = a[(slice(1, 3),) + (slice(None),) * (a.ndim - 1)]
+        a._filters = None                                     # the library's pipeline
+        slow = np.asarray(a)
+        assert direct.dtype == slow.dtype and direct.dtype.isnative
+        assert np.array_equal(direct, slow, equal_nan=True) and np.array_equal(part, slow[1:3], equal_nan=True), name
+    sp = H.H5Array(NC, "sparse", mask=False)                  # seven of its eight chunks were never allocated: the fill value,
+    got = np.asarray(sp)                                      # through H5Dread (the raw path steps aside)
+    assert np.array_equal(got[0:2, 0:3, 0:8], z["T"][0, 0:2, 0:3, 0:8], equal_nan=True)
+    rest = got.copy()
+    rest[0:2, 0:3, 0:8] = -1.0
+    assert (rest == -1.0).all()
+    assert np.array_equal(sp[0:2, 0:3, 0:8], got[0:2, 0:3, 0:8], equal_nan=True)   # (an allocated chunk alone: the raw path)
 
 
 @needs_hdf5

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the chunked-input path (xgcm_amd.chunked): a 75 x 2400 x 3600 f64 field held as a
 BlockArray of 15 blocks of 5 levels through Grid.diff / Grid.cumsum / Grid.integrate, next to the same field as ONE host array
-(the pipelined numpy-in / numpy-out path) and resident in HBM.  Never the bench's `value`: host memory in, host memory out."""
+(the pipelined numpy-in / numpy-out path) and resident in HBM.  Never the bench's `value`: host memory in, host memory out.
+
+`--containers`: the same field held by what a user's reader hands over -- a REAL dask array (tests/real_dask.py finds the image's),
+a zarr-2 store with zarr's default blosc-lz4 chunks (compressed here by libblosc through ctypes) and a NetCDF-4 file with the
+netCDF default of shuffle + deflate chunks (written by the image's h5py interpreter) -- each in blocks of 5 levels, in /dev/shm,
+through diff X and integrate Y; with the read-ahead threads (`XG_READ_AHEAD`, xgcm_amd.chunked.read_ahead) and without."""
 import json
 import os
 import sys
@@ -18,10 +23,11 @@ from tools.bench_configs import mitgcm_grid  # noqa: E402
 
 nz, ny, nx = 75, 2400, 3600
 grid = mitgcm_grid(nz, ny, nx)
-host = D.tohost(D.synthetic((nz, ny, nx), 2))
 dims = ("Z", "YC", "XC")
-blocks = BlockArray.from_array(host, ((5,) * 15, (ny,), (nx,)))
-resident = DataArray(D.asdevice(host), dims)
+if "--containers" not in sys.argv:
+    host = D.tohost(D.synthetic((nz, ny, nx), 2))
+    blocks = BlockArray.from_array(host, ((5,) * 15, (ny,), (nx,)))
+    resident = DataArray(D.asdevice(host), dims)
 
 
 def t(fn, n=3):
@@ -33,6 +39,94 @@ def t(fn, n=3):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n, out
 
+
+def containers():
+    import ctypes
+    import shutil
+    import subprocess
+    import tempfile
+
+    from xgcm_amd import io as IO
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import real_dask
+
+    # smooth data (a model field compresses; the synthetic generator's white noise does not): same shape, same blocks
+    rng = np.random.default_rng(7)
+    field = np.cumsum(rng.standard_normal((nz, ny, nx)) * 1e-3, axis=2) + 15.0
+    tmp = tempfile.mkdtemp(dir="/dev/shm", prefix="xg_rate_")
+    held = {"BlockArray": (BlockArray.from_array(field, ((5,) * 15, (ny,), (nx,))), field)}
+    dsa = real_dask.dask_array()
+    if dsa is not None:
+        held["dask"] = (dsa.from_array(field, chunks=(5, ny, nx)), field)
+    lib = IO._clib("blosc")
+    if lib is not None:
+        lib.blosc_compress_ctx.restype = ctypes.c_int
+        lib.blosc_compress_ctx.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int]
+        zp = os.path.join(tmp, "T.zarr")
+        os.makedirs(zp)
+        json.dump({"zarr_format": 2, "shape": [nz, ny, nx], "chunks": [5, ny, nx], "dtype": "<f8", "order": "C", "fill_value": "NaN", "filters": None,
+                   "compressor": {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}}, open(os.path.join(zp, ".zarray"), "w"))
+        json.dump({"_ARRAY_DIMENSIONS": list(dims)}, open(os.path.join(zp, ".zattrs"), "w"))
+        stored = 0
+        for k in range(nz // 5):
+            raw = field[5 * k:5 * k + 5].tobytes()
+            dst = ctypes.create_string_buffer(len(raw) + 4096)
+            n = lib.blosc_compress_ctx(5, 1, 8, len(raw), raw, dst, len(dst), b"lz4", 0, 8)
+            open(os.path.join(zp, f"{k}.0.0"), "wb").write(dst.raw[:n])
+            stored += n
+        held["zarr blosc-lz4 (%.2f of raw)" % (stored / field.nbytes)] = (IO.ZarrArray(zp), field)
+    py39 = "/opt/conda/bin/python3.9"
+    from xgcm_amd import hdf5 as H
+
+    if os.path.exists(py39) and H.hdf5_available():
+        npy, ncp = os.path.join(tmp, "f.npy"), os.path.join(tmp, "T.nc")
+        part = field[:15]  # (15 levels, 1 GB: deflate runs at some 60 MB/s going in and 300 MB/s coming out, on one core, under libhdf5's lock)
+        np.save(npy, part)
+        code = ("import h5py, numpy as np\n"
+                f"a = np.load({npy!r}, mmap_mode='r')\n"
+                f"f = h5py.File({ncp!r}, 'w')\n"
+                "sc = []\n"
+                "for name, n in zip(('Z', 'YC', 'XC'), a.shape):\n"
+                "    d = f.create_dataset(name, data=np.arange(n) + 0.5); d.make_scale(name); sc.append(d)\n"
+                "v = f.create_dataset('T', shape=a.shape, dtype='f8', chunks=(5, 300, 3600), compression='gzip', compression_opts=1, shuffle=True)\n"
+                "for k in range(0, a.shape[0], 5):\n"
+                "    v[k:k + 5] = a[k:k + 5]\n"
+                "for i, d in enumerate(sc):\n"
+                "    v.dims[i].attach_scale(d)\n"
+                "f.close()\n")
+        try:
+            subprocess.run([py39, "-W", "ignore", "-c", code], check=True, timeout=600, capture_output=True)
+            os.remove(npy)
+            held["NetCDF-4 shuffle+deflate, 15 levels (%.2f of raw)" % (os.path.getsize(ncp) / part.nbytes)] = (H.open_netcdf4(ncp, chunks={"Z": 5, "YC": -1})["T"].data, part, ("time", "YC", "XC"))
+        except Exception as exc:  # noqa: BLE001 -- no h5py interpreter on this box: the line is left out
+            print(json.dumps({"netcdf4": "not written", "why": str(exc)[:200]}), flush=True)
+    want = {}
+    try:
+        for label, entry in held.items():
+            arr, ref = entry[:2]
+            dd = entry[2] if len(entry) > 2 else dims  # (15 levels do not fit the grid's Z: another leading dim)
+            if id(ref) not in want:
+                want[id(ref)] = (np.asarray(grid.diff(DataArray(ref, dd), "X").values), np.asarray(grid.integrate(DataArray(ref, dd), "Y").values))
+            want_d, want_i = want[id(ref)]
+            field = ref
+            for ahead in ("8", "0"):
+                os.environ["XG_READ_AHEAD"] = ahead
+                s_d, out_d = t(lambda: grid.diff(DataArray(arr, dd), "X"), 2)
+                s_i, out_i = t(lambda: grid.integrate(DataArray(arr, dd), "Y"), 2)
+                print(json.dumps({"container": label, "read_ahead_threads": int(ahead), "diff_X_s": round(s_d, 3), "integrate_Y_s": round(s_i, 3),
+                                  "diff_X_GBps_in": round(field.nbytes / 1e9 / s_d, 2), "integrate_Y_GBps_in": round(field.nbytes / 1e9 / s_i, 2),
+                                  "same_values": bool(np.array_equal(np.asarray(out_d.values), want_d, equal_nan=True)
+                                                      and np.allclose(np.asarray(out_i.values), want_i, rtol=1e-12, equal_nan=True))}), flush=True)
+    finally:
+        os.environ.pop("XG_READ_AHEAD", None)
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if "--containers" in sys.argv:
+    containers()
+    sys.exit(0)
 
 for name, call in (("diff X", lambda da: grid.diff(da, "X")), ("derivative Y", lambda da: grid.derivative(da, "Y")),
                    ("cumsum X", lambda da: grid.cumsum(da, "X")), ("integrate Y", lambda da: grid.integrate(da, "Y"))):
