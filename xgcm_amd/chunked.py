@@ -97,6 +97,22 @@ def read_ahead(x, slices, workers: int = None):
                 f.cancel()
 
 
+def pmap(fn, items, workers: int = None):
+    """`fn(item)` for every item, by a few helper threads when there are several (chunk files / raw chunks of ONE request:
+    reading and inflating release the GIL); results in order.  `XG_READ_AHEAD=0` keeps everything in the caller's thread."""
+    import os
+
+    items = list(items)
+    if workers is None:
+        workers = int(os.environ.get("XG_READ_AHEAD", min(8, os.cpu_count() or 1)))
+    if workers <= 1 or len(items) <= 1:
+        return [fn(it) for it in items]
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=min(workers, len(items)), thread_name_prefix="xg-chunk") as pool:
+        return list(pool.map(fn, items))
+
+
 class BlockArray:
     """A host array kept as a grid of numpy blocks.  `.chunks` as dask's; slicing (unit-step slices) assembles just the blocks a
     slice crosses; `numpy.asarray` the whole."""

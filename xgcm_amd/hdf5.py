@@ -394,7 +394,9 @@ class H5Array:
             finally:
                 lib.H5Dclose(did)
         item = self.dtype.itemsize
-        for idx, buf, mask in raws:
+
+        def place(raw):  # one chunk: decode, then copy its part of the hyperslab (chunks write disjoint parts of `out`)
+            idx, buf, mask = raw
             data = buf
             for pos in range(len(self._filters) - 1, -1, -1):  # undone in reverse; a set bit in `mask`: that filter was skipped
                 if mask >> pos & 1:
@@ -417,6 +419,10 @@ class H5Array:
                 src.append(slice(lo - a, hi - a))
                 dst.append(slice(lo - start[d], hi - start[d]))
             out[tuple(dst)] = blk[tuple(src)]  # (assignment converts the file's byte order)
+
+        from .chunked import pmap
+
+        pmap(place, raws)
         return True
 
     def __array__(self, dtype=None, copy=None):

@@ -607,11 +607,14 @@ class ZarrArray:
                 raise IndexError("ZarrArray: unit-step slices only")
             lo, hi, _ = k.indices(n)
             spans.append((lo, max(lo, hi)))
-        out = np.empty([b - a for a, b in spans], dtype=self.dtype)
         import itertools
 
         ranges = [range(lo // c, (hi - 1) // c + 1) if hi > lo else range(0) for (lo, hi), c in zip(spans, self.chunks)]
-        for idx in itertools.product(*ranges):
+        if all(len(r) == 1 and (lo, hi) == (r[0] * c, r[0] * c + c) for r, (lo, hi), c in zip(ranges, spans, self.chunks)):
+            return self._chunk(tuple(r[0] for r in ranges))  # exactly one whole chunk: the decoded chunk itself, no second copy
+        out = np.empty([b - a for a, b in spans], dtype=self.dtype)
+
+        def place(idx):  # one chunk file: read, decode, copy its part of the slice (chunks write disjoint parts of `out`)
             blk = self._chunk(idx)
             src, dst = [], []
             for d, i in enumerate(idx):
@@ -620,6 +623,10 @@ class ZarrArray:
                 src.append(slice(lo - a, hi - a))
                 dst.append(slice(lo - spans[d][0], hi - spans[d][0]))
             out[tuple(dst)] = blk[tuple(src)]
+
+        from .chunked import pmap
+
+        pmap(place, itertools.product(*ranges))  # the chunk files of ONE request side by side (inflating releases the GIL)
         return out
 
     def __array__(self, dtype=None, copy=None):
