@@ -339,20 +339,16 @@ class H5Array:
             did = lib.H5Dopen2(self._file.id, self.name.encode(), 0)
             if did < 0:
                 raise OSError(f"{self.path}:{self.name}: cannot be opened any more")
-            fs = ms = mt = ft = -1
+            fs = ms = mt = ft = 0  # (0 is H5S_ALL / "nothing to close")
             try:
-                fs, ft = lib.H5Dget_space(did), lib.H5Dget_type(did)
+                ft = lib.H5Dget_type(did)
                 mt = lib.H5Tget_native_type(ft, 1)
-                if self.ndim:
+                if self.ndim:  # (a scalar dataset is read whole: H5S_ALL on both sides)
+                    fs = lib.H5Dget_space(did)
                     st, ct = (_hsize * self.ndim)(*start), (_hsize * self.ndim)(*count)
                     if lib.H5Sselect_hyperslab(fs, 0, st, None, ct, None) < 0:
                         raise OSError(f"{self.path}:{self.name}: hyperslab {start} + {count} refused")
                     ms = lib.H5Screate_simple(self.ndim, ct, None)
-                else:
-                    ms = 0  # H5S_ALL
-                    fs_all = fs
-                    lib.H5Sclose(fs_all)
-                    fs = 0
                 if lib.H5Dread(did, mt, ms, fs, 0, out.ctypes.data_as(C.c_void_p)) < 0:
                     raise OSError(f"{self.path}:{self.name}: H5Dread failed (a filter this libhdf5 lacks, or a damaged file)")
             finally:
