@@ -206,6 +206,17 @@ def test_zarr_slices_missing_chunks_and_refusals(tmp_path):
     (tmp_path / "a" / "1.1").unlink()  # a chunk that was never written: the fill value
     assert np.isnan(z[3:6, 2:4]).all() and np.array_equal(z[0:3], a[0:3])
     meta = json.loads((tmp_path / "a" / ".zarray").read_text())
+    import json as _json
+
+    IO.write_zarr(str(tmp_path / "m"), np.array([[1.5, -999.0, 3.0], [np.nan, 5.0, -999.0]]), (1, 3), ("y", "x"), "zlib", attrs={"_FillValue": -999.0})
+    m = IO.ZarrArray(str(tmp_path / "m"))  # xarray's mask_and_scale: `_FillValue` cells of a float variable are NaN
+    assert np.array_equal(np.asarray(m), [[1.5, np.nan, 3.0], [np.nan, 5.0, np.nan]], equal_nan=True)
+    assert np.array_equal(np.asarray(IO.ZarrArray(str(tmp_path / "m"), mask=False)), [[1.5, -999.0, 3.0], [np.nan, 5.0, -999.0]], equal_nan=True)
+    za = _json.loads((tmp_path / "m" / ".zattrs").read_text())
+    za["scale_factor"] = 0.01
+    (tmp_path / "m" / ".zattrs").write_text(_json.dumps(za))
+    with pytest.raises(NotImplementedError, match="packed variable"):
+        IO.ZarrArray(str(tmp_path / "m"))
     meta["compressor"] = {"id": "pcodec", "level": 8}
     (tmp_path / "a" / ".zarray").write_text(json.dumps(meta))
     with pytest.raises(NotImplementedError, match="pcodec"):

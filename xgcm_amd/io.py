@@ -549,7 +549,7 @@ class ZarrArray:
     `_ARRAY_DIMENSIONS` (or None); `x[slices]` (unit-step slices) reads exactly the chunk files the slices cross; a chunk
     that was never written holds the fill value."""
 
-    def __init__(self, path: str):
+    def __init__(self, path: str, mask: bool = True):
         import json
 
         self.path = path
@@ -581,6 +581,16 @@ class ZarrArray:
                 self.attrs = json.load(f)
         dims = self.attrs.get("_ARRAY_DIMENSIONS")
         self.dims = tuple(dims) if dims is not None else None
+        # CF decoding as xarray's default (`mask_and_scale=True`) applies it to what the reference computes on: cells of a
+        # floating-point variable equal to `_FillValue` / `missing_value` are NaN; packed variables are refused by name
+        if any(k in self.attrs for k in ("scale_factor", "add_offset")):
+            raise NotImplementedError(f"{path} is a packed variable (scale_factor / add_offset)")
+        self._missing = []
+        if mask and self.dtype.kind == "f":
+            for key in ("_FillValue", "missing_value"):
+                v = self.attrs.get(key)
+                if isinstance(v, (int, float)) and v == v:
+                    self._missing.append(self.dtype.type(v))
 
     @property
     def nbytes(self) -> int:
@@ -596,6 +606,9 @@ class ZarrArray:
         a = np.frombuffer(raw, dtype=self.dtype)
         if a.size != int(np.prod(self.chunks)):
             raise ValueError(f"{f}: {a.size} cells in a chunk of {self.chunks}")
+        for v in self._missing:
+            if (a == v).any():
+                a = np.where(a == v, self.dtype.type(np.nan), a)
         return a.reshape(self.chunks, order=self._order)  # (edge chunks are stored full-size, padded with the fill value)
 
     def __getitem__(self, key) -> np.ndarray:
@@ -649,7 +662,15 @@ def open_zarr(path: str):
     names = sorted(n for n in os.listdir(path) if os.path.exists(os.path.join(path, n, ".zarray")))
     if not names:
         raise ValueError(f"{path}: neither a zarr array nor a group of arrays")
-    arrays = {n: ZarrArray(os.path.join(path, n)) for n in names}
+    arrays = {}
+    for n in names:
+        try:
+            arrays[n] = ZarrArray(os.path.join(path, n))
+        except NotImplementedError as exc:  # a packed variable / an unknown codec next to the fields: left out, by name
+            import warnings
+
+            warnings.warn(f"{exc}: variable left out of the dataset", stacklevel=2)
+    names = [n for n in names if n in arrays]
     for n, z in arrays.items():
         if z.dims is None:
             raise ValueError(f"{path}/{n}: no `_ARRAY_DIMENSIONS` attribute (a store written by xarray carries the dim names there)")
