@@ -15,8 +15,10 @@ does carry one: an Anaconda tree under /opt/conda (python 3.9) whose `dask` 2021
 Threads are off (`scheduler="synchronous"`): block reads arrive in a fixed order, the way the tests count them."""
 from __future__ import annotations
 
+import atexit
 import importlib
 import os
+import shutil
 import sys
 import tempfile
 
@@ -46,6 +48,7 @@ def dask_array():
         site = os.environ.get("XG_DASK_SITE", "/opt/conda/lib/python3.9/site-packages")
         if os.path.isdir(os.path.join(site, "dask")) and os.path.isdir(os.path.join(site, "toolz")):
             scratch = tempfile.mkdtemp(prefix="xg_dask_site_")
+            atexit.register(shutil.rmtree, scratch, True)  # (symlinks only: the tree itself is never touched)
             for name in _PURE:
                 src = os.path.join(site, name)
                 if os.path.exists(src):
