@@ -203,6 +203,7 @@ def test_zarr_slices_missing_chunks_and_refusals(tmp_path):
     z = IO.ZarrArray(str(tmp_path / "a"))
     assert z.shape == (7, 5) and z.dtype == np.dtype(">f4") and normalize_chunks(z.chunks, z.shape) == ((3, 3, 1), (2, 2, 1))
     assert np.array_equal(z[2:7, 1:4], a[2:7, 1:4]) and np.array_equal(np.asarray(z), a) and z[3:3].shape == (0, 5)
+    assert np.array_equal(z[4], a[4]) and np.array_equal(z[-1, 1:3], a[-1, 1:3]) and z[2, 3] == a[2, 3]  # ints drop their dim
     (tmp_path / "a" / "1.1").unlink()  # a chunk that was never written: the fill value
     assert np.isnan(z[3:6, 2:4]).all() and np.array_equal(z[0:3], a[0:3])
     meta = json.loads((tmp_path / "a" / ".zarray").read_text())

@@ -71,6 +71,9 @@ def test_the_file_opens_as_the_netcdf_library_laid_it_out():
     assert np.array_equal(np.asarray(ds["Z_bnds"].data), z["Z_bnds"]) and float(ds["rho0"].values) == 1029.0
     raw = H.H5Array(NC, "T", mask=False)
     assert np.array_equal(np.asarray(raw), z["T"], equal_nan=True)
+    rec = t.isel(time=1, Z=slice(1, 3))                                   # a record of the file: just the chunks it crosses
+    assert rec.dims == ("Z", "YC", "XC") and np.array_equal(np.asarray(rec.values), T[1, 1:3], equal_nan=True)
+    assert np.array_equal(t.data[-1, :, 2], T[-1, :, 2], equal_nan=True)
     re = H.open_netcdf4(NC, chunks={"time": -1, "YC": 2})["S"]            # xarray's `chunks=`
     assert re.chunks == ((3,), (4,), (2, 2, 2), (16,))
 
@@ -163,6 +166,8 @@ def test_what_is_not_read_says_so(tmp_path):
         H.H5Array(NC, "nope")
     with pytest.raises(IndexError, match="unit-step"):
         H.H5Array(NC, "T")[::2]
+    with pytest.raises(IndexError, match="out of bounds"):
+        H.H5Array(NC, "T")[3]
     with pytest.raises(NotImplementedError, match="packed variable"):
         H.H5Array(NC, "packed")
     with pytest.raises(NotImplementedError, match="type class string"):

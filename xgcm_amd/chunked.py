@@ -97,6 +97,28 @@ def read_ahead(x, slices, workers: int = None):
                 f.cancel()
 
 
+def index_spans(key, shape, what: str = "chunked array"):
+    """an index of ints and unit-step slices -> ([(lo, hi) per dim], [dims an int drops]): the indexing a chunked container
+    serves (`ds["T"].isel(time=0)` on a store reads exactly the chunks that record crosses)"""
+    key = key if isinstance(key, tuple) else (key,)
+    if len(key) > len(shape):
+        raise IndexError(f"{what}: {len(key)} indices for {len(shape)} dims")
+    key = key + (slice(None),) * (len(shape) - len(key))
+    spans, squeeze = [], []
+    for d, (k, n) in enumerate(zip(key, shape)):
+        if isinstance(k, (int, np.integer)):
+            k = int(k) + (n if k < 0 else 0)
+            if not 0 <= k < n:
+                raise IndexError(f"{what}: index {k} is out of bounds for a dim of {n}")
+            squeeze.append(d)
+            k = slice(k, k + 1)
+        if not isinstance(k, slice) or k.step not in (None, 1):
+            raise IndexError(f"{what}: integers and unit-step slices only")
+        lo, hi, _ = k.indices(n)
+        spans.append((lo, max(lo, hi)))
+    return spans, squeeze
+
+
 def pmap(fn, items, workers: int = None):
     """`fn(item)` for every item, by a few helper threads when there are several (chunk files / raw chunks of ONE request:
     reading and inflating release the GIL); results in order.  `XG_READ_AHEAD=0` keeps everything in the caller's thread."""

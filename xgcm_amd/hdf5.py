@@ -316,17 +316,13 @@ class H5Array:
         return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
 
     def __getitem__(self, key) -> np.ndarray:
-        key = key if isinstance(key, tuple) else (key,)
-        key = key + (slice(None),) * (self.ndim - len(key))
-        if len(key) != self.ndim:
-            raise IndexError(f"{len(key)} indices for a dataset of {self.ndim} dims")
-        start, count = [], []
-        for k, n in zip(key, self.shape):
-            if not isinstance(k, slice) or k.step not in (None, 1):
-                raise IndexError("H5Array: unit-step slices only")
-            lo, hi, _ = k.indices(n)
-            start.append(lo)
-            count.append(max(0, hi - lo))
+        from .chunked import index_spans
+
+        spans, squeeze = index_spans(key, self.shape, "H5Array")
+        if squeeze:  # x[i]: that one index, the dim dropped
+            part = self[tuple(slice(lo, hi) for lo, hi in spans)]
+            return part.reshape([n for d, n in enumerate(part.shape) if d not in squeeze])
+        start, count = [lo for lo, _ in spans], [hi - lo for lo, hi in spans]
         out = np.empty(count, dtype=self.dtype)
         if out.size == 0:
             return out

@@ -612,14 +612,12 @@ class ZarrArray:
         return a.reshape(self.chunks, order=self._order)  # (edge chunks are stored full-size, padded with the fill value)
 
     def __getitem__(self, key) -> np.ndarray:
-        key = key if isinstance(key, tuple) else (key,)
-        key = key + (slice(None),) * (self.ndim - len(key))
-        spans = []
-        for k, n in zip(key, self.shape):
-            if not isinstance(k, slice) or k.step not in (None, 1):
-                raise IndexError("ZarrArray: unit-step slices only")
-            lo, hi, _ = k.indices(n)
-            spans.append((lo, max(lo, hi)))
+        from .chunked import index_spans
+
+        spans, squeeze = index_spans(key, self.shape, "ZarrArray")
+        if squeeze:  # x[i]: that one index, the dim dropped
+            part = self[tuple(slice(lo, hi) for lo, hi in spans)]
+            return part.reshape([n for d, n in enumerate(part.shape) if d not in squeeze])
         import itertools
 
         ranges = [range(lo // c, (hi - 1) // c + 1) if hi > lo else range(0) for (lo, hi), c in zip(spans, self.chunks)]
