@@ -96,6 +96,10 @@ def _load():
                 fn = getattr(lib, name)
                 fn.restype, fn.argtypes = res, args
             lib.H5open()
+            maj, mnr, rel = C.c_uint(), C.c_uint(), C.c_uint()
+            lib.H5get_libversion(C.byref(maj), C.byref(mnr), C.byref(rel))
+            if (maj.value, mnr.value) < (1, 10):  # identifiers are 64-bit since 1.10: the prototypes above assume that
+                raise AttributeError("HDF5 older than 1.10")
             lib.H5Eset_auto2(0, None, None)  # failures are reported by the exceptions below, not by a stack dump on stderr
         except AttributeError:  # an HDF5 older than 1.8 / built without these entry points
             lib = None
