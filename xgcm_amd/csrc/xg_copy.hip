@@ -206,7 +206,7 @@ int copy_launch(const void* src_, void* dst_, const CopyGeo& g, hipStream_t st) 
         const double b = (double)g.shape[L] / (double)(((g.shape[L] + ts - 1) / ts) * ts);
         return a * b;
       };
-      const bool wide = sizeof(T) < 8 && filled(64) * 1.15 >= filled(32);
+      const bool wide = (sizeof(T) < 8 || (tune().dbg & 1)) && filled(64) * 1.15 >= filled(32);
       const int ts = wide ? 64 : 32;
       const u32 tiles_t = (u32)((g.shape[t] + ts - 1) / ts), tiles_l = (u32)((g.shape[L] + ts - 1) / ts);
       u64 batch = 1;
@@ -216,7 +216,7 @@ int copy_launch(const void* src_, void* dst_, const CopyGeo& g, hipStream_t st) 
       const u64 grid = ((nblk + 7) / 8) * 8;
       int rc = check_grid(grid);
       if (rc) return rc;
-      if constexpr (sizeof(T) < 8) {
+      {
         if (wide) {
           hipLaunchKernelGGL((k_copy_transpose<T, 64>), dim3((u32)grid), dim3(BLOCK), 0, st, src, dst, g, t, tiles_t, tiles_l, nblk);
           XG_LAUNCH_CHECK();
