@@ -206,7 +206,9 @@ int copy_launch(const void* src_, void* dst_, const CopyGeo& g, hipStream_t st) 
         const double b = (double)g.shape[L] / (double)(((g.shape[L] + ts - 1) / ts) * ts);
         return a * b;
       };
-      const bool wide = (sizeof(T) < 8 || (tune().dbg & 1)) && filled(64) * 1.15 >= filled(32);
+      // (8-byte elements keep 32 x 32: with 64 x 64 tiles -- 512-B rows, 33 KB of LDS per workgroup -- (Z,Y,X) -> (Z,X,Y) fell from
+      // 0.67 to 0.52 of 8 TB/s, two process pairs on one box, profiles/r06_kernels/r06bj_ab_transpose_tile.log)
+      const bool wide = sizeof(T) < 8 && filled(64) * 1.15 >= filled(32);
       const int ts = wide ? 64 : 32;
       const u32 tiles_t = (u32)((g.shape[t] + ts - 1) / ts), tiles_l = (u32)((g.shape[L] + ts - 1) / ts);
       u64 batch = 1;
@@ -216,7 +218,7 @@ int copy_launch(const void* src_, void* dst_, const CopyGeo& g, hipStream_t st) 
       const u64 grid = ((nblk + 7) / 8) * 8;
       int rc = check_grid(grid);
       if (rc) return rc;
-      {
+      if constexpr (sizeof(T) < 8) {
         if (wide) {
           hipLaunchKernelGGL((k_copy_transpose<T, 64>), dim3((u32)grid), dim3(BLOCK), 0, st, src, dst, g, t, tiles_t, tiles_l, nblk);
           XG_LAUNCH_CHECK();
