@@ -238,7 +238,10 @@ def _attrs(lib, oid) -> Dict:
             n = lib.H5Aget_name(aid, 0, None)
             buf = C.create_string_buffer(int(n) + 1)
             lib.H5Aget_name(aid, int(n) + 1, buf)
-            val = _read_attr(lib, aid)
+            try:
+                val = _read_attr(lib, aid)
+            except NotImplementedError:  # a number type numpy has no name for: the attribute is left out
+                val = None
             if val is not None:
                 out[buf.value.decode()] = val
         finally:
@@ -313,7 +316,10 @@ class H5Array:
         if mask and self.dtype.kind == "f":  # xarray's mask_and_scale: these cells are NaN in what the reference computes on
             for key in ("_FillValue", "missing_value"):
                 if key in self.attrs:
-                    self._missing += [v for v in np.asarray(self.attrs[key], dtype=self.dtype).reshape(-1) if not np.isnan(v)]
+                    try:
+                        self._missing += [v for v in np.asarray(self.attrs[key], dtype=self.dtype).reshape(-1) if not np.isnan(v)]
+                    except (TypeError, ValueError):  # an attribute of that name that is not a number: nothing to mask
+                        pass
 
     @property
     def nbytes(self) -> int:
