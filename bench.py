@@ -285,7 +285,7 @@ def run_configs(ranks, field, reps, records4):
                 ms = [r[i][0] for r in per_rank]
                 tot = sum(r[i][1] for r in per_rank)
                 e["per_rank_ms"] = ms
-                e["job_gcell_s"] = round(tot / (max(ms) * 1e-3) / 1e9, 2)
+                e["job_gcell_s"] = float(f"{tot / (max(ms) * 1e-3) / 1e9:.6g}")  # (significant digits: a CPU dry run's rate is tiny, not 0)
         return entries
 
     # ---- config 3: derivative X / Y / Z (random metrics dxC(YC,XG), dyC(YG,XC), drC(Zl)) and integrate Z (drF(Z)) ----
