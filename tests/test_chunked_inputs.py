@@ -156,9 +156,12 @@ def test_what_the_chunked_path_does_not_serve_says_so(tbackend, container):
 # ----------------------------------------------------------------------------------------------
 # zarr-2 directory stores (xarray's `to_zarr` layout) as chunked inputs: read chunk file by chunk file
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("compressor", [None, "zlib", "lzma"])
+@pytest.mark.parametrize("compressor", [None, "zlib", "lzma", "blosc", "zstd", "lz4"])
 def test_zarr_store_walked_chunk_by_chunk(tbackend, tmp_path, compressor):
     from xgcm_amd import io as IO
+
+    if compressor in ("blosc", "zstd", "lz4") and IO._clib(compressor) is None:
+        pytest.skip(f"no lib{compressor} on this box")
 
     grid, ds, a = _setup()
     store = tmp_path / "run.zarr"

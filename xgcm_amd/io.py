@@ -680,10 +680,41 @@ def open_zarr(path: str):
     return Dataset(data, coords)
 
 
+def _c_compress(name: str, raw: bytes, typesize: int) -> bytes:
+    """`raw` as numcodecs' Blosc(lz4, 5, SHUFFLE) / Zstd(1) / LZ4() would store it, through the C library"""
+    import ctypes as c
+
+    lib = _need(name, f"zarr compressor {name!r}")
+    if name == "blosc":
+        lib.blosc_compress_ctx.restype = c.c_int
+        lib.blosc_compress_ctx.argtypes = [c.c_int, c.c_int, c.c_size_t, c.c_size_t, c.c_char_p, c.c_void_p, c.c_size_t, c.c_char_p, c.c_size_t, c.c_int]
+        dst = np.empty(len(raw) + 16 + 4096, dtype="u1")
+        n = lib.blosc_compress_ctx(5, 1, typesize, len(raw), raw, dst.ctypes.data, dst.size, b"lz4", 0, 1)
+    elif name == "zstd":
+        lib.ZSTD_compressBound.restype, lib.ZSTD_compressBound.argtypes = c.c_size_t, [c.c_size_t]
+        lib.ZSTD_compress.restype, lib.ZSTD_compress.argtypes = c.c_size_t, [c.c_void_p, c.c_size_t, c.c_char_p, c.c_size_t, c.c_int]
+        dst = np.empty(lib.ZSTD_compressBound(len(raw)), dtype="u1")
+        n = lib.ZSTD_compress(dst.ctypes.data, dst.size, raw, len(raw), 1)
+        if lib.ZSTD_isError(n):
+            n = -1
+    else:
+        lib.LZ4_compressBound.restype, lib.LZ4_compressBound.argtypes = c.c_int, [c.c_int]
+        lib.LZ4_compress_default.restype, lib.LZ4_compress_default.argtypes = c.c_int, [c.c_char_p, c.c_void_p, c.c_int, c.c_int]
+        dst = np.empty(4 + lib.LZ4_compressBound(len(raw)), dtype="u1")
+        dst[:4] = np.frombuffer(len(raw).to_bytes(4, "little"), dtype="u1")
+        n = lib.LZ4_compress_default(raw, dst.ctypes.data + 4, len(raw), dst.size - 4)
+        n = n + 4 if n > 0 else -1
+    if n <= 0:
+        raise OSError(f"lib{name} could not compress a chunk of {len(raw)} bytes")
+    return dst[:n].tobytes()
+
+
 def write_zarr(path: str, array, chunks: Sequence[int], dims: Optional[Sequence[str]] = None, compressor: Optional[str] = None,
                attrs: Optional[dict] = None) -> None:
     """`array` (numpy, or any chunked container: a result of the block walk is written block by block, never assembled) as a
-    zarr-2 array directory with chunk shape `chunks`; `compressor`: None / "zlib" / "gzip" / "bz2" / "lzma"."""
+    zarr-2 array directory with chunk shape `chunks`; `compressor`: None / "zlib" / "gzip" / "bz2" / "lzma", and -- through the
+    libraries `_clib` finds, an error naming the missing one otherwise -- "blosc" (zarr's default: lz4, level 5, byte
+    shuffle), "zstd", "lz4" (numcodecs' framings).  Chunk files are compressed and written side by side (`chunked.pmap`)."""
     import itertools
     import json
 
@@ -694,17 +725,22 @@ def write_zarr(path: str, array, chunks: Sequence[int], dims: Optional[Sequence[
         dtype = dtype.newbyteorder("<" if np.little_endian else ">")
     os.makedirs(path, exist_ok=True)
     enc = {None: lambda b: b, "zlib": lambda b: __import__("zlib").compress(b, 1), "gzip": lambda b: __import__("gzip").compress(b, 1),
-           "bz2": lambda b: __import__("bz2").compress(b), "lzma": lambda b: __import__("lzma").compress(b)}[compressor]
+           "bz2": lambda b: __import__("bz2").compress(b), "lzma": lambda b: __import__("lzma").compress(b),
+           "blosc": lambda b: _c_compress("blosc", b, dtype.itemsize), "zstd": lambda b: _c_compress("zstd", b, 1),
+           "lz4": lambda b: _c_compress("lz4", b, 1)}[compressor]
+    if compressor in ("blosc", "zstd", "lz4"):
+        _need(compressor, f"zarr compressor {compressor!r}")
+    codec = {None: None, "blosc": {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1, "blocksize": 0}, "zstd": {"id": "zstd", "level": 1},
+             "lz4": {"id": "lz4", "acceleration": 1}}.get(compressor, {"id": compressor, **({"level": 1} if compressor in ("zlib", "gzip") else {})})
     with open(os.path.join(path, ".zarray"), "w") as f:
-        json.dump({"zarr_format": 2, "shape": list(shape), "chunks": list(chunks), "dtype": dtype.str, "order": "C",
-                   "compressor": None if compressor is None else {"id": compressor, **({"level": 1} if compressor in ("zlib", "gzip") else {})},
+        json.dump({"zarr_format": 2, "shape": list(shape), "chunks": list(chunks), "dtype": dtype.str, "order": "C", "compressor": codec,
                    "fill_value": "NaN" if dtype.kind == "f" else 0, "filters": None}, f)
     meta = dict(attrs or {})
     if dims is not None:
         meta["_ARRAY_DIMENSIONS"] = list(dims)
     with open(os.path.join(path, ".zattrs"), "w") as f:
         json.dump(meta, f)
-    for idx in itertools.product(*[range((n + c - 1) // c) for n, c in zip(shape, chunks)]):
+    def put(idx):  # one chunk file
         sl = tuple(slice(i * c, min((i + 1) * c, n)) for i, c, n in zip(idx, chunks, shape))
         part = np.asarray(array[sl], dtype=dtype)
         full = part
@@ -713,3 +749,7 @@ def write_zarr(path: str, array, chunks: Sequence[int], dims: Optional[Sequence[
             full[tuple(slice(0, s) for s in part.shape)] = part
         with open(os.path.join(path, ".".join(str(i) for i in idx) if idx else "0"), "wb") as f:
             f.write(enc(np.ascontiguousarray(full).tobytes()))
+
+    from .chunked import pmap
+
+    pmap(put, itertools.product(*[range((n + c - 1) // c) for n, c in zip(shape, chunks)]))
