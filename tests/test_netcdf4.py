@@ -140,6 +140,55 @@ def test_raw_chunk_reads_decoded_here_equal_the_librarys_own_pipeline():
 
 
 @needs_hdf5
+def test_results_go_back_into_a_netcdf4_file_block_by_block(tbackend, tmp_path):
+    """`write_netcdf4`: a chunked result is written block by block (its blocks shuffled + deflated by helper threads, handed to
+    libhdf5 as stored chunks); the file reads back through this package AND through real h5py (the image's Anaconda
+    interpreter) as the netCDF-4 layout: chunk shape = block shape, gzip + shuffle, dimension scales attached by name"""
+    import json
+    import subprocess
+
+    z, T, S = _expected()
+    ds = H.open_netcdf4(NC)
+    gds = Dataset({}, {"XC": ("XC", z["c_XC"]), "XG": ("XG", z["c_XC"] - 1.0)})
+    grid = Grid(gds, coords={"X": {"center": "XC", "left": "XG"}}, padding={"X": "periodic"}, autoparse_metadata=False)
+    got = grid.diff(ds["T"], "X")                       # ('time', 'Z', 'YC', 'XG'), blocks (1, 2, 3, 8) as the file's chunks
+    got.attrs.update({"units": "degC", "factor": np.float32(0.5)})
+    eta = DataArray(z["eta"], ("time", "YC", "XC"), coords={"time": ("time", z["c_time"], {"units": "s"})}, name="eta")
+    out = str(tmp_path / "out.nc")
+    H.write_netcdf4(out, {"dTdx": got, "eta": eta, "rho0": DataArray(np.float64(1029.0), ())}, attrs={"title": "results"})
+    back = H.open_netcdf4(out)
+    want = np.asarray(got.values)
+    d = back["dTdx"]
+    assert d.dims == got.dims and d.attrs["units"] == "degC" and float(d.attrs["factor"][0]) == 0.5 and back.attrs["title"] == "results"
+    assert np.array_equal(np.asarray(d.data), want, equal_nan=True)
+    assert np.array_equal(np.asarray(back["eta"].data), z["eta"]) and float(back["rho0"].values) == 1029.0
+    np.testing.assert_array_equal(back["time"].values, z["c_time"])
+    assert back["time"].attrs == {"units": "s"} and "XC" not in back.coords    # eta's XC came without a coordinate: a bare dimension
+    np.testing.assert_array_equal(back["Z"].values, z["c_Z"])                  # (the result carried the file's Z along)
+    if tbackend != "oracle-double":
+        assert d.data.layout == "chunked" and d.data._filters == (2, 1) and d.chunks == got.chunks
+    py39 = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py39):
+        return
+    code = ("import h5py, json, numpy as np\n"
+            f"f = h5py.File({out!r}, 'r')\n"
+            "t = f['dTdx']\n"
+            "print(json.dumps({'chunks': list(t.chunks or ()), 'compression': t.compression, 'shuffle': bool(t.shuffle),\n"
+            "    'scales': [[s.name for s in t.dims[i].values()] for i in range(t.ndim)], 'sum': float(np.nansum(t[...])),\n"
+            "    'nan': int(np.isnan(t[...]).sum()), 'zname': f['XC'].attrs['NAME'].decode(), 'eta': str(f['eta'].dtype)}))\n")
+    r = subprocess.run([py39, "-W", "ignore", "-c", code], capture_output=True, text=True, timeout=120)
+    if r.returncode != 0 and "No module named" in r.stderr:
+        return  # that interpreter has no h5py on this box
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = json.loads(r.stdout.strip().splitlines()[-1])
+    assert seen["scales"] == [["/time"], ["/Z"], ["/YC"], ["/XG"]] and seen["eta"] == "int16"
+    assert seen["zname"].startswith("This is a netCDF dimension but not a netCDF variable.")
+    assert seen["sum"] == pytest.approx(float(np.nansum(want)), rel=1e-12) and seen["nan"] == int(np.isnan(want).sum())
+    if tbackend != "oracle-double":
+        assert seen["chunks"] == [1, 2, 3, 8] and seen["compression"] == "gzip" and seen["shuffle"] is True
+
+
+@needs_hdf5
 def test_concurrent_hyperslab_reads_hold_the_library_lock():
     z, T, S = _expected()
     arr = H.open_netcdf4(NC)["T"].data

@@ -31,7 +31,7 @@ from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 
-__all__ = ["H5Array", "open_netcdf4", "hdf5_available"]
+__all__ = ["H5Array", "open_netcdf4", "write_netcdf4", "hdf5_available"]
 
 _hid = C.c_int64
 _hsize = C.c_uint64
@@ -488,3 +488,205 @@ def open_netcdf4(path: str, chunks: Optional[Dict[str, int]] = None, mask: bool 
     coords = {n: (arrays[n].dims or (), np.asarray(arrays[n]), clean(arrays[n])) for n in arrays if n in is_coord}
     data = {n: DataArray(a if a.ndim else np.asarray(a), a.dims or (), name=n, attrs=clean(a)) for n, a in arrays.items() if n not in is_coord}
     return Dataset(data, coords, attrs=gattrs)
+
+
+# ------------------------------------------------------------------------------------------------------
+# writing: results back into a NetCDF-4 file, block by block
+# ------------------------------------------------------------------------------------------------------
+_HL = []
+_NATIVE = {"f8": "H5T_NATIVE_DOUBLE_g", "f4": "H5T_NATIVE_FLOAT_g", "i1": "H5T_NATIVE_INT8_g", "i2": "H5T_NATIVE_INT16_g", "i4": "H5T_NATIVE_INT32_g",
+           "i8": "H5T_NATIVE_INT64_g", "u1": "H5T_NATIVE_UINT8_g", "u2": "H5T_NATIVE_UINT16_g", "u4": "H5T_NATIVE_UINT32_g", "u8": "H5T_NATIVE_UINT64_g"}
+
+
+def _writer():
+    """libhdf5 with the prototypes of the writing entry points, and libhdf5_hl (dimension scales) from the same place"""
+    lib = _h5()
+    if not _HL:
+        hl = None
+        base = getattr(lib, "_name", "") or ""
+        for cand in (os.environ.get("XG_HDF5_HL_LIB"), base.replace("libhdf5.so", "libhdf5_hl.so") if "libhdf5.so" in base else None,
+                     ctypes.util.find_library("hdf5_hl"), "libhdf5_hl.so", *sorted(glob.glob(os.path.join(os.path.dirname(base) or "/opt/conda/lib", "libhdf5_hl.so*")), key=len)):
+            if cand:
+                try:
+                    hl = C.CDLL(cand)
+                    break
+                except OSError:
+                    continue
+        try:
+            for name, (res, args) in {
+                    "H5Fcreate": (_hid, [C.c_char_p, C.c_uint, _hid, _hid]), "H5Pcreate": (_hid, [_hid]),
+                    "H5Pset_chunk": (C.c_int, [_hid, C.c_int, C.POINTER(_hsize)]), "H5Pset_shuffle": (C.c_int, [_hid]),
+                    "H5Pset_deflate": (C.c_int, [_hid, C.c_uint]), "H5Pset_fill_value": (C.c_int, [_hid, _hid, C.c_void_p]),
+                    "H5Dcreate2": (_hid, [_hid, C.c_char_p, _hid, _hid, _hid, _hid, _hid]),
+                    "H5Dwrite": (C.c_int, [_hid, _hid, _hid, _hid, _hid, C.c_void_p]),
+                    "H5Dwrite_chunk": (C.c_int, [_hid, _hid, C.c_uint32, C.POINTER(_hsize), C.c_size_t, C.c_void_p]),
+                    "H5Acreate2": (_hid, [_hid, C.c_char_p, _hid, _hid, _hid, _hid]), "H5Awrite": (C.c_int, [_hid, _hid, C.c_void_p]),
+                    "H5Tcopy": (_hid, [_hid]), "H5Tset_size": (C.c_int, [_hid, C.c_size_t])}.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            if hl is not None:
+                hl.H5DSset_scale.restype, hl.H5DSset_scale.argtypes = C.c_int, [_hid, C.c_char_p]
+                hl.H5DSattach_scale.restype, hl.H5DSattach_scale.argtypes = C.c_int, [_hid, _hid, C.c_uint]
+        except AttributeError:
+            hl = None
+        _HL.append(hl)
+    if _HL[0] is None:
+        raise NotImplementedError("writing NetCDF-4 needs libhdf5_hl (dimension scales) next to libhdf5; XG_HDF5_HL_LIB names one")
+    return lib, _HL[0]
+
+
+def _h5type(lib, dtype: np.dtype) -> int:
+    key = dtype.kind + str(dtype.itemsize)
+    if key not in _NATIVE:
+        raise NotImplementedError(f"dtype {dtype} is not written here (integers and floats are)")
+    return _hid.in_dll(lib, _NATIVE[key]).value
+
+
+def _put_attr(lib, oid, name: str, value) -> None:
+    if isinstance(value, str):  # NC_CHAR: a fixed-length string
+        raw = value.encode()
+        tid = lib.H5Tcopy(_hid.in_dll(lib, "H5T_C_S1_g").value)
+        lib.H5Tset_size(tid, max(1, len(raw)))
+        sid = lib.H5Screate_simple(0, None, None)
+        aid = lib.H5Acreate2(oid, name.encode(), tid, sid, 0, 0)
+        lib.H5Awrite(aid, tid, C.create_string_buffer(raw, max(1, len(raw))))
+        lib.H5Aclose(aid), lib.H5Sclose(sid), lib.H5Tclose(tid)
+        return
+    arr = np.atleast_1d(np.asarray(value))
+    if arr.dtype.kind not in "fiu":
+        return  # (not a number, not a string: left out)
+    arr = np.ascontiguousarray(arr.astype(arr.dtype.newbyteorder("=")))
+    tid = _h5type(lib, arr.dtype)
+    sid = lib.H5Screate_simple(1, (_hsize * 1)(arr.size), None)
+    aid = lib.H5Acreate2(oid, name.encode(), tid, sid, 0, 0)
+    lib.H5Awrite(aid, tid, arr.ctypes.data_as(C.c_void_p))
+    lib.H5Aclose(aid), lib.H5Sclose(sid)
+
+
+def write_netcdf4(path: str, variables, deflate: int = 1, shuffle: bool = True, attrs: Optional[Dict] = None) -> None:
+    """`variables` -- {name: xgcm_amd.DataArray} (or one DataArray with a name) -- as a NetCDF-4 file in the netCDF-4 library's
+    HDF5 layout: one dimension scale per dim (the DataArrays' index coordinates; a dim without one becomes "a netCDF dimension
+    but not a netCDF variable"), `DIMENSION_LIST` on every variable, `_Netcdf4Dimid`, NC_CHAR attributes.  A variable whose data
+    is a chunked container (the result of a block walk) is written BLOCK BY BLOCK and never assembled: its HDF5 chunk shape is the
+    container's block shape, every block is shuffled + deflated HERE by helper threads (`chunked.pmap`) and handed to
+    `H5Dwrite_chunk` as stored bytes -- libhdf5's own filter pipeline would deflate on one core under the library lock.
+    `deflate=0`: no compression (plain `H5Dwrite` of each block)."""
+    import zlib
+
+    from .chunked import block_slices, is_chunked, normalize_chunks, pmap
+
+    lib, hl = _writer()
+    if hasattr(variables, "dims") and hasattr(variables, "data"):
+        variables = {variables.name or "var": variables}
+    variables = dict(variables)
+    sizes, coord_vals = {}, {}
+    for name, da in variables.items():
+        for d, n in zip(da.dims, da.shape):
+            if sizes.setdefault(d, int(n)) != int(n):
+                raise ValueError(f"conflicting sizes for dimension {d!r}: {n} on {name!r} and {sizes[d]}")
+        for cname, c in da.coords.items():
+            if tuple(c.dims) == (cname,) and cname in da.dims:
+                coord_vals.setdefault(cname, (np.asarray(c.values), dict(c.attrs)))
+    with _LOCK:
+        fid = lib.H5Fcreate(os.fsencode(path), 2, 0, 0)  # H5F_ACC_TRUNC
+        if fid < 0:
+            raise OSError(f"{path}: cannot be created")
+        opened = []
+        try:
+            _put_attr(lib, fid, "_NCProperties", "version=2,xgcm_amd=1")
+            for k, v in (attrs or {}).items():
+                _put_attr(lib, fid, k, v)
+            scales = {}
+            for k, (d, n) in enumerate(sizes.items()):
+                vals, cattrs = coord_vals.get(d, (None, {}))
+                arr = np.ascontiguousarray(np.asarray(vals)) if vals is not None and np.asarray(vals).dtype.kind in "fiu" else np.zeros(n, dtype="f4")
+                arr = arr.astype(arr.dtype.newbyteorder("="))
+                sid = lib.H5Screate_simple(1, (_hsize * 1)(n), None)
+                did = lib.H5Dcreate2(fid, d.encode(), _h5type(lib, arr.dtype), sid, 0, 0, 0)
+                lib.H5Sclose(sid)
+                if did < 0:
+                    raise OSError(f"{path}: dimension {d!r} cannot be created")
+                opened.append(did)
+                real = vals is not None and np.asarray(vals).dtype.kind in "fiu"
+                if real:
+                    lib.H5Dwrite(did, _h5type(lib, arr.dtype), 0, 0, 0, arr.ctypes.data_as(C.c_void_p))
+                hl.H5DSset_scale(did, d.encode() if real else f"{_NOT_A_VARIABLE}{n:10d}".encode())
+                _put_attr(lib, did, "_Netcdf4Dimid", np.int32(k))
+                for ak, av in cattrs.items():
+                    _put_attr(lib, did, ak, av)
+                scales[d] = did
+            for name, da in variables.items():
+                if name in scales:
+                    continue  # (an index coordinate handed over as a variable: already written as its dimension's scale)
+                data = da.data
+                dtype = np.dtype(data.dtype).newbyteorder("=")
+                shape = tuple(int(n) for n in da.shape)
+                rank = len(shape)
+                chunked_src = is_chunked(data)
+                blocks = normalize_chunks(data.chunks, shape) if chunked_src else tuple((n,) for n in shape)
+                cshape = tuple(max(1, c[0]) for c in blocks)
+                aligned = all(all(v == c[0] for v in c[:-1]) and c[-1] <= c[0] for c in blocks)  # every block starts on a chunk boundary
+                sid = lib.H5Screate_simple(rank, (_hsize * max(1, rank))(*shape), None) if rank else lib.H5Screate_simple(0, None, None)
+                pid = lib.H5Pcreate(_hid.in_dll(lib, "H5P_CLS_DATASET_CREATE_ID_g").value)
+                direct = bool(rank) and deflate > 0 and aligned and getattr(lib, "_xg_direct", False)
+                if rank and (chunked_src or deflate > 0):
+                    lib.H5Pset_chunk(pid, rank, (_hsize * rank)(*cshape))
+                    if deflate > 0:
+                        if shuffle:
+                            lib.H5Pset_shuffle(pid)
+                        lib.H5Pset_deflate(pid, int(deflate))
+                tid = _h5type(lib, dtype)
+                did = lib.H5Dcreate2(fid, name.encode(), tid, sid, 0, pid, 0)
+                lib.H5Pclose(pid)
+                if did < 0:
+                    lib.H5Sclose(sid)
+                    raise OSError(f"{path}: variable {name!r} cannot be created")
+                opened.append(did)
+                for i, d in enumerate(da.dims):
+                    hl.H5DSattach_scale(did, scales[d], i)
+                for ak, av in da.attrs.items():
+                    _put_attr(lib, did, ak, av)
+                item = dtype.itemsize
+
+                def encode(job):  # one block -> the bytes of its (full-size) chunk as stored; runs in helper threads, outside the lock
+                    idx, sl = job
+                    blk = np.ascontiguousarray(np.asarray(data[sl], dtype=dtype))
+                    if blk.shape != cshape:  # an edge chunk is stored at full chunk size
+                        full = np.zeros(cshape, dtype=dtype)
+                        full[tuple(slice(0, n) for n in blk.shape)] = blk
+                        blk = full
+                    raw = blk.reshape(-1).view("u1")
+                    if shuffle and item > 1:
+                        raw = np.ascontiguousarray(raw.reshape(-1, item).T).reshape(-1)
+                    return [s.start for s in sl], zlib.compress(raw, int(deflate))
+
+                if direct:
+                    _LOCK.release()  # (the helper threads fetch and deflate blocks; only the raw chunk writes need the library)
+                    try:
+                        jobs = list(block_slices(blocks))
+                        for lo in range(0, len(jobs), 16):  # 16 blocks in flight at a time
+                            for start, comp in pmap(encode, jobs[lo:lo + 16]):
+                                with _LOCK:
+                                    if lib.H5Dwrite_chunk(did, 0, 0, (_hsize * rank)(*start), len(comp), comp) < 0:
+                                        raise OSError(f"{path}:{name}: chunk at {start} could not be written")
+                    finally:
+                        _LOCK.acquire()
+                elif rank == 0:
+                    val = np.ascontiguousarray(np.asarray(data, dtype=dtype))
+                    lib.H5Dwrite(did, tid, 0, 0, 0, val.ctypes.data_as(C.c_void_p))
+                else:
+                    for _, sl in block_slices(blocks):
+                        blk = np.ascontiguousarray(np.asarray(data[sl], dtype=dtype))
+                        st, ct = (_hsize * rank)(*[s.start for s in sl]), (_hsize * rank)(*blk.shape)
+                        fs = lib.H5Dget_space(did)
+                        lib.H5Sselect_hyperslab(fs, 0, st, None, ct, None)
+                        ms = lib.H5Screate_simple(rank, ct, None)
+                        rc = lib.H5Dwrite(did, tid, ms, fs, 0, blk.ctypes.data_as(C.c_void_p))
+                        lib.H5Sclose(ms), lib.H5Sclose(fs)
+                        if rc < 0:
+                            raise OSError(f"{path}:{name}: block at {[s.start for s in sl]} could not be written")
+                lib.H5Sclose(sid)
+        finally:
+            for did in reversed(opened):
+                lib.H5Dclose(did)
+            lib.H5Fclose(fid)

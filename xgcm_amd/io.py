@@ -11,8 +11,8 @@ image, so the formats a model run is kept in are read here directly:
 * zarr format 2 directory stores (what `xarray.Dataset.to_zarr` writes; round 6), as CHUNKED CONTAINERS the operators walk
   block by block (`ZarrArray`, `open_zarr`, `write_zarr`; xgcm_amd.chunked) -- codecs none / blosc (zarr's default) / zstd /
   lz4 / zlib / gzip / bz2 / lzma;
-* NetCDF-4 / HDF5 (`open_netcdf4`, `H5Array`: xgcm_amd.hdf5), chunked containers over libhdf5 hyperslab reads -- where a
-  libhdf5 can be loaded (the image's Anaconda tree has one; the library is never bundled or guessed at).
+* NetCDF-4 / HDF5 (`open_netcdf4`, `H5Array`, `write_netcdf4`: xgcm_amd.hdf5), chunked containers over libhdf5 hyperslab reads
+  and results written back block by block -- where a libhdf5 can be loaded (the image's Anaconda tree has one; the library is never bundled or guessed at).
 
 MDS and NetCDF-3 store big-endian numbers.  Their blocks are handed over AS STORED: `iter_stream` copies the raw bytes into
 page-locked memory, sends them over PCIe and reverses the byte order on the GPU (`xg_bswap`), so no host core touches the
@@ -36,9 +36,9 @@ from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 import numpy as np
 
 __all__ = ["read_mds_meta", "mds_blocks", "mds_tile_files", "mds_tiled_blocks", "MdsWriter", "write_mds", "write_mds_tiled",
-           "netcdf_blocks", "netcdf_variable_info", "ZarrArray", "open_zarr", "write_zarr", "H5Array", "open_netcdf4"]
+           "netcdf_blocks", "netcdf_variable_info", "ZarrArray", "open_zarr", "write_zarr", "H5Array", "open_netcdf4", "write_netcdf4"]
 
-from .hdf5 import H5Array, open_netcdf4  # noqa: E402,F401 -- NetCDF-4 / HDF5: its own module (ctypes over libhdf5)
+from .hdf5 import H5Array, open_netcdf4, write_netcdf4  # noqa: E402,F401 -- NetCDF-4 / HDF5: its own module (ctypes over libhdf5)
 
 _PREC = {"float32": ">f4", "float64": ">f8", "real*4": ">f4", "real*8": ">f8"}
 
