@@ -167,6 +167,12 @@ def test_results_go_back_into_a_netcdf4_file_block_by_block(tbackend, tmp_path):
     np.testing.assert_array_equal(back["Z"].values, z["c_Z"])                  # (the result carried the file's Z along)
     if tbackend != "oracle-double":
         assert d.data.layout == "chunked" and d.data._filters == (2, 1) and d.chunks == got.chunks
+    small = str(tmp_path / "small.nc")                # chunks that DIVIDE the blocks once a block is over `chunk_bytes`
+    H.write_netcdf4(small, {"dTdx": got}, chunk_bytes=128)
+    sb = H.open_netcdf4(small)["dTdx"]
+    assert np.array_equal(np.asarray(sb.data), want, equal_nan=True)
+    if tbackend != "oracle-double":
+        assert sb.data._native_chunk == (1, 1, 1, 8) and sb.data._filters == (2, 1)   # (1, 2, 3, 8) blocks: 384 B -> 64 B chunks
     py39 = "/opt/conda/bin/python3.9"
     if not os.path.exists(py39):
         return

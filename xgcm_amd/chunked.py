@@ -125,8 +125,8 @@ def pmap(fn, items, workers: int = None):
     import os
 
     items = list(items)
-    if workers is None:
-        workers = int(os.environ.get("XG_READ_AHEAD", min(8, os.cpu_count() or 1)))
+    if workers is None:  # (more of them than `read_ahead` has: nothing is held ahead here, the items are one request's own pieces)
+        workers = int(os.environ["XG_READ_AHEAD"]) if "XG_READ_AHEAD" in os.environ else min(32, os.cpu_count() or 1)
     if workers <= 1 or len(items) <= 1:
         return [fn(it) for it in items]
     from concurrent.futures import ThreadPoolExecutor

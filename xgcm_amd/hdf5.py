@@ -563,14 +563,17 @@ def _put_attr(lib, oid, name: str, value) -> None:
     lib.H5Aclose(aid), lib.H5Sclose(sid)
 
 
-def write_netcdf4(path: str, variables, deflate: int = 1, shuffle: bool = True, attrs: Optional[Dict] = None) -> None:
+def write_netcdf4(path: str, variables, deflate: int = 1, shuffle: bool = True, attrs: Optional[Dict] = None,
+                  chunk_bytes: int = 16 << 20) -> None:
     """`variables` -- {name: xgcm_amd.DataArray} (or one DataArray with a name) -- as a NetCDF-4 file in the netCDF-4 library's
     HDF5 layout: one dimension scale per dim (the DataArrays' index coordinates; a dim without one becomes "a netCDF dimension
     but not a netCDF variable"), `DIMENSION_LIST` on every variable, `_Netcdf4Dimid`, NC_CHAR attributes.  A variable whose data
-    is a chunked container (the result of a block walk) is written BLOCK BY BLOCK and never assembled: its HDF5 chunk shape is the
-    container's block shape, every block is shuffled + deflated HERE by helper threads (`chunked.pmap`) and handed to
-    `H5Dwrite_chunk` as stored bytes -- libhdf5's own filter pipeline would deflate on one core under the library lock.
-    `deflate=0`: no compression (plain `H5Dwrite` of each block)."""
+    is a chunked container (the result of a block walk) is written BLOCK BY BLOCK and never assembled: the HDF5 chunk shape divides
+    the container's block shape (leading dims cut first until a chunk holds at most `chunk_bytes`: a 345 MB block would be a
+    chunk no other reader's cache takes), every block is fetched once, its chunks are shuffled + deflated HERE by helper threads
+    (`chunked.pmap`) and handed to `H5Dwrite_chunk` as stored bytes -- libhdf5's own filter pipeline would deflate on one core
+    under the library lock.  `deflate=0`: no compression (plain `H5Dwrite` of each block)."""
+    import itertools
     import zlib
 
     from .chunked import block_slices, is_chunked, normalize_chunks, pmap
@@ -624,8 +627,13 @@ def write_netcdf4(path: str, variables, deflate: int = 1, shuffle: bool = True, 
                 rank = len(shape)
                 chunked_src = is_chunked(data)
                 blocks = normalize_chunks(data.chunks, shape) if chunked_src else tuple((n,) for n in shape)
-                cshape = tuple(max(1, c[0]) for c in blocks)
+                cshape = [max(1, c[0]) for c in blocks]
                 aligned = all(all(v == c[0] for v in c[:-1]) and c[-1] <= c[0] for c in blocks)  # every block starts on a chunk boundary
+                for d in range(rank):  # chunks that DIVIDE the block, leading dims cut first, until one holds <= chunk_bytes
+                    while cshape[d] > 1 and int(np.prod(cshape)) * dtype.itemsize > chunk_bytes:
+                        n = cshape[d]
+                        cshape[d] = next(n // k for k in range(2, n + 1) if n % k == 0)  # the largest proper divisor
+                cshape = tuple(cshape)
                 sid = lib.H5Screate_simple(rank, (_hsize * max(1, rank))(*shape), None) if rank else lib.H5Screate_simple(0, None, None)
                 pid = lib.H5Pcreate(_hid.in_dll(lib, "H5P_CLS_DATASET_CREATE_ID_g").value)
                 direct = bool(rank) and deflate > 0 and aligned and getattr(lib, "_xg_direct", False)
@@ -648,24 +656,30 @@ def write_netcdf4(path: str, variables, deflate: int = 1, shuffle: bool = True, 
                     _put_attr(lib, did, ak, av)
                 item = dtype.itemsize
 
-                def encode(job):  # one block -> the bytes of its (full-size) chunk as stored; runs in helper threads, outside the lock
-                    idx, sl = job
-                    blk = np.ascontiguousarray(np.asarray(data[sl], dtype=dtype))
+                def deflate_chunk(piece):  # one chunk of a block -> (its offset, the bytes as stored); helper threads, outside the lock
+                    start, blk = piece
                     if blk.shape != cshape:  # an edge chunk is stored at full chunk size
                         full = np.zeros(cshape, dtype=dtype)
                         full[tuple(slice(0, n) for n in blk.shape)] = blk
                         blk = full
-                    raw = blk.reshape(-1).view("u1")
+                    raw = np.ascontiguousarray(blk).reshape(-1).view("u1")
                     if shuffle and item > 1:
                         raw = np.ascontiguousarray(raw.reshape(-1, item).T).reshape(-1)
-                    return [s.start for s in sl], zlib.compress(raw, int(deflate))
+                    return start, zlib.compress(raw, int(deflate))
 
                 if direct:
-                    _LOCK.release()  # (the helper threads fetch and deflate blocks; only the raw chunk writes need the library)
+                    from .chunked import read_ahead
+
+                    _LOCK.release()  # (helper threads fetch blocks and deflate their chunks; only the raw chunk writes need the library)
                     try:
-                        jobs = list(block_slices(blocks))
-                        for lo in range(0, len(jobs), 16):  # 16 blocks in flight at a time
-                            for start, comp in pmap(encode, jobs[lo:lo + 16]):
+                        jobs = [sl for _, sl in block_slices(blocks)]
+                        for sl, blk in zip(jobs, read_ahead(data, jobs, workers=2)):  # every block fetched ONCE, the next one under way
+                            blk = np.asarray(blk, dtype=dtype)
+                            pieces = []
+                            for off in itertools.product(*[range(0, n, c) for n, c in zip(blk.shape, cshape)]):
+                                part = blk[tuple(slice(o, o + c) for o, c in zip(off, cshape))]
+                                pieces.append(([s_.start + o for s_, o in zip(sl, off)], part))
+                            for start, comp in pmap(deflate_chunk, pieces):
                                 with _LOCK:
                                     if lib.H5Dwrite_chunk(did, 0, 0, (_hsize * rank)(*start), len(comp), comp) < 0:
                                         raise OSError(f"{path}:{name}: chunk at {start} could not be written")
