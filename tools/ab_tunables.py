@@ -67,6 +67,7 @@ def main():
         "iXmw": (lambda: D.stencil1d("interp", T, 2, 1, 0, "periodic", m_in=dx2, m_out=dx), 16 + 16 / nz),
         "iYmw": (lambda: D.stencil1d("interp", T, 1, 1, 0, "extend", m_in=dx2, m_out=dx), 16 + 16 / nz),
         "divT": (lambda: D.binary("div", T, dx), 16 + 8 / nz),
+        "mulT": (lambda: D.binary("mul", T, dx), 16 + 8 / nz),   # the same streams with a product instead of a quotient: what the IEEE division costs
         "mulTT": (lambda: D.binary("mul", T, T2), 24),
         "cumY": (lambda: D.cumsum1d(T, 1, 0, 1, 1, 0, "fill"), 16),
         "cumZ": (lambda: D.cumsum1d(T, 0, 0, 1, 1, 0, "fill"), 16),
