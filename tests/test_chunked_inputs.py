@@ -384,3 +384,45 @@ def test_blocks_are_fetched_ahead_in_order_and_errors_surface():
         for blk in read_ahead(bad, sls, workers=3):
             got.append(float(blk[0]))
     assert got == [float(i) for i in range(9)]
+
+
+def test_random_indices_into_every_container_equal_numpy(tmp_path):
+    """BlockArray, ZarrArray (edge chunks, blosc where a library loads), H5Array (raw-chunk path and H5Dread) and a real dask array
+    under 300 random keys of ints and unit-step slices (negative, empty, out of order) against numpy's indexing of the same array"""
+    from xgcm_amd import hdf5 as H
+    from xgcm_amd import io as IO
+
+    rng = np.random.default_rng(2026)
+    a = rng.standard_normal((7, 5, 11, 13))
+    held = {"block": BlockArray.from_array(a, ((3, 3, 1), (5,), (4, 4, 3), (6, 7)))}
+    IO.write_zarr(str(tmp_path / "z"), a, (3, 2, 4, 5), None, "blosc" if IO._clib("blosc") is not None else "zlib")
+    held["zarr"] = IO.ZarrArray(str(tmp_path / "z"))
+    if H.hdf5_available():
+        try:
+            H.write_netcdf4(str(tmp_path / "a.nc"), {"a": DataArray(held["block"], ("t", "z", "y", "x"))}, chunk_bytes=400)
+            held["hdf5"] = H.H5Array(str(tmp_path / "a.nc"), "a")
+            assert held["hdf5"]._filters == (2, 1)
+            slow = H.H5Array(str(tmp_path / "a.nc"), "a")
+            slow._filters = None
+            held["hdf5-H5Dread"] = slow
+        except NotImplementedError:  # no libhdf5_hl next to libhdf5 on this box: nothing to read back
+            pass
+    dsa = real_dask.dask_array()
+    if dsa is not None:
+        held["dask"] = dsa.from_array(a, chunks=(2, 5, 4, 13))
+    for trial in range(300):
+        key = []
+        for n in a.shape[:int(rng.integers(1, 5))]:
+            kind = rng.integers(0, 4)
+            if kind == 0:
+                key.append(int(rng.integers(-n, n)))
+            elif kind == 1:
+                key.append(slice(None))
+            else:
+                lo, hi = int(rng.integers(-n - 1, n + 2)), int(rng.integers(-n - 1, n + 2))
+                key.append(slice(lo, hi) if kind == 2 else slice(lo, None))
+        key = tuple(key)
+        want = a[key]
+        for label, arr in held.items():
+            got = np.asarray(arr[key])
+            assert got.shape == want.shape and np.array_equal(got, want), (label, key)
