@@ -525,14 +525,17 @@ def main():
     for _ in range(prime):
         step()
     sync()
-    for _ in range(args.warmup):
-        step()
-    K = args.steps
-    ev = [[] for _ in range(K)]
     import gc
 
+    K = args.steps
+    ev = [[] for _ in range(K)]
+    # the collector runs BEFORE the warmup steps: a collection between warmup and the timed region left the GPU idle long
+    # enough to drop its clocks, and the first timed step then ran 0.8 ms (12 %) slower than the others
+    # (`device_ms_per_step.first` against `.median`; three runs on one box: slowest_step = 0 every time)
     gc.collect()
     gc.disable()  # an interpreter GC pause (~10 ms, seen once in r01d) is not part of the hot path
+    for _ in range(args.warmup):
+        step()
     barrier()
     t0 = time.perf_counter()
     for k in range(K):
@@ -555,7 +558,8 @@ def main():
 
     # per-launch durations from the HIP events recorded on the launch stream inside the timed region
     per_op_ms = [float(np.mean([ev[k][i].ms_until(ev[k][i + 1]) for k in range(K)])) for i in range(len(OPS))]
-    step_ms = sorted(ev[k][0].ms_until(ev[k][len(OPS)]) for k in range(K))  # device time per step
+    step_ms_in_order = [ev[k][0].ms_until(ev[k][len(OPS)]) for k in range(K)]
+    step_ms = sorted(step_ms_in_order)  # device time per step
     by_kernel, of_axis = {}, kernel_of_axis()
     for (fn, ax), ms in zip(OPS, per_op_ms):
         by_kernel.setdefault(of_axis[ax], []).append(ms)
@@ -627,7 +631,8 @@ def main():
                       "rank_balance_min_over_max": round(min(per_rank_ms_per_step) / max(per_rank_ms_per_step), 4) if max(per_rank_ms_per_step) > 0 else None,
                       "placement": placement, "numa_bind": os.environ.get("XG_NUMA_BIND", "1") != "0"},
             "device_ms_per_step": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4),
-                                   "max": round(step_ms[-1], 4)},
+                                   "max": round(step_ms[-1], 4), "first": round(step_ms_in_order[0], 4),
+                                   "slowest_step": int(np.argmax(step_ms_in_order))},
             # where the results live (DESIGN section 8 "Placement"): scattered = separately created 64 MiB physical
             # allocations behind one virtual range (xg_pool_alloc); pool_fallbacks > 0 = some result fell back to hipMalloc
             "result_buffers": dict(_result_buffer_stats(), scattered=os.environ.get("XG_SCATTER_OUT", "1") != "0"),
